@@ -1,0 +1,204 @@
+/*
+ * mmfusion.h -- C ABI of libmmfusion.so, the MI355X (gfx950) voxel-fusion library.
+ *
+ * This is the drop-in boundary for the spatial-memory hot path of NVlabs/nvblox_mindmap:
+ * everything the reference reaches through the `nvblox_torch` Python module (a pybind
+ * wrapper around CUDA nvblox, absent from the reference tree) plus the image-side tensor
+ * ops of mindmap/image_processing that feed it.  Plain C: opaque handle, raw device
+ * pointers + sizes, int return codes (0 = ok), no torch types, no exceptions.
+ *
+ * Conventions
+ *   - every `*_dev` pointer is HIP device memory owned by the caller (a torch tensor's
+ *     data_ptr()); it must stay alive until the work enqueued on `stream` completed.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     All work is enqueued asynchronously; only functions documented "synchronises" block.
+ *   - poses are row-major 4x4 float32 camera->world (T_W_C) in HOST memory, intrinsics are
+ *     row-major 3x3 float32 in HOST memory: exactly what the reference passes
+ *     (`camera_pose.cpu(), intrinsics.cpu()`, nvblox_mapping_helpers.py:207-218,255-261).
+ *   - a handle is not thread-safe (the reference drives one Mapper from one Python thread).
+ *   - layer ids: 0 = TSDF, 1 = colour, 2 = feature.
+ *
+ * Reference interface replaced by each entry point is cited as file:line under
+ * /root/reference/mindmap.
+ */
+#ifndef MMFUSION_H_
+#define MMFUSION_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_ABI_VERSION 1
+
+#define MMF_LAYER_TSDF 0
+#define MMF_LAYER_COLOR 1
+#define MMF_LAYER_FEATURE 2
+
+/* error codes */
+#define MMF_OK 0
+#define MMF_ERR_INVALID_ARG 1
+#define MMF_ERR_HIP 2
+#define MMF_ERR_POOL_EXHAUSTED 3
+#define MMF_ERR_BAD_STATE 4
+
+typedef struct mmf_mapper_s* mmf_handle;
+
+/*
+ * Parameters of one mapper.  Mirrors the nvblox_torch parameter bags the reference fills in
+ * get_nvblox_mapper (mapping/helpers/nvblox_mapping_helpers.py:40-70):
+ * ProjectiveIntegratorParams, TsdfDecayIntegratorParams, ViewCalculatorParams,
+ * BlockMemoryPoolParams.  Fields the reference leaves at nvblox defaults are exposed too.
+ */
+typedef struct {
+  float voxel_size_m;
+  /* ProjectiveIntegratorParams */
+  float max_integration_distance_m;    /* projective_integrator_max_integration_distance_m   */
+  float truncation_distance_vox;       /* projective_integrator_truncation_distance_vox      */
+  float max_weight;                    /* projective_integrator_max_weight                   */
+  int32_t weighting_mode;              /* 0 constant, 1 inverse-square                       */
+  float lin_interp_max_diff_vox;       /* bilinear depth only where the 4 taps agree         */
+  float appearance_measurement_weight; /* projective_appearance_integrator_measurement_weight */
+  float appearance_max_weight;
+  /* ViewCalculatorParams */
+  int32_t raycast_subsampling;   /* raycast_subsampling_factor                               */
+  int32_t workspace_bounds_type; /* 0 kUnbounded, 1 kHeightBounds, 2 kBoundingBox            */
+  float ws_min[3];               /* workspace_bounds_min_corner_{x,y}_m, _min_height_m       */
+  float ws_max[3];               /* workspace_bounds_max_corner_{x,y}_m, _max_height_m       */
+  /* TsdfDecayIntegratorParams */
+  float tsdf_decay_factor;
+  float decayed_weight_threshold;
+  int32_t deallocate_decayed_blocks;
+  /* mesh */
+  float mesh_min_weight;
+  /* sphere tracing used by the appearance integrators' occlusion test */
+  int32_t st_subsampling;
+  int32_t st_max_steps;
+  float st_max_ray_length_m;
+  float st_surface_eps_vox;
+  /* feature layer */
+  int32_t feature_channels; /* nvblox_torch.constants.feature_array_num_elements()           */
+  /* BlockMemoryPoolParams */
+  int32_t num_preallocated_blocks; /* 0: size from the workspace bounds / built-in default   */
+  float expansion_factor;          /* kept for API parity; pools grow by doubling            */
+} mmf_params;
+
+/* sizeof(mmf_params) as compiled into the library (binding self-check). */
+int mmf_params_size(void);
+int mmf_abi_version(void);
+/* nvblox defaults (the values a default-constructed nvblox_torch MapperParams carries). */
+int mmf_default_params(mmf_params* out);
+/* Message of the last failing call on this thread ("" if none). */
+const char* mmf_last_error(void);
+/* Number of visible HIP devices (0 if none); does not create a context. */
+int mmf_device_count(void);
+
+/* ---- lifetime: nvblox_torch.mapper.Mapper(voxel_sizes_m, integrator_types, mapper_parameters)
+ *      nvblox_mapping_helpers.py:72-76.  `params` has `n_mappers` entries (one per mapper_id). */
+int mmf_mapper_create(int n_mappers, const mmf_params* params, int device, mmf_handle* out);
+int mmf_mapper_destroy(mmf_handle h);
+int mmf_num_mappers(mmf_handle h); /* Mapper.num_mappers(), visualization/visualizer.py:165 */
+
+/* ---- integration -------------------------------------------------------------------------- */
+/* Mapper.add_depth_frame(depth, T_W_C, K, mask, mapper_id)   nvblox_mapping_helpers.py:207-209
+ * depth: [H,W] f32 metres, <=0 invalid.  mask: [H,W] u8 (1 = integrate) or NULL. */
+int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth_dev, const uint8_t* mask_dev, int H, int W,
+                        const float* T_W_C_host, const float* K_host, void* stream);
+/* Mapper.add_color_frame(rgb, T_W_C, K, mask_frame=, mapper_id=)  nvblox_mapping_helpers.py:212-218
+ * rgb: [H,W,3] u8 contiguous. */
+int mmf_add_color_frame(mmf_handle h, int mapper_id, const uint8_t* rgb_dev, const uint8_t* mask_dev, int H, int W,
+                        const float* T_W_C_host, const float* K_host, void* stream);
+/* Mapper.add_feature_frame(feat, T_W_C, K_feat, mask, mapper_id)  nvblox_mapping_helpers.py:255-261
+ * feat: [Hf,Wf,C] f16 contiguous, C == feature_channels (multiple of 8). */
+int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat_f16_dev, const uint8_t* mask_dev, int Hf, int Wf,
+                          int C, const float* T_W_C_host, const float* K_host, void* stream);
+/* Mapper.decay() / Mapper.clear()   isaaclab_nvblox_mapper.py:252-258.  mapper_id < 0: all mappers. */
+int mmf_decay(mmf_handle h, int mapper_id, void* stream);
+int mmf_clear(mmf_handle h, int mapper_id, void* stream);
+
+/* ---- map -> model input --------------------------------------------------------------------- */
+/* Mapper.update_feature_mesh(mapper_id)   nvblox_output_helpers.py:49.
+ * Counts the surface vertices; synchronises `stream`; *num_vertices receives V. */
+int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_vertices);
+/* Mapper.get_feature_mesh(mapper_id).vertices() / .vertex_features()  nvblox_output_helpers.py:50-52.
+ * Writes V x 3 f32 and V x C f16 into caller-allocated buffers (V from the last update). */
+int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* vertices_dev, void* vertex_features_f16_dev, void* stream);
+
+/* ---- layer views (nvblox_torch tsdf_layer_view / feature_layer_view; paper/utils/utils.py:101-121) */
+/* Number of allocated blocks; synchronises `stream`. */
+int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* stream, int* out);
+/* Block indices [n,3] i32 in allocation order (n from mmf_num_allocated_blocks). */
+int mmf_get_block_indices(mmf_handle h, int mapper_id, int layer, int32_t* indices_dev, int n, void* stream);
+/* All TSDF blocks: out [n,8,8,8,2] f32, [...,0] = distance, [...,1] = weight. */
+int mmf_get_tsdf_blocks(mmf_handle h, int mapper_id, float* out_dev, int n, void* stream);
+/* All feature blocks: feats [n,8,8,8,C] f16, weights [n,8,8,8] f32. */
+int mmf_get_feature_blocks(mmf_handle h, int mapper_id, void* feats_f16_dev, float* weights_dev, int n, void* stream);
+/* All colour blocks: rgb [n,8,8,8,3] u8, weights [n,8,8,8] f32. */
+int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb_dev, float* weights_dev, int n, void* stream);
+/* Mapper.query_layer(QueryType, points, mapper_id)  visualization/visualizer.py:686-691.
+ * layer TSDF: out [n,2] (distance, weight); layer FEATURE: out [n,C+1] f32 (features, weight). */
+int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* points_dev, int n, float* out_dev, void* stream);
+
+/* ---- image-side ops of the path (mindmap/image_processing) ---------------------------------- */
+/* backproject_depth_to_pointcloud + nan_to_num + [B,3,H,W] layout
+ * (image_processing/backprojection.py:51-146).  depth [B,H,W] f32, K [B,3,3] f32 device,
+ * T [B,4,4] f32 device -> out [B,3,H,W] f32.  Integer pixel coordinates (u = col, v = row). */
+int mmf_backproject_depth(const float* depth_dev, const float* K_dev, const float* T_dev, int B, int H, int W,
+                          float* out_dev, void* stream);
+/* erode_mask(mask, kernel_size=3, iterations=k) (image_processing/image_mask_operations.py:16-41):
+ * out = NOT dilate_{(2k+1)x(2k+1)}(NOT mask).  mask/out [H,W] u8 (0/1), tmp [H,W] u8 scratch. */
+int mmf_erode_mask(const uint8_t* mask_dev, uint8_t* out_dev, uint8_t* tmp_dev, int H, int W, int iterations, void* stream);
+/* Fused feature-mask algebra of integrate_frame (nvblox_mapping_helpers.py:201-253):
+ * out[Hf,Wf] = border(border_percent) & nearest_upsample( erode(input_mask,k_in) & erode(depth>min_d,k_depth) ). */
+int mmf_feature_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H, int W, float min_depth_m, int k_in,
+                     int k_depth, int border_percent, int Hf, int Wf, uint8_t* out_dev, uint8_t* tmp_dev, void* stream);
+/* depth_mask = input_mask & (depth > min_d)  (nvblox_mapping_helpers.py:201-204) -> u8 [H,W]. */
+int mmf_depth_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H, int W, float min_depth_m,
+                   uint8_t* out_dev, void* stream);
+/* Bilinear (align_corners=False) upsample of a low-res feature map [h,w,Cin] f32 (channels last) to
+ * [Hf,Wf,Cpad] f16 with zero padding of channels Cin..Cpad-1: the resize + rearrange + pad + cast chain of
+ * image_processing/feature_extraction.py:188-191,198-210 and nvblox_mapping_helpers.py:256. */
+int mmf_upsample_features(const float* lowres_dev, int h, int w, int Cin, void* out_f16_dev, int Hf, int Wf, int Cpad,
+                          void* stream);
+
+/* ---- diagnostics / measurement --------------------------------------------------------------- */
+/* Last sphere-traced synthetic depth image of the mapper: dims, then copy to out [Hs,Ws] f32. */
+int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws);
+int mmf_get_synthetic_depth(mmf_handle h, int mapper_id, float* out_dev, void* stream);
+/* Render only (no integration). */
+int mmf_render_synthetic_depth(mmf_handle h, int mapper_id, int H, int W, const float* T_W_C_host, const float* K_host,
+                               void* stream);
+/* Blocks in view of the last add_depth_frame, sorted (x,y,z): count (synchronises), then indices [n,3]. */
+int mmf_last_view_block_count(mmf_handle h, int mapper_id, void* stream, int* out);
+int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* indices_dev, int n, void* stream);
+
+/* Cumulative counters since creation / last reset (synchronises `stream`):
+ *  [0] depth frames  [1] TSDF blocks updated  [2] TSDF blocks allocated
+ *  [3] colour frames [4] colour blocks updated [5] feature frames [6] feature blocks updated
+ *  [7] feature blocks allocated */
+#define MMF_NUM_STATS 8
+int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8);
+int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
+
+/* Kernel timing with HIP events on the launch stream.  kernel ids: */
+#define MMF_K_RAYCAST 0
+#define MMF_K_ALLOC 1
+#define MMF_K_TSDF 2
+#define MMF_K_CANDIDATES 3
+#define MMF_K_SPHERE 4
+#define MMF_K_COLOR 5
+#define MMF_K_FEATURE 6
+#define MMF_K_DECAY 7
+#define MMF_K_MESH 8
+#define MMF_NUM_KERNEL_IDS 9
+int mmf_profile_enable(mmf_handle h, int enable);
+/* Sum of elapsed ms and number of timed launches of kernel class `kernel_id` (synchronises). */
+int mmf_profile_get(mmf_handle h, int kernel_id, double* total_ms, int64_t* launches);
+int mmf_profile_reset(mmf_handle h);
+const char* mmf_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMFUSION_H_ */

@@ -1,0 +1,165 @@
+"""ctypes binding of ``include/mmfusion.h`` (libmmfusion.so, HIP/gfx950).
+
+This is the only place the package touches native code.  There is NO CPU fallback: if the
+shared library is missing, or no HIP device is visible, the calls raise ``RuntimeError``.
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C nvblox_mindmap_amd/csrc``.
+"""
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+MMF_LAYER_TSDF, MMF_LAYER_COLOR, MMF_LAYER_FEATURE = 0, 1, 2
+MMF_NUM_STATS = 8
+KERNEL_IDS = {
+    "raycast": 0, "alloc": 1, "tsdf": 2, "candidates": 3, "sphere": 4, "color": 5, "feature": 6, "decay": 7, "mesh": 8,
+}
+
+
+class MmfParams(C.Structure):
+    """``mmf_params`` of include/mmfusion.h (field order and types must match)."""
+
+    _fields_ = [
+        ("voxel_size_m", C.c_float),
+        ("max_integration_distance_m", C.c_float),
+        ("truncation_distance_vox", C.c_float),
+        ("max_weight", C.c_float),
+        ("weighting_mode", C.c_int32),
+        ("lin_interp_max_diff_vox", C.c_float),
+        ("appearance_measurement_weight", C.c_float),
+        ("appearance_max_weight", C.c_float),
+        ("raycast_subsampling", C.c_int32),
+        ("workspace_bounds_type", C.c_int32),
+        ("ws_min", C.c_float * 3),
+        ("ws_max", C.c_float * 3),
+        ("tsdf_decay_factor", C.c_float),
+        ("decayed_weight_threshold", C.c_float),
+        ("deallocate_decayed_blocks", C.c_int32),
+        ("mesh_min_weight", C.c_float),
+        ("st_subsampling", C.c_int32),
+        ("st_max_steps", C.c_int32),
+        ("st_max_ray_length_m", C.c_float),
+        ("st_surface_eps_vox", C.c_float),
+        ("feature_channels", C.c_int32),
+        ("num_preallocated_blocks", C.c_int32),
+        ("expansion_factor", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/mmfusion.h declares
+_VP, _I, _F = C.c_void_p, C.c_int, C.c_float
+_PI = C.POINTER(C.c_int)
+SIGNATURES = {
+    "mmf_params_size": (_I, []),
+    "mmf_abi_version": (_I, []),
+    "mmf_default_params": (_I, [C.POINTER(MmfParams)]),
+    "mmf_last_error": (C.c_char_p, []),
+    "mmf_device_count": (_I, []),
+    "mmf_mapper_create": (_I, [_I, C.POINTER(MmfParams), _I, C.POINTER(_VP)]),
+    "mmf_mapper_destroy": (_I, [_VP]),
+    "mmf_num_mappers": (_I, [_VP]),
+    "mmf_add_depth_frame": (_I, [_VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "mmf_add_color_frame": (_I, [_VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "mmf_add_feature_frame": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "mmf_decay": (_I, [_VP, _I, _VP]),
+    "mmf_clear": (_I, [_VP, _I, _VP]),
+    "mmf_update_feature_mesh": (_I, [_VP, _I, _VP, _PI]),
+    "mmf_get_feature_mesh": (_I, [_VP, _I, _VP, _VP, _VP]),
+    "mmf_num_allocated_blocks": (_I, [_VP, _I, _I, _VP, _PI]),
+    "mmf_get_block_indices": (_I, [_VP, _I, _I, _VP, _I, _VP]),
+    "mmf_get_tsdf_blocks": (_I, [_VP, _I, _VP, _I, _VP]),
+    "mmf_get_feature_blocks": (_I, [_VP, _I, _VP, _VP, _I, _VP]),
+    "mmf_get_color_blocks": (_I, [_VP, _I, _VP, _VP, _I, _VP]),
+    "mmf_query_layer": (_I, [_VP, _I, _I, _VP, _I, _VP, _VP]),
+    "mmf_backproject_depth": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "mmf_erode_mask": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmf_feature_mask": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "mmf_depth_mask": (_I, [_VP, _VP, _I, _I, _F, _VP, _VP]),
+    "mmf_upsample_features": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _VP]),
+    "mmf_get_synthetic_depth_dims": (_I, [_VP, _I, _PI, _PI]),
+    "mmf_get_synthetic_depth": (_I, [_VP, _I, _VP, _VP]),
+    "mmf_render_synthetic_depth": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
+    "mmf_last_view_block_count": (_I, [_VP, _I, _VP, _PI]),
+    "mmf_get_last_view_blocks": (_I, [_VP, _I, _VP, _I, _VP]),
+    "mmf_get_stats": (_I, [_VP, _I, _VP, C.POINTER(C.c_int64)]),
+    "mmf_reset_stats": (_I, [_VP, _I, _VP]),
+    "mmf_profile_enable": (_I, [_VP, _I]),
+    "mmf_profile_get": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mmf_profile_reset": (_I, [_VP]),
+    "mmf_kernel_name": (C.c_char_p, [_I]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libmmfusion.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC_DIR, "-j4", "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("hipcc build did not produce " + LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `make -C nvblox_mindmap_amd/csrc` or `__graft_entry__.build()`); there is no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.mmf_params_size() != C.sizeof(MmfParams):
+            raise RuntimeError("mmf_params layout mismatch between the binding and libmmfusion.so")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().mmf_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    """Raise RuntimeError for a non-zero return code (the reference raises from C++ asserts)."""
+    if rc != 0:
+        raise RuntimeError(f"libmmfusion {what} failed (code {rc}): {last_error()}")
+
+
+def default_params() -> MmfParams:
+    p = MmfParams()
+    check(lib().mmf_default_params(C.byref(p)), "mmf_default_params")
+    return p
+
+
+def device_count() -> int:
+    return lib().mmf_device_count()
+
+
+def require_gpu() -> None:
+    if device_count() <= 0:
+        raise RuntimeError("no HIP device visible: nvblox_mindmap_amd runs on MI355X only (no CPU fallback)")
+
+
+def stream_ptr(device: Optional[int] = None) -> C.c_void_p:
+    """hipStream_t of torch's current stream on `device`."""
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dptr(t) -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,956 @@
+// mmf_api.hip -- host side of libmmfusion.so: the C ABI declared in include/mmfusion.h.
+// Owns the block pools / hash tables of every mapper and sequences the kernels of one frame on the
+// caller's HIP stream.  No device->host synchronisation on the per-frame path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mmfusion.h"
+#include "mmf_launch.h"
+
+using namespace mmf;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      return fail(MMF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                   \
+  } while (0)
+
+#define MMF_TRY(expr)          \
+  do {                         \
+    int rc__ = (expr);         \
+    if (rc__ != MMF_OK) return rc__; \
+  } while (0)
+
+struct Layer {
+  LayerDev d{};
+  size_t block_bytes = 0;
+  bool has_w = false;
+  bool allocated = false;
+};
+
+struct Mapper {
+  mmf_params P{};
+  MapConsts mc{};
+  Layer tsdf, color, feat;
+  Scratch sc{};
+  int ncells_cap = 0;
+  uint8_t* kill = nullptr;
+  int* any_kill = nullptr;
+  long long* stats = nullptr;  // device [MMF_NUM_STATS]
+  long long frames[3] = {0, 0, 0};
+  // synthetic depth + cache key
+  float* synth = nullptr;
+  int synth_cap = 0, synth_W = 0, synth_H = 0;
+  long long synth_epoch = -1;
+  float synth_T[16]{}, synth_K[9]{};
+  int synth_iw = 0, synth_ih = 0;
+  long long tsdf_epoch = 0;
+  // mesh
+  int* mesh_counts = nullptr;
+  int* mesh_offsets = nullptr;
+  int* mesh_out2 = nullptr;
+  int mesh_cap = 0, mesh_V = 0, mesh_nblocks = 0;
+  long long mesh_epoch = -1;
+  // last view grid (diagnostics)
+  ViewGrid last_vg{};
+  int app_cap = 0;
+};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  int id;
+};
+
+}  // namespace
+
+struct mmf_mapper_s {
+  int device = 0;
+  std::vector<Mapper*> mappers;
+  int* pinned = nullptr;  // host pinned scratch (16 ints)
+  bool prof = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[MMF_NUM_KERNEL_IDS] = {0};
+  long long prof_n[MMF_NUM_KERNEL_IDS] = {0};
+};
+
+namespace {
+
+struct ProfScope {
+  mmf_mapper_s* h;
+  hipStream_t s;
+  ProfRec r{};
+  bool on;
+  ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(h_->prof) {
+    if (!on) return;
+    r.id = id;
+    r.a = take();
+    r.b = take();
+    (void)hipEventRecord(r.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    h->prof_recs.push_back(r);
+  }
+  hipEvent_t take() {
+    if (!h->ev_pool.empty()) {
+      hipEvent_t e = h->ev_pool.back();
+      h->ev_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+};
+
+int prof_collect(mmf_mapper_s* h) {
+  for (auto& r : h->prof_recs) {
+    HIP_TRY(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    h->prof_ms[r.id] += ms;
+    h->prof_n[r.id] += 1;
+    h->ev_pool.push_back(r.a);
+    h->ev_pool.push_back(r.b);
+  }
+  h->prof_recs.clear();
+  return MMF_OK;
+}
+
+unsigned next_pow2(unsigned v) {
+  unsigned p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+int ifloor_h(float x) { return (int)floorf(x); }
+
+void rigid_from_T(const float* T, Rigid& o) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = T[i * 4 + j];
+    o.t[i] = T[i * 4 + 3];
+  }
+}
+
+// Rinv = R^T, tinv_i = -((Rinv_i0*t0 + Rinv_i1*t1) + Rinv_i2*t2)   
+void rigid_inverse(const Rigid& a, Rigid& o) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = a.R[j * 3 + i];
+  for (int i = 0; i < 3; ++i) o.t[i] = -((o.R[i * 3 + 0] * a.t[0] + o.R[i * 3 + 1] * a.t[1]) + o.R[i * 3 + 2] * a.t[2]);
+}
+
+void xform_h(const Rigid& T, const float* p, float* q) {
+  for (int i = 0; i < 3; ++i) q[i] = ((T.R[i * 3 + 0] * p[0] + T.R[i * 3 + 1] * p[1]) + T.R[i * 3 + 2] * p[2]) + T.t[i];
+}
+
+Cam cam_from_K(const float* K, int W, int H) {
+  Cam c;
+  c.fx = K[0];
+  c.fy = K[4];
+  c.cx = K[2];
+  c.cy = K[5];
+  c.W = W;
+  c.H = H;
+  return c;
+}
+
+void derive_consts(const mmf_params& P, MapConsts& mc) {
+  mc.v = P.voxel_size_m;
+  mc.bs = 8.0f * mc.v;
+  mc.inv_bs = 1.0f / mc.bs;
+  mc.inv_v = 1.0f / mc.v;
+  mc.trunc = P.truncation_distance_vox * mc.v;
+  mc.max_dist = P.max_integration_distance_m;
+  mc.max_weight = P.max_weight;
+  mc.lin_md = P.lin_interp_max_diff_vox * mc.v;
+  mc.weighting_mode = P.weighting_mode;
+  mc.app_wm = P.appearance_measurement_weight;
+  mc.app_max_w = P.appearance_max_weight;
+  mc.ws_type = P.workspace_bounds_type;
+  for (int a = 0; a < 3; ++a) {
+    mc.ws_lo[a] = ifloor_h(P.ws_min[a] * mc.inv_bs);
+    mc.ws_hi[a] = ifloor_h(P.ws_max[a] * mc.inv_bs);
+  }
+  mc.decay_factor = P.tsdf_decay_factor;
+  mc.decay_thr = P.decayed_weight_threshold;
+  mc.dealloc_decayed = P.deallocate_decayed_blocks;
+  mc.mesh_min_w = P.mesh_min_weight;
+  mc.st_sf = P.st_subsampling < 1 ? 1 : P.st_subsampling;
+  mc.st_max_steps = P.st_max_steps;
+  mc.st_max_len = P.st_max_ray_length_m;
+  mc.st_eps = P.st_surface_eps_vox * mc.v;
+  mc.C = P.feature_channels;
+}
+
+int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
+  L.block_bytes = block_bytes;
+  L.has_w = has_w;
+  L.d.cap = cap;
+  unsigned tcap = next_pow2((unsigned)(2 * cap < 1024 ? 1024 : 2 * cap));
+  L.d.hmask = tcap - 1;
+  HIP_TRY(hipMalloc(&L.d.hkeys, sizeof(u64) * tcap));
+  HIP_TRY(hipMalloc(&L.d.hvals, sizeof(int) * tcap));
+  HIP_TRY(hipMalloc(&L.d.slot_key, sizeof(u64) * cap));
+  HIP_TRY(hipMalloc(&L.d.live, sizeof(int) * cap));
+  HIP_TRY(hipMalloc(&L.d.free_stack, sizeof(int) * cap));
+  HIP_TRY(hipMalloc(&L.d.ctr, sizeof(int) * 4));
+  HIP_TRY(hipMalloc(&L.d.pool, block_bytes * (size_t)cap));
+  if (has_w) HIP_TRY(hipMalloc(&L.d.poolw, sizeof(float) * kVPB * (size_t)cap));
+  HIP_TRY(hipMemset(L.d.hkeys, 0xff, sizeof(u64) * tcap));
+  HIP_TRY(hipMemset(L.d.ctr, 0, sizeof(int) * 4));
+  HIP_TRY(hipMemset(L.d.slot_key, 0xff, sizeof(u64) * cap));
+  L.allocated = true;
+  return MMF_OK;
+}
+
+void free_layer(Layer& L) {
+  if (!L.allocated) return;
+  (void)hipFree(L.d.hkeys);
+  (void)hipFree(L.d.hvals);
+  (void)hipFree(L.d.slot_key);
+  (void)hipFree(L.d.live);
+  (void)hipFree(L.d.free_stack);
+  (void)hipFree(L.d.ctr);
+  (void)hipFree(L.d.pool);
+  if (L.d.poolw) (void)hipFree(L.d.poolw);
+  L = Layer{};
+}
+
+void free_scratch(Mapper& m) {
+  (void)hipFree(m.sc.flags);
+  (void)hipFree(m.sc.cell_slot);
+  (void)hipFree(m.sc.tile_counts);
+  (void)hipFree(m.sc.tile_offs);
+  (void)hipFree(m.sc.cand_slot);
+  (void)hipFree(m.sc.cand_key);
+  (void)hipFree(m.sc.cand_new);
+  m.sc.flags = nullptr;
+}
+
+// (Re)allocate the compaction scratch for `ncells` cells.  Growing synchronises the device (rare:
+// only when an unbounded map sees a larger view grid than ever before).
+int ensure_scratch(Mapper& m, int ncells) {
+  if (ncells <= m.ncells_cap) return MMF_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  int* cand_count = m.sc.cand_count;
+  int* alloc_ctx = m.sc.alloc_ctx;
+  if (m.sc.flags) free_scratch(m);
+  int n = (ncells + 1023) & ~1023;
+  int ntiles = n / 1024;
+  HIP_TRY(hipMalloc(&m.sc.flags, (size_t)n));
+  HIP_TRY(hipMemset(m.sc.flags, 0, (size_t)n));
+  HIP_TRY(hipMalloc(&m.sc.cell_slot, sizeof(int) * (size_t)n));
+  HIP_TRY(hipMalloc(&m.sc.tile_counts, sizeof(int2) * (size_t)ntiles));
+  HIP_TRY(hipMalloc(&m.sc.tile_offs, sizeof(int2) * (size_t)ntiles));
+  HIP_TRY(hipMalloc(&m.sc.cand_slot, sizeof(int) * (size_t)n));
+  HIP_TRY(hipMalloc(&m.sc.cand_key, sizeof(u64) * (size_t)n));
+  HIP_TRY(hipMalloc(&m.sc.cand_new, (size_t)n));
+  if (!cand_count) {
+    HIP_TRY(hipMalloc(&cand_count, sizeof(int)));
+    HIP_TRY(hipMemset(cand_count, 0, sizeof(int)));
+    HIP_TRY(hipMalloc(&alloc_ctx, sizeof(int) * 4));
+    HIP_TRY(hipMemset(alloc_ctx, 0, sizeof(int) * 4));
+  }
+  m.sc.cand_count = cand_count;
+  m.sc.alloc_ctx = alloc_ctx;
+  m.ncells_cap = n;
+  return MMF_OK;
+}
+
+int create_mapper(const mmf_params& P, Mapper** out) {
+  if (!(P.voxel_size_m > 0.f)) return fail(MMF_ERR_INVALID_ARG, "voxel_size_m must be > 0");
+  if (P.feature_channels <= 0 || P.feature_channels % 8 != 0)
+    return fail(MMF_ERR_INVALID_ARG, "feature_channels must be a positive multiple of 8");
+  if (P.workspace_bounds_type < 0 || P.workspace_bounds_type > 2)
+    return fail(MMF_ERR_INVALID_ARG, "workspace_bounds_type must be 0, 1 or 2");
+  if (P.workspace_bounds_type != 2 && !(P.max_integration_distance_m > 0.f))
+    return fail(MMF_ERR_INVALID_ARG, "max_integration_distance_m must be > 0 unless the workspace is a bounding box");
+  Mapper* m = new Mapper();
+  m->P = P;
+  derive_consts(P, m->mc);
+  int cap, app_cap;
+  if (P.num_preallocated_blocks > 0) {
+    cap = app_cap = P.num_preallocated_blocks;
+  } else if (P.workspace_bounds_type == 2) {
+    long long n = 1;
+    for (int a = 0; a < 3; ++a) {
+      long long d = (long long)m->mc.ws_hi[a] - m->mc.ws_lo[a] + 1;
+      if (d <= 0) {
+        delete m;
+        return fail(MMF_ERR_INVALID_ARG, "empty workspace bounds");
+      }
+      n *= d;
+    }
+    if (n > (1ll << 24)) {
+      delete m;
+      return fail(MMF_ERR_INVALID_ARG, "workspace bounding box too large; set num_preallocated_blocks");
+    }
+    cap = app_cap = (int)n;
+  } else {
+    cap = 65536;
+    app_cap = 16384;
+  }
+  m->app_cap = app_cap;
+  int rc = alloc_layer(m->tsdf, cap, sizeof(float2) * kVPB, false);
+  if (rc != MMF_OK) {
+    delete m;
+    return rc;
+  }
+  HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
+  HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
+  HIP_TRY(hipMalloc(&m->any_kill, sizeof(int)));
+  HIP_TRY(hipMemset(m->any_kill, 0, sizeof(int)));
+  HIP_TRY(hipMalloc(&m->stats, sizeof(long long) * MMF_NUM_STATS));
+  HIP_TRY(hipMemset(m->stats, 0, sizeof(long long) * MMF_NUM_STATS));
+  HIP_TRY(hipMalloc(&m->mesh_counts, sizeof(int) * (size_t)cap));
+  HIP_TRY(hipMalloc(&m->mesh_offsets, sizeof(int) * (size_t)cap));
+  HIP_TRY(hipMalloc(&m->mesh_out2, sizeof(int) * 2));
+  m->mesh_cap = cap;
+  rc = ensure_scratch(*m, cap);
+  if (rc != MMF_OK) {
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return MMF_OK;
+}
+
+void destroy_mapper(Mapper* m) {
+  free_layer(m->tsdf);
+  free_layer(m->color);
+  free_layer(m->feat);
+  if (m->sc.flags) free_scratch(*m);
+  (void)hipFree(m->sc.cand_count);
+  (void)hipFree(m->sc.alloc_ctx);
+  (void)hipFree(m->kill);
+  (void)hipFree(m->any_kill);
+  (void)hipFree(m->stats);
+  (void)hipFree(m->synth);
+  (void)hipFree(m->mesh_counts);
+  (void)hipFree(m->mesh_offsets);
+  (void)hipFree(m->mesh_out2);
+  delete m;
+}
+
+// View grid: bounding box (in block indices, padded by one block) of the camera centre and the far
+// corners of the frustum at (max distance + truncation), intersected with the workspace bounds.
+int compute_view_grid(const Mapper& m, const Cam& cam, const Rigid& T_L_C, ViewGrid& vg) {
+  const MapConsts& mc = m.mc;
+  int lo[3], hi[3];
+  if (mc.max_dist > 0.f) {
+    const float s = mc.max_dist + mc.trunc;
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = ifloor_h(T_L_C.t[a] * mc.inv_bs);
+    const float us[2] = {0.f, (float)cam.W}, vs[2] = {0.f, (float)cam.H};
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        float pC[3] = {s * ((us[i] - cam.cx) / cam.fx), s * ((vs[j] - cam.cy) / cam.fy), s};
+        float pL[3];
+        xform_h(T_L_C, pC, pL);
+        for (int a = 0; a < 3; ++a) {
+          int b = ifloor_h(pL[a] * mc.inv_bs);
+          if (b < lo[a]) lo[a] = b;
+          if (b > hi[a]) hi[a] = b;
+        }
+      }
+    for (int a = 0; a < 3; ++a) {
+      lo[a] -= 1;
+      hi[a] += 1;
+    }
+  } else {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = mc.ws_lo[a];
+      hi[a] = mc.ws_hi[a];
+    }
+  }
+  if (mc.ws_type >= 1) {
+    if (lo[2] < mc.ws_lo[2]) lo[2] = mc.ws_lo[2];
+    if (hi[2] > mc.ws_hi[2]) hi[2] = mc.ws_hi[2];
+  }
+  if (mc.ws_type == 2) {
+    for (int a = 0; a < 2; ++a) {
+      if (lo[a] < mc.ws_lo[a]) lo[a] = mc.ws_lo[a];
+      if (hi[a] > mc.ws_hi[a]) hi[a] = mc.ws_hi[a];
+    }
+  }
+  vg.ox = lo[0];
+  vg.oy = lo[1];
+  vg.oz = lo[2];
+  vg.nx = hi[0] - lo[0] + 1;
+  vg.ny = hi[1] - lo[1] + 1;
+  vg.nz = hi[2] - lo[2] + 1;
+  if (vg.nx <= 0 || vg.ny <= 0 || vg.nz <= 0) vg.nx = vg.ny = vg.nz = 0;
+  long long n = (long long)vg.nx * vg.ny * vg.nz;
+  if (n > (1ll << 27)) return fail(MMF_ERR_INVALID_ARG, "view grid too large (check pose / max integration distance)");
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] <= -kKeyOff || hi[a] >= kKeyOff) return fail(MMF_ERR_INVALID_ARG, "block index out of the 21-bit key range");
+  return MMF_OK;
+}
+
+int get_mapper(mmf_handle h, int id, Mapper** out) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  if (id < 0 || id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
+  *out = h->mappers[id];
+  return MMF_OK;
+}
+
+int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w) {
+  if (L.allocated) return MMF_OK;
+  return alloc_layer(L, m.app_cap, block_bytes, has_w);
+}
+
+int ensure_synth(mmf_handle h, Mapper& m, const Cam& cam, const Rigid& T_L_C, const float* T16, const float* K9, hipStream_t s) {
+  const int sf = m.mc.st_sf;
+  const int Ws = cam.W / sf, Hs = cam.H / sf;
+  if (Ws <= 0 || Hs <= 0) return fail(MMF_ERR_INVALID_ARG, "image smaller than the sphere-tracing subsampling factor");
+  const bool hit = m.synth && m.synth_epoch == m.tsdf_epoch && m.synth_iw == cam.W && m.synth_ih == cam.H &&
+                   std::memcmp(m.synth_T, T16, sizeof(float) * 16) == 0 && std::memcmp(m.synth_K, K9, sizeof(float) * 9) == 0;
+  if (hit) return MMF_OK;
+  if (Ws * Hs > m.synth_cap) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (m.synth) HIP_TRY(hipFree(m.synth));
+    m.synth = nullptr;
+    HIP_TRY(hipMalloc(&m.synth, sizeof(float) * (size_t)Ws * Hs));
+    m.synth_cap = Ws * Hs;
+  }
+  {
+    ProfScope ps(h, MMF_K_SPHERE, s);
+    launch_sphere_trace(m.tsdf.d, m.mc, cam, T_L_C, m.synth, Ws, Hs, s);
+  }
+  m.synth_W = Ws;
+  m.synth_H = Hs;
+  m.synth_epoch = m.tsdf_epoch;
+  m.synth_iw = cam.W;
+  m.synth_ih = cam.H;
+  std::memcpy(m.synth_T, T16, sizeof(float) * 16);
+  std::memcpy(m.synth_K, K9, sizeof(float) * 9);
+  return MMF_OK;
+}
+
+// candidate selection + allocation in an appearance layer (shared by colour and feature frames)
+int app_prepare(mmf_handle h, Mapper& m, Layer& L, const Cam& cam, const Rigid& T_L_C, const Rigid& T_C_L, const float* T16,
+                const float* K9, int stat_upd, int stat_new, hipStream_t s) {
+  MMF_TRY(ensure_scratch(m, m.tsdf.d.cap));
+  {
+    ProfScope ps(h, MMF_K_CANDIDATES, s);
+    launch_app_candidates(m.tsdf.d, m.mc, cam, T_C_L, m.sc.flags, s);
+  }
+  {
+    ProfScope ps(h, MMF_K_ALLOC, s);
+    KeySrc ks{};
+    ks.mode = 1;
+    ks.slot_key = m.tsdf.d.slot_key;
+    ks.live = m.tsdf.d.live;
+    launch_compact_alloc(L.d, ks, m.sc, m.tsdf.d.cap, m.stats, stat_upd, stat_new, s);
+  }
+  MMF_TRY(ensure_synth(h, m, cam, T_L_C, T16, K9, s));
+  return MMF_OK;
+}
+
+__global__ void k_unpack_keys(const mmf::u64* keys, int n, int32_t* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int x, y, z;
+  mmf::unpack_key(keys[i], x, y, z);
+  out[3 * i] = x;
+  out[3 * i + 1] = y;
+  out[3 * i + 2] = z;
+}
+
+int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MMF_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return MMF_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int mmf_params_size(void) { return (int)sizeof(mmf_params); }
+int mmf_abi_version(void) { return MMF_ABI_VERSION; }
+const char* mmf_last_error(void) { return g_err.c_str(); }
+
+int mmf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int mmf_default_params(mmf_params* p) {
+  if (!p) return fail(MMF_ERR_INVALID_ARG, "null params");
+  std::memset(p, 0, sizeof(*p));
+  p->voxel_size_m = 0.05f;
+  p->max_integration_distance_m = 7.0f;
+  p->truncation_distance_vox = 4.0f;
+  p->max_weight = 5.0f;
+  p->weighting_mode = 1;
+  p->lin_interp_max_diff_vox = 2.0f;
+  p->appearance_measurement_weight = 1.0f;
+  p->appearance_max_weight = 5.0f;
+  p->raycast_subsampling = 4;
+  p->workspace_bounds_type = 0;
+  p->tsdf_decay_factor = 0.95f;
+  p->decayed_weight_threshold = 1e-3f;
+  p->deallocate_decayed_blocks = 1;
+  p->mesh_min_weight = 1e-4f;
+  p->st_subsampling = 4;
+  p->st_max_steps = 100;
+  p->st_max_ray_length_m = 15.0f;
+  p->st_surface_eps_vox = 0.1f;
+  p->feature_channels = 768;
+  p->num_preallocated_blocks = 0;
+  p->expansion_factor = 1.5f;
+  return MMF_OK;
+}
+
+int mmf_mapper_create(int n_mappers, const mmf_params* params, int device, mmf_handle* out) {
+  if (n_mappers <= 0 || !params || !out) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_mapper_create");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(MMF_ERR_HIP, "no HIP device visible: libmmfusion has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(MMF_ERR_INVALID_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  mmf_mapper_s* h = new mmf_mapper_s();
+  h->device = device;
+  for (int i = 0; i < n_mappers; ++i) {
+    Mapper* m = nullptr;
+    int rc = create_mapper(params[i], &m);
+    if (rc != MMF_OK) {
+      for (Mapper* q : h->mappers) destroy_mapper(q);
+      delete h;
+      return rc;
+    }
+    h->mappers.push_back(m);
+  }
+  HIP_TRY(hipHostMalloc(&h->pinned, sizeof(int) * 64));
+  HIP_TRY(hipDeviceSynchronize());
+  *out = h;
+  return MMF_OK;
+}
+
+int mmf_mapper_destroy(mmf_handle h) {
+  if (!h) return MMF_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (Mapper* m : h->mappers) destroy_mapper(m);
+  for (auto& r : h->prof_recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  delete h;
+  return MMF_OK;
+}
+
+int mmf_num_mappers(mmf_handle h) { return h ? (int)h->mappers.size() : 0; }
+
+int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* mask, int H, int W, const float* T16,
+                        const float* K9, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!depth || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_depth_frame");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  Cam cam = cam_from_K(K9, W, H);
+  Rigid T_L_C, T_C_L;
+  rigid_from_T(T16, T_L_C);
+  rigid_inverse(T_L_C, T_C_L);
+  ViewGrid vg;
+  MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
+  m->last_vg = vg;
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  m->frames[0]++;
+  m->tsdf_epoch++;
+  if (ncells == 0) {
+    HIP_TRY(hipMemsetAsync(m->sc.cand_count, 0, sizeof(int), s));
+    return MMF_OK;
+  }
+  MMF_TRY(ensure_scratch(*m, ncells));
+  const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
+  {
+    ProfScope ps(h, MMF_K_RAYCAST, s);
+    launch_raycast(m->mc, cam, T_L_C, depth, mask, sub, vg, m->sc.flags, s);
+  }
+  {
+    ProfScope ps(h, MMF_K_ALLOC, s);
+    KeySrc ks{};
+    ks.mode = 0;
+    ks.ox = vg.ox;
+    ks.oy = vg.oy;
+    ks.oz = vg.oz;
+    ks.ny = vg.ny;
+    ks.nz = vg.nz;
+    launch_compact_alloc(m->tsdf.d, ks, m->sc, ncells, m->stats, 1, 2, s);
+  }
+  {
+    ProfScope ps(h, MMF_K_TSDF, s);
+    launch_tsdf_integrate(m->tsdf.d, m->mc, cam, T_C_L, depth, mask, m->sc, ncells < m->tsdf.d.cap ? ncells : m->tsdf.d.cap, s);
+  }
+  return check_launch();
+}
+
+int mmf_add_color_frame(mmf_handle h, int mapper_id, const uint8_t* rgb, const uint8_t* mask, int H, int W, const float* T16,
+                        const float* K9, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!rgb || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_color_frame");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
+  Cam cam = cam_from_K(K9, W, H);
+  Rigid T_L_C, T_C_L;
+  rigid_from_T(T16, T_L_C);
+  rigid_inverse(T_L_C, T_C_L);
+  m->frames[1]++;
+  MMF_TRY(app_prepare(h, *m, m->color, cam, T_L_C, T_C_L, T16, K9, 4, -1, s));
+  {
+    ProfScope ps(h, MMF_K_COLOR, s);
+    launch_color_integrate(m->color.d, m->mc, cam, T_C_L, rgb, mask, m->synth, m->synth_W, m->synth_H, m->sc, m->color.d.cap, s);
+  }
+  return check_launch();
+}
+
+int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat, const uint8_t* mask, int Hf, int Wf, int C,
+                          const float* T16, const float* K9, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!feat || !T16 || !K9 || Hf <= 1 || Wf <= 1) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_feature_frame");
+  if (C != m->P.feature_channels)
+    return fail(MMF_ERR_INVALID_ARG, "feature frame has " + std::to_string(C) + " channels, the mapper was created with " +
+                                         std::to_string(m->P.feature_channels));
+  if (((uintptr_t)feat & 15) != 0) return fail(MMF_ERR_INVALID_ARG, "feature frame must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)C, true));
+  Cam cam = cam_from_K(K9, Wf, Hf);
+  Rigid T_L_C, T_C_L;
+  rigid_from_T(T16, T_L_C);
+  rigid_inverse(T_L_C, T_C_L);
+  m->frames[2]++;
+  MMF_TRY(app_prepare(h, *m, m->feat, cam, T_L_C, T_C_L, T16, K9, 6, 7, s));
+  {
+    ProfScope ps(h, MMF_K_FEATURE, s);
+    launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc,
+                             m->feat.d.cap, s);
+  }
+  return check_launch();
+}
+
+int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < (int)h->mappers.size(); ++i) {
+    if (mapper_id >= 0 && i != mapper_id) continue;
+    Mapper* m = h->mappers[i];
+    ProfScope ps(h, MMF_K_DECAY, s);
+    launch_decay(m->tsdf.d, m->mc, m->kill, m->any_kill, s);
+    m->tsdf_epoch++;
+  }
+  if (mapper_id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
+  return check_launch();
+}
+
+int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (mapper_id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
+  for (int i = 0; i < (int)h->mappers.size(); ++i) {
+    if (mapper_id >= 0 && i != mapper_id) continue;
+    Mapper* m = h->mappers[i];
+    launch_layer_reset(m->tsdf.d, s);
+    if (m->color.allocated) launch_layer_reset(m->color.d, s);
+    if (m->feat.allocated) launch_layer_reset(m->feat.d, s);
+    m->tsdf_epoch++;
+    m->mesh_epoch = -1;
+  }
+  return check_launch();
+}
+
+int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_vertices) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!num_vertices) return fail(MMF_ERR_INVALID_ARG, "null num_vertices");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope ps(h, MMF_K_MESH, s);
+    launch_mesh_count(m->tsdf.d, m->mc, m->mesh_counts, m->mesh_offsets, m->mesh_out2, s);
+  }
+  HIP_TRY(hipMemcpyAsync(h->pinned, m->mesh_out2, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  m->mesh_V = h->pinned[0];
+  m->mesh_nblocks = h->pinned[1];
+  m->mesh_epoch = m->tsdf_epoch;
+  *num_vertices = m->mesh_V;
+  return check_launch();
+}
+
+int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* verts, void* vfeat, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (m->mesh_epoch != m->tsdf_epoch)
+    return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_update_feature_mesh; call it again");
+  if (m->mesh_V == 0) return MMF_OK;
+  if (!verts || !vfeat) return fail(MMF_ERR_INVALID_ARG, "null output buffer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  LayerDev F = m->feat.allocated ? m->feat.d : LayerDev{};
+  {
+    ProfScope ps(h, MMF_K_MESH, s);
+    launch_mesh_emit(m->tsdf.d, F, m->mc, m->mesh_offsets, m->mesh_nblocks, verts, (__half*)vfeat, m->mesh_V, s);
+  }
+  return check_launch();
+}
+
+static Layer* pick_layer(Mapper* m, int layer) {
+  return layer == MMF_LAYER_TSDF ? &m->tsdf : (layer == MMF_LAYER_COLOR ? &m->color : (layer == MMF_LAYER_FEATURE ? &m->feat : nullptr));
+}
+
+int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* stream, int* out) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  Layer* L = pick_layer(m, layer);
+  if (!L || !out) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
+  if (!L->allocated) {
+    *out = 0;
+    return MMF_OK;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(h->pinned + 8, L->d.ctr, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *out = h->pinned[8];
+  if (h->pinned[11] & 1)
+    return fail(MMF_ERR_POOL_EXHAUSTED, "voxel-block pool exhausted: raise BlockMemoryPoolParams.num_preallocated_blocks");
+  return MMF_OK;
+}
+
+int mmf_get_block_indices(mmf_handle h, int mapper_id, int layer, int32_t* out, int n, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  Layer* L = pick_layer(m, layer);
+  if (!L) return fail(MMF_ERR_INVALID_ARG, "bad layer");
+  if (n <= 0 || !L->allocated) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_get_indices(L->d, out, n, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_get_tsdf_blocks(mmf_handle h, int mapper_id, float* out, int n, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (n <= 0) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_gather_pool(m->tsdf.d, m->tsdf.block_bytes, out, n, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_get_feature_blocks(mmf_handle h, int mapper_id, void* feats, float* weights, int n, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (n <= 0 || !m->feat.allocated) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_gather_pool(m->feat.d, m->feat.block_bytes, feats, n, (hipStream_t)stream);
+  launch_gather_poolw(m->feat.d, weights, n, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb, float* weights, int n, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (n <= 0 || !m->color.allocated) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_gather_color(m->color.d, rgb, weights, n, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* pts, int n, float* out, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (n <= 0) return MMF_OK;
+  if (!pts || !out) return fail(MMF_ERR_INVALID_ARG, "null buffer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (layer == MMF_LAYER_TSDF) {
+    launch_query_tsdf(m->tsdf.d, m->mc, pts, n, out, s);
+  } else if (layer == MMF_LAYER_FEATURE) {
+    if (!m->feat.allocated) {
+      HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * (m->mc.C + 1), s));
+      return MMF_OK;
+    }
+    launch_query_feature(m->feat.d, m->mc, pts, n, out, s);
+  } else {
+    return fail(MMF_ERR_INVALID_ARG, "query_layer supports the TSDF and feature layers");
+  }
+  return check_launch();
+}
+
+// ---- image-side ops -----------------------------------------------------------------------------
+int mmf_backproject_depth(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, void* stream) {
+  if (!depth || !K || !T || !out || B < 0 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_backproject_depth");
+  launch_backproject(depth, K, T, B, H, W, out, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_erode_mask(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int iterations, void* stream) {
+  if (!mask || !out || !tmp || H <= 0 || W <= 0 || iterations < 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_erode_mask");
+  launch_erode(mask, out, tmp, H, W, iterations, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_depth_m, int k_in, int k_depth,
+                     int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, void* stream) {
+  if (!input_mask || !depth || !out || !tmp || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || k_in < 0 || k_depth < 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_feature_mask");
+  launch_feature_mask(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, out, tmp, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_depth_m, uint8_t* out, void* stream) {
+  if (!depth || !out || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_depth_mask");
+  launch_depth_mask(input_mask, depth, H, W, min_depth_m, out, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_upsample_features(const float* lowres, int hh, int ww, int Cin, void* out, int Hf, int Wf, int Cpad, void* stream) {
+  if (!lowres || !out || hh <= 0 || ww <= 0 || Cin <= 0 || Hf <= 0 || Wf <= 0 || Cpad < Cin || Cpad % 8 != 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_upsample_features (Cpad must be a multiple of 8 and >= Cin)");
+  launch_upsample_features(lowres, hh, ww, Cin, (__half*)out, Hf, Wf, Cpad, (hipStream_t)stream);
+  return check_launch();
+}
+
+// ---- diagnostics ----------------------------------------------------------------------------------
+int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  *Hs = m->synth_H;
+  *Ws = m->synth_W;
+  return MMF_OK;
+}
+
+int mmf_get_synthetic_depth(mmf_handle h, int mapper_id, float* out, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!m->synth || m->synth_W * m->synth_H == 0) return fail(MMF_ERR_BAD_STATE, "no synthetic depth rendered yet");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(out, m->synth, sizeof(float) * (size_t)m->synth_W * m->synth_H, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMF_OK;
+}
+
+int mmf_render_synthetic_depth(mmf_handle h, int mapper_id, int H, int W, const float* T16, const float* K9, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  HIP_TRY(hipSetDevice(h->device));
+  Cam cam = cam_from_K(K9, W, H);
+  Rigid T_L_C;
+  rigid_from_T(T16, T_L_C);
+  m->synth_epoch = -1;  // force
+  MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, (hipStream_t)stream));
+  return check_launch();
+}
+
+int mmf_last_view_block_count(mmf_handle h, int mapper_id, void* stream, int* out) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(h->pinned + 16, m->sc.cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *out = h->pinned[16];
+  return MMF_OK;
+}
+
+int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* out, int n, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (n <= 0) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_unpack_keys, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const mmf::u64*)m->sc.cand_key, n, out);
+  return check_launch();
+}
+
+int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  long long* host = reinterpret_cast<long long*>(h->pinned + 32);
+  HIP_TRY(hipMemcpyAsync(host, m->stats, sizeof(long long) * MMF_NUM_STATS, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < MMF_NUM_STATS; ++i) out8[i] = host[i];
+  out8[0] = m->frames[0];
+  out8[3] = m->frames[1];
+  out8[5] = m->frames[2];
+  return MMF_OK;
+}
+
+int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(m->stats, 0, sizeof(long long) * MMF_NUM_STATS, (hipStream_t)stream));
+  m->frames[0] = m->frames[1] = m->frames[2] = 0;
+  return MMF_OK;
+}
+
+int mmf_profile_enable(mmf_handle h, int enable) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  h->prof = enable != 0;
+  return MMF_OK;
+}
+
+int mmf_profile_get(mmf_handle h, int kernel_id, double* total_ms, int64_t* launches) {
+  if (!h || kernel_id < 0 || kernel_id >= MMF_NUM_KERNEL_IDS) return fail(MMF_ERR_INVALID_ARG, "bad kernel id");
+  HIP_TRY(hipSetDevice(h->device));
+  MMF_TRY(prof_collect(h));
+  if (total_ms) *total_ms = h->prof_ms[kernel_id];
+  if (launches) *launches = h->prof_n[kernel_id];
+  return MMF_OK;
+}
+
+int mmf_profile_reset(mmf_handle h) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  MMF_TRY(prof_collect(h));
+  for (int i = 0; i < MMF_NUM_KERNEL_IDS; ++i) {
+    h->prof_ms[i] = 0;
+    h->prof_n[i] = 0;
+  }
+  return MMF_OK;
+}
+
+const char* mmf_kernel_name(int id) {
+  static const char* names[MMF_NUM_KERNEL_IDS] = {"k_raycast_mark",   "k_count_tiles+k_scan_tiles+k_emit", "k_tsdf_integrate",
+                                                  "k_app_candidates", "k_sphere_trace",                    "k_color_integrate",
+                                                  "k_feature_integrate", "k_decay(+compact)",              "k_mesh_count/emit"};
+  return (id >= 0 && id < MMF_NUM_KERNEL_IDS) ? names[id] : "?";
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// mmf_device.h -- device-side structures and arithmetic shared by all libmmfusion kernels.
+//
+// gfx950 (CDNA4) only: 64-wide wavefronts are assumed throughout (ballot masks are 64 bit).
+// The float arithmetic below follows the operation order of the spec in DESIGN.md section 3
+// exactly; the library is compiled with -ffp-contract=off so no multiply-add is fused and
+// results can be compared bit-for-bit with the CPU oracle.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmf {
+
+constexpr int kVPB = 512;  // voxels per 8x8x8 block
+constexpr int kWave = 64;
+typedef unsigned long long u64;
+constexpr u64 kEmptyKey = ~0ull;
+constexpr int kKeyOff = 1 << 20;  // 21 bits per axis: block indices in [-2^20, 2^20)
+
+struct Rigid {
+  float R[9];
+  float t[3];
+};
+
+struct Cam {
+  float fx, fy, cx, cy;
+  int W, H;
+};
+
+// Per-mapper constants derived from mmf_params on the host.
+struct MapConsts {
+  float v, bs, inv_bs, inv_v, trunc;
+  float max_dist, max_weight, lin_md;
+  int weighting_mode;
+  float app_wm, app_max_w;
+  int ws_type;
+  int ws_lo[3], ws_hi[3];
+  float decay_factor, decay_thr;
+  int dealloc_decayed;
+  float mesh_min_w;
+  int st_sf, st_max_steps;
+  float st_max_len, st_eps;
+  int C;
+};
+
+// Device view of one block layer: open-addressing hash (packed 64-bit keys -> pool slot),
+// pool of 8x8x8 blocks, live list (allocation order) and free-slot stack.
+struct LayerDev {
+  u64* hkeys;      // [hmask+1], kEmptyKey when free
+  int* hvals;      // [hmask+1] pool slot of the key
+  unsigned hmask;  // table size - 1 (power of two)
+  u64* slot_key;   // [cap] key stored in each pool slot
+  int* live;       // [cap] pool slots in allocation order
+  int* free_stack; // [cap]
+  int* ctr;        // [0] n_live  [1] n_free  [2] bump (first never-used slot)  [3] error flags
+  char* pool;      // payload A: cap * block_bytes
+  float* poolw;    // payload B: cap * 512 floats (feature layer weights) or nullptr
+  int cap;
+};
+
+// Compaction scratch shared by the three "flag -> ordered candidate list" passes.
+struct Scratch {
+  uint8_t* flags;    // [ncells] (multiple of 4) -- all zero between calls
+  int* cell_slot;    // [ncells]
+  int2* tile_counts; // [ntiles]
+  int2* tile_offs;   // [ntiles]
+  int* cand_slot;    // [ncells]
+  u64* cand_key;     // [ncells]
+  uint8_t* cand_new; // [ncells]
+  int* cand_count;   // [1]
+  int* alloc_ctx;    // [4] old n_live, old n_free, old bump, granted
+};
+
+// Where the key of a compaction cell comes from.
+struct KeySrc {
+  int mode;  // 0: dense view grid (cell -> block index), 1: live list of another layer
+  int ox, oy, oz, ny, nz;
+  const u64* slot_key;
+  const int* live;
+  const int* n_live;
+};
+
+__host__ __device__ inline u64 pack_key(int x, int y, int z) {
+  return ((u64)(unsigned)(x + kKeyOff) << 42) | ((u64)(unsigned)(y + kKeyOff) << 21) | (u64)(unsigned)(z + kKeyOff);
+}
+__host__ __device__ inline void unpack_key(u64 k, int& x, int& y, int& z) {
+  x = (int)((k >> 42) & 0x1fffffu) - kKeyOff;
+  y = (int)((k >> 21) & 0x1fffffu) - kKeyOff;
+  z = (int)(k & 0x1fffffu) - kKeyOff;
+}
+
+__device__ inline unsigned hash_key(u64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  return (unsigned)k;
+}
+
+__device__ inline int hash_find(const LayerDev& L, u64 key) {
+  unsigned h = hash_key(key) & L.hmask;
+  for (unsigned probe = 0; probe <= L.hmask; ++probe) {
+    u64 k = L.hkeys[h];
+    if (k == key) return L.hvals[h];
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & L.hmask;
+  }
+  return -1;
+}
+
+// Insert a key known to be absent. Distinct keys may race for a cell: CAS on the 64-bit key.
+__device__ inline void hash_insert(const LayerDev& L, u64 key, int slot) {
+  unsigned h = hash_key(key) & L.hmask;
+  for (unsigned probe = 0; probe <= L.hmask; ++probe) {
+    u64 prev = atomicCAS(&L.hkeys[h], kEmptyKey, key);
+    if (prev == kEmptyKey) {
+      L.hvals[h] = slot;
+      return;
+    }
+    h = (h + 1) & L.hmask;
+  }
+}
+
+__device__ inline int ifloor(float x) { return (int)floorf(x); }
+
+__device__ inline void xform(const Rigid& T, const float* p, float* q) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = ((T.R[i * 3 + 0] * p[0] + T.R[i * 3 + 1] * p[1]) + T.R[i * 3 + 2] * p[2]) + T.t[i];
+}
+__device__ inline void rotate(const Rigid& T, const float* p, float* q) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = (T.R[i * 3 + 0] * p[0] + T.R[i * 3 + 1] * p[1]) + T.R[i * 3 + 2] * p[2];
+}
+
+__device__ inline void voxel_centre(const MapConsts& mc, int bx, int by, int bz, int lin, float* c) {
+  int vx = lin >> 6, vy = (lin >> 3) & 7, vz = lin & 7;
+  c[0] = (float)bx * mc.bs + ((float)vx + 0.5f) * mc.v;
+  c[1] = (float)by * mc.bs + ((float)vy + 0.5f) * mc.v;
+  c[2] = (float)bz * mc.bs + ((float)vz + 0.5f) * mc.v;
+}
+
+__device__ inline bool project(const Cam& c, const float* p, float& u, float& v) {
+  if (p[2] <= 1e-6f) return false;
+  float iz = 1.0f / p[2];
+  float uu = c.fx * (p[0] * iz) + c.cx;
+  float vv = c.fy * (p[1] * iz) + c.cy;
+  if (uu < 0.0f || vv < 0.0f || uu > (float)c.W || vv > (float)c.H) return false;
+  u = uu;
+  v = vv;
+  return true;
+}
+
+__device__ inline bool bilin_setup(float u, float v, int W, int H, int& x0, int& y0, float& wx, float& wy) {
+  float uc = u - 0.5f, vc = v - 0.5f;
+  float fx0 = floorf(uc), fy0 = floorf(vc);
+  int ix = (int)fx0, iy = (int)fy0;
+  if (ix < 0 || iy < 0 || ix + 1 > W - 1 || iy + 1 > H - 1) return false;
+  x0 = ix;
+  y0 = iy;
+  wx = uc - fx0;
+  wy = vc - fy0;
+  return true;
+}
+
+__device__ inline float bilin(float a00, float a10, float a01, float a11, float wx, float wy) {
+  float top = (1.0f - wx) * a00 + wx * a10;
+  float bot = (1.0f - wx) * a01 + wx * a11;
+  return (1.0f - wy) * top + wy * bot;
+}
+
+__device__ inline bool in_workspace(const MapConsts& mc, int x, int y, int z) {
+  if (mc.ws_type == 0) return true;
+  if (z < mc.ws_lo[2] || z > mc.ws_hi[2]) return false;
+  if (mc.ws_type == 1) return true;
+  if (x < mc.ws_lo[0] || x > mc.ws_hi[0]) return false;
+  if (y < mc.ws_lo[1] || y > mc.ws_hi[1]) return false;
+  return true;
+}
+
+// Voxel containing p: block floor(p*inv_bs), voxel clamp(floor((p - b*bs)*inv_v), 0, 7).
+__device__ inline u64 voxel_at(const MapConsts& mc, const float* p, int& lin) {
+  int b[3], vi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    b[a] = ifloor(p[a] * mc.inv_bs);
+    int q = ifloor((p[a] - (float)b[a] * mc.bs) * mc.inv_v);
+    vi[a] = q < 0 ? 0 : (q > 7 ? 7 : q);
+  }
+  lin = (vi[0] * 8 + vi[1]) * 8 + vi[2];
+  return pack_key(b[0], b[1], b[2]);
+}
+
+// ---- wave / workgroup scans (wave64) ---------------------------------------------------------
+__device__ inline int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of two ints over a workgroup of NW waves; `lds` holds 2*NW+2 ints.
+template <int NW>
+__device__ inline void block_excl_scan2(int a, int b, int* lds, int& ex_a, int& ex_b, int& tot_a, int& tot_b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+  if (lane == 63) {
+    lds[wave] = ia;
+    lds[NW + wave] = ib;
+  }
+  __syncthreads();
+  int ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    int xa = lds[w], xb = lds[NW + w];
+    if (w < wave) {
+      ba += xa;
+      bb += xb;
+    }
+    ta += xa;
+    tb += xb;
+  }
+  ex_a = ba + ia - a;
+  ex_b = bb + ib - b;
+  tot_a = ta;
+  tot_b = tb;
+  __syncthreads();
+}
+
+// XCD-aware candidate mapping: workgroup j handles candidate (j%8)*chunk + j/8 so that each of the
+// 8 XCDs (block j runs on XCD j%8) walks one contiguous, spatially coherent eighth of the sorted
+// candidate list and keeps its image footprint in its own L2.
+__device__ inline int xcd_candidate(int j, int chunk) { return (j & 7) * chunk + (j >> 3); }
+
+}  // namespace mmf

@@ -1,0 +1,324 @@
+// mmf_kernels_app.hip -- appearance (colour / N-channel feature) fusion: candidate selection,
+// sphere-traced synthetic depth for the occlusion test, and the per-voxel weighted update.
+// gfx950 / wave64.
+//
+// Replaces the CUDA behind nvblox_torch Mapper.add_color_frame / add_feature_frame, reached by the
+// reference at mindmap/mapping/helpers/nvblox_mapping_helpers.py:212-218 and :255-261.
+#include "mmf_launch.h"
+
+namespace mmf {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------
+// Candidate blocks: live TSDF blocks with a voxel inside the truncation band (W > 0, |D| < trunc)
+// whose centre projects into the appearance image.  One workgroup per live block, 2 voxels/thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc, Cam cam, Rigid T_C_L,
+                                                       uint8_t* __restrict__ flags) {
+  const int n = T.ctr[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = T.live[i];
+    int bx, by, bz;
+    unpack_key(T.slot_key[slot], bx, by, bz);
+    const float4 a = reinterpret_cast<const float4*>(T.pool)[(size_t)slot * (kVPB / 2) + threadIdx.x];
+    int hit = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float D = r ? a.z : a.x, W = r ? a.w : a.y;
+      if (!(W > 0.0f) || !(fabsf(D) < mc.trunc)) continue;
+      float c[3], p[3], u, v;
+      voxel_centre(mc, bx, by, bz, threadIdx.x * 2 + r, c);
+      xform(T_C_L, c, p);
+      if (!project(cam, p, u, v)) continue;
+      if (mc.max_dist > 0.0f && p[2] > mc.max_dist) continue;
+      hit = 1;
+    }
+    const int any = __syncthreads_or(hit);
+    if (any && threadIdx.x == 0) flags[i] = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sphere tracing: one thread per (subsampled) ray; each step is a hash lookup + one voxel read.
+// The last block's slot is cached because consecutive steps usually stay inside one 8 cm block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
+                                                     int Ws, int Hs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Ws * Hs) return;
+  const int rs = idx / Ws, cs = idx % Ws;
+  const float sf = (float)mc.st_sf;
+  const float u = ((float)cs + 0.5f) * sf, v = ((float)rs + 0.5f) * sf;
+  const float x = (u - cam.cx) / cam.fx, y = (v - cam.cy) / cam.fy;
+  const float nrm = sqrtf((x * x + y * y) + 1.0f);
+  const float dC[3] = {x / nrm, y / nrm, 1.0f / nrm};
+  float dL[3];
+  rotate(T_L_C, dC, dL);
+  const float o[3] = {T_L_C.t[0], T_L_C.t[1], T_L_C.t[2]};
+
+  bool last_pos = false, ok = false;
+  float t = 0.0f;
+  u64 ckey = kEmptyKey;
+  int cslot = -1;
+  for (int i = 0; i < mc.st_max_steps && t < mc.st_max_len; ++i) {
+    const float p[3] = {o[0] + t * dL[0], o[1] + t * dL[1], o[2] + t * dL[2]};
+    int lin;
+    const u64 key = voxel_at(mc, p, lin);
+    if (key != ckey) {
+      ckey = key;
+      cslot = hash_find(T, key);
+    }
+    bool valid = false;
+    float D = 0.0f;
+    if (cslot >= 0) {
+      const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)cslot * kVPB + lin];
+      if (dw.y > 1e-4f) {
+        valid = true;
+        D = dw.x;
+      }
+    }
+    float step;
+    if (!valid) {
+      if (last_pos) break;
+      step = mc.trunc;
+    } else if (D < mc.st_eps) {
+      if (last_pos) {
+        t = t + D;
+        ok = true;
+      }
+      break;
+    } else {
+      step = D;
+      last_pos = true;
+    }
+    t += step;
+  }
+  synth[idx] = ok ? t * dC[2] : -1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared per-voxel gate (projection, occlusion test against the synthetic depth, bilinear footprint,
+// mask).  Same operation order as oracle/mmf_oracle.c:app_gate.
+// ------------------------------------------------------------------------------------------------
+__device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* __restrict__ mask,
+                                const float* __restrict__ synth, int Ws, int Hs, int bx, int by, int bz, int lin, int& x0,
+                                int& y0, float& wx, float& wy) {
+  float c[3], p[3], u, v;
+  voxel_centre(mc, bx, by, bz, lin, c);
+  xform(T_C_L, c, p);
+  if (!project(cam, p, u, v)) return false;
+  if (mc.max_dist > 0.0f && p[2] > mc.max_dist) return false;
+  const float sf = (float)mc.st_sf;
+  int sx, sy;
+  float swx, swy;
+  if (!bilin_setup(u / sf, v / sf, Ws, Hs, sx, sy, swx, swy)) return false;
+  const float s00 = synth[(size_t)sy * Ws + sx], s10 = synth[(size_t)sy * Ws + sx + 1];
+  const float s01 = synth[(size_t)(sy + 1) * Ws + sx], s11 = synth[(size_t)(sy + 1) * Ws + sx + 1];
+  if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) return false;
+  const float sd = bilin(s00, s10, s01, s11, swx, swy);
+  if (fabsf(sd - p[2]) > mc.trunc) return false;
+  if (!bilin_setup(u, v, cam.W, cam.H, x0, y0, wx, wy)) return false;
+  if (mask) {
+    const size_t i = (size_t)y0 * cam.W + x0;
+    if (!mask[i] || !mask[i + 1] || !mask[i + cam.W] || !mask[i + cam.W + 1]) return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Colour: voxel = {uchar4 rgb_, float w} (8 B); one workgroup of 512 threads per block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_color_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+                                                        const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ synth, int Ws, int Hs, Scratch sc) {
+  const int n = *sc.cand_count;
+  const int chunk = (n + 7) >> 3;
+  const int lin = threadIdx.x;
+  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+    const int i = xcd_candidate(j, chunk);
+    if (i >= n) continue;
+    const int slot = sc.cand_slot[i];
+    if (slot < 0) continue;
+    const bool is_new = sc.cand_new[i] != 0;
+    int bx, by, bz;
+    unpack_key(sc.cand_key[i], bx, by, bz);
+    uint2* vox = reinterpret_cast<uint2*>(L.pool) + (size_t)slot * kVPB + lin;
+    uint2 e = is_new ? make_uint2(0u, 0u) : *vox;
+    int x0, y0;
+    float wx, wy;
+    bool upd = false;
+    if (app_gate(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
+      const uint8_t* t00 = rgb + ((size_t)y0 * cam.W + x0) * 3;
+      const uint8_t* t10 = t00 + 3;
+      const uint8_t* t01 = t00 + (size_t)cam.W * 3;
+      const uint8_t* t11 = t01 + 3;
+      const float Wv = __uint_as_float(e.y);
+      const float wm = mc.app_wm;
+      const float inv = 1.0f / (Wv + wm);
+      unsigned out = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
+        const float A = (float)((e.x >> (8 * k)) & 0xffu);
+        const float An = (A * Wv + a * wm) * inv;
+        out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
+      }
+      e.x = out;
+      e.y = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
+      upd = true;
+    }
+    if (upd || is_new) *vox = e;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Features: block payload = half[512][C] (+ float w[512] in poolw).  One workgroup (256 threads) per
+// candidate block.
+//   phase 1: every voxel is gated once (2 voxels per thread); survivors are compacted into LDS
+//            (voxel id, top-left tap pixel, bilinear weights, old weight) with a wave ballot;
+//            the new weight is written immediately.
+//   phase 2: 32 groups of 8 lanes walk the compacted list; a group moves one voxel's channels in
+//            128-byte pieces (8 lanes x 16 B): 4 image taps + the voxel row in, blended row out.
+//            Image taps are HWC f16, so each tap piece is one contiguous 128 B line.
+// HBM-bound: algorithmic traffic = feature image once + (2C+4) B read and written per touched voxel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_feature_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+                                                          const __half* __restrict__ feat,
+                                                          const uint8_t* __restrict__ mask,
+                                                          const float* __restrict__ synth, int Ws, int Hs, Scratch sc) {
+  __shared__ uint16_t s_lin[kVPB];
+  __shared__ uint32_t s_pix[kVPB];
+  __shared__ float s_wx[kVPB], s_wy[kVPB], s_W[kVPB];
+  __shared__ uint8_t s_valid[kVPB];
+  __shared__ int s_n;
+
+  const int n = *sc.cand_count;
+  const int chunk = (n + 7) >> 3;
+  const int C = mc.C, nch = C >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int group = tid >> 3, gl = tid & 7;
+  const float wm = mc.app_wm;
+
+  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+    const int i = xcd_candidate(j, chunk);
+    if (i >= n) continue;
+    const int slot = sc.cand_slot[i];
+    if (slot < 0) continue;
+    const bool is_new = sc.cand_new[i] != 0;
+    int bx, by, bz;
+    unpack_key(sc.cand_key[i], bx, by, bz);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    float* wts = L.poolw + (size_t)slot * kVPB;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int lin = tid + 256 * r;
+      int x0, y0;
+      float wx, wy;
+      const bool valid = app_gate(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
+      const u64 bal = __ballot(valid);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (valid) {
+        const float Wold = is_new ? 0.0f : wts[lin];
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        s_lin[pos] = (uint16_t)lin;
+        s_pix[pos] = (uint32_t)(y0 * cam.W + x0);
+        s_wx[pos] = wx;
+        s_wy[pos] = wy;
+        s_W[pos] = Wold;
+        wts[lin] = fminf(Wold + wm, mc.app_max_w);
+      } else if (is_new) {
+        wts[lin] = 0.0f;
+      }
+      if (is_new) s_valid[lin] = valid ? 1 : 0;
+    }
+    __syncthreads();
+
+    const int nv = s_n;
+    __half* blk = reinterpret_cast<__half*>(L.pool) + (size_t)slot * kVPB * C;
+    for (int vi = group; vi < nv; vi += 32) {
+      const int lin = s_lin[vi];
+      const size_t pix = s_pix[vi];
+      const float wx = s_wx[vi], wy = s_wy[vi], Wv = s_W[vi];
+      const float inv = 1.0f / (Wv + wm);
+      const __half* t00 = feat + pix * C;
+      const __half* t10 = t00 + C;
+      const __half* t01 = t00 + (size_t)cam.W * C;
+      const __half* t11 = t01 + C;
+      __half* A = blk + (size_t)lin * C;
+      for (int ch = gl; ch < nch; ch += 8) {
+        const half8 a00 = *reinterpret_cast<const half8*>(t00 + ch * 8);
+        const half8 a10 = *reinterpret_cast<const half8*>(t10 + ch * 8);
+        const half8 a01 = *reinterpret_cast<const half8*>(t01 + ch * 8);
+        const half8 a11 = *reinterpret_cast<const half8*>(t11 + ch * 8);
+        half8 av;
+        if (is_new) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) av[k] = (_Float16)0.0f;
+        } else {
+          av = *reinterpret_cast<const half8*>(A + ch * 8);
+        }
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float a = bilin((float)a00[k], (float)a10[k], (float)a01[k], (float)a11[k], wx, wy);
+          const float An = ((float)av[k] * Wv + a * wm) * inv;
+          o[k] = (_Float16)An;
+        }
+        *reinterpret_cast<half8*>(A + ch * 8) = o;
+      }
+    }
+    if (is_new) {  // rows of voxels that were not updated must read as zero
+      half8 z;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+      for (int lin = group; lin < kVPB; lin += 32) {
+        if (s_valid[lin]) continue;
+        __half* A = blk + (size_t)lin * C;
+        for (int ch = gl; ch < nch; ch += 8) *reinterpret_cast<half8*>(A + ch * 8) = z;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static inline int grid8(int upper, int cap) {
+  int g = upper < cap ? upper : cap;
+  g = (g + 7) & ~7;
+  return g < 8 ? 8 : g;
+}
+
+void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, uint8_t* flags,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(k_app_candidates, dim3(grid8(tsdf.cap, 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L, flags);
+}
+
+void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
+                         int Hs, hipStream_t s) {
+  int n = Ws * Hs;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_sphere_trace, dim3((n + 255) / 256), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs);
+}
+
+void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
+                            const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_color_integrate, dim3(grid8(max_cand, 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, rgb, mask, synth, Ws,
+                     Hs, sc);
+}
+
+void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
+                              const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(k_feature_integrate, dim3(grid8(max_cand, 8192)), dim3(256), 0, s, L, mc, cam, T_C_L, feat, mask, synth,
+                     Ws, Hs, sc);
+}
+
+}  // namespace mmf

@@ -1,0 +1,241 @@
+// mmf_kernels_image.hip -- image-side kernels of the fusion path (mindmap/image_processing):
+// depth back-projection, mask erosion / feature-mask algebra, feature-map upsample+pad+cast.
+// gfx950 / wave64.  All of these are pure streaming kernels bound by HBM bandwidth.
+#include "mmf_launch.h"
+
+namespace mmf {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------
+// Back-projection (image_processing/backprojection.py:51-146):
+//   p_C = depth * (K^-1 (u, v, 1)^T), u = column, v = row (integer pixel coordinates, no +0.5),
+//   p_W = T (p_C, 1)^T, non-finite -> 0, output channel-first [B,3,H,W].
+// 4 B read + 12 B written per pixel; VEC pixels per thread as 16-byte accesses.
+// ------------------------------------------------------------------------------------------------
+struct Mat3 {
+  float m[9];
+};
+
+__device__ inline Mat3 inverse3(const float* K) {
+  // cofactor inverse in float64, rounded once to float32
+  const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double id = 1.0 / det;
+  Mat3 r;
+  r.m[0] = (float)(A * id);
+  r.m[1] = (float)(-(b * i - c * h) * id);
+  r.m[2] = (float)((b * f - c * e) * id);
+  r.m[3] = (float)(B * id);
+  r.m[4] = (float)((a * i - c * g) * id);
+  r.m[5] = (float)(-(a * f - c * d) * id);
+  r.m[6] = (float)(C * id);
+  r.m[7] = (float)(-(a * h - b * g) * id);
+  r.m[8] = (float)((a * e - b * d) * id);
+  return r;
+}
+
+__device__ inline float finite_or_zero(float x) { return isfinite(x) ? x : 0.0f; }
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_backproject(const float* __restrict__ depth, const float* __restrict__ K,
+                                                    const float* __restrict__ T, int H, int W, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const size_t HW = (size_t)H * W;
+  const size_t p0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (p0 >= HW) return;
+  const Mat3 Ki = inverse3(K + 9 * b);
+  const float* Tb = T + 16 * b;
+  float d[VEC], ox[VEC], oy[VEC], oz[VEC];
+  if (VEC == 4) {
+    const float4 dv = *reinterpret_cast<const float4*>(depth + b * HW + p0);
+    d[0] = dv.x;
+    d[VEC > 1 ? 1 : 0] = dv.y;
+    d[VEC > 2 ? 2 : 0] = dv.z;
+    d[VEC > 3 ? 3 : 0] = dv.w;
+  } else {
+    d[0] = depth[b * HW + p0];
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const size_t p = p0 + k;
+    const float u = (float)(int)(p % W), v = (float)(int)(p / W);
+    const float rx = (u * Ki.m[0] + v * Ki.m[1]) + Ki.m[2];
+    const float ry = (u * Ki.m[3] + v * Ki.m[4]) + Ki.m[5];
+    const float rz = (u * Ki.m[6] + v * Ki.m[7]) + Ki.m[8];
+    const float xc = d[k] * rx, yc = d[k] * ry, zc = d[k] * rz;
+    ox[k] = finite_or_zero(((xc * Tb[0] + yc * Tb[1]) + zc * Tb[2]) + Tb[3]);
+    oy[k] = finite_or_zero(((xc * Tb[4] + yc * Tb[5]) + zc * Tb[6]) + Tb[7]);
+    oz[k] = finite_or_zero(((xc * Tb[8] + yc * Tb[9]) + zc * Tb[10]) + Tb[11]);
+  }
+  float* o = out + (size_t)b * 3 * HW + p0;
+  if (VEC == 4) {
+    *reinterpret_cast<float4*>(o) = make_float4(ox[0], ox[VEC > 1 ? 1 : 0], ox[VEC > 2 ? 2 : 0], ox[VEC > 3 ? 3 : 0]);
+    *reinterpret_cast<float4*>(o + HW) = make_float4(oy[0], oy[VEC > 1 ? 1 : 0], oy[VEC > 2 ? 2 : 0], oy[VEC > 3 ? 3 : 0]);
+    *reinterpret_cast<float4*>(o + 2 * HW) = make_float4(oz[0], oz[VEC > 1 ? 1 : 0], oz[VEC > 2 ? 2 : 0], oz[VEC > 3 ? 3 : 0]);
+  } else {
+    o[0] = ox[0];
+    o[HW] = oy[0];
+    o[2 * HW] = oz[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// erode_mask (image_processing/image_mask_operations.py:16-41): k iterations of a zero-padded 3x3
+// max-pool on the inverted mask == one (2k+1)x(2k+1) square dilation of the inverted mask, done
+// separably: row pass into tmp, column pass out.  Pixels outside the image never contribute.
+// tmp bit0: row-dilated (mask == 0);  bit1 (feature-mask variant): row-dilated !(depth > min_d).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rowpass(const uint8_t* __restrict__ mask, const float* __restrict__ depth, float min_d,
+                                                int H, int W, int k0, int k1, uint8_t* __restrict__ tmp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const uint8_t* mrow = mask ? mask + (size_t)y * W : nullptr;
+  unsigned r = 0;
+  if (mrow) {
+    const int lo = x - k0 < 0 ? 0 : x - k0, hi = x + k0 > W - 1 ? W - 1 : x + k0;
+    for (int xx = lo; xx <= hi; ++xx) r |= (mrow[xx] == 0) ? 1u : 0u;
+  }
+  if (depth) {
+    const float* drow = depth + (size_t)y * W;
+    const int lo = x - k1 < 0 ? 0 : x - k1, hi = x + k1 > W - 1 ? W - 1 : x + k1;
+    for (int xx = lo; xx <= hi; ++xx) r |= (!(drow[xx] > min_d)) ? 2u : 0u;
+  }
+  tmp[(size_t)y * W + x] = (uint8_t)r;
+}
+
+__global__ __launch_bounds__(256) void k_colpass_erode(const uint8_t* __restrict__ tmp, int H, int W, int k,
+                                                      uint8_t* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int lo = y - k < 0 ? 0 : y - k, hi = y + k > H - 1 ? H - 1 : y + k;
+  unsigned r = 0;
+  for (int yy = lo; yy <= hi; ++yy) r |= tmp[(size_t)yy * W + x];
+  out[(size_t)y * W + x] = (r & 1u) ? 0 : 1;
+}
+
+// Column pass + nearest upsample to (Hf,Wf) + border mask (nvblox_mapping_helpers.py:222-253,
+// image_mask_operations.py:44-68).  Nearest source index = min(floor(dst * (in/out)), in-1).
+__global__ __launch_bounds__(256) void k_colpass_feature_mask(const uint8_t* __restrict__ tmp, int H, int W, int k0, int k1,
+                                                             int Hf, int Wf, float sh, float sw, int bh, int bw,
+                                                             uint8_t* __restrict__ out) {
+  const int xf = blockIdx.x * blockDim.x + threadIdx.x, yf = blockIdx.y;
+  if (xf >= Wf) return;
+  uint8_t res = 0;
+  const bool border_ok = (bh <= 0 || bw <= 0) || (yf >= bh && yf < Hf - bh && xf >= bw && xf < Wf - bw);
+  if (border_ok) {
+    int ys = (int)floorf((float)yf * sh), xs = (int)floorf((float)xf * sw);
+    ys = ys > H - 1 ? H - 1 : ys;
+    xs = xs > W - 1 ? W - 1 : xs;
+    unsigned r = 0;
+    {
+      const int lo = ys - k0 < 0 ? 0 : ys - k0, hi = ys + k0 > H - 1 ? H - 1 : ys + k0;
+      for (int yy = lo; yy <= hi; ++yy) r |= tmp[(size_t)yy * W + xs] & 1u;
+    }
+    {
+      const int lo = ys - k1 < 0 ? 0 : ys - k1, hi = ys + k1 > H - 1 ? H - 1 : ys + k1;
+      for (int yy = lo; yy <= hi; ++yy) r |= tmp[(size_t)yy * W + xs] & 2u;
+    }
+    res = r ? 0 : 1;
+  }
+  out[(size_t)yf * Wf + xf] = res;
+}
+
+__global__ __launch_bounds__(256) void k_depth_mask(const uint8_t* __restrict__ mask, const float* __restrict__ depth, size_t n,
+                                                   float min_d, uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool m = mask ? mask[i] != 0 : true;
+  out[i] = (m && depth[i] > min_d) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature-map upsample (feature_extraction.py:126-128,188-191,198-210 + nvblox_mapping_helpers.py:256):
+// bilinear align_corners=False of a channels-last low-res map [h,w,Cin] f32 to [Hf,Wf,Cpad] f16 with
+// channels >= Cin zero.  One thread = one output pixel x 8 channels (16-byte store); the low-res map
+// (<= 1 MB) stays in L2, so traffic is the output write.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_upsample_features(const float* __restrict__ low, int h, int w, int Cin,
+                                                          __half* __restrict__ out, int Hf, int Wf, int Cpad, float sh,
+                                                          float sw) {
+  const int nch = Cpad >> 3;
+  const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Hf * Wf * nch;
+  if (item >= total) return;
+  const int ch = (int)(item % nch);
+  const size_t pix = item / nch;
+  const int xf = (int)(pix % Wf), yf = (int)(pix / Wf);
+  float sy = sh * ((float)yf + 0.5f) - 0.5f, sx = sw * ((float)xf + 0.5f) - 0.5f;
+  sy = sy < 0.0f ? 0.0f : sy;
+  sx = sx < 0.0f ? 0.0f : sx;
+  const int y0 = (int)sy < h - 1 ? (int)sy : h - 1, x0 = (int)sx < w - 1 ? (int)sx : w - 1;
+  const int y1 = y0 < h - 1 ? y0 + 1 : y0, x1 = x0 < w - 1 ? x0 + 1 : x0;
+  const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+  const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+  half8 o;
+  const int c0 = ch * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + k;
+    float val = 0.0f;
+    if (c < Cin) {
+      const float a00 = low[((size_t)y0 * w + x0) * Cin + c], a01 = low[((size_t)y0 * w + x1) * Cin + c];
+      const float a10 = low[((size_t)y1 * w + x0) * Cin + c], a11 = low[((size_t)y1 * w + x1) * Cin + c];
+      val = ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11);
+    }
+    o[k] = (_Float16)val;
+  }
+  *reinterpret_cast<half8*>(out + pix * Cpad + c0) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+void launch_backproject(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, hipStream_t s) {
+  const size_t HW = (size_t)H * W;
+  if (B <= 0 || HW == 0) return;
+  const bool vec = (HW % 4 == 0) && ((uintptr_t)depth % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (vec) {
+    const unsigned gx = (unsigned)((HW / 4 + 255) / 256);
+    hipLaunchKernelGGL(k_backproject<4>, dim3(gx, B), dim3(256), 0, s, depth, K, T, H, W, out);
+  } else {
+    const unsigned gx = (unsigned)((HW + 255) / 256);
+    hipLaunchKernelGGL(k_backproject<1>, dim3(gx, B), dim3(256), 0, s, depth, K, T, H, W, out);
+  }
+}
+
+void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int k, hipStream_t s) {
+  dim3 g((W + 255) / 256, H);
+  hipLaunchKernelGGL(k_rowpass, g, dim3(256), 0, s, mask, (const float*)nullptr, 0.0f, H, W, k, 0, tmp);
+  hipLaunchKernelGGL(k_colpass_erode, g, dim3(256), 0, s, (const uint8_t*)tmp, H, W, k, out);
+}
+
+void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
+                         int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, hipStream_t s) {
+  dim3 g((W + 255) / 256, H);
+  hipLaunchKernelGGL(k_rowpass, g, dim3(256), 0, s, input_mask, depth, min_d, H, W, k_in, k_depth, tmp);
+  // int(mask_border_percent * 0.01 * height) in Python double arithmetic (image_mask_operations.py:62-63)
+  const int bh = (int)((double)border_percent * 0.01 * (double)Hf);
+  const int bw = (int)((double)border_percent * 0.01 * (double)Wf);
+  const float sh = (float)H / (float)Hf, sw = (float)W / (float)Wf;
+  dim3 gf((Wf + 255) / 256, Hf);
+  hipLaunchKernelGGL(k_colpass_feature_mask, gf, dim3(256), 0, s, (const uint8_t*)tmp, H, W, k_in, k_depth, Hf, Wf, sh, sw, bh,
+                     bw, out);
+}
+
+void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s) {
+  const size_t n = (size_t)H * W;
+  if (!n) return;
+  hipLaunchKernelGGL(k_depth_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, input_mask, depth, n, min_d, out);
+}
+
+void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s) {
+  const size_t total = (size_t)Hf * Wf * (Cpad / 8);
+  if (!total) return;
+  const float sh = (float)h / (float)Hf, sw = (float)w / (float)Wf;
+  hipLaunchKernelGGL(k_upsample_features, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf,
+                     Cpad, sh, sw);
+}
+
+}  // namespace mmf

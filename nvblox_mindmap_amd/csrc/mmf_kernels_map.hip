@@ -1,0 +1,572 @@
+// mmf_kernels_map.hip -- voxel-block allocation (raycast marking, flag compaction, hash insertion),
+// projective TSDF update, decay, and the layer views.  gfx950 / wave64.
+//
+// Replaces (through the C ABI in include/mmfusion.h) the CUDA behind nvblox_torch
+// Mapper.add_depth_frame / decay / clear / layer views, reached by the reference at
+// mindmap/mapping/helpers/nvblox_mapping_helpers.py:207-209 and
+// mindmap/mapping/isaaclab_nvblox_mapper.py:252-258.
+#include "mmf_launch.h"
+
+namespace mmf {
+
+// ------------------------------------------------------------------------------------------------
+// 1. Blocks in view: one thread per (subsampled) depth pixel walks the block grid from the camera
+//    centre to (depth + trunc) along its ray and flags every traversed block of the view grid.
+//    Bound: latency / L2 stores; the depth image is read once, coalesced (4 B per lane).
+// ------------------------------------------------------------------------------------------------
+struct Walk {
+  int c[3], g[3], st[3], n;
+  float tm[3], dt[3];
+};
+
+__device__ inline void walk_init(Walk& w, const float* s, const float* e) {
+  w.n = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float fs = floorf(s[a]);
+    w.c[a] = (int)fs;
+    w.g[a] = ifloor(e[a]);
+    int diff = w.g[a] - w.c[a];
+    w.n += diff < 0 ? -diff : diff;
+    float r = e[a] - s[a];
+    w.st[a] = r > 0.0f ? 1 : (r < 0.0f ? -1 : 0);
+    if (w.st[a] != 0) {
+      float corr = w.st[a] > 0 ? 1.0f : 0.0f;
+      float dist = corr - (s[a] - fs);
+      w.tm[a] = dist / r;
+      w.dt[a] = (float)w.st[a] / r;
+    } else {
+      w.tm[a] = 2.0f;
+      w.dt[a] = 2.0f;
+    }
+  }
+}
+
+__device__ inline void walk_step(Walk& w) {
+  int best = -1;
+  float bt = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (w.c[a] == w.g[a]) continue;
+    if (best < 0 || w.tm[a] < bt) {
+      best = a;
+      bt = w.tm[a];
+    }
+  }
+  // written without dynamic register indexing
+  if (best == 0) {
+    w.c[0] += w.st[0];
+    w.tm[0] += w.dt[0];
+  } else if (best == 1) {
+    w.c[1] += w.st[1];
+    w.tm[1] += w.dt[1];
+  } else if (best == 2) {
+    w.c[2] += w.st[2];
+    w.tm[2] += w.dt[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rigid T_L_C, const float* __restrict__ depth,
+                                                     const uint8_t* __restrict__ mask, int sub, int Wsub, int Hsub,
+                                                     ViewGrid vg, uint8_t* __restrict__ flags) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Wsub * Hsub) return;
+  int r = (idx / Wsub) * sub, c = (idx % Wsub) * sub;
+  size_t pix = (size_t)r * cam.W + c;
+  float d = depth[pix];
+  if (!(d > 0.0f)) return;
+  if (mask && !mask[pix]) return;
+  if (mc.max_dist > 0.0f && d > mc.max_dist) d = mc.max_dist;
+  float s = d + mc.trunc;
+  float ray[3] = {((float)c + 0.5f - cam.cx) / cam.fx, ((float)r + 0.5f - cam.cy) / cam.fy, 1.0f};
+  float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
+  float pL[3];
+  xform(T_L_C, pC, pL);
+  float s0[3] = {T_L_C.t[0] * mc.inv_bs, T_L_C.t[1] * mc.inv_bs, T_L_C.t[2] * mc.inv_bs};
+  float e[3] = {pL[0] * mc.inv_bs, pL[1] * mc.inv_bs, pL[2] * mc.inv_bs};
+  Walk w;
+  walk_init(w, s0, e);
+  for (int i = 0; i <= w.n; ++i) {
+    int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
+    // the view grid already is the intersection with the workspace bounds
+    if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
+      flags[(gx * vg.ny + gy) * vg.nz + gz] = 1;
+    }
+    walk_step(w);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. Flag compaction + hash lookup / insertion (shared by TSDF, colour and feature allocation).
+//    count tiles -> scan tiles -> emit.  A tile is 1024 cells (256 threads x 4 flag bytes).
+//    Candidate order = cell order (lexicographic block index for the view grid), so the order of
+//    the live list and of every output derived from it is deterministic.  New blocks take their
+//    pool slot from (rank among the new ones): wave ballot/prefix-sum, no per-block atomics.
+// ------------------------------------------------------------------------------------------------
+__device__ inline u64 cell_key(const KeySrc& ks, int cell) {
+  if (ks.mode == 0) {
+    int gz = cell % ks.nz;
+    int t = cell / ks.nz;
+    int gy = t % ks.ny;
+    int gx = t / ks.ny;
+    return pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
+  }
+  return ks.slot_key[ks.live[cell]];
+}
+
+__global__ __launch_bounds__(256) void k_count_tiles(LayerDev L, KeySrc ks, Scratch sc, int ncells) {
+  __shared__ int lds[10];
+  const int cell0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  uint32_t f4 = 0;
+  if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
+  int nf = 0, nn = 0;
+  if (f4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((f4 >> (8 * k)) & 0xffu) {
+        int cell = cell0 + k;
+        int slot = hash_find(L, cell_key(ks, cell));
+        sc.cell_slot[cell] = slot;
+        nf++;
+        nn += slot < 0;
+      }
+    }
+  }
+  int ea, eb, ta, tb;
+  block_excl_scan2<4>(nf, nn, lds, ea, eb, ta, tb);
+  if (threadIdx.x == 0) sc.tile_counts[blockIdx.x] = make_int2(ta, tb);
+}
+
+// Single workgroup: exclusive scan of the tile counts, slot grant, counter update, statistics.
+__global__ __launch_bounds__(256) void k_scan_tiles(LayerDev L, Scratch sc, int ntiles, long long* stats, int stat_upd,
+                                                   int stat_new) {
+  __shared__ int lds[10];
+  __shared__ int carry[2];
+  if (threadIdx.x == 0) {
+    carry[0] = 0;
+    carry[1] = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 256) {
+    int t = base + threadIdx.x;
+    int2 c = t < ntiles ? sc.tile_counts[t] : make_int2(0, 0);
+    int ea, eb, ta, tb;
+    block_excl_scan2<4>(c.x, c.y, lds, ea, eb, ta, tb);
+    if (t < ntiles) sc.tile_offs[t] = make_int2(carry[0] + ea, carry[1] + eb);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry[0] += ta;
+      carry[1] += tb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int n_cand = carry[0], n_new = carry[1];
+    int n_live = L.ctr[0], n_free = L.ctr[1], bump = L.ctr[2];
+    int room = n_free + (L.cap - bump);
+    int granted = n_new < room ? n_new : room;
+    if (granted < n_new) atomicOr(&L.ctr[3], 1);
+    sc.alloc_ctx[0] = n_live;
+    sc.alloc_ctx[1] = n_free;
+    sc.alloc_ctx[2] = bump;
+    sc.alloc_ctx[3] = granted;
+    int from_free = granted < n_free ? granted : n_free;
+    L.ctr[0] = n_live + granted;
+    L.ctr[1] = n_free - from_free;
+    L.ctr[2] = bump + (granted - from_free);
+    *sc.cand_count = n_cand;
+    if (stats) {
+      if (stat_upd >= 0) stats[stat_upd] += n_cand;
+      if (stat_new >= 0) stats[stat_new] += granted;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc, int ncells) {
+  __shared__ int lds[10];
+  const int cell0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  uint32_t f4 = 0;
+  if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
+  int slot4[4];
+  int nf = 0, nn = 0;
+  if (f4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      slot4[k] = 0;
+      if ((f4 >> (8 * k)) & 0xffu) {
+        slot4[k] = sc.cell_slot[cell0 + k];
+        nf++;
+        nn += slot4[k] < 0;
+      }
+    }
+  }
+  int ea, eb, ta, tb;
+  block_excl_scan2<4>(nf, nn, lds, ea, eb, ta, tb);
+  if (!f4) return;
+  const int2 off = sc.tile_offs[blockIdx.x];
+  const int old_live = sc.alloc_ctx[0], old_free = sc.alloc_ctx[1], old_bump = sc.alloc_ctx[2], granted = sc.alloc_ctx[3];
+  int pos = off.x + ea, rnk = off.y + eb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!((f4 >> (8 * k)) & 0xffu)) continue;
+    const int cell = cell0 + k;
+    const u64 key = cell_key(ks, cell);
+    int slot = slot4[k];
+    const bool is_new = slot < 0;
+    if (is_new) {
+      if (rnk < granted) {
+        slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
+        hash_insert(L, key, slot);
+        L.slot_key[slot] = key;
+        L.live[old_live + rnk] = slot;
+      }
+      rnk++;
+    }
+    sc.cand_slot[pos] = slot;
+    sc.cand_key[pos] = key;
+    sc.cand_new[pos] = is_new ? 1 : 0;
+    pos++;
+  }
+  *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // leave the flag array all-zero for the next frame
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. Projective TSDF update: one workgroup (512 threads = 8 waves) per 8x8x8 block, thread = voxel,
+//    z fastest so a wave reads/writes 512 contiguous bytes of {distance, weight}.  HBM-bound
+//    read-modify-write of 4 KB per block; the 4 depth taps come through L1/L2 (1.2 MB image).
+// ------------------------------------------------------------------------------------------------
+__device__ inline bool depth_tap(const float* depth, const uint8_t* mask, int W, int x, int y, float& out) {
+  size_t i = (size_t)y * W + x;
+  float d = depth[i];
+  if (!(d > 0.0f)) return false;
+  if (mask && !mask[i]) return false;
+  out = d;
+  return true;
+}
+
+__device__ inline bool sample_depth(const MapConsts& mc, const float* depth, const uint8_t* mask, const Cam& cam, float u,
+                                    float v, float& out) {
+  int xn = ifloor(u), yn = ifloor(v);
+  if (xn > cam.W - 1) xn = cam.W - 1;
+  if (yn > cam.H - 1) yn = cam.H - 1;
+  float dn;
+  if (!depth_tap(depth, mask, cam.W, xn, yn, dn)) return false;
+  int x0, y0;
+  float wx, wy;
+  if (bilin_setup(u, v, cam.W, cam.H, x0, y0, wx, wy)) {
+    float a00, a10, a01, a11;
+    if (depth_tap(depth, mask, cam.W, x0, y0, a00) && depth_tap(depth, mask, cam.W, x0 + 1, y0, a10) &&
+        depth_tap(depth, mask, cam.W, x0, y0 + 1, a01) && depth_tap(depth, mask, cam.W, x0 + 1, y0 + 1, a11)) {
+      bool ok = true;
+      if (mc.lin_md > 0.0f) {
+        if (fabsf(a00 - dn) > mc.lin_md || fabsf(a10 - dn) > mc.lin_md || fabsf(a01 - dn) > mc.lin_md ||
+            fabsf(a11 - dn) > mc.lin_md)
+          ok = false;
+      }
+      if (ok) {
+        out = bilin(a00, a10, a01, a11, wx, wy);
+        return true;
+      }
+    }
+  }
+  out = dn;
+  return true;
+}
+
+__global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+                                                       const float* __restrict__ depth,
+                                                       const uint8_t* __restrict__ mask, Scratch sc) {
+  const int n = *sc.cand_count;
+  const int chunk = (n + 7) >> 3;
+  const int lin = threadIdx.x;
+  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+    const int i = xcd_candidate(j, chunk);
+    if (i >= n) continue;
+    const int slot = sc.cand_slot[i];
+    if (slot < 0) continue;
+    const bool is_new = sc.cand_new[i] != 0;
+    int bx, by, bz;
+    unpack_key(sc.cand_key[i], bx, by, bz);
+    float2* vox = reinterpret_cast<float2*>(L.pool) + (size_t)slot * kVPB + lin;
+    float2 dw = is_new ? make_float2(0.0f, 0.0f) : *vox;
+    bool upd = false;
+    float c[3], p[3], u, v;
+    voxel_centre(mc, bx, by, bz, lin, c);
+    xform(T_C_L, c, p);
+    if (project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist)) {
+      float d;
+      if (sample_depth(mc, depth, mask, cam, u, v, d)) {
+        float sdf = d - p[2];
+        if (!(sdf < -mc.trunc)) {
+          float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
+          float Dn = (sdf * wm + dw.x * dw.y) / (wm + dw.y);
+          Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+          dw.x = Dn;
+          dw.y = fminf(dw.y + wm, mc.max_weight);
+          upd = true;
+        }
+      }
+    }
+    if (upd || is_new) *vox = dw;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. Decay: W *= factor over every live TSDF block; blocks whose voxels all fell below the threshold
+//    are flagged, then one workgroup compacts the live list in place (order preserving), pushes the
+//    freed slots and the hash is rebuilt from the survivors.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t* __restrict__ kill, int* any_kill) {
+  const int n = L.ctr[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = L.live[i];
+    float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x;  // 2 voxels
+    float4 a = *vox;
+    a.y = a.y * mc.decay_factor;
+    a.w = a.w * mc.decay_factor;
+    *vox = a;
+    int alive = (!(a.y < mc.decay_thr)) || (!(a.w < mc.decay_thr));
+    int any_alive = __syncthreads_or(alive);
+    if (threadIdx.x == 0 && !any_alive && mc.dealloc_decayed) {
+      kill[i] = 1;
+      *any_kill = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __restrict__ kill, const int* any_kill) {
+  if (!*any_kill) return;
+  __shared__ int lds[34];
+  __shared__ int carry[2];
+  const int n = L.ctr[0];
+  if (threadIdx.x == 0) {
+    carry[0] = 0;          // survivors written so far
+    carry[1] = L.ctr[1];   // free stack size
+  }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    int slot = -1, k = 0;
+    if (i < n) {
+      slot = L.live[i];
+      k = kill[i];
+      kill[i] = 0;
+    }
+    int keep = (i < n && !k) ? 1 : 0, dead = (i < n && k) ? 1 : 0;
+    int ea, eb, ta, tb;
+    block_excl_scan2<16>(keep, dead, lds, ea, eb, ta, tb);
+    const int c0 = carry[0], c1 = carry[1];
+    __syncthreads();  // every read of live[base..] and carry happened before any write below
+    if (keep) L.live[c0 + ea] = slot;
+    if (dead) {
+      L.free_stack[c1 + eb] = slot;
+      L.slot_key[slot] = kEmptyKey;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry[0] = c0 + ta;
+      carry[1] = c1 + tb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    L.ctr[0] = carry[0];
+    L.ctr[1] = carry[1];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hash_clear_if(LayerDev L, const int* cond) {
+  if (cond && !*cond) return;
+  for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h <= L.hmask; h += gridDim.x * blockDim.x) L.hkeys[h] = kEmptyKey;
+}
+
+__global__ __launch_bounds__(256) void k_hash_insert_live_if(LayerDev L, const int* cond) {
+  if (cond && !*cond) return;
+  const int n = L.ctr[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int slot = L.live[i];
+    hash_insert(L, L.slot_key[slot], slot);
+  }
+}
+
+__global__ void k_reset_layer(LayerDev L) {
+  if (threadIdx.x < 4 && blockIdx.x == 0) L.ctr[threadIdx.x] = 0;
+}
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
+
+// ------------------------------------------------------------------------------------------------
+// 5. Views (allocation order) and point queries.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_get_indices(LayerDev L, int32_t* __restrict__ out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || i >= L.ctr[0]) return;
+  int x, y, z;
+  unpack_key(L.slot_key[L.live[i]], x, y, z);
+  out[3 * i] = x;
+  out[3 * i + 1] = y;
+  out[3 * i + 2] = z;
+}
+
+// copy `bytes_per_block` (multiple of 16) of payload A of every live block, in live order
+__global__ __launch_bounds__(256) void k_gather_pool(LayerDev L, size_t bytes_per_block, char* __restrict__ out, int n) {
+  const int nl = L.ctr[0];
+  const size_t n16 = bytes_per_block / 16;
+  for (int i = blockIdx.x; i < n && i < nl; i += gridDim.x) {
+    const uint4* src = reinterpret_cast<const uint4*>(L.pool + (size_t)L.live[i] * bytes_per_block);
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * bytes_per_block);
+    for (size_t k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_poolw(LayerDev L, float* __restrict__ out, int n) {
+  const int nl = L.ctr[0];
+  for (int i = blockIdx.x; i < n && i < nl; i += gridDim.x) {
+    const float* src = L.poolw + (size_t)L.live[i] * kVPB;
+    float* dst = out + (size_t)i * kVPB;
+    for (int k = threadIdx.x; k < kVPB; k += blockDim.x) dst[k] = src[k];
+  }
+}
+
+// colour blocks are stored as {uchar4 rgba, float w}; unpack to rgb[512][3] + w[512]
+__global__ __launch_bounds__(256) void k_gather_color(LayerDev L, uint8_t* __restrict__ rgb, float* __restrict__ w, int n) {
+  const int nl = L.ctr[0];
+  for (int i = blockIdx.x; i < n && i < nl; i += gridDim.x) {
+    const uint2* src = reinterpret_cast<const uint2*>(L.pool) + (size_t)L.live[i] * kVPB;
+    for (int k = threadIdx.x; k < kVPB; k += blockDim.x) {
+      uint2 e = src[k];
+      uint8_t* o = rgb + ((size_t)i * kVPB + k) * 3;
+      o[0] = e.x & 0xff;
+      o[1] = (e.x >> 8) & 0xff;
+      o[2] = (e.x >> 16) & 0xff;
+      w[(size_t)i * kVPB + k] = __uint_as_float(e.y);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_query_tsdf(LayerDev L, MapConsts mc, const float* __restrict__ pts, int n,
+                                                   float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  int lin;
+  u64 key = voxel_at(mc, p, lin);
+  int slot = hash_find(L, key);
+  float2 r = make_float2(0.0f, 0.0f);
+  if (slot >= 0) r = reinterpret_cast<const float2*>(L.pool)[(size_t)slot * kVPB + lin];
+  out[2 * i] = r.x;
+  out[2 * i + 1] = r.y;
+}
+
+// one wave per query point: out[i][0..C-1] = features (f32), out[i][C] = weight
+__global__ __launch_bounds__(256) void k_query_feature(LayerDev L, MapConsts mc, const float* __restrict__ pts, int n,
+                                                      float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  int lin;
+  u64 key = voxel_at(mc, p, lin);
+  int slot = hash_find(L, key);
+  const int C = mc.C;
+  float* o = out + (size_t)i * (C + 1);
+  if (slot < 0) {
+    for (int k = lane; k <= C; k += 64) o[k] = 0.0f;
+    return;
+  }
+  const __half* f = reinterpret_cast<const __half*>(L.pool) + ((size_t)slot * kVPB + lin) * C;
+  for (int k = lane; k < C; k += 64) o[k] = __half2float(f[k]);
+  if (lane == 0) o[C] = L.poolw[(size_t)slot * kVPB + lin];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, int sub,
+                    const ViewGrid& vg, uint8_t* flags, hipStream_t s) {
+  int Wsub = (cam.W + sub - 1) / sub, Hsub = (cam.H + sub - 1) / sub;
+  int n = Wsub * Hsub;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_raycast_mark, dim3((n + 255) / 256), dim3(256), 0, s, mc, cam, T_L_C, depth, mask, sub, Wsub, Hsub, vg,
+                     flags);
+}
+
+void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
+                          int stat_new, hipStream_t s) {
+  int ntiles = (ncells + 1023) / 1024;
+  if (ntiles <= 0) ntiles = 1;
+  hipLaunchKernelGGL(k_count_tiles, dim3(ntiles), dim3(256), 0, s, L, ks, sc, ncells);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, s, L, sc, ntiles, stats, stat_upd, stat_new);
+  hipLaunchKernelGGL(k_emit, dim3(ntiles), dim3(256), 0, s, L, ks, sc, ncells);
+}
+
+static inline int grid_for(int upper, int cap) {
+  int g = upper < cap ? upper : cap;
+  g = (g + 7) & ~7;  // multiple of 8: a workgroup keeps its XCD residue across the stride loop
+  return g < 8 ? 8 : g;
+}
+
+void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
+                           const uint8_t* mask, const Scratch& sc, int max_cand, hipStream_t s) {
+  hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(max_cand, 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, sc);
+}
+
+void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, any_kill, 0);
+  hipLaunchKernelGGL(k_decay, dim3(grid_for(L.cap, 4096)), dim3(256), 0, s, L, mc, kill, any_kill);
+  if (mc.dealloc_decayed) {
+    hipLaunchKernelGGL(k_live_compact, dim3(1), dim3(1024), 0, s, L, kill, any_kill);
+    int hb = (int)((L.hmask + 1 + 255) / 256);
+    if (hb > 1024) hb = 1024;
+    hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)any_kill);
+    hipLaunchKernelGGL(k_hash_insert_live_if, dim3(grid_for((L.cap + 255) / 256, 1024)), dim3(256), 0, s, L,
+                       (const int*)any_kill);
+  }
+}
+
+void launch_layer_reset(const LayerDev& L, hipStream_t s) {
+  int hb = (int)((L.hmask + 1 + 255) / 256);
+  if (hb > 1024) hb = 1024;
+  hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)nullptr);
+  hipLaunchKernelGGL(k_reset_layer, dim3(1), dim3(64), 0, s, L);
+}
+
+void launch_hash_rebuild(const LayerDev& L, hipStream_t s) {
+  int hb = (int)((L.hmask + 1 + 255) / 256);
+  if (hb > 1024) hb = 1024;
+  hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)nullptr);
+  hipLaunchKernelGGL(k_hash_insert_live_if, dim3(grid_for((L.cap + 255) / 256, 1024)), dim3(256), 0, s, L,
+                     (const int*)nullptr);
+}
+
+void launch_get_indices(const LayerDev& L, int32_t* out, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_get_indices, dim3((n + 255) / 256), dim3(256), 0, s, L, out, n);
+}
+
+void launch_gather_pool(const LayerDev& L, size_t bytes_per_block, void* out, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_pool, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, L, bytes_per_block, (char*)out, n);
+}
+
+void launch_gather_poolw(const LayerDev& L, float* out, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_poolw, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, L, out, n);
+}
+
+void launch_gather_color(const LayerDev& L, uint8_t* rgb, float* w, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_color, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, L, rgb, w, n);
+}
+
+void launch_query_tsdf(const LayerDev& L, const MapConsts& mc, const float* pts, int n, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_query_tsdf, dim3((n + 255) / 256), dim3(256), 0, s, L, mc, pts, n, out);
+}
+
+void launch_query_feature(const LayerDev& L, const MapConsts& mc, const float* pts, int n, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_query_feature, dim3((n + 3) / 4), dim3(256), 0, s, L, mc, pts, n, out);
+}
+
+}  // namespace mmf

@@ -1,0 +1,55 @@
+// mmf_launch.h -- host-side launch interface between the C ABI (mmf_api.hip) and the kernel files.
+#pragma once
+#include "mmf_device.h"
+
+namespace mmf {
+
+struct ViewGrid {
+  int ox, oy, oz;  // block index of cell (0,0,0)
+  int nx, ny, nz;
+};
+
+// mmf_kernels_map.hip
+void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, int sub,
+                    const ViewGrid& vg, uint8_t* flags, hipStream_t s);
+void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
+                          int stat_new, hipStream_t s);
+void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
+                           const uint8_t* mask, const Scratch& sc, int max_cand, hipStream_t s);
+void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
+void launch_layer_reset(const LayerDev& L, hipStream_t s);
+void launch_hash_rebuild(const LayerDev& L, hipStream_t s);
+void launch_get_indices(const LayerDev& L, int32_t* out, int n, hipStream_t s);
+void launch_gather_pool(const LayerDev& L, size_t bytes_per_block, void* out, int n, hipStream_t s);
+void launch_gather_poolw(const LayerDev& L, float* out, int n, hipStream_t s);
+void launch_gather_color(const LayerDev& L, uint8_t* rgb, float* w, int n, hipStream_t s);
+void launch_query_tsdf(const LayerDev& L, const MapConsts& mc, const float* pts, int n, float* out, hipStream_t s);
+void launch_query_feature(const LayerDev& L, const MapConsts& mc, const float* pts, int n, float* out, hipStream_t s);
+
+// mmf_kernels_app.hip
+void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, uint8_t* flags,
+                           hipStream_t s);
+void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
+                         int Hs, hipStream_t s);
+void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
+                            const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
+                            hipStream_t s);
+void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
+                              const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
+                              hipStream_t s);
+
+// mmf_kernels_mesh.hip
+void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,
+                       hipStream_t s);
+void launch_mesh_emit(const LayerDev& tsdf, const LayerDev& feat, const MapConsts& mc, const int* offsets, int n_blocks,
+                      float* verts, __half* vfeat, int V, hipStream_t s);
+
+// mmf_kernels_image.hip
+void launch_backproject(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, hipStream_t s);
+void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int k, hipStream_t s);
+void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
+                         int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, hipStream_t s);
+void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s);
+void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s);
+
+}  // namespace mmf

@@ -1,0 +1,386 @@
+"""nvblox_torch.mapper.Mapper on MI355X: ctypes front-end of libmmfusion.so.
+
+Call contract taken from the reference's call sites:
+  Mapper(voxel_sizes_m, integrator_types, mapper_parameters)   mapping/helpers/nvblox_mapping_helpers.py:72-76
+  add_depth_frame(depth, T_W_C, K, mask, mapper_id)            :207-209
+  add_color_frame(rgb, T_W_C, K, mask_frame=, mapper_id=)      :212-218
+  add_feature_frame(feat, T_W_C, K_feat, mask, mapper_id)      :255-261
+  decay() / clear()                                            mapping/isaaclab_nvblox_mapper.py:252-258
+  update_feature_mesh / get_feature_mesh -> vertices(), vertex_features()   mapping/helpers/nvblox_output_helpers.py:49-52
+  tsdf_layer_view / feature_layer_view / query_layer           visualization/visualizer.py:678-691, paper/utils/utils.py:101-121
+All device tensors are borrowed by pointer on torch's current HIP stream; nothing is copied to the host
+on the per-frame path.  Errors surface as RuntimeError (upstream raises from C++ asserts).
+"""
+import ctypes as C
+from enum import Enum
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import constants as _constants
+from .mapper_params import MapperParams
+from .projective_integrator_types import ProjectiveIntegratorType
+
+
+class QueryType(Enum):
+    TSDF = 0
+    FEATURE = 2
+
+
+def _host_f32(x, shape) -> np.ndarray:
+    """Pose / intrinsics arrive as CPU torch tensors in the reference (``.cpu()`` at the call site)."""
+    if isinstance(x, torch.Tensor):
+        x = x.detach().to("cpu", torch.float32).numpy()
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+    if a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _check_dev(t: torch.Tensor, name: str, dtype, ndim: int) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a tensor on the GPU")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if t.ndim != ndim:
+        raise ValueError(f"{name} must have {ndim} dimensions, got shape {tuple(t.shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _mask_u8(mask: Optional[torch.Tensor], shape) -> Optional[torch.Tensor]:
+    if mask is None:
+        return None
+    if not mask.is_cuda:
+        raise ValueError("mask must be a tensor on the GPU")
+    if tuple(mask.shape) != tuple(shape):
+        raise ValueError(f"mask shape {tuple(mask.shape)} does not match the frame {tuple(shape)}")
+    if mask.dtype != torch.uint8:
+        mask = mask.to(torch.uint8)
+    return mask.contiguous()
+
+
+class FeatureMesh:
+    """Result of Mapper.get_feature_mesh(): surface vertices + one feature row per vertex."""
+
+    def __init__(self, vertices: torch.Tensor, vertex_features: torch.Tensor):
+        self._v = vertices
+        self._f = vertex_features
+
+    def vertices(self) -> torch.Tensor:
+        """[V,3] float32 on the GPU, world frame."""
+        return self._v
+
+    def vertex_features(self) -> torch.Tensor:
+        """[V,C] float16 on the GPU (zeros where no feature was observed)."""
+        return self._f
+
+    def vertex_appearances(self) -> torch.Tensor:
+        return self._f
+
+    def triangles(self) -> torch.Tensor:
+        raise NotImplementedError("triangle connectivity is not produced (the policy consumes vertices only)")
+
+
+class _LayerView:
+    def __init__(self, mapper: "Mapper", mapper_id: int, layer: int):
+        self._m, self._id, self._layer = mapper, mapper_id, layer
+
+    def voxel_size(self) -> float:
+        return self._m._voxel_sizes[self._id]
+
+    def block_size(self) -> float:
+        return 8.0 * self.voxel_size()
+
+    def num_allocated_blocks(self) -> int:
+        return self._m._num_blocks(self._id, self._layer)
+
+    def get_all_block_indices(self) -> torch.Tensor:
+        """[n,3] int32, allocation order."""
+        return self._m._block_indices(self._id, self._layer)
+
+
+class TsdfLayerView(_LayerView):
+    def get_all_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """([n,8,8,8,2] float32 with [...,0]=distance, [...,1]=weight, [n,3] int32 indices)."""
+        idx = self.get_all_block_indices()
+        n = idx.shape[0]
+        out = torch.empty((n, 8, 8, 8, 2), dtype=torch.float32, device=self._m.device)
+        if n:
+            L = _lib.lib()
+            _lib.check(L.mmf_get_tsdf_blocks(self._m._h, self._id, _lib.dptr(out), n, self._m._stream()), "mmf_get_tsdf_blocks")
+        return out, idx
+
+    def get_block_at_index(self, index) -> Optional[torch.Tensor]:
+        blocks, idx = self.get_all_blocks()
+        key = torch.as_tensor(index, dtype=torch.int32, device=idx.device).view(1, 3)
+        hit = torch.nonzero(torch.all(idx == key, dim=1))
+        return blocks[hit[0, 0]] if hit.numel() else None
+
+    def get_tsdfs_below_zero(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(tsdf_and_weight [N,2], voxel-centre points [N,3]) of observed voxels with distance < 0."""
+        from .indexing import get_voxel_center_grids
+
+        blocks, idx = self.get_all_blocks()
+        centres = get_voxel_center_grids(idx, self.voxel_size(), device=blocks.device)
+        sel = (blocks[..., 0] < 0) & (blocks[..., 1] > 0)
+        return blocks[sel], centres[sel]
+
+
+class FeatureLayerView(_LayerView):
+    def get_all_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """([n,8,8,8,C+1] float16 with [...,-1]=weight, [n,3] int32 indices)."""
+        feats, weights, idx = self.get_all_blocks_split()
+        return torch.cat([feats, weights.unsqueeze(-1).to(torch.float16)], dim=-1), idx
+
+    def get_all_blocks_split(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """([n,8,8,8,C] float16, [n,8,8,8] float32 weights, [n,3] int32 indices)."""
+        idx = self.get_all_block_indices()
+        n, Cc = idx.shape[0], self._m.feature_channels
+        feats = torch.empty((n, 8, 8, 8, Cc), dtype=torch.float16, device=self._m.device)
+        weights = torch.empty((n, 8, 8, 8), dtype=torch.float32, device=self._m.device)
+        if n:
+            L = _lib.lib()
+            _lib.check(L.mmf_get_feature_blocks(self._m._h, self._id, _lib.dptr(feats), _lib.dptr(weights), n, self._m._stream()),
+                       "mmf_get_feature_blocks")
+        return feats, weights, idx
+
+    def get_block_at_index(self, index) -> Optional[torch.Tensor]:
+        blocks, idx = self.get_all_blocks()
+        key = torch.as_tensor(index, dtype=torch.int32, device=idx.device).view(1, 3)
+        hit = torch.nonzero(torch.all(idx == key, dim=1))
+        return blocks[hit[0, 0]] if hit.numel() else None
+
+
+class ColorLayerView(_LayerView):
+    def get_all_blocks_split(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """([n,8,8,8,3] uint8, [n,8,8,8] float32 weights, [n,3] int32 indices)."""
+        idx = self.get_all_block_indices()
+        n = idx.shape[0]
+        rgb = torch.empty((n, 8, 8, 8, 3), dtype=torch.uint8, device=self._m.device)
+        weights = torch.empty((n, 8, 8, 8), dtype=torch.float32, device=self._m.device)
+        if n:
+            L = _lib.lib()
+            _lib.check(L.mmf_get_color_blocks(self._m._h, self._id, _lib.dptr(rgb), _lib.dptr(weights), n, self._m._stream()),
+                       "mmf_get_color_blocks")
+        return rgb, weights, idx
+
+
+class Mapper:
+    def __init__(
+        self,
+        voxel_sizes_m: Union[float, Sequence[float]],
+        integrator_types: Optional[List[ProjectiveIntegratorType]] = None,
+        mapper_parameters: Optional[MapperParams] = None,
+        device: Union[None, int, str, torch.device] = None,
+        feature_channels: Optional[int] = None,
+    ):
+        if isinstance(voxel_sizes_m, (int, float)):
+            voxel_sizes_m = [float(voxel_sizes_m)]
+        self._voxel_sizes = [float(v) for v in voxel_sizes_m]
+        n = len(self._voxel_sizes)
+        if integrator_types is None:
+            integrator_types = [ProjectiveIntegratorType.TSDF] * n
+        if len(integrator_types) != n:
+            raise ValueError("integrator_types must have one entry per voxel size")
+        for t in integrator_types:
+            if t != ProjectiveIntegratorType.TSDF:
+                raise NotImplementedError("only ProjectiveIntegratorType.TSDF is supported")
+        self._params = mapper_parameters if mapper_parameters is not None else MapperParams()
+        self.feature_channels = int(feature_channels or _constants.constants.feature_array_num_elements())
+
+        L = _lib.lib()  # raises if the HIP extension has not been built
+        _lib.require_gpu()
+        if device is None:
+            dev_index = torch.cuda.current_device()
+        else:
+            d = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+            dev_index = d.index if d.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        arr = (_lib.MmfParams * n)(*[self._params.to_c(v, self.feature_channels) for v in self._voxel_sizes])
+        h = C.c_void_p()
+        _lib.check(L.mmf_mapper_create(n, arr, dev_index, C.byref(h)), "mmf_mapper_create")
+        self._h = h
+        self._n = n
+        self._mesh_V = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().mmf_mapper_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- helpers ------------------------------------------------------------------------
+    def _stream(self) -> C.c_void_p:
+        return _lib.stream_ptr(self.device)
+
+    def _check_id(self, mapper_id: int) -> int:
+        mapper_id = int(mapper_id)
+        if not 0 <= mapper_id < self._n:
+            raise ValueError(f"mapper_id {mapper_id} out of range [0, {self._n})")
+        return mapper_id
+
+    def _num_blocks(self, mapper_id: int, layer: int) -> int:
+        n = C.c_int(0)
+        _lib.check(_lib.lib().mmf_num_allocated_blocks(self._h, mapper_id, layer, self._stream(), C.byref(n)), "mmf_num_allocated_blocks")
+        return n.value
+
+    def _block_indices(self, mapper_id: int, layer: int) -> torch.Tensor:
+        n = self._num_blocks(mapper_id, layer)
+        out = torch.empty((n, 3), dtype=torch.int32, device=self.device)
+        if n:
+            _lib.check(_lib.lib().mmf_get_block_indices(self._h, mapper_id, layer, _lib.dptr(out), n, self._stream()), "mmf_get_block_indices")
+        return out
+
+    # -- nvblox_torch API ---------------------------------------------------------------
+    def num_mappers(self) -> int:
+        return self._n
+
+    def add_depth_frame(self, depth_frame: torch.Tensor, t_w_c, intrinsics, mask_frame: Optional[torch.Tensor] = None,
+                        mapper_id: int = 0) -> None:
+        mapper_id = self._check_id(mapper_id)
+        depth = _check_dev(depth_frame, "depth_frame", torch.float32, 2)
+        H, W = depth.shape
+        mask = _mask_u8(mask_frame, (H, W))
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        _lib.check(_lib.lib().mmf_add_depth_frame(self._h, mapper_id, _lib.dptr(depth), _lib.dptr(mask), H, W, T.ctypes.data, K.ctypes.data,
+                                                  self._stream()), "mmf_add_depth_frame")
+
+    def add_color_frame(self, color_frame: torch.Tensor, t_w_c, intrinsics, mask_frame: Optional[torch.Tensor] = None,
+                        mapper_id: int = 0) -> None:
+        mapper_id = self._check_id(mapper_id)
+        rgb = _check_dev(color_frame, "color_frame", torch.uint8, 3)
+        H, W, ch = rgb.shape
+        if ch != 3:
+            raise ValueError("color_frame must be [H,W,3]")
+        mask = _mask_u8(mask_frame, (H, W))
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        _lib.check(_lib.lib().mmf_add_color_frame(self._h, mapper_id, _lib.dptr(rgb), _lib.dptr(mask), H, W, T.ctypes.data, K.ctypes.data,
+                                                  self._stream()), "mmf_add_color_frame")
+
+    def add_feature_frame(self, feature_frame: torch.Tensor, t_w_c, intrinsics, mask_frame: Optional[torch.Tensor] = None,
+                          mapper_id: int = 0) -> None:
+        mapper_id = self._check_id(mapper_id)
+        feat = _check_dev(feature_frame, "feature_frame", torch.float16, 3)
+        Hf, Wf, ch = feat.shape
+        if ch != self.feature_channels:
+            raise ValueError(
+                f"feature_frame has {ch} channels but the mapper stores {self.feature_channels} "
+                "(constants.feature_array_num_elements())")
+        mask = _mask_u8(mask_frame, (Hf, Wf))
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        _lib.check(_lib.lib().mmf_add_feature_frame(self._h, mapper_id, _lib.dptr(feat), _lib.dptr(mask), Hf, Wf, ch, T.ctypes.data,
+                                                    K.ctypes.data, self._stream()), "mmf_add_feature_frame")
+
+    def decay(self, mapper_id: int = -1) -> None:
+        _lib.check(_lib.lib().mmf_decay(self._h, int(mapper_id), self._stream()), "mmf_decay")
+
+    def clear(self, mapper_id: int = -1) -> None:
+        _lib.check(_lib.lib().mmf_clear(self._h, int(mapper_id), self._stream()), "mmf_clear")
+
+    def update_feature_mesh(self, mapper_id: int = 0) -> int:
+        mapper_id = self._check_id(mapper_id)
+        n = C.c_int(0)
+        _lib.check(_lib.lib().mmf_update_feature_mesh(self._h, mapper_id, self._stream(), C.byref(n)), "mmf_update_feature_mesh")
+        self._mesh_V[mapper_id] = n.value
+        return n.value
+
+    def get_feature_mesh(self, mapper_id: int = 0) -> FeatureMesh:
+        """Mesh of the last update_feature_mesh (re-extracted if the map changed since)."""
+        mapper_id = self._check_id(mapper_id)
+        L = _lib.lib()
+        V = self._mesh_V.get(mapper_id)
+        for attempt in range(2):
+            if V is None:
+                V = self.update_feature_mesh(mapper_id)
+            verts = torch.empty((V, 3), dtype=torch.float32, device=self.device)
+            feats = torch.empty((V, self.feature_channels), dtype=torch.float16, device=self.device)
+            rc = L.mmf_get_feature_mesh(self._h, mapper_id, _lib.dptr(verts), _lib.dptr(feats), self._stream())
+            if rc == 4 and attempt == 0:  # MMF_ERR_BAD_STATE: map changed since the last update
+                V = None
+                continue
+            _lib.check(rc, "mmf_get_feature_mesh")
+            break
+        return FeatureMesh(verts, feats)
+
+    def tsdf_layer_view(self, mapper_id: int = 0) -> TsdfLayerView:
+        return TsdfLayerView(self, self._check_id(mapper_id), _lib.MMF_LAYER_TSDF)
+
+    def feature_layer_view(self, mapper_id: int = 0) -> FeatureLayerView:
+        return FeatureLayerView(self, self._check_id(mapper_id), _lib.MMF_LAYER_FEATURE)
+
+    def color_layer_view(self, mapper_id: int = 0) -> ColorLayerView:
+        return ColorLayerView(self, self._check_id(mapper_id), _lib.MMF_LAYER_COLOR)
+
+    def query_layer(self, query_type: QueryType, query: torch.Tensor, mapper_id: int = 0) -> torch.Tensor:
+        """TSDF: [N,2] (distance, weight).  FEATURE: [N,C+1] float32 (features, weight last)."""
+        mapper_id = self._check_id(mapper_id)
+        pts = _check_dev(query, "query", torch.float32, 2)
+        n = pts.shape[0]
+        if query_type == QueryType.TSDF:
+            layer, width = _lib.MMF_LAYER_TSDF, 2
+        elif query_type == QueryType.FEATURE:
+            layer, width = _lib.MMF_LAYER_FEATURE, self.feature_channels + 1
+        else:
+            raise ValueError(f"unsupported query type {query_type}")
+        out = torch.empty((n, width), dtype=torch.float32, device=self.device)
+        if n:
+            _lib.check(_lib.lib().mmf_query_layer(self._h, mapper_id, layer, _lib.dptr(pts), n, _lib.dptr(out), self._stream()), "mmf_query_layer")
+        return out
+
+    # -- diagnostics / measurement (extensions) -------------------------------------------
+    def last_view_blocks(self, mapper_id: int = 0) -> torch.Tensor:
+        """Block indices the last add_depth_frame found in view, sorted (x,y,z): [n,3] int32."""
+        n = C.c_int(0)
+        _lib.check(_lib.lib().mmf_last_view_block_count(self._h, mapper_id, self._stream(), C.byref(n)), "mmf_last_view_block_count")
+        out = torch.empty((n.value, 3), dtype=torch.int32, device=self.device)
+        if n.value:
+            _lib.check(_lib.lib().mmf_get_last_view_blocks(self._h, mapper_id, _lib.dptr(out), n.value, self._stream()), "mmf_get_last_view_blocks")
+        return out
+
+    def synthetic_depth(self, mapper_id: int = 0) -> torch.Tensor:
+        hs, ws = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().mmf_get_synthetic_depth_dims(self._h, mapper_id, C.byref(hs), C.byref(ws)), "mmf_get_synthetic_depth_dims")
+        out = torch.empty((hs.value, ws.value), dtype=torch.float32, device=self.device)
+        if out.numel():
+            _lib.check(_lib.lib().mmf_get_synthetic_depth(self._h, mapper_id, _lib.dptr(out), self._stream()), "mmf_get_synthetic_depth")
+        return out
+
+    def render_synthetic_depth(self, height: int, width: int, t_w_c, intrinsics, mapper_id: int = 0) -> torch.Tensor:
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        _lib.check(_lib.lib().mmf_render_synthetic_depth(self._h, mapper_id, int(height), int(width), T.ctypes.data, K.ctypes.data, self._stream()),
+                   "mmf_render_synthetic_depth")
+        return self.synthetic_depth(mapper_id)
+
+    def stats(self, mapper_id: int = 0) -> dict:
+        buf = (C.c_int64 * _lib.MMF_NUM_STATS)()
+        _lib.check(_lib.lib().mmf_get_stats(self._h, mapper_id, self._stream(), buf), "mmf_get_stats")
+        names = ["depth_frames", "tsdf_blocks_updated", "tsdf_blocks_allocated", "color_frames", "color_blocks_updated",
+                 "feature_frames", "feature_blocks_updated", "feature_blocks_allocated"]
+        return dict(zip(names, [int(x) for x in buf]))
+
+    def reset_stats(self, mapper_id: int = 0) -> None:
+        _lib.check(_lib.lib().mmf_reset_stats(self._h, mapper_id, self._stream()), "mmf_reset_stats")
+
+    def profile_enable(self, on: bool = True) -> None:
+        _lib.check(_lib.lib().mmf_profile_enable(self._h, 1 if on else 0), "mmf_profile_enable")
+
+    def profile_reset(self) -> None:
+        _lib.check(_lib.lib().mmf_profile_reset(self._h), "mmf_profile_reset")
+
+    def profile(self) -> dict:
+        """{kernel class: (total_ms, launches)} measured with HIP events on the launch stream."""
+        out = {}
+        for name, kid in _lib.KERNEL_IDS.items():
+            ms, n = C.c_double(0), C.c_int64(0)
+            _lib.check(_lib.lib().mmf_profile_get(self._h, kid, C.byref(ms), C.byref(n)), "mmf_profile_get")
+            out[name] = (ms.value, n.value)
+        return out

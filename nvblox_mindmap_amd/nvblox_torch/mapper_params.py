@@ -1,0 +1,154 @@
+"""nvblox_torch.mapper_params: the parameter bags the reference fills in ``get_nvblox_mapper``
+(mindmap/mapping/helpers/nvblox_mapping_helpers.py:13-19,40-70).
+
+Plain attribute bags with the nvblox field names and nvblox defaults (recalled from upstream; see
+DESIGN.md section 3 for the list and their confidence).  Unknown attribute names raise, like the
+pybind classes upstream do.
+"""
+from .. import _lib
+
+
+class _Bag:
+    _fields = {}
+
+    def __init__(self):
+        for k, v in self._fields.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, k, v):
+        if k not in self._fields:
+            raise AttributeError(f"{type(self).__name__} has no parameter '{k}'")
+        object.__setattr__(self, k, v)
+
+    def __repr__(self):
+        return f"{type(self).__name__}({', '.join(f'{k}={getattr(self, k)!r}' for k in self._fields)})"
+
+
+class ProjectiveIntegratorParams(_Bag):
+    _fields = {
+        "projective_integrator_max_integration_distance_m": 7.0,
+        "lidar_projective_integrator_max_integration_distance_m": 10.0,  # accepted, unused (no lidar path)
+        "projective_integrator_truncation_distance_vox": 4.0,
+        "projective_integrator_weighting_mode": "kInverseSquareWeight",
+        "projective_integrator_max_weight": 5.0,
+        "projective_tsdf_integrator_invalid_depth_decay_factor": -1.0,  # accepted, unused
+        "projective_tsdf_integrator_linear_interpolation_max_allowable_difference_vox": 2.0,
+        "projective_appearance_integrator_measurement_weight": 1.0,
+        "projective_appearance_integrator_max_weight": 5.0,
+        "projective_appearance_integrator_sphere_tracing_ray_subsampling_factor": 4,
+    }
+
+
+class TsdfDecayIntegratorParams(_Bag):
+    _fields = {
+        "tsdf_decay_factor": 0.95,
+        "tsdf_decayed_weight_threshold": 1e-3,
+        "decay_integrator_deallocate_decayed_blocks": True,
+    }
+
+
+class ViewCalculatorParams(_Bag):
+    _fields = {
+        "raycast_subsampling_factor": 4,
+        "workspace_bounds_type": "kUnbounded",  # kUnbounded | kHeightBounds | kBoundingBox
+        "workspace_bounds_min_corner_x_m": 0.0,
+        "workspace_bounds_min_corner_y_m": 0.0,
+        "workspace_bounds_min_height_m": 0.0,
+        "workspace_bounds_max_corner_x_m": 0.0,
+        "workspace_bounds_max_corner_y_m": 0.0,
+        "workspace_bounds_max_height_m": 0.0,
+    }
+
+
+class BlockMemoryPoolParams(_Bag):
+    _fields = {
+        "expansion_factor": 1.5,
+        "num_preallocated_blocks": 0,
+    }
+
+
+class MeshIntegratorParams(_Bag):
+    _fields = {
+        "mesh_integrator_min_weight": 1e-4,
+        "mesh_integrator_weld_vertices": True,  # vertices are always welded per block
+    }
+
+
+_WS_TYPES = {"kUnbounded": 0, "kHeightBounds": 1, "kBoundingBox": 2}
+_WEIGHT_MODES = {"kConstantWeight": 0, "kInverseSquareWeight": 1}
+
+
+class MapperParams:
+    def __init__(self):
+        self._projective = ProjectiveIntegratorParams()
+        self._decay = TsdfDecayIntegratorParams()
+        self._view = ViewCalculatorParams()
+        self._pool = BlockMemoryPoolParams()
+        self._mesh = MeshIntegratorParams()
+
+    def set_projective_integrator_params(self, p: ProjectiveIntegratorParams) -> None:
+        self._projective = p
+
+    def set_tsdf_decay_integrator_params(self, p: TsdfDecayIntegratorParams) -> None:
+        self._decay = p
+
+    def set_view_calculator_params(self, p: ViewCalculatorParams) -> None:
+        self._view = p
+
+    def set_block_memory_pool_params(self, p: BlockMemoryPoolParams) -> None:
+        self._pool = p
+
+    def set_mesh_integrator_params(self, p: MeshIntegratorParams) -> None:
+        self._mesh = p
+
+    def get_projective_integrator_params(self) -> ProjectiveIntegratorParams:
+        return self._projective
+
+    def get_tsdf_decay_integrator_params(self) -> TsdfDecayIntegratorParams:
+        return self._decay
+
+    def get_view_calculator_params(self) -> ViewCalculatorParams:
+        return self._view
+
+    def get_block_memory_pool_params(self) -> BlockMemoryPoolParams:
+        return self._pool
+
+    def get_mesh_integrator_params(self) -> MeshIntegratorParams:
+        return self._mesh
+
+    def to_c(self, voxel_size_m: float, feature_channels: int) -> "_lib.MmfParams":
+        """Flatten into the C ABI's ``mmf_params``."""
+        p = _lib.default_params()
+        pi, de, vc, po, me = self._projective, self._decay, self._view, self._pool, self._mesh
+        p.voxel_size_m = float(voxel_size_m)
+        p.max_integration_distance_m = float(pi.projective_integrator_max_integration_distance_m)
+        p.truncation_distance_vox = float(pi.projective_integrator_truncation_distance_vox)
+        p.max_weight = float(pi.projective_integrator_max_weight)
+        wm = pi.projective_integrator_weighting_mode
+        wm = getattr(wm, "name", wm)
+        if wm not in _WEIGHT_MODES:
+            raise ValueError(f"unsupported projective_integrator_weighting_mode: {wm}")
+        p.weighting_mode = _WEIGHT_MODES[wm]
+        p.lin_interp_max_diff_vox = float(pi.projective_tsdf_integrator_linear_interpolation_max_allowable_difference_vox)
+        p.appearance_measurement_weight = float(pi.projective_appearance_integrator_measurement_weight)
+        p.appearance_max_weight = float(pi.projective_appearance_integrator_max_weight)
+        p.st_subsampling = int(pi.projective_appearance_integrator_sphere_tracing_ray_subsampling_factor)
+        p.raycast_subsampling = int(vc.raycast_subsampling_factor)
+        ws = getattr(vc.workspace_bounds_type, "name", vc.workspace_bounds_type)
+        if ws not in _WS_TYPES:
+            raise ValueError(f"unsupported workspace_bounds_type: {ws}")
+        p.workspace_bounds_type = _WS_TYPES[ws]
+        p.ws_min[0] = float(vc.workspace_bounds_min_corner_x_m)
+        p.ws_min[1] = float(vc.workspace_bounds_min_corner_y_m)
+        p.ws_min[2] = float(vc.workspace_bounds_min_height_m)
+        p.ws_max[0] = float(vc.workspace_bounds_max_corner_x_m)
+        p.ws_max[1] = float(vc.workspace_bounds_max_corner_y_m)
+        p.ws_max[2] = float(vc.workspace_bounds_max_height_m)
+        p.tsdf_decay_factor = float(de.tsdf_decay_factor)
+        p.decayed_weight_threshold = float(de.tsdf_decayed_weight_threshold)
+        p.deallocate_decayed_blocks = 1 if de.decay_integrator_deallocate_decayed_blocks else 0
+        p.mesh_min_weight = float(me.mesh_integrator_min_weight)
+        p.feature_channels = int(feature_channels)
+        p.num_preallocated_blocks = int(po.num_preallocated_blocks)
+        p.expansion_factor = float(po.expansion_factor)
+        return p
