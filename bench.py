@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RGB-D + 64-channel feature frames/s fused at 1 cm voxels on MI355X.
+
+Workload = BASELINE.json configs[2] ("TSDF + 64-ch DINO feature-layer fusion, 640x480 stream, one
+MI355X"), the configuration the metric is quoted on.  One step = the hot path over one synthetic frame,
+exactly the call sequence of the reference's policy loop (closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83):
+    mapper.decay(); integrate_frame(depth, rgb, features)   ->  mask algebra, add_depth_frame,
+    add_color_frame, add_feature_frame   (mapping/helpers/nvblox_mapping_helpers.py:162-273)
+All inputs (depth, rgb, f16 HWC feature image, pose, K) are resident in HBM before the timed region.
+
+Per-frame fusion does not shard: with --gpus N every rank runs an independent
+replica (its own map, its own copy of the stream), no data-path collective; value = frames of all ranks /
+max-over-ranks time ("weak" scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_feature_integrate), timed with HIP
+events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle ("port") timed on
+the host cores on a bounded sample of the same frames (reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nvblox_mindmap_amd import synthetic as S  # noqa: E402
+from nvblox_mindmap_amd.image_processing.feature_resize import upsample_features  # noqa: E402
+from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper, integrate_frame  # noqa: E402
+from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg  # noqa: E402
+
+HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3e12 achievable
+
+
+def lowres_features(index: int, channels: int, lowres: int = 16) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(1000003 * (index + 1)))
+    return rng.standard_normal((channels, lowres, lowres), dtype=np.float32)
+
+
+def build_stream(cfg: S.StreamConfig, n_frames: int, channels: int, device):
+    """Pre-generate the frames on the device: depth f32, rgb u8, features f16 HWC (via the HIP upsample
+    kernel, the path's own K11 replacement), dynamic mask, pose, K."""
+    frames = []
+    stride = max(cfg.num_poses // n_frames, 1)
+    for k in range(n_frames):
+        idx = (k * stride) % cfg.num_poses
+        T = S.camera_pose(cfg, idx)
+        depth = S.render_depth(cfg, T)
+        rgb = S.render_rgb(cfg, idx)
+        low = torch.from_numpy(lowres_features(idx, channels)).to(device)
+        feat = upsample_features(low, (cfg.height, cfg.width), channels)
+        frames.append({
+            "index": idx,
+            "depth": torch.from_numpy(depth).to(device),
+            "rgb": torch.from_numpy(rgb).to(device),
+            "features": feat,
+            "dynamic_mask": torch.zeros((cfg.height, cfg.width), dtype=torch.bool, device=device),
+            "T_W_C": torch.from_numpy(T),
+            "K": torch.from_numpy(cfg.intrinsics()),
+        })
+    torch.cuda.synchronize(device)
+    return frames
+
+
+def step(mapper, mcfg, fr):
+    mapper.decay()
+    static_mask = ~fr["dynamic_mask"]
+    integrate_frame(mapper=mapper, nvblox_mapping_config=mcfg, depth_frame=fr["depth"], feature_frame=fr["features"],
+                    intrinsics=fr["K"], camera_pose=fr["T_W_C"], rgb=fr["rgb"], input_mask=static_mask,
+                    input_mask_erosion_iterations=mcfg.static_mask_erosion_iterations,
+                    valid_depth_mask_erosion_iterations=mcfg.valid_depth_mask_erosion_iterations,
+                    mapper_id=MAPPER_TO_ID.STATIC)
+
+
+def cpu_baseline(cfg, mcfg, frames, channels, n_sample):
+    """Same steps on the CPU oracle (test infrastructure used here only as the reported baseline)."""
+    from oracle import oracle as O
+
+    O.build()
+    p = O.default_params(
+        voxel_size=mcfg.voxel_size_m, max_integration_distance_m=mcfg.projective_integrator_max_integration_distance_m,
+        raycast_subsampling=1, workspace_bounds_type=2, ws_min=mcfg.aabb_min_m.tolist(), ws_max=mcfg.aabb_max_m.tolist(),
+        tsdf_decay_factor=mcfg.tsdf_decay_factor,
+        appearance_measurement_weight=mcfg.projective_appearance_integrator_measurement_weight, feature_channels=channels)
+    orc = O.OracleMapper(p)
+    host = []
+    from nvblox_mindmap_amd.image_processing.image_mask_operations import depth_mask, feature_mask
+    for fr in frames[:n_sample]:
+        sm = ~fr["dynamic_mask"]
+        dm = depth_mask(sm, fr["depth"], mcfg.min_integration_distance_m)
+        fm = feature_mask(sm, fr["depth"], mcfg.min_integration_distance_m, mcfg.static_mask_erosion_iterations,
+                          mcfg.valid_depth_mask_erosion_iterations, mcfg.feature_mask_border_percent, fr["features"].shape[:2])
+        host.append((fr["depth"].cpu().numpy(), fr["rgb"].cpu().numpy(), fr["features"].cpu().numpy(), dm.cpu().numpy(),
+                     fm.cpu().numpy(), fr["T_W_C"].numpy(), fr["K"].numpy()))
+    t0 = time.perf_counter()
+    for depth, rgb, feat, dm, fm, T, K in host:
+        orc.decay()
+        orc.add_depth_frame(depth, T, K, dm)
+        orc.add_color_frame(rgb, T, K, dm)
+        orc.add_feature_frame(feat, T, K, fm)
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(host) / dt,
+        "unit": "frames/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"first {len(host)} frames of the same stream, CPU oracle (C, OpenMP on the per-block loops; "
+                  f"raycast single-threaded), masks precomputed",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=0, help="distinct pre-generated frames (default min(steps, 200))")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the fusion path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL via backend "nccl": only barrier + max-reduce of the timing
+
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    cfg = S.StreamConfig()
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    n_frames = args.frames or min(max(args.steps, 1), 200)
+    frames = build_stream(cfg, n_frames, args.channels, device)
+    mapper = get_nvblox_mapper(mcfg, feature_channels=args.channels)
+
+    for i in range(args.warmup):
+        step(mapper, mcfg, frames[i % n_frames])
+    torch.cuda.synchronize(device)
+    mapper.reset_stats(MAPPER_TO_ID.STATIC)
+    mapper.profile_reset()
+    if not args.no_profile:
+        mapper.profile_enable(True, kernels=["feature"])  # only the dominant kernel is bracketed in the timed region
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(mapper, mcfg, frames[(args.warmup + i) % n_frames])
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    mapper.profile_enable(False)
+    prof = mapper.profile()
+    stats = mapper.stats(MAPPER_TO_ID.STATIC)
+    # untimed pass with every kernel class bracketed: per-kernel breakdown for the report
+    breakdown = {}
+    if not args.no_profile:
+        mapper.profile_reset()
+        mapper.profile_enable(True)
+        for i in range(min(args.steps, 50)):
+            step(mapper, mcfg, frames[(args.warmup + args.steps + i) % n_frames])
+        torch.cuda.synchronize(device)
+        mapper.profile_enable(False)
+        breakdown = {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in mapper.profile().items()}
+
+    if rank == 0:
+        C = args.channels
+        n_feat_frames = max(stats["feature_frames"], 1)
+        feat_blocks_per_frame = stats["feature_blocks_updated"] / n_feat_frames
+        tsdf_blocks_per_frame = stats["tsdf_blocks_updated"] / max(stats["depth_frames"], 1)
+        # algorithmic bytes of one k_feature_integrate launch:
+        #   feature image f16 + mask u8, each pixel once; feature voxel (C x f16 + f32 weight) read + written per block
+        bytes_per_launch = cfg.height * cfg.width * (2 * C + 1) + feat_blocks_per_frame * 512 * 2 * (2 * C + 4)
+        feat_ms, feat_n = prof["feature"]
+        roofline = None
+        if feat_n > 0 and feat_ms > 0:
+            avg_s = feat_ms / feat_n * 1e-3
+            achieved = bytes_per_launch / avg_s
+            roofline = {
+                "bound": "hbm",
+                "kernel": "k_feature_integrate",
+                "achieved": achieved / 1e9,
+                "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_BYTES_PER_S,
+                "traffic": None,
+                "avg_launch_us": avg_s * 1e6,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "feature_blocks_per_launch": feat_blocks_per_frame,
+            }
+        frame_bytes = (cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + bytes_per_launch
+                       + cfg.height * cfg.width * 3 + stats["color_blocks_updated"] / max(stats["color_frames"], 1) * 512 * 16)
+        cpu = None
+        if args.cpu_sample > 0:
+            cpu = cpu_baseline(cfg, mcfg, frames, C, min(args.cpu_sample, n_frames))
+        fps = world * args.steps / elapsed
+        out = {
+            "metric": "RGB-D+feature frames/s fused @1 cm voxels",
+            "value": fps,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: decay + depth(TSDF) + colour + 64-ch f16 feature fusion, 640x480 stream, "
+                            "1 cm voxels, DRILL_IN_BOX workspace; replicas only for n_gpus>1",
+                "image": [cfg.height, cfg.width],
+                "feature_channels": C,
+                "voxel_size_m": mcfg.voxel_size_m,
+                "distinct_frames": n_frames,
+                "tsdf_blocks_per_frame": tsdf_blocks_per_frame,
+                "feature_blocks_per_frame": feat_blocks_per_frame,
+                "algorithmic_bytes_per_frame": frame_bytes,
+                "whole_frame_GBps": frame_bytes * fps / world / 1e9,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernel_us_per_launch": breakdown,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

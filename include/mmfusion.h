@@ -192,7 +192,8 @@ int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
 #define MMF_K_DECAY 7
 #define MMF_K_MESH 8
 #define MMF_NUM_KERNEL_IDS 9
-int mmf_profile_enable(mmf_handle h, int enable);
+/* kernel_mask: bit k set = time kernel class k (0 = off, (1<<MMF_NUM_KERNEL_IDS)-1 = all). */
+int mmf_profile_enable(mmf_handle h, int kernel_mask);
 /* Sum of elapsed ms and number of timed launches of kernel class `kernel_id` (synchronises). */
 int mmf_profile_get(mmf_handle h, int kernel_id, double* total_ms, int64_t* launches);
 int mmf_profile_reset(mmf_handle h);

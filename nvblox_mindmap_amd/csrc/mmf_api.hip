@@ -82,7 +82,7 @@ struct mmf_mapper_s {
   int device = 0;
   std::vector<Mapper*> mappers;
   int* pinned = nullptr;  // host pinned scratch (16 ints)
-  bool prof = false;
+  unsigned prof = 0;  // bitmask of kernel ids to time
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   double prof_ms[MMF_NUM_KERNEL_IDS] = {0};
@@ -96,7 +96,7 @@ struct ProfScope {
   hipStream_t s;
   ProfRec r{};
   bool on;
-  ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(h_->prof) {
+  ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(((h_->prof >> id) & 1u) != 0) {
     if (!on) return;
     r.id = id;
     r.a = take();
@@ -922,7 +922,7 @@ int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream) {
 
 int mmf_profile_enable(mmf_handle h, int enable) {
   if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
-  h->prof = enable != 0;
+  h->prof = (unsigned)enable;
   return MMF_OK;
 }
 

@@ -1,0 +1,52 @@
+"""Last step between the surface mesh and the model: sample / pad to N vertices
+(mirror of mindmap/data_loading/vertex_sampling.py:29-170; same RNG draws, so the same
+``torch.manual_seed`` gives the same selection as the reference)."""
+from enum import Enum
+from typing import Optional, Tuple
+
+import torch
+
+
+class VertexSamplingMethod(Enum):
+    RANDOM_WITHOUT_REPLACEMENT = "random_without_replacement"
+    RANDOM_WITH_REPLACEMENT = "random_with_replacement"
+    LOWEST = "lowest"
+    NONE = "none"
+
+
+def sample_to_n_vertices(vertices: torch.Tensor, features: torch.Tensor, desired_num_vertices: int,
+                         method: VertexSamplingMethod, seed: Optional[int] = None
+                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(V,3), (V,C) -> (N,3), (N,C), (N,) valid mask.  V == N or method NONE: inputs are returned unchanged."""
+    assert vertices.dim() == 2 and features.dim() == 2
+    assert vertices.shape[0] == features.shape[0]
+    n = features.shape[0]
+    dev = vertices.device
+    if method == VertexSamplingMethod.NONE or n == desired_num_vertices:
+        return vertices, features, torch.ones(n, device=dev, dtype=torch.bool)
+    if n > desired_num_vertices:
+        valid_mask = torch.ones(desired_num_vertices, device=dev, dtype=torch.bool)
+        if method == VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT:
+            if seed is not None:
+                torch.manual_seed(seed)
+            # CPU default generator, exactly like the reference (vertex_sampling.py:143-145)
+            sel = torch.randperm(n)[:desired_num_vertices].to(dev)
+        elif method == VertexSamplingMethod.RANDOM_WITH_REPLACEMENT:
+            if seed is not None:
+                torch.manual_seed(seed)
+            sel = torch.randint(0, n, (desired_num_vertices,)).to(dev)
+        elif method == VertexSamplingMethod.LOWEST:
+            # the reference sorts by -z (np.argsort(-vertices[:, 2]), vertex_sampling.py:122): i.e. it keeps the
+            # HIGHEST z despite the name; a stable sort reproduces numpy's tie order
+            sel = torch.sort(-vertices[:, 2], stable=True).indices[:desired_num_vertices]
+        else:
+            raise ValueError(f"Vertex sampling method {method} is not yet implemented.")
+        vertices, features = vertices[sel, :], features[sel, :]
+    else:
+        pad = desired_num_vertices - n
+        features = torch.cat([features, torch.zeros((pad, features.shape[1]), device=features.device)], dim=0)
+        vertices = torch.cat([vertices, torch.zeros((pad, vertices.shape[1]), device=dev)], dim=0)
+        valid_mask = torch.ones(desired_num_vertices, device=dev, dtype=torch.bool)
+        valid_mask[n:] = False
+    assert vertices.shape[0] == desired_num_vertices and features.shape[0] == desired_num_vertices
+    return vertices, features, valid_mask

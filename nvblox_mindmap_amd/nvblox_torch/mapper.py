@@ -370,8 +370,13 @@ class Mapper:
     def reset_stats(self, mapper_id: int = 0) -> None:
         _lib.check(_lib.lib().mmf_reset_stats(self._h, mapper_id, self._stream()), "mmf_reset_stats")
 
-    def profile_enable(self, on: bool = True) -> None:
-        _lib.check(_lib.lib().mmf_profile_enable(self._h, 1 if on else 0), "mmf_profile_enable")
+    def profile_enable(self, on: bool = True, kernels=None) -> None:
+        """Time kernel classes with HIP events on the launch stream (`kernels`: names of _lib.KERNEL_IDS, default all)."""
+        mask = 0
+        if on:
+            for k in (kernels if kernels is not None else _lib.KERNEL_IDS):
+                mask |= 1 << _lib.KERNEL_IDS[k]
+        _lib.check(_lib.lib().mmf_profile_enable(self._h, mask), "mmf_profile_enable")
 
     def profile_reset(self) -> None:
         _lib.check(_lib.lib().mmf_profile_reset(self._h), "mmf_profile_reset")
