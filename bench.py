@@ -137,7 +137,7 @@ def main():
 
         dist.init_process_group(backend="nccl", init_method="env://")
 
-    cfg = S.StreamConfig()
+    cfg = S.StreamConfig(hole_mode="patches")
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     n_frames = args.frames or min(max(args.steps, 1), 200)
     frames = build_stream(cfg, n_frames, args.channels, device)

@@ -153,6 +153,11 @@ int mmf_erode_mask(const uint8_t* mask_dev, uint8_t* out_dev, uint8_t* tmp_dev, 
  * out[Hf,Wf] = border(border_percent) & nearest_upsample( erode(input_mask,k_in) & erode(depth>min_d,k_depth) ). */
 int mmf_feature_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H, int W, float min_depth_m, int k_in,
                      int k_depth, int border_percent, int Hf, int Wf, uint8_t* out_dev, uint8_t* tmp_dev, void* stream);
+/* Both masks of integrate_frame in one call (two kernels): depth_mask_out [H,W] (may be NULL) = input_mask & (depth > min_d),
+ * feature_mask_out [Hf,Wf] as mmf_feature_mask.  tmp: H*W bytes, 8-byte aligned. */
+int mmf_frame_masks(const uint8_t* input_mask_dev, const float* depth_dev, int H, int W, float min_depth_m, int k_in,
+                    int k_depth, int border_percent, int Hf, int Wf, uint8_t* depth_mask_out_dev, uint8_t* feature_mask_out_dev,
+                    uint8_t* tmp_dev, void* stream);
 /* depth_mask = input_mask & (depth > min_d)  (nvblox_mapping_helpers.py:201-204) -> u8 [H,W]. */
 int mmf_depth_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H, int W, float min_depth_m,
                    uint8_t* out_dev, void* stream);

@@ -69,6 +69,7 @@ struct Mapper {
   // last view grid (diagnostics)
   ViewGrid last_vg{};
   int app_cap = 0;
+  bool touched = false;  // a depth frame was integrated since creation / clear
 };
 
 struct ProfRec {
@@ -205,16 +206,15 @@ int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
   L.d.cap = cap;
   unsigned tcap = next_pow2((unsigned)(2 * cap < 1024 ? 1024 : 2 * cap));
   L.d.hmask = tcap - 1;
-  HIP_TRY(hipMalloc(&L.d.hkeys, sizeof(u64) * tcap));
-  HIP_TRY(hipMalloc(&L.d.hvals, sizeof(int) * tcap));
+  HIP_TRY(hipMalloc(&L.d.htab, sizeof(HEntry) * tcap));
   HIP_TRY(hipMalloc(&L.d.slot_key, sizeof(u64) * cap));
   HIP_TRY(hipMalloc(&L.d.live, sizeof(int) * cap));
   HIP_TRY(hipMalloc(&L.d.free_stack, sizeof(int) * cap));
-  HIP_TRY(hipMalloc(&L.d.ctr, sizeof(int) * 4));
+  HIP_TRY(hipMalloc(&L.d.ctr, sizeof(int) * 8));
   HIP_TRY(hipMalloc(&L.d.pool, block_bytes * (size_t)cap));
   if (has_w) HIP_TRY(hipMalloc(&L.d.poolw, sizeof(float) * kVPB * (size_t)cap));
-  HIP_TRY(hipMemset(L.d.hkeys, 0xff, sizeof(u64) * tcap));
-  HIP_TRY(hipMemset(L.d.ctr, 0, sizeof(int) * 4));
+  HIP_TRY(hipMemset(L.d.htab, 0xff, sizeof(HEntry) * tcap));
+  HIP_TRY(hipMemset(L.d.ctr, 0, sizeof(int) * 8));
   HIP_TRY(hipMemset(L.d.slot_key, 0xff, sizeof(u64) * cap));
   L.allocated = true;
   return MMF_OK;
@@ -222,14 +222,14 @@ int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
 
 void free_layer(Layer& L) {
   if (!L.allocated) return;
-  (void)hipFree(L.d.hkeys);
-  (void)hipFree(L.d.hvals);
+  (void)hipFree(L.d.htab);
   (void)hipFree(L.d.slot_key);
   (void)hipFree(L.d.live);
   (void)hipFree(L.d.free_stack);
   (void)hipFree(L.d.ctr);
   (void)hipFree(L.d.pool);
   if (L.d.poolw) (void)hipFree(L.d.poolw);
+  if (L.d.dense) (void)hipFree(L.d.dense);
   L = Layer{};
 }
 
@@ -312,6 +312,23 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   if (rc != MMF_OK) {
     delete m;
     return rc;
+  }
+  if (P.workspace_bounds_type == 2 && cap < 65535) {
+    // dense block table of the bounded workspace (mirrors the hash; see LayerDev::dense)
+    LayerDev& d = m->tsdf.d;
+    long long nc = 1;
+    for (int a = 0; a < 3; ++a) {
+      d.d_lo[a] = m->mc.ws_lo[a];
+      nc *= (long long)(m->mc.ws_hi[a] - m->mc.ws_lo[a] + 1);
+    }
+    d.d_ny = m->mc.ws_hi[1] - m->mc.ws_lo[1] + 1;
+    d.d_nz = m->mc.ws_hi[2] - m->mc.ws_lo[2] + 1;
+    if (nc <= 32768) {
+      d.d_ncells = (int)nc;
+      size_t bytes = ((size_t)nc * 2 + 15) / 16 * 16;
+      HIP_TRY(hipMalloc(&d.dense, bytes));
+      HIP_TRY(hipMemset(d.dense, 0, bytes));
+    }
   }
   HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
   HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
@@ -586,6 +603,7 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
   const int ncells = vg.nx * vg.ny * vg.nz;
   m->frames[0]++;
   m->tsdf_epoch++;
+  m->touched = true;
   if (ncells == 0) {
     HIP_TRY(hipMemsetAsync(m->sc.cand_count, 0, sizeof(int), s));
     return MMF_OK;
@@ -668,6 +686,7 @@ int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
   for (int i = 0; i < (int)h->mappers.size(); ++i) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
+    if (!m->touched) continue;  // nothing was ever allocated in this mapper
     ProfScope ps(h, MMF_K_DECAY, s);
     launch_decay(m->tsdf.d, m->mc, m->kill, m->any_kill, s);
     m->tsdf_epoch++;
@@ -689,6 +708,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     if (m->feat.allocated) launch_layer_reset(m->feat.d, s);
     m->tsdf_epoch++;
     m->mesh_epoch = -1;
+    m->touched = false;
   }
   return check_launch();
 }
@@ -830,6 +850,16 @@ int mmf_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W
   if (!input_mask || !depth || !out || !tmp || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || k_in < 0 || k_depth < 0)
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_feature_mask");
   launch_feature_mask(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, out, tmp, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_frame_masks(const uint8_t* input_mask, const float* depth, int H, int W, float min_depth_m, int k_in, int k_depth,
+                    int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
+                    void* stream) {
+  if (!input_mask || !depth || !feature_mask_out || !tmp || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || k_in < 0 || k_depth < 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_frame_masks");
+  launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out, feature_mask_out,
+                     tmp, (hipStream_t)stream);
   return check_launch();
 }
 

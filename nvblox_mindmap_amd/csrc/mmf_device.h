@@ -15,6 +15,14 @@ constexpr int kVPB = 512;  // voxels per 8x8x8 block
 constexpr int kWave = 64;
 typedef unsigned long long u64;
 constexpr u64 kEmptyKey = ~0ull;
+constexpr u64 kTombKey = ~0ull - 1ull;  // deleted entry: probes continue past it, the rebuild drops it
+
+// One 16-byte hash entry so that a probe is a single dwordx4 load.
+struct __attribute__((aligned(16))) HEntry {
+  u64 key;
+  int val;
+  int pad;
+};
 constexpr int kKeyOff = 1 << 20;  // 21 bits per axis: block indices in [-2^20, 2^20)
 
 struct Rigid {
@@ -46,17 +54,28 @@ struct MapConsts {
 // Device view of one block layer: open-addressing hash (packed 64-bit keys -> pool slot),
 // pool of 8x8x8 blocks, live list (allocation order) and free-slot stack.
 struct LayerDev {
-  u64* hkeys;      // [hmask+1], kEmptyKey when free
-  int* hvals;      // [hmask+1] pool slot of the key
+  HEntry* htab;    // [hmask+1] {key, pool slot}; key == kEmptyKey when free
   unsigned hmask;  // table size - 1 (power of two)
   u64* slot_key;   // [cap] key stored in each pool slot
   int* live;       // [cap] pool slots in allocation order
   int* free_stack; // [cap]
-  int* ctr;        // [0] n_live  [1] n_free  [2] bump (first never-used slot)  [3] error flags
+  int* ctr;        // [0] n_live  [1] n_free  [2] bump (first never-used slot)  [3] error flags  [4] tombstones
   char* pool;      // payload A: cap * block_bytes
   float* poolw;    // payload B: cap * 512 floats (feature layer weights) or nullptr
   int cap;
+  // Optional dense block table of a bounded workspace (TSDF layer only): dense[cell] = slot + 1, 0 = none.
+  // It mirrors the hash (maintained by the same insert / erase sites) and exists so that latency-bound
+  // kernels (sphere tracing) can stage the whole index in LDS.
+  unsigned short* dense;
+  int d_lo[3];
+  int d_ny, d_nz, d_ncells;
 };
+
+__device__ inline int dense_cell(const LayerDev& L, int x, int y, int z) {
+  return ((x - L.d_lo[0]) * L.d_ny + (y - L.d_lo[1])) * L.d_nz + (z - L.d_lo[2]);
+}
+__device__ inline void dense_set(const LayerDev& L, unsigned long long key, int slot_plus_1);
+
 
 // Compaction scratch shared by the three "flag -> ordered candidate list" passes.
 struct Scratch {
@@ -89,6 +108,13 @@ __host__ __device__ inline void unpack_key(u64 k, int& x, int& y, int& z) {
   z = (int)(k & 0x1fffffu) - kKeyOff;
 }
 
+__device__ inline void dense_set(const LayerDev& L, unsigned long long key, int slot_plus_1) {
+  if (!L.dense) return;
+  int x, y, z;
+  unpack_key(key, x, y, z);
+  L.dense[dense_cell(L, x, y, z)] = (unsigned short)slot_plus_1;
+}
+
 __device__ inline unsigned hash_key(u64 k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdull;
@@ -96,26 +122,51 @@ __device__ inline unsigned hash_key(u64 k) {
   return (unsigned)k;
 }
 
-__device__ inline int hash_find(const LayerDev& L, u64 key) {
-  unsigned h = hash_key(key) & L.hmask;
+__device__ inline uint4 hash_load(const LayerDev& L, unsigned h) {
+  return *reinterpret_cast<const uint4*>(&L.htab[h]);
+}
+__device__ inline u64 entry_key(const uint4& e) { return ((u64)e.y << 32) | (u64)e.x; }
+
+// Continue a probe sequence whose first entry `e` (at position h) has already been loaded.
+__device__ inline int hash_resolve(const LayerDev& L, u64 key, unsigned h, uint4 e) {
   for (unsigned probe = 0; probe <= L.hmask; ++probe) {
-    u64 k = L.hkeys[h];
-    if (k == key) return L.hvals[h];
+    const u64 k = entry_key(e);
+    if (k == key) return (int)e.z;
     if (k == kEmptyKey) return -1;
     h = (h + 1) & L.hmask;
+    e = hash_load(L, h);
   }
   return -1;
+}
+
+__device__ inline int hash_find(const LayerDev& L, u64 key) {
+  const unsigned h = hash_key(key) & L.hmask;
+  return hash_resolve(L, key, h, hash_load(L, h));
 }
 
 // Insert a key known to be absent. Distinct keys may race for a cell: CAS on the 64-bit key.
 __device__ inline void hash_insert(const LayerDev& L, u64 key, int slot) {
   unsigned h = hash_key(key) & L.hmask;
   for (unsigned probe = 0; probe <= L.hmask; ++probe) {
-    u64 prev = atomicCAS(&L.hkeys[h], kEmptyKey, key);
+    u64 prev = atomicCAS(&L.htab[h].key, kEmptyKey, key);
     if (prev == kEmptyKey) {
-      L.hvals[h] = slot;
+      L.htab[h].val = slot;
       return;
     }
+    h = (h + 1) & L.hmask;
+  }
+}
+
+// Mark the entry of `key` deleted (no-op if absent).
+__device__ inline void hash_erase(const LayerDev& L, u64 key) {
+  unsigned h = hash_key(key) & L.hmask;
+  for (unsigned probe = 0; probe <= L.hmask; ++probe) {
+    const u64 k = L.htab[h].key;
+    if (k == key) {
+      L.htab[h].key = kTombKey;
+      return;
+    }
+    if (k == kEmptyKey) return;
     h = (h + 1) & L.hmask;
   }
 }

@@ -40,14 +40,30 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sphere tracing: one thread per (subsampled) ray; each step is a hash lookup + one voxel read.
-// The last block's slot is cached because consecutive steps usually stay inside one 8 cm block.
+// Sphere tracing: one thread per (subsampled) ray, one wave per 8x8 ray tile.  The kernel is a chain of
+// dependent lookups per ray (latency-bound, ~19k rays), so the work per step is minimised:
+//   * bounded workspace (DENSE): the block table of the workspace (slot+1 per cell, a few KB) is staged
+//     in LDS, so "which block is here" is an LDS read instead of a hash probe in global memory;
+//   * outside the workspace bounds no block can exist: the lookup is skipped (arithmetic-only step), and
+//     once the ray has left the (one-block padded) bounds for good the march stops: every remaining
+//     lookup would miss, so the result (failure) is already known.
+// The sequence of t values is unchanged, so the image is bit-identical to the plain march.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
-                                                     int Ws, int Hs) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Ws * Hs) return;
-  const int rs = idx / Ws, cs = idx % Ws;
+template <bool DENSE>
+__global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
+                                                    int Ws, int Hs, int tiles_x) {
+  extern __shared__ unsigned short s_tab[];
+  if (DENSE) {
+    const uint4* src = reinterpret_cast<const uint4*>(T.dense);
+    uint4* dst = reinterpret_cast<uint4*>(s_tab);
+    const int n16 = (T.d_ncells * 2 + 15) / 16;
+    for (int i = threadIdx.x; i < n16; i += 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int cs = (blockIdx.x % tiles_x) * 8 + (lane & 7), rs = (blockIdx.x / tiles_x) * 8 + (lane >> 3);
+  if (cs >= Ws || rs >= Hs) return;
+  const int idx = rs * Ws + cs;
   const float sf = (float)mc.st_sf;
   const float u = ((float)cs + 0.5f) * sf, v = ((float)rs + 0.5f) * sf;
   const float x = (u - cam.cx) / cam.fx, y = (v - cam.cy) / cam.fy;
@@ -56,6 +72,25 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
   float dL[3];
   rotate(T_L_C, dC, dL);
   const float o[3] = {T_L_C.t[0], T_L_C.t[1], T_L_C.t[2]};
+
+  // last ray parameter at which the ray can still be inside the workspace bounds padded by one block
+  float t_exit = 3.0e38f;
+  if (mc.ws_type != 0) {
+    float tmin = -3.0e38f, tmax = 3.0e38f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (mc.ws_type == 1 && a < 2) continue;
+      const float lo = (float)(mc.ws_lo[a] - 1) * mc.bs, hi = (float)(mc.ws_hi[a] + 2) * mc.bs;
+      if (fabsf(dL[a]) > 1e-9f) {
+        const float t1 = (lo - o[a]) / dL[a], t2 = (hi - o[a]) / dL[a];
+        tmin = fmaxf(tmin, fminf(t1, t2));
+        tmax = fminf(tmax, fmaxf(t1, t2));
+      } else if (o[a] < lo || o[a] > hi) {
+        tmax = -3.0e38f;
+      }
+    }
+    t_exit = (tmax >= tmin) ? tmax : -1.0f;
+  }
 
   bool last_pos = false, ok = false;
   float t = 0.0f;
@@ -67,7 +102,15 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
     const u64 key = voxel_at(mc, p, lin);
     if (key != ckey) {
       ckey = key;
-      cslot = hash_find(T, key);
+      int bx, by, bz;
+      unpack_key(key, bx, by, bz);
+      if (!in_workspace(mc, bx, by, bz)) {
+        cslot = -1;  // blocks are only ever allocated inside the workspace bounds
+      } else if (DENSE) {
+        cslot = (int)s_tab[dense_cell(T, bx, by, bz)] - 1;
+      } else {
+        cslot = hash_find(T, key);
+      }
     }
     bool valid = false;
     float D = 0.0f;
@@ -81,6 +124,7 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
     float step;
     if (!valid) {
       if (last_pos) break;
+      if (t > t_exit) break;  // left the workspace for good: every further sample is unobserved
       step = mc.trunc;
     } else if (D < mc.st_eps) {
       if (last_pos) {
@@ -302,9 +346,15 @@ void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam&
 
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
                          int Hs, hipStream_t s) {
-  int n = Ws * Hs;
+  const int tiles_x = (Ws + 7) / 8, tiles_y = (Hs + 7) / 8;
+  const int n = tiles_x * tiles_y;
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_sphere_trace, dim3((n + 255) / 256), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs);
+  if (tsdf.dense && tsdf.d_ncells <= 32768) {
+    const size_t lds = ((size_t)tsdf.d_ncells * 2 + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_sphere_trace<true>, dim3(n), dim3(64), lds, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, tiles_x);
+  } else {
+    hipLaunchKernelGGL(k_sphere_trace<false>, dim3(n), dim3(64), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, tiles_x);
+  }
 }
 
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,

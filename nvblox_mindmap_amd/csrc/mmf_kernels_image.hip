@@ -151,6 +151,94 @@ __global__ __launch_bounds__(256) void k_depth_mask(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bit-packed mask algebra (fast path of integrate_frame's masks, nvblox_mapping_helpers.py:201-253).
+// Row pass: one workgroup per image row; every wave ballots 64 pixels into a 64-bit word for each of
+// the two "bad pixel" predicates (input mask == 0, !(depth > min_d)), the words of the row are dilated
+// horizontally by k with shifts across word boundaries and stored as [H][nw] u64 bit-rows.  It can also
+// emit depth_mask = input_mask & (depth > min_d) on the way (the same bytes are already in registers).
+// Column pass: one workgroup per OUTPUT row; the first 2*nw threads OR the bit-rows of the 2k+1 source
+// rows, then all threads expand bits to bytes with the nearest-neighbour upsample and the border mask.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxMaskWords = 64;  // rows up to 4096 pixels
+
+__device__ inline u64 row_word(const u64* w, int j, int nw) { return (j >= 0 && j < nw) ? w[j] : 0ull; }
+
+__global__ __launch_bounds__(256) void k_mask_rowbits(const uint8_t* __restrict__ mask, const float* __restrict__ depth,
+                                                     float min_d, int H, int W, int nw, int k0, int k1,
+                                                     u64* __restrict__ bits_in, u64* __restrict__ bits_d,
+                                                     uint8_t* __restrict__ depth_mask_out) {
+  __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
+  const int y = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  for (int x0 = 0; x0 < nw * 64; x0 += 256) {
+    const int x = x0 + threadIdx.x;
+    bool bad_in = false, bad_d = false;
+    if (x < W) {
+      const size_t i = (size_t)y * W + x;
+      bad_in = mask ? mask[i] == 0 : false;
+      bad_d = depth ? !(depth[i] > min_d) : false;
+      if (depth_mask_out) depth_mask_out[i] = (!bad_in && !bad_d) ? 1 : 0;
+    }
+    const u64 b_in = __ballot(bad_in), b_d = __ballot(bad_d);
+    if (lane == 0 && (x >> 6) < nw) {
+      s_in[x >> 6] = b_in;
+      s_d[x >> 6] = b_d;
+    }
+  }
+  __syncthreads();
+  // horizontal dilation: bit x of the result = OR of bits [x-k, x+k]
+  for (int j = threadIdx.x; j < 2 * nw; j += 256) {
+    const bool second = j >= nw;
+    const int w = second ? j - nw : j;
+    const u64* src = second ? s_d : s_in;
+    const int k = second ? k1 : k0;
+    u64 r = src[w];
+    for (int s = 1; s <= k; ++s) {
+      const int q = s >> 6, sh = s & 63;  // shift by s = q words + sh bits
+      // bits coming from the left (lower x) and from the right (higher x)
+      u64 left = row_word(src, w - q, nw) << sh;
+      if (sh) left |= row_word(src, w - q - 1, nw) >> (64 - sh);
+      u64 right = row_word(src, w + q, nw) >> sh;
+      if (sh) right |= row_word(src, w + q + 1, nw) << (64 - sh);
+      r |= left | right;
+    }
+    (second ? bits_d : bits_in)[(size_t)y * nw + w] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mask_colemit(const u64* __restrict__ bits_in, const u64* __restrict__ bits_d, int H,
+                                                     int W, int nw, int k0, int k1, int Hf, int Wf, float sh, float sw,
+                                                     int bh, int bw, uint8_t* __restrict__ out) {
+  __shared__ u64 s_bad[kMaxMaskWords];
+  const int yf = blockIdx.x;
+  int ys = (int)floorf((float)yf * sh);
+  ys = ys > H - 1 ? H - 1 : ys;
+  for (int j = threadIdx.x; j < nw; j += 256) {
+    u64 r = 0;
+    {
+      const int lo = ys - k0 < 0 ? 0 : ys - k0, hi = ys + k0 > H - 1 ? H - 1 : ys + k0;
+      for (int yy = lo; yy <= hi; ++yy) r |= bits_in[(size_t)yy * nw + j];
+    }
+    {
+      const int lo = ys - k1 < 0 ? 0 : ys - k1, hi = ys + k1 > H - 1 ? H - 1 : ys + k1;
+      for (int yy = lo; yy <= hi; ++yy) r |= bits_d[(size_t)yy * nw + j];
+    }
+    s_bad[j] = r;
+  }
+  __syncthreads();
+  const bool row_ok = (bh <= 0 || bw <= 0) || (yf >= bh && yf < Hf - bh);
+  for (int xf = threadIdx.x; xf < Wf; xf += 256) {
+    uint8_t res = 0;
+    if (row_ok && ((bh <= 0 || bw <= 0) || (xf >= bw && xf < Wf - bw))) {
+      int xs = (int)floorf((float)xf * sw);
+      xs = xs > W - 1 ? W - 1 : xs;
+      res = ((s_bad[xs >> 6] >> (xs & 63)) & 1ull) ? 0 : 1;
+    }
+    out[(size_t)yf * Wf + xf] = res;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Feature-map upsample (feature_extraction.py:126-128,188-191,198-210 + nvblox_mapping_helpers.py:256):
 // bilinear align_corners=False of a channels-last low-res map [h,w,Cin] f32 to [Hf,Wf,Cpad] f16 with
 // channels >= Cin zero.  One thread = one output pixel x 8 channels (16-byte store); the low-res map
@@ -213,15 +301,35 @@ void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W,
 
 void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
                          int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, hipStream_t s) {
-  dim3 g((W + 255) / 256, H);
-  hipLaunchKernelGGL(k_rowpass, g, dim3(256), 0, s, input_mask, depth, min_d, H, W, k_in, k_depth, tmp);
+  launch_frame_masks(input_mask, depth, H, W, min_d, k_in, k_depth, border_percent, Hf, Wf, nullptr, out, tmp, s);
+}
+
+// depth_mask_out (optional) and the feature mask in two launches.  `tmp` holds H*W bytes.
+void launch_frame_masks(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
+                        int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
+                        hipStream_t s) {
   // int(mask_border_percent * 0.01 * height) in Python double arithmetic (image_mask_operations.py:62-63)
   const int bh = (int)((double)border_percent * 0.01 * (double)Hf);
   const int bw = (int)((double)border_percent * 0.01 * (double)Wf);
   const float sh = (float)H / (float)Hf, sw = (float)W / (float)Wf;
+  const int nw = (W + 63) / 64;
+  const bool packed = nw <= kMaxMaskWords && (size_t)2 * H * nw * sizeof(u64) <= (size_t)H * W && ((uintptr_t)tmp % 8 == 0);
+  if (packed) {
+    u64* bits_in = reinterpret_cast<u64*>(tmp);
+    u64* bits_d = bits_in + (size_t)H * nw;
+    hipLaunchKernelGGL(k_mask_rowbits, dim3(H), dim3(256), 0, s, input_mask, depth, min_d, H, W, nw, k_in, k_depth, bits_in, bits_d,
+                       depth_mask_out);
+    hipLaunchKernelGGL(k_mask_colemit, dim3(Hf), dim3(256), 0, s, (const u64*)bits_in, (const u64*)bits_d, H, W, nw, k_in, k_depth,
+                       Hf, Wf, sh, sw, bh, bw, feature_mask_out);
+    return;
+  }
+  // generic byte path (very narrow or very wide images)
+  if (depth_mask_out) launch_depth_mask(input_mask, depth, H, W, min_d, depth_mask_out, s);
+  dim3 g((W + 255) / 256, H);
+  hipLaunchKernelGGL(k_rowpass, g, dim3(256), 0, s, input_mask, depth, min_d, H, W, k_in, k_depth, tmp);
   dim3 gf((Wf + 255) / 256, Hf);
   hipLaunchKernelGGL(k_colpass_feature_mask, gf, dim3(256), 0, s, (const uint8_t*)tmp, H, W, k_in, k_depth, Hf, Wf, sh, sw, bh,
-                     bw, out);
+                     bw, feature_mask_out);
 }
 
 void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s) {

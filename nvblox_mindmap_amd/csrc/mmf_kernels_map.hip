@@ -69,9 +69,13 @@ __device__ inline void walk_step(Walk& w) {
 __global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rigid T_L_C, const float* __restrict__ depth,
                                                      const uint8_t* __restrict__ mask, int sub, int Wsub, int Hsub,
                                                      ViewGrid vg, uint8_t* __restrict__ flags) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Wsub * Hsub) return;
-  int r = (idx / Wsub) * sub, c = (idx % Wsub) * sub;
+  // one wave = one 8x8 tile of (subsampled) pixels: neighbouring rays traverse the same blocks, so the
+  // 64 flag stores of a step collapse onto a few addresses
+  const int tiles_x = (Wsub + 7) >> 3;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int cs = (tile % tiles_x) * 8 + (lane & 7), rs = (tile / tiles_x) * 8 + (lane >> 3);
+  if (cs >= Wsub || rs >= Hsub) return;
+  int r = rs * sub, c = cs * sub;
   size_t pix = (size_t)r * cam.W + c;
   float d = depth[pix];
   if (!(d > 0.0f)) return;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
       if (rnk < granted) {
         slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
         hash_insert(L, key, slot);
+        dense_set(L, key, slot + 1);
         L.slot_key[slot] = key;
         L.live[old_live + rnk] = slot;
       }
@@ -228,6 +233,103 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
     pos++;
   }
   *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // leave the flag array all-zero for the next frame
+}
+
+
+// Small cell counts (bounded workspaces: a few thousand cells): count + scan + emit fused into ONE launch
+// of one 1024-thread workgroup, 4096 cells per pass with a running carry.  Same candidate order, same
+// slot assignment as the three-kernel path.
+__global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scratch sc, int ncells, long long* stats,
+                                                     int stat_upd, int stat_new) {
+  __shared__ int lds[34];
+  __shared__ int carry[2];
+  __shared__ int ctx[4];
+  if (threadIdx.x == 0) {
+    carry[0] = 0;
+    carry[1] = 0;
+    ctx[0] = L.ctr[0];
+    ctx[1] = L.ctr[1];
+    ctx[2] = L.ctr[2];
+    ctx[3] = L.ctr[1] + (L.cap - L.ctr[2]);  // room
+  }
+  __syncthreads();
+  const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
+  for (int base = 0; base < ncells; base += 4096) {
+    const int cell0 = base + threadIdx.x * 4;
+    uint32_t f4 = 0;
+    if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
+    int slot4[4] = {0, 0, 0, 0};
+    u64 key4[4] = {0, 0, 0, 0};
+    int nf = 0, nn = 0;
+    if (f4) {
+      // the four first probes are independent 16-byte loads: issue them together, then resolve
+      unsigned h4[4] = {0, 0, 0, 0};
+      uint4 e4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e4[k] = make_uint4(0, 0, 0, 0);
+        if ((f4 >> (8 * k)) & 0xffu) {
+          key4[k] = cell_key(ks, cell0 + k);
+          h4[k] = hash_key(key4[k]) & L.hmask;
+          e4[k] = hash_load(L, h4[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((f4 >> (8 * k)) & 0xffu) {
+          slot4[k] = hash_resolve(L, key4[k], h4[k], e4[k]);
+          nf++;
+          nn += slot4[k] < 0;
+        }
+      }
+    }
+    int ea, eb, ta, tb;
+    block_excl_scan2<16>(nf, nn, lds, ea, eb, ta, tb);
+    if (f4) {
+      int pos = carry[0] + ea, rnk = carry[1] + eb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!((f4 >> (8 * k)) & 0xffu)) continue;
+        int slot = slot4[k];
+        const bool is_new = slot < 0;
+        if (is_new) {
+          if (rnk < room) {
+            slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
+            hash_insert(L, key4[k], slot);
+            dense_set(L, key4[k], slot + 1);
+            L.slot_key[slot] = key4[k];
+            L.live[old_live + rnk] = slot;
+          }
+          rnk++;
+        }
+        sc.cand_slot[pos] = slot;
+        sc.cand_key[pos] = key4[k];
+        sc.cand_new[pos] = is_new ? 1 : 0;
+        pos++;
+      }
+      *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry[0] += ta;
+      carry[1] += tb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int n_cand = carry[0], n_new = carry[1];
+    const int granted = n_new < room ? n_new : room;
+    if (granted < n_new) atomicOr(&L.ctr[3], 1);
+    const int from_free = granted < old_free ? granted : old_free;
+    L.ctr[0] = old_live + granted;
+    L.ctr[1] = old_free - from_free;
+    L.ctr[2] = old_bump + (granted - from_free);
+    *sc.cand_count = n_cand;
+    if (stats) {
+      if (stat_upd >= 0) stats[stat_upd] += n_cand;
+      if (stat_new >= 0) stats[stat_new] += granted;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -334,7 +436,7 @@ __global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t
   }
 }
 
-__global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __restrict__ kill, const int* any_kill) {
+__global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __restrict__ kill, int* any_kill) {
   if (!*any_kill) return;
   __shared__ int lds[34];
   __shared__ int carry[2];
@@ -344,6 +446,7 @@ __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __re
     carry[1] = L.ctr[1];   // free stack size
   }
   __syncthreads();
+  const int free0 = carry[1];
   for (int base = 0; base < n; base += 1024) {
     const int i = base + threadIdx.x;
     int slot = -1, k = 0;
@@ -360,6 +463,8 @@ __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __re
     if (keep) L.live[c0 + ea] = slot;
     if (dead) {
       L.free_stack[c1 + eb] = slot;
+      hash_erase(L, L.slot_key[slot]);  // tombstone; dropped at the next rebuild
+      dense_set(L, L.slot_key[slot], 0);
       L.slot_key[slot] = kEmptyKey;
     }
     __syncthreads();
@@ -369,15 +474,30 @@ __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __re
     }
     __syncthreads();
   }
+  const int n_live = carry[0];
+  const int n_tomb = L.ctr[4] + (carry[1] - free0);
+  // amortised rebuild: only when tombstones fill more than a quarter of the table
+  const bool rebuild = (unsigned)n_tomb * 4u > L.hmask + 1u;
+  __syncthreads();
+  if (rebuild) {
+    for (unsigned h = threadIdx.x; h <= L.hmask; h += 1024) L.htab[h].key = kEmptyKey;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_live; i += 1024) {
+      const int slot = L.live[i];
+      hash_insert(L, L.slot_key[slot], slot);
+    }
+  }
   if (threadIdx.x == 0) {
-    L.ctr[0] = carry[0];
+    L.ctr[0] = n_live;
     L.ctr[1] = carry[1];
+    L.ctr[4] = rebuild ? 0 : n_tomb;
+    *any_kill = 0;
   }
 }
 
 __global__ __launch_bounds__(256) void k_hash_clear_if(LayerDev L, const int* cond) {
   if (cond && !*cond) return;
-  for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h <= L.hmask; h += gridDim.x * blockDim.x) L.hkeys[h] = kEmptyKey;
+  for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h <= L.hmask; h += gridDim.x * blockDim.x) L.htab[h].key = kEmptyKey;
 }
 
 __global__ __launch_bounds__(256) void k_hash_insert_live_if(LayerDev L, const int* cond) {
@@ -390,7 +510,9 @@ __global__ __launch_bounds__(256) void k_hash_insert_live_if(LayerDev L, const i
 }
 
 __global__ void k_reset_layer(LayerDev L) {
-  if (threadIdx.x < 4 && blockIdx.x == 0) L.ctr[threadIdx.x] = 0;
+  if (threadIdx.x < 8 && blockIdx.x == 0) L.ctr[threadIdx.x] = 0;
+  if (L.dense)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < L.d_ncells; c += gridDim.x * blockDim.x) L.dense[c] = 0;
 }
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
@@ -485,14 +607,20 @@ __global__ __launch_bounds__(256) void k_query_feature(LayerDev L, MapConsts mc,
 void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, int sub,
                     const ViewGrid& vg, uint8_t* flags, hipStream_t s) {
   int Wsub = (cam.W + sub - 1) / sub, Hsub = (cam.H + sub - 1) / sub;
-  int n = Wsub * Hsub;
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_raycast_mark, dim3((n + 255) / 256), dim3(256), 0, s, mc, cam, T_L_C, depth, mask, sub, Wsub, Hsub, vg,
+  int ntiles = ((Wsub + 7) / 8) * ((Hsub + 7) / 8);
+  if (ntiles <= 0) return;
+  hipLaunchKernelGGL(k_raycast_mark, dim3((ntiles + 3) / 4), dim3(256), 0, s, mc, cam, T_L_C, depth, mask, sub, Wsub, Hsub, vg,
                      flags);
 }
 
+constexpr int kFusedAllocMaxCells = 16384;
+
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s) {
+  if (ncells <= kFusedAllocMaxCells) {
+    hipLaunchKernelGGL(k_alloc_fused, dim3(1), dim3(1024), 0, s, L, ks, sc, ncells, stats, stat_upd, stat_new);
+    return;
+  }
   int ntiles = (ncells + 1023) / 1024;
   if (ntiles <= 0) ntiles = 1;
   hipLaunchKernelGGL(k_count_tiles, dim3(ntiles), dim3(256), 0, s, L, ks, sc, ncells);
@@ -512,23 +640,16 @@ void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& ca
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, any_kill, 0);
+  // any_kill is zero on entry (initialised at creation, reset by k_live_compact)
   hipLaunchKernelGGL(k_decay, dim3(grid_for(L.cap, 4096)), dim3(256), 0, s, L, mc, kill, any_kill);
-  if (mc.dealloc_decayed) {
-    hipLaunchKernelGGL(k_live_compact, dim3(1), dim3(1024), 0, s, L, kill, any_kill);
-    int hb = (int)((L.hmask + 1 + 255) / 256);
-    if (hb > 1024) hb = 1024;
-    hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)any_kill);
-    hipLaunchKernelGGL(k_hash_insert_live_if, dim3(grid_for((L.cap + 255) / 256, 1024)), dim3(256), 0, s, L,
-                       (const int*)any_kill);
-  }
+  if (mc.dealloc_decayed) hipLaunchKernelGGL(k_live_compact, dim3(1), dim3(1024), 0, s, L, kill, any_kill);
 }
 
 void launch_layer_reset(const LayerDev& L, hipStream_t s) {
   int hb = (int)((L.hmask + 1 + 255) / 256);
   if (hb > 1024) hb = 1024;
   hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)nullptr);
-  hipLaunchKernelGGL(k_reset_layer, dim3(1), dim3(64), 0, s, L);
+  hipLaunchKernelGGL(k_reset_layer, dim3(L.dense ? 64 : 1), dim3(256), 0, s, L);
 }
 
 void launch_hash_rebuild(const LayerDev& L, hipStream_t s) {

@@ -49,6 +49,9 @@ void launch_backproject(const float* depth, const float* K, const float* T, int 
 void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int k, hipStream_t s);
 void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
                          int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, hipStream_t s);
+void launch_frame_masks(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
+                        int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
+                        hipStream_t s);
 void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s);
 void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s);
 

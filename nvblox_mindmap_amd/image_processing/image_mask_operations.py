@@ -14,7 +14,27 @@ from .. import _lib
 def _u8(mask: torch.Tensor) -> torch.Tensor:
     if not mask.is_cuda:
         raise RuntimeError("mask operations run on the GPU only (no CPU fallback)")
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)  # torch bools are 0/1 bytes: reinterpret, no copy
     return (mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)).contiguous()
+
+
+def frame_masks(input_mask: torch.Tensor, depth: torch.Tensor, min_depth_m: float, input_mask_erosion_iterations: int,
+                valid_depth_mask_erosion_iterations: int, border_percent: int, feature_hw: Tuple[int, int]
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(depth_mask uint8 (H,W), feature_mask uint8 (Hf,Wf)) of integrate_frame in one library call
+    (nvblox_mapping_helpers.py:201-204 and :222-253)."""
+    H, W = depth.shape
+    Hf, Wf = int(feature_hw[0]), int(feature_hw[1])
+    m = _u8(input_mask)
+    d = depth if (depth.dtype == torch.float32 and depth.is_contiguous()) else depth.to(torch.float32).contiguous()
+    dm = torch.empty((H, W), dtype=torch.uint8, device=depth.device)
+    fm = torch.empty((Hf, Wf), dtype=torch.uint8, device=depth.device)
+    tmp = torch.empty((H * W + 8,), dtype=torch.uint8, device=depth.device)
+    _lib.check(_lib.lib().mmf_frame_masks(_lib.dptr(m), _lib.dptr(d), H, W, float(min_depth_m), int(input_mask_erosion_iterations),
+                                          int(valid_depth_mask_erosion_iterations), int(border_percent), Hf, Wf, _lib.dptr(dm),
+                                          _lib.dptr(fm), _lib.dptr(tmp), _lib.stream_ptr(depth.device)), "mmf_frame_masks")
+    return dm, fm
 
 
 def erode_mask(mask: torch.Tensor, kernel_size: int = 3, iterations: int = 1) -> torch.Tensor:

@@ -9,14 +9,44 @@ from typing import Dict, Optional
 
 import torch
 
-from ...image_processing.image_mask_operations import depth_mask as _depth_mask
-from ...image_processing.image_mask_operations import feature_mask as _feature_mask
+from ...image_processing.image_mask_operations import frame_masks as _frame_masks
 from ...nvblox_torch.mapper import Mapper
 from ...nvblox_torch.mapper_params import (
     BlockMemoryPoolParams, MapperParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams, ViewCalculatorParams)
 from ...nvblox_torch.projective_integrator_types import ProjectiveIntegratorType
 from ...nvblox_torch.timer import Timer
 from ..nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
+
+
+class _IntegrationImages(dict):
+    """The images dictionary integrate_frame returns (:263-271).  ``rgb_frame`` (CHW float in [0,1], only
+    consumed by the visualiser) is computed on first access instead of on every frame."""
+
+    def __init__(self, items, rgb):
+        super().__init__(items)
+        self._rgb = rgb
+
+    def __missing__(self, key):
+        if key == "rgb_frame":
+            value = self._rgb.permute(2, 0, 1) / 255.0
+            self[key] = value
+            return value
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "rgb_frame" or super().__contains__(key)
+
+    def keys(self):
+        self["rgb_frame"]
+        return super().keys()
+
+    def items(self):
+        self["rgb_frame"]
+        return super().items()
+
+    def values(self):
+        self["rgb_frame"]
+        return super().values()
 
 
 def get_nvblox_mapper(mapper_config: NvbloxMappingCfg, feature_channels: Optional[int] = None) -> Mapper:
@@ -61,17 +91,17 @@ def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, dep
     H, W = depth_frame.shape
     Hf, Wf = feature_frame.shape[0], feature_frame.shape[1]
 
-    # depth_mask = input_mask & (depth > min_integration_distance)  (:201-204)
-    depth_mask_u8 = _depth_mask(input_mask, depth_frame, cfg.min_integration_distance_m)
+    # depth_mask = input_mask & (depth > min_integration_distance)  (:201-204) and
+    # feature_mask = border & nearest_upsample(erode(input_mask, k1) & erode(depth > min_d, k2))  (:222-253):
+    # both from one library call (two kernels)
+    depth_mask_u8, feature_mask = _frame_masks(input_mask, depth_frame, cfg.min_integration_distance_m,
+                                               input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
+                                               cfg.feature_mask_border_percent, (Hf, Wf))
     pose_host = camera_pose.detach().to("cpu", torch.float32)
     k_host = intrinsics.detach().to("cpu", torch.float32)
 
     mapper.add_depth_frame(depth_frame, pose_host, k_host, depth_mask_u8, mapper_id)
     mapper.add_color_frame(rgb.contiguous(), pose_host, k_host, mask_frame=depth_mask_u8, mapper_id=mapper_id)
-
-    # erode(input_mask, k1) & erode(depth > min_d, k2) -> nearest upsample -> & border  (:222-253)
-    feature_mask = _feature_mask(input_mask, depth_frame, cfg.min_integration_distance_m, input_mask_erosion_iterations,
-                                 valid_depth_mask_erosion_iterations, cfg.feature_mask_border_percent, (Hf, Wf))
 
     # intrinsics of the feature image: first two rows scaled (:229-234) -- per axis, so non-square images work
     feature_intrinsics = k_host.clone()
@@ -81,16 +111,15 @@ def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, dep
     feat16 = feature_frame if feature_frame.dtype == torch.float16 else feature_frame.to(torch.float16)
     mapper.add_feature_frame(feat16.contiguous(), pose_host, feature_intrinsics, feature_mask, mapper_id)
 
-    depth_mask = depth_mask_u8.to(torch.bool)
-    return {
+    depth_mask = depth_mask_u8.view(torch.bool)  # 0/1 bytes: reinterpret, no copy
+    return _IntegrationImages({
         "depth_frame": depth_frame,
         "depth_mask": depth_mask,
-        "rgb_frame": rgb.permute(2, 0, 1) / 255.0,
         "rgb_mask": depth_mask,
         "feature_frame": feature_frame,
         "feature_mask": feature_mask,
         "input_mask": input_mask,
-    }
+    }, rgb)
 
 
 def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, feature_extractor, depth_frame: torch.Tensor,

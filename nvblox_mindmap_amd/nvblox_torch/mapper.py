@@ -56,6 +56,8 @@ def _mask_u8(mask: Optional[torch.Tensor], shape) -> Optional[torch.Tensor]:
         raise ValueError("mask must be a tensor on the GPU")
     if tuple(mask.shape) != tuple(shape):
         raise ValueError(f"mask shape {tuple(mask.shape)} does not match the frame {tuple(shape)}")
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)  # 0/1 bytes: reinterpret, no copy
     if mask.dtype != torch.uint8:
         mask = mask.to(torch.uint8)
     return mask.contiguous()

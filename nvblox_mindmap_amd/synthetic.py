@@ -37,6 +37,11 @@ class StreamConfig:
     radius_m: float = 1.2
     height_m: float = 0.6
     invalid_holes: bool = True
+    # "pixels": isolated invalid pixels where (u*73856093 ^ v*19349663) % 97 == 0;
+    # "patches": 16x16 invalid patches on ~1/61 of the patch grid.  The reference erodes the valid-depth mask
+    # by 20 pixels before feature fusion (nvblox_mapper_constants.py:70): 1 %-density pixel holes would
+    # erase the whole feature mask, so streams that run the reference's mask algebra use "patches".
+    hole_mode: str = "pixels"
 
     def intrinsics(self) -> np.ndarray:
         return np.array([[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]], dtype=np.float32)
@@ -108,7 +113,10 @@ def render_depth(cfg: StreamConfig, T_W_C: np.ndarray) -> np.ndarray:
     depth = np.where(np.isfinite(t), t, 0.0).astype(np.float32)
     if cfg.invalid_holes:
         uu, vv = np.meshgrid(np.arange(cfg.width, dtype=np.int64), np.arange(cfg.height, dtype=np.int64))
-        holes = ((uu * 73856093) ^ (vv * 19349663)) % 97 == 0
+        if cfg.hole_mode == "patches":
+            holes = (((uu // 16) * 73856093) ^ ((vv // 16) * 19349663)) % 61 == 0
+        else:
+            holes = ((uu * 73856093) ^ (vv * 19349663)) % 97 == 0
         depth[holes] = 0.0
     return depth
 
