@@ -59,10 +59,10 @@ def test_frame_masks_vs_oracle_full_size(shape):
 
     h, w, hf, wf = shape
     rng = np.random.default_rng(h * 7 + w)
-    im = rng.uniform(size=(h, w)) > 0.0005
+    im = rng.uniform(size=(h, w)) > 0.00005
     im[h // 3: h // 3 + 5, w // 4: w // 4 + 9] = False
-    d = rng.uniform(0.2, 2.0, size=(h, w)).astype(np.float32)
-    d[rng.uniform(size=(h, w)) > 0.9995] = 0.0
+    d = rng.uniform(0.5, 2.0, size=(h, w)).astype(np.float32)
+    d[rng.uniform(size=(h, w)) > 0.99995] = 0.0
     odm, ofm = IO.frame_masks(im, d, 0.30, 17, 20, 5, hf, wf)
     dm, fm = frame_masks(cu(im), cu(d), 0.30, 17, 20, 5, (hf, wf))
     assert np.array_equal(dm.cpu().numpy().astype(bool), odm)
