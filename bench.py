@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(mapper, mcfg, frames[(args.warmup + i) % n_frames])
+    t_enqueued = time.perf_counter() - t0  # host time to enqueue all steps (GPU may lag behind)
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -220,6 +221,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -113,6 +113,18 @@ int mmf_add_color_frame(mmf_handle h, int mapper_id, const uint8_t* rgb_dev, con
  * feat: [Hf,Wf,C] f16 contiguous, C == feature_channels (multiple of 8). */
 int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat_f16_dev, const uint8_t* mask_dev, int Hf, int Wf,
                           int C, const float* T_W_C_host, const float* K_host, void* stream);
+/* integrate_frame(...) of the reference as ONE call (mapping/helpers/nvblox_mapping_helpers.py:162-273):
+ *   depth_mask   = input_mask & (depth > min_depth_m)                                   -> depth_mask_out [H,W] u8
+ *   feature_mask = border & nearest_upsample(erode(input_mask,k_in) & erode(depth>min_depth_m,k_depth)) -> feature_mask_out [Hf,Wf] u8
+ *   add_depth_frame(depth, mask=depth_mask); add_color_frame(rgb, mask=depth_mask);
+ *   add_feature_frame(feat, K scaled by (Wf/W, Hf/H), mask=feature_mask)
+ * Results are identical to the four separate calls; independent kernel chains (masks | TSDF chain, sphere trace |
+ * candidate selection, colour | feature update) run concurrently on internal streams and are joined on `stream`
+ * before the call returns.  Requires (Hf,Wf) == (H,W).  input_mask: [H,W] u8 (or torch bool bytes). */
+int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth_dev, const uint8_t* rgb_dev, const void* feat_f16_dev,
+                        const uint8_t* input_mask_dev, int H, int W, int Hf, int Wf, int C, const float* T_W_C_host,
+                        const float* K_host, float min_depth_m, int k_in, int k_depth, int border_percent,
+                        uint8_t* depth_mask_out_dev, uint8_t* feature_mask_out_dev, void* stream);
 /* Mapper.decay() / Mapper.clear()   isaaclab_nvblox_mapper.py:252-258.  mapper_id < 0: all mappers. */
 int mmf_decay(mmf_handle h, int mapper_id, void* stream);
 int mmf_clear(mmf_handle h, int mapper_id, void* stream);

@@ -67,6 +67,10 @@ struct LayerDev {
   // It mirrors the hash (maintained by the same insert / erase sites) and exists so that latency-bound
   // kernels (sphere tracing) can stage the whole index in LDS.
   unsigned short* dense;
+  // TSDF layer only: block_free[slot] = 1 iff every voxel of the block is observed free space (W > 1e-4 and
+  // D == +trunc).  Recomputed by k_tsdf_integrate / k_decay for every block they touch; lets the sphere tracer
+  // step through such blocks without reading voxels (the sample result is known: valid, distance = trunc).
+  unsigned char* block_free;
   int d_lo[3];
   int d_ny, d_nz, d_ncells;
 };
@@ -81,6 +85,7 @@ __device__ inline void dense_set(const LayerDev& L, unsigned long long key, int 
 struct Scratch {
   uint8_t* flags;    // [ncells] (multiple of 4) -- all zero between calls
   int* cell_slot;    // [ncells]
+  u64* cell_key;     // [ncells] key of a flagged cell when the cells are list positions (KeySrc mode 1)
   int2* tile_counts; // [ntiles]
   int2* tile_offs;   // [ntiles]
   int* cand_slot;    // [ncells]
@@ -169,6 +174,16 @@ __device__ inline void hash_erase(const LayerDev& L, u64 key) {
     if (k == kEmptyKey) return;
     h = (h + 1) & L.hmask;
   }
+}
+
+// Pool slot of a block key (-1 if absent): dense table when the layer has one, hash otherwise.
+__device__ inline int layer_lookup(const LayerDev& L, u64 key) {
+  if (L.dense) {
+    int x, y, z;
+    unpack_key(key, x, y, z);
+    return (int)L.dense[dense_cell(L, x, y, z)] - 1;
+  }
+  return hash_find(L, key);
 }
 
 __device__ inline int ifloor(float x) { return (int)floorf(x); }

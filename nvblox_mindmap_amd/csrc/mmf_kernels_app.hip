@@ -15,12 +15,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // whose centre projects into the appearance image.  One workgroup per live block, 2 voxels/thread.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc, Cam cam, Rigid T_C_L,
-                                                       uint8_t* __restrict__ flags) {
+                                                       uint8_t* __restrict__ flags, u64* __restrict__ cell_key) {
   const int n = T.ctr[0];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int slot = T.live[i];
     int bx, by, bz;
-    unpack_key(T.slot_key[slot], bx, by, bz);
+    const u64 key = T.slot_key[slot];
+    unpack_key(key, bx, by, bz);
     const float4 a = reinterpret_cast<const float4*>(T.pool)[(size_t)slot * (kVPB / 2) + threadIdx.x];
     int hit = 0;
 #pragma unroll
@@ -35,31 +36,27 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
       hit = 1;
     }
     const int any = __syncthreads_or(hit);
-    if (any && threadIdx.x == 0) flags[i] = 1;
+    if (any && threadIdx.x == 0) {
+      flags[i] = 1;
+      cell_key[i] = key;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sphere tracing: one thread per (subsampled) ray, one wave per 8x8 ray tile.  The kernel is a chain of
-// dependent lookups per ray (latency-bound, ~19k rays), so the work per step is minimised:
-//   * bounded workspace (DENSE): the block table of the workspace (slot+1 per cell, a few KB) is staged
-//     in LDS, so "which block is here" is an LDS read instead of a hash probe in global memory;
-//   * outside the workspace bounds no block can exist: the lookup is skipped (arithmetic-only step), and
-//     once the ray has left the (one-block padded) bounds for good the march stops: every remaining
-//     lookup would miss, so the result (failure) is already known.
-// The sequence of t values is unchanged, so the image is bit-identical to the plain march.
+// Sphere tracing: one thread per (subsampled) ray, one wave per 8x8 ray tile.  ~19k rays, each a chain of
+// dependent samples with a single wave per SIMD: the kernel is bound by instruction-issue and load latency,
+// so the work PER STEP is what matters.  Three exact shortcuts (the sequence of t values is unchanged, the
+// image is bit-identical to the plain march of the spec):
+//   * outside the workspace bounds no block can exist: no lookup, arithmetic-only step;
+//   * once the ray has left the (one-block padded) bounds for good every remaining sample would be
+//     unobserved, so the march stops (result: failure);
+//   * a block whose voxels are all observed free space (LayerDev::block_free) yields "valid, distance =
+//     trunc" for any sample inside it: no voxel read.
+// Block lookup: dense table of the bounded workspace (7.5 KB, L1-resident) or the hash.
 // ------------------------------------------------------------------------------------------------
-template <bool DENSE>
 __global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
                                                     int Ws, int Hs, int tiles_x) {
-  extern __shared__ unsigned short s_tab[];
-  if (DENSE) {
-    const uint4* src = reinterpret_cast<const uint4*>(T.dense);
-    uint4* dst = reinterpret_cast<uint4*>(s_tab);
-    const int n16 = (T.d_ncells * 2 + 15) / 16;
-    for (int i = threadIdx.x; i < n16; i += 64) dst[i] = src[i];
-    __syncthreads();
-  }
   const int lane = threadIdx.x & 63;
   const int cs = (blockIdx.x % tiles_x) * 8 + (lane & 7), rs = (blockIdx.x / tiles_x) * 8 + (lane >> 3);
   if (cs >= Ws || rs >= Hs) return;
@@ -94,28 +91,36 @@ __global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, C
 
   bool last_pos = false, ok = false;
   float t = 0.0f;
-  u64 ckey = kEmptyKey;
+  int cb0 = 0x7fffffff, cb1 = 0, cb2 = 0;  // block of the previous sample
   int cslot = -1;
+  bool cfree = false;
   for (int i = 0; i < mc.st_max_steps && t < mc.st_max_len; ++i) {
-    const float p[3] = {o[0] + t * dL[0], o[1] + t * dL[1], o[2] + t * dL[2]};
-    int lin;
-    const u64 key = voxel_at(mc, p, lin);
-    if (key != ckey) {
-      ckey = key;
-      int bx, by, bz;
-      unpack_key(key, bx, by, bz);
-      if (!in_workspace(mc, bx, by, bz)) {
+    const float p0 = o[0] + t * dL[0], p1 = o[1] + t * dL[1], p2 = o[2] + t * dL[2];
+    const int b0 = ifloor(p0 * mc.inv_bs), b1 = ifloor(p1 * mc.inv_bs), b2 = ifloor(p2 * mc.inv_bs);
+    if (b0 != cb0 || b1 != cb1 || b2 != cb2) {
+      cb0 = b0;
+      cb1 = b1;
+      cb2 = b2;
+      cfree = false;
+      if (!in_workspace(mc, b0, b1, b2)) {
         cslot = -1;  // blocks are only ever allocated inside the workspace bounds
-      } else if (DENSE) {
-        cslot = (int)s_tab[dense_cell(T, bx, by, bz)] - 1;
       } else {
-        cslot = hash_find(T, key);
+        cslot = T.dense ? (int)T.dense[dense_cell(T, b0, b1, b2)] - 1 : hash_find(T, pack_key(b0, b1, b2));
+        if (cslot >= 0) cfree = T.block_free[cslot] != 0;
       }
     }
     bool valid = false;
     float D = 0.0f;
-    if (cslot >= 0) {
-      const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)cslot * kVPB + lin];
+    if (cfree) {
+      valid = true;
+      D = mc.trunc;
+    } else if (cslot >= 0) {
+      int q0 = ifloor((p0 - (float)b0 * mc.bs) * mc.inv_v), q1 = ifloor((p1 - (float)b1 * mc.bs) * mc.inv_v),
+          q2 = ifloor((p2 - (float)b2 * mc.bs) * mc.inv_v);
+      q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
+      q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
+      q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
+      const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)cslot * kVPB + ((q0 * 8 + q1) * 8 + q2)];
       if (dw.y > 1e-4f) {
         valid = true;
         D = dw.x;
@@ -123,8 +128,7 @@ __global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, C
     }
     float step;
     if (!valid) {
-      if (last_pos) break;
-      if (t > t_exit) break;  // left the workspace for good: every further sample is unobserved
+      if (last_pos || t > t_exit) break;
       step = mc.trunc;
     } else if (D < mc.st_eps) {
       if (last_pos) {
@@ -340,8 +344,8 @@ static inline int grid8(int upper, int cap) {
 }
 
 void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, uint8_t* flags,
-                           hipStream_t s) {
-  hipLaunchKernelGGL(k_app_candidates, dim3(grid8(tsdf.cap, 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L, flags);
+                           u64* cell_key, hipStream_t s) {
+  hipLaunchKernelGGL(k_app_candidates, dim3(grid8(tsdf.cap, 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L, flags, cell_key);
 }
 
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
@@ -349,12 +353,7 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   const int tiles_x = (Ws + 7) / 8, tiles_y = (Hs + 7) / 8;
   const int n = tiles_x * tiles_y;
   if (n <= 0) return;
-  if (tsdf.dense && tsdf.d_ncells <= 32768) {
-    const size_t lds = ((size_t)tsdf.d_ncells * 2 + 15) / 16 * 16;
-    hipLaunchKernelGGL(k_sphere_trace<true>, dim3(n), dim3(64), lds, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, tiles_x);
-  } else {
-    hipLaunchKernelGGL(k_sphere_trace<false>, dim3(n), dim3(64), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, tiles_x);
-  }
+  hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(64), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, tiles_x);
 }
 
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,

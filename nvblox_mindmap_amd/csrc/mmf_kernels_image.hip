@@ -163,14 +163,15 @@ constexpr int kMaxMaskWords = 64;  // rows up to 4096 pixels
 
 __device__ inline u64 row_word(const u64* w, int j, int nw) { return (j >= 0 && j < nw) ? w[j] : 0ull; }
 
-__global__ __launch_bounds__(256) void k_mask_rowbits(const uint8_t* __restrict__ mask, const float* __restrict__ depth,
-                                                     float min_d, int H, int W, int nw, int k0, int k1,
-                                                     u64* __restrict__ bits_in, u64* __restrict__ bits_d,
-                                                     uint8_t* __restrict__ depth_mask_out) {
+__global__ __launch_bounds__(1024) void k_mask_rowbits(const uint8_t* __restrict__ mask, const float* __restrict__ depth,
+                                                      float min_d, int H, int W, int nw, int k0, int k1,
+                                                      u64* __restrict__ bits_in, u64* __restrict__ bits_d,
+                                                      uint8_t* __restrict__ depth_mask_out) {
   __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
   const int y = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  for (int x0 = 0; x0 < nw * 64; x0 += 256) {
+  // blockDim covers the whole row for W <= 1024 (one pass, every load of the row in flight at once)
+  for (int x0 = 0; x0 < nw * 64; x0 += blockDim.x) {
     const int x = x0 + threadIdx.x;
     bool bad_in = false, bad_d = false;
     if (x < W) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_mask_rowbits(const uint8_t* __restrict_
   }
   __syncthreads();
   // horizontal dilation: bit x of the result = OR of bits [x-k, x+k]
-  for (int j = threadIdx.x; j < 2 * nw; j += 256) {
+  for (int j = threadIdx.x; j < 2 * nw; j += blockDim.x) {
     const bool second = j >= nw;
     const int w = second ? j - nw : j;
     const u64* src = second ? s_d : s_in;
@@ -195,7 +196,6 @@ __global__ __launch_bounds__(256) void k_mask_rowbits(const uint8_t* __restrict_
     u64 r = src[w];
     for (int s = 1; s <= k; ++s) {
       const int q = s >> 6, sh = s & 63;  // shift by s = q words + sh bits
-      // bits coming from the left (lower x) and from the right (higher x)
       u64 left = row_word(src, w - q, nw) << sh;
       if (sh) left |= row_word(src, w - q - 1, nw) >> (64 - sh);
       u64 right = row_word(src, w + q, nw) >> sh;
@@ -211,22 +211,29 @@ __global__ __launch_bounds__(256) void k_mask_colemit(const u64* __restrict__ bi
                                                      int bh, int bw, uint8_t* __restrict__ out) {
   __shared__ u64 s_bad[kMaxMaskWords];
   const int yf = blockIdx.x;
-  int ys = (int)floorf((float)yf * sh);
-  ys = ys > H - 1 ? H - 1 : ys;
-  for (int j = threadIdx.x; j < nw; j += 256) {
-    u64 r = 0;
-    {
-      const int lo = ys - k0 < 0 ? 0 : ys - k0, hi = ys + k0 > H - 1 ? H - 1 : ys + k0;
-      for (int yy = lo; yy <= hi; ++yy) r |= bits_in[(size_t)yy * nw + j];
-    }
-    {
-      const int lo = ys - k1 < 0 ? 0 : ys - k1, hi = ys + k1 > H - 1 ? H - 1 : ys + k1;
-      for (int yy = lo; yy <= hi; ++yy) r |= bits_d[(size_t)yy * nw + j];
-    }
-    s_bad[j] = r;
-  }
-  __syncthreads();
   const bool row_ok = (bh <= 0 || bw <= 0) || (yf >= bh && yf < Hf - bh);
+  if (row_ok) {  // block-uniform
+    int ys = (int)floorf((float)yf * sh);
+    ys = ys > H - 1 ? H - 1 : ys;
+    for (int j = threadIdx.x; j < nw; j += 256) s_bad[j] = 0ull;
+    __syncthreads();
+    // vertical OR of the 2k+1 source bit-rows, spread over all threads: thread -> (word, row phase)
+    const int groups = 256 / nw > 0 ? 256 / nw : 1;
+    const int j = threadIdx.x % nw, g = threadIdx.x / nw;
+    if (g < groups) {
+      u64 r = 0;
+      {
+        const int lo = ys - k0 < 0 ? 0 : ys - k0, hi = ys + k0 > H - 1 ? H - 1 : ys + k0;
+        for (int yy = lo + g; yy <= hi; yy += groups) r |= bits_in[(size_t)yy * nw + j];
+      }
+      {
+        const int lo = ys - k1 < 0 ? 0 : ys - k1, hi = ys + k1 > H - 1 ? H - 1 : ys + k1;
+        for (int yy = lo + g; yy <= hi; yy += groups) r |= bits_d[(size_t)yy * nw + j];
+      }
+      if (r) atomicOr(&s_bad[j], r);
+    }
+    __syncthreads();
+  }
   for (int xf = threadIdx.x; xf < Wf; xf += 256) {
     uint8_t res = 0;
     if (row_ok && ((bh <= 0 || bw <= 0) || (xf >= bw && xf < Wf - bw))) {
@@ -317,8 +324,9 @@ void launch_frame_masks(const uint8_t* input_mask, const float* depth, int H, in
   if (packed) {
     u64* bits_in = reinterpret_cast<u64*>(tmp);
     u64* bits_d = bits_in + (size_t)H * nw;
-    hipLaunchKernelGGL(k_mask_rowbits, dim3(H), dim3(256), 0, s, input_mask, depth, min_d, H, W, nw, k_in, k_depth, bits_in, bits_d,
-                       depth_mask_out);
+    const int rb_threads = nw * 64 < 1024 ? nw * 64 : 1024;
+    hipLaunchKernelGGL(k_mask_rowbits, dim3(H), dim3(rb_threads), 0, s, input_mask, depth, min_d, H, W, nw, k_in, k_depth, bits_in,
+                       bits_d, depth_mask_out);
     hipLaunchKernelGGL(k_mask_colemit, dim3(Hf), dim3(256), 0, s, (const u64*)bits_in, (const u64*)bits_d, H, W, nw, k_in, k_depth,
                        Hf, Wf, sh, sw, bh, bw, feature_mask_out);
     return;

@@ -66,37 +66,69 @@ __device__ inline void walk_step(Walk& w) {
   }
 }
 
+// LDSFLAGS: the view grid has at most kRaycastLdsCells cells, so a workgroup first collects the cells its 256
+// rays traverse as byte flags in LDS (plain same-value stores, no atomics) and then writes one global flag
+// byte per DISTINCT cell: the hot loop issues no global stores at all.
+constexpr int kRaycastLdsCells = 32768;
+
+template <bool LDSFLAGS>
 __global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rigid T_L_C, const float* __restrict__ depth,
-                                                     const uint8_t* __restrict__ mask, int sub, int Wsub, int Hsub,
-                                                     ViewGrid vg, uint8_t* __restrict__ flags) {
-  // one wave = one 8x8 tile of (subsampled) pixels: neighbouring rays traverse the same blocks, so the
-  // 64 flag stores of a step collapse onto a few addresses
+                                                     const uint8_t* __restrict__ mask, float min_d, int sub, int Wsub,
+                                                     int Hsub, ViewGrid vg, uint8_t* __restrict__ flags) {
+  extern __shared__ unsigned s_words[];  // LDSFLAGS: ceil(ncells/4) words of 4 byte flags
+  uint8_t* s_flags = reinterpret_cast<uint8_t*>(s_words);
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  const int nwords = (ncells + 3) >> 2;
+  if (LDSFLAGS) {
+    for (int w = threadIdx.x; w < nwords; w += 256) s_words[w] = 0u;
+    __syncthreads();
+  }
+  // one wave = one 8x8 tile of (subsampled) pixels: neighbouring rays traverse the same blocks
   const int tiles_x = (Wsub + 7) >> 3;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int cs = (tile % tiles_x) * 8 + (lane & 7), rs = (tile / tiles_x) * 8 + (lane >> 3);
-  if (cs >= Wsub || rs >= Hsub) return;
+  bool active = cs < Wsub && rs < Hsub;
   int r = rs * sub, c = cs * sub;
-  size_t pix = (size_t)r * cam.W + c;
-  float d = depth[pix];
-  if (!(d > 0.0f)) return;
-  if (mask && !mask[pix]) return;
-  if (mc.max_dist > 0.0f && d > mc.max_dist) d = mc.max_dist;
-  float s = d + mc.trunc;
-  float ray[3] = {((float)c + 0.5f - cam.cx) / cam.fx, ((float)r + 0.5f - cam.cy) / cam.fy, 1.0f};
-  float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
-  float pL[3];
-  xform(T_L_C, pC, pL);
-  float s0[3] = {T_L_C.t[0] * mc.inv_bs, T_L_C.t[1] * mc.inv_bs, T_L_C.t[2] * mc.inv_bs};
-  float e[3] = {pL[0] * mc.inv_bs, pL[1] * mc.inv_bs, pL[2] * mc.inv_bs};
-  Walk w;
-  walk_init(w, s0, e);
-  for (int i = 0; i <= w.n; ++i) {
-    int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
-    // the view grid already is the intersection with the workspace bounds
-    if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
-      flags[(gx * vg.ny + gy) * vg.nz + gz] = 1;
+  float d = 0.0f;
+  if (active) {
+    const size_t pix = (size_t)r * cam.W + c;
+    d = depth[pix];
+    if (!(d > min_d)) active = false;  // min_d >= 0: "depth > 0" and the caller's "depth > min distance" mask in one test
+    if (active && mask && !mask[pix]) active = false;
+  }
+  if (active) {
+    if (mc.max_dist > 0.0f && d > mc.max_dist) d = mc.max_dist;
+    float s = d + mc.trunc;
+    float ray[3] = {((float)c + 0.5f - cam.cx) / cam.fx, ((float)r + 0.5f - cam.cy) / cam.fy, 1.0f};
+    float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
+    float pL[3];
+    xform(T_L_C, pC, pL);
+    float s0[3] = {T_L_C.t[0] * mc.inv_bs, T_L_C.t[1] * mc.inv_bs, T_L_C.t[2] * mc.inv_bs};
+    float e[3] = {pL[0] * mc.inv_bs, pL[1] * mc.inv_bs, pL[2] * mc.inv_bs};
+    Walk w;
+    walk_init(w, s0, e);
+    for (int i = 0; i <= w.n; ++i) {
+      int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
+      // the view grid already is the intersection with the workspace bounds
+      if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
+        const int cell = (gx * vg.ny + gy) * vg.nz + gz;
+        if (LDSFLAGS)
+          s_flags[cell] = 1;
+        else
+          flags[cell] = 1;
+      }
+      walk_step(w);
     }
-    walk_step(w);
+  }
+  if (LDSFLAGS) {
+    __syncthreads();
+    for (int wd = threadIdx.x; wd < nwords; wd += 256) {
+      const unsigned v = s_words[wd];
+      if (!v) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((v >> (8 * k)) & 0xffu) flags[wd * 4 + k] = 1;
+    }
   }
 }
 
@@ -107,15 +139,18 @@ __global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rig
 //    the live list and of every output derived from it is deterministic.  New blocks take their
 //    pool slot from (rank among the new ones): wave ballot/prefix-sum, no per-block atomics.
 // ------------------------------------------------------------------------------------------------
-__device__ inline u64 cell_key(const KeySrc& ks, int cell) {
-  if (ks.mode == 0) {
-    int gz = cell % ks.nz;
-    int t = cell / ks.nz;
-    int gy = t % ks.ny;
-    int gx = t / ks.ny;
-    return pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
-  }
-  return ks.slot_key[ks.live[cell]];
+__device__ inline u64 grid_cell_key(const KeySrc& ks, int cell) {
+  int gz = cell % ks.nz;
+  int t = cell / ks.nz;
+  int gy = t % ks.ny;
+  int gx = t / ks.ny;
+  return pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
+}
+
+// mode 0: the cell is a cell of the dense view grid; mode 1: the cell is a position of another layer's live
+// list and the producer of the flags (k_app_candidates) stored the block key next to the flag.
+__device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
+  return ks.mode == 0 ? grid_cell_key(ks, cell) : sc.cell_key[cell];
 }
 
 __global__ __launch_bounds__(256) void k_count_tiles(LayerDev L, KeySrc ks, Scratch sc, int ncells) {
@@ -129,7 +164,7 @@ __global__ __launch_bounds__(256) void k_count_tiles(LayerDev L, KeySrc ks, Scra
     for (int k = 0; k < 4; ++k) {
       if ((f4 >> (8 * k)) & 0xffu) {
         int cell = cell0 + k;
-        int slot = hash_find(L, cell_key(ks, cell));
+        int slot = layer_lookup(L, cell_key(ks, sc, cell));
         sc.cell_slot[cell] = slot;
         nf++;
         nn += slot < 0;
@@ -214,7 +249,7 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
   for (int k = 0; k < 4; ++k) {
     if (!((f4 >> (8 * k)) & 0xffu)) continue;
     const int cell = cell0 + k;
-    const u64 key = cell_key(ks, cell);
+    const u64 key = cell_key(ks, sc, cell);
     int slot = slot4[k];
     const bool is_new = slot < 0;
     if (is_new) {
@@ -261,25 +296,65 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
     int slot4[4] = {0, 0, 0, 0};
     u64 key4[4] = {0, 0, 0, 0};
     int nf = 0, nn = 0;
-    if (f4) {
-      // the four first probes are independent 16-byte loads: issue them together, then resolve
-      unsigned h4[4] = {0, 0, 0, 0};
-      uint4 e4[4];
+    if (cell0 < ncells) {
+      // Every load of this pass is issued before the first one is consumed.  Grid cells have computable keys,
+      // so their table entries are fetched without waiting for the flags; list cells read key + flag together
+      // and look the flagged ones up in a second round.
+      if (ks.mode == 0) {
+        unsigned h4[4] = {0, 0, 0, 0};
+        uint4 e4[4];
+        int d4[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        e4[k] = make_uint4(0, 0, 0, 0);
-        if ((f4 >> (8 * k)) & 0xffu) {
-          key4[k] = cell_key(ks, cell0 + k);
-          h4[k] = hash_key(key4[k]) & L.hmask;
-          e4[k] = hash_load(L, h4[k]);
+        for (int k = 0; k < 4; ++k) {
+          e4[k] = make_uint4(0, 0, 0, 0);
+          if (cell0 + k < ncells) {
+            key4[k] = grid_cell_key(ks, cell0 + k);
+            if (L.dense) {
+              int x, y, z;
+              unpack_key(key4[k], x, y, z);
+              d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
+            } else {
+              h4[k] = hash_key(key4[k]) & L.hmask;
+              e4[k] = hash_load(L, h4[k]);
+            }
+          }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((f4 >> (8 * k)) & 0xffu) {
-          slot4[k] = hash_resolve(L, key4[k], h4[k], e4[k]);
-          nf++;
-          nn += slot4[k] < 0;
+        for (int k = 0; k < 4; ++k) {
+          if ((f4 >> (8 * k)) & 0xffu) {
+            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
+            nf++;
+            nn += slot4[k] < 0;
+          }
+        }
+      } else if (f4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((f4 >> (8 * k)) & 0xffu) key4[k] = sc.cell_key[cell0 + k];
+        unsigned h4[4] = {0, 0, 0, 0};
+        uint4 e4[4];
+        int d4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          e4[k] = make_uint4(0, 0, 0, 0);
+          if ((f4 >> (8 * k)) & 0xffu) {
+            if (L.dense) {
+              int x, y, z;
+              unpack_key(key4[k], x, y, z);
+              d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
+            } else {
+              h4[k] = hash_key(key4[k]) & L.hmask;
+              e4[k] = hash_load(L, h4[k]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((f4 >> (8 * k)) & 0xffu) {
+            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
+            nf++;
+            nn += slot4[k] < 0;
+          }
         }
       }
     }
@@ -337,28 +412,28 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
 //    z fastest so a wave reads/writes 512 contiguous bytes of {distance, weight}.  HBM-bound
 //    read-modify-write of 4 KB per block; the 4 depth taps come through L1/L2 (1.2 MB image).
 // ------------------------------------------------------------------------------------------------
-__device__ inline bool depth_tap(const float* depth, const uint8_t* mask, int W, int x, int y, float& out) {
+__device__ inline bool depth_tap(const float* depth, const uint8_t* mask, float min_d, int W, int x, int y, float& out) {
   size_t i = (size_t)y * W + x;
   float d = depth[i];
-  if (!(d > 0.0f)) return false;
+  if (!(d > min_d)) return false;
   if (mask && !mask[i]) return false;
   out = d;
   return true;
 }
 
-__device__ inline bool sample_depth(const MapConsts& mc, const float* depth, const uint8_t* mask, const Cam& cam, float u,
-                                    float v, float& out) {
+__device__ inline bool sample_depth(const MapConsts& mc, const float* depth, const uint8_t* mask, float min_d, const Cam& cam,
+                                    float u, float v, float& out) {
   int xn = ifloor(u), yn = ifloor(v);
   if (xn > cam.W - 1) xn = cam.W - 1;
   if (yn > cam.H - 1) yn = cam.H - 1;
   float dn;
-  if (!depth_tap(depth, mask, cam.W, xn, yn, dn)) return false;
+  if (!depth_tap(depth, mask, min_d, cam.W, xn, yn, dn)) return false;
   int x0, y0;
   float wx, wy;
   if (bilin_setup(u, v, cam.W, cam.H, x0, y0, wx, wy)) {
     float a00, a10, a01, a11;
-    if (depth_tap(depth, mask, cam.W, x0, y0, a00) && depth_tap(depth, mask, cam.W, x0 + 1, y0, a10) &&
-        depth_tap(depth, mask, cam.W, x0, y0 + 1, a01) && depth_tap(depth, mask, cam.W, x0 + 1, y0 + 1, a11)) {
+    if (depth_tap(depth, mask, min_d, cam.W, x0, y0, a00) && depth_tap(depth, mask, min_d, cam.W, x0 + 1, y0, a10) &&
+        depth_tap(depth, mask, min_d, cam.W, x0, y0 + 1, a01) && depth_tap(depth, mask, min_d, cam.W, x0 + 1, y0 + 1, a11)) {
       bool ok = true;
       if (mc.lin_md > 0.0f) {
         if (fabsf(a00 - dn) > mc.lin_md || fabsf(a10 - dn) > mc.lin_md || fabsf(a01 - dn) > mc.lin_md ||
@@ -377,7 +452,7 @@ __device__ inline bool sample_depth(const MapConsts& mc, const float* depth, con
 
 __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        const float* __restrict__ depth,
-                                                       const uint8_t* __restrict__ mask, Scratch sc) {
+                                                       const uint8_t* __restrict__ mask, float min_d, Scratch sc) {
   const int n = *sc.cand_count;
   const int chunk = (n + 7) >> 3;
   const int lin = threadIdx.x;
@@ -397,7 +472,7 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
     xform(T_C_L, c, p);
     if (project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist)) {
       float d;
-      if (sample_depth(mc, depth, mask, cam, u, v, d)) {
+      if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
         float sdf = d - p[2];
         if (!(sdf < -mc.trunc)) {
           float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
@@ -410,6 +485,9 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
       }
     }
     if (upd || is_new) *vox = dw;
+    // block summary for the sphere tracer's empty-space skipping
+    const int all_free = __syncthreads_and((dw.y > 1e-4f && dw.x == mc.trunc) ? 1 : 0);
+    if (lin == 0) L.block_free[slot] = all_free ? 1 : 0;
   }
 }
 
@@ -429,6 +507,8 @@ __global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t
     *vox = a;
     int alive = (!(a.y < mc.decay_thr)) || (!(a.w < mc.decay_thr));
     int any_alive = __syncthreads_or(alive);
+    const int all_free = __syncthreads_and((a.y > 1e-4f && a.x == mc.trunc && a.w > 1e-4f && a.z == mc.trunc) ? 1 : 0);
+    if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
     if (threadIdx.x == 0 && !any_alive && mc.dealloc_decayed) {
       kill[i] = 1;
       *any_kill = 1;
@@ -604,13 +684,18 @@ __global__ __launch_bounds__(256) void k_query_feature(LayerDev L, MapConsts mc,
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, int sub,
-                    const ViewGrid& vg, uint8_t* flags, hipStream_t s) {
+void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
+                    int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s) {
   int Wsub = (cam.W + sub - 1) / sub, Hsub = (cam.H + sub - 1) / sub;
   int ntiles = ((Wsub + 7) / 8) * ((Hsub + 7) / 8);
   if (ntiles <= 0) return;
-  hipLaunchKernelGGL(k_raycast_mark, dim3((ntiles + 3) / 4), dim3(256), 0, s, mc, cam, T_L_C, depth, mask, sub, Wsub, Hsub, vg,
-                     flags);
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  if (ncells <= kRaycastLdsCells)
+    hipLaunchKernelGGL(k_raycast_mark<true>, dim3((ntiles + 3) / 4), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, mc, cam, T_L_C,
+                       depth, mask, min_d, sub, Wsub, Hsub, vg, flags);
+  else
+    hipLaunchKernelGGL(k_raycast_mark<false>, dim3((ntiles + 3) / 4), dim3(256), 0, s, mc, cam, T_L_C, depth, mask, min_d, sub, Wsub,
+                       Hsub, vg, flags);
 }
 
 constexpr int kFusedAllocMaxCells = 16384;
@@ -635,8 +720,8 @@ static inline int grid_for(int upper, int cap) {
 }
 
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
-                           const uint8_t* mask, const Scratch& sc, int max_cand, hipStream_t s) {
-  hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(max_cand, 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, sc);
+                           const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s) {
+  hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(max_cand, 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, sc);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

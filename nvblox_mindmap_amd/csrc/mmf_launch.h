@@ -10,12 +10,12 @@ struct ViewGrid {
 };
 
 // mmf_kernels_map.hip
-void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, int sub,
-                    const ViewGrid& vg, uint8_t* flags, hipStream_t s);
+void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
+                    int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s);
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
-                           const uint8_t* mask, const Scratch& sc, int max_cand, hipStream_t s);
+                           const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s);
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
 void launch_layer_reset(const LayerDev& L, hipStream_t s);
 void launch_hash_rebuild(const LayerDev& L, hipStream_t s);
@@ -28,7 +28,7 @@ void launch_query_feature(const LayerDev& L, const MapConsts& mc, const float* p
 
 // mmf_kernels_app.hip
 void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, uint8_t* flags,
-                           hipStream_t s);
+                           u64* cell_key, hipStream_t s);
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
                          int Hs, hipStream_t s);
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,

@@ -91,6 +91,22 @@ def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, dep
     H, W = depth_frame.shape
     Hf, Wf = feature_frame.shape[0], feature_frame.shape[1]
 
+    feat16 = feature_frame if feature_frame.dtype == torch.float16 else feature_frame.to(torch.float16)
+    if (Hf, Wf) == (H, W):
+        # the reference's only configuration (512 -> 512): the whole function body is one native call
+        depth_mask_u8, feature_mask = mapper.integrate_frame(
+            depth_frame, rgb, feat16, input_mask, camera_pose, intrinsics, cfg.min_integration_distance_m,
+            input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, cfg.feature_mask_border_percent, mapper_id)
+        depth_mask = depth_mask_u8.view(torch.bool)
+        return _IntegrationImages({
+            "depth_frame": depth_frame,
+            "depth_mask": depth_mask,
+            "rgb_mask": depth_mask,
+            "feature_frame": feature_frame,
+            "feature_mask": feature_mask,
+            "input_mask": input_mask,
+        }, rgb)
+
     # depth_mask = input_mask & (depth > min_integration_distance)  (:201-204) and
     # feature_mask = border & nearest_upsample(erode(input_mask, k1) & erode(depth > min_d, k2))  (:222-253):
     # both from one library call (two kernels)
@@ -108,7 +124,6 @@ def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, dep
     feature_intrinsics[0, :] *= Wf / W
     feature_intrinsics[1, :] *= Hf / H
 
-    feat16 = feature_frame if feature_frame.dtype == torch.float16 else feature_frame.to(torch.float16)
     mapper.add_feature_frame(feat16.contiguous(), pose_host, feature_intrinsics, feature_mask, mapper_id)
 
     depth_mask = depth_mask_u8.view(torch.bool)  # 0/1 bytes: reinterpret, no copy

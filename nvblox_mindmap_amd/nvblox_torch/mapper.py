@@ -281,6 +281,34 @@ class Mapper:
         _lib.check(_lib.lib().mmf_add_feature_frame(self._h, mapper_id, _lib.dptr(feat), _lib.dptr(mask), Hf, Wf, ch, T.ctypes.data,
                                                     K.ctypes.data, self._stream()), "mmf_add_feature_frame")
 
+    def integrate_frame(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor,
+                        input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float, input_mask_erosion_iterations: int,
+                        valid_depth_mask_erosion_iterations: int, border_percent: int, mapper_id: int = 0):
+        """Extension: the reference's ``integrate_frame`` (mapping/helpers/nvblox_mapping_helpers.py:162-273) as one
+        native call -- mask algebra + add_depth_frame + add_color_frame + add_feature_frame with identical results,
+        independent kernel chains overlapped on internal streams.  Needs the feature image at the depth resolution.
+        Returns (depth_mask uint8 [H,W], feature_mask uint8 [Hf,Wf])."""
+        mapper_id = self._check_id(mapper_id)
+        depth = _check_dev(depth_frame, "depth_frame", torch.float32, 2)
+        rgb = _check_dev(color_frame, "color_frame", torch.uint8, 3)
+        feat = _check_dev(feature_frame, "feature_frame", torch.float16, 3)
+        H, W = depth.shape
+        Hf, Wf, ch = feat.shape
+        if tuple(rgb.shape) != (H, W, 3):
+            raise ValueError("color_frame must be [H,W,3] with the depth frame's H,W")
+        if ch != self.feature_channels:
+            raise ValueError(f"feature_frame has {ch} channels but the mapper stores {self.feature_channels}")
+        mask = _mask_u8(input_mask, (H, W))
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        dm = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        fm = torch.empty((Hf, Wf), dtype=torch.uint8, device=self.device)
+        _lib.check(_lib.lib().mmf_integrate_frame(
+            self._h, mapper_id, _lib.dptr(depth), _lib.dptr(rgb), _lib.dptr(feat), _lib.dptr(mask), H, W, Hf, Wf, ch, T.ctypes.data,
+            K.ctypes.data, float(min_depth_m), int(input_mask_erosion_iterations), int(valid_depth_mask_erosion_iterations),
+            int(border_percent), _lib.dptr(dm), _lib.dptr(fm), self._stream()), "mmf_integrate_frame")
+        return dm, fm
+
     def decay(self, mapper_id: int = -1) -> None:
         _lib.check(_lib.lib().mmf_decay(self._h, int(mapper_id), self._stream()), "mmf_decay")
 

@@ -216,3 +216,64 @@ def test_errors_are_loud():
         gpu.add_depth_frame(torch.zeros((8, 8), dtype=torch.float32), torch.eye(4), torch.eye(3), None, 0)
     with pytest.raises(ValueError):
         gpu.add_depth_frame(torch.zeros((8, 8), dtype=torch.float32, device="cuda"), torch.eye(4), torch.eye(3), None, 5)
+
+
+@pytest.mark.parametrize("scale,channels", [(4, 16), (1, 64)])
+def test_integrate_frame_fused_matches_oracle(oracle_mod, scale, channels):
+    """The reference's integrate_frame as one native call (masks + depth + colour + feature on overlapping
+    internal streams) against the oracle driven with the numpy-oracle masks, over several frames with decay."""
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper, integrate_frame
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
+    from oracle import image_ops as IO
+
+    base = small_cfg(scale)
+    cfg = S.StreamConfig(width=base.width, height=base.height, fx=base.fx, fy=base.fy, cx=base.cx, cy=base.cy, hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    k_in, k_depth = (3, 4) if scale > 1 else (mcfg.static_mask_erosion_iterations, mcfg.valid_depth_mask_erosion_iterations)
+    gpu = get_nvblox_mapper(mcfg, feature_channels=channels)
+    orc = make_oracle(oracle_mod, channels)
+    frames = [0, 5, 10] if scale > 1 else [0, 7]
+    for k, i in enumerate(frames):
+        f = S.frame(cfg, i, channels)
+        dyn = np.zeros(f["depth"].shape, dtype=bool)
+        dyn[10 + k: 20 + k, 30:50] = True
+        static = ~dyn
+        odm, ofm = IO.frame_masks(static, f["depth"], mcfg.min_integration_distance_m, k_in, k_depth,
+                                  mcfg.feature_mask_border_percent, cfg.height, cfg.width)
+        orc.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+        gpu.decay()
+        K = torch.from_numpy(f["K"])
+        images = integrate_frame(mapper=gpu, nvblox_mapping_config=mcfg, depth_frame=dev(f["depth"]), feature_frame=dev(f["features"]),
+                                 intrinsics=K, camera_pose=torch.from_numpy(f["T_W_C"]), rgb=dev(f["rgb"]), input_mask=dev(static),
+                                 input_mask_erosion_iterations=k_in, valid_depth_mask_erosion_iterations=k_depth,
+                                 mapper_id=MAPPER_TO_ID.STATIC)
+        assert torch.equal(K, torch.from_numpy(f["K"])), "the caller's intrinsics must not be modified"
+        assert np.array_equal(images["depth_mask"].cpu().numpy(), odm)
+        assert np.array_equal(images["feature_mask"].cpu().numpy().astype(bool), ofm)
+        assert set(images.keys()) == {"depth_frame", "depth_mask", "rgb_frame", "rgb_mask", "feature_frame", "feature_mask", "input_mask"}
+        assert images["rgb_frame"].shape == (3, cfg.height, cfg.width) and float(images["rgb_frame"].max()) <= 1.0
+    compare_tsdf(orc, gpu)
+    compare_features(orc, gpu)
+    rgb, w, idx = gpu.color_layer_view(0).get_all_blocks_split()
+    orgb, ow = orc.all_colors()
+    assert np.array_equal(idx.cpu().numpy(), orc.block_indices(1))
+    assert np.array_equal(w.cpu().numpy(), ow) and np.array_equal(rgb.cpu().numpy(), orgb)
+    assert (ow > 0).sum() > 500
+    _, fw = orc.all_features()
+    assert (fw > 0).sum() > 500
+    # and the model-input extraction on top of it
+    from nvblox_mindmap_amd.data_loading.vertex_sampling import VertexSamplingMethod
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_output_helpers import get_vertices_and_features
+
+    v, feats, valid = get_vertices_and_features(gpu, MAPPER_TO_ID.STATIC, mcfg, remove_zero_features=True, num_excess_features=0,
+                                                sample_vertices=True, number_of_vertices_to_sample=2048,
+                                                vertex_sampling_method=VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT)
+    assert v.shape == (1, 2048, 3) and feats.shape == (1, 2048, channels) and valid.shape == (1, 2048)
+    ov, of = orc.feature_mesh()
+    inside = np.all((ov > mcfg.aabb_min_m.numpy()) & (ov < mcfg.aabb_max_m.numpy()), axis=1)
+    nonzero = np.any(of != 0, axis=1)
+    n_expected = int((inside & nonzero).sum())
+    assert int(valid.sum()) == min(n_expected, 2048)
