@@ -44,22 +44,27 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sphere tracing: one thread per (subsampled) ray, one wave per 8x8 ray tile.  ~19k rays, each a chain of
-// dependent samples with a single wave per SIMD: the kernel is bound by instruction-issue and load latency,
-// so the work PER STEP is what matters.  Three exact shortcuts (the sequence of t values is unchanged, the
-// image is bit-identical to the plain march of the spec):
-//   * outside the workspace bounds no block can exist: no lookup, arithmetic-only step;
-//   * once the ray has left the (one-block padded) bounds for good every remaining sample would be
-//     unobserved, so the march stops (result: failure);
-//   * a block whose voxels are all observed free space (LayerDev::block_free) yields "valid, distance =
-//     trunc" for any sample inside it: no voxel read.
-// Block lookup: dense table of the bounded workspace (7.5 KB, L1-resident) or the hash.
+// Sphere tracing, cooperative form: 16 lanes per (subsampled) ray, workgroup = 4x4 ray patch.
+// The march of the spec is a chain of dependent samples, most of them exactly `trunc` apart (unobserved space
+// and observed free space whose distance is clamped to +trunc).  A thread-per-ray kernel has ~19k threads and
+// one wave per SIMD: pure latency (47 us).  Here lane k of a ray group evaluates the sample the march WOULD
+// take after k trunc-steps (t_k built by the same k sequential float adds), a ballot finds the first lane whose
+// sample ends the run of trunc-steps (termination, or a step != trunc), and the group resumes from that lane's
+// state.  Every sample that is consumed is the spec's sample at bitwise the same t, so the image is identical;
+// the kernel now has ~300k threads and is throughput-bound.
+// Exact shortcuts kept from the scalar form: no lookup outside the workspace bounds (no block can exist there),
+// arithmetic-only fast-forward up to the entry into the (one-block padded) bounds, stop after leaving them,
+// no voxel read inside all-free blocks (LayerDev::block_free).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
-                                                    int Ws, int Hs, int tiles_x) {
-  const int lane = threadIdx.x & 63;
-  const int cs = (blockIdx.x % tiles_x) * 8 + (lane & 7), rs = (blockIdx.x / tiles_x) * 8 + (lane >> 3);
-  if (cs >= Ws || rs >= Hs) return;
+constexpr int kRayLanes = 16;
+
+__global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
+                                                     int Ws, int Hs, int patches_x) {
+  const int k = threadIdx.x & (kRayLanes - 1);          // sample lane within the ray group
+  const int rl = threadIdx.x >> 4;                      // ray within the 4x4 patch
+  const int gshift = (threadIdx.x & 63) & ~(kRayLanes - 1);  // first lane of this group inside its wave
+  const int cs = (blockIdx.x % patches_x) * 4 + (rl & 3), rs = (blockIdx.x / patches_x) * 4 + (rl >> 2);
+  if (cs >= Ws || rs >= Hs) return;  // whole groups leave together
   const int idx = rs * Ws + cs;
   const float sf = (float)mc.st_sf;
   const float u = ((float)cs + 0.5f) * sf, v = ((float)rs + 0.5f) * sf;
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, C
   rotate(T_L_C, dC, dL);
   const float o[3] = {T_L_C.t[0], T_L_C.t[1], T_L_C.t[2]};
 
-  // last ray parameter at which the ray can still be inside the workspace bounds padded by one block
-  float t_exit = 3.0e38f;
+  // [t_enter, t_exit]: ray parameters at which the ray can be inside the workspace bounds padded by one block
+  float t_enter = -3.0e38f, t_exit = 3.0e38f;
   if (mc.ws_type != 0) {
     float tmin = -3.0e38f, tmax = 3.0e38f;
 #pragma unroll
@@ -86,63 +91,90 @@ __global__ __launch_bounds__(64) void k_sphere_trace(LayerDev T, MapConsts mc, C
         tmax = -3.0e38f;
       }
     }
-    t_exit = (tmax >= tmin) ? tmax : -1.0f;
+    if (tmax >= tmin) {
+      t_enter = tmin;
+      t_exit = tmax;
+    } else {
+      t_exit = -1.0f;  // never inside: the first sample already fails
+    }
   }
 
-  bool last_pos = false, ok = false;
+  bool last_pos = false, ok = false, done = false;
   float t = 0.0f;
-  int cb0 = 0x7fffffff, cb1 = 0, cb2 = 0;  // block of the previous sample
-  int cslot = -1;
-  bool cfree = false;
-  for (int i = 0; i < mc.st_max_steps && t < mc.st_max_len; ++i) {
-    const float p0 = o[0] + t * dL[0], p1 = o[1] + t * dL[1], p2 = o[2] + t * dL[2];
-    const int b0 = ifloor(p0 * mc.inv_bs), b1 = ifloor(p1 * mc.inv_bs), b2 = ifloor(p2 * mc.inv_bs);
-    if (b0 != cb0 || b1 != cb1 || b2 != cb2) {
-      cb0 = b0;
-      cb1 = b1;
-      cb2 = b2;
-      cfree = false;
-      if (!in_workspace(mc, b0, b1, b2)) {
-        cslot = -1;  // blocks are only ever allocated inside the workspace bounds
-      } else {
-        cslot = T.dense ? (int)T.dense[dense_cell(T, b0, b1, b2)] - 1 : hash_find(T, pack_key(b0, b1, b2));
-        if (cslot >= 0) cfree = T.block_free[cslot] != 0;
-      }
+  int i = 0;
+  // fast-forward: before the padded bounds every sample is unobserved and (nothing observed yet) the step is trunc
+  if (t_exit >= 0.0f)
+    while (i < mc.st_max_steps && t < mc.st_max_len && t < t_enter) {
+      t += mc.trunc;
+      ++i;
     }
+
+  while (!done) {
+    // this lane's sample: the march position after k further trunc-steps
+    float tk = t;
+    for (int j = 0; j < k; ++j) tk += mc.trunc;
+    const float tk_next_guess = tk + mc.trunc;  // == lane k+1's tk
+    const float p0 = o[0] + tk * dL[0], p1 = o[1] + tk * dL[1], p2 = o[2] + tk * dL[2];
+    const int b0 = ifloor(p0 * mc.inv_bs), b1 = ifloor(p1 * mc.inv_bs), b2 = ifloor(p2 * mc.inv_bs);
     bool valid = false;
     float D = 0.0f;
-    if (cfree) {
-      valid = true;
-      D = mc.trunc;
-    } else if (cslot >= 0) {
-      int q0 = ifloor((p0 - (float)b0 * mc.bs) * mc.inv_v), q1 = ifloor((p1 - (float)b1 * mc.bs) * mc.inv_v),
-          q2 = ifloor((p2 - (float)b2 * mc.bs) * mc.inv_v);
-      q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
-      q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
-      q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
-      const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)cslot * kVPB + ((q0 * 8 + q1) * 8 + q2)];
-      if (dw.y > 1e-4f) {
-        valid = true;
-        D = dw.x;
+    if (in_workspace(mc, b0, b1, b2)) {  // blocks are only ever allocated inside the workspace bounds
+      const int slot = T.dense ? (int)T.dense[dense_cell(T, b0, b1, b2)] - 1 : hash_find(T, pack_key(b0, b1, b2));
+      if (slot >= 0) {
+        if (T.block_free[slot]) {
+          valid = true;
+          D = mc.trunc;
+        } else {
+          int q0 = ifloor((p0 - (float)b0 * mc.bs) * mc.inv_v), q1 = ifloor((p1 - (float)b1 * mc.bs) * mc.inv_v),
+              q2 = ifloor((p2 - (float)b2 * mc.bs) * mc.inv_v);
+          q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
+          q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
+          q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
+          const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)slot * kVPB + ((q0 * 8 + q1) * 8 + q2)];
+          if (dw.y > 1e-4f) {
+            valid = true;
+            D = dw.x;
+          }
+        }
       }
     }
-    float step;
-    if (!valid) {
-      if (last_pos || t > t_exit) break;
-      step = mc.trunc;
-    } else if (D < mc.st_eps) {
-      if (last_pos) {
-        t = t + D;
+    const bool pos = valid && !(D < mc.st_eps);  // a sample that sets "previous sample was a valid positive distance"
+    const unsigned mpos = (unsigned)((__ballot(pos) >> gshift) & 0xffffu);
+    const bool last_pos_k = last_pos || (mpos & ((1u << k) - 1u)) != 0u;
+    const bool bound = !((i + k) < mc.st_max_steps && tk < mc.st_max_len);
+    const bool fail_unobserved = !valid && (last_pos_k || tk > t_exit);
+    const bool surface = valid && D < mc.st_eps;
+    const float tnext = tk + (valid ? D : mc.trunc);
+    const bool deviate = pos && !(tnext == tk_next_guess);
+    const unsigned mev = (unsigned)((__ballot(bound || fail_unobserved || surface || deviate) >> gshift) & 0xffffu);
+    if (mev == 0u) {  // 16 plain trunc-steps
+      t = __shfl(tnext, gshift + kRayLanes - 1, 64);
+      i += kRayLanes;
+      last_pos = last_pos || mpos != 0u;
+      continue;
+    }
+    const int e = __ffs(mev) - 1;  // first lane whose sample ends the run
+    const int src = gshift + e;
+    const bool e_bound = __shfl((int)bound, src, 64) != 0;
+    const bool e_fail = __shfl((int)fail_unobserved, src, 64) != 0;
+    const bool e_surface = __shfl((int)surface, src, 64) != 0;
+    const bool e_last = __shfl((int)last_pos_k, src, 64) != 0;
+    const float e_tk = __shfl(tk, src, 64), e_D = __shfl(D, src, 64), e_tnext = __shfl(tnext, src, 64);
+    if (e_bound || e_fail) {
+      done = true;
+    } else if (e_surface) {
+      if (e_last) {
+        t = e_tk + e_D;
         ok = true;
       }
-      break;
-    } else {
-      step = D;
+      done = true;
+    } else {  // a positive distance other than trunc: resume the march from there
+      t = e_tnext;
+      i += e + 1;
       last_pos = true;
     }
-    t += step;
   }
-  synth[idx] = ok ? t * dC[2] : -1.0f;
+  if (k == 0) synth[idx] = ok ? t * dC[2] : -1.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -350,10 +382,10 @@ void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam&
 
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
                          int Hs, hipStream_t s) {
-  const int tiles_x = (Ws + 7) / 8, tiles_y = (Hs + 7) / 8;
-  const int n = tiles_x * tiles_y;
+  const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
+  const int n = patches_x * patches_y;
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(64), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, tiles_x);
+  hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
 }
 
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
