@@ -189,7 +189,11 @@ def main():
         tsdf_blocks_per_frame = stats["tsdf_blocks_updated"] / max(stats["depth_frames"], 1)
         # algorithmic bytes of one k_feature_integrate launch:
         #   feature image f16 + mask u8, each pixel once; feature voxel (C x f16 + f32 weight) read + written per block
+        col_blocks_per_frame = stats["color_blocks_updated"] / max(stats["color_frames"], 1)
         bytes_per_launch = cfg.height * cfg.width * (2 * C + 1) + feat_blocks_per_frame * 512 * 2 * (2 * C + 4)
+        # integrate_frame launches the colour and the feature update as ONE kernel (k_app_integrate2): add the colour
+        # image (3 B/pixel + mask) and the colour voxels (8 B read + 8 B written)
+        bytes_per_launch += cfg.height * cfg.width * (3 + 1) + col_blocks_per_frame * 512 * 16
         feat_ms, feat_n = prof["feature"]
         roofline = None
         if feat_n > 0 and feat_ms > 0:
@@ -197,7 +201,7 @@ def main():
             achieved = bytes_per_launch / avg_s
             roofline = {
                 "bound": "hbm",
-                "kernel": "k_feature_integrate",
+                "kernel": "k_app_integrate2 (feature + colour update, one launch)",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                 "unit": "GB/s",
@@ -207,8 +211,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "feature_blocks_per_launch": feat_blocks_per_frame,
             }
-        frame_bytes = (cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + bytes_per_launch
-                       + cfg.height * cfg.width * 3 + stats["color_blocks_updated"] / max(stats["color_frames"], 1) * 512 * 16)
+        frame_bytes = cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + bytes_per_launch
         cpu = None
         if args.cpu_sample > 0:
             cpu = cpu_baseline(cfg, mcfg, frames, C, min(args.cpu_sample, n_frames))

@@ -498,6 +498,7 @@ int app_alloc(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, cons
     ProfScope ps(h, MMF_K_ALLOC, s);
     KeySrc ks{};
     ks.mode = 1;
+    ks.n_live = m.tsdf.d.ctr;
     launch_compact_alloc(L.d, ks, m.sc[which], m.tsdf.d.cap, m.stats, stat_upd, stat_new, s);
   }
   return MMF_OK;
@@ -782,6 +783,108 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
   Rigid T_L_C, T_C_L;
   rigid_from_T(T16, T_L_C);
   rigid_inverse(T_L_C, T_C_L);
+
+  if (!fork) {
+    // ---- in-order path with horizontally fused launches (default) --------------------------------------------
+    //   1  raycast tiles            | mask row pass
+    //   2  TSDF allocation (1 WG)   | mask column pass          (k_alloc_jobs)
+    //   3  TSDF update
+    //   4  candidate selection (once: colour and feature camera coincide)
+    //   5  sphere trace
+    //   6  colour allocation | feature allocation              (k_alloc_jobs, 2 WGs)
+    //   7  colour update     | feature update                  (k_app_integrate2)
+    MaskJob M;
+    const bool packed = make_mask_job(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
+                                      feature_mask_out, m->mask_tmp, M);
+    ViewGrid vg;
+    MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
+    const int ncells = vg.nx * vg.ny * vg.nz;
+    const bool fusable = packed && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
+    if (!fusable) {
+      // odd shapes / very large grids: the plain sequence of stand-alone launches
+      launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
+                         feature_mask_out, m->mask_tmp, s);
+      MMF_TRY(depth_chain(h, *m, depth, input_mask, min_depth_m, cam, T_L_C, T_C_L, s));
+      m->frames[1]++;
+      MMF_TRY(app_alloc(h, *m, 1, m->color, cam, T_C_L, 4, -1, s));
+      MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, s));
+      launch_color_integrate(m->color.d, m->mc, cam, T_C_L, rgb, depth_mask_out, m->synth, m->synth_W, m->synth_H, m->sc[1],
+                             m->color.d.cap, s);
+      m->frames[2]++;
+      MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
+      launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
+                               m->synth_H, m->sc[2], m->feat.d.cap, s);
+      return check_launch();
+    }
+    m->last_vg = vg;
+    m->frames[0]++;
+    m->frames[1]++;
+    m->frames[2]++;
+    m->tsdf_epoch++;
+    m->touched = true;
+    MMF_TRY(ensure_scratch(*m, 0, ncells));
+    const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
+    {
+      ProfScope ps(h, MMF_K_RAYCAST, s);
+      launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, s);
+    }
+    {
+      ProfScope ps(h, MMF_K_ALLOC, s);
+      KeySrc ks{};
+      ks.mode = 0;
+      ks.ox = vg.ox;
+      ks.oy = vg.oy;
+      ks.oz = vg.oz;
+      ks.ny = vg.ny;
+      ks.nz = vg.nz;
+      AllocJob job;
+      job.L = m->tsdf.d;
+      job.ks = ks;
+      job.sc = m->sc[0];
+      job.ncells = ncells;
+      job.stat_upd = 1;
+      job.stat_new = 2;
+      launch_alloc_jobs(&job, 1, m->stats, &M, s);
+    }
+    {
+      ProfScope ps(h, MMF_K_TSDF, s);
+      launch_tsdf_integrate(m->tsdf.d, m->mc, cam, T_C_L, depth, input_mask, min_depth_m, m->sc[0],
+                            ncells < m->tsdf.d.cap ? ncells : m->tsdf.d.cap, s);
+    }
+    {
+      ProfScope ps(h, MMF_K_CANDIDATES, s);
+      launch_app_candidates(m->tsdf.d, m->mc, cam, T_C_L, m->sc[1].flags, m->sc[1].cell_key, s);
+    }
+    MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, s));
+    {
+      ProfScope ps(h, MMF_K_ALLOC, s);
+      KeySrc ks{};
+      ks.mode = 1;
+      ks.n_live = m->tsdf.d.ctr;
+      AllocJob jobs[2];
+      jobs[0].L = m->color.d;
+      jobs[0].ks = ks;
+      jobs[0].sc = m->sc[1];
+      jobs[0].ncells = m->tsdf.d.cap;
+      jobs[0].stat_upd = 4;
+      jobs[0].stat_new = -1;
+      jobs[1].L = m->feat.d;
+      jobs[1].ks = ks;
+      jobs[1].sc = m->sc[2];
+      jobs[1].sc.flags = m->sc[1].flags;  // same camera: one candidate selection serves both layers
+      jobs[1].sc.cell_key = m->sc[1].cell_key;
+      jobs[1].ncells = m->tsdf.d.cap;
+      jobs[1].stat_upd = 6;
+      jobs[1].stat_new = 7;
+      launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
+    }
+    {
+      ProfScope ps(h, MMF_K_FEATURE, s);
+      launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, s);
+    }
+    return check_launch();
+  }
 
   // fork: masks on side stream A while the TSDF chain runs on the caller's stream
   HIP_TRY(record(0, s));

@@ -104,6 +104,15 @@ struct KeySrc {
   const int* n_live;
 };
 
+// One compaction + allocation job (flags -> ordered candidate list, new blocks inserted) for one layer.
+struct AllocJob {
+  LayerDev L;
+  KeySrc ks;
+  Scratch sc;
+  int ncells;
+  int stat_upd, stat_new;  // indices into the mapper's statistics array (-1: none)
+};
+
 __host__ __device__ inline u64 pack_key(int x, int y, int z) {
   return ((u64)(unsigned)(x + kKeyOff) << 42) | ((u64)(unsigned)(y + kKeyOff) << 21) | (u64)(unsigned)(z + kKeyOff);
 }

@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
       hit = 1;
     }
     const int any = __syncthreads_or(hit);
-    if (any && threadIdx.x == 0) {
-      flags[i] = 1;
-      cell_key[i] = key;
+    if (threadIdx.x == 0) {
+      flags[i] = any ? 1 : 0;
+      if (any) cell_key[i] = key;
     }
   }
 }
@@ -207,49 +207,75 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
 }
 
 // ------------------------------------------------------------------------------------------------
-// Colour: voxel = {uchar4 rgb_, float w} (8 B); one workgroup of 512 threads per block.
+// Colour: voxel = {uchar4 rgb_, float w} (8 B); one workgroup of 256 threads per block, 2 voxels (16 B) per thread.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_color_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
-                                                        const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ mask,
-                                                        const float* __restrict__ synth, int Ws, int Hs, Scratch sc) {
-  const int n = *sc.cand_count;
+struct AppArgs {
+  LayerDev L;
+  Cam cam;
+  Rigid T_C_L;
+  const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]
+  const uint8_t* mask;
+  Scratch sc;
+};
+
+__device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs, int bid,
+                                  int nb) {
+  const LayerDev& L = A.L;
+  const Cam& cam = A.cam;
+  const uint8_t* __restrict__ rgb = reinterpret_cast<const uint8_t*>(A.image);
+  const int n = *A.sc.cand_count;
   const int chunk = (n + 7) >> 3;
-  const int lin = threadIdx.x;
-  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+  for (int j = bid; j < chunk * 8; j += nb) {
     const int i = xcd_candidate(j, chunk);
     if (i >= n) continue;
-    const int slot = sc.cand_slot[i];
+    const int slot = A.sc.cand_slot[i];
     if (slot < 0) continue;
-    const bool is_new = sc.cand_new[i] != 0;
+    const bool is_new = A.sc.cand_new[i] != 0;
     int bx, by, bz;
-    unpack_key(sc.cand_key[i], bx, by, bz);
-    uint2* vox = reinterpret_cast<uint2*>(L.pool) + (size_t)slot * kVPB + lin;
-    uint2 e = is_new ? make_uint2(0u, 0u) : *vox;
-    int x0, y0;
-    float wx, wy;
+    unpack_key(A.sc.cand_key[i], bx, by, bz);
+    uint4* vox2 = reinterpret_cast<uint4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x;
+    uint4 e2 = is_new ? make_uint4(0u, 0u, 0u, 0u) : *vox2;
     bool upd = false;
-    if (app_gate(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
-      const uint8_t* t00 = rgb + ((size_t)y0 * cam.W + x0) * 3;
-      const uint8_t* t10 = t00 + 3;
-      const uint8_t* t01 = t00 + (size_t)cam.W * 3;
-      const uint8_t* t11 = t01 + 3;
-      const float Wv = __uint_as_float(e.y);
-      const float wm = mc.app_wm;
-      const float inv = 1.0f / (Wv + wm);
-      unsigned out = 0;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
-        const float A = (float)((e.x >> (8 * k)) & 0xffu);
-        const float An = (A * Wv + a * wm) * inv;
-        out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
+    for (int r = 0; r < 2; ++r) {
+      const int lin = threadIdx.x * 2 + r;
+      unsigned ex = r ? e2.z : e2.x, ey = r ? e2.w : e2.y;
+      int x0, y0;
+      float wx, wy;
+      if (app_gate(mc, cam, A.T_C_L, A.mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
+        const uint8_t* t00 = rgb + ((size_t)y0 * cam.W + x0) * 3;
+        const uint8_t* t10 = t00 + 3;
+        const uint8_t* t01 = t00 + (size_t)cam.W * 3;
+        const uint8_t* t11 = t01 + 3;
+        const float Wv = __uint_as_float(ey);
+        const float wm = mc.app_wm;
+        const float inv = 1.0f / (Wv + wm);
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
+          const float Aold = (float)((ex >> (8 * k)) & 0xffu);
+          const float An = (Aold * Wv + a * wm) * inv;
+          out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
+        }
+        ex = out;
+        ey = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
+        upd = true;
       }
-      e.x = out;
-      e.y = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
-      upd = true;
+      if (r) {
+        e2.z = ex;
+        e2.w = ey;
+      } else {
+        e2.x = ex;
+        e2.y = ey;
+      }
     }
-    if (upd || is_new) *vox = e;
+    if (upd || is_new) *vox2 = e2;
   }
+}
+
+__global__ __launch_bounds__(256) void k_color_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws, int Hs) {
+  color_body(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,15 +289,27 @@ __global__ __launch_bounds__(512) void k_color_integrate(LayerDev L, MapConsts m
 //            Image taps are HWC f16, so each tap piece is one contiguous 128 B line.
 // HBM-bound: algorithmic traffic = feature image once + (2C+4) B read and written per touched voxel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_feature_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
-                                                          const __half* __restrict__ feat,
-                                                          const uint8_t* __restrict__ mask,
-                                                          const float* __restrict__ synth, int Ws, int Hs, Scratch sc) {
-  __shared__ uint16_t s_lin[kVPB];
-  __shared__ uint32_t s_pix[kVPB];
-  __shared__ float s_wx[kVPB], s_wy[kVPB], s_W[kVPB];
-  __shared__ uint8_t s_valid[kVPB];
-  __shared__ int s_n;
+struct FeatLds {
+  uint16_t lin[kVPB];
+  uint32_t pix[kVPB];
+  float wx[kVPB], wy[kVPB], W[kVPB];
+  uint8_t valid[kVPB];
+  int n;
+};
+
+__device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
+                                    int bid, int nb, FeatLds& S) {
+  const LayerDev& L = A.L;
+  const Cam& cam = A.cam;
+  const Rigid& T_C_L = A.T_C_L;
+  const __half* __restrict__ feat = reinterpret_cast<const __half*>(A.image);
+  const uint8_t* __restrict__ mask = A.mask;
+  const Scratch& sc = A.sc;
+  uint16_t* s_lin = S.lin;
+  uint32_t* s_pix = S.pix;
+  float *s_wx = S.wx, *s_wy = S.wy, *s_W = S.W;
+  uint8_t* s_valid = S.valid;
+  int& s_n = S.n;
 
   const int n = *sc.cand_count;
   const int chunk = (n + 7) >> 3;
@@ -280,7 +318,7 @@ __global__ __launch_bounds__(256) void k_feature_integrate(LayerDev L, MapConsts
   const int group = tid >> 3, gl = tid & 7;
   const float wm = mc.app_wm;
 
-  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+  for (int j = bid; j < chunk * 8; j += nb) {
     const int i = xcd_candidate(j, chunk);
     if (i >= n) continue;
     const int slot = sc.cand_slot[i];
@@ -366,6 +404,23 @@ __global__ __launch_bounds__(256) void k_feature_integrate(LayerDev L, MapConsts
   }
 }
 
+__global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws,
+                                                          int Hs) {
+  __shared__ FeatLds S;
+  feature_body(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+}
+
+// Horizontal fusion: colour and feature update of one frame in ONE launch (different layers, same TSDF / synthetic
+// depth inputs): the first g_col workgroups walk the colour candidates, the rest the feature candidates.
+__global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth,
+                                                       int Ws, int Hs, int g_col) {
+  __shared__ FeatLds S;
+  if ((int)blockIdx.x < g_col)
+    color_body(Acol, mc, synth, Ws, Hs, blockIdx.x, g_col);
+  else
+    feature_body(Afeat, mc, synth, Ws, Hs, (int)blockIdx.x - g_col, (int)gridDim.x - g_col, S);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
@@ -388,18 +443,39 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
 }
 
+static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
+                             const Scratch& sc) {
+  AppArgs A;
+  A.L = L;
+  A.cam = cam;
+  A.T_C_L = T_C_L;
+  A.image = image;
+  A.mask = mask;
+  A.sc = sc;
+  return A;
+}
+
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s) {
-  hipLaunchKernelGGL(k_color_integrate, dim3(grid8(max_cand, 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, rgb, mask, synth, Ws,
-                     Hs, sc);
+  hipLaunchKernelGGL(k_color_integrate, dim3(grid8(max_cand, 8192)), dim3(256), 0, s, make_app_args(L, cam, T_C_L, rgb, mask, sc), mc,
+                     synth, Ws, Hs);
 }
 
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                               hipStream_t s) {
-  hipLaunchKernelGGL(k_feature_integrate, dim3(grid8(max_cand, 8192)), dim3(256), 0, s, L, mc, cam, T_C_L, feat, mask, synth,
-                     Ws, Hs, sc);
+  hipLaunchKernelGGL(k_feature_integrate, dim3(grid8(max_cand, 8192)), dim3(256), 0, s, make_app_args(L, cam, T_C_L, feat, mask, sc),
+                     mc, synth, Ws, Hs);
+}
+
+// colour + feature update in one launch
+void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
+                           const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
+                           const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, hipStream_t s) {
+  const int g = grid8(max_cand, 4096);
+  hipLaunchKernelGGL(k_app_integrate2, dim3(2 * g), dim3(256), 0, s, make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
+                     make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc), mc, synth, Ws, Hs, g);
 }
 
 }  // namespace mmf

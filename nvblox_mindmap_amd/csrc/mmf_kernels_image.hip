@@ -2,6 +2,7 @@
 // depth back-projection, mask erosion / feature-mask algebra, feature-map upsample+pad+cast.
 // gfx950 / wave64.  All of these are pure streaming kernels bound by HBM bandwidth.
 #include "mmf_launch.h"
+#include "mmf_mask_device.h"
 
 namespace mmf {
 
@@ -151,98 +152,16 @@ __global__ __launch_bounds__(256) void k_depth_mask(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bit-packed mask algebra (fast path of integrate_frame's masks, nvblox_mapping_helpers.py:201-253).
-// Row pass: one workgroup per image row; every wave ballots 64 pixels into a 64-bit word for each of
-// the two "bad pixel" predicates (input mask == 0, !(depth > min_d)), the words of the row are dilated
-// horizontally by k with shifts across word boundaries and stored as [H][nw] u64 bit-rows.  It can also
-// emit depth_mask = input_mask & (depth > min_d) on the way (the same bytes are already in registers).
-// Column pass: one workgroup per OUTPUT row; the first 2*nw threads OR the bit-rows of the 2k+1 source
-// rows, then all threads expand bits to bytes with the nearest-neighbour upsample and the border mask.
+// Bit-packed mask algebra (fast path of integrate_frame's masks): bodies in mmf_mask_device.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMaxMaskWords = 64;  // rows up to 4096 pixels
-
-__device__ inline u64 row_word(const u64* w, int j, int nw) { return (j >= 0 && j < nw) ? w[j] : 0ull; }
-
-__global__ __launch_bounds__(1024) void k_mask_rowbits(const uint8_t* __restrict__ mask, const float* __restrict__ depth,
-                                                      float min_d, int H, int W, int nw, int k0, int k1,
-                                                      u64* __restrict__ bits_in, u64* __restrict__ bits_d,
-                                                      uint8_t* __restrict__ depth_mask_out) {
+__global__ __launch_bounds__(1024) void k_mask_rowbits(MaskJob J) {
   __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
-  const int y = blockIdx.x;
-  const int lane = threadIdx.x & 63;
-  // blockDim covers the whole row for W <= 1024 (one pass, every load of the row in flight at once)
-  for (int x0 = 0; x0 < nw * 64; x0 += blockDim.x) {
-    const int x = x0 + threadIdx.x;
-    bool bad_in = false, bad_d = false;
-    if (x < W) {
-      const size_t i = (size_t)y * W + x;
-      bad_in = mask ? mask[i] == 0 : false;
-      bad_d = depth ? !(depth[i] > min_d) : false;
-      if (depth_mask_out) depth_mask_out[i] = (!bad_in && !bad_d) ? 1 : 0;
-    }
-    const u64 b_in = __ballot(bad_in), b_d = __ballot(bad_d);
-    if (lane == 0 && (x >> 6) < nw) {
-      s_in[x >> 6] = b_in;
-      s_d[x >> 6] = b_d;
-    }
-  }
-  __syncthreads();
-  // horizontal dilation: bit x of the result = OR of bits [x-k, x+k]
-  for (int j = threadIdx.x; j < 2 * nw; j += blockDim.x) {
-    const bool second = j >= nw;
-    const int w = second ? j - nw : j;
-    const u64* src = second ? s_d : s_in;
-    const int k = second ? k1 : k0;
-    u64 r = src[w];
-    for (int s = 1; s <= k; ++s) {
-      const int q = s >> 6, sh = s & 63;  // shift by s = q words + sh bits
-      u64 left = row_word(src, w - q, nw) << sh;
-      if (sh) left |= row_word(src, w - q - 1, nw) >> (64 - sh);
-      u64 right = row_word(src, w + q, nw) >> sh;
-      if (sh) right |= row_word(src, w + q + 1, nw) << (64 - sh);
-      r |= left | right;
-    }
-    (second ? bits_d : bits_in)[(size_t)y * nw + w] = r;
-  }
+  mask_rowbits_row(J, blockIdx.x, s_in, s_d);
 }
 
-__global__ __launch_bounds__(256) void k_mask_colemit(const u64* __restrict__ bits_in, const u64* __restrict__ bits_d, int H,
-                                                     int W, int nw, int k0, int k1, int Hf, int Wf, float sh, float sw,
-                                                     int bh, int bw, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_mask_colemit(MaskJob J) {
   __shared__ u64 s_bad[kMaxMaskWords];
-  const int yf = blockIdx.x;
-  const bool row_ok = (bh <= 0 || bw <= 0) || (yf >= bh && yf < Hf - bh);
-  if (row_ok) {  // block-uniform
-    int ys = (int)floorf((float)yf * sh);
-    ys = ys > H - 1 ? H - 1 : ys;
-    for (int j = threadIdx.x; j < nw; j += 256) s_bad[j] = 0ull;
-    __syncthreads();
-    // vertical OR of the 2k+1 source bit-rows, spread over all threads: thread -> (word, row phase)
-    const int groups = 256 / nw > 0 ? 256 / nw : 1;
-    const int j = threadIdx.x % nw, g = threadIdx.x / nw;
-    if (g < groups) {
-      u64 r = 0;
-      {
-        const int lo = ys - k0 < 0 ? 0 : ys - k0, hi = ys + k0 > H - 1 ? H - 1 : ys + k0;
-        for (int yy = lo + g; yy <= hi; yy += groups) r |= bits_in[(size_t)yy * nw + j];
-      }
-      {
-        const int lo = ys - k1 < 0 ? 0 : ys - k1, hi = ys + k1 > H - 1 ? H - 1 : ys + k1;
-        for (int yy = lo + g; yy <= hi; yy += groups) r |= bits_d[(size_t)yy * nw + j];
-      }
-      if (r) atomicOr(&s_bad[j], r);
-    }
-    __syncthreads();
-  }
-  for (int xf = threadIdx.x; xf < Wf; xf += 256) {
-    uint8_t res = 0;
-    if (row_ok && ((bh <= 0 || bw <= 0) || (xf >= bw && xf < Wf - bw))) {
-      int xs = (int)floorf((float)xf * sw);
-      xs = xs > W - 1 ? W - 1 : xs;
-      res = ((s_bad[xs >> 6] >> (xs & 63)) & 1ull) ? 0 : 1;
-    }
-    out[(size_t)yf * Wf + xf] = res;
-  }
+  mask_colemit_row(J, blockIdx.x, s_bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,27 +230,51 @@ void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, i
   launch_frame_masks(input_mask, depth, H, W, min_d, k_in, k_depth, border_percent, Hf, Wf, nullptr, out, tmp, s);
 }
 
+// Fill the job descriptor of the bit-packed path; returns false if the image does not fit it (then the byte
+// kernels are used).  `tmp` holds H*W bytes.
+bool make_mask_job(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
+                   int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
+                   MaskJob& J) {
+  const int nw = (W + 63) / 64;
+  if (!(nw <= kMaxMaskWords && (size_t)2 * H * nw * sizeof(u64) <= (size_t)H * W && ((uintptr_t)tmp % 8 == 0))) return false;
+  J.mask = input_mask;
+  J.depth = depth;
+  J.min_d = min_d;
+  J.H = H;
+  J.W = W;
+  J.nw = nw;
+  J.k0 = k_in;
+  J.k1 = k_depth;
+  J.bits_in = reinterpret_cast<u64*>(tmp);
+  J.bits_d = J.bits_in + (size_t)H * nw;
+  J.depth_mask_out = depth_mask_out;
+  J.Hf = Hf;
+  J.Wf = Wf;
+  J.sh = (float)H / (float)Hf;
+  J.sw = (float)W / (float)Wf;
+  // int(mask_border_percent * 0.01 * height) in Python double arithmetic (image_mask_operations.py:62-63)
+  J.bh = (int)((double)border_percent * 0.01 * (double)Hf);
+  J.bw = (int)((double)border_percent * 0.01 * (double)Wf);
+  J.out = feature_mask_out;
+  return true;
+}
+
 // depth_mask_out (optional) and the feature mask in two launches.  `tmp` holds H*W bytes.
 void launch_frame_masks(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
                         int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
                         hipStream_t s) {
-  // int(mask_border_percent * 0.01 * height) in Python double arithmetic (image_mask_operations.py:62-63)
-  const int bh = (int)((double)border_percent * 0.01 * (double)Hf);
-  const int bw = (int)((double)border_percent * 0.01 * (double)Wf);
-  const float sh = (float)H / (float)Hf, sw = (float)W / (float)Wf;
-  const int nw = (W + 63) / 64;
-  const bool packed = nw <= kMaxMaskWords && (size_t)2 * H * nw * sizeof(u64) <= (size_t)H * W && ((uintptr_t)tmp % 8 == 0);
-  if (packed) {
-    u64* bits_in = reinterpret_cast<u64*>(tmp);
-    u64* bits_d = bits_in + (size_t)H * nw;
-    const int rb_threads = nw * 64 < 1024 ? nw * 64 : 1024;
-    hipLaunchKernelGGL(k_mask_rowbits, dim3(H), dim3(rb_threads), 0, s, input_mask, depth, min_d, H, W, nw, k_in, k_depth, bits_in,
-                       bits_d, depth_mask_out);
-    hipLaunchKernelGGL(k_mask_colemit, dim3(Hf), dim3(256), 0, s, (const u64*)bits_in, (const u64*)bits_d, H, W, nw, k_in, k_depth,
-                       Hf, Wf, sh, sw, bh, bw, feature_mask_out);
+  MaskJob J;
+  if (make_mask_job(input_mask, depth, H, W, min_d, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out, feature_mask_out, tmp,
+                    J)) {
+    const int rb_threads = J.nw * 64 < 1024 ? J.nw * 64 : 1024;
+    hipLaunchKernelGGL(k_mask_rowbits, dim3(H), dim3(rb_threads), 0, s, J);
+    hipLaunchKernelGGL(k_mask_colemit, dim3(Hf), dim3(256), 0, s, J);
     return;
   }
   // generic byte path (very narrow or very wide images)
+  const int bh = (int)((double)border_percent * 0.01 * (double)Hf);
+  const int bw = (int)((double)border_percent * 0.01 * (double)Wf);
+  const float sh = (float)H / (float)Hf, sw = (float)W / (float)Wf;
   if (depth_mask_out) launch_depth_mask(input_mask, depth, H, W, min_d, depth_mask_out, s);
   dim3 g((W + 255) / 256, H);
   hipLaunchKernelGGL(k_rowpass, g, dim3(256), 0, s, input_mask, depth, min_d, H, W, k_in, k_depth, tmp);

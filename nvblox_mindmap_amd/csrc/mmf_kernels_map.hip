@@ -6,6 +6,7 @@
 // mindmap/mapping/helpers/nvblox_mapping_helpers.py:207-209 and
 // mindmap/mapping/isaaclab_nvblox_mapper.py:252-258.
 #include "mmf_launch.h"
+#include "mmf_mask_device.h"
 
 namespace mmf {
 
@@ -71,11 +72,29 @@ __device__ inline void walk_step(Walk& w) {
 // byte per DISTINCT cell: the hot loop issues no global stores at all.
 constexpr int kRaycastLdsCells = 32768;
 
+struct RaycastJob {
+  MapConsts mc;
+  Cam cam;
+  Rigid T_L_C;
+  const float* depth;
+  const uint8_t* mask;
+  float min_d;
+  int sub, Wsub, Hsub;
+  ViewGrid vg;
+  uint8_t* flags;
+};
+
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rigid T_L_C, const float* __restrict__ depth,
-                                                     const uint8_t* __restrict__ mask, float min_d, int sub, int Wsub,
-                                                     int Hsub, ViewGrid vg, uint8_t* __restrict__ flags) {
-  extern __shared__ unsigned s_words[];  // LDSFLAGS: ceil(ncells/4) words of 4 byte flags
+__device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_words) {
+  const MapConsts& mc = R.mc;
+  const Cam& cam = R.cam;
+  const Rigid& T_L_C = R.T_L_C;
+  const float* __restrict__ depth = R.depth;
+  const uint8_t* __restrict__ mask = R.mask;
+  const float min_d = R.min_d;
+  const int sub = R.sub, Wsub = R.Wsub, Hsub = R.Hsub;
+  const ViewGrid& vg = R.vg;
+  uint8_t* __restrict__ flags = R.flags;
   uint8_t* s_flags = reinterpret_cast<uint8_t*>(s_words);
   const int ncells = vg.nx * vg.ny * vg.nz;
   const int nwords = (ncells + 3) >> 2;
@@ -85,7 +104,7 @@ __global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rig
   }
   // one wave = one 8x8 tile of (subsampled) pixels: neighbouring rays traverse the same blocks
   const int tiles_x = (Wsub + 7) >> 3;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tile = bid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int cs = (tile % tiles_x) * 8 + (lane & 7), rs = (tile / tiles_x) * 8 + (lane >> 3);
   bool active = cs < Wsub && rs < Hsub;
   int r = rs * sub, c = cs * sub;
@@ -132,6 +151,24 @@ __global__ __launch_bounds__(256) void k_raycast_mark(MapConsts mc, Cam cam, Rig
   }
 }
 
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256) void k_raycast_mark(RaycastJob R) {
+  extern __shared__ unsigned s_words[];  // LDSFLAGS: ceil(ncells/4) words of 4 byte flags
+  raycast_body<LDSFLAGS>(R, blockIdx.x, s_words);
+}
+
+// Horizontal fusion: the raycast tiles and the row pass of the frame's mask job in ONE launch (independent work:
+// both only read the depth image / input mask).
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M) {
+  extern __shared__ unsigned s_words[];
+  __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
+  if ((int)blockIdx.x < n_ray_wgs)
+    raycast_body<LDSFLAGS>(R, blockIdx.x, s_words);
+  else
+    mask_rowbits_row(M, (int)blockIdx.x - n_ray_wgs, s_in, s_d);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. Flag compaction + hash lookup / insertion (shared by TSDF, colour and feature allocation).
 //    count tiles -> scan tiles -> emit.  A tile is 1024 cells (256 threads x 4 flag bytes).
@@ -155,6 +192,10 @@ __device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
 
 __global__ __launch_bounds__(256) void k_count_tiles(LayerDev L, KeySrc ks, Scratch sc, int ncells) {
   __shared__ int lds[10];
+  if (ks.mode == 1) {
+    const int nl = *ks.n_live;
+    ncells = ncells < nl ? ncells : nl;
+  }
   const int cell0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   uint32_t f4 = 0;
   if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
@@ -162,7 +203,7 @@ __global__ __launch_bounds__(256) void k_count_tiles(LayerDev L, KeySrc ks, Scra
   if (f4) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if ((f4 >> (8 * k)) & 0xffu) {
+      if (((f4 >> (8 * k)) & 0xffu) && cell0 + k < ncells) {
         int cell = cell0 + k;
         int slot = layer_lookup(L, cell_key(ks, sc, cell));
         sc.cell_slot[cell] = slot;
@@ -223,9 +264,16 @@ __global__ __launch_bounds__(256) void k_scan_tiles(LayerDev L, Scratch sc, int 
 
 __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc, int ncells) {
   __shared__ int lds[10];
+  if (ks.mode == 1) {
+    const int nl = *ks.n_live;
+    ncells = ncells < nl ? ncells : nl;
+  }
   const int cell0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   uint32_t f4 = 0;
   if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (cell0 + k >= ncells) f4 &= ~(0xffu << (8 * k));  // stale flags beyond the live count
   int slot4[4];
   int nf = 0, nn = 0;
   if (f4) {
@@ -267,18 +315,23 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
     sc.cand_new[pos] = is_new ? 1 : 0;
     pos++;
   }
-  *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // leave the flag array all-zero for the next frame
+  if (ks.mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
 }
 
 
 // Small cell counts (bounded workspaces: a few thousand cells): count + scan + emit fused into ONE launch
 // of one 1024-thread workgroup, 4096 cells per pass with a running carry.  Same candidate order, same
 // slot assignment as the three-kernel path.
-__global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scratch sc, int ncells, long long* stats,
-                                                     int stat_upd, int stat_new) {
-  __shared__ int lds[34];
-  __shared__ int carry[2];
-  __shared__ int ctx[4];
+__device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx) {
+  const LayerDev& L = J.L;
+  const KeySrc& ks = J.ks;
+  const Scratch& sc = J.sc;
+  const int stat_upd = J.stat_upd, stat_new = J.stat_new;
+  int ncells = J.ncells;
+  if (ks.mode == 1) {  // list cells: only the producer's live positions carry meaningful flags
+    const int nl = *ks.n_live;
+    ncells = ncells < nl ? ncells : nl;
+  }
   if (threadIdx.x == 0) {
     carry[0] = 0;
     carry[1] = 0;
@@ -287,12 +340,15 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
     ctx[2] = L.ctr[2];
     ctx[3] = L.ctr[1] + (L.cap - L.ctr[2]);  // room
   }
-  __syncthreads();
-  const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
+  // no barrier here: ctx / carry are first read after the barriers of the workgroup scan below, so the counter
+  // round trip of thread 0 overlaps with everyone's table loads
   for (int base = 0; base < ncells; base += 4096) {
     const int cell0 = base + threadIdx.x * 4;
     uint32_t f4 = 0;
     if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cell0 + k >= ncells) f4 &= ~(0xffu << (8 * k));  // stale flags beyond the live count
     int slot4[4] = {0, 0, 0, 0};
     u64 key4[4] = {0, 0, 0, 0};
     int nf = 0, nn = 0;
@@ -360,6 +416,7 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
     }
     int ea, eb, ta, tb;
     block_excl_scan2<16>(nf, nn, lds, ea, eb, ta, tb);
+    const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
     if (f4) {
       int pos = carry[0] + ea, rnk = carry[1] + eb;
 #pragma unroll
@@ -382,7 +439,7 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
         sc.cand_new[pos] = is_new ? 1 : 0;
         pos++;
       }
-      *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;
+      if (ks.mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -392,6 +449,7 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
     const int n_cand = carry[0], n_new = carry[1];
     const int granted = n_new < room ? n_new : room;
     if (granted < n_new) atomicOr(&L.ctr[3], 1);
@@ -404,6 +462,29 @@ __global__ __launch_bounds__(1024) void k_alloc_fused(LayerDev L, KeySrc ks, Scr
       if (stat_upd >= 0) stats[stat_upd] += n_cand;
       if (stat_new >= 0) stats[stat_new] += granted;
     }
+  }
+}
+
+
+__global__ __launch_bounds__(1024) void k_alloc_fused(AllocJob J, long long* stats) {
+  __shared__ int lds[34];
+  __shared__ int carry[2];
+  __shared__ int ctx[4];
+  alloc_job_body(J, stats, lds, carry, ctx);
+}
+
+// Horizontal fusion: up to two allocation jobs (one workgroup each) and the column pass of the frame's mask job
+// (one workgroup per output row) in ONE launch.  The roles are independent; this only removes launch boundaries.
+__global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, int njobs, long long* stats, MaskJob M,
+                                                    int mask_rows) {
+  __shared__ int lds[34];
+  __shared__ int carry[2];
+  __shared__ int ctx[4];
+  __shared__ u64 s_bad[kMaxMaskWords];
+  if ((int)blockIdx.x < njobs) {
+    alloc_job_body(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
+  } else if ((int)blockIdx.x - njobs < mask_rows) {
+    mask_colemit_row(M, (int)blockIdx.x - njobs, s_bad);
   }
 }
 
@@ -684,26 +765,66 @@ __global__ __launch_bounds__(256) void k_query_feature(LayerDev L, MapConsts mc,
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+static RaycastJob make_raycast_job(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask,
+                                   float min_d, int sub, const ViewGrid& vg, uint8_t* flags, int& n_wgs) {
+  RaycastJob R;
+  R.mc = mc;
+  R.cam = cam;
+  R.T_L_C = T_L_C;
+  R.depth = depth;
+  R.mask = mask;
+  R.min_d = min_d;
+  R.sub = sub;
+  R.Wsub = (cam.W + sub - 1) / sub;
+  R.Hsub = (cam.H + sub - 1) / sub;
+  R.vg = vg;
+  R.flags = flags;
+  const int ntiles = ((R.Wsub + 7) / 8) * ((R.Hsub + 7) / 8);
+  n_wgs = (ntiles + 3) / 4;
+  return R;
+}
+
 void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                     int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s) {
-  int Wsub = (cam.W + sub - 1) / sub, Hsub = (cam.H + sub - 1) / sub;
-  int ntiles = ((Wsub + 7) / 8) * ((Hsub + 7) / 8);
-  if (ntiles <= 0) return;
+  int n_wgs;
+  RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
+  if (n_wgs <= 0) return;
   const int ncells = vg.nx * vg.ny * vg.nz;
   if (ncells <= kRaycastLdsCells)
-    hipLaunchKernelGGL(k_raycast_mark<true>, dim3((ntiles + 3) / 4), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, mc, cam, T_L_C,
-                       depth, mask, min_d, sub, Wsub, Hsub, vg, flags);
+    hipLaunchKernelGGL(k_raycast_mark<true>, dim3(n_wgs), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R);
   else
-    hipLaunchKernelGGL(k_raycast_mark<false>, dim3((ntiles + 3) / 4), dim3(256), 0, s, mc, cam, T_L_C, depth, mask, min_d, sub, Wsub,
-                       Hsub, vg, flags);
+    hipLaunchKernelGGL(k_raycast_mark<false>, dim3(n_wgs), dim3(256), 0, s, R);
+}
+
+// raycast + mask row pass in one launch
+void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
+                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, hipStream_t s) {
+  int n_wgs;
+  RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  if (ncells <= kRaycastLdsCells)
+    hipLaunchKernelGGL(k_front<true>, dim3(n_wgs + M.H), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R, n_wgs, M);
+  else
+    hipLaunchKernelGGL(k_front<false>, dim3(n_wgs + M.H), dim3(256), 0, s, R, n_wgs, M);
 }
 
 constexpr int kFusedAllocMaxCells = 16384;
 
+static AllocJob make_alloc_job(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, int stat_upd, int stat_new) {
+  AllocJob J;
+  J.L = L;
+  J.ks = ks;
+  J.sc = sc;
+  J.ncells = ncells;
+  J.stat_upd = stat_upd;
+  J.stat_new = stat_new;
+  return J;
+}
+
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s) {
   if (ncells <= kFusedAllocMaxCells) {
-    hipLaunchKernelGGL(k_alloc_fused, dim3(1), dim3(1024), 0, s, L, ks, sc, ncells, stats, stat_upd, stat_new);
+    hipLaunchKernelGGL(k_alloc_fused, dim3(1), dim3(1024), 0, s, make_alloc_job(L, ks, sc, ncells, stat_upd, stat_new), stats);
     return;
   }
   int ntiles = (ncells + 1023) / 1024;
@@ -711,6 +832,19 @@ void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc
   hipLaunchKernelGGL(k_count_tiles, dim3(ntiles), dim3(256), 0, s, L, ks, sc, ncells);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, s, L, sc, ntiles, stats, stat_upd, stat_new);
   hipLaunchKernelGGL(k_emit, dim3(ntiles), dim3(256), 0, s, L, ks, sc, ncells);
+}
+
+bool alloc_jobs_fusable(int ncells0, int ncells1) { return ncells0 <= kFusedAllocMaxCells && ncells1 <= kFusedAllocMaxCells; }
+
+// njobs (1 or 2) allocation jobs + (optionally) the mask column pass in one launch
+void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s) {
+  MaskJob mj{};
+  int rows = 0;
+  if (M) {
+    mj = *M;
+    rows = M->Hf;
+  }
+  hipLaunchKernelGGL(k_alloc_jobs, dim3(njobs + rows), dim3(1024), 0, s, jobs[0], jobs[njobs > 1 ? 1 : 0], njobs, stats, mj, rows);
 }
 
 static inline int grid_for(int upper, int cap) {

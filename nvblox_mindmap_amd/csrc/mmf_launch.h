@@ -1,6 +1,7 @@
 // mmf_launch.h -- host-side launch interface between the C ABI (mmf_api.hip) and the kernel files.
 #pragma once
 #include "mmf_device.h"
+#include "mmf_mask_device.h"
 
 namespace mmf {
 
@@ -14,6 +15,10 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
                     int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s);
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s);
+void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
+                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, hipStream_t s);
+bool alloc_jobs_fusable(int ncells0, int ncells1);
+void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s);
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
@@ -38,6 +43,10 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                               hipStream_t s);
 
+void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
+                           const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
+                           const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, hipStream_t s);
+
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,
                        hipStream_t s);
@@ -52,6 +61,9 @@ void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, i
 void launch_frame_masks(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
                         int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
                         hipStream_t s);
+bool make_mask_job(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
+                   int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
+                   MaskJob& J);
 void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s);
 void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s);
 

@@ -1,0 +1,110 @@
+// mmf_mask_device.h -- bit-packed mask algebra as device functions, so that the stand-alone mask kernels
+// (mmf_kernels_image.hip) and the horizontally fused frame kernels (mmf_kernels_map.hip) share one body.
+//
+// integrate_frame's masks (mindmap/mapping/helpers/nvblox_mapping_helpers.py:201-253):
+//   row pass   : one workgroup per image row; every wave ballots 64 pixels into a 64-bit word for each of the two
+//                "bad pixel" predicates (input mask == 0, !(depth > min_d)); the words of the row are dilated
+//                horizontally by k with shifts across word boundaries and stored as [H][nw] u64 bit-rows.  Also emits
+//                depth_mask = input_mask & (depth > min_d) on the way.
+//   column pass: one workgroup per OUTPUT row; all threads OR the bit-rows of the 2k+1 source rows, then expand bits
+//                to bytes with the nearest-neighbour upsample and the border mask.
+#pragma once
+#include "mmf_device.h"
+
+namespace mmf {
+
+constexpr int kMaxMaskWords = 64;  // rows up to 4096 pixels
+
+struct MaskJob {
+  const uint8_t* mask;     // [H,W] input mask (0/1 bytes)
+  const float* depth;      // [H,W]
+  float min_d;
+  int H, W, nw, k0, k1;    // nw = ceil(W/64); k0 / k1 = erosion radius of the input / valid-depth mask
+  u64* bits_in;            // [H][nw] row-dilated bad-pixel bit rows
+  u64* bits_d;
+  uint8_t* depth_mask_out; // [H,W] or nullptr
+  int Hf, Wf;
+  float sh, sw;            // H/Hf, W/Wf
+  int bh, bw;              // border in pixels
+  uint8_t* out;            // [Hf,Wf] feature mask
+};
+
+__device__ inline u64 row_word(const u64* w, int j, int nw) { return (j >= 0 && j < nw) ? w[j] : 0ull; }
+
+// Row pass of image row y by the calling workgroup (any blockDim that is a multiple of 64).
+__device__ inline void mask_rowbits_row(const MaskJob& J, int y, u64* s_in, u64* s_d) {
+  const int lane = threadIdx.x & 63;
+  const int nt = blockDim.x;
+  for (int x0 = 0; x0 < J.nw * 64; x0 += nt) {
+    const int x = x0 + threadIdx.x;
+    bool bad_in = false, bad_d = false;
+    if (x < J.W) {
+      const size_t i = (size_t)y * J.W + x;
+      bad_in = J.mask ? J.mask[i] == 0 : false;
+      bad_d = J.depth ? !(J.depth[i] > J.min_d) : false;
+      if (J.depth_mask_out) J.depth_mask_out[i] = (!bad_in && !bad_d) ? 1 : 0;
+    }
+    const u64 b_in = __ballot(bad_in), b_d = __ballot(bad_d);
+    if (lane == 0 && (x >> 6) < J.nw) {
+      s_in[x >> 6] = b_in;
+      s_d[x >> 6] = b_d;
+    }
+  }
+  __syncthreads();
+  // horizontal dilation: bit x of the result = OR of bits [x-k, x+k]
+  for (int j = threadIdx.x; j < 2 * J.nw; j += nt) {
+    const bool second = j >= J.nw;
+    const int w = second ? j - J.nw : j;
+    const u64* src = second ? s_d : s_in;
+    const int k = second ? J.k1 : J.k0;
+    u64 r = src[w];
+    for (int s = 1; s <= k; ++s) {
+      const int q = s >> 6, sh = s & 63;  // shift by s = q words + sh bits
+      u64 left = row_word(src, w - q, J.nw) << sh;
+      if (sh) left |= row_word(src, w - q - 1, J.nw) >> (64 - sh);
+      u64 right = row_word(src, w + q, J.nw) >> sh;
+      if (sh) right |= row_word(src, w + q + 1, J.nw) << (64 - sh);
+      r |= left | right;
+    }
+    (second ? J.bits_d : J.bits_in)[(size_t)y * J.nw + w] = r;
+  }
+}
+
+// Column pass + nearest upsample + border of output row yf by the calling workgroup.
+__device__ inline void mask_colemit_row(const MaskJob& J, int yf, u64* s_bad) {
+  const int nt = blockDim.x;
+  const bool row_ok = (J.bh <= 0 || J.bw <= 0) || (yf >= J.bh && yf < J.Hf - J.bh);
+  if (row_ok) {  // block-uniform
+    int ys = (int)floorf((float)yf * J.sh);
+    ys = ys > J.H - 1 ? J.H - 1 : ys;
+    for (int j = threadIdx.x; j < J.nw; j += nt) s_bad[j] = 0ull;
+    __syncthreads();
+    // vertical OR of the 2k+1 source bit-rows, spread over all threads: thread -> (word, row phase)
+    const int groups = nt / J.nw > 0 ? nt / J.nw : 1;
+    const int j = threadIdx.x % J.nw, g = threadIdx.x / J.nw;
+    if (g < groups) {
+      u64 r = 0;
+      {
+        const int lo = ys - J.k0 < 0 ? 0 : ys - J.k0, hi = ys + J.k0 > J.H - 1 ? J.H - 1 : ys + J.k0;
+        for (int yy = lo + g; yy <= hi; yy += groups) r |= J.bits_in[(size_t)yy * J.nw + j];
+      }
+      {
+        const int lo = ys - J.k1 < 0 ? 0 : ys - J.k1, hi = ys + J.k1 > J.H - 1 ? J.H - 1 : ys + J.k1;
+        for (int yy = lo + g; yy <= hi; yy += groups) r |= J.bits_d[(size_t)yy * J.nw + j];
+      }
+      if (r) atomicOr(&s_bad[j], r);
+    }
+    __syncthreads();
+  }
+  for (int xf = threadIdx.x; xf < J.Wf; xf += nt) {
+    uint8_t res = 0;
+    if (row_ok && ((J.bh <= 0 || J.bw <= 0) || (xf >= J.bw && xf < J.Wf - J.bw))) {
+      int xs = (int)floorf((float)xf * J.sw);
+      xs = xs > J.W - 1 ? J.W - 1 : xs;
+      res = ((s_bad[xs >> 6] >> (xs & 63)) & 1ull) ? 0 : 1;
+    }
+    J.out[(size_t)yf * J.Wf + xf] = res;
+  }
+}
+
+}  // namespace mmf
