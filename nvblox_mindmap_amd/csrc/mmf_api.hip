@@ -52,6 +52,7 @@ struct Mapper {
   int sc_cap[3] = {0, 0, 0};
   uint8_t* mask_tmp = nullptr;  // bit-row scratch of the mask kernels
   size_t mask_tmp_cap = 0;
+  float* masked_depth = nullptr;  // depth with invalid / masked pixels zeroed (written by the mask row pass)
   uint8_t* kill = nullptr;
   int* any_kill = nullptr;
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
@@ -376,6 +377,7 @@ void destroy_mapper(Mapper* m) {
     (void)hipFree(m->sc[w].alloc_ctx);
   }
   (void)hipFree(m->mask_tmp);
+  (void)hipFree(m->masked_depth);
   (void)hipFree(m->kill);
   (void)hipFree(m->any_kill);
   (void)hipFree(m->stats);
@@ -766,8 +768,11 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
   if ((size_t)H * W + 8 > m->mask_tmp_cap) {
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(m->mask_tmp);
+    (void)hipFree(m->masked_depth);
     m->mask_tmp = nullptr;
+    m->masked_depth = nullptr;
     HIP_TRY(hipMalloc(&m->mask_tmp, (size_t)H * W + 8));
+    HIP_TRY(hipMalloc(&m->masked_depth, sizeof(float) * (size_t)H * W));
     m->mask_tmp_cap = (size_t)H * W + 8;
   }
   const Cam cam = cam_from_K(K9, W, H);
@@ -800,6 +805,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
     MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
     const int ncells = vg.nx * vg.ny * vg.nz;
     const bool fusable = packed && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
+    if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
     if (!fusable) {
       // odd shapes / very large grids: the plain sequence of stand-alone launches
       launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
@@ -848,7 +854,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
     }
     {
       ProfScope ps(h, MMF_K_TSDF, s);
-      launch_tsdf_integrate(m->tsdf.d, m->mc, cam, T_C_L, depth, input_mask, min_depth_m, m->sc[0],
+      launch_tsdf_integrate(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, m->sc[0],
                             ncells < m->tsdf.d.cap ? ncells : m->tsdf.d.cap, s);
     }
     {

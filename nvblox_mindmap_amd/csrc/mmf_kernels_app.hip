@@ -9,6 +9,8 @@
 namespace mmf {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load with dword alignment
+typedef unsigned short ushort_u __attribute__((aligned(1)));             // 2-byte load with byte alignment
 
 // ------------------------------------------------------------------------------------------------
 // Candidate blocks: live TSDF blocks with a voxel inside the truncation band (W > 0, |D| < trunc)
@@ -192,17 +194,23 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
   const float sf = (float)mc.st_sf;
   int sx, sy;
   float swx, swy;
+  // both footprints first, then every load of the gate in one batch (row pairs: 8-byte / 2-byte loads); the
+  // accept/reject result is the same as testing them one after the other
   if (!bilin_setup(u / sf, v / sf, Ws, Hs, sx, sy, swx, swy)) return false;
-  const float s00 = synth[(size_t)sy * Ws + sx], s10 = synth[(size_t)sy * Ws + sx + 1];
-  const float s01 = synth[(size_t)(sy + 1) * Ws + sx], s11 = synth[(size_t)(sy + 1) * Ws + sx + 1];
-  if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) return false;
-  const float sd = bilin(s00, s10, s01, s11, swx, swy);
-  if (fabsf(sd - p[2]) > mc.trunc) return false;
   if (!bilin_setup(u, v, cam.W, cam.H, x0, y0, wx, wy)) return false;
+  const size_t si = (size_t)sy * Ws + sx;
+  const float2_u s0 = *reinterpret_cast<const float2_u*>(synth + si);
+  const float2_u s1 = *reinterpret_cast<const float2_u*>(synth + si + Ws);
+  unsigned m0 = 0x0101u, m1 = 0x0101u;
   if (mask) {
     const size_t i = (size_t)y0 * cam.W + x0;
-    if (!mask[i] || !mask[i + 1] || !mask[i + cam.W] || !mask[i + cam.W + 1]) return false;
+    m0 = *reinterpret_cast<const ushort_u*>(mask + i);
+    m1 = *reinterpret_cast<const ushort_u*>(mask + i + cam.W);
   }
+  if (!(s0.x > 0.0f) || !(s0.y > 0.0f) || !(s1.x > 0.0f) || !(s1.y > 0.0f)) return false;
+  const float sd = bilin(s0.x, s0.y, s1.x, s1.y, swx, swy);
+  if (fabsf(sd - p[2]) > mc.trunc) return false;
+  if (!(m0 & 0xffu) || !(m0 & 0xff00u) || !(m1 & 0xffu) || !(m1 & 0xff00u)) return false;
   return true;
 }
 

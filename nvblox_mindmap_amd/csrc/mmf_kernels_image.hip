@@ -248,6 +248,7 @@ bool make_mask_job(const uint8_t* input_mask, const float* depth, int H, int W, 
   J.bits_in = reinterpret_cast<u64*>(tmp);
   J.bits_d = J.bits_in + (size_t)H * nw;
   J.depth_mask_out = depth_mask_out;
+  J.masked_depth_out = nullptr;
   J.Hf = Hf;
   J.Wf = Wf;
   J.sh = (float)H / (float)Hf;

@@ -128,6 +128,12 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     walk_init(w, s0, e);
     for (int i = 0; i <= w.n; ++i) {
       int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
+      // The walk is monotone along every axis: once it is past the view grid in its direction of travel (or off
+      // the grid along an axis it does not move on) no later cell can be inside the grid -> stop.  This bounds
+      // the longest rays (far depths clamped to the maximum distance walk ~100 cells, most of them outside).
+      if ((w.st[0] >= 0 && gx >= vg.nx) || (w.st[0] <= 0 && gx < 0) || (w.st[1] >= 0 && gy >= vg.ny) || (w.st[1] <= 0 && gy < 0) ||
+          (w.st[2] >= 0 && gz >= vg.nz) || (w.st[2] <= 0 && gz < 0))
+        break;
       // the view grid already is the intersection with the workspace bounds
       if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
         const int cell = (gx * vg.ny + gy) * vg.nz + gz;
@@ -493,40 +499,58 @@ __global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, i
 //    z fastest so a wave reads/writes 512 contiguous bytes of {distance, weight}.  HBM-bound
 //    read-modify-write of 4 KB per block; the 4 depth taps come through L1/L2 (1.2 MB image).
 // ------------------------------------------------------------------------------------------------
-__device__ inline bool depth_tap(const float* depth, const uint8_t* mask, float min_d, int W, int x, int y, float& out) {
-  size_t i = (size_t)y * W + x;
-  float d = depth[i];
-  if (!(d > min_d)) return false;
-  if (mask && !mask[i]) return false;
-  out = d;
-  return true;
-}
+__device__ inline bool depth_ok(float d, float min_d) { return d > min_d; }
 
-__device__ inline bool sample_depth(const MapConsts& mc, const float* depth, const uint8_t* mask, float min_d, const Cam& cam,
-                                    float u, float v, float& out) {
-  int xn = ifloor(u), yn = ifloor(v);
-  if (xn > cam.W - 1) xn = cam.W - 1;
-  if (yn > cam.H - 1) yn = cam.H - 1;
-  float dn;
-  if (!depth_tap(depth, mask, min_d, cam.W, xn, yn, dn)) return false;
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load with dword alignment
+
+// Measured surface depth at image-plane point (u,v) (spec: oracle/mmf_oracle.c:sample_depth).
+// `depth` is either the raw image with `mask` (valid iff depth > min_d and mask != 0) or, with mask == nullptr,
+// an image whose invalid pixels are already <= min_d.  The 2x2 bilinear footprint is fetched as two 8-byte
+// row-pair loads; the nearest tap (pixel floor(u), floor(v)) is one of the four whenever the footprint is inside
+// the image (u - 0.5 is exact in float32, so floor(u) = x0 + (wx >= 0.5)), which turns 5 scattered depth reads
+// (+5 mask reads) per voxel into 2.
+__device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                    float min_d, const Cam& cam, float u, float v, float& out) {
   int x0, y0;
   float wx, wy;
   if (bilin_setup(u, v, cam.W, cam.H, x0, y0, wx, wy)) {
-    float a00, a10, a01, a11;
-    if (depth_tap(depth, mask, min_d, cam.W, x0, y0, a00) && depth_tap(depth, mask, min_d, cam.W, x0 + 1, y0, a10) &&
-        depth_tap(depth, mask, min_d, cam.W, x0, y0 + 1, a01) && depth_tap(depth, mask, min_d, cam.W, x0 + 1, y0 + 1, a11)) {
+    const size_t i0 = (size_t)y0 * cam.W + x0;
+    const float2_u r0 = *reinterpret_cast<const float2_u*>(depth + i0);
+    const float2_u r1 = *reinterpret_cast<const float2_u*>(depth + i0 + cam.W);
+    bool v00 = depth_ok(r0.x, min_d), v10 = depth_ok(r0.y, min_d), v01 = depth_ok(r1.x, min_d), v11 = depth_ok(r1.y, min_d);
+    if (mask) {
+      v00 = v00 && mask[i0];
+      v10 = v10 && mask[i0 + 1];
+      v01 = v01 && mask[i0 + cam.W];
+      v11 = v11 && mask[i0 + cam.W + 1];
+    }
+    const bool nx = wx >= 0.5f, ny = wy >= 0.5f;
+    const float dn = ny ? (nx ? r1.y : r1.x) : (nx ? r0.y : r0.x);
+    const bool vn = ny ? (nx ? v11 : v01) : (nx ? v10 : v00);
+    if (!vn) return false;
+    if (v00 && v10 && v01 && v11) {
       bool ok = true;
       if (mc.lin_md > 0.0f) {
-        if (fabsf(a00 - dn) > mc.lin_md || fabsf(a10 - dn) > mc.lin_md || fabsf(a01 - dn) > mc.lin_md ||
-            fabsf(a11 - dn) > mc.lin_md)
+        if (fabsf(r0.x - dn) > mc.lin_md || fabsf(r0.y - dn) > mc.lin_md || fabsf(r1.x - dn) > mc.lin_md ||
+            fabsf(r1.y - dn) > mc.lin_md)
           ok = false;
       }
       if (ok) {
-        out = bilin(a00, a10, a01, a11, wx, wy);
+        out = bilin(r0.x, r0.y, r1.x, r1.y, wx, wy);
         return true;
       }
     }
+    out = dn;
+    return true;
   }
+  // footprint leaves the image: nearest tap only
+  int xn = ifloor(u), yn = ifloor(v);
+  if (xn > cam.W - 1) xn = cam.W - 1;
+  if (yn > cam.H - 1) yn = cam.H - 1;
+  const size_t i = (size_t)yn * cam.W + xn;
+  const float dn = depth[i];
+  if (!depth_ok(dn, min_d)) return false;
+  if (mask && !mask[i]) return false;
   out = dn;
   return true;
 }

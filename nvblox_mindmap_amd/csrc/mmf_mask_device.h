@@ -23,6 +23,7 @@ struct MaskJob {
   u64* bits_in;            // [H][nw] row-dilated bad-pixel bit rows
   u64* bits_d;
   uint8_t* depth_mask_out; // [H,W] or nullptr
+  float* masked_depth_out; // [H,W] or nullptr: depth where (mask != 0 and depth > min_d), else 0
   int Hf, Wf;
   float sh, sw;            // H/Hf, W/Wf
   int bh, bw;              // border in pixels
@@ -43,6 +44,7 @@ __device__ inline void mask_rowbits_row(const MaskJob& J, int y, u64* s_in, u64*
       bad_in = J.mask ? J.mask[i] == 0 : false;
       bad_d = J.depth ? !(J.depth[i] > J.min_d) : false;
       if (J.depth_mask_out) J.depth_mask_out[i] = (!bad_in && !bad_d) ? 1 : 0;
+      if (J.masked_depth_out) J.masked_depth_out[i] = (!bad_in && !bad_d) ? J.depth[i] : 0.0f;
     }
     const u64 b_in = __ballot(bad_in), b_d = __ballot(bad_d);
     if (lane == 0 && (x >> 6) < J.nw) {
