@@ -113,6 +113,43 @@ def cpu_baseline(cfg, mcfg, frames, channels, n_sample):
     }
 
 
+def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
+    """Short untimed-for-the-headline run at the shape the reference really uses: 512x512 images,
+    fx = 586.4 px, 768 feature channels (403 MB f16 feature image per frame)."""
+    cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    C = 768
+    frames = build_stream(cfg, n_frames, C, device)
+    mapper = get_nvblox_mapper(mcfg, feature_channels=C)
+    for i in range(warmup):
+        step(mapper, mcfg, frames[i % n_frames])
+    torch.cuda.synchronize(device)
+    mapper.reset_stats(MAPPER_TO_ID.STATIC)
+    mapper.profile_reset()
+    mapper.profile_enable(True, kernels=["feature"])
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(mapper, mcfg, frames[(warmup + i) % n_frames])
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    mapper.profile_enable(False)
+    ms, n = mapper.profile()["feature"]
+    st = mapper.stats(MAPPER_TO_ID.STATIC)
+    fb = st["feature_blocks_updated"] / max(st["feature_frames"], 1)
+    cb = st["color_blocks_updated"] / max(st["color_frames"], 1)
+    vox = st["feature_voxels_updated"] / max(st["feature_frames"], 1)
+    nbytes = vox * (2 * (2 * C + 4) + 4 * 2 * C) + fb * 512 * (4 + 16 + 4)
+    out = {"image": [cfg.height, cfg.width], "feature_channels": C, "frames_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
+           "feature_blocks_per_frame": fb, "feature_voxels_updated_per_frame": vox}
+    if n:
+        out["feature_kernel_us"] = ms / n * 1e3
+        out["feature_kernel_algorithmic_GBps"] = nbytes / (ms / n * 1e-3) / 1e9
+        out["feature_kernel_frac_of_hbm_peak"] = nbytes / (ms / n * 1e-3) / HBM_PEAK_BYTES_PER_S
+    del mapper, frames
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +159,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="distinct pre-generated frames (default min(steps, 200))")
     ap.add_argument("--cpu-sample", type=int, default=12, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-ref-shape", action="store_true", help="skip the short run at the reference's real shape (512x512x768)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,6 +220,10 @@ def main():
         mapper.profile_enable(False)
         breakdown = {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in mapper.profile().items()}
 
+    ref_shape = None
+    if rank == 0 and not args.no_ref_shape:
+        ref_shape = run_reference_shape(device)
+
     if rank == 0:
         C = args.channels
         n_feat_frames = max(stats["feature_frames"], 1)
@@ -190,12 +232,26 @@ def main():
         # algorithmic bytes of one k_feature_integrate launch:
         #   feature image f16 + mask u8, each pixel once; feature voxel (C x f16 + f32 weight) read + written per block
         col_blocks_per_frame = stats["color_blocks_updated"] / max(stats["color_frames"], 1)
-        bytes_per_launch = cfg.height * cfg.width * (2 * C + 1) + feat_blocks_per_frame * 512 * 2 * (2 * C + 4)
-        # integrate_frame launches the colour and the feature update as ONE kernel (k_app_integrate2): add the colour
-        # image (3 B/pixel + mask) and the colour voxels (8 B read + 8 B written)
-        bytes_per_launch += cfg.height * cfg.width * (3 + 1) + col_blocks_per_frame * 512 * 16
+        feat_voxels_per_frame = stats["feature_voxels_updated"] / n_feat_frames
+        # (1) SURVEY.md section 8(d) model: the whole feature image once + every voxel of every candidate block
+        #     read and written (plus the colour image / voxels: the two updates are one launch, k_app_integrate2)
+        model_bytes = (cfg.height * cfg.width * (2 * C + 1) + feat_blocks_per_frame * 512 * 2 * (2 * C + 4)
+                       + cfg.height * cfg.width * (3 + 1) + col_blocks_per_frame * 512 * 16)
+        # (2) algorithmic bytes with unit = a voxel the launch actually updates (device counter): the kernel gates
+        #     every candidate voxel first and only moves the survivors: voxel row + weight read and written
+        #     (2*(2C+4) B), its 4 bilinear taps (4 * 2C B), and the per-candidate-voxel gate inputs (weight 4 B,
+        #     2x2 synthetic-depth taps 16 B, 2x2 mask taps 4 B)
+        bytes_per_launch = (feat_voxels_per_frame * (2 * (2 * C + 4) + 4 * 2 * C)
+                            + feat_blocks_per_frame * 512 * (4 + 16 + 4))
         feat_ms, feat_n = prof["feature"]
         roofline = None
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+            with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
+                pmc = json.load(f)["k_app_integrate2"]
+            traffic = (2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0  # FETCH_SIZE x2: gfx950 correction
+        except Exception:
+            traffic = None
         if feat_n > 0 and feat_ms > 0:
             avg_s = feat_ms / feat_n * 1e-3
             achieved = bytes_per_launch / avg_s
@@ -206,12 +262,16 @@ def main():
                 "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_BYTES_PER_S,
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_us": avg_s * 1e6,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "unit_of_work": "feature voxel updated (passed the occlusion/mask gate)",
+                "feature_voxels_updated_per_launch": feat_voxels_per_frame,
                 "feature_blocks_per_launch": feat_blocks_per_frame,
+                "survey_8d_model_bytes_per_launch": model_bytes,
+                "survey_8d_model_GBps": model_bytes / avg_s / 1e9,
             }
-        frame_bytes = cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + bytes_per_launch
+        frame_bytes = cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + model_bytes
         cpu = None
         if args.cpu_sample > 0:
             cpu = cpu_baseline(cfg, mcfg, frames, C, min(args.cpu_sample, n_frames))
@@ -239,12 +299,13 @@ def main():
                 "distinct_frames": n_frames,
                 "tsdf_blocks_per_frame": tsdf_blocks_per_frame,
                 "feature_blocks_per_frame": feat_blocks_per_frame,
-                "algorithmic_bytes_per_frame": frame_bytes,
-                "whole_frame_GBps": frame_bytes * fps / world / 1e9,
+                "survey_8d_model_bytes_per_frame": frame_bytes,
+                "survey_8d_model_whole_frame_GBps": frame_bytes * fps / world / 1e9,
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernel_us_per_launch": breakdown,
+            "reference_shape": ref_shape,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -193,9 +193,9 @@ int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* indices_dev, 
 /* Cumulative counters since creation / last reset (synchronises `stream`):
  *  [0] depth frames  [1] TSDF blocks updated  [2] TSDF blocks allocated
  *  [3] colour frames [4] colour blocks updated [5] feature frames [6] feature blocks updated
- *  [7] feature blocks allocated */
-#define MMF_NUM_STATS 8
-int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8);
+ *  [7] feature blocks allocated  [8] feature voxels updated (voxels that passed the occlusion / mask gate) */
+#define MMF_NUM_STATS 9
+int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out /* [MMF_NUM_STATS] */);
 int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
 
 /* Kernel timing with HIP events on the launch stream.  kernel ids: */

@@ -52,7 +52,8 @@ struct Mapper {
   int sc_cap[3] = {0, 0, 0};
   uint8_t* mask_tmp = nullptr;  // bit-row scratch of the mask kernels
   size_t mask_tmp_cap = 0;
-  float* masked_depth = nullptr;  // depth with invalid / masked pixels zeroed (written by the mask row pass)
+  float* masked_depth = nullptr;
+  int* hints = nullptr;  // pinned host ints the device publishes counts to: [0..2] candidates of sc[0..2], [3..5] live blocks  // depth with invalid / masked pixels zeroed (written by the mask row pass)
   uint8_t* kill = nullptr;
   int* any_kill = nullptr;
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
@@ -283,6 +284,7 @@ int ensure_scratch(Mapper& m, int which, int ncells) {
   }
   sc.cand_count = cand_count;
   sc.alloc_ctx = alloc_ctx;
+  sc.hint_cand = m.hints ? m.hints + which : nullptr;
   m.sc_cap[which] = n;
   return MMF_OK;
 }
@@ -340,12 +342,15 @@ int create_mapper(const mmf_params& P, Mapper** out) {
     app_cap = 16384;
   }
   m->app_cap = app_cap;
+  HIP_TRY(hipHostMalloc(&m->hints, sizeof(int) * 8));
+  for (int i = 0; i < 8; ++i) m->hints[i] = 0;
   int rc = alloc_layer(m->tsdf, cap, sizeof(float2) * kVPB, false);
   if (rc != MMF_OK) {
     delete m;
     return rc;
   }
   MMF_TRY(attach_dense_table(*m, m->tsdf));
+  m->tsdf.d.hint_live = m->hints + 3;
   HIP_TRY(hipMalloc(&m->tsdf.d.block_free, (size_t)cap));
   HIP_TRY(hipMemset(m->tsdf.d.block_free, 0, (size_t)cap));
   HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
@@ -378,6 +383,7 @@ void destroy_mapper(Mapper* m) {
   }
   (void)hipFree(m->mask_tmp);
   (void)hipFree(m->masked_depth);
+  if (m->hints) (void)hipHostFree(m->hints);
   (void)hipFree(m->kill);
   (void)hipFree(m->any_kill);
   (void)hipFree(m->stats);
@@ -735,7 +741,7 @@ int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat, const u
   {
     ProfScope ps(h, MMF_K_FEATURE, s);
     launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc[2],
-                             m->feat.d.cap, s);
+                             m->feat.d.cap, m->stats, s);
   }
   return check_launch();
 }
@@ -819,7 +825,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
       m->frames[2]++;
       MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
       launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
-                               m->synth_H, m->sc[2], m->feat.d.cap, s);
+                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s);
       return check_launch();
     }
     m->last_vg = vg;
@@ -887,7 +893,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
     {
       ProfScope ps(h, MMF_K_FEATURE, s);
       launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, s);
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s);
     }
     return check_launch();
   }
@@ -922,7 +928,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
   {
     ProfScope ps(h, MMF_K_FEATURE, sa);
     launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, fsynth, fWs, fHs, m->sc[2],
-                             m->feat.d.cap, sa);
+                             m->feat.d.cap, m->stats, sa);
   }
   HIP_TRY(record(4, sa));
 
@@ -968,6 +974,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     m->tsdf_epoch++;
     m->mesh_epoch = -1;
     m->touched = false;
+    for (int q = 0; q < 8; ++q) m->hints[q] = 0;
   }
   return check_launch();
 }

@@ -71,6 +71,7 @@ struct LayerDev {
   // D == +trunc).  Recomputed by k_tsdf_integrate / k_decay for every block they touch; lets the sphere tracer
   // step through such blocks without reading voxels (the sample result is known: valid, distance = trunc).
   unsigned char* block_free;
+  int* hint_live;  // pinned host int (may be null): last live-block count, read by the host to size later grids
   int d_lo[3];
   int d_ny, d_nz, d_ncells;
 };
@@ -93,6 +94,7 @@ struct Scratch {
   uint8_t* cand_new; // [ncells]
   int* cand_count;   // [1]
   int* alloc_ctx;    // [4] old n_live, old n_free, old bump, granted
+  int* hint_cand;    // pinned host int (may be null): last candidate count, read by the host to size later grids
 };
 
 // Where the key of a compaction cell comes from.

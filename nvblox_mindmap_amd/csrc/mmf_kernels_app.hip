@@ -224,6 +224,7 @@ struct AppArgs {
   const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]
   const uint8_t* mask;
   Scratch sc;
+  long long* stats;  // mapper statistics (may be null)
 };
 
 __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs, int bid,
@@ -365,6 +366,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
     __syncthreads();
 
     const int nv = s_n;
+    if (tid == 0 && A.stats && nv) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)nv);
     __half* blk = reinterpret_cast<__half*>(L.pool) + (size_t)slot * kVPB * C;
     for (int vi = group; vi < nv; vi += 32) {
       const int lin = s_lin[vi];
@@ -440,7 +442,8 @@ static inline int grid8(int upper, int cap) {
 
 void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, uint8_t* flags,
                            u64* cell_key, hipStream_t s) {
-  hipLaunchKernelGGL(k_app_candidates, dim3(grid8(tsdf.cap, 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L, flags, cell_key);
+  hipLaunchKernelGGL(k_app_candidates, dim3(grid8(hinted(tsdf.hint_live, tsdf.cap), 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L,
+                     flags, cell_key);
 }
 
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
@@ -452,8 +455,9 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
-                             const Scratch& sc) {
+                             const Scratch& sc, long long* stats = nullptr) {
   AppArgs A;
+  A.stats = stats;
   A.L = L;
   A.cam = cam;
   A.T_C_L = T_C_L;
@@ -466,24 +470,25 @@ static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s) {
-  hipLaunchKernelGGL(k_color_integrate, dim3(grid8(max_cand, 8192)), dim3(256), 0, s, make_app_args(L, cam, T_C_L, rgb, mask, sc), mc,
-                     synth, Ws, Hs);
+  hipLaunchKernelGGL(k_color_integrate, dim3(grid8(hinted(sc.hint_cand, max_cand), 8192)), dim3(256), 0, s,
+                     make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
 }
 
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
-                              hipStream_t s) {
-  hipLaunchKernelGGL(k_feature_integrate, dim3(grid8(max_cand, 8192)), dim3(256), 0, s, make_app_args(L, cam, T_C_L, feat, mask, sc),
-                     mc, synth, Ws, Hs);
+                              long long* stats, hipStream_t s) {
+  hipLaunchKernelGGL(k_feature_integrate, dim3(grid8(hinted(sc.hint_cand, max_cand), 8192)), dim3(256), 0, s,
+                     make_app_args(L, cam, T_C_L, feat, mask, sc, stats), mc, synth, Ws, Hs);
 }
 
 // colour + feature update in one launch
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
-                           const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, hipStream_t s) {
-  const int g = grid8(max_cand, 4096);
-  hipLaunchKernelGGL(k_app_integrate2, dim3(2 * g), dim3(256), 0, s, make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
-                     make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc), mc, synth, Ws, Hs, g);
+                           const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
+                           hipStream_t s) {
+  const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
+  hipLaunchKernelGGL(k_app_integrate2, dim3(gc + gf), dim3(256), 0, s, make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
+                     make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats), mc, synth, Ws, Hs, gc);
 }
 
 }  // namespace mmf

@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void k_scan_tiles(LayerDev L, Scratch sc, int 
     L.ctr[1] = n_free - from_free;
     L.ctr[2] = bump + (granted - from_free);
     *sc.cand_count = n_cand;
+    if (sc.hint_cand) *sc.hint_cand = n_cand;
+    if (L.hint_live) *L.hint_live = L.ctr[0];
     if (stats) {
       if (stat_upd >= 0) stats[stat_upd] += n_cand;
       if (stat_new >= 0) stats[stat_new] += granted;
@@ -464,6 +466,8 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
     L.ctr[1] = old_free - from_free;
     L.ctr[2] = old_bump + (granted - from_free);
     *sc.cand_count = n_cand;
+    if (sc.hint_cand) *sc.hint_cand = n_cand;
+    if (L.hint_live) *L.hint_live = L.ctr[0];
     if (stats) {
       if (stat_upd >= 0) stats[stat_upd] += n_cand;
       if (stat_new >= 0) stats[stat_new] += granted;
@@ -676,6 +680,7 @@ __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __re
     L.ctr[0] = n_live;
     L.ctr[1] = carry[1];
     L.ctr[4] = rebuild ? 0 : n_tomb;
+    if (L.hint_live) *L.hint_live = n_live;
     *any_kill = 0;
   }
 }
@@ -871,6 +876,17 @@ void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const 
   hipLaunchKernelGGL(k_alloc_jobs, dim3(njobs + rows), dim3(1024), 0, s, jobs[0], jobs[njobs > 1 ? 1 : 0], njobs, stats, mj, rows);
 }
 
+// Grid size from the last count the device published to pinned host memory (stale by a frame or two, which is
+// fine: every block kernel strides over its work list, so any grid size is correct).  Empty workgroups are not
+// free -- dispatching 3 744 of them costs ~6 us -- so grids follow the real count with 25 % headroom.
+int hinted(const int* hint, int upper) {
+  if (!hint) return upper;
+  const int v = *reinterpret_cast<const volatile int*>(hint);
+  if (v <= 0) return upper;
+  long long g = (long long)v + v / 4 + 64;
+  return g < upper ? (int)g : upper;
+}
+
 static inline int grid_for(int upper, int cap) {
   int g = upper < cap ? upper : cap;
   g = (g + 7) & ~7;  // multiple of 8: a workgroup keeps its XCD residue across the stride loop
@@ -879,12 +895,13 @@ static inline int grid_for(int upper, int cap) {
 
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s) {
-  hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(max_cand, 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, sc);
+  hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
+                     mask, min_d, sc);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {
   // any_kill is zero on entry (initialised at creation, reset by k_live_compact)
-  hipLaunchKernelGGL(k_decay, dim3(grid_for(L.cap, 4096)), dim3(256), 0, s, L, mc, kill, any_kill);
+  hipLaunchKernelGGL(k_decay, dim3(grid_for(hinted(L.hint_live, L.cap), 4096)), dim3(256), 0, s, L, mc, kill, any_kill);
   if (mc.dealloc_decayed) hipLaunchKernelGGL(k_live_compact, dim3(1), dim3(1024), 0, s, L, kill, any_kill);
 }
 

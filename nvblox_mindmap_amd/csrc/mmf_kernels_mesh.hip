@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void k_mesh_emit(LayerDev T, LayerDev F, MapCo
 }
 
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* out2, hipStream_t s) {
-  int g = tsdf.cap < 8192 ? tsdf.cap : 8192;
+  int g = hinted(tsdf.hint_live, tsdf.cap);
+  g = g < 8192 ? g : 8192;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_mesh_count, dim3(g), dim3(256), 0, s, tsdf, mc, counts);
   hipLaunchKernelGGL(k_mesh_scan, dim3(1), dim3(256), 0, s, tsdf, (const int*)counts, offsets, out2);

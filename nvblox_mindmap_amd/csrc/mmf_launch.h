@@ -11,6 +11,7 @@ struct ViewGrid {
 };
 
 // mmf_kernels_map.hip
+int hinted(const int* hint, int upper);
 void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                     int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s);
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
@@ -41,11 +42,12 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                             hipStream_t s);
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
-                              hipStream_t s);
+                              long long* stats, hipStream_t s);
 
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
-                           const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, hipStream_t s);
+                           const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
+                           hipStream_t s);
 
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,

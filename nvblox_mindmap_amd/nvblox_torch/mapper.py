@@ -394,7 +394,7 @@ class Mapper:
         buf = (C.c_int64 * _lib.MMF_NUM_STATS)()
         _lib.check(_lib.lib().mmf_get_stats(self._h, mapper_id, self._stream(), buf), "mmf_get_stats")
         names = ["depth_frames", "tsdf_blocks_updated", "tsdf_blocks_allocated", "color_frames", "color_blocks_updated",
-                 "feature_frames", "feature_blocks_updated", "feature_blocks_allocated"]
+                 "feature_frames", "feature_blocks_updated", "feature_blocks_allocated", "feature_voxels_updated"]
         return dict(zip(names, [int(x) for x in buf]))
 
     def reset_stats(self, mapper_id: int = 0) -> None:

@@ -277,3 +277,37 @@ def test_integrate_frame_fused_matches_oracle(oracle_mod, scale, channels):
     nonzero = np.any(of != 0, axis=1)
     n_expected = int((inside & nonzero).sum())
     assert int(valid.sum()) == min(n_expected, 2048)
+
+
+def test_reference_channel_count_768(oracle_mod):
+    """The reference build's feature width (C_pad = 768, docker/install_nvblox.sh:24-25): 96 pieces per voxel row."""
+    cfg = small_cfg(8)
+    orc, gpu = run_both(oracle_mod, cfg, 768, [0, 9], use_mask=True, color=False, decay=True)
+    compare_tsdf(orc, gpu)
+    compare_features(orc, gpu)
+    ov, of = orc.feature_mesh()
+    mesh = gpu.get_feature_mesh(0)
+    assert np.array_equal(mesh.vertices().cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    assert np.array_equal(mesh.vertex_features().cpu().numpy().view(np.uint16), of.view(np.uint16))
+
+
+def test_two_mappers_are_independent(oracle_mod):
+    """STATIC / DYNAMIC mappers of one Mapper object (nvblox_mapper_constants.py:27-29) do not interact."""
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg
+
+    cfg = small_cfg(4)
+    gpu = get_nvblox_mapper(NvbloxMappingCfg("DRILL_IN_BOX"), feature_channels=16)
+    assert gpu.num_mappers() == 2
+    o0, o1 = make_oracle(oracle_mod, 16), make_oracle(oracle_mod, 16)
+    for i, (orc, mid) in enumerate([(o0, 0), (o1, 1), (o0, 0)]):
+        f = S.frame(cfg, 7 * i, 16)
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"])
+        gpu.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, mid)
+    for orc, mid in ((o0, 0), (o1, 1)):
+        blocks, idx = gpu.tsdf_layer_view(mid).get_all_blocks()
+        assert np.array_equal(idx.cpu().numpy(), orc.block_indices(0))
+        assert np.array_equal(blocks.cpu().numpy().view(np.uint32), orc.all_tsdf().view(np.uint32))
+    gpu.clear(1)
+    assert gpu.tsdf_layer_view(1).num_allocated_blocks() == 0
+    assert gpu.tsdf_layer_view(0).num_allocated_blocks() == o0.num_blocks(0)
