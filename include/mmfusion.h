@@ -179,6 +179,13 @@ int mmf_depth_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H,
 int mmf_upsample_features(const float* lowres_dev, int h, int w, int Cin, void* out_f16_dev, int Hf, int Wf, int Cpad,
                           void* stream);
 
+/* ---- policy-side op ---------------------------------------------------- */
+/* dgl.geometry.farthest_point_sampler(x, npoints, start_idx) (diffuser_actor/encoder.py:366-370): farthest-point
+ * sampling of x [B,N,C] f32 in C-dimensional feature space, squared L2, first index on ties.
+ * out_idx [B,npoints] i64.  N <= 8192, C <= 1024. */
+int mmf_farthest_point_sampling(const float* x_dev, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx_dev,
+                                void* stream);
+
 /* ---- diagnostics / measurement --------------------------------------------------------------- */
 /* Last sphere-traced synthetic depth image of the mapper: dims, then copy to out [Hs,Ws] f32. */
 int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws);

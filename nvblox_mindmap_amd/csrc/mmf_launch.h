@@ -69,4 +69,7 @@ bool make_mask_job(const uint8_t* input_mask, const float* depth, int H, int W, 
 void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s);
 void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s);
 
+// mmf_kernels_fps.hip
+int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s);
+
 }  // namespace mmf

@@ -1,0 +1,47 @@
+"""Image backbone stand-in.
+
+The reference's default image encoder is a frozen RADIO v2.5-B (ViT-B/16-class, ~100 M parameters, 768-d tokens on a
+16x16-pixel patch grid; mindmap/image_processing/feature_extraction.py:339-370), fetched from torch.hub.  There is no
+network here, so the benchmark uses a randomly initialised ViT-B/16 of the same shape: identical compute and memory
+profile for the training step (a frozen forward over B x ncam 512x512 images), not identical features.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio=4):
+        super().__init__()
+        self.n1, self.n2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.qkv, self.proj = nn.Linear(dim, 3 * dim), nn.Linear(dim, dim)
+        self.fc1, self.fc2 = nn.Linear(dim, mlp_ratio * dim), nn.Linear(mlp_ratio * dim, dim)
+        self.heads = heads
+
+    def forward(self, x):
+        B, L, D = x.shape
+        q, k, v = self.qkv(self.n1(x)).view(B, L, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        x = x + self.proj(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D))
+        return x + self.fc2(F.gelu(self.fc1(self.n2(x))))
+
+
+class VitBackbone(nn.Module):
+    """ViT-B/16-shaped encoder: (B,3,H,W) in [0,1] -> (B,dim,H/16,W/16)."""
+
+    def __init__(self, dim: int = 768, depth: int = 12, heads: int = 12, patch: int = 16, max_grid: int = 32):
+        super().__init__()
+        self.patch, self.dim = patch, dim
+        self.embed = nn.Conv2d(3, dim, patch, patch)
+        self.pos = nn.Parameter(torch.zeros(1, max_grid * max_grid, dim))
+        nn.init.trunc_normal_(self.pos, std=0.02)
+        self.blocks = nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        h, w = H // self.patch, W // self.patch
+        t = self.embed(x).flatten(2).transpose(1, 2)
+        t = t + self.pos[:, : h * w]
+        for blk in self.blocks:
+            t = blk(t)
+        return self.norm(t).transpose(1, 2).reshape(B, self.dim, h, w)

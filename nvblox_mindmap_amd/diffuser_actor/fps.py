@@ -1,0 +1,40 @@
+"""Farthest-point sampling in feature space (HIP kernel; counterpart of the dgl CUDA op used at
+mindmap/diffuser_actor/encoder.py:366-370)."""
+import torch
+
+from .. import _lib
+
+
+def farthest_point_sampling(x: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:
+    """x (B,N,C) float32 on the GPU -> indices (B,npoints) int64: start_idx first, then repeatedly the point whose
+    squared distance to the selected set is largest (first index on ties)."""
+    if not x.is_cuda:
+        raise RuntimeError("farthest_point_sampling runs on the GPU only (no CPU fallback)")
+    B, N, C = x.shape
+    xx = x.detach().to(torch.float32).contiguous()
+    out = torch.empty((B, npoints), dtype=torch.int64, device=x.device)
+    _lib.check(_lib.lib().mmf_farthest_point_sampling(_lib.dptr(xx), B, N, C, int(npoints), int(start_idx), _lib.dptr(out),
+                                                     _lib.stream_ptr(x.device)), "mmf_farthest_point_sampling")
+    return out
+
+
+def farthest_point_sampling_reference(x: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:
+    """Same algorithm in plain torch (any device): used by the CPU plumbing test of the model (BASELINE configs[0]) and as
+    the checker of the HIP kernel in tests.  O(npoints) sequential steps."""
+    B, N, C = x.shape
+    xx = x.detach().to(torch.float32)
+    dist = torch.full((B, N), float("inf"), device=x.device)
+    idx = torch.empty((B, npoints), dtype=torch.int64, device=x.device)
+    cur = torch.full((B,), int(start_idx), dtype=torch.int64, device=x.device)
+    ar = torch.arange(B, device=x.device)
+    for it in range(npoints):
+        idx[:, it] = cur
+        if it + 1 == npoints:
+            break
+        d = xx - xx[ar, cur][:, None, :]
+        acc = torch.zeros((B, N), device=x.device)
+        for c in range(C):  # sequential float32 accumulation, the kernel's order
+            acc = acc + d[..., c] * d[..., c]
+        dist = torch.minimum(dist, acc)
+        cur = dist.argmax(dim=1)  # first maximal index
+    return idx

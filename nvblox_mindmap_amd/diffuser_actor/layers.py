@@ -1,0 +1,149 @@
+"""Attention building blocks of the policy: 3-D rotary position code, AdaLN-conditioned attention / feed-forward
+blocks (counterparts of mindmap/diffuser_actor/{layers,multihead_custom_attention,position_encodings}.py;
+batch-first, ``F.scaled_dot_product_attention``)."""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def sinusoidal_embedding(x: torch.Tensor, dim: int) -> torch.Tensor:
+    """(B,) scalars -> (B,dim): [sin(x w_k) ... , cos(x w_k) ...], w_k = 10000^(-k/(dim/2-1))."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, device=x.device, dtype=torch.float32) * (-math.log(10000.0) / (half - 1)))
+    arg = x.to(torch.float32)[:, None] * freq[None, :]
+    return torch.cat([arg.sin(), arg.cos()], dim=-1)
+
+
+@torch.no_grad()
+def rotary3d(xyz: torch.Tensor, dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """3-D rotary code of points (B,N,3): the channel dimension is split into three thirds (x, y, z); inside a third
+    channel pair (2k, 2k+1) rotates with frequency 10000^(-2k/(dim/3)).  Returns (cos, sin), each (B,N,dim)."""
+    assert dim % 6 == 0, "embedding_dim must be divisible by 6"
+    third = dim // 3
+    freq = torch.exp(torch.arange(0, third, 2, device=xyz.device, dtype=torch.float32) * (-math.log(10000.0) / third))
+    ang = xyz.to(torch.float32)[..., :, None] * freq  # (B,N,3,third/2)
+    ang = ang.repeat_interleave(2, dim=-1).flatten(-2)  # pairs share an angle; x-third, y-third, z-third
+    return ang.cos(), ang.sin()
+
+
+def apply_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """Rotate channel pairs (x_{2k}, x_{2k+1}) by the pair's angle."""
+    x_rot = torch.stack([-x[..., 1::2], x[..., 0::2]], dim=-1).flatten(-2)
+    return x * cos + x_rot * sin
+
+
+class AdaLN(nn.Module):
+    """x * (1 + scale(c)) + shift(c), conditioning vector c: (B,dim); zero-initialised (starts as identity)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.proj = nn.Linear(dim, 2 * dim)
+        nn.init.zeros_(self.proj.weight)
+        nn.init.zeros_(self.proj.bias)
+
+    def forward(self, x: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        scale, shift = self.proj(F.silu(cond)).chunk(2, dim=-1)
+        return x * (1 + scale[:, None, :]) + shift[:, None, :]
+
+
+class RelativeAttention(nn.Module):
+    """Multi-head attention with rotary position codes applied to the projected queries / keys."""
+
+    def __init__(self, dim: int, heads: int, dropout: float = 0.0):
+        super().__init__()
+        assert dim % heads == 0
+        self.dim, self.heads, self.dropout = dim, heads, dropout
+        self.q_proj = nn.Linear(dim, dim)
+        self.kv_proj = nn.Linear(dim, 2 * dim)
+        self.out_proj = nn.Linear(dim, dim)
+        for lin in (self.q_proj, self.kv_proj):
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.zeros_(lin.bias)
+        nn.init.zeros_(self.out_proj.bias)
+
+    def forward(self, query: torch.Tensor, memory: torch.Tensor, q_rot=None, kv_rot=None,
+                key_padding_mask: Optional[torch.Tensor] = None, need_weights: bool = False):
+        """query (B,Lq,D), memory (B,Lk,D); key_padding_mask (B,Lk) True = ignore.  Returns (out, weights or None)."""
+        B, Lq, D = query.shape
+        Lk = memory.shape[1]
+        q = self.q_proj(query)
+        k, v = self.kv_proj(memory).chunk(2, dim=-1)
+        if q_rot is not None:
+            q = apply_rotary(q, *q_rot)
+            k = apply_rotary(k, *kv_rot)
+        h = self.heads
+        q = q.view(B, Lq, h, D // h).transpose(1, 2)
+        k = k.view(B, Lk, h, D // h).transpose(1, 2)
+        v = v.view(B, Lk, h, D // h).transpose(1, 2)
+        mask = None
+        if key_padding_mask is not None:
+            mask = (~key_padding_mask)[:, None, None, :]  # True = attend
+        weights = None
+        if need_weights:
+            logits = (q @ k.transpose(-1, -2)) / math.sqrt(D // h)
+            if mask is not None:
+                logits = logits.masked_fill(~mask, float("-inf"))
+            weights = logits.softmax(dim=-1)
+            out = F.dropout(weights, self.dropout, self.training) @ v
+        else:
+            out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.dropout if self.training else 0.0)
+        out = out.transpose(1, 2).reshape(B, Lq, D)
+        return self.out_proj(out), weights
+
+
+class AttentionBlock(nn.Module):
+    """(AdaLN on the query) -> attention -> residual -> LayerNorm  (post-norm)."""
+
+    def __init__(self, dim: int, heads: int, dropout: float = 0.0, use_adaln: bool = False):
+        super().__init__()
+        self.attn = RelativeAttention(dim, heads, dropout)
+        self.norm = nn.LayerNorm(dim)
+        self.drop = nn.Dropout(dropout)
+        self.adaln = AdaLN(dim) if use_adaln else None
+
+    def forward(self, query, memory, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False):
+        q_in = self.adaln(query, cond) if (self.adaln is not None and cond is not None) else query
+        out, w = self.attn(q_in, memory, q_rot, kv_rot, key_padding_mask, need_weights)
+        return self.norm(query + self.drop(out)), w
+
+
+class FeedForwardBlock(nn.Module):
+    """(AdaLN) -> Linear -> ReLU -> Linear -> residual -> LayerNorm; hidden width = dim."""
+
+    def __init__(self, dim: int, hidden: int, dropout: float = 0.0, use_adaln: bool = False):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+        nn.init.xavier_uniform_(self.fc1.weight)
+        nn.init.xavier_uniform_(self.fc2.weight)
+        self.norm = nn.LayerNorm(dim)
+        self.drop = nn.Dropout(dropout)
+        self.adaln = AdaLN(dim) if use_adaln else None
+
+    def forward(self, x, cond=None):
+        if self.adaln is not None and cond is not None:
+            x = self.adaln(x, cond)
+        return self.norm(x + self.drop(self.fc2(self.drop(F.relu(self.fc1(x))))))
+
+
+class AttentionStack(nn.Module):
+    """`num_layers` x (AttentionBlock, FeedForwardBlock).  ``self_attention=True``: the memory is the running query
+    itself (un-modulated), as in the reference's FFWRelativeSelfAttentionModule."""
+
+    def __init__(self, dim: int, heads: int, num_layers: int, dropout: float = 0.0, use_adaln: bool = True,
+                 self_attention: bool = False):
+        super().__init__()
+        self.self_attention = self_attention
+        self.attn = nn.ModuleList([AttentionBlock(dim, heads, dropout, use_adaln) for _ in range(num_layers)])
+        self.ffw = nn.ModuleList([FeedForwardBlock(dim, dim, dropout, use_adaln) for _ in range(num_layers)])
+
+    def forward(self, query, memory=None, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False):
+        weights = None
+        for attn, ffw in zip(self.attn, self.ffw):
+            mem = query if self.self_attention else memory
+            rot = q_rot if self.self_attention else kv_rot
+            query, weights = attn(query, mem, cond, q_rot, rot, key_padding_mask, need_weights)
+            query = ffw(query, cond)
+        return query, weights

@@ -1,0 +1,295 @@
+"""DiffuserActor: encoder + diffusion head + two DDPM schedules.
+
+Counterpart of mindmap/diffuser_actor/{diffuser_actor,encoder,diffusion_head}.py with the same forward() input
+tensors (diffuser_actor.py:518-531) and the same architecture: context tokens = image-patch tokens (frozen backbone ->
+Linear) and/or map-vertex tokens (Linear), 3-D rotary attention, gripper-history queries attending to the context
+(3 layers), farthest-point subsampling of the context in feature space, a diffusion head with AdaLN conditioning on
+(denoising step + gripper history): 2 cross-attention layers over the full context, 4 shared + 2 + 2 head-specific
+self-attention layers over [trajectory tokens ; subsampled context], predictors for position noise (3), 6-D rotation
+noise (6), gripper openness (1) and head yaw (1).
+"""
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..nvblox_torch.timer import Timer
+from .backbone import VitBackbone
+from .fps import farthest_point_sampling, farthest_point_sampling_reference
+from .layers import AttentionBlock, AttentionStack, FeedForwardBlock, rotary3d, sinusoidal_embedding
+from .loss import LossWeights, compute_loss
+from .rotations import normalize_pointcloud, normalize_pos, normalize_trajectory, unnormalize_trajectory
+from .scheduler import DDPMScheduler
+
+
+@dataclass
+class DiffuserActorConfig:
+    """Defaults = mindmap/cli/args.py:57-93 (ModelArgs)."""
+
+    data_type: str = "rgbd_and_mesh"       # "rgbd" | "mesh" | "rgbd_and_mesh"
+    image_size: Tuple[int, int] = (512, 512)
+    feature_dim: int = 768                  # channels of image features and of the map's vertex features
+    embedding_dim: int = 120
+    num_attn_heads: int = 8
+    num_history: int = 3
+    ngrippers: int = 2                      # humanoid (Drill-in-Box): 2, arm: 1
+    prediction_horizon: int = 1
+    fps_subsampling_factor: int = 5
+    use_fps: bool = True
+    diffusion_timesteps: int = 100
+    encode_openness: bool = True
+    use_shared_feature_encoder: bool = False
+    predict_head_yaw: bool = True
+    use_instruction: bool = False
+    quaternion_format: str = "wxyz"
+    add_external_cam: bool = False
+    dropout: float = 0.0
+    backbone: str = "vit_b16"               # random-init stand-in for the frozen RADIO v2.5-B ("none": rgb tokens are given)
+    loss_weights: LossWeights = field(default_factory=LossWeights)
+
+
+class Encoder(nn.Module):
+    def __init__(self, cfg: DiffuserActorConfig):
+        super().__init__()
+        self.cfg = cfg
+        D, nq = cfg.embedding_dim, cfg.num_history * cfg.ngrippers
+        self.uses_images = cfg.data_type in ("rgbd", "rgbd_and_mesh")
+        self.uses_mesh = cfg.data_type in ("mesh", "rgbd_and_mesh")
+        if self.uses_images:
+            self.backbone = VitBackbone(dim=cfg.feature_dim) if cfg.backbone == "vit_b16" else None
+            if self.backbone is not None:
+                for p in self.backbone.parameters():
+                    p.requires_grad = False
+            self.image_embed = nn.Linear(cfg.feature_dim, D)
+        if self.uses_mesh and not cfg.use_shared_feature_encoder:
+            self.mesh_embed = nn.Linear(cfg.feature_dim, D)
+        if cfg.encode_openness:
+            # binary closedness per (history step, gripper) -> one learnable query per state (encoder.py:108-114)
+            self.open_close = nn.Linear(nq, nq * D)
+        else:
+            self.history_embed = nn.Embedding(nq, D)
+        self.gripper_context = AttentionStack(D, cfg.num_attn_heads, 3, cfg.dropout, use_adaln=False)
+        # present in the reference, unused when use_instruction = 0 (why DDP needs find_unused_parameters=True)
+        self.goal_embed = nn.Embedding(1, D)
+        self.instruction_encoder = nn.Linear(512, D)
+        self.vl_attention = nn.ModuleList([AttentionBlock(D, cfg.num_attn_heads, cfg.dropout) for _ in range(2)])
+        self.vl_ffn = nn.ModuleList([FeedForwardBlock(D, 4 * D, cfg.dropout) for _ in range(2)])
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if getattr(self, "backbone", None) is not None:
+            self.backbone.eval()  # frozen
+        return self
+
+    # -- context tokens ---------------------------------------------------------------------------------------------
+    def encode_images(self, rgb, pcd, valid_mask):
+        """rgb (B,ncam,3,H,W) in [0,1], pcd (B,ncam,3,H,W) normalised points, valid_mask (B,ncam,H,W) ->
+        tokens (B,ncam*h*w,D), positions (B,ncam*h*w,3), mask (B,ncam*h*w)."""
+        B, ncam = rgb.shape[:2]
+        with torch.no_grad():
+            feats = self.backbone(rgb.flatten(0, 1))  # (B*ncam, C, h, w)
+        h, w = feats.shape[-2:]
+        tokens = self.image_embed(feats.flatten(2).transpose(1, 2)).reshape(B, ncam * h * w, -1)
+        pos = F.interpolate(pcd.flatten(0, 1), (h, w), mode="bilinear", align_corners=False)
+        pos = pos.flatten(2).transpose(1, 2).reshape(B, ncam * h * w, 3)
+        f = valid_mask.shape[-1] // w  # AND-pooling: a token is valid iff all its pixels are (image_mask_operations.py:71)
+        m = valid_mask.reshape(B, ncam, h, f, w, f).all(dim=-1).all(dim=-2).reshape(B, ncam * h * w)
+        return tokens, pos, m
+
+    def encode_vertices(self, vertex_features, vertices):
+        embed = self.image_embed if self.cfg.use_shared_feature_encoder else self.mesh_embed
+        assert vertex_features.shape[-1] == embed.in_features, (
+            f"vertex features have {vertex_features.shape[-1]} channels, the model expects {embed.in_features}")
+        return embed(vertex_features.to(torch.float32)), vertices
+
+    # -- gripper history queries --------------------------------------------------------------------------------------
+    def encode_gripper_history(self, gripper_history, context_feats, context_pos, closedness):
+        """gripper_history (B,nhist,ngrip,9), closedness (B,nhist,ngrip,1) -> (B,nhist*ngrip,D)."""
+        B = gripper_history.shape[0]
+        D = self.cfg.embedding_dim
+        if self.cfg.encode_openness:
+            q = self.open_close(closedness.flatten(1)).reshape(B, -1, D)
+        else:
+            q = self.history_embed.weight[None].expand(B, -1, -1)
+        q_rot = rotary3d(gripper_history[..., :3].flatten(1, 2), D)
+        out, _ = self.gripper_context(q, context_feats, None, q_rot, rotary3d(context_pos, D))
+        return out
+
+    def attend_instruction(self, context_feats, instruction):
+        instr = self.instruction_encoder(instruction)
+        for attn, ffn in zip(self.vl_attention, self.vl_ffn):
+            context_feats, _ = attn(context_feats, instr)
+            context_feats = ffn(context_feats)
+        return context_feats, instr
+
+    # -- farthest point subsampling -------------------------------------------------------------------------------------
+    def run_fps(self, context_feats, context_pos, context_mask):
+        """Subsample the context to N / fps_subsampling_factor tokens by FPS in feature space (invalid tokens zeroed
+        first, so at most one of them is picked before every valid one; encoder.py:338-419)."""
+        B, N, D = context_feats.shape
+        masked = context_feats * context_mask[..., None]
+        n_keep = max(N // self.cfg.fps_subsampling_factor, 1)
+        fps = farthest_point_sampling if masked.is_cuda else farthest_point_sampling_reference
+        idx = fps(masked, n_keep, 0)
+        feats = torch.gather(masked, 1, idx[..., None].expand(-1, -1, D))
+        pos = torch.gather(context_pos, 1, idx[..., None].expand(-1, -1, 3))
+        return feats, pos, (feats != 0).any(dim=-1)
+
+
+class DiffusionHead(nn.Module):
+    def __init__(self, cfg: DiffuserActorConfig):
+        super().__init__()
+        self.cfg = cfg
+        D, H, p = cfg.embedding_dim, cfg.num_attn_heads, cfg.dropout
+        nq = cfg.num_history * cfg.ngrippers
+        self.traj_encoder = nn.Linear(9, D)
+        self.time_mlp = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D))
+        self.history_mlp = nn.Sequential(nn.Linear(D * nq, D), nn.ReLU(), nn.Linear(D, D))
+        self.cross_attn = AttentionStack(D, H, 2, p, use_adaln=True)
+        self.self_attn = AttentionStack(D, H, 4, p, use_adaln=True, self_attention=True)
+        self.rotation_attn = AttentionStack(D, H, 2, p, use_adaln=True, self_attention=True)
+        self.position_attn = AttentionStack(D, H, 2, p, use_adaln=True, self_attention=True)
+        self.rotation_proj, self.position_proj = nn.Linear(D, D), nn.Linear(D, D)
+        self.rotation_out = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 6))
+        self.position_out = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 3))
+        self.openness_out = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 1))
+        self.head_yaw_out = nn.Sequential(nn.Linear(D * cfg.ngrippers, D), nn.ReLU(), nn.Linear(D, 1)) if cfg.predict_head_yaw else None
+        self.drop = nn.Dropout(p)
+
+    def forward(self, trajectory, timestep, enc, need_weights: bool = False):
+        """trajectory (B,L,ngrip,9) noisy sample, timestep (B,), enc = Encoder outputs.
+        Returns (pred (B,L,ngrip,10), head_yaw (B,L,1) or None, cross-attention weights or None)."""
+        cfg, D = self.cfg, self.cfg.embedding_dim
+        B, L, G, _ = trajectory.shape
+        nt = L * G
+        tokens = self.drop(self.traj_encoder(trajectory)).flatten(1, 2)
+        tokens = tokens + sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
+        cond = self.time_mlp(sinusoidal_embedding(timestep, D)) + self.history_mlp(enc["history_feats"].flatten(1))
+
+        ctx_mask, fps_mask = enc["context_mask"], enc["fps_mask"]
+        ctx_feats, fps_feats = enc["context_feats"], enc["fps_feats"]
+        # a sample whose context is fully masked would give NaN attention rows: attend to (zeroed) everything instead
+        empty, empty_fps = ~ctx_mask.any(dim=-1), ~fps_mask.any(dim=-1)
+        if bool(empty.any()) or bool(empty_fps.any()):
+            ctx_mask = ctx_mask | empty[:, None]
+            fps_mask = fps_mask | empty_fps[:, None]
+            ctx_feats = ctx_feats * (~empty)[:, None, None]
+            fps_feats = fps_feats * (~empty_fps)[:, None, None]
+
+        traj_rot = rotary3d(trajectory[..., :3].flatten(1, 2), D)
+        tokens, weights = self.cross_attn(tokens, ctx_feats, cond, traj_rot, rotary3d(enc["context_pos"], D),
+                                          key_padding_mask=~ctx_mask, need_weights=need_weights)
+        seq = torch.cat([tokens, fps_feats], dim=1)
+        fps_rot = rotary3d(enc["fps_pos"], D)
+        seq_rot = (torch.cat([traj_rot[0], fps_rot[0]], dim=1), torch.cat([traj_rot[1], fps_rot[1]], dim=1))
+        pad = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=seq.device), ~fps_mask], dim=1)
+        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
+        rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
+        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
+        rot_feat = self.drop(self.rotation_proj(rot_seq[:, :nt]))
+        pos_feat = self.drop(self.position_proj(pos_seq[:, :nt]))
+        pred = torch.cat([self.position_out(pos_feat), self.rotation_out(rot_feat), self.openness_out(pos_feat)], dim=-1)
+        head_yaw = self.head_yaw_out(pos_feat.reshape(B, L, G * D)) if self.head_yaw_out is not None else None
+        if weights is not None:
+            weights = weights.mean(dim=1)  # average over heads
+        return pred.reshape(B, L, G, 10), head_yaw, weights
+
+
+class DiffuserActor(nn.Module):
+    def __init__(self, cfg: DiffuserActorConfig, workspace_bounds: torch.Tensor):
+        super().__init__()
+        self.cfg = cfg
+        self.register_buffer("workspace_bounds", workspace_bounds.to(torch.float32).clone(), persistent=False)
+        self.encoder = Encoder(cfg)
+        self.prediction_head = DiffusionHead(cfg)
+        self.position_noise_scheduler = DDPMScheduler(cfg.diffusion_timesteps, "scaled_linear")
+        self.rotation_noise_scheduler = DDPMScheduler(cfg.diffusion_timesteps, "squaredcos_cap_v2")
+
+    # -- shared encoding --------------------------------------------------------------------------------------------------
+    def encode_inputs(self, rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices, vertices_valid_mask, instruction,
+                      gripper_history, closedness):
+        enc = self.encoder
+        feats, pos, mask = [], [], []
+        if enc.uses_images:
+            f, p, m = enc.encode_images(rgb_obs, pcd_obs, pcd_valid_mask)
+            feats.append(f), pos.append(p), mask.append(m)
+        if enc.uses_mesh:
+            assert vertices.ndim == 3 and vertices_valid_mask.ndim == 2 and vertices.shape[1] == vertices_valid_mask.shape[1]
+            f, p = enc.encode_vertices(vertex_features, vertices)
+            feats.append(f), pos.append(p), mask.append(vertices_valid_mask)
+        context_feats, context_pos, context_mask = torch.cat(feats, 1), torch.cat(pos, 1), torch.cat(mask, 1)
+        instr = None
+        if self.cfg.use_instruction:
+            context_feats, instr = enc.attend_instruction(context_feats, instruction)
+        history_feats = enc.encode_gripper_history(gripper_history, context_feats, context_pos, closedness)
+        if self.cfg.use_fps:
+            with Timer("diffuser_actor/encode_inputs/fps"):
+                fps_feats, fps_pos, fps_mask = enc.run_fps(context_feats, context_pos, context_mask)
+        else:
+            fps_feats, fps_pos, fps_mask = context_feats, context_pos, context_mask
+        return {"context_feats": context_feats, "context_pos": context_pos, "context_mask": context_mask, "instr_feats": instr,
+                "history_feats": history_feats, "fps_feats": fps_feats, "fps_pos": fps_pos, "fps_mask": fps_mask}
+
+    # -- inference: full reverse diffusion ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_trajectory(self, enc, batch: int, device, generator=None):
+        cfg = self.cfg
+        shape = (batch, cfg.prediction_horizon, cfg.ngrippers, 9)
+        traj = torch.randn(shape, device=device, generator=generator)
+        self.position_noise_scheduler.set_timesteps(cfg.diffusion_timesteps)
+        self.rotation_noise_scheduler.set_timesteps(cfg.diffusion_timesteps)
+        pred = head_yaw = None
+        for t in self.position_noise_scheduler.timesteps.tolist():
+            ts = torch.full((batch,), t, dtype=torch.long, device=device)
+            pred, head_yaw, _ = self.prediction_head(traj, ts, enc)
+            pos = self.position_noise_scheduler.step(pred[..., :3], t, traj[..., :3], generator)
+            rot = self.rotation_noise_scheduler.step(pred[..., 3:9], t, traj[..., 3:9], generator)
+            traj = torch.cat([pos, rot], dim=-1)
+        return torch.cat([traj, pred[..., 9:]], dim=-1), head_yaw  # openness / head yaw are not diffused
+
+    # -- forward --------------------------------------------------------------------------------------------------------
+    def forward(self, gt_gripper_pred, gt_head_yaw, rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices,
+                vertices_valid_mask, instruction, gripper_history, run_inference: bool = False):
+        """Arguments as in the reference (diffuser_actor.py:518-531):
+          gt_gripper_pred (B,L,ngrip,8) xyz + quaternion + openness (or None at inference), gt_head_yaw (B,L,1),
+          rgb_obs (B,ncam,3,H,W) in [0,1], pcd_obs (B,ncam,3,H,W) world points, pcd_valid_mask (B,ncam,H,W),
+          vertex_features (B,N,C), vertices (B,N,3) world, vertices_valid_mask (B,N), instruction (B,T,512) or None,
+          gripper_history (B,nhist,ngrip,8).
+        Training: returns ((total, pos, rot, gripper, head_yaw) losses, encoded inputs, None).
+        Inference: returns (trajectory (B,L,ngrip,8), head_yaw, losses or None, encoded inputs, None)."""
+        cfg, wb = self.cfg, self.workspace_bounds
+        closedness = gripper_history[..., 7:8]
+        history = normalize_trajectory(gripper_history[..., :7], wb, cfg.quaternion_format)
+        if pcd_obs is not None:
+            pcd_obs, inside = normalize_pointcloud(pcd_obs, wb)
+            pcd_valid_mask = pcd_valid_mask & inside
+        if vertices is not None:
+            vertices, _ = normalize_pos(vertices, wb)
+        gt, gt_open = None, None
+        if gt_gripper_pred is not None:
+            assert gt_gripper_pred.shape[-1] == 8
+            gt_open = gt_gripper_pred[..., 7:]
+            gt = normalize_trajectory(gt_gripper_pred[..., :7], wb, cfg.quaternion_format)
+        with Timer("diffuser_actor/encode_inputs"):
+            enc = self.encode_inputs(rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices, vertices_valid_mask,
+                                     instruction, history, closedness)
+        B, dev = history.shape[0], history.device
+        if run_inference:
+            traj, head_yaw = self.sample_trajectory(enc, B, dev)
+            losses = None
+            if gt is not None:
+                losses = compute_loss(traj, head_yaw, gt, gt_open, gt_head_yaw, cfg.loss_weights, cfg.predict_head_yaw)
+            traj = unnormalize_trajectory(traj, wb, cfg.quaternion_format)
+            if head_yaw is not None:
+                head_yaw = head_yaw.clamp(-torch.pi, torch.pi - 1e-6)
+            return traj, head_yaw, losses, enc, None
+        noise = torch.randn(gt.shape, device=dev)
+        timesteps = torch.randint(0, cfg.diffusion_timesteps, (B,), device=dev)
+        noisy = torch.cat([self.position_noise_scheduler.add_noise(gt[..., :3], noise[..., :3], timesteps),
+                           self.rotation_noise_scheduler.add_noise(gt[..., 3:9], noise[..., 3:9], timesteps)], dim=-1)
+        with Timer("diffuser_actor/policy_forward_pass"):
+            pred, head_yaw, _ = self.prediction_head(noisy, timesteps, enc)
+        losses = compute_loss(pred, head_yaw, noise, gt_open, gt_head_yaw, cfg.loss_weights, cfg.predict_head_yaw)
+        return losses, enc, None
