@@ -150,6 +150,42 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
     return out
 
 
+def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32):
+    """Policy training step/s (second half of the BASELINE metric; config 5): diffuser_actor, RGBD_AND_MESH, per-GPU batch 32,
+    one 512x512 camera, 2048 vertices x 768 features, frozen ViT-B/16-shaped backbone (random-init stand-in for RADIO v2.5-B),
+    fp32, synthetic cached-sample-shaped batches resident on the GPU; DDP (RCCL all-reduce) when world > 1."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, build_optimizer, synthetic_batch, train_one_step, wrap_ddp
+    from nvblox_mindmap_amd.training.distributed import barrier, max_over_ranks
+
+    torch.manual_seed(0)
+    cfg = DiffuserActorConfig()
+    model = build_model(cfg, device=device)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    n_frozen = sum(p.numel() for p in model.parameters() if not p.requires_grad)
+    ddp = wrap_ddp(model, device)
+    opt = build_optimizer(ddp)
+    batches = [synthetic_batch(cfg, per_gpu_batch, device, seed=1000 * int(os.environ.get("RANK", "0")) + i) for i in range(2)]
+    for i in range(warmup):
+        train_one_step(cfg, ddp, opt, batches[i % 2])
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        train_one_step(cfg, ddp, opt, batches[i % 2])
+    torch.cuda.synchronize(device)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, device)
+    out = {"step_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "samples_per_s": steps * per_gpu_batch * world / dt,
+           "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup,
+           "trainable_params": n_train, "frozen_backbone_params": n_frozen, "dtype": "f32",
+           "allreduce_payload_MB": n_train * 4 / 1e6, "parallelism": f"dp{world}" if world > 1 else "single",
+           "model": "diffuser_actor RGBD_AND_MESH, 1 cam 512x512, 2048 vertices x 768, frozen ViT-B/16-shaped backbone (random init)"}
+    del model, ddp, opt, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +196,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ref-shape", action="store_true", help="skip the short run at the reference's real shape (512x512x768)")
+    ap.add_argument("--no-train", action="store_true", help="skip the policy training-step measurement")
+    ap.add_argument("--train-steps", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -223,6 +261,11 @@ def main():
     ref_shape = None
     if rank == 0 and not args.no_ref_shape:
         ref_shape = run_reference_shape(device)
+    train = None
+    if not args.no_train:  # every rank takes part (DDP)
+        if dist is not None:
+            dist.barrier()
+        train = run_training(device, world, steps=args.train_steps)
 
     if rank == 0:
         C = args.channels
@@ -306,6 +349,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_us_per_launch": breakdown,
             "reference_shape": ref_shape,
+            "train": train,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -44,6 +44,7 @@ class DiffuserActorConfig:
     predict_head_yaw: bool = True
     use_instruction: bool = False
     quaternion_format: str = "wxyz"
+    rotation_parametrization: str = "6D_from_query"  # reference default (cli/args.py); see rotations.unnormalize_trajectory
     add_external_cam: bool = False
     dropout: float = 0.0
     backbone: str = "vit_b16"               # random-init stand-in for the frozen RADIO v2.5-B ("none": rgb tokens are given)
@@ -281,7 +282,7 @@ class DiffuserActor(nn.Module):
             losses = None
             if gt is not None:
                 losses = compute_loss(traj, head_yaw, gt, gt_open, gt_head_yaw, cfg.loss_weights, cfg.predict_head_yaw)
-            traj = unnormalize_trajectory(traj, wb, cfg.quaternion_format)
+            traj = unnormalize_trajectory(traj, wb, cfg.quaternion_format, cfg.rotation_parametrization)
             if head_yaw is not None:
                 head_yaw = head_yaw.clamp(-torch.pi, torch.pi - 1e-6)
             return traj, head_yaw, losses, enc, None

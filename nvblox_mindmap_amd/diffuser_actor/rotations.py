@@ -83,10 +83,19 @@ def normalize_trajectory(traj: torch.Tensor, workspace_bounds: torch.Tensor, qua
     return torch.cat([pos, matrix_to_ortho6d(quat_wxyz_to_matrix(q))], dim=-1)
 
 
-def unnormalize_trajectory(traj: torch.Tensor, workspace_bounds: torch.Tensor, quaternion_format: str = "wxyz") -> torch.Tensor:
-    """(...,9[+1]) normalised xyz + 6-D rotation [+ openness logit] -> (...,7[+1]) xyz + quaternion [+ openness prob]."""
+def unnormalize_trajectory(traj: torch.Tensor, workspace_bounds: torch.Tensor, quaternion_format: str = "wxyz",
+                           rotation_parametrization: str = "6D_from_query") -> torch.Tensor:
+    """(...,9[+1]) normalised xyz + 6-D rotation [+ openness logit] -> (...,7[+1]) xyz + quaternion [+ openness prob].
+
+    Reference quirk kept for parity: unless ``rotation_parametrization`` is exactly "6D", the reference first L2-normalises
+    channels 3:7 as if they held a quaternion (mindmap/model_utils/normalization.py, ``if rotation_parametrization !=
+    "6D"``) -- with its default "6D_from_query" that rescales the first four of the six rotation channels before the
+    Gram-Schmidt step."""
     pos = unnormalize_pos(traj[..., :3], workspace_bounds)
-    q = matrix_to_quat_wxyz(ortho6d_to_matrix(traj[..., 3:9]))
+    d6 = traj[..., 3:9]
+    if rotation_parametrization != "6D":
+        d6 = torch.cat([normalise_quat(d6[..., :4]), d6[..., 4:]], dim=-1)
+    q = matrix_to_quat_wxyz(ortho6d_to_matrix(d6))
     if quaternion_format == "xyzw":
         q = q[..., (1, 2, 3, 0)]
     out = [pos, q]

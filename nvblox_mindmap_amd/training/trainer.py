@@ -1,0 +1,112 @@
+"""Training step of the policy (counterpart of mindmap/run_training.py:140-217,597-642)."""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn.parallel import DistributedDataParallel
+
+from ..diffuser_actor import DiffuserActor, DiffuserActorConfig
+from ..image_processing.backprojection import get_camera_pointcloud
+from ..mapping.nvblox_mapper_constants import get_workspace_bounds
+from ..nvblox_torch.timer import Timer
+from .distributed import get_world_size
+
+
+def build_model(cfg: Optional[DiffuserActorConfig] = None, task: str = "DRILL_IN_BOX", device="cuda") -> DiffuserActor:
+    cfg = cfg or DiffuserActorConfig()
+    return DiffuserActor(cfg, get_workspace_bounds(task)).to(device)
+
+
+def wrap_ddp(model: nn.Module, device) -> nn.Module:
+    """DDP exactly as the reference wraps it (run_training.py:608-613): find_unused_parameters because the instruction
+    branch is unused when use_instruction = 0, no buffer broadcast.  Single process: the bare model."""
+    if get_world_size() == 1:
+        return model
+    dev = torch.device(device)
+    ids = [dev.index] if dev.type == "cuda" else None
+    return DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False, find_unused_parameters=True)
+
+
+def build_optimizer(model: nn.Module, lr: float = 1e-4, weight_decay: float = 5e-4) -> torch.optim.Optimizer:
+    """AdamW, two groups: biases and LayerNorm parameters without weight decay (run_training.py:140-153)."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (name.endswith("bias") or "norm" in name.lower()) else decay).append(p)
+    return torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0, "lr": lr}, {"params": decay, "weight_decay": weight_decay, "lr": lr}])
+
+
+def build_lr_scheduler(optimizer, train_iters: int = 100000, convergence_percentage: float = 0.75, end_factor: float = 0.5):
+    return torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=1.0, end_factor=end_factor,
+                                             total_iters=int(train_iters * convergence_percentage))
+
+
+def synthetic_batch(cfg: DiffuserActorConfig, batch_size: int, device, num_vertices: int = 2048, seed: int = 0,
+                    task: str = "DRILL_IN_BOX") -> Dict[str, torch.Tensor]:
+    """A cached-sample-shaped batch as the data loader hands it over BEFORE unpack_batch:
+    rgb in [0,1], metric depth, camera intrinsics / pose, sampled map vertices + f16 features, gripper states."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    wb = get_workspace_bounds(task)
+    lo, hi = wb[0], wb[1]
+    H, W = cfg.image_size
+    ncam = 2 if cfg.add_external_cam else 1
+    B = batch_size
+
+    def poses(*shape):
+        q = torch.nn.functional.normalize(torch.randn(*shape, 4, generator=g), dim=-1)
+        p = lo + (hi - lo) * torch.rand(*shape, 3, generator=g)
+        return torch.cat([p, q, (torch.rand(*shape, 1, generator=g) > 0.5).float()], dim=-1)
+
+    cam_pos = torch.tensor([1.4, 0.0, 0.6]) + 0.05 * torch.randn(B, ncam, 3, generator=g)
+    cam_quat = torch.tensor([0.5, -0.5, 0.5, -0.5]).expand(B, ncam, 4) + 0.01 * torch.randn(B, ncam, 4, generator=g)
+    batch = {
+        "rgbs": torch.rand(B, ncam, 3, H, W, generator=g),
+        "depths": 0.4 + 1.2 * torch.rand(B, ncam, H, W, generator=g),
+        "intrinsics": torch.tensor([[586.4, 0.0, W / 2.0], [0.0, 586.4, H / 2.0], [0.0, 0.0, 1.0]]).expand(B, ncam, 3, 3).contiguous(),
+        "camera_poses": torch.cat([cam_pos, cam_quat], dim=-1),
+        "vertices": lo + (hi - lo) * torch.rand(B, num_vertices, 3, generator=g),
+        "vertex_features": torch.randn(B, num_vertices, cfg.feature_dim, generator=g).to(torch.float16),
+        "vertices_valid_mask": torch.rand(B, num_vertices, generator=g) > 0.05,
+        "gripper_history": poses(B, cfg.num_history, cfg.ngrippers),
+        "gt_gripper_pred": poses(B, cfg.prediction_horizon, cfg.ngrippers),
+        "gt_head_yaw": torch.rand(B, cfg.prediction_horizon, 1, generator=g) - 0.5,
+    }
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+def unpack_batch(cfg: DiffuserActorConfig, batch: Dict[str, torch.Tensor], min_depth: float = 0.0) -> Dict[str, torch.Tensor]:
+    """Loader batch -> model inputs (mindmap/data_loading/batching.py:213-262,304-326,360-417).  The reference back-projects
+    the depth on the CPU before ``.to(device)`` (its "CPU back-projection path"); here it is the HIP kernel on the GPU."""
+    out = dict(batch)
+    uses_images = cfg.data_type in ("rgbd", "rgbd_and_mesh")
+    if uses_images:
+        ncam = batch["depths"].shape[1]
+        with Timer("step/train/unpack_pcd"):
+            out["pcds"] = torch.stack([
+                get_camera_pointcloud(batch["intrinsics"][:, c], batch["depths"][:, c], batch["camera_poses"][:, c, :3],
+                                      batch["camera_poses"][:, c, 3:]) for c in range(ncam)], dim=1)
+        out["pcd_valid_mask"] = batch["depths"] > min_depth
+    else:
+        out["rgbs"], out["pcds"], out["pcd_valid_mask"] = None, None, None
+    if cfg.data_type in ("mesh", "rgbd_and_mesh"):
+        out["vertex_features"] = batch["vertex_features"].to(torch.float32)
+    else:
+        out["vertex_features"], out["vertices"], out["vertices_valid_mask"] = None, None, None
+    return out
+
+
+def train_one_step(cfg: DiffuserActorConfig, model: nn.Module, optimizer, batch: Dict[str, torch.Tensor], scheduler=None):
+    """unpack -> forward (losses) -> backward (DDP all-reduce overlaps) -> AdamW step.  Returns the detached losses."""
+    with Timer("step/train/unpack_batch"):
+        s = unpack_batch(cfg, batch)
+    optimizer.zero_grad(set_to_none=True)
+    with Timer("step/train/compute_losses"):
+        losses, _, _ = model(s["gt_gripper_pred"], s["gt_head_yaw"], s["rgbs"], s["pcds"], s["pcd_valid_mask"], s["vertex_features"],
+                             s["vertices"], s["vertices_valid_mask"], None, s["gripper_history"])
+    with Timer("step/train/backprop"):
+        losses[0].backward()
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return tuple(None if x is None else x.detach() for x in losses)

@@ -168,6 +168,50 @@ def main():
     q = rng.standard_normal((16, 4)).astype(np.float32)
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     np.savez_compressed(os.path.join(HERE, "quaternion.npz"), q=q, R=quaternion_to_matrix(torch.from_numpy(q)).numpy())
+
+    # ---------------- policy math (normalisation, rotations, position codes, loss) ----------------
+    from mindmap.diffuser_actor.position_encodings import RotaryPositionEncoding, RotaryPositionEncoding3D, SinusoidalPosEmb
+    from mindmap.geometry.utils import (compute_rotation_matrix_from_ortho6d, get_ortho6d_from_rotation_matrix,
+                                        matrix_to_quaternion)
+    from mindmap.model_utils.loss import LossWeights, compute_loss
+    from mindmap.model_utils.normalization import normalize_pos, normalize_trajectory, unnormalize_trajectory
+
+    pm = {}
+    wb = torch.tensor([[-0.37, -0.75, -0.13], [0.95, 0.75, 0.65]])
+    pm["wb"] = wb.numpy()
+    traj = torch.from_numpy(rng.uniform(-0.5, 0.9, size=(3, 2, 2, 7)).astype(np.float32))
+    traj[..., 3:] = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((3, 2, 2, 4)).astype(np.float32)), dim=-1)
+    pm["traj"] = traj.numpy()
+    n9 = normalize_trajectory(traj.clone(), wb, "6D_from_query", "wxyz")
+    pm["traj_norm"] = n9.numpy()
+    n10 = torch.cat([n9, torch.from_numpy(rng.standard_normal((3, 2, 2, 1)).astype(np.float32))], dim=-1)
+    pm["traj_norm10"] = n10.numpy()
+    pm["traj_unnorm"] = unnormalize_trajectory(n10.clone(), wb, "6D_from_query", "wxyz").numpy()
+    pts = torch.from_numpy(rng.uniform(-1, 1.2, size=(5, 7, 3)).astype(np.float32))
+    pn, pv = normalize_pos(pts, wb)
+    pm["pts"], pm["pts_norm"], pm["pts_valid"] = pts.numpy(), pn.numpy(), pv.numpy()
+    d6 = torch.from_numpy(rng.standard_normal((9, 6)).astype(np.float32))
+    R = compute_rotation_matrix_from_ortho6d(d6)
+    pm["d6"], pm["d6_R"] = d6.numpy(), R.numpy()
+    pm["R_d6"] = get_ortho6d_from_rotation_matrix(R).numpy()
+    pm["R_quat"] = matrix_to_quaternion(R).numpy()
+    xyz = torch.from_numpy(rng.uniform(-1, 1, size=(2, 11, 3)).astype(np.float32))
+    pe = RotaryPositionEncoding3D(120)(xyz)
+    pm["rot_xyz"], pm["rot_code"] = xyz.numpy(), pe.numpy()
+    x = torch.from_numpy(rng.standard_normal((2, 11, 120)).astype(np.float32))
+    pm["rot_x"] = x.numpy()
+    pm["rot_applied"] = RotaryPositionEncoding.embed_rotary(x, pe[..., 0], pe[..., 1]).numpy()
+    t = torch.tensor([0.0, 1.0, 17.0, 99.0])
+    pm["sin_t"], pm["sin_emb"] = t.numpy(), SinusoidalPosEmb(120)(t).numpy()
+    pred = torch.from_numpy(rng.standard_normal((4, 1, 2, 10)).astype(np.float32))
+    tgt = torch.from_numpy(rng.standard_normal((4, 1, 2, 9)).astype(np.float32))
+    go = (torch.from_numpy(rng.uniform(size=(4, 1, 2, 1))) > 0.5).float()
+    hy_p = torch.from_numpy(rng.standard_normal((4, 1, 1)).astype(np.float32))
+    hy_g = torch.from_numpy(rng.uniform(-1, 1, size=(4, 1, 1)).astype(np.float32))
+    L = compute_loss(pred, hy_p, tgt, go, hy_g, LossWeights(), True, rotation_form="6D")
+    pm["loss_pred"], pm["loss_tgt"], pm["loss_open"], pm["loss_hyp"], pm["loss_hyg"] = pred.numpy(), tgt.numpy(), go.numpy(), hy_p.numpy(), hy_g.numpy()
+    pm["loss_out"] = np.array([float(v) for v in L])
+    np.savez_compressed(os.path.join(HERE, "policy_math.npz"), **pm)
     print("golden fixtures written to", HERE)
 
 
