@@ -1145,8 +1145,9 @@ int mmf_upsample_features(const float* lowres, int hh, int ww, int Cin, void* ou
 int mmf_farthest_point_sampling(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* stream) {
   if (!x || !out_idx || B <= 0 || N <= 0 || C <= 0 || npoints <= 0 || npoints > N || start_idx < 0 || start_idx >= N)
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_farthest_point_sampling");
-  if (launch_fps(x, B, N, C, npoints, start_idx, reinterpret_cast<long long*>(out_idx), (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_farthest_point_sampling supports N <= 8192 and C <= 1024");
+  const int rc = launch_fps(x, B, N, C, npoints, start_idx, reinterpret_cast<long long*>(out_idx), (hipStream_t)stream);
+  if (rc == 1) return fail(MMF_ERR_INVALID_ARG, "mmf_farthest_point_sampling supports N <= 8192 and C <= 1024");
+  if (rc != 0) return fail(MMF_ERR_HIP, "mmf_farthest_point_sampling: HIP runtime call failed");
   return check_launch();
 }
 

@@ -4,21 +4,121 @@
 // build) called at mindmap/diffuser_actor/encoder.py:366-370 with B = 32, N = 3072 tokens, C = 120 channels,
 // npoints = N/5 = 614.
 //
-// Algorithm (classic FPS): dist[i] = +inf; pick start; repeat npoints-1 times: dist[i] = min(dist[i], |x_i - x_sel|^2),
-// select argmax_i dist[i] (first index on ties).  Iterations are sequential, so one batch element is one workgroup
-// (1024 threads): the selected row is broadcast through LDS, every thread keeps the running distance of its points in
-// registers, the argmax is a wave-shuffle + LDS reduction.  The point matrix of one batch element (1.5 MB) is
-// re-read from L2 every iteration: the kernel is L2-bandwidth / latency bound, ~3 us per iteration.
+// Algorithm (classic FPS): dist[i] = +inf; pick start; repeat npoints-1 times: dist[i] = min(dist[i], |x_i - x_sel|^2)
+// with the squared distance accumulated channel by channel in float32 (acc += d*d, no fma), select argmax_i dist[i]
+// (first index on ties).  The picks are sequential, so the only parallelism is inside one pick.
+//
+// Resident-point kernel (k_fps_resident, the path for N <= 4096, C <= 128):
+//   * one batch element is spread over W = ceil(N/64) single-wave workgroups; lane l of wave w owns point 64*w + l and
+//     keeps its CP (C padded to 16/32/64/96/128) channels IN REGISTERS for the whole kernel: after the first touch no
+//     point data is read from memory again (the first version streamed the 1.5 MB point matrix from L2 on every pick,
+//     uncoalesced: 65 us per pick);
+//   * the selected row is wave-uniform: 512 B of scalar loads from a zero-padded copy of x made by k_fps_pad;
+//   * the argmax is a wave butterfly + an exchange through global memory: every wave publishes one 64-bit key
+//     {f32 bits of dist | 12 bits ~index | 20-bit pick number} into slot[batch][pick & 1][wave] with a relaxed
+//     agent-scope store and polls the W slots of its batch element until all carry the current pick number.  Two
+//     slot rows suffice: a wave can publish pick p+2 only after it has read every wave's pick p+1 key, which that wave
+//     stored after reading all keys of pick p.  No other data is ordered by the exchange, so no fences are needed;
+//   * the waves of one batch element take block ids of the same residue mod 8 (same XCD), adjacent in launch order.
+//     Launches are chunked so that the whole grid is co-resident; the spin is bounded (writes -1 and leaves).
+// Fallback kernel (k_fps_stream) for larger N or C: one 1024-thread workgroup per batch element, points streamed.
+#include <math.h>
+
 #include "mmf_launch.h"
 
 namespace mmf {
+
+constexpr int kFpsMaxResidentN = 4096;  // 12 index bits in the key, <= 64 waves polled by one wave
+constexpr int kFpsMaxResidentC = 128;
+constexpr unsigned kFpsSpinLimit = 1u << 22;
+
+template <int CP>
+__global__ __launch_bounds__(256) void k_fps_pad(const float* __restrict__ x, long long rows, int C, float* __restrict__ xp) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * CP) return;
+  const long long r = i / CP;
+  const int c = (int)(i - r * CP);
+  xp[i] = c < C ? x[r * C + c] : 0.0f;
+}
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const u64 o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int CP>
+__global__ __launch_bounds__(64) void k_fps_resident(const float* __restrict__ xp, int b0, int bend, int N, int W, int npoints,
+                                                    int start, u64* slots, long long* __restrict__ out_idx) {
+  const int id = blockIdx.x, lane = threadIdx.x;
+  const int r = id >> 3;
+  const int g = b0 + (id & 7) + 8 * (r / W);  // batch element: its W waves share id % 8 (one XCD)
+  const int w = r % W;
+  if (g >= bend) return;  // rounded-up tail of this launch: belongs to the next chunk (or to nobody)
+  const int p = w * 64 + lane;
+  const bool valid = p < N;
+  const float* xb = xp + (size_t)g * N * CP;
+  float v[CP];
+  {
+    const float4* src = reinterpret_cast<const float4*>(xb + (size_t)(valid ? p : 0) * CP);
+#pragma unroll
+    for (int c = 0; c < CP / 4; ++c) {
+      const float4 q = src[c];
+      v[4 * c] = q.x, v[4 * c + 1] = q.y, v[4 * c + 2] = q.z, v[4 * c + 3] = q.w;
+    }
+  }
+  u64* myslots = slots + (size_t)g * 2 * 64;
+  long long* ob = out_idx + (size_t)g * npoints;
+  float dist = INFINITY;
+  int cur = start;
+  if (w == 0 && lane == 0) ob[0] = cur;
+  const u64 pidx = (u64)(0xFFFu - (unsigned)p) << 20;
+  for (int it = 1; it < npoints; ++it) {
+    const float* row = xb + (size_t)__builtin_amdgcn_readfirstlane(cur) * CP;  // wave-uniform: scalar loads
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float d = v[c] - row[c];
+      acc += d * d;
+    }
+    dist = fminf(dist, acc);
+    const u64 tag = (u64)(it & 0xFFFFF);
+    u64 key = valid ? (((u64)__float_as_uint(dist) << 32) | pidx | tag) : tag;
+    key = wave_max_u64(key);
+    u64* row_slots = myslots + (it & 1) * 64;
+    if (lane == 0) __hip_atomic_store(row_slots + w, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 got = tag;
+    if (lane < W) {
+      unsigned spins = 0;
+      for (;;) {
+        got = __hip_atomic_load(row_slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((got & 0xFFFFF) == tag) break;
+        if (++spins > kFpsSpinLimit) {
+          got = ~0ull;  // the exchange never completed (a peer wave is not running): give up, flagged below
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    got = wave_max_u64(got);
+    if (got == ~0ull) {
+      if (lane == 0) ob[it] = -1;
+      return;
+    }
+    cur = 0xFFF - (int)((got >> 20) & 0xFFF);
+    if (w == 0 && lane == 0) ob[it] = cur;
+  }
+}
 
 constexpr int kFpsThreads = 1024;
 constexpr int kFpsMaxPerThread = 8;  // N <= 8192
 constexpr int kFpsMaxC = 1024;
 
-__global__ __launch_bounds__(kFpsThreads) void k_fps(const float* __restrict__ x, int N, int C, int npoints, int start,
-                                                    long long* __restrict__ out_idx) {
+__global__ __launch_bounds__(kFpsThreads) void k_fps_stream(const float* __restrict__ x, int N, int C, int npoints, int start,
+                                                           long long* __restrict__ out_idx) {
   __shared__ float s_sel[kFpsMaxC];
   __shared__ float s_best_d[kFpsThreads / 64];
   __shared__ int s_best_i[kFpsThreads / 64];
@@ -28,7 +128,7 @@ __global__ __launch_bounds__(kFpsThreads) void k_fps(const float* __restrict__ x
   long long* ob = out_idx + (size_t)b * npoints;
   float dist[kFpsMaxPerThread];
 #pragma unroll
-  for (int k = 0; k < kFpsMaxPerThread; ++k) dist[k] = 3.0e38f;
+  for (int k = 0; k < kFpsMaxPerThread; ++k) dist[k] = INFINITY;
   int cur = start;
   if (tid == 0) ob[0] = cur;
   for (int it = 1; it < npoints; ++it) {
@@ -85,9 +185,49 @@ __global__ __launch_bounds__(kFpsThreads) void k_fps(const float* __restrict__ x
   }
 }
 
+template <int CP>
+static int fps_resident(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+  const int W = (N + 63) / 64;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fps_resident<CP>, 64, 0) != hipSuccess || per_cu <= 0)
+    return 2;
+  // batch elements per launch: the whole grid must be co-resident (waves of one element wait for each other)
+  int chunk = (int)((long long)cus * per_cu / W) / 8 * 8;
+  if (chunk < 8) return 1;
+  float* xp = nullptr;
+  u64* slots = nullptr;
+  const size_t xp_bytes = sizeof(float) * (size_t)B * N * CP, slot_bytes = sizeof(u64) * (size_t)B * 2 * 64;
+  if (hipMallocAsync((void**)&xp, xp_bytes, s) != hipSuccess) return 2;
+  if (hipMallocAsync((void**)&slots, slot_bytes, s) != hipSuccess) {
+    (void)hipFreeAsync(xp, s);
+    return 2;
+  }
+  (void)hipMemsetAsync(slots, 0, slot_bytes, s);
+  const long long rows = (long long)B * N;
+  hipLaunchKernelGGL(k_fps_pad<CP>, dim3((unsigned)((rows * CP + 255) / 256)), dim3(256), 0, s, x, rows, C, xp);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = (B - b0 < chunk ? B - b0 : chunk);
+    hipLaunchKernelGGL(k_fps_resident<CP>, dim3(8 * W * ((nb + 7) / 8)), dim3(64), 0, s, xp, b0, b0 + nb, N, W, npoints, start, slots,
+                       out_idx);
+  }
+  (void)hipFreeAsync(slots, s);
+  (void)hipFreeAsync(xp, s);
+  return 0;
+}
+
+// 0 = launched, 1 = unsupported shape, 2 = HIP runtime error
 int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+  if (N <= kFpsMaxResidentN && C <= kFpsMaxResidentC) {
+    const int rc = C <= 16   ? fps_resident<16>(x, B, N, C, npoints, start, out_idx, s)
+                   : C <= 32 ? fps_resident<32>(x, B, N, C, npoints, start, out_idx, s)
+                   : C <= 64 ? fps_resident<64>(x, B, N, C, npoints, start, out_idx, s)
+                   : C <= 96 ? fps_resident<96>(x, B, N, C, npoints, start, out_idx, s)
+                             : fps_resident<128>(x, B, N, C, npoints, start, out_idx, s);
+    if (rc != 1) return rc;  // 1: the waves of 8 batch elements cannot be co-resident on this device -> stream
+  }
   if (N > kFpsThreads * kFpsMaxPerThread || C > kFpsMaxC) return 1;
-  hipLaunchKernelGGL(k_fps, dim3(B), dim3(kFpsThreads), 0, s, x, N, C, npoints, start, out_idx);
+  hipLaunchKernelGGL(k_fps_stream, dim3(B), dim3(kFpsThreads), 0, s, x, N, C, npoints, start, out_idx);
   return 0;
 }
 
