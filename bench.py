@@ -55,6 +55,7 @@ def build_stream(cfg: S.StreamConfig, n_frames: int, channels: int, device):
         feat = upsample_features(low, (cfg.height, cfg.width), channels)
         frames.append({
             "index": idx,
+            "lowres": low.permute(1, 2, 0).contiguous(),  # [h,w,C] f32: the backbone output the image was made from
             "depth": torch.from_numpy(depth).to(device),
             "rgb": torch.from_numpy(rgb).to(device),
             "features": feat,
@@ -145,8 +146,95 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
         out["feature_kernel_us"] = ms / n * 1e3
         out["feature_kernel_algorithmic_GBps"] = nbytes / (ms / n * 1e-3) / 1e9
         out["feature_kernel_frac_of_hbm_peak"] = nbytes / (ms / n * 1e-3) / HBM_PEAK_BYTES_PER_S
+
+    # The whole per-frame pipeline from the backbone's 16x16xC output (what the reference's FeatureExtractor hands over
+    # before its own resize, feature_extraction.py:188-191): (a) up-sample to [512,512,768] f16 then integrate (two steps,
+    # 403 MB image written and gathered); (b) the fused low-res path (mmf_integrate_frame_lowres), same results.
+    def timed(fn):
+        for i in range(warmup):
+            fn(frames[i % n_frames])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(frames[(warmup + i) % n_frames])
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / steps
+
+    def with_upsample(fr):
+        fr2 = dict(fr)
+        fr2["features"] = upsample_features(fr["lowres"].permute(2, 0, 1), (cfg.height, cfg.width), C)
+        step(mapper, mcfg, fr2)
+
+    def fused_lowres(fr):
+        mapper.decay()
+        mapper.integrate_frame_lowres(fr["depth"], fr["rgb"], fr["lowres"], ~fr["dynamic_mask"], fr["T_W_C"], fr["K"],
+                                      mcfg.min_integration_distance_m, mcfg.static_mask_erosion_iterations,
+                                      mcfg.valid_depth_mask_erosion_iterations, mcfg.feature_mask_border_percent,
+                                      MAPPER_TO_ID.STATIC)
+
+    mapper.clear()
+    dt_up = timed(with_upsample)
+    mapper.clear()
+    mapper.profile_reset()
+    mapper.profile_enable(True, kernels=["feature"])
+    dt_low = timed(fused_lowres)
+    mapper.profile_enable(False)
+    ms, n = mapper.profile()["feature"]
+    out["from_backbone_output"] = {
+        "upsample_then_integrate_frames_per_s": 1.0 / dt_up, "upsample_then_integrate_ms": dt_up * 1e3,
+        "fused_lowres_frames_per_s": 1.0 / dt_low, "fused_lowres_ms": dt_low * 1e3,
+        "fused_lowres_feature_kernel_us": (ms / n * 1e3) if n else None,
+        "upsampled_image_MB_avoided": cfg.height * cfg.width * C * 2 / 1e6}
     del mapper, frames
     torch.cuda.empty_cache()
+    return out
+
+
+def run_backprojection(device, cpu=True):
+    """Depth back-projection: one HIP kernel, 4 B read + 12 B written per pixel.
+    Timed for the 640x480 single frame and the training batch [32,512,512]; the CPU figure is the reference's op sequence
+    on torch CPU tensors (oracle/image_ops.py:backproject_torch_cpu) with all host threads.  All GPU timing happens first
+    (after a warm-up long enough to bring the clocks back up), the CPU legs afterwards."""
+    from nvblox_mindmap_amd.image_processing.backprojection import _backproject_chw
+
+    out, host = {}, {}
+    for name, (B, H, W) in {"single_640x480": (1, 480, 640), "batch_32x512x512": (32, 512, 512)}.items():
+        g = torch.Generator().manual_seed(B)
+        depth = (torch.rand((B, H, W), generator=g) * 2.0 + 0.3)
+        K = torch.tensor([[525.0, 0, W / 2 - 0.5], [0, 525.0, H / 2 - 0.5], [0, 0, 1]]).expand(B, 3, 3).contiguous()
+        T = torch.eye(4).expand(B, 4, 4).clone()
+        T[:, :3, 3] = torch.rand((B, 3), generator=g)
+        host[name] = (depth, K, T)
+        d_d, K_d, T_d = depth.to(device), K.to(device), T.to(device)
+        t_end = time.perf_counter() + 0.25
+        while time.perf_counter() < t_end:
+            _backproject_chw(d_d, K_d, T_d)
+        torch.cuda.synchronize(device)
+        n = 300
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            _backproject_chw(d_d, K_d, T_d)  # includes the output allocation from torch's caching allocator
+        b.record()
+        torch.cuda.synchronize(device)
+        ms = a.elapsed_time(b) / n
+        px = B * H * W
+        out[name] = {"frames_per_s": B / (ms * 1e-3), "ms_per_call": ms, "algorithmic_GBps": px * 16 / (ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": px * 16 / (ms * 1e-3) / HBM_PEAK_BYTES_PER_S, "bytes_per_pixel": 16}
+    if cpu:
+        from oracle.image_ops import backproject_torch_cpu
+
+        torch.set_num_threads(os.cpu_count() or 1)
+        for name, (depth, K, T) in host.items():
+            B = depth.shape[0]
+            backproject_torch_cpu(depth, K, T)
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                backproject_torch_cpu(depth, K, T)
+            dt = (time.perf_counter() - t0) / reps
+            out[name]["cpu_frames_per_s"] = B / dt
+            out[name]["cpu_threads"] = torch.get_num_threads()
     return out
 
 
@@ -266,6 +354,7 @@ def main():
         if dist is not None:
             dist.barrier()
         train = run_training(device, world, steps=args.train_steps)
+    backproj = run_backprojection(device) if rank == 0 else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
         C = args.channels
@@ -349,6 +438,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_us_per_launch": breakdown,
             "reference_shape": ref_shape,
+            "backprojection": backproj,
             "train": train,
         }
         print(json.dumps(out))

@@ -179,6 +179,22 @@ int mmf_depth_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H,
 int mmf_upsample_features(const float* lowres_dev, int h, int w, int Cin, void* out_f16_dev, int Hf, int Wf, int Cpad,
                           void* stream);
 
+/* ---- fused up-sample + feature integration ("K11 inside the appearance kernel") ---------- */
+/* mmf_add_feature_frame without the materialised [Hf,Wf,C_pad] f16 image: the kernel samples the low-res backbone map
+ * lowres_dev [lh,lw,Cin] f32 (channels last) at each tap with the arithmetic of mmf_upsample_features
+ * (feature_extraction.py:188-191,198-210: bilinear align_corners=False -> zero pad to the mapper's channel count -> f16)
+ * and blends as mmf_add_feature_frame does.  Results are bit-identical to mmf_upsample_features followed by
+ * mmf_add_feature_frame (nvblox_mapping_helpers.py:255-261); at the reference shape this removes a 403 MB image per
+ * camera frame.  Cin % 8 == 0, Cin <= feature_channels, map 16-byte aligned.  mask: u8 [Hf,Wf] or NULL. */
+int mmf_add_feature_frame_lowres(mmf_handle h, int mapper_id, const float* lowres_dev, int lh, int lw, int Cin,
+                                 const uint8_t* mask_dev, int Hf, int Wf, const float* T_W_C_host16, const float* K_feat_host9,
+                                 void* stream);
+/* mmf_integrate_frame with the same low-res feature source (Hf == H, Wf == W as there). */
+int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth_dev, const uint8_t* rgb_dev,
+                               const float* lowres_dev, int lh, int lw, int Cin, const uint8_t* input_mask_dev, int H, int W, int Hf,
+                               int Wf, const float* T_W_C_host16, const float* K_host9, float min_depth_m, int k_in, int k_depth,
+                               int border_percent, uint8_t* depth_mask_out_dev, uint8_t* feature_mask_out_dev, void* stream);
+
 /* ---- policy-side op ---------------------------------------------------- */
 /* dgl.geometry.farthest_point_sampler(x, npoints, start_idx) (diffuser_actor/encoder.py:366-370): farthest-point
  * sampling of x [B,N,C] f32 in C-dimensional feature space, squared L2, first index on ties.

@@ -67,6 +67,9 @@ SIGNATURES = {
     "mmf_add_color_frame": (_I, [_VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "mmf_add_feature_frame": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "mmf_integrate_frame": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP]),
+    "mmf_add_feature_frame_lowres": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
+    "mmf_integrate_frame_lowres": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _I, _I, _I, _I, _VP, _VP, _F, _I, _I, _I, _VP, _VP,
+                                         _VP]),
     "mmf_decay": (_I, [_VP, _I, _VP]),
     "mmf_clear": (_I, [_VP, _I, _VP]),
     "mmf_update_feature_mesh": (_I, [_VP, _I, _VP, _PI]),

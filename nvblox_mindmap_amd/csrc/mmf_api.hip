@@ -720,11 +720,29 @@ int mmf_add_color_frame(mmf_handle h, int mapper_id, const uint8_t* rgb, const u
   return check_launch();
 }
 
-int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat, const uint8_t* mask, int Hf, int Wf, int C,
-                          const float* T16, const float* K9, void* stream) {
+// Validates a low-res feature source and fills the kernel-side descriptor (scales as in launch_upsample_features).
+static int make_lowres(const Mapper& m, const float* lowres, int lh, int lw, int Cin, int Hf, int Wf, LowRes& lr) {
+  if (!lowres || lh <= 0 || lw <= 0 || Cin <= 0 || Hf <= 1 || Wf <= 1) return fail(MMF_ERR_INVALID_ARG, "bad low-res feature map");
+  if (Cin > m.P.feature_channels)
+    return fail(MMF_ERR_INVALID_ARG, "low-res feature map has " + std::to_string(Cin) + " channels, the mapper holds " +
+                                         std::to_string(m.P.feature_channels));
+  if (Cin % 8 != 0 || ((uintptr_t)lowres & 15) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "the fused low-res path needs Cin % 8 == 0 and a 16-byte aligned map; "
+                                     "use mmf_upsample_features + mmf_add_feature_frame otherwise");
+  lr.data = lowres;
+  lr.h = lh;
+  lr.w = lw;
+  lr.cin = Cin;
+  lr.sh = (float)lh / (float)Hf;
+  lr.sw = (float)lw / (float)Wf;
+  return MMF_OK;
+}
+
+static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat, const LowRes* low, const uint8_t* mask, int Hf,
+                                  int Wf, int C, const float* T16, const float* K9, void* stream) {
   Mapper* m;
   MMF_TRY(get_mapper(h, mapper_id, &m));
-  if (!feat || !T16 || !K9 || Hf <= 1 || Wf <= 1) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_feature_frame");
+  if ((!feat && !low) || !T16 || !K9 || Hf <= 1 || Wf <= 1) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_feature_frame");
   if (C != m->P.feature_channels)
     return fail(MMF_ERR_INVALID_ARG, "feature frame has " + std::to_string(C) + " channels, the mapper was created with " +
                                          std::to_string(m->P.feature_channels));
@@ -741,18 +759,33 @@ int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat, const u
   {
     ProfScope ps(h, MMF_K_FEATURE, s);
     launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc[2],
-                             m->feat.d.cap, m->stats, s);
+                             m->feat.d.cap, m->stats, s, low);
   }
   return check_launch();
 }
 
-int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,
-                        const uint8_t* input_mask, int H, int W, int Hf, int Wf, int C, const float* T16, const float* K9,
-                        float min_depth_m, int k_in, int k_depth, int border_percent, uint8_t* depth_mask_out,
-                        uint8_t* feature_mask_out, void* stream) {
+int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat, const uint8_t* mask, int Hf, int Wf, int C,
+                          const float* T16, const float* K9, void* stream) {
+  if (!feat) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_feature_frame");
+  return add_feature_frame_impl(h, mapper_id, feat, nullptr, mask, Hf, Wf, C, T16, K9, stream);
+}
+
+int mmf_add_feature_frame_lowres(mmf_handle h, int mapper_id, const float* lowres, int lh, int lw, int Cin, const uint8_t* mask,
+                                 int Hf, int Wf, const float* T16, const float* K9, void* stream) {
   Mapper* m;
   MMF_TRY(get_mapper(h, mapper_id, &m));
-  if (!depth || !rgb || !feat || !input_mask || !T16 || !K9 || !depth_mask_out || !feature_mask_out || H <= 1 || W <= 1 ||
+  LowRes lr;
+  MMF_TRY(make_lowres(*m, lowres, lh, lw, Cin, Hf, Wf, lr));
+  return add_feature_frame_impl(h, mapper_id, nullptr, &lr, mask, Hf, Wf, m->P.feature_channels, T16, K9, stream);
+}
+
+static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,
+                                const LowRes* low, const uint8_t* input_mask, int H, int W, int Hf, int Wf, int C, const float* T16,
+                                const float* K9, float min_depth_m, int k_in, int k_depth, int border_percent,
+                                uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!depth || !rgb || (!feat && !low) || !input_mask || !T16 || !K9 || !depth_mask_out || !feature_mask_out || H <= 1 || W <= 1 ||
       Hf <= 1 || Wf <= 1 || k_in < 0 || k_depth < 0 || !(min_depth_m >= 0.0f))
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_integrate_frame");
   if (C != m->P.feature_channels)
@@ -825,7 +858,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
       m->frames[2]++;
       MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
       launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
-                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s);
+                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low);
       return check_launch();
     }
     m->last_vg = vg;
@@ -893,7 +926,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
     {
       ProfScope ps(h, MMF_K_FEATURE, s);
       launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s);
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low);
     }
     return check_launch();
   }
@@ -928,7 +961,7 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
   {
     ProfScope ps(h, MMF_K_FEATURE, sa);
     launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, fsynth, fWs, fHs, m->sc[2],
-                             m->feat.d.cap, m->stats, sa);
+                             m->feat.d.cap, m->stats, sa, low);
   }
   HIP_TRY(record(4, sa));
 
@@ -942,6 +975,27 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const u
   // join: everything enqueued by this call is ordered before later work on the caller's stream
   HIP_TRY(wait(s, 4));
   return check_launch();
+}
+
+int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,
+                        const uint8_t* input_mask, int H, int W, int Hf, int Wf, int C, const float* T16, const float* K9,
+                        float min_depth_m, int k_in, int k_depth, int border_percent, uint8_t* depth_mask_out,
+                        uint8_t* feature_mask_out, void* stream) {
+  if (!feat) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_integrate_frame");
+  return integrate_frame_impl(h, mapper_id, depth, rgb, feat, nullptr, input_mask, H, W, Hf, Wf, C, T16, K9, min_depth_m, k_in,
+                              k_depth, border_percent, depth_mask_out, feature_mask_out, stream);
+}
+
+int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const float* lowres, int lh,
+                               int lw, int Cin, const uint8_t* input_mask, int H, int W, int Hf, int Wf, const float* T16,
+                               const float* K9, float min_depth_m, int k_in, int k_depth, int border_percent,
+                               uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  LowRes lr;
+  MMF_TRY(make_lowres(*m, lowres, lh, lw, Cin, Hf, Wf, lr));
+  return integrate_frame_impl(h, mapper_id, depth, rgb, nullptr, &lr, input_mask, H, W, Hf, Wf, m->P.feature_channels, T16, K9,
+                              min_depth_m, k_in, k_depth, border_percent, depth_mask_out, feature_mask_out, stream);
 }
 
 int mmf_decay(mmf_handle h, int mapper_id, void* stream) {

@@ -221,7 +221,8 @@ struct AppArgs {
   LayerDev L;
   Cam cam;
   Rigid T_C_L;
-  const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]
+  const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]  (null when `low` is the feature source)
+  LowRes low;            // features only: low-res backbone map sampled in the kernel instead of a materialised image
   const uint8_t* mask;
   Scratch sc;
   long long* stats;  // mapper statistics (may be null)
@@ -306,12 +307,54 @@ struct FeatLds {
   int n;
 };
 
+// One tap of the virtual up-sampled image: f16( bilinear align_corners=False of the low-res map at pixel (xf,yf) ),
+// the arithmetic of k_upsample_features (mmf_kernels_image.hip), 8 channels starting at c0.
+struct LowAxis {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ LowAxis low_axis(float scale, int out_idx, int n_in) {
+  float sv = scale * ((float)out_idx + 0.5f) - 0.5f;
+  sv = sv < 0.0f ? 0.0f : sv;
+  LowAxis a;
+  a.i0 = (int)sv < n_in - 1 ? (int)sv : n_in - 1;
+  a.i1 = a.i0 < n_in - 1 ? a.i0 + 1 : a.i0;
+  a.l1 = sv - (float)a.i0;
+  a.l0 = 1.0f - a.l1;
+  return a;
+}
+struct Low8 {
+  float4 lo, hi;
+};
+__device__ __forceinline__ Low8 low_load8(const float* __restrict__ low, int w, int Cin, int y, int x, int c0) {
+  const float4* p = reinterpret_cast<const float4*>(low + ((size_t)y * w + x) * Cin + c0);
+  Low8 r;
+  r.lo = p[0];
+  r.hi = p[1];
+  return r;
+}
+__device__ __forceinline__ float low_at(const Low8& v, int k) {
+  return k == 0 ? v.lo.x : k == 1 ? v.lo.y : k == 2 ? v.lo.z : k == 3 ? v.lo.w : k == 4 ? v.hi.x : k == 5 ? v.hi.y : k == 6 ? v.hi.z : v.hi.w;
+}
+__device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const Low8& a10, const Low8& a11, const LowAxis& X,
+                                         const LowAxis& Y) {
+  half8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float val = Y.l0 * (X.l0 * low_at(a00, k) + X.l1 * low_at(a01, k)) + Y.l1 * (X.l0 * low_at(a10, k) + X.l1 * low_at(a11, k));
+    o[k] = (_Float16)val;
+  }
+  return o;
+}
+
+template <bool LOW>
 __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
                                     int bid, int nb, FeatLds& S) {
   const LayerDev& L = A.L;
   const Cam& cam = A.cam;
   const Rigid& T_C_L = A.T_C_L;
   const __half* __restrict__ feat = reinterpret_cast<const __half*>(A.image);
+  const LowRes LR = A.low;
   const uint8_t* __restrict__ mask = A.mask;
   const Scratch& sc = A.sc;
   uint16_t* s_lin = S.lin;
@@ -378,11 +421,50 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
       const __half* t01 = t00 + (size_t)cam.W * C;
       const __half* t11 = t01 + C;
       __half* A = blk + (size_t)lin * C;
+      // LOW: the four taps are pixels (px,py) (px+1,py) (px,py+1) (px+1,py+1) of the virtual up-sampled image
+      LowAxis X0, X1, Y0, Y1;
+      bool one_cell = false;
+      if constexpr (LOW) {
+        const int py = (int)(pix / (size_t)cam.W), px = (int)(pix - (size_t)py * cam.W);
+        X0 = low_axis(LR.sw, px, LR.w);
+        X1 = low_axis(LR.sw, px + 1, LR.w);
+        Y0 = low_axis(LR.sh, py, LR.h);
+        Y1 = low_axis(LR.sh, py + 1, LR.h);
+        one_cell = X0.i0 == X1.i0 && X0.i1 == X1.i1 && Y0.i0 == Y1.i0 && Y0.i1 == Y1.i1;  // usual case: 4 loads serve 4 taps
+      }
       for (int ch = gl; ch < nch; ch += 8) {
-        const half8 a00 = *reinterpret_cast<const half8*>(t00 + ch * 8);
-        const half8 a10 = *reinterpret_cast<const half8*>(t10 + ch * 8);
-        const half8 a01 = *reinterpret_cast<const half8*>(t01 + ch * 8);
-        const half8 a11 = *reinterpret_cast<const half8*>(t11 + ch * 8);
+        half8 a00, a10, a01, a11;
+        if constexpr (LOW) {
+          const int c0 = ch * 8;
+          if (c0 >= LR.cin) {  // zero-padded channels of the feature array
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a00[k] = a10[k] = a01[k] = a11[k] = (_Float16)0.0f;
+          } else if (one_cell) {
+            const Low8 c00 = low_load8(LR.data, LR.w, LR.cin, Y0.i0, X0.i0, c0), c01 = low_load8(LR.data, LR.w, LR.cin, Y0.i0, X0.i1, c0);
+            const Low8 c10 = low_load8(LR.data, LR.w, LR.cin, Y0.i1, X0.i0, c0), c11 = low_load8(LR.data, LR.w, LR.cin, Y0.i1, X0.i1, c0);
+            a00 = low_tap(c00, c01, c10, c11, X0, Y0);
+            a10 = low_tap(c00, c01, c10, c11, X1, Y0);
+            a01 = low_tap(c00, c01, c10, c11, X0, Y1);
+            a11 = low_tap(c00, c01, c10, c11, X1, Y1);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const LowAxis& X = (t & 1) ? X1 : X0;
+              const LowAxis& Y = (t & 2) ? Y1 : Y0;
+              const half8 v = low_tap(low_load8(LR.data, LR.w, LR.cin, Y.i0, X.i0, c0), low_load8(LR.data, LR.w, LR.cin, Y.i0, X.i1, c0),
+                                      low_load8(LR.data, LR.w, LR.cin, Y.i1, X.i0, c0), low_load8(LR.data, LR.w, LR.cin, Y.i1, X.i1, c0), X, Y);
+              if (t == 0) a00 = v;
+              else if (t == 1) a10 = v;
+              else if (t == 2) a01 = v;
+              else a11 = v;
+            }
+          }
+        } else {
+          a00 = *reinterpret_cast<const half8*>(t00 + ch * 8);
+          a10 = *reinterpret_cast<const half8*>(t10 + ch * 8);
+          a01 = *reinterpret_cast<const half8*>(t01 + ch * 8);
+          a11 = *reinterpret_cast<const half8*>(t11 + ch * 8);
+        }
         half8 av;
         if (is_new) {
 #pragma unroll
@@ -414,21 +496,23 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
   }
 }
 
+template <bool LOW>
 __global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                           int Hs) {
   __shared__ FeatLds S;
-  feature_body(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+  feature_body<LOW>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 }
 
 // Horizontal fusion: colour and feature update of one frame in ONE launch (different layers, same TSDF / synthetic
 // depth inputs): the first g_col workgroups walk the colour candidates, the rest the feature candidates.
+template <bool LOW>
 __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth,
                                                        int Ws, int Hs, int g_col) {
   __shared__ FeatLds S;
   if ((int)blockIdx.x < g_col)
     color_body(Acol, mc, synth, Ws, Hs, blockIdx.x, g_col);
   else
-    feature_body(Afeat, mc, synth, Ws, Hs, (int)blockIdx.x - g_col, (int)gridDim.x - g_col, S);
+    feature_body<LOW>(Afeat, mc, synth, Ws, Hs, (int)blockIdx.x - g_col, (int)gridDim.x - g_col, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -455,8 +539,9 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
-                             const Scratch& sc, long long* stats = nullptr) {
+                             const Scratch& sc, long long* stats = nullptr, const LowRes* low = nullptr) {
   AppArgs A;
+  A.low = low ? *low : LowRes{};
   A.stats = stats;
   A.L = L;
   A.cam = cam;
@@ -476,19 +561,26 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
 
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
-                              long long* stats, hipStream_t s) {
-  hipLaunchKernelGGL(k_feature_integrate, dim3(grid8(hinted(sc.hint_cand, max_cand), 8192)), dim3(256), 0, s,
-                     make_app_args(L, cam, T_C_L, feat, mask, sc, stats), mc, synth, Ws, Hs);
+                              long long* stats, hipStream_t s, const LowRes* low) {
+  const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
+  const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low);
+  if (low)
+    hipLaunchKernelGGL(k_feature_integrate<true>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  else
+    hipLaunchKernelGGL(k_feature_integrate<false>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
 }
 
 // colour + feature update in one launch
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s) {
+                           hipStream_t s, const LowRes* low) {
   const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
-  hipLaunchKernelGGL(k_app_integrate2, dim3(gc + gf), dim3(256), 0, s, make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
-                     make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats), mc, synth, Ws, Hs, gc);
+  const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc), Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low);
+  if (low)
+    hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
+  else
+    hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
 }
 
 }  // namespace mmf

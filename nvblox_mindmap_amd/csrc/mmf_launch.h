@@ -5,6 +5,14 @@
 
 namespace mmf {
 
+// low-res feature source of the fused up-sample + integrate path: [h,w,cin] f32 channels-last, cin % 8 == 0,
+// sh = h / Hf, sw = w / Wf (float division, as k_upsample_features)
+struct LowRes {
+  const float* data = nullptr;
+  int h = 0, w = 0, cin = 0;
+  float sh = 0.0f, sw = 0.0f;
+};
+
 struct ViewGrid {
   int ox, oy, oz;  // block index of cell (0,0,0)
   int nx, ny, nz;
@@ -42,12 +50,12 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                             hipStream_t s);
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
-                              long long* stats, hipStream_t s);
+                              long long* stats, hipStream_t s, const LowRes* low = nullptr);
 
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s);
+                           hipStream_t s, const LowRes* low = nullptr);
 
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,

@@ -281,6 +281,50 @@ class Mapper:
         _lib.check(_lib.lib().mmf_add_feature_frame(self._h, mapper_id, _lib.dptr(feat), _lib.dptr(mask), Hf, Wf, ch, T.ctypes.data,
                                                     K.ctypes.data, self._stream()), "mmf_add_feature_frame")
 
+    def add_feature_frame_lowres(self, lowres_features: torch.Tensor, feature_size, t_w_c, intrinsics,
+                                 mask_frame: Optional[torch.Tensor] = None, mapper_id: int = 0) -> None:
+        """Extension: ``add_feature_frame`` fed with the backbone's low-res map [h,w,Cin] float32
+        (channels last) instead of the up-sampled, padded f16 image.  The kernel evaluates
+        ``f16(pad(bilinear(lowres -> feature_size)))`` at each tap itself (feature_extraction.py:188-191,198-210), so the
+        result is bit-identical to ``upsample_features`` + ``add_feature_frame`` while the [Hf,Wf,C_pad] image
+        (403 MB at 512x512x768) is never written or read.  ``intrinsics`` are those of the (virtual) feature image."""
+        mapper_id = self._check_id(mapper_id)
+        low = _check_dev(lowres_features, "lowres_features", torch.float32, 3)
+        lh, lw, cin = low.shape
+        Hf, Wf = int(feature_size[0]), int(feature_size[1])
+        mask = _mask_u8(mask_frame, (Hf, Wf))
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        _lib.check(_lib.lib().mmf_add_feature_frame_lowres(self._h, mapper_id, _lib.dptr(low), lh, lw, cin, _lib.dptr(mask), Hf, Wf,
+                                                           T.ctypes.data, K.ctypes.data, self._stream()),
+                   "mmf_add_feature_frame_lowres")
+
+    def integrate_frame_lowres(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, lowres_features: torch.Tensor,
+                               input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float,
+                               input_mask_erosion_iterations: int, valid_depth_mask_erosion_iterations: int,
+                               border_percent: int, mapper_id: int = 0):
+        """``integrate_frame`` with the low-res feature source of ``add_feature_frame_lowres`` (virtual feature image at
+        the depth resolution).  Returns (depth_mask uint8 [H,W], feature_mask uint8 [H,W])."""
+        mapper_id = self._check_id(mapper_id)
+        depth = _check_dev(depth_frame, "depth_frame", torch.float32, 2)
+        rgb = _check_dev(color_frame, "color_frame", torch.uint8, 3)
+        low = _check_dev(lowres_features, "lowres_features", torch.float32, 3)
+        H, W = depth.shape
+        lh, lw, cin = low.shape
+        if tuple(rgb.shape) != (H, W, 3):
+            raise ValueError("color_frame must be [H,W,3] with the depth frame's H,W")
+        mask = _mask_u8(input_mask, (H, W))
+        T = _host_f32(t_w_c, (4, 4))
+        K = _host_f32(intrinsics, (3, 3))
+        dm = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        fm = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        _lib.check(_lib.lib().mmf_integrate_frame_lowres(
+            self._h, mapper_id, _lib.dptr(depth), _lib.dptr(rgb), _lib.dptr(low), lh, lw, cin, _lib.dptr(mask), H, W, H, W,
+            T.ctypes.data, K.ctypes.data, float(min_depth_m), int(input_mask_erosion_iterations),
+            int(valid_depth_mask_erosion_iterations), int(border_percent), _lib.dptr(dm), _lib.dptr(fm), self._stream()),
+            "mmf_integrate_frame_lowres")
+        return dm, fm
+
     def integrate_frame(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor,
                         input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float, input_mask_erosion_iterations: int,
                         valid_depth_mask_erosion_iterations: int, border_percent: int, mapper_id: int = 0):

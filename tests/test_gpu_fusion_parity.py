@@ -311,3 +311,73 @@ def test_two_mappers_are_independent(oracle_mod):
     gpu.clear(1)
     assert gpu.tsdf_layer_view(1).num_allocated_blocks() == 0
     assert gpu.tsdf_layer_view(0).num_allocated_blocks() == o0.num_blocks(0)
+
+
+def _lowres_map(index, cin, lh=16, lw=16):
+    return np.random.default_rng(1000 + index).standard_normal((lh, lw, cin)).astype(np.float32)
+
+
+@pytest.mark.parametrize("scale,cin,channels,lh,lw", [(4, 16, 16, 16, 16), (4, 24, 32, 5, 7), (2, 64, 64, 16, 16)])
+def test_add_feature_frame_lowres_is_upsample_plus_add(oracle_mod, scale, cin, channels, lh, lw):
+    """Fused up-sample + integrate == materialised path, bit for bit: against the HIP
+    upsample_features + add_feature_frame pair and against the oracle fed with the same up-sampled f16 image."""
+    from nvblox_mindmap_amd.image_processing import upsample_features
+
+    cfg = small_cfg(scale)
+    fused, plain, orc = make_mapper(channels), make_mapper(channels), make_oracle(oracle_mod, channels)
+    for k, i in enumerate([0, 6, 12]):
+        f = S.frame(cfg, i, 0)
+        mask = frame_masks(f["depth"], k)
+        low = _lowres_map(i, cin, lh, lw)
+        T, K = torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"])
+        up = upsample_features(dev(np.ascontiguousarray(low.transpose(2, 0, 1))), (cfg.height, cfg.width), channels)
+        for m in (fused, plain):
+            m.decay()
+            m.add_depth_frame(dev(f["depth"]), T, K, dev(mask), 0)
+        plain.add_feature_frame(up, T, K, dev(mask), 0)
+        fused.add_feature_frame_lowres(dev(low), (cfg.height, cfg.width), T, K, dev(mask), 0)
+        orc.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], mask)
+        orc.add_feature_frame(up.cpu().numpy(), f["T_W_C"], f["K"], mask)
+    fa, wa, ia = fused.feature_layer_view(0).get_all_blocks_split()
+    fb, wb, ib = plain.feature_layer_view(0).get_all_blocks_split()
+    assert torch.equal(ia, ib) and torch.equal(wa, wb)
+    assert torch.equal(fa.view(torch.int16), fb.view(torch.int16))
+    assert int((wa > 0).sum()) > 1000
+    if cin < channels:
+        assert float(fa[..., cin:].abs().max()) == 0.0
+    compare_tsdf(orc, fused)
+    compare_features(orc, fused)
+
+
+def test_integrate_frame_lowres_matches_integrate_frame():
+    """One-call frame integration with the low-res source == the same call with the up-sampled image (full 640x480)."""
+    from nvblox_mindmap_amd.image_processing import upsample_features
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg
+
+    cfg = S.StreamConfig(hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    a, b = get_nvblox_mapper(mcfg, feature_channels=64), get_nvblox_mapper(mcfg, feature_channels=64)
+    for i in [0, 9]:
+        f = S.frame(cfg, i, 0)
+        low = _lowres_map(i, 64)
+        up = upsample_features(dev(np.ascontiguousarray(low.transpose(2, 0, 1))), (cfg.height, cfg.width), 64)
+        static = np.ones(f["depth"].shape, dtype=bool)
+        args = (dev(static), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), mcfg.min_integration_distance_m, 3, 4,
+                mcfg.feature_mask_border_percent, 0)
+        a.decay()
+        b.decay()
+        dm_a, fm_a = a.integrate_frame(dev(f["depth"]), dev(f["rgb"]), up, *args)
+        dm_b, fm_b = b.integrate_frame_lowres(dev(f["depth"]), dev(f["rgb"]), dev(low), *args)
+        assert torch.equal(dm_a, dm_b) and torch.equal(fm_a, fm_b)
+    fa, wa, ia = a.feature_layer_view(0).get_all_blocks_split()
+    fb, wb, ib = b.feature_layer_view(0).get_all_blocks_split()
+    assert torch.equal(ia, ib) and torch.equal(wa, wb) and torch.equal(fa.view(torch.int16), fb.view(torch.int16))
+    assert int((wa > 0).sum()) > 10000
+    ca, cwa, _ = a.color_layer_view(0).get_all_blocks_split()
+    cb, cwb, _ = b.color_layer_view(0).get_all_blocks_split()
+    assert torch.equal(ca, cb) and torch.equal(cwa, cwb)
+    with pytest.raises(RuntimeError):  # Cin not a multiple of 8: the fused path refuses, loudly
+        b.add_feature_frame_lowres(dev(_lowres_map(0, 12)), (cfg.height, cfg.width), torch.from_numpy(f["T_W_C"]),
+                                   torch.from_numpy(f["K"]), None, 0)
