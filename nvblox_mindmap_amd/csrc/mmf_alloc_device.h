@@ -1,0 +1,237 @@
+// mmf_alloc_device.h -- single-workgroup block allocation (flag compaction + hash lookup / insertion) as a device
+// function, so that it can be one role of several horizontally fused launches (k_alloc_jobs, k_sphere_alloc).
+#pragma once
+#include "mmf_device.h"
+
+namespace mmf {
+
+__device__ inline u64 grid_cell_key(const KeySrc& ks, int cell) {
+  int gz = cell % ks.nz;
+  int t = cell / ks.nz;
+  int gy = t % ks.ny;
+  int gx = t / ks.ny;
+  return pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
+}
+
+// mode 0: the cell is a cell of the dense view grid; mode 1: the cell is a position of another layer's live
+// list and the producer of the flags (k_app_candidates) stored the block key next to the flag.
+__device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
+  return ks.mode == 0 ? grid_cell_key(ks, cell) : sc.cell_key[cell];
+}
+
+// Deallocation of the blocks flagged by the decay pass: one 1024-thread workgroup compacts the live list in place (order
+// preserving), pushes the freed slots, tombstones their hash entries (amortised rebuild).  No-op when nothing was flagged.
+__device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict__ kill, int* any_kill, int* lds, int* carry) {
+
+  if (!*any_kill) return;
+  const int n = L.ctr[0];
+  if (threadIdx.x == 0) {
+    carry[0] = 0;          // survivors written so far
+    carry[1] = L.ctr[1];   // free stack size
+  }
+  __syncthreads();
+  const int free0 = carry[1];
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    int slot = -1, k = 0;
+    if (i < n) {
+      slot = L.live[i];
+      k = kill[i];
+      kill[i] = 0;
+    }
+    int keep = (i < n && !k) ? 1 : 0, dead = (i < n && k) ? 1 : 0;
+    int ea, eb, ta, tb;
+    block_excl_scan2<16>(keep, dead, lds, ea, eb, ta, tb);
+    const int c0 = carry[0], c1 = carry[1];
+    __syncthreads();  // every read of live[base..] and carry happened before any write below
+    if (keep) L.live[c0 + ea] = slot;
+    if (dead) {
+      L.free_stack[c1 + eb] = slot;
+      hash_erase(L, L.slot_key[slot]);  // tombstone; dropped at the next rebuild
+      dense_set(L, L.slot_key[slot], 0);
+      L.slot_key[slot] = kEmptyKey;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry[0] = c0 + ta;
+      carry[1] = c1 + tb;
+    }
+    __syncthreads();
+  }
+  const int n_live = carry[0];
+  const int n_tomb = L.ctr[4] + (carry[1] - free0);
+  // amortised rebuild: only when tombstones fill more than a quarter of the table
+  const bool rebuild = (unsigned)n_tomb * 4u > L.hmask + 1u;
+  __syncthreads();
+  if (rebuild) {
+    for (unsigned h = threadIdx.x; h <= L.hmask; h += 1024) L.htab[h].key = kEmptyKey;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_live; i += 1024) {
+      const int slot = L.live[i];
+      hash_insert(L, L.slot_key[slot], slot);
+    }
+  }
+  if (threadIdx.x == 0) {
+    L.ctr[0] = n_live;
+    L.ctr[1] = carry[1];
+    L.ctr[4] = rebuild ? 0 : n_tomb;
+    if (L.hint_live) *L.hint_live = n_live;
+    *any_kill = 0;
+  }
+}
+
+// Small cell counts (bounded workspaces: a few thousand cells): count + scan + emit fused into ONE launch
+// of one 1024-thread workgroup, 4096 cells per pass with a running carry.  Same candidate order, same
+// slot assignment as the three-kernel path.
+__device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx) {
+  const LayerDev& L = J.L;
+  const KeySrc& ks = J.ks;
+  const Scratch& sc = J.sc;
+  const int stat_upd = J.stat_upd, stat_new = J.stat_new;
+  int ncells = J.ncells;
+  if (J.kill) {  // a decay pass ran in the previous launch: drop its dead blocks before allocating (slot reuse order is spec)
+    live_compact_body(L, J.kill, J.any_kill, lds, carry);
+    __syncthreads();
+  }
+  if (ks.mode == 1) {  // list cells: only the producer's live positions carry meaningful flags
+    const int nl = *ks.n_live;
+    ncells = ncells < nl ? ncells : nl;
+  }
+  if (threadIdx.x == 0) {
+    carry[0] = 0;
+    carry[1] = 0;
+    ctx[0] = L.ctr[0];
+    ctx[1] = L.ctr[1];
+    ctx[2] = L.ctr[2];
+    ctx[3] = L.ctr[1] + (L.cap - L.ctr[2]);  // room
+  }
+  // no barrier here: ctx / carry are first read after the barriers of the workgroup scan below, so the counter
+  // round trip of thread 0 overlaps with everyone's table loads
+  for (int base = 0; base < ncells; base += 4096) {
+    const int cell0 = base + threadIdx.x * 4;
+    uint32_t f4 = 0;
+    if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cell0 + k >= ncells) f4 &= ~(0xffu << (8 * k));  // stale flags beyond the live count
+    int slot4[4] = {0, 0, 0, 0};
+    u64 key4[4] = {0, 0, 0, 0};
+    int nf = 0, nn = 0;
+    if (cell0 < ncells) {
+      // Every load of this pass is issued before the first one is consumed.  Grid cells have computable keys,
+      // so their table entries are fetched without waiting for the flags; list cells read key + flag together
+      // and look the flagged ones up in a second round.
+      if (ks.mode == 0) {
+        unsigned h4[4] = {0, 0, 0, 0};
+        uint4 e4[4];
+        int d4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          e4[k] = make_uint4(0, 0, 0, 0);
+          if (cell0 + k < ncells) {
+            key4[k] = grid_cell_key(ks, cell0 + k);
+            if (L.dense) {
+              int x, y, z;
+              unpack_key(key4[k], x, y, z);
+              d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
+            } else {
+              h4[k] = hash_key(key4[k]) & L.hmask;
+              e4[k] = hash_load(L, h4[k]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((f4 >> (8 * k)) & 0xffu) {
+            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
+            nf++;
+            nn += slot4[k] < 0;
+          }
+        }
+      } else if (f4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((f4 >> (8 * k)) & 0xffu) key4[k] = sc.cell_key[cell0 + k];
+        unsigned h4[4] = {0, 0, 0, 0};
+        uint4 e4[4];
+        int d4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          e4[k] = make_uint4(0, 0, 0, 0);
+          if ((f4 >> (8 * k)) & 0xffu) {
+            if (L.dense) {
+              int x, y, z;
+              unpack_key(key4[k], x, y, z);
+              d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
+            } else {
+              h4[k] = hash_key(key4[k]) & L.hmask;
+              e4[k] = hash_load(L, h4[k]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((f4 >> (8 * k)) & 0xffu) {
+            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
+            nf++;
+            nn += slot4[k] < 0;
+          }
+        }
+      }
+    }
+    int ea, eb, ta, tb;
+    block_excl_scan2<16>(nf, nn, lds, ea, eb, ta, tb);
+    const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
+    if (f4) {
+      int pos = carry[0] + ea, rnk = carry[1] + eb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!((f4 >> (8 * k)) & 0xffu)) continue;
+        int slot = slot4[k];
+        const bool is_new = slot < 0;
+        if (is_new) {
+          if (rnk < room) {
+            slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
+            hash_insert(L, key4[k], slot);
+            dense_set(L, key4[k], slot + 1);
+            L.slot_key[slot] = key4[k];
+            L.live[old_live + rnk] = slot;
+          }
+          rnk++;
+        }
+        sc.cand_slot[pos] = slot;
+        sc.cand_key[pos] = key4[k];
+        sc.cand_new[pos] = is_new ? 1 : 0;
+        if (J.stamp && slot >= 0) L.stamp[slot] = (J.stamp << 1) | (is_new ? 1 : 0);
+        pos++;
+      }
+      if (ks.mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry[0] += ta;
+      carry[1] += tb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
+    const int n_cand = carry[0], n_new = carry[1];
+    const int granted = n_new < room ? n_new : room;
+    if (granted < n_new) atomicOr(&L.ctr[3], 1);
+    const int from_free = granted < old_free ? granted : old_free;
+    L.ctr[0] = old_live + granted;
+    L.ctr[1] = old_free - from_free;
+    L.ctr[2] = old_bump + (granted - from_free);
+    *sc.cand_count = n_cand;
+    if (sc.hint_cand) *sc.hint_cand = n_cand;
+    if (L.hint_live) *L.hint_live = L.ctr[0];
+    if (stats) {
+      if (stat_upd >= 0) stats[stat_upd] += n_cand;
+      if (stat_new >= 0) stats[stat_new] += granted;
+    }
+  }
+}
+
+
+}  // namespace mmf

@@ -65,6 +65,7 @@ struct Mapper {
   float synth_T[16]{}, synth_K[9]{};
   int synth_iw = 0, synth_ih = 0;
   long long tsdf_epoch = 0;
+  bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
   // mesh
   int* mesh_counts = nullptr;
   int* mesh_offsets = nullptr;
@@ -241,6 +242,7 @@ void free_layer(Layer& L) {
   if (L.d.poolw) (void)hipFree(L.d.poolw);
   if (L.d.dense) (void)hipFree(L.d.dense);
   if (L.d.block_free) (void)hipFree(L.d.block_free);
+  if (L.d.stamp) (void)hipFree(L.d.stamp);
   L = Layer{};
 }
 
@@ -353,6 +355,8 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   m->tsdf.d.hint_live = m->hints + 3;
   HIP_TRY(hipMalloc(&m->tsdf.d.block_free, (size_t)cap));
   HIP_TRY(hipMemset(m->tsdf.d.block_free, 0, (size_t)cap));
+  HIP_TRY(hipMalloc(&m->tsdf.d.stamp, sizeof(int) * (size_t)cap));
+  HIP_TRY(hipMemset(m->tsdf.d.stamp, 0, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
   HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
   HIP_TRY(hipMalloc(&m->any_kill, sizeof(int)));
@@ -455,6 +459,23 @@ int get_mapper(mmf_handle h, int id, Mapper** out) {
   return MMF_OK;
 }
 
+// A pending decay is applied now, as its own launches (every consumer of the map except the fused frame path).
+void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
+  if (!m.pending_decay) return;
+  m.pending_decay = false;
+  ProfScope ps(h, MMF_K_DECAY, s);
+  launch_decay(m.tsdf.d, m.mc, m.kill, m.any_kill, s);
+}
+
+int get_mapper_ready(mmf_handle h, int id, Mapper** out, void* stream) {
+  MMF_TRY(get_mapper(h, id, out));
+  if ((*out)->pending_decay) {
+    HIP_TRY(hipSetDevice(h->device));
+    flush_decay(h, **out, (hipStream_t)stream);
+  }
+  return MMF_OK;
+}
+
 int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w) {
   if (L.allocated) return MMF_OK;
   MMF_TRY(alloc_layer(L, m.app_cap, block_bytes, has_w));
@@ -467,23 +488,26 @@ bool synth_cached(const Mapper& m, const Cam& cam, const float* T16, const float
          std::memcmp(m.synth_T, T16, sizeof(float) * 16) == 0 && std::memcmp(m.synth_K, K9, sizeof(float) * 9) == 0;
 }
 
-// Sphere-trace the synthetic depth image of `cam` on stream `s` (no-op when cached).
-int ensure_synth(mmf_handle h, Mapper& m, const Cam& cam, const Rigid& T_L_C, const float* T16, const float* K9, hipStream_t s) {
+// Makes room for the synthetic depth image of `cam`; *need = the image must be rendered (not cached).
+int synth_prepare(Mapper& m, const Cam& cam, const float* T16, const float* K9, int* Ws_out, int* Hs_out, bool* need) {
   const int sf = m.mc.st_sf;
   const int Ws = cam.W / sf, Hs = cam.H / sf;
   if (Ws <= 0 || Hs <= 0) return fail(MMF_ERR_INVALID_ARG, "image smaller than the sphere-tracing subsampling factor");
-  if (synth_cached(m, cam, T16, K9)) return MMF_OK;
-  if (Ws * Hs > m.synth_cap) {
+  *Ws_out = Ws;
+  *Hs_out = Hs;
+  *need = !synth_cached(m, cam, T16, K9);
+  if (*need && Ws * Hs > m.synth_cap) {
     HIP_TRY(hipDeviceSynchronize());
     if (m.synth) HIP_TRY(hipFree(m.synth));
     m.synth = nullptr;
     HIP_TRY(hipMalloc(&m.synth, sizeof(float) * (size_t)Ws * Hs));
     m.synth_cap = Ws * Hs;
   }
-  {
-    ProfScope ps(h, MMF_K_SPHERE, s);
-    launch_sphere_trace(m.tsdf.d, m.mc, cam, T_L_C, m.synth, Ws, Hs, s);
-  }
+  return MMF_OK;
+}
+
+// Records that m.synth now holds the image of `cam` for the current TSDF state.
+void synth_commit(Mapper& m, const Cam& cam, const float* T16, const float* K9, int Ws, int Hs) {
   m.synth_W = Ws;
   m.synth_H = Hs;
   m.synth_epoch = m.tsdf_epoch;
@@ -491,6 +515,19 @@ int ensure_synth(mmf_handle h, Mapper& m, const Cam& cam, const Rigid& T_L_C, co
   m.synth_ih = cam.H;
   std::memcpy(m.synth_T, T16, sizeof(float) * 16);
   std::memcpy(m.synth_K, K9, sizeof(float) * 9);
+}
+
+// Sphere-trace the synthetic depth image of `cam` on stream `s` (no-op when cached).
+int ensure_synth(mmf_handle h, Mapper& m, const Cam& cam, const Rigid& T_L_C, const float* T16, const float* K9, hipStream_t s) {
+  int Ws, Hs;
+  bool need;
+  MMF_TRY(synth_prepare(m, cam, T16, K9, &Ws, &Hs, &need));
+  if (!need) return MMF_OK;
+  {
+    ProfScope ps(h, MMF_K_SPHERE, s);
+    launch_sphere_trace(m.tsdf.d, m.mc, cam, T_L_C, m.synth, Ws, Hs, s);
+  }
+  synth_commit(m, cam, T16, K9, Ws, Hs);
   return MMF_OK;
 }
 
@@ -687,7 +724,7 @@ int mmf_num_mappers(mmf_handle h) { return h ? (int)h->mappers.size() : 0; }
 int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* mask, int H, int W, const float* T16,
                         const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (!depth || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_depth_frame");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -702,7 +739,7 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
 int mmf_add_color_frame(mmf_handle h, int mapper_id, const uint8_t* rgb, const uint8_t* mask, int H, int W, const float* T16,
                         const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (!rgb || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_color_frame");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -741,7 +778,7 @@ static int make_lowres(const Mapper& m, const float* lowres, int lh, int lw, int
 static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat, const LowRes* low, const uint8_t* mask, int Hf,
                                   int Wf, int C, const float* T16, const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if ((!feat && !low) || !T16 || !K9 || Hf <= 1 || Wf <= 1) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_feature_frame");
   if (C != m->P.feature_channels)
     return fail(MMF_ERR_INVALID_ARG, "feature frame has " + std::to_string(C) + " channels, the mapper was created with " +
@@ -847,6 +884,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
     if (!fusable) {
       // odd shapes / very large grids: the plain sequence of stand-alone launches
+      flush_decay(h, *m, s);
       launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
                          feature_mask_out, m->mask_tmp, s);
       MMF_TRY(depth_chain(h, *m, depth, input_mask, min_depth_m, cam, T_L_C, T_C_L, s));
@@ -867,11 +905,16 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     m->frames[2]++;
     m->tsdf_epoch++;
     m->touched = true;
+    const int stamp = (int)(m->tsdf_epoch & 0x3fffffff) ? (int)(m->tsdf_epoch & 0x3fffffff) : 1;
     MMF_TRY(ensure_scratch(*m, 0, ncells));
     const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
+    const bool do_decay = m->pending_decay;
+    m->pending_decay = false;
     {
+      // raycast tiles | mask row pass | pending decay of the TSDF layer
       ProfScope ps(h, MMF_K_RAYCAST, s);
-      launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, s);
+      launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
+                   m->kill, m->any_kill, s);
     }
     {
       ProfScope ps(h, MMF_K_ALLOC, s);
@@ -889,20 +932,20 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       job.ncells = ncells;
       job.stat_upd = 1;
       job.stat_new = 2;
+      job.stamp = stamp;
+      if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave before the allocation hands out slots
+        job.kill = m->kill;
+        job.any_kill = m->any_kill;
+      }
       launch_alloc_jobs(&job, 1, m->stats, &M, s);
     }
     {
+      // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
       ProfScope ps(h, MMF_K_TSDF, s);
-      launch_tsdf_integrate(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, m->sc[0],
-                            ncells < m->tsdf.d.cap ? ncells : m->tsdf.d.cap, s);
+      launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key, s);
     }
     {
-      ProfScope ps(h, MMF_K_CANDIDATES, s);
-      launch_app_candidates(m->tsdf.d, m->mc, cam, T_C_L, m->sc[1].flags, m->sc[1].cell_key, s);
-    }
-    MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, s));
-    {
-      ProfScope ps(h, MMF_K_ALLOC, s);
+      // sphere trace | colour allocation | feature allocation: one launch
       KeySrc ks{};
       ks.mode = 1;
       ks.n_live = m->tsdf.d.ctr;
@@ -921,7 +964,16 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       jobs[1].ncells = m->tsdf.d.cap;
       jobs[1].stat_upd = 6;
       jobs[1].stat_new = 7;
-      launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
+      int Ws, Hs;
+      bool need;
+      MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
+      ProfScope ps(h, MMF_K_SPHERE, s);
+      if (need) {
+        launch_sphere_alloc(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats, s);
+        synth_commit(*m, cam, T16, K9, Ws, Hs);
+      } else {
+        launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
+      }
     }
     {
       ProfScope ps(h, MMF_K_FEATURE, s);
@@ -932,6 +984,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   }
 
   // fork: masks on side stream A while the TSDF chain runs on the caller's stream
+  flush_decay(h, *m, s);
   HIP_TRY(record(0, s));
   HIP_TRY(wait(sa, 0));
   launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out, feature_mask_out,
@@ -1006,8 +1059,10 @@ int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
     if (!m->touched) continue;  // nothing was ever allocated in this mapper
-    ProfScope ps(h, MMF_K_DECAY, s);
-    launch_decay(m->tsdf.d, m->mc, m->kill, m->any_kill, s);
+    // Lazy: the fused frame path (mmf_integrate_frame) applies it inside its first two launches; anything else that
+    // touches the map first flushes it as stand-alone launches.  Same arithmetic, same order of effects.
+    flush_decay(h, *m, s);  // an earlier decay that nothing consumed
+    m->pending_decay = true;
     m->tsdf_epoch++;
   }
   if (mapper_id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
@@ -1022,6 +1077,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
   for (int i = 0; i < (int)h->mappers.size(); ++i) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
+    m->pending_decay = false;  // decaying blocks that are about to be dropped is a no-op
     launch_layer_reset(m->tsdf.d, s);
     if (m->color.allocated) launch_layer_reset(m->color.d, s);
     if (m->feat.allocated) launch_layer_reset(m->feat.d, s);
@@ -1035,7 +1091,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
 
 int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_vertices) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (!num_vertices) return fail(MMF_ERR_INVALID_ARG, "null num_vertices");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1054,7 +1110,7 @@ int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_
 
 int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* verts, void* vfeat, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (m->mesh_epoch != m->tsdf_epoch)
     return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_update_feature_mesh; call it again");
   if (m->mesh_V == 0) return MMF_OK;
@@ -1075,7 +1131,7 @@ static Layer* pick_layer(Mapper* m, int layer) {
 
 int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* stream, int* out) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   Layer* L = pick_layer(m, layer);
   if (!L || !out) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
   if (!L->allocated) {
@@ -1094,7 +1150,7 @@ int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* strea
 
 int mmf_get_block_indices(mmf_handle h, int mapper_id, int layer, int32_t* out, int n, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   Layer* L = pick_layer(m, layer);
   if (!L) return fail(MMF_ERR_INVALID_ARG, "bad layer");
   if (n <= 0 || !L->allocated) return MMF_OK;
@@ -1105,7 +1161,7 @@ int mmf_get_block_indices(mmf_handle h, int mapper_id, int layer, int32_t* out, 
 
 int mmf_get_tsdf_blocks(mmf_handle h, int mapper_id, float* out, int n, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (n <= 0) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
   launch_gather_pool(m->tsdf.d, m->tsdf.block_bytes, out, n, (hipStream_t)stream);
@@ -1114,7 +1170,7 @@ int mmf_get_tsdf_blocks(mmf_handle h, int mapper_id, float* out, int n, void* st
 
 int mmf_get_feature_blocks(mmf_handle h, int mapper_id, void* feats, float* weights, int n, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (n <= 0 || !m->feat.allocated) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
   launch_gather_pool(m->feat.d, m->feat.block_bytes, feats, n, (hipStream_t)stream);
@@ -1124,7 +1180,7 @@ int mmf_get_feature_blocks(mmf_handle h, int mapper_id, void* feats, float* weig
 
 int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb, float* weights, int n, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (n <= 0 || !m->color.allocated) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
   launch_gather_color(m->color.d, rgb, weights, n, (hipStream_t)stream);
@@ -1133,7 +1189,7 @@ int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb, float* weigh
 
 int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* pts, int n, float* out, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   if (n <= 0) return MMF_OK;
   if (!pts || !out) return fail(MMF_ERR_INVALID_ARG, "null buffer");
   HIP_TRY(hipSetDevice(h->device));
@@ -1225,7 +1281,7 @@ int mmf_get_synthetic_depth(mmf_handle h, int mapper_id, float* out, void* strea
 
 int mmf_render_synthetic_depth(mmf_handle h, int mapper_id, int H, int W, const float* T16, const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   HIP_TRY(hipSetDevice(h->device));
   Cam cam = cam_from_K(K9, W, H);
   Rigid T_L_C;

@@ -71,6 +71,9 @@ struct LayerDev {
   // D == +trunc).  Recomputed by k_tsdf_integrate / k_decay for every block they touch; lets the sphere tracer
   // step through such blocks without reading voxels (the sample result is known: valid, distance = trunc).
   unsigned char* block_free;
+  // TSDF layer only: stamp[slot] = (frame stamp << 1) | is_new, written by the allocation job of a fused frame for every
+  // candidate block, so that a pass over the LIVE list (k_tsdf_pass) knows which blocks this frame integrates.
+  int* stamp;
   int* hint_live;  // pinned host int (may be null): last live-block count, read by the host to size later grids
   int d_lo[3];
   int d_ny, d_nz, d_ncells;
@@ -113,6 +116,9 @@ struct AllocJob {
   Scratch sc;
   int ncells;
   int stat_upd, stat_new;  // indices into the mapper's statistics array (-1: none)
+  int stamp = 0;           // != 0: mark every candidate slot in L.stamp (see LayerDev::stamp)
+  uint8_t* kill = nullptr; // != null: first apply the kill flags of a decay pass (live_compact_body)
+  int* any_kill = nullptr;
 };
 
 __host__ __device__ inline u64 pack_key(int x, int y, int z) {

@@ -5,6 +5,7 @@
 // Replaces the CUDA behind nvblox_torch Mapper.add_color_frame / add_feature_frame, reached by the
 // reference at mindmap/mapping/helpers/nvblox_mapping_helpers.py:212-218 and :255-261.
 #include "mmf_launch.h"
+#include "mmf_alloc_device.h"
 
 namespace mmf {
 
@@ -60,12 +61,13 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
 // ------------------------------------------------------------------------------------------------
 constexpr int kRayLanes = 16;
 
-__global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
-                                                     int Ws, int Hs, int patches_x) {
-  const int k = threadIdx.x & (kRayLanes - 1);          // sample lane within the ray group
-  const int rl = threadIdx.x >> 4;                      // ray within the 4x4 patch
-  const int gshift = (threadIdx.x & 63) & ~(kRayLanes - 1);  // first lane of this group inside its wave
-  const int cs = (blockIdx.x % patches_x) * 4 + (rl & 3), rs = (blockIdx.x / patches_x) * 4 + (rl >> 2);
+// One 4x4 ray patch = 256 threads (4 whole waves; no LDS, no barriers: the body may share a workgroup with other roles).
+__device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C,
+                                    float* __restrict__ synth, int Ws, int Hs, int patches_x, int patch, int tid) {
+  const int k = tid & (kRayLanes - 1);          // sample lane within the ray group
+  const int rl = tid >> 4;                      // ray within the 4x4 patch
+  const int gshift = (tid & 63) & ~(kRayLanes - 1);  // first lane of this group inside its wave
+  const int cs = (patch % patches_x) * 4 + (rl & 3), rs = (patch / patches_x) * 4 + (rl >> 2);
   if (cs >= Ws || rs >= Hs) return;  // whole groups leave together
   const int idx = rs * Ws + cs;
   const float sf = (float)mc.st_sf;
@@ -177,6 +179,28 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
     }
   }
   if (k == 0) synth[idx] = ok ? t * dC[2] : -1.0f;
+}
+
+__global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
+                                                     int Ws, int Hs, int patches_x) {
+  sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, blockIdx.x, threadIdx.x);
+}
+
+// Horizontal fusion: the sphere trace (reads the TSDF layer) and the block allocation of the colour and the feature layer
+// (touch only their own hash / lists; inputs = the candidate flags) are independent once the TSDF update and the candidate
+// selection are done.  Workgroups [0, njobs) run one allocation job each, the others four ray patches each.
+__global__ __launch_bounds__(1024) void k_sphere_alloc(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
+                                                      int Ws, int Hs, int patches_x, int n_patches, AllocJob J0, AllocJob J1,
+                                                      int njobs, long long* stats) {
+  __shared__ int lds[34];
+  __shared__ int carry[2];
+  __shared__ int ctx[4];
+  if ((int)blockIdx.x < njobs) {
+    alloc_job_body(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
+    return;
+  }
+  const int patch = ((int)blockIdx.x - njobs) * 4 + (int)(threadIdx.x >> 8);
+  if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x & 255);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -536,6 +560,14 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   const int n = patches_x * patches_y;
   if (n <= 0) return;
   hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+}
+
+void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
+                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s) {
+  const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
+  const int n = patches_x * patches_y;
+  hipLaunchKernelGGL(k_sphere_alloc, dim3(njobs + (n + 3) / 4), dim3(1024), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n,
+                     jobs[0], jobs[njobs > 1 ? 1 : 0], njobs, stats);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,

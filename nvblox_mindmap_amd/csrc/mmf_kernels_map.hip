@@ -6,9 +6,12 @@
 // mindmap/mapping/helpers/nvblox_mapping_helpers.py:207-209 and
 // mindmap/mapping/isaaclab_nvblox_mapper.py:252-258.
 #include "mmf_launch.h"
+#include "mmf_alloc_device.h"
 #include "mmf_mask_device.h"
 
 namespace mmf {
+
+static inline int grid_for(int upper, int cap);
 
 // ------------------------------------------------------------------------------------------------
 // 1. Blocks in view: one thread per (subsampled) depth pixel walks the block grid from the camera
@@ -165,14 +168,26 @@ __global__ __launch_bounds__(256) void k_raycast_mark(RaycastJob R) {
 
 // Horizontal fusion: the raycast tiles and the row pass of the frame's mask job in ONE launch (independent work:
 // both only read the depth image / input mask).
+__device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb);
+
+struct DecayJob {
+  LayerDev L;
+  uint8_t* kill;
+  int* any_kill;
+  int n_wgs;  // 0: no decay pending
+};
+
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M) {
+__global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D) {
   extern __shared__ unsigned s_words[];
   __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
-  if ((int)blockIdx.x < n_ray_wgs)
-    raycast_body<LDSFLAGS>(R, blockIdx.x, s_words);
-  else
-    mask_rowbits_row(M, (int)blockIdx.x - n_ray_wgs, s_in, s_d);
+  const int b = (int)blockIdx.x;
+  if (b < n_ray_wgs)
+    raycast_body<LDSFLAGS>(R, b, s_words);
+  else if (b < n_ray_wgs + M.H)
+    mask_rowbits_row(M, b - n_ray_wgs, s_in, s_d);
+  else  // a pending Mapper.decay(): touches only the TSDF pool, which neither other role reads
+    decay_body(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,20 +197,6 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
 //    the live list and of every output derived from it is deterministic.  New blocks take their
 //    pool slot from (rank among the new ones): wave ballot/prefix-sum, no per-block atomics.
 // ------------------------------------------------------------------------------------------------
-__device__ inline u64 grid_cell_key(const KeySrc& ks, int cell) {
-  int gz = cell % ks.nz;
-  int t = cell / ks.nz;
-  int gy = t % ks.ny;
-  int gx = t / ks.ny;
-  return pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
-}
-
-// mode 0: the cell is a cell of the dense view grid; mode 1: the cell is a position of another layer's live
-// list and the producer of the flags (k_app_candidates) stored the block key next to the flag.
-__device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
-  return ks.mode == 0 ? grid_cell_key(ks, cell) : sc.cell_key[cell];
-}
-
 __global__ __launch_bounds__(256) void k_count_tiles(LayerDev L, KeySrc ks, Scratch sc, int ncells) {
   __shared__ int lds[10];
   if (ks.mode == 1) {
@@ -327,155 +328,7 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
 }
 
 
-// Small cell counts (bounded workspaces: a few thousand cells): count + scan + emit fused into ONE launch
-// of one 1024-thread workgroup, 4096 cells per pass with a running carry.  Same candidate order, same
-// slot assignment as the three-kernel path.
-__device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx) {
-  const LayerDev& L = J.L;
-  const KeySrc& ks = J.ks;
-  const Scratch& sc = J.sc;
-  const int stat_upd = J.stat_upd, stat_new = J.stat_new;
-  int ncells = J.ncells;
-  if (ks.mode == 1) {  // list cells: only the producer's live positions carry meaningful flags
-    const int nl = *ks.n_live;
-    ncells = ncells < nl ? ncells : nl;
-  }
-  if (threadIdx.x == 0) {
-    carry[0] = 0;
-    carry[1] = 0;
-    ctx[0] = L.ctr[0];
-    ctx[1] = L.ctr[1];
-    ctx[2] = L.ctr[2];
-    ctx[3] = L.ctr[1] + (L.cap - L.ctr[2]);  // room
-  }
-  // no barrier here: ctx / carry are first read after the barriers of the workgroup scan below, so the counter
-  // round trip of thread 0 overlaps with everyone's table loads
-  for (int base = 0; base < ncells; base += 4096) {
-    const int cell0 = base + threadIdx.x * 4;
-    uint32_t f4 = 0;
-    if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (cell0 + k >= ncells) f4 &= ~(0xffu << (8 * k));  // stale flags beyond the live count
-    int slot4[4] = {0, 0, 0, 0};
-    u64 key4[4] = {0, 0, 0, 0};
-    int nf = 0, nn = 0;
-    if (cell0 < ncells) {
-      // Every load of this pass is issued before the first one is consumed.  Grid cells have computable keys,
-      // so their table entries are fetched without waiting for the flags; list cells read key + flag together
-      // and look the flagged ones up in a second round.
-      if (ks.mode == 0) {
-        unsigned h4[4] = {0, 0, 0, 0};
-        uint4 e4[4];
-        int d4[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          e4[k] = make_uint4(0, 0, 0, 0);
-          if (cell0 + k < ncells) {
-            key4[k] = grid_cell_key(ks, cell0 + k);
-            if (L.dense) {
-              int x, y, z;
-              unpack_key(key4[k], x, y, z);
-              d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
-            } else {
-              h4[k] = hash_key(key4[k]) & L.hmask;
-              e4[k] = hash_load(L, h4[k]);
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if ((f4 >> (8 * k)) & 0xffu) {
-            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
-            nf++;
-            nn += slot4[k] < 0;
-          }
-        }
-      } else if (f4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((f4 >> (8 * k)) & 0xffu) key4[k] = sc.cell_key[cell0 + k];
-        unsigned h4[4] = {0, 0, 0, 0};
-        uint4 e4[4];
-        int d4[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          e4[k] = make_uint4(0, 0, 0, 0);
-          if ((f4 >> (8 * k)) & 0xffu) {
-            if (L.dense) {
-              int x, y, z;
-              unpack_key(key4[k], x, y, z);
-              d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
-            } else {
-              h4[k] = hash_key(key4[k]) & L.hmask;
-              e4[k] = hash_load(L, h4[k]);
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if ((f4 >> (8 * k)) & 0xffu) {
-            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
-            nf++;
-            nn += slot4[k] < 0;
-          }
-        }
-      }
-    }
-    int ea, eb, ta, tb;
-    block_excl_scan2<16>(nf, nn, lds, ea, eb, ta, tb);
-    const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
-    if (f4) {
-      int pos = carry[0] + ea, rnk = carry[1] + eb;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (!((f4 >> (8 * k)) & 0xffu)) continue;
-        int slot = slot4[k];
-        const bool is_new = slot < 0;
-        if (is_new) {
-          if (rnk < room) {
-            slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
-            hash_insert(L, key4[k], slot);
-            dense_set(L, key4[k], slot + 1);
-            L.slot_key[slot] = key4[k];
-            L.live[old_live + rnk] = slot;
-          }
-          rnk++;
-        }
-        sc.cand_slot[pos] = slot;
-        sc.cand_key[pos] = key4[k];
-        sc.cand_new[pos] = is_new ? 1 : 0;
-        pos++;
-      }
-      if (ks.mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      carry[0] += ta;
-      carry[1] += tb;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
-    const int n_cand = carry[0], n_new = carry[1];
-    const int granted = n_new < room ? n_new : room;
-    if (granted < n_new) atomicOr(&L.ctr[3], 1);
-    const int from_free = granted < old_free ? granted : old_free;
-    L.ctr[0] = old_live + granted;
-    L.ctr[1] = old_free - from_free;
-    L.ctr[2] = old_bump + (granted - from_free);
-    *sc.cand_count = n_cand;
-    if (sc.hint_cand) *sc.hint_cand = n_cand;
-    if (L.hint_live) *L.hint_live = L.ctr[0];
-    if (stats) {
-      if (stat_upd >= 0) stats[stat_upd] += n_cand;
-      if (stat_new >= 0) stats[stat_new] += granted;
-    }
-  }
-}
-
-
+// alloc_job_body (count + scan + emit of a small cell set in one 1024-thread workgroup): mmf_alloc_device.h
 __global__ __launch_bounds__(1024) void k_alloc_fused(AllocJob J, long long* stats) {
   __shared__ int lds[34];
   __shared__ int carry[2];
@@ -600,14 +453,69 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
   }
 }
 
+// Fused-frame form of the TSDF update: ONE pass over the live list that (a) integrates the blocks stamped by this
+// frame's allocation job exactly as k_tsdf_integrate does and (b) evaluates, on the voxels it already holds, the
+// appearance-candidate test of k_app_candidates (mmf_kernels_app.hip) for every live block -- the colour / feature camera
+// of a fused frame is the depth camera, so the projection is shared.  Saves a launch and a second read of the layer.
+__global__ __launch_bounds__(512) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+                                                  const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                  float min_d, int stamp, uint8_t* __restrict__ flags,
+                                                  u64* __restrict__ cell_key) {
+  const int n = L.ctr[0];
+  const int chunk = (n + 7) >> 3;
+  const int lin = threadIdx.x;
+  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+    const int i = xcd_candidate(j, chunk);
+    if (i >= n) continue;
+    const int slot = L.live[i];
+    const u64 key = L.slot_key[slot];
+    const int st = L.stamp[slot];
+    const bool cand = (st >> 1) == stamp, is_new = cand && (st & 1);
+    int bx, by, bz;
+    unpack_key(key, bx, by, bz);
+    float2* vox = reinterpret_cast<float2*>(L.pool) + (size_t)slot * kVPB + lin;
+    float2 dw = is_new ? make_float2(0.0f, 0.0f) : *vox;
+    float c[3], p[3], u, v;
+    voxel_centre(mc, bx, by, bz, lin, c);
+    xform(T_C_L, c, p);
+    const bool in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+    if (cand) {  // workgroup-uniform
+      bool upd = false;
+      if (in_view) {
+        float d;
+        if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
+          float sdf = d - p[2];
+          if (!(sdf < -mc.trunc)) {
+            float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
+            float Dn = (sdf * wm + dw.x * dw.y) / (wm + dw.y);
+            Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+            dw.x = Dn;
+            dw.y = fminf(dw.y + wm, mc.max_weight);
+            upd = true;
+          }
+        }
+      }
+      if (upd || is_new) *vox = dw;
+      const int all_free = __syncthreads_and((dw.y > 1e-4f && dw.x == mc.trunc) ? 1 : 0);
+      if (lin == 0) L.block_free[slot] = all_free ? 1 : 0;
+    }
+    const int hit = (dw.y > 0.0f && fabsf(dw.x) < mc.trunc && in_view) ? 1 : 0;
+    const int any = __syncthreads_or(hit);
+    if (lin == 0) {
+      flags[i] = any ? 1 : 0;
+      if (any) cell_key[i] = key;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 4. Decay: W *= factor over every live TSDF block; blocks whose voxels all fell below the threshold
 //    are flagged, then one workgroup compacts the live list in place (order preserving), pushes the
 //    freed slots and the hash is rebuilt from the survivors.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t* __restrict__ kill, int* any_kill) {
+__device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb) {
   const int n = L.ctr[0];
-  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+  for (int i = bid; i < n; i += nb) {
     const int slot = L.live[i];
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x;  // 2 voxels
     float4 a = *vox;
@@ -625,64 +533,14 @@ __global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t
   }
 }
 
+__global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t* __restrict__ kill, int* any_kill) {
+  decay_body(L, mc, kill, any_kill, blockIdx.x, gridDim.x);
+}
+
 __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __restrict__ kill, int* any_kill) {
-  if (!*any_kill) return;
   __shared__ int lds[34];
   __shared__ int carry[2];
-  const int n = L.ctr[0];
-  if (threadIdx.x == 0) {
-    carry[0] = 0;          // survivors written so far
-    carry[1] = L.ctr[1];   // free stack size
-  }
-  __syncthreads();
-  const int free0 = carry[1];
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    int slot = -1, k = 0;
-    if (i < n) {
-      slot = L.live[i];
-      k = kill[i];
-      kill[i] = 0;
-    }
-    int keep = (i < n && !k) ? 1 : 0, dead = (i < n && k) ? 1 : 0;
-    int ea, eb, ta, tb;
-    block_excl_scan2<16>(keep, dead, lds, ea, eb, ta, tb);
-    const int c0 = carry[0], c1 = carry[1];
-    __syncthreads();  // every read of live[base..] and carry happened before any write below
-    if (keep) L.live[c0 + ea] = slot;
-    if (dead) {
-      L.free_stack[c1 + eb] = slot;
-      hash_erase(L, L.slot_key[slot]);  // tombstone; dropped at the next rebuild
-      dense_set(L, L.slot_key[slot], 0);
-      L.slot_key[slot] = kEmptyKey;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      carry[0] = c0 + ta;
-      carry[1] = c1 + tb;
-    }
-    __syncthreads();
-  }
-  const int n_live = carry[0];
-  const int n_tomb = L.ctr[4] + (carry[1] - free0);
-  // amortised rebuild: only when tombstones fill more than a quarter of the table
-  const bool rebuild = (unsigned)n_tomb * 4u > L.hmask + 1u;
-  __syncthreads();
-  if (rebuild) {
-    for (unsigned h = threadIdx.x; h <= L.hmask; h += 1024) L.htab[h].key = kEmptyKey;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_live; i += 1024) {
-      const int slot = L.live[i];
-      hash_insert(L, L.slot_key[slot], slot);
-    }
-  }
-  if (threadIdx.x == 0) {
-    L.ctr[0] = n_live;
-    L.ctr[1] = carry[1];
-    L.ctr[4] = rebuild ? 0 : n_tomb;
-    if (L.hint_live) *L.hint_live = n_live;
-    *any_kill = 0;
-  }
+  live_compact_body(L, kill, any_kill, lds, carry);
 }
 
 __global__ __launch_bounds__(256) void k_hash_clear_if(LayerDev L, const int* cond) {
@@ -827,14 +685,23 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
 
 // raycast + mask row pass in one launch
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
-                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, hipStream_t s) {
+                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, uint8_t* kill,
+                  int* any_kill, hipStream_t s) {
   int n_wgs;
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
   const int ncells = vg.nx * vg.ny * vg.nz;
+  DecayJob D{};
+  if (decay_layer) {
+    D.L = *decay_layer;
+    D.kill = kill;
+    D.any_kill = any_kill;
+    D.n_wgs = grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
+  }
+  const dim3 grid(n_wgs + M.H + D.n_wgs);
   if (ncells <= kRaycastLdsCells)
-    hipLaunchKernelGGL(k_front<true>, dim3(n_wgs + M.H), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R, n_wgs, M);
+    hipLaunchKernelGGL(k_front<true>, grid, dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R, n_wgs, M, D);
   else
-    hipLaunchKernelGGL(k_front<false>, dim3(n_wgs + M.H), dim3(256), 0, s, R, n_wgs, M);
+    hipLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, R, n_wgs, M, D);
 }
 
 constexpr int kFusedAllocMaxCells = 16384;
@@ -897,6 +764,12 @@ void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& ca
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s) {
   hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
                      mask, min_d, sc);
+}
+
+void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
+                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, hipStream_t s) {
+  hipLaunchKernelGGL(k_tsdf_pass, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask,
+                     min_d, stamp, flags, cell_key);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {
