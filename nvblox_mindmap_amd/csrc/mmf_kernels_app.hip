@@ -207,6 +207,37 @@ __global__ __launch_bounds__(1024) void k_sphere_alloc(LayerDev T, MapConsts mc,
 // Shared per-voxel gate (projection, occlusion test against the synthetic depth, bilinear footprint,
 // mask).  Same operation order as oracle/mmf_oracle.c:app_gate.
 // ------------------------------------------------------------------------------------------------
+// geometry + occlusion part: everything that does not depend on the integration mask
+__device__ inline bool app_gate_geo(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ synth, int Ws,
+                                    int Hs, int bx, int by, int bz, int lin, int& x0, int& y0, float& wx, float& wy) {
+  float c[3], p[3], u, v;
+  voxel_centre(mc, bx, by, bz, lin, c);
+  xform(T_C_L, c, p);
+  if (!project(cam, p, u, v)) return false;
+  if (mc.max_dist > 0.0f && p[2] > mc.max_dist) return false;
+  const float sf = (float)mc.st_sf;
+  int sx, sy;
+  float swx, swy;
+  if (!bilin_setup(u / sf, v / sf, Ws, Hs, sx, sy, swx, swy)) return false;
+  if (!bilin_setup(u, v, cam.W, cam.H, x0, y0, wx, wy)) return false;
+  const size_t si = (size_t)sy * Ws + sx;
+  const float2_u s0 = *reinterpret_cast<const float2_u*>(synth + si);
+  const float2_u s1 = *reinterpret_cast<const float2_u*>(synth + si + Ws);
+  if (!(s0.x > 0.0f) || !(s0.y > 0.0f) || !(s1.x > 0.0f) || !(s1.y > 0.0f)) return false;
+  const float sd = bilin(s0.x, s0.y, s1.x, s1.y, swx, swy);
+  if (fabsf(sd - p[2]) > mc.trunc) return false;
+  return true;
+}
+
+// mask part: all four taps of the bilinear footprint must be inside the mask
+__device__ inline bool app_gate_mask(const uint8_t* __restrict__ mask, int W, int x0, int y0) {
+  if (!mask) return true;
+  const size_t i = (size_t)y0 * W + x0;
+  const unsigned m0 = *reinterpret_cast<const ushort_u*>(mask + i);
+  const unsigned m1 = *reinterpret_cast<const ushort_u*>(mask + i + W);
+  return (m0 & 0xffu) && (m0 & 0xff00u) && (m1 & 0xffu) && (m1 & 0xff00u);
+}
+
 __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* __restrict__ mask,
                                 const float* __restrict__ synth, int Ws, int Hs, int bx, int by, int bz, int lin, int& x0,
                                 int& y0, float& wx, float& wy) {
@@ -252,6 +283,28 @@ struct AppArgs {
   long long* stats;  // mapper statistics (may be null)
 };
 
+// blend one colour voxel {rgb_, w} with the bilinear sample at footprint (x0,y0,wx,wy)
+__device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, const MapConsts& mc, int x0, int y0, float wx, float wy,
+                                    unsigned& ex, unsigned& ey) {
+  const uint8_t* t00 = rgb + ((size_t)y0 * W + x0) * 3;
+  const uint8_t* t10 = t00 + 3;
+  const uint8_t* t01 = t00 + (size_t)W * 3;
+  const uint8_t* t11 = t01 + 3;
+  const float Wv = __uint_as_float(ey);
+  const float wm = mc.app_wm;
+  const float inv = 1.0f / (Wv + wm);
+  unsigned out = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
+    const float Aold = (float)((ex >> (8 * k)) & 0xffu);
+    const float An = (Aold * Wv + a * wm) * inv;
+    out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
+  }
+  ex = out;
+  ey = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
+}
+
 __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs, int bid,
                                   int nb) {
   const LayerDev& L = A.L;
@@ -277,23 +330,7 @@ __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const f
       int x0, y0;
       float wx, wy;
       if (app_gate(mc, cam, A.T_C_L, A.mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
-        const uint8_t* t00 = rgb + ((size_t)y0 * cam.W + x0) * 3;
-        const uint8_t* t10 = t00 + 3;
-        const uint8_t* t01 = t00 + (size_t)cam.W * 3;
-        const uint8_t* t11 = t01 + 3;
-        const float Wv = __uint_as_float(ey);
-        const float wm = mc.app_wm;
-        const float inv = 1.0f / (Wv + wm);
-        unsigned out = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
-          const float Aold = (float)((ex >> (8 * k)) & 0xffu);
-          const float An = (Aold * Wv + a * wm) * inv;
-          out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
-        }
-        ex = out;
-        ey = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
+        color_update(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
         upd = true;
       }
       if (r) {
@@ -371,67 +408,24 @@ __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const
   return o;
 }
 
+// Phase 2 of the feature update of one block: 32 groups of 8 lanes walk the survivor list the workgroup compacted into
+// LDS (S.n entries); a group moves one voxel's channels in 128-byte pieces.  Also zero-fills the untouched rows of a new
+// block.  Callers synchronise before (list complete) and after (LDS reuse).
 template <bool LOW>
-__device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
-                                    int bid, int nb, FeatLds& S) {
+__device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
   const LayerDev& L = A.L;
   const Cam& cam = A.cam;
-  const Rigid& T_C_L = A.T_C_L;
   const __half* __restrict__ feat = reinterpret_cast<const __half*>(A.image);
   const LowRes LR = A.low;
-  const uint8_t* __restrict__ mask = A.mask;
-  const Scratch& sc = A.sc;
-  uint16_t* s_lin = S.lin;
-  uint32_t* s_pix = S.pix;
-  float *s_wx = S.wx, *s_wy = S.wy, *s_W = S.W;
-  uint8_t* s_valid = S.valid;
-  int& s_n = S.n;
-
-  const int n = *sc.cand_count;
-  const int chunk = (n + 7) >> 3;
+  const uint16_t* s_lin = S.lin;
+  const uint32_t* s_pix = S.pix;
+  const float *s_wx = S.wx, *s_wy = S.wy, *s_W = S.W;
+  const uint8_t* s_valid = S.valid;
   const int C = mc.C, nch = C >> 3;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int group = tid >> 3, gl = tid & 7;
   const float wm = mc.app_wm;
-
-  for (int j = bid; j < chunk * 8; j += nb) {
-    const int i = xcd_candidate(j, chunk);
-    if (i >= n) continue;
-    const int slot = sc.cand_slot[i];
-    if (slot < 0) continue;
-    const bool is_new = sc.cand_new[i] != 0;
-    int bx, by, bz;
-    unpack_key(sc.cand_key[i], bx, by, bz);
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-
-    float* wts = L.poolw + (size_t)slot * kVPB;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int lin = tid + 256 * r;
-      int x0, y0;
-      float wx, wy;
-      const bool valid = app_gate(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
-      const u64 bal = __ballot(valid);
-      int base = 0;
-      if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
-      base = __shfl(base, 0, 64);
-      if (valid) {
-        const float Wold = is_new ? 0.0f : wts[lin];
-        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        s_lin[pos] = (uint16_t)lin;
-        s_pix[pos] = (uint32_t)(y0 * cam.W + x0);
-        s_wx[pos] = wx;
-        s_wy[pos] = wy;
-        s_W[pos] = Wold;
-        wts[lin] = fminf(Wold + wm, mc.app_max_w);
-      } else if (is_new) {
-        wts[lin] = 0.0f;
-      }
-      if (is_new) s_valid[lin] = valid ? 1 : 0;
-    }
-    __syncthreads();
-
+  const int& s_n = S.n;
     const int nv = s_n;
     if (tid == 0 && A.stats && nv) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)nv);
     __half* blk = reinterpret_cast<__half*>(L.pool) + (size_t)slot * kVPB * C;
@@ -516,6 +510,66 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
         for (int ch = gl; ch < nch; ch += 8) *reinterpret_cast<half8*>(A + ch * 8) = z;
       }
     }
+}
+
+template <bool LOW>
+__device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
+                                    int bid, int nb, FeatLds& S) {
+  const LayerDev& L = A.L;
+  const Cam& cam = A.cam;
+  const Rigid& T_C_L = A.T_C_L;
+  const uint8_t* __restrict__ mask = A.mask;
+  const Scratch& sc = A.sc;
+  uint16_t* s_lin = S.lin;
+  uint32_t* s_pix = S.pix;
+  float *s_wx = S.wx, *s_wy = S.wy, *s_W = S.W;
+  uint8_t* s_valid = S.valid;
+  int& s_n = S.n;
+
+  const int n = *sc.cand_count;
+  const int chunk = (n + 7) >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float wm = mc.app_wm;
+
+  for (int j = bid; j < chunk * 8; j += nb) {
+    const int i = xcd_candidate(j, chunk);
+    if (i >= n) continue;
+    const int slot = sc.cand_slot[i];
+    if (slot < 0) continue;
+    const bool is_new = sc.cand_new[i] != 0;
+    int bx, by, bz;
+    unpack_key(sc.cand_key[i], bx, by, bz);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    float* wts = L.poolw + (size_t)slot * kVPB;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int lin = tid + 256 * r;
+      int x0, y0;
+      float wx, wy;
+      const bool valid = app_gate(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
+      const u64 bal = __ballot(valid);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (valid) {
+        const float Wold = is_new ? 0.0f : wts[lin];
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        s_lin[pos] = (uint16_t)lin;
+        s_pix[pos] = (uint32_t)(y0 * cam.W + x0);
+        s_wx[pos] = wx;
+        s_wy[pos] = wy;
+        s_W[pos] = Wold;
+        wts[lin] = fminf(Wold + wm, mc.app_max_w);
+      } else if (is_new) {
+        wts[lin] = 0.0f;
+      }
+      if (is_new) s_valid[lin] = valid ? 1 : 0;
+    }
+    __syncthreads();
+
+    feature_apply<LOW>(A, mc, S, slot, is_new);
     __syncthreads();
   }
 }
@@ -537,6 +591,89 @@ __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Af
     color_body(Acol, mc, synth, Ws, Hs, blockIdx.x, g_col);
   else
     feature_body<LOW>(Afeat, mc, synth, Ws, Hs, (int)blockIdx.x - g_col, (int)gridDim.x - g_col, S);
+}
+
+// Colour and feature update of the candidate blocks of a fused frame with ONE geometric gate per voxel.  In a fused
+// frame both layers see the same camera and the same candidate list (the allocation jobs read the same flags), so the
+// projection, the two bilinear footprints and the occlusion test against the synthetic depth are evaluated once; only
+// the masks (depth mask for colour, eroded feature mask for features) differ.  Voxel order: thread t owns voxels 2t, 2t+1.
+template <bool LOW>
+__device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, const MapConsts& mc, const float* __restrict__ synth,
+                                      int Ws, int Hs, int bid, int nb, FeatLds& S) {
+  const Cam& cam = Ac.cam;
+  const uint8_t* __restrict__ rgb = reinterpret_cast<const uint8_t*>(Ac.image);
+  const int n = *Ac.sc.cand_count;
+  const int chunk = (n + 7) >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float wm = mc.app_wm;
+  for (int j = bid; j < chunk * 8; j += nb) {
+    const int i = xcd_candidate(j, chunk);
+    if (i >= n) continue;
+    const int cslot = Ac.sc.cand_slot[i], fslot = Af.sc.cand_slot[i];
+    if (cslot < 0 && fslot < 0) continue;
+    const bool c_new = Ac.sc.cand_new[i] != 0, f_new = Af.sc.cand_new[i] != 0;
+    int bx, by, bz;
+    unpack_key(Ac.sc.cand_key[i], bx, by, bz);
+    if (tid == 0) S.n = 0;
+    __syncthreads();
+    uint4* vox2 = reinterpret_cast<uint4*>(Ac.L.pool) + (size_t)(cslot < 0 ? 0 : cslot) * (kVPB / 2) + tid;
+    uint4 e2 = make_uint4(0u, 0u, 0u, 0u);
+    if (cslot >= 0 && !c_new) e2 = *vox2;
+    float* wts = Af.L.poolw + (size_t)(fslot < 0 ? 0 : fslot) * kVPB;
+    float2 w2 = make_float2(0.0f, 0.0f);
+    if (fslot >= 0 && !f_new) w2 = *reinterpret_cast<const float2*>(wts + 2 * tid);
+    bool c_upd = false, f_upd = false;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int lin = tid * 2 + r;
+      int x0 = 0, y0 = 0;
+      float wx = 0.0f, wy = 0.0f;
+      const bool geo = app_gate_geo(mc, cam, Ac.T_C_L, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
+      const bool c_ok = geo && cslot >= 0 && app_gate_mask(Ac.mask, cam.W, x0, y0);
+      const bool f_ok = geo && fslot >= 0 && app_gate_mask(Af.mask, cam.W, x0, y0);
+      if (c_ok) {
+        unsigned ex = r ? e2.z : e2.x, ey = r ? e2.w : e2.y;
+        color_update(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
+        if (r) {
+          e2.z = ex;
+          e2.w = ey;
+        } else {
+          e2.x = ex;
+          e2.y = ey;
+        }
+        c_upd = true;
+      }
+      const u64 bal = __ballot(f_ok);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&S.n, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (f_ok) {
+        const float Wold = r ? w2.y : w2.x;
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        S.lin[pos] = (uint16_t)lin;
+        S.pix[pos] = (uint32_t)(y0 * cam.W + x0);
+        S.wx[pos] = wx;
+        S.wy[pos] = wy;
+        S.W[pos] = Wold;
+        const float Wn = fminf(Wold + wm, mc.app_max_w);
+        if (r) w2.y = Wn; else w2.x = Wn;
+        f_upd = true;
+      }
+      if (f_new) S.valid[lin] = f_ok ? 1 : 0;
+    }
+    if (cslot >= 0 && (c_upd || c_new)) *vox2 = e2;
+    if (fslot >= 0 && (f_upd || f_new)) *reinterpret_cast<float2*>(wts + 2 * tid) = w2;
+    __syncthreads();
+    if (fslot >= 0) feature_apply<LOW>(Af, mc, S, fslot, f_new);
+    __syncthreads();
+  }
+}
+
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
+                                                  int Hs) {
+  __shared__ FeatLds S;
+  app_frame_body<LOW>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,8 +744,18 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
                            hipStream_t s, const LowRes* low) {
-  const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
   const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc), Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low);
+  const bool same_cam = ccam.W == fcam.W && ccam.H == fcam.H && ccam.fx == fcam.fx && ccam.fy == fcam.fy && ccam.cx == fcam.cx &&
+                        ccam.cy == fcam.cy && csc.flags == fsc.flags;
+  if (same_cam) {  // one candidate list, one geometric gate per voxel
+    const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
+    if (low)
+      hipLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
+    else
+      hipLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
+    return;
+  }
+  const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
   if (low)
     hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
   else

@@ -457,13 +457,14 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // frame's allocation job exactly as k_tsdf_integrate does and (b) evaluates, on the voxels it already holds, the
 // appearance-candidate test of k_app_candidates (mmf_kernels_app.hip) for every live block -- the colour / feature camera
 // of a fused frame is the depth camera, so the projection is shared.  Saves a launch and a second read of the layer.
-__global__ __launch_bounds__(512) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+__global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                   const float* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                   float min_d, int stamp, uint8_t* __restrict__ flags,
                                                   u64* __restrict__ cell_key) {
+  // 256 threads x 2 z-adjacent voxels (one 16-byte access): twice as many resident workgroups as thread-per-voxel and
+  // two independent dependency chains per thread
   const int n = L.ctr[0];
   const int chunk = (n + 7) >> 3;
-  const int lin = threadIdx.x;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
     const int i = xcd_candidate(j, chunk);
     if (i >= n) continue;
@@ -473,35 +474,48 @@ __global__ __launch_bounds__(512) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
     const bool cand = (st >> 1) == stamp, is_new = cand && (st & 1);
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
-    float2* vox = reinterpret_cast<float2*>(L.pool) + (size_t)slot * kVPB + lin;
-    float2 dw = is_new ? make_float2(0.0f, 0.0f) : *vox;
-    float c[3], p[3], u, v;
-    voxel_centre(mc, bx, by, bz, lin, c);
-    xform(T_C_L, c, p);
-    const bool in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
-    if (cand) {  // workgroup-uniform
-      bool upd = false;
-      if (in_view) {
+    float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x;
+    float4 a = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : *vox;
+    bool upd = false;
+    int hit = 0, freev = 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float D = r ? a.z : a.x, W = r ? a.w : a.y;
+      float c[3], p[3], u, v;
+      voxel_centre(mc, bx, by, bz, threadIdx.x * 2 + r, c);
+      xform(T_C_L, c, p);
+      const bool in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+      if (cand && in_view) {
         float d;
         if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
           float sdf = d - p[2];
           if (!(sdf < -mc.trunc)) {
             float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
-            float Dn = (sdf * wm + dw.x * dw.y) / (wm + dw.y);
+            float Dn = (sdf * wm + D * W) / (wm + W);
             Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-            dw.x = Dn;
-            dw.y = fminf(dw.y + wm, mc.max_weight);
+            D = Dn;
+            W = fminf(W + wm, mc.max_weight);
             upd = true;
           }
         }
       }
-      if (upd || is_new) *vox = dw;
-      const int all_free = __syncthreads_and((dw.y > 1e-4f && dw.x == mc.trunc) ? 1 : 0);
-      if (lin == 0) L.block_free[slot] = all_free ? 1 : 0;
+      if (r) {
+        a.z = D;
+        a.w = W;
+      } else {
+        a.x = D;
+        a.y = W;
+      }
+      hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
+      freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
     }
-    const int hit = (dw.y > 0.0f && fabsf(dw.x) < mc.trunc && in_view) ? 1 : 0;
+    if (cand) {  // workgroup-uniform
+      if (upd || is_new) *vox = a;
+      const int all_free = __syncthreads_and(freev);
+      if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
+    }
     const int any = __syncthreads_or(hit);
-    if (lin == 0) {
+    if (threadIdx.x == 0) {
       flags[i] = any ? 1 : 0;
       if (any) cell_key[i] = key;
     }
@@ -768,7 +782,7 @@ void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& ca
 
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, hipStream_t s) {
-  hipLaunchKernelGGL(k_tsdf_pass, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask,
+  hipLaunchKernelGGL(k_tsdf_pass, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(256), 0, s, L, mc, cam, T_C_L, depth, mask,
                      min_d, stamp, flags, cell_key);
 }
 
