@@ -98,6 +98,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
     ncells = ncells < nl ? ncells : nl;
   }
   if (threadIdx.x == 0) {
+    if (J.zero_me) *J.zero_me = 0;
     carry[0] = 0;
     carry[1] = 0;
     ctx[0] = L.ctr[0];

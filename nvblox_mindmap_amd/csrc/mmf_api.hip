@@ -65,6 +65,7 @@ struct Mapper {
   float synth_T[16]{}, synth_K[9]{};
   int synth_iw = 0, synth_ih = 0;
   long long tsdf_epoch = 0;
+  FlatList flat;               // survivor list of a feature frame (balanced phase 2); rec == null: not in use
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
   // mesh
   int* mesh_counts = nullptr;
@@ -387,6 +388,9 @@ void destroy_mapper(Mapper* m) {
   }
   (void)hipFree(m->mask_tmp);
   (void)hipFree(m->masked_depth);
+  (void)hipFree(m->flat.rec);
+  (void)hipFree(m->flat.w);
+  (void)hipFree(m->flat.count);
   if (m->hints) (void)hipHostFree(m->hints);
   (void)hipFree(m->kill);
   (void)hipFree(m->any_kill);
@@ -479,6 +483,19 @@ int get_mapper_ready(mmf_handle h, int id, Mapper** out, void* stream) {
 int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w) {
   if (L.allocated) return MMF_OK;
   MMF_TRY(alloc_layer(L, m.app_cap, block_bytes, has_w));
+  if (has_w && !m.flat.rec) {
+    // survivor list of a feature frame: every voxel of every block may survive.  Bounded workspaces (what the
+    // reference configures) need a few tens of MB; very large pools keep phase 2 inside the gating workgroups.
+    const size_t recs = (size_t)m.app_cap * kVPB;
+    if (m.app_cap < (1 << 22) && recs * 20 <= ((size_t)256 << 20)) {
+      HIP_TRY(hipMalloc(&m.flat.rec, sizeof(uint4) * recs));
+      HIP_TRY(hipMalloc(&m.flat.w, sizeof(float) * recs));
+      HIP_TRY(hipMalloc(&m.flat.count, sizeof(int)));
+      HIP_TRY(hipMemset(m.flat.count, 0, sizeof(int)));
+      m.flat.cap = (int)recs;
+      m.flat.hint = m.hints ? m.hints + 6 : nullptr;
+    }
+  }
   return attach_dense_table(m, L);
 }
 
@@ -793,10 +810,11 @@ static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat,
   rigid_inverse(T_L_C, T_C_L);
   m->frames[2]++;
   MMF_TRY(app_prepare(h, *m, 2, m->feat, cam, T_L_C, T_C_L, T16, K9, 6, 7, s));
+  if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
   {
     ProfScope ps(h, MMF_K_FEATURE, s);
     launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc[2],
-                             m->feat.d.cap, m->stats, s, low);
+                             m->feat.d.cap, m->stats, s, low, &m->flat);
   }
   return check_launch();
 }
@@ -895,8 +913,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                              m->color.d.cap, s);
       m->frames[2]++;
       MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
+      if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
       launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
-                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low);
+                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
       return check_launch();
     }
     m->last_vg = vg;
@@ -964,6 +983,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       jobs[1].ncells = m->tsdf.d.cap;
       jobs[1].stat_upd = 6;
       jobs[1].stat_new = 7;
+      jobs[1].zero_me = m->flat.count;  // survivor counter of this frame's feature update
       int Ws, Hs;
       bool need;
       MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
@@ -978,7 +998,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     {
       ProfScope ps(h, MMF_K_FEATURE, s);
       launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low);
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat);
     }
     return check_launch();
   }
@@ -1013,8 +1033,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   const int fWs = m->synth_W, fHs = m->synth_H;
   {
     ProfScope ps(h, MMF_K_FEATURE, sa);
+    if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), sa));
     launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, fsynth, fWs, fHs, m->sc[2],
-                             m->feat.d.cap, m->stats, sa, low);
+                             m->feat.d.cap, m->stats, sa, low, &m->flat);
   }
   HIP_TRY(record(4, sa));
 

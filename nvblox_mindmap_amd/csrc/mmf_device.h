@@ -119,6 +119,7 @@ struct AllocJob {
   int stamp = 0;           // != 0: mark every candidate slot in L.stamp (see LayerDev::stamp)
   uint8_t* kill = nullptr; // != null: first apply the kill flags of a decay pass (live_compact_body)
   int* any_kill = nullptr;
+  int* zero_me = nullptr;  // != null: an int this job resets (the frame's feature survivor counter)
 };
 
 __host__ __device__ inline u64 pack_key(int x, int y, int z) {

@@ -277,6 +277,7 @@ struct AppArgs {
   Cam cam;
   Rigid T_C_L;
   const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]  (null when `low` is the feature source)
+  FlatList flat;         // features only: survivor list of the frame (rec == null: phase 2 stays in the gating workgroup)
   LowRes low;            // features only: low-res backbone map sampled in the kernel instead of a materialised image
   const uint8_t* mask;
   Scratch sc;
@@ -365,7 +366,7 @@ struct FeatLds {
   uint32_t pix[kVPB];
   float wx[kVPB], wy[kVPB], W[kVPB];
   uint8_t valid[kVPB];
-  int n;
+  int n, base;
 };
 
 // One tap of the virtual up-sampled image: f16( bilinear align_corners=False of the low-res map at pixel (xf,yf) ),
@@ -408,37 +409,21 @@ __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const
   return o;
 }
 
-// Phase 2 of the feature update of one block: 32 groups of 8 lanes walk the survivor list the workgroup compacted into
-// LDS (S.n entries); a group moves one voxel's channels in 128-byte pieces.  Also zero-fills the untouched rows of a new
-// block.  Callers synchronise before (list complete) and after (LDS reuse).
+// One surviving voxel: blend its channel row with the bilinear sample of the feature image (or of the virtual up-sampled
+// low-res map).  `lanes` lanes (gl = 0..lanes-1) share the row in 16-byte pieces.
 template <bool LOW>
-__device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
-  const LayerDev& L = A.L;
-  const Cam& cam = A.cam;
-  const __half* __restrict__ feat = reinterpret_cast<const __half*>(A.image);
-  const LowRes LR = A.low;
-  const uint16_t* s_lin = S.lin;
-  const uint32_t* s_pix = S.pix;
-  const float *s_wx = S.wx, *s_wy = S.wy, *s_W = S.W;
-  const uint8_t* s_valid = S.valid;
+__device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts& mc, __half* __restrict__ A, bool is_new, size_t pix,
+                                              float wx, float wy, float Wv, int gl, int lanes) {
+  const Cam& cam = Aa.cam;
+  const __half* __restrict__ feat = reinterpret_cast<const __half*>(Aa.image);
+  const LowRes LR = Aa.low;
   const int C = mc.C, nch = C >> 3;
-  const int tid = threadIdx.x;
-  const int group = tid >> 3, gl = tid & 7;
   const float wm = mc.app_wm;
-  const int& s_n = S.n;
-    const int nv = s_n;
-    if (tid == 0 && A.stats && nv) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)nv);
-    __half* blk = reinterpret_cast<__half*>(L.pool) + (size_t)slot * kVPB * C;
-    for (int vi = group; vi < nv; vi += 32) {
-      const int lin = s_lin[vi];
-      const size_t pix = s_pix[vi];
-      const float wx = s_wx[vi], wy = s_wy[vi], Wv = s_W[vi];
-      const float inv = 1.0f / (Wv + wm);
-      const __half* t00 = feat + pix * C;
-      const __half* t10 = t00 + C;
-      const __half* t01 = t00 + (size_t)cam.W * C;
-      const __half* t11 = t01 + C;
-      __half* A = blk + (size_t)lin * C;
+  const float inv = 1.0f / (Wv + wm);
+  const __half* t00 = feat + pix * C;
+  const __half* t10 = t00 + C;
+  const __half* t01 = t00 + (size_t)cam.W * C;
+  const __half* t11 = t01 + C;
       // LOW: the four taps are pixels (px,py) (px+1,py) (px,py+1) (px+1,py+1) of the virtual up-sampled image
       LowAxis X0, X1, Y0, Y1;
       bool one_cell = false;
@@ -450,7 +435,7 @@ __device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, Feat
         Y1 = low_axis(LR.sh, py + 1, LR.h);
         one_cell = X0.i0 == X1.i0 && X0.i1 == X1.i1 && Y0.i0 == Y1.i0 && Y0.i1 == Y1.i1;  // usual case: 4 loads serve 4 taps
       }
-      for (int ch = gl; ch < nch; ch += 8) {
+      for (int ch = gl; ch < nch; ch += lanes) {
         half8 a00, a10, a01, a11;
         if constexpr (LOW) {
           const int c0 = ch * 8;
@@ -499,17 +484,75 @@ __device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, Feat
         }
         *reinterpret_cast<half8*>(A + ch * 8) = o;
       }
-    }
-    if (is_new) {  // rows of voxels that were not updated must read as zero
-      half8 z;
+}
+
+// Phase 2 inside the workgroup that gated the block: 32 groups of 8 lanes walk the survivor list in LDS.
+template <bool LOW>
+__device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
+  const int C = mc.C;
+  const int group = threadIdx.x >> 3, gl = threadIdx.x & 7;
+  const int nv = S.n;
+  __half* blk = reinterpret_cast<__half*>(A.L.pool) + (size_t)slot * kVPB * C;
+  for (int vi = group; vi < nv; vi += 32)
+    feature_voxel<LOW>(A, mc, blk + (size_t)S.lin[vi] * C, is_new, S.pix[vi], S.wx[vi], S.wy[vi], S.W[vi], gl, 8);
+}
+
+// Phase 2 deferred: append the survivor list to the frame's global list (FlatList); k_feature_flat then spreads the
+// rows evenly over the whole chip.  Blocks on a surface have up to 512 survivors, the average is ~50: done inside the
+// gating workgroup, the heavy blocks set the kernel time (16 serial rounds vs 1.6 on average).
+// Returns false (workgroup-uniform) when the list is not in use; contains a barrier.
+__device__ inline bool feature_publish(const AppArgs& A, FeatLds& S, int slot, bool is_new) {
+  if (!A.flat.rec) return false;
+  const int nv = S.n;
+  if (threadIdx.x == 0) S.base = nv ? atomicAdd(A.flat.count, nv) : 0;
+  __syncthreads();
+  const int base = S.base;
+  const unsigned hi = ((unsigned)slot << 9) | (is_new ? 0x80000000u : 0u);
+  for (int v = threadIdx.x; v < nv; v += 256) {
+    A.flat.rec[base + v] = make_uint4(hi | S.lin[v], S.pix[v], __float_as_uint(S.wx[v]), __float_as_uint(S.wy[v]));
+    A.flat.w[base + v] = S.W[v];
+  }
+  return true;
+}
+
+// rows of a new block that were not updated must read as zero
+__device__ inline void feature_zero_fill(const AppArgs& A, const MapConsts& mc, const FeatLds& S, int slot) {
+  const int C = mc.C, nch = C >> 3;
+  const int group = threadIdx.x >> 3, gl = threadIdx.x & 7;
+  __half* blk = reinterpret_cast<__half*>(A.L.pool) + (size_t)slot * kVPB * C;
+  half8 z;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
-      for (int lin = group; lin < kVPB; lin += 32) {
-        if (s_valid[lin]) continue;
-        __half* A = blk + (size_t)lin * C;
-        for (int ch = gl; ch < nch; ch += 8) *reinterpret_cast<half8*>(A + ch * 8) = z;
-      }
-    }
+  for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+  for (int lin = group; lin < kVPB; lin += 32) {
+    if (S.valid[lin]) continue;
+    __half* A2 = blk + (size_t)lin * C;
+    for (int ch = gl; ch < nch; ch += 8) *reinterpret_cast<half8*>(A2 + ch * 8) = z;
+  }
+}
+
+// tail of both gating bodies once the survivor list of the block is complete in LDS (callers synchronised before)
+template <bool LOW>
+__device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
+  if (threadIdx.x == 0 && A.stats && S.n) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
+  if (!feature_publish(A, S, slot, is_new)) feature_apply<LOW>(A, mc, S, slot, is_new);
+  if (is_new) feature_zero_fill(A, mc, S, slot);
+}
+
+// Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size.
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
+  const int total = *A.flat.count;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && A.flat.hint) *A.flat.hint = total;
+  const int vpw = 256 / lpv;
+  const int group = threadIdx.x / lpv, gl = threadIdx.x % lpv;
+  const int C = mc.C;
+  __half* pool = reinterpret_cast<__half*>(A.L.pool);
+  for (int v = blockIdx.x * vpw + group; v < total; v += gridDim.x * vpw) {
+    const uint4 r = A.flat.rec[v];
+    const float Wv = A.flat.w[v];
+    const size_t row = (size_t)(r.x & 0x7fffffffu);  // slot * 512 + lin
+    feature_voxel<LOW>(A, mc, pool + row * C, (r.x >> 31) != 0u, r.y, __uint_as_float(r.z), __uint_as_float(r.w), Wv, gl, lpv);
+  }
 }
 
 template <bool LOW>
@@ -569,7 +612,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
     }
     __syncthreads();
 
-    feature_apply<LOW>(A, mc, S, slot, is_new);
+    feature_finish<LOW>(A, mc, S, slot, is_new);
     __syncthreads();
   }
 }
@@ -664,7 +707,7 @@ __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, cons
     if (cslot >= 0 && (c_upd || c_new)) *vox2 = e2;
     if (fslot >= 0 && (f_upd || f_new)) *reinterpret_cast<float2*>(wts + 2 * tid) = w2;
     __syncthreads();
-    if (fslot >= 0) feature_apply<LOW>(Af, mc, S, fslot, f_new);
+    if (fslot >= 0) feature_finish<LOW>(Af, mc, S, fslot, f_new);
     __syncthreads();
   }
 }
@@ -708,9 +751,11 @@ void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
-                             const Scratch& sc, long long* stats = nullptr, const LowRes* low = nullptr) {
+                             const Scratch& sc, long long* stats = nullptr, const LowRes* low = nullptr,
+                             const FlatList* flat = nullptr) {
   AppArgs A;
   A.low = low ? *low : LowRes{};
+  A.flat = flat ? *flat : FlatList{};
   A.stats = stats;
   A.L = L;
   A.cam = cam;
@@ -728,23 +773,40 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                      make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
 }
 
+// balanced phase 2 over the frame's survivor list (enqueued right behind the gating launch)
+static void launch_feature_flat(const AppArgs& Af, const MapConsts& mc, const FlatList& fl, bool low, hipStream_t s) {
+  const int nch = mc.C >> 3;
+  const int lpv = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);  // lanes per voxel row
+  const int vpw = 256 / lpv;
+  const long long vox = hinted(fl.hint, fl.cap);
+  long long wgs = (vox + vpw - 1) / vpw;
+  wgs = wgs > 16384 ? 16384 : wgs;
+  const dim3 grid((unsigned)grid8((int)wgs, 16384));
+  if (low)
+    hipLaunchKernelGGL(k_feature_flat<true>, grid, dim3(256), 0, s, Af, mc, lpv);
+  else
+    hipLaunchKernelGGL(k_feature_flat<false>, grid, dim3(256), 0, s, Af, mc, lpv);
+}
+
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
-                              long long* stats, hipStream_t s, const LowRes* low) {
+                              long long* stats, hipStream_t s, const LowRes* low, const FlatList* flat) {
   const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
-  const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low);
+  const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low, flat);
   if (low)
     hipLaunchKernelGGL(k_feature_integrate<true>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
   else
     hipLaunchKernelGGL(k_feature_integrate<false>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  if (flat && flat->rec) launch_feature_flat(A, mc, *flat, low != nullptr, s);
 }
 
-// colour + feature update in one launch
+// colour + feature update of one frame (gating launch, then the balanced feature pass when a survivor list is given)
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low) {
-  const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc), Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low);
+                           hipStream_t s, const LowRes* low, const FlatList* flat) {
+  const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
+                Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low, flat);
   const bool same_cam = ccam.W == fcam.W && ccam.H == fcam.H && ccam.fx == fcam.fx && ccam.fy == fcam.fy && ccam.cx == fcam.cx &&
                         ccam.cy == fcam.cy && csc.flags == fsc.flags;
   if (same_cam) {  // one candidate list, one geometric gate per voxel
@@ -753,13 +815,14 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
       hipLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
     else
       hipLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
-    return;
+  } else {
+    const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
+    if (low)
+      hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
+    else
+      hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
   }
-  const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
-  if (low)
-    hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
-  else
-    hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
+  if (flat && flat->rec) launch_feature_flat(Af, mc, *flat, low != nullptr, s);
 }
 
 }  // namespace mmf

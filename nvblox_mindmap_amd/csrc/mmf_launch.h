@@ -13,6 +13,16 @@ struct LowRes {
   float sh = 0.0f, sw = 0.0f;
 };
 
+// Survivor list of one feature frame: voxels that passed the gate, appended by the gating workgroups and consumed by
+// k_feature_flat.  rec = {is_new << 31 | slot << 9 | voxel, top-left tap pixel, wx, wy}, w = weight before the update.
+struct FlatList {
+  uint4* rec = nullptr;
+  float* w = nullptr;
+  int* count = nullptr;  // device counter, zero before the gating launch
+  int* hint = nullptr;   // pinned host int: last count (sizes the next grid)
+  int cap = 0;
+};
+
 struct ViewGrid {
   int ox, oy, oz;  // block index of cell (0,0,0)
   int nx, ny, nz;
@@ -55,12 +65,12 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                             hipStream_t s);
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
-                              long long* stats, hipStream_t s, const LowRes* low = nullptr);
+                              long long* stats, hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr);
 
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low = nullptr);
+                           hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr);
 
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,
