@@ -12,9 +12,13 @@ Per-frame fusion does not shard: with --gpus N every ra
 replica (its own map, its own copy of the stream), no data-path collective; value = frames of all ranks /
 max-over-ranks time ("weak" scaling).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_feature_integrate), timed with HIP
-events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle ("port") timed on
-the host cores on a bounded sample of the same frames (reported baseline, not the target).
+Prints ONE JSON line (rank 0).  `roofline` is for k_feature_flat, the HBM-bound kernel that moves the feature rows of
+the voxels a frame updates (the dominant kernel at the reference's 512x512x768 shape; at C=64 the frame is six
+latency-bound launches, all listed in `kernel_us_per_launch`), timed with HIP events on the launch stream inside the
+timed region; `cpu_baseline` is the CPU oracle ("port") timed on the host cores on a bounded sample of the same frames
+(reported baseline, not the target).  Extra legs in the same line: `reference_shape` (512x512x768, with and without the
+fused low-res feature path), `train` (policy training step/s, DDP over RCCL when launched with N > 1) and
+`backprojection` (GPU kernel + torch-CPU baseline).
 """
 import argparse
 import json
@@ -114,6 +118,12 @@ def cpu_baseline(cfg, mcfg, frames, channels, n_sample):
     }
 
 
+def flat_bytes_per_voxel(C: int) -> int:
+    """Algorithmic bytes k_feature_flat moves per updated voxel: the voxel's f16 channel row read and written (2 x 2C), its
+    four bilinear taps of the f16 feature image (4 x 2C) and its 20-byte survivor record."""
+    return 2 * 2 * C + 4 * 2 * C + 20
+
+
 def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
     """Short untimed-for-the-headline run at the shape the reference really uses: 512x512 images,
     fx = 586.4 px, 768 feature channels (403 MB f16 feature image per frame)."""
@@ -127,25 +137,29 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
     torch.cuda.synchronize(device)
     mapper.reset_stats(MAPPER_TO_ID.STATIC)
     mapper.profile_reset()
-    mapper.profile_enable(True, kernels=["feature"])
+    mapper.profile_enable(True, kernels=["feature", "feature_flat"])
     t0 = time.perf_counter()
     for i in range(steps):
         step(mapper, mcfg, frames[(warmup + i) % n_frames])
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     mapper.profile_enable(False)
-    ms, n = mapper.profile()["feature"]
+    ms, n = mapper.profile()["feature_flat"]
+    gate_ms, gate_n = mapper.profile()["feature"]
     st = mapper.stats(MAPPER_TO_ID.STATIC)
     fb = st["feature_blocks_updated"] / max(st["feature_frames"], 1)
     cb = st["color_blocks_updated"] / max(st["color_frames"], 1)
     vox = st["feature_voxels_updated"] / max(st["feature_frames"], 1)
-    nbytes = vox * (2 * (2 * C + 4) + 4 * 2 * C) + fb * 512 * (4 + 16 + 4)
+    nbytes = vox * flat_bytes_per_voxel(C)
     out = {"image": [cfg.height, cfg.width], "feature_channels": C, "frames_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
            "feature_blocks_per_frame": fb, "feature_voxels_updated_per_frame": vox}
     if n:
-        out["feature_kernel_us"] = ms / n * 1e3
-        out["feature_kernel_algorithmic_GBps"] = nbytes / (ms / n * 1e-3) / 1e9
-        out["feature_kernel_frac_of_hbm_peak"] = nbytes / (ms / n * 1e-3) / HBM_PEAK_BYTES_PER_S
+        out["k_feature_flat_us"] = ms / n * 1e3
+        out["k_feature_flat_algorithmic_bytes"] = nbytes
+        out["k_feature_flat_algorithmic_GBps"] = nbytes / (ms / n * 1e-3) / 1e9
+        out["k_feature_flat_frac_of_hbm_peak"] = nbytes / (ms / n * 1e-3) / HBM_PEAK_BYTES_PER_S
+    if gate_n:
+        out["k_app_frame_gating_us"] = gate_ms / gate_n * 1e3
 
     # The whole per-frame pipeline from the backbone's 16x16xC output (what the reference's FeatureExtractor hands over
     # before its own resize, feature_extraction.py:188-191): (a) up-sample to [512,512,768] f16 then integrate (two steps,
@@ -176,14 +190,14 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
     dt_up = timed(with_upsample)
     mapper.clear()
     mapper.profile_reset()
-    mapper.profile_enable(True, kernels=["feature"])
+    mapper.profile_enable(True, kernels=["feature_flat"])
     dt_low = timed(fused_lowres)
     mapper.profile_enable(False)
-    ms, n = mapper.profile()["feature"]
+    ms, n = mapper.profile()["feature_flat"]
     out["from_backbone_output"] = {
         "upsample_then_integrate_frames_per_s": 1.0 / dt_up, "upsample_then_integrate_ms": dt_up * 1e3,
         "fused_lowres_frames_per_s": 1.0 / dt_low, "fused_lowres_ms": dt_low * 1e3,
-        "fused_lowres_feature_kernel_us": (ms / n * 1e3) if n else None,
+        "fused_lowres_k_feature_flat_us": (ms / n * 1e3) if n else None,
         "upsampled_image_MB_avoided": cfg.height * cfg.width * C * 2 / 1e6}
     del mapper, frames
     torch.cuda.empty_cache()
@@ -313,7 +327,7 @@ def main():
     mapper.reset_stats(MAPPER_TO_ID.STATIC)
     mapper.profile_reset()
     if not args.no_profile:
-        mapper.profile_enable(True, kernels=["feature"])  # only the dominant kernel is bracketed in the timed region
+        mapper.profile_enable(True, kernels=["feature_flat"])  # only the roofline kernel is bracketed in the timed region
 
     if dist is not None:
         dist.barrier()
@@ -361,26 +375,21 @@ def main():
         n_feat_frames = max(stats["feature_frames"], 1)
         feat_blocks_per_frame = stats["feature_blocks_updated"] / n_feat_frames
         tsdf_blocks_per_frame = stats["tsdf_blocks_updated"] / max(stats["depth_frames"], 1)
-        # algorithmic bytes of one k_feature_integrate launch:
-        #   feature image f16 + mask u8, each pixel once; feature voxel (C x f16 + f32 weight) read + written per block
         col_blocks_per_frame = stats["color_blocks_updated"] / max(stats["color_frames"], 1)
         feat_voxels_per_frame = stats["feature_voxels_updated"] / n_feat_frames
         # (1) SURVEY.md section 8(d) model: the whole feature image once + every voxel of every candidate block
         #     read and written (plus the colour image / voxels: the two updates are one launch, k_app_integrate2)
         model_bytes = (cfg.height * cfg.width * (2 * C + 1) + feat_blocks_per_frame * 512 * 2 * (2 * C + 4)
                        + cfg.height * cfg.width * (3 + 1) + col_blocks_per_frame * 512 * 16)
-        # (2) algorithmic bytes with unit = a voxel the launch actually updates (device counter): the kernel gates
-        #     every candidate voxel first and only moves the survivors: voxel row + weight read and written
-        #     (2*(2C+4) B), its 4 bilinear taps (4 * 2C B), and the per-candidate-voxel gate inputs (weight 4 B,
-        #     2x2 synthetic-depth taps 16 B, 2x2 mask taps 4 B)
-        bytes_per_launch = (feat_voxels_per_frame * (2 * (2 * C + 4) + 4 * 2 * C)
-                            + feat_blocks_per_frame * 512 * (4 + 16 + 4))
-        feat_ms, feat_n = prof["feature"]
+        # (2) roofline kernel = k_feature_flat, the balanced feature-row update that carries the path's bulk data.  Unit of
+        #     work = a voxel the frame actually updates (device counter; the gating launch k_app_frame decides which).
+        bytes_per_launch = feat_voxels_per_frame * flat_bytes_per_voxel(C)
+        feat_ms, feat_n = prof["feature_flat"]
         roofline = None
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
             with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
-                pmc = json.load(f)["k_app_integrate2"]
+                pmc = json.load(f)["k_feature_flat"]
             traffic = (2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0  # FETCH_SIZE x2: gfx950 correction
         except Exception:
             traffic = None
@@ -389,7 +398,7 @@ def main():
             achieved = bytes_per_launch / avg_s
             roofline = {
                 "bound": "hbm",
-                "kernel": "k_app_integrate2 (feature + colour update, one launch)",
+                "kernel": "k_feature_flat (balanced feature-row update of the frame's surviving voxels)",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                 "unit": "GB/s",
@@ -397,11 +406,13 @@ def main():
                 "traffic": traffic,
                 "avg_launch_us": avg_s * 1e6,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "bytes_per_unit": flat_bytes_per_voxel(C),
                 "unit_of_work": "feature voxel updated (passed the occlusion/mask gate)",
                 "feature_voxels_updated_per_launch": feat_voxels_per_frame,
                 "feature_blocks_per_launch": feat_blocks_per_frame,
-                "survey_8d_model_bytes_per_launch": model_bytes,
-                "survey_8d_model_GBps": model_bytes / avg_s / 1e9,
+                "note": "at C=64 the frame is 6 latency-bound launches of 10-25 us (kernel_us_per_launch); this kernel is "
+                        "the HBM-bound one and dominates at the reference shape (reference_shape.k_feature_flat_*)",
+                "survey_8d_model_bytes_per_frame": model_bytes,
             }
         frame_bytes = cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + model_bytes
         cpu = None

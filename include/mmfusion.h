@@ -231,7 +231,8 @@ int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
 #define MMF_K_FEATURE 6
 #define MMF_K_DECAY 7
 #define MMF_K_MESH 8
-#define MMF_NUM_KERNEL_IDS 9
+#define MMF_K_FEATURE_FLAT 9 /* balanced phase 2 of the feature update (k_feature_flat) */
+#define MMF_NUM_KERNEL_IDS 10
 /* kernel_mask: bit k set = time kernel class k (0 = off, (1<<MMF_NUM_KERNEL_IDS)-1 = all). */
 int mmf_profile_enable(mmf_handle h, int kernel_mask);
 /* Sum of elapsed ms and number of timed launches of kernel class `kernel_id` (synchronises). */

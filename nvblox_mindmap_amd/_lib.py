@@ -18,6 +18,7 @@ MMF_LAYER_TSDF, MMF_LAYER_COLOR, MMF_LAYER_FEATURE = 0, 1, 2
 MMF_NUM_STATS = 9
 KERNEL_IDS = {
     "raycast": 0, "alloc": 1, "tsdf": 2, "candidates": 3, "sphere": 4, "color": 5, "feature": 6, "decay": 7, "mesh": 8,
+    "feature_flat": 9,
 }
 
 

@@ -816,6 +816,10 @@ static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat,
     launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc[2],
                              m->feat.d.cap, m->stats, s, low, &m->flat);
   }
+  {
+    ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
+    launch_feature_flat(m->feat.d, m->mc, cam, (const __half*)feat, low, m->flat, s);
+  }
   return check_launch();
 }
 
@@ -916,6 +920,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
       launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
                                m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
+      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s);
       return check_launch();
     }
     m->last_vg = vg;
@@ -1000,6 +1005,10 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
                             m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat);
     }
+    {
+      ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
+      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s);
+    }
     return check_launch();
   }
 
@@ -1036,6 +1045,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), sa));
     launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, fsynth, fWs, fHs, m->sc[2],
                              m->feat.d.cap, m->stats, sa, low, &m->flat);
+    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, sa);
   }
   HIP_TRY(record(4, sa));
 
@@ -1383,9 +1393,11 @@ int mmf_profile_reset(mmf_handle h) {
 }
 
 const char* mmf_kernel_name(int id) {
-  static const char* names[MMF_NUM_KERNEL_IDS] = {"k_raycast_mark",   "k_count_tiles+k_scan_tiles+k_emit", "k_tsdf_integrate",
-                                                  "k_app_candidates", "k_sphere_trace",                    "k_color_integrate",
-                                                  "k_feature_integrate", "k_decay(+compact)",              "k_mesh_count/emit"};
+  static const char* names[MMF_NUM_KERNEL_IDS] = {
+      "k_raycast_mark / k_front",  "k_alloc_jobs / k_count_tiles+k_scan_tiles+k_emit", "k_tsdf_integrate / k_tsdf_pass",
+      "k_app_candidates",          "k_sphere_trace / k_sphere_alloc",                  "k_color_integrate",
+      "k_feature_integrate / k_app_frame (gating)", "k_decay(+compact)",              "k_mesh_count/emit",
+      "k_feature_flat"};
   return (id >= 0 && id < MMF_NUM_KERNEL_IDS) ? names[id] : "?";
 }
 

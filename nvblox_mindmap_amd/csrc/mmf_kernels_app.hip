@@ -773,8 +773,15 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                      make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
 }
 
+static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
+                             const Scratch& sc, long long* stats, const LowRes* low, const FlatList* flat);
+
 // balanced phase 2 over the frame's survivor list (enqueued right behind the gating launch)
-static void launch_feature_flat(const AppArgs& Af, const MapConsts& mc, const FlatList& fl, bool low, hipStream_t s) {
+void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* lowres,
+                         const FlatList& fl, hipStream_t s) {
+  if (!fl.rec) return;
+  const bool low = lowres != nullptr;
+  const AppArgs Af = make_app_args(L, cam, Rigid{}, feat, nullptr, Scratch{}, nullptr, lowres, &fl);
   const int nch = mc.C >> 3;
   const int lpv = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);  // lanes per voxel row
   const int vpw = 256 / lpv;
@@ -797,7 +804,6 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
     hipLaunchKernelGGL(k_feature_integrate<true>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
   else
     hipLaunchKernelGGL(k_feature_integrate<false>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  if (flat && flat->rec) launch_feature_flat(A, mc, *flat, low != nullptr, s);
 }
 
 // colour + feature update of one frame (gating launch, then the balanced feature pass when a survivor list is given)
@@ -822,7 +828,6 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
     else
       hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
   }
-  if (flat && flat->rec) launch_feature_flat(Af, mc, *flat, low != nullptr, s);
 }
 
 }  // namespace mmf

@@ -72,6 +72,10 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
                            hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr);
 
+// balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
+void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,
+                         const FlatList& fl, hipStream_t s);
+
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,
                        hipStream_t s);

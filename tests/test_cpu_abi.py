@@ -36,7 +36,7 @@ def test_params_layout_and_defaults():
     assert L.mmf_abi_version() == 1
     p = _lib.default_params()
     assert p.truncation_distance_vox == 4.0 and p.max_weight == 5.0 and p.feature_channels == 768
-    assert L.mmf_kernel_name(6).decode() == "k_feature_integrate"
+    assert L.mmf_kernel_name(6).decode().startswith("k_feature_integrate") and L.mmf_kernel_name(9).decode() == "k_feature_flat"
 
 
 def test_mapper_params_flatten_like_the_reference_config():
