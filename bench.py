@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--no-ref-shape", action="store_true", help="skip the short run at the reference's real shape (512x512x768)")
     ap.add_argument("--no-train", action="store_true", help="skip the policy training-step measurement")
     ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--no-backproj", action="store_true", help="skip the back-projection leg (GPU kernel + torch-CPU baseline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -368,7 +369,7 @@ def main():
         if dist is not None:
             dist.barrier()
         train = run_training(device, world, steps=args.train_steps)
-    backproj = run_backprojection(device) if rank == 0 else None  # has CPU legs: after every GPU measurement
+    backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
         C = args.channels

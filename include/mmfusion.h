@@ -220,6 +220,10 @@ int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* indices_dev, 
 #define MMF_NUM_STATS 9
 int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out /* [MMF_NUM_STATS] */);
 int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
+/* Diagnostics: 100 MHz device timestamps taken by the TSDF allocation workgroup of the last fused frame (start, after the
+ * decay compaction, table loads consumed, scan done, inserts done, counters published).  enable != 0 switches the
+ * recording on for later frames (off otherwise); out6 receives the last recording (zeros if none).  Synchronises. */
+int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out6);
 
 /* Kernel timing with HIP events on the launch stream.  kernel ids: */
 #define MMF_K_RAYCAST 0

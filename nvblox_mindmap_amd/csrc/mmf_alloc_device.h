@@ -22,7 +22,6 @@ __device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
 // Deallocation of the blocks flagged by the decay pass: one 1024-thread workgroup compacts the live list in place (order
 // preserving), pushes the freed slots, tombstones their hash entries (amortised rebuild).  No-op when nothing was flagged.
 __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict__ kill, int* any_kill, int* lds, int* carry) {
-
   if (!*any_kill) return;
   const int n = L.ctr[0];
   if (threadIdx.x == 0) {
@@ -31,25 +30,48 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
   }
   __syncthreads();
   const int free0 = carry[1];
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    int slot = -1, k = 0;
-    if (i < n) {
-      slot = L.live[i];
-      k = kill[i];
-      kill[i] = 0;
+  // 4 consecutive entries per thread: a few thousand live blocks are one pass (the pass cost is the workgroup scan)
+  for (int base = 0; base < n; base += 4096) {
+    const int i0 = base + (int)threadIdx.x * 4;
+    int slot[4] = {-1, -1, -1, -1};
+    unsigned k4 = 0;
+    if (i0 + 3 < n) {
+      const int4 s4 = *reinterpret_cast<const int4*>(L.live + i0);
+      slot[0] = s4.x, slot[1] = s4.y, slot[2] = s4.z, slot[3] = s4.w;
+      k4 = *reinterpret_cast<const uint32_t*>(kill + i0);
+      *reinterpret_cast<uint32_t*>(kill + i0) = 0u;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i0 + q < n) {
+          slot[q] = L.live[i0 + q];
+          k4 |= (unsigned)(kill[i0 + q] ? 1u : 0u) << (8 * q);
+          kill[i0 + q] = 0;
+        }
     }
-    int keep = (i < n && !k) ? 1 : 0, dead = (i < n && k) ? 1 : 0;
+    int keep = 0, dead = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i0 + q >= n) continue;
+      if ((k4 >> (8 * q)) & 0xffu) dead++;
+      else keep++;
+    }
     int ea, eb, ta, tb;
     block_excl_scan2<16>(keep, dead, lds, ea, eb, ta, tb);
     const int c0 = carry[0], c1 = carry[1];
     __syncthreads();  // every read of live[base..] and carry happened before any write below
-    if (keep) L.live[c0 + ea] = slot;
-    if (dead) {
-      L.free_stack[c1 + eb] = slot;
-      hash_erase(L, L.slot_key[slot]);  // tombstone; dropped at the next rebuild
-      dense_set(L, L.slot_key[slot], 0);
-      L.slot_key[slot] = kEmptyKey;
+    int wk = c0 + ea, wd = c1 + eb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i0 + q >= n) continue;
+      if ((k4 >> (8 * q)) & 0xffu) {
+        L.free_stack[wd++] = slot[q];
+        hash_erase(L, L.slot_key[slot[q]]);  // tombstone; dropped at the next rebuild
+        dense_set(L, L.slot_key[slot[q]], 0);
+        L.slot_key[slot[q]] = kEmptyKey;
+      } else {
+        L.live[wk++] = slot[q];
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -89,10 +111,12 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
   const Scratch& sc = J.sc;
   const int stat_upd = J.stat_upd, stat_new = J.stat_new;
   int ncells = J.ncells;
+  if (J.timeline && threadIdx.x == 0) J.timeline[0] = wall_clock64();
   if (J.kill) {  // a decay pass ran in the previous launch: drop its dead blocks before allocating (slot reuse order is spec)
     live_compact_body(L, J.kill, J.any_kill, lds, carry);
     __syncthreads();
   }
+  if (J.timeline && threadIdx.x == 0) J.timeline[1] = wall_clock64();
   if (ks.mode == 1) {  // list cells: only the producer's live positions carry meaningful flags
     const int nl = *ks.n_live;
     ncells = ncells < nl ? ncells : nl;
@@ -180,8 +204,10 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
         }
       }
     }
+    if (J.timeline && threadIdx.x == 0) J.timeline[2] = wall_clock64();  // table loads consumed
     int ea, eb, ta, tb;
     block_excl_scan2<16>(nf, nn, lds, ea, eb, ta, tb);
+    if (J.timeline && threadIdx.x == 0) J.timeline[3] = wall_clock64();  // scan done
     const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
     if (f4) {
       int pos = carry[0] + ea, rnk = carry[1] + eb;
@@ -215,6 +241,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
     }
     __syncthreads();
   }
+  if (J.timeline && threadIdx.x == 0) J.timeline[4] = wall_clock64();  // inserts + candidate list written
   if (threadIdx.x == 0) {
     const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
     const int n_cand = carry[0], n_new = carry[1];
@@ -231,6 +258,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
       if (stat_upd >= 0) stats[stat_upd] += n_cand;
       if (stat_new >= 0) stats[stat_new] += granted;
     }
+    if (J.timeline) J.timeline[5] = wall_clock64();
   }
 }
 

@@ -65,6 +65,7 @@ struct Mapper {
   float synth_T[16]{}, synth_K[9]{};
   int synth_iw = 0, synth_ih = 0;
   long long tsdf_epoch = 0;
+  long long* timeline = nullptr;  // 8 device int64: timestamps of the last TSDF allocation job (mmf_get_alloc_timeline)
   FlatList flat;               // survivor list of a feature frame (balanced phase 2); rec == null: not in use
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
   // mesh
@@ -388,6 +389,7 @@ void destroy_mapper(Mapper* m) {
   }
   (void)hipFree(m->mask_tmp);
   (void)hipFree(m->masked_depth);
+  (void)hipFree(m->timeline);
   (void)hipFree(m->flat.rec);
   (void)hipFree(m->flat.w);
   (void)hipFree(m->flat.count);
@@ -957,6 +959,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       job.stat_upd = 1;
       job.stat_new = 2;
       job.stamp = stamp;
+      job.timeline = m->timeline;
       if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave before the allocation hands out slots
         job.kill = m->kill;
         job.any_kill = m->any_kill;
@@ -1003,7 +1006,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     {
       ProfScope ps(h, MMF_K_FEATURE, s);
       launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat);
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
     }
     {
       ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
@@ -1354,6 +1357,25 @@ int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
   out8[0] = m->frames[0];
   out8[3] = m->frames[1];
   out8[5] = m->frames[2];
+  return MMF_OK;
+}
+
+int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out6) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (out6) {
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (m->timeline) HIP_TRY(hipMemcpy(out6, m->timeline, sizeof(long long) * 6, hipMemcpyDeviceToHost));
+  }
+  if (enable && !m->timeline) {
+    HIP_TRY(hipMalloc(&m->timeline, sizeof(long long) * 8));
+    HIP_TRY(hipMemset(m->timeline, 0, sizeof(long long) * 8));
+  } else if (!enable && m->timeline) {
+    (void)hipFree(m->timeline);
+    m->timeline = nullptr;
+  }
   return MMF_OK;
 }
 

@@ -120,6 +120,7 @@ struct AllocJob {
   uint8_t* kill = nullptr; // != null: first apply the kill flags of a decay pass (live_compact_body)
   int* any_kill = nullptr;
   int* zero_me = nullptr;  // != null: an int this job resets (the frame's feature survivor counter)
+  long long* timeline = nullptr;  // != null: thread 0 stores wall_clock64() (100 MHz) at 6 points of the job (diagnostics)
 };
 
 __host__ __device__ inline u64 pack_key(int x, int y, int z) {

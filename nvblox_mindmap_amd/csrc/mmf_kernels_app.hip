@@ -810,11 +810,12 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low, const FlatList* flat) {
+                           hipStream_t s, const LowRes* low, const FlatList* flat, bool same_candidates) {
   const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
                 Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low, flat);
-  const bool same_cam = ccam.W == fcam.W && ccam.H == fcam.H && ccam.fx == fcam.fx && ccam.fy == fcam.fy && ccam.cx == fcam.cx &&
-                        ccam.cy == fcam.cy && csc.flags == fsc.flags;
+  // same_candidates: both allocation jobs compacted the same flag array, so candidate i is the same block in both lists
+  const bool same_cam = same_candidates && ccam.W == fcam.W && ccam.H == fcam.H && ccam.fx == fcam.fx && ccam.fy == fcam.fy &&
+                        ccam.cx == fcam.cx && ccam.cy == fcam.cy;
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
     if (low)

@@ -70,7 +70,7 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr);
+                           hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr, bool same_candidates = false);
 
 // balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,

@@ -1,0 +1,29 @@
+"""Prints the in-kernel timeline of the TSDF allocation workgroup (k_alloc_jobs) over a few fused frames."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+from nvblox_mindmap_amd import _lib  # noqa: E402
+from nvblox_mindmap_amd import synthetic as S  # noqa: E402
+from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper  # noqa: E402
+from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg  # noqa: E402
+
+dev = torch.device("cuda", 0)
+cfg = S.StreamConfig(hole_mode="patches")
+mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+frames = B.build_stream(cfg, 40, 64, dev)
+m = get_nvblox_mapper(mcfg, feature_channels=64)
+for i in range(20):
+    B.step(m, mcfg, frames[i])
+out = (C.c_int64 * 6)()
+_lib.check(_lib.lib().mmf_get_alloc_timeline(m._h, 0, 1, out))
+names = ["compaction", "table loads", "scan", "insert+emit", "publish"]
+for i in range(20, 32):
+    B.step(m, mcfg, frames[i])
+    _lib.check(_lib.lib().mmf_get_alloc_timeline(m._h, 0, 1, out))
+    t = list(out)
+    print("frame", i, " ".join(f"{n}={(t[k + 1] - t[k]) / 100.0:.1f}us" for k, n in enumerate(names)), f"total={(t[5] - t[0]) / 100.0:.1f}us")

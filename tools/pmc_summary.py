@@ -1,0 +1,46 @@
+"""Average PMC counter value per dispatch and kernel from rocprofv3 `--pmc X --output-format csv` runs.
+Usage: python tools/pmc_summary.py out.json <dir_or_csv> [<dir_or_csv> ...]
+Kernel names are shortened to the function name (no namespace, template arguments or parameters).  FETCH_SIZE / WRITE_SIZE
+are reported in KB as the counters deliver them (gfx950: double FETCH_SIZE before comparing with byte counts, see
+/opt/skills/guides/MI355X_MICROARCH.md)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)          # parameters
+    name = re.sub(r"<.*$", "", name)           # template arguments
+    name = name.replace("void ", "").strip()
+    return name.split("::")[-1].replace(".kd", "")
+
+
+def main(out, paths):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for p in paths:
+        files = [p] if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True)
+        for f in files:
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    k = short(row["Kernel_Name"])
+                    c = row["Counter_Name"]
+                    a = acc[k][c]
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
+    res = {}
+    for k, cs in sorted(acc.items()):
+        res[k] = {}
+        for c, (tot, n) in cs.items():
+            res[k][c + ("_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = tot / n
+            res[k]["dispatches"] = n
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    print(f"{len(res)} kernels -> {out}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2:])
