@@ -19,9 +19,15 @@ __device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
   return ks.mode == 0 ? grid_cell_key(ks, cell) : sc.cell_key[cell];
 }
 
-// Deallocation of the blocks flagged by the decay pass: one 1024-thread workgroup compacts the live list in place (order
-// preserving), pushes the freed slots, tombstones their hash entries (amortised rebuild).  No-op when nothing was flagged.
+// Deallocation of the blocks flagged by the decay pass: ONE workgroup of 64*NW threads compacts the live list in place
+// (order preserving), pushes the freed slots in live order and accounts the tombstones (amortised rebuild).  IPT
+// consecutive entries per thread, so a few thousand live blocks are one pass (the pass cost is the workgroup scan).
+// ERASE: also drop the dead blocks from the hash / dense table / slot keys here; false when the decay workgroup that
+// found the block already did (fused frame: decay_body<true>).  No-op when nothing was flagged.
+template <int NW, int IPT, bool ERASE>
 __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict__ kill, int* any_kill, int* lds, int* carry) {
+  static_assert(IPT % 4 == 0, "entries are fetched four at a time");
+  constexpr int NT = 64 * NW;
   if (!*any_kill) return;
   const int n = L.ctr[0];
   if (threadIdx.x == 0) {
@@ -30,45 +36,56 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
   }
   __syncthreads();
   const int free0 = carry[1];
-  // 4 consecutive entries per thread: a few thousand live blocks are one pass (the pass cost is the workgroup scan)
-  for (int base = 0; base < n; base += 4096) {
-    const int i0 = base + (int)threadIdx.x * 4;
-    int slot[4] = {-1, -1, -1, -1};
-    unsigned k4 = 0;
-    if (i0 + 3 < n) {
-      const int4 s4 = *reinterpret_cast<const int4*>(L.live + i0);
-      slot[0] = s4.x, slot[1] = s4.y, slot[2] = s4.z, slot[3] = s4.w;
-      k4 = *reinterpret_cast<const uint32_t*>(kill + i0);
-      *reinterpret_cast<uint32_t*>(kill + i0) = 0u;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (i0 + q < n) {
-          slot[q] = L.live[i0 + q];
-          k4 |= (unsigned)(kill[i0 + q] ? 1u : 0u) << (8 * q);
-          kill[i0 + q] = 0;
-        }
-    }
+  for (int base = 0; base < n; base += NT * IPT) {
+    const int i0 = base + (int)threadIdx.x * IPT;
+    int slot[IPT];
+    bool dead_q[IPT];
     int keep = 0, dead = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (i0 + q >= n) continue;
-      if ((k4 >> (8 * q)) & 0xffu) dead++;
-      else keep++;
+    for (int g = 0; g < IPT; g += 4) {
+      unsigned k4 = 0;
+      int s4[4] = {-1, -1, -1, -1};
+      if (i0 + g + 3 < n) {
+        const int4 v = *reinterpret_cast<const int4*>(L.live + i0 + g);
+        s4[0] = v.x, s4[1] = v.y, s4[2] = v.z, s4[3] = v.w;
+        k4 = *reinterpret_cast<const uint32_t*>(kill + i0 + g);
+        if (k4) *reinterpret_cast<uint32_t*>(kill + i0 + g) = 0u;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (i0 + g + q < n) {
+            s4[q] = L.live[i0 + g + q];
+            if (kill[i0 + g + q]) {
+              k4 |= 1u << (8 * q);
+              kill[i0 + g + q] = 0;
+            }
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        slot[g + q] = s4[q];
+        dead_q[g + q] = ((k4 >> (8 * q)) & 0xffu) != 0u;
+        if (i0 + g + q < n) {
+          if (dead_q[g + q]) dead++;
+          else keep++;
+        }
+      }
     }
     int ea, eb, ta, tb;
-    block_excl_scan2<16>(keep, dead, lds, ea, eb, ta, tb);
+    block_excl_scan2<NW>(keep, dead, lds, ea, eb, ta, tb);
     const int c0 = carry[0], c1 = carry[1];
     __syncthreads();  // every read of live[base..] and carry happened before any write below
     int wk = c0 + ea, wd = c1 + eb;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < IPT; ++q) {
       if (i0 + q >= n) continue;
-      if ((k4 >> (8 * q)) & 0xffu) {
+      if (dead_q[q]) {
         L.free_stack[wd++] = slot[q];
-        hash_erase(L, L.slot_key[slot[q]]);  // tombstone; dropped at the next rebuild
-        dense_set(L, L.slot_key[slot[q]], 0);
-        L.slot_key[slot[q]] = kEmptyKey;
+        if (ERASE) {
+          hash_erase(L, L.slot_key[slot[q]]);  // tombstone; dropped at the next rebuild
+          dense_set(L, L.slot_key[slot[q]], 0);
+          L.slot_key[slot[q]] = kEmptyKey;
+        }
       } else {
         L.live[wk++] = slot[q];
       }
@@ -86,9 +103,9 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
   const bool rebuild = (unsigned)n_tomb * 4u > L.hmask + 1u;
   __syncthreads();
   if (rebuild) {
-    for (unsigned h = threadIdx.x; h <= L.hmask; h += 1024) L.htab[h].key = kEmptyKey;
+    for (unsigned h = threadIdx.x; h <= L.hmask; h += NT) L.htab[h].key = kEmptyKey;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_live; i += 1024) {
+    for (int i = threadIdx.x; i < n_live; i += NT) {
       const int slot = L.live[i];
       hash_insert(L, L.slot_key[slot], slot);
     }
@@ -112,8 +129,9 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
   const int stat_upd = J.stat_upd, stat_new = J.stat_new;
   int ncells = J.ncells;
   if (J.timeline && threadIdx.x == 0) J.timeline[0] = wall_clock64();
-  if (J.kill) {  // a decay pass ran in the previous launch: drop its dead blocks before allocating (slot reuse order is spec)
-    live_compact_body(L, J.kill, J.any_kill, lds, carry);
+  if (J.kill) {  // a decay pass ran in the previous launch (and already erased its dead blocks from the index): compact
+                 // the live list / push the freed slots before allocating (slot reuse order is spec)
+    live_compact_body<16, 4, false>(L, J.kill, J.any_kill, lds, carry);
     __syncthreads();
   }
   if (J.timeline && threadIdx.x == 0) J.timeline[1] = wall_clock64();

@@ -110,7 +110,7 @@ struct ProfScope {
   hipStream_t s;
   ProfRec r{};
   bool on;
-  ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(((h_->prof >> id) & 1u) != 0) {
+  ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(id >= 0 && ((h_->prof >> id) & 1u) != 0) {
     if (!on) return;
     r.id = id;
     r.a = take();
@@ -132,6 +132,25 @@ struct ProfScope {
     (void)hipEventCreate(&e);
     return e;
   }
+};
+
+// Timing of ONE kernel with the events of an extension launch (hipExtLaunchKernelGGL): the launcher receives a() / b().
+struct ProfExt {
+  mmf_mapper_s* h;
+  ProfRec r{};
+  bool on;
+  ProfExt(mmf_mapper_s* h_, int id) : h(h_), on(((h_->prof >> id) & 1u) != 0) {
+    if (!on) return;
+    ProfScope tmp(h_, -1, nullptr);  // only for its event pool accessor
+    r.id = id;
+    r.a = tmp.take();
+    r.b = tmp.take();
+  }
+  ~ProfExt() {
+    if (on) h->prof_recs.push_back(r);
+  }
+  hipEvent_t a() const { return on ? r.a : nullptr; }
+  hipEvent_t b() const { return on ? r.b : nullptr; }
 };
 
 int prof_collect(mmf_mapper_s* h) {
@@ -819,8 +838,8 @@ static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat,
                              m->feat.d.cap, m->stats, s, low, &m->flat);
   }
   {
-    ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
-    launch_feature_flat(m->feat.d, m->mc, cam, (const __half*)feat, low, m->flat, s);
+    ProfExt pe(h, MMF_K_FEATURE_FLAT);
+    launch_feature_flat(m->feat.d, m->mc, cam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
   }
   return check_launch();
 }
@@ -960,7 +979,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       job.stat_new = 2;
       job.stamp = stamp;
       job.timeline = m->timeline;
-      if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave before the allocation hands out slots
+      if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands out slots
         job.kill = m->kill;
         job.any_kill = m->any_kill;
       }
@@ -1009,8 +1028,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                             m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
     }
     {
-      ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
-      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s);
+      ProfExt pe(h, MMF_K_FEATURE_FLAT);
+      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
     }
     return check_launch();
   }
@@ -1361,17 +1380,24 @@ int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
 }
 
 int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out6) {
+  // out6 is really out8: [6] latest end / [7] earliest start of the mask column workgroups sharing the launch
   Mapper* m;
   MMF_TRY(get_mapper(h, mapper_id, &m));
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   if (out6) {
-    for (int i = 0; i < 6; ++i) out6[i] = 0;
-    if (m->timeline) HIP_TRY(hipMemcpy(out6, m->timeline, sizeof(long long) * 6, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out6[i] = 0;
+    if (m->timeline) {
+      HIP_TRY(hipMemcpy(out6, m->timeline, sizeof(long long) * 8, hipMemcpyDeviceToHost));
+      const long long reset[2] = {0, 0x7fffffffffffffffll};
+      HIP_TRY(hipMemcpy(m->timeline + 6, reset, sizeof(reset), hipMemcpyHostToDevice));
+    }
   }
   if (enable && !m->timeline) {
     HIP_TRY(hipMalloc(&m->timeline, sizeof(long long) * 8));
     HIP_TRY(hipMemset(m->timeline, 0, sizeof(long long) * 8));
+    const long long big = 0x7fffffffffffffffll;
+    HIP_TRY(hipMemcpy(m->timeline + 7, &big, sizeof(big), hipMemcpyHostToDevice));
   } else if (!enable && m->timeline) {
     (void)hipFree(m->timeline);
     m->timeline = nullptr;

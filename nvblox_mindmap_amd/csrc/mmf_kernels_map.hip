@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void k_raycast_mark(RaycastJob R) {
 
 // Horizontal fusion: the raycast tiles and the row pass of the frame's mask job in ONE launch (independent work:
 // both only read the depth image / input mask).
+template <bool ERASE>
 __device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb);
 
 struct DecayJob {
@@ -186,8 +187,14 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     raycast_body<LDSFLAGS>(R, b, s_words);
   else if (b < n_ray_wgs + M.H)
     mask_rowbits_row(M, b - n_ray_wgs, s_in, s_d);
-  else  // a pending Mapper.decay(): touches only the TSDF pool, which neither other role reads
-    decay_body(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
+  else
+    // A pending Mapper.decay(): touches only the TSDF layer, which neither other role reads.  Each workgroup also drops
+    // the blocks it finds dead from the hash / dense table (in parallel, off the critical path); the order-preserving
+    // compaction of the live list is the first thing the allocation workgroup of the next launch does.
+    // (Tried: decay workgroups first + "last one compacts" inside this launch -- an agent-scope fence per workgroup is a
+    // full L2 write-back (339 us), atomics on one arrival counter serialise (69 us), and even with a two-level counter
+    // the launch grew by 9 us while the next one shrank by 2.)
+    decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,7 +354,12 @@ __global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, i
   if ((int)blockIdx.x < njobs) {
     alloc_job_body(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
   } else if ((int)blockIdx.x - njobs < mask_rows) {
+    const long long t0 = J0.timeline ? wall_clock64() : 0;
     mask_colemit_row(M, (int)blockIdx.x - njobs, s_bad);
+    if (J0.timeline && threadIdx.x == 0) {  // diagnostics: earliest start / latest end over the mask workgroups
+      atomicMin(reinterpret_cast<unsigned long long*>(J0.timeline + 7), (unsigned long long)t0);
+      atomicMax(reinterpret_cast<unsigned long long*>(J0.timeline + 6), (unsigned long long)wall_clock64());
+    }
   }
 }
 
@@ -527,6 +539,7 @@ __global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
 //    are flagged, then one workgroup compacts the live list in place (order preserving), pushes the
 //    freed slots and the hash is rebuilt from the survivors.
 // ------------------------------------------------------------------------------------------------
+template <bool ERASE>
 __device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb) {
   const int n = L.ctr[0];
   for (int i = bid; i < n; i += nb) {
@@ -543,18 +556,24 @@ __device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_
     if (threadIdx.x == 0 && !any_alive && mc.dealloc_decayed) {
       kill[i] = 1;
       *any_kill = 1;
+      if (ERASE) {  // the compaction (live_compact_body<.., false>) then only moves list entries
+        const u64 key = L.slot_key[slot];
+        hash_erase(L, key);
+        dense_set(L, key, 0);
+        L.slot_key[slot] = kEmptyKey;
+      }
     }
   }
 }
 
 __global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t* __restrict__ kill, int* any_kill) {
-  decay_body(L, mc, kill, any_kill, blockIdx.x, gridDim.x);
+  decay_body<false>(L, mc, kill, any_kill, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __restrict__ kill, int* any_kill) {
   __shared__ int lds[34];
   __shared__ int carry[2];
-  live_compact_body(L, kill, any_kill, lds, carry);
+  live_compact_body<16, 4, true>(L, kill, any_kill, lds, carry);
 }
 
 __global__ __launch_bounds__(256) void k_hash_clear_if(LayerDev L, const int* cond) {

@@ -74,7 +74,7 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
 
 // balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,
-                         const FlatList& fl, hipStream_t s);
+                         const FlatList& fl, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,
