@@ -100,7 +100,7 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
   const int n_live = carry[0];
   const int n_tomb = L.ctr[4] + (carry[1] - free0);
   // amortised rebuild: only when tombstones fill more than a quarter of the table
-  const bool rebuild = (unsigned)n_tomb * 4u > L.hmask + 1u;
+  const bool rebuild = !L.dense && (unsigned)n_tomb * 4u > L.hmask + 1u;
   __syncthreads();
   if (rebuild) {
     for (unsigned h = threadIdx.x; h <= L.hmask; h += NT) L.htab[h].key = kEmptyKey;

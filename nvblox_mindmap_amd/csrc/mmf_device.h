@@ -169,7 +169,9 @@ __device__ inline int hash_find(const LayerDev& L, u64 key) {
 }
 
 // Insert a key known to be absent. Distinct keys may race for a cell: CAS on the 64-bit key.
+// Layers with a dense block table (bounded workspace) do not keep the hash at all: the table is the index.
 __device__ inline void hash_insert(const LayerDev& L, u64 key, int slot) {
+  if (L.dense) return;
   unsigned h = hash_key(key) & L.hmask;
   for (unsigned probe = 0; probe <= L.hmask; ++probe) {
     u64 prev = atomicCAS(&L.htab[h].key, kEmptyKey, key);
@@ -183,6 +185,7 @@ __device__ inline void hash_insert(const LayerDev& L, u64 key, int slot) {
 
 // Mark the entry of `key` deleted (no-op if absent).
 __device__ inline void hash_erase(const LayerDev& L, u64 key) {
+  if (L.dense) return;
   unsigned h = hash_key(key) & L.hmask;
   for (unsigned probe = 0; probe <= L.hmask; ++probe) {
     const u64 k = L.htab[h].key;
@@ -197,10 +200,14 @@ __device__ inline void hash_erase(const LayerDev& L, u64 key) {
 
 // Pool slot of a block key (-1 if absent): dense table when the layer has one, hash otherwise.
 __device__ inline int layer_lookup(const LayerDev& L, u64 key) {
-  if (L.dense) {
+  if (L.dense) {  // blocks only ever exist inside the workspace bounds the table covers
     int x, y, z;
     unpack_key(key, x, y, z);
-    return (int)L.dense[dense_cell(L, x, y, z)] - 1;
+    const int dx = x - L.d_lo[0], dy = y - L.d_lo[1], dz = z - L.d_lo[2];
+    if (dx < 0 || (unsigned)dy >= (unsigned)L.d_ny || (unsigned)dz >= (unsigned)L.d_nz) return -1;
+    const int cell = (dx * L.d_ny + dy) * L.d_nz + dz;
+    if (cell >= L.d_ncells) return -1;
+    return (int)L.dense[cell] - 1;
   }
   return hash_find(L, key);
 }

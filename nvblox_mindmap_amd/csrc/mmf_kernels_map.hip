@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_query_tsdf(LayerDev L, MapConsts mc, co
   float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
   int lin;
   u64 key = voxel_at(mc, p, lin);
-  int slot = hash_find(L, key);
+  int slot = layer_lookup(L, key);
   float2 r = make_float2(0.0f, 0.0f);
   if (slot >= 0) r = reinterpret_cast<const float2*>(L.pool)[(size_t)slot * kVPB + lin];
   out[2 * i] = r.x;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_query_feature(LayerDev L, MapConsts mc,
   float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
   int lin;
   u64 key = voxel_at(mc, p, lin);
-  int slot = hash_find(L, key);
+  int slot = layer_lookup(L, key);
   const int C = mc.C;
   float* o = out + (size_t)i * (C + 1);
   if (slot < 0) {

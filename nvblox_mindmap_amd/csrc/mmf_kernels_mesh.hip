@@ -31,7 +31,7 @@ __device__ inline void load_lattice(const LayerDev& T, const MapConsts& mc, int 
   const int tid = threadIdx.x;
   if (tid < 8) {
     const int dx = tid >> 2, dy = (tid >> 1) & 1, dz = tid & 1;
-    m.nslot[tid] = tid == 0 ? slot : hash_find(T, pack_key(bx + dx, by + dy, bz + dz));
+    m.nslot[tid] = tid == 0 ? slot : layer_lookup(T, pack_key(bx + dx, by + dy, bz + dz));
   }
   __syncthreads();
   for (int q = tid; q < kLat; q += 256) {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_mesh_emit(LayerDev T, LayerDev F, MapCo
         const u64 key = voxel_at(mc, pos, lin);
         int fv = -1;
         if (F.pool) {
-          const int fs = hash_find(F, key);
+          const int fs = layer_lookup(F, key);
           if (fs >= 0 && F.poolw[(size_t)fs * kVPB + lin] > 0.0f) fv = fs * kVPB + lin;
         }
         s_vox[local] = fv;
