@@ -195,6 +195,31 @@ int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth_d
                                int Wf, const float* T_W_C_host16, const float* K_host9, float min_depth_m, int k_in, int k_depth,
                                int border_percent, uint8_t* depth_mask_out_dev, uint8_t* feature_mask_out_dev, void* stream);
 
+/* ---- frame descriptor form of mmf_integrate_frame / mmf_integrate_frame_lowres ---------------------------------- */
+/* One frame of nvblox_integrate (nvblox_mapping_helpers.py:79-159) for one mapper.  Same work and results as
+ * mmf_integrate_frame; in addition `invert_input_mask` makes the call use the input mask inverted (valid where the byte
+ * is 0), which is the reference's `static_mask = ~dynamic_mask` (nvblox_mapping_helpers.py:116-117) without a separate
+ * pass over the mask.  Pointers are device pointers except T_W_C / K (host).  Exactly one of features_f16 [Hf,Wf,C] and
+ * lowres_features [lowres_h, lowres_w, lowres_channels] f32 is non-NULL. */
+typedef struct mmf_frame {
+  int struct_size; /* sizeof(mmf_frame) */
+  const float* depth;
+  const uint8_t* rgb;
+  const void* features_f16;
+  const float* lowres_features;
+  int lowres_h, lowres_w, lowres_channels;
+  const uint8_t* input_mask;
+  int invert_input_mask;
+  int H, W, Hf, Wf, feature_channels;
+  const float* T_W_C; /* host, 16 floats row-major */
+  const float* K;     /* host, 9 floats row-major */
+  float min_depth_m;
+  int input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, border_percent;
+  uint8_t* depth_mask_out;   /* [H,W] */
+  uint8_t* feature_mask_out; /* [Hf,Wf] */
+} mmf_frame;
+int mmf_integrate_frame_desc(mmf_handle h, int mapper_id, const mmf_frame* frame, void* stream);
+
 /* ---- policy-side op ---------------------------------------------------- */
 /* dgl.geometry.farthest_point_sampler(x, npoints, start_idx) (diffuser_actor/encoder.py:366-370): farthest-point
  * sampling of x [B,N,C] f32 in C-dimensional feature space, squared L2, first index on ties.
@@ -240,6 +265,9 @@ int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out
 #define MMF_NUM_KERNEL_IDS 10
 /* kernel_mask: bit k set = time kernel class k (0 = off, (1<<MMF_NUM_KERNEL_IDS)-1 = all). */
 int mmf_profile_enable(mmf_handle h, int kernel_mask);
+/* Time only every `stride`-th launch of each enabled kernel class (default 1 = every launch): keeps the event overhead
+ * out of a throughput measurement while the timing is still taken live inside it. */
+int mmf_profile_set_stride(mmf_handle h, int stride);
 /* Sum of elapsed ms and number of timed launches of kernel class `kernel_id` (synchronises). */
 int mmf_profile_get(mmf_handle h, int kernel_id, double* total_ms, int64_t* launches);
 int mmf_profile_reset(mmf_handle h);

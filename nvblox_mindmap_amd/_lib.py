@@ -52,6 +52,28 @@ class MmfParams(C.Structure):
     ]
 
 
+class MmfFrame(C.Structure):
+    """``mmf_frame`` of include/mmfusion.h."""
+
+    _fields_ = [
+        ("struct_size", C.c_int),
+        ("depth", C.c_void_p),
+        ("rgb", C.c_void_p),
+        ("features_f16", C.c_void_p),
+        ("lowres_features", C.c_void_p),
+        ("lowres_h", C.c_int), ("lowres_w", C.c_int), ("lowres_channels", C.c_int),
+        ("input_mask", C.c_void_p),
+        ("invert_input_mask", C.c_int),
+        ("H", C.c_int), ("W", C.c_int), ("Hf", C.c_int), ("Wf", C.c_int), ("feature_channels", C.c_int),
+        ("T_W_C", C.c_void_p),
+        ("K", C.c_void_p),
+        ("min_depth_m", C.c_float),
+        ("input_mask_erosion_iterations", C.c_int), ("valid_depth_mask_erosion_iterations", C.c_int), ("border_percent", C.c_int),
+        ("depth_mask_out", C.c_void_p),
+        ("feature_mask_out", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes): every symbol include/mmfusion.h declares
 _VP, _I, _F = C.c_void_p, C.c_int, C.c_float
 _PI = C.POINTER(C.c_int)
@@ -71,6 +93,7 @@ SIGNATURES = {
     "mmf_add_feature_frame_lowres": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
     "mmf_integrate_frame_lowres": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _I, _I, _I, _I, _VP, _VP, _F, _I, _I, _I, _VP, _VP,
                                          _VP]),
+    "mmf_integrate_frame_desc": (_I, [_VP, _I, C.POINTER(MmfFrame), _VP]),
     "mmf_decay": (_I, [_VP, _I, _VP]),
     "mmf_clear": (_I, [_VP, _I, _VP]),
     "mmf_update_feature_mesh": (_I, [_VP, _I, _VP, _PI]),
@@ -97,6 +120,7 @@ SIGNATURES = {
     "mmf_reset_stats": (_I, [_VP, _I, _VP]),
     "mmf_get_alloc_timeline": (_I, [_VP, _I, _I, C.POINTER(C.c_int64)]),
     "mmf_profile_enable": (_I, [_VP, _I]),
+    "mmf_profile_set_stride": (_I, [_VP, _I]),
     "mmf_profile_get": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mmf_profile_reset": (_I, [_VP]),
     "mmf_kernel_name": (C.c_char_p, [_I]),

@@ -65,6 +65,8 @@ struct Mapper {
   float synth_T[16]{}, synth_K[9]{};
   int synth_iw = 0, synth_ih = 0;
   long long tsdf_epoch = 0;
+  uint8_t* inv_mask = nullptr;  // scratch for an inverted input mask (stand-alone kernel path only)
+  size_t inv_mask_cap = 0;
   long long* timeline = nullptr;  // 8 device int64: timestamps of the last TSDF allocation job (mmf_get_alloc_timeline)
   FlatList flat;               // survivor list of a feature frame (balanced phase 2); rec == null: not in use
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
@@ -99,6 +101,8 @@ struct mmf_mapper_s {
   unsigned prof = 0;  // bitmask of kernel ids to time
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
+  unsigned prof_stride = 1;   // time every prof_stride-th eligible launch of a kernel class (mmf_profile_set_stride)
+  unsigned prof_seen[MMF_NUM_KERNEL_IDS] = {0};
   double prof_ms[MMF_NUM_KERNEL_IDS] = {0};
   long long prof_n[MMF_NUM_KERNEL_IDS] = {0};
 };
@@ -111,6 +115,7 @@ struct ProfScope {
   ProfRec r{};
   bool on;
   ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(id >= 0 && ((h_->prof >> id) & 1u) != 0) {
+    if (on) on = (h->prof_seen[id]++ % h->prof_stride) == 0;
     if (!on) return;
     r.id = id;
     r.a = take();
@@ -140,6 +145,7 @@ struct ProfExt {
   ProfRec r{};
   bool on;
   ProfExt(mmf_mapper_s* h_, int id) : h(h_), on(((h_->prof >> id) & 1u) != 0) {
+    if (on) on = (h->prof_seen[id]++ % h->prof_stride) == 0;
     if (!on) return;
     ProfScope tmp(h_, -1, nullptr);  // only for its event pool accessor
     r.id = id;
@@ -408,6 +414,7 @@ void destroy_mapper(Mapper* m) {
   }
   (void)hipFree(m->mask_tmp);
   (void)hipFree(m->masked_depth);
+  (void)hipFree(m->inv_mask);
   (void)hipFree(m->timeline);
   (void)hipFree(m->flat.rec);
   (void)hipFree(m->flat.w);
@@ -862,7 +869,7 @@ int mmf_add_feature_frame_lowres(mmf_handle h, int mapper_id, const float* lowre
 static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,
                                 const LowRes* low, const uint8_t* input_mask, int H, int W, int Hf, int Wf, int C, const float* T16,
                                 const float* K9, float min_depth_m, int k_in, int k_depth, int border_percent,
-                                uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream) {
+                                uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream, bool invert_mask = false) {
   Mapper* m;
   MMF_TRY(get_mapper(h, mapper_id, &m));
   if (!depth || !rgb || (!feat && !low) || !input_mask || !T16 || !K9 || !depth_mask_out || !feature_mask_out || H <= 1 || W <= 1 ||
@@ -925,6 +932,18 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     const int ncells = vg.nx * vg.ny * vg.nz;
     const bool fusable = packed && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
     if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
+    if (fusable) M.invert = invert_mask ? 1 : 0;
+    if (!fusable && invert_mask) {  // stand-alone kernels take the mask as it is: invert it once into scratch
+      if (!m->inv_mask || m->inv_mask_cap < (size_t)H * W) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(m->inv_mask);
+        m->inv_mask = nullptr;
+        HIP_TRY(hipMalloc(&m->inv_mask, (size_t)H * W));
+        m->inv_mask_cap = (size_t)H * W;
+      }
+      launch_invert_mask(input_mask, m->inv_mask, (size_t)H * W, s);
+      input_mask = m->inv_mask;
+    }
     if (!fusable) {
       // odd shapes / very large grids: the plain sequence of stand-alone launches
       flush_decay(h, *m, s);
@@ -1035,6 +1054,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   }
 
   // fork: masks on side stream A while the TSDF chain runs on the caller's stream
+  if (invert_mask) return fail(MMF_ERR_INVALID_ARG, "invert_input_mask is not supported with MMF_SIDE_STREAMS=1");
   flush_decay(h, *m, s);
   HIP_TRY(record(0, s));
   HIP_TRY(wait(sa, 0));
@@ -1102,6 +1122,20 @@ int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth, 
   MMF_TRY(make_lowres(*m, lowres, lh, lw, Cin, Hf, Wf, lr));
   return integrate_frame_impl(h, mapper_id, depth, rgb, nullptr, &lr, input_mask, H, W, Hf, Wf, m->P.feature_channels, T16, K9,
                               min_depth_m, k_in, k_depth, border_percent, depth_mask_out, feature_mask_out, stream);
+}
+
+int mmf_integrate_frame_desc(mmf_handle h, int mapper_id, const mmf_frame* f, void* stream) {
+  if (!f || f->struct_size != (int)sizeof(mmf_frame)) return fail(MMF_ERR_INVALID_ARG, "mmf_frame: null or struct_size mismatch");
+  if ((f->features_f16 != nullptr) == (f->lowres_features != nullptr))
+    return fail(MMF_ERR_INVALID_ARG, "mmf_frame: give exactly one of features_f16 / lowres_features");
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  LowRes lr;
+  if (f->lowres_features) MMF_TRY(make_lowres(*m, f->lowres_features, f->lowres_h, f->lowres_w, f->lowres_channels, f->Hf, f->Wf, lr));
+  return integrate_frame_impl(h, mapper_id, f->depth, f->rgb, f->features_f16, f->lowres_features ? &lr : nullptr, f->input_mask, f->H,
+                              f->W, f->Hf, f->Wf, f->lowres_features ? m->P.feature_channels : f->feature_channels, f->T_W_C, f->K,
+                              f->min_depth_m, f->input_mask_erosion_iterations, f->valid_depth_mask_erosion_iterations,
+                              f->border_percent, f->depth_mask_out, f->feature_mask_out, stream, f->invert_input_mask != 0);
 }
 
 int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
@@ -1417,6 +1451,13 @@ int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream) {
 int mmf_profile_enable(mmf_handle h, int enable) {
   if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
   h->prof = (unsigned)enable;
+  return MMF_OK;
+}
+
+int mmf_profile_set_stride(mmf_handle h, int stride) {
+  if (!h || stride < 1) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_profile_set_stride");
+  h->prof_stride = (unsigned)stride;
+  for (int i = 0; i < MMF_NUM_KERNEL_IDS; ++i) h->prof_seen[i] = 0;
   return MMF_OK;
 }
 

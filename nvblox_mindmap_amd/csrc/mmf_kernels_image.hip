@@ -282,6 +282,7 @@ bool make_mask_job(const uint8_t* input_mask, const float* depth, int H, int W, 
   const int nw = (W + 63) / 64;
   if (!(nw <= kMaxMaskWords && (size_t)2 * H * nw * sizeof(u64) <= (size_t)H * W && ((uintptr_t)tmp % 8 == 0))) return false;
   J.mask = input_mask;
+  J.invert = 0;
   J.depth = depth;
   J.min_d = min_d;
   J.H = H;

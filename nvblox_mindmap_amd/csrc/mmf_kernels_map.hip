@@ -81,6 +81,7 @@ struct RaycastJob {
   Rigid T_L_C;
   const float* depth;
   const uint8_t* mask;
+  int mask_invert;  // != 0: a pixel is valid where the mask byte is 0
   float min_d;
   int sub, Wsub, Hsub;
   ViewGrid vg;
@@ -116,7 +117,7 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     const size_t pix = (size_t)r * cam.W + c;
     d = depth[pix];
     if (!(d > min_d)) active = false;  // min_d >= 0: "depth > 0" and the caller's "depth > min distance" mask in one test
-    if (active && mask && !mask[pix]) active = false;
+    if (active && mask && ((mask[pix] == 0) != (R.mask_invert != 0))) active = false;
   }
   if (active) {
     if (mc.max_dist > 0.0f && d > mc.max_dist) d = mc.max_dist;
@@ -598,6 +599,11 @@ __global__ void k_reset_layer(LayerDev L) {
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
 
+__global__ __launch_bounds__(256) void k_invert_mask(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[i] == 0 ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 5. Views (allocation order) and point queries.
 // ------------------------------------------------------------------------------------------------
@@ -693,6 +699,7 @@ static RaycastJob make_raycast_job(const MapConsts& mc, const Cam& cam, const Ri
   R.T_L_C = T_L_C;
   R.depth = depth;
   R.mask = mask;
+  R.mask_invert = 0;
   R.min_d = min_d;
   R.sub = sub;
   R.Wsub = (cam.W + sub - 1) / sub;
@@ -722,6 +729,7 @@ void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const
                   int* any_kill, hipStream_t s) {
   int n_wgs;
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
+  R.mask_invert = M.invert;
   const int ncells = vg.nx * vg.ny * vg.nz;
   DecayJob D{};
   if (decay_layer) {
@@ -797,6 +805,10 @@ void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& ca
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s) {
   hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
                      mask, min_d, sc);
+}
+
+void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_invert_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,

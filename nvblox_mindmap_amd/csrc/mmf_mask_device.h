@@ -17,6 +17,7 @@ constexpr int kMaxMaskWords = 64;  // rows up to 4096 pixels
 
 struct MaskJob {
   const uint8_t* mask;     // [H,W] input mask (0/1 bytes)
+  int invert;              // != 0: the mask is used inverted (valid where the byte is 0): static = ~dynamic without a pass
   const float* depth;      // [H,W]
   float min_d;
   int H, W, nw, k0, k1;    // nw = ceil(W/64); k0 / k1 = erosion radius of the input / valid-depth mask
@@ -41,7 +42,7 @@ __device__ inline void mask_rowbits_row(const MaskJob& J, int y, u64* s_in, u64*
     bool bad_in = false, bad_d = false;
     if (x < J.W) {
       const size_t i = (size_t)y * J.W + x;
-      bad_in = J.mask ? J.mask[i] == 0 : false;
+      bad_in = J.mask ? ((J.mask[i] == 0) != (J.invert != 0)) : false;
       bad_d = J.depth ? !(J.depth[i] > J.min_d) : false;
       if (J.depth_mask_out) J.depth_mask_out[i] = (!bad_in && !bad_d) ? 1 : 0;
       if (J.masked_depth_out) J.masked_depth_out[i] = (!bad_in && !bad_d) ? J.depth[i] : 0.0f;

@@ -19,33 +19,40 @@ from ..nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
 
 
 class _IntegrationImages(dict):
-    """The images dictionary integrate_frame returns (:263-271).  ``rgb_frame`` (CHW float in [0,1], only
-    consumed by the visualiser) is computed on first access instead of on every frame."""
+    """The images dictionary integrate_frame returns (:263-271).  Entries only the visualiser consumes are computed on
+    first access instead of on every frame: ``rgb_frame`` (CHW float in [0,1]) and, when the native call was given the
+    dynamic mask to use inverted, ``input_mask`` (= ~dynamic_mask)."""
 
-    def __init__(self, items, rgb):
+    def __init__(self, items, rgb, lazy=None):
         super().__init__(items)
-        self._rgb = rgb
+        self._lazy = {"rgb_frame": lambda: rgb.permute(2, 0, 1) / 255.0}
+        if lazy:
+            self._lazy.update(lazy)
 
     def __missing__(self, key):
-        if key == "rgb_frame":
-            value = self._rgb.permute(2, 0, 1) / 255.0
+        if key in self._lazy:
+            value = self._lazy[key]()
             self[key] = value
             return value
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key == "rgb_frame" or super().__contains__(key)
+        return key in self._lazy or super().__contains__(key)
+
+    def _materialise(self):
+        for k in self._lazy:
+            self[k]
 
     def keys(self):
-        self["rgb_frame"]
+        self._materialise()
         return super().keys()
 
     def items(self):
-        self["rgb_frame"]
+        self._materialise()
         return super().items()
 
     def values(self):
-        self["rgb_frame"]
+        self._materialise()
         return super().values()
 
 
@@ -84,8 +91,11 @@ def get_nvblox_mapper(mapper_config: NvbloxMappingCfg, feature_channels: Optiona
 def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, depth_frame: torch.Tensor,
                     feature_frame: torch.Tensor, intrinsics: torch.Tensor, camera_pose: torch.Tensor, rgb: torch.Tensor,
                     input_mask: torch.Tensor, input_mask_erosion_iterations: int,
-                    valid_depth_mask_erosion_iterations: int, mapper_id: int) -> Dict[str, torch.Tensor]:
-    """Depth + colour + feature integration of one frame into `mapper_id` (:162-273)."""
+                    valid_depth_mask_erosion_iterations: int, mapper_id: int,
+                    invert_input_mask: bool = False) -> Dict[str, torch.Tensor]:
+    """Depth + colour + feature integration of one frame into `mapper_id` (:162-273).
+    Extension: ``invert_input_mask=True`` integrates with ``~input_mask`` (how nvblox_integrate derives the static mask
+    from the dynamic one, :116-117); the native call reads the mask inverted, no inverted copy is made."""
     assert input_mask.dtype == torch.bool
     cfg = nvblox_mapping_config
     H, W = depth_frame.shape
@@ -96,16 +106,23 @@ def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, dep
         # the reference's only configuration (512 -> 512): the whole function body is one native call
         depth_mask_u8, feature_mask = mapper.integrate_frame(
             depth_frame, rgb, feat16, input_mask, camera_pose, intrinsics, cfg.min_integration_distance_m,
-            input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, cfg.feature_mask_border_percent, mapper_id)
+            input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, cfg.feature_mask_border_percent, mapper_id,
+            invert_input_mask=invert_input_mask)
         depth_mask = depth_mask_u8.view(torch.bool)
-        return _IntegrationImages({
+        items = {
             "depth_frame": depth_frame,
             "depth_mask": depth_mask,
             "rgb_mask": depth_mask,
             "feature_frame": feature_frame,
             "feature_mask": feature_mask,
-            "input_mask": input_mask,
-        }, rgb)
+        }
+        if invert_input_mask:
+            return _IntegrationImages(items, rgb, {"input_mask": lambda: ~input_mask})
+        items["input_mask"] = input_mask
+        return _IntegrationImages(items, rgb)
+
+    if invert_input_mask:
+        input_mask = ~input_mask
 
     # depth_mask = input_mask & (depth > min_integration_distance)  (:201-204) and
     # feature_mask = border & nearest_upsample(erode(input_mask, k1) & erode(depth > min_d, k2))  (:222-253):
@@ -143,15 +160,17 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
     """Extract features and integrate the frame into the STATIC (and optionally DYNAMIC) mapper (:79-159)."""
     assert dynamic_mask.dtype == torch.bool
     cfg = nvblox_mapping_config
-    static_mask = ~dynamic_mask if cfg.use_dynamic_mask else torch.ones_like(dynamic_mask).to(torch.bool)
     with Timer("nvblox_mapper/compute_features"):
         feature_frame = feature_extractor.compute(rgb=rgb.unsqueeze(0)).squeeze(0)
     out = {}
+    # static_mask = ~dynamic_mask (:116-117): the native call reads the dynamic mask inverted instead
+    use_dyn = bool(cfg.use_dynamic_mask)
     out[MAPPER_TO_ID.STATIC.name] = integrate_frame(
         mapper=mapper, nvblox_mapping_config=cfg, depth_frame=depth_frame, feature_frame=feature_frame, intrinsics=intrinsics,
-        camera_pose=camera_pose, rgb=rgb, input_mask=static_mask,
+        camera_pose=camera_pose, rgb=rgb, input_mask=dynamic_mask if use_dyn else torch.ones_like(dynamic_mask),
         input_mask_erosion_iterations=cfg.static_mask_erosion_iterations,
-        valid_depth_mask_erosion_iterations=cfg.valid_depth_mask_erosion_iterations, mapper_id=MAPPER_TO_ID.STATIC)
+        valid_depth_mask_erosion_iterations=cfg.valid_depth_mask_erosion_iterations, mapper_id=MAPPER_TO_ID.STATIC,
+        invert_input_mask=use_dyn)
     if include_dynamic:
         out[MAPPER_TO_ID.DYNAMIC.name] = integrate_frame(
             mapper=mapper, nvblox_mapping_config=cfg, depth_frame=depth_frame, feature_frame=feature_frame, intrinsics=intrinsics,

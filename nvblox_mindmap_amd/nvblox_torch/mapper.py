@@ -299,59 +299,70 @@ class Mapper:
                                                            T.ctypes.data, K.ctypes.data, self._stream()),
                    "mmf_add_feature_frame_lowres")
 
-    def integrate_frame_lowres(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, lowres_features: torch.Tensor,
-                               input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float,
-                               input_mask_erosion_iterations: int, valid_depth_mask_erosion_iterations: int,
-                               border_percent: int, mapper_id: int = 0):
-        """``integrate_frame`` with the low-res feature source of ``add_feature_frame_lowres`` (virtual feature image at
-        the depth resolution).  Returns (depth_mask uint8 [H,W], feature_mask uint8 [H,W])."""
+    def _integrate_frame_desc(self, depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
+                              min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, border_percent,
+                              mapper_id, invert_input_mask):
         mapper_id = self._check_id(mapper_id)
         depth = _check_dev(depth_frame, "depth_frame", torch.float32, 2)
         rgb = _check_dev(color_frame, "color_frame", torch.uint8, 3)
-        low = _check_dev(lowres_features, "lowres_features", torch.float32, 3)
         H, W = depth.shape
-        lh, lw, cin = low.shape
         if tuple(rgb.shape) != (H, W, 3):
             raise ValueError("color_frame must be [H,W,3] with the depth frame's H,W")
-        mask = _mask_u8(input_mask, (H, W))
-        T = _host_f32(t_w_c, (4, 4))
-        K = _host_f32(intrinsics, (3, 3))
-        dm = torch.empty((H, W), dtype=torch.uint8, device=self.device)
-        fm = torch.empty((H, W), dtype=torch.uint8, device=self.device)
-        _lib.check(_lib.lib().mmf_integrate_frame_lowres(
-            self._h, mapper_id, _lib.dptr(depth), _lib.dptr(rgb), _lib.dptr(low), lh, lw, cin, _lib.dptr(mask), H, W, H, W,
-            T.ctypes.data, K.ctypes.data, float(min_depth_m), int(input_mask_erosion_iterations),
-            int(valid_depth_mask_erosion_iterations), int(border_percent), _lib.dptr(dm), _lib.dptr(fm), self._stream()),
-            "mmf_integrate_frame_lowres")
-        return dm, fm
-
-    def integrate_frame(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor,
-                        input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float, input_mask_erosion_iterations: int,
-                        valid_depth_mask_erosion_iterations: int, border_percent: int, mapper_id: int = 0):
-        """Extension: the reference's ``integrate_frame`` (mapping/helpers/nvblox_mapping_helpers.py:162-273) as one
-        native call -- mask algebra + add_depth_frame + add_color_frame + add_feature_frame with identical results,
-        independent kernel chains overlapped on internal streams.  Needs the feature image at the depth resolution.
-        Returns (depth_mask uint8 [H,W], feature_mask uint8 [Hf,Wf])."""
-        mapper_id = self._check_id(mapper_id)
-        depth = _check_dev(depth_frame, "depth_frame", torch.float32, 2)
-        rgb = _check_dev(color_frame, "color_frame", torch.uint8, 3)
-        feat = _check_dev(feature_frame, "feature_frame", torch.float16, 3)
-        H, W = depth.shape
-        Hf, Wf, ch = feat.shape
-        if tuple(rgb.shape) != (H, W, 3):
-            raise ValueError("color_frame must be [H,W,3] with the depth frame's H,W")
-        if ch != self.feature_channels:
-            raise ValueError(f"feature_frame has {ch} channels but the mapper stores {self.feature_channels}")
+        f = _lib.MmfFrame()
+        f.struct_size = C.sizeof(_lib.MmfFrame)
+        if lowres_features is not None:
+            low = _check_dev(lowres_features, "lowres_features", torch.float32, 3)
+            f.lowres_features = low.data_ptr()
+            f.lowres_h, f.lowres_w, f.lowres_channels = low.shape
+            Hf, Wf, ch = H, W, self.feature_channels
+            keep = low
+        else:
+            feat = _check_dev(feature_frame, "feature_frame", torch.float16, 3)
+            Hf, Wf, ch = feat.shape
+            if ch != self.feature_channels:
+                raise ValueError(f"feature_frame has {ch} channels but the mapper stores {self.feature_channels}")
+            f.features_f16 = feat.data_ptr()
+            keep = feat
         mask = _mask_u8(input_mask, (H, W))
         T = _host_f32(t_w_c, (4, 4))
         K = _host_f32(intrinsics, (3, 3))
         dm = torch.empty((H, W), dtype=torch.uint8, device=self.device)
         fm = torch.empty((Hf, Wf), dtype=torch.uint8, device=self.device)
-        _lib.check(_lib.lib().mmf_integrate_frame(
-            self._h, mapper_id, _lib.dptr(depth), _lib.dptr(rgb), _lib.dptr(feat), _lib.dptr(mask), H, W, Hf, Wf, ch, T.ctypes.data,
-            K.ctypes.data, float(min_depth_m), int(input_mask_erosion_iterations), int(valid_depth_mask_erosion_iterations),
-            int(border_percent), _lib.dptr(dm), _lib.dptr(fm), self._stream()), "mmf_integrate_frame")
+        f.depth, f.rgb, f.input_mask = depth.data_ptr(), rgb.data_ptr(), mask.data_ptr()
+        f.invert_input_mask = 1 if invert_input_mask else 0
+        f.H, f.W, f.Hf, f.Wf, f.feature_channels = H, W, Hf, Wf, ch
+        f.T_W_C, f.K = T.ctypes.data, K.ctypes.data
+        f.min_depth_m = float(min_depth_m)
+        f.input_mask_erosion_iterations = int(input_mask_erosion_iterations)
+        f.valid_depth_mask_erosion_iterations = int(valid_depth_mask_erosion_iterations)
+        f.border_percent = int(border_percent)
+        f.depth_mask_out, f.feature_mask_out = dm.data_ptr(), fm.data_ptr()
+        _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
+        del keep
         return dm, fm
+
+    def integrate_frame_lowres(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, lowres_features: torch.Tensor,
+                               input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float,
+                               input_mask_erosion_iterations: int, valid_depth_mask_erosion_iterations: int,
+                               border_percent: int, mapper_id: int = 0, invert_input_mask: bool = False):
+        """``integrate_frame`` with the low-res feature source of ``add_feature_frame_lowres`` (virtual feature image at
+        the depth resolution).  Returns (depth_mask uint8 [H,W], feature_mask uint8 [H,W])."""
+        return self._integrate_frame_desc(depth_frame, color_frame, None, lowres_features, input_mask, t_w_c, intrinsics,
+                                          min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
+                                          border_percent, mapper_id, invert_input_mask)
+
+    def integrate_frame(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor,
+                        input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float, input_mask_erosion_iterations: int,
+                        valid_depth_mask_erosion_iterations: int, border_percent: int, mapper_id: int = 0,
+                        invert_input_mask: bool = False):
+        """Extension: the reference's ``integrate_frame`` (mapping/helpers/nvblox_mapping_helpers.py:162-273) as one
+        native call -- mask algebra + add_depth_frame + add_color_frame + add_feature_frame with identical results in
+        six fused launches (a preceding ``decay()`` is folded into the first two).  Needs the feature image at the depth
+        resolution.  ``invert_input_mask``: use ``~input_mask`` (the reference's static mask from the dynamic mask,
+        :116-117) without materialising it.  Returns (depth_mask uint8 [H,W], feature_mask uint8 [Hf,Wf])."""
+        return self._integrate_frame_desc(depth_frame, color_frame, feature_frame, None, input_mask, t_w_c, intrinsics,
+                                          min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
+                                          border_percent, mapper_id, invert_input_mask)
 
     def decay(self, mapper_id: int = -1) -> None:
         _lib.check(_lib.lib().mmf_decay(self._h, int(mapper_id), self._stream()), "mmf_decay")
@@ -444,8 +455,10 @@ class Mapper:
     def reset_stats(self, mapper_id: int = 0) -> None:
         _lib.check(_lib.lib().mmf_reset_stats(self._h, mapper_id, self._stream()), "mmf_reset_stats")
 
-    def profile_enable(self, on: bool = True, kernels=None) -> None:
-        """Time kernel classes with HIP events on the launch stream (`kernels`: names of _lib.KERNEL_IDS, default all)."""
+    def profile_enable(self, on: bool = True, kernels=None, stride: int = 1) -> None:
+        """Time kernel classes with HIP events on the launch stream (`kernels`: names of _lib.KERNEL_IDS, default all);
+        `stride` = time every stride-th launch only."""
+        _lib.check(_lib.lib().mmf_profile_set_stride(self._h, int(stride)), "mmf_profile_set_stride")
         mask = 0
         if on:
             for k in (kernels if kernels is not None else _lib.KERNEL_IDS):

@@ -381,3 +381,50 @@ def test_integrate_frame_lowres_matches_integrate_frame():
     with pytest.raises(RuntimeError):  # Cin not a multiple of 8: the fused path refuses, loudly
         b.add_feature_frame_lowres(dev(_lowres_map(0, 12)), (cfg.height, cfg.width), torch.from_numpy(f["T_W_C"]),
                                    torch.from_numpy(f["K"]), None, 0)
+
+
+def test_inverted_input_mask_equals_materialised_inverse():
+    """integrate_frame(dynamic_mask, invert_input_mask=True) == integrate_frame(~dynamic_mask): the reference's
+    static_mask = ~dynamic_mask (nvblox_mapping_helpers.py:116-117) read inverted by the native call; both the fused
+    path (640x480) and nvblox_integrate on top of it."""
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper, integrate_frame, nvblox_integrate
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
+
+    cfg = S.StreamConfig(hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    a, b, c = (get_nvblox_mapper(mcfg, feature_channels=16) for _ in range(3))
+
+    class Extractor:  # stands in for FeatureExtractor.compute (the DNN is out of scope): returns the frame's feature image
+        def __init__(self):
+            self.next = None
+
+        def compute(self, rgb):
+            return self.next.unsqueeze(0)
+
+    ex = Extractor()
+    for k, i in enumerate([0, 8]):
+        f = S.frame(cfg, i, 16)
+        dyn = np.zeros(f["depth"].shape, dtype=bool)
+        dyn[100 + 5 * k: 220, 200:330] = True
+        kw = dict(nvblox_mapping_config=mcfg, depth_frame=dev(f["depth"]), feature_frame=dev(f["features"]),
+                  intrinsics=torch.from_numpy(f["K"]), camera_pose=torch.from_numpy(f["T_W_C"]), rgb=dev(f["rgb"]),
+                  input_mask_erosion_iterations=3, valid_depth_mask_erosion_iterations=4, mapper_id=MAPPER_TO_ID.STATIC)
+        for m in (a, b, c):
+            m.decay()
+        ia = integrate_frame(mapper=a, input_mask=dev(~dyn), **kw)
+        ib = integrate_frame(mapper=b, input_mask=dev(dyn), invert_input_mask=True, **kw)
+        assert torch.equal(ia["depth_mask"], ib["depth_mask"]) and torch.equal(ia["feature_mask"], ib["feature_mask"])
+        assert torch.equal(ia["input_mask"], ib["input_mask"]) and set(ia.keys()) == set(ib.keys())
+        ex.next = dev(f["features"])
+        mcfg_c = NvbloxMappingCfg("DRILL_IN_BOX")
+        mcfg_c.static_mask_erosion_iterations, mcfg_c.valid_depth_mask_erosion_iterations = 3, 4
+        out = nvblox_integrate(c, mcfg_c, ex, dev(f["depth"]), torch.from_numpy(f["K"]), torch.from_numpy(f["T_W_C"]), dev(f["rgb"]),
+                               dev(dyn), include_dynamic=False)
+        assert torch.equal(out["STATIC"]["depth_mask"], ia["depth_mask"])
+    ref = [t.clone() for t in a.feature_layer_view(0).get_all_blocks_split()]
+    for m in (b, c):
+        got = m.feature_layer_view(0).get_all_blocks_split()
+        assert torch.equal(got[2], ref[2]) and torch.equal(got[1], ref[1]) and torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16))
+        ta, tb = a.tsdf_layer_view(0).get_all_blocks(), m.tsdf_layer_view(0).get_all_blocks()
+        assert torch.equal(ta[0], tb[0]) and torch.equal(ta[1], tb[1])
+    assert int((ref[1] > 0).sum()) > 5000
