@@ -195,6 +195,14 @@ int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth_d
                                int Wf, const float* T_W_C_host16, const float* K_host9, float min_depth_m, int k_in, int k_depth,
                                int border_percent, uint8_t* depth_mask_out_dev, uint8_t* feature_mask_out_dev, void* stream);
 
+/* Mapper.load_from_file (nvblox_to_disk_helpers.py:88-93 saves with save_map; paper/teaser/convert_maps_usd.py loads):
+ * replace the content of one layer by n blocks in the order given (= allocation order of the saved map, what
+ * mmf_get_block_indices / mmf_get_*_blocks export): block i takes live position i.  payload / weights as exported:
+ * TSDF f32 [n,512,2] (weights NULL); COLOR u8 rgb [n,512,3] + f32 w [n,512]; FEATURE f16 [n,512,C] + f32 w [n,512].
+ * Indices outside the mapper's workspace bounds are an error.  Synchronises. */
+int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx_dev, const void* payload_dev,
+                      const float* weights_dev, int n, void* stream);
+
 /* ---- frame descriptor form of mmf_integrate_frame / mmf_integrate_frame_lowres ---------------------------------- */
 /* One frame of nvblox_integrate (nvblox_mapping_helpers.py:79-159) for one mapper.  Same work and results as
  * mmf_integrate_frame; in addition `invert_input_mask` makes the call use the input mask inverted (valid where the byte

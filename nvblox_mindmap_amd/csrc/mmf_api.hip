@@ -1274,6 +1274,47 @@ int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb, float* weigh
   return check_launch();
 }
 
+int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx, const void* payload, const float* weights, int n,
+                      void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (n < 0 || (n > 0 && (!idx || !payload))) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_import_blocks");
+  if (layer < MMF_LAYER_TSDF || layer > MMF_LAYER_FEATURE) return fail(MMF_ERR_INVALID_ARG, "bad layer id");
+  if (layer != MMF_LAYER_TSDF && n > 0 && !weights) return fail(MMF_ERR_INVALID_ARG, "appearance layers need the weight plane");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (layer == MMF_LAYER_COLOR) MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
+  if (layer == MMF_LAYER_FEATURE)
+    MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)m->P.feature_channels, true));
+  Layer& L = layer == MMF_LAYER_TSDF ? m->tsdf : layer == MMF_LAYER_COLOR ? m->color : m->feat;
+  if (n > L.d.cap)
+    return fail(MMF_ERR_POOL_EXHAUSTED, "saved layer has " + std::to_string(n) + " blocks, the pool holds " + std::to_string(L.d.cap));
+  if (layer == MMF_LAYER_TSDF) m->pending_decay = false;  // the content it would have decayed is replaced
+  launch_layer_reset(L.d, s);
+  launch_import_index(L.d, idx, n, s);
+  if (n > 0) {
+    if (layer == MMF_LAYER_COLOR) {
+      launch_import_color(L.d, (const uint8_t*)payload, weights, n, s);
+    } else {
+      HIP_TRY(hipMemcpyAsync(L.d.pool, payload, L.block_bytes * (size_t)n, hipMemcpyDeviceToDevice, s));
+      if (layer == MMF_LAYER_FEATURE)
+        HIP_TRY(hipMemcpyAsync(L.d.poolw, weights, sizeof(float) * kVPB * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
+    if (layer == MMF_LAYER_TSDF) launch_block_free_all(L.d, m->mc, n, s);
+  }
+  if (layer == MMF_LAYER_TSDF) {
+    m->touched = m->touched || n > 0;
+    m->tsdf_epoch++;
+    m->mesh_epoch = -1;
+  }
+  // out-of-range indices are flagged on the device; report them now (loading is not a hot path)
+  HIP_TRY(hipStreamSynchronize(s));
+  int err = 0;
+  HIP_TRY(hipMemcpy(&err, L.d.ctr + 3, sizeof(int), hipMemcpyDeviceToHost));
+  if (err & 2) return fail(MMF_ERR_INVALID_ARG, "saved block indices lie outside this mapper's workspace bounds / key range");
+  return check_launch();
+}
+
 int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* pts, int n, float* out, void* stream) {
   Mapper* m;
   MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));

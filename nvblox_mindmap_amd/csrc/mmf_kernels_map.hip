@@ -807,6 +807,71 @@ void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& ca
                      mask, min_d, sc);
 }
 
+// ---- import of a saved layer (Mapper.load_from_file): block i of the file takes pool slot i, live position i -----------
+__global__ __launch_bounds__(256) void k_import_index(LayerDev L, const int32_t* __restrict__ idx, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    L.ctr[0] = n;
+    L.ctr[1] = 0;
+    L.ctr[2] = n;
+    L.ctr[4] = 0;
+    if (L.hint_live) *L.hint_live = n;
+  }
+  if (i >= n) return;
+  const int x = idx[3 * i], y = idx[3 * i + 1], z = idx[3 * i + 2];
+  if (x <= -kKeyOff || x >= kKeyOff || y <= -kKeyOff || y >= kKeyOff || z <= -kKeyOff || z >= kKeyOff) {
+    atomicOr(&L.ctr[3], 2);
+    return;
+  }
+  const u64 key = pack_key(x, y, z);
+  if (L.dense) {  // the saved map must fit this mapper's workspace
+    const int dx = x - L.d_lo[0], dy = y - L.d_lo[1], dz = z - L.d_lo[2];
+    if (dx < 0 || (unsigned)dy >= (unsigned)L.d_ny || (unsigned)dz >= (unsigned)L.d_nz ||
+        (dx * L.d_ny + dy) * L.d_nz + dz >= L.d_ncells) {
+      atomicOr(&L.ctr[3], 2);
+      return;
+    }
+  }
+  L.slot_key[i] = key;
+  L.live[i] = i;
+  hash_insert(L, key, i);
+  dense_set(L, key, i + 1);
+  if (L.stamp) L.stamp[i] = 0;
+}
+
+// colour payload {uchar4 rgb_, f32 w}[512] from the exported planes rgb [n,512,3] u8 and w [n,512] f32
+__global__ __launch_bounds__(256) void k_import_color(LayerDev L, const uint8_t* __restrict__ rgb, const float* __restrict__ w, int n) {
+  for (int b = blockIdx.x; b < n; b += gridDim.x)
+    for (int v = threadIdx.x; v < kVPB; v += 256) {
+      const size_t q = (size_t)b * kVPB + v;
+      uint2 e;
+      e.x = (unsigned)rgb[3 * q] | ((unsigned)rgb[3 * q + 1] << 8) | ((unsigned)rgb[3 * q + 2] << 16);
+      e.y = __float_as_uint(w[q]);
+      reinterpret_cast<uint2*>(L.pool)[q] = e;
+    }
+}
+
+// block_free summary of every live TSDF block (after an import)
+__global__ __launch_bounds__(256) void k_block_free_all(LayerDev L, MapConsts mc) {
+  const int n = L.ctr[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = L.live[i];
+    const float4 a = reinterpret_cast<const float4*>(L.pool)[(size_t)slot * (kVPB / 2) + threadIdx.x];
+    const int all_free = __syncthreads_and((a.y > 1e-4f && a.x == mc.trunc && a.w > 1e-4f && a.z == mc.trunc) ? 1 : 0);
+    if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
+  }
+}
+
+void launch_import_index(const LayerDev& L, const int32_t* idx, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_import_index, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, L, idx, n);
+}
+void launch_import_color(const LayerDev& L, const uint8_t* rgb, const float* w, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_import_color, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, L, rgb, w, n);
+}
+void launch_block_free_all(const LayerDev& L, const MapConsts& mc, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_block_free_all, dim3(n < 4096 ? n : 4096), dim3(256), 0, s, L, mc);
+}
+
 void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_invert_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }

@@ -41,6 +41,9 @@ bool alloc_jobs_fusable(int ncells0, int ncells1);
 void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s);
+void launch_import_index(const LayerDev& L, const int32_t* idx, int n, hipStream_t s);
+void launch_import_color(const LayerDev& L, const uint8_t* rgb, const float* w, int n, hipStream_t s);
+void launch_block_free_all(const LayerDev& L, const MapConsts& mc, int n, hipStream_t s);
 void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s);
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, hipStream_t s);

@@ -364,6 +364,49 @@ class Mapper:
                                           min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
                                           border_percent, mapper_id, invert_input_mask)
 
+    def save_map(self, path: str, mapper_id: int = 0) -> None:
+        """``mapper.save_map(path, mapper_id)`` (nvblox_to_disk_helpers.py:88-93): checkpoint of one mapper -- every
+        block of the TSDF, colour and feature layer in allocation order.  Own container, see io/map_file.py."""
+        from ..io.map_file import write_map_file
+
+        mapper_id = self._check_id(mapper_id)
+        tsdf, tidx = self.tsdf_layer_view(mapper_id).get_all_blocks()
+        rgb, cw, cidx = self.color_layer_view(mapper_id).get_all_blocks_split()
+        feat, fw, fidx = self.feature_layer_view(mapper_id).get_all_blocks_split()
+        arrays = {"tsdf_idx": tidx, "tsdf": tsdf, "color_idx": cidx, "color_rgb": rgb, "color_w": cw,
+                  "feature_idx": fidx, "feature": feat, "feature_w": fw}
+        meta = {"voxel_size_m": self._voxel_sizes[mapper_id], "feature_channels": self.feature_channels}
+        write_map_file(path, meta, {k: v.cpu().numpy() for k, v in arrays.items()})
+
+    def load_from_file(self, path: str, mapper_id: int = 0) -> None:
+        """Replace the content of mapper `mapper_id` by a map saved with ``save_map``; fusion then continues exactly as it
+        would have on the mapper that was saved (same block order, same values).  The mapper must have the voxel size and
+        feature width of the saved one, and workspace bounds that contain it."""
+        from ..io.map_file import read_map_file
+
+        mapper_id = self._check_id(mapper_id)
+        meta, a = read_map_file(path)
+        if abs(float(meta["voxel_size_m"]) - self._voxel_sizes[mapper_id]) > 1e-9:
+            raise ValueError(f"map was saved at voxel size {meta['voxel_size_m']}, this mapper uses {self._voxel_sizes[mapper_id]}")
+        if int(meta["feature_channels"]) != self.feature_channels:
+            raise ValueError(f"map was saved with {meta['feature_channels']} feature channels, this mapper stores {self.feature_channels}")
+        L = _lib.lib()
+
+        def dev(x, dtype):
+            return torch.from_numpy(np.ascontiguousarray(x)).to(self.device, dtype)
+
+        jobs = [(_lib.MMF_LAYER_TSDF, "tsdf_idx", dev(a["tsdf"], torch.float32), None),
+                (_lib.MMF_LAYER_COLOR, "color_idx", dev(a["color_rgb"], torch.uint8), dev(a["color_w"], torch.float32)),
+                (_lib.MMF_LAYER_FEATURE, "feature_idx", dev(a["feature"], torch.float16), dev(a["feature_w"], torch.float32))]
+        for layer, key, payload, weights in jobs:
+            idx = dev(a[key], torch.int32)
+            n = int(idx.shape[0])
+            if n == 0 and layer != _lib.MMF_LAYER_TSDF and not self._num_blocks(mapper_id, layer):
+                continue  # never-used appearance layer stays unallocated
+            _lib.check(L.mmf_import_blocks(self._h, mapper_id, layer, _lib.dptr(idx), _lib.dptr(payload), _lib.dptr(weights), n,
+                                           self._stream()), "mmf_import_blocks")
+        self._mesh_V.pop(mapper_id, None)
+
     def decay(self, mapper_id: int = -1) -> None:
         _lib.check(_lib.lib().mmf_decay(self._h, int(mapper_id), self._stream()), "mmf_decay")
 

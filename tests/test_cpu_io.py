@@ -1,0 +1,99 @@
+"""On-disk formats on the CPU: zstd binding, vertex-feature files, depth / rgb PNG, pose and
+intrinsics files, the map container, the per-item transforms."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from nvblox_mindmap_amd.data_loading.sample_transformer import DepthTransformer, RgbTransformer
+from nvblox_mindmap_amd.io import dataset_files as D
+from nvblox_mindmap_amd.io import zstd
+from nvblox_mindmap_amd.io.map_file import read_map_file, write_map_file
+
+
+def test_zstd_matches_an_independent_codec():
+    pa = pytest.importorskip("pyarrow")  # bundles its own zstd: an independent implementation of the format
+    rng = np.random.default_rng(0)
+    for data in (b"", b"a", rng.integers(0, 40, 300000, dtype=np.uint8).tobytes(), os.urandom(70000)):
+        c = zstd.compress(data, 1)
+        assert zstd.decompress(c) == data
+        if data:
+            assert pa.decompress(c, decompressed_size=len(data), codec="zstd").to_pybytes() == data
+            assert zstd.decompress(pa.compress(data, codec="zstd", asbytes=True)) == data
+    assert zstd.decompress(zstd.compress(b"abc") + zstd.compress(b"def", 9)) == b"abcdef"  # concatenated frames
+    with pytest.raises(ValueError):
+        zstd.decompress(b"definitely not zstd")
+
+
+def test_vertex_feature_file_roundtrip_and_layout(tmp_path):
+    v, f = torch.randn(257, 3) * 2, torch.randn(257, 24)
+    path = D.frame_path(str(tmp_path), 7, D.VERTEX_FEATURES_FILE_NAME)
+    assert os.path.basename(path) == "0007.nvblox_vertex_features.zst"  # {frame_index:04d}.<item name>
+    D.write_vertex_features(path, v, f)
+    # what the reference's reader does (dataset.py:410-415): zstd stream -> pickle -> dict of f16 CPU tensors
+    raw = pickle.loads(zstd.decompress(open(path, "rb").read()))
+    assert set(raw) == {"vertices", "features", "channel_length"} and raw["channel_length"] == 24
+    assert raw["vertices"].dtype == torch.float16 and raw["features"].dtype == torch.float16
+    s = D.load_item(path)
+    assert torch.equal(s["vertices"], v.half()) and torch.equal(s["features"], f.half())
+
+
+def test_vertex_feature_reader_refuses_code_execution(tmp_path):
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    p = tmp_path / "0000.nvblox_vertex_features.zst"
+    p.write_bytes(zstd.compress(pickle.dumps({"vertices": Evil(), "features": 1})))
+    with pytest.raises(pickle.UnpicklingError):
+        D.read_vertex_features(str(p))
+
+
+def test_depth_png_is_u16_millimetres_with_the_writers_clamp(tmp_path):
+    depth = torch.rand(48, 64) * 70.0  # beyond the 65.535 m a u16 millimetre image can hold
+    depth[0, 0], depth[0, 1], depth[0, 2] = float("inf"), -1.0, 1.2345
+    path = D.frame_path(str(tmp_path), 3, "pov_depth.png")
+    D.write_depth_png(path, depth)
+    from PIL import Image
+
+    with Image.open(path) as im:
+        assert im.mode in ("I;16", "I") and im.size == (64, 48)
+    got = D.load_item(path, torch.float32)
+    exp = (torch.clamp(depth, 0.0, 65535 / 1000.0 - 1e-3) * 1000.0).to(torch.int32).to(torch.float32)
+    assert torch.equal(got, exp)
+    assert got[0, 0] == 65533 and got[0, 1] == 0 and got[0, 2] == 1234  # truncation, not rounding
+    metres = DepthTransformer()(got)
+    assert metres.dtype == torch.float32 and abs(float(metres[0, 2]) - 1.234) < 1e-6
+
+
+def test_rgb_pose_intrinsics_files(tmp_path):
+    rgb = torch.randint(0, 256, (20, 30, 3), dtype=torch.uint8)
+    D.write_rgb_png(D.frame_path(str(tmp_path), 0, "pov_rgb.png"), rgb)
+    back = D.load_item(D.frame_path(str(tmp_path), 0, "pov_rgb.png"), torch.float32)
+    assert torch.equal(back, rgb.float())
+    chw = RgbTransformer()(back)
+    assert chw.shape == (3, 20, 30) and chw.dtype == torch.float32 and float(chw.max()) <= 1.0
+    assert torch.equal(chw, (rgb.float() / 255.0).permute(2, 0, 1))
+    D.write_pose(D.frame_path(str(tmp_path), 0, "pov_pose.npy"), torch.tensor([1.0, 2.0, 3.0]), torch.tensor([1.0, 0.0, 0.0, 0.0]))
+    assert D.load_item(D.frame_path(str(tmp_path), 0, "pov_pose.npy")).tolist() == [1, 2, 3, 1, 0, 0, 0]
+    K = torch.tensor([[500.0, 0, 320], [0, 500, 240], [0, 0, 1]])
+    D.write_intrinsics(D.frame_path(str(tmp_path), 0, "pov_intrinsics.npy"), K)
+    assert torch.equal(D.load_item(D.frame_path(str(tmp_path), 0, "pov_intrinsics.npy")), K)
+    with pytest.raises(ValueError):
+        D.load_item(str(tmp_path / "0000.something.xyz"))
+
+
+def test_map_container_roundtrip(tmp_path):
+    arrays = {"tsdf_idx": np.arange(12, dtype=np.int32).reshape(4, 3), "tsdf": np.random.rand(4, 8, 8, 8, 2).astype(np.float32),
+              "feature": (np.random.rand(4, 8, 8, 8, 16) * 10).astype(np.float16), "color_idx": np.zeros((0, 3), np.int32)}
+    path = str(tmp_path / "0000.nvblox_map_static.nvblx")
+    write_map_file(path, {"voxel_size_m": 0.01, "feature_channels": 16}, dict(arrays))
+    meta, got = read_map_file(path)
+    assert meta == {"voxel_size_m": 0.01, "feature_channels": 16}
+    for k, v in arrays.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(np.asarray(got[k]), v)
+    (tmp_path / "other.nvblx").write_bytes(b"SQLite format 3\0" + b"\0" * 100)  # what CUDA nvblox writes
+    with pytest.raises(ValueError):
+        read_map_file(str(tmp_path / "other.nvblx"))
