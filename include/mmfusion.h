@@ -195,6 +195,14 @@ int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth_d
                                int Wf, const float* T_W_C_host16, const float* K_host9, float min_depth_m, int k_in, int k_depth,
                                int border_percent, uint8_t* depth_mask_out_dev, uint8_t* feature_mask_out_dev, void* stream);
 
+/* Triangle connectivity and per-vertex colour of the surface mesh: Mapper.update_color_mesh / get_color_mesh
+ * (visualization/visualizer.py:656-672) and FeatureMesh.triangles() (paper/utils/utils.py:84-92).  Vertices are those of
+ * mmf_get_feature_mesh (same order); triangles [T,3] i32 index them, wound so that normals point into free space;
+ * vertex_colors [V,3] u8 = colour voxel containing the vertex (black if unobserved; may be NULL).  The update call
+ * synchronises and returns V and T; it includes mmf_update_feature_mesh. */
+int mmf_update_mesh_topology(mmf_handle h, int mapper_id, void* stream, int* num_vertices, int* num_triangles);
+int mmf_get_mesh_topology(mmf_handle h, int mapper_id, int32_t* triangles_dev, uint8_t* vertex_colors_dev, void* stream);
+
 /* Mapper.load_from_file (nvblox_to_disk_helpers.py:88-93 saves with save_map; paper/teaser/convert_maps_usd.py loads):
  * replace the content of one layer by n blocks in the order given (= allocation order of the saved map, what
  * mmf_get_block_indices / mmf_get_*_blocks export): block i takes live position i.  payload / weights as exported:

@@ -103,6 +103,8 @@ SIGNATURES = {
     "mmf_get_tsdf_blocks": (_I, [_VP, _I, _VP, _I, _VP]),
     "mmf_get_feature_blocks": (_I, [_VP, _I, _VP, _VP, _I, _VP]),
     "mmf_get_color_blocks": (_I, [_VP, _I, _VP, _VP, _I, _VP]),
+    "mmf_update_mesh_topology": (_I, [_VP, _I, _VP, _PI, _PI]),
+    "mmf_get_mesh_topology": (_I, [_VP, _I, _VP, _VP, _VP]),
     "mmf_import_blocks": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _VP]),
     "mmf_query_layer": (_I, [_VP, _I, _I, _VP, _I, _VP, _VP]),
     "mmf_backproject_depth": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),

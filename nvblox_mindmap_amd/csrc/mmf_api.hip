@@ -76,6 +76,11 @@ struct Mapper {
   int* mesh_out2 = nullptr;
   int mesh_cap = 0, mesh_V = 0, mesh_nblocks = 0;
   long long mesh_epoch = -1;
+  int* mesh_tcounts = nullptr;   // triangle counts / offsets per live block (mmf_update_mesh_topology)
+  int* mesh_toffsets = nullptr;
+  int* mesh_tout2 = nullptr;
+  int mesh_T = 0;
+  long long mesh_tepoch = -1;
   // last view grid (diagnostics)
   ViewGrid last_vg{};
   int app_cap = 0;
@@ -393,6 +398,9 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   HIP_TRY(hipMalloc(&m->mesh_counts, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->mesh_offsets, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->mesh_out2, sizeof(int) * 2));
+  HIP_TRY(hipMalloc(&m->mesh_tcounts, sizeof(int) * (size_t)cap));
+  HIP_TRY(hipMalloc(&m->mesh_toffsets, sizeof(int) * (size_t)cap));
+  HIP_TRY(hipMalloc(&m->mesh_tout2, sizeof(int) * 2));
   m->mesh_cap = cap;
   rc = ensure_scratch(*m, 0, cap);
   if (rc != MMF_OK) {
@@ -427,6 +435,9 @@ void destroy_mapper(Mapper* m) {
   (void)hipFree(m->mesh_counts);
   (void)hipFree(m->mesh_offsets);
   (void)hipFree(m->mesh_out2);
+  (void)hipFree(m->mesh_tcounts);
+  (void)hipFree(m->mesh_toffsets);
+  (void)hipFree(m->mesh_tout2);
   delete m;
 }
 
@@ -1208,6 +1219,42 @@ int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* verts, void* vfeat,
   {
     ProfScope ps(h, MMF_K_MESH, s);
     launch_mesh_emit(m->tsdf.d, F, m->mc, m->mesh_offsets, m->mesh_nblocks, verts, (__half*)vfeat, m->mesh_V, s);
+  }
+  return check_launch();
+}
+
+int mmf_update_mesh_topology(mmf_handle h, int mapper_id, void* stream, int* num_vertices, int* num_triangles) {
+  if (!num_vertices || !num_triangles) return fail(MMF_ERR_INVALID_ARG, "null output");
+  MMF_TRY(mmf_update_feature_mesh(h, mapper_id, stream, num_vertices));  // vertex counts / offsets (flushes a pending decay)
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope ps(h, MMF_K_MESH, s);
+    launch_mesh_tri_count(m->tsdf.d, m->mc, m->mesh_tcounts, m->mesh_toffsets, m->mesh_tout2, s);
+  }
+  HIP_TRY(hipMemcpyAsync(h->pinned, m->mesh_tout2, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  m->mesh_T = h->pinned[0];
+  m->mesh_tepoch = m->tsdf_epoch;
+  *num_triangles = m->mesh_T;
+  return check_launch();
+}
+
+int mmf_get_mesh_topology(mmf_handle h, int mapper_id, int32_t* triangles, uint8_t* vertex_colors, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
+  if (m->mesh_tepoch != m->tsdf_epoch || m->mesh_epoch != m->tsdf_epoch)
+    return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_update_mesh_topology; call it again");
+  if (m->mesh_V == 0) return MMF_OK;
+  if (!triangles && m->mesh_T > 0) return fail(MMF_ERR_INVALID_ARG, "null triangle buffer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  LayerDev Cl = m->color.allocated ? m->color.d : LayerDev{};
+  {
+    ProfScope ps(h, MMF_K_MESH, s);
+    launch_mesh_tri_emit(m->tsdf.d, Cl, m->mc, m->mesh_offsets, m->mesh_toffsets, m->mesh_nblocks, triangles, vertex_colors,
+                         m->mesh_V, m->mesh_T, s);
   }
   return check_launch();
 }

@@ -11,6 +11,9 @@
 // deterministic output position: count pass -> scan over blocks -> emit pass.
 #include "mmf_launch.h"
 
+#define MMF_MC_QUAL static __device__ const
+#include "../../include/mmf_mc_table.h"  // generated marching-cubes table (tools/gen_mc_table.py), shared with the oracle
+
 namespace mmf {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -231,6 +234,148 @@ void launch_mesh_emit(const LayerDev& tsdf, const LayerDev& feat, const MapConst
   if (n_blocks <= 0 || V <= 0) return;
   int g = n_blocks < 8192 ? n_blocks : 8192;
   hipLaunchKernelGGL(k_mesh_emit, dim3(g), dim3(256), 0, s, tsdf, feat, mc, offsets, n_blocks, verts, vfeat, V);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangle connectivity + per-vertex colour (Mapper.get_color_mesh / FeatureMesh.triangles(), consumed by the
+// reference's visualiser: visualization/visualizer.py:656-672, paper/utils/utils.py:84-92).  Not on the per-frame path.
+// Per block: the vertex walk of k_mesh_emit gives every lattice edge its vertex index (LDS, u16); the 512 cubes, two per
+// thread in lexicographic order, emit the triangles of their corner pattern (mmf_mc_table.h).  Same order as the oracle.
+// ------------------------------------------------------------------------------------------------
+__device__ inline int cube_pattern(const MeshLds& m, int c) {
+  if (!m.CV[c]) return 0;
+  const int x = c >> 6, y = (c >> 3) & 7, z = c & 7;
+  const int q = x * 81 + y * 9 + z;
+  int pat = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (m.D[q + (k >> 2) * 81 + ((k >> 1) & 1) * 9 + (k & 1)] < 0.0f) pat |= 1 << k;
+  return pat;
+}
+
+__global__ __launch_bounds__(256) void k_mesh_tri_count(LayerDev T, MapConsts mc, int* __restrict__ tcounts) {
+  __shared__ MeshLds m;
+  const int n = T.ctr[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = T.live[i];
+    int bx, by, bz;
+    unpack_key(T.slot_key[slot], bx, by, bz);
+    load_lattice(T, mc, slot, bx, by, bz, m);
+    const int cnt = mmf_mc_num_tris[cube_pattern(m, 2 * threadIdx.x)] + mmf_mc_num_tris[cube_pattern(m, 2 * threadIdx.x + 1)];
+    int ea, eb, ta, tb;
+    block_excl_scan2<4>(cnt, 0, m.scan, ea, eb, ta, tb);
+    if (threadIdx.x == 0) tcounts[i] = ta;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mesh_tri_emit(LayerDev T, LayerDev Cl, MapConsts mc, const int* __restrict__ voffsets,
+                                                      const int* __restrict__ toffsets, int n_blocks, int32_t* __restrict__ tris,
+                                                      uint8_t* __restrict__ vcolors, int V, int Tn) {
+  __shared__ MeshLds m;
+  __shared__ uint16_t s_vid[kEdges];  // vertex index (within the block) of every lattice edge, 0xffff = none
+  for (int i = blockIdx.x; i < n_blocks; i += gridDim.x) {
+    const int slot = T.live[i];
+    int bx, by, bz;
+    unpack_key(T.slot_key[slot], bx, by, bz);
+    load_lattice(T, mc, slot, bx, by, bz, m);
+    int cnt = 0;
+    const int e0 = threadIdx.x * kEdgesPerThread;
+    for (int k = 0; k < kEdgesPerThread; ++k) {
+      const int e = e0 + k;
+      if (e >= kEdges) break;
+      int qx, qy, qz, a;
+      float t;
+      cnt += edge_vertex(m, e, qx, qy, qz, a, t) ? 1 : 0;
+    }
+    int ea, eb, nv, tb;
+    block_excl_scan2<4>(cnt, 0, m.scan, ea, eb, nv, tb);
+    const int voff = voffsets[i];
+    int local = ea;
+    for (int k = 0; k < kEdgesPerThread; ++k) {
+      const int e = e0 + k;
+      if (e >= kEdges) break;
+      int qx, qy, qz, a;
+      float t;
+      if (!edge_vertex(m, e, qx, qy, qz, a, t)) {
+        s_vid[e] = 0xffffu;
+        continue;
+      }
+      s_vid[e] = (uint16_t)local;
+      if (vcolors && voff + local < V) {  // colour voxel containing the vertex (same position arithmetic as k_mesh_emit)
+        float pos[3] = {(float)bx * mc.bs + ((float)qx + 0.5f) * mc.v, (float)by * mc.bs + ((float)qy + 0.5f) * mc.v,
+                        (float)bz * mc.bs + ((float)qz + 0.5f) * mc.v};
+        const int qa = a == 0 ? qx : (a == 1 ? qy : qz);
+        const int ba = a == 0 ? bx : (a == 1 ? by : bz);
+        const float pa = a == 0 ? pos[0] : (a == 1 ? pos[1] : pos[2]);
+        const float pb = (float)ba * mc.bs + ((float)(qa + 1) + 0.5f) * mc.v;
+        const float pn = pa + t * (pb - pa);
+        if (a == 0) pos[0] = pn;
+        else if (a == 1) pos[1] = pn;
+        else pos[2] = pn;
+        int lin;
+        const u64 key = voxel_at(mc, pos, lin);
+        unsigned rgb = 0;
+        if (Cl.pool) {
+          const int cs = layer_lookup(Cl, key);
+          if (cs >= 0) {
+            const uint2 e2 = reinterpret_cast<const uint2*>(Cl.pool)[(size_t)cs * kVPB + lin];
+            if (__uint_as_float(e2.y) > 0.0f) rgb = e2.x;
+          }
+        }
+        uint8_t* o = vcolors + 3 * (size_t)(voff + local);
+        o[0] = (uint8_t)(rgb & 0xffu);
+        o[1] = (uint8_t)((rgb >> 8) & 0xffu);
+        o[2] = (uint8_t)((rgb >> 16) & 0xffu);
+      }
+      local++;
+    }
+    __syncthreads();
+    const int p0 = cube_pattern(m, 2 * threadIdx.x), p1 = cube_pattern(m, 2 * threadIdx.x + 1);
+    int tea, teb, nt, ttb;
+    block_excl_scan2<4>((int)mmf_mc_num_tris[p0] + (int)mmf_mc_num_tris[p1], 0, m.scan, tea, teb, nt, ttb);
+    int tpos = toffsets[i] + tea;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int c = 2 * threadIdx.x + r, pat = r ? p1 : p0;
+      const int x = c >> 6, y = (c >> 3) & 7, z = c & 7;
+      for (int k = 0; k < (int)mmf_mc_num_tris[pat]; ++k) {
+        int v3[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int e = mmf_mc_tris[pat][3 * k + j];
+          const int a = e >> 2, s1 = (e >> 1) & 1, s2 = e & 1;
+          const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+          int qx = x, qy = y, qz = z;  // lattice point the cube edge starts at (no dynamic register indexing)
+          if (a1 == 0) qx += s1; else if (a1 == 1) qy += s1; else qz += s1;
+          if (a2 == 0) qx += s2; else if (a2 == 1) qy += s2; else qz += s2;
+          v3[j] = voff + (int)s_vid[3 * (qx * 81 + qy * 9 + qz) + a];
+        }
+        if (tpos < Tn) {
+          tris[3 * (size_t)tpos] = v3[0];
+          tris[3 * (size_t)tpos + 1] = v3[1];
+          tris[3 * (size_t)tpos + 2] = v3[2];
+        }
+        tpos++;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void launch_mesh_tri_count(const LayerDev& tsdf, const MapConsts& mc, int* tcounts, int* toffsets, int* out2, hipStream_t s) {
+  int g = hinted(tsdf.hint_live, tsdf.cap);
+  g = g < 8192 ? g : 8192;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_mesh_tri_count, dim3(g), dim3(256), 0, s, tsdf, mc, tcounts);
+  hipLaunchKernelGGL(k_mesh_scan, dim3(1), dim3(256), 0, s, tsdf, (const int*)tcounts, toffsets, out2);
+}
+
+void launch_mesh_tri_emit(const LayerDev& tsdf, const LayerDev& color, const MapConsts& mc, const int* voffsets, const int* toffsets,
+                          int n_blocks, int32_t* tris, uint8_t* vcolors, int V, int Tn, hipStream_t s) {
+  if (n_blocks <= 0 || V <= 0) return;
+  int g = n_blocks < 8192 ? n_blocks : 8192;
+  hipLaunchKernelGGL(k_mesh_tri_emit, dim3(g), dim3(256), 0, s, tsdf, color, mc, voffsets, toffsets, n_blocks, tris, vcolors, V, Tn);
 }
 
 }  // namespace mmf

@@ -86,6 +86,10 @@ void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, i
 void launch_mesh_emit(const LayerDev& tsdf, const LayerDev& feat, const MapConsts& mc, const int* offsets, int n_blocks,
                       float* verts, __half* vfeat, int V, hipStream_t s);
 
+void launch_mesh_tri_count(const LayerDev& tsdf, const MapConsts& mc, int* tcounts, int* toffsets, int* out2, hipStream_t s);
+void launch_mesh_tri_emit(const LayerDev& tsdf, const LayerDev& color, const MapConsts& mc, const int* voffsets, const int* toffsets,
+                          int n_blocks, int32_t* tris, uint8_t* vcolors, int V, int Tn, hipStream_t s);
+
 // mmf_kernels_image.hip
 void launch_backproject(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, hipStream_t s);
 void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int k, hipStream_t s);

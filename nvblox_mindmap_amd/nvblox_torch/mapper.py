@@ -63,12 +63,38 @@ def _mask_u8(mask: Optional[torch.Tensor], shape) -> Optional[torch.Tensor]:
     return mask.contiguous()
 
 
-class FeatureMesh:
-    """Result of Mapper.get_feature_mesh(): surface vertices + one feature row per vertex."""
+def _write_ply(path: str, vertices, triangles, colors=None) -> None:
+    """Binary little-endian PLY (what Open3D / MeshLab read): float32 xyz [+ uchar rgb], int32 triangle indices."""
+    v = vertices.detach().to("cpu", torch.float32).numpy()
+    t = triangles.detach().to("cpu", torch.int32).numpy()
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    header = ["ply", "format binary_little_endian 1.0", f"element vertex {v.shape[0]}", "property float x", "property float y",
+              "property float z"]
+    if colors is not None:
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+        header += ["property uchar red", "property uchar green", "property uchar blue"]
+    header += [f"element face {t.shape[0]}", "property list uchar int vertex_indices", "end_header"]
+    vert = np.zeros(v.shape[0], dtype=fields)
+    vert["x"], vert["y"], vert["z"] = v[:, 0], v[:, 1], v[:, 2]
+    if colors is not None:
+        c = colors.detach().to("cpu", torch.uint8).numpy()
+        vert["red"], vert["green"], vert["blue"] = c[:, 0], c[:, 1], c[:, 2]
+    face = np.zeros(t.shape[0], dtype=[("n", "u1"), ("i", "<i4", (3,))])
+    face["n"], face["i"] = 3, t
+    with open(path, "wb") as f:
+        f.write(("\n".join(header) + "\n").encode("ascii"))
+        f.write(vert.tobytes())
+        f.write(face.tobytes())
 
-    def __init__(self, vertices: torch.Tensor, vertex_features: torch.Tensor):
+
+class FeatureMesh:
+    """Result of Mapper.get_feature_mesh(): surface vertices with their feature vectors; triangles on demand."""
+
+    def __init__(self, vertices: torch.Tensor, vertex_features: torch.Tensor, mapper: "Mapper" = None, mapper_id: int = 0):
         self._v = vertices
         self._f = vertex_features
+        self._mapper, self._id = mapper, mapper_id
+        self._t = None
 
     def vertices(self) -> torch.Tensor:
         """[V,3] float32 on the GPU, world frame."""
@@ -82,7 +108,52 @@ class FeatureMesh:
         return self._f
 
     def triangles(self) -> torch.Tensor:
-        raise NotImplementedError("triangle connectivity is not produced (the policy consumes vertices only)")
+        """[T,3] int32 indices into vertices() (marching-cubes connectivity, normals towards free space); extracted on
+        first use -- the policy consumes vertices only (paper/utils/utils.py:84-92 is the consumer)."""
+        if self._t is None:
+            if self._mapper is None:
+                raise RuntimeError("this FeatureMesh is not attached to a Mapper")
+            tris, _, V = self._mapper._mesh_topology(self._id, want_colors=False)
+            if V != self._v.shape[0]:
+                raise RuntimeError("the map changed since this mesh was extracted; call get_feature_mesh() again")
+            self._t = tris
+        return self._t
+
+
+class ColorMesh:
+    """Result of Mapper.get_color_mesh(): vertices, per-vertex colours, triangles (visualization/visualizer.py:656-672)."""
+
+    def __init__(self, vertices: torch.Tensor, triangles: torch.Tensor, colors_u8: torch.Tensor):
+        self._v, self._t, self._c = vertices, triangles, colors_u8
+
+    def vertices(self) -> torch.Tensor:
+        return self._v
+
+    def triangles(self) -> torch.Tensor:
+        return self._t
+
+    def vertex_colors(self) -> torch.Tensor:
+        """[V,3] float32 in [0,1] (Open3D convention)."""
+        return self._c.to(torch.float32) / 255.0
+
+    def vertex_colors_u8(self) -> torch.Tensor:
+        return self._c
+
+    def vertex_appearances(self) -> torch.Tensor:
+        return self.vertex_colors()
+
+    def save(self, path: str) -> None:
+        """Write a PLY file (the reference calls mesh.save(path) with a .ply name, visualizer.py:667-672)."""
+        _write_ply(path, self._v, self._t, self._c)
+
+    def to_open3d(self):
+        import open3d as o3d  # not a dependency of this package
+
+        mesh = o3d.geometry.TriangleMesh()
+        mesh.vertices = o3d.utility.Vector3dVector(self._v.cpu().numpy().astype(np.float64))
+        mesh.triangles = o3d.utility.Vector3iVector(self._t.cpu().numpy())
+        mesh.vertex_colors = o3d.utility.Vector3dVector(self.vertex_colors().cpu().numpy().astype(np.float64))
+        return mesh
 
 
 class _LayerView:
@@ -436,7 +507,31 @@ class Mapper:
                 continue
             _lib.check(rc, "mmf_get_feature_mesh")
             break
-        return FeatureMesh(verts, feats)
+        return FeatureMesh(verts, feats, self, mapper_id)
+
+    def _mesh_topology(self, mapper_id: int, want_colors: bool):
+        """(triangles [T,3] int32, colours [V,3] uint8 or None, V) of the current map."""
+        L = _lib.lib()
+        nv, nt = C.c_int(0), C.c_int(0)
+        _lib.check(L.mmf_update_mesh_topology(self._h, mapper_id, self._stream(), C.byref(nv), C.byref(nt)), "mmf_update_mesh_topology")
+        self._mesh_V[mapper_id] = nv.value
+        tris = torch.empty((nt.value, 3), dtype=torch.int32, device=self.device)
+        cols = torch.empty((nv.value, 3), dtype=torch.uint8, device=self.device) if want_colors else None
+        _lib.check(L.mmf_get_mesh_topology(self._h, mapper_id, _lib.dptr(tris), _lib.dptr(cols), self._stream()), "mmf_get_mesh_topology")
+        return tris, cols, nv.value
+
+    def update_color_mesh(self, mapper_id: int = 0) -> None:
+        """Kept for call compatibility (visualizer.py:657): extraction happens in get_color_mesh, from the current map."""
+        self._check_id(mapper_id)
+
+    def get_color_mesh(self, mapper_id: int = 0) -> Optional[ColorMesh]:
+        """Surface mesh with per-vertex colours of the colour layer, or None when the map has no surface yet."""
+        mapper_id = self._check_id(mapper_id)
+        tris, cols, V = self._mesh_topology(mapper_id, want_colors=True)
+        if V == 0:
+            return None
+        mesh = self.get_feature_mesh(mapper_id)
+        return ColorMesh(mesh.vertices(), tris, cols)
 
     def tsdf_layer_view(self, mapper_id: int = 0) -> TsdfLayerView:
         return TsdfLayerView(self, self._check_id(mapper_id), _lib.MMF_LAYER_TSDF)

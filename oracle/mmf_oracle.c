@@ -45,6 +45,7 @@
  *   need x0>=0, y0>=0, x0+1<=W-1, y0+1<=H-1; wx = uc-x0, wy = vc-y0;
  *   val = (1-wy)*((1-wx)*a00 + wx*a10) + wy*((1-wx)*a01 + wx*a11)   (aXY: x0+X, y0+Y).
  */
+#include "../include/mmf_mc_table.h" /* generated marching-cubes table (tools/gen_mc_table.py), shared with the HIP kernels */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -395,6 +396,9 @@ typedef struct {
   uint16_t* mesh_f;
   int mesh_n, mesh_cap;
   int mesh_C;
+  uint8_t* mesh_c; /* [mesh_n][3] vertex colours */
+  int* mesh_t;     /* [mesh_nt][3] triangles (vertex indices) */
+  int mesh_nt, mesh_tcap;
   /* counters of the last integrate call (blocks updated) */
   int last_n_tsdf_blocks, last_n_app_blocks;
 } orc_mapper;
@@ -422,6 +426,8 @@ void orc_destroy(orc_mapper* m) {
   free(m->synth);
   free(m->mesh_v);
   free(m->mesh_f);
+  free(m->mesh_c);
+  free(m->mesh_t);
   free(m);
 }
 
@@ -1004,6 +1010,7 @@ static void mesh_push(orc_mapper* m, const float* pos, int C) {
     m->mesh_C = C;
     m->mesh_v = (float*)realloc(m->mesh_v, sizeof(float) * 3 * m->mesh_cap);
     m->mesh_f = (uint16_t*)realloc(m->mesh_f, sizeof(uint16_t) * (size_t)C * m->mesh_cap);
+    m->mesh_c = (uint8_t*)realloc(m->mesh_c, 3 * (size_t)m->mesh_cap);
   }
   memcpy(&m->mesh_v[3 * (size_t)m->mesh_n], pos, sizeof(float) * 3);
   uint16_t* f = &m->mesh_f[(size_t)C * m->mesh_n];
@@ -1014,14 +1021,38 @@ static void mesh_push(orc_mapper* m, const float* pos, int C) {
     const void* data = m->feat.blocks[p].data;
     if (featw_ptr((void*)data, C)[lin] > 0.0f) memcpy(f, feat_ptr((void*)data) + (size_t)lin * C, sizeof(uint16_t) * C);
   }
+  /* vertex colour: colour voxel containing pos (if its block exists and W > 0), else black */
+  uint8_t* c = &m->mesh_c[3 * (size_t)m->mesh_n];
+  c[0] = c[1] = c[2] = 0;
+  p = voxel_at(m, &m->color, pos, &lin);
+  if (p >= 0) {
+    const color_block* cb = (const color_block*)m->color.blocks[p].data;
+    if (cb->w[lin] > 0.0f) memcpy(c, &cb->rgb[lin * 3], 3);
+  }
   m->mesh_n++;
+}
+
+/* Triangles: for each block, after its vertices, the valid cubes (i,j,k) in lexicographic order emit the triangles of
+ * their corner pattern (include/mmf_mc_table.h: corner c = dx*4+dy*2+dz inside iff D < 0; cube edge e = a*4+s1*2+s2 is the
+ * lattice edge from o + s1*e_(a+1) + s2*e_(a+2) along a), as indices of the block's vertices. */
+static void mesh_push_tri(orc_mapper* m, int a, int b, int c) {
+  if (m->mesh_nt == m->mesh_tcap) {
+    m->mesh_tcap = m->mesh_tcap ? m->mesh_tcap * 2 : 8192;
+    m->mesh_t = (int*)realloc(m->mesh_t, sizeof(int) * 3 * m->mesh_tcap);
+  }
+  int* t = &m->mesh_t[3 * (size_t)m->mesh_nt++];
+  t[0] = a;
+  t[1] = b;
+  t[2] = c;
 }
 
 int orc_update_feature_mesh(orc_mapper* m) {
   const int C = m->P.feature_channels;
   m->mesh_n = 0;
+  m->mesh_nt = 0;
   m->mesh_C = C;
   static const int E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  static int vid[9][9][9][3]; /* vertex index of lattice edge (q, a) of the current block, -1 = none */
   for (int bi = 0; bi < m->tsdf.n; ++bi) {
     const block_t* B = &m->tsdf.blocks[bi];
     float D[9][9][9];
@@ -1057,6 +1088,7 @@ int orc_update_feature_mesh(orc_mapper* m) {
       for (int y = 0; y < 9; ++y)
         for (int z = 0; z < 9; ++z)
           for (int a = 0; a < 3; ++a) {
+            vid[x][y][z][a] = -1;
             int q[3] = {x, y, z};
             int r[3] = {x + E[a][0], y + E[a][1], z + E[a][2]};
             if (r[a] > 8) continue;
@@ -1083,10 +1115,39 @@ int orc_update_feature_mesh(orc_mapper* m) {
             float t = Da / (Da - Db);
             float pos[3] = {pa[0], pa[1], pa[2]};
             pos[a] = pa[a] + t * (pb_a - pa[a]);
+            vid[x][y][z][a] = m->mesh_n;
             mesh_push(m, pos, C);
           }
+    for (int x = 0; x < 8; ++x)
+      for (int y = 0; y < 8; ++y)
+        for (int z = 0; z < 8; ++z) {
+          if (!CV[x][y][z]) continue;
+          int pat = 0;
+          for (int c = 0; c < 8; ++c)
+            if (D[x + (c >> 2)][y + ((c >> 1) & 1)][z + (c & 1)] < 0.0f) pat |= 1 << c;
+          for (int k = 0; k < mmf_mc_num_tris[pat]; ++k) {
+            int v3[3];
+            for (int j = 0; j < 3; ++j) {
+              const int e = mmf_mc_tris[pat][3 * k + j];
+              const int a = e >> 2, s1 = (e >> 1) & 1, s2 = e & 1;
+              int q[3] = {x, y, z};
+              q[(a + 1) % 3] += s1;
+              q[(a + 2) % 3] += s2;
+              v3[j] = vid[q[0]][q[1]][q[2]][a];
+            }
+            mesh_push_tri(m, v3[0], v3[1], v3[2]);
+          }
+        }
   }
   return m->mesh_n;
+}
+
+/* triangles [T,3] and vertex colours [V,3] of the last orc_update_feature_mesh; returns T */
+int orc_mesh_num_triangles(const orc_mapper* m) { return m->mesh_nt; }
+int orc_get_mesh_topology(const orc_mapper* m, int* tris, uint8_t* colors) {
+  if (tris) memcpy(tris, m->mesh_t, sizeof(int) * 3 * (size_t)m->mesh_nt);
+  if (colors) memcpy(colors, m->mesh_c, 3 * (size_t)m->mesh_n);
+  return m->mesh_nt;
 }
 
 int orc_get_feature_mesh(const orc_mapper* m, float* verts, uint16_t* feats) {

@@ -68,7 +68,8 @@ def lib():
         L.orc_f2h.argtypes = [C.c_float]
         for name in [
             "orc_destroy", "orc_clear", "orc_decay", "orc_add_depth_frame", "orc_add_color_frame",
-            "orc_add_feature_frame", "orc_update_feature_mesh", "orc_get_feature_mesh", "orc_num_blocks",
+            "orc_add_feature_frame", "orc_update_feature_mesh", "orc_get_feature_mesh", "orc_mesh_num_triangles",
+            "orc_get_mesh_topology", "orc_num_blocks",
             "orc_get_block_indices", "orc_get_tsdf_block", "orc_get_all_tsdf", "orc_get_feature_block",
             "orc_get_all_features", "orc_get_color_block", "orc_get_all_colors", "orc_last_view_blocks",
             "orc_last_counts", "orc_get_synthetic_depth", "orc_render_synthetic_depth", "orc_query_features",
@@ -225,6 +226,15 @@ class OracleMapper:
         if V:
             lib().orc_get_feature_mesh(self._h, _ptr(v), _ptr(f))
         return v, f
+
+    def mesh_topology(self):
+        """(triangles [T,3] int32 into the vertices of feature_mesh(), vertex colours [V,3] uint8) of the current map."""
+        V = lib().orc_update_feature_mesh(self._h)
+        T = lib().orc_mesh_num_triangles(self._h)
+        t = np.zeros((T, 3), dtype=np.int32)
+        c = np.zeros((V, 3), dtype=np.uint8)
+        lib().orc_get_mesh_topology(self._h, _ptr(t), _ptr(c))
+        return t, c
 
     def query_features(self, pts) -> np.ndarray:
         pts = np.ascontiguousarray(pts, dtype=np.float32)

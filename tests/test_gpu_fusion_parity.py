@@ -428,3 +428,46 @@ def test_inverted_input_mask_equals_materialised_inverse():
         ta, tb = a.tsdf_layer_view(0).get_all_blocks(), m.tsdf_layer_view(0).get_all_blocks()
         assert torch.equal(ta[0], tb[0]) and torch.equal(ta[1], tb[1])
     assert int((ref[1] > 0).sum()) > 5000
+
+
+def test_mesh_topology_and_color_mesh(oracle_mod, tmp_path):
+    """Triangle connectivity + per-vertex colours (Mapper.get_color_mesh, FeatureMesh.triangles()) against the oracle:
+    same triangles in the same order, same colours; the surface is consistently oriented; PLY export round-trips."""
+    cfg = small_cfg(4)
+    orc, gpu = run_both(oracle_mod, cfg, 16, [0, 6, 12], use_mask=True, color=True, decay=True)
+    ov, _ = orc.feature_mesh()
+    ot, oc = orc.mesh_topology()
+    mesh = gpu.get_feature_mesh(0)
+    assert np.array_equal(mesh.vertices().cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    tris = mesh.triangles()
+    assert tris.dtype == torch.int32 and np.array_equal(tris.cpu().numpy(), ot) and ot.shape[0] > 10000
+    gpu.update_color_mesh(0)
+    cm = gpu.get_color_mesh(0)
+    assert np.array_equal(cm.vertices().cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    assert np.array_equal(cm.triangles().cpu().numpy(), ot)
+    assert np.array_equal(cm.vertex_colors_u8().cpu().numpy(), oc) and (oc.sum(axis=1) > 0).mean() > 0.5
+    assert cm.vertex_colors().dtype == torch.float32 and float(cm.vertex_colors().max()) <= 1.0
+    # orientation: every directed edge inside one block is matched by its reverse at most once, never duplicated
+    t = ot.astype(np.int64)
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
+    code = e[:, 0] * (ov.shape[0] + 1) + e[:, 1]
+    uniq, counts = np.unique(code, return_counts=True)
+    assert counts.max() <= 2  # (2 only at pinched ambiguous patterns)
+    rev = e[:, 1] * (ov.shape[0] + 1) + e[:, 0]
+    assert np.isin(rev, uniq).mean() > 0.8  # interior edges have their opposite; block borders (per-block vertices) / map boundary do not
+    # normals point towards free space: for a floor seen from above that is +z on average
+    tri = ov[ot]
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    cam = S.camera_pose(cfg, 6)[:3, 3]
+    towards_cam = ((cam[None, :] - tri.mean(axis=1)) * n).sum(axis=1)
+    assert (towards_cam > 0).mean() > 0.8
+    path = str(tmp_path / "nvblox_mesh_00000.ply")
+    cm.save(path)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"element vertex %d" % ov.shape[0] in head and b"element face %d" % ot.shape[0] in head
+    assert len(body) == ov.shape[0] * 15 + ot.shape[0] * 13
+    assert np.array_equal(np.frombuffer(body[:12], "<f4"), ov[0])
+    # an empty map has no mesh
+    gpu.clear()
+    assert gpu.get_color_mesh(0) is None
