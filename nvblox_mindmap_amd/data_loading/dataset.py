@@ -1,0 +1,142 @@
+"""File-fed samples for policy training.
+
+``MindmapFrameDataset`` reads demos stored in the reference's per-frame layout (io/dataset_files.py) the way
+``NvbloxMindmapDataset.__getitem__`` does (mindmap/data_loading/dataset.py:425-490): one sample = the items of one frame.
+Two deliberate differences, both about where the work happens:
+  * images stay in their storage dtype on the host (rgb u8, depth u16 millimetres): the ``RgbTransformer`` /
+    ``DepthTransformer`` arithmetic runs on the GPU after the copy (``gpu_unpack``), so the host -> device copy moves
+    1 + 2 bytes per pixel instead of 12 + 4 and the loader workers only decode;
+  * the depth back-projection of ``unpack_pcd`` (data_loading/batching.py:213-262), a CPU job in the reference, is the HIP
+    kernel behind ``training.trainer.unpack_batch``.
+The embodiment-specific parts of the reference dataset (robot states -> keyposes / policy states) are out of scope: the
+gripper history / prediction targets are read from per-frame ``.npy`` items (``gripper_history.npy``,
+``gt_gripper_pred.npy``, the names the reference itself uses for cached samples, dataset.py:233-250).
+"""
+import glob
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from ..io import dataset_files as D
+from ..mapping.nvblox_mapper_constants import DEPTH_SCALE_FACTOR
+from .vertex_sampling import VertexSamplingMethod, sample_to_n_vertices
+
+
+class MindmapFrameDataset(Dataset):
+    def __init__(self, dataset_path: str, cameras: Sequence[str] = ("pov",), num_vertices: int = 2048,
+                 vertex_sampling_method: VertexSamplingMethod = VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT,
+                 with_vertex_features: bool = True, seed: Optional[int] = None):
+        self.cameras = list(cameras)
+        self.num_vertices = num_vertices
+        self.method = vertex_sampling_method
+        self.with_vertex_features = with_vertex_features
+        self.seed = seed
+        self.samples: List[Dict[str, str]] = []
+        demos = sorted(d for d in glob.glob(os.path.join(dataset_path, "demo_*")) if os.path.isdir(d)) or [dataset_path]
+        for demo in demos:
+            ok = os.path.join(demo, "demo_successful.npy")
+            if os.path.exists(ok) and not bool(np.load(ok)):  # failed demos are skipped (dataset.py:160-175)
+                continue
+            for pose in sorted(glob.glob(os.path.join(demo, f"*.{self.cameras[0]}_pose.npy"))):
+                frame = os.path.basename(pose).split(".")[0]
+                items = {}
+                for cam in self.cameras:
+                    for kind, ext in (("rgb", "png"), ("depth", "png"), ("pose", "npy"), ("intrinsics", "npy")):
+                        items[f"{cam}_{kind}"] = os.path.join(demo, f"{frame}.{cam}_{kind}.{ext}")
+                items["gripper_history"] = os.path.join(demo, f"{frame}.gripper_history.npy")
+                items["gt_gripper_pred"] = os.path.join(demo, f"{frame}.gt_gripper_pred.npy")
+                if with_vertex_features:
+                    items["vertex_features"] = os.path.join(demo, f"{frame}.{D.VERTEX_FEATURES_FILE_NAME}")
+                if all(os.path.exists(p) for p in items.values()):
+                    yaw = os.path.join(demo, f"{frame}.gt_head_yaw.npy")
+                    if os.path.exists(yaw):
+                        items["gt_head_yaw"] = yaw
+                    self.samples.append(items)
+        if not self.samples:
+            raise FileNotFoundError(f"no complete frames under {dataset_path}")
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+    def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
+        it = self.samples[idx]
+        out = {}
+        rgb, depth, pose, intr = [], [], [], []
+        for cam in self.cameras:
+            rgb.append(D.read_png(it[f"{cam}_rgb"]))                                   # [H,W,3] u8
+            depth.append(D.read_png(it[f"{cam}_depth"]).to(torch.int16))               # u16 bit pattern, 2 B / pixel
+            pose.append(torch.as_tensor(np.load(it[f"{cam}_pose"])).to(torch.float32))
+            intr.append(torch.as_tensor(np.load(it[f"{cam}_intrinsics"])).to(torch.float32))
+        out["rgb_u8"] = torch.stack(rgb)
+        out["depth_mm"] = torch.stack(depth)
+        out["camera_poses"] = torch.stack(pose)
+        out["intrinsics"] = torch.stack(intr)
+        out["gripper_history"] = torch.as_tensor(np.load(it["gripper_history"])).to(torch.float32)
+        out["gt_gripper_pred"] = torch.as_tensor(np.load(it["gt_gripper_pred"])).to(torch.float32)
+        if "gt_head_yaw" in it:
+            out["gt_head_yaw"] = torch.as_tensor(np.load(it["gt_head_yaw"])).to(torch.float32)
+        if self.with_vertex_features:
+            s = D.read_vertex_features(it["vertex_features"])
+            v, f, valid = sample_to_n_vertices(s["vertices"].to(torch.float32), s["features"].to(torch.float32), self.num_vertices,
+                                               self.method, None if self.seed is None else self.seed + idx)
+            out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = v, f.to(torch.float16), valid
+        return out
+
+
+_TABLES: Dict[str, Dict[str, torch.Tensor]] = {}
+
+
+def _tables(device) -> Dict[str, torch.Tensor]:
+    """value -> transformed value for every possible pixel value, computed ON THE CPU with the reference's arithmetic
+    (image / 255.0, image / DEPTH_SCALE_FACTOR in float32).  The GPU's float division is not guaranteed to round like the
+    CPU's; a gather from these tables is, and is as cheap."""
+    key = str(torch.device(device))
+    if key not in _TABLES:
+        _TABLES[key] = {
+            "rgb": (torch.arange(256, dtype=torch.float32) / 255.0).type(torch.float32).to(device),
+            "depth": (torch.arange(65536, dtype=torch.float32) / DEPTH_SCALE_FACTOR).to(torch.float32).to(device),
+        }
+    return _TABLES[key]
+
+
+def gpu_unpack(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+    """Collated loader batch (host, storage dtypes) -> the batch format of training.trainer (device): the copies are
+    issued first, then RgbTransformer / DepthTransformer (sample_transformer.py:42-73) on the GPU, bit-identical to the
+    CPU transformers."""
+    dev = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+    out = {k: v for k, v in dev.items() if k not in ("rgb_u8", "depth_mm")}
+    tab = _tables(device)
+    out["rgbs"] = tab["rgb"][dev["rgb_u8"].long()].permute(0, 1, 4, 2, 3).contiguous()       # [B,ncam,3,H,W] in [0,1]
+    out["depths"] = tab["depth"][dev["depth_mm"].to(torch.int32) & 0xFFFF]                    # metres
+    if "gt_head_yaw" not in out:
+        out["gt_head_yaw"] = torch.zeros(out["gt_gripper_pred"].shape[0], out["gt_gripper_pred"].shape[1], 1, device=device)
+    return out
+
+
+def write_synthetic_demo(directory: str, n_frames: int, image_size=(64, 64), feature_dim: int = 16, num_history: int = 3,
+                         prediction_horizon: int = 1, ngrippers: int = 1, camera: str = "pov", seed: int = 0) -> None:
+    """A demo in the reference's on-disk layout with random content (tests / loader benchmarks)."""
+    os.makedirs(directory, exist_ok=True)
+    g = torch.Generator().manual_seed(seed)
+    H, W = image_size
+    for i in range(n_frames):
+        D.write_rgb_png(D.frame_path(directory, i, f"{camera}_rgb.png"), torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8))
+        D.write_depth_png(D.frame_path(directory, i, f"{camera}_depth.png"), 0.4 + 1.2 * torch.rand(H, W, generator=g))
+        D.write_pose(D.frame_path(directory, i, f"{camera}_pose.npy"), torch.tensor([1.4, 0.0, 0.6]) + 0.05 * torch.randn(3, generator=g),
+                     torch.nn.functional.normalize(torch.tensor([0.5, -0.5, 0.5, -0.5]) + 0.01 * torch.randn(4, generator=g), dim=0))
+        D.write_intrinsics(D.frame_path(directory, i, f"{camera}_intrinsics.npy"),
+                           torch.tensor([[586.4 * W / 512, 0.0, W / 2.0], [0.0, 586.4 * H / 512, H / 2.0], [0.0, 0.0, 1.0]]))
+        nv = int(torch.randint(200, 3000, (1,), generator=g))
+        D.write_vertex_features(D.frame_path(directory, i, D.VERTEX_FEATURES_FILE_NAME), torch.rand(nv, 3, generator=g),
+                                torch.randn(nv, feature_dim, generator=g))
+
+        def poses(n):
+            q = torch.nn.functional.normalize(torch.randn(n, ngrippers, 4, generator=g), dim=-1)
+            return torch.cat([torch.rand(n, ngrippers, 3, generator=g), q, (torch.rand(n, ngrippers, 1, generator=g) > 0.5).float()], dim=-1)
+
+        np.save(D.frame_path(directory, i, "gripper_history.npy"), poses(num_history).numpy())
+        np.save(D.frame_path(directory, i, "gt_gripper_pred.npy"), poses(prediction_horizon).numpy())
+    np.save(os.path.join(directory, "demo_successful.npy"), np.array(True))

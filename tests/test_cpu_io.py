@@ -97,3 +97,28 @@ def test_map_container_roundtrip(tmp_path):
     (tmp_path / "other.nvblx").write_bytes(b"SQLite format 3\0" + b"\0" * 100)  # what CUDA nvblox writes
     with pytest.raises(ValueError):
         read_map_file(str(tmp_path / "other.nvblx"))
+
+
+def test_frame_dataset_reads_the_reference_layout(tmp_path):
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.data_loading.dataset import MindmapFrameDataset, write_synthetic_demo
+
+    write_synthetic_demo(str(tmp_path / "demo_00000"), 5, image_size=(32, 48), feature_dim=16)
+    write_synthetic_demo(str(tmp_path / "demo_00001"), 3, image_size=(32, 48), feature_dim=16, seed=1)
+    np.save(str(tmp_path / "demo_00001" / "demo_successful.npy"), np.array(False))  # failed demo: skipped
+    os.remove(str(tmp_path / "demo_00000" / "0004.pov_depth.png"))                 # incomplete frame: skipped
+    ds = MindmapFrameDataset(str(tmp_path), num_vertices=512, seed=0)
+    assert len(ds) == 4
+    s = ds[1]
+    assert s["rgb_u8"].shape == (1, 32, 48, 3) and s["rgb_u8"].dtype == torch.uint8
+    assert s["depth_mm"].shape == (1, 32, 48) and s["depth_mm"].dtype == torch.int16
+    assert s["camera_poses"].shape == (1, 7) and s["intrinsics"].shape == (1, 3, 3)
+    assert s["vertices"].shape == (512, 3) and s["vertex_features"].shape == (512, 16) and s["vertex_features"].dtype == torch.float16
+    assert s["vertices_valid_mask"].dtype == torch.bool and s["gripper_history"].shape == (3, 1, 8)
+    raw = D.read_png(str(tmp_path / "demo_00000" / "0001.pov_depth.png"))
+    assert torch.equal(s["depth_mm"][0].to(torch.int32) & 0xFFFF, raw)
+    batch = next(iter(DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)))
+    assert batch["rgb_u8"].shape == (2, 1, 32, 48, 3) and batch["vertices"].shape == (2, 512, 3)
+    with pytest.raises(FileNotFoundError):
+        MindmapFrameDataset(str(tmp_path / "demo_00001"))

@@ -52,3 +52,29 @@ def test_training_step_on_gpu_with_images():
     traj, yaw, _, _, _ = model(None, None, s["rgbs"], s["pcds"], s["pcd_valid_mask"], s["vertex_features"], s["vertices"],
                                s["vertices_valid_mask"], None, s["gripper_history"], run_inference=True)
     assert traj.shape == (1, 1, 2, 8) and torch.isfinite(traj).all()
+
+
+def test_file_fed_training_step(tmp_path):
+    """Demo on disk (reference layout) -> DataLoader -> gpu_unpack (transforms on the GPU) -> training step; the GPU
+    transforms equal the reference's CPU transformers bit for bit."""
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.data_loading.dataset import MindmapFrameDataset, gpu_unpack, write_synthetic_demo
+    from nvblox_mindmap_amd.data_loading.sample_transformer import DepthTransformer, RgbTransformer
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, build_optimizer, train_one_step
+
+    cfg = DiffuserActorConfig(data_type="rgbd_and_mesh", image_size=(128, 128), feature_dim=768)
+    write_synthetic_demo(str(tmp_path / "demo_00000"), 4, image_size=(128, 128), feature_dim=768, num_history=cfg.num_history,
+                         prediction_horizon=cfg.prediction_horizon, ngrippers=cfg.ngrippers)
+    ds = MindmapFrameDataset(str(tmp_path), num_vertices=256, seed=0)
+    host = next(iter(DataLoader(ds, batch_size=2, shuffle=False, num_workers=2)))
+    b = gpu_unpack(host, "cuda")
+    assert b["rgbs"].shape == (2, 1, 3, 128, 128) and b["rgbs"].is_cuda and b["depths"].shape == (2, 1, 128, 128)
+    ref_rgb = torch.stack([RgbTransformer()(host["rgb_u8"][i, 0].float()) for i in range(2)])
+    ref_depth = torch.stack([DepthTransformer()((host["depth_mm"][i, 0].to(torch.int32) & 0xFFFF).float()) for i in range(2)])
+    assert torch.equal(b["rgbs"][:, 0].cpu(), ref_rgb) and torch.equal(b["depths"][:, 0].cpu(), ref_depth)
+    torch.manual_seed(0)
+    model = build_model(cfg, device="cuda")
+    losses = train_one_step(cfg, model, build_optimizer(model), b)
+    assert torch.isfinite(losses[0])
