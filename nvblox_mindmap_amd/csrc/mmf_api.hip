@@ -98,11 +98,6 @@ struct mmf_mapper_s {
   int device = 0;
   std::vector<Mapper*> mappers;
   int* pinned = nullptr;  // host pinned scratch (16 ints)
-  hipStream_t side[2] = {nullptr, nullptr};  // internal streams for the independent chains of one frame
-  hipEvent_t ev[8] = {};
-  // Overlap independent kernel chains of a frame on the internal streams.  Off by default: on ROCm 7.2 a
-  // cross-queue event wait costs more than the ~20 us kernels it would overlap (measured: 226 vs 196 us/frame).
-  bool fork = false;
   unsigned prof = 0;  // bitmask of kernel ids to time
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
@@ -605,21 +600,11 @@ int app_alloc(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, cons
   return MMF_OK;
 }
 
-// Stand-alone appearance call: the sphere trace (if the image is not cached) runs on an internal stream
-// concurrently with candidate selection + allocation, and is joined before the integrate kernel.
+// Stand-alone appearance call: synthetic depth (if not cached), then candidate selection + allocation.
 int app_prepare(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, const Rigid& T_L_C, const Rigid& T_C_L,
                 const float* T16, const float* K9, int stat_upd, int stat_new, hipStream_t s) {
-  const bool fork = h->fork && !synth_cached(m, cam, T16, K9);
-  if (!fork) MMF_TRY(ensure_synth(h, m, cam, T_L_C, T16, K9, s));
-  if (fork) {
-    HIP_TRY(hipEventRecord(h->ev[0], s));
-    HIP_TRY(hipStreamWaitEvent(h->side[1], h->ev[0], 0));
-    MMF_TRY(ensure_synth(h, m, cam, T_L_C, T16, K9, h->side[1]));
-    HIP_TRY(hipEventRecord(h->ev[1], h->side[1]));
-  }
-  MMF_TRY(app_alloc(h, m, which, L, cam, T_C_L, stat_upd, stat_new, s));
-  if (fork) HIP_TRY(hipStreamWaitEvent(s, h->ev[1], 0));
-  return MMF_OK;
+  MMF_TRY(ensure_synth(h, m, cam, T_L_C, T16, K9, s));
+  return app_alloc(h, m, which, L, cam, T_C_L, stat_upd, stat_new, s);
 }
 
 // TSDF chain of one depth frame on stream s: raycast marking -> compaction/allocation -> TSDF update.
@@ -745,12 +730,6 @@ int mmf_mapper_create(int n_mappers, const mmf_params* params, int device, mmf_h
     h->mappers.push_back(m);
   }
   HIP_TRY(hipHostMalloc(&h->pinned, sizeof(int) * 64));
-  for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
-  for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
-  {
-    const char* e = std::getenv("MMF_SIDE_STREAMS");
-    h->fork = e && e[0] == '1';
-  }
   HIP_TRY(hipDeviceSynchronize());
   *out = h;
   return MMF_OK;
@@ -767,10 +746,6 @@ int mmf_mapper_destroy(mmf_handle h) {
   }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->pinned) (void)hipHostFree(h->pinned);
-  for (int i = 0; i < 2; ++i)
-    if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
-  for (int i = 0; i < 8; ++i)
-    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   delete h;
   return MMF_OK;
 }
@@ -894,10 +869,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame needs the feature image at the depth resolution; "
                                      "use the separate add_*_frame calls otherwise");
   HIP_TRY(hipSetDevice(h->device));
-  const bool fork = h->fork;
-  hipStream_t s = (hipStream_t)stream, sa = fork ? h->side[0] : s, sb = fork ? h->side[1] : s;
-  auto record = [&](int i, hipStream_t st) -> hipError_t { return fork ? hipEventRecord(h->ev[i], st) : hipSuccess; };
-  auto wait = [&](hipStream_t st, int i) -> hipError_t { return fork ? hipStreamWaitEvent(st, h->ev[i], 0) : hipSuccess; };
+  hipStream_t s = (hipStream_t)stream;
   MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
   MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)C, true));
   MMF_TRY(ensure_scratch(*m, 1, m->tsdf.d.cap));
@@ -926,191 +898,140 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   rigid_from_T(T16, T_L_C);
   rigid_inverse(T_L_C, T_C_L);
 
-  if (!fork) {
-    // ---- in-order path with horizontally fused launches (default) --------------------------------------------
-    //   1  raycast tiles            | mask row pass
-    //   2  TSDF allocation (1 WG)   | mask column pass          (k_alloc_jobs)
-    //   3  TSDF update
-    //   4  candidate selection (once: colour and feature camera coincide)
-    //   5  sphere trace
-    //   6  colour allocation | feature allocation              (k_alloc_jobs, 2 WGs)
-    //   7  colour update     | feature update                  (k_app_integrate2)
-    MaskJob M;
-    const bool packed = make_mask_job(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
-                                      feature_mask_out, m->mask_tmp, M);
-    ViewGrid vg;
-    MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
-    const int ncells = vg.nx * vg.ny * vg.nz;
-    const bool fusable = packed && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
-    if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
-    if (fusable) M.invert = invert_mask ? 1 : 0;
-    if (!fusable && invert_mask) {  // stand-alone kernels take the mask as it is: invert it once into scratch
-      if (!m->inv_mask || m->inv_mask_cap < (size_t)H * W) {
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(m->inv_mask);
-        m->inv_mask = nullptr;
-        HIP_TRY(hipMalloc(&m->inv_mask, (size_t)H * W));
-        m->inv_mask_cap = (size_t)H * W;
-      }
-      launch_invert_mask(input_mask, m->inv_mask, (size_t)H * W, s);
-      input_mask = m->inv_mask;
+  // ---- in-order path with horizontally fused launches (default) --------------------------------------------
+  //   1  raycast tiles            | mask row pass
+  //   2  TSDF allocation (1 WG)   | mask column pass          (k_alloc_jobs)
+  //   3  TSDF update
+  //   4  candidate selection (once: colour and feature camera coincide)
+  //   5  sphere trace
+  //   6  colour allocation | feature allocation              (k_alloc_jobs, 2 WGs)
+  //   7  colour update     | feature update                  (k_app_integrate2)
+  MaskJob M;
+  const bool packed = make_mask_job(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
+                                    feature_mask_out, m->mask_tmp, M);
+  ViewGrid vg;
+  MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  const bool fusable = packed && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
+  if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
+  if (fusable) M.invert = invert_mask ? 1 : 0;
+  if (!fusable && invert_mask) {  // stand-alone kernels take the mask as it is: invert it once into scratch
+    if (!m->inv_mask || m->inv_mask_cap < (size_t)H * W) {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(m->inv_mask);
+      m->inv_mask = nullptr;
+      HIP_TRY(hipMalloc(&m->inv_mask, (size_t)H * W));
+      m->inv_mask_cap = (size_t)H * W;
     }
-    if (!fusable) {
-      // odd shapes / very large grids: the plain sequence of stand-alone launches
-      flush_decay(h, *m, s);
-      launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
-                         feature_mask_out, m->mask_tmp, s);
-      MMF_TRY(depth_chain(h, *m, depth, input_mask, min_depth_m, cam, T_L_C, T_C_L, s));
-      m->frames[1]++;
-      MMF_TRY(app_alloc(h, *m, 1, m->color, cam, T_C_L, 4, -1, s));
-      MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, s));
-      launch_color_integrate(m->color.d, m->mc, cam, T_C_L, rgb, depth_mask_out, m->synth, m->synth_W, m->synth_H, m->sc[1],
-                             m->color.d.cap, s);
-      m->frames[2]++;
-      MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
-      if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
-      launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
-                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
-      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s);
-      return check_launch();
-    }
-    m->last_vg = vg;
-    m->frames[0]++;
+    launch_invert_mask(input_mask, m->inv_mask, (size_t)H * W, s);
+    input_mask = m->inv_mask;
+  }
+  if (!fusable) {
+    // odd shapes / very large grids: the plain sequence of stand-alone launches
+    flush_decay(h, *m, s);
+    launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out,
+                       feature_mask_out, m->mask_tmp, s);
+    MMF_TRY(depth_chain(h, *m, depth, input_mask, min_depth_m, cam, T_L_C, T_C_L, s));
     m->frames[1]++;
-    m->frames[2]++;
-    m->tsdf_epoch++;
-    m->touched = true;
-    const int stamp = (int)(m->tsdf_epoch & 0x3fffffff) ? (int)(m->tsdf_epoch & 0x3fffffff) : 1;
-    MMF_TRY(ensure_scratch(*m, 0, ncells));
-    const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
-    const bool do_decay = m->pending_decay;
-    m->pending_decay = false;
-    {
-      // raycast tiles | mask row pass | pending decay of the TSDF layer
-      ProfScope ps(h, MMF_K_RAYCAST, s);
-      launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
-                   m->kill, m->any_kill, s);
-    }
-    {
-      ProfScope ps(h, MMF_K_ALLOC, s);
-      KeySrc ks{};
-      ks.mode = 0;
-      ks.ox = vg.ox;
-      ks.oy = vg.oy;
-      ks.oz = vg.oz;
-      ks.ny = vg.ny;
-      ks.nz = vg.nz;
-      AllocJob job;
-      job.L = m->tsdf.d;
-      job.ks = ks;
-      job.sc = m->sc[0];
-      job.ncells = ncells;
-      job.stat_upd = 1;
-      job.stat_new = 2;
-      job.stamp = stamp;
-      job.timeline = m->timeline;
-      if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands out slots
-        job.kill = m->kill;
-        job.any_kill = m->any_kill;
-      }
-      launch_alloc_jobs(&job, 1, m->stats, &M, s);
-    }
-    {
-      // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
-      ProfScope ps(h, MMF_K_TSDF, s);
-      launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key, s);
-    }
-    {
-      // sphere trace | colour allocation | feature allocation: one launch
-      KeySrc ks{};
-      ks.mode = 1;
-      ks.n_live = m->tsdf.d.ctr;
-      AllocJob jobs[2];
-      jobs[0].L = m->color.d;
-      jobs[0].ks = ks;
-      jobs[0].sc = m->sc[1];
-      jobs[0].ncells = m->tsdf.d.cap;
-      jobs[0].stat_upd = 4;
-      jobs[0].stat_new = -1;
-      jobs[1].L = m->feat.d;
-      jobs[1].ks = ks;
-      jobs[1].sc = m->sc[2];
-      jobs[1].sc.flags = m->sc[1].flags;  // same camera: one candidate selection serves both layers
-      jobs[1].sc.cell_key = m->sc[1].cell_key;
-      jobs[1].ncells = m->tsdf.d.cap;
-      jobs[1].stat_upd = 6;
-      jobs[1].stat_new = 7;
-      jobs[1].zero_me = m->flat.count;  // survivor counter of this frame's feature update
-      int Ws, Hs;
-      bool need;
-      MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
-      ProfScope ps(h, MMF_K_SPHERE, s);
-      if (need) {
-        launch_sphere_alloc(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats, s);
-        synth_commit(*m, cam, T16, K9, Ws, Hs);
-      } else {
-        launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
-      }
-    }
-    {
-      ProfScope ps(h, MMF_K_FEATURE, s);
-      launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
-    }
-    {
-      ProfExt pe(h, MMF_K_FEATURE_FLAT);
-      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
-    }
-    return check_launch();
-  }
-
-  // fork: masks on side stream A while the TSDF chain runs on the caller's stream
-  if (invert_mask) return fail(MMF_ERR_INVALID_ARG, "invert_input_mask is not supported with MMF_SIDE_STREAMS=1");
-  flush_decay(h, *m, s);
-  HIP_TRY(record(0, s));
-  HIP_TRY(wait(sa, 0));
-  launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out, feature_mask_out,
-                     m->mask_tmp, sa);
-  HIP_TRY(record(1, sa));  // masks ready
-
-  // depth_mask = input_mask & (depth > min_d) is evaluated on the fly: the TSDF chain does not wait for the masks
-  MMF_TRY(depth_chain(h, *m, depth, input_mask, min_depth_m, cam, T_L_C, T_C_L, s));
-  HIP_TRY(record(2, s));  // TSDF of this frame complete
-
-  // side stream B: sphere trace for the colour camera
-  HIP_TRY(wait(sb, 2));
-  MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, sb));
-  HIP_TRY(record(3, sb));  // synthetic depth ready
-
-  // caller's stream: colour candidates + allocation, then the colour update
-  m->frames[1]++;
-  MMF_TRY(app_alloc(h, *m, 1, m->color, cam, T_C_L, 4, -1, s));
-
-  // side stream A: feature candidates + allocation (needs the TSDF), then the feature update
-  m->frames[2]++;
-  HIP_TRY(wait(sa, 2));
-  MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, sa));
-  HIP_TRY(wait(sa, 3));
-  const float* fsynth = m->synth;
-  const int fWs = m->synth_W, fHs = m->synth_H;
-  {
-    ProfScope ps(h, MMF_K_FEATURE, sa);
-    if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), sa));
-    launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, fsynth, fWs, fHs, m->sc[2],
-                             m->feat.d.cap, m->stats, sa, low, &m->flat);
-    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, sa);
-  }
-  HIP_TRY(record(4, sa));
-
-  HIP_TRY(wait(s, 3));
-  HIP_TRY(wait(s, 1));
-  {
-    ProfScope ps(h, MMF_K_COLOR, s);
+    MMF_TRY(app_alloc(h, *m, 1, m->color, cam, T_C_L, 4, -1, s));
+    MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, s));
     launch_color_integrate(m->color.d, m->mc, cam, T_C_L, rgb, depth_mask_out, m->synth, m->synth_W, m->synth_H, m->sc[1],
                            m->color.d.cap, s);
+    m->frames[2]++;
+    MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
+    if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
+    launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
+                             m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
+    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s);
+    return check_launch();
   }
-  // join: everything enqueued by this call is ordered before later work on the caller's stream
-  HIP_TRY(wait(s, 4));
+  m->last_vg = vg;
+  m->frames[0]++;
+  m->frames[1]++;
+  m->frames[2]++;
+  m->tsdf_epoch++;
+  m->touched = true;
+  const int stamp = (int)(m->tsdf_epoch & 0x3fffffff) ? (int)(m->tsdf_epoch & 0x3fffffff) : 1;
+  MMF_TRY(ensure_scratch(*m, 0, ncells));
+  const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
+  const bool do_decay = m->pending_decay;
+  m->pending_decay = false;
+  {
+    // raycast tiles | mask row pass | pending decay of the TSDF layer
+    ProfScope ps(h, MMF_K_RAYCAST, s);
+    launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
+                 m->kill, m->any_kill, s);
+  }
+  {
+    ProfScope ps(h, MMF_K_ALLOC, s);
+    KeySrc ks{};
+    ks.mode = 0;
+    ks.ox = vg.ox;
+    ks.oy = vg.oy;
+    ks.oz = vg.oz;
+    ks.ny = vg.ny;
+    ks.nz = vg.nz;
+    AllocJob job;
+    job.L = m->tsdf.d;
+    job.ks = ks;
+    job.sc = m->sc[0];
+    job.ncells = ncells;
+    job.stat_upd = 1;
+    job.stat_new = 2;
+    job.stamp = stamp;
+    job.timeline = m->timeline;
+    if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands out slots
+      job.kill = m->kill;
+      job.any_kill = m->any_kill;
+    }
+    launch_alloc_jobs(&job, 1, m->stats, &M, s);
+  }
+  {
+    // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
+    ProfScope ps(h, MMF_K_TSDF, s);
+    launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key, s);
+  }
+  {
+    // sphere trace | colour allocation | feature allocation: one launch
+    KeySrc ks{};
+    ks.mode = 1;
+    ks.n_live = m->tsdf.d.ctr;
+    AllocJob jobs[2];
+    jobs[0].L = m->color.d;
+    jobs[0].ks = ks;
+    jobs[0].sc = m->sc[1];
+    jobs[0].ncells = m->tsdf.d.cap;
+    jobs[0].stat_upd = 4;
+    jobs[0].stat_new = -1;
+    jobs[1].L = m->feat.d;
+    jobs[1].ks = ks;
+    jobs[1].sc = m->sc[2];
+    jobs[1].sc.flags = m->sc[1].flags;  // same camera: one candidate selection serves both layers
+    jobs[1].sc.cell_key = m->sc[1].cell_key;
+    jobs[1].ncells = m->tsdf.d.cap;
+    jobs[1].stat_upd = 6;
+    jobs[1].stat_new = 7;
+    jobs[1].zero_me = m->flat.count;  // survivor counter of this frame's feature update
+    int Ws, Hs;
+    bool need;
+    MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
+    ProfScope ps(h, MMF_K_SPHERE, s);
+    if (need) {
+      launch_sphere_alloc(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats, s);
+      synth_commit(*m, cam, T16, K9, Ws, Hs);
+    } else {
+      launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
+    }
+  }
+  {
+    ProfScope ps(h, MMF_K_FEATURE, s);
+    launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
+                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
+  }
+  {
+    ProfExt pe(h, MMF_K_FEATURE_FLAT);
+    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
+  }
   return check_launch();
 }
 
