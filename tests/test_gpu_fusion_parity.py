@@ -70,7 +70,7 @@ def compare_features(orc, gpu):
     d = np.abs(f.astype(np.float32) - of.astype(np.float32))
     # f16 storage: 1e-5 abs is below one f16 ulp for |x| > 0.01, so demand bit equality of the halves
     assert np.array_equal(f.view(np.uint16), of.view(np.uint16)), f"feature values differ, max abs {d.max()}"
-    return float(d.max())
+    return float(d.max()) if d.size else 0.0
 
 
 def test_tsdf_only_small(oracle_mod):
@@ -471,3 +471,85 @@ def test_mesh_topology_and_color_mesh(oracle_mod, tmp_path):
     # an empty map has no mesh
     gpu.clear()
     assert gpu.get_color_mesh(0) is None
+
+
+def _fused_vs_oracle(oracle_mod, gpu, orc, cfg, frames, channels, k_in=3, k_depth=4, border=5, invert=False):
+    from oracle import image_ops as IO
+
+    for k, i in enumerate(frames):
+        f = S.frame(cfg, i, channels) if not callable(i) else i()
+        dyn = np.zeros(f["depth"].shape, dtype=bool)
+        dyn[2 + k: 2 + k + f["depth"].shape[0] // 4, 3: 3 + f["depth"].shape[1] // 3] = True
+        static = ~dyn
+        odm, ofm = IO.frame_masks(static, f["depth"], 0.3, k_in, k_depth, border, cfg.height, cfg.width)
+        orc.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+        gpu.decay()
+        dm, fm = gpu.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), dev(dyn if invert else static),
+                                     torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), 0.3, k_in, k_depth, border, 0,
+                                     invert_input_mask=invert)
+        assert np.array_equal(dm.cpu().numpy().astype(bool), odm) and np.array_equal(fm.cpu().numpy().astype(bool), ofm)
+    compare_tsdf(orc, gpu)
+    compare_features(orc, gpu)
+    rgb, w, idx = gpu.color_layer_view(0).get_all_blocks_split()
+    orgb, ow = orc.all_colors()
+    assert np.array_equal(idx.cpu().numpy(), orc.block_indices(1)) and np.array_equal(w.cpu().numpy(), ow)
+    assert np.array_equal(rgb.cpu().numpy(), orgb)
+
+
+@pytest.mark.parametrize("invert", [False, True])
+def test_fused_call_falls_back_for_unbounded_workspaces(oracle_mod, invert):
+    """No workspace bounds -> view grid of tens of thousands of cells, no dense table: mmf_integrate_frame takes its
+    stand-alone-kernel route (three-kernel allocation, hash index, eager decay, inverted mask through scratch)."""
+    cfg = small_cfg(4)
+    over = dict(workspace_bounds_type=0, max_integration_distance_m=2.5)
+    _fused_vs_oracle(oracle_mod, make_mapper(16, **over), make_oracle(oracle_mod, 16, **over), cfg, [0, 6, 40, 46], 16, invert=invert)
+
+
+def test_fused_call_on_images_too_narrow_for_the_bit_packed_masks(oracle_mod):
+    """W < 16: the bit-packed mask job does not fit its scratch, the byte kernels run instead."""
+    cfg = S.StreamConfig(width=12, height=40, fx=10.0, fy=10.0, cx=5.5, cy=19.5)
+    _fused_vs_oracle(oracle_mod, make_mapper(8), make_oracle(oracle_mod, 8), cfg, [0, 3], 8, k_in=1, k_depth=1, border=0, invert=True)
+
+
+def test_degenerate_frames(oracle_mod):
+    """Frames that carry no information: all depth invalid, camera looking away from the workspace, then a normal one."""
+    cfg = small_cfg(4)
+    base = S.frame(cfg, 0, 16)
+
+    def blind():
+        f = dict(base)
+        f["depth"] = np.zeros_like(base["depth"])
+        return f
+
+    def away():
+        f = dict(S.frame(cfg, 3, 16))
+        T = f["T_W_C"].copy()
+        T[:3, :3] = T[:3, :3] @ np.diag([1.0, -1.0, -1.0]).astype(np.float32)  # turn around: optical axis away from the scene
+        f["T_W_C"] = T
+        return f
+
+    gpu, orc = make_mapper(16), make_oracle(oracle_mod, 16)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [blind, away], 16)
+    assert gpu.tsdf_layer_view(0).num_allocated_blocks() == orc.block_indices(0).shape[0]
+    assert gpu.get_color_mesh(0) is None or gpu.get_feature_mesh(0).vertices().shape[0] == orc.feature_mesh()[0].shape[0]
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [5, blind, 7], 16)
+    assert gpu.tsdf_layer_view(0).num_allocated_blocks() > 100
+
+
+def test_pool_exhaustion_is_reported():
+    from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
+    from nvblox_mindmap_amd.nvblox_torch.mapper_params import BlockMemoryPoolParams, MapperParams
+
+    mp = MapperParams()
+    pool = BlockMemoryPoolParams()
+    pool.num_preallocated_blocks = 64  # far fewer than one 160x120 view touches
+    mp.set_block_memory_pool_params(pool)
+    m = Mapper(voxel_sizes_m=0.01, mapper_parameters=mp, feature_channels=16)
+    cfg = small_cfg(4)
+    f = S.frame(cfg, 0, 16)
+    m.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+    with pytest.raises(RuntimeError, match="pool exhausted"):
+        m.tsdf_layer_view(0).num_allocated_blocks()
