@@ -266,9 +266,10 @@ int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out /* [MM
 int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
 /* Diagnostics: 100 MHz device timestamps taken by the TSDF allocation workgroup of the last fused frame (start, after the
  * decay compaction, table loads consumed, scan done, inserts done, counters published).  enable != 0 switches the
- * recording on for later frames (off otherwise); out8 receives the last recording (zeros if none): the six stamps, then
- * the latest end [6] and earliest start [7] over the mask column workgroups that share the launch.  Synchronises. */
-int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out8);
+ * recording on for later frames (off otherwise); out10 receives the last recording (zeros if none): the six stamps, then
+ * over the mask column workgroups that share the launch: latest end [6], earliest start [7], longest duration [8],
+ * latest start [9].  Synchronises. */
+int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out10);
 
 /* Kernel timing with HIP events on the launch stream.  kernel ids: */
 #define MMF_K_RAYCAST 0

@@ -1429,16 +1429,16 @@ int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   if (out6) {
-    for (int i = 0; i < 8; ++i) out6[i] = 0;
+    for (int i = 0; i < 10; ++i) out6[i] = 0;
     if (m->timeline) {
-      HIP_TRY(hipMemcpy(out6, m->timeline, sizeof(long long) * 8, hipMemcpyDeviceToHost));
-      const long long reset[2] = {0, 0x7fffffffffffffffll};
+      HIP_TRY(hipMemcpy(out6, m->timeline, sizeof(long long) * 10, hipMemcpyDeviceToHost));
+      const long long reset[4] = {0, 0x7fffffffffffffffll, 0, 0};
       HIP_TRY(hipMemcpy(m->timeline + 6, reset, sizeof(reset), hipMemcpyHostToDevice));
     }
   }
   if (enable && !m->timeline) {
-    HIP_TRY(hipMalloc(&m->timeline, sizeof(long long) * 8));
-    HIP_TRY(hipMemset(m->timeline, 0, sizeof(long long) * 8));
+    HIP_TRY(hipMalloc(&m->timeline, sizeof(long long) * 16));
+    HIP_TRY(hipMemset(m->timeline, 0, sizeof(long long) * 16));
     const long long big = 0x7fffffffffffffffll;
     HIP_TRY(hipMemcpy(m->timeline + 7, &big, sizeof(big), hipMemcpyHostToDevice));
   } else if (!enable && m->timeline) {

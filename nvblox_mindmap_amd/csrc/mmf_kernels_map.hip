@@ -358,8 +358,11 @@ __global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, i
     const long long t0 = J0.timeline ? wall_clock64() : 0;
     mask_colemit_row(M, (int)blockIdx.x - njobs, s_bad);
     if (J0.timeline && threadIdx.x == 0) {  // diagnostics: earliest start / latest end over the mask workgroups
+      const long long t1 = wall_clock64();
       atomicMin(reinterpret_cast<unsigned long long*>(J0.timeline + 7), (unsigned long long)t0);
-      atomicMax(reinterpret_cast<unsigned long long*>(J0.timeline + 6), (unsigned long long)wall_clock64());
+      atomicMax(reinterpret_cast<unsigned long long*>(J0.timeline + 6), (unsigned long long)t1);
+      atomicMax(reinterpret_cast<unsigned long long*>(J0.timeline + 8), (unsigned long long)(t1 - t0));   // longest one
+      atomicMax(reinterpret_cast<unsigned long long*>(J0.timeline + 9), (unsigned long long)t0);          // latest start
     }
   }
 }

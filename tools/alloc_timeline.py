@@ -19,7 +19,7 @@ frames = B.build_stream(cfg, 40, 64, dev)
 m = get_nvblox_mapper(mcfg, feature_channels=64)
 for i in range(20):
     B.step(m, mcfg, frames[i])
-out = (C.c_int64 * 8)()
+out = (C.c_int64 * 10)()
 _lib.check(_lib.lib().mmf_get_alloc_timeline(m._h, 0, 1, out))
 names = ["compaction", "table loads", "scan", "insert+emit", "publish"]
 for i in range(20, 32):
@@ -27,4 +27,5 @@ for i in range(20, 32):
     _lib.check(_lib.lib().mmf_get_alloc_timeline(m._h, 0, 1, out))
     t = list(out)
     print("frame", i, " ".join(f"{n}={(t[k + 1] - t[k]) / 100.0:.1f}us" for k, n in enumerate(names)), f"total={(t[5] - t[0]) / 100.0:.1f}us",
-          f"| mask cols: first start {(t[7] - t[0]) / 100.0:+.1f}us, last end {(t[6] - t[0]) / 100.0:+.1f}us relative to alloc start")
+          f"| mask cols: first start {(t[7] - t[0]) / 100.0:+.1f}us, last start {(t[9] - t[0]) / 100.0:+.1f}us, last end {(t[6] - t[0]) / 100.0:+.1f}us "
+          f"relative to alloc start; longest workgroup {t[8] / 100.0:.1f}us")
