@@ -1,0 +1,57 @@
+"""Training checkpoints (mirror of mindmap/model_utils/checkpoint.py:30-52,103-136): ``last.pth`` after every validation
+round, ``best.pth`` when the validation loss improved; each holds {weight, optimizer, iter, best_loss}.  Files written by the
+reference load here and vice versa (same keys; "weight" is the state_dict of whatever wraps the model -- a DDP wrapper saves
+"module."-prefixed names, which both loaders accept by stripping / adding the prefix)."""
+import os
+import pathlib
+from typing import Optional, Tuple
+
+import torch
+
+
+def save_checkpoint(checkpoint_log_dir, model, optimizer, step_id: int, new_loss: Optional[float], best_loss: Optional[float]):
+    """Write last.pth (always) and best.pth (if new_loss <= best_loss or either is None); returns the updated best loss.
+    Call on rank 0 only (run_training.py:747-752).  Files appear atomically (written to .tmp, then renamed)."""
+    os.makedirs(checkpoint_log_dir, exist_ok=True)
+
+    def dump(name, best):
+        path = pathlib.Path(checkpoint_log_dir) / name
+        tmp = str(path) + ".tmp"
+        torch.save({"weight": model.state_dict(), "optimizer": optimizer.state_dict(), "iter": step_id + 1, "best_loss": best}, tmp)
+        os.replace(tmp, path)
+
+    if new_loss is None or best_loss is None or new_loss <= best_loss:
+        best_loss = new_loss
+        dump("best.pth", best_loss)
+    dump("last.pth", best_loss)
+    return best_loss
+
+
+def _match_prefix(state: dict, model) -> dict:
+    want = any(k.startswith("module.") for k in model.state_dict())
+    have = any(k.startswith("module.") for k in state)
+    if want == have:
+        return state
+    return {("module." + k) if want else k[len("module."):]: v for k, v in state.items()}
+
+
+def load_inference_checkpoint(checkpoint_path: str, model, device):
+    assert checkpoint_path is not None and os.path.exists(checkpoint_path), checkpoint_path
+    model_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    model.load_state_dict(_match_prefix(model_dict["weight"], model))
+    model.eval()
+    return model.to(device=device)
+
+
+def load_train_checkpoint(checkpoint_path: str, model, optimizer, initial_learning_rate: Optional[float] = None) -> Tuple[int, Optional[float]]:
+    """Restore weights + optimizer state, reset the learning rate (the scheduler restarts, checkpoint.py:124-127); returns
+    (start_iter, best_loss)."""
+    assert checkpoint_path is not None and os.path.exists(checkpoint_path), checkpoint_path
+    model_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    model.load_state_dict(_match_prefix(model_dict["weight"], model))
+    if "optimizer" in model_dict:
+        optimizer.load_state_dict(model_dict["optimizer"])
+        if initial_learning_rate is not None:
+            for g in optimizer.param_groups:
+                g["lr"] = initial_learning_rate
+    return model_dict.get("iter", 0), model_dict.get("best_loss", None)

@@ -262,3 +262,42 @@ def test_ddp_two_ranks_gloo():
     assert gathered[0]["checksum"] == gathered[1]["checksum"]
     assert gathered[0]["loss"] != gathered[1]["loss"]
     assert tmax == 2.0
+
+
+def test_training_checkpoint_resume(tmp_path):
+    """save_checkpoint / load_train_checkpoint (model_utils/checkpoint.py:30-52,117-136): resuming reproduces the run that
+    never stopped, bit for bit; best.pth only moves when the validation loss improves."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, build_optimizer, load_train_checkpoint, save_checkpoint
+
+    from nvblox_mindmap_amd.training import synthetic_batch, train_one_step
+
+    cfg = DiffuserActorConfig(data_type="mesh", feature_dim=24)
+
+    def step(model, opt, seed):
+        torch.manual_seed(seed)  # noise / timestep draws inside the model
+        return float(train_one_step(cfg, model, opt, synthetic_batch(cfg, 2, "cpu", num_vertices=64, seed=seed))[0])
+
+    torch.manual_seed(0)
+    a = build_model(cfg, device="cpu")
+    oa = build_optimizer(a)
+    for s in range(2):
+        step(a, oa, s)
+    best = save_checkpoint(str(tmp_path), a, oa, step_id=1, new_loss=0.5, best_loss=None)
+    assert best == 0.5 and (tmp_path / "best.pth").exists() and (tmp_path / "last.pth").exists()
+    torch.manual_seed(123)
+    b = build_model(cfg, device="cpu")  # different initial weights
+    ob = build_optimizer(b)
+    start, best_b = load_train_checkpoint(str(tmp_path / "last.pth"), b, ob, initial_learning_rate=1e-4)
+    assert start == 2 and best_b == 0.5
+    la, lb = step(a, oa, 7), step(b, ob, 7)
+    assert la == lb
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    mtime = (tmp_path / "best.pth").stat().st_mtime_ns
+    assert save_checkpoint(str(tmp_path), a, oa, step_id=2, new_loss=0.9, best_loss=0.5) == 0.5
+    assert (tmp_path / "best.pth").stat().st_mtime_ns == mtime  # worse loss: best.pth untouched
+    # a DDP-wrapped save ("module." names) loads into a bare model
+    wrapped = {"weight": {"module." + k: v for k, v in a.state_dict().items()}, "iter": 5}
+    torch.save(wrapped, tmp_path / "ddp.pth")
+    assert load_train_checkpoint(str(tmp_path / "ddp.pth"), b, ob)[0] == 5
