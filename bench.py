@@ -253,6 +253,42 @@ def run_backprojection(device, cpu=True):
     return out
 
 
+def run_policy_inference(device, reps=3):
+    """Closed-loop serving latency of the policy: batch 1, encoder once + 100 denoising steps of the
+    diffusion head, eager and with the denoising loop replayed as one captured HIP graph (same results bit for bit)."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, synthetic_batch
+    from nvblox_mindmap_amd.training.trainer import unpack_batch
+
+    cfg = DiffuserActorConfig()
+    torch.manual_seed(0)
+    model = build_model(cfg, device=device).eval()
+    s = unpack_batch(cfg, synthetic_batch(cfg, 1, device, seed=1))
+
+    def infer():
+        with torch.no_grad():
+            return model(None, None, s["rgbs"], s["pcds"], s["pcd_valid_mask"], s["vertex_features"], s["vertices"],
+                         s["vertices_valid_mask"], None, s["gripper_history"], run_inference=True)[0]
+
+    def timed():
+        infer()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            infer()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    eager = timed()
+    model.enable_graph_sampling(True)
+    graphed = timed()  # its warm-up call captures the graph
+    out = {"batch": 1, "diffusion_steps": cfg.diffusion_timesteps, "eager_ms": eager, "hip_graph_ms": graphed,
+           "inferences_per_s_hip_graph": 1e3 / graphed, "dtype": "f32"}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32):
     """Policy training step/s (second half of the BASELINE metric; config 5): diffuser_actor, RGBD_AND_MESH, per-GPU batch 32,
     one 512x512 camera, 2048 vertices x 768 features, frozen ViT-B/16-shaped backbone (random-init stand-in for RADIO v2.5-B),
@@ -301,6 +337,7 @@ def main():
     ap.add_argument("--no-ref-shape", action="store_true", help="skip the short run at the reference's real shape (512x512x768)")
     ap.add_argument("--no-train", action="store_true", help="skip the policy training-step measurement")
     ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--no-infer", action="store_true", help="skip the policy inference latency leg")
     ap.add_argument("--no-backproj", action="store_true", help="skip the back-projection leg (GPU kernel + torch-CPU baseline)")
     args = ap.parse_args()
 
@@ -371,6 +408,7 @@ def main():
         if dist is not None:
             dist.barrier()
         train = run_training(device, world, steps=args.train_steps)
+    infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
@@ -452,6 +490,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_us_per_launch": breakdown,
             "reference_shape": ref_shape,
+            "policy_inference": infer,
             "backprojection": backproj,
             "train": train,
         }

@@ -159,33 +159,41 @@ class DiffusionHead(nn.Module):
         self.head_yaw_out = nn.Sequential(nn.Linear(D * cfg.ngrippers, D), nn.ReLU(), nn.Linear(D, 1)) if cfg.predict_head_yaw else None
         self.drop = nn.Dropout(p)
 
-    def forward(self, trajectory, timestep, enc, need_weights: bool = False):
-        """trajectory (B,L,ngrip,9) noisy sample, timestep (B,), enc = Encoder outputs.
-        Returns (pred (B,L,ngrip,10), head_yaw (B,L,1) or None, cross-attention weights or None)."""
-        cfg, D = self.cfg, self.cfg.embedding_dim
-        B, L, G, _ = trajectory.shape
-        nt = L * G
-        tokens = self.drop(self.traj_encoder(trajectory)).flatten(1, 2)
-        tokens = tokens + sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
-        cond = self.time_mlp(sinusoidal_embedding(timestep, D)) + self.history_mlp(enc["history_feats"].flatten(1))
-
+    def prepare_context(self, enc):
+        """Everything the head needs from the encoder outputs that does not depend on the denoising step: masks made safe
+        against fully masked samples (branch-free: no host synchronisation, so the sampling loop can be captured in a HIP
+        graph), rotary embeddings of the context / sub-sampled context positions, the history conditioning."""
+        D = self.cfg.embedding_dim
         ctx_mask, fps_mask = enc["context_mask"], enc["fps_mask"]
         ctx_feats, fps_feats = enc["context_feats"], enc["fps_feats"]
         # a sample whose context is fully masked would give NaN attention rows: attend to (zeroed) everything instead
         empty, empty_fps = ~ctx_mask.any(dim=-1), ~fps_mask.any(dim=-1)
-        if bool(empty.any()) or bool(empty_fps.any()):
-            ctx_mask = ctx_mask | empty[:, None]
-            fps_mask = fps_mask | empty_fps[:, None]
-            ctx_feats = ctx_feats * (~empty)[:, None, None]
-            fps_feats = fps_feats * (~empty_fps)[:, None, None]
+        ctx_mask = ctx_mask | empty[:, None]
+        fps_mask = fps_mask | empty_fps[:, None]
+        ctx_feats = ctx_feats * (~empty)[:, None, None]      # x * 1.0 is exact: samples with context are untouched
+        fps_feats = fps_feats * (~empty_fps)[:, None, None]
+        return {"ctx_feats": ctx_feats, "fps_feats": fps_feats, "ctx_pad": ~ctx_mask, "fps_pad": ~fps_mask,
+                "ctx_rot": rotary3d(enc["context_pos"], D), "fps_rot": rotary3d(enc["fps_pos"], D),
+                "history": self.history_mlp(enc["history_feats"].flatten(1))}
+
+    def forward(self, trajectory, timestep, enc, need_weights: bool = False, prepared=None):
+        """trajectory (B,L,ngrip,9) noisy sample, timestep (B,), enc = Encoder outputs (`prepared` = prepare_context(enc),
+        computed here when not given).  Returns (pred (B,L,ngrip,10), head_yaw (B,L,1) or None, cross-attention weights or None)."""
+        cfg, D = self.cfg, self.cfg.embedding_dim
+        B, L, G, _ = trajectory.shape
+        nt = L * G
+        P = prepared if prepared is not None else self.prepare_context(enc)
+        tokens = self.drop(self.traj_encoder(trajectory)).flatten(1, 2)
+        tokens = tokens + sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
+        cond = self.time_mlp(sinusoidal_embedding(timestep, D)) + P["history"]
+        ctx_feats, fps_feats, fps_rot = P["ctx_feats"], P["fps_feats"], P["fps_rot"]
 
         traj_rot = rotary3d(trajectory[..., :3].flatten(1, 2), D)
-        tokens, weights = self.cross_attn(tokens, ctx_feats, cond, traj_rot, rotary3d(enc["context_pos"], D),
-                                          key_padding_mask=~ctx_mask, need_weights=need_weights)
+        tokens, weights = self.cross_attn(tokens, ctx_feats, cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"],
+                                          need_weights=need_weights)
         seq = torch.cat([tokens, fps_feats], dim=1)
-        fps_rot = rotary3d(enc["fps_pos"], D)
         seq_rot = (torch.cat([traj_rot[0], fps_rot[0]], dim=1), torch.cat([traj_rot[1], fps_rot[1]], dim=1))
-        pad = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=seq.device), ~fps_mask], dim=1)
+        pad = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=seq.device), P["fps_pad"]], dim=1)
         seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
         rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
         pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
@@ -207,6 +215,8 @@ class DiffuserActor(nn.Module):
         self.prediction_head = DiffusionHead(cfg)
         self.position_noise_scheduler = DDPMScheduler(cfg.diffusion_timesteps, "scaled_linear")
         self.rotation_noise_scheduler = DDPMScheduler(cfg.diffusion_timesteps, "squaredcos_cap_v2")
+        self._graph_sampler = None       # see enable_graph_sampling()
+        self._inference_timesteps = []
 
     # -- shared encoding --------------------------------------------------------------------------------------------------
     def encode_inputs(self, rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices, vertices_valid_mask, instruction,
@@ -235,20 +245,42 @@ class DiffuserActor(nn.Module):
 
     # -- inference: full reverse diffusion ------------------------------------------------------------------------------
     @torch.no_grad()
-    def sample_trajectory(self, enc, batch: int, device, generator=None):
+    def _denoise(self, enc, noise):
+        """The reverse diffusion loop as a pure function of tensors: noise[0] is x_T, noise[1 + k] feeds the variance term
+        of step k.  No host synchronisation, no RNG: eager and HIP-graph replays give identical results."""
         cfg = self.cfg
-        shape = (batch, cfg.prediction_horizon, cfg.ngrippers, 9)
-        traj = torch.randn(shape, device=device, generator=generator)
-        self.position_noise_scheduler.set_timesteps(cfg.diffusion_timesteps)
-        self.rotation_noise_scheduler.set_timesteps(cfg.diffusion_timesteps)
+        traj = noise[0]
+        batch, device = traj.shape[0], traj.device
         pred = head_yaw = None
-        for t in self.position_noise_scheduler.timesteps.tolist():
+        prepared = self.prediction_head.prepare_context(enc)  # step-invariant part of the head, once per inference
+        for k, t in enumerate(self._inference_timesteps):
             ts = torch.full((batch,), t, dtype=torch.long, device=device)
-            pred, head_yaw, _ = self.prediction_head(traj, ts, enc)
-            pos = self.position_noise_scheduler.step(pred[..., :3], t, traj[..., :3], generator)
-            rot = self.rotation_noise_scheduler.step(pred[..., 3:9], t, traj[..., 3:9], generator)
+            pred, head_yaw, _ = self.prediction_head(traj, ts, enc, prepared=prepared)
+            pos = self.position_noise_scheduler.step(pred[..., :3], t, traj[..., :3], noise=noise[1 + k][..., :3])
+            rot = self.rotation_noise_scheduler.step(pred[..., 3:9], t, traj[..., 3:9], noise=noise[1 + k][..., 3:9])
             traj = torch.cat([pos, rot], dim=-1)
         return torch.cat([traj, pred[..., 9:]], dim=-1), head_yaw  # openness / head yaw are not diffused
+
+    def sample_trajectory(self, enc, batch: int, device, generator=None):
+        """DDPM sampling of the trajectory (diffuser_actor.py:conditional_sample).  All Gaussian noise of the loop is drawn
+        up front in ONE call ([1 + T, B, L, G, 9]); with ``enable_graph_sampling()`` the loop itself is one HIP-graph launch."""
+        cfg = self.cfg
+        self.position_noise_scheduler.set_timesteps(cfg.diffusion_timesteps)
+        self.rotation_noise_scheduler.set_timesteps(cfg.diffusion_timesteps)
+        self._inference_timesteps = self.position_noise_scheduler.timesteps.tolist()
+        shape = (1 + len(self._inference_timesteps), batch, cfg.prediction_horizon, cfg.ngrippers, 9)
+        noise = torch.randn(shape, device=device, generator=generator)
+        if self._graph_sampler is not None and torch.device(device).type == "cuda" and not torch.is_grad_enabled():
+            return self._graph_sampler.run(enc, noise)
+        return self._denoise(enc, noise)
+
+    def enable_graph_sampling(self, on: bool = True) -> None:
+        """Replay the denoising loop (T steps x ~150 small kernels, launch-bound at batch 1) as a captured HIP graph.
+        Used under torch.no_grad() / inference_mode on the GPU; captured per distinct input shape, weights are read at
+        replay time (loading new weights into the same parameters needs no re-capture)."""
+        from .graph_sampler import GraphSampler
+
+        self._graph_sampler = GraphSampler(self) if on else None
 
     # -- forward --------------------------------------------------------------------------------------------------------
     def forward(self, gt_gripper_pred, gt_head_yaw, rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices,

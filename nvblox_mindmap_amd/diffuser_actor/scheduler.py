@@ -45,8 +45,10 @@ class DDPMScheduler:
         shape = (-1,) + (1,) * (original.ndim - 1)
         return acp.sqrt().reshape(shape) * original + (1.0 - acp).sqrt().reshape(shape) * noise
 
-    def step(self, model_output: torch.Tensor, t: int, sample: torch.Tensor, generator=None) -> torch.Tensor:
-        """One reverse step x_t -> x_{t-1} from the predicted noise (the timestep grid may be strided)."""
+    def step(self, model_output: torch.Tensor, t: int, sample: torch.Tensor, generator=None, noise: torch.Tensor = None) -> torch.Tensor:
+        """One reverse step x_t -> x_{t-1} from the predicted noise (the timestep grid may be strided).  `noise`: standard
+        normal tensor of the sample's shape to use for the variance term instead of drawing one (pre-drawn noise makes the
+        step a pure function of tensors: capturable in a HIP graph, and identical between eager and captured sampling)."""
         t = int(t)
         stride = self.num_train_timesteps // len(self.timesteps)
         prev_t = t - stride
@@ -63,6 +65,7 @@ class DDPMScheduler:
         prev = c_x0 * x0 + c_xt * sample
         if t > 0:
             variance = max(beta_prod_prev / beta_prod_t * beta_t, 1e-20)
-            noise = torch.randn(sample.shape, dtype=sample.dtype, device=sample.device, generator=generator)
+            if noise is None:
+                noise = torch.randn(sample.shape, dtype=sample.dtype, device=sample.device, generator=generator)
             prev = prev + variance ** 0.5 * noise
         return prev

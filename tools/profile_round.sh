@@ -6,7 +6,7 @@ tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
-args="bench.py --steps 100 --warmup 10 --cpu-sample 0 --no-profile --no-train --no-backproj --no-ref-shape"
+args="bench.py --steps 100 --warmup 10 --cpu-sample 0 --no-profile --no-train --no-infer --no-backproj --no-ref-shape"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o $tag -- python3 $args > $out/trace.log 2>&1
 echo "trace rc=$?"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o $tag -- python3 $args > $out/fetch.log 2>&1
