@@ -279,11 +279,20 @@ def run_policy_inference(device, reps=3):
         torch.cuda.synchronize(device)
         return (time.perf_counter() - t0) / reps * 1e3
 
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActor
+
     eager = timed()
     model.enable_graph_sampling(True)
     graphed = timed()  # its warm-up call captures the graph
+    DiffuserActor.enable_fused_inference(True)  # fused rotary / AdaLN / attention / scheduler kernels, cached context K/V
+    try:
+        fused = timed()
+    finally:
+        DiffuserActor.enable_fused_inference(False)
+        model.enable_graph_sampling(False)
     out = {"batch": 1, "diffusion_steps": cfg.diffusion_timesteps, "eager_ms": eager, "hip_graph_ms": graphed,
-           "inferences_per_s_hip_graph": 1e3 / graphed, "dtype": "f32"}
+           "fused_ops_hip_graph_ms": fused, "inferences_per_s": 1e3 / fused, "dtype": "f32",
+           "note": "hip_graph: same kernels, bit-identical; fused_ops: agrees to float rounding (tests/test_gpu_policy.py)"}
     del model
     torch.cuda.empty_cache()
     return out

@@ -246,6 +246,24 @@ int mmf_integrate_frame_desc(mmf_handle h, int mapper_id, const mmf_frame* frame
 int mmf_farthest_point_sampling(const float* x_dev, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx_dev,
                                 void* stream);
 
+/* Inference-side fused ops of the diffusion head (no autograd; the training path keeps the composite torch ops).
+ * mmf_rotary_apply: apply_rotary of diffuser_actor/position_encodings.py (x*cos + rotate_pairs(x)*sin), x [rows,D] with a
+ *   row stride (a column slice of a wider projection is fine), cos/sin/out [rows,D] contiguous -- same float operations.
+ * mmf_adaln_modulate: x*(1+scale)+shift of the AdaLN blocks (diffuser_actor/layers.py), x/out [B,L,D], scale_shift [B,2D].
+ * mmf_attention_small: softmax(q k^T/sqrt(d) + key padding) v per head for small problems (head_dim in {8,15,16,20,24,32}), fp32;
+ *   q/out [B,Lq,heads*d], k/v [B,Lk,heads*d] with row strides, key_padding [B,Lk] bytes (1 = ignore) or NULL.  Agrees with
+ *   torch's SDPA math path to float rounding (not bit for bit: different summation order).
+ * mmf_ddpm_step: DDPMScheduler.step of the position (channels [0,split)) and rotation ([split,C)) schedulers in one launch:
+ *   x0 = (x - s1*eps)*inv_s2 [clamp +-clip if clip > 0]; prev = c0*x0 + c1*x [+ sigma*noise if sigma > 0]; x/noise/out [rows,C],
+ *   eps [rows, >=C] with a row stride; coef = {s1, inv_s2, c0, c1, sigma, clip} per scheduler (host). */
+int mmf_ddpm_step(const float* x_dev, const float* eps_dev, long long eps_row_stride, const float* noise_dev, float* out_dev,
+                  long long rows, int C, int split, const float* coef_a_host6, const float* coef_b_host6, void* stream);
+int mmf_rotary_apply(const float* x_dev, long long x_row_stride, const float* cos_dev, const float* sin_dev, float* out_dev,
+                     long long rows, int D, void* stream);
+int mmf_adaln_modulate(const float* x_dev, const float* scale_shift_dev, float* out_dev, int B, int L, int D, void* stream);
+int mmf_attention_small(const float* q_dev, const float* k_dev, long long k_row_stride, const float* v_dev, long long v_row_stride,
+                        const uint8_t* key_padding_dev, float* out_dev, int B, int Lq, int Lk, int heads, int head_dim, void* stream);
+
 /* ---- diagnostics / measurement --------------------------------------------------------------- */
 /* Last sphere-traced synthetic depth image of the mapper: dims, then copy to out [Hs,Ws] f32. */
 int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws);

@@ -113,6 +113,10 @@ SIGNATURES = {
     "mmf_depth_mask": (_I, [_VP, _VP, _I, _I, _F, _VP, _VP]),
     "mmf_frame_masks": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "mmf_upsample_features": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _VP]),
+    "mmf_rotary_apply": (_I, [_VP, C.c_longlong, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
+    "mmf_adaln_modulate": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmf_ddpm_step": (_I, [_VP, _VP, C.c_longlong, _VP, _VP, C.c_longlong, _I, _I, _VP, _VP, _VP]),
+    "mmf_attention_small": (_I, [_VP, _VP, C.c_longlong, _VP, C.c_longlong, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmf_farthest_point_sampling": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "mmf_get_synthetic_depth_dims": (_I, [_VP, _I, _PI, _PI]),
     "mmf_get_synthetic_depth": (_I, [_VP, _I, _VP, _VP]),

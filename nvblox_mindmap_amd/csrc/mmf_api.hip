@@ -1357,6 +1357,38 @@ int mmf_farthest_point_sampling(const float* x, int B, int N, int C, int npoints
   return check_launch();
 }
 
+// ---- inference-side fused ops of the diffusion head ------------------------------------------------------------------
+int mmf_rotary_apply(const float* x, long long x_row_stride, const float* cos_, const float* sin_, float* out, long long rows, int D,
+                     void* stream) {
+  if (!x || !cos_ || !sin_ || !out || rows < 0 || D <= 0 || (D & 1) || x_row_stride < D)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_rotary_apply");
+  launch_rotary_apply(x, x_row_stride, cos_, sin_, out, rows, D, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_adaln_modulate(const float* x, const float* scale_shift, float* out, int B, int L, int D, void* stream) {
+  if (!x || !scale_shift || !out || B <= 0 || L <= 0 || D <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_adaln_modulate");
+  launch_adaln_modulate(x, scale_shift, out, B, L, D, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_ddpm_step(const float* x, const float* eps, long long eps_row_stride, const float* noise, float* out, long long rows, int C,
+                  int split, const float* coef_a_host6, const float* coef_b_host6, void* stream) {
+  if (!x || !eps || !noise || !out || !coef_a_host6 || !coef_b_host6 || rows < 0 || C <= 0 || split < 0 || split > C || eps_row_stride < C)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_ddpm_step");
+  launch_ddpm_step(x, eps, eps_row_stride, noise, out, rows, C, split, coef_a_host6, coef_b_host6, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_attention_small(const float* q, const float* k, long long k_row_stride, const float* v, long long v_row_stride,
+                        const uint8_t* key_padding, float* out, int B, int Lq, int Lk, int heads, int head_dim, void* stream) {
+  if (!q || !k || !v || !out || k_row_stride < (long long)heads * head_dim || v_row_stride < (long long)heads * head_dim)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_small");
+  if (launch_attention_small(q, k, k_row_stride, v, v_row_stride, key_padding, out, B, Lq, Lk, heads, head_dim, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_attention_small supports head_dim 8, 15, 16, 20, 24, 32");
+  return check_launch();
+}
+
 // ---- diagnostics ----------------------------------------------------------------------------------
 int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws) {
   Mapper* m;

@@ -107,4 +107,13 @@ void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half
 // mmf_kernels_fps.hip
 int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s);
 
+// mmf_kernels_policy.hip (inference-side fused ops of the diffusion head)
+void launch_rotary_apply(const float* x, long long x_stride, const float* cs, const float* sn, float* out, long long rows, int D,
+                         hipStream_t s);
+void launch_adaln_modulate(const float* x, const float* ss, float* out, int B, int L, int D, hipStream_t s);
+void launch_ddpm_step(const float* x, const float* eps, long long eps_stride, const float* noise, float* out, long long rows, int C,
+                      int split, const float* coefA, const float* coefB, hipStream_t s);
+int launch_attention_small(const float* q, const float* k, long long k_stride, const float* v, long long v_stride, const uint8_t* pad,
+                           float* out, int B, int Lq, int Lk, int H, int d, hipStream_t s);
+
 }  // namespace mmf

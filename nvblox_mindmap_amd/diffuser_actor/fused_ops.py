@@ -1,0 +1,75 @@
+"""Inference-only fused HIP ops of the diffusion head (libmmfusion: mmf_rotary_apply, mmf_adaln_modulate,
+mmf_attention_small).  No autograd: callers use them under torch.no_grad() and keep the composite torch ops for training."""
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+
+def rotary_apply(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """layers.apply_rotary(x, cos, sin) in one kernel (identical float operations)."""
+    D = x.shape[-1]
+    shape = x.shape
+    if x.dim() == 3 and x.stride(-1) == 1 and x.stride(0) == x.shape[1] * x.stride(1):
+        rows, stride = x.shape[0] * x.shape[1], x.stride(1)  # e.g. the key half of a fused key/value projection
+    else:
+        x = x.contiguous()
+        rows, stride = x.numel() // D, D
+    cos = cos.expand(shape).contiguous()
+    sin = sin.expand(shape).contiguous()
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mmf_rotary_apply(_lib.dptr(x), stride, _lib.dptr(cos), _lib.dptr(sin), _lib.dptr(out), rows, D,
+                                           _lib.stream_ptr(x.device)), "mmf_rotary_apply")
+    return out
+
+
+def adaln_modulate(x: torch.Tensor, scale_shift: torch.Tensor) -> torch.Tensor:
+    """x * (1 + scale[:, None]) + shift[:, None] with scale_shift = (scale | shift) [B, 2D], x [B, L, D]."""
+    x = x.contiguous()
+    ss = scale_shift.contiguous()
+    B, L, D = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mmf_adaln_modulate(_lib.dptr(x), _lib.dptr(ss), _lib.dptr(out), B, L, D, _lib.stream_ptr(x.device)),
+               "mmf_adaln_modulate")
+    return out
+
+
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_padding_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d) + padding) v per head.  q [B,Lq,D]; k, v [B,Lk,D], possibly column slices of one
+    [B,Lk,2D] projection (row stride 2D); key_padding_mask [B,Lk] bool, True = ignore."""
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    q = q.contiguous()
+
+    def strided(t):
+        if t.stride(-1) == 1 and t.stride(0) == Lk * t.stride(1):
+            return t, t.stride(1)
+        t = t.contiguous()
+        return t, D
+
+    k, ks = strided(k)
+    v, vs = strided(v)
+    pad = None if key_padding_mask is None else key_padding_mask.contiguous().view(torch.uint8)
+    out = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().mmf_attention_small(_lib.dptr(q), _lib.dptr(k), ks, _lib.dptr(v), vs, _lib.dptr(pad), _lib.dptr(out), B, Lq,
+                                              Lk, heads, D // heads, _lib.stream_ptr(q.device)), "mmf_attention_small")
+    return out
+
+
+def ddpm_step(traj: torch.Tensor, pred: torch.Tensor, noise: torch.Tensor, coef_pos, coef_rot, split: int = 3) -> torch.Tensor:
+    """Both schedulers' reverse step on the trajectory in one launch: traj / noise [..., C], pred [..., >= C] (the head's
+    output carries extra channels), coefficients from DDPMScheduler.step_coefficients."""
+    import ctypes as Ct
+
+    traj = traj.contiguous()
+    noise = noise.contiguous()
+    pred = pred.contiguous()
+    Cc = traj.shape[-1]
+    rows = traj.numel() // Cc
+    out = torch.empty_like(traj)
+    a = (Ct.c_float * 6)(*coef_pos)
+    b = (Ct.c_float * 6)(*coef_rot)
+    _lib.check(_lib.lib().mmf_ddpm_step(_lib.dptr(traj), _lib.dptr(pred), pred.shape[-1], _lib.dptr(noise), _lib.dptr(out), rows, Cc, split,
+                                        Ct.cast(a, Ct.c_void_p), Ct.cast(b, Ct.c_void_p), _lib.stream_ptr(traj.device)), "mmf_ddpm_step")
+    return out

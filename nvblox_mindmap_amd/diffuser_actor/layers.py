@@ -9,6 +9,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Inference fast path (DiffuserActor.enable_fused_inference): fused HIP ops instead of the composite torch ops wherever a
+# block runs without autograd on CUDA float32 tensors.  Rotary / AdaLN are the same float operations; the attention core
+# agrees with the SDPA math path to rounding.
+FUSED_INFERENCE = False
+
+
+def _fused(x: torch.Tensor) -> bool:
+    return FUSED_INFERENCE and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
 def sinusoidal_embedding(x: torch.Tensor, dim: int) -> torch.Tensor:
     """(B,) scalars -> (B,dim): [sin(x w_k) ... , cos(x w_k) ...], w_k = 10000^(-k/(dim/2-1))."""
     half = dim // 2
@@ -35,6 +45,26 @@ def apply_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch
     return x * cos + x_rot * sin
 
 
+class AdaLNBatch:
+    """The scale/shift projections of many AdaLN blocks from ONE GEMM: every block applies its own Linear to the same
+    silu(cond), so their weights are stacked once and a forward pass computes all of them together (fused inference path)."""
+
+    def __init__(self, modules):
+        self.index = {id(m): i for i, m in enumerate(modules)}
+        self.weight = torch.cat([m.proj.weight for m in modules], dim=0)
+        self.bias = torch.cat([m.proj.bias for m in modules], dim=0)
+        self.width = modules[0].proj.out_features
+        self.all = None
+
+    def compute(self, cond_act: torch.Tensor) -> "AdaLNBatch":
+        self.all = F.linear(cond_act, self.weight, self.bias)
+        return self
+
+    def lookup(self, module) -> torch.Tensor:
+        i = self.index[id(module)]
+        return self.all[:, i * self.width:(i + 1) * self.width]
+
+
 class AdaLN(nn.Module):
     """x * (1 + scale(c)) + shift(c), conditioning vector c: (B,dim); zero-initialised (starts as identity)."""
 
@@ -44,8 +74,18 @@ class AdaLN(nn.Module):
         nn.init.zeros_(self.proj.weight)
         nn.init.zeros_(self.proj.bias)
 
-    def forward(self, x: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
-        scale, shift = self.proj(F.silu(cond)).chunk(2, dim=-1)
+    def forward(self, x: torch.Tensor, cond: torch.Tensor, cond_act=None) -> torch.Tensor:
+        """cond_act = F.silu(cond) if the caller already has it (it is the same for every block of a forward pass), or an
+        AdaLNBatch holding this block's projection already."""
+        if isinstance(cond_act, AdaLNBatch):
+            ss = cond_act.lookup(self)
+        else:
+            ss = self.proj(F.silu(cond) if cond_act is None else cond_act)
+        if _fused(x) and x.dim() == 3:
+            from .fused_ops import adaln_modulate
+
+            return adaln_modulate(x, ss)
+        scale, shift = ss.chunk(2, dim=-1)
         return x * (1 + scale[:, None, :]) + shift[:, None, :]
 
 
@@ -64,11 +104,30 @@ class RelativeAttention(nn.Module):
             nn.init.zeros_(lin.bias)
         nn.init.zeros_(self.out_proj.bias)
 
+    def project_kv(self, memory: torch.Tensor, kv_rot=None):
+        """Keys (rotated) and values of `memory` for the fused path: computed once per inference for a memory that does not
+        change between denoising steps (the context of the cross-attention layers)."""
+        from .fused_ops import rotary_apply
+
+        D = self.dim
+        kv = self.kv_proj(memory)
+        k = kv[..., :D]
+        return (rotary_apply(k, *kv_rot) if kv_rot is not None else k), kv[..., D:]
+
     def forward(self, query: torch.Tensor, memory: torch.Tensor, q_rot=None, kv_rot=None,
-                key_padding_mask: Optional[torch.Tensor] = None, need_weights: bool = False):
-        """query (B,Lq,D), memory (B,Lk,D); key_padding_mask (B,Lk) True = ignore.  Returns (out, weights or None)."""
+                key_padding_mask: Optional[torch.Tensor] = None, need_weights: bool = False, kv_cache=None):
+        """query (B,Lq,D), memory (B,Lk,D); key_padding_mask (B,Lk) True = ignore.  Returns (out, weights or None).
+        kv_cache: (keys, values) from project_kv, fused inference path only."""
         B, Lq, D = query.shape
         Lk = memory.shape[1]
+        if _fused(query) and not need_weights and (D // self.heads) in (8, 15, 16, 20, 24, 32):  # head dims the kernel is built for
+            from .fused_ops import attention_small, rotary_apply
+
+            q = self.q_proj(query)
+            if q_rot is not None:
+                q = rotary_apply(q, *q_rot)
+            k, v = kv_cache if kv_cache is not None else self.project_kv(memory, kv_rot if q_rot is not None else None)
+            return self.out_proj(attention_small(q, k, v, key_padding_mask, self.heads)), None
         q = self.q_proj(query)
         k, v = self.kv_proj(memory).chunk(2, dim=-1)
         if q_rot is not None:
@@ -104,9 +163,10 @@ class AttentionBlock(nn.Module):
         self.drop = nn.Dropout(dropout)
         self.adaln = AdaLN(dim) if use_adaln else None
 
-    def forward(self, query, memory, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False):
-        q_in = self.adaln(query, cond) if (self.adaln is not None and cond is not None) else query
-        out, w = self.attn(q_in, memory, q_rot, kv_rot, key_padding_mask, need_weights)
+    def forward(self, query, memory, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False, cond_act=None,
+                kv_cache=None):
+        q_in = self.adaln(query, cond, cond_act) if (self.adaln is not None and cond is not None) else query
+        out, w = self.attn(q_in, memory, q_rot, kv_rot, key_padding_mask, need_weights, kv_cache)
         return self.norm(query + self.drop(out)), w
 
 
@@ -122,9 +182,9 @@ class FeedForwardBlock(nn.Module):
         self.drop = nn.Dropout(dropout)
         self.adaln = AdaLN(dim) if use_adaln else None
 
-    def forward(self, x, cond=None):
+    def forward(self, x, cond=None, cond_act=None):
         if self.adaln is not None and cond is not None:
-            x = self.adaln(x, cond)
+            x = self.adaln(x, cond, cond_act)
         return self.norm(x + self.drop(self.fc2(self.drop(F.relu(self.fc1(x))))))
 
 
@@ -139,11 +199,15 @@ class AttentionStack(nn.Module):
         self.attn = nn.ModuleList([AttentionBlock(dim, heads, dropout, use_adaln) for _ in range(num_layers)])
         self.ffw = nn.ModuleList([FeedForwardBlock(dim, dim, dropout, use_adaln) for _ in range(num_layers)])
 
-    def forward(self, query, memory=None, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False):
+    def forward(self, query, memory=None, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False,
+                cond_act=None, kv_caches=None):
+        """cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
+        is constant across calls (cross-attention at inference)."""
         weights = None
-        for attn, ffw in zip(self.attn, self.ffw):
+        for li, (attn, ffw) in enumerate(zip(self.attn, self.ffw)):
             mem = query if self.self_attention else memory
             rot = q_rot if self.self_attention else kv_rot
-            query, weights = attn(query, mem, cond, q_rot, rot, key_padding_mask, need_weights)
-            query = ffw(query, cond)
+            cache = kv_caches[li] if (kv_caches is not None and not self.self_attention) else None
+            query, weights = attn(query, mem, cond, q_rot, rot, key_padding_mask, need_weights, cond_act, cache)
+            query = ffw(query, cond, cond_act)
         return query, weights

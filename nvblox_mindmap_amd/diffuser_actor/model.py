@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from ..nvblox_torch.timer import Timer
 from .backbone import VitBackbone
 from .fps import farthest_point_sampling, farthest_point_sampling_reference
+from . import layers as L
 from .layers import AttentionBlock, AttentionStack, FeedForwardBlock, rotary3d, sinusoidal_embedding
 from .loss import LossWeights, compute_loss
 from .rotations import normalize_pointcloud, normalize_pos, normalize_trajectory, unnormalize_trajectory
@@ -172,11 +173,27 @@ class DiffusionHead(nn.Module):
         fps_mask = fps_mask | empty_fps[:, None]
         ctx_feats = ctx_feats * (~empty)[:, None, None]      # x * 1.0 is exact: samples with context are untouched
         fps_feats = fps_feats * (~empty_fps)[:, None, None]
-        return {"ctx_feats": ctx_feats, "fps_feats": fps_feats, "ctx_pad": ~ctx_mask, "fps_pad": ~fps_mask,
-                "ctx_rot": rotary3d(enc["context_pos"], D), "fps_rot": rotary3d(enc["fps_pos"], D),
-                "history": self.history_mlp(enc["history_feats"].flatten(1))}
+        P = {"ctx_feats": ctx_feats, "fps_feats": fps_feats, "ctx_pad": ~ctx_mask, "fps_pad": ~fps_mask,
+             "ctx_rot": rotary3d(enc["context_pos"], D), "fps_rot": rotary3d(enc["fps_pos"], D),
+             "history": self.history_mlp(enc["history_feats"].flatten(1)), "cross_kv": None}
+        P["adaln"] = None
+        if L._fused(ctx_feats):  # keys / values of the (step-invariant) context, once per inference instead of per step
+            P["cross_kv"] = [blk.attn.project_kv(ctx_feats, P["ctx_rot"]) for blk in self.cross_attn.attn]
+            P["adaln"] = L.AdaLNBatch([mod for mod in self.modules() if isinstance(mod, L.AdaLN)])
+        return P
 
-    def forward(self, trajectory, timestep, enc, need_weights: bool = False, prepared=None):
+    def time_embeddings(self, timesteps, device):
+        """time_mlp(sinusoidal(t)) for a list of timesteps in one batched pass ([T, D]): the time part of the conditioning
+        vector depends on the step only, not on the inputs."""
+        timesteps = list(timesteps)
+        n = len(timesteps)
+        stride = timesteps[0] - timesteps[1] if n > 1 else 1
+        assert all(timesteps[i] == timesteps[0] - i * stride for i in range(n)), "evenly strided, descending timesteps"
+        # built on the device (no host-to-device copy: this runs inside HIP-graph capture)
+        ts = timesteps[0] - torch.arange(n, device=device, dtype=torch.long) * stride
+        return self.time_mlp(sinusoidal_embedding(ts, self.cfg.embedding_dim))
+
+    def forward(self, trajectory, timestep, enc, need_weights: bool = False, prepared=None, time_emb=None):
         """trajectory (B,L,ngrip,9) noisy sample, timestep (B,), enc = Encoder outputs (`prepared` = prepare_context(enc),
         computed here when not given).  Returns (pred (B,L,ngrip,10), head_yaw (B,L,1) or None, cross-attention weights or None)."""
         cfg, D = self.cfg, self.cfg.embedding_dim
@@ -185,18 +202,21 @@ class DiffusionHead(nn.Module):
         P = prepared if prepared is not None else self.prepare_context(enc)
         tokens = self.drop(self.traj_encoder(trajectory)).flatten(1, 2)
         tokens = tokens + sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
-        cond = self.time_mlp(sinusoidal_embedding(timestep, D)) + P["history"]
+        cond = (self.time_mlp(sinusoidal_embedding(timestep, D)) if time_emb is None else time_emb) + P["history"]
+        cond_act = F.silu(cond)  # every AdaLN block applies the same activation to the same conditioning vector
+        if P.get("adaln") is not None and not need_weights:
+            cond_act = P["adaln"].compute(cond_act)  # ... and all their projections are one GEMM
         ctx_feats, fps_feats, fps_rot = P["ctx_feats"], P["fps_feats"], P["fps_rot"]
 
         traj_rot = rotary3d(trajectory[..., :3].flatten(1, 2), D)
         tokens, weights = self.cross_attn(tokens, ctx_feats, cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"],
-                                          need_weights=need_weights)
+                                          need_weights=need_weights, cond_act=cond_act, kv_caches=None if need_weights else P["cross_kv"])
         seq = torch.cat([tokens, fps_feats], dim=1)
         seq_rot = (torch.cat([traj_rot[0], fps_rot[0]], dim=1), torch.cat([traj_rot[1], fps_rot[1]], dim=1))
         pad = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=seq.device), P["fps_pad"]], dim=1)
-        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
-        rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
-        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad)
+        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
+        rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
+        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
         rot_feat = self.drop(self.rotation_proj(rot_seq[:, :nt]))
         pos_feat = self.drop(self.position_proj(pos_seq[:, :nt]))
         pred = torch.cat([self.position_out(pos_feat), self.rotation_out(rot_feat), self.openness_out(pos_feat)], dim=-1)
@@ -253,7 +273,16 @@ class DiffuserActor(nn.Module):
         batch, device = traj.shape[0], traj.device
         pred = head_yaw = None
         prepared = self.prediction_head.prepare_context(enc)  # step-invariant part of the head, once per inference
+        fused = L._fused(traj)
+        time_table = self.prediction_head.time_embeddings(self._inference_timesteps, device) if fused else None
         for k, t in enumerate(self._inference_timesteps):
+            if fused:
+                from .fused_ops import ddpm_step
+
+                pred, head_yaw, _ = self.prediction_head(traj, None, enc, prepared=prepared, time_emb=time_table[k:k + 1].expand(batch, -1))
+                traj = ddpm_step(traj, pred, noise[1 + k], self.position_noise_scheduler.step_coefficients(t),
+                                 self.rotation_noise_scheduler.step_coefficients(t))
+                continue
             ts = torch.full((batch,), t, dtype=torch.long, device=device)
             pred, head_yaw, _ = self.prediction_head(traj, ts, enc, prepared=prepared)
             pos = self.position_noise_scheduler.step(pred[..., :3], t, traj[..., :3], noise=noise[1 + k][..., :3])
@@ -273,6 +302,12 @@ class DiffuserActor(nn.Module):
         if self._graph_sampler is not None and torch.device(device).type == "cuda" and not torch.is_grad_enabled():
             return self._graph_sampler.run(enc, noise)
         return self._denoise(enc, noise)
+
+    @staticmethod
+    def enable_fused_inference(on: bool = True) -> None:
+        """Use the fused HIP ops (rotary, AdaLN, small attention; cached context keys/values) in blocks that run without
+        autograd on the GPU.  Process-wide switch; training (autograd on) always takes the composite torch ops."""
+        L.FUSED_INFERENCE = bool(on)
 
     def enable_graph_sampling(self, on: bool = True) -> None:
         """Replay the denoising loop (T steps x ~150 small kernels, launch-bound at batch 1) as a captured HIP graph.

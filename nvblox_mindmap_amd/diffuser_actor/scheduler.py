@@ -45,6 +45,26 @@ class DDPMScheduler:
         shape = (-1,) + (1,) * (original.ndim - 1)
         return acp.sqrt().reshape(shape) * original + (1.0 - acp).sqrt().reshape(shape) * noise
 
+    def step_coefficients(self, t: int):
+        """{s1, inv_s2, c0, c1, sigma, clip} of `step` at timestep t as float32 values: x0 = (x - s1*eps)*inv_s2 [clamped];
+        prev = c0*x0 + c1*x + sigma*noise.  (torch divides a tensor by a Python scalar as a multiplication by the
+        float32 reciprocal; inv_s2 is that reciprocal.)"""
+        import numpy as np
+
+        t = int(t)
+        stride = self.num_train_timesteps // len(self.timesteps)
+        prev_t = t - stride
+        acp_t = float(self.alphas_cumprod[t])
+        acp_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        beta_prod_t, beta_prod_prev = 1.0 - acp_t, 1.0 - acp_prev
+        alpha_t = acp_t / acp_prev
+        beta_t = 1.0 - alpha_t
+        sigma = (max(beta_prod_prev / beta_prod_t * beta_t, 1e-20) ** 0.5) if t > 0 else 0.0
+        f32 = np.float32
+        return [float(f32(beta_prod_t ** 0.5)), float(f32(1.0) / f32(acp_t ** 0.5)), float(f32(acp_prev ** 0.5 * beta_t / beta_prod_t)),
+                float(f32(alpha_t ** 0.5 * beta_prod_prev / beta_prod_t)), float(f32(sigma)),
+                float(self.clip_sample_range) if self.clip_sample else 0.0]
+
     def step(self, model_output: torch.Tensor, t: int, sample: torch.Tensor, generator=None, noise: torch.Tensor = None) -> torch.Tensor:
         """One reverse step x_t -> x_{t-1} from the predicted noise (the timestep grid may be strided).  `noise`: standard
         normal tensor of the sample's shape to use for the variance term instead of drawing one (pre-drawn noise makes the

@@ -109,3 +109,69 @@ def test_graph_sampling_matches_eager_sampling():
     assert not torch.equal(graphed[0], graphed[1])
     model.enable_graph_sampling(False)
     assert torch.equal(infer(5, 1), eager[0])
+
+
+def test_fused_inference_ops_match_the_composite_ops():
+    """mmf_rotary_apply / mmf_adaln_modulate are bit-identical to the torch composites; mmf_attention_small matches the
+    SDPA math path to float rounding, with padding masks, for both kernel shapes (many queries / a few queries)."""
+    import torch.nn.functional as F
+
+    from nvblox_mindmap_amd.diffuser_actor import fused_ops as FO
+    from nvblox_mindmap_amd.diffuser_actor.layers import apply_rotary, rotary3d
+
+    torch.manual_seed(0)
+    B, Lq, D, H = 2, 37, 120, 8
+    x = torch.randn(B, Lq, 2 * D, device="cuda")
+    cos, sin = rotary3d(torch.rand(B, Lq, 3, device="cuda") * 2 - 1, D)
+    with torch.no_grad():
+        for view in (x[..., :D], x[..., D:].contiguous()):  # strided column slice and contiguous input
+            assert torch.equal(FO.rotary_apply(view, cos, sin), apply_rotary(view, cos, sin))
+        xs, ss = torch.randn(B, Lq, D, device="cuda"), torch.randn(B, 2 * D, device="cuda")
+        scale, shift = ss.chunk(2, dim=-1)
+        assert torch.equal(FO.adaln_modulate(xs, ss), xs * (1 + scale[:, None, :]) + shift[:, None, :])
+        for (lq, lk) in ((616, 616), (2, 3072), (16, 300), (5, 40)):
+            q, kv = torch.randn(B, lq, D, device="cuda"), torch.randn(B, lk, 2 * D, device="cuda")
+            pad = torch.rand(B, lk, device="cuda") < 0.3
+            pad[:, 0] = False
+            k, v = kv[..., :D], kv[..., D:]
+            got = FO.attention_small(q, k, v, pad, H)
+            qh, kh, vh = (t.reshape(B, -1, H, D // H).transpose(1, 2) for t in (q, k, v))
+            ref = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=(~pad)[:, None, None, :]).transpose(1, 2).reshape(B, lq, D)
+            assert torch.allclose(got, ref, rtol=1e-5, atol=2e-6), float((got - ref).abs().max())
+            got2 = FO.attention_small(q, k.contiguous(), v.contiguous(), None, H)
+            ref2 = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, lq, D)
+            assert torch.allclose(got2, ref2, rtol=1e-5, atol=2e-6)
+
+
+def test_fused_inference_matches_composite_inference():
+    """Whole policy inference with the fused ops (+ cached context keys/values, + HIP graph) against the composite-op run."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, synthetic_batch
+    from nvblox_mindmap_amd.training.trainer import unpack_batch
+
+    cfg = DiffuserActorConfig(data_type="mesh", feature_dim=64, diffusion_timesteps=20)
+    torch.manual_seed(0)
+    model = build_model(cfg, device="cuda").eval()
+    for p in model.parameters():  # AdaLN / output layers start at zero: perturb so that every path matters
+        if p.requires_grad:
+            p.data.add_(0.02 * torch.randn_like(p))
+    s = unpack_batch(cfg, synthetic_batch(cfg, 1, "cuda", num_vertices=3072, seed=3))
+
+    def infer():
+        torch.manual_seed(11)
+        with torch.no_grad():
+            return model(None, None, None, None, None, s["vertex_features"], s["vertices"], s["vertices_valid_mask"], None,
+                         s["gripper_history"], run_inference=True)[0]
+
+    ref = infer()
+    try:
+        DiffuserActor.enable_fused_inference(True)
+        fused = infer()
+        model.enable_graph_sampling(True)
+        fused_graph = infer()
+    finally:
+        DiffuserActor.enable_fused_inference(False)
+        model.enable_graph_sampling(False)
+    assert torch.equal(fused, fused_graph)
+    assert torch.allclose(fused, ref, rtol=1e-3, atol=1e-4), float((fused - ref).abs().max())
+    assert torch.equal(infer(), ref)  # switches off again: the composite path is untouched

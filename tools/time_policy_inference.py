@@ -38,8 +38,15 @@ def main():
     torch.cuda.synchronize()
     capture = (time.perf_counter() - t0) * 1e3
     graphed = timed()
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActor
+
+    DiffuserActor.enable_fused_inference(True)
+    model.enable_graph_sampling(False)
+    fused_eager = timed()
+    model.enable_graph_sampling(True)
+    fused_graph = timed()
     print(f"policy inference B=1, {cfg.diffusion_timesteps} steps: eager {eager:.1f} ms, graph replay {graphed:.1f} ms "
-          f"(first call incl. capture {capture:.0f} ms)")
+          f"(first call incl. capture {capture:.0f} ms); fused ops: eager {fused_eager:.1f} ms, graph replay {fused_graph:.1f} ms")
 
 
 if __name__ == "__main__":
