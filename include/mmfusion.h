@@ -256,6 +256,24 @@ int mmf_farthest_point_sampling(const float* x_dev, int B, int N, int C, int npo
  * mmf_ddpm_step: DDPMScheduler.step of the position (channels [0,split)) and rotation ([split,C)) schedulers in one launch:
  *   x0 = (x - s1*eps)*inv_s2 [clamp +-clip if clip > 0]; prev = c0*x0 + c1*x [+ sigma*noise if sigma > 0]; x/noise/out [rows,C],
  *   eps [rows, >=C] with a row stride; coef = {s1, inv_s2, c0, c1, sigma, clip} per scheduler (host). */
+/* Whole-block kernels of the head's AttentionBlock / FeedForwardBlock at inference (embedding dim D = 120), weights as
+ * the TRANSPOSE of what torch.nn.Linear stores, i.e. [in,out] row-major (coalesced weight fetch), biases [out],
+ * scale_shift [B,2D] or NULL, cos/sin [B*L,D] or both NULL:
+ *   mmf_ffn_block      h = x*(1+scale)+shift; out = LayerNorm(h + fc2(relu(fc1(h))))
+ *   mmf_q_block        out = rotary(q_proj(x*(1+scale)+shift))
+ *   mmf_kv_block       k_out = rotary(kv_proj(memory)[:, :D]), v_out = kv_proj(memory)[:, D:]
+ *   mmf_attn_out_block out = LayerNorm(residual + out_proj(att))
+ * One launch each instead of 3-7; results agree with the composite torch ops to float rounding. */
+int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
+                  const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
+                  int D, void* stream);
+int mmf_q_block(const float* x_dev, const float* scale_shift_dev, const float* Wq_dev, const float* bq_dev, const float* cos_dev,
+                const float* sin_dev, float* out_dev, int B, int L, int D, void* stream);
+int mmf_kv_block(const float* memory_dev, const float* Wkv_dev, const float* bkv_dev, const float* cos_dev, const float* sin_dev,
+                 float* k_out_dev, float* v_out_dev, long long tokens, int D, void* stream);
+int mmf_attn_out_block(const float* att_dev, const float* residual_dev, const float* Wo_dev, const float* bo_dev,
+                       const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, long long tokens, int D,
+                       void* stream);
 int mmf_ddpm_step(const float* x_dev, const float* eps_dev, long long eps_row_stride, const float* noise_dev, float* out_dev,
                   long long rows, int C, int split, const float* coef_a_host6, const float* coef_b_host6, void* stream);
 int mmf_rotary_apply(const float* x_dev, long long x_row_stride, const float* cos_dev, const float* sin_dev, float* out_dev,

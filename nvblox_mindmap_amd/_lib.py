@@ -115,6 +115,10 @@ SIGNATURES = {
     "mmf_upsample_features": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _VP]),
     "mmf_rotary_apply": (_I, [_VP, C.c_longlong, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
     "mmf_adaln_modulate": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmf_ffn_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP]),
+    "mmf_q_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmf_kv_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
+    "mmf_attn_out_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, C.c_longlong, _I, _VP]),
     "mmf_ddpm_step": (_I, [_VP, _VP, C.c_longlong, _VP, _VP, C.c_longlong, _I, _I, _VP, _VP, _VP]),
     "mmf_attention_small": (_I, [_VP, _VP, C.c_longlong, _VP, C.c_longlong, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmf_farthest_point_sampling": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),

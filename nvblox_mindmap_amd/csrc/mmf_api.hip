@@ -1372,6 +1372,42 @@ int mmf_adaln_modulate(const float* x, const float* scale_shift, float* out, int
   return check_launch();
 }
 
+int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
+                  const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
+  if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_ffn_block");
+  if (launch_ffn_block(x, scale_shift, W1, b1, W2, b2, ln_weight, ln_bias, ln_eps, out, B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_ffn_block is built for D = 120");
+  return check_launch();
+}
+
+int mmf_q_block(const float* x, const float* scale_shift, const float* Wq, const float* bq, const float* cos_, const float* sin_,
+                float* out, int B, int L, int D, void* stream) {
+  if (!x || !Wq || !bq || !out || B <= 0 || L <= 0 || ((cos_ == nullptr) != (sin_ == nullptr)))
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_q_block");
+  if (launch_q_block(x, scale_shift, Wq, bq, cos_, sin_, out, B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_q_block is built for D = 120");
+  return check_launch();
+}
+
+int mmf_kv_block(const float* memory, const float* Wkv, const float* bkv, const float* cos_, const float* sin_, float* k_out,
+                 float* v_out, long long tokens, int D, void* stream) {
+  if (!memory || !Wkv || !bkv || !k_out || !v_out || tokens <= 0 || ((cos_ == nullptr) != (sin_ == nullptr)))
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_kv_block");
+  if (launch_kv_block(memory, Wkv, bkv, cos_, sin_, k_out, v_out, tokens, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_kv_block is built for D = 120");
+  return check_launch();
+}
+
+int mmf_attn_out_block(const float* att, const float* residual, const float* Wo, const float* bo, const float* ln_weight,
+                       const float* ln_bias, float ln_eps, float* out, long long tokens, int D, void* stream) {
+  if (!att || !residual || !Wo || !bo || !ln_weight || !ln_bias || !out || tokens <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attn_out_block");
+  if (launch_attn_out_block(att, residual, Wo, bo, ln_weight, ln_bias, ln_eps, out, tokens, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_attn_out_block is built for D = 120");
+  return check_launch();
+}
+
 int mmf_ddpm_step(const float* x, const float* eps, long long eps_row_stride, const float* noise, float* out, long long rows, int C,
                   int split, const float* coef_a_host6, const float* coef_b_host6, void* stream) {
   if (!x || !eps || !noise || !out || !coef_a_host6 || !coef_b_host6 || rows < 0 || C <= 0 || split < 0 || split > C || eps_row_stride < C)

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
                                                        const float* __restrict__ v, long long v_stride,
                                                        const uint8_t* __restrict__ pad, float* __restrict__ out, int Lq, int Lk,
                                                        int H, float scale) {
-  __shared__ float sK[kAttTile][DH + 1];
-  __shared__ float sV[kAttTile][DH + 1];
+  // odd row stride: the 16 key lanes of a query row read 16 consecutive tile rows at the same channel -> 16 distinct banks
+  constexpr int RS = DH | 1;
+  __shared__ float sK[kAttTile][RS];
+  __shared__ float sV[kAttTile][RS];
   __shared__ uint8_t sP[kAttTile];
   const int b = blockIdx.z, h = blockIdx.y;
   const int qi = threadIdx.x >> 4, lane = threadIdx.x & 15;
@@ -243,6 +245,224 @@ static void attention_dispatch(const float* q, const float* k, long long k_strid
                        scale);
   else
     hipLaunchKernelGGL(k_attention_few<DH>, dim3(Lq, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H, scale);
+}
+
+// ---- whole-block kernels for D-channel token streams (D = embedding dim, 120 in the policy) -------------------------------
+// One thread per output channel keeps its weight row(s) in registers (fetched from the TRANSPOSED matrix [in, out], so the
+// fetch is coalesced across threads); a workgroup walks a contiguous range of tokens, the token's activation vector is
+// exchanged through LDS (broadcast reads).  [616 x 120] x [120 x 120] is 18 MFLOP: far too
+// small for a library GEMM launch (6-8 us each) per Linear; here a block of the network is one launch.
+template <int D>
+struct TokLds {
+  float a[D + 8], b[2 * D + 8];
+  float red[8];
+};
+
+template <int D>
+__device__ __forceinline__ float dot_row(const float (&w)[D], const float* __restrict__ s) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < D; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(s + c);
+    acc += w[c] * v.x;
+    acc += w[c + 1] * v.y;
+    acc += w[c + 2] * v.z;
+    acc += w[c + 3] * v.w;
+  }
+  return acc;
+}
+
+// sum over the D active threads (threads >= D contribute 0): wave shuffles + one LDS exchange; result to all threads
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.0f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += red[w];
+  return t;
+}
+
+template <int D, int NT>
+__device__ __forceinline__ float layer_norm_channel(float r, bool active, float gamma, float beta, float eps, float* red) {
+  const float mean = block_sum<NT>(active ? r : 0.0f, red) / (float)D;
+  const float dlt = active ? r - mean : 0.0f;
+  const float var = block_sum<NT>(dlt * dlt, red) / (float)D;
+  return dlt * rsqrtf(var + eps) * gamma + beta;
+}
+
+// FeedForwardBlock at inference: h = x*(1+scale)+shift; out = LayerNorm(h + fc2(relu(fc1(h))))      (hidden width = D)
+template <int D>
+__global__ __launch_bounds__(128) void k_ffn_block(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ W1,
+                                                  const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                  float* __restrict__ out, int L, long long tokens, int tok_per_wg) {
+  __shared__ __attribute__((aligned(16))) TokLds<D> S;
+  const int j = threadIdx.x;
+  const bool act = j < D;
+  float w1[D], w2[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    w1[c] = act ? W1[(size_t)c * D + j] : 0.0f;  // weights arrive transposed ([in, out]): coalesced over threads
+    w2[c] = act ? W2[(size_t)c * D + j] : 0.0f;
+  }
+  const float bb1 = act ? b1[j] : 0.0f, bb2 = act ? b2[j] : 0.0f, gg = act ? gamma[j] : 0.0f, be = act ? beta[j] : 0.0f;
+  const long long t0 = (long long)blockIdx.x * tok_per_wg;
+  for (long long t = t0; t < t0 + tok_per_wg && t < tokens; ++t) {
+    const long long b = t / L;
+    float h = 0.0f;
+    if (act) {
+      h = x[t * D + j];
+      if (ss) h = h * (1.0f + ss[b * 2 * D + j]) + ss[b * 2 * D + D + j];
+      S.a[j] = h;
+    }
+    __syncthreads();
+    const float u = fmaxf(dot_row<D>(w1, S.a) + bb1, 0.0f);
+    if (act) S.b[j] = u;
+    __syncthreads();
+    const float r = h + (dot_row<D>(w2, S.b) + bb2);
+    const float o = layer_norm_channel<D, 128>(r, act, gg, be, eps, S.red);
+    if (act) out[t * D + j] = o;
+  }
+}
+
+// Query side of an AttentionBlock: q = rotary(q_proj(x*(1+scale)+shift))            (ss / cos may be null)
+template <int D>
+__global__ __launch_bounds__(128) void k_q_block(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ Wq,
+                                                const float* __restrict__ bq, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                float* __restrict__ out, int L, long long tokens, int tok_per_wg) {
+  __shared__ __attribute__((aligned(16))) TokLds<D> S;
+  const int j = threadIdx.x;
+  const bool act = j < D;
+  float w[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) w[c] = act ? Wq[(size_t)c * D + j] : 0.0f;  // transposed weights
+  const float bb = act ? bq[j] : 0.0f;
+  const long long t0 = (long long)blockIdx.x * tok_per_wg;
+  for (long long t = t0; t < t0 + tok_per_wg && t < tokens; ++t) {
+    const long long b = t / L;
+    __syncthreads();
+    if (act) {
+      float h = x[t * D + j];
+      if (ss) h = h * (1.0f + ss[b * 2 * D + j]) + ss[b * 2 * D + D + j];
+      S.a[j] = h;
+    }
+    __syncthreads();
+    const float qv = dot_row<D>(w, S.a) + bb;
+    if (!cs) {
+      if (act) out[t * D + j] = qv;
+      continue;
+    }
+    if (act) S.b[j] = qv;
+    __syncthreads();
+    if (act) {
+      const float partner = (j & 1) ? S.b[j - 1] : -S.b[j + 1];  // x_rot = (-x1, x0) per channel pair
+      out[t * D + j] = qv * cs[t * D + j] + partner * sn[t * D + j];
+    }
+  }
+}
+
+// Key / value side: k = rotary(kv_proj(m)[:D]), v = kv_proj(m)[D:]          (2D threads: thread j owns output channel j)
+template <int D>
+__global__ __launch_bounds__(256) void k_kv_block(const float* __restrict__ m, const float* __restrict__ Wkv, const float* __restrict__ bkv,
+                                                 const float* __restrict__ cs, const float* __restrict__ sn, float* __restrict__ kout,
+                                                 float* __restrict__ vout, long long tokens, int tok_per_wg) {
+  __shared__ __attribute__((aligned(16))) TokLds<D> S;
+  const int j = threadIdx.x;
+  const bool act = j < 2 * D;
+  float w[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) w[c] = act ? Wkv[(size_t)c * (2 * D) + j] : 0.0f;  // transposed weights [D, 2D]
+  const float bb = act ? bkv[j] : 0.0f;
+  const long long t0 = (long long)blockIdx.x * tok_per_wg;
+  for (long long t = t0; t < t0 + tok_per_wg && t < tokens; ++t) {
+    __syncthreads();
+    if (j < D) S.a[j] = m[t * D + j];
+    __syncthreads();
+    const float y = dot_row<D>(w, S.a) + bb;
+    if (act) S.b[j] = y;
+    __syncthreads();
+    if (j < D) {
+      float kv = y;
+      if (cs) {
+        const float partner = (j & 1) ? S.b[j - 1] : -S.b[j + 1];
+        kv = y * cs[t * D + j] + partner * sn[t * D + j];
+      }
+      kout[t * D + j] = kv;
+    } else if (act) {
+      vout[t * D + (j - D)] = y;
+    }
+  }
+}
+
+// Output side of an AttentionBlock: out = LayerNorm(res + out_proj(att))
+template <int D>
+__global__ __launch_bounds__(128) void k_attn_out_block(const float* __restrict__ att, const float* __restrict__ res,
+                                                       const float* __restrict__ Wo, const float* __restrict__ bo,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       float* __restrict__ out, long long tokens, int tok_per_wg) {
+  __shared__ __attribute__((aligned(16))) TokLds<D> S;
+  const int j = threadIdx.x;
+  const bool act = j < D;
+  float w[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) w[c] = act ? Wo[(size_t)c * D + j] : 0.0f;  // transposed weights
+  const float bb = act ? bo[j] : 0.0f, gg = act ? gamma[j] : 0.0f, be = act ? beta[j] : 0.0f;
+  const long long t0 = (long long)blockIdx.x * tok_per_wg;
+  for (long long t = t0; t < t0 + tok_per_wg && t < tokens; ++t) {
+    __syncthreads();
+    if (act) S.a[j] = att[t * D + j];
+    __syncthreads();
+    const float r = (act ? res[t * D + j] : 0.0f) + (dot_row<D>(w, S.a) + bb);
+    const float o = layer_norm_channel<D, 128>(r, act, gg, be, eps, S.red);
+    if (act) out[t * D + j] = o;
+  }
+}
+
+static inline int tok_split(long long tokens, int* tok_per_wg) {
+  // enough workgroups to fill the chip, few enough that the per-workgroup weight fetch (58-115 KB) stays small
+  int per = (int)((tokens + 255) / 256);
+  if (per < 1) per = 1;
+  *tok_per_wg = per;
+  return (int)((tokens + per - 1) / per);
+}
+
+int launch_ffn_block(const float* x, const float* ss, const float* W1, const float* b1, const float* W2, const float* b2,
+                     const float* gamma, const float* beta, float eps, float* out, int B, int L, int D, hipStream_t s) {
+  if (D != 120) return 1;
+  int per;
+  const long long tokens = (long long)B * L;
+  const int g = tok_split(tokens, &per);
+  hipLaunchKernelGGL(k_ffn_block<120>, dim3(g), dim3(128), 0, s, x, ss, W1, b1, W2, b2, gamma, beta, eps, out, L, tokens, per);
+  return 0;
+}
+int launch_q_block(const float* x, const float* ss, const float* Wq, const float* bq, const float* cs, const float* sn, float* out,
+                   int B, int L, int D, hipStream_t s) {
+  if (D != 120) return 1;
+  int per;
+  const long long tokens = (long long)B * L;
+  const int g = tok_split(tokens, &per);
+  hipLaunchKernelGGL(k_q_block<120>, dim3(g), dim3(128), 0, s, x, ss, Wq, bq, cs, sn, out, L, tokens, per);
+  return 0;
+}
+int launch_kv_block(const float* m, const float* Wkv, const float* bkv, const float* cs, const float* sn, float* kout, float* vout,
+                    long long tokens, int D, hipStream_t s) {
+  if (D != 120) return 1;
+  int per;
+  const int g = tok_split(tokens, &per);
+  hipLaunchKernelGGL(k_kv_block<120>, dim3(g), dim3(256), 0, s, m, Wkv, bkv, cs, sn, kout, vout, tokens, per);
+  return 0;
+}
+int launch_attn_out_block(const float* att, const float* res, const float* Wo, const float* bo, const float* gamma, const float* beta,
+                          float eps, float* out, long long tokens, int D, hipStream_t s) {
+  if (D != 120) return 1;
+  int per;
+  const int g = tok_split(tokens, &per);
+  hipLaunchKernelGGL(k_attn_out_block<120>, dim3(g), dim3(128), 0, s, att, res, Wo, bo, gamma, beta, eps, out, tokens, per);
+  return 0;
 }
 
 void launch_rotary_apply(const float* x, long long x_stride, const float* cs, const float* sn, float* out, long long rows, int D,

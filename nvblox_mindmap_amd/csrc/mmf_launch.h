@@ -111,6 +111,14 @@ int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long
 void launch_rotary_apply(const float* x, long long x_stride, const float* cs, const float* sn, float* out, long long rows, int D,
                          hipStream_t s);
 void launch_adaln_modulate(const float* x, const float* ss, float* out, int B, int L, int D, hipStream_t s);
+int launch_ffn_block(const float* x, const float* ss, const float* W1, const float* b1, const float* W2, const float* b2,
+                     const float* gamma, const float* beta, float eps, float* out, int B, int L, int D, hipStream_t s);
+int launch_q_block(const float* x, const float* ss, const float* Wq, const float* bq, const float* cs, const float* sn, float* out,
+                   int B, int L, int D, hipStream_t s);
+int launch_kv_block(const float* m, const float* Wkv, const float* bkv, const float* cs, const float* sn, float* kout, float* vout,
+                    long long tokens, int D, hipStream_t s);
+int launch_attn_out_block(const float* att, const float* res, const float* Wo, const float* bo, const float* gamma, const float* beta,
+                          float eps, float* out, long long tokens, int D, hipStream_t s);
 void launch_ddpm_step(const float* x, const float* eps, long long eps_stride, const float* noise, float* out, long long rows, int C,
                       int split, const float* coefA, const float* coefB, hipStream_t s);
 int launch_attention_small(const float* q, const float* k, long long k_stride, const float* v, long long v_stride, const uint8_t* pad,

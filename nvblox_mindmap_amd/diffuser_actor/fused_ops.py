@@ -73,3 +73,72 @@ def ddpm_step(traj: torch.Tensor, pred: torch.Tensor, noise: torch.Tensor, coef_
     _lib.check(_lib.lib().mmf_ddpm_step(_lib.dptr(traj), _lib.dptr(pred), pred.shape[-1], _lib.dptr(noise), _lib.dptr(out), rows, Cc, split,
                                         Ct.cast(a, Ct.c_void_p), Ct.cast(b, Ct.c_void_p), _lib.stream_ptr(traj.device)), "mmf_ddpm_step")
     return out
+
+
+BLOCK_DIMS = (120,)  # embedding dims the whole-block kernels are built for
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.contiguous()
+
+
+_WT_CACHE = {}
+
+
+def _wt(linear) -> torch.Tensor:
+    """Transposed ([in, out]) contiguous copy of a Linear's weight, cached until the weight is modified or moved."""
+    w = linear.weight
+    key = id(linear)
+    hit = _WT_CACHE.get(key)
+    if hit is None or hit[0] != (w.data_ptr(), w._version, w.device):
+        hit = ((w.data_ptr(), w._version, w.device), w.detach().t().contiguous())
+        _WT_CACHE[key] = hit
+    return hit[1]
+
+
+def ffn_block(x, scale_shift, fc1, fc2, norm) -> torch.Tensor:
+    """FeedForwardBlock at inference in one launch: h = x*(1+scale)+shift (if scale_shift); LayerNorm(h + fc2(relu(fc1(h))))."""
+    x = x.contiguous()
+    B, L, D = x.shape
+    out = torch.empty_like(x)
+    ss = _c(scale_shift)
+    _lib.check(_lib.lib().mmf_ffn_block(_lib.dptr(x), _lib.dptr(ss), _lib.dptr(_wt(fc1)), _lib.dptr(_c(fc1.bias)), _lib.dptr(_wt(fc2)),
+                                        _lib.dptr(_c(fc2.bias)), _lib.dptr(_c(norm.weight)), _lib.dptr(_c(norm.bias)), float(norm.eps),
+                                        _lib.dptr(out), B, L, D, _lib.stream_ptr(x.device)), "mmf_ffn_block")
+    return out
+
+
+def q_block(x, scale_shift, q_proj, rot) -> torch.Tensor:
+    """rotary(q_proj(x*(1+scale)+shift)); rot = (cos, sin) [B,L,D] or None."""
+    x = x.contiguous()
+    B, L, D = x.shape
+    out = torch.empty_like(x)
+    ss = _c(scale_shift)
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    _lib.check(_lib.lib().mmf_q_block(_lib.dptr(x), _lib.dptr(ss), _lib.dptr(_wt(q_proj)), _lib.dptr(_c(q_proj.bias)), _lib.dptr(cs),
+                                      _lib.dptr(sn), _lib.dptr(out), B, L, D, _lib.stream_ptr(x.device)), "mmf_q_block")
+    return out
+
+
+def kv_block(memory, kv_proj, rot):
+    """(rotary(keys), values) of kv_proj(memory), both [B,Lk,D] contiguous."""
+    memory = memory.contiguous()
+    B, L, D = memory.shape
+    k = torch.empty_like(memory)
+    v = torch.empty_like(memory)
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    _lib.check(_lib.lib().mmf_kv_block(_lib.dptr(memory), _lib.dptr(_wt(kv_proj)), _lib.dptr(_c(kv_proj.bias)), _lib.dptr(cs), _lib.dptr(sn),
+                                       _lib.dptr(k), _lib.dptr(v), B * L, D, _lib.stream_ptr(memory.device)), "mmf_kv_block")
+    return k, v
+
+
+def attn_out_block(att, residual, out_proj, norm) -> torch.Tensor:
+    """LayerNorm(residual + out_proj(att))."""
+    att = att.contiguous()
+    residual = residual.contiguous()
+    B, L, D = att.shape
+    out = torch.empty_like(att)
+    _lib.check(_lib.lib().mmf_attn_out_block(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_wt(out_proj)), _lib.dptr(_c(out_proj.bias)),
+                                             _lib.dptr(_c(norm.weight)), _lib.dptr(_c(norm.bias)), float(norm.eps), _lib.dptr(out), B * L, D,
+                                             _lib.stream_ptr(att.device)), "mmf_attn_out_block")
+    return out

@@ -19,6 +19,12 @@ def _fused(x: torch.Tensor) -> bool:
     return FUSED_INFERENCE and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
+def _block_dims():
+    from .fused_ops import BLOCK_DIMS
+
+    return BLOCK_DIMS
+
+
 def sinusoidal_embedding(x: torch.Tensor, dim: int) -> torch.Tensor:
     """(B,) scalars -> (B,dim): [sin(x w_k) ... , cos(x w_k) ...], w_k = 10000^(-k/(dim/2-1))."""
     half = dim // 2
@@ -107,9 +113,11 @@ class RelativeAttention(nn.Module):
     def project_kv(self, memory: torch.Tensor, kv_rot=None):
         """Keys (rotated) and values of `memory` for the fused path: computed once per inference for a memory that does not
         change between denoising steps (the context of the cross-attention layers)."""
-        from .fused_ops import rotary_apply
+        from .fused_ops import BLOCK_DIMS, kv_block, rotary_apply
 
         D = self.dim
+        if D in BLOCK_DIMS:
+            return kv_block(memory, self.kv_proj, kv_rot)
         kv = self.kv_proj(memory)
         k = kv[..., :D]
         return (rotary_apply(k, *kv_rot) if kv_rot is not None else k), kv[..., D:]
@@ -165,6 +173,18 @@ class AttentionBlock(nn.Module):
 
     def forward(self, query, memory, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False, cond_act=None,
                 kv_cache=None):
+        A = self.attn
+        if _fused(query) and not need_weights and A.dim in _block_dims() and (A.dim // A.heads) in (8, 15, 16, 20, 24, 32):
+            # whole-block kernels: (modulate + q_proj + rotary) | (kv_proj + rotary) | attention | (out_proj + residual + LayerNorm)
+            from . import fused_ops as FO
+
+            ss = None
+            if self.adaln is not None and cond is not None:
+                ss = cond_act.lookup(self.adaln) if isinstance(cond_act, AdaLNBatch) else self.adaln.proj(F.silu(cond) if cond_act is None else cond_act)
+            q = FO.q_block(query, ss, A.q_proj, q_rot)
+            k, v = kv_cache if kv_cache is not None else FO.kv_block(memory, A.kv_proj, kv_rot if q_rot is not None else None)
+            att = FO.attention_small(q, k, v, key_padding_mask, A.heads)
+            return FO.attn_out_block(att, query, A.out_proj, self.norm), None
         q_in = self.adaln(query, cond, cond_act) if (self.adaln is not None and cond is not None) else query
         out, w = self.attn(q_in, memory, q_rot, kv_rot, key_padding_mask, need_weights, kv_cache)
         return self.norm(query + self.drop(out)), w
@@ -183,6 +203,13 @@ class FeedForwardBlock(nn.Module):
         self.adaln = AdaLN(dim) if use_adaln else None
 
     def forward(self, x, cond=None, cond_act=None):
+        if _fused(x) and x.dim() == 3 and x.shape[-1] in _block_dims() and self.fc1.out_features == x.shape[-1]:
+            from . import fused_ops as FO
+
+            ss = None
+            if self.adaln is not None and cond is not None:
+                ss = cond_act.lookup(self.adaln) if isinstance(cond_act, AdaLNBatch) else self.adaln.proj(F.silu(cond) if cond_act is None else cond_act)
+            return FO.ffn_block(x, ss, self.fc1, self.fc2, self.norm)
         if self.adaln is not None and cond is not None:
             x = self.adaln(x, cond, cond_act)
         return self.norm(x + self.drop(self.fc2(self.drop(F.relu(self.fc1(x))))))

@@ -175,3 +175,37 @@ def test_fused_inference_matches_composite_inference():
     assert torch.equal(fused, fused_graph)
     assert torch.allclose(fused, ref, rtol=1e-3, atol=1e-4), float((fused - ref).abs().max())
     assert torch.equal(infer(), ref)  # switches off again: the composite path is untouched
+
+
+def test_block_kernels_match_the_composite_blocks():
+    """mmf_ffn_block / mmf_q_block / mmf_kv_block / mmf_attn_out_block through AttentionBlock / FeedForwardBlock at D = 120
+    against the composite torch path (float-rounding agreement)."""
+    from nvblox_mindmap_amd.diffuser_actor import layers as L
+
+    torch.manual_seed(1)
+    D, H, B, Lq, Lk = 120, 8, 2, 50, 333
+    blk = L.AttentionBlock(D, H, 0.0, use_adaln=True).cuda().eval()
+    ffw = L.FeedForwardBlock(D, D, 0.0, use_adaln=True).cuda().eval()
+    for p in list(blk.parameters()) + list(ffw.parameters()):
+        p.data.add_(0.05 * torch.randn_like(p))
+    x, mem, cond = torch.randn(B, Lq, D, device="cuda"), torch.randn(B, Lk, D, device="cuda"), torch.randn(B, D, device="cuda")
+    q_rot = L.rotary3d(torch.rand(B, Lq, 3, device="cuda"), D)
+    kv_rot = L.rotary3d(torch.rand(B, Lk, 3, device="cuda"), D)
+    pad = torch.rand(B, Lk, device="cuda") < 0.2
+    pad[:, 0] = False
+    with torch.no_grad():
+        ref_a, _ = blk(x, mem, cond, q_rot, kv_rot, pad)
+        ref_f = ffw(x, cond)
+        ref_self, _ = blk(x, x, cond, q_rot, q_rot, None)
+        L.FUSED_INFERENCE = True
+        try:
+            got_a, _ = blk(x, mem, cond, q_rot, kv_rot, pad)
+            got_f = ffw(x, cond)
+            got_self, _ = blk(x, x, cond, q_rot, q_rot, None)
+            cache = blk.attn.project_kv(mem, kv_rot)
+            got_cached, _ = blk(x, mem, cond, q_rot, kv_rot, pad, kv_cache=cache)
+        finally:
+            L.FUSED_INFERENCE = False
+    for got, ref in ((got_a, ref_a), (got_f, ref_f), (got_self, ref_self), (got_cached, ref_a)):
+        assert torch.allclose(got, ref, rtol=2e-4, atol=2e-5), float((got - ref).abs().max())
+    assert torch.equal(got_cached, got_a)
