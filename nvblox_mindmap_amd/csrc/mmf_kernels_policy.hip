@@ -68,10 +68,10 @@ void launch_ddpm_step(const float* x, const float* eps, long long eps_stride, co
 
 // ---- small attention -----------------------------------------------------------------------------------------------------
 // Head dim DH is a compile-time constant (the policy uses 120 / 8 = 15).  Two shapes:
-//  * k_attention_rows<DH>: many query rows.  Workgroup = 16 query rows x 16 key lanes; keys / values stream through LDS in
-//    tiles of 64; lane j of a row scores keys j, j+16, j+32, j+48 of the tile, the row maximum / sum are combined with
-//    16-lane shuffles once per tile (one rescale per tile, not per key), each lane keeps a partial output that is summed
-//    over the 16 lanes at the end.
+//  * k_attention_rows<DH>: many query rows.  Workgroup = 8 query rows x 32 key lanes; keys / values stream through LDS in
+//    tiles of 64; lane j of a row scores keys j and j+32 of the tile, the row maximum / sum are combined with 32-lane
+//    shuffles once per tile (one rescale per tile, not per key), each lane keeps a partial output that is summed over the
+//    32 lanes at the end.
 //  * k_attention_few<DH>: a handful of query rows over thousands of keys (cross-attention of the trajectory tokens).
 //    Workgroup = one query row, 256 threads stride over the keys straight from global memory (no reuse to stage for),
 //    then a workgroup reduction of (max, sum, partial output).
@@ -82,14 +82,15 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
                                                        const float* __restrict__ v, long long v_stride,
                                                        const uint8_t* __restrict__ pad, float* __restrict__ out, int Lq, int Lk,
                                                        int H, float scale) {
-  // odd row stride: the 16 key lanes of a query row read 16 consecutive tile rows at the same channel -> 16 distinct banks
-  constexpr int RS = DH | 1;
+  // 8 query rows x 32 key lanes per workgroup; lane j of a row scores keys j and j + 32 of each 64-key tile.
+  // odd row stride: the 32 key lanes of a query row read consecutive tile rows at the same channel -> distinct banks
+  constexpr int RS = DH | 1, QR = 8, KL = 32;
   __shared__ float sK[kAttTile][RS];
   __shared__ float sV[kAttTile][RS];
   __shared__ uint8_t sP[kAttTile];
   const int b = blockIdx.z, h = blockIdx.y;
-  const int qi = threadIdx.x >> 4, lane = threadIdx.x & 15;
-  const int row = blockIdx.x * 16 + qi;
+  const int qi = threadIdx.x / KL, lane = threadIdx.x % KL;
+  const int row = blockIdx.x * QR + qi;
   const int D = H * DH;
   const bool live = row < Lq;
   float qv[DH];
@@ -103,37 +104,28 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
   for (int k0 = 0; k0 < Lk; k0 += kAttTile) {
     const int nk = Lk - k0 < kAttTile ? Lk - k0 : kAttTile;
     __syncthreads();
-    // stage: thread t -> key t/4, channels (t%4)*4 .. +3
-    {
+    {  // stage: thread t -> key t/4, channels (t%4)*4 .. +3 (and +16, +32 .. for wider heads)
       const int kk = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
       if (kk < nk) {
         const float* kp = k + (kb + k0 + kk) * k_stride + h * DH;
         const float* vp = v + (kb + k0 + kk) * v_stride + h * DH;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c0 + c < DH) {
-            sK[kk][c0 + c] = kp[c0 + c];
-            sV[kk][c0 + c] = vp[c0 + c];
-          }
-        if (DH > 16) {
+        for (int cb = 0; cb < DH; cb += 16)
 #pragma unroll
-          for (int c = 16 + c0; c < DH; c += 16)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c + e < DH) {
-                sK[kk][c + e] = kp[c + e];
-                sV[kk][c + e] = vp[c + e];
-              }
-        }
+          for (int e = 0; e < 4; ++e)
+            if (cb + c0 + e < DH) {
+              sK[kk][cb + c0 + e] = kp[cb + c0 + e];
+              sV[kk][cb + c0 + e] = vp[cb + c0 + e];
+            }
       }
-      if (threadIdx.x < kAttTile) sP[threadIdx.x] = (threadIdx.x < nk && pad) ? pad[kb + k0 + threadIdx.x] : (threadIdx.x < nk ? 0 : 1);
+      if (threadIdx.x < kAttTile) sP[threadIdx.x] = (threadIdx.x < nk) ? (pad ? pad[kb + k0 + threadIdx.x] : 0) : 1;
     }
     __syncthreads();
-    float sc[4];
+    float sc[2];
     float tmax = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = lane + 16 * j;
+    for (int j = 0; j < 2; ++j) {
+      const int kk = lane + KL * j;
       float dot = -INFINITY;
       if (!sP[kk]) {
         dot = 0.0f;
@@ -144,16 +136,16 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
       tmax = fmaxf(tmax, dot);
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, 16));
+    for (int off = KL / 2; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, KL));
     const float mn = fmaxf(m, tmax);
-    if (mn == -INFINITY) continue;  // every key so far is padding (row-uniform: all 16 lanes agree)
+    if (mn == -INFINITY) continue;  // every key so far is padding (row-uniform: all key lanes of the row agree)
     const float corr = __expf(m - mn);  // m = -inf: 0
     ssum *= corr;
 #pragma unroll
     for (int c = 0; c < DH; ++c) acc[c] *= corr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = lane + 16 * j;
+    for (int j = 0; j < 2; ++j) {
+      const int kk = lane + KL * j;
       const float p = sc[j] == -INFINITY ? 0.0f : __expf(sc[j] - mn);
       ssum += p;
 #pragma unroll
@@ -162,10 +154,10 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
     m = mn;
   }
 #pragma unroll
-  for (int off = 8; off > 0; off >>= 1) {
-    ssum += __shfl_xor(ssum, off, 16);
+  for (int off = KL / 2; off > 0; off >>= 1) {
+    ssum += __shfl_xor(ssum, off, KL);
 #pragma unroll
-    for (int c = 0; c < DH; ++c) acc[c] += __shfl_xor(acc[c], off, 16);
+    for (int c = 0; c < DH; ++c) acc[c] += __shfl_xor(acc[c], off, KL);
   }
   if (live && lane == 0) {
     float* o = out + ((size_t)b * Lq + row) * D + h * DH;
@@ -240,8 +232,8 @@ template <int DH>
 static void attention_dispatch(const float* q, const float* k, long long k_stride, const float* v, long long v_stride, const uint8_t* pad,
                                float* out, int B, int Lq, int Lk, int H, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)DH);
-  if (Lq >= 16)
-    hipLaunchKernelGGL(k_attention_rows<DH>, dim3((Lq + 15) / 16, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H,
+  if (Lq >= 8)
+    hipLaunchKernelGGL(k_attention_rows<DH>, dim3((Lq + 7) / 8, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H,
                        scale);
   else
     hipLaunchKernelGGL(k_attention_few<DH>, dim3(Lq, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H, scale);
