@@ -48,7 +48,11 @@ class GraphSampler:
         self._graphs: Dict[Tuple, dict] = {}
 
     def _key(self, leaves, noise):
-        return (tuple((tuple(t.shape), t.dtype) for t in leaves), tuple(noise.shape), tuple(self.model._inference_timesteps))
+        from . import layers as L
+
+        # the captured kernels depend on the input shapes, the timestep grid and on which inference path is switched on
+        return (tuple((tuple(t.shape), t.dtype) for t in leaves), tuple(noise.shape), tuple(self.model._inference_timesteps),
+                bool(L.FUSED_INFERENCE))
 
     def run(self, enc, noise):
         leaves, spec, rebuild = _flatten(enc)

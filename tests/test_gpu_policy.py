@@ -165,10 +165,17 @@ def test_fused_inference_matches_composite_inference():
 
     ref = infer()
     try:
+        model.enable_graph_sampling(True)
+        assert torch.equal(infer(), ref)  # graph of the composite path, captured BEFORE the fused switch is flipped ...
+        model.enable_graph_sampling(False)
         DiffuserActor.enable_fused_inference(True)
         fused = infer()
         model.enable_graph_sampling(True)
         fused_graph = infer()
+        assert len(model._graph_sampler._graphs) == 1
+        DiffuserActor.enable_fused_inference(False)
+        assert torch.equal(infer(), ref) and len(model._graph_sampler._graphs) == 2  # ... is not replayed for the other path
+        DiffuserActor.enable_fused_inference(True)
     finally:
         DiffuserActor.enable_fused_inference(False)
         model.enable_graph_sampling(False)
