@@ -253,6 +253,99 @@ def run_backprojection(device, cpu=True):
     return out
 
 
+def run_tsdf_only(device, steps=200, warmup=20):
+    """BASELINE configs[1]: TSDF-only integration (decay + add_depth_frame: raycast, allocation, TSDF update) of the 640x480
+    stream at 1 cm voxels, through the reference's stand-alone Mapper calls."""
+    cfg = S.StreamConfig(hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    n = 50
+    stride = cfg.num_poses // n
+    frames = []
+    for k in range(n):
+        T = S.camera_pose(cfg, k * stride)
+        frames.append((torch.from_numpy(S.render_depth(cfg, T)).to(device), torch.from_numpy(T), torch.from_numpy(cfg.intrinsics())))
+    mapper = get_nvblox_mapper(mcfg, feature_channels=64)
+
+    def step(i):
+        d, T, K = frames[i % n]
+        mapper.decay()
+        mapper.add_depth_frame(d, T, K, None, MAPPER_TO_ID.STATIC)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    del mapper
+    return {"frames_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "workload": "decay + add_depth_frame, 640x480, 1 cm voxels"}
+
+
+def run_closed_loop(device, steps=5):
+    """BASELINE configs[3]: one control step of the closed loop on one GPU, end to end -- decay + fused RGB-D/feature frame
+    (512x512, 768 feature channels, the reference's shape) -> surface vertices + features sampled to 2048
+    (get_vertices_and_features) -> depth back-projection -> policy inference (encoder + 100 denoising steps, fused ops + HIP
+    graph).  The backbone's feature extraction for the frame is part of the policy encoder here (random-init ViT-B/16)."""
+    from nvblox_mindmap_amd.data_loading.vertex_sampling import VertexSamplingMethod
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
+    from nvblox_mindmap_amd.image_processing.backprojection import get_camera_pointcloud
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_output_helpers import get_vertices_and_features
+    from nvblox_mindmap_amd.training import build_model, synthetic_batch
+
+    C = 768
+    cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    frames = build_stream(cfg, 4, C, device)
+    mapper = get_nvblox_mapper(mcfg, feature_channels=C)
+    pcfg = DiffuserActorConfig()
+    torch.manual_seed(0)
+    model = build_model(pcfg, device=device).eval()
+    DiffuserActor.enable_fused_inference(True)
+    model.enable_graph_sampling(True)
+    hist = synthetic_batch(pcfg, 1, device, seed=3)["gripper_history"]
+    parts = {"fusion": 0.0, "map_to_model_input": 0.0, "policy_inference": 0.0}
+
+    def control_step(i, record):
+        fr = frames[i % 4]
+        t = [time.perf_counter()]
+        step(mapper, mcfg, fr)
+        torch.cuda.synchronize(device)
+        t.append(time.perf_counter())
+        v, f, valid = get_vertices_and_features(mapper, MAPPER_TO_ID.STATIC, mcfg, remove_zero_features=True, num_excess_features=0,
+                                                sample_vertices=True, number_of_vertices_to_sample=2048,
+                                                vertex_sampling_method=VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT)
+        q = torch.tensor([[0.5, -0.5, 0.5, -0.5]], device=device)
+        pcd = get_camera_pointcloud(fr["K"].to(device)[None], fr["depth"][None], fr["T_W_C"][:3, 3].to(device)[None], q)
+        rgb = (fr["rgb"].permute(2, 0, 1).float() / 255.0)[None, None]
+        torch.cuda.synchronize(device)
+        t.append(time.perf_counter())
+        with torch.no_grad():
+            traj = model(None, None, rgb, pcd[:, None], (fr["depth"] > 0)[None, None], f.float(), v, valid, None, hist, run_inference=True)[0]
+        torch.cuda.synchronize(device)
+        t.append(time.perf_counter())
+        if record:
+            for name, a, b in zip(parts, t[:-1], t[1:]):
+                parts[name] += (b - a) * 1e3
+        return traj
+
+    try:
+        for i in range(3):
+            control_step(i, False)  # warm-up: fills the map, captures the graph
+        t0 = time.perf_counter()
+        for i in range(steps):
+            control_step(3 + i, True)
+        total = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        DiffuserActor.enable_fused_inference(False)
+    out = {"ms_per_control_step": total, "control_steps_per_s": 1e3 / total, "breakdown_ms": {k: v / steps for k, v in parts.items()},
+           "shape": "512x512 RGB-D, 768 feature channels, 2048 sampled vertices, 100 denoising steps, batch 1"}
+    del mapper, model, frames
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_policy_inference(device, reps=3):
     """Closed-loop serving latency of the policy: batch 1, encoder once + 100 denoising steps of the
     diffusion head, eager and with the denoising loop replayed as one captured HIP graph (same results bit for bit)."""
@@ -418,6 +511,8 @@ def main():
             dist.barrier()
         train = run_training(device, world, steps=args.train_steps)
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
+    closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
+    tsdf_only = run_tsdf_only(device) if (rank == 0 and not args.no_ref_shape) else None
     backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
@@ -500,6 +595,8 @@ def main():
             "kernel_us_per_launch": breakdown,
             "reference_shape": ref_shape,
             "policy_inference": infer,
+            "closed_loop": closed_loop,
+            "tsdf_only": tsdf_only,
             "backprojection": backproj,
             "train": train,
         }

@@ -69,22 +69,24 @@ void launch_ddpm_step(const float* x, const float* eps, long long eps_stride, co
 // ---- small attention -----------------------------------------------------------------------------------------------------
 // Head dim DH is a compile-time constant (the policy uses 120 / 8 = 15).  Two shapes:
 //  * k_attention_rows<DH>: many query rows.  Workgroup = 8 query rows x 32 key lanes; keys / values stream through LDS in
-//    tiles of 64; lane j of a row scores keys j and j+32 of the tile, the row maximum / sum are combined with 32-lane
+//    tiles of 320; lane j of a row scores keys j, j+32, ... of the tile, the row maximum / sum are combined with 32-lane
 //    shuffles once per tile (one rescale per tile, not per key), each lane keeps a partial output that is summed over the
 //    32 lanes at the end.
 //  * k_attention_few<DH>: a handful of query rows over thousands of keys (cross-attention of the trajectory tokens).
 //    Workgroup = one query row, 256 threads stride over the keys straight from global memory (no reuse to stage for),
 //    then a workgroup reduction of (max, sum, partial output).
-constexpr int kAttTile = 64;
+constexpr int kAttTile = 320;
 
 template <int DH>
 __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict__ q, const float* __restrict__ k, long long k_stride,
                                                        const float* __restrict__ v, long long v_stride,
                                                        const uint8_t* __restrict__ pad, float* __restrict__ out, int Lq, int Lk,
                                                        int H, float scale) {
-  // 8 query rows x 32 key lanes per workgroup; lane j of a row scores keys j and j + 32 of each 64-key tile.
+  // 8 query rows x 32 key lanes per workgroup; lane j of a row scores keys j, j + 32, ... of the tile.  The tile is large
+  // (kAttTile keys, ~40 KB of LDS for K and V): a tile costs one global-load latency + two barriers, so a 616-key head is
+  // two such rounds (64-key tiles made it ten, and the kernel was a chain of load latencies).
   // odd row stride: the 32 key lanes of a query row read consecutive tile rows at the same channel -> distinct banks
-  constexpr int RS = DH | 1, QR = 8, KL = 32;
+  constexpr int RS = DH | 1, QR = 8, KL = 32, KPL = kAttTile / KL;
   __shared__ float sK[kAttTile][RS];
   __shared__ float sV[kAttTile][RS];
   __shared__ uint8_t sP[kAttTile];
@@ -104,27 +106,17 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
   for (int k0 = 0; k0 < Lk; k0 += kAttTile) {
     const int nk = Lk - k0 < kAttTile ? Lk - k0 : kAttTile;
     __syncthreads();
-    {  // stage: thread t -> key t/4, channels (t%4)*4 .. +3 (and +16, +32 .. for wider heads)
-      const int kk = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
-      if (kk < nk) {
-        const float* kp = k + (kb + k0 + kk) * k_stride + h * DH;
-        const float* vp = v + (kb + k0 + kk) * v_stride + h * DH;
-#pragma unroll
-        for (int cb = 0; cb < DH; cb += 16)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (cb + c0 + e < DH) {
-              sK[kk][cb + c0 + e] = kp[cb + c0 + e];
-              sV[kk][cb + c0 + e] = vp[cb + c0 + e];
-            }
-      }
-      if (threadIdx.x < kAttTile) sP[threadIdx.x] = (threadIdx.x < nk) ? (pad ? pad[kb + k0 + threadIdx.x] : 0) : 1;
+    for (int e = threadIdx.x; e < nk * DH; e += 256) {
+      const int kk = e / DH, c = e - kk * DH;
+      sK[kk][c] = k[(kb + k0 + kk) * k_stride + h * DH + c];
+      sV[kk][c] = v[(kb + k0 + kk) * v_stride + h * DH + c];
     }
+    for (int e = threadIdx.x; e < kAttTile; e += 256) sP[e] = (e < nk) ? (pad ? pad[kb + k0 + e] : 0) : 1;
     __syncthreads();
-    float sc[2];
+    float sc[KPL];
     float tmax = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < KPL; ++j) {
       const int kk = lane + KL * j;
       float dot = -INFINITY;
       if (!sP[kk]) {
@@ -144,9 +136,10 @@ __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < DH; ++c) acc[c] *= corr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < KPL; ++j) {
+      if (sc[j] == -INFINITY) continue;
       const int kk = lane + KL * j;
-      const float p = sc[j] == -INFINITY ? 0.0f : __expf(sc[j] - mn);
+      const float p = __expf(sc[j] - mn);
       ssum += p;
 #pragma unroll
       for (int c = 0; c < DH; ++c) acc[c] += p * sV[kk][c];

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from ..nvblox_torch.timer import Timer
 from .backbone import VitBackbone
 from .fps import farthest_point_sampling, farthest_point_sampling_reference
-from . import layers as L
+from . import layers as layers_mod
 from .layers import AttentionBlock, AttentionStack, FeedForwardBlock, rotary3d, sinusoidal_embedding
 from .loss import LossWeights, compute_loss
 from .rotations import normalize_pointcloud, normalize_pos, normalize_trajectory, unnormalize_trajectory
@@ -159,6 +159,7 @@ class DiffusionHead(nn.Module):
         self.openness_out = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 1))
         self.head_yaw_out = nn.Sequential(nn.Linear(D * cfg.ngrippers, D), nn.ReLU(), nn.Linear(D, 1)) if cfg.predict_head_yaw else None
         self.drop = nn.Dropout(p)
+        self._side_stream = None  # second stream of the fused inference path (rotation stack || position stack)
 
     def prepare_context(self, enc):
         """Everything the head needs from the encoder outputs that does not depend on the denoising step: masks made safe
@@ -177,9 +178,9 @@ class DiffusionHead(nn.Module):
              "ctx_rot": rotary3d(enc["context_pos"], D), "fps_rot": rotary3d(enc["fps_pos"], D),
              "history": self.history_mlp(enc["history_feats"].flatten(1)), "cross_kv": None}
         P["adaln"] = None
-        if L._fused(ctx_feats):  # keys / values of the (step-invariant) context, once per inference instead of per step
+        if layers_mod._fused(ctx_feats):  # keys / values of the (step-invariant) context, once per inference instead of per step
             P["cross_kv"] = [blk.attn.project_kv(ctx_feats, P["ctx_rot"]) for blk in self.cross_attn.attn]
-            P["adaln"] = L.AdaLNBatch([mod for mod in self.modules() if isinstance(mod, L.AdaLN)])
+            P["adaln"] = layers_mod.AdaLNBatch([mod for mod in self.modules() if isinstance(mod, layers_mod.AdaLN)])
         return P
 
     def time_embeddings(self, timesteps, device):
@@ -215,8 +216,21 @@ class DiffusionHead(nn.Module):
         seq_rot = (torch.cat([traj_rot[0], fps_rot[0]], dim=1), torch.cat([traj_rot[1], fps_rot[1]], dim=1))
         pad = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=seq.device), P["fps_pad"]], dim=1)
         seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
-        rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
-        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
+        if layers_mod._fused(seq):
+            # the two output stacks are independent: fork the rotation stack onto a second stream (parallel branches of the
+            # captured HIP graph; concurrent small kernels in eager mode), join before the projections
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=seq.device)
+            main, side = torch.cuda.current_stream(seq.device), self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
+            pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
+            main.wait_stream(side)
+            rot_seq.record_stream(main)
+        else:
+            rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
+            pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=cond_act)
         rot_feat = self.drop(self.rotation_proj(rot_seq[:, :nt]))
         pos_feat = self.drop(self.position_proj(pos_seq[:, :nt]))
         pred = torch.cat([self.position_out(pos_feat), self.rotation_out(rot_feat), self.openness_out(pos_feat)], dim=-1)
@@ -273,7 +287,7 @@ class DiffuserActor(nn.Module):
         batch, device = traj.shape[0], traj.device
         pred = head_yaw = None
         prepared = self.prediction_head.prepare_context(enc)  # step-invariant part of the head, once per inference
-        fused = L._fused(traj)
+        fused = layers_mod._fused(traj)
         time_table = self.prediction_head.time_embeddings(self._inference_timesteps, device) if fused else None
         for k, t in enumerate(self._inference_timesteps):
             if fused:
@@ -307,7 +321,7 @@ class DiffuserActor(nn.Module):
     def enable_fused_inference(on: bool = True) -> None:
         """Use the fused HIP ops (rotary, AdaLN, small attention; cached context keys/values) in blocks that run without
         autograd on the GPU.  Process-wide switch; training (autograd on) always takes the composite torch ops."""
-        L.FUSED_INFERENCE = bool(on)
+        layers_mod.FUSED_INFERENCE = bool(on)
 
     def enable_graph_sampling(self, on: bool = True) -> None:
         """Replay the denoising loop (T steps x ~150 small kernels, launch-bound at batch 1) as a captured HIP graph.
