@@ -76,17 +76,19 @@ void launch_ddpm_step(const float* x, const float* eps, long long eps_stride, co
 //    Workgroup = one query row, 256 threads stride over the keys straight from global memory (no reuse to stage for),
 //    then a workgroup reduction of (max, sum, partial output).
 constexpr int kAttTile = 320;
+constexpr int kAttRows = 8;   // query rows per workgroup of k_attention_rows (each workgroup stages its head's K/V once)
 
 template <int DH>
 __global__ __launch_bounds__(256) void k_attention_rows(const float* __restrict__ q, const float* __restrict__ k, long long k_stride,
                                                        const float* __restrict__ v, long long v_stride,
                                                        const uint8_t* __restrict__ pad, float* __restrict__ out, int Lq, int Lk,
                                                        int H, float scale) {
-  // 8 query rows x 32 key lanes per workgroup; lane j of a row scores keys j, j + 32, ... of the tile.  The tile is large
+  // kAttRows query rows x (256 / kAttRows) key lanes per workgroup; lane j of a row scores keys j, j + KL, ... of the tile.
+  // Every workgroup stages its head's K and V: more rows per workgroup = less L2 -> LDS traffic.  The tile is large
   // (kAttTile keys, ~40 KB of LDS for K and V): a tile costs one global-load latency + two barriers, so a 616-key head is
   // two such rounds (64-key tiles made it ten, and the kernel was a chain of load latencies).
   // odd row stride: the 32 key lanes of a query row read consecutive tile rows at the same channel -> distinct banks
-  constexpr int RS = DH | 1, QR = 8, KL = 32, KPL = kAttTile / KL;
+  constexpr int RS = DH | 1, QR = kAttRows, KL = 256 / kAttRows, KPL = kAttTile / KL;
   __shared__ float sK[kAttTile][RS];
   __shared__ float sV[kAttTile][RS];
   __shared__ uint8_t sP[kAttTile];
@@ -226,7 +228,7 @@ static void attention_dispatch(const float* q, const float* k, long long k_strid
                                float* out, int B, int Lq, int Lk, int H, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)DH);
   if (Lq >= 8)
-    hipLaunchKernelGGL(k_attention_rows<DH>, dim3((Lq + 7) / 8, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H,
+    hipLaunchKernelGGL(k_attention_rows<DH>, dim3((Lq + kAttRows - 1) / kAttRows, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H,
                        scale);
   else
     hipLaunchKernelGGL(k_attention_few<DH>, dim3(Lq, H, B), dim3(256), 0, s, q, k, k_stride, v, v_stride, pad, out, Lq, Lk, H, scale);
