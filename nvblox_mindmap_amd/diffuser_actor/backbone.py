@@ -40,7 +40,11 @@ class VitBackbone(nn.Module):
     def forward(self, x):
         B, _, H, W = x.shape
         h, w = H // self.patch, W // self.patch
-        t = self.embed(x).flatten(2).transpose(1, 2)
+        # Patch embedding as reshape + GEMM: a stride-16 16x16 convolution touches every pixel once, and MIOpen has only its
+        # naive kernel for it (1 ms per 512x512 image).  Same parameters (self.embed), same sums in a different order.
+        P = self.patch
+        patches = x.reshape(B, 3, h, P, w, P).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, 3 * P * P)
+        t = F.linear(patches, self.embed.weight.reshape(self.dim, 3 * P * P), self.embed.bias)
         t = t + self.pos[:, : h * w]
         for blk in self.blocks:
             t = blk(t)
