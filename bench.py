@@ -391,7 +391,7 @@ def run_policy_inference(device, reps=3):
     return out
 
 
-def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32):
+def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_matmul_dtype="float32"):
     """Policy training step/s (second half of the BASELINE metric; config 5): diffuser_actor, RGBD_AND_MESH, per-GPU batch 32,
     one 512x512 camera, 2048 vertices x 768 features, frozen ViT-B/16-shaped backbone (random-init stand-in for RADIO v2.5-B),
     fp32, synthetic cached-sample-shaped batches resident on the GPU; DDP (RCCL all-reduce) when world > 1."""
@@ -400,7 +400,7 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32):
     from nvblox_mindmap_amd.training.distributed import barrier, max_over_ranks
 
     torch.manual_seed(0)
-    cfg = DiffuserActorConfig()
+    cfg = DiffuserActorConfig(backbone_matmul_dtype=backbone_matmul_dtype)
     model = build_model(cfg, device=device)
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     n_frozen = sum(p.numel() for p in model.parameters() if not p.requires_grad)
@@ -510,6 +510,12 @@ def main():
         if dist is not None:
             dist.barrier()
         train = run_training(device, world, steps=args.train_steps)
+        # secondary figure, not the headline: the frozen backbone's matmuls with float16 inputs / fp32 accumulation -- the
+        # mantissa width of the TF32 mode the reference runs its backbone in (feature_extraction.py:322); gfx950 has no TF32
+        t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16")
+        train["fp16_backbone_matmuls"] = {"step_per_s": t16["step_per_s"], "ms_per_step": t16["ms_per_step"],
+                                          "note": "frozen backbone under float16 autocast (10-bit mantissa like the reference's TF32 "
+                                                  "backbone, fp32 accumulate); everything trainable stays float32"}
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     tsdf_only = run_tsdf_only(device) if (rank == 0 and not args.no_ref_shape) else None

@@ -49,6 +49,7 @@ class DiffuserActorConfig:
     add_external_cam: bool = False
     dropout: float = 0.0
     backbone: str = "vit_b16"               # random-init stand-in for the frozen RADIO v2.5-B ("none": rgb tokens are given)
+    backbone_matmul_dtype: str = "float32"  # "float16": frozen backbone under fp16 autocast (the reference's TF32 mantissa)
     loss_weights: LossWeights = field(default_factory=LossWeights)
 
 
@@ -91,7 +92,12 @@ class Encoder(nn.Module):
         tokens (B,ncam*h*w,D), positions (B,ncam*h*w,3), mask (B,ncam*h*w)."""
         B, ncam = rgb.shape[:2]
         with torch.no_grad():
-            feats = self.backbone(rgb.flatten(0, 1))  # (B*ncam, C, h, w)
+            # The reference runs the frozen backbone under AllowMatMulTf32 (image_processing/feature_extraction.py:322): 10-bit
+            # mantissa inputs, fp32 accumulation.  gfx950 has no TF32 MFMA; float16 inputs carry the same mantissa.  Default: fp32.
+            fp16 = self.cfg.backbone_matmul_dtype == "float16" and rgb.is_cuda
+            with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+                feats = self.backbone(rgb.flatten(0, 1))  # (B*ncam, C, h, w)
+            feats = feats.float()
         h, w = feats.shape[-2:]
         tokens = self.image_embed(feats.flatten(2).transpose(1, 2)).reshape(B, ncam * h * w, -1)
         pos = F.interpolate(pcd.flatten(0, 1), (h, w), mode="bilinear", align_corners=False)
