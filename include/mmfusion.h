@@ -263,7 +263,16 @@ int mmf_farthest_point_sampling(const float* x_dev, int B, int N, int C, int npo
  *   mmf_q_block        out = rotary(q_proj(x*(1+scale)+shift))
  *   mmf_kv_block       k_out = rotary(kv_proj(memory)[:, :D]), v_out = kv_proj(memory)[:, D:]
  *   mmf_attn_out_block out = LayerNorm(residual + out_proj(att))
- * One launch each instead of 3-7; results agree with the composite torch ops to float rounding. */
+ * One launch each instead of 3-7; results agree with the composite torch ops to float rounding.
+ *   mmf_qkv_block      self-attention: mmf_q_block and mmf_kv_block of the same tokens in one launch
+ *   mmf_out_ffn_block  mmf_attn_out_block followed by mmf_ffn_block (scale_shift is the FFN's) in one launch */
+int mmf_qkv_block(const float* x_dev, const float* scale_shift_dev, const float* Wq_dev, const float* bq_dev, const float* Wkv_dev,
+                  const float* bkv_dev, const float* cos_dev, const float* sin_dev, float* q_out_dev, float* k_out_dev, float* v_out_dev, int B,
+                  int L, int D, void* stream);
+int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const float* Wo_dev, const float* bo_dev, const float* ln1_weight_dev,
+                      const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev,
+                      const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev, const float* ln2_bias_dev, float ln2_eps,
+                      float* out_dev, int B, int L, int D, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

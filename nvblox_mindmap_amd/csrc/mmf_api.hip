@@ -1372,6 +1372,28 @@ int mmf_adaln_modulate(const float* x, const float* scale_shift, float* out, int
   return check_launch();
 }
 
+int mmf_qkv_block(const float* x, const float* scale_shift, const float* Wq, const float* bq, const float* Wkv, const float* bkv,
+                  const float* cos_, const float* sin_, float* q_out, float* k_out, float* v_out, int B, int L, int D, void* stream) {
+  if (!x || !Wq || !bq || !Wkv || !bkv || !q_out || !k_out || !v_out || B <= 0 || L <= 0 || ((cos_ == nullptr) != (sin_ == nullptr)))
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_qkv_block");
+  if (launch_qkv_block(x, scale_shift, Wq, bq, Wkv, bkv, cos_, sin_, q_out, k_out, v_out, B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_block is built for D = 120");
+  return check_launch();
+}
+
+int mmf_out_ffn_block(const float* att, const float* residual, const float* Wo, const float* bo, const float* ln1_weight,
+                      const float* ln1_bias, float ln1_eps, const float* scale_shift, const float* W1, const float* b1, const float* W2,
+                      const float* b2, const float* ln2_weight, const float* ln2_bias, float ln2_eps, float* out, int B, int L, int D,
+                      void* stream) {
+  if (!att || !residual || !Wo || !bo || !ln1_weight || !ln1_bias || !W1 || !b1 || !W2 || !b2 || !ln2_weight || !ln2_bias || !out || B <= 0 ||
+      L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_block");
+  if (launch_out_ffn_block(att, residual, Wo, bo, ln1_weight, ln1_bias, ln1_eps, scale_shift, W1, b1, W2, b2, ln2_weight, ln2_bias, ln2_eps, out,
+                           B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_block is built for D = 120");
+  return check_launch();
+}
+
 int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)

@@ -409,12 +409,117 @@ __global__ __launch_bounds__(128) void k_attn_out_block(const float* __restrict_
   }
 }
 
+// Self-attention input side in one launch: q = rotary(q_proj(x*(1+scale)+shift)), k = rotary(kv_proj(x)[:D]), v = kv_proj(x)[D:].
+// 3D threads: thread j < D owns query channel j (modulated input), thread D + j owns key/value channel j (raw input).
+template <int D>
+__global__ __launch_bounds__(384) void k_qkv_block(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ Wq,
+                                                  const float* __restrict__ bq, const float* __restrict__ Wkv, const float* __restrict__ bkv,
+                                                  const float* __restrict__ cs, const float* __restrict__ sn, float* __restrict__ qout,
+                                                  float* __restrict__ kout, float* __restrict__ vout, int L, long long tokens, int tok_per_wg) {
+  __shared__ __attribute__((aligned(16))) float s_raw[D + 8], s_mod[D + 8], s_y[3 * D + 8];
+  const int j = threadIdx.x;
+  const bool act = j < 3 * D, is_q = j < D;
+  float w[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) w[c] = !act ? 0.0f : (is_q ? Wq[(size_t)c * D + j] : Wkv[(size_t)c * (2 * D) + (j - D)]);
+  const float bb = !act ? 0.0f : (is_q ? bq[j] : bkv[j - D]);
+  const long long t0 = (long long)blockIdx.x * tok_per_wg;
+  for (long long t = t0; t < t0 + tok_per_wg && t < tokens; ++t) {
+    const long long b = t / L;
+    __syncthreads();
+    if (is_q) {
+      const float xv = x[t * D + j];
+      s_raw[j] = xv;
+      s_mod[j] = ss ? xv * (1.0f + ss[b * 2 * D + j]) + ss[b * 2 * D + D + j] : xv;
+    }
+    __syncthreads();
+    const float y = dot_row<D>(w, is_q ? s_mod : s_raw) + bb;
+    if (act) s_y[j] = y;
+    __syncthreads();
+    if (j < 2 * D) {  // q (j < D) and k (D <= j < 2D): rotary; the pair partner sits next to it in s_y
+      const int c = is_q ? j : j - D;
+      float r = y;
+      if (cs) {
+        const float partner = (c & 1) ? s_y[j - 1] : -s_y[j + 1];
+        r = y * cs[t * D + c] + partner * sn[t * D + c];
+      }
+      (is_q ? qout : kout)[t * D + c] = r;
+    } else if (act) {
+      vout[t * D + (j - 2 * D)] = y;
+    }
+  }
+}
+
+// Output side of a layer in one launch: x1 = LayerNorm(res + out_proj(att)); h = x1*(1+scale)+shift;
+// out = LayerNorm(h + fc2(relu(fc1(h))))            (AttentionBlock tail + the following FeedForwardBlock)
+template <int D>
+__global__ __launch_bounds__(128) void k_out_ffn_block(const float* __restrict__ att, const float* __restrict__ res, const float* __restrict__ Wo,
+                                                      const float* __restrict__ bo, const float* __restrict__ g1, const float* __restrict__ be1,
+                                                      float eps1, const float* __restrict__ ss, const float* __restrict__ W1,
+                                                      const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                      const float* __restrict__ g2, const float* __restrict__ be2, float eps2,
+                                                      float* __restrict__ out, int L, long long tokens, int tok_per_wg) {
+  __shared__ __attribute__((aligned(16))) TokLds<D> S;
+  const int j = threadIdx.x;
+  const bool act = j < D;
+  float wo[D], w1[D], w2[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    wo[c] = act ? Wo[(size_t)c * D + j] : 0.0f;
+    w1[c] = act ? W1[(size_t)c * D + j] : 0.0f;
+    w2[c] = act ? W2[(size_t)c * D + j] : 0.0f;
+  }
+  const float bbo = act ? bo[j] : 0.0f, bb1 = act ? b1[j] : 0.0f, bb2 = act ? b2[j] : 0.0f;
+  const float gg1 = act ? g1[j] : 0.0f, bt1 = act ? be1[j] : 0.0f, gg2 = act ? g2[j] : 0.0f, bt2 = act ? be2[j] : 0.0f;
+  const long long t0 = (long long)blockIdx.x * tok_per_wg;
+  for (long long t = t0; t < t0 + tok_per_wg && t < tokens; ++t) {
+    const long long b = t / L;
+    __syncthreads();
+    if (act) S.a[j] = att[t * D + j];
+    __syncthreads();
+    const float r1 = (act ? res[t * D + j] : 0.0f) + (dot_row<D>(wo, S.a) + bbo);
+    const float x1 = layer_norm_channel<D, 128>(r1, act, gg1, bt1, eps1, S.red);
+    float h = x1;
+    if (act && ss) h = x1 * (1.0f + ss[b * 2 * D + j]) + ss[b * 2 * D + D + j];
+    __syncthreads();
+    if (act) S.a[j] = h;
+    __syncthreads();
+    const float u = fmaxf(dot_row<D>(w1, S.a) + bb1, 0.0f);
+    if (act) S.b[j] = u;
+    __syncthreads();
+    const float r2 = h + (dot_row<D>(w2, S.b) + bb2);
+    const float o = layer_norm_channel<D, 128>(r2, act, gg2, bt2, eps2, S.red);
+    if (act) out[t * D + j] = o;
+  }
+}
+
 static inline int tok_split(long long tokens, int* tok_per_wg) {
   // enough workgroups to fill the chip, few enough that the per-workgroup weight fetch (58-115 KB) stays small
   int per = (int)((tokens + 255) / 256);
   if (per < 1) per = 1;
   *tok_per_wg = per;
   return (int)((tokens + per - 1) / per);
+}
+
+int launch_qkv_block(const float* x, const float* ss, const float* Wq, const float* bq, const float* Wkv, const float* bkv, const float* cs,
+                     const float* sn, float* qout, float* kout, float* vout, int B, int L, int D, hipStream_t s) {
+  if (D != 120) return 1;
+  int per;
+  const long long tokens = (long long)B * L;
+  const int g = tok_split(tokens, &per);
+  hipLaunchKernelGGL(k_qkv_block<120>, dim3(g), dim3(384), 0, s, x, ss, Wq, bq, Wkv, bkv, cs, sn, qout, kout, vout, L, tokens, per);
+  return 0;
+}
+int launch_out_ffn_block(const float* att, const float* res, const float* Wo, const float* bo, const float* g1, const float* be1, float eps1,
+                         const float* ss, const float* W1, const float* b1, const float* W2, const float* b2, const float* g2,
+                         const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s) {
+  if (D != 120) return 1;
+  int per;
+  const long long tokens = (long long)B * L;
+  const int g = tok_split(tokens, &per);
+  hipLaunchKernelGGL(k_out_ffn_block<120>, dim3(g), dim3(128), 0, s, att, res, Wo, bo, g1, be1, eps1, ss, W1, b1, W2, b2, g2, be2, eps2, out, L,
+                     tokens, per);
+  return 0;
 }
 
 int launch_ffn_block(const float* x, const float* ss, const float* W1, const float* b1, const float* W2, const float* b2,

@@ -111,6 +111,11 @@ int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long
 void launch_rotary_apply(const float* x, long long x_stride, const float* cs, const float* sn, float* out, long long rows, int D,
                          hipStream_t s);
 void launch_adaln_modulate(const float* x, const float* ss, float* out, int B, int L, int D, hipStream_t s);
+int launch_qkv_block(const float* x, const float* ss, const float* Wq, const float* bq, const float* Wkv, const float* bkv, const float* cs,
+                     const float* sn, float* qout, float* kout, float* vout, int B, int L, int D, hipStream_t s);
+int launch_out_ffn_block(const float* att, const float* res, const float* Wo, const float* bo, const float* g1, const float* be1, float eps1,
+                         const float* ss, const float* W1, const float* b1, const float* W2, const float* b2, const float* g2,
+                         const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s);
 int launch_ffn_block(const float* x, const float* ss, const float* W1, const float* b1, const float* W2, const float* b2,
                      const float* gamma, const float* beta, float eps, float* out, int B, int L, int D, hipStream_t s);
 int launch_q_block(const float* x, const float* ss, const float* Wq, const float* bq, const float* cs, const float* sn, float* out,

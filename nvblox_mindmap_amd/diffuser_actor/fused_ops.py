@@ -142,3 +142,32 @@ def attn_out_block(att, residual, out_proj, norm) -> torch.Tensor:
                                              _lib.dptr(_c(norm.weight)), _lib.dptr(_c(norm.bias)), float(norm.eps), _lib.dptr(out), B * L, D,
                                              _lib.stream_ptr(att.device)), "mmf_attn_out_block")
     return out
+
+
+def qkv_block(x, scale_shift, q_proj, kv_proj, rot):
+    """Self-attention input side in one launch: (rotary(q_proj(modulated x)), rotary(keys), values), each [B,L,D]."""
+    x = x.contiguous()
+    B, L, D = x.shape
+    q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    ss = _c(scale_shift)
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    _lib.check(_lib.lib().mmf_qkv_block(_lib.dptr(x), _lib.dptr(ss), _lib.dptr(_wt(q_proj)), _lib.dptr(_c(q_proj.bias)), _lib.dptr(_wt(kv_proj)),
+                                        _lib.dptr(_c(kv_proj.bias)), _lib.dptr(cs), _lib.dptr(sn), _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D,
+                                        _lib.stream_ptr(x.device)), "mmf_qkv_block")
+    return q, k, v
+
+
+def out_ffn_block(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) -> torch.Tensor:
+    """AttentionBlock tail + FeedForwardBlock in one launch: x1 = LN1(residual + out_proj(att)); h = modulate(x1);
+    LN2(h + fc2(relu(fc1(h))))."""
+    att = att.contiguous()
+    residual = residual.contiguous()
+    B, L, D = att.shape
+    out = torch.empty_like(att)
+    ss = _c(scale_shift)
+    _lib.check(_lib.lib().mmf_out_ffn_block(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_wt(out_proj)), _lib.dptr(_c(out_proj.bias)),
+                                            _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)), float(norm1.eps), _lib.dptr(ss),
+                                            _lib.dptr(_wt(fc1)), _lib.dptr(_c(fc1.bias)), _lib.dptr(_wt(fc2)), _lib.dptr(_c(fc2.bias)),
+                                            _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out), B, L, D,
+                                            _lib.stream_ptr(att.device)), "mmf_out_ffn_block")
+    return out

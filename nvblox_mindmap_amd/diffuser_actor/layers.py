@@ -240,6 +240,27 @@ class AttentionStack(nn.Module):
         """cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
         is constant across calls (cross-attention at inference)."""
         weights = None
+        if (_fused(query) and not need_weights and query.shape[-1] in _block_dims() and len(self.attn) > 0
+                and (query.shape[-1] // self.attn[0].attn.heads) in (8, 15, 16, 20, 24, 32) and self.ffw[0].fc1.out_features == query.shape[-1]):
+            # three launches per layer: (q | k | v) [or q alone with cached context keys / values], attention,
+            # (out_proj + residual + LayerNorm + feed-forward block)
+            from . import fused_ops as FO
+
+            def ss_of(adaln):
+                if adaln is None or cond is None:
+                    return None
+                return cond_act.lookup(adaln) if isinstance(cond_act, AdaLNBatch) else adaln.proj(F.silu(cond) if cond_act is None else cond_act)
+
+            for li, (blk, ffw) in enumerate(zip(self.attn, self.ffw)):
+                A = blk.attn
+                if self.self_attention:
+                    q, k, v = FO.qkv_block(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot)
+                else:
+                    q = FO.q_block(query, ss_of(blk.adaln), A.q_proj, q_rot)
+                    k, v = kv_caches[li] if kv_caches is not None else FO.kv_block(memory, A.kv_proj, kv_rot if q_rot is not None else None)
+                att = FO.attention_small(q, k, v, key_padding_mask, A.heads)
+                query = FO.out_ffn_block(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
+            return query, None
         for li, (attn, ffw) in enumerate(zip(self.attn, self.ffw)):
             mem = query if self.self_attention else memory
             rot = q_rot if self.self_attention else kv_rot

@@ -216,3 +216,30 @@ def test_block_kernels_match_the_composite_blocks():
     for got, ref in ((got_a, ref_a), (got_f, ref_f), (got_self, ref_self), (got_cached, ref_a)):
         assert torch.allclose(got, ref, rtol=2e-4, atol=2e-5), float((got - ref).abs().max())
     assert torch.equal(got_cached, got_a)
+
+
+def test_fused_attention_stack_matches_composite_stack():
+    """AttentionStack (self- and cross-attention) through the merged kernels (mmf_qkv_block, mmf_out_ffn_block) vs composite."""
+    from nvblox_mindmap_amd.diffuser_actor import layers as L
+
+    torch.manual_seed(2)
+    D, H, B, Lq, Lk = 120, 8, 2, 70, 260
+    x, mem, cond = torch.randn(B, Lq, D, device="cuda"), torch.randn(B, Lk, D, device="cuda"), torch.randn(B, D, device="cuda")
+    q_rot = L.rotary3d(torch.rand(B, Lq, 3, device="cuda"), D)
+    kv_rot = L.rotary3d(torch.rand(B, Lk, 3, device="cuda"), D)
+    pad_q = torch.rand(B, Lq, device="cuda") < 0.2
+    pad_k = torch.rand(B, Lk, device="cuda") < 0.2
+    pad_q[:, 0] = pad_k[:, 0] = False
+    for self_att in (True, False):
+        stack = L.AttentionStack(D, H, 3, 0.0, use_adaln=True, self_attention=self_att).cuda().eval()
+        for p in stack.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+        args = (x, None if self_att else mem, cond, q_rot, None if self_att else kv_rot)
+        with torch.no_grad():
+            ref, _ = stack(*args, key_padding_mask=pad_q if self_att else pad_k)
+            L.FUSED_INFERENCE = True
+            try:
+                got, _ = stack(*args, key_padding_mask=pad_q if self_att else pad_k)
+            finally:
+                L.FUSED_INFERENCE = False
+        assert torch.allclose(got, ref, rtol=5e-4, atol=5e-5), (self_att, float((got - ref).abs().max()))
