@@ -416,7 +416,8 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
         train_one_step(cfg, ddp, opt, batches[i % 2])
     torch.cuda.synchronize(device)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, device)
+    dt = max_over_ranks(time.perf_counter() - t0, device if torch.distributed.get_backend() == "nccl" else None) if world > 1 else \
+        time.perf_counter() - t0
     out = {"step_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "samples_per_s": steps * per_gpu_batch * world / dt,
            "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup,
            "trainable_params": n_train, "frozen_backbone_params": n_frozen, "dtype": "f32",
@@ -448,13 +449,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the fusion path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU.  (BENCH_DIST_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than
+    # ranks -- ranks then share devices modulo the device count; RCCL itself refuses two ranks on one GPU.)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
-        import torch.distributed as dist  # RCCL via backend "nccl": only barrier + max-reduce of the timing
+        import torch.distributed as dist  # RCCL via backend "nccl": barrier + max-reduce of the timing, DDP all-reduce
 
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://")
 
     cfg = S.StreamConfig(hole_mode="patches")
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
@@ -484,7 +488,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -606,8 +610,9 @@ def main():
             "backprojection": backproj,
             "train": train,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()  # rank 0 runs its single-GPU legs after the timed regions: nobody tears the group down before it is done
         dist.destroy_process_group()
 
 
