@@ -116,3 +116,18 @@ def test_nvblox_torch_surface():
     t = Timer("a/b")
     t.stop()
     assert get_mean_time("a/b") >= 0 and get_last_time("a/b") >= 0 and "a/b" in timer_status_string()
+
+    import torch
+    from nvblox_torch.indexing import get_voxel_center_grids
+    from nvblox_torch.layer import FeatureLayer, Layer, convert_layer_to_dense_tensor  # noqa
+    from nvblox_torch.visualization import get_voxel_mesh
+
+    grids = get_voxel_center_grids(torch.tensor([[0, 0, 0], [-1, 2, 3]], dtype=torch.int32), 0.01)
+    assert grids.shape == (2, 8, 8, 8, 3)
+    assert torch.allclose(grids[1, 0, 0, 0], torch.tensor([-0.08 + 0.005, 0.16 + 0.005, 0.24 + 0.005]))
+    cubes = get_voxel_mesh(grids[0].reshape(-1, 3)[:5], 0.01, colors=torch.full((5, 3), 255, dtype=torch.uint8))
+    assert cubes.vertices.shape == (40, 3) and cubes.triangles.shape == (60, 3) and cubes.vertex_colors.shape == (40, 3)
+    # every cube is closed and outward-facing: signed volume of its 12 triangles = voxel volume
+    v = cubes.vertices[cubes.triangles.long()].double()
+    vol = (v[:, 0] * torch.linalg.cross(v[:, 1], v[:, 2])).sum(-1).reshape(5, 12).sum(-1) / 6.0
+    assert torch.allclose(vol, torch.full((5,), 1e-6, dtype=torch.float64), rtol=1e-4)
