@@ -391,12 +391,13 @@ def run_policy_inference(device, reps=3):
     return out
 
 
-def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_matmul_dtype="float32"):
+def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_matmul_dtype="float32", prefetch_backbone=False):
     """Policy training step/s (second half of the BASELINE metric; config 5): diffuser_actor, RGBD_AND_MESH, per-GPU batch 32,
     one 512x512 camera, 2048 vertices x 768 features, frozen ViT-B/16-shaped backbone (random-init stand-in for RADIO v2.5-B),
     fp32, synthetic cached-sample-shaped batches resident on the GPU; DDP (RCCL all-reduce) when world > 1."""
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
-    from nvblox_mindmap_amd.training import build_model, build_optimizer, synthetic_batch, train_one_step, wrap_ddp
+    from nvblox_mindmap_amd.training import (BackbonePrefetcher, build_model, build_optimizer, synthetic_batch, train_one_step,
+                                             wrap_ddp)
     from nvblox_mindmap_amd.training.distributed import barrier, max_over_ranks
 
     torch.manual_seed(0)
@@ -407,20 +408,29 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     ddp = wrap_ddp(model, device)
     opt = build_optimizer(ddp)
     batches = [synthetic_batch(cfg, per_gpu_batch, device, seed=1000 * int(os.environ.get("RANK", "0")) + i) for i in range(2)]
-    for i in range(warmup):
-        train_one_step(cfg, ddp, opt, batches[i % 2])
+    pre = BackbonePrefetcher(ddp, priority=int(os.environ.get("BENCH_PREFETCH_PRIORITY", "0"))) if prefetch_backbone else None
+
+    def run(n, first, feats):
+        # with the prefetcher: the frozen backbone of batch i+1 runs on a second stream next to the trainable pass of batch i;
+        # every timed step executes exactly one backbone forward and one trainable forward/backward/optimizer step
+        for i in range(first, first + n):
+            nxt = pre.submit(batches[(i + 1) % 2]) if pre else None
+            train_one_step(cfg, ddp, opt, batches[i % 2], backbone_feats=pre.wait(feats) if pre else None)
+            feats = nxt
+        return feats
+
+    feats = run(warmup, 0, pre.submit(batches[0]) if pre else None)
     barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for i in range(steps):
-        train_one_step(cfg, ddp, opt, batches[i % 2])
+    run(steps, warmup, feats)
     torch.cuda.synchronize(device)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, device if torch.distributed.get_backend() == "nccl" else None) if world > 1 else \
         time.perf_counter() - t0
     out = {"step_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "samples_per_s": steps * per_gpu_batch * world / dt,
            "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup,
-           "trainable_params": n_train, "frozen_backbone_params": n_frozen, "dtype": "f32",
+           "trainable_params": n_train, "frozen_backbone_params": n_frozen, "dtype": "f32", "backbone_prefetch": bool(prefetch_backbone),
            "allreduce_payload_MB": n_train * 4 / 1e6, "parallelism": f"dp{world}" if world > 1 else "single",
            "model": "diffuser_actor RGBD_AND_MESH, 1 cam 512x512, 2048 vertices x 768, frozen ViT-B/16-shaped backbone (random init)"}
     del model, ddp, opt, batches
@@ -513,10 +523,14 @@ def main():
     if not args.no_train:  # every rank takes part (DDP)
         if dist is not None:
             dist.barrier()
-        train = run_training(device, world, steps=args.train_steps)
+        # the product trainer path: the frozen backbone of the next batch runs on a second stream (BackbonePrefetcher); the
+        # strictly serial order is reported beside it
+        train = run_training(device, world, steps=args.train_steps, prefetch_backbone=True)
+        serial = run_training(device, world, steps=args.train_steps)
+        train["serial_order"] = {"step_per_s": serial["step_per_s"], "ms_per_step": serial["ms_per_step"]}
         # secondary figure, not the headline: the frozen backbone's matmuls with float16 inputs / fp32 accumulation -- the
         # mantissa width of the TF32 mode the reference runs its backbone in (feature_extraction.py:322); gfx950 has no TF32
-        t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16")
+        t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16", prefetch_backbone=True)
         train["fp16_backbone_matmuls"] = {"step_per_s": t16["step_per_s"], "ms_per_step": t16["ms_per_step"],
                                           "note": "frozen backbone under float16 autocast (10-bit mantissa like the reference's TF32 "
                                                   "backbone, fp32 accumulate); everything trainable stays float32"}

@@ -87,17 +87,24 @@ class Encoder(nn.Module):
         return self
 
     # -- context tokens ---------------------------------------------------------------------------------------------
-    def encode_images(self, rgb, pcd, valid_mask):
+    @torch.no_grad()
+    def backbone_features(self, rgb):
+        """Frozen image backbone: rgb (B,ncam,3,H,W) in [0,1] -> (B*ncam, C, h, w) float32.  No parameter of it is trained,
+        so a trainer may evaluate it for the NEXT batch on a second stream while the trainable part of the current batch
+        runs (training.trainer.BackbonePrefetcher)."""
+        # The reference runs the frozen backbone under AllowMatMulTf32 (image_processing/feature_extraction.py:322): 10-bit
+        # mantissa inputs, fp32 accumulation.  gfx950 has no TF32 MFMA; float16 inputs carry the same mantissa.  Default: fp32.
+        fp16 = self.cfg.backbone_matmul_dtype == "float16" and rgb.is_cuda
+        with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+            feats = self.backbone(rgb.flatten(0, 1))
+        return feats.float()
+
+    def encode_images(self, rgb, pcd, valid_mask, backbone_feats=None):
         """rgb (B,ncam,3,H,W) in [0,1], pcd (B,ncam,3,H,W) normalised points, valid_mask (B,ncam,H,W) ->
-        tokens (B,ncam*h*w,D), positions (B,ncam*h*w,3), mask (B,ncam*h*w)."""
-        B, ncam = rgb.shape[:2]
-        with torch.no_grad():
-            # The reference runs the frozen backbone under AllowMatMulTf32 (image_processing/feature_extraction.py:322): 10-bit
-            # mantissa inputs, fp32 accumulation.  gfx950 has no TF32 MFMA; float16 inputs carry the same mantissa.  Default: fp32.
-            fp16 = self.cfg.backbone_matmul_dtype == "float16" and rgb.is_cuda
-            with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
-                feats = self.backbone(rgb.flatten(0, 1))  # (B*ncam, C, h, w)
-            feats = feats.float()
+        tokens (B,ncam*h*w,D), positions (B,ncam*h*w,3), mask (B,ncam*h*w).  ``backbone_feats``: the output of
+        ``backbone_features(rgb)`` when it has been computed ahead of time."""
+        B, ncam = pcd.shape[:2]
+        feats = self.backbone_features(rgb) if backbone_feats is None else backbone_feats
         h, w = feats.shape[-2:]
         tokens = self.image_embed(feats.flatten(2).transpose(1, 2)).reshape(B, ncam * h * w, -1)
         pos = F.interpolate(pcd.flatten(0, 1), (h, w), mode="bilinear", align_corners=False)
@@ -260,11 +267,11 @@ class DiffuserActor(nn.Module):
 
     # -- shared encoding --------------------------------------------------------------------------------------------------
     def encode_inputs(self, rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices, vertices_valid_mask, instruction,
-                      gripper_history, closedness):
+                      gripper_history, closedness, backbone_feats=None):
         enc = self.encoder
         feats, pos, mask = [], [], []
         if enc.uses_images:
-            f, p, m = enc.encode_images(rgb_obs, pcd_obs, pcd_valid_mask)
+            f, p, m = enc.encode_images(rgb_obs, pcd_obs, pcd_valid_mask, backbone_feats)
             feats.append(f), pos.append(p), mask.append(m)
         if enc.uses_mesh:
             assert vertices.ndim == 3 and vertices_valid_mask.ndim == 2 and vertices.shape[1] == vertices_valid_mask.shape[1]
@@ -339,7 +346,7 @@ class DiffuserActor(nn.Module):
 
     # -- forward --------------------------------------------------------------------------------------------------------
     def forward(self, gt_gripper_pred, gt_head_yaw, rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices,
-                vertices_valid_mask, instruction, gripper_history, run_inference: bool = False):
+                vertices_valid_mask, instruction, gripper_history, run_inference: bool = False, backbone_feats=None):
         """Arguments as in the reference (diffuser_actor.py:518-531):
           gt_gripper_pred (B,L,ngrip,8) xyz + quaternion + openness (or None at inference), gt_head_yaw (B,L,1),
           rgb_obs (B,ncam,3,H,W) in [0,1], pcd_obs (B,ncam,3,H,W) world points, pcd_valid_mask (B,ncam,H,W),
@@ -362,7 +369,7 @@ class DiffuserActor(nn.Module):
             gt = normalize_trajectory(gt_gripper_pred[..., :7], wb, cfg.quaternion_format)
         with Timer("diffuser_actor/encode_inputs"):
             enc = self.encode_inputs(rgb_obs, pcd_obs, pcd_valid_mask, vertex_features, vertices, vertices_valid_mask,
-                                     instruction, history, closedness)
+                                     instruction, history, closedness, backbone_feats)
         B, dev = history.shape[0], history.device
         if run_inference:
             traj, head_yaw = self.sample_trajectory(enc, B, dev)

@@ -3,4 +3,4 @@
 from .checkpoint import load_inference_checkpoint, load_train_checkpoint, save_checkpoint  # noqa: F401
 from .distributed import ProcessGroup, all_gather_objects, get_rank, get_world_size, max_over_ranks  # noqa: F401
 from .sampler import DistributedWeightedSampler  # noqa: F401
-from .trainer import build_model, build_optimizer, synthetic_batch, train_one_step, wrap_ddp  # noqa: F401
+from .trainer import BackbonePrefetcher, build_model, build_optimizer, synthetic_batch, train_one_step, wrap_ddp  # noqa: F401

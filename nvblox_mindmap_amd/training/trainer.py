@@ -96,14 +96,55 @@ def unpack_batch(cfg: DiffuserActorConfig, batch: Dict[str, torch.Tensor], min_d
     return out
 
 
-def train_one_step(cfg: DiffuserActorConfig, model: nn.Module, optimizer, batch: Dict[str, torch.Tensor], scheduler=None):
-    """unpack -> forward (losses) -> backward (DDP all-reduce overlaps) -> AdamW step.  Returns the detached losses."""
+class BackbonePrefetcher:
+    """Evaluates the frozen image backbone of the NEXT batch on a second HIP stream while the trainable part of the current
+    batch (encoder + diffusion head forward, backward, optimizer) runs on the main stream.
+
+    The backbone is frozen (feature_extraction.py: the extractor is never trained), so its output for batch t+1 does not
+    depend on the optimizer step of batch t: the result is identical to the serial order.  Its fp32 GEMMs are MFMA-bound while
+    the trainable part is a long tail of small HBM-bound kernels, so the two fill each other's gaps.  Every step still runs
+    one backbone forward and one full trainable pass.
+
+        pre = BackbonePrefetcher(model)
+        feats = pre.submit(first_batch)
+        for batch, next_batch in ...:
+            nxt = pre.submit(next_batch)             # enqueued on the side stream, returns at once
+            train_one_step(cfg, model, opt, batch, backbone_feats=pre.wait(feats))
+            feats = nxt
+    """
+
+    def __init__(self, model: nn.Module, priority: int = 0):
+        self.model = model.module if hasattr(model, "module") else model
+        self.stream = torch.cuda.Stream(priority=priority)
+
+    def submit(self, batch: Dict[str, torch.Tensor]):
+        rgbs = batch["rgbs"]
+        self.stream.wait_stream(torch.cuda.current_stream())  # the batch was produced on the main stream
+        with torch.cuda.stream(self.stream):
+            feats = self.model.encoder.backbone_features(rgbs)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        rgbs.record_stream(self.stream)
+        return feats, done
+
+    @staticmethod
+    def wait(handle) -> torch.Tensor:
+        feats, done = handle
+        torch.cuda.current_stream().wait_event(done)
+        feats.record_stream(torch.cuda.current_stream())
+        return feats
+
+
+def train_one_step(cfg: DiffuserActorConfig, model: nn.Module, optimizer, batch: Dict[str, torch.Tensor], scheduler=None,
+                   backbone_feats: Optional[torch.Tensor] = None):
+    """unpack -> forward (losses) -> backward (DDP all-reduce overlaps) -> AdamW step.  Returns the detached losses.
+    ``backbone_feats``: the frozen backbone's output for this batch when a BackbonePrefetcher computed it ahead."""
     with Timer("step/train/unpack_batch"):
         s = unpack_batch(cfg, batch)
     optimizer.zero_grad(set_to_none=True)
     with Timer("step/train/compute_losses"):
         losses, _, _ = model(s["gt_gripper_pred"], s["gt_head_yaw"], s["rgbs"], s["pcds"], s["pcd_valid_mask"], s["vertex_features"],
-                             s["vertices"], s["vertices_valid_mask"], None, s["gripper_history"])
+                             s["vertices"], s["vertices_valid_mask"], None, s["gripper_history"], backbone_feats=backbone_feats)
     with Timer("step/train/backprop"):
         losses[0].backward()
     optimizer.step()

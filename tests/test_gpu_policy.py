@@ -54,6 +54,36 @@ def test_training_step_on_gpu_with_images():
     assert traj.shape == (1, 1, 2, 8) and torch.isfinite(traj).all()
 
 
+def test_backbone_prefetch_trains_like_the_serial_order():
+    """The frozen backbone of batch i+1 evaluated on a second stream next to the trainable pass of batch i: same losses and
+    same parameters as the serial order, bit for bit (the backbone has no trainable parameter)."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import BackbonePrefetcher, build_model, build_optimizer, synthetic_batch, train_one_step
+
+    cfg = DiffuserActorConfig(data_type="rgbd_and_mesh", image_size=(128, 128), feature_dim=768)
+    batches = [synthetic_batch(cfg, 2, "cuda", num_vertices=256, seed=i) for i in range(4)]
+    results = []
+    for prefetch in (False, True):
+        torch.manual_seed(0)
+        model = build_model(cfg, device="cuda")
+        opt = build_optimizer(model)
+        torch.manual_seed(1)  # noise / timestep draws of the steps
+        losses = []
+        if prefetch:
+            pre = BackbonePrefetcher(model)
+            feats = pre.submit(batches[0])
+            for i, b in enumerate(batches):
+                nxt = pre.submit(batches[i + 1]) if i + 1 < len(batches) else None
+                losses.append(train_one_step(cfg, model, opt, b, backbone_feats=pre.wait(feats))[0])
+                feats = nxt
+        else:
+            losses = [train_one_step(cfg, model, opt, b)[0] for b in batches]
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses), torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad])))
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+
+
 def test_file_fed_training_step(tmp_path):
     """Demo on disk (reference layout) -> DataLoader -> gpu_unpack (transforms on the GPU) -> training step; the GPU
     transforms equal the reference's CPU transformers bit for bit."""

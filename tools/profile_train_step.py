@@ -41,11 +41,36 @@ def main():
             print("backbone fwd bf16-autocast ms", timed(lambda: model.encoder.backbone(rgb)))
     from torch.profiler import ProfilerActivity, profile
 
+    # stage times: forward pieces under no_grad (the backward of a stage costs about twice its forward)
+    from nvblox_mindmap_amd.training.trainer import unpack_batch
+    s = unpack_batch(cfg, batch)
+    enc_mod = model.encoder
+    with torch.no_grad():
+        print("fwd encode_inputs ms", timed(lambda: model(s["gt_gripper_pred"], s["gt_head_yaw"], s["rgbs"], s["pcds"], s["pcd_valid_mask"],
+                                                           s["vertex_features"], s["vertices"], s["vertices_valid_mask"], None,
+                                                           s["gripper_history"])))
+    print("fwd (autograd on) ms", timed(lambda: model(s["gt_gripper_pred"], s["gt_head_yaw"], s["rgbs"], s["pcds"], s["pcd_valid_mask"],
+                                                      s["vertex_features"], s["vertices"], s["vertices_valid_mask"], None,
+                                                      s["gripper_history"])[0][0]))
+
+    def fwd_bwd():
+        opt.zero_grad(set_to_none=True)
+        model(s["gt_gripper_pred"], s["gt_head_yaw"], s["rgbs"], s["pcds"], s["pcd_valid_mask"], s["vertex_features"], s["vertices"],
+              s["vertices_valid_mask"], None, s["gripper_history"])[0][0].backward()
+
+    print("fwd + bwd ms", timed(fwd_bwd))
+    print("optimizer.step ms", timed(opt.step))
+
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         for _ in range(2):
             train_one_step(cfg, model, opt, batch)
         torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=70))
+    rows = [e for e in prof.key_averages() if e.self_device_time_total > 0]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    total = sum(e.self_device_time_total for e in rows)
+    print(f"device time per step {total / 2e3:.2f} ms over {sum(e.count for e in rows) // 2} kernels")
+    for e in rows[:60]:
+        print(f"{e.self_device_time_total / 2e3:9.3f} ms {e.count // 2:5d} x {e.self_device_time_total / e.count:9.1f} us  {e.key[:110]}")
 
 
 if __name__ == "__main__":
