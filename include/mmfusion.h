@@ -273,6 +273,21 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
                       const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev,
                       const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev, const float* ln2_bias_dev, float ln2_eps,
                       float* out_dev, int B, int L, int D, void* stream);
+/* Matrix-core (v_mfma_f32_16x16x4_f32, exact f32) forms of the per-layer kernels, built for D = 120, H = 8 (head_dim 15):
+ *   mmf_qkv_heads        the projections of mmf_qkv_block written head-major and padded to 16 channels:
+ *                        q_heads, k_heads [B, H, L16, 16], v_heads_t [B, H, 16, L16] (L16 = L rounded up to 16; padding = 0).
+ *                        roles: 7 = q | k | v, 1 = q alone (Wkv / k / v may be null), 6 = k | v alone (Wq / q may be null)
+ *   mmf_attention_heads  softmax(q k^T / sqrt(head_dim) + key padding) v over those layouts -> out [B, Lq, D]
+ *   mmf_out_ffn_mfma     same contract as mmf_out_ffn_block */
+int mmf_qkv_heads(const float* x_dev, const float* scale_shift_dev, const float* Wq_dev, const float* bq_dev, const float* Wkv_dev,
+                  const float* bkv_dev, const float* cos_dev, const float* sin_dev, float* q_heads_dev, float* k_heads_dev,
+                  float* v_heads_t_dev, int B, int L, int D, int H, int roles, void* stream);
+int mmf_attention_heads(const float* q_heads_dev, const float* k_heads_dev, const float* v_heads_t_dev, const uint8_t* key_padding_dev,
+                        float* out_dev, int B, int Lq, int Lk, int H, int head_dim, void* stream);
+int mmf_out_ffn_mfma(const float* att_dev, const float* residual_dev, const float* Wo_dev, const float* bo_dev, const float* ln1_weight_dev,
+                     const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev,
+                     const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev, const float* ln2_bias_dev, float ln2_eps,
+                     float* out_dev, int B, int L, int D, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

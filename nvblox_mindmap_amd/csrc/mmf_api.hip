@@ -1394,6 +1394,40 @@ int mmf_out_ffn_block(const float* att, const float* residual, const float* Wo, 
   return check_launch();
 }
 
+int mmf_qkv_heads(const float* x, const float* scale_shift, const float* Wq, const float* bq, const float* Wkv, const float* bkv,
+                  const float* cos_, const float* sin_, float* q_heads, float* k_heads, float* v_heads_t, int B, int L, int D, int H, int roles,
+                  void* stream) {
+  const bool need_q = (roles & 1) != 0, need_kv = (roles & 6) != 0;
+  if (!x || B <= 0 || L <= 0 || (roles != 7 && roles != 1 && roles != 6) || (need_q && (!Wq || !bq || !q_heads)) ||
+      (need_kv && (!Wkv || !bkv || !k_heads || !v_heads_t)) || ((cos_ == nullptr) != (sin_ == nullptr)))
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_qkv_heads");
+  if (launch_qkv_heads(x, scale_shift, Wq, bq, Wkv, bkv, cos_, sin_, q_heads, k_heads, v_heads_t, B, L, D, H, roles, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_heads is built for D = 120, H = 8");
+  return check_launch();
+}
+
+int mmf_attention_heads(const float* q_heads, const float* k_heads, const float* v_heads_t, const uint8_t* key_padding, float* out, int B,
+                        int Lq, int Lk, int H, int head_dim, void* stream) {
+  if (!q_heads || !k_heads || !v_heads_t || !out || B <= 0 || Lq <= 0 || Lk <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_heads");
+  if (launch_attention_heads(q_heads, k_heads, v_heads_t, key_padding, out, B, Lq, Lk, H, head_dim, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_attention_heads is built for H = 8, head_dim = 15");
+  return check_launch();
+}
+
+int mmf_out_ffn_mfma(const float* att, const float* residual, const float* Wo, const float* bo, const float* ln1_weight,
+                     const float* ln1_bias, float ln1_eps, const float* scale_shift, const float* W1, const float* b1, const float* W2,
+                     const float* b2, const float* ln2_weight, const float* ln2_bias, float ln2_eps, float* out, int B, int L, int D,
+                     void* stream) {
+  if (!att || !residual || !Wo || !bo || !ln1_weight || !ln1_bias || !W1 || !b1 || !W2 || !b2 || !ln2_weight || !ln2_bias || !out || B <= 0 ||
+      L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_mfma");
+  if (launch_out_ffn_mfma(att, residual, Wo, bo, ln1_weight, ln1_bias, ln1_eps, scale_shift, W1, b1, W2, b2, ln2_weight, ln2_bias, ln2_eps, out,
+                          B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma is built for D = 120");
+  return check_launch();
+}
+
 int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)

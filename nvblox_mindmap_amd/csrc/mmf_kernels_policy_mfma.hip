@@ -1,0 +1,444 @@
+// Matrix-core (MFMA) forms of the per-layer inference kernels of the diffusion head (mmf_kernels_policy.hip holds the
+// thread-per-channel forms and everything that is not GEMM-shaped).
+//
+// A denoising step works on ~616 tokens x 120 channels, 8 heads of 15 channels.  All three kernels use the f32-input
+// v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation: an fmaf chain) on tiles of 16 tokens:
+//
+//   operand maps (lane l, j = l & 15, s = l >> 4):   A[i = j][k = s]   B[k = s][col = j]   D[row = 4 s + r][col = j], r = 0..3
+//
+// The reduction index is free to be permuted as long as A and B agree, so every lane loads its share of an operand row
+// as ONE 16-byte piece: step (m, kk) of a 120-channel reduction is channel 16 m + 4 s + kk (k_qkv_heads, k_out_ffn_mfma),
+// and the 16-key (16-channel) reductions of the attention kernel use key (channel) 4 s + kk.
+//
+//   k_qkv_heads       q = rotary(q_proj(modulated x)) | k = rotary(k_proj(x)) | v = v_proj(x), written HEAD-MAJOR and padded
+//                     to 16 channels: Qp, Kp [B, H, L16, 16], Vt [B, H, 16, L16] (values transposed) -- the layouts from which
+//                     k_attention_heads loads every operand with one aligned 16-byte access per lane
+//   k_attention_heads softmax(q k^T / sqrt(dh) + padding) v: scores are produced TRANSPOSED (S^T = K Q^T), which leaves each
+//                     lane holding, for its query row, exactly the four probabilities the B operand of O^T = V^T P^T needs,
+//                     and makes the softmax statistics of a query row lane-aligned with the columns of O^T: no transposes, no
+//                     LDS, two shuffles per reduction.  The keys of a (query tile, head) are split over the 4 waves of the
+//                     workgroup and merged once through LDS
+//   k_out_ffn_mfma    x1 = LN(res + out_proj(att)); h = modulate(x1); out = LN(h + fc2(relu(fc1(h)))): three chained GEMMs on a
+//                     16-token tile, the tile moves between them through LDS (D layout -> A layout)
+#include "mmf_device.h"
+#include "mmf_launch.h"
+
+namespace mmf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int kD = 120, kH = 8, kDH = 15;  // the policy's embedding dim / heads / head dim (the kernels are built for these)
+constexpr int kKSteps = 32;                 // 8 x 4 reduction steps cover 128 >= 120 channels
+
+// A-operand share of one token row: a[4 m + kk] = row[16 m + 4 s + kk] (0 beyond D)
+__device__ __forceinline__ void load_row_share(const float* __restrict__ row, int s, bool ok, float (&a)[kKSteps]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int c0 = 16 * m + 4 * s;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && c0 < kD) v = *reinterpret_cast<const float4*>(row + c0);
+    a[4 * m] = v.x;
+    a[4 * m + 1] = v.y;
+    a[4 * m + 2] = v.z;
+    a[4 * m + 3] = v.w;
+  }
+}
+
+// B-operand share of one output column: w[4 m + kk] = Wt[(16 m + 4 s + kk) * ld + col] (Wt = transposed weights [in, out])
+__device__ __forceinline__ void load_col_share(const float* __restrict__ Wt, int ld, int col, bool ok, int s, float (&w)[kKSteps]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = 16 * m + 4 * s + kk;
+      w[4 * m + kk] = (ok && c < kD) ? Wt[(size_t)c * ld + col] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ f32x4 tile_gemm(const float (&a)[kKSteps], const float (&w)[kKSteps]) {
+  // two accumulators: the dependent-accumulator latency of the 16x16x4 form (40 cycles) exceeds its issue interval (32)
+  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < kKSteps; i += 2) {
+    c0 = mfma4(a[i], w[i], c0);
+    c1 = mfma4(a[i + 1], w[i + 1], c1);
+  }
+  return c0 + c1;
+}
+
+// ---- q | k | v projections, rotary, head-major outputs ---------------------------------------------------------------------
+// grid (B * L16 / 16, 3 roles), 256 threads: wave w owns heads 2 w and 2 w + 1 (30 channels: rotary pairs never leave the wave).
+__global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ WqT,
+                                                  const float* __restrict__ bq, const float* __restrict__ WkvT,
+                                                  const float* __restrict__ bkv, const float* __restrict__ cs,
+                                                  const float* __restrict__ sn, float* __restrict__ Qp, float* __restrict__ Kp,
+                                                  float* __restrict__ Vt, int L, int L16, int role0) {
+  const int tpb = L16 / 16;
+  const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
+  const int role = role0 + (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+
+  float a[kKSteps];
+  {
+    const int tok = l0 + j;
+    const bool ok = tok < L;
+    load_row_share(x + ((size_t)b * L + (ok ? tok : 0)) * kD, s, ok, a);
+    if (role == 0 && ss != nullptr && ok) {  // AdaLN modulation of the query input
+      const float* sc = ss + (size_t)b * 2 * kD;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int c0 = 16 * m + 4 * s;
+        if (c0 < kD) {
+          const float4 g = *reinterpret_cast<const float4*>(sc + c0), h = *reinterpret_cast<const float4*>(sc + kD + c0);
+          a[4 * m] = a[4 * m] * (1.0f + g.x) + h.x;
+          a[4 * m + 1] = a[4 * m + 1] * (1.0f + g.y) + h.y;
+          a[4 * m + 2] = a[4 * m + 2] * (1.0f + g.z) + h.z;
+          a[4 * m + 3] = a[4 * m + 3] * (1.0f + g.w) + h.w;
+        }
+      }
+    }
+  }
+  const float* Wt = role == 0 ? WqT : WkvT;
+  const int ld = role == 0 ? kD : 2 * kD, off = role == 2 ? kD : 0;
+  const float* bias = role == 0 ? bq : bkv + off;
+
+  f32x4 y[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = kDH * (2 * w + n) + j;  // column j = 15 of a head tile is padding
+    float wv[kKSteps];
+    load_col_share(Wt + off, ld, col, j < kDH, s, wv);
+    y[n] = tile_gemm(a, wv);
+    const float bb = j < kDH ? bias[col] : 0.0f;
+    y[n] += bb;
+  }
+
+  if (role < 2 && cs != nullptr) {
+    // rotary over the 120-vector: out[c] = y[c] cos[c] + (c odd ? y[c-1] : -y[c+1]) sin[c].  Within the wave's 30 channels
+    // p = 15 n + j the partner is p ^ 1, held by lane (s, j') of tile n'.
+    f32x4 part[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int p = kDH * n + (j < kDH ? j : 0), pp = p ^ 1;
+      const int np = pp >= kDH ? 1 : 0, jp = pp - kDH * np;
+      const int src = s * 16 + jp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = __shfl(y[0][r], src, 64), v1 = __shfl(y[1][r], src, 64);
+        const float v = np ? v1 : v0;
+        part[n][r] = (p & 1) ? v : -v;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int col = kDH * (2 * w + n) + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = l0 + 4 * s + r;
+        if (j < kDH && tok < L) {
+          const size_t e = ((size_t)b * L + tok) * kD + col;
+          y[n][r] = y[n][r] * cs[e] + part[n][r] * sn[e];
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int h = 2 * w + n;
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (j < kDH && l0 + 4 * s + r < L) ? y[n][r] : 0.0f;  // padding stays finite (zero)
+    if (role == 2) {
+      *reinterpret_cast<f32x4*>(Vt + (((size_t)b * kH + h) * 16 + j) * L16 + l0 + 4 * s) = o;
+    } else {
+      float* P = (role == 0 ? Qp : Kp) + (((size_t)b * kH + h) * L16 + l0 + 4 * s) * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[r * 16] = o[r];
+    }
+  }
+}
+
+// ---- attention over head-major operands -------------------------------------------------------------------------------------
+constexpr int kAttChunk = 10;  // key tiles a wave scores before it runs the softmax update (40 score registers)
+
+__global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict__ Qp, const float* __restrict__ Kp,
+                                                        const float* __restrict__ Vt, const uint8_t* __restrict__ pad,
+                                                        float* __restrict__ out, int Lq, int Lq16, int Lk, int Lk16, float scale) {
+  __shared__ float sM[4][16], sL[4][16];
+  __shared__ float sO[4][16][17];
+  const int q0 = (int)blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+  const size_t bh = (size_t)b * kH + h;
+
+  float q[4];
+  {
+    const float4 v = *reinterpret_cast<const float4*>(Qp + (bh * Lq16 + q0 + j) * 16 + 4 * s);
+    q[0] = v.x * scale, q[1] = v.y * scale, q[2] = v.z * scale, q[3] = v.w * scale;
+  }
+  const float* Kb = Kp + bh * Lk16 * 16;
+  const float* Vb = Vt + (bh * 16 + j) * Lk16;
+  const uint8_t* pb = pad ? pad + (size_t)b * Lk : nullptr;
+
+  float m_run = -INFINITY, l_run = 0.0f;
+  f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f};  // O^T: rows = channel 4 s + r, column = query row j
+  const int ntiles = Lk16 / 16;
+  for (int tb = w; tb < ntiles; tb += 4 * kAttChunk) {  // this wave's tiles: tb, tb + 4, ...
+    float4 kv[kAttChunk], vv[kAttChunk];
+#pragma unroll
+    for (int i = 0; i < kAttChunk; ++i) {
+      const int t = tb + 4 * i;
+      if (t < ntiles) {
+        kv[i] = *reinterpret_cast<const float4*>(Kb + ((size_t)t * 16 + j) * 16 + 4 * s);
+        vv[i] = *reinterpret_cast<const float4*>(Vb + t * 16 + 4 * s);
+      } else {
+        kv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    f32x4 S[kAttChunk];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kAttChunk; ++i) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      c = mfma4(kv[i].x, q[0], c);
+      c = mfma4(kv[i].y, q[1], c);
+      c = mfma4(kv[i].z, q[2], c);
+      c = mfma4(kv[i].w, q[3], c);
+      const int t = tb + 4 * i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * s + r;
+        bool dead = t >= ntiles || key >= Lk;
+        if (!dead && pb) dead = pb[key] != 0;
+        c[r] = dead ? -INFINITY : c[r];
+        cmax = fmaxf(cmax, c[r]);
+      }
+      S[i] = c;
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+    const float m_new = fmaxf(m_run, cmax);
+    const float corr = (m_run == -INFINITY) ? 0.0f : __expf(m_run - m_new);
+    l_run *= corr;
+    O0 *= corr;
+    O1 *= corr;
+#pragma unroll
+    for (int i = 0; i < kAttChunk; ++i) {
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = (S[i][r] == -INFINITY) ? 0.0f : __expf(S[i][r] - m_new);
+        l_run += p[r];
+      }
+      if (i & 1) {
+        O1 = mfma4(vv[i].x, p[0], O1);
+        O1 = mfma4(vv[i].y, p[1], O1);
+        O1 = mfma4(vv[i].z, p[2], O1);
+        O1 = mfma4(vv[i].w, p[3], O1);
+      } else {
+        O0 = mfma4(vv[i].x, p[0], O0);
+        O0 = mfma4(vv[i].y, p[1], O0);
+        O0 = mfma4(vv[i].z, p[2], O0);
+        O0 = mfma4(vv[i].w, p[3], O0);
+      }
+    }
+    m_run = m_new;
+  }
+  // merge the four key ranges
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const f32x4 O = O0 + O1;
+  if (s == 0) {
+    sM[w][j] = m_run;
+    sL[w][j] = l_run;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sO[w][4 * s + r][j] = O[r];
+  __syncthreads();
+  if (w == 0) {
+    float M = fmaxf(fmaxf(sM[0][j], sM[1][j]), fmaxf(sM[2][j], sM[3][j]));
+    float f[4], l = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f[u] = (sM[u][j] == -INFINITY) ? 0.0f : __expf(sM[u][j] - M);
+      l += f[u] * sL[u][j];
+    }
+    const int row = q0 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = 4 * s + r;
+      float o = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o += f[u] * sO[u][ch][j];
+      if (ch < kDH && row < Lq) out[((size_t)b * Lq + row) * kD + h * kDH + ch] = o / l;
+    }
+  }
+}
+
+// ---- out_proj + LayerNorm + feed-forward block -----------------------------------------------------------------------------
+constexpr int kRS = 132;  // LDS row stride of a 16-token tile (floats)
+
+// LayerNorm of the 16 x 120 tile in `src` (wave w: tokens 4 w .. 4 w + 3, 16 lanes per token, 8 channels per lane); result
+// (optionally AdaLN-modulated) goes to `dst` (LDS) and / or `gout` (global, row stride D)
+__device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (*dst)[kRS], float* __restrict__ gout, long long t0,
+                                                long long tokens, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float eps, const float* __restrict__ ss, int L, int lane, int w) {
+  const int tl = 4 * w + (lane >> 4), q = lane & 15;
+  float v[8];
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = q + 16 * i;
+    v[i] = c < kD ? src[tl][c] : 0.0f;
+    sum += v[i];
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  const float mean = sum / (float)kD;
+  float var = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = q + 16 * i;
+    const float d = c < kD ? v[i] - mean : 0.0f;
+    v[i] = d;
+    var += d * d;
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+  const float inv = rsqrtf(var / (float)kD + eps);
+  const long long tok = t0 + tl;
+  const bool live = tok < tokens;
+  const float* sc = (ss != nullptr && live) ? ss + (size_t)(tok / L) * 2 * kD : nullptr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = q + 16 * i;
+    if (c < kD) {
+      float o = v[i] * inv * gamma[c] + beta[c];
+      if (sc) o = o * (1.0f + sc[c]) + sc[kD + c];
+      if (dst) dst[tl][c] = o;
+      if (gout && live) gout[tok * kD + c] = o;
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_row_share(const float (*src)[kRS], int j, int s, float (&a)[kKSteps]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int c0 = 16 * m + 4 * s;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < kD) v = *reinterpret_cast<const float4*>(&src[j][c0]);
+    a[4 * m] = v.x;
+    a[4 * m + 1] = v.y;
+    a[4 * m + 2] = v.z;
+    a[4 * m + 3] = v.w;
+  }
+}
+
+// grid = 16-token tiles of the flattened [B L] token axis; wave w owns output columns [32 w, 32 w + 32)
+__global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ att, const float* __restrict__ res,
+                                                     const float* __restrict__ WoT, const float* __restrict__ bo,
+                                                     const float* __restrict__ g1, const float* __restrict__ be1, float eps1,
+                                                     const float* __restrict__ ss, const float* __restrict__ W1T,
+                                                     const float* __restrict__ b1, const float* __restrict__ W2T,
+                                                     const float* __restrict__ b2, const float* __restrict__ g2,
+                                                     const float* __restrict__ be2, float eps2, float* __restrict__ out, int L,
+                                                     long long tokens) {
+  __shared__ __attribute__((aligned(16))) float sH[16][kRS];  // h = modulate(LN1(..)): A operand of fc1 and residual of fc2
+  __shared__ __attribute__((aligned(16))) float sU[16][kRS];  // relu(fc1(h)): A operand of fc2
+  __shared__ __attribute__((aligned(16))) float sY[16][kRS];  // pre-LayerNorm sums
+  const long long t0 = (long long)blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+
+  float a[kKSteps], wv[2][kKSteps];
+  {
+    const long long tok = t0 + j;
+    const bool ok = tok < tokens;
+    load_row_share(att + (ok ? tok : 0) * kD, s, ok, a);
+  }
+  // ---- x1 = LN1(res + out_proj(att)), h = modulate(x1)
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(WoT, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = 32 * w + 16 * n + j;
+    const f32x4 y = tile_gemm(a, wv[n]);
+    if (col < kD) {
+      const float bb = bo[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long tok = t0 + 4 * s + r;
+        sY[4 * s + r][col] = y[r] + bb + (tok < tokens ? res[tok * kD + col] : 0.0f);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(W1T, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);  // in flight over the LN
+  __syncthreads();
+  tile_layer_norm(sY, sH, nullptr, t0, tokens, g1, be1, eps1, ss, L, lane, w);
+  __syncthreads();
+  // ---- u = relu(fc1(h))
+  lds_row_share(sH, j, s, a);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = 32 * w + 16 * n + j;
+    const f32x4 y = tile_gemm(a, wv[n]);
+    if (col < kD) {
+      const float bb = b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sU[4 * s + r][col] = fmaxf(y[r] + bb, 0.0f);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(W2T, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);
+  __syncthreads();
+  // ---- out = LN2(h + fc2(u))
+  lds_row_share(sU, j, s, a);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = 32 * w + 16 * n + j;
+    const f32x4 y = tile_gemm(a, wv[n]);
+    if (col < kD) {
+      const float bb = b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = sH[4 * s + r][col] + (y[r] + bb);
+    }
+  }
+  __syncthreads();
+  tile_layer_norm(sY, nullptr, out, t0, tokens, g2, be2, eps2, nullptr, L, lane, w);
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------
+int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const float* bq, const float* WkvT, const float* bkv,
+                     const float* cs, const float* sn, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H, int roles,
+                     hipStream_t s) {
+  if (D != kD || H != kH) return 1;
+  const int L16 = (L + 15) / 16 * 16;
+  // roles: 7 = q | k | v (self-attention), 1 = q alone, 6 = k | v alone (a memory whose keys / values are cached)
+  const int role0 = (roles & 1) ? 0 : 1, nroles = roles == 7 ? 3 : (roles == 1 ? 1 : 2);
+  hipLaunchKernelGGL(k_qkv_heads, dim3(B * (L16 / 16), nroles), dim3(256), 0, s, x, ss, WqT, bq, WkvT, bkv, cs, sn, Qp, Kp, Vt, L, L16, role0);
+  return 0;
+}
+
+int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* out, int B, int Lq, int Lk,
+                           int H, int dh, hipStream_t s) {
+  if (H != kH || dh != kDH) return 1;
+  const int Lq16 = (Lq + 15) / 16 * 16, Lk16 = (Lk + 15) / 16 * 16;
+  hipLaunchKernelGGL(k_attention_heads, dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16,
+                     1.0f / sqrtf((float)dh));
+  return 0;
+}
+
+int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, const float* bo, const float* g1, const float* be1,
+                        float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T, const float* b2,
+                        const float* g2, const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s) {
+  if (D != kD) return 1;
+  const long long tokens = (long long)B * L;
+  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, att, res, WoT, bo, g1, be1, eps1, ss, W1T, b1,
+                     W2T, b2, g2, be2, eps2, out, L, tokens);
+  return 0;
+}
+
+}  // namespace mmf

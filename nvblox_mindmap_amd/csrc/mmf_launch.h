@@ -129,4 +129,14 @@ void launch_ddpm_step(const float* x, const float* eps, long long eps_stride, co
 int launch_attention_small(const float* q, const float* k, long long k_stride, const float* v, long long v_stride, const uint8_t* pad,
                            float* out, int B, int Lq, int Lk, int H, int d, hipStream_t s);
 
+// mmf_kernels_policy_mfma.hip (matrix-core forms: head-major q/k/v, attention over them, out_proj + LN + FFN)
+int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const float* bq, const float* WkvT, const float* bkv,
+                     const float* cs, const float* sn, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H, int roles,
+                     hipStream_t s);
+int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* out, int B, int Lq, int Lk,
+                           int H, int dh, hipStream_t s);
+int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, const float* bo, const float* g1, const float* be1,
+                        float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T, const float* b2,
+                        const float* g2, const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s);
+
 }  // namespace mmf

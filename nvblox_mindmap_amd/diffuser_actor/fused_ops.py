@@ -171,3 +171,58 @@ def out_ffn_block(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) 
                                             _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out), B, L, D,
                                             _lib.stream_ptr(att.device)), "mmf_out_ffn_block")
     return out
+
+
+# ---- matrix-core forms (mmf_kernels_policy_mfma.hip): head-major q / k / v, attention over them, out_proj + LN + FFN ----------
+MFMA_DIMS = (120, 8)  # (embedding dim, heads) the MFMA kernels are built for
+
+
+def _l16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def qkv_heads(x, scale_shift, q_proj, kv_proj, rot, heads: int, roles: int = 7):
+    """The projections of ``qkv_block`` written head-major, padded to 16 channels per head (padding = 0):
+    (q_heads [B,H,L16,16], k_heads [B,H,L16,16], v_heads_t [B,H,16,L16]).  roles: 7 = q|k|v, 1 = q alone (kv_proj unused),
+    6 = k|v alone (q_proj / scale_shift unused): entries that are not produced are None."""
+    x = x.contiguous()
+    B, L, D = x.shape
+    L16 = _l16(L)
+    dev = x.device
+    q = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev) if roles & 1 else None
+    k = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev) if roles & 6 else None
+    v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev) if roles & 6 else None
+    ss = _c(scale_shift) if roles & 1 else None
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    wq, bq = (_wt(q_proj), _c(q_proj.bias)) if roles & 1 else (None, None)
+    wkv, bkv = (_wt(kv_proj), _c(kv_proj.bias)) if roles & 6 else (None, None)
+    _lib.check(_lib.lib().mmf_qkv_heads(_lib.dptr(x), _lib.dptr(ss), _lib.dptr(wq), _lib.dptr(bq), _lib.dptr(wkv), _lib.dptr(bkv), _lib.dptr(cs),
+                                        _lib.dptr(sn), _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, roles,
+                                        _lib.stream_ptr(dev)), "mmf_qkv_heads")
+    return q, k, v
+
+
+def attention_heads(q_heads, k_heads, v_heads_t, key_padding_mask: Optional[torch.Tensor], Lq: int, Lk: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(15) + padding) v over the head-major operands of ``qkv_heads`` -> [B, Lq, 120]."""
+    B, H = q_heads.shape[:2]
+    assert q_heads.shape[2] == _l16(Lq) and k_heads.shape[2] == _l16(Lk) and v_heads_t.shape[3] == _l16(Lk)
+    pad = None if key_padding_mask is None else key_padding_mask.contiguous().view(torch.uint8)
+    out = torch.empty((B, Lq, H * 15), dtype=torch.float32, device=q_heads.device)
+    _lib.check(_lib.lib().mmf_attention_heads(_lib.dptr(q_heads), _lib.dptr(k_heads), _lib.dptr(v_heads_t), _lib.dptr(pad), _lib.dptr(out), B,
+                                              Lq, Lk, H, 15, _lib.stream_ptr(q_heads.device)), "mmf_attention_heads")
+    return out
+
+
+def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) -> torch.Tensor:
+    """``out_ffn_block`` on the matrix cores (16-token tiles, three chained GEMMs)."""
+    att = att.contiguous()
+    residual = residual.contiguous()
+    B, L, D = att.shape
+    out = torch.empty_like(att)
+    ss = _c(scale_shift)
+    _lib.check(_lib.lib().mmf_out_ffn_mfma(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_wt(out_proj)), _lib.dptr(_c(out_proj.bias)),
+                                           _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)), float(norm1.eps), _lib.dptr(ss),
+                                           _lib.dptr(_wt(fc1)), _lib.dptr(_c(fc1.bias)), _lib.dptr(_wt(fc2)), _lib.dptr(_c(fc2.bias)),
+                                           _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out), B, L, D,
+                                           _lib.stream_ptr(att.device)), "mmf_out_ffn_mfma")
+    return out

@@ -253,6 +253,13 @@ class AttentionStack(nn.Module):
 
             for li, (blk, ffw) in enumerate(zip(self.attn, self.ffw)):
                 A = blk.attn
+                if self.self_attention and (query.shape[-1], A.heads) == FO.MFMA_DIMS:
+                    # matrix-core forms: head-major q / k / v -> attention -> out_proj + LN + FFN
+                    L_ = query.shape[1]
+                    qh, kh, vt = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot, A.heads)
+                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, L_, L_)
+                    query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
+                    continue
                 if self.self_attention:
                     q, k, v = FO.qkv_block(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot)
                 else:

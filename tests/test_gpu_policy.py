@@ -273,3 +273,56 @@ def test_fused_attention_stack_matches_composite_stack():
             finally:
                 L.FUSED_INFERENCE = False
         assert torch.allclose(got, ref, rtol=5e-4, atol=5e-5), (self_att, float((got - ref).abs().max()))
+
+
+@pytest.mark.parametrize("B,L", [(1, 616), (2, 37), (1, 16)])
+def test_mfma_layer_kernels_match_the_channel_kernels(B, L):
+    """mmf_qkv_heads / mmf_attention_heads / mmf_out_ffn_mfma (v_mfma_f32_16x16x4_f32, head-major operands) against
+    mmf_qkv_block / mmf_attention_small / mmf_out_ffn_block on the same inputs: float-rounding agreement (exact f32
+    products, different summation order), including ragged tiles, key padding and missing rotary / modulation."""
+    from nvblox_mindmap_amd.diffuser_actor import fused_ops as FO
+    from nvblox_mindmap_amd.diffuser_actor import layers as Ly
+
+    torch.manual_seed(5)
+    D, H = 120, 8
+    blk = Ly.AttentionBlock(D, H, 0.0, use_adaln=True).cuda().eval()
+    ffw = Ly.FeedForwardBlock(D, D, 0.0, use_adaln=True).cuda().eval()
+    for p in list(blk.parameters()) + list(ffw.parameters()):
+        p.data.add_(0.05 * torch.randn_like(p))
+    A = blk.attn
+    x = torch.randn(B, L, D, device="cuda")
+    ss1, ss2 = 0.3 * torch.randn(B, 2 * D, device="cuda"), 0.3 * torch.randn(B, 2 * D, device="cuda")
+    rot = Ly.rotary3d(torch.rand(B, L, 3, device="cuda"), D)
+    pad = torch.rand(B, L, device="cuda") < 0.25
+    pad[:, 0] = False
+    L16 = (L + 15) // 16 * 16
+
+    def close(a, b, what):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (what, float((a - b).abs().max()))
+
+    with torch.no_grad():
+        for ss, r in ((ss1, rot), (None, None), (ss1, None), (None, rot)):
+            q, k, v = FO.qkv_block(x, ss, A.q_proj, A.kv_proj, r)
+            qh, kh, vt = FO.qkv_heads(x, ss, A.q_proj, A.kv_proj, r, H)
+            assert qh.shape == (B, H, L16, 16) and vt.shape == (B, H, 16, L16)
+            close(qh[:, :, :L, :15].permute(0, 2, 1, 3).reshape(B, L, D), q, "q")
+            close(kh[:, :, :L, :15].permute(0, 2, 1, 3).reshape(B, L, D), k, "k")
+            close(vt[:, :, :15, :L].permute(0, 3, 1, 2).reshape(B, L, D), v, "v")
+            # padding rows / channels are zero (the attention kernel multiplies them)
+            assert float(qh[:, :, L:].abs().max() if L16 > L else 0) == 0 and float(qh[..., 15].abs().max()) == 0
+            assert float(kh[..., 15].abs().max()) == 0 and float(vt[:, :, 15].abs().max()) == 0
+            assert float(vt[..., L:].abs().max() if L16 > L else 0) == 0
+        q1, _, _ = FO.qkv_heads(x, ss1, A.q_proj, None, rot, H, roles=1)
+        _, k6, v6 = FO.qkv_heads(x, None, None, A.kv_proj, rot, H, roles=6)
+        qh, kh, vt = FO.qkv_heads(x, ss1, A.q_proj, A.kv_proj, rot, H)
+        assert torch.equal(q1, qh) and torch.equal(k6, kh) and torch.equal(v6, vt)
+        q, k, v = FO.qkv_block(x, ss1, A.q_proj, A.kv_proj, rot)
+        for mask in (None, pad):
+            ref = FO.attention_small(q, k, v, mask, H)
+            got = FO.attention_heads(qh, kh, vt, mask, L, L)
+            close(got, ref, "attention")
+        att = FO.attention_small(q, k, v, pad, H)
+        for ss in (ss2, None):
+            ref = FO.out_ffn_block(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
+            got = FO.out_ffn_mfma(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
+            close(got, ref, "out_ffn")
