@@ -288,6 +288,24 @@ int mmf_out_ffn_mfma(const float* att_dev, const float* residual_dev, const floa
                      const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev,
                      const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev, const float* ln2_bias_dev, float ln2_eps,
                      float* out_dev, int B, int L, int D, void* stream);
+/* Head and tail of a denoising step (D = 120), one launch each instead of ~15:
+ *   mmf_step_prologue  tokens_out [B, num_tokens, D] = trajectory [B, num_tokens, 9] x traj_encoder + position_table [num_tokens, D];
+ *                      adaln_out [B, adaln_width] = silu(time_embedding [D] + history [B, D]) x adaln_wt [D, adaln_width] + adaln_bias
+ *                      (the stacked scale/shift projections of every AdaLN block); cos_out / sin_out: 3-D rotary tables of the
+ *                      trajectory positions (channel thirds x, y, z; pair k of a third uses rotary_freq[k]), row i of batch b at
+ *                      b * rotary_batch_stride + i * D (so they can be the first rows of sequence-wide tables)
+ *   mmf_head_outputs   pred_out [B, L, G, 10] = (position 3 | rotation 6 | openness 1) and head_yaw_out [B, L] from rows
+ *                      l * G + g of the two output stacks (batch stride seq_batch_stride floats).  weights20 (HOST array of 20
+ *                      device pointers, transposed [in, out] weights then bias): rotation_proj, position_proj, rotation_out.0,
+ *                      rotation_out.2, position_out.0, position_out.2, openness_out.0, openness_out.2, head_yaw_out.0,
+ *                      head_yaw_out.2 (the last four entries null: no head yaw) */
+int mmf_step_prologue(const float* trajectory_dev, int B, int num_tokens, const float* traj_encoder_wt_dev, const float* traj_encoder_bias_dev,
+                      const float* position_table_dev, const float* time_embedding_dev, const float* history_dev,
+                      const float* rotary_freq_dev, const float* adaln_wt_dev, const float* adaln_bias_dev, int adaln_width,
+                      float* tokens_out_dev, float* adaln_out_dev, float* cos_out_dev, float* sin_out_dev, long long rotary_batch_stride,
+                      int D, void* stream);
+int mmf_head_outputs(const float* rotation_seq_dev, const float* position_seq_dev, long long seq_batch_stride, int B, int L, int G,
+                     const float* const* weights20, float* pred_out_dev, float* head_yaw_out_dev, int D, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

@@ -139,4 +139,11 @@ int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, co
                         float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T, const float* b2,
                         const float* g2, const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s);
 
+// mmf_kernels_policy_head.hip (what runs before the first and after the last attention layer of a denoising step)
+void launch_step_prologue(const float* traj, int B, int nt, const float* WeT, const float* be, const float* pos_table, const float* time_row,
+                          const float* history, const float* freq, const float* AwT, const float* Ab, int NA, float* tokens, float* adaln,
+                          float* cos_out, float* sin_out, long long rot_batch_stride, hipStream_t s);
+int launch_head_outputs(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
+                        float* pred, float* head_yaw, hipStream_t s);
+
 }  // namespace mmf

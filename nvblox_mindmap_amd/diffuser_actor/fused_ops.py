@@ -226,3 +226,51 @@ def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) -
                                            _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out), B, L, D,
                                            _lib.stream_ptr(att.device)), "mmf_out_ffn_mfma")
     return out
+
+
+# ---- head and tail of a denoising step (mmf_kernels_policy_head.hip) -----------------------------------------------------------
+def step_prologue(trajectory, traj_encoder, pos_table, time_row, history, rot_freq, adaln_wt, adaln_bias, seq_cos, seq_sin):
+    """One launch for everything in front of the first attention layer of a denoising step.  trajectory [B,L,G,9];
+    pos_table [L*G, D]; time_row [D] (this step's time embedding); history [B, D]; adaln_wt [D, NA] / adaln_bias [NA]: the
+    stacked AdaLN projections; seq_cos / seq_sin [B, Ls, D]: sequence-wide rotary tables whose first L*G rows are (re)written.
+    Returns (tokens [B, L*G, D], adaln [B, NA])."""
+    trajectory = trajectory.contiguous()
+    B = trajectory.shape[0]
+    nt = trajectory.shape[1] * trajectory.shape[2]
+    D = pos_table.shape[-1]
+    NA = adaln_wt.shape[1]
+    assert seq_cos.is_contiguous() and seq_sin.is_contiguous() and seq_cos.shape[1] >= nt and time_row.numel() == D
+    tokens = torch.empty((B, nt, D), dtype=torch.float32, device=trajectory.device)
+    adaln = torch.empty((B, NA), dtype=torch.float32, device=trajectory.device)
+    _lib.check(_lib.lib().mmf_step_prologue(_lib.dptr(trajectory), B, nt, _lib.dptr(_wt(traj_encoder)), _lib.dptr(_c(traj_encoder.bias)),
+                                            _lib.dptr(_c(pos_table)), _lib.dptr(_c(time_row)), _lib.dptr(_c(history)), _lib.dptr(_c(rot_freq)),
+                                            _lib.dptr(adaln_wt), _lib.dptr(adaln_bias), NA, _lib.dptr(tokens), _lib.dptr(adaln),
+                                            _lib.dptr(seq_cos), _lib.dptr(seq_sin), seq_cos.stride(0), D, _lib.stream_ptr(trajectory.device)),
+               "mmf_step_prologue")
+    return tokens, adaln
+
+
+def head_outputs(head, rot_seq, pos_seq, B: int, L: int, G: int):
+    """rotation_proj / position_proj + the position / rotation / openness / head-yaw MLPs of the DiffusionHead on the
+    trajectory rows (the first L*G) of the two output stacks: (pred [B,L,G,10], head_yaw [B,L,1] or None)."""
+    import ctypes as Ct
+
+    assert rot_seq.is_contiguous() and pos_seq.is_contiguous() and rot_seq.shape == pos_seq.shape
+    lins = [head.rotation_proj, head.position_proj, head.rotation_out[0], head.rotation_out[2], head.position_out[0], head.position_out[2],
+            head.openness_out[0], head.openness_out[2]]
+    if head.head_yaw_out is not None:
+        lins += [head.head_yaw_out[0], head.head_yaw_out[2]]
+    ptrs = []
+    keep = []
+    for lin in lins:
+        w, b = _wt(lin), _c(lin.bias)
+        keep += [w, b]
+        ptrs += [w.data_ptr(), b.data_ptr()]
+    ptrs += [0] * (20 - len(ptrs))
+    arr = (Ct.c_void_p * 20)(*[p or None for p in ptrs])
+    dev = rot_seq.device
+    pred = torch.empty((B, L, G, 10), dtype=torch.float32, device=dev)
+    yaw = torch.empty((B, L, 1), dtype=torch.float32, device=dev) if head.head_yaw_out is not None else None
+    _lib.check(_lib.lib().mmf_head_outputs(_lib.dptr(rot_seq), _lib.dptr(pos_seq), rot_seq.stride(0), B, L, G, Ct.cast(arr, Ct.c_void_p),
+                                           _lib.dptr(pred), _lib.dptr(yaw), rot_seq.shape[-1], _lib.stream_ptr(dev)), "mmf_head_outputs")
+    return pred, yaw

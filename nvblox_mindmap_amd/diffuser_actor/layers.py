@@ -60,6 +60,7 @@ class AdaLNBatch:
         self.weight = torch.cat([m.proj.weight for m in modules], dim=0)
         self.bias = torch.cat([m.proj.bias for m in modules], dim=0)
         self.width = modules[0].proj.out_features
+        self.weight_t = self.weight.t().contiguous()  # [D, NA]: the layout mmf_step_prologue reads coalesced
         self.all = None
 
     def compute(self, cond_act: torch.Tensor) -> "AdaLNBatch":

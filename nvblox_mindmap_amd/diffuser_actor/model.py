@@ -8,6 +8,7 @@ Linear) and/or map-vertex tokens (Linear), 3-D rotary attention, gripper-history
 self-attention layers over [trajectory tokens ; subsampled context], predictors for position noise (3), 6-D rotation
 noise (6), gripper openness (1) and head yaw (1).
 """
+import math
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -194,6 +195,19 @@ class DiffusionHead(nn.Module):
         if layers_mod._fused(ctx_feats):  # keys / values of the (step-invariant) context, once per inference instead of per step
             P["cross_kv"] = [blk.attn.project_kv(ctx_feats, P["ctx_rot"]) for blk in self.cross_attn.attn]
             P["adaln"] = layers_mod.AdaLNBatch([mod for mod in self.modules() if isinstance(mod, layers_mod.AdaLN)])
+            if D in layers_mod._block_dims():
+                # step-invariant parts of the step's sequence-wide tensors: the sub-sampled context rows of the token
+                # sequence, of its rotary tables and of its padding mask are filled once; a step rewrites the trajectory rows
+                B, nt = fps_feats.shape[0], self.cfg.prediction_horizon * self.cfg.ngrippers
+                dev = fps_feats.device
+                head = torch.zeros((B, nt, D), device=dev)
+                P["seq"] = torch.cat([head, fps_feats], dim=1)
+                P["seq_cos"] = torch.cat([head, P["fps_rot"][0].expand(B, -1, D)], dim=1)
+                P["seq_sin"] = torch.cat([head, P["fps_rot"][1].expand(B, -1, D)], dim=1)
+                P["seq_pad"] = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=dev), P["fps_pad"]], dim=1)
+                P["pos_table"] = sinusoidal_embedding(torch.arange(nt, device=dev), D)
+                third = D // 3
+                P["rot_freq"] = torch.exp(torch.arange(0, third, 2, device=dev, dtype=torch.float32) * (-math.log(10000.0) / third))
         return P
 
     def time_embeddings(self, timesteps, device):
@@ -214,6 +228,9 @@ class DiffusionHead(nn.Module):
         B, L, G, _ = trajectory.shape
         nt = L * G
         P = prepared if prepared is not None else self.prepare_context(enc)
+        if (not need_weights and time_emb is not None and P.get("seq") is not None and layers_mod._fused(trajectory)
+                and nt == P["pos_table"].shape[0] and G <= 4):
+            return self._forward_fused(trajectory, P, time_emb)
         tokens = self.drop(self.traj_encoder(trajectory)).flatten(1, 2)
         tokens = tokens + sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
         cond = (self.time_mlp(sinusoidal_embedding(timestep, D)) if time_emb is None else time_emb) + P["history"]
@@ -251,6 +268,39 @@ class DiffusionHead(nn.Module):
         if weights is not None:
             weights = weights.mean(dim=1)  # average over heads
         return pred.reshape(B, L, G, 10), head_yaw, weights
+
+
+    def _forward_fused(self, trajectory, P, time_emb):
+        """The same pass on the inference kernels end to end (DiffuserActor.enable_fused_inference): one prologue launch
+        (trajectory tokens, conditioning, every AdaLN projection, trajectory rotary codes), the attention stacks on the
+        whole-layer kernels over preassembled sequence buffers, one launch for the projections and output MLPs."""
+        from . import fused_ops as FO
+
+        B, L, G, _ = trajectory.shape
+        nt = L * G
+        ada = P["adaln"]
+        tokens, ada.all = FO.step_prologue(trajectory, self.traj_encoder, P["pos_table"], time_emb[0], P["history"], P["rot_freq"],
+                                           ada.weight_t, ada.bias, P["seq_cos"], P["seq_sin"])
+        cond = time_emb  # only its presence matters below: every AdaLN projection comes from `ada`
+        traj_rot = (P["seq_cos"][:, :nt], P["seq_sin"][:, :nt])
+        tokens, _ = self.cross_attn(tokens, P["ctx_feats"], cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"], cond_act=ada,
+                                    kv_caches=P["cross_kv"])
+        seq, seq_rot, pad = P["seq"], (P["seq_cos"], P["seq_sin"]), P["seq_pad"]
+        seq[:, :nt].copy_(tokens)
+        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada)
+        # the two output stacks are independent: fork the rotation stack onto a second stream (parallel branches of the
+        # captured HIP graph; concurrent small kernels in eager mode), join before the output heads
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=seq.device)
+        main, side = torch.cuda.current_stream(seq.device), self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada)
+        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada)
+        main.wait_stream(side)
+        rot_seq.record_stream(main)
+        pred, head_yaw = FO.head_outputs(self, rot_seq, pos_seq, B, L, G)
+        return pred, head_yaw, None
 
 
 class DiffuserActor(nn.Module):

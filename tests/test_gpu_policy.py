@@ -1,5 +1,7 @@
 """GPU tests of the policy side: HIP farthest-point sampling against the plain-torch restatement, one training step of
 the full input pipeline (HIP back-projection inside unpack_batch) on cuda:0."""
+import math
+
 import pytest
 import torch
 
@@ -326,3 +328,47 @@ def test_mfma_layer_kernels_match_the_channel_kernels(B, L):
             ref = FO.out_ffn_block(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
             got = FO.out_ffn_mfma(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
             close(got, ref, "out_ffn")
+
+
+@pytest.mark.parametrize("B,G", [(1, 2), (2, 1), (2, 3)])
+def test_step_prologue_and_head_outputs_match_torch(B, G):
+    """mmf_step_prologue / mmf_head_outputs against the torch ops of DiffusionHead.forward they replace."""
+    import torch.nn.functional as F
+
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.diffuser_actor import fused_ops as FO
+    from nvblox_mindmap_amd.diffuser_actor import layers as Ly
+    from nvblox_mindmap_amd.diffuser_actor.model import DiffusionHead
+
+    torch.manual_seed(7)
+    cfg = DiffuserActorConfig(ngrippers=G)
+    head = DiffusionHead(cfg).cuda().eval()
+    for p in head.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    D, L = cfg.embedding_dim, cfg.prediction_horizon
+    nt, Ls = L * G, L * G + 37
+    traj = torch.randn(B, L, G, 9, device="cuda")
+    time_row, history = torch.randn(D, device="cuda"), torch.randn(B, D, device="cuda")
+    with torch.no_grad():
+        ada = Ly.AdaLNBatch([m for m in head.modules() if isinstance(m, Ly.AdaLN)])
+        pos_table = Ly.sinusoidal_embedding(torch.arange(nt, device="cuda"), D)
+        third = D // 3
+        freq = torch.exp(torch.arange(0, third, 2, device="cuda", dtype=torch.float32) * (-math.log(10000.0) / third))
+        seq_cos, seq_sin = torch.full((B, Ls, D), 7.0, device="cuda"), torch.full((B, Ls, D), 7.0, device="cuda")
+        tokens, adaln = FO.step_prologue(traj, head.traj_encoder, pos_table, time_row, history, freq, ada.weight_t, ada.bias, seq_cos, seq_sin)
+        ref_tokens = head.traj_encoder(traj).flatten(1, 2) + pos_table[None]
+        ref_adaln = F.linear(F.silu(time_row[None] + history), ada.weight, ada.bias)
+        ref_cos, ref_sin = Ly.rotary3d(traj[..., :3].flatten(1, 2), D)
+        assert torch.allclose(tokens, ref_tokens, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(adaln, ref_adaln, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(seq_cos[:, :nt], ref_cos, atol=1e-6) and torch.allclose(seq_sin[:, :nt], ref_sin, atol=1e-6)
+        assert bool((seq_cos[:, nt:] == 7.0).all()) and bool((seq_sin[:, nt:] == 7.0).all())  # the other rows are not touched
+
+        rot_seq, pos_seq = torch.randn(B, Ls, D, device="cuda"), torch.randn(B, Ls, D, device="cuda")
+        pred, yaw = FO.head_outputs(head, rot_seq, pos_seq, B, L, G)
+        rot_feat = head.rotation_proj(rot_seq[:, :nt])
+        pos_feat = head.position_proj(pos_seq[:, :nt])
+        ref = torch.cat([head.position_out(pos_feat), head.rotation_out(rot_feat), head.openness_out(pos_feat)], dim=-1).reshape(B, L, G, 10)
+        assert torch.allclose(pred, ref, rtol=1e-4, atol=1e-5), float((pred - ref).abs().max())
+        if head.head_yaw_out is not None:
+            assert torch.allclose(yaw, head.head_yaw_out(pos_feat.reshape(B, L, G * D)), rtol=1e-4, atol=1e-5)
