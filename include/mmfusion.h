@@ -277,7 +277,8 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  *   mmf_qkv_heads        the projections of mmf_qkv_block written head-major and padded to 16 channels:
  *                        q_heads, k_heads [B, H, L16, 16], v_heads_t [B, H, 16, L16] (L16 = L rounded up to 16; padding = 0).
  *                        roles: 7 = q | k | v, 1 = q alone (Wkv / k / v may be null), 6 = k | v alone (Wq / q may be null)
- *   mmf_attention_heads  softmax(q k^T / sqrt(head_dim) + key padding) v over those layouts -> out [B, Lq, D]
+ *   mmf_attention_heads  softmax(q k^T / sqrt(head_dim) + key padding) v over those layouts -> out [B, Lq, D]; key_padding: [B, Lk16]
+ *                        bytes, 1 = ignore, the keys beyond Lk marked too (or null)
  *   mmf_out_ffn_mfma     same contract as mmf_out_ffn_block */
 int mmf_qkv_heads(const float* x_dev, const float* scale_shift_dev, const float* Wq_dev, const float* bq_dev, const float* Wkv_dev,
                   const float* bkv_dev, const float* cos_dev, const float* sin_dev, float* q_heads_dev, float* k_heads_dev,

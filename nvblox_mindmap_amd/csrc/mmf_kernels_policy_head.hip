@@ -63,38 +63,6 @@ void launch_step_prologue(const float* traj, int B, int nt, const float* WeT, co
 // ---- output heads ---------------------------------------------------------------------------------------------------------------
 constexpr int kMaxG = 4;
 
-// out[g][j] = act(bias[j] + sum_c in[g][c] Wt[c * nout + j]) for g < G, j < nout <= 128; the reduction is split over the four
-// 128-thread parts of the workgroup and summed through LDS.  `concat`: one input vector made of the G rows of `in` (head yaw).
-__device__ __forceinline__ void dense(const float* __restrict__ Wt, const float* __restrict__ bias, int nin, int nout, const float (*in)[128],
-                                      int G, bool concat, bool relu, float (*out)[128], float (*red)[kMaxG][128]) {
-  const int j = threadIdx.x & 127, part = threadIdx.x >> 7;
-  const int per = nin / 4, c0 = part * per;
-  const int rows = concat ? 1 : G;
-  float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
-  if (j < nout)
-    for (int c = c0; c < c0 + per; ++c) {
-      const float w = Wt[(size_t)c * nout + j];
-      if (concat) {
-        acc[0] += w * in[c / kHD][c % kHD];
-      } else {
-#pragma unroll
-        for (int g = 0; g < kMaxG; ++g)
-          if (g < G) acc[g] += w * in[g][c];
-      }
-    }
-#pragma unroll
-  for (int g = 0; g < kMaxG; ++g) red[part][g][j] = acc[g];
-  __syncthreads();
-  if (part == 0 && j < nout) {
-    const float bb = bias[j];
-    for (int g = 0; g < rows; ++g) {
-      float v = ((red[0][g][j] + red[1][g][j]) + (red[2][g][j] + red[3][g][j])) + bb;
-      out[g][j] = relu ? fmaxf(v, 0.0f) : v;
-    }
-  }
-  __syncthreads();
-}
-
 struct HeadWeights {  // transposed ([in, out]) weights and biases
   const float *rp, *rpb, *pp, *ppb;        // rotation_proj, position_proj
   const float *r1, *r1b, *r2, *r2b;        // rotation_out
@@ -103,34 +71,97 @@ struct HeadWeights {  // transposed ([in, out]) weights and biases
   const float *y1, *y1b, *y2, *y2b;        // head_yaw_out (null: no head yaw)
 };
 
-// grid (B * L), 512 threads: one (batch element, horizon step) = G trajectory tokens
+// acc[g] += sum_{c in [c0, c0 + N)} in[g][c] * Wt[c * kHD + j]: N independent, coalesced weight loads in flight at once
+template <int N>
+__device__ __forceinline__ void dot_cols(const float* __restrict__ Wt, int j, int c0, const float (*in)[128], int G, float (&acc)[kMaxG]) {
+  float w[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) w[c] = Wt[(size_t)(c0 + c) * kHD + j];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g)
+      if (g < G) acc[g] += w[c] * in[g][c0 + c];
+}
+
+// grid (B * L), 512 threads = 4 parts x 128 channel threads: one (batch element, horizon step) = G trajectory tokens.
+//   stage A  rotation_proj (parts 0, 1: halves of the reduction) | position_proj (parts 2, 3)
+//   stage B  first layers of the four MLPs, one per part (rotation | position | openness | head yaw), ReLU
+//   stage C  their 10 G + 1 scalar outputs, one 8-lane group each
 __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ rot_seq, const float* __restrict__ pos_seq,
                                                      long long seq_batch_stride, int L, int G, HeadWeights W, float* __restrict__ pred,
                                                      float* __restrict__ head_yaw) {
-  __shared__ float s_in[2][kMaxG][128], s_feat[2][kMaxG][128], s_h[4][kMaxG][128], s_o[4][kMaxG][128];
+  __shared__ float s_in[2][kMaxG][128], s_feat[2][kMaxG][128], s_h[4][kMaxG][128];
   __shared__ float s_red[4][kMaxG][128];
   const int b = (int)blockIdx.x / L, l = (int)blockIdx.x % L;
+  const int j = threadIdx.x & 127, part = threadIdx.x >> 7;
+  const bool act = j < kHD;
   for (int e = threadIdx.x; e < 2 * G * kHD; e += 512) {
     const int which = e / (G * kHD), r = e - which * G * kHD, g = r / kHD, c = r - g * kHD;
     s_in[which][g][c] = (which ? pos_seq : rot_seq)[(size_t)b * seq_batch_stride + (size_t)(l * G + g) * kHD + c];
   }
   __syncthreads();
-  dense(W.rp, W.rpb, kHD, kHD, s_in[0], G, false, false, s_feat[0], s_red);
-  dense(W.pp, W.ppb, kHD, kHD, s_in[1], G, false, false, s_feat[1], s_red);
-  dense(W.r1, W.r1b, kHD, kHD, s_feat[0], G, false, true, s_h[0], s_red);
-  dense(W.p1, W.p1b, kHD, kHD, s_feat[1], G, false, true, s_h[1], s_red);
-  dense(W.o1, W.o1b, kHD, kHD, s_feat[1], G, false, true, s_h[2], s_red);
-  if (W.y1) dense(W.y1, W.y1b, kHD * G, kHD, s_feat[1], G, true, true, s_h[3], s_red);
-  dense(W.p2, W.p2b, kHD, 3, s_h[1], G, false, false, s_o[0], s_red);
-  dense(W.r2, W.r2b, kHD, 6, s_h[0], G, false, false, s_o[1], s_red);
-  dense(W.o2, W.o2b, kHD, 1, s_h[2], G, false, false, s_o[2], s_red);
-  if (W.y1) dense(W.y2, W.y2b, kHD, 1, s_h[3], 1, false, false, s_o[3], s_red);
-  if ((int)threadIdx.x < G * 10) {
-    const int g = threadIdx.x / 10, k = threadIdx.x % 10;
-    const float v = k < 3 ? s_o[0][g][k] : (k < 9 ? s_o[1][g][k - 3] : s_o[2][g][0]);
-    pred[(((size_t)b * L + l) * G + g) * 10 + k] = v;
+  {  // stage A
+    float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
+    if (act) dot_cols<60>(part < 2 ? W.rp : W.pp, j, (part & 1) * 60, s_in[part >> 1], G, acc);
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) s_red[part][g][j] = acc[g];
+    __syncthreads();
+    if (act && !(part & 1)) {
+      const float bb = (part ? W.ppb : W.rpb)[j];
+      for (int g = 0; g < G; ++g) s_feat[part >> 1][g][j] = (s_red[part][g][j] + s_red[part + 1][g][j]) + bb;
+    }
+    __syncthreads();
   }
-  if (W.y1 && threadIdx.x == 0) head_yaw[(size_t)b * L + l] = s_o[3][0][0];
+  {  // stage B
+    float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
+    if (part < 3) {
+      const float* Wt = part == 0 ? W.r1 : (part == 1 ? W.p1 : W.o1);
+      const float* bs = part == 0 ? W.r1b : (part == 1 ? W.p1b : W.o1b);
+      if (act) {
+        dot_cols<60>(Wt, j, 0, s_feat[part ? 1 : 0], G, acc);
+        dot_cols<60>(Wt, j, 60, s_feat[part ? 1 : 0], G, acc);
+        const float bb = bs[j];
+        for (int g = 0; g < G; ++g) s_h[part][g][j] = fmaxf(acc[g] + bb, 0.0f);
+      }
+    } else if (W.y1 && act) {  // head yaw: one input vector made of the G position features
+      float a1[kMaxG] = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < G; ++g) {
+        dot_cols<60>(W.y1 + (size_t)g * kHD * kHD, j, 0, &s_feat[1][g], 1, a1);
+        dot_cols<60>(W.y1 + (size_t)g * kHD * kHD, j, 60, &s_feat[1][g], 1, a1);
+      }
+      s_h[3][0][j] = fmaxf(a1[0] + W.y1b[j], 0.0f);
+    }
+    __syncthreads();
+  }
+  {  // stage C: output o of token g = one 8-lane group (15 channels per lane)
+    const int grp = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const int n_out = 10 * G + (W.y1 ? 1 : 0);
+    const bool live = grp < n_out;
+    const int g = live ? (grp < 10 * G ? grp / 10 : 0) : 0, k = grp - 10 * g;  // k: 0-2 position, 3-8 rotation, 9 openness, 10 yaw
+    const bool yaw = grp == 10 * G;
+    const float* Wt = yaw ? W.y2 : (k < 3 ? W.p2 : (k < 9 ? W.r2 : W.o2));
+    const int nout = yaw ? 1 : (k < 3 ? 3 : (k < 9 ? 6 : 1)), col = yaw ? 0 : (k < 3 ? k : (k < 9 ? k - 3 : 0));
+    const float(*h)[128] = yaw ? s_h[3] : (k < 3 ? s_h[1] : (k < 9 ? s_h[0] : s_h[2]));
+    float acc = 0.0f;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 15; ++i) {
+        const int c = q * 15 + i;
+        acc += h[yaw ? 0 : g][c] * Wt[c * nout + col];
+      }
+    }
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    if (live && q == 0) {
+      const float bb = (yaw ? W.y2b : (k < 3 ? W.p2b : (k < 9 ? W.r2b : W.o2b)))[col];
+      if (yaw)
+        head_yaw[(size_t)b * L + l] = acc + bb;
+      else
+        pred[(((size_t)b * L + l) * G + g) * 10 + k] = acc + bb;
+    }
+  }
 }
 
 int launch_head_outputs(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,

@@ -104,18 +104,33 @@ __global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, 
   const int ld = role == 0 ? kD : 2 * kD, off = role == 2 ? kD : 0;
   const float* bias = role == 0 ? bq : bkv + off;
 
-  f32x4 y[2];
+  // epilogue operands are fetched up front: their latency hides behind the weight loads and the GEMM
+  const bool rotary = role < 2 && cs != nullptr;
+  float bb[2], cv[2][4], sv[2][4];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = kDH * (2 * w + n) + j;  // column j = 15 of a head tile is padding
+    bb[n] = j < kDH ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = l0 + 4 * s + r;
+      const bool ok = rotary && j < kDH && tok < L;
+      const size_t e = ((size_t)b * L + (ok ? tok : 0)) * kD + (ok ? col : 0);
+      cv[n][r] = ok ? cs[e] : 1.0f;
+      sv[n][r] = ok ? sn[e] : 0.0f;
+    }
+  }
+  f32x4 y[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = kDH * (2 * w + n) + j;
     float wv[kKSteps];
     load_col_share(Wt + off, ld, col, j < kDH, s, wv);
     y[n] = tile_gemm(a, wv);
-    const float bb = j < kDH ? bias[col] : 0.0f;
-    y[n] += bb;
+    y[n] += bb[n];
   }
 
-  if (role < 2 && cs != nullptr) {
+  if (rotary) {
     // rotary over the 120-vector: out[c] = y[c] cos[c] + (c odd ? y[c-1] : -y[c+1]) sin[c].  Within the wave's 30 channels
     // p = 15 n + j the partner is p ^ 1, held by lane (s, j') of tile n'.
     f32x4 part[2];
@@ -132,17 +147,9 @@ __global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, 
       }
     }
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int col = kDH * (2 * w + n) + j;
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tok = l0 + 4 * s + r;
-        if (j < kDH && tok < L) {
-          const size_t e = ((size_t)b * L + tok) * kD + col;
-          y[n][r] = y[n][r] * cs[e] + part[n][r] * sn[e];
-        }
-      }
-    }
+      for (int r = 0; r < 4; ++r) y[n][r] = y[n][r] * cv[n][r] + part[n][r] * sv[n][r];  // padding lanes: * 1 + * 0
   }
 
 #pragma unroll
@@ -162,13 +169,16 @@ __global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, 
 }
 
 // ---- attention over head-major operands -------------------------------------------------------------------------------------
-constexpr int kAttChunk = 10;  // key tiles a wave scores before it runs the softmax update (40 score registers)
+// CH = key tiles a wave scores before it runs the softmax update (4 CH score registers + 8 CH operand registers)
 
-__global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict__ Qp, const float* __restrict__ Kp,
-                                                        const float* __restrict__ Vt, const uint8_t* __restrict__ pad,
-                                                        float* __restrict__ out, int Lq, int Lq16, int Lk, int Lk16, float scale) {
-  __shared__ float sM[4][16], sL[4][16];
-  __shared__ float sO[4][16][17];
+// NW waves per workgroup share the keys of one (query tile, head): 4 for self-attention over a few hundred keys, 16 when a
+// handful of query rows attend to thousands of keys (the trajectory tokens over the full context).
+template <int NW, int CH>
+__global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __restrict__ Qp, const float* __restrict__ Kp,
+                                                            const float* __restrict__ Vt, const uint8_t* __restrict__ pad,
+                                                            float* __restrict__ out, int Lq, int Lq16, int Lk, int Lk16, float scale) {
+  __shared__ float sM[NW][16], sL[NW][16];
+  __shared__ float sO[NW][16][17];
   const int q0 = (int)blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
   const size_t bh = (size_t)b * kH + h;
@@ -180,39 +190,42 @@ __global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict
   }
   const float* Kb = Kp + bh * Lk16 * 16;
   const float* Vb = Vt + (bh * 16 + j) * Lk16;
-  const uint8_t* pb = pad ? pad + (size_t)b * Lk : nullptr;
+  // key padding: [B, Lk16] bytes (1 = ignore; keys >= Lk are marked too), one aligned 32-bit word per (tile, lane)
+  const uint8_t* pb = pad ? pad + (size_t)b * Lk16 : nullptr;
 
   float m_run = -INFINITY, l_run = 0.0f;
   f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f};  // O^T: rows = channel 4 s + r, column = query row j
   const int ntiles = Lk16 / 16;
-  for (int tb = w; tb < ntiles; tb += 4 * kAttChunk) {  // this wave's tiles: tb, tb + 4, ...
-    float4 kv[kAttChunk], vv[kAttChunk];
+  for (int tb = w; tb < ntiles; tb += NW * CH) {  // this wave's tiles: tb, tb + NW, ...
+    float4 kv[CH], vv[CH];
+    uint32_t pw[CH];
 #pragma unroll
-    for (int i = 0; i < kAttChunk; ++i) {
-      const int t = tb + 4 * i;
+    for (int i = 0; i < CH; ++i) {
+      const int t = tb + NW * i;
       if (t < ntiles) {
         kv[i] = *reinterpret_cast<const float4*>(Kb + ((size_t)t * 16 + j) * 16 + 4 * s);
         vv[i] = *reinterpret_cast<const float4*>(Vb + t * 16 + 4 * s);
+        pw[i] = pb ? *reinterpret_cast<const uint32_t*>(pb + t * 16 + 4 * s) : 0u;
       } else {
         kv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pw[i] = 0xffffffffu;
       }
     }
-    f32x4 S[kAttChunk];
+    f32x4 S[CH];
     float cmax = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < kAttChunk; ++i) {
+    for (int i = 0; i < CH; ++i) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
       c = mfma4(kv[i].x, q[0], c);
       c = mfma4(kv[i].y, q[1], c);
       c = mfma4(kv[i].z, q[2], c);
       c = mfma4(kv[i].w, q[3], c);
-      const int t = tb + 4 * i;
+      const int t = tb + NW * i;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + 4 * s + r;
-        bool dead = t >= ntiles || key >= Lk;
-        if (!dead && pb) dead = pb[key] != 0;
+        const bool dead = key >= Lk || ((pw[i] >> (8 * r)) & 0xffu) != 0u;
         c[r] = dead ? -INFINITY : c[r];
         cmax = fmaxf(cmax, c[r]);
       }
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict
     O0 *= corr;
     O1 *= corr;
 #pragma unroll
-    for (int i = 0; i < kAttChunk; ++i) {
+    for (int i = 0; i < CH; ++i) {
       float p[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -259,10 +272,12 @@ __global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict
   for (int r = 0; r < 4; ++r) sO[w][4 * s + r][j] = O[r];
   __syncthreads();
   if (w == 0) {
-    float M = fmaxf(fmaxf(sM[0][j], sM[1][j]), fmaxf(sM[2][j], sM[3][j]));
-    float f[4], l = 0.0f;
+    float M = sM[0][j];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 1; u < NW; ++u) M = fmaxf(M, sM[u][j]);
+    float f[NW], l = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
       f[u] = (sM[u][j] == -INFINITY) ? 0.0f : __expf(sM[u][j] - M);
       l += f[u] * sL[u][j];
     }
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict
       const int ch = 4 * s + r;
       float o = 0.0f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) o += f[u] * sO[u][ch][j];
+      for (int u = 0; u < NW; ++u) o += f[u] * sO[u][ch][j];
       if (ch < kDH && row < Lq) out[((size_t)b * Lq + row) * kD + h * kDH + ch] = o / l;
     }
   }
@@ -281,11 +296,26 @@ __global__ __launch_bounds__(256) void k_attention_heads(const float* __restrict
 // ---- out_proj + LayerNorm + feed-forward block -----------------------------------------------------------------------------
 constexpr int kRS = 132;  // LDS row stride of a 16-token tile (floats)
 
-// LayerNorm of the 16 x 120 tile in `src` (wave w: tokens 4 w .. 4 w + 3, 16 lanes per token, 8 channels per lane); result
+// LayerNorm of the 16 x 120 tile in `src` (wave w: tokens 4 w .. 4 w + 3, 16 lanes per token, channels q + 16 i per lane);
+// gamma / beta / (scale, shift) of the lane's 8 channels arrive in registers (fetched at kernel start).  The result
 // (optionally AdaLN-modulated) goes to `dst` (LDS) and / or `gout` (global, row stride D)
+struct LnShare {
+  float g[8], b[8];
+};
+__device__ __forceinline__ LnShare load_ln_share(const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
+  LnShare P;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = q + 16 * i;
+    P.g[i] = c < kD ? gamma[c] : 0.0f;
+    P.b[i] = c < kD ? beta[c] : 0.0f;
+  }
+  return P;
+}
+
 __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (*dst)[kRS], float* __restrict__ gout, long long t0,
-                                                long long tokens, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                float eps, const float* __restrict__ ss, int L, int lane, int w) {
+                                                long long tokens, const LnShare& P, float eps, bool modulate, const float (&sc)[8],
+                                                const float (&sh)[8], int lane, int w) {
   const int tl = 4 * w + (lane >> 4), q = lane & 15;
   float v[8];
   float sum = 0.0f;
@@ -311,13 +341,12 @@ __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (
   const float inv = rsqrtf(var / (float)kD + eps);
   const long long tok = t0 + tl;
   const bool live = tok < tokens;
-  const float* sc = (ss != nullptr && live) ? ss + (size_t)(tok / L) * 2 * kD : nullptr;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = q + 16 * i;
     if (c < kD) {
-      float o = v[i] * inv * gamma[c] + beta[c];
-      if (sc) o = o * (1.0f + sc[c]) + sc[kD + c];
+      float o = v[i] * inv * P.g[i] + P.b[i];
+      if (modulate) o = o * (1.0f + sc[i]) + sh[i];
       if (dst) dst[tl][c] = o;
       if (gout && live) gout[tok * kD + c] = o;
     }
@@ -358,26 +387,51 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ 
     const bool ok = tok < tokens;
     load_row_share(att + (ok ? tok : 0) * kD, s, ok, a);
   }
-  // ---- x1 = LN1(res + out_proj(att)), h = modulate(x1)
 #pragma unroll
   for (int n = 0; n < 2; ++n) load_col_share(WoT, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);
+  // every small operand of the later stages is fetched now: nothing but LDS traffic and MFMAs between the barriers below
+  float bbo[2], bb1[2], bb2[2], rs[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = 32 * w + 16 * n + j;
+    const bool cok = col < kD;
+    bbo[n] = cok ? bo[col] : 0.0f;
+    bb1[n] = cok ? b1[col] : 0.0f;
+    bb2[n] = cok ? b2[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long tok = t0 + 4 * s + r;
+      rs[n][r] = (cok && tok < tokens) ? res[tok * kD + col] : 0.0f;
+    }
+  }
+  const int ln_q = lane & 15;
+  const LnShare P1 = load_ln_share(g1, be1, ln_q), P2 = load_ln_share(g2, be2, ln_q);
+  float sc[8], sh[8];
+  {
+    const long long tok = t0 + 4 * w + (lane >> 4);
+    const bool mod = ss != nullptr && tok < tokens;
+    const float* sp = ss + (mod ? (size_t)(tok / L) * 2 * kD : 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ln_q + 16 * i;
+      sc[i] = (mod && c < kD) ? sp[c] : 0.0f;
+      sh[i] = (mod && c < kD) ? sp[kD + c] : 0.0f;
+    }
+  }
+  // ---- x1 = LN1(res + out_proj(att)), h = modulate(x1)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
     const f32x4 y = tile_gemm(a, wv[n]);
     if (col < kD) {
-      const float bb = bo[col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long tok = t0 + 4 * s + r;
-        sY[4 * s + r][col] = y[r] + bb + (tok < tokens ? res[tok * kD + col] : 0.0f);
-      }
+      for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = y[r] + bbo[n] + rs[n][r];
     }
   }
 #pragma unroll
   for (int n = 0; n < 2; ++n) load_col_share(W1T, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);  // in flight over the LN
   __syncthreads();
-  tile_layer_norm(sY, sH, nullptr, t0, tokens, g1, be1, eps1, ss, L, lane, w);
+  tile_layer_norm(sY, sH, nullptr, t0, tokens, P1, eps1, ss != nullptr, sc, sh, lane, w);
   __syncthreads();
   // ---- u = relu(fc1(h))
   lds_row_share(sH, j, s, a);
@@ -386,9 +440,8 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ 
     const int col = 32 * w + 16 * n + j;
     const f32x4 y = tile_gemm(a, wv[n]);
     if (col < kD) {
-      const float bb = b1[col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sU[4 * s + r][col] = fmaxf(y[r] + bb, 0.0f);
+      for (int r = 0; r < 4; ++r) sU[4 * s + r][col] = fmaxf(y[r] + bb1[n], 0.0f);
     }
   }
 #pragma unroll
@@ -401,13 +454,12 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ 
     const int col = 32 * w + 16 * n + j;
     const f32x4 y = tile_gemm(a, wv[n]);
     if (col < kD) {
-      const float bb = b2[col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = sH[4 * s + r][col] + (y[r] + bb);
+      for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = sH[4 * s + r][col] + (y[r] + bb2[n]);
     }
   }
   __syncthreads();
-  tile_layer_norm(sY, nullptr, out, t0, tokens, g2, be2, eps2, nullptr, L, lane, w);
+  tile_layer_norm(sY, nullptr, out, t0, tokens, P2, eps2, false, sc, sh, lane, w);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
@@ -426,8 +478,11 @@ int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, co
                            int H, int dh, hipStream_t s) {
   if (H != kH || dh != kDH) return 1;
   const int Lq16 = (Lq + 15) / 16 * 16, Lk16 = (Lk + 15) / 16 * 16;
-  hipLaunchKernelGGL(k_attention_heads, dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16,
-                     1.0f / sqrtf((float)dh));
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (Lk16 / 16 > 80 && Lq16 / 16 * H * B < 128)  // long key axis, few workgroups: spread the keys over 16 waves
+    hipLaunchKernelGGL((k_attention_heads<16, 6>), dim3(Lq16 / 16, H, B), dim3(1024), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+  else
+    hipLaunchKernelGGL((k_attention_heads<4, 10>), dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
   return 0;
 }
 

@@ -202,13 +202,24 @@ def qkv_heads(x, scale_shift, q_proj, kv_proj, rot, heads: int, roles: int = 7):
     return q, k, v
 
 
-def attention_heads(q_heads, k_heads, v_heads_t, key_padding_mask: Optional[torch.Tensor], Lq: int, Lk: int) -> torch.Tensor:
-    """softmax(q k^T / sqrt(15) + padding) v over the head-major operands of ``qkv_heads`` -> [B, Lq, 120]."""
+def pad_mask16(key_padding_mask: torch.Tensor) -> torch.Tensor:
+    """[B, Lk] bool (True = ignore) -> [B, Lk16] uint8 with the keys beyond Lk marked: the form mmf_attention_heads reads
+    (one aligned 32-bit word per four keys).  Step-invariant masks are converted once per inference."""
+    Lk = key_padding_mask.shape[1]
+    return torch.nn.functional.pad(key_padding_mask.to(torch.uint8), (0, _l16(Lk) - Lk), value=1).contiguous()
+
+
+def attention_heads(q_heads, k_heads, v_heads_t, key_padding_mask: Optional[torch.Tensor], Lq: int, Lk: int,
+                    mask16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(15) + padding) v over the head-major operands of ``qkv_heads`` -> [B, Lq, 120].
+    ``mask16``: pad_mask16(key_padding_mask) when the caller has it already."""
     B, H = q_heads.shape[:2]
     assert q_heads.shape[2] == _l16(Lq) and k_heads.shape[2] == _l16(Lk) and v_heads_t.shape[3] == _l16(Lk)
-    pad = None if key_padding_mask is None else key_padding_mask.contiguous().view(torch.uint8)
+    if mask16 is None and key_padding_mask is not None:
+        mask16 = pad_mask16(key_padding_mask)
+    assert mask16 is None or (mask16.shape == (B, _l16(Lk)) and mask16.dtype == torch.uint8 and mask16.is_contiguous())
     out = torch.empty((B, Lq, H * 15), dtype=torch.float32, device=q_heads.device)
-    _lib.check(_lib.lib().mmf_attention_heads(_lib.dptr(q_heads), _lib.dptr(k_heads), _lib.dptr(v_heads_t), _lib.dptr(pad), _lib.dptr(out), B,
+    _lib.check(_lib.lib().mmf_attention_heads(_lib.dptr(q_heads), _lib.dptr(k_heads), _lib.dptr(v_heads_t), _lib.dptr(mask16), _lib.dptr(out), B,
                                               Lq, Lk, H, 15, _lib.stream_ptr(q_heads.device)), "mmf_attention_heads")
     return out
 

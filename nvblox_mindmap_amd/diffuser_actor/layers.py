@@ -111,6 +111,14 @@ class RelativeAttention(nn.Module):
             nn.init.zeros_(lin.bias)
         nn.init.zeros_(self.out_proj.bias)
 
+    def project_kv_heads(self, memory: torch.Tensor, kv_rot=None):
+        """(head-major keys, transposed values, Lk) of a memory for the matrix-core attention kernel (fused inference;
+        AttentionStack consumes 3-tuples in ``kv_caches`` this way)."""
+        from .fused_ops import qkv_heads
+
+        _, kh, vt = qkv_heads(memory, None, None, self.kv_proj, kv_rot, self.heads, roles=6)
+        return kh, vt, memory.shape[1]
+
     def project_kv(self, memory: torch.Tensor, kv_rot=None):
         """Keys (rotated) and values of `memory` for the fused path: computed once per inference for a memory that does not
         change between denoising steps (the context of the cross-attention layers)."""
@@ -237,8 +245,9 @@ class AttentionStack(nn.Module):
         self.ffw = nn.ModuleList([FeedForwardBlock(dim, dim, dropout, use_adaln) for _ in range(num_layers)])
 
     def forward(self, query, memory=None, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False,
-                cond_act=None, kv_caches=None):
-        """cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
+                cond_act=None, kv_caches=None, key_padding_mask16=None):
+        """key_padding_mask16: fused_ops.pad_mask16(key_padding_mask) if the caller keeps it (matrix-core attention path).
+        cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
         is constant across calls (cross-attention at inference)."""
         weights = None
         if (_fused(query) and not need_weights and query.shape[-1] in _block_dims() and len(self.attn) > 0
@@ -258,7 +267,15 @@ class AttentionStack(nn.Module):
                     # matrix-core forms: head-major q / k / v -> attention -> out_proj + LN + FFN
                     L_ = query.shape[1]
                     qh, kh, vt = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot, A.heads)
-                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, L_, L_)
+                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, L_, L_, key_padding_mask16)
+                    query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
+                    continue
+                if (not self.self_attention and kv_caches is not None and len(kv_caches[li]) == 3
+                        and (query.shape[-1], A.heads) == FO.MFMA_DIMS):
+                    # cross-attention over a context whose head-major keys / values were cached (project_kv_heads)
+                    kh, vt, Lk = kv_caches[li]
+                    qh, _, _ = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, None, q_rot, A.heads, roles=1)
+                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, query.shape[1], Lk, key_padding_mask16)
                     query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
                     continue
                 if self.self_attention:

@@ -195,6 +195,13 @@ class DiffusionHead(nn.Module):
         if layers_mod._fused(ctx_feats):  # keys / values of the (step-invariant) context, once per inference instead of per step
             P["cross_kv"] = [blk.attn.project_kv(ctx_feats, P["ctx_rot"]) for blk in self.cross_attn.attn]
             P["adaln"] = layers_mod.AdaLNBatch([mod for mod in self.modules() if isinstance(mod, layers_mod.AdaLN)])
+            from .fused_ops import MFMA_DIMS
+
+            if (D, self.cfg.num_attn_heads) == MFMA_DIMS:
+                from .fused_ops import pad_mask16
+
+                P["cross_kv"] = [blk.attn.project_kv_heads(ctx_feats, P["ctx_rot"]) for blk in self.cross_attn.attn]
+                P["ctx_pad16"] = pad_mask16(P["ctx_pad"])
             if D in layers_mod._block_dims():
                 # step-invariant parts of the step's sequence-wide tensors: the sub-sampled context rows of the token
                 # sequence, of its rotary tables and of its padding mask are filled once; a step rewrites the trajectory rows
@@ -205,6 +212,10 @@ class DiffusionHead(nn.Module):
                 P["seq_cos"] = torch.cat([head, P["fps_rot"][0].expand(B, -1, D)], dim=1)
                 P["seq_sin"] = torch.cat([head, P["fps_rot"][1].expand(B, -1, D)], dim=1)
                 P["seq_pad"] = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=dev), P["fps_pad"]], dim=1)
+                if P.get("ctx_pad16") is not None:
+                    from .fused_ops import pad_mask16
+
+                    P["seq_pad16"] = pad_mask16(P["seq_pad"])
                 P["pos_table"] = sinusoidal_embedding(torch.arange(nt, device=dev), D)
                 third = D // 3
                 P["rot_freq"] = torch.exp(torch.arange(0, third, 2, device=dev, dtype=torch.float32) * (-math.log(10000.0) / third))
@@ -284,10 +295,10 @@ class DiffusionHead(nn.Module):
         cond = time_emb  # only its presence matters below: every AdaLN projection comes from `ada`
         traj_rot = (P["seq_cos"][:, :nt], P["seq_sin"][:, :nt])
         tokens, _ = self.cross_attn(tokens, P["ctx_feats"], cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"], cond_act=ada,
-                                    kv_caches=P["cross_kv"])
-        seq, seq_rot, pad = P["seq"], (P["seq_cos"], P["seq_sin"]), P["seq_pad"]
+                                    kv_caches=P["cross_kv"], key_padding_mask16=P.get("ctx_pad16"))
+        seq, seq_rot, pad, pad16 = P["seq"], (P["seq_cos"], P["seq_sin"]), P["seq_pad"], P.get("seq_pad16")
         seq[:, :nt].copy_(tokens)
-        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada)
+        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
         # the two output stacks are independent: fork the rotation stack onto a second stream (parallel branches of the
         # captured HIP graph; concurrent small kernels in eager mode), join before the output heads
         if self._side_stream is None:
@@ -295,8 +306,8 @@ class DiffusionHead(nn.Module):
         main, side = torch.cuda.current_stream(seq.device), self._side_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada)
-        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada)
+            rot_seq, _ = self.rotation_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
+        pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
         main.wait_stream(side)
         rot_seq.record_stream(main)
         pred, head_yaw = FO.head_outputs(self, rot_seq, pos_seq, B, L, G)

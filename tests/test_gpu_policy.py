@@ -372,3 +372,30 @@ def test_step_prologue_and_head_outputs_match_torch(B, G):
         assert torch.allclose(pred, ref, rtol=1e-4, atol=1e-5), float((pred - ref).abs().max())
         if head.head_yaw_out is not None:
             assert torch.allclose(yaw, head.head_yaw_out(pos_feat.reshape(B, L, G * D)), rtol=1e-4, atol=1e-5)
+
+
+def test_mfma_cross_attention_over_a_long_context():
+    """Two trajectory tokens over 3072 context keys (the 16-wave form of mmf_attention_heads, cached head-major keys / values)
+    against mmf_q_block + mmf_kv_block + mmf_attention_small."""
+    from nvblox_mindmap_amd.diffuser_actor import fused_ops as FO
+    from nvblox_mindmap_amd.diffuser_actor import layers as Ly
+
+    torch.manual_seed(9)
+    D, H, B, Lq, Lk = 120, 8, 2, 2, 3072
+    A = Ly.AttentionBlock(D, H, 0.0, use_adaln=True).cuda().eval().attn
+    for p in A.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    x, mem = torch.randn(B, Lq, D, device="cuda"), torch.randn(B, Lk, D, device="cuda")
+    ss = 0.3 * torch.randn(B, 2 * D, device="cuda")
+    q_rot = Ly.rotary3d(torch.rand(B, Lq, 3, device="cuda"), D)
+    kv_rot = Ly.rotary3d(torch.rand(B, Lk, 3, device="cuda"), D)
+    pad = torch.rand(B, Lk, device="cuda") < 0.3
+    pad[:, 5] = False
+    with torch.no_grad():
+        q = FO.q_block(x, ss, A.q_proj, q_rot)
+        k, v = FO.kv_block(mem, A.kv_proj, kv_rot)
+        ref = FO.attention_small(q, k, v, pad, H)
+        kh, vt, n = A.project_kv_heads(mem, kv_rot)
+        qh, _, _ = FO.qkv_heads(x, ss, A.q_proj, None, q_rot, H, roles=1)
+        got = FO.attention_heads(qh, kh, vt, pad, Lq, n)
+    assert n == Lk and torch.allclose(got, ref, rtol=1e-4, atol=1e-5), float((got - ref).abs().max())
