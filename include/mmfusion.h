@@ -299,7 +299,12 @@ int mmf_out_ffn_mfma(const float* att_dev, const float* residual_dev, const floa
  *                      l * G + g of the two output stacks (batch stride seq_batch_stride floats).  weights20 (HOST array of 20
  *                      device pointers, transposed [in, out] weights then bias): rotation_proj, position_proj, rotation_out.0,
  *                      rotation_out.2, position_out.0, position_out.2, openness_out.0, openness_out.2, head_yaw_out.0,
- *                      head_yaw_out.2 (the last four entries null: no head yaw) */
+ *                      head_yaw_out.2 (the last four entries null: no head yaw)
+ *   mmf_step_tail      mmf_head_outputs, then the reverse-diffusion update of the trajectory (the arithmetic of mmf_ddpm_step on
+ *                      channels [0,3) with coef_pos6 and [3,9) with coef_rot6 = {s1, inv_s2, c0, c1, sigma, clip}, HOST arrays),
+ *                      then -- unless tokens_out is null -- the token / rotary part of mmf_step_prologue for the NEW trajectory:
+ *                      a denoising step ends, and the next one begins, in this one launch.
+ *                      mmf_step_prologue with adaln_width = 0 computes tokens and rotary codes only. */
 int mmf_step_prologue(const float* trajectory_dev, int B, int num_tokens, const float* traj_encoder_wt_dev, const float* traj_encoder_bias_dev,
                       const float* position_table_dev, const float* time_embedding_dev, const float* history_dev,
                       const float* rotary_freq_dev, const float* adaln_wt_dev, const float* adaln_bias_dev, int adaln_width,
@@ -307,6 +312,12 @@ int mmf_step_prologue(const float* trajectory_dev, int B, int num_tokens, const 
                       int D, void* stream);
 int mmf_head_outputs(const float* rotation_seq_dev, const float* position_seq_dev, long long seq_batch_stride, int B, int L, int G,
                      const float* const* weights20, float* pred_out_dev, float* head_yaw_out_dev, int D, void* stream);
+int mmf_step_tail(const float* rotation_seq_dev, const float* position_seq_dev, long long seq_batch_stride, int B, int L, int G,
+                  const float* const* weights20, float* pred_out_dev, float* head_yaw_out_dev, const float* trajectory_dev,
+                  const float* noise_dev, const float* coef_pos6, const float* coef_rot6, float* trajectory_out_dev,
+                  const float* traj_encoder_wt_dev, const float* traj_encoder_bias_dev, const float* position_table_dev,
+                  const float* rotary_freq_dev, float* tokens_out_dev, float* cos_out_dev, float* sin_out_dev, long long rotary_batch_stride,
+                  int D, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

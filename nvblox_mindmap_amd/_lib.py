@@ -122,6 +122,8 @@ SIGNATURES = {
     "mmf_out_ffn_mfma": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP]),
     "mmf_step_prologue": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
     "mmf_head_outputs": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _I, _VP]),
+    "mmf_step_tail": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                           C.c_longlong, _I, _VP]),
     "mmf_ffn_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP]),
     "mmf_q_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_kv_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),

@@ -1432,8 +1432,9 @@ int mmf_step_prologue(const float* trajectory, int B, int num_tokens, const floa
                       const float* position_table, const float* time_embedding, const float* history, const float* rotary_freq,
                       const float* adaln_wt, const float* adaln_bias, int adaln_width, float* tokens_out, float* adaln_out, float* cos_out,
                       float* sin_out, long long rotary_batch_stride, int D, void* stream) {
-  if (!trajectory || !traj_encoder_wt || !traj_encoder_bias || !position_table || !time_embedding || !history || !rotary_freq || !adaln_wt ||
-      !adaln_bias || !tokens_out || !adaln_out || !cos_out || !sin_out || B <= 0 || num_tokens <= 0 || adaln_width <= 0)
+  const bool ada = adaln_width > 0;  // adaln_width 0: tokens and rotary codes only
+  if (!trajectory || !traj_encoder_wt || !traj_encoder_bias || !position_table || !rotary_freq || !tokens_out || !cos_out || !sin_out ||
+      B <= 0 || num_tokens <= 0 || adaln_width < 0 || (ada && (!time_embedding || !history || !adaln_wt || !adaln_bias || !adaln_out)))
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_step_prologue");
   if (D != 120) return fail(MMF_ERR_INVALID_ARG, "mmf_step_prologue is built for D = 120");
   launch_step_prologue(trajectory, B, num_tokens, traj_encoder_wt, traj_encoder_bias, position_table, time_embedding, history, rotary_freq,
@@ -1452,6 +1453,27 @@ int mmf_head_outputs(const float* rotation_seq, const float* position_seq, long 
   if (D != 120 || launch_head_outputs(rotation_seq, position_seq, seq_batch_stride, B, L, G, weights20, pred_out, head_yaw_out,
                                       (hipStream_t)stream) != 0)
     return fail(MMF_ERR_INVALID_ARG, "mmf_head_outputs is built for D = 120 and at most 4 grippers");
+  return check_launch();
+}
+
+int mmf_step_tail(const float* rotation_seq, const float* position_seq, long long seq_batch_stride, int B, int L, int G,
+                  const float* const* weights20, float* pred_out, float* head_yaw_out, const float* trajectory, const float* noise,
+                  const float* coef_pos6, const float* coef_rot6, float* trajectory_out, const float* traj_encoder_wt,
+                  const float* traj_encoder_bias, const float* position_table, const float* rotary_freq, float* tokens_out, float* cos_out,
+                  float* sin_out, long long rotary_batch_stride, int D, void* stream) {
+  if (!rotation_seq || !position_seq || !weights20 || !pred_out || !trajectory || !noise || !coef_pos6 || !coef_rot6 || !trajectory_out ||
+      B <= 0 || L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_step_tail");
+  if (tokens_out && (!traj_encoder_wt || !traj_encoder_bias || !position_table || !rotary_freq || !cos_out || !sin_out))
+    return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail: incomplete next-step arguments");
+  for (int i = 0; i < 16; ++i)
+    if (!weights20[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail: missing weight");
+  if (weights20[16] && (!weights20[17] || !weights20[18] || !weights20[19] || !head_yaw_out))
+    return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail: incomplete head-yaw arguments");
+  if (D != 120 || launch_step_tail(rotation_seq, position_seq, seq_batch_stride, B, L, G, weights20, pred_out, head_yaw_out, trajectory, noise,
+                                   coef_pos6, coef_rot6, trajectory_out, traj_encoder_wt, traj_encoder_bias, position_table, rotary_freq,
+                                   tokens_out, cos_out, sin_out, rotary_batch_stride, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail is built for D = 120 and at most 4 grippers");
   return check_launch();
 }
 

@@ -5,7 +5,8 @@
 //                    ALL AdaLN scale/shift projections of the step (one GEMV, [120] x [120, NA]); 3-D rotary cos / sin of the
 //                    trajectory positions, written straight into the first rows of the sequence-wide rotary tables
 //   k_head_outputs   rotation_proj / position_proj of the trajectory rows of the two output stacks, the four small MLPs
-//                    (position 3, rotation 6, openness 1, head yaw 1), concatenated into pred [B, L, G, 10]
+//                    (position 3, rotation 6, openness 1, head yaw 1), concatenated into pred [B, L, G, 10]; as the step's TAIL
+//                    also the reverse-diffusion update of the trajectory and the next step's tokens / rotary codes
 #include "mmf_device.h"
 #include "mmf_launch.h"
 
@@ -71,12 +72,15 @@ struct HeadWeights {  // transposed ([in, out]) weights and biases
   const float *y1, *y1b, *y2, *y2b;        // head_yaw_out (null: no head yaw)
 };
 
-// acc[g] += sum_{c in [c0, c0 + N)} in[g][c] * Wt[c * kHD + j]: N independent, coalesced weight loads in flight at once
+// N independent, coalesced weight loads of output column j (rows c0 .. c0 + N of the transposed matrix) ...
 template <int N>
-__device__ __forceinline__ void dot_cols(const float* __restrict__ Wt, int j, int c0, const float (*in)[128], int G, float (&acc)[kMaxG]) {
-  float w[N];
+__device__ __forceinline__ void load_cols(const float* __restrict__ Wt, int j, int c0, float (&w)[N]) {
 #pragma unroll
   for (int c = 0; c < N; ++c) w[c] = Wt[(size_t)(c0 + c) * kHD + j];
+}
+// ... and acc[g] += sum_c in[g][c0 + c] * w[c]
+template <int N>
+__device__ __forceinline__ void fma_cols(const float (&w)[N], int c0, const float (*in)[128], int G, float (&acc)[kMaxG]) {
 #pragma unroll
   for (int c = 0; c < N; ++c)
 #pragma unroll
@@ -84,18 +88,39 @@ __device__ __forceinline__ void dot_cols(const float* __restrict__ Wt, int j, in
       if (g < G) acc[g] += w[c] * in[g][c0 + c];
 }
 
+struct StepCoef {  // DDPMScheduler.step_coefficients
+  float s1, inv_s2, c0, c1, sigma, clip;
+};
+struct StepTail {  // the reverse-diffusion update and the next step's trajectory tokens (null traj: outputs only)
+  const float *traj, *noise;            // [B, L, G, 9]
+  StepCoef pos, rot;                    // channels [0, 3) / [3, 9)
+  float* traj_out;                      // [B, L, G, 9]
+  const float *WeT, *be, *pos_table, *freq;
+  float *tokens_out, *cos_out, *sin_out;  // tokens_out null: last step, no next tokens
+  long long rot_batch_stride;
+};
+
 // grid (B * L), 512 threads = 4 parts x 128 channel threads: one (batch element, horizon step) = G trajectory tokens.
 //   stage A  rotation_proj (parts 0, 1: halves of the reduction) | position_proj (parts 2, 3)
 //   stage B  first layers of the four MLPs, one per part (rotation | position | openness | head yaw), ReLU
 //   stage C  their 10 G + 1 scalar outputs, one 8-lane group each
+//   tail     x_{t-1} from (x_t, predicted noise, pre-drawn noise); next step's tokens and rotary codes of the new positions
+// The weights of stage B are requested before stage A computes: the kernel is a chain of cold-weight fetches otherwise.
 __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ rot_seq, const float* __restrict__ pos_seq,
                                                      long long seq_batch_stride, int L, int G, HeadWeights W, float* __restrict__ pred,
-                                                     float* __restrict__ head_yaw) {
+                                                     float* __restrict__ head_yaw, StepTail T) {
   __shared__ float s_in[2][kMaxG][128], s_feat[2][kMaxG][128], s_h[4][kMaxG][128];
   __shared__ float s_red[4][kMaxG][128];
+  __shared__ float s_pred[kMaxG][10], s_traj[kMaxG][9];
   const int b = (int)blockIdx.x / L, l = (int)blockIdx.x % L;
   const int j = threadIdx.x & 127, part = threadIdx.x >> 7;
   const bool act = j < kHD;
+  const int jc = act ? j : 0;
+  const float* WB = part == 0 ? W.r1 : (part == 1 ? W.p1 : (part == 2 ? W.o1 : W.y1));
+  const bool partB = part < 3 || W.y1 != nullptr;
+  float wA[60], wB0[60], wB1[60];
+  load_cols<60>(part < 2 ? W.rp : W.pp, jc, (part & 1) * 60, wA);
+  if (partB) load_cols<60>(WB, jc, 0, wB0);
   for (int e = threadIdx.x; e < 2 * G * kHD; e += 512) {
     const int which = e / (G * kHD), r = e - which * G * kHD, g = r / kHD, c = r - g * kHD;
     s_in[which][g][c] = (which ? pos_seq : rot_seq)[(size_t)b * seq_batch_stride + (size_t)(l * G + g) * kHD + c];
@@ -103,7 +128,8 @@ __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ 
   __syncthreads();
   {  // stage A
     float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
-    if (act) dot_cols<60>(part < 2 ? W.rp : W.pp, j, (part & 1) * 60, s_in[part >> 1], G, acc);
+    fma_cols<60>(wA, (part & 1) * 60, s_in[part >> 1], G, acc);
+    if (partB) load_cols<60>(WB, jc, 60, wB1);
 #pragma unroll
     for (int g = 0; g < kMaxG; ++g) s_red[part][g][j] = acc[g];
     __syncthreads();
@@ -116,21 +142,23 @@ __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ 
   {  // stage B
     float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
     if (part < 3) {
-      const float* Wt = part == 0 ? W.r1 : (part == 1 ? W.p1 : W.o1);
       const float* bs = part == 0 ? W.r1b : (part == 1 ? W.p1b : W.o1b);
+      fma_cols<60>(wB0, 0, s_feat[part ? 1 : 0], G, acc);
+      fma_cols<60>(wB1, 60, s_feat[part ? 1 : 0], G, acc);
       if (act) {
-        dot_cols<60>(Wt, j, 0, s_feat[part ? 1 : 0], G, acc);
-        dot_cols<60>(Wt, j, 60, s_feat[part ? 1 : 0], G, acc);
         const float bb = bs[j];
         for (int g = 0; g < G; ++g) s_h[part][g][j] = fmaxf(acc[g] + bb, 0.0f);
       }
-    } else if (W.y1 && act) {  // head yaw: one input vector made of the G position features
-      float a1[kMaxG] = {0.f, 0.f, 0.f, 0.f};
-      for (int g = 0; g < G; ++g) {
-        dot_cols<60>(W.y1 + (size_t)g * kHD * kHD, j, 0, &s_feat[1][g], 1, a1);
-        dot_cols<60>(W.y1 + (size_t)g * kHD * kHD, j, 60, &s_feat[1][g], 1, a1);
+    } else if (W.y1) {  // head yaw: one input vector made of the G position features
+      fma_cols<60>(wB0, 0, &s_feat[1][0], 1, acc);
+      fma_cols<60>(wB1, 60, &s_feat[1][0], 1, acc);
+      for (int g = 1; g < G; ++g) {
+        load_cols<60>(W.y1 + (size_t)g * kHD * kHD, jc, 0, wB0);
+        load_cols<60>(W.y1 + (size_t)g * kHD * kHD, jc, 60, wB1);
+        fma_cols<60>(wB0, 0, &s_feat[1][g], 1, acc);
+        fma_cols<60>(wB1, 60, &s_feat[1][g], 1, acc);
       }
-      s_h[3][0][j] = fmaxf(a1[0] + W.y1b[j], 0.0f);
+      if (act) s_h[3][0][j] = fmaxf(acc[0] + W.y1b[j], 0.0f);
     }
     __syncthreads();
   }
@@ -155,20 +183,66 @@ __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ 
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 1, 64);
     if (live && q == 0) {
-      const float bb = (yaw ? W.y2b : (k < 3 ? W.p2b : (k < 9 ? W.r2b : W.o2b)))[col];
-      if (yaw)
-        head_yaw[(size_t)b * L + l] = acc + bb;
-      else
-        pred[(((size_t)b * L + l) * G + g) * 10 + k] = acc + bb;
+      const float v = acc + (yaw ? W.y2b : (k < 3 ? W.p2b : (k < 9 ? W.r2b : W.o2b)))[col];
+      if (yaw) {
+        head_yaw[(size_t)b * L + l] = v;
+      } else {
+        pred[(((size_t)b * L + l) * G + g) * 10 + k] = v;
+        s_pred[g][k] = v;
+      }
     }
   }
+  if (T.traj == nullptr) return;
+  __syncthreads();
+  if ((int)threadIdx.x < G * 9) {  // x_{t-1}: the arithmetic of k_ddpm_step
+    const int g = threadIdx.x / 9, c = threadIdx.x % 9;
+    const size_t e = (((size_t)b * L + l) * G + g) * 9 + c;
+    const StepCoef K = c < 3 ? T.pos : T.rot;
+    const float xv = T.traj[e];
+    float x0 = (xv - K.s1 * s_pred[g][c]) * K.inv_s2;
+    if (K.clip > 0.0f) x0 = fminf(fmaxf(x0, -K.clip), K.clip);
+    float prev = K.c0 * x0 + K.c1 * xv;
+    if (K.sigma > 0.0f) prev = prev + K.sigma * T.noise[e];
+    T.traj_out[e] = prev;
+    s_traj[g][c] = prev;
+  }
+  if (T.tokens_out == nullptr) return;
+  __syncthreads();
+  const int third = kHD / 3, nt = L * G;
+  for (int e = threadIdx.x; e < G * kHD; e += 512) {  // the next step's trajectory tokens and rotary codes (k_step_prologue)
+    const int g = e / kHD, c = e - g * kHD, i = l * G + g;
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) acc += s_traj[g][u] * T.WeT[u * kHD + c];
+    T.tokens_out[((size_t)b * nt + i) * kHD + c] = (acc + T.be[c]) + T.pos_table[i * kHD + c];
+    const int a = c / third, k = (c - a * third) >> 1;
+    const float ang = s_traj[g][a] * T.freq[k];
+    T.cos_out[(size_t)b * T.rot_batch_stride + (size_t)i * kHD + c] = cosf(ang);
+    T.sin_out[(size_t)b * T.rot_batch_stride + (size_t)i * kHD + c] = sinf(ang);
+  }
+}
+
+static HeadWeights head_weights(const float* const* w) {
+  return HeadWeights{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18], w[19]};
 }
 
 int launch_head_outputs(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
                         float* pred, float* head_yaw, hipStream_t s) {
   if (G < 1 || G > kMaxG) return 1;
-  HeadWeights W{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18], w[19]};
-  hipLaunchKernelGGL(k_head_outputs, dim3(B * L), dim3(512), 0, s, rot_seq, pos_seq, seq_batch_stride, L, G, W, pred, head_yaw);
+  StepTail T{};
+  hipLaunchKernelGGL(k_head_outputs, dim3(B * L), dim3(512), 0, s, rot_seq, pos_seq, seq_batch_stride, L, G, head_weights(w), pred, head_yaw, T);
+  return 0;
+}
+
+int launch_step_tail(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
+                     float* pred, float* head_yaw, const float* traj, const float* noise, const float* coef_pos, const float* coef_rot,
+                     float* traj_out, const float* WeT, const float* be, const float* pos_table, const float* freq, float* tokens_out,
+                     float* cos_out, float* sin_out, long long rot_batch_stride, hipStream_t s) {
+  if (G < 1 || G > kMaxG) return 1;
+  StepTail T{traj, noise, StepCoef{coef_pos[0], coef_pos[1], coef_pos[2], coef_pos[3], coef_pos[4], coef_pos[5]},
+             StepCoef{coef_rot[0], coef_rot[1], coef_rot[2], coef_rot[3], coef_rot[4], coef_rot[5]}, traj_out, WeT, be, pos_table, freq,
+             tokens_out, cos_out, sin_out, rot_batch_stride};
+  hipLaunchKernelGGL(k_head_outputs, dim3(B * L), dim3(512), 0, s, rot_seq, pos_seq, seq_batch_stride, L, G, head_weights(w), pred, head_yaw, T);
   return 0;
 }
 

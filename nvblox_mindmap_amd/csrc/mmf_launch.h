@@ -145,5 +145,9 @@ void launch_step_prologue(const float* traj, int B, int nt, const float* WeT, co
                           float* cos_out, float* sin_out, long long rot_batch_stride, hipStream_t s);
 int launch_head_outputs(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
                         float* pred, float* head_yaw, hipStream_t s);
+int launch_step_tail(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
+                     float* pred, float* head_yaw, const float* traj, const float* noise, const float* coef_pos, const float* coef_rot,
+                     float* traj_out, const float* WeT, const float* be, const float* pos_table, const float* freq, float* tokens_out,
+                     float* cos_out, float* sin_out, long long rot_batch_stride, hipStream_t s);
 
 }  // namespace mmf

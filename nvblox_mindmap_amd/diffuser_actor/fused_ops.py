@@ -243,22 +243,38 @@ def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) -
 def step_prologue(trajectory, traj_encoder, pos_table, time_row, history, rot_freq, adaln_wt, adaln_bias, seq_cos, seq_sin):
     """One launch for everything in front of the first attention layer of a denoising step.  trajectory [B,L,G,9];
     pos_table [L*G, D]; time_row [D] (this step's time embedding); history [B, D]; adaln_wt [D, NA] / adaln_bias [NA]: the
-    stacked AdaLN projections; seq_cos / seq_sin [B, Ls, D]: sequence-wide rotary tables whose first L*G rows are (re)written.
-    Returns (tokens [B, L*G, D], adaln [B, NA])."""
+    stacked AdaLN projections (adaln_wt None: trajectory tokens and rotary codes only); seq_cos / seq_sin [B, Ls, D]:
+    sequence-wide rotary tables whose first L*G rows are (re)written.  Returns (tokens [B, L*G, D], adaln [B, NA] or None)."""
     trajectory = trajectory.contiguous()
     B = trajectory.shape[0]
     nt = trajectory.shape[1] * trajectory.shape[2]
     D = pos_table.shape[-1]
-    NA = adaln_wt.shape[1]
-    assert seq_cos.is_contiguous() and seq_sin.is_contiguous() and seq_cos.shape[1] >= nt and time_row.numel() == D
+    NA = 0 if adaln_wt is None else adaln_wt.shape[1]
+    assert seq_cos.is_contiguous() and seq_sin.is_contiguous() and seq_cos.shape[1] >= nt
     tokens = torch.empty((B, nt, D), dtype=torch.float32, device=trajectory.device)
-    adaln = torch.empty((B, NA), dtype=torch.float32, device=trajectory.device)
+    adaln = torch.empty((B, NA), dtype=torch.float32, device=trajectory.device) if NA else None
     _lib.check(_lib.lib().mmf_step_prologue(_lib.dptr(trajectory), B, nt, _lib.dptr(_wt(traj_encoder)), _lib.dptr(_c(traj_encoder.bias)),
-                                            _lib.dptr(_c(pos_table)), _lib.dptr(_c(time_row)), _lib.dptr(_c(history)), _lib.dptr(_c(rot_freq)),
-                                            _lib.dptr(adaln_wt), _lib.dptr(adaln_bias), NA, _lib.dptr(tokens), _lib.dptr(adaln),
-                                            _lib.dptr(seq_cos), _lib.dptr(seq_sin), seq_cos.stride(0), D, _lib.stream_ptr(trajectory.device)),
-               "mmf_step_prologue")
+                                            _lib.dptr(_c(pos_table)), _lib.dptr(_c(time_row) if NA else None),
+                                            _lib.dptr(_c(history) if NA else None), _lib.dptr(_c(rot_freq)), _lib.dptr(adaln_wt),
+                                            _lib.dptr(adaln_bias if NA else None), NA, _lib.dptr(tokens), _lib.dptr(adaln), _lib.dptr(seq_cos),
+                                            _lib.dptr(seq_sin), seq_cos.stride(0), D, _lib.stream_ptr(trajectory.device)), "mmf_step_prologue")
     return tokens, adaln
+
+
+def _head_weight_array(head):
+    import ctypes as Ct
+
+    lins = [head.rotation_proj, head.position_proj, head.rotation_out[0], head.rotation_out[2], head.position_out[0], head.position_out[2],
+            head.openness_out[0], head.openness_out[2]]
+    if head.head_yaw_out is not None:
+        lins += [head.head_yaw_out[0], head.head_yaw_out[2]]
+    ptrs, keep = [], []
+    for lin in lins:
+        w, b = _wt(lin), _c(lin.bias)
+        keep += [w, b]
+        ptrs += [w.data_ptr(), b.data_ptr()]
+    ptrs += [0] * (20 - len(ptrs))
+    return (Ct.c_void_p * 20)(*[p or None for p in ptrs]), keep
 
 
 def head_outputs(head, rot_seq, pos_seq, B: int, L: int, G: int):
@@ -267,21 +283,36 @@ def head_outputs(head, rot_seq, pos_seq, B: int, L: int, G: int):
     import ctypes as Ct
 
     assert rot_seq.is_contiguous() and pos_seq.is_contiguous() and rot_seq.shape == pos_seq.shape
-    lins = [head.rotation_proj, head.position_proj, head.rotation_out[0], head.rotation_out[2], head.position_out[0], head.position_out[2],
-            head.openness_out[0], head.openness_out[2]]
-    if head.head_yaw_out is not None:
-        lins += [head.head_yaw_out[0], head.head_yaw_out[2]]
-    ptrs = []
-    keep = []
-    for lin in lins:
-        w, b = _wt(lin), _c(lin.bias)
-        keep += [w, b]
-        ptrs += [w.data_ptr(), b.data_ptr()]
-    ptrs += [0] * (20 - len(ptrs))
-    arr = (Ct.c_void_p * 20)(*[p or None for p in ptrs])
+    arr, _keep = _head_weight_array(head)
     dev = rot_seq.device
     pred = torch.empty((B, L, G, 10), dtype=torch.float32, device=dev)
     yaw = torch.empty((B, L, 1), dtype=torch.float32, device=dev) if head.head_yaw_out is not None else None
     _lib.check(_lib.lib().mmf_head_outputs(_lib.dptr(rot_seq), _lib.dptr(pos_seq), rot_seq.stride(0), B, L, G, Ct.cast(arr, Ct.c_void_p),
                                            _lib.dptr(pred), _lib.dptr(yaw), rot_seq.shape[-1], _lib.stream_ptr(dev)), "mmf_head_outputs")
     return pred, yaw
+
+
+def step_tail(head, rot_seq, pos_seq, traj, noise, coef_pos, coef_rot, pos_table, rot_freq, seq_cos, seq_sin, last: bool):
+    """The end of a denoising step and the beginning of the next in one launch: ``head_outputs``, the reverse-diffusion
+    update of ``traj`` [B,L,G,9] (``ddpm_step``), and -- unless ``last`` -- the next step's trajectory tokens and rotary codes
+    (the token part of ``step_prologue``).  Returns (pred, head_yaw, new traj, next tokens or None)."""
+    import ctypes as Ct
+
+    assert rot_seq.is_contiguous() and pos_seq.is_contiguous() and rot_seq.shape == pos_seq.shape
+    traj, noise = traj.contiguous(), noise.contiguous()
+    B, L, G, _ = traj.shape
+    arr, _keep = _head_weight_array(head)
+    dev = rot_seq.device
+    D = rot_seq.shape[-1]
+    pred = torch.empty((B, L, G, 10), dtype=torch.float32, device=dev)
+    yaw = torch.empty((B, L, 1), dtype=torch.float32, device=dev) if head.head_yaw_out is not None else None
+    new_traj = torch.empty_like(traj)
+    tokens = None if last else torch.empty((B, L * G, D), dtype=torch.float32, device=dev)
+    a, b = (Ct.c_float * 6)(*coef_pos), (Ct.c_float * 6)(*coef_rot)
+    enc = head.traj_encoder
+    _lib.check(_lib.lib().mmf_step_tail(_lib.dptr(rot_seq), _lib.dptr(pos_seq), rot_seq.stride(0), B, L, G, Ct.cast(arr, Ct.c_void_p),
+                                        _lib.dptr(pred), _lib.dptr(yaw), _lib.dptr(traj), _lib.dptr(noise), Ct.cast(a, Ct.c_void_p),
+                                        Ct.cast(b, Ct.c_void_p), _lib.dptr(new_traj), _lib.dptr(_wt(enc)), _lib.dptr(_c(enc.bias)),
+                                        _lib.dptr(_c(pos_table)), _lib.dptr(_c(rot_freq)), _lib.dptr(tokens), _lib.dptr(seq_cos),
+                                        _lib.dptr(seq_sin), seq_cos.stride(0), D, _lib.stream_ptr(dev)), "mmf_step_tail")
+    return pred, yaw, new_traj, tokens

@@ -281,18 +281,11 @@ class DiffusionHead(nn.Module):
         return pred.reshape(B, L, G, 10), head_yaw, weights
 
 
-    def _forward_fused(self, trajectory, P, time_emb):
-        """The same pass on the inference kernels end to end (DiffuserActor.enable_fused_inference): one prologue launch
-        (trajectory tokens, conditioning, every AdaLN projection, trajectory rotary codes), the attention stacks on the
-        whole-layer kernels over preassembled sequence buffers, one launch for the projections and output MLPs."""
-        from . import fused_ops as FO
-
-        B, L, G, _ = trajectory.shape
-        nt = L * G
-        ada = P["adaln"]
-        tokens, ada.all = FO.step_prologue(trajectory, self.traj_encoder, P["pos_table"], time_emb[0], P["history"], P["rot_freq"],
-                                           ada.weight_t, ada.bias, P["seq_cos"], P["seq_sin"])
-        cond = time_emb  # only its presence matters below: every AdaLN projection comes from `ada`
+    def _stacks_fused(self, tokens, P, ada):
+        """Cross-attention, self-attention and the two output stacks of a step on the whole-layer kernels over the
+        preassembled sequence buffers; `ada` holds this step's AdaLN projections.  Returns (rotation seq, position seq)."""
+        nt = tokens.shape[1]
+        cond = P["history"]  # only its presence matters below: every AdaLN projection comes from `ada`
         traj_rot = (P["seq_cos"][:, :nt], P["seq_sin"][:, :nt])
         tokens, _ = self.cross_attn(tokens, P["ctx_feats"], cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"], cond_act=ada,
                                     kv_caches=P["cross_kv"], key_padding_mask16=P.get("ctx_pad16"))
@@ -310,8 +303,46 @@ class DiffusionHead(nn.Module):
         pos_seq, _ = self.position_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
         main.wait_stream(side)
         rot_seq.record_stream(main)
+        return rot_seq, pos_seq
+
+    def _forward_fused(self, trajectory, P, time_emb):
+        """One pass on the inference kernels end to end (DiffuserActor.enable_fused_inference): one prologue launch
+        (trajectory tokens, conditioning, every AdaLN projection, trajectory rotary codes), the attention stacks, one launch
+        for the projections and output MLPs."""
+        from . import fused_ops as FO
+
+        B, L, G, _ = trajectory.shape
+        ada = P["adaln"]
+        tokens, ada.all = FO.step_prologue(trajectory, self.traj_encoder, P["pos_table"], time_emb[0], P["history"], P["rot_freq"],
+                                           ada.weight_t, ada.bias, P["seq_cos"], P["seq_sin"])
+        rot_seq, pos_seq = self._stacks_fused(tokens, P, ada)
         pred, head_yaw = FO.head_outputs(self, rot_seq, pos_seq, B, L, G)
         return pred, head_yaw, None
+
+    def can_denoise_fused(self, P, traj) -> bool:
+        return (P.get("seq") is not None and layers_mod._fused(traj) and traj.shape[1] * traj.shape[2] == P["pos_table"].shape[0]
+                and traj.shape[2] <= 4)
+
+    def denoise_fused(self, noise, P, time_table, coefs):
+        """The whole reverse-diffusion loop on the inference kernels.  noise [1 + T, B, L, G, 9] (noise[0] = x_T), time_table
+        [T, D] (time embeddings of the steps), coefs[k] = (position, rotation) DDPMScheduler.step_coefficients of step k.
+        The AdaLN projections of ALL steps come from one GEMM (their input depends on the step index only); a step is
+        [attention stacks] + ONE launch that produces the step's outputs, x_{t-1}, and the next step's tokens."""
+        from . import fused_ops as FO
+
+        traj = noise[0]
+        ada = P["adaln"]
+        T = time_table.shape[0]
+        ada_steps = F.linear(F.silu(time_table[:, None, :] + P["history"][None]), ada.weight, ada.bias)  # [T, B, NA]
+        tokens, _ = FO.step_prologue(traj, self.traj_encoder, P["pos_table"], None, None, P["rot_freq"], None, None, P["seq_cos"],
+                                     P["seq_sin"])
+        pred = head_yaw = None
+        for k in range(T):
+            ada.all = ada_steps[k]
+            rot_seq, pos_seq = self._stacks_fused(tokens, P, ada)
+            pred, head_yaw, traj, tokens = FO.step_tail(self, rot_seq, pos_seq, traj, noise[1 + k], coefs[k][0], coefs[k][1],
+                                                        P["pos_table"], P["rot_freq"], P["seq_cos"], P["seq_sin"], last=(k == T - 1))
+        return traj, pred, head_yaw
 
 
 class DiffuserActor(nn.Module):
@@ -363,6 +394,12 @@ class DiffuserActor(nn.Module):
         prepared = self.prediction_head.prepare_context(enc)  # step-invariant part of the head, once per inference
         fused = layers_mod._fused(traj)
         time_table = self.prediction_head.time_embeddings(self._inference_timesteps, device) if fused else None
+        head = self.prediction_head
+        if fused and head.can_denoise_fused(prepared, traj):
+            coefs = [(self.position_noise_scheduler.step_coefficients(t), self.rotation_noise_scheduler.step_coefficients(t))
+                     for t in self._inference_timesteps]
+            traj, pred, head_yaw = head.denoise_fused(noise, prepared, time_table, coefs)
+            return torch.cat([traj, pred[..., 9:]], dim=-1), head_yaw
         for k, t in enumerate(self._inference_timesteps):
             if fused:
                 from .fused_ops import ddpm_step

@@ -373,6 +373,26 @@ def test_step_prologue_and_head_outputs_match_torch(B, G):
         if head.head_yaw_out is not None:
             assert torch.allclose(yaw, head.head_yaw_out(pos_feat.reshape(B, L, G * D)), rtol=1e-4, atol=1e-5)
 
+        # the step tail = head outputs + ddpm step + the next step's tokens / rotary codes, bit for bit
+        from nvblox_mindmap_amd.diffuser_actor.scheduler import DDPMScheduler
+
+        sp, sr = DDPMScheduler(100, "scaled_linear"), DDPMScheduler(100, "squaredcos_cap_v2")
+        sp.set_timesteps(100), sr.set_timesteps(100)
+        noise = torch.randn_like(traj)
+        for t, last in ((57, False), (0, True)):
+            cp, cr = sp.step_coefficients(t), sr.step_coefficients(t)
+            c2, s2 = seq_cos.clone(), seq_sin.clone()
+            pred2, yaw2, traj2, tok2 = FO.step_tail(head, rot_seq, pos_seq, traj, noise, cp, cr, pos_table, freq, c2, s2, last=last)
+            assert torch.equal(pred2, pred) and (yaw is None or torch.equal(yaw2, yaw))
+            ref_traj = FO.ddpm_step(traj, pred, noise, cp, cr)
+            assert torch.equal(traj2, ref_traj)
+            if last:
+                assert tok2 is None and torch.equal(c2, seq_cos)
+            else:
+                c3, s3 = seq_cos.clone(), seq_sin.clone()
+                tok3, none = FO.step_prologue(ref_traj, head.traj_encoder, pos_table, None, None, freq, None, None, c3, s3)
+                assert none is None and torch.equal(tok2, tok3) and torch.equal(c2, c3) and torch.equal(s2, s3)
+
 
 def test_mfma_cross_attention_over_a_long_context():
     """Two trajectory tokens over 3072 context keys (the 16-wave form of mmf_attention_heads, cached head-major keys / values)
