@@ -175,7 +175,8 @@ def test_fused_inference_ops_match_the_composite_ops():
             assert torch.allclose(got2, ref2, rtol=1e-5, atol=2e-6)
 
 
-def test_fused_inference_matches_composite_inference():
+@pytest.mark.parametrize("batch", [1, 2])
+def test_fused_inference_matches_composite_inference(batch):
     """Whole policy inference with the fused ops (+ cached context keys/values, + HIP graph) against the composite-op run."""
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
     from nvblox_mindmap_amd.training import build_model, synthetic_batch
@@ -187,7 +188,7 @@ def test_fused_inference_matches_composite_inference():
     for p in model.parameters():  # AdaLN / output layers start at zero: perturb so that every path matters
         if p.requires_grad:
             p.data.add_(0.02 * torch.randn_like(p))
-    s = unpack_batch(cfg, synthetic_batch(cfg, 1, "cuda", num_vertices=3072, seed=3))
+    s = unpack_batch(cfg, synthetic_batch(cfg, batch, "cuda", num_vertices=3072, seed=3))
 
     def infer():
         torch.manual_seed(11)
