@@ -523,14 +523,15 @@ def main():
     if not args.no_train:  # every rank takes part (DDP)
         if dist is not None:
             dist.barrier()
-        # the product trainer path: the frozen backbone of the next batch runs on a second stream (BackbonePrefetcher); the
-        # strictly serial order is reported beside it
-        train = run_training(device, world, steps=args.train_steps, prefetch_backbone=True)
-        serial = run_training(device, world, steps=args.train_steps)
-        train["serial_order"] = {"step_per_s": serial["step_per_s"], "ms_per_step": serial["ms_per_step"]}
+        train = run_training(device, world, steps=args.train_steps)  # strictly serial order: the figure compared across N
+        if world == 1:
+            # single GPU only (measured there; not exercised next to RCCL): the frozen backbone of the next batch on a second
+            # stream beside the trainable pass of the current one (training.BackbonePrefetcher, bit-identical results)
+            pre = run_training(device, world, steps=args.train_steps, prefetch_backbone=True)
+            train["with_backbone_prefetch"] = {"step_per_s": pre["step_per_s"], "ms_per_step": pre["ms_per_step"]}
         # secondary figure, not the headline: the frozen backbone's matmuls with float16 inputs / fp32 accumulation -- the
         # mantissa width of the TF32 mode the reference runs its backbone in (feature_extraction.py:322); gfx950 has no TF32
-        t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16", prefetch_backbone=True)
+        t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16", prefetch_backbone=(world == 1))
         train["fp16_backbone_matmuls"] = {"step_per_s": t16["step_per_s"], "ms_per_step": t16["ms_per_step"],
                                           "note": "frozen backbone under float16 autocast (10-bit mantissa like the reference's TF32 "
                                                   "backbone, fp32 accumulate); everything trainable stays float32"}
