@@ -279,7 +279,11 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  *                        roles: 7 = q | k | v, 1 = q alone (Wkv / k / v may be null), 6 = k | v alone (Wq / q may be null)
  *   mmf_attention_heads  softmax(q k^T / sqrt(head_dim) + key padding) v over those layouts -> out [B, Lq, D]; key_padding: [B, Lk16]
  *                        bytes, 1 = ignore, the keys beyond Lk marked too (or null)
- *   mmf_out_ffn_mfma     same contract as mmf_out_ffn_block */
+ *   mmf_out_ffn_mfma     same contract as mmf_out_ffn_block
+ *   mmf_out_ffn_qkv      mmf_out_ffn_mfma of layer i followed, in the same launch, by mmf_qkv_heads (roles 7) of layer i + 1 on
+ *                        its output.  layer13 (HOST array of device pointers): att, residual, Wo, bo, ln1_weight, ln1_bias,
+ *                        scale_shift (or null), W1, b1, W2, b2, ln2_weight, ln2_bias; next7: scale_shift of the next layer's
+ *                        query input (or null), Wq, bq, Wkv, bkv, cos, sin (both null: no rotary) */
 int mmf_qkv_heads(const float* x_dev, const float* scale_shift_dev, const float* Wq_dev, const float* bq_dev, const float* Wkv_dev,
                   const float* bkv_dev, const float* cos_dev, const float* sin_dev, float* q_heads_dev, float* k_heads_dev,
                   float* v_heads_t_dev, int B, int L, int D, int H, int roles, void* stream);
@@ -318,6 +322,8 @@ int mmf_step_tail(const float* rotation_seq_dev, const float* position_seq_dev, 
                   const float* traj_encoder_wt_dev, const float* traj_encoder_bias_dev, const float* position_table_dev,
                   const float* rotary_freq_dev, float* tokens_out_dev, float* cos_out_dev, float* sin_out_dev, long long rotary_batch_stride,
                   int D, void* stream);
+int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, float* out_dev, const float* const* next7,
+                    float* q_heads_dev, float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

@@ -124,6 +124,7 @@ SIGNATURES = {
     "mmf_head_outputs": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _I, _VP]),
     "mmf_step_tail": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                            C.c_longlong, _I, _VP]),
+    "mmf_out_ffn_qkv": (_I, [_VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "mmf_ffn_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP]),
     "mmf_q_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_kv_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),

@@ -78,14 +78,19 @@ __device__ __forceinline__ void load_cols(const float* __restrict__ Wt, int j, i
 #pragma unroll
   for (int c = 0; c < N; ++c) w[c] = Wt[(size_t)(c0 + c) * kHD + j];
 }
-// ... and acc[g] += sum_c in[g][c0 + c] * w[c]
-template <int N>
-__device__ __forceinline__ void fma_cols(const float (&w)[N], int c0, const float (*in)[128], int G, float (&acc)[kMaxG]) {
+// ... and acc[g] += sum_c in[g][c0 + c] * w[c] for g < G (compile time: no branches in the unrolled body; 16-byte LDS reads)
+template <int N, int G>
+__device__ __forceinline__ void fma_cols(const float (&w)[N], int c0, const float (*in)[128], float (&acc)[kMaxG]) {
 #pragma unroll
-  for (int c = 0; c < N; ++c)
+  for (int c = 0; c < N; c += 4)
 #pragma unroll
-    for (int g = 0; g < kMaxG; ++g)
-      if (g < G) acc[g] += w[c] * in[g][c0 + c];
+    for (int g = 0; g < G; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(&in[g][c0 + c]);
+      acc[g] += w[c] * v.x;
+      acc[g] += w[c + 1] * v.y;
+      acc[g] += w[c + 2] * v.z;
+      acc[g] += w[c + 3] * v.w;
+    }
 }
 
 struct StepCoef {  // DDPMScheduler.step_coefficients
@@ -100,27 +105,31 @@ struct StepTail {  // the reverse-diffusion update and the next step's trajector
   long long rot_batch_stride;
 };
 
-// grid (B * L), 512 threads = 4 parts x 128 channel threads: one (batch element, horizon step) = G trajectory tokens.
-//   stage A  rotation_proj (parts 0, 1: halves of the reduction) | position_proj (parts 2, 3)
-//   stage B  first layers of the four MLPs, one per part (rotation | position | openness | head yaw), ReLU
-//   stage C  their 10 G + 1 scalar outputs, one 8-lane group each
-//   tail     x_{t-1} from (x_t, predicted noise, pre-drawn noise); next step's tokens and rotary codes of the new positions
-// The weights of stage B are requested before stage A computes: the kernel is a chain of cold-weight fetches otherwise.
+// grid (B * L, 2 roles), 512 threads = 4 parts x 128 channel threads: one (batch element, horizon step) = G trajectory tokens.
+// Role 0 = rotation and position branches (+ the step tail, which needs exactly their outputs), role 1 = openness and head-yaw
+// branches: two compute units share the weight traffic (6 matrices of 57 KB), each thread has 120 weight loads in flight.
+//   stage A  rotation_proj (parts 0, 1: halves of the reduction; role 0 only) | position_proj (parts 2, 3)
+//   stage B  first MLP layers, ReLU: role 0 rotation (parts 0, 1) | position (parts 2, 3); role 1 openness | head yaw
+//   stage C  the scalar outputs, one 8-lane group each: role 0 position 3 + rotation 6 per token; role 1 openness per token + yaw
+//   tail     (role 0) x_{t-1} from (x_t, predicted noise, pre-drawn noise); next step's tokens and rotary codes
+template <int G>
 __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ rot_seq, const float* __restrict__ pos_seq,
-                                                     long long seq_batch_stride, int L, int G, HeadWeights W, float* __restrict__ pred,
+                                                     long long seq_batch_stride, int L, HeadWeights W, float* __restrict__ pred,
                                                      float* __restrict__ head_yaw, StepTail T) {
-  __shared__ float s_in[2][kMaxG][128], s_feat[2][kMaxG][128], s_h[4][kMaxG][128];
+  __shared__ __attribute__((aligned(16))) float s_in[2][kMaxG][128], s_feat[2][kMaxG][128], s_h[2][kMaxG][128];
   __shared__ float s_red[4][kMaxG][128];
   __shared__ float s_pred[kMaxG][10], s_traj[kMaxG][9];
-  const int b = (int)blockIdx.x / L, l = (int)blockIdx.x % L;
-  const int j = threadIdx.x & 127, part = threadIdx.x >> 7;
+  const int b = (int)blockIdx.x / L, l = (int)blockIdx.x % L, role = blockIdx.y;
+  const int j = threadIdx.x & 127, part = threadIdx.x >> 7, half = part & 1, pair = part >> 1;
   const bool act = j < kHD;
   const int jc = act ? j : 0;
-  const float* WB = part == 0 ? W.r1 : (part == 1 ? W.p1 : (part == 2 ? W.o1 : W.y1));
-  const bool partB = part < 3 || W.y1 != nullptr;
-  float wA[60], wB0[60], wB1[60];
-  load_cols<60>(part < 2 ? W.rp : W.pp, jc, (part & 1) * 60, wA);
-  if (partB) load_cols<60>(WB, jc, 0, wB0);
+  const bool yaw_on = W.y1 != nullptr;
+  // stage B matrix of this thread's pair: role 0: rotation_out.0 | position_out.0; role 1: openness_out.0 | head_yaw_out.0
+  const float* WB = role == 0 ? (pair == 0 ? W.r1 : W.p1) : (pair == 0 ? W.o1 : W.y1);
+  const bool doA = role == 0 || pair == 1, doB = role == 0 || pair == 0 || yaw_on, yawB = role == 1 && pair == 1;
+  float wA[60], wB[60];
+  if (doA) load_cols<60>(pair == 0 ? W.rp : W.pp, jc, half * 60, wA);
+  if (doB) load_cols<60>(WB, jc, half * 60, wB);  // head yaw: rows of token 0 (the other tokens' rows follow in the loop below)
   for (int e = threadIdx.x; e < 2 * G * kHD; e += 512) {
     const int which = e / (G * kHD), r = e - which * G * kHD, g = r / kHD, c = r - g * kHD;
     s_in[which][g][c] = (which ? pos_seq : rot_seq)[(size_t)b * seq_batch_stride + (size_t)(l * G + g) * kHD + c];
@@ -128,62 +137,66 @@ __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ 
   __syncthreads();
   {  // stage A
     float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
-    fma_cols<60>(wA, (part & 1) * 60, s_in[part >> 1], G, acc);
-    if (partB) load_cols<60>(WB, jc, 60, wB1);
+    if (doA) fma_cols<60, G>(wA, half * 60, s_in[pair], acc);
 #pragma unroll
-    for (int g = 0; g < kMaxG; ++g) s_red[part][g][j] = acc[g];
+    for (int g = 0; g < G; ++g) s_red[part][g][j] = acc[g];
     __syncthreads();
-    if (act && !(part & 1)) {
-      const float bb = (part ? W.ppb : W.rpb)[j];
-      for (int g = 0; g < G; ++g) s_feat[part >> 1][g][j] = (s_red[part][g][j] + s_red[part + 1][g][j]) + bb;
+    if (act && half == 0 && doA) {
+      const float bb = (pair ? W.ppb : W.rpb)[j];
+#pragma unroll
+      for (int g = 0; g < G; ++g) s_feat[pair][g][j] = (s_red[part][g][j] + s_red[part + 1][g][j]) + bb;
     }
     __syncthreads();
   }
   {  // stage B
     float acc[kMaxG] = {0.f, 0.f, 0.f, 0.f};
-    if (part < 3) {
-      const float* bs = part == 0 ? W.r1b : (part == 1 ? W.p1b : W.o1b);
-      fma_cols<60>(wB0, 0, s_feat[part ? 1 : 0], G, acc);
-      fma_cols<60>(wB1, 60, s_feat[part ? 1 : 0], G, acc);
-      if (act) {
-        const float bb = bs[j];
-        for (int g = 0; g < G; ++g) s_h[part][g][j] = fmaxf(acc[g] + bb, 0.0f);
+    if (yawB) {  // one input vector made of the G position features: [120 G] x [120 G, 120]
+      if (yaw_on) {
+        fma_cols<60, 1>(wB, half * 60, &s_feat[1][0], acc);
+#pragma unroll
+        for (int g = 1; g < G; ++g) {
+          load_cols<60>(W.y1 + (size_t)g * kHD * kHD, jc, half * 60, wB);
+          fma_cols<60, 1>(wB, half * 60, &s_feat[1][g], acc);
+        }
       }
-    } else if (W.y1) {  // head yaw: one input vector made of the G position features
-      fma_cols<60>(wB0, 0, &s_feat[1][0], 1, acc);
-      fma_cols<60>(wB1, 60, &s_feat[1][0], 1, acc);
-      for (int g = 1; g < G; ++g) {
-        load_cols<60>(W.y1 + (size_t)g * kHD * kHD, jc, 0, wB0);
-        load_cols<60>(W.y1 + (size_t)g * kHD * kHD, jc, 60, wB1);
-        fma_cols<60>(wB0, 0, &s_feat[1][g], 1, acc);
-        fma_cols<60>(wB1, 60, &s_feat[1][g], 1, acc);
-      }
-      if (act) s_h[3][0][j] = fmaxf(acc[0] + W.y1b[j], 0.0f);
+    } else {
+      fma_cols<60, G>(wB, half * 60, s_feat[role == 0 ? pair : 1], acc);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) s_red[part][g][j] = acc[g];
+    __syncthreads();
+    if (act && half == 0 && doB) {
+      const float bb = (role == 0 ? (pair == 0 ? W.r1b : W.p1b) : (pair == 0 ? W.o1b : W.y1b))[j];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (!yawB || g == 0) s_h[pair][g][j] = fmaxf((s_red[part][g][j] + s_red[part + 1][g][j]) + bb, 0.0f);
     }
     __syncthreads();
   }
-  {  // stage C: output o of token g = one 8-lane group (15 channels per lane)
+  {  // stage C: one scalar output = one 8-lane group (15 channels per lane)
     const int grp = threadIdx.x >> 3, q = threadIdx.x & 7;
-    const int n_out = 10 * G + (W.y1 ? 1 : 0);
+    // role 0: group = 9 g + k, k in 0..2 position (hidden s_h[1]), 3..8 rotation (s_h[0]); role 1: g < G openness (s_h[0]), G: yaw (s_h[1][0])
+    const int n_out = role == 0 ? 9 * G : G + (yaw_on ? 1 : 0);
     const bool live = grp < n_out;
-    const int g = live ? (grp < 10 * G ? grp / 10 : 0) : 0, k = grp - 10 * g;  // k: 0-2 position, 3-8 rotation, 9 openness, 10 yaw
-    const bool yaw = grp == 10 * G;
-    const float* Wt = yaw ? W.y2 : (k < 3 ? W.p2 : (k < 9 ? W.r2 : W.o2));
-    const int nout = yaw ? 1 : (k < 3 ? 3 : (k < 9 ? 6 : 1)), col = yaw ? 0 : (k < 3 ? k : (k < 9 ? k - 3 : 0));
-    const float(*h)[128] = yaw ? s_h[3] : (k < 3 ? s_h[1] : (k < 9 ? s_h[0] : s_h[2]));
+    const bool yaw = role == 1 && grp == G;
+    const int g = (!live || yaw) ? 0 : (role == 0 ? grp / 9 : grp), k = role == 0 ? grp - 9 * g : 9;
+    const float* Wt = role == 0 ? (k < 3 ? W.p2 : W.r2) : (yaw ? W.y2 : W.o2);
+    const float* bs = role == 0 ? (k < 3 ? W.p2b : W.r2b) : (yaw ? W.y2b : W.o2b);
+    const int nout = role == 0 ? (k < 3 ? 3 : 6) : 1, col = role == 0 ? (k < 3 ? k : k - 3) : 0;
+    const float* h = role == 0 ? s_h[k < 3 ? 1 : 0][g] : s_h[yaw ? 1 : 0][g];
     float acc = 0.0f;
     if (live) {
 #pragma unroll
       for (int i = 0; i < 15; ++i) {
         const int c = q * 15 + i;
-        acc += h[yaw ? 0 : g][c] * Wt[c * nout + col];
+        acc += h[c] * Wt[c * nout + col];
       }
     }
     acc += __shfl_xor(acc, 4, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 1, 64);
     if (live && q == 0) {
-      const float v = acc + (yaw ? W.y2b : (k < 3 ? W.p2b : (k < 9 ? W.r2b : W.o2b)))[col];
+      const float v = acc + bs[col];
       if (yaw) {
         head_yaw[(size_t)b * L + l] = v;
       } else {
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(512) void k_head_outputs(const float* __restrict__ 
       }
     }
   }
-  if (T.traj == nullptr) return;
+  if (role != 0 || T.traj == nullptr) return;
   __syncthreads();
   if ((int)threadIdx.x < G * 9) {  // x_{t-1}: the arithmetic of k_ddpm_step
     const int g = threadIdx.x / 9, c = threadIdx.x % 9;
@@ -226,24 +239,36 @@ static HeadWeights head_weights(const float* const* w) {
   return HeadWeights{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18], w[19]};
 }
 
+template <int G>
+static void head_outputs_g(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, const HeadWeights& W, float* pred,
+                           float* head_yaw, const StepTail& T, hipStream_t s) {
+  hipLaunchKernelGGL(k_head_outputs<G>, dim3(B * L, 2), dim3(512), 0, s, rot_seq, pos_seq, seq_batch_stride, L, W, pred, head_yaw, T);
+}
+static int head_outputs_dispatch(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G,
+                                 const HeadWeights& W, float* pred, float* head_yaw, const StepTail& T, hipStream_t s) {
+  switch (G) {
+    case 1: head_outputs_g<1>(rot_seq, pos_seq, seq_batch_stride, B, L, W, pred, head_yaw, T, s); return 0;
+    case 2: head_outputs_g<2>(rot_seq, pos_seq, seq_batch_stride, B, L, W, pred, head_yaw, T, s); return 0;
+    case 3: head_outputs_g<3>(rot_seq, pos_seq, seq_batch_stride, B, L, W, pred, head_yaw, T, s); return 0;
+    case 4: head_outputs_g<4>(rot_seq, pos_seq, seq_batch_stride, B, L, W, pred, head_yaw, T, s); return 0;
+    default: return 1;
+  }
+}
+
 int launch_head_outputs(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
                         float* pred, float* head_yaw, hipStream_t s) {
-  if (G < 1 || G > kMaxG) return 1;
   StepTail T{};
-  hipLaunchKernelGGL(k_head_outputs, dim3(B * L), dim3(512), 0, s, rot_seq, pos_seq, seq_batch_stride, L, G, head_weights(w), pred, head_yaw, T);
-  return 0;
+  return head_outputs_dispatch(rot_seq, pos_seq, seq_batch_stride, B, L, G, head_weights(w), pred, head_yaw, T, s);
 }
 
 int launch_step_tail(const float* rot_seq, const float* pos_seq, long long seq_batch_stride, int B, int L, int G, const float* const* w,
                      float* pred, float* head_yaw, const float* traj, const float* noise, const float* coef_pos, const float* coef_rot,
                      float* traj_out, const float* WeT, const float* be, const float* pos_table, const float* freq, float* tokens_out,
                      float* cos_out, float* sin_out, long long rot_batch_stride, hipStream_t s) {
-  if (G < 1 || G > kMaxG) return 1;
   StepTail T{traj, noise, StepCoef{coef_pos[0], coef_pos[1], coef_pos[2], coef_pos[3], coef_pos[4], coef_pos[5]},
              StepCoef{coef_rot[0], coef_rot[1], coef_rot[2], coef_rot[3], coef_rot[4], coef_rot[5]}, traj_out, WeT, be, pos_table, freq,
              tokens_out, cos_out, sin_out, rot_batch_stride};
-  hipLaunchKernelGGL(k_head_outputs, dim3(B * L), dim3(512), 0, s, rot_seq, pos_seq, seq_batch_stride, L, G, head_weights(w), pred, head_yaw, T);
-  return 0;
+  return head_outputs_dispatch(rot_seq, pos_seq, seq_batch_stride, B, L, G, head_weights(w), pred, head_yaw, T, s);
 }
 
 }  // namespace mmf

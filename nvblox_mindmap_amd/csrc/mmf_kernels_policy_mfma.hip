@@ -32,28 +32,33 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 constexpr int kD = 120, kH = 8, kDH = 15;  // the policy's embedding dim / heads / head dim (the kernels are built for these)
 constexpr int kKSteps = 32;                 // 8 x 4 reduction steps cover 128 >= 120 channels
 
-// A-operand share of one token row: a[4 m + kk] = row[16 m + 4 s + kk] (0 beyond D)
+// All loads below are UNCONDITIONAL from clamped (always valid) addresses, with a select on the value where it matters: a
+// guarded load compiles to a branch plus register copies, and these kernels run once through straight-line code fetched
+// through a cold instruction cache -- their duration follows their code size.
+
+// A-operand share of one token row: a[4 m + kk] = row[16 m + 4 s + kk] (0 beyond D, 0 if !ok; `row` must be readable)
 __device__ __forceinline__ void load_row_share(const float* __restrict__ row, int s, bool ok, float (&a)[kKSteps]) {
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const int c0 = 16 * m + 4 * s;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && c0 < kD) v = *reinterpret_cast<const float4*>(row + c0);
-    a[4 * m] = v.x;
-    a[4 * m + 1] = v.y;
-    a[4 * m + 2] = v.z;
-    a[4 * m + 3] = v.w;
+    const float4 v = *reinterpret_cast<const float4*>(row + (m < 7 ? c0 : min(c0, kD - 4)));
+    const bool keep = ok && (m < 7 || c0 < kD);
+    a[4 * m] = keep ? v.x : 0.0f;
+    a[4 * m + 1] = keep ? v.y : 0.0f;
+    a[4 * m + 2] = keep ? v.z : 0.0f;
+    a[4 * m + 3] = keep ? v.w : 0.0f;
   }
 }
 
-// B-operand share of one output column: w[4 m + kk] = Wt[(16 m + 4 s + kk) * ld + col] (Wt = transposed weights [in, out])
-__device__ __forceinline__ void load_col_share(const float* __restrict__ Wt, int ld, int col, bool ok, int s, float (&w)[kKSteps]) {
+// B-operand share of one output column: w[4 m + kk] = Wt[(16 m + 4 s + kk) * ld + col] (Wt = transposed weights [in, out];
+// `col` must be a valid column; rows beyond D are read from row D - 1: their A values are zero)
+__device__ __forceinline__ void load_col_share(const float* __restrict__ Wt, int ld, int col, int s, float (&w)[kKSteps]) {
 #pragma unroll
   for (int m = 0; m < 8; ++m)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = 16 * m + 4 * s + kk;
-      w[4 * m + kk] = (ok && c < kD) ? Wt[(size_t)c * ld + col] : 0.0f;
+      w[4 * m + kk] = Wt[(size_t)(m < 7 ? c : min(c, kD - 1)) * ld + col];
     }
 }
 
@@ -69,63 +74,58 @@ __device__ __forceinline__ f32x4 tile_gemm(const float (&a)[kKSteps], const floa
 }
 
 // ---- q | k | v projections, rotary, head-major outputs ---------------------------------------------------------------------
-// grid (B * L16 / 16, 3 roles), 256 threads: wave w owns heads 2 w and 2 w + 1 (30 channels: rotary pairs never leave the wave).
-__global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ WqT,
-                                                  const float* __restrict__ bq, const float* __restrict__ WkvT,
-                                                  const float* __restrict__ bkv, const float* __restrict__ cs,
-                                                  const float* __restrict__ sn, float* __restrict__ Qp, float* __restrict__ Kp,
-                                                  float* __restrict__ Vt, int L, int L16, int role0) {
-  const int tpb = L16 / 16;
-  const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
-  const int role = role0 + (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+struct QkvArgs {
+  const float *ss, *WqT, *bq, *WkvT, *bkv, *cs, *sn;  // ss: AdaLN (scale | shift) [B, 2 D] of the query input or null; cs / sn [B, L, D] or null
+  float *Qp, *Kp, *Vt;
+};
 
-  float a[kKSteps];
-  {
-    const int tok = l0 + j;
-    const bool ok = tok < L;
-    load_row_share(x + ((size_t)b * L + (ok ? tok : 0)) * kD, s, ok, a);
-    if (role == 0 && ss != nullptr && ok) {  // AdaLN modulation of the query input
-      const float* sc = ss + (size_t)b * 2 * kD;
+// AdaLN modulation of an A-operand share (token of batch element b)
+__device__ __forceinline__ void modulate_share(const float* __restrict__ ss, int b, int s, float (&a)[kKSteps]) {
+  const float* sc = ss + (size_t)b * 2 * kD;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int c0 = 16 * m + 4 * s;
-        if (c0 < kD) {
-          const float4 g = *reinterpret_cast<const float4*>(sc + c0), h = *reinterpret_cast<const float4*>(sc + kD + c0);
-          a[4 * m] = a[4 * m] * (1.0f + g.x) + h.x;
-          a[4 * m + 1] = a[4 * m + 1] * (1.0f + g.y) + h.y;
-          a[4 * m + 2] = a[4 * m + 2] * (1.0f + g.z) + h.z;
-          a[4 * m + 3] = a[4 * m + 3] * (1.0f + g.w) + h.w;
-        }
-      }
+  for (int m = 0; m < 8; ++m) {
+    const int c0 = 16 * m + 4 * s;
+    if (c0 < kD) {
+      const float4 g = *reinterpret_cast<const float4*>(sc + c0), h = *reinterpret_cast<const float4*>(sc + kD + c0);
+      a[4 * m] = a[4 * m] * (1.0f + g.x) + h.x;
+      a[4 * m + 1] = a[4 * m + 1] * (1.0f + g.y) + h.y;
+      a[4 * m + 2] = a[4 * m + 2] * (1.0f + g.z) + h.z;
+      a[4 * m + 3] = a[4 * m + 3] * (1.0f + g.w) + h.w;
     }
   }
-  const float* Wt = role == 0 ? WqT : WkvT;
-  const int ld = role == 0 ? kD : 2 * kD, off = role == 2 ? kD : 0;
-  const float* bias = role == 0 ? bq : bkv + off;
+}
 
-  // epilogue operands are fetched up front: their latency hides behind the weight loads and the GEMM
-  const bool rotary = role < 2 && cs != nullptr;
+// One role (0 = q, 1 = k, 2 = v) of a 16-token tile (batch element b, first token l0) for the wave's two heads 2 w, 2 w + 1
+// (30 channels: rotary pairs never leave the wave); `a` = the wave's A-operand share of the (modulated / raw) input rows.
+__device__ __forceinline__ void qkv_role_tile(const float (&a)[kKSteps], int role, const QkvArgs& Q, int b, int l0, int L, int L16, int w,
+                                              int j, int s) {
+  const float* Wt = role == 0 ? Q.WqT : Q.WkvT;
+  const int ld = role == 0 ? kD : 2 * kD, off = role == 2 ? kD : 0;
+  const float* bias = role == 0 ? Q.bq : Q.bkv + off;
+
+  // epilogue operands are fetched up front: their latency hides behind the weight loads and the GEMM.  Lanes of the padding
+  // column (j = 15) and of rows beyond L compute on clamped addresses; their results are zeroed at the store.
+  const bool rotary = role < 2 && Q.cs != nullptr;
+  const int jc = min(j, kDH - 1);
   float bb[2], cv[2][4], sv[2][4];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int col = kDH * (2 * w + n) + j;  // column j = 15 of a head tile is padding
-    bb[n] = j < kDH ? bias[col] : 0.0f;
+    const int col = kDH * (2 * w + n) + jc;
+    bb[n] = bias[col];
+    if (rotary) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int tok = l0 + 4 * s + r;
-      const bool ok = rotary && j < kDH && tok < L;
-      const size_t e = ((size_t)b * L + (ok ? tok : 0)) * kD + (ok ? col : 0);
-      cv[n][r] = ok ? cs[e] : 1.0f;
-      sv[n][r] = ok ? sn[e] : 0.0f;
+      for (int r = 0; r < 4; ++r) {
+        const size_t e = ((size_t)b * L + min(l0 + 4 * s + r, L - 1)) * kD + col;
+        cv[n][r] = Q.cs[e];
+        sv[n][r] = Q.sn[e];
+      }
     }
   }
   f32x4 y[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int col = kDH * (2 * w + n) + j;
     float wv[kKSteps];
-    load_col_share(Wt + off, ld, col, j < kDH, s, wv);
+    load_col_share(Wt + off, ld, kDH * (2 * w + n) + jc, s, wv);
     y[n] = tile_gemm(a, wv);
     y[n] += bb[n];
   }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, 
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) y[n][r] = y[n][r] * cv[n][r] + part[n][r] * sv[n][r];  // padding lanes: * 1 + * 0
+      for (int r = 0; r < 4; ++r) y[n][r] = y[n][r] * cv[n][r] + part[n][r] * sv[n][r];
   }
 
 #pragma unroll
@@ -159,13 +159,27 @@ __global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = (j < kDH && l0 + 4 * s + r < L) ? y[n][r] : 0.0f;  // padding stays finite (zero)
     if (role == 2) {
-      *reinterpret_cast<f32x4*>(Vt + (((size_t)b * kH + h) * 16 + j) * L16 + l0 + 4 * s) = o;
+      *reinterpret_cast<f32x4*>(Q.Vt + (((size_t)b * kH + h) * 16 + j) * L16 + l0 + 4 * s) = o;
     } else {
-      float* P = (role == 0 ? Qp : Kp) + (((size_t)b * kH + h) * L16 + l0 + 4 * s) * 16 + j;
+      float* P = (role == 0 ? Q.Qp : Q.Kp) + (((size_t)b * kH + h) * L16 + l0 + 4 * s) * 16 + j;
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[r * 16] = o[r];
     }
   }
+}
+
+// grid (B * L16 / 16, roles), 256 threads
+__global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, QkvArgs Q, int L, int L16, int role0) {
+  const int tpb = L16 / 16;
+  const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
+  const int role = role0 + (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+  float a[kKSteps];
+  const int tok = l0 + j;
+  const bool ok = tok < L;
+  load_row_share(x + ((size_t)b * L + min(tok, L - 1)) * kD, s, ok, a);
+  if (role == 0 && Q.ss != nullptr && ok) modulate_share(Q.ss, b, s, a);  // AdaLN modulation of the query input
+  qkv_role_tile(a, role, Q, b, l0, L, L16, w, j, s);
 }
 
 // ---- attention over head-major operands -------------------------------------------------------------------------------------
@@ -201,16 +215,12 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
     uint32_t pw[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int t = tb + NW * i;
-      if (t < ntiles) {
-        kv[i] = *reinterpret_cast<const float4*>(Kb + ((size_t)t * 16 + j) * 16 + 4 * s);
-        vv[i] = *reinterpret_cast<const float4*>(Vb + t * 16 + 4 * s);
-        pw[i] = pb ? *reinterpret_cast<const uint32_t*>(pb + t * 16 + 4 * s) : 0u;
-      } else {
-        kv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pw[i] = 0xffffffffu;
-      }
+      const int t = tb + NW * i, tc = min(t, ntiles - 1);  // tiles beyond the end: a valid tile's data, every key marked dead
+      kv[i] = *reinterpret_cast<const float4*>(Kb + ((size_t)tc * 16 + j) * 16 + 4 * s);
+      vv[i] = *reinterpret_cast<const float4*>(Vb + tc * 16 + 4 * s);
+      uint32_t word = 0u;
+      if (pb) word = *reinterpret_cast<const uint32_t*>(pb + tc * 16 + 4 * s);
+      pw[i] = t < ntiles ? word : 0xffffffffu;
     }
     f32x4 S[CH];
     float cmax = -INFINITY;
@@ -306,9 +316,9 @@ __device__ __forceinline__ LnShare load_ln_share(const float* __restrict__ gamma
   LnShare P;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = q + 16 * i;
-    P.g[i] = c < kD ? gamma[c] : 0.0f;
-    P.b[i] = c < kD ? beta[c] : 0.0f;
+    const int c = min(q + 16 * i, kD - 1);  // lanes q >= 8 hold no channel for i = 7: the value is not used
+    P.g[i] = gamma[c];
+    P.b[i] = beta[c];
   }
   return P;
 }
@@ -322,7 +332,8 @@ __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = q + 16 * i;
-    v[i] = c < kD ? src[tl][c] : 0.0f;
+    const float x = src[tl][c];
+    v[i] = (i < 7 || c < kD) ? x : 0.0f;
     sum += v[i];
   }
 #pragma unroll
@@ -332,7 +343,7 @@ __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = q + 16 * i;
-    const float d = c < kD ? v[i] - mean : 0.0f;
+    const float d = (i < 7 || c < kD) ? v[i] - mean : 0.0f;
     v[i] = d;
     var += d * d;
   }
@@ -344,12 +355,10 @@ __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = q + 16 * i;
-    if (c < kD) {
-      float o = v[i] * inv * P.g[i] + P.b[i];
-      if (modulate) o = o * (1.0f + sc[i]) + sh[i];
-      if (dst) dst[tl][c] = o;
-      if (gout && live) gout[tok * kD + c] = o;
-    }
+    float o = v[i] * inv * P.g[i] + P.b[i];
+    if (modulate) o = o * (1.0f + sc[i]) + sh[i];
+    if (dst) dst[tl][c] = o;  // columns 120 .. 127 of the LDS tile exist and are never read
+    if (gout && live && (i < 7 || c < kD)) gout[tok * kD + c] = o;
   }
 }
 
@@ -357,65 +366,63 @@ __device__ __forceinline__ void lds_row_share(const float (*src)[kRS], int j, in
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const int c0 = 16 * m + 4 * s;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c0 < kD) v = *reinterpret_cast<const float4*>(&src[j][c0]);
-    a[4 * m] = v.x;
-    a[4 * m + 1] = v.y;
-    a[4 * m + 2] = v.z;
-    a[4 * m + 3] = v.w;
+    const float4 v = *reinterpret_cast<const float4*>(&src[j][c0]);  // c0 <= 124: inside the 132-float row
+    const bool keep = m < 7 || c0 < kD;
+    a[4 * m] = keep ? v.x : 0.0f;
+    a[4 * m + 1] = keep ? v.y : 0.0f;
+    a[4 * m + 2] = keep ? v.z : 0.0f;
+    a[4 * m + 3] = keep ? v.w : 0.0f;
   }
 }
 
-// grid = 16-token tiles of the flattened [B L] token axis; wave w owns output columns [32 w, 32 w + 32)
-__global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ att, const float* __restrict__ res,
-                                                     const float* __restrict__ WoT, const float* __restrict__ bo,
-                                                     const float* __restrict__ g1, const float* __restrict__ be1, float eps1,
-                                                     const float* __restrict__ ss, const float* __restrict__ W1T,
-                                                     const float* __restrict__ b1, const float* __restrict__ W2T,
-                                                     const float* __restrict__ b2, const float* __restrict__ g2,
-                                                     const float* __restrict__ be2, float eps2, float* __restrict__ out, int L,
-                                                     long long tokens) {
-  __shared__ __attribute__((aligned(16))) float sH[16][kRS];  // h = modulate(LN1(..)): A operand of fc1 and residual of fc2
-  __shared__ __attribute__((aligned(16))) float sU[16][kRS];  // relu(fc1(h)): A operand of fc2
-  __shared__ __attribute__((aligned(16))) float sY[16][kRS];  // pre-LayerNorm sums
-  const long long t0 = (long long)blockIdx.x * 16;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+struct OutFfnArgs {
+  const float *att, *res, *WoT, *bo, *g1, *be1, *ss, *W1T, *b1, *W2T, *b2, *g2, *be2;  // ss: AdaLN (scale | shift) of the FFN or null
+  float eps1, eps2;
+  float* out;
+};
 
+// x1 = LN1(res + out_proj(att)); h = modulate(x1); out = LN2(h + fc2(relu(fc1(h)))) for the 16 tokens t0 .. t0 + 15 of the
+// flattened [B L] token axis (`tokens` = B L; rows beyond it are inert); wave w owns output columns [32 w, 32 w + 32).
+// `keep`: where the result additionally stays in LDS (rows of invalid tokens zeroed) for a consumer in the same kernel.
+__device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, long long tokens, int L, float (*sH)[kRS], float (*sU)[kRS],
+                                             float (*sY)[kRS], float (*keep)[kRS], int lane, int w, int j, int s) {
   float a[kKSteps], wv[2][kKSteps];
   {
     const long long tok = t0 + j;
-    const bool ok = tok < tokens;
-    load_row_share(att + (ok ? tok : 0) * kD, s, ok, a);
+    load_row_share(A.att + min(tok, tokens - 1) * kD, s, tok < tokens, a);
   }
+  // output columns 120 .. 127 (the last 8 lanes of wave 3's second tile) compute on column 119's operands; their results
+  // land in LDS columns that are never read
+  const int colc[2] = {min(32 * w + j, kD - 1), min(32 * w + 16 + j, kD - 1)};
 #pragma unroll
-  for (int n = 0; n < 2; ++n) load_col_share(WoT, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);
+  for (int n = 0; n < 2; ++n) load_col_share(A.WoT, kD, colc[n], s, wv[n]);
   // every small operand of the later stages is fetched now: nothing but LDS traffic and MFMAs between the barriers below
   float bbo[2], bb1[2], bb2[2], rs[2][4];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int col = 32 * w + 16 * n + j;
-    const bool cok = col < kD;
-    bbo[n] = cok ? bo[col] : 0.0f;
-    bb1[n] = cok ? b1[col] : 0.0f;
-    bb2[n] = cok ? b2[col] : 0.0f;
+    bbo[n] = A.bo[colc[n]];
+    bb1[n] = A.b1[colc[n]];
+    bb2[n] = A.b2[colc[n]];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long long tok = t0 + 4 * s + r;
-      rs[n][r] = (cok && tok < tokens) ? res[tok * kD + col] : 0.0f;
+      const float v = A.res[min(tok, tokens - 1) * kD + colc[n]];
+      rs[n][r] = tok < tokens ? v : 0.0f;
     }
   }
   const int ln_q = lane & 15;
-  const LnShare P1 = load_ln_share(g1, be1, ln_q), P2 = load_ln_share(g2, be2, ln_q);
-  float sc[8], sh[8];
+  const LnShare P1 = load_ln_share(A.g1, A.be1, ln_q), P2 = load_ln_share(A.g2, A.be2, ln_q);
+  float sc[8] = {}, sh[8] = {};
   {
-    const long long tok = t0 + 4 * w + (lane >> 4);
-    const bool mod = ss != nullptr && tok < tokens;
-    const float* sp = ss + (mod ? (size_t)(tok / L) * 2 * kD : 0);
+    const long long tok = min(t0 + 4 * w + (lane >> 4), tokens - 1);
+    if (A.ss != nullptr) {
+      const float* sp = A.ss + (size_t)(tok / L) * 2 * kD;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = ln_q + 16 * i;
-      sc[i] = (mod && c < kD) ? sp[c] : 0.0f;
-      sh[i] = (mod && c < kD) ? sp[kD + c] : 0.0f;
+      for (int i = 0; i < 8; ++i) {
+        const int c = min(ln_q + 16 * i, kD - 1);
+        sc[i] = sp[c];
+        sh[i] = sp[kD + c];
+      }
     }
   }
   // ---- x1 = LN1(res + out_proj(att)), h = modulate(x1)
@@ -423,15 +430,13 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ 
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
     const f32x4 y = tile_gemm(a, wv[n]);
-    if (col < kD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = y[r] + bbo[n] + rs[n][r];
-    }
+    for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = y[r] + bbo[n] + rs[n][r];
   }
 #pragma unroll
-  for (int n = 0; n < 2; ++n) load_col_share(W1T, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);  // in flight over the LN
+  for (int n = 0; n < 2; ++n) load_col_share(A.W1T, kD, colc[n], s, wv[n]);  // in flight over the LN
   __syncthreads();
-  tile_layer_norm(sY, sH, nullptr, t0, tokens, P1, eps1, ss != nullptr, sc, sh, lane, w);
+  tile_layer_norm(sY, sH, nullptr, t0, tokens, P1, A.eps1, A.ss != nullptr, sc, sh, lane, w);
   __syncthreads();
   // ---- u = relu(fc1(h))
   lds_row_share(sH, j, s, a);
@@ -439,13 +444,11 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ 
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
     const f32x4 y = tile_gemm(a, wv[n]);
-    if (col < kD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sU[4 * s + r][col] = fmaxf(y[r] + bb1[n], 0.0f);
-    }
+    for (int r = 0; r < 4; ++r) sU[4 * s + r][col] = fmaxf(y[r] + bb1[n], 0.0f);
   }
 #pragma unroll
-  for (int n = 0; n < 2; ++n) load_col_share(W2T, kD, 32 * w + 16 * n + j, 32 * w + 16 * n + j < kD, s, wv[n]);
+  for (int n = 0; n < 2; ++n) load_col_share(A.W2T, kD, colc[n], s, wv[n]);
   __syncthreads();
   // ---- out = LN2(h + fc2(u))
   lds_row_share(sU, j, s, a);
@@ -453,13 +456,45 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(const float* __restrict__ 
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
     const f32x4 y = tile_gemm(a, wv[n]);
-    if (col < kD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = sH[4 * s + r][col] + (y[r] + bb2[n]);
-    }
+    for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = sH[4 * s + r][col] + (y[r] + bb2[n]);
   }
+  __syncthreads();  // also: every read of sH / sU above is done, `keep` may alias them
+  tile_layer_norm(sY, keep, A.out, t0, tokens, P2, A.eps2, false, sc, sh, lane, w);
+}
+
+// grid = 16-token tiles of the flattened [B L] token axis
+__global__ __launch_bounds__(256) void k_out_ffn_mfma(OutFfnArgs A, int L, long long tokens) {
+  __shared__ __attribute__((aligned(16))) float sH[16][kRS];  // h = modulate(LN1(..)): A operand of fc1 and residual of fc2
+  __shared__ __attribute__((aligned(16))) float sU[16][kRS];  // relu(fc1(h)): A operand of fc2
+  __shared__ __attribute__((aligned(16))) float sY[16][kRS];  // pre-LayerNorm sums
+  const int lane = threadIdx.x & 63;
+  out_ffn_tile(A, (long long)blockIdx.x * 16, tokens, L, sH, sU, sY, nullptr, lane, threadIdx.x >> 6, lane & 15, lane >> 4);
+}
+
+// The tail of layer i and the head of layer i + 1 in one launch: k_out_ffn_mfma on a 16-token tile of ONE batch element, then
+// the q | k | v projections of the NEXT layer on the tile's fresh output, which never leaves the workgroup (one kernel boundary
+// and one round trip of the activations through memory less per layer).  grid (B * L16 / 16), 256 threads.
+__global__ __launch_bounds__(256) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, int L, int L16) {
+  __shared__ __attribute__((aligned(16))) float sH[16][kRS];
+  __shared__ __attribute__((aligned(16))) float sU[16][kRS];
+  __shared__ __attribute__((aligned(16))) float sY[16][kRS];
+  const int tpb = L16 / 16;
+  const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+  // rows of the tile beyond the batch element's L tokens are inert: the tile's token range ends at (b + 1) L
+  out_ffn_tile(A, (long long)b * L + l0, (long long)(b + 1) * L, L, sH, sU, sY, sU, lane, w, j, s);
   __syncthreads();
-  tile_layer_norm(sY, nullptr, out, t0, tokens, P2, eps2, false, sc, sh, lane, w);
+  float a[kKSteps];
+  lds_row_share(sU, j, s, a);
+  if (l0 + j >= L) {
+#pragma unroll
+    for (int i = 0; i < kKSteps; ++i) a[i] = 0.0f;
+  }
+  qkv_role_tile(a, 1, Q, b, l0, L, L16, w, j, s);
+  qkv_role_tile(a, 2, Q, b, l0, L, L16, w, j, s);
+  if (Q.ss != nullptr && l0 + j < L) modulate_share(Q.ss, b, s, a);
+  qkv_role_tile(a, 0, Q, b, l0, L, L16, w, j, s);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
@@ -470,7 +505,8 @@ int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const fl
   const int L16 = (L + 15) / 16 * 16;
   // roles: 7 = q | k | v (self-attention), 1 = q alone, 6 = k | v alone (a memory whose keys / values are cached)
   const int role0 = (roles & 1) ? 0 : 1, nroles = roles == 7 ? 3 : (roles == 1 ? 1 : 2);
-  hipLaunchKernelGGL(k_qkv_heads, dim3(B * (L16 / 16), nroles), dim3(256), 0, s, x, ss, WqT, bq, WkvT, bkv, cs, sn, Qp, Kp, Vt, L, L16, role0);
+  QkvArgs Q{ss, WqT, bq, WkvT, bkv, cs, sn, Qp, Kp, Vt};
+  hipLaunchKernelGGL(k_qkv_heads, dim3(B * (L16 / 16), nroles), dim3(256), 0, s, x, Q, L, L16, role0);
   return 0;
 }
 
@@ -491,8 +527,20 @@ int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, co
                         const float* g2, const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s) {
   if (D != kD) return 1;
   const long long tokens = (long long)B * L;
-  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, att, res, WoT, bo, g1, be1, eps1, ss, W1T, b1,
-                     W2T, b2, g2, be2, eps2, out, L, tokens);
+  OutFfnArgs A{att, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2, eps1, eps2, out};
+  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, A, L, tokens);
+  return 0;
+}
+
+// args13: att, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2 (OutFfnArgs order); next7: ss, WqT, bq, WkvT, bkv, cs, sn
+int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp,
+                       float* Vt, int B, int L, int D, int H, hipStream_t s) {
+  if (D != kD || H != kH) return 1;
+  const int L16 = (L + 15) / 16 * 16;
+  OutFfnArgs A{args13[0], args13[1], args13[2], args13[3], args13[4], args13[5], args13[6], args13[7], args13[8], args13[9], args13[10],
+               args13[11], args13[12], eps1, eps2, out};
+  QkvArgs Q{next7[0], next7[1], next7[2], next7[3], next7[4], next7[5], next7[6], Qp, Kp, Vt};
+  hipLaunchKernelGGL(k_out_ffn_qkv, dim3(B * (L16 / 16)), dim3(256), 0, s, A, Q, L, L16);
   return 0;
 }
 

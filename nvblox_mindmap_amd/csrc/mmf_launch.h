@@ -133,6 +133,8 @@ int launch_attention_small(const float* q, const float* k, long long k_stride, c
 int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const float* bq, const float* WkvT, const float* bkv,
                      const float* cs, const float* sn, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H, int roles,
                      hipStream_t s);
+int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp,
+                       float* Vt, int B, int L, int D, int H, hipStream_t s);
 int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* out, int B, int Lq, int Lk,
                            int H, int dh, hipStream_t s);
 int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, const float* bo, const float* g1, const float* be1,

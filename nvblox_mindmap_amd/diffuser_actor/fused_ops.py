@@ -175,6 +175,7 @@ def out_ffn_block(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) 
 
 # ---- matrix-core forms (mmf_kernels_policy_mfma.hip): head-major q / k / v, attention over them, out_proj + LN + FFN ----------
 MFMA_DIMS = (120, 8)  # (embedding dim, heads) the MFMA kernels are built for
+FUSE_OUT_FFN_QKV = False  # (measured: no faster than the two launches at the policy shape) layer i's tail and layer i + 1's q | k | v in one launch (mmf_out_ffn_qkv)
 
 
 def _l16(n: int) -> int:
@@ -237,6 +238,31 @@ def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) -
                                            _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out), B, L, D,
                                            _lib.stream_ptr(att.device)), "mmf_out_ffn_mfma")
     return out
+
+
+def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, next_scale_shift, next_q_proj, next_kv_proj, rot, heads: int):
+    """``out_ffn_mfma`` of a layer and ``qkv_heads`` of the NEXT layer (on the result) in one launch.
+    Returns (out [B,L,D], q_heads, k_heads, v_heads_t)."""
+    import ctypes as Ct
+
+    att = att.contiguous()
+    residual = residual.contiguous()
+    B, L, D = att.shape
+    L16 = _l16(L)
+    dev = att.device
+    out = torch.empty_like(att)
+    q = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev)
+    k = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev)
+    v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev)
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    layer = [att, residual, _wt(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(scale_shift), _wt(fc1), _c(fc1.bias),
+             _wt(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+    nxt = [_c(next_scale_shift), _wt(next_q_proj), _c(next_q_proj.bias), _wt(next_kv_proj), _c(next_kv_proj.bias), cs, sn]
+    a13 = (Ct.c_void_p * 13)(*[None if t is None else t.data_ptr() for t in layer])
+    a7 = (Ct.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in nxt])
+    _lib.check(_lib.lib().mmf_out_ffn_qkv(Ct.cast(a13, Ct.c_void_p), float(norm1.eps), float(norm2.eps), _lib.dptr(out), Ct.cast(a7, Ct.c_void_p),
+                                          _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, _lib.stream_ptr(dev)), "mmf_out_ffn_qkv")
+    return out, q, k, v
 
 
 # ---- head and tail of a denoising step (mmf_kernels_policy_head.hip) -----------------------------------------------------------

@@ -261,15 +261,26 @@ class AttentionStack(nn.Module):
                     return None
                 return cond_act.lookup(adaln) if isinstance(cond_act, AdaLNBatch) else adaln.proj(F.silu(cond) if cond_act is None else cond_act)
 
+            if self.self_attention and (query.shape[-1], self.attn[0].attn.heads) == FO.MFMA_DIMS:
+                # matrix-core forms, two launches per layer: attention | (out_proj + LN + FFN of this layer + q/k/v of the next)
+                L_, n = query.shape[1], len(self.attn)
+                A0 = self.attn[0].attn
+                qh, kh, vt = FO.qkv_heads(query, ss_of(self.attn[0].adaln), A0.q_proj, A0.kv_proj, q_rot, A0.heads)
+                for li, (blk, ffw) in enumerate(zip(self.attn, self.ffw)):
+                    A = blk.attn
+                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, L_, L_, key_padding_mask16)
+                    if li + 1 < n and FO.FUSE_OUT_FFN_QKV:
+                        nb = self.attn[li + 1]
+                        query, qh, kh, vt = FO.out_ffn_qkv(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm,
+                                                           ss_of(nb.adaln), nb.attn.q_proj, nb.attn.kv_proj, q_rot, A.heads)
+                    else:
+                        query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
+                        if li + 1 < n:
+                            nb = self.attn[li + 1]
+                            qh, kh, vt = FO.qkv_heads(query, ss_of(nb.adaln), nb.attn.q_proj, nb.attn.kv_proj, q_rot, A.heads)
+                return query, None
             for li, (blk, ffw) in enumerate(zip(self.attn, self.ffw)):
                 A = blk.attn
-                if self.self_attention and (query.shape[-1], A.heads) == FO.MFMA_DIMS:
-                    # matrix-core forms: head-major q / k / v -> attention -> out_proj + LN + FFN
-                    L_ = query.shape[1]
-                    qh, kh, vt = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot, A.heads)
-                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, L_, L_, key_padding_mask16)
-                    query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
-                    continue
                 if (not self.self_attention and kv_caches is not None and len(kv_caches[li]) == 3
                         and (query.shape[-1], A.heads) == FO.MFMA_DIMS):
                     # cross-attention over a context whose head-major keys / values were cached (project_kv_heads)

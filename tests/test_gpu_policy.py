@@ -329,6 +329,11 @@ def test_mfma_layer_kernels_match_the_channel_kernels(B, L):
             ref = FO.out_ffn_block(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
             got = FO.out_ffn_mfma(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
             close(got, ref, "out_ffn")
+            # ... and with the next layer's q | k | v in the same launch: identical to the two launches
+            for nss, r in ((ss1, rot), (None, None)):
+                out2, q2, k2, v2 = FO.out_ffn_qkv(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm, nss, A.q_proj, A.kv_proj, r, H)
+                q3, k3, v3 = FO.qkv_heads(got, nss, A.q_proj, A.kv_proj, r, H)
+                assert torch.equal(out2, got) and torch.equal(q2, q3) and torch.equal(k2, k3) and torch.equal(v2, v3)
 
 
 @pytest.mark.parametrize("B,G", [(1, 2), (2, 1), (2, 3)])

@@ -7,7 +7,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_ddpm_step" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_head_outputs" in r["Kernel_Name"] or "k_ddpm_step" in r["Kernel_Name"]]
 N = 50
 win = rows[idx[-N - 1] + 1: idx[-1] + 1]  # the last N denoising steps (graph replay)
 t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
