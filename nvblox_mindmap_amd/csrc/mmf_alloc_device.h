@@ -24,9 +24,12 @@ __device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
 // consecutive entries per thread, so a few thousand live blocks are one pass (the pass cost is the workgroup scan).
 // ERASE: also drop the dead blocks from the hash / dense table / slot keys here; false when the decay workgroup that
 // found the block already did (fused frame: decay_body<true>).  No-op when nothing was flagged.
-template <int NW, int IPT, bool ERASE>
+// DENSE: the layer is known to be indexed by its dense table (bounded workspace): the hash paths are compiled out.  These
+// bodies run in ONE workgroup, once, through a cold instruction cache -- their duration follows their code size.
+template <int NW, int IPT, bool ERASE, bool DENSE = false>
 __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict__ kill, int* any_kill, int* lds, int* carry) {
   static_assert(IPT % 4 == 0, "entries are fetched four at a time");
+  const bool dense = DENSE || L.dense != nullptr;
   constexpr int NT = 64 * NW;
   if (!*any_kill) return;
   const int n = L.ctr[0];
@@ -82,7 +85,7 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
       if (dead_q[q]) {
         L.free_stack[wd++] = slot[q];
         if (ERASE) {
-          hash_erase(L, L.slot_key[slot[q]]);  // tombstone; dropped at the next rebuild
+          if (!dense) hash_erase(L, L.slot_key[slot[q]]);  // tombstone; dropped at the next rebuild
           dense_set(L, L.slot_key[slot[q]], 0);
           L.slot_key[slot[q]] = kEmptyKey;
         }
@@ -100,7 +103,7 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
   const int n_live = carry[0];
   const int n_tomb = L.ctr[4] + (carry[1] - free0);
   // amortised rebuild: only when tombstones fill more than a quarter of the table
-  const bool rebuild = !L.dense && (unsigned)n_tomb * 4u > L.hmask + 1u;
+  const bool rebuild = !dense && (unsigned)n_tomb * 4u > L.hmask + 1u;
   __syncthreads();
   if (rebuild) {
     for (unsigned h = threadIdx.x; h <= L.hmask; h += NT) L.htab[h].key = kEmptyKey;
@@ -122,8 +125,12 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
 // Small cell counts (bounded workspaces: a few thousand cells): count + scan + emit fused into ONE launch
 // of one 1024-thread workgroup, 4096 cells per pass with a running carry.  Same candidate order, same
 // slot assignment as the three-kernel path.
+// MODE: the job's KeySrc mode when the launcher knows it (0 grid cells, 1 list cells), -1 = read it from the job.
+template <bool DENSE = false, int MODE = -1>
 __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx) {
   const LayerDev& L = J.L;
+  const bool dense = DENSE || L.dense != nullptr;
+  const int mode = MODE >= 0 ? MODE : J.ks.mode;
   const KeySrc& ks = J.ks;
   const Scratch& sc = J.sc;
   const int stat_upd = J.stat_upd, stat_new = J.stat_new;
@@ -131,11 +138,11 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
   if (J.timeline && threadIdx.x == 0) J.timeline[0] = wall_clock64();
   if (J.kill) {  // a decay pass ran in the previous launch (and already erased its dead blocks from the index): compact
                  // the live list / push the freed slots before allocating (slot reuse order is spec)
-    live_compact_body<16, 4, false>(L, J.kill, J.any_kill, lds, carry);
+    live_compact_body<16, 4, false, DENSE>(L, J.kill, J.any_kill, lds, carry);
     __syncthreads();
   }
   if (J.timeline && threadIdx.x == 0) J.timeline[1] = wall_clock64();
-  if (ks.mode == 1) {  // list cells: only the producer's live positions carry meaningful flags
+  if (mode == 1) {  // list cells: only the producer's live positions carry meaningful flags
     const int nl = *ks.n_live;
     ncells = ncells < nl ? ncells : nl;
   }
@@ -164,7 +171,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
       // Every load of this pass is issued before the first one is consumed.  Grid cells have computable keys,
       // so their table entries are fetched without waiting for the flags; list cells read key + flag together
       // and look the flagged ones up in a second round.
-      if (ks.mode == 0) {
+      if (mode == 0) {
         unsigned h4[4] = {0, 0, 0, 0};
         uint4 e4[4];
         int d4[4] = {0, 0, 0, 0};
@@ -173,7 +180,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
           e4[k] = make_uint4(0, 0, 0, 0);
           if (cell0 + k < ncells) {
             key4[k] = grid_cell_key(ks, cell0 + k);
-            if (L.dense) {
+            if (dense) {
               int x, y, z;
               unpack_key(key4[k], x, y, z);
               d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
@@ -186,7 +193,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if ((f4 >> (8 * k)) & 0xffu) {
-            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
+            slot4[k] = dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
             nf++;
             nn += slot4[k] < 0;
           }
@@ -202,7 +209,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
         for (int k = 0; k < 4; ++k) {
           e4[k] = make_uint4(0, 0, 0, 0);
           if ((f4 >> (8 * k)) & 0xffu) {
-            if (L.dense) {
+            if (dense) {
               int x, y, z;
               unpack_key(key4[k], x, y, z);
               d4[k] = (int)L.dense[dense_cell(L, x, y, z)];
@@ -215,7 +222,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if ((f4 >> (8 * k)) & 0xffu) {
-            slot4[k] = L.dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
+            slot4[k] = dense ? d4[k] - 1 : hash_resolve(L, key4[k], h4[k], e4[k]);
             nf++;
             nn += slot4[k] < 0;
           }
@@ -237,7 +244,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
         if (is_new) {
           if (rnk < room) {
             slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
-            hash_insert(L, key4[k], slot);
+            if (!dense) hash_insert(L, key4[k], slot);
             dense_set(L, key4[k], slot + 1);
             L.slot_key[slot] = key4[k];
             L.live[old_live + rnk] = slot;
@@ -250,7 +257,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
         if (J.stamp && slot >= 0) L.stamp[slot] = (J.stamp << 1) | (is_new ? 1 : 0);
         pos++;
       }
-      if (ks.mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
+      if (mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
 // Horizontal fusion: the sphere trace (reads the TSDF layer) and the block allocation of the colour and the feature layer
 // (touch only their own hash / lists; inputs = the candidate flags) are independent once the TSDF update and the candidate
 // selection are done.  Workgroups [0, njobs) run one allocation job each, the others four ray patches each.
+template <bool DENSE, int MODE>
 __global__ __launch_bounds__(1024) void k_sphere_alloc(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
                                                       int Ws, int Hs, int patches_x, int n_patches, AllocJob J0, AllocJob J1,
                                                       int njobs, long long* stats) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_sphere_alloc(LayerDev T, MapConsts mc,
   __shared__ int carry[2];
   __shared__ int ctx[4];
   if ((int)blockIdx.x < njobs) {
-    alloc_job_body(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
+    alloc_job_body<DENSE, MODE>(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
     return;
   }
   const int patch = ((int)blockIdx.x - njobs) * 4 + (int)(threadIdx.x >> 8);
@@ -748,8 +749,13 @@ void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
                          const AllocJob* jobs, int njobs, long long* stats, hipStream_t s) {
   const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
   const int n = patches_x * patches_y;
-  hipLaunchKernelGGL(k_sphere_alloc, dim3(njobs + (n + 3) / 4), dim3(1024), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n,
-                     jobs[0], jobs[njobs > 1 ? 1 : 0], njobs, stats);
+  const AllocJob& j1 = jobs[njobs > 1 ? 1 : 0];
+  if (jobs[0].L.dense && j1.L.dense && jobs[0].ks.mode == 1 && j1.ks.mode == 1)  // bounded workspace, list cells: no hash paths
+    hipLaunchKernelGGL((k_sphere_alloc<true, 1>), dim3(njobs + (n + 3) / 4), dim3(1024), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x,
+                       n, jobs[0], j1, njobs, stats);
+  else
+    hipLaunchKernelGGL((k_sphere_alloc<false, -1>), dim3(njobs + (n + 3) / 4), dim3(1024), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x,
+                       n, jobs[0], j1, njobs, stats);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,

@@ -337,15 +337,18 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
 
 
 // alloc_job_body (count + scan + emit of a small cell set in one 1024-thread workgroup): mmf_alloc_device.h
+template <bool DENSE>
 __global__ __launch_bounds__(1024) void k_alloc_fused(AllocJob J, long long* stats) {
   __shared__ int lds[34];
   __shared__ int carry[2];
   __shared__ int ctx[4];
-  alloc_job_body(J, stats, lds, carry, ctx);
+  alloc_job_body<DENSE>(J, stats, lds, carry, ctx);
 }
 
 // Horizontal fusion: up to two allocation jobs (one workgroup each) and the column pass of the frame's mask job
 // (one workgroup per output row) in ONE launch.  The roles are independent; this only removes launch boundaries.
+// TWO = false: a single job (J1 is ignored: half the kernel arguments to keep in scalar registers).
+template <bool DENSE, int MODE, bool TWO>
 __global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, int njobs, long long* stats, MaskJob M,
                                                     int mask_rows) {
   __shared__ int lds[34];
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, i
   __shared__ int ctx[4];
   __shared__ u64 s_bad[kMaxMaskWords];
   if ((int)blockIdx.x < njobs) {
-    alloc_job_body(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
+    alloc_job_body<DENSE, MODE>((!TWO || blockIdx.x == 0) ? J0 : J1, stats, lds, carry, ctx);
   } else if ((int)blockIdx.x - njobs < mask_rows) {
     const long long t0 = J0.timeline ? wall_clock64() : 0;
     mask_colemit_row(M, (int)blockIdx.x - njobs, s_bad);
@@ -764,7 +767,10 @@ static AllocJob make_alloc_job(const LayerDev& L, const KeySrc& ks, const Scratc
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s) {
   if (ncells <= kFusedAllocMaxCells) {
-    hipLaunchKernelGGL(k_alloc_fused, dim3(1), dim3(1024), 0, s, make_alloc_job(L, ks, sc, ncells, stat_upd, stat_new), stats);
+    if (L.dense)
+      hipLaunchKernelGGL(k_alloc_fused<true>, dim3(1), dim3(1024), 0, s, make_alloc_job(L, ks, sc, ncells, stat_upd, stat_new), stats);
+    else
+      hipLaunchKernelGGL(k_alloc_fused<false>, dim3(1), dim3(1024), 0, s, make_alloc_job(L, ks, sc, ncells, stat_upd, stat_new), stats);
     return;
   }
   int ntiles = (ncells + 1023) / 1024;
@@ -784,7 +790,14 @@ void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const 
     mj = *M;
     rows = M->Hf;
   }
-  hipLaunchKernelGGL(k_alloc_jobs, dim3(njobs + rows), dim3(1024), 0, s, jobs[0], jobs[njobs > 1 ? 1 : 0], njobs, stats, mj, rows);
+  const AllocJob& j1 = jobs[njobs > 1 ? 1 : 0];
+  const bool dense = jobs[0].L.dense && j1.L.dense;  // bounded workspace: the specialisations without the hash paths
+  if (dense && njobs == 1 && jobs[0].ks.mode == 0)  // the TSDF allocation of the fused frame
+    hipLaunchKernelGGL((k_alloc_jobs<true, 0, false>), dim3(njobs + rows), dim3(1024), 0, s, jobs[0], j1, njobs, stats, mj, rows);
+  else if (dense)
+    hipLaunchKernelGGL((k_alloc_jobs<true, -1, true>), dim3(njobs + rows), dim3(1024), 0, s, jobs[0], j1, njobs, stats, mj, rows);
+  else
+    hipLaunchKernelGGL((k_alloc_jobs<false, -1, true>), dim3(njobs + rows), dim3(1024), 0, s, jobs[0], j1, njobs, stats, mj, rows);
 }
 
 // Grid size from the last count the device published to pinned host memory (stale by a frame or two, which is
