@@ -366,6 +366,12 @@ int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
  * over the mask column workgroups that share the launch: latest end [6], earliest start [7], longest duration [8],
  * latest start [9].  Synchronises. */
 int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out10);
+/* Diagnostics: per-workgroup timeline of the fused frame kernels.  buffer_dev: uint64 [3 * capacity_records] on the device
+ * (capacity_records >= 6 * 8192; the caller zeroes it), records {role id, start, end} in 100 MHz ticks at slot
+ * (role id / 10 - 1) * 8192 + workgroup index; null = off (the default).
+ * Role ids: 10 raycast, 11 mask rows, 12 decay (k_front); 20 allocation, 21 mask columns (k_alloc_jobs); 30 k_tsdf_pass;
+ * 40 allocation, 41 sphere trace (k_sphere_alloc); 50 k_app_frame; 60 k_feature_flat.  tools/wg_trace.py prints it. */
+int mmf_debug_wg_trace(uint64_t* buffer_dev, int capacity_records);
 
 /* Kernel timing with HIP events on the launch stream.  kernel ids: */
 #define MMF_K_RAYCAST 0

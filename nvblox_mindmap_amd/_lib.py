@@ -11,7 +11,9 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
+# MMF_LIB=<file name> selects another build in the package directory (e.g. libmmfusion_trace.so: the library with the
+# per-workgroup timeline hooks, `make -C csrc WG_TRACE=1 OUT=../libmmfusion_trace.so BUILD=_build_trace`)
+LIB_PATH = os.path.join(_HERE, os.environ.get("MMF_LIB", "libmmfusion.so"))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 MMF_LAYER_TSDF, MMF_LAYER_COLOR, MMF_LAYER_FEATURE = 0, 1, 2
@@ -125,6 +127,7 @@ SIGNATURES = {
     "mmf_step_tail": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                            C.c_longlong, _I, _VP]),
     "mmf_out_ffn_qkv": (_I, [_VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "mmf_debug_wg_trace": (_I, [_VP, _I]),
     "mmf_ffn_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP]),
     "mmf_q_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_kv_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),

@@ -31,14 +31,30 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
   static_assert(IPT % 4 == 0, "entries are fetched four at a time");
   const bool dense = DENSE || L.dense != nullptr;
   constexpr int NT = 64 * NW;
-  if (!*any_kill) return;
+  // One memory round trip instead of three: the flag, the two counters and the thread's entries of the first pass (the
+  // only pass for up to NT * IPT live blocks) are requested together, the entries from clamped -- always valid --
+  // positions, before any of them is looked at.
+  const int pending = *any_kill;
   const int n = L.ctr[0];
+  const int free0 = L.ctr[1];
+  int4 pre_v[IPT / 4];
+  uint32_t pre_k[IPT / 4];
+  {
+    const int last4 = (L.cap & ~3) - 4;
+#pragma unroll
+    for (int g = 0; g < IPT; g += 4) {
+      int p = (int)threadIdx.x * IPT + g;
+      p = p < last4 ? p : last4;
+      pre_v[g / 4] = *reinterpret_cast<const int4*>(L.live + p);
+      pre_k[g / 4] = *reinterpret_cast<const uint32_t*>(kill + p);
+    }
+  }
+  if (!pending) return;
   if (threadIdx.x == 0) {
-    carry[0] = 0;          // survivors written so far
-    carry[1] = L.ctr[1];   // free stack size
+    carry[0] = 0;      // survivors written so far
+    carry[1] = free0;  // free stack size
   }
   __syncthreads();
-  const int free0 = carry[1];
   for (int base = 0; base < n; base += NT * IPT) {
     const int i0 = base + (int)threadIdx.x * IPT;
     int slot[IPT];
@@ -49,9 +65,10 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
       unsigned k4 = 0;
       int s4[4] = {-1, -1, -1, -1};
       if (i0 + g + 3 < n) {
-        const int4 v = *reinterpret_cast<const int4*>(L.live + i0 + g);
+        // (i0 + g + 3 < n <= cap: the clamp above did not move a prefetched position of the first pass)
+        const int4 v = base == 0 ? pre_v[g / 4] : *reinterpret_cast<const int4*>(L.live + i0 + g);
         s4[0] = v.x, s4[1] = v.y, s4[2] = v.z, s4[3] = v.w;
-        k4 = *reinterpret_cast<const uint32_t*>(kill + i0 + g);
+        k4 = base == 0 ? pre_k[g / 4] : *reinterpret_cast<const uint32_t*>(kill + i0 + g);
         if (k4) *reinterpret_cast<uint32_t*>(kill + i0 + g) = 0u;
       } else {
 #pragma unroll

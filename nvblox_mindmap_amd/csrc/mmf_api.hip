@@ -1490,6 +1490,17 @@ int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, f
   return check_launch();
 }
 
+int mmf_debug_wg_trace(uint64_t* buffer_dev, int capacity_records) {
+  // buffer: {id, start, end} triples in 100 MHz ticks at slot (id / 10 - 1) * 8192 + workgroup index (zero it before the frame of
+  // interest); null switches the trace off.  Synchronises the device (symbol copies).
+  if (buffer_dev && capacity_records <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_debug_wg_trace");
+  const int r0 = set_wg_trace_map(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
+  const int r1 = set_wg_trace_app(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
+  if (r0 == 2 || r1 == 2) return fail(MMF_ERR_INVALID_ARG, "mmf_debug_wg_trace: this library was built without the hooks (make WG_TRACE=1)");
+  if (r0 != 0 || r1 != 0) return fail(MMF_ERR_HIP, "mmf_debug_wg_trace: hipMemcpyToSymbol failed");
+  return MMF_OK;
+}
+
 int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)

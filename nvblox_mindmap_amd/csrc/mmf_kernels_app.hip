@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 
 #include "mmf_launch.h"
+#include "mmf_trace_device.h"
 #include "mmf_alloc_device.h"
 
 namespace mmf {
@@ -65,7 +66,8 @@ constexpr int kRayLanes = 16;
 
 // One 4x4 ray patch = 256 threads (4 whole waves; no LDS, no barriers: the body may share a workgroup with other roles).
 __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C,
-                                    float* __restrict__ synth, int Ws, int Hs, int patches_x, int patch, int tid) {
+                                    float* __restrict__ synth, int Ws, int Hs, int patches_x, int patch, int tid,
+                                    int* trace_iters = nullptr) {
   const int k = tid & (kRayLanes - 1);          // sample lane within the ray group
   const int rl = tid >> 4;                      // ray within the 4x4 patch
   const int gshift = (tid & 63) & ~(kRayLanes - 1);  // first lane of this group inside its wave
@@ -115,35 +117,110 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
       ++i;
     }
 
-  while (!done) {
-    // this lane's sample: the march position after k further trunc-steps
-    float tk = t;
-    for (int j = 0; j < k; ++j) tk += mc.trunc;
-    const float tk_next_guess = tk + mc.trunc;  // == lane k+1's tk
-    const float p0 = o[0] + tk * dL[0], p1 = o[1] + tk * dL[1], p2 = o[2] + tk * dL[2];
-    const int b0 = ifloor(p0 * mc.inv_bs), b1 = ifloor(p1 * mc.inv_bs), b2 = ifloor(p2 * mc.inv_bs);
-    bool valid = false;
-    float D = 0.0f;
-    if (in_workspace(mc, b0, b1, b2)) {  // blocks are only ever allocated inside the workspace bounds
-      const int slot = T.dense ? (int)T.dense[dense_cell(T, b0, b1, b2)] - 1 : hash_find(T, pack_key(b0, b1, b2));
+  // Two modes per ray (uniform over its 16 lanes).
+  // WIDE: lane k speculates the sample after k trunc-steps (free / unobserved space: 16 steps per memory round trip).
+  // NARROW: inside the truncation band every step is a distance read from the map and the next position depends on it,
+  // but the VOXELS the march can reach next are the ones the ray crosses just ahead: lane k fetches the voxel at t + k/2
+  // voxel sizes (lane 0: at t, the march's own sample), then the group marches through the fetched voxels without further
+  // loads -- each new position is looked up among the 16 probes by (block, voxel) identity; a position whose voxel was
+  // not fetched ends the round and the next one probes from there.  A round trip costs ~2 us under load whatever it
+  // carries, so the work per ray is its number of rounds: 3-4 wide + up to 14 one-step rounds became 3-4 + 1-2.
+  // Entered when a step came from the map (a positive distance other than trunc), left on the first plain trunc-step.
+  // Either mode consumes exactly the samples of the sequential march, at bitwise the same t.
+  struct Sample {
+    bool inws, exists, valid;
+    float D;
+    int b0, b1, b2, lin;
+  };
+  auto locate = [&](float tt, int& b0, int& b1, int& b2, int& lin) {  // block / voxel containing the ray point at tt
+    const float p0 = o[0] + tt * dL[0], p1 = o[1] + tt * dL[1], p2 = o[2] + tt * dL[2];
+    b0 = ifloor(p0 * mc.inv_bs), b1 = ifloor(p1 * mc.inv_bs), b2 = ifloor(p2 * mc.inv_bs);
+    int q0 = ifloor((p0 - (float)b0 * mc.bs) * mc.inv_v), q1 = ifloor((p1 - (float)b1 * mc.bs) * mc.inv_v),
+        q2 = ifloor((p2 - (float)b2 * mc.bs) * mc.inv_v);
+    q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
+    q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
+    q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
+    lin = (q0 * 8 + q1) * 8 + q2;
+    return in_workspace(mc, b0, b1, b2);  // blocks are only ever allocated inside the workspace bounds
+  };
+  auto sample = [&](float tt) {
+    Sample S;
+    S.exists = S.valid = false;
+    S.D = 0.0f;
+    S.inws = locate(tt, S.b0, S.b1, S.b2, S.lin);
+    if (S.inws) {
+      const int slot = T.dense ? (int)T.dense[dense_cell(T, S.b0, S.b1, S.b2)] - 1 : hash_find(T, pack_key(S.b0, S.b1, S.b2));
       if (slot >= 0) {
+        S.exists = true;
         if (T.block_free[slot]) {
-          valid = true;
-          D = mc.trunc;
+          S.valid = true;
+          S.D = mc.trunc;
         } else {
-          int q0 = ifloor((p0 - (float)b0 * mc.bs) * mc.inv_v), q1 = ifloor((p1 - (float)b1 * mc.bs) * mc.inv_v),
-              q2 = ifloor((p2 - (float)b2 * mc.bs) * mc.inv_v);
-          q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
-          q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
-          q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
-          const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)slot * kVPB + ((q0 * 8 + q1) * 8 + q2)];
+          const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)slot * kVPB + S.lin];
           if (dw.y > 1e-4f) {
-            valid = true;
-            D = dw.x;
+            S.valid = true;
+            S.D = dw.x;
           }
         }
       }
     }
+    return S;
+  };
+  bool narrow = false;
+#ifdef MMF_WG_TRACE
+  int n_wide = 0, n_narrow = 0;
+#endif
+  while (!done) {
+    if (narrow) {
+#ifdef MMF_WG_TRACE
+      ++n_narrow;
+#endif
+      const Sample S = sample(k == 0 ? t : t + (float)k * (0.5f * mc.v));
+      int hold = 0;  // the probe that holds the march's current sample (lane 0's at first); -1: a point outside the workspace
+      for (int step = 0; step < kRayLanes; ++step) {
+        const int src = gshift + (hold < 0 ? 0 : hold);
+        const bool v_valid = hold >= 0 && __shfl((int)S.valid, src, 64) != 0;
+        const float v_D = __shfl(S.D, src, 64);
+        if (!(i < mc.st_max_steps && t < mc.st_max_len) || !v_valid) {  // (last_pos holds in this mode: unobserved = failure)
+          done = true;
+          break;
+        }
+        if (v_D < mc.st_eps) {  // the surface, reached from a valid positive distance
+          t = t + v_D;
+          ok = true;
+          done = true;
+          break;
+        }
+        const float tn = t + v_D;
+        const bool plain = tn == t + mc.trunc;
+        t = tn;
+        ++i;
+        if (plain) {  // out of the band: speculate again
+          narrow = false;
+          break;
+        }
+        int n0, n1, n2, nlin;
+        if (!locate(t, n0, n1, n2, nlin)) {
+          hold = -1;
+          continue;
+        }
+        const bool mine = S.inws && S.b0 == n0 && S.b1 == n1 && S.b2 == n2 && (!S.exists || S.lin == nlin);
+        const unsigned match = (unsigned)((__ballot(mine) >> gshift) & 0xffffu);
+        if (match == 0u) break;  // not fetched: the next round probes from here
+        hold = __ffs(match) - 1;
+      }
+      continue;
+    }
+#ifdef MMF_WG_TRACE
+    ++n_wide;
+#endif
+    // this lane's sample: the march position after k further trunc-steps
+    float tk = t;
+    for (int j = 0; j < k; ++j) tk += mc.trunc;
+    const float tk_next_guess = tk + mc.trunc;  // == lane k+1's tk
+    const Sample S = sample(tk);
+    const bool valid = S.valid;
+    const float D = S.D;
     const bool pos = valid && !(D < mc.st_eps);  // a sample that sets "previous sample was a valid positive distance"
     const unsigned mpos = (unsigned)((__ballot(pos) >> gshift) & 0xffffu);
     const bool last_pos_k = last_pos || (mpos & ((1u << k) - 1u)) != 0u;
@@ -174,13 +251,20 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
         ok = true;
       }
       done = true;
-    } else {  // a positive distance other than trunc: resume the march from there
+    } else {  // a positive distance other than trunc: resume the march from there, through the fetched voxels ahead
       t = e_tnext;
       i += e + 1;
       last_pos = true;
+      narrow = true;
     }
   }
   if (k == 0) synth[idx] = ok ? t * dC[2] : -1.0f;
+#ifdef MMF_WG_TRACE
+  if (trace_iters) {
+    atomicMax(&trace_iters[0], n_wide);
+    atomicMax(&trace_iters[1], n_narrow);
+  }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
@@ -198,11 +282,21 @@ __global__ __launch_bounds__(1024) void k_sphere_alloc(LayerDev T, MapConsts mc,
   __shared__ int lds[34];
   __shared__ int carry[2];
   __shared__ int ctx[4];
+  const long long tr0 = wg_trace_begin();
   if ((int)blockIdx.x < njobs) {
     alloc_job_body<DENSE, MODE>(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
+    wg_trace_end(tr0, kTrSphereAlloc);
     return;
   }
   const int patch = ((int)blockIdx.x - njobs) * 4 + (int)(threadIdx.x >> 8);
+  if (wg_trace_on()) {  // diagnostics only: longest wide / narrow iteration counts of the workgroup ride in the record id
+    if (threadIdx.x < 2) lds[threadIdx.x] = 0;
+    __syncthreads();
+    if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x & 255, lds);
+    __syncthreads();
+    wg_trace_end(tr0, kTrSphereTrace + (lds[0] << 8) + (lds[1] << 20));
+    return;
+  }
   if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x & 255);
 }
 
@@ -544,6 +638,7 @@ __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, Fea
 // Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size.
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
+  const long long tr0 = wg_trace_begin();
   const int total = *A.flat.count;
   if (blockIdx.x == 0 && threadIdx.x == 0 && A.flat.hint) *A.flat.hint = total;
   const int vpw = 256 / lpv;
@@ -556,6 +651,7 @@ __global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, i
     const size_t row = (size_t)(r.x & 0x7fffffffu);  // slot * 512 + lin
     feature_voxel<LOW>(A, mc, pool + row * C, (r.x >> 31) != 0u, r.y, __uint_as_float(r.z), __uint_as_float(r.w), Wv, gl, lpv);
   }
+  wg_trace_end(tr0, kTrFeatureFlat);
 }
 
 template <bool LOW>
@@ -719,8 +815,12 @@ template <bool LOW>
 __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                   int Hs) {
   __shared__ FeatLds S;
+  const long long tr0 = wg_trace_begin();
   app_frame_body<LOW>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+  wg_trace_end(tr0, kTrAppFrame);
 }
+
+MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_app)
 
 // ------------------------------------------------------------------------------------------------
 // host launchers

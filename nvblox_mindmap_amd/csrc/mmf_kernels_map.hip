@@ -6,6 +6,7 @@
 // mindmap/mapping/helpers/nvblox_mapping_helpers.py:207-209 and
 // mindmap/mapping/isaaclab_nvblox_mapper.py:252-258.
 #include "mmf_launch.h"
+#include "mmf_trace_device.h"
 #include "mmf_alloc_device.h"
 #include "mmf_mask_device.h"
 
@@ -184,11 +185,14 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
   extern __shared__ unsigned s_words[];
   __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
   const int b = (int)blockIdx.x;
-  if (b < n_ray_wgs)
+  const long long tr0 = wg_trace_begin();
+  if (b < n_ray_wgs) {
     raycast_body<LDSFLAGS>(R, b, s_words);
-  else if (b < n_ray_wgs + M.H)
+    wg_trace_end(tr0, kTrFrontRay);
+  } else if (b < n_ray_wgs + M.H) {
     mask_rowbits_row(M, b - n_ray_wgs, s_in, s_d);
-  else
+    wg_trace_end(tr0, kTrFrontMaskRows);
+  } else {
     // A pending Mapper.decay(): touches only the TSDF layer, which neither other role reads.  Each workgroup also drops
     // the blocks it finds dead from the hash / dense table (in parallel, off the critical path); the order-preserving
     // compaction of the live list is the first thing the allocation workgroup of the next launch does.
@@ -196,6 +200,8 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     // full L2 write-back (339 us), atomics on one arrival counter serialise (69 us), and even with a two-level counter
     // the launch grew by 9 us while the next one shrank by 2.)
     decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
+    wg_trace_end(tr0, kTrFrontDecay);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,11 +361,14 @@ __global__ __launch_bounds__(1024) void k_alloc_jobs(AllocJob J0, AllocJob J1, i
   __shared__ int carry[2];
   __shared__ int ctx[4];
   __shared__ u64 s_bad[kMaxMaskWords];
+  const long long tr0 = wg_trace_begin();
   if ((int)blockIdx.x < njobs) {
     alloc_job_body<DENSE, MODE>((!TWO || blockIdx.x == 0) ? J0 : J1, stats, lds, carry, ctx);
+    wg_trace_end(tr0, kTrAllocJob);
   } else if ((int)blockIdx.x - njobs < mask_rows) {
     const long long t0 = J0.timeline ? wall_clock64() : 0;
     mask_colemit_row(M, (int)blockIdx.x - njobs, s_bad);
+    wg_trace_end(tr0, kTrAllocMaskCols);
     if (J0.timeline && threadIdx.x == 0) {  // diagnostics: earliest start / latest end over the mask workgroups
       const long long t1 = wall_clock64();
       atomicMin(reinterpret_cast<unsigned long long*>(J0.timeline + 7), (unsigned long long)t0);
@@ -482,6 +491,7 @@ __global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
                                                   u64* __restrict__ cell_key) {
   // 256 threads x 2 z-adjacent voxels (one 16-byte access): twice as many resident workgroups as thread-per-voxel and
   // two independent dependency chains per thread
+  const long long tr0 = wg_trace_begin();
   const int n = L.ctr[0];
   const int chunk = (n + 7) >> 3;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
@@ -539,7 +549,10 @@ __global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
       if (any) cell_key[i] = key;
     }
   }
+  wg_trace_end(tr0, kTrTsdfPass);
 }
+
+MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_map)
 
 // ------------------------------------------------------------------------------------------------
 // 4. Decay: W *= factor over every live TSDF block; blocks whose voxels all fell below the threshold

@@ -152,4 +152,8 @@ int launch_step_tail(const float* rot_seq, const float* pos_seq, long long seq_b
                      float* traj_out, const float* WeT, const float* be, const float* pos_table, const float* freq, float* tokens_out,
                      float* cos_out, float* sin_out, long long rot_batch_stride, hipStream_t s);
 
+// diagnostics: per-workgroup timeline buffer of the fused frame kernels (mmf_trace_device.h); one setter per translation unit
+int set_wg_trace_map(unsigned long long* buf, int cap);
+int set_wg_trace_app(unsigned long long* buf, int cap);
+
 }  // namespace mmf

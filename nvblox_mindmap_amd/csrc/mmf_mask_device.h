@@ -55,6 +55,46 @@ __device__ inline void mask_rowbits_row(const MaskJob& J, int y, u64* s_in, u64*
   }
   __syncthreads();
   // horizontal dilation: bit x of the result = OR of bits [x-k, x+k]
+  if (2 * J.nw <= 64 && J.k0 < 64 && J.k1 < 64) {
+    // Rows up to 2048 pixels: one lane of the first wave per word (both masks), neighbour words by wave shuffles, and the
+    // run [0, k] covered by DOUBLING -- r |= r << 1, << 2, << 4 ... then one last shift of k + 1 - covered -- in each
+    // direction: ~2 log2(k) multiword shifts instead of 2 k.  (The linear loop below was ~1 500 instructions on ONE wave of
+    // every row's workgroup: a quarter of the instruction issue of the whole k_front launch.)  Same bit set, exactly.
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const bool act = l < 2 * J.nw, second = l >= J.nw;
+      const int w = second ? l - J.nw : l;
+      const int k = second ? J.k1 : J.k0, kmax = J.k0 > J.k1 ? J.k0 : J.k1;
+      const u64 x = act ? (second ? s_d : s_in)[w] : 0ull;
+      const bool has_lo = act && w > 0, has_hi = act && w < J.nw - 1;
+      u64 up = x, dn = x;  // dilated towards higher / lower pixel indices
+      auto shift_up = [&](u64 v, int sft) {  // multiword v << sft, 0 < sft < 64
+        const u64 nb = __shfl_up(v, 1, 64);
+        return (v << sft) | ((has_lo ? nb : 0ull) >> (64 - sft));
+      };
+      auto shift_dn = [&](u64 v, int sft) {
+        const u64 nb = __shfl_down(v, 1, 64);
+        return (v >> sft) | ((has_hi ? nb : 0ull) << (64 - sft));
+      };
+      int cov = 1;  // shifts 0 .. cov - 1 are covered
+      for (int c = 1; 2 * c <= kmax + 1; c *= 2) {  // uniform trip count; lanes whose k is smaller sit steps out
+        const u64 a = shift_up(up, c), b = shift_dn(dn, c);
+        if (2 * c <= k + 1) {
+          up |= a;
+          dn |= b;
+          cov = 2 * c;
+        }
+      }
+      const int rest = k + 1 - cov;  // 0 <= rest <= cov
+      const u64 a = shift_up(up, rest > 0 ? rest : 1), b = shift_dn(dn, rest > 0 ? rest : 1);
+      if (rest > 0) {
+        up |= a;
+        dn |= b;
+      }
+      if (act) (second ? J.bits_d : J.bits_in)[(size_t)y * J.nw + w] = up | dn;
+    }
+    return;
+  }
   for (int j = threadIdx.x; j < 2 * J.nw; j += nt) {
     const bool second = j >= J.nw;
     const int w = second ? j - J.nw : j;

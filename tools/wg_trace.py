@@ -1,0 +1,66 @@
+"""Per-workgroup timeline of the fused frame kernels (mmf_debug_wg_trace): for every role of every launch of one frame, the
+first start, the last start, the last end and the mean / longest workgroup, relative to the frame's first record.
+Needs the instrumented build of the library (the default build compiles the hooks out).  On the GPU box:
+    make -C nvblox_mindmap_amd/csrc WG_TRACE=1 OUT=../libmmfusion_trace.so BUILD=_build_trace
+    MMF_LIB=libmmfusion_trace.so python tools/wg_trace.py [frames]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+from nvblox_mindmap_amd import _lib  # noqa: E402
+from nvblox_mindmap_amd import synthetic as S  # noqa: E402
+from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper  # noqa: E402
+from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg  # noqa: E402
+
+NAMES = {10: "k_front raycast", 11: "k_front mask rows", 12: "k_front decay", 20: "k_alloc_jobs allocation", 21: "k_alloc_jobs mask cols",
+         30: "k_tsdf_pass", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame", 60: "k_feature_flat"}
+
+
+def main():
+    nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    dev = torch.device("cuda", 0)
+    cfg = S.StreamConfig(hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    frames = B.build_stream(cfg, 40, 64, dev)
+    m = get_nvblox_mapper(mcfg, feature_channels=64)
+    for i in range(24):
+        B.step(m, mcfg, frames[i])
+    torch.cuda.synchronize()
+    cap = 6 * 8192
+    buf = torch.zeros(3 * cap, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().mmf_debug_wg_trace(_lib.dptr(buf), cap), "mmf_debug_wg_trace")
+    try:
+        for i in range(24, 24 + nframes):
+            buf.zero_()
+            torch.cuda.synchronize()
+            B.step(m, mcfg, frames[i])
+            torch.cuda.synchronize()
+            rec = buf.cpu().numpy().reshape(cap, 3)
+            rec = rec[rec[:, 0] != 0]
+            extra = rec[:, 0] >> 8
+            rec[:, 0] &= 0xff
+            tr = rec[:, 0] == 41
+            if tr.any():  # sphere trace: longest wide / narrow iteration counts per workgroup ride in the record id
+                wide, narrow, dur = extra[tr] & 0xfff, extra[tr] >> 12, (rec[tr, 2] - rec[tr, 1]) / 100.0
+                order = np.argsort(-dur)[:6]
+                print("  sphere trace, slowest workgroups (us, wide iterations, narrow iterations):",
+                      ", ".join(f"{dur[o]:.1f}/{wide[o]}/{narrow[o]}" for o in order),
+                      f"| mean iterations wide {wide.mean():.1f} narrow {narrow.mean():.1f}")
+            t0 = rec[:, 1].min()
+            print(f"frame {i}: {len(rec)} workgroup records, span {(rec[:, 2].max() - t0) / 100.0:.1f} us")
+            for rid in sorted(set(rec[:, 0].tolist()), key=lambda r: rec[rec[:, 0] == r, 1].min()):
+                r = rec[rec[:, 0] == rid]
+                st, en = (r[:, 1] - t0) / 100.0, (r[:, 2] - t0) / 100.0
+                d = en - st
+                print(f"  {NAMES.get(rid, rid):28s} n={len(r):5d}  first start {st.min():6.1f}  last start {st.max():6.1f}  last end {en.max():6.1f}"
+                      f"  mean wg {d.mean():5.2f}  longest wg {d.max():5.2f} us")
+    finally:
+        _lib.check(_lib.lib().mmf_debug_wg_trace(None, 0), "mmf_debug_wg_trace")
+
+
+if __name__ == "__main__":
+    main()
