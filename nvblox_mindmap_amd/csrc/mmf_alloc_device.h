@@ -143,7 +143,8 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
 // of one 1024-thread workgroup, 4096 cells per pass with a running carry.  Same candidate order, same
 // slot assignment as the three-kernel path.
 // MODE: the job's KeySrc mode when the launcher knows it (0 grid cells, 1 list cells), -1 = read it from the job.
-template <bool DENSE = false, int MODE = -1>
+// NW: waves of the calling workgroup (16 = the 1024-thread form; 4 when the job shares a launch of 256-thread workgroups).
+template <bool DENSE = false, int MODE = -1, int NW = 16>
 __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx) {
   const LayerDev& L = J.L;
   const bool dense = DENSE || L.dense != nullptr;
@@ -155,7 +156,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
   if (J.timeline && threadIdx.x == 0) J.timeline[0] = wall_clock64();
   if (J.kill) {  // a decay pass ran in the previous launch (and already erased its dead blocks from the index): compact
                  // the live list / push the freed slots before allocating (slot reuse order is spec)
-    live_compact_body<16, 4, false, DENSE>(L, J.kill, J.any_kill, lds, carry);
+    live_compact_body<NW, 64 / NW, false, DENSE>(L, J.kill, J.any_kill, lds, carry);  // 4096 entries per pass
     __syncthreads();
   }
   if (J.timeline && threadIdx.x == 0) J.timeline[1] = wall_clock64();
@@ -174,7 +175,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
   }
   // no barrier here: ctx / carry are first read after the barriers of the workgroup scan below, so the counter
   // round trip of thread 0 overlaps with everyone's table loads
-  for (int base = 0; base < ncells; base += 4096) {
+  for (int base = 0; base < ncells; base += 256 * NW) {  // 4 cells per thread
     const int cell0 = base + threadIdx.x * 4;
     uint32_t f4 = 0;
     if (cell0 < ncells) f4 = *reinterpret_cast<const uint32_t*>(sc.flags + cell0);
@@ -248,7 +249,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
     }
     if (J.timeline && threadIdx.x == 0) J.timeline[2] = wall_clock64();  // table loads consumed
     int ea, eb, ta, tb;
-    block_excl_scan2<16>(nf, nn, lds, ea, eb, ta, tb);
+    block_excl_scan2<NW>(nf, nn, lds, ea, eb, ta, tb);
     if (J.timeline && threadIdx.x == 0) J.timeline[3] = wall_clock64();  // scan done
     const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
     if (f4) {

@@ -274,30 +274,34 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
 
 // Horizontal fusion: the sphere trace (reads the TSDF layer) and the block allocation of the colour and the feature layer
 // (touch only their own hash / lists; inputs = the candidate flags) are independent once the TSDF update and the candidate
-// selection are done.  Workgroups [0, njobs) run one allocation job each, the others four ray patches each.
+// selection are done.  Workgroups [0, njobs) run one allocation job each, the others one 4x4 ray patch each.
+// 256-thread workgroups at <= 102 registers: five fit a compute unit, so all ~1 200 patches of a 640x480 frame are resident
+// at once.  (With four patches per 1 024-thread workgroup only 256 of the 300 workgroups fitted, and the 44 late ones -- each
+// as long as any other -- doubled the duration of the launch.)  The allocation jobs run in the 4-wave form: three passes
+// instead of one, still well inside the trace's shadow.
 template <bool DENSE, int MODE>
-__global__ __launch_bounds__(1024) void k_sphere_alloc(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
-                                                      int Ws, int Hs, int patches_x, int n_patches, AllocJob J0, AllocJob J1,
-                                                      int njobs, long long* stats) {
+__global__ __launch_bounds__(256, 5) void k_sphere_alloc(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
+                                                        int Ws, int Hs, int patches_x, int n_patches, AllocJob J0, AllocJob J1,
+                                                        int njobs, long long* stats) {
   __shared__ int lds[34];
   __shared__ int carry[2];
   __shared__ int ctx[4];
   const long long tr0 = wg_trace_begin();
   if ((int)blockIdx.x < njobs) {
-    alloc_job_body<DENSE, MODE>(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
+    alloc_job_body<DENSE, MODE, 4>(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
     wg_trace_end(tr0, kTrSphereAlloc);
     return;
   }
-  const int patch = ((int)blockIdx.x - njobs) * 4 + (int)(threadIdx.x >> 8);
+  const int patch = (int)blockIdx.x - njobs;
   if (wg_trace_on()) {  // diagnostics only: longest wide / narrow iteration counts of the workgroup ride in the record id
     if (threadIdx.x < 2) lds[threadIdx.x] = 0;
     __syncthreads();
-    if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x & 255, lds);
+    if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x, lds);
     __syncthreads();
     wg_trace_end(tr0, kTrSphereTrace + (lds[0] << 8) + (lds[1] << 20));
     return;
   }
-  if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x & 255);
+  if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -851,11 +855,11 @@ void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   const int n = patches_x * patches_y;
   const AllocJob& j1 = jobs[njobs > 1 ? 1 : 0];
   if (jobs[0].L.dense && j1.L.dense && jobs[0].ks.mode == 1 && j1.ks.mode == 1)  // bounded workspace, list cells: no hash paths
-    hipLaunchKernelGGL((k_sphere_alloc<true, 1>), dim3(njobs + (n + 3) / 4), dim3(1024), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x,
-                       n, jobs[0], j1, njobs, stats);
+    hipLaunchKernelGGL((k_sphere_alloc<true, 1>), dim3(njobs + n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n,
+                       jobs[0], j1, njobs, stats);
   else
-    hipLaunchKernelGGL((k_sphere_alloc<false, -1>), dim3(njobs + (n + 3) / 4), dim3(1024), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x,
-                       n, jobs[0], j1, njobs, stats);
+    hipLaunchKernelGGL((k_sphere_alloc<false, -1>), dim3(njobs + n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n,
+                       jobs[0], j1, njobs, stats);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
