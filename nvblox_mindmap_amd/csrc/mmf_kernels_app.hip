@@ -821,7 +821,16 @@ __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, 
   __shared__ FeatLds S;
   const long long tr0 = wg_trace_begin();
   app_frame_body<LOW>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+#ifdef MMF_WG_TRACE
+  {  // diagnostics: survivors of the (last) block and whether it was new ride in the record id
+    const int n = *Acol.sc.cand_count;
+    const int i = xcd_candidate((int)blockIdx.x, (n + 7) >> 3);
+    const int extra = (i < n) ? (S.n & 0x3ff) | ((Afeat.sc.cand_new[i] != 0) << 10) | ((Acol.sc.cand_new[i] != 0) << 11) : 0xfff;
+    wg_trace_end(tr0, kTrAppFrame + (extra << 8));
+  }
+#else
   wg_trace_end(tr0, kTrAppFrame);
+#endif
 }
 
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_app)

@@ -43,6 +43,19 @@ def main():
             rec = rec[rec[:, 0] != 0]
             extra = rec[:, 0] >> 8
             rec[:, 0] &= 0xff
+            ap = rec[:, 0] == 50
+            if ap.any():  # k_app_frame: survivors / new-block flags of the workgroup's block ride in the record id
+                ex, dur = extra[ap], (rec[ap, 2] - rec[ap, 1]) / 100.0
+                surv, fnew, cnew, idle = ex & 0x3ff, (ex >> 10) & 1, (ex >> 11) & 1, ex == 0xfff
+                order = np.argsort(-dur)[:8]
+                print("  k_app_frame, slowest workgroups (us / survivors / feature block new / colour block new):",
+                      ", ".join(f"{dur[o]:.1f}/{surv[o]}/{fnew[o]}/{cnew[o]}" for o in order))
+                for name, m in (("new feature blocks", (fnew == 1) & ~idle), ("old feature blocks", (fnew == 0) & ~idle), ("no block", idle)):
+                    if m.any():
+                        print(f"    {name}: n={int(m.sum())} mean {dur[m].mean():.2f} us, mean survivors {surv[m].mean():.0f}")
+                live = ~idle
+                if live.sum() > 10:
+                    print(f"    correlation(duration, survivors) = {np.corrcoef(dur[live], surv[live])[0, 1]:.2f}")
             tr = rec[:, 0] == 41
             if tr.any():  # sphere trace: longest wide / narrow iteration counts per workgroup ride in the record id
                 wide, narrow, dur = extra[tr] & 0xfff, extra[tr] >> 12, (rec[tr, 2] - rec[tr, 1]) / 100.0
