@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): bit-exact voxel-block indices / occupancy; TSDF 
 1e-5 abs.  Because both sides use the same float32 operation order without FMA contraction the values are
 in fact expected to be bit-identical; the tests assert the 1e-5 bar and report exactness.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -553,3 +555,18 @@ def test_pool_exhaustion_is_reported():
     m.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
     with pytest.raises(RuntimeError, match="pool exhausted"):
         m.tsdf_layer_view(0).num_allocated_blocks()
+
+
+def test_wg_trace_hooks_are_compiled_out_of_the_product_build():
+    """mmf_debug_wg_trace: the per-workgroup timeline exists in the instrumented build only (make WG_TRACE=1); the product
+    library refuses a buffer (and accepts switching the trace off)."""
+    import torch
+
+    from nvblox_mindmap_amd import _lib
+
+    if os.environ.get("MMF_LIB", "libmmfusion.so") != "libmmfusion.so":
+        pytest.skip("instrumented library selected")
+    buf = torch.zeros(3 * 6 * 8192, dtype=torch.int64, device="cuda")
+    with pytest.raises(RuntimeError, match="WG_TRACE"):
+        _lib.check(_lib.lib().mmf_debug_wg_trace(_lib.dptr(buf), 6 * 8192), "mmf_debug_wg_trace")
+    _lib.check(_lib.lib().mmf_debug_wg_trace(None, 0), "mmf_debug_wg_trace")
