@@ -225,12 +225,16 @@ def attention_heads(q_heads, k_heads, v_heads_t, key_padding_mask: Optional[torc
     return out
 
 
-def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) -> torch.Tensor:
-    """``out_ffn_block`` on the matrix cores (16-token tiles, three chained GEMMs)."""
+def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out_ffn_block`` on the matrix cores (16-token tiles, three chained GEMMs).  ``out``: a contiguous [B, L, D] float32
+    destination (e.g. the leading rows of a larger sequence buffer) instead of a fresh tensor."""
     att = att.contiguous()
     residual = residual.contiguous()
     B, L, D = att.shape
-    out = torch.empty_like(att)
+    if out is None:
+        out = torch.empty_like(att)
+    else:
+        assert out.shape == att.shape and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() != residual.data_ptr()
     ss = _c(scale_shift)
     _lib.check(_lib.lib().mmf_out_ffn_mfma(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_wt(out_proj)), _lib.dptr(_c(out_proj.bias)),
                                            _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)), float(norm1.eps), _lib.dptr(ss),

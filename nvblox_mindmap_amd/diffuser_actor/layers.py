@@ -245,8 +245,10 @@ class AttentionStack(nn.Module):
         self.ffw = nn.ModuleList([FeedForwardBlock(dim, dim, dropout, use_adaln) for _ in range(num_layers)])
 
     def forward(self, query, memory=None, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False,
-                cond_act=None, kv_caches=None, key_padding_mask16=None):
-        """key_padding_mask16: fused_ops.pad_mask16(key_padding_mask) if the caller keeps it (matrix-core attention path).
+                cond_act=None, kv_caches=None, key_padding_mask16=None, out_last=None):
+        """out_last: contiguous [B, L, D] destination of the last layer's output (matrix-core cross-attention path only; the
+        caller checks that the returned tensor is it).
+        key_padding_mask16: fused_ops.pad_mask16(key_padding_mask) if the caller keeps it (matrix-core attention path).
         cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
         is constant across calls (cross-attention at inference)."""
         weights = None
@@ -287,7 +289,8 @@ class AttentionStack(nn.Module):
                     kh, vt, Lk = kv_caches[li]
                     qh, _, _ = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, None, q_rot, A.heads, roles=1)
                     att = FO.attention_heads(qh, kh, vt, key_padding_mask, query.shape[1], Lk, key_padding_mask16)
-                    query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm)
+                    query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm,
+                                            out=out_last if li + 1 == len(self.attn) else None)
                     continue
                 if self.self_attention:
                     q, k, v = FO.qkv_block(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot)

@@ -287,10 +287,13 @@ class DiffusionHead(nn.Module):
         nt = tokens.shape[1]
         cond = P["history"]  # only its presence matters below: every AdaLN projection comes from `ada`
         traj_rot = (P["seq_cos"][:, :nt], P["seq_sin"][:, :nt])
-        tokens, _ = self.cross_attn(tokens, P["ctx_feats"], cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"], cond_act=ada,
-                                    kv_caches=P["cross_kv"], key_padding_mask16=P.get("ctx_pad16"))
         seq, seq_rot, pad, pad16 = P["seq"], (P["seq_cos"], P["seq_sin"]), P["seq_pad"], P.get("seq_pad16")
-        seq[:, :nt].copy_(tokens)
+        head_rows = seq[:, :nt]  # batch 1: a contiguous view -- the cross-attention stack's last launch writes it directly
+        tokens, _ = self.cross_attn(tokens, P["ctx_feats"], cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"], cond_act=ada,
+                                    kv_caches=P["cross_kv"], key_padding_mask16=P.get("ctx_pad16"),
+                                    out_last=head_rows if head_rows.is_contiguous() else None)
+        if tokens.data_ptr() != head_rows.data_ptr():
+            head_rows.copy_(tokens)
         seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
         # the two output stacks are independent: fork the rotation stack onto a second stream (parallel branches of the
         # captured HIP graph; concurrent small kernels in eager mode), join before the output heads
