@@ -280,6 +280,10 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  *   mmf_attention_heads  softmax(q k^T / sqrt(head_dim) + key padding) v over those layouts -> out [B, Lq, D]; key_padding: [B, Lk16]
  *                        bytes, 1 = ignore, the keys beyond Lk marked too (or null)
  *   mmf_out_ffn_mfma     same contract as mmf_out_ffn_block
+ *   mmf_qkv_heads2, mmf_out_ffn_mfma2   the same kernels for TWO independent stacks of identical shape in one launch (the
+ *                        rotation and the position stack of the diffusion head).  next14 / layer26: the next7 / layer13 arrays of
+ *                        mmf_out_ffn_qkv for stack 0 then stack 1; eps4 = {ln1, ln2} of stack 0 then stack 1 (HOST array);
+ *                        activations and outputs are stack-major ([2, B, ...]: mmf_attention_heads runs the pair as batch 2 B)
  *   mmf_out_ffn_qkv      mmf_out_ffn_mfma of layer i followed, in the same launch, by mmf_qkv_heads (roles 7) of layer i + 1 on
  *                        its output.  layer13 (HOST array of device pointers): att, residual, Wo, bo, ln1_weight, ln1_bias,
  *                        scale_shift (or null), W1, b1, W2, b2, ln2_weight, ln2_bias; next7: scale_shift of the next layer's
@@ -324,6 +328,9 @@ int mmf_step_tail(const float* rotation_seq_dev, const float* position_seq_dev, 
                   int D, void* stream);
 int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, float* out_dev, const float* const* next7,
                     float* q_heads_dev, float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
+int mmf_qkv_heads2(const float* x0_dev, const float* x1_dev, const float* const* next14, float* q_heads_dev, float* k_heads_dev,
+                   float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
+int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out_dev, int B, int L, int D, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

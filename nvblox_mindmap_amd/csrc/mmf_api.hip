@@ -1501,6 +1501,29 @@ int mmf_debug_wg_trace(uint64_t* buffer_dev, int capacity_records) {
   return MMF_OK;
 }
 
+int mmf_qkv_heads2(const float* x0, const float* x1, const float* const* next14, float* q_heads, float* k_heads, float* v_heads_t, int B,
+                   int L, int D, int H, void* stream) {
+  if (!x0 || !x1 || !next14 || !q_heads || !k_heads || !v_heads_t || B <= 0 || L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_qkv_heads2");
+  for (int st = 0; st < 2; ++st) {
+    const float* const* q = next14 + 7 * st;
+    if (!q[1] || !q[2] || !q[3] || !q[4] || ((q[5] == nullptr) != (q[6] == nullptr)))
+      return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_heads2: missing operand");
+  }
+  if (launch_qkv_heads2(x0, x1, next14, q_heads, k_heads, v_heads_t, B, L, D, H, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_heads2 is built for D = 120, H = 8");
+  return check_launch();
+}
+
+int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out, int B, int L, int D, void* stream) {
+  if (!layer26 || !eps4 || !out || B <= 0 || L <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_mfma2");
+  for (int i = 0; i < 26; ++i)
+    if (i % 13 != 6 && !layer26[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma2: missing operand");  // [6]: scale_shift, optional
+  if (launch_out_ffn_mfma2(layer26, eps4, out, B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma2 is built for D = 120");
+  return check_launch();
+}
+
 int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)

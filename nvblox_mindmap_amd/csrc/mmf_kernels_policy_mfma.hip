@@ -472,6 +472,37 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(OutFfnArgs A, int L, long 
   out_ffn_tile(A, (long long)blockIdx.x * 16, tokens, L, sH, sU, sY, nullptr, lane, threadIdx.x >> 6, lane & 15, lane >> 4);
 }
 
+// Two independent stacks of identical shape (the rotation and the position stack of the diffusion head) in ONE launch:
+// blockIdx.z / the upper half of blockIdx.x selects the stack's operands.  Activations and head-major outputs are stack-major
+// ([2, B, ...]), so the attention kernel sees the pair as a batch of 2 B.
+__global__ __launch_bounds__(256) void k_qkv_heads2(const float* __restrict__ x0, const float* __restrict__ x1, QkvArgs Q0, QkvArgs Q1,
+                                                   int L, int L16) {
+  const bool second = blockIdx.z != 0;
+  const float* x = second ? x1 : x0;
+  const QkvArgs& Q = second ? Q1 : Q0;
+  const int tpb = L16 / 16;
+  const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
+  const int role = (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+  float a[kKSteps];
+  const int tok = l0 + j;
+  const bool ok = tok < L;
+  load_row_share(x + ((size_t)b * L + min(tok, L - 1)) * kD, s, ok, a);
+  if (role == 0 && Q.ss != nullptr && ok) modulate_share(Q.ss, b, s, a);
+  qkv_role_tile(a, role, Q, b, l0, L, L16, w, j, s);
+}
+
+__global__ __launch_bounds__(256) void k_out_ffn_mfma2(OutFfnArgs A0, OutFfnArgs A1, int L, long long tokens, int tiles) {
+  __shared__ __attribute__((aligned(16))) float sH[16][kRS];
+  __shared__ __attribute__((aligned(16))) float sU[16][kRS];
+  __shared__ __attribute__((aligned(16))) float sY[16][kRS];
+  const bool second = (int)blockIdx.x >= tiles;
+  const OutFfnArgs& A = second ? A1 : A0;
+  const int lane = threadIdx.x & 63;
+  out_ffn_tile(A, (long long)((int)blockIdx.x - (second ? tiles : 0)) * 16, tokens, L, sH, sU, sY, nullptr, lane, threadIdx.x >> 6, lane & 15,
+               lane >> 4);
+}
+
 // The tail of layer i and the head of layer i + 1 in one launch: k_out_ffn_mfma on a 16-token tile of ONE batch element, then
 // the q | k | v projections of the NEXT layer on the tile's fresh output, which never leaves the workgroup (one kernel boundary
 // and one round trip of the activations through memory less per layer).  grid (B * L16 / 16), 256 threads.
@@ -507,6 +538,30 @@ int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const fl
   const int role0 = (roles & 1) ? 0 : 1, nroles = roles == 7 ? 3 : (roles == 1 ? 1 : 2);
   QkvArgs Q{ss, WqT, bq, WkvT, bkv, cs, sn, Qp, Kp, Vt};
   hipLaunchKernelGGL(k_qkv_heads, dim3(B * (L16 / 16), nroles), dim3(256), 0, s, x, Q, L, L16, role0);
+  return 0;
+}
+
+// q14: {ss, WqT, bq, WkvT, bkv, cs, sn} of stack 0 then of stack 1; Qp / Kp / Vt: stack-major [2, B, H, ...] outputs
+int launch_qkv_heads2(const float* x0, const float* x1, const float* const* q14, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H,
+                      hipStream_t s) {
+  if (D != kD || H != kH) return 1;
+  const int L16 = (L + 15) / 16 * 16;
+  const size_t half = (size_t)B * kH * L16 * 16;
+  QkvArgs Q0{q14[0], q14[1], q14[2], q14[3], q14[4], q14[5], q14[6], Qp, Kp, Vt};
+  QkvArgs Q1{q14[7], q14[8], q14[9], q14[10], q14[11], q14[12], q14[13], Qp + half, Kp + half, Vt + half};
+  hipLaunchKernelGGL(k_qkv_heads2, dim3(B * (L16 / 16), 3, 2), dim3(256), 0, s, x0, x1, Q0, Q1, L, L16);
+  return 0;
+}
+
+// a26: OutFfnArgs pointer fields (att .. be2) of stack 0 then of stack 1; out: stack-major [2, B, L, D]
+int launch_out_ffn_mfma2(const float* const* a26, const float* eps4, float* out, int B, int L, int D, hipStream_t s) {
+  if (D != kD) return 1;
+  const long long tokens = (long long)B * L;
+  const int tiles = (int)((tokens + 15) / 16);
+  OutFfnArgs A0{a26[0], a26[1], a26[2], a26[3], a26[4], a26[5], a26[6], a26[7], a26[8], a26[9], a26[10], a26[11], a26[12], eps4[0], eps4[1], out};
+  OutFfnArgs A1{a26[13], a26[14], a26[15], a26[16], a26[17], a26[18], a26[19], a26[20], a26[21], a26[22], a26[23], a26[24], a26[25], eps4[2],
+                eps4[3], out + tokens * kD};
+  hipLaunchKernelGGL(k_out_ffn_mfma2, dim3(2 * tiles), dim3(256), 0, s, A0, A1, L, tokens, tiles);
   return 0;
 }
 

@@ -269,6 +269,83 @@ def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, ne
     return out, q, k, v
 
 
+def _ptr_array(tensors):
+    import ctypes as Ct
+
+    arr = (Ct.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+    return Ct.cast(arr, Ct.c_void_p), arr
+
+
+def qkv_heads2(x0, x1, ss01, q_proj01, kv_proj01, rot, heads: int):
+    """``qkv_heads`` (roles 7) of TWO stacks in one launch: inputs x0 / x1 [B,L,D], per-stack (scale_shift, q_proj, kv_proj);
+    the rotary tables are shared.  Returns stack-major (q_heads, k_heads, v_heads_t) of leading dimension 2 B."""
+    x0, x1 = x0.contiguous(), x1.contiguous()
+    B, L, D = x0.shape
+    L16 = _l16(L)
+    dev = x0.device
+    q = torch.empty((2 * B, heads, L16, 16), dtype=torch.float32, device=dev)
+    k = torch.empty((2 * B, heads, L16, 16), dtype=torch.float32, device=dev)
+    v = torch.empty((2 * B, heads, 16, L16), dtype=torch.float32, device=dev)
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    ops = []
+    for st in range(2):
+        ops += [_c(ss01[st]), _wt(q_proj01[st]), _c(q_proj01[st].bias), _wt(kv_proj01[st]), _c(kv_proj01[st].bias), cs, sn]
+    ptr, _keep = _ptr_array(ops)
+    _lib.check(_lib.lib().mmf_qkv_heads2(_lib.dptr(x0), _lib.dptr(x1), ptr, _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads,
+                                         _lib.stream_ptr(dev)), "mmf_qkv_heads2")
+    return q, k, v
+
+
+def out_ffn_mfma2(att2, res0, res1, blocks01) -> torch.Tensor:
+    """``out_ffn_mfma`` of TWO stacks in one launch.  att2 [2B, L, D] stack-major attention output; res0 / res1 [B,L,D] the
+    stacks' residual inputs; blocks01[st] = (out_proj, norm1, scale_shift, fc1, fc2, norm2).  Returns [2B, L, D]."""
+    import ctypes as Ct
+
+    att2 = att2.contiguous()
+    res0, res1 = res0.contiguous(), res1.contiguous()
+    B2, L, D = att2.shape
+    B = B2 // 2
+    out = torch.empty_like(att2)
+    ops, eps = [], []
+    for st, res in enumerate((res0, res1)):
+        out_proj, norm1, ss, fc1, fc2, norm2 = blocks01[st]
+        ops += [att2[st * B:(st + 1) * B], res, _wt(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(ss), _wt(fc1),
+                _c(fc1.bias), _wt(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+        eps += [float(norm1.eps), float(norm2.eps)]
+    ptr, _keep = _ptr_array(ops)
+    e4 = (Ct.c_float * 4)(*eps)
+    _lib.check(_lib.lib().mmf_out_ffn_mfma2(ptr, Ct.cast(e4, Ct.c_void_p), _lib.dptr(out), B, L, D, _lib.stream_ptr(att2.device)),
+               "mmf_out_ffn_mfma2")
+    return out
+
+
+def paired_self_attention_stacks(stack0, stack1, x, ss_of, rot, key_padding_mask2_16, heads: int):
+    """Two self-attention AttentionStacks of identical shape on the same input x [B,L,D] (the rotation and position stacks
+    of the diffusion head), every layer's three launches shared between them.  ss_of(adaln) -> that block's (scale | shift)
+    [B, 2D] or None; key_padding_mask2_16: pad_mask16 of the key padding mask repeated for both stacks ([2B, L16]) or None.
+    Returns the two outputs [B,L,D]."""
+    B, L, D = x.shape
+    n = len(stack0.attn)
+    assert len(stack1.attn) == n and n > 0
+    x0 = x1 = x
+    A0, A1 = stack0.attn[0], stack1.attn[0]
+    qh, kh, vt = qkv_heads2(x0, x1, (ss_of(A0.adaln), ss_of(A1.adaln)), (A0.attn.q_proj, A1.attn.q_proj), (A0.attn.kv_proj, A1.attn.kv_proj),
+                            rot, heads)
+    for li in range(n):
+        blocks = []
+        for st in (stack0, stack1):
+            blk, ffw = st.attn[li], st.ffw[li]
+            blocks.append((blk.attn.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm))
+        att2 = attention_heads(qh, kh, vt, None, L, L, key_padding_mask2_16)
+        y2 = out_ffn_mfma2(att2, x0, x1, blocks)
+        x0, x1 = y2[:B], y2[B:]
+        if li + 1 < n:
+            N0, N1 = stack0.attn[li + 1], stack1.attn[li + 1]
+            qh, kh, vt = qkv_heads2(x0, x1, (ss_of(N0.adaln), ss_of(N1.adaln)), (N0.attn.q_proj, N1.attn.q_proj),
+                                    (N0.attn.kv_proj, N1.attn.kv_proj), rot, heads)
+    return x0, x1
+
+
 # ---- head and tail of a denoising step (mmf_kernels_policy_head.hip) -----------------------------------------------------------
 def step_prologue(trajectory, traj_encoder, pos_table, time_row, history, rot_freq, adaln_wt, adaln_bias, seq_cos, seq_sin):
     """One launch for everything in front of the first attention layer of a denoising step.  trajectory [B,L,G,9];

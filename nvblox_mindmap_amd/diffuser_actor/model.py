@@ -216,6 +216,7 @@ class DiffusionHead(nn.Module):
                     from .fused_ops import pad_mask16
 
                     P["seq_pad16"] = pad_mask16(P["seq_pad"])
+                    P["seq_pad16x2"] = torch.cat([P["seq_pad16"], P["seq_pad16"]], dim=0)  # rotation | position stacks as one batch
                 P["pos_table"] = sinusoidal_embedding(torch.arange(nt, device=dev), D)
                 third = D // 3
                 P["rot_freq"] = torch.exp(torch.arange(0, third, 2, device=dev, dtype=torch.float32) * (-math.log(10000.0) / third))
@@ -295,8 +296,18 @@ class DiffusionHead(nn.Module):
         if tokens.data_ptr() != head_rows.data_ptr():
             head_rows.copy_(tokens)
         seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
-        # the two output stacks are independent: fork the rotation stack onto a second stream (parallel branches of the
-        # captured HIP graph; concurrent small kernels in eager mode), join before the output heads
+        # the two output stacks are independent and of identical shape
+        from . import fused_ops as FO
+
+        ra, pa = self.rotation_attn, self.position_attn
+        if (P.get("seq_pad16x2") is not None and (seq.shape[-1], ra.attn[0].attn.heads) == FO.MFMA_DIMS and len(ra.attn) == len(pa.attn)
+                and ra.ffw[0].fc1.out_features == seq.shape[-1]):
+            # ... every layer's three launches serve both (stack-major activations, the attention kernel sees a batch of 2 B)
+            rot_seq, pos_seq = FO.paired_self_attention_stacks(ra, pa, seq, lambda adaln: None if adaln is None else ada.lookup(adaln),
+                                                               seq_rot, P["seq_pad16x2"], ra.attn[0].attn.heads)
+            return rot_seq.contiguous(), pos_seq.contiguous()
+        # otherwise: fork the rotation stack onto a second stream (parallel branches of the captured HIP graph; concurrent small
+        # kernels in eager mode), join before the output heads
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=seq.device)
         main, side = torch.cuda.current_stream(seq.device), self._side_stream

@@ -428,3 +428,35 @@ def test_mfma_cross_attention_over_a_long_context():
         qh, _, _ = FO.qkv_heads(x, ss, A.q_proj, None, q_rot, H, roles=1)
         got = FO.attention_heads(qh, kh, vt, pad, Lq, n)
     assert n == Lk and torch.allclose(got, ref, rtol=1e-4, atol=1e-5), float((got - ref).abs().max())
+
+
+def test_paired_stacks_equal_the_two_stacks_run_separately():
+    """mmf_qkv_heads2 / mmf_out_ffn_mfma2: two self-attention stacks sharing every launch give bit-identical results to the
+    same stacks run one after the other on the matrix-core kernels."""
+    from nvblox_mindmap_amd.diffuser_actor import fused_ops as FO
+    from nvblox_mindmap_amd.diffuser_actor import layers as Ly
+
+    torch.manual_seed(13)
+    D, H, B, L = 120, 8, 2, 77
+    stacks = [Ly.AttentionStack(D, H, 2, 0.0, use_adaln=True, self_attention=True).cuda().eval() for _ in range(2)]
+    for st in stacks:
+        for p in st.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+    x, cond = torch.randn(B, L, D, device="cuda"), torch.randn(B, D, device="cuda")
+    rot = Ly.rotary3d(torch.rand(B, L, 3, device="cuda"), D)
+    pad = torch.rand(B, L, device="cuda") < 0.2
+    pad[:, 0] = False
+    with torch.no_grad():
+        ada = Ly.AdaLNBatch([m for st in stacks for m in st.modules() if isinstance(m, Ly.AdaLN)]).compute(torch.nn.functional.silu(cond))
+        pad16 = FO.pad_mask16(pad)
+        Ly.FUSED_INFERENCE = True
+        try:
+            ref = [st(x, None, cond, rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)[0] for st in stacks]
+            got = FO.paired_self_attention_stacks(stacks[0], stacks[1], x, lambda a: None if a is None else ada.lookup(a), rot,
+                                                  torch.cat([pad16, pad16], dim=0), H)
+        finally:
+            Ly.FUSED_INFERENCE = False
+        composite = [st(x, None, cond, rot, key_padding_mask=pad)[0] for st in stacks]
+    for g, r, c in zip(got, ref, composite):
+        assert torch.equal(g, r)
+        assert torch.allclose(g, c, rtol=2e-4, atol=2e-5), float((g - c).abs().max())
