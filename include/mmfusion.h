@@ -280,6 +280,12 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  *   mmf_attention_heads  softmax(q k^T / sqrt(head_dim) + key padding) v over those layouts -> out [B, Lq, D]; key_padding: [B, Lk16]
  *                        bytes, 1 = ignore, the keys beyond Lk marked too (or null)
  *   mmf_out_ffn_mfma     same contract as mmf_out_ffn_block
+ *   mmf_attention_heads_split + mmf_out_ffn_mfma_partials   Lq <= 16 query rows over a long key axis (the trajectory tokens over
+ *                        the whole context): the keys are divided among n_split workgroups per (batch element, head), each leaves
+ *                        an un-normalised partial {O [16 channels][16 rows], maxima [16], sums [16]} in partials
+ *                        [B, H, n_split, 18, 16], and the following out-projection kernel merges them while it loads its input
+ *                        (no cross-workgroup merge, i.e. no device-scope fence, inside the attention kernel).  partials_dev null:
+ *                        only *n_split_out is set (size query)
  *   mmf_qkv_heads2, mmf_out_ffn_mfma2   the same kernels for TWO independent stacks of identical shape in one launch (the
  *                        rotation and the position stack of the diffusion head).  next14 / layer26: the next7 / layer13 arrays of
  *                        mmf_out_ffn_qkv for stack 0 then stack 1; eps4 = {ln1, ln2} of stack 0 then stack 1 (HOST array);
@@ -331,6 +337,12 @@ int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, f
 int mmf_qkv_heads2(const float* x0_dev, const float* x1_dev, const float* const* next14, float* q_heads_dev, float* k_heads_dev,
                    float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
 int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out_dev, int B, int L, int D, void* stream);
+int mmf_attention_heads_split(const float* q_heads_dev, const float* k_heads_dev, const float* v_heads_t_dev, const uint8_t* key_padding_dev,
+                              float* partials_dev, int B, int Lq, int Lk, int H, int head_dim, int* n_split_out, void* stream);
+int mmf_out_ffn_mfma_partials(const float* partials_dev, int n_split, const float* residual_dev, const float* Wo_dev, const float* bo_dev,
+                              const float* ln1_weight_dev, const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev,
+                              const float* W1_dev, const float* b1_dev, const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev,
+                              const float* ln2_bias_dev, float ln2_eps, float* out_dev, int B, int L, int D, void* stream);
 int mmf_ffn_block(const float* x_dev, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev,
                   const float* b2_dev, const float* ln_weight_dev, const float* ln_bias_dev, float ln_eps, float* out_dev, int B, int L,
                   int D, void* stream);

@@ -1524,6 +1524,33 @@ int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out
   return check_launch();
 }
 
+int mmf_attention_heads_split(const float* q_heads, const float* k_heads, const float* v_heads_t, const uint8_t* key_padding, float* partials,
+                              int B, int Lq, int Lk, int H, int head_dim, int* n_split_out, void* stream) {
+  if (!q_heads || !k_heads || !v_heads_t || !n_split_out || B <= 0 || Lq <= 0 || Lk <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_heads_split");
+  if (!partials) {  // size query: partials = float [B, H, n_split, 18, 16]
+    *n_split_out = 4;
+    return MMF_OK;
+  }
+  const int rc = launch_attention_heads_split(q_heads, k_heads, v_heads_t, key_padding, partials, B, Lq, Lk, H, head_dim, (hipStream_t)stream);
+  if (rc == 1) return fail(MMF_ERR_INVALID_ARG, "mmf_attention_heads_split is built for H = 8, head_dim = 15, Lq <= 16");
+  *n_split_out = rc >> 8;
+  return check_launch();
+}
+
+int mmf_out_ffn_mfma_partials(const float* partials, int n_split, const float* residual, const float* Wo, const float* bo,
+                              const float* ln1_weight, const float* ln1_bias, float ln1_eps, const float* scale_shift, const float* W1,
+                              const float* b1, const float* W2, const float* b2, const float* ln2_weight, const float* ln2_bias, float ln2_eps,
+                              float* out, int B, int L, int D, void* stream) {
+  if (!partials || !residual || !Wo || !bo || !ln1_weight || !ln1_bias || !W1 || !b1 || !W2 || !b2 || !ln2_weight || !ln2_bias || !out ||
+      B <= 0 || L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_mfma_partials");
+  if (launch_out_ffn_mfma_partials(partials, n_split, residual, Wo, bo, ln1_weight, ln1_bias, ln1_eps, scale_shift, W1, b1, W2, b2, ln2_weight,
+                                   ln2_bias, ln2_eps, out, B, L, D, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma_partials is built for D = 120, L <= 16");
+  return check_launch();
+}
+
 int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)

@@ -187,13 +187,20 @@ __global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, 
 
 // NW waves per workgroup share the keys of one (query tile, head): 4 for self-attention over a few hundred keys, 16 when a
 // handful of query rows attend to thousands of keys (the trajectory tokens over the full context).
-template <int NW, int CH>
+// SPLIT > 1 (one query tile per batch element, i.e. Lq <= 16): the keys are additionally divided among SPLIT WORKGROUPS, each
+// of which leaves an un-normalised partial result {O^T [16 channels][16 rows], running maximum [16], sum [16]} in `out`
+// ([B, H, SPLIT, 18, 16] floats) -- k_out_ffn_mfma merges them while it loads its input tile.  A cross-workgroup merge inside
+// this kernel would need a device-scope release per workgroup; the kernel boundary that follows anyway is free.
+constexpr int kPartRows = 18;  // rows of one partial: 16 channels of O^T, then the maxima, then the sums
+
+template <int NW, int CH, int SPLIT>
 __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __restrict__ Qp, const float* __restrict__ Kp,
                                                             const float* __restrict__ Vt, const uint8_t* __restrict__ pad,
                                                             float* __restrict__ out, int Lq, int Lq16, int Lk, int Lk16, float scale) {
   __shared__ float sM[NW][16], sL[NW][16];
   __shared__ float sO[NW][16][17];
-  const int q0 = (int)blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  const int split = SPLIT > 1 ? (int)blockIdx.x : 0;
+  const int q0 = SPLIT > 1 ? 0 : (int)blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
   const size_t bh = (size_t)b * kH + h;
 
@@ -209,13 +216,14 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
 
   float m_run = -INFINITY, l_run = 0.0f;
   f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f};  // O^T: rows = channel 4 s + r, column = query row j
-  const int ntiles = Lk16 / 16;
-  for (int tb = w; tb < ntiles; tb += NW * CH) {  // this wave's tiles: tb, tb + NW, ...
+  const int all_tiles = Lk16 / 16, per_split = (all_tiles + SPLIT - 1) / SPLIT;
+  const int t_begin = split * per_split, ntiles = min(t_begin + per_split, all_tiles);  // this workgroup's key tiles
+  for (int tb = t_begin + w; tb < ntiles; tb += NW * CH) {  // this wave's tiles: tb, tb + NW, ...
     float4 kv[CH], vv[CH];
     uint32_t pw[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int t = tb + NW * i, tc = min(t, ntiles - 1);  // tiles beyond the end: a valid tile's data, every key marked dead
+      const int t = tb + NW * i, tc = min(t, all_tiles - 1);  // tiles beyond the end: a valid tile's data, every key marked dead
       kv[i] = *reinterpret_cast<const float4*>(Kb + ((size_t)tc * 16 + j) * 16 + 4 * s);
       vv[i] = *reinterpret_cast<const float4*>(Vb + tc * 16 + 4 * s);
       uint32_t word = 0u;
@@ -292,13 +300,21 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
       l += f[u] * sL[u][j];
     }
     const int row = q0 + j;
+    float* part = out + (((size_t)b * kH + h) * SPLIT + split) * kPartRows * 16;  // SPLIT > 1 only
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ch = 4 * s + r;
       float o = 0.0f;
 #pragma unroll
       for (int u = 0; u < NW; ++u) o += f[u] * sO[u][ch][j];
-      if (ch < kDH && row < Lq) out[((size_t)b * Lq + row) * kD + h * kDH + ch] = o / l;
+      if (SPLIT > 1)
+        part[ch * 16 + j] = o;
+      else if (ch < kDH && row < Lq)
+        out[((size_t)b * Lq + row) * kD + h * kDH + ch] = o / l;
+    }
+    if (SPLIT > 1 && s == 0) {
+      part[16 * 16 + j] = M;
+      part[17 * 16 + j] = l;
     }
   }
 }
@@ -375,6 +391,11 @@ __device__ __forceinline__ void lds_row_share(const float (*src)[kRS], int j, in
   }
 }
 
+struct AttPartials {  // k_attention_heads<.., SPLIT > 1> output to merge instead of reading `att` (null: read att)
+  const float* part;  // [B, H, n_split, 18, 16]
+  int n_split, Lq;    // Lq <= 16 query rows per batch element
+};
+
 struct OutFfnArgs {
   const float *att, *res, *WoT, *bo, *g1, *be1, *ss, *W1T, *b1, *W2T, *b2, *g2, *be2;  // ss: AdaLN (scale | shift) of the FFN or null
   float eps1, eps2;
@@ -385,9 +406,36 @@ struct OutFfnArgs {
 // flattened [B L] token axis (`tokens` = B L; rows beyond it are inert); wave w owns output columns [32 w, 32 w + 32).
 // `keep`: where the result additionally stays in LDS (rows of invalid tokens zeroed) for a consumer in the same kernel.
 __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, long long tokens, int L, float (*sH)[kRS], float (*sU)[kRS],
-                                             float (*sY)[kRS], float (*keep)[kRS], int lane, int w, int j, int s) {
+                                             float (*sY)[kRS], float (*keep)[kRS], int lane, int w, int j, int s,
+                                             const AttPartials& AP = AttPartials{nullptr, 0, 0}) {
   float a[kKSteps], wv[2][kKSteps];
-  {
+  if (AP.part != nullptr) {
+    // the attention output of this tile, merged from the key splits: element (token, channel c = 15 h + ch) =
+    // sum_sp e^(m_sp - M) O_sp[ch][row] / sum_sp e^(m_sp - M) l_sp, M = max_sp m_sp
+    for (int e = threadIdx.x; e < 16 * 128; e += 256) {
+      const int tl = e >> 7, c = e & 127;
+      const long long tok = t0 + tl;
+      float v = 0.0f;
+      if (c < kD && tok < tokens) {
+        const int b = (int)(tok / AP.Lq), row = (int)(tok - (long long)b * AP.Lq), h = c / kDH, ch = c - h * kDH;
+        const float* P = AP.part + ((size_t)b * kH + h) * AP.n_split * kPartRows * 16;
+        float M = -INFINITY;
+        for (int sp = 0; sp < AP.n_split; ++sp) M = fmaxf(M, P[(sp * kPartRows + 16) * 16 + row]);
+        float num = 0.0f, den = 0.0f;
+        for (int sp = 0; sp < AP.n_split; ++sp) {
+          const float m = P[(sp * kPartRows + 16) * 16 + row];
+          const float f = (m == -INFINITY) ? 0.0f : __expf(m - M);
+          num += f * P[(sp * kPartRows + ch) * 16 + row];
+          den += f * P[(sp * kPartRows + 17) * 16 + row];
+        }
+        v = num / den;
+      }
+      sU[tl][c] = v;
+    }
+    __syncthreads();
+    lds_row_share(sU, j, s, a);
+    __syncthreads();  // sU is reused below
+  } else {
     const long long tok = t0 + j;
     load_row_share(A.att + min(tok, tokens - 1) * kD, s, tok < tokens, a);
   }
@@ -464,12 +512,12 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
 }
 
 // grid = 16-token tiles of the flattened [B L] token axis
-__global__ __launch_bounds__(256) void k_out_ffn_mfma(OutFfnArgs A, int L, long long tokens) {
+__global__ __launch_bounds__(256) void k_out_ffn_mfma(OutFfnArgs A, int L, long long tokens, AttPartials AP) {
   __shared__ __attribute__((aligned(16))) float sH[16][kRS];  // h = modulate(LN1(..)): A operand of fc1 and residual of fc2
   __shared__ __attribute__((aligned(16))) float sU[16][kRS];  // relu(fc1(h)): A operand of fc2
   __shared__ __attribute__((aligned(16))) float sY[16][kRS];  // pre-LayerNorm sums
   const int lane = threadIdx.x & 63;
-  out_ffn_tile(A, (long long)blockIdx.x * 16, tokens, L, sH, sU, sY, nullptr, lane, threadIdx.x >> 6, lane & 15, lane >> 4);
+  out_ffn_tile(A, (long long)blockIdx.x * 16, tokens, L, sH, sU, sY, nullptr, lane, threadIdx.x >> 6, lane & 15, lane >> 4, AP);
 }
 
 // Two independent stacks of identical shape (the rotation and the position stack of the diffusion head) in ONE launch:
@@ -571,10 +619,21 @@ int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, co
   const int Lq16 = (Lq + 15) / 16 * 16, Lk16 = (Lk + 15) / 16 * 16;
   const float scale = 1.0f / sqrtf((float)dh);
   if (Lk16 / 16 > 80 && Lq16 / 16 * H * B < 128)  // long key axis, few workgroups: spread the keys over 16 waves
-    hipLaunchKernelGGL((k_attention_heads<16, 6>), dim3(Lq16 / 16, H, B), dim3(1024), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+    hipLaunchKernelGGL((k_attention_heads<16, 6, 1>), dim3(Lq16 / 16, H, B), dim3(1024), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
   else
-    hipLaunchKernelGGL((k_attention_heads<4, 10>), dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+    hipLaunchKernelGGL((k_attention_heads<4, 10, 1>), dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
   return 0;
+}
+
+// Lq <= 16 query rows over a long key axis: kAttSplit workgroups of 16 waves per (batch element, head), partial results out
+constexpr int kAttSplit = 4;
+int launch_attention_heads_split(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* partials, int B, int Lq, int Lk,
+                                 int H, int dh, hipStream_t s) {
+  if (H != kH || dh != kDH || Lq > 16) return 1;
+  const int Lk16 = (Lk + 15) / 16 * 16;
+  hipLaunchKernelGGL((k_attention_heads<16, 3, kAttSplit>), dim3(kAttSplit, H, B), dim3(1024), 0, s, Qp, Kp, Vt, pad, partials, Lq, 16, Lk, Lk16,
+                     1.0f / sqrtf((float)dh));
+  return kAttSplit << 8;  // (number of splits << 8): the caller sizes / passes on the partial buffer with it
 }
 
 int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, const float* bo, const float* g1, const float* be1,
@@ -583,7 +642,19 @@ int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, co
   if (D != kD) return 1;
   const long long tokens = (long long)B * L;
   OutFfnArgs A{att, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2, eps1, eps2, out};
-  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, A, L, tokens);
+  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, A, L, tokens, AttPartials{nullptr, 0, 0});
+  return 0;
+}
+
+// the same with the attention output given as the key-split partials of launch_attention_heads_split (L = Lq <= 16)
+int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float* res, const float* WoT, const float* bo, const float* g1,
+                                 const float* be1, float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T,
+                                 const float* b2, const float* g2, const float* be2, float eps2, float* out, int B, int L, int D,
+                                 hipStream_t s) {
+  if (D != kD || L > 16 || n_split < 1) return 1;
+  const long long tokens = (long long)B * L;
+  OutFfnArgs A{partials, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2, eps1, eps2, out};
+  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, A, L, tokens, AttPartials{partials, n_split, L});
   return 0;
 }
 

@@ -135,6 +135,12 @@ int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const fl
                      hipStream_t s);
 int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp,
                        float* Vt, int B, int L, int D, int H, hipStream_t s);
+int launch_attention_heads_split(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* partials, int B, int Lq, int Lk,
+                                 int H, int dh, hipStream_t s);
+int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float* res, const float* WoT, const float* bo, const float* g1,
+                                 const float* be1, float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T,
+                                 const float* b2, const float* g2, const float* be2, float eps2, float* out, int B, int L, int D,
+                                 hipStream_t s);
 int launch_qkv_heads2(const float* x0, const float* x1, const float* const* q14, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H,
                       hipStream_t s);
 int launch_out_ffn_mfma2(const float* const* a26, const float* eps4, float* out, int B, int L, int D, hipStream_t s);

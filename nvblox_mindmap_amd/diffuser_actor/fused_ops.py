@@ -82,18 +82,22 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.contiguous()
 
 
-_WT_CACHE = {}
+import weakref
+
+_WT_CACHE = {}  # id(weight Parameter) -> (weak reference to it, version, transposed copy); dropped when the parameter dies
 
 
 def _wt(linear) -> torch.Tensor:
-    """Transposed ([in, out]) contiguous copy of a Linear's weight, cached until the weight is modified or moved."""
+    """Transposed ([in, out]) contiguous copy of a Linear's weight, cached per weight TENSOR OBJECT until it is modified
+    (version counter) or moved.  The entry holds a weak reference and is validated by identity: ids and device addresses of
+    freed modules get reused, a key made of those alone can serve another module's weights."""
     w = linear.weight
-    key = id(linear)
+    key = id(w)
     hit = _WT_CACHE.get(key)
-    if hit is None or hit[0] != (w.data_ptr(), w._version, w.device):
-        hit = ((w.data_ptr(), w._version, w.device), w.detach().t().contiguous())
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[2].device != w.device:
+        hit = (weakref.ref(w, lambda _r, k=key: _WT_CACHE.pop(k, None)), w._version, w.detach().t().contiguous())
         _WT_CACHE[key] = hit
-    return hit[1]
+    return hit[2]
 
 
 def ffn_block(x, scale_shift, fc1, fc2, norm) -> torch.Tensor:
@@ -225,16 +229,45 @@ def attention_heads(q_heads, k_heads, v_heads_t, key_padding_mask: Optional[torc
     return out
 
 
+def attention_heads_split(q_heads, k_heads, v_heads_t, Lq: int, Lk: int, mask16: Optional[torch.Tensor]) -> torch.Tensor:
+    """``attention_heads`` for Lq <= 16 query rows over a long key axis with the keys divided among several workgroups per
+    (batch element, head): returns the partial results [B, H, n_split, 18, 16] that ``out_ffn_mfma(att_partials=...)`` merges."""
+    import ctypes as Ct
+
+    B, H = q_heads.shape[:2]
+    assert Lq <= 16 and q_heads.shape[2] == 16 and k_heads.shape[2] == _l16(Lk)
+    assert mask16 is None or (mask16.shape == (B, _l16(Lk)) and mask16.dtype == torch.uint8 and mask16.is_contiguous())
+    n = Ct.c_int(0)
+    dev = q_heads.device
+    _lib.check(_lib.lib().mmf_attention_heads_split(_lib.dptr(q_heads), _lib.dptr(k_heads), _lib.dptr(v_heads_t), None, None, B, Lq, Lk, H, 15,
+                                                    Ct.byref(n), _lib.stream_ptr(dev)), "mmf_attention_heads_split")
+    part = torch.empty((B, H, n.value, 18, 16), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().mmf_attention_heads_split(_lib.dptr(q_heads), _lib.dptr(k_heads), _lib.dptr(v_heads_t), _lib.dptr(mask16),
+                                                    _lib.dptr(part), B, Lq, Lk, H, 15, Ct.byref(n), _lib.stream_ptr(dev)),
+               "mmf_attention_heads_split")
+    return part
+
+
 def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``out_ffn_block`` on the matrix cores (16-token tiles, three chained GEMMs).  ``out``: a contiguous [B, L, D] float32
-    destination (e.g. the leading rows of a larger sequence buffer) instead of a fresh tensor."""
-    att = att.contiguous()
+    """``out_ffn_block`` on the matrix cores (16-token tiles, three chained GEMMs).  ``att``: the attention output [B, L, D], or
+    the 5-D key-split partials of ``attention_heads_split``.  ``out``: a contiguous [B, L, D] float32 destination (e.g. the
+    leading rows of a larger sequence buffer) instead of a fresh tensor."""
     residual = residual.contiguous()
-    B, L, D = att.shape
+    B, L, D = residual.shape
     if out is None:
-        out = torch.empty_like(att)
+        out = torch.empty_like(residual)
     else:
-        assert out.shape == att.shape and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() != residual.data_ptr()
+        assert out.shape == residual.shape and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() != residual.data_ptr()
+    if att.dim() == 5:  # key-split partials of attention_heads_split: merged by the kernel while it loads its input
+        part = att.contiguous()
+        _lib.check(_lib.lib().mmf_out_ffn_mfma_partials(_lib.dptr(part), part.shape[2], _lib.dptr(residual), _lib.dptr(_wt(out_proj)),
+                                                        _lib.dptr(_c(out_proj.bias)), _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)),
+                                                        float(norm1.eps), _lib.dptr(_c(scale_shift)), _lib.dptr(_wt(fc1)),
+                                                        _lib.dptr(_c(fc1.bias)), _lib.dptr(_wt(fc2)), _lib.dptr(_c(fc2.bias)),
+                                                        _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out),
+                                                        B, L, D, _lib.stream_ptr(residual.device)), "mmf_out_ffn_mfma_partials")
+        return out
+    att = att.contiguous()
     ss = _c(scale_shift)
     _lib.check(_lib.lib().mmf_out_ffn_mfma(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_wt(out_proj)), _lib.dptr(_c(out_proj.bias)),
                                            _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)), float(norm1.eps), _lib.dptr(ss),

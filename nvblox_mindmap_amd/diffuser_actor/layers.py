@@ -288,7 +288,11 @@ class AttentionStack(nn.Module):
                     # cross-attention over a context whose head-major keys / values were cached (project_kv_heads)
                     kh, vt, Lk = kv_caches[li]
                     qh, _, _ = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, None, q_rot, A.heads, roles=1)
-                    att = FO.attention_heads(qh, kh, vt, key_padding_mask, query.shape[1], Lk, key_padding_mask16)
+                    if query.shape[1] <= 16 and Lk >= 1536 and (key_padding_mask is None or key_padding_mask16 is not None):
+                        # a handful of query rows over a long context: keys split over several workgroups, merged by the next launch
+                        att = FO.attention_heads_split(qh, kh, vt, query.shape[1], Lk, key_padding_mask16)
+                    else:
+                        att = FO.attention_heads(qh, kh, vt, key_padding_mask, query.shape[1], Lk, key_padding_mask16)
                     query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm,
                                             out=out_last if li + 1 == len(self.attn) else None)
                     continue

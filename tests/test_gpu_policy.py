@@ -427,7 +427,20 @@ def test_mfma_cross_attention_over_a_long_context():
         kh, vt, n = A.project_kv_heads(mem, kv_rot)
         qh, _, _ = FO.qkv_heads(x, ss, A.q_proj, None, q_rot, H, roles=1)
         got = FO.attention_heads(qh, kh, vt, pad, Lq, n)
-    assert n == Lk and torch.allclose(got, ref, rtol=1e-4, atol=1e-5), float((got - ref).abs().max())
+        assert n == Lk and torch.allclose(got, ref, rtol=1e-4, atol=1e-5), float((got - ref).abs().max())
+        # keys split over several workgroups, partial results merged by the out-projection kernel
+        blk = Ly.AttentionBlock(D, H, 0.0, use_adaln=True).cuda().eval()
+        ffw = Ly.FeedForwardBlock(D, D, 0.0, use_adaln=True).cuda().eval()
+        for p in list(blk.parameters()) + list(ffw.parameters()):
+            p.data.add_(0.05 * torch.randn_like(p))
+        pad16 = FO.pad_mask16(pad)
+        for mask16 in (pad16, None):
+            part = FO.attention_heads_split(qh, kh, vt, Lq, n, mask16)
+            assert part.dim() == 5 and part.shape[:2] == (B, H) and part.shape[3:] == (18, 16)
+            full = FO.attention_heads(qh, kh, vt, None if mask16 is None else pad, Lq, n, mask16)
+            a = FO.out_ffn_mfma(full, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
+            b = FO.out_ffn_mfma(part, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
 
 
 def test_paired_stacks_equal_the_two_stacks_run_separately():
