@@ -293,7 +293,10 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  *   mmf_out_ffn_qkv      mmf_out_ffn_mfma of layer i followed, in the same launch, by mmf_qkv_heads (roles 7) of layer i + 1 on
  *                        its output.  layer13 (HOST array of device pointers): att, residual, Wo, bo, ln1_weight, ln1_bias,
  *                        scale_shift (or null), W1, b1, W2, b2, ln2_weight, ln2_bias; next7: scale_shift of the next layer's
- *                        query input (or null), Wq, bq, Wkv, bkv, cos, sin (both null: no rotary) */
+ *                        query input (or null), Wq, bq, Wkv, bkv, cos, sin (both null: no rotary).  roles: 7 = q | k | v,
+ *                        1 = q alone (the next layer attends to a cached memory; Wkv / bkv / k / v may be null).
+ *                        att_partials_dev non-null: layer13[0] is ignored and the attention output is merged from the key-split
+ *                        partials of mmf_attention_heads_split (L <= 16) */
 int mmf_qkv_heads(const float* x_dev, const float* scale_shift_dev, const float* Wq_dev, const float* bq_dev, const float* Wkv_dev,
                   const float* bkv_dev, const float* cos_dev, const float* sin_dev, float* q_heads_dev, float* k_heads_dev,
                   float* v_heads_t_dev, int B, int L, int D, int H, int roles, void* stream);
@@ -333,7 +336,8 @@ int mmf_step_tail(const float* rotation_seq_dev, const float* position_seq_dev, 
                   const float* rotary_freq_dev, float* tokens_out_dev, float* cos_out_dev, float* sin_out_dev, long long rotary_batch_stride,
                   int D, void* stream);
 int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, float* out_dev, const float* const* next7,
-                    float* q_heads_dev, float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
+                    float* q_heads_dev, float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, int roles,
+                    const float* att_partials_dev, int n_split, void* stream);
 int mmf_qkv_heads2(const float* x0_dev, const float* x1_dev, const float* const* next14, float* q_heads_dev, float* k_heads_dev,
                    float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
 int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out_dev, int B, int L, int D, void* stream);

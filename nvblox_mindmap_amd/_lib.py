@@ -126,7 +126,7 @@ SIGNATURES = {
     "mmf_head_outputs": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _I, _VP]),
     "mmf_step_tail": (_I, [_VP, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                            C.c_longlong, _I, _VP]),
-    "mmf_out_ffn_qkv": (_I, [_VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "mmf_out_ffn_qkv": (_I, [_VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _VP]),
     "mmf_debug_wg_trace": (_I, [_VP, _I]),
     "mmf_qkv_heads2": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "mmf_out_ffn_mfma2": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),

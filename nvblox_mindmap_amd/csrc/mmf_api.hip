@@ -1478,15 +1478,19 @@ int mmf_step_tail(const float* rotation_seq, const float* position_seq, long lon
 }
 
 int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, float* out, const float* const* next7, float* q_heads,
-                    float* k_heads, float* v_heads_t, int B, int L, int D, int H, void* stream) {
-  if (!layer13 || !next7 || !out || !q_heads || !k_heads || !v_heads_t || B <= 0 || L <= 0)
+                    float* k_heads, float* v_heads_t, int B, int L, int D, int H, int roles, const float* att_partials, int n_split,
+                    void* stream) {
+  const bool need_q = (roles & 1) != 0, need_kv = (roles & 6) != 0;
+  if (!layer13 || !next7 || !out || B <= 0 || L <= 0 || (roles != 7 && roles != 1) || (need_q && !q_heads) ||
+      (need_kv && (!k_heads || !v_heads_t)) || (att_partials && n_split < 1))
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_qkv");
-  for (int i = 0; i < 13; ++i)
+  for (int i = att_partials ? 1 : 0; i < 13; ++i)
     if (i != 6 && !layer13[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv: missing layer operand");  // [6] = scale_shift, optional
-  if (!next7[1] || !next7[2] || !next7[3] || !next7[4] || ((next7[5] == nullptr) != (next7[6] == nullptr)))
+  if (!next7[1] || !next7[2] || (need_kv && (!next7[3] || !next7[4])) || ((next7[5] == nullptr) != (next7[6] == nullptr)))
     return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv: missing next-layer operand");
-  if (launch_out_ffn_qkv(layer13, ln1_eps, ln2_eps, out, next7, q_heads, k_heads, v_heads_t, B, L, D, H, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv is built for D = 120, H = 8");
+  if (launch_out_ffn_qkv(layer13, ln1_eps, ln2_eps, out, next7, q_heads, k_heads, v_heads_t, B, L, D, H, roles, att_partials, n_split,
+                         (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv is built for D = 120, H = 8 (and L <= 16 with partials)");
   return check_launch();
 }
 

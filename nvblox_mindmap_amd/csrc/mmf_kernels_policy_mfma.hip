@@ -554,7 +554,9 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma2(OutFfnArgs A0, OutFfnArgs
 // The tail of layer i and the head of layer i + 1 in one launch: k_out_ffn_mfma on a 16-token tile of ONE batch element, then
 // the q | k | v projections of the NEXT layer on the tile's fresh output, which never leaves the workgroup (one kernel boundary
 // and one round trip of the activations through memory less per layer).  grid (B * L16 / 16), 256 threads.
-__global__ __launch_bounds__(256) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, int L, int L16) {
+// `roles`: which of the next layer's projections (bit 0 q, 1 k, 2 v); q alone when the next layer attends to a cached memory.
+// `AP`: the attention output arrives as key-split partials (then L <= 16).
+__global__ __launch_bounds__(256) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, int L, int L16, int roles, AttPartials AP) {
   __shared__ __attribute__((aligned(16))) float sH[16][kRS];
   __shared__ __attribute__((aligned(16))) float sU[16][kRS];
   __shared__ __attribute__((aligned(16))) float sY[16][kRS];
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, in
   const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
   // rows of the tile beyond the batch element's L tokens are inert: the tile's token range ends at (b + 1) L
-  out_ffn_tile(A, (long long)b * L + l0, (long long)(b + 1) * L, L, sH, sU, sY, sU, lane, w, j, s);
+  out_ffn_tile(A, (long long)b * L + l0, (long long)(b + 1) * L, L, sH, sU, sY, sU, lane, w, j, s, AP);
   __syncthreads();
   float a[kKSteps];
   lds_row_share(sU, j, s, a);
@@ -570,10 +572,12 @@ __global__ __launch_bounds__(256) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, in
 #pragma unroll
     for (int i = 0; i < kKSteps; ++i) a[i] = 0.0f;
   }
-  qkv_role_tile(a, 1, Q, b, l0, L, L16, w, j, s);
-  qkv_role_tile(a, 2, Q, b, l0, L, L16, w, j, s);
-  if (Q.ss != nullptr && l0 + j < L) modulate_share(Q.ss, b, s, a);
-  qkv_role_tile(a, 0, Q, b, l0, L, L16, w, j, s);
+  if (roles & 2) qkv_role_tile(a, 1, Q, b, l0, L, L16, w, j, s);
+  if (roles & 4) qkv_role_tile(a, 2, Q, b, l0, L, L16, w, j, s);
+  if (roles & 1) {
+    if (Q.ss != nullptr && l0 + j < L) modulate_share(Q.ss, b, s, a);
+    qkv_role_tile(a, 0, Q, b, l0, L, L16, w, j, s);
+  }
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
@@ -660,13 +664,13 @@ int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float
 
 // args13: att, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2 (OutFfnArgs order); next7: ss, WqT, bq, WkvT, bkv, cs, sn
 int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp,
-                       float* Vt, int B, int L, int D, int H, hipStream_t s) {
-  if (D != kD || H != kH) return 1;
+                       float* Vt, int B, int L, int D, int H, int roles, const float* partials, int n_split, hipStream_t s) {
+  if (D != kD || H != kH || (partials && L > 16)) return 1;
   const int L16 = (L + 15) / 16 * 16;
   OutFfnArgs A{args13[0], args13[1], args13[2], args13[3], args13[4], args13[5], args13[6], args13[7], args13[8], args13[9], args13[10],
                args13[11], args13[12], eps1, eps2, out};
   QkvArgs Q{next7[0], next7[1], next7[2], next7[3], next7[4], next7[5], next7[6], Qp, Kp, Vt};
-  hipLaunchKernelGGL(k_out_ffn_qkv, dim3(B * (L16 / 16)), dim3(256), 0, s, A, Q, L, L16);
+  hipLaunchKernelGGL(k_out_ffn_qkv, dim3(B * (L16 / 16)), dim3(256), 0, s, A, Q, L, L16, roles, AttPartials{partials, n_split, L});
   return 0;
 }
 

@@ -134,7 +134,7 @@ int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const fl
                      const float* cs, const float* sn, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H, int roles,
                      hipStream_t s);
 int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp,
-                       float* Vt, int B, int L, int D, int H, hipStream_t s);
+                       float* Vt, int B, int L, int D, int H, int roles, const float* partials, int n_split, hipStream_t s);
 int launch_attention_heads_split(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* partials, int B, int Lq, int Lk,
                                  int H, int dh, hipStream_t s);
 int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float* res, const float* WoT, const float* bo, const float* g1,

@@ -277,28 +277,37 @@ def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, o
     return out
 
 
-def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, next_scale_shift, next_q_proj, next_kv_proj, rot, heads: int):
-    """``out_ffn_mfma`` of a layer and ``qkv_heads`` of the NEXT layer (on the result) in one launch.
-    Returns (out [B,L,D], q_heads, k_heads, v_heads_t)."""
+def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, next_scale_shift, next_q_proj, next_kv_proj, rot, heads: int,
+                out: Optional[torch.Tensor] = None):
+    """``out_ffn_mfma`` of a layer and ``qkv_heads`` of the NEXT layer (on the result) in one launch.  ``att``: [B,L,D] or the
+    5-D key-split partials of ``attention_heads_split``; ``next_kv_proj`` None: the next layer's queries alone (it attends to
+    a cached memory).  Returns (out [B,L,D], q_heads, k_heads or None, v_heads_t or None)."""
     import ctypes as Ct
 
-    att = att.contiguous()
     residual = residual.contiguous()
-    B, L, D = att.shape
+    B, L, D = residual.shape
     L16 = _l16(L)
-    dev = att.device
-    out = torch.empty_like(att)
+    dev = residual.device
+    roles = 7 if next_kv_proj is not None else 1
+    partials = att.contiguous() if att.dim() == 5 else None
+    att = None if partials is not None else att.contiguous()
+    if out is None:
+        out = torch.empty_like(residual)
+    else:
+        assert out.shape == residual.shape and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() != residual.data_ptr()
     q = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev)
-    k = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev)
-    v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev)
+    k = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev) if roles == 7 else None
+    v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev) if roles == 7 else None
     cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
     layer = [att, residual, _wt(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(scale_shift), _wt(fc1), _c(fc1.bias),
              _wt(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
-    nxt = [_c(next_scale_shift), _wt(next_q_proj), _c(next_q_proj.bias), _wt(next_kv_proj), _c(next_kv_proj.bias), cs, sn]
+    nxt = [_c(next_scale_shift), _wt(next_q_proj), _c(next_q_proj.bias), None if roles == 1 else _wt(next_kv_proj),
+           None if roles == 1 else _c(next_kv_proj.bias), cs, sn]
     a13 = (Ct.c_void_p * 13)(*[None if t is None else t.data_ptr() for t in layer])
     a7 = (Ct.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in nxt])
     _lib.check(_lib.lib().mmf_out_ffn_qkv(Ct.cast(a13, Ct.c_void_p), float(norm1.eps), float(norm2.eps), _lib.dptr(out), Ct.cast(a7, Ct.c_void_p),
-                                          _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, _lib.stream_ptr(dev)), "mmf_out_ffn_qkv")
+                                          _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, roles, _lib.dptr(partials),
+                                          0 if partials is None else partials.shape[2], _lib.stream_ptr(dev)), "mmf_out_ffn_qkv")
     return out, q, k, v
 
 

@@ -281,20 +281,30 @@ class AttentionStack(nn.Module):
                             nb = self.attn[li + 1]
                             qh, kh, vt = FO.qkv_heads(query, ss_of(nb.adaln), nb.attn.q_proj, nb.attn.kv_proj, q_rot, A.heads)
                 return query, None
+            qh_next = None
             for li, (blk, ffw) in enumerate(zip(self.attn, self.ffw)):
                 A = blk.attn
                 if (not self.self_attention and kv_caches is not None and len(kv_caches[li]) == 3
                         and (query.shape[-1], A.heads) == FO.MFMA_DIMS):
-                    # cross-attention over a context whose head-major keys / values were cached (project_kv_heads)
+                    # cross-attention over a context whose head-major keys / values were cached (project_kv_heads): per layer
+                    # attention | (out_proj + LN + FFN + the NEXT layer's query projection)
                     kh, vt, Lk = kv_caches[li]
-                    qh, _, _ = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, None, q_rot, A.heads, roles=1)
+                    if li == 0 or qh_next is None:
+                        qh, _, _ = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, None, q_rot, A.heads, roles=1)
+                    else:
+                        qh = qh_next
                     if query.shape[1] <= 16 and Lk >= 1536 and (key_padding_mask is None or key_padding_mask16 is not None):
                         # a handful of query rows over a long context: keys split over several workgroups, merged by the next launch
                         att = FO.attention_heads_split(qh, kh, vt, query.shape[1], Lk, key_padding_mask16)
                     else:
                         att = FO.attention_heads(qh, kh, vt, key_padding_mask, query.shape[1], Lk, key_padding_mask16)
-                    query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm,
-                                            out=out_last if li + 1 == len(self.attn) else None)
+                    last = li + 1 == len(self.attn)
+                    if last:
+                        query = FO.out_ffn_mfma(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm, out=out_last)
+                    else:
+                        nb = self.attn[li + 1]
+                        query, qh_next, _, _ = FO.out_ffn_qkv(att, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm,
+                                                              ss_of(nb.adaln), nb.attn.q_proj, None, q_rot, A.heads)
                     continue
                 if self.self_attention:
                     q, k, v = FO.qkv_block(query, ss_of(blk.adaln), A.q_proj, A.kv_proj, q_rot)
