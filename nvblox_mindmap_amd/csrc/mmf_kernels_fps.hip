@@ -113,6 +113,149 @@ __global__ __launch_bounds__(64) void k_fps_resident(const float* __restrict__ x
   }
 }
 
+// ---- grouped form: a batch element = G workgroups of NWV waves ----------------------------------------------------------------
+// The single-wave form above pays two dependent memory round trips per pick: the key exchange, then the fetch of the winner's
+// row.  Here the waves of a workgroup settle their best point through LDS, and each workgroup publishes its best point's KEY
+// AND ROW (CP + 1 self-validating 64-bit words: {tag | payload}, relaxed agent-scope stores, no fences); every workgroup
+// then polls the G x (CP + 1) words of its batch element -- one word per thread -- and finds the winner's row already in
+// hand: ONE round trip per pick.  Publishing rows is affordable because G is 4, not 48.
+constexpr int kFpsMaxGroups = 8;
+
+template <int CP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_fps_groups(const float* __restrict__ xp, int b0, int bend, int N, int G, int npoints, int start,
+                                                        u64* pub, long long* __restrict__ out_idx) {
+  constexpr int NT = 64 * NWV;
+  __shared__ u64 s_wkey[NWV];
+  __shared__ __attribute__((aligned(16))) float s_pub[CP];
+  __shared__ __attribute__((aligned(16))) float s_cand[kFpsMaxGroups][CP];
+  __shared__ u64 s_ckey[kFpsMaxGroups];
+  __shared__ int s_fail;
+  const int id = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = id >> 3;
+  const int b = b0 + (id & 7) + 8 * (r / G);  // batch element: its G workgroups share id % 8 (one XCD)
+  const int g = r % G;
+  if (b >= bend) return;  // rounded-up tail of this launch
+  const int p = (g * NWV + wave) * 64 + lane;
+  const bool valid = p < N;
+  const float* xb = xp + (size_t)b * N * CP;
+  float v[CP];
+  {
+    const float4* src = reinterpret_cast<const float4*>(xb + (size_t)(valid ? p : 0) * CP);
+#pragma unroll
+    for (int c = 0; c < CP / 4; ++c) {
+      const float4 q = src[c];
+      v[4 * c] = q.x, v[4 * c + 1] = q.y, v[4 * c + 2] = q.z, v[4 * c + 3] = q.w;
+    }
+  }
+  // the first selected row
+  for (int c = tid; c < CP; c += NT) s_cand[0][c] = xb[(size_t)start * CP + c];
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  u64* mypub = pub + (size_t)b * 2 * G * (CP + 1);
+  long long* ob = out_idx + (size_t)b * npoints;
+  float dist = INFINITY;
+  int win = 0;  // which candidate row holds the current selection
+  if (g == 0 && tid == 0) ob[0] = start;
+  const u64 pidx = (u64)(0xFFFu - (unsigned)p) << 20;
+  for (int it = 1; it < npoints; ++it) {
+    const float* row = s_cand[win];
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CP; c += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(row + c);
+      float d = v[c] - q.x;
+      acc += d * d;
+      d = v[c + 1] - q.y;
+      acc += d * d;
+      d = v[c + 2] - q.z;
+      acc += d * d;
+      d = v[c + 3] - q.w;
+      acc += d * d;
+    }
+    dist = fminf(dist, acc);
+    const u64 tag = (u64)(it & 0xFFFFF);
+    u64 key = valid ? (((u64)__float_as_uint(dist) << 32) | pidx | tag) : tag;
+    key = wave_max_u64(key);
+    if (lane == 0) s_wkey[wave] = key;
+    __syncthreads();
+    u64 best = s_wkey[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) best = s_wkey[w] > best ? s_wkey[w] : best;
+    const int best_p = 0xFFF - (int)((best >> 20) & 0xFFF);
+    if (valid && p == best_p) {  // the owner of the workgroup's best point hands its row over
+#pragma unroll
+      for (int c = 0; c < CP; c += 4) *reinterpret_cast<float4*>(s_pub + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+    }
+    __syncthreads();
+    u64* slot_row = mypub + (size_t)(it & 1) * G * (CP + 1);
+    if (tid <= CP) {
+      const u64 word = tid < CP ? (((u64)(unsigned)it << 32) | (u64)__float_as_uint(s_pub[tid])) : best;
+      __hip_atomic_store(slot_row + (size_t)g * (CP + 1) + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < G * (CP + 1)) {
+      const int gg = tid / (CP + 1), c = tid - gg * (CP + 1);
+      u64 got = 0;
+      unsigned spins = 0;
+      bool ok = false;
+      for (;;) {
+        got = __hip_atomic_load(slot_row + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = c < CP ? (unsigned)(got >> 32) == (unsigned)it : (got & 0xFFFFF) == tag;
+        if (ok || ++spins > kFpsSpinLimit) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) s_fail = 1;  // a peer workgroup is not running: give up (flagged below)
+      if (c < CP)
+        s_cand[gg][c] = __uint_as_float((unsigned)got);
+      else
+        s_ckey[gg] = got;
+    }
+    __syncthreads();
+    if (s_fail) {
+      if (g == 0 && tid == 0) ob[it] = -1;
+      return;
+    }
+    u64 top = s_ckey[0];
+    win = 0;
+    for (int gg = 1; gg < G; ++gg)
+      if (s_ckey[gg] > top) {
+        top = s_ckey[gg];
+        win = gg;
+      }
+    if (g == 0 && tid == 0) ob[it] = 0xFFF - (int)((top >> 20) & 0xFFF);
+  }
+}
+
+template <int CP, int NWV>
+static int fps_groups(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+  const int G = (N + 64 * NWV - 1) / (64 * NWV);
+  if (G > kFpsMaxGroups || G * (CP + 1) > 64 * NWV) return 1;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fps_groups<CP, NWV>, 64 * NWV, 0) != hipSuccess || per_cu <= 0)
+    return 2;
+  int chunk = (int)((long long)cus * per_cu / G) / 8 * 8;  // batch elements per launch: the whole grid must be co-resident
+  if (chunk < 8) return 1;
+  float* xp = nullptr;
+  u64* pub = nullptr;
+  const size_t xp_bytes = sizeof(float) * (size_t)B * N * CP, pub_bytes = sizeof(u64) * (size_t)B * 2 * G * (CP + 1);
+  if (hipMallocAsync((void**)&xp, xp_bytes, s) != hipSuccess) return 2;
+  if (hipMallocAsync((void**)&pub, pub_bytes, s) != hipSuccess) {
+    (void)hipFreeAsync(xp, s);
+    return 2;
+  }
+  (void)hipMemsetAsync(pub, 0, pub_bytes, s);
+  const long long rows = (long long)B * N;
+  hipLaunchKernelGGL(k_fps_pad<CP>, dim3((unsigned)((rows * CP + 255) / 256)), dim3(256), 0, s, x, rows, C, xp);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = (B - b0 < chunk ? B - b0 : chunk);
+    hipLaunchKernelGGL((k_fps_groups<CP, NWV>), dim3(8 * G * ((nb + 7) / 8)), dim3(64 * NWV), 0, s, xp, b0, b0 + nb, N, G, npoints, start, pub,
+                       out_idx);
+  }
+  (void)hipFreeAsync(pub, s);
+  (void)hipFreeAsync(xp, s);
+  return 0;
+}
+
 constexpr int kFpsThreads = 1024;
 constexpr int kFpsMaxPerThread = 8;  // N <= 8192
 constexpr int kFpsMaxC = 1024;
@@ -218,6 +361,10 @@ static int fps_resident(const float* x, int B, int N, int C, int npoints, int st
 
 // 0 = launched, 1 = unsupported shape, 2 = HIP runtime error
 int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+  if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120): grouped form
+    const int rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);
+    if (rc != 1) return rc;
+  }
   if (N <= kFpsMaxResidentN && C <= kFpsMaxResidentC) {
     const int rc = C <= 16   ? fps_resident<16>(x, B, N, C, npoints, start, out_idx, s)
                    : C <= 32 ? fps_resident<32>(x, B, N, C, npoints, start, out_idx, s)
