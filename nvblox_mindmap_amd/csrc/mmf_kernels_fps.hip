@@ -192,13 +192,13 @@ __global__ __launch_bounds__(64 * NWV) void k_fps_groups(const float* __restrict
       const u64 word = tid < CP ? (((u64)(unsigned)it << 32) | (u64)__float_as_uint(s_pub[tid])) : best;
       __hip_atomic_store(slot_row + (size_t)g * (CP + 1) + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < G * (CP + 1)) {
-      const int gg = tid / (CP + 1), c = tid - gg * (CP + 1);
+    for (int idx = tid; idx < G * (CP + 1); idx += NT) {
+      const int gg = idx / (CP + 1), c = idx - gg * (CP + 1);
       u64 got = 0;
       unsigned spins = 0;
       bool ok = false;
       for (;;) {
-        got = __hip_atomic_load(slot_row + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = __hip_atomic_load(slot_row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = c < CP ? (unsigned)(got >> 32) == (unsigned)it : (got & 0xFFFFF) == tag;
         if (ok || ++spins > kFpsSpinLimit) break;
         __builtin_amdgcn_s_sleep(1);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * NWV) void k_fps_groups(const float* __restrict
 template <int CP, int NWV>
 static int fps_groups(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
   const int G = (N + 64 * NWV - 1) / (64 * NWV);
-  if (G > kFpsMaxGroups || G * (CP + 1) > 64 * NWV) return 1;
+  if (G > kFpsMaxGroups || CP + 1 > 64 * NWV) return 1;
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fps_groups<CP, NWV>, 64 * NWV, 0) != hipSuccess || per_cu <= 0)
@@ -362,7 +362,7 @@ static int fps_resident(const float* x, int B, int N, int C, int npoints, int st
 // 0 = launched, 1 = unsupported shape, 2 = HIP runtime error
 int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
   if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120): grouped form
-    const int rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);
+    const int rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);  // (8 groups of 6 waves: 7 % slower)
     if (rc != 1) return rc;
   }
   if (N <= kFpsMaxResidentN && C <= kFpsMaxResidentC) {
