@@ -485,12 +485,16 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // frame's allocation job exactly as k_tsdf_integrate does and (b) evaluates, on the voxels it already holds, the
 // appearance-candidate test of k_app_candidates (mmf_kernels_app.hip) for every live block -- the colour / feature camera
 // of a fused frame is the depth camera, so the projection is shared.  Saves a launch and a second read of the layer.
-__global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
-                                                  const float* __restrict__ depth, const uint8_t* __restrict__ mask,
-                                                  float min_d, int stamp, uint8_t* __restrict__ flags,
-                                                  u64* __restrict__ cell_key) {
-  // 256 threads x 2 z-adjacent voxels (one 16-byte access): twice as many resident workgroups as thread-per-voxel and
-  // two independent dependency chains per thread
+// VPT voxels per thread (z-adjacent, 16-byte accesses), 512 / VPT threads per block.  VPT = 4: two waves per block, so every
+// live block of a bounded workspace is resident at once (at four waves per block 1 792 of ~2 300 fitted and the rest formed a
+// second round).
+template <int VPT>
+__global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+                                                        const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                        float min_d, int stamp, uint8_t* __restrict__ flags,
+                                                        u64* __restrict__ cell_key) {
+  static_assert(VPT == 2 || VPT == 4, "one or two 16-byte voxel pairs per thread");
+  constexpr int NP = VPT / 2;  // float4 = two {distance, weight} voxels
   const long long tr0 = wg_trace_begin();
   const int n = L.ctr[0];
   const int chunk = (n + 7) >> 3;
@@ -503,15 +507,19 @@ __global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
     const bool cand = (st >> 1) == stamp, is_new = cand && (st & 1);
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
-    float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x;
-    float4 a = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : *vox;
+    float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x * NP;
+    float4 av[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
     bool upd = false;
     int hit = 0, freev = 1;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      float D = r ? a.z : a.x, W = r ? a.w : a.y;
+    for (int r = 0; r < VPT; ++r) {
+      float4& a = av[r >> 1];
+      const bool hi = (r & 1) != 0;
+      float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
       float c[3], p[3], u, v;
-      voxel_centre(mc, bx, by, bz, threadIdx.x * 2 + r, c);
+      voxel_centre(mc, bx, by, bz, threadIdx.x * VPT + r, c);
       xform(T_C_L, c, p);
       const bool in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
       if (cand && in_view) {
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
           }
         }
       }
-      if (r) {
+      if (hi) {
         a.z = D;
         a.w = W;
       } else {
@@ -539,7 +547,10 @@ __global__ __launch_bounds__(256) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam
       freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
     }
     if (cand) {  // workgroup-uniform
-      if (upd || is_new) *vox = a;
+      if (upd || is_new) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) vox[q] = av[q];
+      }
       const int all_free = __syncthreads_and(freev);
       if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
     }
@@ -907,7 +918,7 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
 
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, hipStream_t s) {
-  hipLaunchKernelGGL(k_tsdf_pass, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(256), 0, s, L, mc, cam, T_C_L, depth, mask,
+  hipLaunchKernelGGL(k_tsdf_pass<4>, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask,
                      min_d, stamp, flags, cell_key);
 }
 
