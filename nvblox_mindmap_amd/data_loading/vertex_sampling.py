@@ -14,6 +14,26 @@ class VertexSamplingMethod(Enum):
     NONE = "none"
 
 
+def select_vertex_indices(n: int, desired_num_vertices: int, method: VertexSamplingMethod, device, seed: Optional[int] = None,
+                          z: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row indices ``sample_to_n_vertices`` keeps when n > desired_num_vertices (same RNG draws / same sort); ``z``: the
+    vertices' z column, needed by LOWEST only."""
+    if method == VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT:
+        if seed is not None:
+            torch.manual_seed(seed)
+        # CPU default generator, exactly like the reference (vertex_sampling.py:143-145)
+        return torch.randperm(n)[:desired_num_vertices].to(device)
+    if method == VertexSamplingMethod.RANDOM_WITH_REPLACEMENT:
+        if seed is not None:
+            torch.manual_seed(seed)
+        return torch.randint(0, n, (desired_num_vertices,)).to(device)
+    if method == VertexSamplingMethod.LOWEST:
+        # the reference sorts by -z (np.argsort(-vertices[:, 2]), vertex_sampling.py:122): i.e. it keeps the
+        # HIGHEST z despite the name; a stable sort reproduces numpy's tie order
+        return torch.sort(-z, stable=True).indices[:desired_num_vertices]
+    raise ValueError(f"Vertex sampling method {method} is not yet implemented.")
+
+
 def sample_to_n_vertices(vertices: torch.Tensor, features: torch.Tensor, desired_num_vertices: int,
                          method: VertexSamplingMethod, seed: Optional[int] = None
                          ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -26,21 +46,7 @@ def sample_to_n_vertices(vertices: torch.Tensor, features: torch.Tensor, desired
         return vertices, features, torch.ones(n, device=dev, dtype=torch.bool)
     if n > desired_num_vertices:
         valid_mask = torch.ones(desired_num_vertices, device=dev, dtype=torch.bool)
-        if method == VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT:
-            if seed is not None:
-                torch.manual_seed(seed)
-            # CPU default generator, exactly like the reference (vertex_sampling.py:143-145)
-            sel = torch.randperm(n)[:desired_num_vertices].to(dev)
-        elif method == VertexSamplingMethod.RANDOM_WITH_REPLACEMENT:
-            if seed is not None:
-                torch.manual_seed(seed)
-            sel = torch.randint(0, n, (desired_num_vertices,)).to(dev)
-        elif method == VertexSamplingMethod.LOWEST:
-            # the reference sorts by -z (np.argsort(-vertices[:, 2]), vertex_sampling.py:122): i.e. it keeps the
-            # HIGHEST z despite the name; a stable sort reproduces numpy's tie order
-            sel = torch.sort(-vertices[:, 2], stable=True).indices[:desired_num_vertices]
-        else:
-            raise ValueError(f"Vertex sampling method {method} is not yet implemented.")
+        sel = select_vertex_indices(n, desired_num_vertices, method, dev, seed, vertices[:, 2])
         vertices, features = vertices[sel, :], features[sel, :]
     else:
         pad = desired_num_vertices - n

@@ -279,6 +279,19 @@ def test_integrate_frame_fused_matches_oracle(oracle_mod, scale, channels):
     nonzero = np.any(of != 0, axis=1)
     n_expected = int((inside & nonzero).sum())
     assert int(valid.sum()) == min(n_expected, 2048)
+    # the single-gather path of the helper (more vertices than requested) returns what the step-by-step form returns
+    from nvblox_mindmap_amd.data_loading.vertex_sampling import sample_to_n_vertices
+
+    for method in (VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT, VertexSamplingMethod.RANDOM_WITH_REPLACEMENT, VertexSamplingMethod.LOWEST):
+        torch.manual_seed(5)
+        v1, f1, m1 = get_vertices_and_features(gpu, MAPPER_TO_ID.STATIC, mcfg, remove_zero_features=True, num_excess_features=1,
+                                               sample_vertices=True, number_of_vertices_to_sample=300, vertex_sampling_method=method)
+        torch.manual_seed(5)
+        va, fa, _ = get_vertices_and_features(gpu, MAPPER_TO_ID.STATIC, mcfg, remove_zero_features=True, num_excess_features=1,
+                                              sample_vertices=False)
+        assert va.shape[0] > 300
+        v2, f2, m2 = sample_to_n_vertices(va, fa, 300, method)
+        assert torch.equal(v1[0], v2) and torch.equal(f1[0], f2) and torch.equal(m1[0], m2)
 
 
 def test_reference_channel_count_768(oracle_mod):
