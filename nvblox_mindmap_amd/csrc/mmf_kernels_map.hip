@@ -131,14 +131,23 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     float e[3] = {pL[0] * mc.inv_bs, pL[1] * mc.inv_bs, pL[2] * mc.inv_bs};
     Walk w;
     walk_init(w, s0, e);
-    for (int i = 0; i <= w.n; ++i) {
-      int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
-      // The walk is monotone along every axis: once it is past the view grid in its direction of travel (or off
-      // the grid along an axis it does not move on) no later cell can be inside the grid -> stop.  This bounds
-      // the longest rays (far depths clamped to the maximum distance walk ~100 cells, most of them outside).
-      if ((w.st[0] >= 0 && gx >= vg.nx) || (w.st[0] <= 0 && gx < 0) || (w.st[1] >= 0 && gy >= vg.ny) || (w.st[1] <= 0 && gy < 0) ||
-          (w.st[2] >= 0 && gz >= vg.nz) || (w.st[2] <= 0 && gz < 0))
-        break;
+    // The walk is monotone along every axis: once it is past the view grid in its direction of travel (or off the grid
+    // along an axis it does not move on) no later cell can be inside the grid -> stop.  This bounds the longest rays (far
+    // depths clamped to the maximum distance walk ~100 cells, most of them outside).  A coordinate changes by one per
+    // step, so "past the grid" is first reached as EQUALITY with the first cell beyond it: the test is made once in full
+    // before the loop (a ray that starts beyond never enters) and as three compares per step inside it.
+    const int n3[3] = {vg.nx, vg.ny, vg.nz}, o3[3] = {vg.ox, vg.oy, vg.oz};
+    int beyond[3];
+    bool never = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int g = w.c[a] - o3[a];
+      never = never || (w.st[a] >= 0 && g >= n3[a]) || (w.st[a] <= 0 && g < 0);
+      beyond[a] = w.st[a] > 0 ? o3[a] + n3[a] : (w.st[a] < 0 ? o3[a] - 1 : (int)0x80000000);
+    }
+    for (int i = 0; i <= w.n && !never; ++i) {
+      if (w.c[0] == beyond[0] || w.c[1] == beyond[1] || w.c[2] == beyond[2]) break;
+      const int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
       // the view grid already is the intersection with the workspace bounds
       if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
         const int cell = (gx * vg.ny + gy) * vg.nz + gz;
