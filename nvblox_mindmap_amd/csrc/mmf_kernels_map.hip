@@ -48,27 +48,20 @@ __device__ inline void walk_init(Walk& w, const float* s, const float* e) {
 }
 
 __device__ inline void walk_step(Walk& w) {
-  int best = -1;
-  float bt = 0.0f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (w.c[a] == w.g[a]) continue;
-    if (best < 0 || w.tm[a] < bt) {
-      best = a;
-      bt = w.tm[a];
-    }
-  }
-  // written without dynamic register indexing
-  if (best == 0) {
-    w.c[0] += w.st[0];
-    w.tm[0] += w.dt[0];
-  } else if (best == 1) {
-    w.c[1] += w.st[1];
-    w.tm[1] += w.dt[1];
-  } else if (best == 2) {
-    w.c[2] += w.st[2];
-    w.tm[2] += w.dt[2];
-  }
+  // the axis with the smallest boundary parameter among those that have not reached their goal cell; ties and the choice
+  // among finished axes resolve to the lowest axis, exactly like a first-unfinished / strictly-smaller scan.  Branch-free:
+  // this is the hot loop of the most instruction-bound launch of a frame.
+  const bool f0 = w.c[0] == w.g[0], f1 = w.c[1] == w.g[1], f2 = w.c[2] == w.g[2];
+  const bool p1 = !f1 && (f0 || w.tm[1] < w.tm[0]);
+  const float t01 = p1 ? w.tm[1] : w.tm[0];
+  const bool p2 = !f2 && ((f0 && f1) || w.tm[2] < t01);
+  const bool s0 = !p1 && !p2 && !f0, s1 = p1 && !p2;  // p2: axis 2
+  w.c[0] += s0 ? w.st[0] : 0;
+  w.tm[0] = s0 ? w.tm[0] + w.dt[0] : w.tm[0];
+  w.c[1] += s1 ? w.st[1] : 0;
+  w.tm[1] = s1 ? w.tm[1] + w.dt[1] : w.tm[1];
+  w.c[2] += p2 ? w.st[2] : 0;
+  w.tm[2] = p2 ? w.tm[2] + w.dt[2] : w.tm[2];
 }
 
 // LDSFLAGS: the view grid has at most kRaycastLdsCells cells, so a workgroup first collects the cells its 256
