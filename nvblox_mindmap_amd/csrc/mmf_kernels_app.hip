@@ -214,9 +214,14 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
 #ifdef MMF_WG_TRACE
     ++n_wide;
 #endif
-    // this lane's sample: the march position after k further trunc-steps
+    // this lane's sample: the march position after k further trunc-steps (k sequential float additions, as the march makes
+    // them; straight-line add + select instead of a lane-divergent loop)
     float tk = t;
-    for (int j = 0; j < k; ++j) tk += mc.trunc;
+#pragma unroll
+    for (int j = 0; j < kRayLanes - 1; ++j) {
+      const float nx = tk + mc.trunc;
+      tk = j < k ? nx : tk;
+    }
     const float tk_next_guess = tk + mc.trunc;  // == lane k+1's tk
     const Sample S = sample(tk);
     const bool valid = S.valid;
