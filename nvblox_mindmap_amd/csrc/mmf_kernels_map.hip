@@ -52,10 +52,12 @@ __device__ inline void walk_step(Walk& w) {
   // among finished axes resolve to the lowest axis, exactly like a first-unfinished / strictly-smaller scan.  Branch-free:
   // this is the hot loop of the most instruction-bound launch of a frame.
   const bool f0 = w.c[0] == w.g[0], f1 = w.c[1] == w.g[1], f2 = w.c[2] == w.g[2];
-  const bool p1 = !f1 && (f0 || w.tm[1] < w.tm[0]);
+  const bool lt10 = w.tm[1] < w.tm[0];
+  const bool p1 = !f1 & (f0 | lt10);  // (bitwise on purpose: no short-circuit branches in this loop)
   const float t01 = p1 ? w.tm[1] : w.tm[0];
-  const bool p2 = !f2 && ((f0 && f1) || w.tm[2] < t01);
-  const bool s0 = !p1 && !p2 && !f0, s1 = p1 && !p2;  // p2: axis 2
+  const bool lt2 = w.tm[2] < t01;
+  const bool p2 = !f2 & ((f0 & f1) | lt2);
+  const bool s0 = !p1 & !p2 & !f0, s1 = p1 & !p2;  // p2: axis 2
   w.c[0] += s0 ? w.st[0] : 0;
   w.tm[0] = s0 ? w.tm[0] + w.dt[0] : w.tm[0];
   w.c[1] += s1 ? w.st[1] : 0;
