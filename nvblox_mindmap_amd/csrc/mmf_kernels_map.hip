@@ -131,18 +131,20 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     // depths clamped to the maximum distance walk ~100 cells, most of them outside).  A coordinate changes by one per
     // step, so "past the grid" is first reached as EQUALITY with the first cell beyond it: the test is made once in full
     // before the loop (a ray that starts beyond never enters) and as three compares per step inside it.
+    // From here on the walk lives in grid-relative coordinates (cell (0,0,0) = the grid's origin block).
     const int n3[3] = {vg.nx, vg.ny, vg.nz}, o3[3] = {vg.ox, vg.oy, vg.oz};
     int beyond[3];
     bool never = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const int g = w.c[a] - o3[a];
-      never = never || (w.st[a] >= 0 && g >= n3[a]) || (w.st[a] <= 0 && g < 0);
-      beyond[a] = w.st[a] > 0 ? o3[a] + n3[a] : (w.st[a] < 0 ? o3[a] - 1 : (int)0x80000000);
+      w.c[a] -= o3[a];
+      w.g[a] -= o3[a];
+      never = never || (w.st[a] >= 0 && w.c[a] >= n3[a]) || (w.st[a] <= 0 && w.c[a] < 0);
+      beyond[a] = w.st[a] > 0 ? n3[a] : (w.st[a] < 0 ? -1 : (int)0x80000000);
     }
     for (int i = 0; i <= w.n && !never; ++i) {
       if (w.c[0] == beyond[0] || w.c[1] == beyond[1] || w.c[2] == beyond[2]) break;
-      const int gx = w.c[0] - vg.ox, gy = w.c[1] - vg.oy, gz = w.c[2] - vg.oz;
+      const int gx = w.c[0], gy = w.c[1], gz = w.c[2];
       // the view grid already is the intersection with the workspace bounds
       if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
         // inside the grid the coordinates are small and non-negative: 24-bit multiplies (full rate; 32-bit ones are quarter rate)
