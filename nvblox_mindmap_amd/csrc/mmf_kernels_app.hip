@@ -393,17 +393,21 @@ struct AppArgs {
 // blend one colour voxel {rgb_, w} with the bilinear sample at footprint (x0,y0,wx,wy)
 __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, const MapConsts& mc, int x0, int y0, float wx, float wy,
                                     unsigned& ex, unsigned& ey) {
-  const uint8_t* t00 = rgb + ((size_t)y0 * W + x0) * 3;
-  const uint8_t* t10 = t00 + 3;
-  const uint8_t* t01 = t00 + (size_t)W * 3;
-  const uint8_t* t11 = t01 + 3;
+  // the two pixels of a footprint row are 6 consecutive bytes: one 4-byte + one 2-byte load (byte-aligned) instead of six
+  typedef unsigned u32_b __attribute__((aligned(1)));
+  typedef unsigned short u16_b __attribute__((aligned(1)));
+  const uint8_t* r0 = rgb + ((size_t)y0 * W + x0) * 3;
+  const uint8_t* r1 = r0 + (size_t)W * 3;
+  const u64 top = (u64)*reinterpret_cast<const u32_b*>(r0) | ((u64)*reinterpret_cast<const u16_b*>(r0 + 4) << 32);
+  const u64 bot = (u64)*reinterpret_cast<const u32_b*>(r1) | ((u64)*reinterpret_cast<const u16_b*>(r1 + 4) << 32);
   const float Wv = __uint_as_float(ey);
   const float wm = mc.app_wm;
   const float inv = 1.0f / (Wv + wm);
   unsigned out = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
+    const float a = bilin((float)((top >> (8 * k)) & 0xffu), (float)((top >> (8 * (k + 3))) & 0xffu), (float)((bot >> (8 * k)) & 0xffu),
+                          (float)((bot >> (8 * (k + 3))) & 0xffu), wx, wy);
     const float Aold = (float)((ex >> (8 * k)) & 0xffu);
     const float An = (Aold * Wv + a * wm) * inv;
     out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
