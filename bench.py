@@ -391,6 +391,25 @@ def run_policy_inference(device, reps=3):
     return out
 
 
+def measure_d2d_copy(device, mib=1024, iters=10):
+    """Device-to-device copy rate of the box (the measured counterpart of the 8 TB/s spec peak): bytes read +
+    bytes written per second of a large torch copy."""
+    src = torch.empty(mib * 1024 * 1024, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize(device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize(device)
+    sec = a.elapsed_time(b) / iters * 1e-3
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * mib * 1024 * 1024 / sec / 1e9
+
+
 def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_matmul_dtype="float32", prefetch_backbone=False):
     """Policy training step/s (second half of the BASELINE metric; config 5): diffuser_actor, RGBD_AND_MESH, per-GPU batch 32,
     one 512x512 camera, 2048 vertices x 768 features, frozen ViT-B/16-shaped backbone (random-init stand-in for RADIO v2.5-B),
@@ -580,7 +599,8 @@ def main():
                 "unit_of_work": "feature voxel updated (passed the occlusion/mask gate)",
                 "feature_voxels_updated_per_launch": feat_voxels_per_frame,
                 "feature_blocks_per_launch": feat_blocks_per_frame,
-                "note": "at C=64 the frame is 6 latency-bound launches of 10-25 us (kernel_us_per_launch); this kernel is "
+                "measured_d2d_copy_GBps": measure_d2d_copy(device),  # read + write rate of a 1 GiB copy on this box
+                "note": "at C=64 the frame is 6 latency-bound launches of 7-17 us (kernel_us_per_launch); this kernel is "
                         "the HBM-bound one and dominates at the reference shape (reference_shape.k_feature_flat_*)",
                 "survey_8d_model_bytes_per_frame": model_bytes,
             }
