@@ -70,6 +70,8 @@ struct Mapper {
   long long* timeline = nullptr;  // 8 device int64: timestamps of the last TSDF allocation job (mmf_get_alloc_timeline)
   FlatList flat;               // survivor list of a feature frame (balanced phase 2); rec == null: not in use
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
+  bool wmax_valid = true;      // (an empty map trivially) tsdf.d.wmax holds every live block's largest weight (set by a fused frame, cleared by whatever
+                               // else writes TSDF weights): a pending decay can then take the light path
   // mesh
   int* mesh_counts = nullptr;
   int* mesh_offsets = nullptr;
@@ -269,6 +271,7 @@ void free_layer(Layer& L) {
   if (L.d.poolw) (void)hipFree(L.d.poolw);
   if (L.d.dense) (void)hipFree(L.d.dense);
   if (L.d.block_free) (void)hipFree(L.d.block_free);
+  if (L.d.wmax) (void)hipFree(L.d.wmax);
   if (L.d.stamp) (void)hipFree(L.d.stamp);
   L = Layer{};
 }
@@ -382,6 +385,8 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   m->tsdf.d.hint_live = m->hints + 3;
   HIP_TRY(hipMalloc(&m->tsdf.d.block_free, (size_t)cap));
   HIP_TRY(hipMemset(m->tsdf.d.block_free, 0, (size_t)cap));
+  HIP_TRY(hipMalloc(&m->tsdf.d.wmax, sizeof(float) * (size_t)cap));
+  HIP_TRY(hipMemset(m->tsdf.d.wmax, 0, sizeof(float) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->tsdf.d.stamp, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMemset(m->tsdf.d.stamp, 0, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
@@ -501,6 +506,7 @@ int get_mapper(mmf_handle h, int id, Mapper** out) {
 void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
   if (!m.pending_decay) return;
   m.pending_decay = false;
+  m.wmax_valid = false;  // the stand-alone decay does not maintain wmax
   ProfScope ps(h, MMF_K_DECAY, s);
   launch_decay(m.tsdf.d, m.mc, m.kill, m.any_kill, s);
 }
@@ -641,6 +647,7 @@ int depth_chain(mmf_handle h, Mapper& m, const float* depth, const uint8_t* mask
   }
   {
     ProfScope ps(h, MMF_K_TSDF, s);
+    m.wmax_valid = false;  // the stand-alone integrator does not maintain wmax
     launch_tsdf_integrate(m.tsdf.d, m.mc, cam, T_C_L, depth, mask, min_d, m.sc[0], ncells < m.tsdf.d.cap ? ncells : m.tsdf.d.cap, s);
   }
   return MMF_OK;
@@ -956,11 +963,14 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
   const bool do_decay = m->pending_decay;
   m->pending_decay = false;
+  // wmax current (the previous writer of the TSDF weights was a fused frame): the decay's deallocations are decided from it by
+  // a dozen workgroups and its W *= f rides in this frame's k_tsdf_pass -- no extra pass over the layer
+  const bool light_decay = do_decay && m->wmax_valid;
   {
     // raycast tiles | mask row pass | pending decay of the TSDF layer
     ProfScope ps(h, MMF_K_RAYCAST, s);
     launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
-                 m->kill, m->any_kill, s);
+                 light_decay, m->kill, m->any_kill, s);
   }
   {
     ProfScope ps(h, MMF_K_ALLOC, s);
@@ -989,7 +999,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   {
     // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
     ProfScope ps(h, MMF_K_TSDF, s);
-    launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key, s);
+    launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key,
+                     light_decay ? m->mc.decay_factor : 0.0f, s);
+    m->wmax_valid = true;  // k_tsdf_pass refreshed it for every live block
   }
   {
     // sphere trace | colour allocation | feature allocation: one launch
@@ -1098,6 +1110,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     Mapper* m = h->mappers[i];
     m->pending_decay = false;  // decaying blocks that are about to be dropped is a no-op
     launch_layer_reset(m->tsdf.d, s);
+    m->wmax_valid = true;  // no live block
     if (m->color.allocated) launch_layer_reset(m->color.d, s);
     if (m->feat.allocated) launch_layer_reset(m->feat.d, s);
     m->tsdf_epoch++;
@@ -1258,6 +1271,7 @@ int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx
   if (n > L.d.cap)
     return fail(MMF_ERR_POOL_EXHAUSTED, "saved layer has " + std::to_string(n) + " blocks, the pool holds " + std::to_string(L.d.cap));
   if (layer == MMF_LAYER_TSDF) m->pending_decay = false;  // the content it would have decayed is replaced
+  if (layer == MMF_LAYER_TSDF) m->wmax_valid = false;  // imported weights: wmax is rebuilt by the next fused frame
   launch_layer_reset(L.d, s);
   launch_import_index(L.d, idx, n, s);
   if (n > 0) {

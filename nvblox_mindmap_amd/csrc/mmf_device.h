@@ -71,6 +71,10 @@ struct LayerDev {
   // D == +trunc).  Recomputed by k_tsdf_integrate / k_decay for every block they touch; lets the sphere tracer
   // step through such blocks without reading voxels (the sample result is known: valid, distance = trunc).
   unsigned char* block_free;
+  // TSDF layer only: wmax[slot] = largest voxel weight of the block, written by k_tsdf_pass for every live block.  A pending
+  // Mapper.decay() then needs no voxel pass to find the blocks it deallocates (all W f < threshold <=> max(W) f < threshold,
+  // exactly: multiplication by f > 0 is monotone) and the multiplication itself rides in the next k_tsdf_pass.
+  float* wmax;
   // TSDF layer only: stamp[slot] = (frame stamp << 1) | is_new, written by the allocation job of a fused frame for every
   // candidate block, so that a pass over the LIVE list (k_tsdf_pass) knows which blocks this frame integrates.
   int* stamp;

@@ -185,7 +185,12 @@ struct DecayJob {
   uint8_t* kill;
   int* any_kill;
   int n_wgs;  // 0: no decay pending
+  int light;  // != 0: L.wmax is current -- decide the deallocations from it (one thread per block, no voxel access); the
+              // weights themselves are multiplied by the next k_tsdf_pass
 };
+
+template <bool ERASE>
+__device__ inline void decay_light_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb);
 
 template <bool LDSFLAGS>
 __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D) {
@@ -206,7 +211,10 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     // (Tried: decay workgroups first + "last one compacts" inside this launch -- an agent-scope fence per workgroup is a
     // full L2 write-back (339 us), atomics on one arrival counter serialise (69 us), and even with a two-level counter
     // the launch grew by 9 us while the next one shrank by 2.)
-    decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
+    if (D.light)
+      decay_light_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
+    else
+      decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
     wg_trace_end(tr0, kTrFrontDecay);
   }
 }
@@ -499,8 +507,11 @@ template <int VPT>
 __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                         const float* __restrict__ depth, const uint8_t* __restrict__ mask,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
-                                                        u64* __restrict__ cell_key) {
+                                                        u64* __restrict__ cell_key, float decay_f) {
+  // decay_f > 0: a Mapper.decay() is pending whose deallocations k_front already made from L.wmax -- its W *= f is applied
+  // here, on the voxels this pass loads anyway (and every block is written back).  L.wmax is refreshed for every live block.
   static_assert(VPT == 2 || VPT == 4, "one or two 16-byte voxel pairs per thread");
+  __shared__ float s_wmax[512 / VPT / 64];
   constexpr int NP = VPT / 2;  // float4 = two {distance, weight} voxels
   const long long tr0 = wg_trace_begin();
   const int n = L.ctr[0];
@@ -518,7 +529,16 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
     float4 av[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
+    const bool decayed = decay_f > 0.0f;  // uniform
+    if (decayed) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        av[q].y = av[q].y * decay_f;
+        av[q].w = av[q].w * decay_f;
+      }
+    }
     bool upd = false;
+    float wmx = 0.0f;
     int hit = 0, freev = 1;
 #pragma unroll
     for (int r = 0; r < VPT; ++r) {
@@ -552,19 +572,27 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
       }
       hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
       freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
+      wmx = fmaxf(wmx, W);
     }
-    if (cand) {  // workgroup-uniform
-      if (upd || is_new) {
+    if (upd || is_new || decayed) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) vox[q] = av[q];
-      }
+      for (int q = 0; q < NP; ++q) vox[q] = av[q];
+    }
+    if (cand || decayed) {  // workgroup-uniform: the block's voxels changed -> its empty-space summary may have
       const int all_free = __syncthreads_and(freev);
       if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
     }
-    const int any = __syncthreads_or(hit);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, off, 64));
+    if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmx;
+    const int any = __syncthreads_or(hit);  // (also orders s_wmax)
     if (threadIdx.x == 0) {
       flags[i] = any ? 1 : 0;
       if (any) cell_key[i] = key;
+      float m = s_wmax[0];
+#pragma unroll
+      for (int q = 1; q < 512 / VPT / 64; ++q) m = fmaxf(m, s_wmax[q]);
+      L.wmax[slot] = m;
     }
   }
   wg_trace_end(tr0, kTrTsdfPass);
@@ -595,6 +623,27 @@ __device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_
       kill[i] = 1;
       *any_kill = 1;
       if (ERASE) {  // the compaction (live_compact_body<.., false>) then only moves list entries
+        const u64 key = L.slot_key[slot];
+        hash_erase(L, key);
+        dense_set(L, key, 0);
+        L.slot_key[slot] = kEmptyKey;
+      }
+    }
+  }
+}
+
+// The deallocation decision of a decay whose multiplication is deferred to k_tsdf_pass: thread per live block.
+template <bool ERASE>
+__device__ inline void decay_light_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb) {
+  if (!mc.dealloc_decayed) return;
+  const int n = L.ctr[0];
+  for (int i = bid * (int)blockDim.x + (int)threadIdx.x; i < n; i += nb * (int)blockDim.x) {
+    const int slot = L.live[i];
+    const float w = L.wmax[slot] * mc.decay_factor;
+    if (w < mc.decay_thr) {  // every voxel: W f <= max(W) f < threshold
+      kill[i] = 1;
+      *any_kill = 1;
+      if (ERASE) {
         const u64 key = L.slot_key[slot];
         hash_erase(L, key);
         dense_set(L, key, 0);
@@ -762,8 +811,8 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
 
 // raycast + mask row pass in one launch
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
-                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, uint8_t* kill,
-                  int* any_kill, hipStream_t s) {
+                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
+                  uint8_t* kill, int* any_kill, hipStream_t s) {
   int n_wgs;
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
   R.mask_invert = M.invert;
@@ -773,7 +822,9 @@ void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const
     D.L = *decay_layer;
     D.kill = kill;
     D.any_kill = any_kill;
-    D.n_wgs = grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
+    D.light = light_decay ? 1 : 0;
+    D.n_wgs = light_decay ? (hinted(decay_layer->hint_live, decay_layer->cap) + 255) / 256
+                          : grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
   }
   const dim3 grid(n_wgs + M.H + D.n_wgs);
   if (ncells <= kRaycastLdsCells)
@@ -924,9 +975,9 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
 }
 
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
-                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, hipStream_t s) {
+                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
   hipLaunchKernelGGL(k_tsdf_pass<4>, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask,
-                     min_d, stamp, flags, cell_key);
+                     min_d, stamp, flags, cell_key, decay_f);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

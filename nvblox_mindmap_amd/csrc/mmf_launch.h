@@ -35,8 +35,8 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s);
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
-                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, uint8_t* kill,
-                  int* any_kill, hipStream_t s);
+                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
+                  uint8_t* kill, int* any_kill, hipStream_t s);
 bool alloc_jobs_fusable(int ncells0, int ncells1);
 void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
@@ -46,7 +46,7 @@ void launch_import_color(const LayerDev& L, const uint8_t* rgb, const float* w, 
 void launch_block_free_all(const LayerDev& L, const MapConsts& mc, int n, hipStream_t s);
 void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s);
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
-                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, hipStream_t s);
+                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s);
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
 void launch_layer_reset(const LayerDev& L, hipStream_t s);
 void launch_hash_rebuild(const LayerDev& L, hipStream_t s);
