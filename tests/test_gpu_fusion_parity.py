@@ -583,3 +583,28 @@ def test_wg_trace_hooks_are_compiled_out_of_the_product_build():
     with pytest.raises(RuntimeError, match="WG_TRACE"):
         _lib.check(_lib.lib().mmf_debug_wg_trace(_lib.dptr(buf), 6 * 8192), "mmf_debug_wg_trace")
     _lib.check(_lib.lib().mmf_debug_wg_trace(None, 0), "mmf_debug_wg_trace")
+
+
+def test_lazy_decay_deallocates_in_fused_frames_and_survives_interleaved_standalone_calls(oracle_mod):
+    """Strong decay inside fused frames: the deallocations come from the per-block maximum weights (light path, the W *= f rides
+    in k_tsdf_pass); a stand-alone add_depth_frame / eager decay in between marks those maxima stale, the next fused frame
+    takes the full decay pass, the one after it the light path again.  Blocks, order and values equal the oracle's throughout."""
+    cfg = small_cfg(4)
+    over = dict(tsdf_decay_factor=0.2, decayed_weight_threshold=1e-2)
+    gpu, orc = make_mapper(8, **over), make_oracle(oracle_mod, 8, **over)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 60, 120, 180, 0], 8)
+    n_after_orbit = orc.num_blocks(0)
+    f = S.frame(cfg, 30, 8)
+    for m in (orc, gpu):
+        m.decay()
+    orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"])
+    gpu.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+    compare_tsdf(orc, gpu)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [90, 150, 150], 8)
+    for _ in range(3):  # and an eager decay (a reader in between) after light frames
+        orc.decay()
+        gpu.decay()
+        assert gpu.tsdf_layer_view(0).num_allocated_blocks() == orc.num_blocks(0)
+    compare_tsdf(orc, gpu)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [10, 200], 8)
+    assert orc.num_blocks(0) > 0 and n_after_orbit > 0
