@@ -26,15 +26,20 @@ __device__ inline u64 cell_key(const KeySrc& ks, const Scratch& sc, int cell) {
 // found the block already did (fused frame: decay_body<true>).  No-op when nothing was flagged.
 // DENSE: the layer is known to be indexed by its dense table (bounded workspace): the hash paths are compiled out.  These
 // bodies run in ONE workgroup, once, through a cold instruction cache -- their duration follows their code size.
-template <int NW, int IPT, bool ERASE, bool DENSE = false>
-__device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict__ kill, int* any_kill, int* lds, int* carry) {
+// WMAX: the dead blocks are not read from kill[] but decided here, from the block's largest weight (LayerDev::wmax, kept
+// current by k_tsdf_pass): dead <=> wmax * decay_f < decay_thr, i.e. every voxel of the block would fall under the
+// threshold -- the whole deallocation of a Mapper.decay() in one workgroup that touches no voxel (kill / any_kill unused).
+template <int NW, int IPT, bool ERASE, bool DENSE = false, bool WMAX = false>
+__device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict__ kill, int* any_kill, int* lds, int* carry,
+                                         float decay_f = 0.0f, float decay_thr = 0.0f) {
   static_assert(IPT % 4 == 0, "entries are fetched four at a time");
+  static_assert(!WMAX || ERASE, "the wmax rule is the only pass over the dead blocks: it must also drop them from the index");
   const bool dense = DENSE || L.dense != nullptr;
   constexpr int NT = 64 * NW;
   // One memory round trip instead of three: the flag, the two counters and the thread's entries of the first pass (the
   // only pass for up to NT * IPT live blocks) are requested together, the entries from clamped -- always valid --
   // positions, before any of them is looked at.
-  const int pending = *any_kill;
+  const int pending = WMAX ? 1 : *any_kill;
   const int n = L.ctr[0];
   const int free0 = L.ctr[1];
   int4 pre_v[IPT / 4];
@@ -46,7 +51,7 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
       int p = (int)threadIdx.x * IPT + g;
       p = p < last4 ? p : last4;
       pre_v[g / 4] = *reinterpret_cast<const int4*>(L.live + p);
-      pre_k[g / 4] = *reinterpret_cast<const uint32_t*>(kill + p);
+      pre_k[g / 4] = WMAX ? 0u : *reinterpret_cast<const uint32_t*>(kill + p);
     }
   }
   if (!pending) return;
@@ -68,18 +73,28 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
         // (i0 + g + 3 < n <= cap: the clamp above did not move a prefetched position of the first pass)
         const int4 v = base == 0 ? pre_v[g / 4] : *reinterpret_cast<const int4*>(L.live + i0 + g);
         s4[0] = v.x, s4[1] = v.y, s4[2] = v.z, s4[3] = v.w;
-        k4 = base == 0 ? pre_k[g / 4] : *reinterpret_cast<const uint32_t*>(kill + i0 + g);
-        if (k4) *reinterpret_cast<uint32_t*>(kill + i0 + g) = 0u;
+        if (!WMAX) {
+          k4 = base == 0 ? pre_k[g / 4] : *reinterpret_cast<const uint32_t*>(kill + i0 + g);
+          if (k4) *reinterpret_cast<uint32_t*>(kill + i0 + g) = 0u;
+        }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (i0 + g + q < n) {
             s4[q] = L.live[i0 + g + q];
-            if (kill[i0 + g + q]) {
+            if (!WMAX && kill[i0 + g + q]) {
               k4 |= 1u << (8 * q);
               kill[i0 + g + q] = 0;
             }
           }
+      }
+      if (WMAX) {  // four independent gathers (slot 0 stands in for the entries past the list: not counted below)
+        float w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w4[q] = L.wmax[s4[q] < 0 ? 0 : s4[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (w4[q] * decay_f < decay_thr) k4 |= 1u << (8 * q);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -135,7 +150,7 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
     L.ctr[1] = carry[1];
     L.ctr[4] = rebuild ? 0 : n_tomb;
     if (L.hint_live) *L.hint_live = n_live;
-    *any_kill = 0;
+    if (!WMAX) *any_kill = 0;
   }
 }
 

@@ -990,7 +990,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     job.stat_new = 2;
     job.stamp = stamp;
     job.timeline = m->timeline;
-    if (do_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands out slots
+    if (do_decay && !light_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands out
+                                                               // slots (the light decay compacted in k_front already)
       job.kill = m->kill;
       job.any_kill = m->any_kill;
     }

@@ -185,12 +185,10 @@ struct DecayJob {
   uint8_t* kill;
   int* any_kill;
   int n_wgs;  // 0: no decay pending
-  int light;  // != 0: L.wmax is current -- decide the deallocations from it (one thread per block, no voxel access); the
-              // weights themselves are multiplied by the next k_tsdf_pass
+  int light;  // != 0: L.wmax is current -- ONE workgroup decides the deallocations from it and compacts the lists (no voxel
+              // access); the weights themselves are multiplied by the next k_tsdf_pass
 };
 
-template <bool ERASE>
-__device__ inline void decay_light_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb);
 
 template <bool LDSFLAGS>
 __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D) {
@@ -211,10 +209,16 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     // (Tried: decay workgroups first + "last one compacts" inside this launch -- an agent-scope fence per workgroup is a
     // full L2 write-back (339 us), atomics on one arrival counter serialise (69 us), and even with a two-level counter
     // the launch grew by 9 us while the next one shrank by 2.)
-    if (D.light)
-      decay_light_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
-    else
+    if (D.light) {
+      // wmax is current: ONE workgroup decides the dead blocks from it and compacts the live list / pushes the freed slots
+      // right here, beside the raycast (nothing else in this launch reads the layer's lists): the allocation workgroup of
+      // the next launch starts on a clean list.
+      __shared__ int s_scan[10], s_carry[2];
+      if (R.mc.dealloc_decayed)
+        live_compact_body<4, 16, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
+    } else {
       decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
+    }
     wg_trace_end(tr0, kTrFrontDecay);
   }
 }
@@ -632,27 +636,6 @@ __device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_
   }
 }
 
-// The deallocation decision of a decay whose multiplication is deferred to k_tsdf_pass: thread per live block.
-template <bool ERASE>
-__device__ inline void decay_light_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb) {
-  if (!mc.dealloc_decayed) return;
-  const int n = L.ctr[0];
-  for (int i = bid * (int)blockDim.x + (int)threadIdx.x; i < n; i += nb * (int)blockDim.x) {
-    const int slot = L.live[i];
-    const float w = L.wmax[slot] * mc.decay_factor;
-    if (w < mc.decay_thr) {  // every voxel: W f <= max(W) f < threshold
-      kill[i] = 1;
-      *any_kill = 1;
-      if (ERASE) {
-        const u64 key = L.slot_key[slot];
-        hash_erase(L, key);
-        dense_set(L, key, 0);
-        L.slot_key[slot] = kEmptyKey;
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t* __restrict__ kill, int* any_kill) {
   decay_body<false>(L, mc, kill, any_kill, blockIdx.x, gridDim.x);
 }
@@ -823,8 +806,7 @@ void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const
     D.kill = kill;
     D.any_kill = any_kill;
     D.light = light_decay ? 1 : 0;
-    D.n_wgs = light_decay ? (hinted(decay_layer->hint_live, decay_layer->cap) + 255) / 256
-                          : grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
+    D.n_wgs = light_decay ? 1 : grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
   }
   const dim3 grid(n_wgs + M.H + D.n_wgs);
   if (ncells <= kRaycastLdsCells)
