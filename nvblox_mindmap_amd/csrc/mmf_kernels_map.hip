@@ -194,8 +194,19 @@ template <bool LDSFLAGS>
 __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D) {
   extern __shared__ unsigned s_words[];
   __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
-  const int b = (int)blockIdx.x;
   const long long tr0 = wg_trace_begin();
+  // A pending Mapper.decay() touches only the TSDF layer and its lists, which neither other role reads.
+  if (D.light && blockIdx.x == 0) {
+    // wmax is current: ONE workgroup -- the first of the grid, so that it is long done when the last ray is -- decides the
+    // dead blocks from it and compacts the live list / pushes the freed slots right here, beside the raycast: the
+    // allocation workgroup of the next launch starts on a clean list.
+    __shared__ int s_scan[10], s_carry[2];
+    if (R.mc.dealloc_decayed)
+      live_compact_body<4, 16, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
+    wg_trace_end(tr0, kTrFrontDecay);
+    return;
+  }
+  const int b = (int)blockIdx.x - (D.light ? 1 : 0);
   if (b < n_ray_wgs) {
     raycast_body<LDSFLAGS>(R, b, s_words);
     wg_trace_end(tr0, kTrFrontRay);
@@ -203,22 +214,13 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     mask_rowbits_row(M, b - n_ray_wgs, s_in, s_d);
     wg_trace_end(tr0, kTrFrontMaskRows);
   } else {
-    // A pending Mapper.decay(): touches only the TSDF layer, which neither other role reads.  Each workgroup also drops
-    // the blocks it finds dead from the hash / dense table (in parallel, off the critical path); the order-preserving
+    // wmax stale (a stand-alone call wrote TSDF weights): the full pass over the voxels.  Each workgroup also drops the
+    // blocks it finds dead from the hash / dense table (in parallel, off the critical path); the order-preserving
     // compaction of the live list is the first thing the allocation workgroup of the next launch does.
     // (Tried: decay workgroups first + "last one compacts" inside this launch -- an agent-scope fence per workgroup is a
     // full L2 write-back (339 us), atomics on one arrival counter serialise (69 us), and even with a two-level counter
     // the launch grew by 9 us while the next one shrank by 2.)
-    if (D.light) {
-      // wmax is current: ONE workgroup decides the dead blocks from it and compacts the live list / pushes the freed slots
-      // right here, beside the raycast (nothing else in this launch reads the layer's lists): the allocation workgroup of
-      // the next launch starts on a clean list.
-      __shared__ int s_scan[10], s_carry[2];
-      if (R.mc.dealloc_decayed)
-        live_compact_body<4, 16, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
-    } else {
-      decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
-    }
+    decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
     wg_trace_end(tr0, kTrFrontDecay);
   }
 }

@@ -50,9 +50,9 @@ def main():
                 order = np.argsort(-dur)[:8]
                 print("  k_app_frame, slowest workgroups (us / survivors / feature block new / colour block new):",
                       ", ".join(f"{dur[o]:.1f}/{surv[o]}/{fnew[o]}/{cnew[o]}" for o in order))
-                for name, m in (("new feature blocks", (fnew == 1) & ~idle), ("old feature blocks", (fnew == 0) & ~idle), ("no block", idle)):
-                    if m.any():
-                        print(f"    {name}: n={int(m.sum())} mean {dur[m].mean():.2f} us, mean survivors {surv[m].mean():.0f}")
+                for name, sel in (("new feature blocks", (fnew == 1) & ~idle), ("old feature blocks", (fnew == 0) & ~idle), ("no block", idle)):
+                    if sel.any():
+                        print(f"    {name}: n={int(sel.sum())} mean {dur[sel].mean():.2f} us, mean survivors {surv[sel].mean():.0f}")
                 live = ~idle
                 if live.sum() > 10:
                     print(f"    correlation(duration, survivors) = {np.corrcoef(dur[live], surv[live])[0, 1]:.2f}")
