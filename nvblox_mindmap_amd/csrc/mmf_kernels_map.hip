@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     // wmax is current: ONE workgroup -- the first of the grid, so that it is long done when the last ray is -- decides the
     // dead blocks from it and compacts the live list / pushes the freed slots right here, beside the raycast: the
     // allocation workgroup of the next launch starts on a clean list.
+    // (8 entries per thread, not 16: the launch's register count is that of its largest role, and at 86 VGPRs the raycast
+    // ran at 5 waves per SIMD instead of 7 -- the mask rows had to wait for a slot.)
     __shared__ int s_scan[10], s_carry[2];
     if (R.mc.dealloc_decayed)
-      live_compact_body<4, 16, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
+      live_compact_body<4, 8, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
     wg_trace_end(tr0, kTrFrontDecay);
     return;
   }
