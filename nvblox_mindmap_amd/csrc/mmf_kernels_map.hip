@@ -511,16 +511,18 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // VPT voxels per thread (z-adjacent, 16-byte accesses), 512 / VPT threads per block.  VPT = 4: two waves per block, so every
 // live block of a bounded workspace is resident at once (at four waves per block 1 792 of ~2 300 fitted and the rest formed a
 // second round).
-template <int VPT>
+// MASKED = false: the depth image is already masked (the fused frame's masked depth): the mask taps are compiled out.
+template <int VPT, bool MASKED>
 __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
-                                                        const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ depth, const uint8_t* __restrict__ mask_arg,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
                                                         u64* __restrict__ cell_key, float decay_f) {
   // decay_f > 0: a Mapper.decay() is pending whose deallocations k_front already made from L.wmax -- its W *= f is applied
   // here, on the voxels this pass loads anyway (and every block is written back).  L.wmax is refreshed for every live block.
-  static_assert(VPT == 2 || VPT == 4, "one or two 16-byte voxel pairs per thread");
+  static_assert(VPT == 2 || VPT == 4 || VPT == 8, "one, two or four 16-byte voxel pairs per thread");
   __shared__ float s_wmax[512 / VPT / 64];
   constexpr int NP = VPT / 2;  // float4 = two {distance, weight} voxels
+  const uint8_t* __restrict__ mask = MASKED ? mask_arg : nullptr;
   const long long tr0 = wg_trace_begin();
   const int n = L.ctr[0];
   const int chunk = (n + 7) >> 3;
@@ -554,9 +556,13 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
       const bool hi = (r & 1) != 0;
       float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
       float c[3], p[3], u, v;
-      voxel_centre(mc, bx, by, bz, threadIdx.x * VPT + r, c);
-      xform(T_C_L, c, p);
-      const bool in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+      // the projection is needed by the update (cand) and by the appearance flag of a near-surface voxel only
+      bool in_view = false;
+      if (cand || (W > 0.0f && fabsf(D) < mc.trunc)) {
+        voxel_centre(mc, bx, by, bz, threadIdx.x * VPT + r, c);
+        xform(T_C_L, c, p);
+        in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+      }
       if (cand && in_view) {
         float d;
         if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
@@ -962,8 +968,11 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
 
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
-  hipLaunchKernelGGL(k_tsdf_pass<4>, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask,
-                     min_d, stamp, flags, cell_key, decay_f);
+  const dim3 grid(grid_for(hinted(L.hint_live, L.cap), 8192));
+  if (mask)
+    hipLaunchKernelGGL((k_tsdf_pass<4, true>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
+  else
+    hipLaunchKernelGGL((k_tsdf_pass<4, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {
