@@ -321,4 +321,149 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
 }
 
 
+// The allocation job of k_alloc_tsdf: dense-table layer, view-grid cells, shared by `nwg` workgroups of 64 * NW threads that
+// each take ONE pass over 64 * NW * 4 * G consecutive cells (4 * G consecutive cells per thread; grid coordinates are stepped,
+// not divided out; keys are packed only for the flagged cells).  Workgroup w publishes its candidate / new-block counts and
+// sums those of the workgroups before it (decoupled prefix: w words to read, all published within a microsecond of each other;
+// workgroups are dispatched in index order and never wait on a later one), so the whole job is one load round trip + one
+// workgroup scan + the writes instead of a pass per 2 048 cells in sequence.  Same candidate order, slot assignment and
+// outputs as alloc_job_body<true, 0>.  Every granted new block is also published to the launch as it is assigned: three
+// self-validating 64-bit words {tag | slot}, {tag | key low}, {tag | key high} at J.pub[kPubRec + 3 * rank ..]; the last
+// workgroup publishes the number of granted blocks {tag | n} at J.pub[0].  All with relaxed agent-scope atomics, no fences: a
+// reader polls until the tag of the word it needs is this launch's.  The grid flags are left set: the launch's TSDF
+// workgroups read them too; a later launch of the frame clears them.
+constexpr int kPubRec = 16;      // J.pub: [0] total, [1 .. 8] per-workgroup counts, [kPubRec ..] new-block records
+constexpr int kAllocMaxWgs = 8;  // kFusedAllocMaxCells / 2 048
+template <int NW, int G>
+__device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx, int w, int nwg) {
+  const LayerDev& L = J.L;
+  const KeySrc& ks = J.ks;
+  const Scratch& sc = J.sc;
+  constexpr int NT = 64 * NW, CPT = 4 * G;
+  const int ncells = J.ncells;
+  if (threadIdx.x == 0) {
+    if (w == 0 && J.zero_me) *J.zero_me = 0;
+    ctx[0] = L.ctr[0];
+    ctx[1] = L.ctr[1];
+    ctx[2] = L.ctr[2];
+    ctx[3] = L.ctr[1] + (L.cap - L.ctr[2]);  // room
+  }
+  // (no barrier: ctx is first read after the barriers of the workgroup scan below)
+  const u64 tg = (u64)J.pub_tag << 32;
+  const int cell0 = w * NT * CPT + (int)threadIdx.x * CPT;
+  const int gz0 = cell0 % ks.nz, t0 = cell0 / ks.nz, gy0 = t0 % ks.ny, gx0 = t0 / ks.ny;
+  uint32_t f[G];
+  int d[CPT];
+  {  // every load before the first is consumed; cells past the grid read entry 0 and are masked
+    int gx = gx0, gy = gy0, gz = gz0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c4 = cell0 + 4 * g;
+      f[g] = *reinterpret_cast<const uint32_t*>(sc.flags + (unsigned)(c4 < ncells ? c4 : 0));
+      if (c4 >= ncells) f[g] = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool in = c4 + k < ncells;
+        if (!in) f[g] &= ~(0xffu << (8 * k));  // stale flags beyond the grid
+        const unsigned idx = in ? (unsigned)dense_cell(L, gx + ks.ox, gy + ks.oy, gz + ks.oz) : 0u;
+        d[4 * g + k] = (int)L.dense[idx];
+        if (++gz == ks.nz) {
+          gz = 0;
+          if (++gy == ks.ny) {
+            gy = 0;
+            ++gx;
+          }
+        }
+      }
+    }
+  }
+  int nf = 0, nn = 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((f[g] >> (8 * k)) & 0xffu) {
+        nf++;
+        nn += d[4 * g + k] == 0;
+      }
+  int ea, eb, ta, tb;
+  block_excl_scan2<NW>(nf, nn, lds, ea, eb, ta, tb);
+  if (threadIdx.x == 0) {
+    // (ctx above is complete: thread 0 passed the scan's barriers after writing it)
+    __hip_atomic_store(J.pub + 1 + w, tg | ((u64)(unsigned)ta << 16) | (u64)(unsigned)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int pa = 0, pb = 0;
+    for (int v = 0; v < w; ++v) {
+      u64 x = 0;
+      for (int spins = 0; spins < (1 << 22); ++spins) {
+        x = __hip_atomic_load(J.pub + 1 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == J.pub_tag) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if ((unsigned)(x >> 32) != J.pub_tag) atomicOr(&L.ctr[3], 2);  // gave up waiting (never observed)
+      pa += (int)((x >> 16) & 0xffffu);
+      pb += (int)(x & 0xffffu);
+    }
+    carry[0] = pa;
+    carry[1] = pb;
+  }
+  __syncthreads();
+  const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
+  if (nf) {
+    int pos = carry[0] + ea, rnk = carry[1] + eb;
+    int gx = gx0, gy = gy0, gz = gz0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((f[g] >> (8 * k)) & 0xffu) {
+          const u64 key = pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
+          int slot = d[4 * g + k] - 1;
+          const bool is_new = slot < 0;
+          if (is_new) {
+            if (rnk < room) {
+              slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
+              L.dense[dense_cell(L, gx + ks.ox, gy + ks.oy, gz + ks.oz)] = (unsigned short)(slot + 1);
+              L.slot_key[slot] = key;
+              L.live[old_live + rnk] = slot;
+              u64* rec = J.pub + kPubRec + 3 * (size_t)rnk;
+              __hip_atomic_store(rec, tg | (u64)(unsigned)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(rec + 1, tg | (key & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(rec + 2, tg | (key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            rnk++;
+          }
+          sc.cand_slot[pos] = slot;
+          sc.cand_key[pos] = key;
+          sc.cand_new[pos] = is_new ? 1 : 0;
+          if (J.stamp && slot >= 0) L.stamp[slot] = (J.stamp << 1) | (is_new ? 1 : 0);
+          pos++;
+        }
+        if (++gz == ks.nz) {
+          gz = 0;
+          if (++gy == ks.ny) {
+            gy = 0;
+            ++gx;
+          }
+        }
+      }
+  }
+  if (w == nwg - 1 && threadIdx.x == 0) {  // the last workgroup knows the totals
+    const int n_cand = carry[0] + ta, n_new = carry[1] + tb;
+    const int granted = n_new < room ? n_new : room;
+    if (granted < n_new) atomicOr(&L.ctr[3], 1);
+    const int from_free = granted < old_free ? granted : old_free;
+    L.ctr[0] = old_live + granted;
+    L.ctr[1] = old_free - from_free;
+    L.ctr[2] = old_bump + (granted - from_free);
+    *sc.cand_count = n_cand;
+    if (sc.hint_cand) *sc.hint_cand = n_cand;
+    if (L.hint_live) *L.hint_live = old_live + granted;
+    __hip_atomic_store(J.pub, tg | (u64)(unsigned)granted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stats) {
+      if (J.stat_upd >= 0) stats[J.stat_upd] += n_cand;
+      if (J.stat_new >= 0) stats[J.stat_new] += granted;
+    }
+  }
+}
+
 }  // namespace mmf

@@ -56,6 +56,7 @@ struct Mapper {
   int* hints = nullptr;  // pinned host ints the device publishes counts to: [0..2] candidates of sc[0..2], [3..5] live blocks  // depth with invalid / masked pixels zeroed (written by the mask row pass)
   uint8_t* kill = nullptr;
   int* any_kill = nullptr;
+  u64* pub = nullptr;          // [16 + 3 * cap] new blocks published by the allocation workgroup of k_alloc_tsdf to its own launch
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
   long long frames[3] = {0, 0, 0};
   // synthetic depth + cache key
@@ -391,6 +392,8 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   HIP_TRY(hipMemset(m->tsdf.d.stamp, 0, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
   HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
+  HIP_TRY(hipMalloc(&m->pub, sizeof(u64) * (16 + 3 * (size_t)cap)));
+  HIP_TRY(hipMemset(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)cap)));
   HIP_TRY(hipMalloc(&m->any_kill, sizeof(int)));
   HIP_TRY(hipMemset(m->any_kill, 0, sizeof(int)));
   HIP_TRY(hipMalloc(&m->stats, sizeof(long long) * MMF_NUM_STATS));
@@ -429,6 +432,7 @@ void destroy_mapper(Mapper* m) {
   (void)hipFree(m->flat.count);
   if (m->hints) (void)hipHostFree(m->hints);
   (void)hipFree(m->kill);
+  (void)hipFree(m->pub);
   (void)hipFree(m->any_kill);
   (void)hipFree(m->stats);
   (void)hipFree(m->synth);
@@ -966,43 +970,58 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   // wmax current (the previous writer of the TSDF weights was a fused frame): the decay's deallocations are decided from it by
   // a dozen workgroups and its W *= f rides in this frame's k_tsdf_pass -- no extra pass over the layer
   const bool light_decay = do_decay && m->wmax_valid;
+  // Merged launch 2 (k_alloc_tsdf): bounded workspace and no voxel-pass decay in this frame -- the live list is final when
+  // k_front ends, so the TSDF pass of the existing blocks runs beside the allocation workgroup instead of after it.
+  const bool merged = m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
   {
     // raycast tiles | mask row pass | pending decay of the TSDF layer
     ProfScope ps(h, MMF_K_RAYCAST, s);
     launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
-                 light_decay, m->kill, m->any_kill, s);
+                 light_decay, m->kill, m->any_kill, merged ? m->tsdf.d.ctr : nullptr, s);
   }
-  {
-    ProfScope ps(h, MMF_K_ALLOC, s);
-    KeySrc ks{};
-    ks.mode = 0;
-    ks.ox = vg.ox;
-    ks.oy = vg.oy;
-    ks.oz = vg.oz;
-    ks.ny = vg.ny;
-    ks.nz = vg.nz;
-    AllocJob job;
-    job.L = m->tsdf.d;
-    job.ks = ks;
-    job.sc = m->sc[0];
-    job.ncells = ncells;
-    job.stat_upd = 1;
-    job.stat_new = 2;
-    job.stamp = stamp;
-    job.timeline = m->timeline;
-    if (do_decay && !light_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands out
-                                                               // slots (the light decay compacted in k_front already)
-      job.kill = m->kill;
-      job.any_kill = m->any_kill;
-    }
-    launch_alloc_jobs(&job, 1, m->stats, &M, s);
-  }
-  {
-    // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
+  KeySrc ks0{};
+  ks0.mode = 0;
+  ks0.ox = vg.ox;
+  ks0.oy = vg.oy;
+  ks0.oz = vg.oz;
+  ks0.ny = vg.ny;
+  ks0.nz = vg.nz;
+  AllocJob job0;
+  job0.L = m->tsdf.d;
+  job0.ks = ks0;
+  job0.sc = m->sc[0];
+  job0.ncells = ncells;
+  job0.stat_upd = 1;
+  job0.stat_new = 2;
+  job0.stamp = stamp;
+  job0.timeline = m->timeline;
+  if (merged) {
+    // TSDF allocation | mask column pass | TSDF update + appearance-candidate flags of every live block
     ProfScope ps(h, MMF_K_TSDF, s);
-    launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key,
-                     light_decay ? m->mc.decay_factor : 0.0f, s);
-    m->wmax_valid = true;  // k_tsdf_pass refreshed it for every live block
+    job0.pub = m->pub;
+    job0.pub_tag = (unsigned)stamp;
+    if ((m->tsdf_epoch & 0x3fffffff) == 0)  // the 30-bit tag wraps (once in 2^30 frames): no stale word may carry a tag again
+      HIP_TRY(hipMemsetAsync(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)m->tsdf.d.cap), s));
+    launch_alloc_tsdf(job0, m->stats, M, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
+                      light_decay ? m->mc.decay_factor : 0.0f, s);
+    m->wmax_valid = true;  // refreshed for every live block
+  } else {
+    {
+      ProfScope ps(h, MMF_K_ALLOC, s);
+      if (do_decay && !light_decay && m->mc.dealloc_decayed) {  // dead blocks leave the live list before the allocation hands
+                                                                 // out slots (the light decay compacted in k_front already)
+        job0.kill = m->kill;
+        job0.any_kill = m->any_kill;
+      }
+      launch_alloc_jobs(&job0, 1, m->stats, &M, s);
+    }
+    {
+      // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
+      ProfScope ps(h, MMF_K_TSDF, s);
+      launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key,
+                       light_decay ? m->mc.decay_factor : 0.0f, s);
+      m->wmax_valid = true;  // k_tsdf_pass refreshed it for every live block
+    }
   }
   {
     // sphere trace | colour allocation | feature allocation: one launch
@@ -1039,7 +1058,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   {
     ProfScope ps(h, MMF_K_FEATURE, s);
     launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
+                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
+                          merged ? m->sc[0].flags : nullptr, ncells);
   }
   {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);

@@ -125,6 +125,8 @@ struct AllocJob {
   int* any_kill = nullptr;
   int* zero_me = nullptr;  // != null: an int this job resets (the frame's feature survivor counter)
   long long* timeline = nullptr;  // != null: thread 0 stores wall_clock64() (100 MHz) at 6 points of the job (diagnostics)
+  u64* pub = nullptr;      // alloc_grid_multi_body: [16 + 3 * cap] published counts and new blocks (see there)
+  unsigned pub_tag = 0;
 };
 
 __host__ __device__ inline u64 pack_key(int x, int y, int z) {

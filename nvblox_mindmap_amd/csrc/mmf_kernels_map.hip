@@ -191,7 +191,7 @@ struct DecayJob {
 
 
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D) {
+__global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D, int* snap_ctr) {
   extern __shared__ unsigned s_words[];
   __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
   const long long tr0 = wg_trace_begin();
@@ -205,10 +205,14 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     __shared__ int s_scan[10], s_carry[2];
     if (R.mc.dealloc_decayed)
       live_compact_body<4, 8, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
+    // (thread 0 wrote ctr[0] itself.)  ctr[6] = the live count k_alloc_tsdf's pass over the EXISTING blocks runs to, while the
+    // allocation workgroup of that launch appends to the list and moves ctr[0]
+    if (snap_ctr && threadIdx.x == 0) snap_ctr[6] = snap_ctr[0];
     wg_trace_end(tr0, kTrFrontDecay);
     return;
   }
   const int b = (int)blockIdx.x - (D.light ? 1 : 0);
+  if (snap_ctr && !D.light && b == 0 && threadIdx.x == 0) snap_ctr[6] = snap_ctr[0];
   if (b < n_ray_wgs) {
     raycast_body<LDSFLAGS>(R, b, s_words);
     wg_trace_end(tr0, kTrFrontRay);
@@ -612,6 +616,227 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
   wg_trace_end(tr0, kTrTsdfPass);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3c. Allocation | mask columns | TSDF pass in ONE launch (bounded workspace, fused frame).
+//     The TSDF pass does not need the allocation's result for the blocks that already exist: whether such a block is
+//     integrated this frame is the raycast flag of its view-grid cell, and its position in the live list is final once
+//     k_front has compacted the list.  So the existing blocks (all of them in steady state but a few dozen) are
+//     processed BESIDE the allocation workgroup, whose ~8 us chain used to stand alone on the critical path with a launch
+//     boundary on either side.  The new blocks of the frame are handled by a few workgroups at the end of the grid that
+//     wait for the allocation workgroup of the same launch: it publishes {slot, key} of every new block and their number
+//     as self-validating tagged words with relaxed agent-scope atomics (alloc_grid_multi_body; the scheme of the grouped
+//     FPS kernel: no fences, bounded polling).  The allocation workgroup is block 0, so it is resident before any waiter.
+//     256-thread workgroups; a TSDF workgroup holds TWO blocks (one per half, 4 voxels per thread as in k_tsdf_pass).
+// ------------------------------------------------------------------------------------------------
+struct TsdfFrameArgs {
+  MapConsts mc;
+  Cam cam;
+  Rigid T_C_L;
+  const float* depth;         // the frame's masked depth image
+  const uint8_t* grid_flags;  // raycast flags of the view grid (left set by the PUB allocation job)
+  int ox, oy, oz, nx, ny, nz; // view grid
+  uint8_t* flags_out;         // [live position] appearance-candidate flag
+  u64* cell_key_out;
+  float decay_f;              // > 0: pending decay's W *= f (its deallocations were made by k_front)
+  const int* n_old;           // live blocks before this frame's allocation (ctr[6], published by k_front)
+  const u64* pub;             // the allocation job's published new blocks
+  unsigned tag;
+  int* err;                   // layer error flags (ctr[3]): bit 1 = a waiter gave up
+  int n_pair_wgs, n_new_wgs;
+};
+
+struct TsdfPairLds {
+  int free_[2][4], hit[2][4];
+  float wmax[2][4];
+  int slot[2], act[2];
+  unsigned klo[2], khi[2];
+};
+
+// One block by one half (128 threads) of the workgroup; `par` alternates between consecutive calls of a workgroup so that
+// the reduction scratch of one call is not overwritten before everybody has read it.  Contains ONE barrier: call uniformly.
+__device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int par, bool act, int i,
+                                        int slot, u64 key, bool cand, bool is_new) {
+  const int t = threadIdx.x & 127, wv = threadIdx.x >> 6;
+  const MapConsts& mc = P.mc;
+  int hit = 0, freev = 1;
+  float wmx = 0.0f;
+  const bool decayed = P.decay_f > 0.0f;  // uniform
+  if (act) {
+    int bx, by, bz;
+    unpack_key(key, bx, by, bz);
+    float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + t * 2;
+    float4 av[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
+    if (decayed) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        av[q].y = av[q].y * P.decay_f;
+        av[q].w = av[q].w * P.decay_f;
+      }
+    }
+    bool upd = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4& a = av[r >> 1];
+      const bool hi = (r & 1) != 0;
+      float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
+      float c[3], p[3], u, v;
+      bool in_view = false;
+      if (cand || (W > 0.0f && fabsf(D) < mc.trunc)) {
+        voxel_centre(mc, bx, by, bz, t * 4 + r, c);
+        xform(P.T_C_L, c, p);
+        in_view = project(P.cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+      }
+      if (cand && in_view) {
+        float d;
+        if (sample_depth(mc, P.depth, nullptr, 0.0f, P.cam, u, v, d)) {
+          float sdf = d - p[2];
+          if (!(sdf < -mc.trunc)) {
+            float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
+            float Dn = (sdf * wm + D * W) / (wm + W);
+            Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+            D = Dn;
+            W = fminf(W + wm, mc.max_weight);
+            upd = true;
+          }
+        }
+      }
+      if (hi) {
+        a.z = D;
+        a.w = W;
+      } else {
+        a.x = D;
+        a.y = W;
+      }
+      hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
+      freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
+      wmx = fmaxf(wmx, W);
+    }
+    if (upd || is_new || decayed) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) vox[q] = av[q];
+    }
+  }
+  const int w_free = __all(freev), w_hit = __any(hit);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    S.free_[par][wv] = w_free;
+    S.hit[par][wv] = w_hit;
+    S.wmax[par][wv] = wmx;
+  }
+  __syncthreads();
+  if (act && t == 0) {
+    const int h2 = (threadIdx.x >> 7) * 2;
+    if (cand || decayed) L.block_free[slot] = (S.free_[par][h2] && S.free_[par][h2 + 1]) ? 1 : 0;
+    const int any = S.hit[par][h2] | S.hit[par][h2 + 1];
+    P.flags_out[i] = any ? 1 : 0;
+    if (any) P.cell_key_out[i] = key;
+    L.wmax[slot] = fmaxf(S.wmax[par][h2], S.wmax[par][h2 + 1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_alloc_tsdf(AllocJob J, long long* stats, int alloc_wgs, MaskJob M, int mask_rows, int lead,
+                                                   TsdfFrameArgs P) {
+  __shared__ int lds[34];
+  __shared__ int carry[2];
+  __shared__ int ctx[4];
+  __shared__ u64 s_bad[kMaxMaskWords];
+  __shared__ TsdfPairLds S;
+  const long long tr0 = wg_trace_begin();
+  const int b = (int)blockIdx.x;
+  const LayerDev& L = J.L;
+  if (b < alloc_wgs) {
+    alloc_grid_multi_body<4, 2>(J, stats, lds, carry, ctx, b, alloc_wgs);
+    wg_trace_end(tr0, kTrAllocJob);
+    return;
+  }
+  if (b - alloc_wgs < mask_rows) {
+    mask_colemit_row(M, b - alloc_wgs, s_bad);
+    wg_trace_end(tr0, kTrAllocMaskCols);
+    return;
+  }
+  if (b < lead) return;  // padding: the TSDF workgroups start at a multiple of 8 (workgroup -> XCD residue)
+  const int half = threadIdx.x >> 7;
+  const int n_old = *P.n_old;
+  const int c = b - lead;
+  if (c < P.n_pair_wgs) {
+    // existing blocks, two list-adjacent ones per workgroup, pairs in XCD-contiguous chunks
+    const int npairs = (n_old + 1) >> 1;
+    const int chunk = (npairs + 7) >> 3;
+    int par = 0;
+    for (int j = c; j < chunk * 8; j += P.n_pair_wgs, par ^= 1) {
+      const int i = 2 * xcd_candidate(j, chunk) + half;
+      const bool act = i < n_old;
+      int slot = 0;
+      u64 key = 0;
+      bool cand = false;
+      if (act) {
+        slot = L.live[i];
+        key = L.slot_key[slot];
+        int bx, by, bz;
+        unpack_key(key, bx, by, bz);
+        const int gx = bx - P.ox, gy = by - P.oy, gz = bz - P.oz;
+        if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.nx && gy < P.ny && gz < P.nz)
+          cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] != 0;
+      }
+      tsdf_frame_block(L, P, S, par, act, i, slot, key, cand, false);
+    }
+    wg_trace_end(tr0, kTrTsdfPass);
+    return;
+  }
+  // new blocks: rank k is taken as soon as the allocation workgroup of this launch has published it (it may still be
+  // scanning later cells); the published total ends the loop
+  const int d = c - P.n_pair_wgs;
+  int par = 0;
+  for (int k0 = d * 2;; k0 += P.n_new_wgs * 2) {
+    const int k = k0 + half;
+    if ((threadIdx.x & 127) == 0) {
+      int got = 0;
+      u64 w0 = 0;
+      for (int spins = 0; spins < (1 << 22); ++spins) {
+        w0 = __hip_atomic_load(P.pub + kPubRec + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w0 >> 32) == P.tag) {
+          got = 1;
+          break;
+        }
+        const u64 tot = __hip_atomic_load(P.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(tot >> 32) == P.tag) {
+          // (a rank below the total was published before the total: one more look at its word settles it)
+          if (k >= (int)(unsigned)(tot & 0xffffffffull)) {
+            got = -1;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (got == 0) atomicOr(P.err, 2);  // gave up waiting (never observed)
+      if (got == 1) {
+        u64 w1, w2;
+        int spins = 0;
+        do {
+          w1 = __hip_atomic_load(P.pub + kPubRec + 1 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w2 = __hip_atomic_load(P.pub + kPubRec + 2 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (((unsigned)(w1 >> 32) != P.tag || (unsigned)(w2 >> 32) != P.tag) && ++spins < (1 << 22));
+        S.slot[half] = (int)(unsigned)(w0 & 0xffffffffull);
+        S.klo[half] = (unsigned)(w1 & 0xffffffffull);
+        S.khi[half] = (unsigned)(w2 & 0xffffffffull);
+      }
+      S.act[half] = got == 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!S.act[0]) break;  // ranks are granted in order: nothing beyond a missing one
+    const bool act = S.act[half] != 0;
+    const int slot = S.slot[half];
+    const u64 key = ((u64)S.khi[half] << 32) | (u64)S.klo[half];
+    tsdf_frame_block(L, P, S, par, act, n_old + k, slot, key, true, true);
+    par ^= 1;
+    __syncthreads();  // S.slot / klo / khi / act are rewritten by the next round
+  }
+  wg_trace_end(tr0, kTrTsdfNew);
+}
+
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_map)
 
 // ------------------------------------------------------------------------------------------------
@@ -805,7 +1030,7 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
 // raycast + mask row pass in one launch
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                   int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
-                  uint8_t* kill, int* any_kill, hipStream_t s) {
+                  uint8_t* kill, int* any_kill, int* snap_ctr, hipStream_t s) {
   int n_wgs;
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
   R.mask_invert = M.invert;
@@ -820,9 +1045,9 @@ void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const
   }
   const dim3 grid(n_wgs + M.H + D.n_wgs);
   if (ncells <= kRaycastLdsCells)
-    hipLaunchKernelGGL(k_front<true>, grid, dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R, n_wgs, M, D);
+    hipLaunchKernelGGL(k_front<true>, grid, dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R, n_wgs, M, D, snap_ctr);
   else
-    hipLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, R, n_wgs, M, D);
+    hipLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, R, n_wgs, M, D, snap_ctr);
 }
 
 constexpr int kFusedAllocMaxCells = 16384;
@@ -973,6 +1198,32 @@ void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, co
     hipLaunchKernelGGL((k_tsdf_pass<4, true>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
   else
     hipLaunchKernelGGL((k_tsdf_pass<4, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
+}
+
+// allocation | mask columns | TSDF pass (existing blocks beside the allocation, new blocks behind it): k_alloc_tsdf
+void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L,
+                       const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out, float decay_f,
+                       hipStream_t s) {
+  TsdfFrameArgs P;
+  P.mc = mc;
+  P.cam = cam;
+  P.T_C_L = T_C_L;
+  P.depth = masked_depth;
+  P.grid_flags = job.sc.flags;
+  P.ox = vg.ox, P.oy = vg.oy, P.oz = vg.oz, P.nx = vg.nx, P.ny = vg.ny, P.nz = vg.nz;
+  P.flags_out = flags_out;
+  P.cell_key_out = cell_key_out;
+  P.decay_f = decay_f;
+  P.n_old = job.L.ctr + 6;
+  P.pub = job.pub;
+  P.tag = job.pub_tag;
+  P.err = job.L.ctr + 3;
+  P.n_pair_wgs = grid_for((hinted(job.L.hint_live, job.L.cap) + 1) / 2, 8192);
+  P.n_new_wgs = 32;
+  const int rows = M.Hf;
+  const int alloc_wgs = (job.ncells + 2047) / 2048;  // alloc_grid_multi_body<4, 2>: 2 048 cells per workgroup (<= kAllocMaxWgs)
+  const int lead = (alloc_wgs + rows + 7) & ~7;
+  hipLaunchKernelGGL(k_alloc_tsdf, dim3(lead + P.n_pair_wgs + P.n_new_wgs), dim3(256), 0, s, job, stats, alloc_wgs, M, rows, lead, P);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

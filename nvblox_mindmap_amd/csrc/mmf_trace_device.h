@@ -49,7 +49,7 @@ constexpr int kWgTraceBuilt = 0;
 enum : int {
   kTrFrontRay = 10, kTrFrontMaskRows = 11, kTrFrontDecay = 12,
   kTrAllocJob = 20, kTrAllocMaskCols = 21,
-  kTrTsdfPass = 30,
+  kTrTsdfPass = 30, kTrTsdfNew = 31,
   kTrSphereAlloc = 40, kTrSphereTrace = 41,
   kTrAppFrame = 50,
   kTrFeatureFlat = 60,

@@ -17,7 +17,7 @@ from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox
 from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg  # noqa: E402
 
 NAMES = {10: "k_front raycast", 11: "k_front mask rows", 12: "k_front decay", 20: "k_alloc_jobs allocation", 21: "k_alloc_jobs mask cols",
-         30: "k_tsdf_pass", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame", 60: "k_feature_flat"}
+         30: "k_tsdf_pass", 31: "k_alloc_tsdf new blocks", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame", 60: "k_feature_flat"}
 
 
 def main():
