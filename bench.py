@@ -600,7 +600,7 @@ def main():
                 "feature_voxels_updated_per_launch": feat_voxels_per_frame,
                 "feature_blocks_per_launch": feat_blocks_per_frame,
                 "measured_d2d_copy_GBps": measure_d2d_copy(device),  # read + write rate of a 1 GiB copy on this box
-                "note": "at C=64 the frame is 6 latency-bound launches of 7-17 us (kernel_us_per_launch); this kernel is "
+                "note": "at C=64 the frame is 5 latency-bound launches of 7-17 us (kernel_us_per_launch); this kernel is "
                         "the HBM-bound one and dominates at the reference shape (reference_shape.k_feature_flat_*)",
                 "survey_8d_model_bytes_per_frame": model_bytes,
             }

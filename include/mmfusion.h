@@ -118,9 +118,9 @@ int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat_f16_dev,
  *   feature_mask = border & nearest_upsample(erode(input_mask,k_in) & erode(depth>min_depth_m,k_depth)) -> feature_mask_out [Hf,Wf] u8
  *   add_depth_frame(depth, mask=depth_mask); add_color_frame(rgb, mask=depth_mask);
  *   add_feature_frame(feat, K scaled by (Wf/W, Hf/H), mask=feature_mask)
- * Results are identical to the four separate calls.  Everything is enqueued on `stream`, in order, as six launches
+ * Results are identical to the four separate calls.  Everything is enqueued on `stream`, in order, as five launches
  * whose independent roles are fused horizontally (raycast | mask rows | a pending mmf_decay, TSDF allocation | mask
- * columns, TSDF update + candidate flags, sphere trace | colour / feature allocation, colour update + feature gating,
+ * columns | TSDF update + candidate flags, sphere trace | colour / feature allocation, colour update + feature gating,
  * balanced feature-row update).  Requires (Hf,Wf) == (H,W).  input_mask: [H,W] u8 (or torch bool bytes). */
 int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth_dev, const uint8_t* rgb_dev, const void* feat_f16_dev,
                         const uint8_t* input_mask_dev, int H, int W, int Hf, int Wf, int C, const float* T_W_C_host,

@@ -16,8 +16,8 @@ from nvblox_mindmap_amd import synthetic as S  # noqa: E402
 from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper  # noqa: E402
 from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg  # noqa: E402
 
-NAMES = {10: "k_front raycast", 11: "k_front mask rows", 12: "k_front decay", 20: "k_alloc_jobs allocation", 21: "k_alloc_jobs mask cols",
-         30: "k_tsdf_pass", 31: "k_alloc_tsdf new blocks", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame", 60: "k_feature_flat"}
+NAMES = {10: "k_front raycast", 11: "k_front mask rows", 12: "k_front decay", 20: "allocation workgroups", 21: "mask cols",
+         30: "TSDF pass (existing blocks)", 31: "TSDF pass (new blocks)", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame", 60: "k_feature_flat"}
 
 
 def main():
