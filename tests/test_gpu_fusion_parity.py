@@ -12,7 +12,7 @@ import torch
 
 from nvblox_mindmap_amd import synthetic as S
 
-from fusion_common import frame_masks, make_mapper, make_oracle, small_cfg, sort_rows
+from fusion_common import REF_PARAMS, frame_masks, make_mapper, make_oracle, small_cfg, sort_rows
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -608,3 +608,43 @@ def test_lazy_decay_deallocates_in_fused_frames_and_survives_interleaved_standal
     compare_tsdf(orc, gpu)
     _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [10, 200], 8)
     assert orc.num_blocks(0) > 0 and n_after_orbit > 0
+
+
+def test_merged_allocation_and_tsdf_launch_under_pool_exhaustion():
+    """k_alloc_tsdf with fewer pool slots than the view needs: the allocation grants what fits, the workgroups that wait for new
+    blocks stop at the granted count (no hang), the error is reported, and later frames keep running on the full pool."""
+    from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
+    from nvblox_mindmap_amd.nvblox_torch.mapper_params import BlockMemoryPoolParams, MapperParams, ViewCalculatorParams
+
+    mp = MapperParams()
+    pool = BlockMemoryPoolParams()
+    pool.num_preallocated_blocks = 96
+    mp.set_block_memory_pool_params(pool)
+    vc = ViewCalculatorParams()
+    vc.workspace_bounds_type = "kBoundingBox"
+    for k, v in zip(("x", "y"), (0, 1)):
+        setattr(vc, f"workspace_bounds_min_corner_{k}_m", float(REF_PARAMS["ws_min"][v]))
+        setattr(vc, f"workspace_bounds_max_corner_{k}_m", float(REF_PARAMS["ws_max"][v]))
+    vc.workspace_bounds_min_height_m = float(REF_PARAMS["ws_min"][2])
+    vc.workspace_bounds_max_height_m = float(REF_PARAMS["ws_max"][2])
+    mp.set_view_calculator_params(vc)
+    m = Mapper(voxel_sizes_m=0.01, mapper_parameters=mp, feature_channels=8)
+    cfg = small_cfg(4)
+    for i in (0, 5, 10):
+        f = S.frame(cfg, i, 8)
+        m.decay()
+        m.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), dev(np.ones(f["depth"].shape, dtype=bool)),
+                          torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), 0.3, 1, 1, 0, 0)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="pool exhausted"):
+        m.tsdf_layer_view(0).num_allocated_blocks()
+
+
+def test_merged_launch_with_churn_matches_oracle(oracle_mod):
+    """Every frame of this sequence deallocates blocks (strong decay) and allocates others while the camera jumps around the
+    orbit: k_alloc_tsdf's pass over the existing blocks runs beside an allocation that reuses the freed slots, its new-block
+    workgroups take dozens to hundreds of published blocks.  Block sets, order and values equal the oracle's."""
+    cfg = small_cfg(4)
+    over = dict(tsdf_decay_factor=0.3, decayed_weight_threshold=5e-2)
+    gpu, orc = make_mapper(8, **over), make_oracle(oracle_mod, 8, **over)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 90, 10, 200, 100, 20, 300, 110, 30], 8)
