@@ -341,6 +341,8 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
   const Scratch& sc = J.sc;
   constexpr int NT = 64 * NW, CPT = 4 * G;
   const int ncells = J.ncells;
+  long long* tl = (J.timeline && w == nwg - 1 && threadIdx.x == 0) ? J.timeline : nullptr;  // diagnostics: the last workgroup
+  if (tl) tl[0] = tl[1] = wall_clock64();
   if (threadIdx.x == 0) {
     if (w == 0 && J.zero_me) *J.zero_me = 0;
     ctx[0] = L.ctr[0];
@@ -386,8 +388,10 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
         nf++;
         nn += d[4 * g + k] == 0;
       }
+  if (tl) tl[2] = wall_clock64();  // loads consumed
   int ea, eb, ta, tb;
   block_excl_scan2<NW>(nf, nn, lds, ea, eb, ta, tb);
+  if (tl) tl[3] = wall_clock64();  // scan done
   if (threadIdx.x == 0) {
     // (ctx above is complete: thread 0 passed the scan's barriers after writing it)
     __hip_atomic_store(J.pub + 1 + w, tg | ((u64)(unsigned)ta << 16) | (u64)(unsigned)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -407,6 +411,7 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
     carry[1] = pb;
   }
   __syncthreads();
+  if (tl) tl[4] = wall_clock64();  // counts of the earlier workgroups collected
   const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
   if (nf) {
     int pos = carry[0] + ea, rnk = carry[1] + eb;
@@ -463,6 +468,7 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
       if (J.stat_upd >= 0) stats[J.stat_upd] += n_cand;
       if (J.stat_new >= 0) stats[J.stat_new] += granted;
     }
+    if (tl) tl[5] = wall_clock64();
   }
 }
 
