@@ -587,7 +587,7 @@ def test_wg_trace_hooks_are_compiled_out_of_the_product_build():
 
 def test_lazy_decay_deallocates_in_fused_frames_and_survives_interleaved_standalone_calls(oracle_mod):
     """Strong decay inside fused frames: the deallocations come from the per-block maximum weights (light path, the W *= f rides
-    in k_tsdf_pass); a stand-alone add_depth_frame / eager decay in between marks those maxima stale, the next fused frame
+    in the TSDF pass); a stand-alone add_depth_frame / eager decay in between marks those maxima stale, the next fused frame
     takes the full decay pass, the one after it the light path again.  Blocks, order and values equal the oracle's throughout."""
     cfg = small_cfg(4)
     over = dict(tsdf_decay_factor=0.2, decayed_weight_threshold=1e-2)
