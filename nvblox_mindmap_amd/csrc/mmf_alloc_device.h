@@ -362,6 +362,14 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
     for (int g = 0; g < G; ++g) {
       const int c4 = cell0 + 4 * g;
       f[g] = *reinterpret_cast<const uint32_t*>(sc.flags + (unsigned)(c4 < ncells ? c4 : 0));
+      {  // byte k := 0xff where the cell's byte equals the frame's tag, else 0 (bytes of other frames are stale, never cleared)
+        const uint32_t x = f[g] ^ (0x01010101u * (uint32_t)J.flag_value);
+        uint32_t eq = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (((x >> (8 * k)) & 0xffu) == 0u) eq |= 0xffu << (8 * k);
+        f[g] = eq;
+      }
       if (c4 >= ncells) f[g] = 0u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {

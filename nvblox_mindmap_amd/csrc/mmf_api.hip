@@ -56,6 +56,12 @@ struct Mapper {
   int* hints = nullptr;  // pinned host ints the device publishes counts to: [0..2] candidates of sc[0..2], [3..5] live blocks  // depth with invalid / masked pixels zeroed (written by the mask row pass)
   uint8_t* kill = nullptr;
   int* any_kill = nullptr;
+  // Raycast flags of the view grid (sc[0].flags).  Stand-alone chains set a touched cell to 1 and their allocation clears the
+  // grid again (all-zero between calls).  k_alloc_tsdf frames have two readers of the flags in one launch, so nobody clears:
+  // the raycast writes the frame's tag (1 .. 255) and the readers compare for equality; the buffer is zeroed when the tag
+  // wraps and when a stand-alone chain follows (untag_grid).
+  bool grid_tagged = false;
+  int grid_tag = 0;
   u64* pub = nullptr;          // [16 + 3 * cap] new blocks published by the allocation workgroup of k_alloc_tsdf to its own launch
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
   long long frames[3] = {0, 0, 0};
@@ -617,6 +623,23 @@ int app_prepare(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, co
   return app_alloc(h, m, which, L, cam, T_C_L, stat_upd, stat_new, s);
 }
 
+int untag_grid(Mapper& m, hipStream_t s) {
+  if (m.grid_tagged && m.sc[0].flags) HIP_TRY(hipMemsetAsync(m.sc[0].flags, 0, (size_t)m.sc_cap[0], s));
+  m.grid_tagged = false;
+  m.grid_tag = 0;
+  return MMF_OK;
+}
+
+int next_grid_tag(Mapper& m, hipStream_t s, int* tag) {
+  m.grid_tagged = true;
+  if (++m.grid_tag > 255) {
+    HIP_TRY(hipMemsetAsync(m.sc[0].flags, 0, (size_t)m.sc_cap[0], s));
+    m.grid_tag = 1;
+  }
+  *tag = m.grid_tag;
+  return MMF_OK;
+}
+
 // TSDF chain of one depth frame on stream s: raycast marking -> compaction/allocation -> TSDF update.
 // A pixel is valid iff depth > min_d (min_d >= 0) and mask != 0.
 int depth_chain(mmf_handle h, Mapper& m, const float* depth, const uint8_t* mask, float min_d, const Cam& cam,
@@ -633,6 +656,7 @@ int depth_chain(mmf_handle h, Mapper& m, const float* depth, const uint8_t* mask
     return MMF_OK;
   }
   MMF_TRY(ensure_scratch(m, 0, ncells));
+  MMF_TRY(untag_grid(m, s));
   const int sub = m.P.raycast_subsampling < 1 ? 1 : m.P.raycast_subsampling;
   {
     ProfScope ps(h, MMF_K_RAYCAST, s);
@@ -973,11 +997,16 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   // Merged launch 2 (k_alloc_tsdf): bounded workspace and no voxel-pass decay in this frame -- the live list is final when
   // k_front ends, so the TSDF pass of the existing blocks runs beside the allocation workgroup instead of after it.
   const bool merged = m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
+  int grid_tag = 1;
+  if (merged)
+    MMF_TRY(next_grid_tag(*m, s, &grid_tag));
+  else
+    MMF_TRY(untag_grid(*m, s));
   {
     // raycast tiles | mask row pass | pending decay of the TSDF layer
     ProfScope ps(h, MMF_K_RAYCAST, s);
     launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
-                 light_decay, m->kill, m->any_kill, merged ? m->tsdf.d.ctr : nullptr, s);
+                 light_decay, m->kill, m->any_kill, merged ? m->tsdf.d.ctr : nullptr, grid_tag, s);
   }
   KeySrc ks0{};
   ks0.mode = 0;
@@ -1000,6 +1029,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     ProfScope ps(h, MMF_K_TSDF, s);
     job0.pub = m->pub;
     job0.pub_tag = (unsigned)stamp;
+    job0.flag_value = grid_tag;
     if ((m->tsdf_epoch & 0x3fffffff) == 0)  // the 30-bit tag wraps (once in 2^30 frames): no stale word may carry a tag again
       HIP_TRY(hipMemsetAsync(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)m->tsdf.d.cap), s));
     launch_alloc_tsdf(job0, m->stats, M, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
@@ -1058,8 +1088,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   {
     ProfScope ps(h, MMF_K_FEATURE, s);
     launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
-                          merged ? m->sc[0].flags : nullptr, ncells);
+                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
   }
   {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);

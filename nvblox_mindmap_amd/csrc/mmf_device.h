@@ -127,6 +127,7 @@ struct AllocJob {
   long long* timeline = nullptr;  // != null: thread 0 stores wall_clock64() (100 MHz) at 6 points of the job (diagnostics)
   u64* pub = nullptr;      // alloc_grid_multi_body: [16 + 3 * cap] published counts and new blocks (see there)
   unsigned pub_tag = 0;
+  int flag_value = 1;      // alloc_grid_multi_body: a grid cell is flagged iff its byte equals this (the frame's grid tag)
 };
 
 __host__ __device__ inline u64 pack_key(int x, int y, int z) {

@@ -740,9 +740,8 @@ __global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts 
 // depth inputs): the first g_col workgroups walk the colour candidates, the rest the feature candidates.
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth,
-                                                       int Ws, int Hs, int g_col, uint32_t* __restrict__ zero, int n_zero) {
+                                                       int Ws, int Hs, int g_col) {
   __shared__ FeatLds S;
-  for (int w = blockIdx.x * 256 + threadIdx.x; w < n_zero; w += gridDim.x * 256) zero[w] = 0u;  // see k_app_frame
   if ((int)blockIdx.x < g_col)
     color_body(Acol, mc, synth, Ws, Hs, blockIdx.x, g_col);
   else
@@ -827,11 +826,9 @@ __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, cons
 
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
-                                                  int Hs, uint32_t* __restrict__ zero, int n_zero) {
+                                                  int Hs) {
   __shared__ FeatLds S;
   const long long tr0 = wg_trace_begin();
-  // the raycast flags of the view grid, which k_alloc_tsdf's two readers left set: all-zero again for the next frame
-  for (int w = blockIdx.x * 256 + threadIdx.x; w < n_zero; w += gridDim.x * 256) zero[w] = 0u;
   app_frame_body<LOW>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 #ifdef MMF_WG_TRACE
   {  // diagnostics: survivors of the (last) block and whether it was new ride in the record id
@@ -945,10 +942,7 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low, const FlatList* flat, bool same_candidates, uint8_t* zero_flags,
-                           int n_zero_bytes) {
-  uint32_t* zero = reinterpret_cast<uint32_t*>(zero_flags);
-  const int n_zero = zero_flags ? (n_zero_bytes + 3) / 4 : 0;
+                           hipStream_t s, const LowRes* low, const FlatList* flat, bool same_candidates) {
   const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
                 Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low, flat);
   // same_candidates: both allocation jobs compacted the same flag array, so candidate i is the same block in both lists
@@ -957,15 +951,15 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
     if (low)
-      hipLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, zero, n_zero);
+      hipLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
     else
-      hipLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, zero, n_zero);
+      hipLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
   } else {
     const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
     if (low)
-      hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc, zero, n_zero);
+      hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
     else
-      hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc, zero, n_zero);
+      hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
   }
 }
 

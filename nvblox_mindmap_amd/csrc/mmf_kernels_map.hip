@@ -82,6 +82,8 @@ struct RaycastJob {
   int sub, Wsub, Hsub;
   ViewGrid vg;
   uint8_t* flags;
+  int flag_value;  // the byte a touched cell is set to: 1 (consumers clear the grid after use) or the frame's tag of a k_alloc_tsdf
+                   // frame, whose consumers compare for equality and never clear (Mapper::grid_tagged)
 };
 
 template <bool LDSFLAGS>
@@ -152,7 +154,7 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
         if (LDSFLAGS)
           s_flags[cell] = 1;
         else
-          flags[cell] = 1;
+          flags[cell] = (uint8_t)R.flag_value;
       }
       walk_step(w);
     }
@@ -164,7 +166,7 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
       if (!v) continue;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if ((v >> (8 * k)) & 0xffu) flags[wd * 4 + k] = 1;
+        if ((v >> (8 * k)) & 0xffu) flags[wd * 4 + k] = (uint8_t)R.flag_value;
     }
   }
 }
@@ -633,7 +635,8 @@ struct TsdfFrameArgs {
   Cam cam;
   Rigid T_C_L;
   const float* depth;         // the frame's masked depth image
-  const uint8_t* grid_flags;  // raycast flags of the view grid (left set by the PUB allocation job)
+  const uint8_t* grid_flags;  // raycast flags of the view grid: a cell was touched this frame iff its byte == grid_tag
+  int grid_tag;
   int ox, oy, oz, nx, ny, nz; // view grid
   uint8_t* flags_out;         // [live position] appearance-candidate flag
   u64* cell_key_out;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(256) void k_alloc_tsdf(AllocJob J, long long* stats
         unpack_key(key, bx, by, bz);
         const int gx = bx - P.ox, gy = by - P.oy, gz = bz - P.oz;
         if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.nx && gy < P.ny && gz < P.nz)
-          cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] != 0;
+          cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] == (uint8_t)P.grid_tag;
       }
       tsdf_frame_block(L, P, S, par, act, i, slot, key, cand, false);
     }
@@ -1010,6 +1013,7 @@ static RaycastJob make_raycast_job(const MapConsts& mc, const Cam& cam, const Ri
   R.Hsub = (cam.H + sub - 1) / sub;
   R.vg = vg;
   R.flags = flags;
+  R.flag_value = 1;
   const int ntiles = ((R.Wsub + 7) / 8) * ((R.Hsub + 7) / 8);
   n_wgs = (ntiles + 3) / 4;
   return R;
@@ -1030,9 +1034,10 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
 // raycast + mask row pass in one launch
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                   int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
-                  uint8_t* kill, int* any_kill, int* snap_ctr, hipStream_t s) {
+                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s) {
   int n_wgs;
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
+  R.flag_value = flag_value;
   R.mask_invert = M.invert;
   const int ncells = vg.nx * vg.ny * vg.nz;
   DecayJob D{};
@@ -1210,6 +1215,7 @@ void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, 
   P.T_C_L = T_C_L;
   P.depth = masked_depth;
   P.grid_flags = job.sc.flags;
+  P.grid_tag = job.flag_value;
   P.ox = vg.ox, P.oy = vg.oy, P.oz = vg.oz, P.nx = vg.nx, P.ny = vg.ny, P.nz = vg.nz;
   P.flags_out = flags_out;
   P.cell_key_out = cell_key_out;
