@@ -102,7 +102,9 @@ int mmf_num_mappers(mmf_handle h); /* Mapper.num_mappers(), visualization/visual
 
 /* ---- integration -------------------------------------------------------------------------- */
 /* Mapper.add_depth_frame(depth, T_W_C, K, mask, mapper_id)   nvblox_mapping_helpers.py:207-209
- * depth: [H,W] f32 metres, <=0 invalid.  mask: [H,W] u8 (1 = integrate) or NULL. */
+ * depth: [H,W] f32 metres, <=0 invalid.  mask: [H,W] u8 (1 = integrate) or NULL.
+ * Bounded workspaces: two launches (raycast | masked depth | a pending mmf_decay, then allocation | TSDF update); environment
+ * MMF_NO_ALLOC_TSDF=1 at mapper creation keeps the separate launches everywhere (same results; the tests' reference point). */
 int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth_dev, const uint8_t* mask_dev, int H, int W,
                         const float* T_W_C_host, const float* K_host, void* stream);
 /* Mapper.add_color_frame(rgb, T_W_C, K, mask_frame=, mapper_id=)  nvblox_mapping_helpers.py:212-218

@@ -62,6 +62,8 @@ struct Mapper {
   // wraps and when a stand-alone chain follows (untag_grid).
   bool grid_tagged = false;
   int grid_tag = 0;
+  bool allow_merged = true;    // false: environment MMF_NO_ALLOC_TSDF=1 at creation -- keep allocation and TSDF pass as separate launches
+                               // (the reference point of the parity tests of k_alloc_tsdf)
   u64* pub = nullptr;          // [16 + 3 * cap] new blocks published by the allocation workgroup of k_alloc_tsdf to its own launch
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
   long long frames[3] = {0, 0, 0};
@@ -398,6 +400,10 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   HIP_TRY(hipMemset(m->tsdf.d.stamp, 0, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->kill, (size_t)cap));
   HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
+  {
+    const char* e = std::getenv("MMF_NO_ALLOC_TSDF");
+    m->allow_merged = !(e && e[0] == '1');
+  }
   HIP_TRY(hipMalloc(&m->pub, sizeof(u64) * (16 + 3 * (size_t)cap)));
   HIP_TRY(hipMemset(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)cap)));
   HIP_TRY(hipMalloc(&m->any_kill, sizeof(int)));
@@ -623,6 +629,20 @@ int app_prepare(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, co
   return app_alloc(h, m, which, L, cam, T_C_L, stat_upd, stat_new, s);
 }
 
+// bit-row scratch of the mask kernels + the masked depth image of a frame
+int ensure_mask_scratch(Mapper& m, int H, int W) {
+  if ((size_t)H * W + 8 <= m.mask_tmp_cap) return MMF_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(m.mask_tmp);
+  (void)hipFree(m.masked_depth);
+  m.mask_tmp = nullptr;
+  m.masked_depth = nullptr;
+  HIP_TRY(hipMalloc(&m.mask_tmp, (size_t)H * W + 8));
+  HIP_TRY(hipMalloc(&m.masked_depth, sizeof(float) * (size_t)H * W));
+  m.mask_tmp_cap = (size_t)H * W + 8;
+  return MMF_OK;
+}
+
 int untag_grid(Mapper& m, hipStream_t s) {
   if (m.grid_tagged && m.sc[0].flags) HIP_TRY(hipMemsetAsync(m.sc[0].flags, 0, (size_t)m.sc_cap[0], s));
   m.grid_tagged = false;
@@ -790,7 +810,7 @@ int mmf_num_mappers(mmf_handle h) { return h ? (int)h->mappers.size() : 0; }
 int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* mask, int H, int W, const float* T16,
                         const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
+  MMF_TRY(get_mapper(h, mapper_id, &m));
   if (!depth || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_depth_frame");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -798,7 +818,69 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
   Rigid T_L_C, T_C_L;
   rigid_from_T(T16, T_L_C);
   rigid_inverse(T_L_C, T_C_L);
-  MMF_TRY(depth_chain(h, *m, depth, mask, 0.0f, cam, T_L_C, T_C_L, s));
+  // Bounded workspace: the two-launch form of the fused frame's TSDF half -- k_front (raycast | masked depth | a pending decay's
+  // deallocations) + k_alloc_tsdf (allocation | TSDF pass) -- instead of raycast, allocation, update and an eager decay pass.
+  ViewGrid vg;
+  MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  bool fast = m->allow_merged && m->tsdf.d.dense != nullptr && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
+  MaskJob M;
+  if (fast) {
+    MMF_TRY(ensure_mask_scratch(*m, H, W));
+    fast = make_mask_job(mask, depth, H, W, 0.0f, 0, 0, 0, H, W, nullptr, nullptr, m->mask_tmp, M);
+  }
+  if (!fast) {
+    flush_decay(h, *m, s);
+    MMF_TRY(depth_chain(h, *m, depth, mask, 0.0f, cam, T_L_C, T_C_L, s));
+    return check_launch();
+  }
+  if (m->pending_decay && !m->wmax_valid) flush_decay(h, *m, s);  // wmax stale: the decay needs its pass over the voxels
+  const bool do_decay = m->pending_decay;                          // (else: light -- decided from wmax, W *= f in the TSDF pass)
+  m->pending_decay = false;
+  m->last_vg = vg;
+  m->frames[0]++;
+  m->tsdf_epoch++;
+  m->touched = true;
+  const int stamp = (int)(m->tsdf_epoch & 0x3fffffff) ? (int)(m->tsdf_epoch & 0x3fffffff) : 1;
+  MMF_TRY(ensure_scratch(*m, 0, ncells));
+  MMF_TRY(ensure_scratch(*m, 1, m->tsdf.d.cap));
+  M.masked_depth_out = m->masked_depth;
+  int grid_tag = 1;
+  MMF_TRY(next_grid_tag(*m, s, &grid_tag));
+  const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
+  {
+    ProfScope ps(h, MMF_K_RAYCAST, s);
+    launch_front(m->mc, cam, T_L_C, depth, mask, 0.0f, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr, do_decay, m->kill,
+                 m->any_kill, m->tsdf.d.ctr, grid_tag, s);
+  }
+  {
+    ProfScope ps(h, MMF_K_TSDF, s);
+    KeySrc ks{};
+    ks.mode = 0;
+    ks.ox = vg.ox;
+    ks.oy = vg.oy;
+    ks.oz = vg.oz;
+    ks.ny = vg.ny;
+    ks.nz = vg.nz;
+    AllocJob job;
+    job.L = m->tsdf.d;
+    job.ks = ks;
+    job.sc = m->sc[0];
+    job.ncells = ncells;
+    job.stat_upd = 1;
+    job.stat_new = 2;
+    job.stamp = stamp;
+    job.pub = m->pub;
+    job.pub_tag = (unsigned)stamp;
+    job.flag_value = grid_tag;
+    if ((m->tsdf_epoch & 0x3fffffff) == 0)
+      HIP_TRY(hipMemsetAsync(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)m->tsdf.d.cap), s));
+    MaskJob Mc = M;
+    Mc.Hf = 0;  // no column pass: there is no feature mask to emit
+    launch_alloc_tsdf(job, m->stats, Mc, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
+                      do_decay ? m->mc.decay_factor : 0.0f, s);
+    m->wmax_valid = true;
+  }
   return check_launch();
 }
 
@@ -909,16 +991,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)C, true));
   MMF_TRY(ensure_scratch(*m, 1, m->tsdf.d.cap));
   MMF_TRY(ensure_scratch(*m, 2, m->tsdf.d.cap));
-  if ((size_t)H * W + 8 > m->mask_tmp_cap) {
-    HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(m->mask_tmp);
-    (void)hipFree(m->masked_depth);
-    m->mask_tmp = nullptr;
-    m->masked_depth = nullptr;
-    HIP_TRY(hipMalloc(&m->mask_tmp, (size_t)H * W + 8));
-    HIP_TRY(hipMalloc(&m->masked_depth, sizeof(float) * (size_t)H * W));
-    m->mask_tmp_cap = (size_t)H * W + 8;
-  }
+  MMF_TRY(ensure_mask_scratch(*m, H, W));
   const Cam cam = cam_from_K(K9, W, H);
   // intrinsics of the feature image: first two rows scaled per axis (nvblox_mapping_helpers.py:229-234)
   float Kf[9];
@@ -996,7 +1069,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   const bool light_decay = do_decay && m->wmax_valid;
   // Merged launch 2 (k_alloc_tsdf): bounded workspace and no voxel-pass decay in this frame -- the live list is final when
   // k_front ends, so the TSDF pass of the existing blocks runs beside the allocation workgroup instead of after it.
-  const bool merged = m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
+  const bool merged = m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
   int grid_tag = 1;
   if (merged)
     MMF_TRY(next_grid_tag(*m, s, &grid_tag));

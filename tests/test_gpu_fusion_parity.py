@@ -650,26 +650,28 @@ def test_merged_launch_with_churn_matches_oracle(oracle_mod):
     _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 90, 10, 200, 100, 20, 300, 110, 30], 8)
 
 
-def test_grid_tag_wraps_and_merged_path_equals_separate_launches():
-    """270 fused frames: mapper A stays on the merged k_alloc_tsdf path (tagged grid flags, the 8-bit tag wraps once); before each
-    frame mapper B gets a stand-alone add_depth_frame whose mask rejects every pixel -- a no-op for the map that marks wmax stale
-    and clears the grid tags, so B's frames take the separate allocation / TSDF launches with the full decay pass.  Same blocks,
-    same order, same bits."""
+def test_grid_tag_wraps_and_merged_path_equals_separate_launches(monkeypatch):
+    """270 x (decay, fused frame, stand-alone add_depth_frame of another view): mapper A runs the merged k_alloc_tsdf launch in
+    both calls (tagged grid flags: the 8-bit tag wraps twice; light decay); mapper B is created with MMF_NO_ALLOC_TSDF=1 and keeps
+    the separate allocation / TSDF launches (cleared grid flags, eager decay before the stand-alone call).  Same blocks, same
+    order, same bits."""
     cfg = small_cfg(4)
     over = dict(tsdf_decay_factor=0.9, decayed_weight_threshold=0.3)
-    a, b = make_mapper(8, **over), make_mapper(8, **over)
-    nothing = torch.zeros((cfg.height, cfg.width), dtype=torch.uint8, device="cuda")
+    a = make_mapper(8, **over)
+    monkeypatch.setenv("MMF_NO_ALLOC_TSDF", "1")
+    b = make_mapper(8, **over)
+    monkeypatch.delenv("MMF_NO_ALLOC_TSDF")
     ones = dev(np.ones((cfg.height, cfg.width), dtype=bool))
     frames = [S.frame(cfg, i, 8) for i in range(0, 360, 12)]
     for k in range(270):
-        f = frames[(k * 7) % len(frames)]
-        args = (dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), ones, torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]),
-                0.3, 2, 2, 0, 0)
-        a.decay()
-        a.integrate_frame(*args)
-        b.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), nothing, 0)
-        b.decay()
-        b.integrate_frame(*args)
+        f, g = frames[(k * 7) % len(frames)], frames[(k * 11 + 3) % len(frames)]
+        for m in (a, b):
+            m.decay()
+            m.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), ones, torch.from_numpy(f["T_W_C"]),
+                              torch.from_numpy(f["K"]), 0.3, 2, 2, 0, 0)
+            if k % 3 == 0:
+                m.decay()
+            m.add_depth_frame(dev(g["depth"]), torch.from_numpy(g["T_W_C"]), torch.from_numpy(g["K"]), None, 0)
     ta, ia = a.tsdf_layer_view(0).get_all_blocks()[:2]
     tb, ib = b.tsdf_layer_view(0).get_all_blocks()[:2]
     assert ia.shape[0] > 50 and torch.equal(ia, ib) and torch.equal(ta, tb)
