@@ -253,6 +253,51 @@ def run_backprojection(device, cpu=True):
     return out
 
 
+def run_two_mappers(device, frames, channels, steps=100, warmup=20):
+    """The reference's full nvblox_integrate (nvblox_mapping_helpers.py:79-159): decay of both mappers, then the frame into the
+    STATIC mapper (mask = ~dynamic) and into the DYNAMIC one (mask = dynamic).  Timed with the two mappers' chains in sequence
+    on one stream (the helper's default) and with the dynamic mapper's chain on a second stream (MMF_OVERLAP_MAPPERS=1)."""
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+
+    class Extractor:  # the backbone is out of scope here: the stream's feature image stands in for its output
+        def compute(self, rgb):
+            return self.next.unsqueeze(0)
+
+    ex = Extractor()
+    out = {}
+    dyn = torch.zeros_like(frames[0]["dynamic_mask"])
+    dyn[dyn.shape[0] // 4: 3 * dyn.shape[0] // 4, dyn.shape[1] // 3: 2 * dyn.shape[1] // 3] = True  # a sixth of the image is "dynamic"
+    saved = H.OVERLAP_MAPPERS
+    try:
+        for name, overlap in (("sequential", False), ("two_streams", True)):
+            H.OVERLAP_MAPPERS = overlap
+            mapper = get_nvblox_mapper(mcfg, feature_channels=channels)
+            if mapper.num_mappers() < 2:
+                return None
+
+            def step(i):
+                fr = frames[i % len(frames)]
+                ex.next = fr["features"]
+                mapper.decay()
+                H.nvblox_integrate(mapper, mcfg, ex, fr["depth"], fr["K"], fr["T_W_C"], fr["rgb"], dyn, include_dynamic=True)
+
+            for i in range(warmup):
+                step(i)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(warmup + i)
+            torch.cuda.synchronize(device)
+            out[name + "_ms_per_frame"] = (time.perf_counter() - t0) / steps * 1e3
+            del mapper
+    finally:
+        H.OVERLAP_MAPPERS = saved
+    out["workload"] = "decay + nvblox_integrate(include_dynamic=True): static and dynamic mapper, a sixth of the image dynamic, 640x480, C=%d" % channels
+    return out
+
+
 def run_tsdf_only(device, steps=200, warmup=20):
     """BASELINE configs[1]: TSDF-only integration (decay + add_depth_frame: raycast, allocation, TSDF update) of the 640x480
     stream at 1 cm voxels, through the reference's stand-alone Mapper calls."""
@@ -557,6 +602,7 @@ def main():
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     tsdf_only = run_tsdf_only(device) if (rank == 0 and not args.no_ref_shape) else None
+    two_mappers = run_two_mappers(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
@@ -642,6 +688,7 @@ def main():
             "policy_inference": infer,
             "closed_loop": closed_loop,
             "tsdf_only": tsdf_only,
+            "two_mappers": two_mappers,
             "backprojection": backproj,
             "train": train,
         }
