@@ -1334,6 +1334,8 @@ int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* strea
   HIP_TRY(hipMemcpyAsync(h->pinned + 8, L->d.ctr, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   *out = h->pinned[8];
+  if (h->pinned[11] & 2)  // a workgroup of k_alloc_tsdf gave up polling for a word of its own launch (never observed)
+    return fail(MMF_ERR_BAD_STATE, "k_alloc_tsdf: a workgroup timed out waiting for the allocation workgroups of its launch; the map is incomplete");
   if (h->pinned[11] & 1)
     return fail(MMF_ERR_POOL_EXHAUSTED, "voxel-block pool exhausted: raise BlockMemoryPoolParams.num_preallocated_blocks");
   return MMF_OK;
