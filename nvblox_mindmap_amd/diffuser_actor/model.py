@@ -163,6 +163,11 @@ class DiffusionHead(nn.Module):
         self.traj_encoder = nn.Linear(9, D)
         self.time_mlp = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D))
         self.history_mlp = nn.Sequential(nn.Linear(D * nq, D), nn.ReLU(), nn.Linear(D, D))
+        # trajectory tokens attend to the language tokens (use_instruction only; diffusion_head.py:61-78,204-214).  The
+        # feed-forward half exists in the reference's state dict but is never applied there (apply_ffn=False): kept so that
+        # checkpoints convert both ways (reference_weights.py)
+        self.traj_lang_attention = nn.ModuleList([AttentionBlock(D, H, p)])
+        self.traj_lang_ffn = nn.ModuleList([FeedForwardBlock(D, 4 * D, p)])
         self.cross_attn = AttentionStack(D, H, 2, p, use_adaln=True)
         self.self_attn = AttentionStack(D, H, 4, p, use_adaln=True, self_attention=True)
         self.rotation_attn = AttentionStack(D, H, 2, p, use_adaln=True, self_attention=True)
@@ -241,10 +246,15 @@ class DiffusionHead(nn.Module):
         nt = L * G
         P = prepared if prepared is not None else self.prepare_context(enc)
         if (not need_weights and time_emb is not None and P.get("seq") is not None and layers_mod._fused(trajectory)
-                and nt == P["pos_table"].shape[0] and G <= 4):
+                and nt == P["pos_table"].shape[0] and G <= 4 and not cfg.use_instruction):
             return self._forward_fused(trajectory, P, time_emb)
         tokens = self.drop(self.traj_encoder(trajectory)).flatten(1, 2)
-        tokens = tokens + sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
+        token_pos = sinusoidal_embedding(torch.arange(nt, device=tokens.device), D)[None]
+        if cfg.use_instruction:
+            lang = self.traj_lang_attention[0]
+            out, _ = lang.attn(tokens + token_pos, enc["instr_feats"])
+            tokens = lang.norm(tokens + lang.drop(out))
+        tokens = tokens + token_pos
         cond = (self.time_mlp(sinusoidal_embedding(timestep, D)) if time_emb is None else time_emb) + P["history"]
         cond_act = F.silu(cond)  # every AdaLN block applies the same activation to the same conditioning vector
         if P.get("adaln") is not None and not need_weights:
@@ -335,7 +345,7 @@ class DiffusionHead(nn.Module):
 
     def can_denoise_fused(self, P, traj) -> bool:
         return (P.get("seq") is not None and layers_mod._fused(traj) and traj.shape[1] * traj.shape[2] == P["pos_table"].shape[0]
-                and traj.shape[2] <= 4)
+                and traj.shape[2] <= 4 and not self.cfg.use_instruction)
 
     def denoise_fused(self, noise, P, time_table, coefs):
         """The whole reverse-diffusion loop on the inference kernels.  noise [1 + T, B, L, G, 9] (noise[0] = x_T), time_table

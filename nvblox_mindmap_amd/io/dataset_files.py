@@ -37,9 +37,17 @@ def write_vertex_features(path: str, vertices: torch.Tensor, features: torch.Ten
         f.write(zstd.compress(pickle.dumps(pc_ob, protocol=pickle.HIGHEST_PROTOCOL), level=1))
 
 
+def _safe_load_from_bytes(b: bytes):
+    """Stand-in for torch.storage._load_from_bytes, which a pickled tensor's storage names (TypedStorage.__reduce__): the
+    original is ``torch.load(..., weights_only=False)``, i.e. a second, UNRESTRICTED unpickle of bytes nested in the file.
+    The nested stream is read with torch's weights-only unpickler instead (tensors / storages only, anything else raises)."""
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
 class _TensorUnpickler(pickle.Unpickler):
     """pickle.load restricted to what a vertex-feature file contains (CPU torch tensors, numpy arrays, builtins): public
-    datasets are untrusted input and a plain pickle.load executes whatever the file names."""
+    datasets are untrusted input and a plain pickle.load executes whatever the file names -- including, one level down, the
+    storage bytes of a tensor (see _safe_load_from_bytes)."""
 
     _ALLOWED = {
         ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch", "HalfStorage"),
@@ -51,6 +59,8 @@ class _TensorUnpickler(pickle.Unpickler):
     }
 
     def find_class(self, module, name):
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _safe_load_from_bytes
         if (module, name) in self._ALLOWED:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"vertex-feature file references {module}.{name}: refused")

@@ -1,7 +1,13 @@
 """Training checkpoints (mirror of mindmap/model_utils/checkpoint.py:30-52,103-136): ``last.pth`` after every validation
-round, ``best.pth`` when the validation loss improved; each holds {weight, optimizer, iter, best_loss}.  Files written by the
-reference load here and vice versa (same keys; "weight" is the state_dict of whatever wraps the model -- a DDP wrapper saves
-"module."-prefixed names, which both loaders accept by stripping / adding the prefix)."""
+round, ``best.pth`` when the validation loss improved; each holds {weight, optimizer, iter, best_loss} -- the reference's
+container layout.  "weight" is the state_dict of whatever wraps the model (a DDP wrapper saves "module."-prefixed names,
+which the loaders accept by stripping / adding the prefix).
+
+The parameter NAMES inside "weight" differ between the two code bases (this package's modules are organised differently);
+a checkpoint written by the reference is recognised by its key names and converted on load
+(diffuser_actor/reference_weights.py, pinned by tests/test_cpu_policy_golden.py); ``export_reference_checkpoint`` writes the
+reference's names.  Optimizer state is NOT interchangeable (parameter order and grouping differ): loading a reference
+checkpoint for training restores the weights and restarts the optimizer."""
 import os
 import pathlib
 from typing import Optional, Tuple
@@ -35,12 +41,32 @@ def _match_prefix(state: dict, model) -> dict:
     return {("module." + k) if want else k[len("module."):]: v for k, v in state.items()}
 
 
+def _load_weights(model, state: dict) -> bool:
+    """Returns True if `state` was a reference-named state dict (converted on the way in)."""
+    from ..diffuser_actor import reference_weights as RW
+
+    if RW.is_reference_state_dict(state):
+        RW.load_reference_state_dict(model, state)
+        return True
+    model.load_state_dict(_match_prefix(state, model))
+    return False
+
+
 def load_inference_checkpoint(checkpoint_path: str, model, device):
+    """mindmap/model_utils/checkpoint.py:103-114; accepts checkpoints of either code base."""
     assert checkpoint_path is not None and os.path.exists(checkpoint_path), checkpoint_path
     model_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-    model.load_state_dict(_match_prefix(model_dict["weight"], model))
+    _load_weights(model, model_dict["weight"])
     model.eval()
     return model.to(device=device)
+
+
+def export_reference_checkpoint(path: str, model, step_id: int = 0, best_loss: Optional[float] = None) -> None:
+    """Write {weight, iter, best_loss} with the REFERENCE's parameter names and layouts, loadable by the reference's
+    load_inference_checkpoint (no optimizer entry: its load_train_checkpoint treats it as optional, :124)."""
+    from ..diffuser_actor.reference_weights import to_reference_state_dict
+
+    torch.save({"weight": to_reference_state_dict(model.state_dict()), "iter": step_id + 1, "best_loss": best_loss}, path)
 
 
 def load_train_checkpoint(checkpoint_path: str, model, optimizer, initial_learning_rate: Optional[float] = None) -> Tuple[int, Optional[float]]:
@@ -48,8 +74,8 @@ def load_train_checkpoint(checkpoint_path: str, model, optimizer, initial_learni
     (start_iter, best_loss)."""
     assert checkpoint_path is not None and os.path.exists(checkpoint_path), checkpoint_path
     model_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-    model.load_state_dict(_match_prefix(model_dict["weight"], model))
-    if "optimizer" in model_dict:
+    from_reference = _load_weights(model, model_dict["weight"])
+    if "optimizer" in model_dict and not from_reference:
         optimizer.load_state_dict(model_dict["optimizer"])
         if initial_learning_rate is not None:
             for g in optimizer.param_groups:

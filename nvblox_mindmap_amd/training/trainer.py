@@ -28,12 +28,17 @@ def wrap_ddp(model: nn.Module, device) -> nn.Module:
 
 
 def build_optimizer(model: nn.Module, lr: float = 1e-4, weight_decay: float = 5e-4) -> torch.optim.Optimizer:
-    """AdamW, two groups: biases and LayerNorm parameters without weight decay (run_training.py:140-153)."""
+    """AdamW with the reference's two groups and its exact rule (run_training.py:140-153): a parameter whose NAME contains
+    "bias", "LayerNorm.weight" or "LayerNorm.bias" gets no weight decay, everything else 5e-4.  The reference's LayerNorm
+    modules are attributes called ``norm*`` (layers.py:331,358), so -- as there -- LayerNorm gains ARE decayed; the same holds
+    here (``norm`` attributes).  Only the frozen stand-in backbone is left out: the reference's extractor is not part of its
+    module tree (feature_extraction.py:132-160), hence not in its optimizer either."""
+    no_decay_names = ["bias", "LayerNorm.weight", "LayerNorm.bias"]
     decay, no_decay = [], []
     for name, p in model.named_parameters():
         if not p.requires_grad:
             continue
-        (no_decay if (name.endswith("bias") or "norm" in name.lower()) else decay).append(p)
+        (no_decay if any(nd in name for nd in no_decay_names) else decay).append(p)
     return torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0, "lr": lr}, {"params": decay, "weight_decay": weight_decay, "lr": lr}])
 
 

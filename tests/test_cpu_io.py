@@ -51,6 +51,29 @@ def test_vertex_feature_reader_refuses_code_execution(tmp_path):
         D.read_vertex_features(str(p))
 
 
+def test_vertex_feature_reader_refuses_a_nested_pickle_in_the_storage_bytes(tmp_path):
+    """A tensor's storage is pickled as torch.storage._load_from_bytes(<bytes>), which upstream is an unrestricted
+    torch.load of those bytes: a payload one level down must be refused as well (and must not run)."""
+    import torch.storage
+
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    class Nested:  # what a crafted file would name in place of a real storage
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (pickle.dumps(Evil()),))
+
+    p = tmp_path / "0000.nvblox_vertex_features.zst"
+    p.write_bytes(zstd.compress(pickle.dumps({"vertices": Nested(), "features": 1})))
+    with pytest.raises(Exception) as e:
+        D.read_vertex_features(str(p))
+    assert isinstance(e.value, (pickle.UnpicklingError, RuntimeError))
+    assert not marker.exists()
+
+
 def test_depth_png_is_u16_millimetres_with_the_writers_clamp(tmp_path):
     depth = torch.rand(48, 64) * 70.0  # beyond the 65.535 m a u16 millimetre image can hold
     depth[0, 0], depth[0, 1], depth[0, 2] = float("inf"), -1.0, 1.2345

@@ -166,7 +166,7 @@ def test_model_single_forward_cpu_plumbing():
     assert enc["history_feats"].shape == (2, cfg.num_history * cfg.ngrippers, 60)
     losses[0].backward()
     unused = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
-    assert unused and all(("vl_" in n or "instruction" in n or "goal_embed" in n) for n in unused), unused
+    assert unused and all(("vl_" in n or "instruction" in n or "goal_embed" in n or "traj_lang_" in n) for n in unused), unused
     model.eval()
     traj, yaw, l2, _, _ = model(s["gt_gripper_pred"], s["gt_head_yaw"], None, None, None, s["vertex_features"], s["vertices"],
                                 s["vertices_valid_mask"], None, s["gripper_history"], run_inference=True)
