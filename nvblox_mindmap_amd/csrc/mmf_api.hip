@@ -1077,9 +1077,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     MMF_TRY(untag_grid(*m, s));
   {
     // raycast tiles | mask row pass | pending decay of the TSDF layer
-    ProfScope ps(h, MMF_K_RAYCAST, s);
+    ProfExt pe(h, MMF_K_RAYCAST);
     launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
-                 light_decay, m->kill, m->any_kill, merged ? m->tsdf.d.ctr : nullptr, grid_tag, s);
+                 light_decay, m->kill, m->any_kill, merged ? m->tsdf.d.ctr : nullptr, grid_tag, s, pe.a(), pe.b());
   }
   KeySrc ks0{};
   ks0.mode = 0;
@@ -1099,14 +1099,14 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   job0.timeline = m->timeline;
   if (merged) {
     // TSDF allocation | mask column pass | TSDF update + appearance-candidate flags of every live block
-    ProfScope ps(h, MMF_K_TSDF, s);
+    ProfExt pe(h, MMF_K_TSDF);
     job0.pub = m->pub;
     job0.pub_tag = (unsigned)stamp;
     job0.flag_value = grid_tag;
     if ((m->tsdf_epoch & 0x3fffffff) == 0)  // the 30-bit tag wraps (once in 2^30 frames): no stale word may carry a tag again
       HIP_TRY(hipMemsetAsync(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)m->tsdf.d.cap), s));
     launch_alloc_tsdf(job0, m->stats, M, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
-                      light_decay ? m->mc.decay_factor : 0.0f, s);
+                      light_decay ? m->mc.decay_factor : 0.0f, s, pe.a(), pe.b());
     m->wmax_valid = true;  // refreshed for every live block
   } else {
     {
@@ -1150,18 +1150,20 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     int Ws, Hs;
     bool need;
     MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
-    ProfScope ps(h, MMF_K_SPHERE, s);
     if (need) {
-      launch_sphere_alloc(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats, s);
+      ProfExt pe(h, MMF_K_SPHERE);
+      launch_sphere_alloc(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats, s, pe.a(), pe.b());
       synth_commit(*m, cam, T16, K9, Ws, Hs);
     } else {
+      ProfScope ps(h, MMF_K_SPHERE, s);
       launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
     }
   }
   {
-    ProfScope ps(h, MMF_K_FEATURE, s);
+    ProfExt pe(h, MMF_K_FEATURE);
     launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true);
+                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
+                          pe.a(), pe.b());
   }
   {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);

@@ -868,16 +868,16 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
 }
 
 void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
-                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s) {
+                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
   const int n = patches_x * patches_y;
   const AllocJob& j1 = jobs[njobs > 1 ? 1 : 0];
   if (jobs[0].L.dense && j1.L.dense && jobs[0].ks.mode == 1 && j1.ks.mode == 1)  // bounded workspace, list cells: no hash paths
-    hipLaunchKernelGGL((k_sphere_alloc<true, 1>), dim3(njobs + n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n,
-                       jobs[0], j1, njobs, stats);
+    hipExtLaunchKernelGGL((k_sphere_alloc<true, 1>), dim3(njobs + n), dim3(256), 0, s, ev_start, ev_stop, 0, tsdf, mc, cam, T_L_C, synth, Ws,
+                          Hs, patches_x, n, jobs[0], j1, njobs, stats);
   else
-    hipLaunchKernelGGL((k_sphere_alloc<false, -1>), dim3(njobs + n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n,
-                       jobs[0], j1, njobs, stats);
+    hipExtLaunchKernelGGL((k_sphere_alloc<false, -1>), dim3(njobs + n), dim3(256), 0, s, ev_start, ev_stop, 0, tsdf, mc, cam, T_L_C, synth,
+                          Ws, Hs, patches_x, n, jobs[0], j1, njobs, stats);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
@@ -942,7 +942,8 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low, const FlatList* flat, bool same_candidates) {
+                           hipStream_t s, const LowRes* low, const FlatList* flat, bool same_candidates, hipEvent_t ev_start,
+                           hipEvent_t ev_stop) {
   const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
                 Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low, flat);
   // same_candidates: both allocation jobs compacted the same flag array, so candidate i is the same block in both lists
@@ -951,15 +952,15 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
     if (low)
-      hipLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
+      hipExtLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
     else
-      hipLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs);
+      hipExtLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
   } else {
     const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
     if (low)
-      hipLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
+      hipExtLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc);
     else
-      hipLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, Ac, Af, mc, synth, Ws, Hs, gc);
+      hipExtLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc);
   }
 }
 

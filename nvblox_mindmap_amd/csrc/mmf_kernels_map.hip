@@ -5,6 +5,8 @@
 // Mapper.add_depth_frame / decay / clear / layer views, reached by the reference at
 // mindmap/mapping/helpers/nvblox_mapping_helpers.py:207-209 and
 // mindmap/mapping/isaaclab_nvblox_mapper.py:252-258.
+#include <hip/hip_ext.h>
+
 #include "mmf_launch.h"
 #include "mmf_trace_device.h"
 #include "mmf_alloc_device.h"
@@ -1034,7 +1036,7 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
 // raycast + mask row pass in one launch
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                   int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
-                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s) {
+                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   int n_wgs;
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
   R.flag_value = flag_value;
@@ -1050,9 +1052,9 @@ void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const
   }
   const dim3 grid(n_wgs + M.H + D.n_wgs);
   if (ncells <= kRaycastLdsCells)
-    hipLaunchKernelGGL(k_front<true>, grid, dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R, n_wgs, M, D, snap_ctr);
+    hipExtLaunchKernelGGL(k_front<true>, grid, dim3(256), (size_t)((ncells + 3) / 4) * 4, s, ev_start, ev_stop, 0, R, n_wgs, M, D, snap_ctr);
   else
-    hipLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, R, n_wgs, M, D, snap_ctr);
+    hipExtLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, R, n_wgs, M, D, snap_ctr);
 }
 
 constexpr int kFusedAllocMaxCells = 16384;
@@ -1208,7 +1210,7 @@ void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, co
 // allocation | mask columns | TSDF pass (existing blocks beside the allocation, new blocks behind it): k_alloc_tsdf
 void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L,
                        const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out, float decay_f,
-                       hipStream_t s) {
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   TsdfFrameArgs P;
   P.mc = mc;
   P.cam = cam;
@@ -1229,7 +1231,8 @@ void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, 
   const int rows = M.Hf;
   const int alloc_wgs = (job.ncells + 2047) / 2048;  // alloc_grid_multi_body<4, 2>: 2 048 cells per workgroup (<= kAllocMaxWgs)
   const int lead = (alloc_wgs + rows + 7) & ~7;
-  hipLaunchKernelGGL(k_alloc_tsdf, dim3(lead + P.n_pair_wgs + P.n_new_wgs), dim3(256), 0, s, job, stats, alloc_wgs, M, rows, lead, P);
+  hipExtLaunchKernelGGL(k_alloc_tsdf, dim3(lead + P.n_pair_wgs + P.n_new_wgs), dim3(256), 0, s, ev_start, ev_stop, 0, job, stats, alloc_wgs, M,
+                        rows, lead, P);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

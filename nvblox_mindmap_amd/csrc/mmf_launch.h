@@ -36,10 +36,11 @@ void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc
                           int stat_new, hipStream_t s);
 void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                   int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
-                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s);
+                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s, hipEvent_t ev_start = nullptr,
+                  hipEvent_t ev_stop = nullptr);  // events: stamped with the dispatch's own begin / end (extension launch)
 void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L,
                        const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out, float decay_f,
-                       hipStream_t s);
+                       hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 bool alloc_jobs_fusable(int ncells0, int ncells1);
 void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
@@ -66,7 +67,8 @@ void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam&
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
                          int Hs, hipStream_t s);
 void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
-                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s);
+                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s, hipEvent_t ev_start = nullptr,
+                         hipEvent_t ev_stop = nullptr);
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s);
@@ -77,7 +79,8 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
 void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
-                           hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr, bool same_candidates = false);
+                           hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr, bool same_candidates = false,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,

@@ -117,8 +117,11 @@ def gpu_unpack(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor
 
 
 def write_synthetic_demo(directory: str, n_frames: int, image_size=(64, 64), feature_dim: int = 16, num_history: int = 3,
-                         prediction_horizon: int = 1, ngrippers: int = 1, camera: str = "pov", seed: int = 0) -> None:
-    """A demo in the reference's on-disk layout with random content (tests / loader benchmarks)."""
+                         prediction_horizon: int = 1, ngrippers: int = 1, camera: str = "pov", seed: int = 0,
+                         vertex_count_range=(200, 3000)) -> None:
+    """A demo in the reference's on-disk layout with random content (tests / loader benchmarks).  ``vertex_count_range``: the
+    reference stores the UNSAMPLED feature mesh of a frame (save_feature_mesh_to_disk calls get_vertices_and_features with
+    sample_vertices=False, nvblox_to_disk_helpers.py:40-50), i.e. 10^4 .. 10^5 vertices; the default keeps the tests small."""
     os.makedirs(directory, exist_ok=True)
     g = torch.Generator().manual_seed(seed)
     H, W = image_size
@@ -129,7 +132,7 @@ def write_synthetic_demo(directory: str, n_frames: int, image_size=(64, 64), fea
                      torch.nn.functional.normalize(torch.tensor([0.5, -0.5, 0.5, -0.5]) + 0.01 * torch.randn(4, generator=g), dim=0))
         D.write_intrinsics(D.frame_path(directory, i, f"{camera}_intrinsics.npy"),
                            torch.tensor([[586.4 * W / 512, 0.0, W / 2.0], [0.0, 586.4 * H / 512, H / 2.0], [0.0, 0.0, 1.0]]))
-        nv = int(torch.randint(200, 3000, (1,), generator=g))
+        nv = int(torch.randint(int(vertex_count_range[0]), int(vertex_count_range[1]), (1,), generator=g))
         D.write_vertex_features(D.frame_path(directory, i, D.VERTEX_FEATURES_FILE_NAME), torch.rand(nv, 3, generator=g),
                                 torch.randn(nv, feature_dim, generator=g))
 

@@ -570,26 +570,41 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
   int sub = P->raycast_subsampling < 1 ? 1 : P->raycast_subsampling;
   float s0[3];
   for (int a = 0; a < 3; ++a) s0[a] = T_L_C->t[a] * m->inv_bs;
-  for (int r = 0; r < cam->H; r += sub) {
-    for (int c = 0; c < cam->W; c += sub) {
-      float d = depth[(size_t)r * cam->W + c];
-      if (!(d > 0.0f)) continue;
-      if (mask && !mask[(size_t)r * cam->W + c]) continue;
-      if (P->max_integration_distance_m > 0.0f && d > P->max_integration_distance_m)
-        d = P->max_integration_distance_m;
-      float s = d + m->trunc;
-      float ray[3] = {((float)c + 0.5f - cam->cx) / cam->fx, ((float)r + 0.5f - cam->cy) / cam->fy, 1.0f};
-      float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
-      float pL[3];
-      xform(T_L_C, pC, pL);
-      float e[3] = {pL[0] * m->inv_bs, pL[1] * m->inv_bs, pL[2] * m->inv_bs};
-      walk_t w;
-      walk_init(&w, s0, e);
-      for (int i = 0; i <= w.n; ++i) {
-        if (in_workspace(m, w.c[0], w.c[1], w.c[2])) set3_insert(&S, w.c[0], w.c[1], w.c[2]);
-        walk_step(&w);
+  /* rows are independent: every thread collects into its own set, the sets are merged afterwards (the result is a
+   * sorted set, so neither the thread count nor the merge order can change it) */
+#pragma omp parallel
+  {
+    set3 Sl;
+    set3_init(&Sl, 1024);
+#pragma omp for schedule(dynamic, 8) nowait
+    for (int r = 0; r < cam->H; r += sub) {
+      for (int c = 0; c < cam->W; c += sub) {
+        float d = depth[(size_t)r * cam->W + c];
+        if (!(d > 0.0f)) continue;
+        if (mask && !mask[(size_t)r * cam->W + c]) continue;
+        if (P->max_integration_distance_m > 0.0f && d > P->max_integration_distance_m)
+          d = P->max_integration_distance_m;
+        float s = d + m->trunc;
+        float ray[3] = {((float)c + 0.5f - cam->cx) / cam->fx, ((float)r + 0.5f - cam->cy) / cam->fy, 1.0f};
+        float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
+        float pL[3];
+        xform(T_L_C, pC, pL);
+        float e[3] = {pL[0] * m->inv_bs, pL[1] * m->inv_bs, pL[2] * m->inv_bs};
+        walk_t w;
+        walk_init(&w, s0, e);
+        for (int i = 0; i <= w.n; ++i) {
+          if (in_workspace(m, w.c[0], w.c[1], w.c[2])) set3_insert(&Sl, w.c[0], w.c[1], w.c[2]);
+          walk_step(&w);
+        }
       }
     }
+#pragma omp critical(orc_view_merge)
+    {
+      for (int i = 0; i < Sl.cap; ++i)
+        if (Sl.used[i]) set3_insert(&S, Sl.keys[3 * i], Sl.keys[3 * i + 1], Sl.keys[3 * i + 2]);
+    }
+    free(Sl.keys);
+    free(Sl.used);
   }
   if (m->cand_cap < S.n) {
     m->cand_cap = S.n;
@@ -1276,5 +1291,14 @@ int orc_num_threads(void) {
   return omp_get_max_threads();
 #else
   return 1;
+#endif
+}
+
+/* bench.py's cpu_baseline sweeps the thread count and reports the best */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
 #endif
 }

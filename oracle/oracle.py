@@ -253,3 +253,7 @@ class OracleMapper:
 
 def num_threads() -> int:
     return lib().orc_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(int(n))

@@ -1,5 +1,6 @@
 """Average PMC counter value per dispatch and kernel from rocprofv3 `--pmc X --output-format csv` runs.
-Usage: python tools/pmc_summary.py out.json <dir_or_csv> [<dir_or_csv> ...]
+Usage: python tools/pmc_summary.py out.json "<source label>" <dir_or_csv> [<dir_or_csv> ...]
+The label (which run the numbers come from) is stored under "__source__"; bench.py quotes it as `roofline.traffic_source`.
 Kernel names are shortened to the function name (no namespace, template arguments or parameters).  FETCH_SIZE / WRITE_SIZE
 are reported in KB as the counters deliver them (gfx950: double FETCH_SIZE before comparing with byte counts, see
 /opt/skills/guides/MI355X_MICROARCH.md)."""
@@ -19,7 +20,7 @@ def short(name):
     return name.split("::")[-1].replace(".kd", "")
 
 
-def main(out, paths):
+def main(out, source, paths):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for p in paths:
         files = [p] if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True)
@@ -37,10 +38,11 @@ def main(out, paths):
         for c, (tot, n) in cs.items():
             res[k][c + ("_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = tot / n
             res[k]["dispatches"] = n
+    res["__source__"] = source
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     print(f"{len(res)} kernels -> {out}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])
