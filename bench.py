@@ -428,21 +428,43 @@ def run_tsdf_only(device, steps=200, warmup=20):
 
 
 def run_closed_loop(device, steps=5):
-    """BASELINE configs[3]: one control step of the closed loop on one GPU, end to end -- decay + fused RGB-D/feature frame
-    (512x512, 768 feature channels, the reference's shape) -> surface vertices + features sampled to 2048
-    (get_vertices_and_features) -> depth back-projection -> policy inference (encoder + 100 denoising steps, fused ops + HIP
-    graph).  The backbone's feature extraction for the frame is part of the policy encoder here (random-init ViT-B/16)."""
-    from nvblox_mindmap_amd.data_loading.vertex_sampling import VertexSamplingMethod
+    """BASELINE configs[3]: one control step of the closed loop on one GPU, end to end, through the object the reference's policy
+    drives (mapping/isaaclab_nvblox_mapper.py; closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83,206-211):
+    mapper.decay() + update_reconstruction_from_sample (input helpers: pose 7-vector -> 4x4, rgb float -> u8, back-projection;
+    then the fused RGB-D/feature frame, 512x512, 768 feature channels) -> get_nvblox_model_inputs (surface vertices + features
+    sampled to 2048) -> policy inference (encoder + 100 denoising steps, fused ops + HIP graph).  The image backbone runs once,
+    inside the policy encoder (random-init ViT-B/16); the mapper's extractor hands the stream's pre-computed feature image over."""
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
     from nvblox_mindmap_amd.image_processing.backprojection import get_camera_pointcloud
-    from nvblox_mindmap_amd.mapping.helpers.nvblox_output_helpers import get_vertices_and_features
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
     from nvblox_mindmap_amd.training import build_model, synthetic_batch
 
     C = 768
     cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
-    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     frames = build_stream(cfg, 4, C, device)
-    mapper = get_nvblox_mapper(mcfg, feature_channels=C)
+
+    class Extractor:
+        next = None
+
+        def compute(self, rgb):
+            return self.next.unsqueeze(0)
+
+        def num_excess_features(self):
+            return 0
+
+    ex = Extractor()
+    facade = IsaacLabNvbloxMapper("rgbd_and_mesh", None, device, feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
+                                  num_vertices_to_sample=2048)
+    from scipy.spatial.transform import Rotation
+
+    samples = []
+    for fr in frames:  # what the loader / simulator hands the policy: [1, ncam, ...] tensors on the device
+        T = fr["T_W_C"].numpy().astype(np.float64)
+        q = Rotation.from_matrix(T[:3, :3]).as_quat()
+        pose7 = torch.tensor(np.concatenate([T[:3, 3], [q[3], q[0], q[1], q[2]]]), dtype=torch.float32, device=device)
+        samples.append({"depths": fr["depth"][None, None], "intrinsics": fr["K"].to(device)[None, None], "camera_poses": pose7[None, None],
+                        "rgbs": (fr["rgb"].permute(2, 0, 1).float() / 255.0)[None, None].contiguous(),
+                        "segmentation_masks": fr["dynamic_mask"][None, None]})
     pcfg = DiffuserActorConfig()
     torch.manual_seed(0)
     model = build_model(pcfg, device=device).eval()
@@ -452,21 +474,20 @@ def run_closed_loop(device, steps=5):
     parts = {"fusion": 0.0, "map_to_model_input": 0.0, "policy_inference": 0.0}
 
     def control_step(i, record):
-        fr = frames[i % 4]
+        fr, smp = frames[i % 4], samples[i % 4]
+        ex.next = fr["features"]
         t = [time.perf_counter()]
-        step(mapper, mcfg, fr)
+        facade.decay()
+        facade.update_reconstruction_from_sample(smp, "pov")
         torch.cuda.synchronize(device)
         t.append(time.perf_counter())
-        v, f, valid = get_vertices_and_features(mapper, MAPPER_TO_ID.STATIC, mcfg, remove_zero_features=True, num_excess_features=0,
-                                                sample_vertices=True, number_of_vertices_to_sample=2048,
-                                                vertex_sampling_method=VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT)
-        q = torch.tensor([[0.5, -0.5, 0.5, -0.5]], device=device)
-        pcd = get_camera_pointcloud(fr["K"].to(device)[None], fr["depth"][None], fr["T_W_C"][:3, 3].to(device)[None], q)
-        rgb = (fr["rgb"].permute(2, 0, 1).float() / 255.0)[None, None]
+        inp = facade.get_nvblox_model_inputs(MAPPER_TO_ID.STATIC, remove_zero_features=True)
+        pcd = get_camera_pointcloud(smp["intrinsics"][0], smp["depths"][0], smp["camera_poses"][0, :, :3], smp["camera_poses"][0, :, 3:])
         torch.cuda.synchronize(device)
         t.append(time.perf_counter())
         with torch.no_grad():
-            traj = model(None, None, rgb, pcd[:, None], (fr["depth"] > 0)[None, None], f.float(), v, valid, None, hist, run_inference=True)[0]
+            traj = model(None, None, smp["rgbs"], pcd[:, None], (smp["depths"] > 0), inp["vertex_features"], inp["vertices"],
+                         inp["vertices_valid_mask"], None, hist, run_inference=True)[0]
         torch.cuda.synchronize(device)
         t.append(time.perf_counter())
         if record:
@@ -484,8 +505,9 @@ def run_closed_loop(device, steps=5):
     finally:
         DiffuserActor.enable_fused_inference(False)
     out = {"ms_per_control_step": total, "control_steps_per_s": 1e3 / total, "breakdown_ms": {k: v / steps for k, v in parts.items()},
-           "shape": "512x512 RGB-D, 768 feature channels, 2048 sampled vertices, 100 denoising steps, batch 1"}
-    del mapper, model, frames
+           "shape": "512x512 RGB-D, 768 feature channels, 2048 sampled vertices, 100 denoising steps, batch 1",
+           "through": "IsaacLabNvbloxMapper.update_reconstruction_from_sample / get_nvblox_model_inputs"}
+    del facade, model, frames, samples
     torch.cuda.empty_cache()
     return out
 
@@ -631,6 +653,9 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
         t_write = time.perf_counter() - t0
         ds = MindmapFrameDataset(root, num_vertices=2048)
         mb = sum(os.path.getsize(p) for smp in ds.samples for p in smp.values()) / len(ds) / 1e6
+        # a DataLoader hands whole batches to workers: an epoch must hold several batches per worker or most workers idle.  The
+        # frames on disk are revisited (page-cache reads; a real dataset adds storage latency on top of what is measured here)
+        ds.samples = ds.samples * max(1, -(-3 * workers * per_gpu_batch // len(ds.samples)))
 
         def loader():
             return DataLoader(ds, batch_size=per_gpu_batch, shuffle=True, num_workers=workers, drop_last=False, pin_memory=True,
@@ -638,13 +663,13 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
 
         dl = loader()
         n = 0
-        for b in dl:  # first epoch: page cache + worker start-up, untimed
-            n += b["rgb_u8"].shape[0]
+        for i, b in enumerate(dl):  # page cache + worker start-up, untimed
+            if i >= workers:
+                break
         t0 = time.perf_counter()
         n = 0
-        for _ in range(2):
-            for b in dl:
-                n += b["rgb_u8"].shape[0]
+        for b in dl:
+            n += b["rgb_u8"].shape[0]
         loader_sps = n / (time.perf_counter() - t0)
 
         torch.manual_seed(0)

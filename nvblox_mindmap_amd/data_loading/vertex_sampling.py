@@ -50,8 +50,8 @@ def sample_to_n_vertices(vertices: torch.Tensor, features: torch.Tensor, desired
         vertices, features = vertices[sel, :], features[sel, :]
     else:
         pad = desired_num_vertices - n
-        features = torch.cat([features, torch.zeros((pad, features.shape[1]), device=features.device)], dim=0)
-        vertices = torch.cat([vertices, torch.zeros((pad, vertices.shape[1]), device=dev)], dim=0)
+        features = torch.cat([features, torch.zeros((pad, features.shape[1]), device=features.device, dtype=features.dtype)], dim=0)
+        vertices = torch.cat([vertices, torch.zeros((pad, vertices.shape[1]), device=dev, dtype=vertices.dtype)], dim=0)
         valid_mask = torch.ones(desired_num_vertices, device=dev, dtype=torch.bool)
         valid_mask[n:] = False
     assert vertices.shape[0] == desired_num_vertices and features.shape[0] == desired_num_vertices

@@ -1,0 +1,135 @@
+"""A2 input helpers + the IsaacLabNvbloxMapper facade (mindmap/mapping/helpers/nvblox_input_helpers.py:18-82,
+mindmap/mapping/isaaclab_nvblox_mapper.py:35-258) on the GPU, including the end-to-end check of BASELINE configs[3] at the
+reference's real shape: loader sample -> facade (fused 512x512x768 frames) == CPU oracle, -> model inputs -> policy."""
+import numpy as np
+import pytest
+import torch
+
+from fusion_common import make_oracle
+from nvblox_mindmap_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make_sample(cfg, index, device, ncam=1, dynamic=None):
+    """A loader sample as get_nvblox_inputs_from_sample expects it (shapes of nvblox_input_helpers.py:26-33)."""
+    T = S.camera_pose(cfg, index)
+    depth = S.render_depth(cfg, T)
+    rgb = S.render_rgb(cfg, index).astype(np.float32) / 255.0
+    from scipy.spatial.transform import Rotation
+
+    q = Rotation.from_matrix(T[:3, :3].astype(np.float64)).as_quat()  # xyzw
+    pose7 = np.concatenate([T[:3, 3], [q[3], q[0], q[1], q[2]]]).astype(np.float32)
+    dyn = np.zeros((cfg.height, cfg.width), dtype=bool) if dynamic is None else dynamic
+    one = lambda a: torch.from_numpy(np.stack([a] * ncam)[None]).to(device)  # noqa: E731
+    return {"depths": one(depth), "intrinsics": one(cfg.intrinsics()), "camera_poses": one(pose7),
+            "rgbs": one(np.ascontiguousarray(rgb.transpose(2, 0, 1))), "segmentation_masks": one(dyn)}, T, depth
+
+
+def test_get_nvblox_inputs_from_sample_matches_the_reference_semantics():
+    from oracle import image_ops as IMG
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_input_helpers import get_nvblox_inputs_from_sample
+
+    cfg = S.StreamConfig(width=64, height=48, fx=52.5, fy=52.5, cx=31.5, cy=23.5)
+    sample, T, depth = make_sample(cfg, 3, "cuda", ncam=2)
+    sample["rgbs"][0, 1, :, 0, 0] = torch.tensor([0.999, 0.5, 1.0], device="cuda")  # truncation: 254.745 -> 254, 127.5 -> 127
+    d, K, Th, rgb, dyn, pcd = get_nvblox_inputs_from_sample(sample, 1)
+    assert d.shape == (48, 64) and K.shape == (3, 3) and Th.shape == (4, 4) and rgb.shape == (48, 64, 3) and rgb.dtype == torch.uint8
+    assert dyn.dtype == torch.bool and dyn.shape == (48, 64) and pcd.shape == (3, 48, 64)
+    assert rgb[0, 0].tolist() == [254, 127, 255]
+    assert torch.equal(rgb, (sample["rgbs"][0, 1].permute(1, 2, 0) * 255).to(torch.uint8))
+    pose7 = sample["camera_poses"][0, 1].cpu().numpy()
+    assert np.abs(Th.cpu().numpy() - IMG.pose_to_homo(pose7)[0]).max() <= 1e-6
+    assert np.abs(Th.cpu().numpy() - T).max() <= 1e-5  # quaternion round trip of the stream's pose
+    ref = IMG.get_camera_pointcloud(cfg.intrinsics()[None], depth[None], pose7[None, :3], pose7[None, 3:])[0]
+    assert np.abs(pcd.cpu().numpy() - ref).max() <= 1e-5
+    with pytest.raises(AssertionError):
+        get_nvblox_inputs_from_sample(sample, 2)
+    bad = dict(sample)
+    bad["rgbs"] = sample["rgbs"] * 2.0
+    with pytest.raises(AssertionError):
+        get_nvblox_inputs_from_sample(bad, 0)
+
+
+class StreamFeatures:
+    """Stand-in extractor: hands the synthetic stream's feature image over (the DNN is out of scope)."""
+
+    def __init__(self):
+        self.next = None
+
+    def compute(self, rgb):
+        assert rgb.shape[0] == 1 and rgb.dtype == torch.uint8
+        return self.next.unsqueeze(0)
+
+    def num_excess_features(self):
+        return 0
+
+
+def test_facade_closed_loop_at_the_reference_shape_matches_the_oracle():
+    """512x512, 768 feature channels, DRILL_IN_BOX mask algebra (17 / 20-pixel erosions, 25-pixel border), three frames with a
+    decay before each: facade.update_reconstruction_from_sample vs the oracle driven call by call; then the model inputs and one
+    policy inference from them."""
+    from oracle import image_ops as IMG
+    from oracle import oracle as O
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID
+    from nvblox_mindmap_amd.training import build_model, synthetic_batch
+
+    C = 768
+    cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
+    ex = StreamFeatures()
+    facade = IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
+                                  num_vertices_to_sample=2048)
+    mc = facade.mapping_config
+    orc = make_oracle(O, C, tsdf_decay_factor=mc.tsdf_decay_factor)
+    for idx in (0, 7, 14):
+        sample, T, depth = make_sample(cfg, idx, "cuda")
+        feat = S.render_features(cfg, idx, C)
+        ex.next = torch.from_numpy(feat).cuda()
+        facade.decay()
+        facade.update_reconstruction_from_sample(sample, "pov")
+        rgb_u8 = (sample["rgbs"][0, 0].permute(1, 2, 0) * 255).to(torch.uint8).cpu().numpy()
+        pose7 = sample["camera_poses"][0, 0].cpu().numpy()
+        Th = IMG.pose_to_homo(pose7)[0]
+        dm, fm = IMG.frame_masks(np.ones(depth.shape, bool), depth, mc.min_integration_distance_m, mc.static_mask_erosion_iterations,
+                                 mc.valid_depth_mask_erosion_iterations, mc.feature_mask_border_percent, 512, 512)
+        orc.decay()
+        orc.add_depth_frame(depth, Th, cfg.intrinsics(), dm.astype(np.uint8))
+        orc.add_color_frame(rgb_u8, Th, cfg.intrinsics(), dm.astype(np.uint8))
+        orc.add_feature_frame(feat, Th, cfg.intrinsics(), fm.astype(np.uint8))
+    images = facade.last_nvblox_integration_images["pov"]["STATIC"]
+    assert np.array_equal(images["feature_mask"].cpu().numpy().astype(bool), fm) and images["pcd"].shape == (1, 512, 512, 3)
+    m = facade.mapper
+    blocks, idx = m.tsdf_layer_view(0).get_all_blocks()
+    assert np.array_equal(idx.cpu().numpy(), orc.block_indices(0))
+    assert np.abs(blocks.cpu().numpy() - orc.all_tsdf()).max() <= 1e-5
+    fg, wg, fidx = m.feature_layer_view(0).get_all_blocks_split()
+    fo, wo = orc.all_features()
+    assert fidx.shape[0] > 100 and np.array_equal(fidx.cpu().numpy(), orc.block_indices(2))
+    assert np.array_equal(wg.cpu().numpy(), wo)
+    assert np.abs(fg.cpu().numpy().astype(np.float32) - fo.astype(np.float32)).max() <= 1e-5
+    del fg, fo
+    # map -> model inputs (isaaclab_nvblox_mapper.py:207-250), against the oracle's mesh
+    torch.manual_seed(0)
+    inputs = facade.get_nvblox_model_inputs(MAPPER_TO_ID.STATIC, remove_zero_features=True)
+    v, f, valid = inputs["vertices"], inputs["vertex_features"], inputs["vertices_valid_mask"]
+    assert v.shape == (1, 2048, 3) and f.shape == (1, 2048, C) and valid.shape == (1, 2048) and f.dtype == torch.float32 and valid.all()
+    ov, of = orc.feature_mesh()
+    lo, hi = mc.aabb_min_m.numpy(), mc.aabb_max_m.numpy()
+    keep = np.all((ov > lo) & (ov < hi), axis=1) & np.any(of != 0, axis=1)
+    table = {tuple(np.round(p * 1e6).astype(np.int64)): i for i, p in enumerate(ov) if keep[i]}
+    vv, ff = v[0].cpu().numpy(), f[0].cpu().numpy()
+    for p, row in zip(vv[::64], ff[::64]):  # every sampled vertex is a kept oracle vertex carrying that vertex' feature row
+        i = table[tuple(np.round(p * 1e6).astype(np.int64))]
+        assert np.array_equal(row, of[i].astype(np.float32))
+    # ... -> policy (configs[3]'s last stage; few denoising steps: the 100-step loop is timed by bench.py)
+    pcfg = DiffuserActorConfig(data_type="mesh", feature_dim=C, diffusion_timesteps=5)
+    torch.manual_seed(0)
+    model = build_model(pcfg, device="cuda").eval()
+    hist = synthetic_batch(pcfg, 1, "cuda", seed=3)["gripper_history"]
+    with torch.no_grad():
+        traj, head_yaw, _, _, _ = model(None, None, None, None, None, f, v, valid, None, hist, run_inference=True)
+    assert traj.shape == (1, pcfg.prediction_horizon, pcfg.ngrippers, 8) and torch.isfinite(traj).all() and torch.isfinite(head_yaw).all()
+    facade.clear()
+    assert m.tsdf_layer_view(0).num_allocated_blocks() == 0
