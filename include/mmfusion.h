@@ -391,6 +391,11 @@ int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream);
  * over the mask column workgroups that share the launch: latest end [6], earliest start [7], longest duration [8],
  * latest start [9].  Synchronises. */
 int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out10);
+/* Diagnostics: number of new TSDF blocks that were integrated by the sweeper of k_alloc_tsdf since the mapper was created,
+ * i.e. blocks whose waiter workgroup abandoned its wait for the allocation workgroups of the same launch (0 in normal
+ * operation; the environment variable MMF_DEBUG_FORCE_ALLOC_TIMEOUT=1 at mapper creation makes half of the waiters abandon
+ * at once, =2 makes the sweeper fail too: the next call on the mapper then returns MMF_ERR_BAD_STATE once).  Synchronises. */
+int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_t* out);
 /* Diagnostics: per-workgroup timeline of the fused frame kernels.  buffer_dev: uint64 [3 * capacity_records] on the device
  * (capacity_records >= 6 * 8192; the caller zeroes it), records {role id, start, end} in 100 MHz ticks at slot
  * (role id / 10 - 1) * 8192 + workgroup index; null = off (the default).

@@ -332,8 +332,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
 // workgroup publishes the number of granted blocks {tag | n} at J.pub[0].  All with relaxed agent-scope atomics, no fences: a
 // reader polls until the tag of the word it needs is this launch's.  The grid flags are left set: the launch's TSDF
 // workgroups read them too; a later launch of the frame clears them.
-constexpr int kPubRec = 16;      // J.pub: [0] total, [1 .. 8] per-workgroup counts, [kPubRec ..] new-block records
-constexpr int kAllocMaxWgs = 8;  // kFusedAllocMaxCells / 2 048
+// (kPubRec, kAllocMaxWgs: mmf_device.h)
 template <int NW, int G>
 __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats, int* lds, int* carry, int* ctx, int w, int nwg) {
   const LayerDev& L = J.L;

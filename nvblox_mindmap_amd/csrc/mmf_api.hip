@@ -64,7 +64,10 @@ struct Mapper {
   int grid_tag = 0;
   bool allow_merged = true;    // false: environment MMF_NO_ALLOC_TSDF=1 at creation -- keep allocation and TSDF pass as separate launches
                                // (the reference point of the parity tests of k_alloc_tsdf)
-  u64* pub = nullptr;          // [16 + 3 * cap] new blocks published by the allocation workgroup of k_alloc_tsdf to its own launch
+  u64* pub = nullptr;          // [16 + 3 * cap + 2 + kNewBlockWgs] new blocks published by the allocation workgroups of k_alloc_tsdf to
+                               // their own launch + the control words of the hand-over (AllocJob::pub)
+  unsigned pub_tag = 0;        // tag of the last k_alloc_tsdf launch (30 bits, incremented by those launches only; 0 is never used)
+  int debug_abandon = 0;       // environment MMF_DEBUG_FORCE_ALLOC_TIMEOUT at creation (test hook of the hand-over's recovery)
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
   long long frames[3] = {0, 0, 0};
   // synthetic depth + cache key
@@ -250,6 +253,7 @@ void derive_consts(const mmf_params& P, MapConsts& mc) {
 }
 
 int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
+  L.allocated = true;  // from here on free_layer releases whatever exists (a failure below must not leak the earlier buffers)
   L.block_bytes = block_bytes;
   L.has_w = has_w;
   L.d.cap = cap;
@@ -349,15 +353,12 @@ int attach_dense_table(const Mapper& m, Layer& L) {
   return MMF_OK;
 }
 
-int create_mapper(const mmf_params& P, Mapper** out) {
-  if (!(P.voxel_size_m > 0.f)) return fail(MMF_ERR_INVALID_ARG, "voxel_size_m must be > 0");
-  if (P.feature_channels <= 0 || P.feature_channels % 8 != 0)
-    return fail(MMF_ERR_INVALID_ARG, "feature_channels must be a positive multiple of 8");
-  if (P.workspace_bounds_type < 0 || P.workspace_bounds_type > 2)
-    return fail(MMF_ERR_INVALID_ARG, "workspace_bounds_type must be 0, 1 or 2");
-  if (P.workspace_bounds_type != 2 && !(P.max_integration_distance_m > 0.f))
-    return fail(MMF_ERR_INVALID_ARG, "max_integration_distance_m must be > 0 unless the workspace is a bounding box");
-  Mapper* m = new Mapper();
+size_t pub_words(const Mapper& m) { return kPubRec + 3 * (size_t)m.tsdf.d.cap + 2 + kNewBlockWgs; }
+
+void destroy_mapper(Mapper* m);
+
+// Fills a freshly constructed Mapper; on failure the caller (create_mapper) releases whatever was allocated so far.
+int create_mapper_impl(const mmf_params& P, Mapper* m) {
   m->P = P;
   derive_consts(P, m->mc);
   int cap, app_cap;
@@ -367,16 +368,10 @@ int create_mapper(const mmf_params& P, Mapper** out) {
     long long n = 1;
     for (int a = 0; a < 3; ++a) {
       long long d = (long long)m->mc.ws_hi[a] - m->mc.ws_lo[a] + 1;
-      if (d <= 0) {
-        delete m;
-        return fail(MMF_ERR_INVALID_ARG, "empty workspace bounds");
-      }
+      if (d <= 0) return fail(MMF_ERR_INVALID_ARG, "empty workspace bounds");
       n *= d;
     }
-    if (n > (1ll << 24)) {
-      delete m;
-      return fail(MMF_ERR_INVALID_ARG, "workspace bounding box too large; set num_preallocated_blocks");
-    }
+    if (n > (1ll << 24)) return fail(MMF_ERR_INVALID_ARG, "workspace bounding box too large; set num_preallocated_blocks");
     cap = app_cap = (int)n;
   } else {
     cap = 65536;
@@ -385,11 +380,7 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   m->app_cap = app_cap;
   HIP_TRY(hipHostMalloc(&m->hints, sizeof(int) * 8));
   for (int i = 0; i < 8; ++i) m->hints[i] = 0;
-  int rc = alloc_layer(m->tsdf, cap, sizeof(float2) * kVPB, false);
-  if (rc != MMF_OK) {
-    delete m;
-    return rc;
-  }
+  MMF_TRY(alloc_layer(m->tsdf, cap, sizeof(float2) * kVPB, false));
   MMF_TRY(attach_dense_table(*m, m->tsdf));
   m->tsdf.d.hint_live = m->hints + 3;
   HIP_TRY(hipMalloc(&m->tsdf.d.block_free, (size_t)cap));
@@ -404,8 +395,12 @@ int create_mapper(const mmf_params& P, Mapper** out) {
     const char* e = std::getenv("MMF_NO_ALLOC_TSDF");
     m->allow_merged = !(e && e[0] == '1');
   }
-  HIP_TRY(hipMalloc(&m->pub, sizeof(u64) * (16 + 3 * (size_t)cap)));
-  HIP_TRY(hipMemset(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)cap)));
+  HIP_TRY(hipMalloc(&m->pub, sizeof(u64) * pub_words(*m)));
+  HIP_TRY(hipMemset(m->pub, 0, sizeof(u64) * pub_words(*m)));
+  {
+    const char* e = std::getenv("MMF_DEBUG_FORCE_ALLOC_TIMEOUT");
+    m->debug_abandon = e ? std::atoi(e) : 0;
+  }
   HIP_TRY(hipMalloc(&m->any_kill, sizeof(int)));
   HIP_TRY(hipMemset(m->any_kill, 0, sizeof(int)));
   HIP_TRY(hipMalloc(&m->stats, sizeof(long long) * MMF_NUM_STATS));
@@ -417,9 +412,23 @@ int create_mapper(const mmf_params& P, Mapper** out) {
   HIP_TRY(hipMalloc(&m->mesh_toffsets, sizeof(int) * (size_t)cap));
   HIP_TRY(hipMalloc(&m->mesh_tout2, sizeof(int) * 2));
   m->mesh_cap = cap;
-  rc = ensure_scratch(*m, 0, cap);
+  return ensure_scratch(*m, 0, cap);
+}
+
+int create_mapper(const mmf_params& P, Mapper** out) {
+  if (!(P.voxel_size_m > 0.f)) return fail(MMF_ERR_INVALID_ARG, "voxel_size_m must be > 0");
+  if (P.feature_channels <= 0 || P.feature_channels % 8 != 0)
+    return fail(MMF_ERR_INVALID_ARG, "feature_channels must be a positive multiple of 8");
+  if (P.workspace_bounds_type < 0 || P.workspace_bounds_type > 2)
+    return fail(MMF_ERR_INVALID_ARG, "workspace_bounds_type must be 0, 1 or 2");
+  if (P.workspace_bounds_type != 2 && !(P.max_integration_distance_m > 0.f))
+    return fail(MMF_ERR_INVALID_ARG, "max_integration_distance_m must be > 0 unless the workspace is a bounding box");
+  Mapper* m = new Mapper();
+  const int rc = create_mapper_impl(P, m);
   if (rc != MMF_OK) {
-    delete m;
+    const std::string msg = g_err;  // the releases below must not clobber the message of the failure
+    destroy_mapper(m);              // every earlier allocation (hipFree(nullptr) is a no-op)
+    g_err = msg;
     return rc;
   }
   *out = m;
@@ -643,6 +652,37 @@ int ensure_mask_scratch(Mapper& m, int H, int W) {
   return MMF_OK;
 }
 
+// Tag of the next k_alloc_tsdf launch.  Words of earlier launches stay in the buffer and are told apart by their tag, so the
+// buffer is zeroed when the 30-bit counter wraps (no stale word may validate against a reused tag).
+int next_pub_tag(Mapper& m, hipStream_t s, unsigned* tag) {
+  m.pub_tag = (m.pub_tag + 1) & 0x3fffffffu;
+  if (m.pub_tag == 0) {
+    HIP_TRY(hipMemsetAsync(m.pub, 0, sizeof(u64) * pub_words(m), s));
+    m.pub_tag = 1;
+  }
+  *tag = m.pub_tag;
+  return MMF_OK;
+}
+
+// Errors the device raised asynchronously (LayerDev::ctr[3] of the TSDF layer; the hard one also sets the pinned flag
+// hints[7]).  Called where the API synchronises anyway (`synced`: ctr[3] has just been copied to *err_bits) and, for the pinned
+// flag alone, at the start of every frame.  An error is reported ONCE and cleared: the caller decides how to go on (clear()).
+int report_device_errors(mmf_handle h, Mapper& m, Layer* layer, const int* err_bits, hipStream_t s) {
+  int bits = err_bits ? *err_bits : 0;
+  if (m.hints && m.hints[7]) bits |= 2;
+  if (!(bits & 3)) return MMF_OK;
+  if (m.hints[7]) {
+    m.hints[7] = 0;
+    HIP_TRY(hipMemsetAsync(m.tsdf.d.ctr + 3, 0, sizeof(int), s));
+  }
+  if (layer && layer->allocated) HIP_TRY(hipMemsetAsync(layer->d.ctr + 3, 0, sizeof(int), s));
+  if (bits & 2)
+    return fail(MMF_ERR_BAD_STATE, "k_alloc_tsdf: the in-launch hand-over of new blocks failed (waiters and sweeper timed out waiting for the "
+                                   "allocation workgroups of their launch); the TSDF map is incomplete -- clear() it, and set "
+                                   "MMF_NO_ALLOC_TSDF=1 to keep allocation and TSDF pass as separate launches");
+  return fail(MMF_ERR_POOL_EXHAUSTED, "voxel-block pool exhausted: raise BlockMemoryPoolParams.num_preallocated_blocks");
+}
+
 int untag_grid(Mapper& m, hipStream_t s) {
   if (m.grid_tagged && m.sc[0].flags) HIP_TRY(hipMemsetAsync(m.sc[0].flags, 0, (size_t)m.sc_cap[0], s));
   m.grid_tagged = false;
@@ -814,6 +854,7 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
   if (!depth || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_depth_frame");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
+  MMF_TRY(report_device_errors(h, *m, nullptr, nullptr, s));
   Cam cam = cam_from_K(K9, W, H);
   Rigid T_L_C, T_C_L;
   rigid_from_T(T16, T_L_C);
@@ -871,10 +912,10 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
     job.stat_new = 2;
     job.stamp = stamp;
     job.pub = m->pub;
-    job.pub_tag = (unsigned)stamp;
+    MMF_TRY(next_pub_tag(*m, s, &job.pub_tag));
     job.flag_value = grid_tag;
-    if ((m->tsdf_epoch & 0x3fffffff) == 0)
-      HIP_TRY(hipMemsetAsync(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)m->tsdf.d.cap), s));
+    job.host_err = m->hints + 7;
+    job.debug_abandon = m->debug_abandon;
     MaskJob Mc = M;
     Mc.Hf = 0;  // no column pass: there is no feature mask to emit
     launch_alloc_tsdf(job, m->stats, Mc, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
@@ -987,6 +1028,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                                      "use the separate add_*_frame calls otherwise");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
+  MMF_TRY(report_device_errors(h, *m, nullptr, nullptr, s));  // an earlier frame's hand-over failed for good: do not integrate on top
   MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
   MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)C, true));
   MMF_TRY(ensure_scratch(*m, 1, m->tsdf.d.cap));
@@ -1101,10 +1143,10 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     // TSDF allocation | mask column pass | TSDF update + appearance-candidate flags of every live block
     ProfExt pe(h, MMF_K_TSDF);
     job0.pub = m->pub;
-    job0.pub_tag = (unsigned)stamp;
+    MMF_TRY(next_pub_tag(*m, s, &job0.pub_tag));
     job0.flag_value = grid_tag;
-    if ((m->tsdf_epoch & 0x3fffffff) == 0)  // the 30-bit tag wraps (once in 2^30 frames): no stale word may carry a tag again
-      HIP_TRY(hipMemsetAsync(m->pub, 0, sizeof(u64) * (16 + 3 * (size_t)m->tsdf.d.cap), s));
+    job0.host_err = m->hints + 7;
+    job0.debug_abandon = m->debug_abandon;
     launch_alloc_tsdf(job0, m->stats, M, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
                       light_decay ? m->mc.decay_factor : 0.0f, s, pe.a(), pe.b());
     m->wmax_valid = true;  // refreshed for every live block
@@ -1234,6 +1276,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
     m->pending_decay = false;  // decaying blocks that are about to be dropped is a no-op
+    m->hints[7] = 0;           // (k_reset_layer zeroes the layer's error bits)
     launch_layer_reset(m->tsdf.d, s);
     m->wmax_valid = true;  // no live block
     if (m->color.allocated) launch_layer_reset(m->color.d, s);
@@ -1257,11 +1300,16 @@ int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_
     launch_mesh_count(m->tsdf.d, m->mc, m->mesh_counts, m->mesh_offsets, m->mesh_out2, s);
   }
   HIP_TRY(hipMemcpyAsync(h->pinned, m->mesh_out2, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->pinned + 11, m->tsdf.d.ctr + 3, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   m->mesh_V = h->pinned[0];
   m->mesh_nblocks = h->pinned[1];
   m->mesh_epoch = m->tsdf_epoch;
   *num_vertices = m->mesh_V;
+  {  // a natural synchronisation point: asynchronous device errors (hand-over failure, pool exhaustion) surface here, once
+    const int bits = h->pinned[11] & 2;  // (exhaustion keeps its own reporting point: mmf_num_allocated_blocks)
+    MMF_TRY(report_device_errors(h, *m, &m->tsdf, &bits, s));
+  }
   return check_launch();
 }
 
@@ -1336,11 +1384,7 @@ int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* strea
   HIP_TRY(hipMemcpyAsync(h->pinned + 8, L->d.ctr, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   *out = h->pinned[8];
-  if (h->pinned[11] & 2)  // a workgroup of k_alloc_tsdf gave up polling for a word of its own launch (never observed)
-    return fail(MMF_ERR_BAD_STATE, "k_alloc_tsdf: a workgroup timed out waiting for the allocation workgroups of its launch; the map is incomplete");
-  if (h->pinned[11] & 1)
-    return fail(MMF_ERR_POOL_EXHAUSTED, "voxel-block pool exhausted: raise BlockMemoryPoolParams.num_preallocated_blocks");
-  return MMF_OK;
+  return report_device_errors(h, *m, L, &h->pinned[11], s);
 }
 
 int mmf_get_block_indices(mmf_handle h, int mapper_id, int layer, int32_t* out, int n, void* stream) {
@@ -1811,6 +1855,18 @@ int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
   out8[0] = m->frames[0];
   out8[3] = m->frames[1];
   out8[5] = m->frames[2];
+  return MMF_OK;
+}
+
+int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_t* out) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (!out) return fail(MMF_ERR_INVALID_ARG, "null out");
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, m->pub + kPubRec + 3 * (size_t)m->tsdf.d.cap + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  *out = (int64_t)v;
   return MMF_OK;
 }
 

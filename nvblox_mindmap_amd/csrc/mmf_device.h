@@ -114,6 +114,10 @@ struct KeySrc {
 };
 
 // One compaction + allocation job (flags -> ordered candidate list, new blocks inserted) for one layer.
+constexpr int kNewBlockWgs = 32;  // waiter workgroups of k_alloc_tsdf (new blocks of the frame)
+constexpr int kPubRec = 16;       // AllocJob::pub: [0] total, [1 .. 8] per-workgroup counts, [kPubRec ..] new-block records
+constexpr int kAllocMaxWgs = 8;   // kFusedAllocMaxCells / 2 048
+
 struct AllocJob {
   LayerDev L;
   KeySrc ks;
@@ -125,8 +129,11 @@ struct AllocJob {
   int* any_kill = nullptr;
   int* zero_me = nullptr;  // != null: an int this job resets (the frame's feature survivor counter)
   long long* timeline = nullptr;  // != null: thread 0 stores wall_clock64() (100 MHz) at 6 points of the job (diagnostics)
-  u64* pub = nullptr;      // alloc_grid_multi_body: [16 + 3 * cap] published counts and new blocks (see there)
+  u64* pub = nullptr;      // alloc_grid_multi_body: [16 + 3 * cap + 2 + kNewBlockWgs] published counts, new blocks (see there) and
+                           // the control words of k_alloc_tsdf's hand-over (TsdfFrameArgs::ctl)
   unsigned pub_tag = 0;
+  int* host_err = nullptr; // pinned host int: set when the in-launch hand-over failed for good
+  int debug_abandon = 0;   // test hook, see TsdfFrameArgs
   int flag_value = 1;      // alloc_grid_multi_body: a grid cell is flagged iff its byte equals this (the frame's grid tag)
 };
 

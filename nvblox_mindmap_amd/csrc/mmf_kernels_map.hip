@@ -646,8 +646,12 @@ struct TsdfFrameArgs {
   const int* n_old;           // live blocks before this frame's allocation (ctr[6], published by k_front)
   const u64* pub;             // the allocation job's published new blocks
   unsigned tag;
-  int* err;                   // layer error flags (ctr[3]): bit 1 = a waiter gave up
+  int* err;                   // layer error flags (ctr[3]): bit 1 = the hand-over failed for good (see new_blocks_role)
   int n_pair_wgs, n_new_wgs;
+  u64* ctl;                   // control words of the hand-over, behind the records: [0] terminated / abandoned workgroup counter,
+                              // [1] ranks integrated by the sweeper (diagnostics), [2 + d] {tag | first abandoned round} of waiter d
+  int* host_err;              // pinned host int (may be null): set when the hand-over failed for good
+  int debug_abandon;          // test hook (MMF_DEBUG_FORCE_ALLOC_TIMEOUT): 1 = odd waiters "time out" at once, 2 = so does the sweeper
 };
 
 struct TsdfPairLds {
@@ -742,6 +746,145 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
   }
 }
 
+// One round of the new-block hand-over: the two halves of the workgroup take ranks k0 and k0 + 1 as soon as the allocation
+// workgroups of this launch have published them (they may still be scanning later cells) and integrate them from zeroed
+// voxels.  Workgroup-uniform result: 1 = round done, 0 = the published total says there is no rank k0 (ranks are granted in
+// order: nothing beyond a missing one), -1 = a half did not see its record within `bound` polls.
+__device__ inline int new_block_round(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int& par, int k0, int n_old, int bound,
+                                      bool pretend_timeout) {
+  const int half = threadIdx.x >> 7;
+  const int k = k0 + half;
+  if ((threadIdx.x & 127) == 0) {
+    int got = 0;
+    u64 w0 = 0;
+    for (int spins = 0; spins < bound && !pretend_timeout; ++spins) {
+      w0 = __hip_atomic_load(P.pub + kPubRec + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(w0 >> 32) == P.tag) {
+        got = 1;
+        break;
+      }
+      const u64 tot = __hip_atomic_load(P.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(tot >> 32) == P.tag) {
+        // (a rank below the total was published before the total: one more look at its word settles it)
+        if (k >= (int)(unsigned)(tot & 0xffffffffull)) {
+          got = -1;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (got == 1) {
+      u64 w1, w2;
+      int spins = 0;
+      do {
+        w1 = __hip_atomic_load(P.pub + kPubRec + 1 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w2 = __hip_atomic_load(P.pub + kPubRec + 2 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while (((unsigned)(w1 >> 32) != P.tag || (unsigned)(w2 >> 32) != P.tag) && ++spins < bound);
+      if ((unsigned)(w1 >> 32) != P.tag || (unsigned)(w2 >> 32) != P.tag) got = 0;
+      S.slot[half] = (int)(unsigned)(w0 & 0xffffffffull);
+      S.klo[half] = (unsigned)(w1 & 0xffffffffull);
+      S.khi[half] = (unsigned)(w2 & 0xffffffffull);
+    }
+    S.act[half] = got == 1 ? 1 : (got == 0 ? -1 : 0);
+  }
+  __syncthreads();
+  const int a0 = S.act[0], a1 = S.act[1];
+  int status = 1;
+  if (a0 < 0 || a1 < 0)
+    status = -1;
+  else if (!a0)
+    status = 0;
+  if (status == 1) {
+    const bool act = S.act[half] != 0;
+    const int slot = S.slot[half];
+    const u64 key = ((u64)S.khi[half] << 32) | (u64)S.klo[half];
+    tsdf_frame_block(L, P, S, par, act, n_old + k, slot, key, true, true);
+    par ^= 1;
+  }
+  __syncthreads();  // S.slot / klo / khi / act are rewritten by the next round
+  return status;
+}
+
+// The waiters of k_alloc_tsdf: workgroup d of n_new_wgs takes rounds d, d + n_new_wgs, ... (two ranks per round).
+// The hand-over relies on the allocation workgroups of the SAME launch making progress while a waiter polls; workgroups are
+// dispatched in index order and the producers lead the grid, so they are resident first -- but that is an observation about
+// the hardware, not a guarantee of the programming model.  A waiter therefore polls with a bound and, instead of leaving
+// allocated-but-never-initialised blocks behind when it expires, ABANDONS its remaining rounds: it publishes the first one as a
+// tagged word and counts itself out.  The workgroup that terminates last sees in the same counter whether anybody abandoned
+// and, if so, becomes the sweeper: it waits (much longer) for the published total and integrates every abandoned round itself.
+// Common path cost: one atomic per waiter workgroup at exit.  Only if the sweeper cannot finish either is the map incomplete:
+// it then raises error bit 1 (ctr[3]) and the pinned host flag, and the next API call on the mapper fails with
+// MMF_ERR_BAD_STATE instead of integrating on top of a broken map.
+__device__ inline void new_blocks_role(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int d, int n_old) {
+  const u64 tg = (u64)P.tag << 32;
+  const int stride = P.n_new_wgs * 2;
+  int par = 0, abandoned_at = -1;
+  for (int k0 = d * 2;; k0 += stride) {
+    const int st = new_block_round(L, P, S, par, k0, n_old, 1 << 22, P.debug_abandon != 0 && (d & 1) != 0);
+    if (st < 0) abandoned_at = k0;
+    if (st <= 0) break;
+  }
+  if (threadIdx.x == 0) {
+    if (abandoned_at >= 0)
+      __hip_atomic_store(P.ctl + 2 + d, tg | (u64)(unsigned)abandoned_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 prev = __hip_atomic_fetch_add(P.ctl, 1ull + (abandoned_at >= 0 ? (1ull << 32) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int count = (int)(prev & 0xffffffffull) + 1, n_ab = (int)(prev >> 32) + (abandoned_at >= 0 ? 1 : 0);
+    S.slot[0] = count == P.n_new_wgs ? n_ab : -1;
+    if (count == P.n_new_wgs) __hip_atomic_store(P.ctl, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next frame counts from zero
+  }
+  __syncthreads();
+  const int n_ab = S.slot[0];
+  __syncthreads();
+  if (n_ab <= 0) return;  // not the last workgroup, or nobody abandoned (always, so far)
+  // ---- sweeper
+  const int bound = P.debug_abandon == 2 ? 0 : (1 << 26);
+  int total = -1;
+  if (threadIdx.x == 0) {
+    for (int spins = 0; spins < bound; ++spins) {
+      const u64 tot = __hip_atomic_load(P.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(tot >> 32) == P.tag) {
+        total = (int)(unsigned)(tot & 0xffffffffull);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    S.slot[1] = total;
+  }
+  __syncthreads();
+  total = S.slot[1];
+  __syncthreads();
+  bool failed = total < 0;
+  int found = 0;
+  for (int w = 0; w < P.n_new_wgs && !failed; ++w) {
+    // which workgroups abandoned is in their tagged words (written before they counted themselves out; polled until n_ab of
+    // them have been seen -- a word of another frame never carries this frame's tag)
+    if (threadIdx.x == 0) {
+      u64 x = 0;
+      for (int spins = 0; spins < (found + (P.n_new_wgs - w) > n_ab ? 1 : bound); ++spins) {
+        x = __hip_atomic_load(P.ctl + 2 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == P.tag) break;
+      }
+      S.slot[1] = (unsigned)(x >> 32) == P.tag ? (int)(unsigned)(x & 0xffffffffull) : -1;
+    }
+    __syncthreads();
+    const int from = S.slot[1];
+    __syncthreads();
+    if (from < 0) continue;
+    found++;
+    for (int k0 = from; k0 < total; k0 += stride) {
+      const int st = new_block_round(L, P, S, par, k0, n_old, bound, false);
+      if (st < 0) failed = true;
+      if (st <= 0) break;
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(P.ctl + 1, (u64)((k0 + 1 < total) ? 2 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (found < n_ab) failed = true;
+  if (failed && threadIdx.x == 0) {
+    atomicOr(P.err, 2);
+    if (P.host_err) *P.host_err = 1;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_alloc_tsdf(AllocJob J, long long* stats, int alloc_wgs, MaskJob M, int mask_rows, int lead,
                                                    TsdfFrameArgs P) {
   __shared__ int lds[34];
@@ -791,54 +934,7 @@ __global__ __launch_bounds__(256) void k_alloc_tsdf(AllocJob J, long long* stats
     wg_trace_end(tr0, kTrTsdfPass);
     return;
   }
-  // new blocks: rank k is taken as soon as the allocation workgroup of this launch has published it (it may still be
-  // scanning later cells); the published total ends the loop
-  const int d = c - P.n_pair_wgs;
-  int par = 0;
-  for (int k0 = d * 2;; k0 += P.n_new_wgs * 2) {
-    const int k = k0 + half;
-    if ((threadIdx.x & 127) == 0) {
-      int got = 0;
-      u64 w0 = 0;
-      for (int spins = 0; spins < (1 << 22); ++spins) {
-        w0 = __hip_atomic_load(P.pub + kPubRec + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(w0 >> 32) == P.tag) {
-          got = 1;
-          break;
-        }
-        const u64 tot = __hip_atomic_load(P.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(tot >> 32) == P.tag) {
-          // (a rank below the total was published before the total: one more look at its word settles it)
-          if (k >= (int)(unsigned)(tot & 0xffffffffull)) {
-            got = -1;
-            break;
-          }
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      if (got == 0) atomicOr(P.err, 2);  // gave up waiting (never observed)
-      if (got == 1) {
-        u64 w1, w2;
-        int spins = 0;
-        do {
-          w1 = __hip_atomic_load(P.pub + kPubRec + 1 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          w2 = __hip_atomic_load(P.pub + kPubRec + 2 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while (((unsigned)(w1 >> 32) != P.tag || (unsigned)(w2 >> 32) != P.tag) && ++spins < (1 << 22));
-        S.slot[half] = (int)(unsigned)(w0 & 0xffffffffull);
-        S.klo[half] = (unsigned)(w1 & 0xffffffffull);
-        S.khi[half] = (unsigned)(w2 & 0xffffffffull);
-      }
-      S.act[half] = got == 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (!S.act[0]) break;  // ranks are granted in order: nothing beyond a missing one
-    const bool act = S.act[half] != 0;
-    const int slot = S.slot[half];
-    const u64 key = ((u64)S.khi[half] << 32) | (u64)S.klo[half];
-    tsdf_frame_block(L, P, S, par, act, n_old + k, slot, key, true, true);
-    par ^= 1;
-    __syncthreads();  // S.slot / klo / khi / act are rewritten by the next round
-  }
+  new_blocks_role(L, P, S, c - P.n_pair_wgs, n_old);
   wg_trace_end(tr0, kTrTsdfNew);
 }
 
@@ -1227,7 +1323,10 @@ void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, 
   P.tag = job.pub_tag;
   P.err = job.L.ctr + 3;
   P.n_pair_wgs = grid_for((hinted(job.L.hint_live, job.L.cap) + 1) / 2, 8192);
-  P.n_new_wgs = 32;
+  P.n_new_wgs = kNewBlockWgs;
+  P.ctl = job.pub + kPubRec + 3 * (size_t)job.L.cap;
+  P.host_err = job.host_err;
+  P.debug_abandon = job.debug_abandon;
   const int rows = M.Hf;
   const int alloc_wgs = (job.ncells + 2047) / 2048;  // alloc_grid_multi_body<4, 2>: 2 048 cells per workgroup (<= kAllocMaxWgs)
   const int lead = (alloc_wgs + rows + 7) & ~7;

@@ -590,6 +590,12 @@ class Mapper:
                  "feature_frames", "feature_blocks_updated", "feature_blocks_allocated", "feature_voxels_updated"]
         return dict(zip(names, [int(x) for x in buf]))
 
+    def debug_alloc_recoveries(self, mapper_id: int = 0) -> int:
+        """New TSDF blocks integrated by the sweeper of k_alloc_tsdf (their waiter abandoned its wait): 0 in normal operation."""
+        out = C.c_int64(0)
+        _lib.check(_lib.lib().mmf_debug_alloc_recoveries(self._h, mapper_id, self._stream(), C.byref(out)), "mmf_debug_alloc_recoveries")
+        return int(out.value)
+
     def reset_stats(self, mapper_id: int = 0) -> None:
         _lib.check(_lib.lib().mmf_reset_stats(self._h, mapper_id, self._stream()), "mmf_reset_stats")
 

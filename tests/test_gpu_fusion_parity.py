@@ -650,6 +650,57 @@ def test_merged_launch_with_churn_matches_oracle(oracle_mod):
     _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 90, 10, 200, 100, 20, 300, 110, 30], 8)
 
 
+def test_hand_over_recovery_yields_the_oracle_map(oracle_mod, monkeypatch):
+    """MMF_DEBUG_FORCE_ALLOC_TIMEOUT=1: every second waiter workgroup of k_alloc_tsdf "times out" at once and abandons its rounds;
+    the workgroup that terminates last sweeps them.  Same churn sequence as above (hundreds of new blocks per frame): block
+    sets, order and values equal the oracle's, and the sweeper really did the work."""
+    monkeypatch.setenv("MMF_DEBUG_FORCE_ALLOC_TIMEOUT", "1")
+    cfg = small_cfg(4)
+    over = dict(tsdf_decay_factor=0.3, decayed_weight_threshold=5e-2)
+    gpu, orc = make_mapper(8, **over), make_oracle(oracle_mod, 8, **over)
+    monkeypatch.delenv("MMF_DEBUG_FORCE_ALLOC_TIMEOUT")
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 90, 10, 200, 100, 20, 300, 110, 30], 8)
+    assert gpu.debug_alloc_recoveries(0) > 100
+    # the stand-alone depth call shares the launch
+    f = S.frame(cfg, 150, 8)
+    for m in (orc, gpu):
+        m.decay()
+    orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"])
+    gpu.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+    compare_tsdf(orc, gpu)
+    normal = make_mapper(8, **over)
+    f = S.frame(cfg, 0, 8)
+    normal.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+    assert normal.debug_alloc_recoveries(0) == 0  # ordinary operation never needs the sweeper
+
+
+def test_hand_over_failure_is_reported_once_and_cleared(monkeypatch):
+    """MMF_DEBUG_FORCE_ALLOC_TIMEOUT=2: the sweeper gives up as well -> the map is incomplete.  The next call on the mapper
+    fails with MMF_ERR_BAD_STATE (no integration on top of a broken map), the error is then cleared, clear() gives a usable
+    mapper again."""
+    monkeypatch.setenv("MMF_DEBUG_FORCE_ALLOC_TIMEOUT", "2")
+    gpu = make_mapper(8)
+    monkeypatch.delenv("MMF_DEBUG_FORCE_ALLOC_TIMEOUT")
+    cfg = small_cfg(4)
+
+    def frame(i):
+        f = S.frame(cfg, i, 8)
+        gpu.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), dev(np.ones(f["depth"].shape, dtype=bool)),
+                            torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), 0.3, 1, 1, 0, 0)
+
+    frame(0)  # asynchronous: the call itself succeeds
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="hand-over"):
+        frame(5)
+    torch.cuda.synchronize()
+    gpu.clear()
+    assert gpu.tsdf_layer_view(0).num_allocated_blocks() == 0  # reported once: no error left after clear()
+    frame(0)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="hand-over"):  # also surfaces at a synchronising call
+        gpu.update_feature_mesh(0)
+
+
 def test_grid_tag_wraps_and_merged_path_equals_separate_launches(monkeypatch):
     """270 x (decay, fused frame, stand-alone add_depth_frame of another view): mapper A runs the merged k_alloc_tsdf launch in
     both calls (tagged grid flags: the 8-bit tag wraps twice; light decay); mapper B is created with MMF_NO_ALLOC_TSDF=1 and keeps

@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(4, 3072, 120, 614), (2, 500, 7, 100), (1, 8192, 16, 33), (3, 64, 1024, 64)])
+@pytest.mark.parametrize("shape", [(4, 3072, 120, 614), (2, 500, 7, 100), (1, 8192, 16, 33), (3, 64, 1024, 64),
+                                   (200, 3072, 120, 40)])  # more batch elements than can be co-resident: launched in chunks
 def test_fps_kernel_matches_reference(shape):
     from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling, farthest_point_sampling_reference
 
