@@ -240,6 +240,14 @@ typedef struct mmf_frame {
   uint8_t* feature_mask_out; /* [Hf,Wf] */
 } mmf_frame;
 int mmf_integrate_frame_desc(mmf_handle h, int mapper_id, const mmf_frame* frame, void* stream);
+/* nvblox_integrate(..., include_dynamic=True) (nvblox_mapping_helpers.py:128-156) as ONE call: frame i goes to mapper
+ * mapper_ids[i] (all different -- in the reference the STATIC mapper with mask = ~dynamic_mask and the DYNAMIC mapper with
+ * mask = dynamic_mask, different erosion radii, same images).  Consecutive frames that share the feature source and image
+ * size are integrated as roles of the SAME five launches (the second frame's workgroups follow the first's in every grid):
+ * one latency chain and one enqueue for both maps.  Results are identical to mmf_integrate_frame_desc called per frame in
+ * the order given, which is also what the call does for frames that cannot be paired (odd count, a mapper whose scratch is
+ * not sized yet, unbounded workspace, MMF_NO_ALLOC_TSDF=1, a decay that needs its voxel pass). */
+int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids, const mmf_frame* frames, void* stream);
 
 /* ---- policy-side op ---------------------------------------------------- */
 /* dgl.geometry.farthest_point_sampler(x, npoints, start_idx) (diffuser_actor/encoder.py:366-370): farthest-point

@@ -146,6 +146,7 @@ SIGNATURES = {
     "mmf_get_last_view_blocks": (_I, [_VP, _I, _VP, _I, _VP]),
     "mmf_get_stats": (_I, [_VP, _I, _VP, C.POINTER(C.c_int64)]),
     "mmf_reset_stats": (_I, [_VP, _I, _VP]),
+    "mmf_integrate_frame_multi": (_I, [_VP, _I, _PI, C.POINTER(MmfFrame), _VP]),
     "mmf_get_alloc_timeline": (_I, [_VP, _I, _I, C.POINTER(C.c_int64)]),
     "mmf_debug_alloc_recoveries": (_I, [_VP, _I, _VP, C.POINTER(C.c_int64)]),
     "mmf_profile_enable": (_I, [_VP, _I]),

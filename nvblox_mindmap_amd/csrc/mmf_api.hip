@@ -891,8 +891,9 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
   const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
   {
     ProfScope ps(h, MMF_K_RAYCAST, s);
-    launch_front(m->mc, cam, T_L_C, depth, mask, 0.0f, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr, do_decay, m->kill,
-                 m->any_kill, m->tsdf.d.ctr, grid_tag, s);
+    const FrontArgs FA = make_front_args(m->mc, cam, T_L_C, depth, mask, 0.0f, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
+                                         do_decay, m->kill, m->any_kill, m->tsdf.d.ctr, grid_tag);
+    launch_front(&FA, 1, s);
   }
   {
     ProfScope ps(h, MMF_K_TSDF, s);
@@ -918,8 +919,9 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
     job.debug_abandon = m->debug_abandon;
     MaskJob Mc = M;
     Mc.Hf = 0;  // no column pass: there is no feature mask to emit
-    launch_alloc_tsdf(job, m->stats, Mc, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
-                      do_decay ? m->mc.decay_factor : 0.0f, s);
+    const AllocTsdfArgs TA = make_alloc_tsdf_args(job, m->stats, Mc, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags,
+                                                  m->sc[1].cell_key, do_decay ? m->mc.decay_factor : 0.0f);
+    launch_alloc_tsdf(&TA, 1, s);
     m->wmax_valid = true;
   }
   return check_launch();
@@ -1120,8 +1122,10 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   {
     // raycast tiles | mask row pass | pending decay of the TSDF layer
     ProfExt pe(h, MMF_K_RAYCAST);
-    launch_front(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M, do_decay ? &m->tsdf.d : nullptr,
-                 light_decay, m->kill, m->any_kill, merged ? m->tsdf.d.ctr : nullptr, grid_tag, s, pe.a(), pe.b());
+    const FrontArgs FA = make_front_args(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M,
+                                         do_decay ? &m->tsdf.d : nullptr, light_decay, m->kill, m->any_kill,
+                                         merged ? m->tsdf.d.ctr : nullptr, grid_tag);
+    launch_front(&FA, 1, s, pe.a(), pe.b());
   }
   KeySrc ks0{};
   ks0.mode = 0;
@@ -1147,8 +1151,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     job0.flag_value = grid_tag;
     job0.host_err = m->hints + 7;
     job0.debug_abandon = m->debug_abandon;
-    launch_alloc_tsdf(job0, m->stats, M, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags, m->sc[1].cell_key,
-                      light_decay ? m->mc.decay_factor : 0.0f, s, pe.a(), pe.b());
+    const AllocTsdfArgs TA = make_alloc_tsdf_args(job0, m->stats, M, m->mc, cam, T_C_L, m->masked_depth, vg, m->sc[1].flags,
+                                                  m->sc[1].cell_key, light_decay ? m->mc.decay_factor : 0.0f);
+    launch_alloc_tsdf(&TA, 1, s, pe.a(), pe.b());
     m->wmax_valid = true;  // refreshed for every live block
   } else {
     {
@@ -1194,7 +1199,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
     if (need) {
       ProfExt pe(h, MMF_K_SPHERE);
-      launch_sphere_alloc(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats, s, pe.a(), pe.b());
+      const SphereArgs SA = make_sphere_args(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats);
+      launch_sphere_alloc(&SA, 1, s, pe.a(), pe.b());
       synth_commit(*m, cam, T16, K9, Ws, Hs);
     } else {
       ProfScope ps(h, MMF_K_SPHERE, s);
@@ -1212,6 +1218,222 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
   }
   return check_launch();
+}
+
+// ---- two mappers, one camera frame, ONE set of launches ---------------------------------------------------------------
+// The reference's control step feeds every camera frame to the static AND the dynamic mapper (nvblox_integrate with
+// include_dynamic, nvblox_mapping_helpers.py:128-156): two independent maps, the same images, two different masks.  A fused
+// frame is five dependent launches that each fill the chip for a few microseconds, so two frames cost twice the latency
+// chain when issued one after the other.  Here the two frames are ROLES OF THE SAME FIVE LAUNCHES (k_front2, k_alloc_tsdf2,
+// k_sphere_alloc2, k_app_frame2, k_feature_flat2: the second frame's workgroups follow the first's in every grid): one
+// latency chain for both, one host enqueue.  Results are bit-identical to the two calls in sequence (same role code).
+struct FrameIn {
+  const float* depth;
+  const uint8_t* rgb;
+  const void* feat;
+  LowRes low;
+  bool has_low;
+  const uint8_t* input_mask;
+  int H, W, Hf, Wf, C;
+  const float* T16;
+  const float* K9;
+  float min_depth_m;
+  int k_in, k_depth, border_percent;
+  uint8_t* depth_mask_out;
+  uint8_t* feature_mask_out;
+  bool invert_mask;
+};
+
+static int frame_in_from_desc(const Mapper& m, const mmf_frame* f, FrameIn& in) {
+  if (!f || f->struct_size != (int)sizeof(mmf_frame)) return fail(MMF_ERR_INVALID_ARG, "mmf_frame: null or struct_size mismatch");
+  if ((f->features_f16 != nullptr) == (f->lowres_features != nullptr))
+    return fail(MMF_ERR_INVALID_ARG, "mmf_frame: give exactly one of features_f16 / lowres_features");
+  in.has_low = f->lowres_features != nullptr;
+  if (in.has_low) MMF_TRY(make_lowres(m, f->lowres_features, f->lowres_h, f->lowres_w, f->lowres_channels, f->Hf, f->Wf, in.low));
+  in.depth = f->depth, in.rgb = f->rgb, in.feat = f->features_f16, in.input_mask = f->input_mask;
+  in.H = f->H, in.W = f->W, in.Hf = f->Hf, in.Wf = f->Wf;
+  in.C = in.has_low ? m.P.feature_channels : f->feature_channels;
+  in.T16 = f->T_W_C, in.K9 = f->K;
+  in.min_depth_m = f->min_depth_m;
+  in.k_in = f->input_mask_erosion_iterations, in.k_depth = f->valid_depth_mask_erosion_iterations, in.border_percent = f->border_percent;
+  in.depth_mask_out = f->depth_mask_out, in.feature_mask_out = f->feature_mask_out;
+  in.invert_mask = f->invert_input_mask != 0;
+  return MMF_OK;
+}
+
+static int integrate_frame_in(mmf_handle h, int mapper_id, const FrameIn& in, void* stream) {
+  return integrate_frame_impl(h, mapper_id, in.depth, in.rgb, in.feat, in.has_low ? &in.low : nullptr, in.input_mask, in.H, in.W, in.Hf,
+                              in.Wf, in.C, in.T16, in.K9, in.min_depth_m, in.k_in, in.k_depth, in.border_percent, in.depth_mask_out,
+                              in.feature_mask_out, stream, in.invert_mask);
+}
+
+// Can this frame take the five-launch merged path (the only one the pair kernels implement)?  No side effects.
+static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGrid& vg, Cam& cam, Rigid& T_L_C, Rigid& T_C_L) {
+  if (!in.depth || !in.rgb || (!in.feat && !in.has_low) || !in.input_mask || !in.T16 || !in.K9 || !in.depth_mask_out ||
+      !in.feature_mask_out || in.H <= 1 || in.W <= 1 || in.Hf != in.H || in.Wf != in.W || in.k_in < 0 || in.k_depth < 0 ||
+      !(in.min_depth_m >= 0.0f) || in.C != m.P.feature_channels || ((uintptr_t)in.feat & 15) != 0)
+    return false;
+  if (!m.mask_tmp || (size_t)in.H * in.W + 8 > m.mask_tmp_cap) return false;  // (first frame of a mapper: the single path sizes the scratch)
+  if (!m.color.allocated || !m.feat.allocated || !m.flat.rec) return false;
+  cam = cam_from_K(in.K9, in.W, in.H);
+  rigid_from_T(in.T16, T_L_C);
+  rigid_inverse(T_L_C, T_C_L);
+  if (!make_mask_job(in.input_mask, in.depth, in.H, in.W, in.min_depth_m, in.k_in, in.k_depth, in.border_percent, in.Hf, in.Wf,
+                     in.depth_mask_out, in.feature_mask_out, m.mask_tmp, M))
+    return false;
+  if (compute_view_grid(m, cam, T_L_C, vg) != MMF_OK) return false;
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  if (ncells <= 0 || !alloc_jobs_fusable(ncells, m.tsdf.d.cap) || ncells > m.sc_cap[0] || m.tsdf.d.cap > m.sc_cap[1] ||
+      m.tsdf.d.cap > m.sc_cap[2])
+    return false;
+  if (!m.allow_merged || !m.tsdf.d.dense) return false;
+  if (m.pending_decay && !m.wmax_valid) return false;  // that decay needs its voxel pass: separate launches
+  const int sf = m.mc.st_sf;
+  if (in.W / sf <= 0 || in.H / sf <= 0 || (in.W / sf) * (in.H / sf) > m.synth_cap) return false;
+  return true;
+}
+
+// One frame of a pair: the bookkeeping of integrate_frame_impl's merged path + the argument blocks of its five launches.
+struct PairFrame {
+  FrontArgs front;
+  AllocTsdfArgs at;
+  SphereArgs sphere;
+  AppFrameArgs app;
+};
+
+static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, const ViewGrid& vg, const Cam& cam, const Rigid& T_L_C,
+                        const Rigid& T_C_L, hipStream_t s, PairFrame& F) {
+  const int ncells = vg.nx * vg.ny * vg.nz;
+  M.masked_depth_out = m.masked_depth;
+  M.invert = in.invert_mask ? 1 : 0;
+  m.last_vg = vg;
+  m.frames[0]++;
+  m.frames[1]++;
+  m.frames[2]++;
+  m.tsdf_epoch++;
+  m.touched = true;
+  const int stamp = (int)(m.tsdf_epoch & 0x3fffffff) ? (int)(m.tsdf_epoch & 0x3fffffff) : 1;
+  const int sub = m.P.raycast_subsampling < 1 ? 1 : m.P.raycast_subsampling;
+  const bool do_decay = m.pending_decay;  // (eligible: wmax is current, so it is the light form)
+  m.pending_decay = false;
+  int grid_tag = 1;
+  MMF_TRY(next_grid_tag(m, s, &grid_tag));
+  F.front = make_front_args(m.mc, cam, T_L_C, in.depth, in.input_mask, in.min_depth_m, sub, vg, m.sc[0].flags, M,
+                            do_decay ? &m.tsdf.d : nullptr, do_decay, m.kill, m.any_kill, m.tsdf.d.ctr, grid_tag);
+  KeySrc ks0{};
+  ks0.mode = 0;
+  ks0.ox = vg.ox, ks0.oy = vg.oy, ks0.oz = vg.oz, ks0.ny = vg.ny, ks0.nz = vg.nz;
+  AllocJob job0;
+  job0.L = m.tsdf.d;
+  job0.ks = ks0;
+  job0.sc = m.sc[0];
+  job0.ncells = ncells;
+  job0.stat_upd = 1;
+  job0.stat_new = 2;
+  job0.stamp = stamp;
+  job0.timeline = m.timeline;
+  job0.pub = m.pub;
+  MMF_TRY(next_pub_tag(m, s, &job0.pub_tag));
+  job0.flag_value = grid_tag;
+  job0.host_err = m.hints + 7;
+  job0.debug_abandon = m.debug_abandon;
+  F.at = make_alloc_tsdf_args(job0, m.stats, M, m.mc, cam, T_C_L, m.masked_depth, vg, m.sc[1].flags, m.sc[1].cell_key,
+                              do_decay ? m.mc.decay_factor : 0.0f);
+  m.wmax_valid = true;
+  KeySrc ks{};
+  ks.mode = 1;
+  ks.n_live = m.tsdf.d.ctr;
+  AllocJob jobs[2];
+  jobs[0].L = m.color.d;
+  jobs[0].ks = ks;
+  jobs[0].sc = m.sc[1];
+  jobs[0].ncells = m.tsdf.d.cap;
+  jobs[0].stat_upd = 4;
+  jobs[0].stat_new = -1;
+  jobs[1].L = m.feat.d;
+  jobs[1].ks = ks;
+  jobs[1].sc = m.sc[2];
+  jobs[1].sc.flags = m.sc[1].flags;  // same camera: one candidate selection serves both layers
+  jobs[1].sc.cell_key = m.sc[1].cell_key;
+  jobs[1].ncells = m.tsdf.d.cap;
+  jobs[1].stat_upd = 6;
+  jobs[1].stat_new = 7;
+  jobs[1].zero_me = m.flat.count;
+  int Ws, Hs;
+  bool need;
+  MMF_TRY(synth_prepare(m, cam, in.T16, in.K9, &Ws, &Hs, &need));  // (need: the TSDF epoch moved on in this call)
+  F.sphere = make_sphere_args(m.tsdf.d, m.mc, cam, T_L_C, m.synth, Ws, Hs, jobs, 2, m.stats);
+  synth_commit(m, cam, in.T16, in.K9, Ws, Hs);
+  F.app = make_app_frame_args(m.color.d, cam, in.rgb, in.depth_mask_out, m.sc[1], m.feat.d, (const __half*)in.feat, in.feature_mask_out,
+                              m.sc[2], m.mc, T_C_L, m.synth, m.synth_W, m.synth_H, m.feat.d.cap, m.stats,
+                              in.has_low ? &in.low : nullptr, &m.flat);
+  return MMF_OK;
+}
+
+int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids, const mmf_frame* frames, void* stream) {
+  if (!h || n_frames <= 0 || !mapper_ids || !frames) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_integrate_frame_multi");
+  std::vector<Mapper*> ms(n_frames);
+  std::vector<FrameIn> ins(n_frames);
+  for (int i = 0; i < n_frames; ++i) {
+    MMF_TRY(get_mapper(h, mapper_ids[i], &ms[i]));
+    MMF_TRY(frame_in_from_desc(*ms[i], &frames[i], ins[i]));
+    for (int j = 0; j < i; ++j)
+      if (ms[j] == ms[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_multi: every frame must go to a different mapper");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  while (i < n_frames) {
+    bool pair = false;
+    MaskJob M[2];
+    ViewGrid vg[2];
+    Cam cam[2];
+    Rigid T_L_C[2], T_C_L[2];
+    if (i + 1 < n_frames) {
+      const FrameIn &a = ins[i], &b = ins[i + 1];
+      // one feature source and one image size for both (k_feature_flat2 reads one image): what nvblox_integrate passes
+      pair = a.feat == b.feat && a.has_low == b.has_low && (!a.has_low || (a.low.data == b.low.data && a.low.h == b.low.h && a.low.w == b.low.w)) &&
+             a.H == b.H && a.W == b.W && ms[i]->mc.C == ms[i + 1]->mc.C &&
+             pair_eligible(*ms[i], a, M[0], vg[0], cam[0], T_L_C[0], T_C_L[0]) &&
+             pair_eligible(*ms[i + 1], b, M[1], vg[1], cam[1], T_L_C[1], T_C_L[1]);
+    }
+    if (!pair) {
+      MMF_TRY(integrate_frame_in(h, mapper_ids[i], ins[i], stream));
+      ++i;
+      continue;
+    }
+    MMF_TRY(report_device_errors(h, *ms[i], nullptr, nullptr, s));
+    MMF_TRY(report_device_errors(h, *ms[i + 1], nullptr, nullptr, s));
+    PairFrame F[2];
+    for (int q = 0; q < 2; ++q) MMF_TRY(pair_prepare(h, *ms[i + q], ins[i + q], M[q], vg[q], cam[q], T_L_C[q], T_C_L[q], s, F[q]));
+    {
+      ProfExt pe(h, MMF_K_RAYCAST);
+      const FrontArgs A[2] = {F[0].front, F[1].front};
+      launch_front(A, 2, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h, MMF_K_TSDF);
+      const AllocTsdfArgs A[2] = {F[0].at, F[1].at};
+      launch_alloc_tsdf(A, 2, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h, MMF_K_SPHERE);
+      const SphereArgs A[2] = {F[0].sphere, F[1].sphere};
+      launch_sphere_alloc(A, 2, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h, MMF_K_FEATURE);
+      launch_app_frame2(F[0].app, F[1].app, ins[i].has_low, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h, MMF_K_FEATURE_FLAT);
+      launch_feature_flat2(ms[i]->feat.d, ms[i]->mc, ms[i]->flat, ms[i + 1]->feat.d, ms[i + 1]->mc, ms[i + 1]->flat, cam[0],
+                           (const __half*)ins[i].feat, ins[i].has_low ? &ins[i].low : nullptr, s, pe.a(), pe.b());
+    }
+    MMF_TRY(check_launch());
+    i += 2;
+  }
+  return MMF_OK;
 }
 
 int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,

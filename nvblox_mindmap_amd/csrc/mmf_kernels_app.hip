@@ -284,29 +284,50 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
 // at once.  (With four patches per 1 024-thread workgroup only 256 of the 300 workgroups fitted, and the 44 late ones -- each
 // as long as any other -- doubled the duration of the launch.)  The allocation jobs run in the 4-wave form: three passes
 // instead of one, still well inside the trace's shadow.
+struct SphereLds {
+  int lds[34];
+  int carry[2];
+  int ctx[4];
+};
+
 template <bool DENSE, int MODE>
-__global__ __launch_bounds__(256, 5) void k_sphere_alloc(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
-                                                        int Ws, int Hs, int patches_x, int n_patches, AllocJob J0, AllocJob J1,
-                                                        int njobs, long long* stats) {
-  __shared__ int lds[34];
-  __shared__ int carry[2];
-  __shared__ int ctx[4];
+__device__ inline void sphere_alloc_role(const SphereArgs& A, SphereLds& Q, int job) {
   const long long tr0 = wg_trace_begin();
-  if ((int)blockIdx.x < njobs) {
-    alloc_job_body<DENSE, MODE, 4>(blockIdx.x == 0 ? J0 : J1, stats, lds, carry, ctx);
-    wg_trace_end(tr0, kTrSphereAlloc);
-    return;
-  }
-  const int patch = (int)blockIdx.x - njobs;
+  alloc_job_body<DENSE, MODE, 4>(job == 0 ? A.J0 : A.J1, A.stats, Q.lds, Q.carry, Q.ctx);
+  wg_trace_end(tr0, kTrSphereAlloc);
+}
+
+__device__ inline void sphere_patch_role(const SphereArgs& A, SphereLds& Q, int patch) {
+  const long long tr0 = wg_trace_begin();
   if (wg_trace_on()) {  // diagnostics only: longest wide / narrow iteration counts of the workgroup ride in the record id
-    if (threadIdx.x < 2) lds[threadIdx.x] = 0;
+    if (threadIdx.x < 2) Q.lds[threadIdx.x] = 0;
     __syncthreads();
-    if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x, lds);
+    if (patch < A.n_patches) sphere_patch(A.T, A.mc, A.cam, A.T_L_C, A.synth, A.Ws, A.Hs, A.patches_x, patch, threadIdx.x, Q.lds);
     __syncthreads();
-    wg_trace_end(tr0, kTrSphereTrace + (lds[0] << 8) + (lds[1] << 20));
+    wg_trace_end(tr0, kTrSphereTrace + (Q.lds[0] << 8) + (Q.lds[1] << 20));
     return;
   }
-  if (patch < n_patches) sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, patch, threadIdx.x);
+  if (patch < A.n_patches) sphere_patch(A.T, A.mc, A.cam, A.T_L_C, A.synth, A.Ws, A.Hs, A.patches_x, patch, threadIdx.x);
+}
+
+template <bool DENSE, int MODE>
+__global__ __launch_bounds__(256, 5) void k_sphere_alloc(SphereArgs A) {
+  __shared__ SphereLds Q;
+  if ((int)blockIdx.x < A.njobs) return sphere_alloc_role<DENSE, MODE>(A, Q, (int)blockIdx.x);
+  sphere_patch_role(A, Q, (int)blockIdx.x - A.njobs);
+}
+
+// two frames (mmf_integrate_frame_multi): [allocation jobs 0 | allocation jobs 1 | ray patches 0 | ray patches 1]
+template <bool DENSE, int MODE>
+__global__ __launch_bounds__(256, 5) void k_sphere_alloc2(SphereArgs A0, SphereArgs A1) {
+  __shared__ SphereLds Q;
+  int b = (int)blockIdx.x;
+  if (b < A0.njobs) return sphere_alloc_role<DENSE, MODE>(A0, Q, b);
+  b -= A0.njobs;
+  if (b < A1.njobs) return sphere_alloc_role<DENSE, MODE>(A1, Q, b);
+  b -= A1.njobs;
+  if (b < A0.n_patches) return sphere_patch_role(A0, Q, b);
+  sphere_patch_role(A1, Q, b - A0.n_patches);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,17 +399,6 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
 // ------------------------------------------------------------------------------------------------
 // Colour: voxel = {uchar4 rgb_, float w} (8 B); one workgroup of 256 threads per block, 2 voxels (16 B) per thread.
 // ------------------------------------------------------------------------------------------------
-struct AppArgs {
-  LayerDev L;
-  Cam cam;
-  Rigid T_C_L;
-  const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]  (null when `low` is the feature source)
-  FlatList flat;         // features only: survivor list of the frame (rec == null: phase 2 stays in the gating workgroup)
-  LowRes low;            // features only: low-res backbone map sampled in the kernel instead of a materialised image
-  const uint8_t* mask;
-  Scratch sc;
-  long long* stats;  // mapper statistics (may be null)
-};
 
 // blend one colour voxel {rgb_, w} with the bilinear sample at footprint (x0,y0,wx,wy)
 __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, const MapConsts& mc, int x0, int y0, float wx, float wy,
@@ -648,23 +658,37 @@ __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, Fea
   if (is_new) feature_zero_fill(A, mc, S, slot);
 }
 
-// Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size.
+// Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size (workgroup bid of nb).
 template <bool LOW>
-__global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
+__device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, int lpv, int bid, int nb) {
   const long long tr0 = wg_trace_begin();
   const int total = *A.flat.count;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && A.flat.hint) *A.flat.hint = total;
+  if (bid == 0 && threadIdx.x == 0 && A.flat.hint) *A.flat.hint = total;
   const int vpw = 256 / lpv;
   const int group = threadIdx.x / lpv, gl = threadIdx.x % lpv;
   const int C = mc.C;
   __half* pool = reinterpret_cast<__half*>(A.L.pool);
-  for (int v = blockIdx.x * vpw + group; v < total; v += gridDim.x * vpw) {
+  for (int v = bid * vpw + group; v < total; v += nb * vpw) {
     const uint4 r = A.flat.rec[v];
     const float Wv = A.flat.w[v];
     const size_t row = (size_t)(r.x & 0x7fffffffu);  // slot * 512 + lin
     feature_voxel<LOW>(A, mc, pool + row * C, (r.x >> 31) != 0u, r.y, __uint_as_float(r.z), __uint_as_float(r.w), Wv, gl, lpv);
   }
   wg_trace_end(tr0, kTrFeatureFlat);
+}
+
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
+  feature_flat_role<LOW>(A, mc, lpv, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// two frames' survivor lists in one launch: the first nb0 workgroups walk list 0, the rest list 1
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_feature_flat2(AppArgs A0, MapConsts mc0, AppArgs A1, MapConsts mc1, int lpv, int nb0) {
+  if ((int)blockIdx.x < nb0)
+    feature_flat_role<LOW>(A0, mc0, lpv, (int)blockIdx.x, nb0);
+  else
+    feature_flat_role<LOW>(A1, mc1, lpv, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
 }
 
 template <bool LOW>
@@ -842,6 +866,18 @@ __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, 
 #endif
 }
 
+// two frames' candidate lists in one launch (mmf_integrate_frame_multi)
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_app_frame2(AppFrameArgs F0, AppFrameArgs F1, int nb0) {
+  __shared__ FeatLds S;
+  const long long tr0 = wg_trace_begin();
+  if ((int)blockIdx.x < nb0)
+    app_frame_body<LOW>(F0.Ac, F0.Af, F0.mc, F0.synth, F0.Ws, F0.Hs, (int)blockIdx.x, nb0, S);
+  else
+    app_frame_body<LOW>(F1.Ac, F1.Af, F1.mc, F1.synth, F1.Ws, F1.Hs, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, S);
+  wg_trace_end(tr0, kTrAppFrame);
+}
+
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_app)
 
 // ------------------------------------------------------------------------------------------------
@@ -867,17 +903,43 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
 }
 
-void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
-                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
-  const int n = patches_x * patches_y;
-  const AllocJob& j1 = jobs[njobs > 1 ? 1 : 0];
-  if (jobs[0].L.dense && j1.L.dense && jobs[0].ks.mode == 1 && j1.ks.mode == 1)  // bounded workspace, list cells: no hash paths
-    hipExtLaunchKernelGGL((k_sphere_alloc<true, 1>), dim3(njobs + n), dim3(256), 0, s, ev_start, ev_stop, 0, tsdf, mc, cam, T_L_C, synth, Ws,
-                          Hs, patches_x, n, jobs[0], j1, njobs, stats);
-  else
-    hipExtLaunchKernelGGL((k_sphere_alloc<false, -1>), dim3(njobs + n), dim3(256), 0, s, ev_start, ev_stop, 0, tsdf, mc, cam, T_L_C, synth,
-                          Ws, Hs, patches_x, n, jobs[0], j1, njobs, stats);
+SphereArgs make_sphere_args(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
+                            const AllocJob* jobs, int njobs, long long* stats) {
+  SphereArgs A;
+  A.T = tsdf;
+  A.mc = mc;
+  A.cam = cam;
+  A.T_L_C = T_L_C;
+  A.synth = synth;
+  A.Ws = Ws;
+  A.Hs = Hs;
+  A.patches_x = (Ws + 3) / 4;
+  A.n_patches = A.patches_x * ((Hs + 3) / 4);
+  A.J0 = jobs[0];
+  A.J1 = jobs[njobs > 1 ? 1 : 0];
+  A.njobs = njobs;
+  A.stats = stats;
+  return A;
+}
+
+static inline bool sphere_dense(const SphereArgs& A) {  // bounded workspace, list cells: no hash paths
+  return A.J0.L.dense && A.J1.L.dense && A.J0.ks.mode == 1 && A.J1.ks.mode == 1;
+}
+
+void launch_sphere_alloc(const SphereArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (n == 1) {
+    const dim3 grid(A[0].njobs + A[0].n_patches);
+    if (sphere_dense(A[0]))
+      hipExtLaunchKernelGGL((k_sphere_alloc<true, 1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0]);
+    else
+      hipExtLaunchKernelGGL((k_sphere_alloc<false, -1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0]);
+  } else {
+    const dim3 grid(A[0].njobs + A[1].njobs + A[0].n_patches + A[1].n_patches);
+    if (sphere_dense(A[0]) && sphere_dense(A[1]))
+      hipExtLaunchKernelGGL((k_sphere_alloc2<true, 1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1]);
+    else
+      hipExtLaunchKernelGGL((k_sphere_alloc2<false, -1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1]);
+  }
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
@@ -962,6 +1024,54 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
     else
       hipExtLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc);
   }
+}
+
+// ---- two frames in one launch (mmf_integrate_frame_multi): same camera for colour and features in each frame ------------
+AppFrameArgs make_app_frame_args(const LayerDev& Lc, const Cam& cam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
+                                 const LayerDev& Lf, const __half* feat, const uint8_t* fmask, const Scratch& fsc, const MapConsts& mc,
+                                 const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats, const LowRes* low,
+                                 const FlatList* flat) {
+  AppFrameArgs F;
+  F.Ac = make_app_args(Lc, cam, T_C_L, rgb, cmask, csc);
+  F.Af = make_app_args(Lf, cam, T_C_L, feat, fmask, fsc, stats, low, flat);
+  F.mc = mc;
+  F.synth = synth;
+  F.Ws = Ws;
+  F.Hs = Hs;
+  F.nb = grid8(hinted(csc.hint_cand, max_cand), 8192);
+  return F;
+}
+
+void launch_app_frame2(const AppFrameArgs& F0, const AppFrameArgs& F1, bool low, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const dim3 grid(F0.nb + F1.nb);
+  if (low)
+    hipExtLaunchKernelGGL(k_app_frame2<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
+  else
+    hipExtLaunchKernelGGL(k_app_frame2<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
+}
+
+static int flat_wgs(const MapConsts& mc, const FlatList& fl, int& lpv) {
+  const int nch = mc.C >> 3;
+  lpv = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);  // lanes per voxel row
+  const int vpw = 256 / lpv;
+  const long long vox = hinted(fl.hint, fl.cap);
+  long long wgs = (vox + vpw - 1) / vpw;
+  wgs = wgs > 16384 ? 16384 : wgs;
+  return grid8((int)wgs, 16384);
+}
+
+void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, const LayerDev& L1, const MapConsts& mc1,
+                          const FlatList& fl1, const Cam& cam, const __half* feat, const LowRes* lowres, hipStream_t s,
+                          hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const AppArgs A0 = make_app_args(L0, cam, Rigid{}, feat, nullptr, Scratch{}, nullptr, lowres, &fl0);
+  const AppArgs A1 = make_app_args(L1, cam, Rigid{}, feat, nullptr, Scratch{}, nullptr, lowres, &fl1);
+  int lpv0, lpv1;
+  const int nb0 = flat_wgs(mc0, fl0, lpv0), nb1 = flat_wgs(mc1, fl1, lpv1);
+  const dim3 grid(nb0 + nb1);  // (both mappers of one Mapper object hold the same channel count: lpv0 == lpv1)
+  if (lowres)
+    hipExtLaunchKernelGGL(k_feature_flat2<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A0, mc0, A1, mc1, lpv0, nb0);
+  else
+    hipExtLaunchKernelGGL(k_feature_flat2<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A0, mc0, A1, mc1, lpv0, nb0);
 }
 
 }  // namespace mmf

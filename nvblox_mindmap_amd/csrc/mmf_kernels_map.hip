@@ -73,20 +73,6 @@ __device__ inline void walk_step(Walk& w) {
 // byte per DISTINCT cell: the hot loop issues no global stores at all.
 constexpr int kRaycastLdsCells = 32768;
 
-struct RaycastJob {
-  MapConsts mc;
-  Cam cam;
-  Rigid T_L_C;
-  const float* depth;
-  const uint8_t* mask;
-  int mask_invert;  // != 0: a pixel is valid where the mask byte is 0
-  float min_d;
-  int sub, Wsub, Hsub;
-  ViewGrid vg;
-  uint8_t* flags;
-  int flag_value;  // the byte a touched cell is set to: 1 (consumers clear the grid after use) or the frame's tag of a k_alloc_tsdf
-                   // frame, whose consumers compare for equality and never clear (Mapper::grid_tagged)
-};
 
 template <bool LDSFLAGS>
 __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_words) {
@@ -184,44 +170,44 @@ __global__ __launch_bounds__(256) void k_raycast_mark(RaycastJob R) {
 template <bool ERASE>
 __device__ inline void decay_body(const LayerDev& L, const MapConsts& mc, uint8_t* __restrict__ kill, int* any_kill, int bid, int nb);
 
-struct DecayJob {
-  LayerDev L;
-  uint8_t* kill;
-  int* any_kill;
-  int n_wgs;  // 0: no decay pending
-  int light;  // != 0: L.wmax is current -- ONE workgroup decides the deallocations from it and compacts the lists (no voxel
-              // access); the weights themselves are multiplied by the next k_tsdf_pass
+
+
+
+struct FrontLds {
+  u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
+  int s_scan[10], s_carry[2];
 };
 
-
+// Workgroup `bid` of the frame's first launch.
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, MaskJob M, DecayJob D, int* snap_ctr) {
-  extern __shared__ unsigned s_words[];
-  __shared__ u64 s_in[kMaxMaskWords], s_d[kMaxMaskWords];
+__device__ inline void front_role(const FrontArgs& A, int bid, unsigned* s_words, FrontLds& S) {
+  const RaycastJob& R = A.R;
+  const MaskJob& M = A.M;
+  const DecayJob& D = A.D;
+  int* snap_ctr = A.snap_ctr;
   const long long tr0 = wg_trace_begin();
   // A pending Mapper.decay() touches only the TSDF layer and its lists, which neither other role reads.
-  if (D.light && blockIdx.x == 0) {
+  if (D.light && bid == 0) {
     // wmax is current: ONE workgroup -- the first of the grid, so that it is long done when the last ray is -- decides the
     // dead blocks from it and compacts the live list / pushes the freed slots right here, beside the raycast: the
     // allocation workgroup of the next launch starts on a clean list.
     // (8 entries per thread, not 16: the launch's register count is that of its largest role, and at 86 VGPRs the raycast
     // ran at 5 waves per SIMD instead of 7 -- the mask rows had to wait for a slot.)
-    __shared__ int s_scan[10], s_carry[2];
     if (R.mc.dealloc_decayed)
-      live_compact_body<4, 8, true, false, true>(D.L, nullptr, nullptr, s_scan, s_carry, R.mc.decay_factor, R.mc.decay_thr);
+      live_compact_body<4, 8, true, false, true>(D.L, nullptr, nullptr, S.s_scan, S.s_carry, R.mc.decay_factor, R.mc.decay_thr);
     // (thread 0 wrote ctr[0] itself.)  ctr[6] = the live count k_alloc_tsdf's pass over the EXISTING blocks runs to, while the
     // allocation workgroup of that launch appends to the list and moves ctr[0]
     if (snap_ctr && threadIdx.x == 0) snap_ctr[6] = snap_ctr[0];
     wg_trace_end(tr0, kTrFrontDecay);
     return;
   }
-  const int b = (int)blockIdx.x - (D.light ? 1 : 0);
+  const int b = bid - (D.light ? 1 : 0);
   if (snap_ctr && !D.light && b == 0 && threadIdx.x == 0) snap_ctr[6] = snap_ctr[0];
-  if (b < n_ray_wgs) {
+  if (b < A.n_ray_wgs) {
     raycast_body<LDSFLAGS>(R, b, s_words);
     wg_trace_end(tr0, kTrFrontRay);
-  } else if (b < n_ray_wgs + M.H) {
-    mask_rowbits_row(M, b - n_ray_wgs, s_in, s_d);
+  } else if (b < A.n_ray_wgs + M.H) {
+    mask_rowbits_row(M, b - A.n_ray_wgs, S.s_in, S.s_d);
     wg_trace_end(tr0, kTrFrontMaskRows);
   } else {
     // wmax stale (a stand-alone call wrote TSDF weights): the full pass over the voxels.  Each workgroup also drops the
@@ -230,9 +216,29 @@ __global__ __launch_bounds__(256) void k_front(RaycastJob R, int n_ray_wgs, Mask
     // (Tried: decay workgroups first + "last one compacts" inside this launch -- an agent-scope fence per workgroup is a
     // full L2 write-back (339 us), atomics on one arrival counter serialise (69 us), and even with a two-level counter
     // the launch grew by 9 us while the next one shrank by 2.)
-    decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - n_ray_wgs - M.H, D.n_wgs);
+    decay_body<true>(D.L, R.mc, D.kill, D.any_kill, b - A.n_ray_wgs - M.H, D.n_wgs);
     wg_trace_end(tr0, kTrFrontDecay);
   }
+}
+
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256) void k_front(FrontArgs A) {
+  extern __shared__ unsigned s_words[];
+  __shared__ FrontLds S;
+  front_role<LDSFLAGS>(A, (int)blockIdx.x, s_words, S);
+}
+
+// Two frames (two mappers fed by the same camera frame: mmf_integrate_frame_multi) in ONE launch: the workgroups of the second
+// follow those of the first.  Same role code, same results; the launch is as long as its slower half instead of their sum.
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256) void k_front2(FrontArgs A0, FrontArgs A1) {
+  extern __shared__ unsigned s_words[];
+  __shared__ FrontLds S;
+  const int b = (int)blockIdx.x;
+  if (b < A0.n_wgs)
+    front_role<LDSFLAGS>(A0, b, s_words, S);
+  else
+    front_role<LDSFLAGS>(A1, b - A0.n_wgs, s_words, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -632,27 +638,6 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
 //     FPS kernel: no fences, bounded polling).  The allocation workgroup is block 0, so it is resident before any waiter.
 //     256-thread workgroups; a TSDF workgroup holds TWO blocks (one per half, 4 voxels per thread as in k_tsdf_pass).
 // ------------------------------------------------------------------------------------------------
-struct TsdfFrameArgs {
-  MapConsts mc;
-  Cam cam;
-  Rigid T_C_L;
-  const float* depth;         // the frame's masked depth image
-  const uint8_t* grid_flags;  // raycast flags of the view grid: a cell was touched this frame iff its byte == grid_tag
-  int grid_tag;
-  int ox, oy, oz, nx, ny, nz; // view grid
-  uint8_t* flags_out;         // [live position] appearance-candidate flag
-  u64* cell_key_out;
-  float decay_f;              // > 0: pending decay's W *= f (its deallocations were made by k_front)
-  const int* n_old;           // live blocks before this frame's allocation (ctr[6], published by k_front)
-  const u64* pub;             // the allocation job's published new blocks
-  unsigned tag;
-  int* err;                   // layer error flags (ctr[3]): bit 1 = the hand-over failed for good (see new_blocks_role)
-  int n_pair_wgs, n_new_wgs;
-  u64* ctl;                   // control words of the hand-over, behind the records: [0] terminated / abandoned workgroup counter,
-                              // [1] ranks integrated by the sweeper (diagnostics), [2 + d] {tag | first abandoned round} of waiter d
-  int* host_err;              // pinned host int (may be null): set when the hand-over failed for good
-  int debug_abandon;          // test hook (MMF_DEBUG_FORCE_ALLOC_TIMEOUT): 1 = odd waiters "time out" at once, 2 = so does the sweeper
-};
 
 struct TsdfPairLds {
   int free_[2][4], hit[2][4];
@@ -885,57 +870,97 @@ __device__ inline void new_blocks_role(const LayerDev& L, const TsdfFrameArgs& P
   }
 }
 
-__global__ __launch_bounds__(256) void k_alloc_tsdf(AllocJob J, long long* stats, int alloc_wgs, MaskJob M, int mask_rows, int lead,
-                                                   TsdfFrameArgs P) {
-  __shared__ int lds[34];
-  __shared__ int carry[2];
-  __shared__ int ctx[4];
-  __shared__ u64 s_bad[kMaxMaskWords];
-  __shared__ TsdfPairLds S;
+
+struct AllocTsdfLds {
+  int lds[34];
+  int carry[2];
+  int ctx[4];
+  u64 s_bad[kMaxMaskWords];
+  TsdfPairLds S;
+};
+
+__device__ inline void alloc_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, int w) {
   const long long tr0 = wg_trace_begin();
-  const int b = (int)blockIdx.x;
-  const LayerDev& L = J.L;
-  if (b < alloc_wgs) {
-    alloc_grid_multi_body<4, 2>(J, stats, lds, carry, ctx, b, alloc_wgs);
-    wg_trace_end(tr0, kTrAllocJob);
-    return;
-  }
-  if (b - alloc_wgs < mask_rows) {
-    mask_colemit_row(M, b - alloc_wgs, s_bad);
-    wg_trace_end(tr0, kTrAllocMaskCols);
-    return;
-  }
-  if (b < lead) return;  // padding: the TSDF workgroups start at a multiple of 8 (workgroup -> XCD residue)
+  alloc_grid_multi_body<4, 2>(A.J, A.stats, Q.lds, Q.carry, Q.ctx, w, A.alloc_wgs);
+  wg_trace_end(tr0, kTrAllocJob);
+}
+
+__device__ inline void mask_cols_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, int row) {
+  const long long tr0 = wg_trace_begin();
+  mask_colemit_row(A.M, row, Q.s_bad);
+  wg_trace_end(tr0, kTrAllocMaskCols);
+}
+
+// existing blocks, two list-adjacent ones per workgroup, pairs in XCD-contiguous chunks (workgroup c of n_pair_wgs; the
+// caller places the role at a multiple of 8 so that c mod 8 is the workgroup's XCD)
+__device__ inline void tsdf_pairs_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, int c) {
+  const long long tr0 = wg_trace_begin();
+  const LayerDev& L = A.J.L;
+  const TsdfFrameArgs& P = A.P;
   const int half = threadIdx.x >> 7;
   const int n_old = *P.n_old;
-  const int c = b - lead;
-  if (c < P.n_pair_wgs) {
-    // existing blocks, two list-adjacent ones per workgroup, pairs in XCD-contiguous chunks
-    const int npairs = (n_old + 1) >> 1;
-    const int chunk = (npairs + 7) >> 3;
-    int par = 0;
-    for (int j = c; j < chunk * 8; j += P.n_pair_wgs, par ^= 1) {
-      const int i = 2 * xcd_candidate(j, chunk) + half;
-      const bool act = i < n_old;
-      int slot = 0;
-      u64 key = 0;
-      bool cand = false;
-      if (act) {
-        slot = L.live[i];
-        key = L.slot_key[slot];
-        int bx, by, bz;
-        unpack_key(key, bx, by, bz);
-        const int gx = bx - P.ox, gy = by - P.oy, gz = bz - P.oz;
-        if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.nx && gy < P.ny && gz < P.nz)
-          cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] == (uint8_t)P.grid_tag;
-      }
-      tsdf_frame_block(L, P, S, par, act, i, slot, key, cand, false);
+  const int npairs = (n_old + 1) >> 1;
+  const int chunk = (npairs + 7) >> 3;
+  int par = 0;
+  for (int j = c; j < chunk * 8; j += P.n_pair_wgs, par ^= 1) {
+    const int i = 2 * xcd_candidate(j, chunk) + half;
+    const bool act = i < n_old;
+    int slot = 0;
+    u64 key = 0;
+    bool cand = false;
+    if (act) {
+      slot = L.live[i];
+      key = L.slot_key[slot];
+      int bx, by, bz;
+      unpack_key(key, bx, by, bz);
+      const int gx = bx - P.ox, gy = by - P.oy, gz = bz - P.oz;
+      if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.nx && gy < P.ny && gz < P.nz)
+        cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] == (uint8_t)P.grid_tag;
     }
-    wg_trace_end(tr0, kTrTsdfPass);
-    return;
+    tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false);
   }
-  new_blocks_role(L, P, S, c - P.n_pair_wgs, n_old);
+  wg_trace_end(tr0, kTrTsdfPass);
+}
+
+__device__ inline void tsdf_new_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, int d) {
+  const long long tr0 = wg_trace_begin();
+  new_blocks_role(A.J.L, A.P, Q.S, d, *A.P.n_old);
   wg_trace_end(tr0, kTrTsdfNew);
+}
+
+// grid: [allocation | mask columns | padding to `lead` (a multiple of 8) | existing-block pairs | new-block waiters]
+__global__ __launch_bounds__(256) void k_alloc_tsdf(AllocTsdfArgs A, int lead) {
+  __shared__ AllocTsdfLds Q;
+  const int b = (int)blockIdx.x;
+  if (b < A.alloc_wgs) return alloc_role(A, Q, b);
+  if (b - A.alloc_wgs < A.mask_rows) return mask_cols_role(A, Q, b - A.alloc_wgs);
+  if (b < lead) return;  // padding: the TSDF workgroups start at a multiple of 8 (workgroup -> XCD residue)
+  const int c = b - lead;
+  if (c < A.P.n_pair_wgs) return tsdf_pairs_role(A, Q, c);
+  tsdf_new_role(A, Q, c - A.P.n_pair_wgs);
+}
+
+// Two frames in one launch (mmf_integrate_frame_multi).  Workgroups are dispatched in index order and the new-block waiters
+// poll for words of the allocation workgroups of their own launch, so BOTH frames' producers lead the grid and both frames'
+// waiters close it:  [alloc 0 | alloc 1 | mask columns 0 | mask columns 1 | padding | pairs 0 | pairs 1 | new 0 | new 1].
+__global__ __launch_bounds__(256) void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdfArgs A1, int lead) {
+  __shared__ AllocTsdfLds Q;
+  int b = (int)blockIdx.x;
+  if (b < A0.alloc_wgs) return alloc_role(A0, Q, b);
+  b -= A0.alloc_wgs;
+  if (b < A1.alloc_wgs) return alloc_role(A1, Q, b);
+  b -= A1.alloc_wgs;
+  if (b < A0.mask_rows) return mask_cols_role(A0, Q, b);
+  b -= A0.mask_rows;
+  if (b < A1.mask_rows) return mask_cols_role(A1, Q, b);
+  if ((int)blockIdx.x < lead) return;
+  int c = (int)blockIdx.x - lead;
+  if (c < A0.P.n_pair_wgs) return tsdf_pairs_role(A0, Q, c);
+  c -= A0.P.n_pair_wgs;
+  if (c < A1.P.n_pair_wgs) return tsdf_pairs_role(A1, Q, c);
+  c -= A1.P.n_pair_wgs;
+  if (c < A0.P.n_new_wgs) return tsdf_new_role(A0, Q, c);
+  tsdf_new_role(A1, Q, c - A0.P.n_new_wgs);
 }
 
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_map)
@@ -1129,28 +1154,48 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
     hipLaunchKernelGGL(k_raycast_mark<false>, dim3(n_wgs), dim3(256), 0, s, R);
 }
 
-// raycast + mask row pass in one launch
-void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
-                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
-                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  int n_wgs;
-  RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
-  R.flag_value = flag_value;
-  R.mask_invert = M.invert;
-  const int ncells = vg.nx * vg.ny * vg.nz;
-  DecayJob D{};
+// raycast + mask row pass (+ pending decay) of a frame: arguments of its share of the first launch
+FrontArgs make_front_args(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
+                          int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
+                          uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value) {
+  FrontArgs A;
+  A.R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, A.n_ray_wgs);
+  A.R.flag_value = flag_value;
+  A.R.mask_invert = M.invert;
+  A.M = M;
+  A.D = DecayJob{};
   if (decay_layer) {
-    D.L = *decay_layer;
-    D.kill = kill;
-    D.any_kill = any_kill;
-    D.light = light_decay ? 1 : 0;
-    D.n_wgs = light_decay ? 1 : grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
+    A.D.L = *decay_layer;
+    A.D.kill = kill;
+    A.D.any_kill = any_kill;
+    A.D.light = light_decay ? 1 : 0;
+    A.D.n_wgs = light_decay ? 1 : grid_for(hinted(decay_layer->hint_live, decay_layer->cap), 4096);
   }
-  const dim3 grid(n_wgs + M.H + D.n_wgs);
-  if (ncells <= kRaycastLdsCells)
-    hipExtLaunchKernelGGL(k_front<true>, grid, dim3(256), (size_t)((ncells + 3) / 4) * 4, s, ev_start, ev_stop, 0, R, n_wgs, M, D, snap_ctr);
-  else
-    hipExtLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, R, n_wgs, M, D, snap_ctr);
+  A.snap_ctr = snap_ctr;
+  A.n_wgs = A.n_ray_wgs + M.H + A.D.n_wgs;
+  return A;
+}
+
+static inline int front_cells(const FrontArgs& A) { return A.R.vg.nx * A.R.vg.ny * A.R.vg.nz; }
+
+void launch_front(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  int ncells = front_cells(A[0]);
+  if (n > 1 && front_cells(A[1]) > ncells) ncells = front_cells(A[1]);
+  const bool lds = ncells <= kRaycastLdsCells;
+  const size_t shm = lds ? (size_t)((ncells + 3) / 4) * 4 : 0;
+  if (n == 1) {
+    const dim3 grid(A[0].n_wgs);
+    if (lds)
+      hipExtLaunchKernelGGL(k_front<true>, grid, dim3(256), shm, s, ev_start, ev_stop, 0, A[0]);
+    else
+      hipExtLaunchKernelGGL(k_front<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0]);
+  } else {
+    const dim3 grid(A[0].n_wgs + A[1].n_wgs);
+    if (lds)
+      hipExtLaunchKernelGGL(k_front2<true>, grid, dim3(256), shm, s, ev_start, ev_stop, 0, A[0], A[1]);
+    else
+      hipExtLaunchKernelGGL(k_front2<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1]);
+  }
 }
 
 constexpr int kFusedAllocMaxCells = 16384;
@@ -1303,11 +1348,15 @@ void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, co
     hipLaunchKernelGGL((k_tsdf_pass<4, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
 }
 
-// allocation | mask columns | TSDF pass (existing blocks beside the allocation, new blocks behind it): k_alloc_tsdf
-void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L,
-                       const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out, float decay_f,
-                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  TsdfFrameArgs P;
+// allocation | mask columns | TSDF pass (existing blocks beside the allocation, new blocks behind it): a frame's share of k_alloc_tsdf
+AllocTsdfArgs make_alloc_tsdf_args(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam,
+                                   const Rigid& T_C_L, const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out,
+                                   float decay_f) {
+  AllocTsdfArgs A;
+  A.J = job;
+  A.stats = stats;
+  A.M = M;
+  TsdfFrameArgs& P = A.P;
   P.mc = mc;
   P.cam = cam;
   P.T_C_L = T_C_L;
@@ -1327,11 +1376,20 @@ void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, 
   P.ctl = job.pub + kPubRec + 3 * (size_t)job.L.cap;
   P.host_err = job.host_err;
   P.debug_abandon = job.debug_abandon;
-  const int rows = M.Hf;
-  const int alloc_wgs = (job.ncells + 2047) / 2048;  // alloc_grid_multi_body<4, 2>: 2 048 cells per workgroup (<= kAllocMaxWgs)
-  const int lead = (alloc_wgs + rows + 7) & ~7;
-  hipExtLaunchKernelGGL(k_alloc_tsdf, dim3(lead + P.n_pair_wgs + P.n_new_wgs), dim3(256), 0, s, ev_start, ev_stop, 0, job, stats, alloc_wgs, M,
-                        rows, lead, P);
+  A.mask_rows = M.Hf;
+  A.alloc_wgs = (job.ncells + 2047) / 2048;  // alloc_grid_multi_body<4, 2>: 2 048 cells per workgroup (<= kAllocMaxWgs)
+  return A;
+}
+
+void launch_alloc_tsdf(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (n == 1) {
+    const int lead = (A[0].alloc_wgs + A[0].mask_rows + 7) & ~7;
+    hipExtLaunchKernelGGL(k_alloc_tsdf, dim3(lead + A[0].P.n_pair_wgs + A[0].P.n_new_wgs), dim3(256), 0, s, ev_start, ev_stop, 0, A[0], lead);
+  } else {
+    const int lead = (A[0].alloc_wgs + A[1].alloc_wgs + A[0].mask_rows + A[1].mask_rows + 7) & ~7;
+    const int total = lead + A[0].P.n_pair_wgs + A[1].P.n_pair_wgs + A[0].P.n_new_wgs + A[1].P.n_new_wgs;
+    hipExtLaunchKernelGGL(k_alloc_tsdf2, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1], lead);
+  }
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

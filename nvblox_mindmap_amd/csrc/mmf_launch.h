@@ -28,19 +28,121 @@ struct ViewGrid {
   int nx, ny, nz;
 };
 
+// ---- argument blocks of the fused-frame launches (one per frame; the *2 kernels take two) -----------------------------
+struct RaycastJob {
+  MapConsts mc;
+  Cam cam;
+  Rigid T_L_C;
+  const float* depth;
+  const uint8_t* mask;
+  int mask_invert;  // != 0: a pixel is valid where the mask byte is 0
+  float min_d;
+  int sub, Wsub, Hsub;
+  ViewGrid vg;
+  uint8_t* flags;
+  int flag_value;  // the byte a touched cell is set to: 1 (consumers clear the grid after use) or the frame's tag of a k_alloc_tsdf
+                   // frame, whose consumers compare for equality and never clear (Mapper::grid_tagged)
+};
+
+struct DecayJob {
+  LayerDev L;
+  uint8_t* kill;
+  int* any_kill;
+  int n_wgs;  // 0: no decay pending
+  int light;  // != 0: L.wmax is current -- ONE workgroup decides the deallocations from it and compacts the lists (no voxel
+              // access); the weights themselves are multiplied by the next k_tsdf_pass
+};
+
+// Everything one frame's first launch needs; `n_wgs` = its workgroups (light decay 0/1 + rays + mask rows + decay pass).
+struct FrontArgs {
+  RaycastJob R;
+  int n_ray_wgs;
+  MaskJob M;
+  DecayJob D;
+  int* snap_ctr;
+  int n_wgs;
+};
+
+struct TsdfFrameArgs {
+  MapConsts mc;
+  Cam cam;
+  Rigid T_C_L;
+  const float* depth;         // the frame's masked depth image
+  const uint8_t* grid_flags;  // raycast flags of the view grid: a cell was touched this frame iff its byte == grid_tag
+  int grid_tag;
+  int ox, oy, oz, nx, ny, nz; // view grid
+  uint8_t* flags_out;         // [live position] appearance-candidate flag
+  u64* cell_key_out;
+  float decay_f;              // > 0: pending decay's W *= f (its deallocations were made by k_front)
+  const int* n_old;           // live blocks before this frame's allocation (ctr[6], published by k_front)
+  const u64* pub;             // the allocation job's published new blocks
+  unsigned tag;
+  int* err;                   // layer error flags (ctr[3]): bit 1 = the hand-over failed for good (see new_blocks_role)
+  int n_pair_wgs, n_new_wgs;
+  u64* ctl;                   // control words of the hand-over, behind the records: [0] terminated / abandoned workgroup counter,
+                              // [1] ranks integrated by the sweeper (diagnostics), [2 + d] {tag | first abandoned round} of waiter d
+  int* host_err;              // pinned host int (may be null): set when the hand-over failed for good
+  int debug_abandon;          // test hook (MMF_DEBUG_FORCE_ALLOC_TIMEOUT): 1 = odd waiters "time out" at once, 2 = so does the sweeper
+};
+
+// One frame's share of the launch: its allocation job, mask job and TSDF-pass arguments + role sizes.
+struct AllocTsdfArgs {
+  AllocJob J;
+  long long* stats;
+  MaskJob M;
+  TsdfFrameArgs P;
+  int alloc_wgs, mask_rows;
+};
+
+struct AppArgs {
+  LayerDev L;
+  Cam cam;
+  Rigid T_C_L;
+  const void* image;     // rgb u8 [H,W,3]  or  features f16 [Hf,Wf,C]  (null when `low` is the feature source)
+  FlatList flat;         // features only: survivor list of the frame (rec == null: phase 2 stays in the gating workgroup)
+  LowRes low;            // features only: low-res backbone map sampled in the kernel instead of a materialised image
+  const uint8_t* mask;
+  Scratch sc;
+  long long* stats;  // mapper statistics (may be null)
+};
+
+// a frame's share of the sphere-trace | appearance-allocation launch
+struct SphereArgs {
+  LayerDev T;
+  MapConsts mc;
+  Cam cam;
+  Rigid T_L_C;
+  float* synth;
+  int Ws, Hs, patches_x, n_patches;
+  AllocJob J0, J1;
+  int njobs;
+  long long* stats;
+};
+
+// a frame's share of the colour-update + feature-gating launch (one camera for both layers)
+struct AppFrameArgs {
+  AppArgs Ac, Af;
+  MapConsts mc;
+  const float* synth;
+  int Ws, Hs;
+  int nb;  // workgroups
+};
+
 // mmf_kernels_map.hip
 int hinted(const int* hint, int upper);
 void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                     int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s);
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
                           int stat_new, hipStream_t s);
-void launch_front(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
-                  int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
-                  uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value, hipStream_t s, hipEvent_t ev_start = nullptr,
-                  hipEvent_t ev_stop = nullptr);  // events: stamped with the dispatch's own begin / end (extension launch)
-void launch_alloc_tsdf(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L,
-                       const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out, float decay_f,
-                       hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+FrontArgs make_front_args(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
+                          int sub, const ViewGrid& vg, uint8_t* flags, const MaskJob& M, const LayerDev* decay_layer, bool light_decay,
+                          uint8_t* kill, int* any_kill, int* snap_ctr, int flag_value);
+// n = 1 or 2 frames in the launch; events: stamped with the dispatch's own begin / end (extension launch)
+void launch_front(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+AllocTsdfArgs make_alloc_tsdf_args(const AllocJob& job, long long* stats, const MaskJob& M, const MapConsts& mc, const Cam& cam,
+                                   const Rigid& T_C_L, const float* masked_depth, const ViewGrid& vg, uint8_t* flags_out, u64* cell_key_out,
+                                   float decay_f);
+void launch_alloc_tsdf(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 bool alloc_jobs_fusable(int ncells0, int ncells1);
 void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
@@ -66,9 +168,18 @@ void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam&
                            u64* cell_key, hipStream_t s);
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
                          int Hs, hipStream_t s);
-void launch_sphere_alloc(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
-                         const AllocJob* jobs, int njobs, long long* stats, hipStream_t s, hipEvent_t ev_start = nullptr,
-                         hipEvent_t ev_stop = nullptr);
+SphereArgs make_sphere_args(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
+                            const AllocJob* jobs, int njobs, long long* stats);
+void launch_sphere_alloc(const SphereArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+AppFrameArgs make_app_frame_args(const LayerDev& Lc, const Cam& cam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc,
+                                 const LayerDev& Lf, const __half* feat, const uint8_t* fmask, const Scratch& fsc, const MapConsts& mc,
+                                 const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats, const LowRes* low,
+                                 const FlatList* flat);
+void launch_app_frame2(const AppFrameArgs& F0, const AppFrameArgs& F1, bool low, hipStream_t s, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr);
+void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, const LayerDev& L1, const MapConsts& mc1,
+                          const FlatList& fl1, const Cam& cam, const __half* feat, const LowRes* lowres, hipStream_t s,
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s);

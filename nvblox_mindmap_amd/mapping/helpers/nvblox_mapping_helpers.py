@@ -23,6 +23,9 @@ from ..nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
 # pays when both mappers see comparable work (two full frames: 134 -> ~112 us), not when the dynamic mask is a small region
 # (the fork / join costs more than the short dynamic chain it hides; bench.py `two_mappers`).
 OVERLAP_MAPPERS = os.environ.get("MMF_OVERLAP_MAPPERS", "0") == "1"
+# nvblox_integrate(include_dynamic=True): both mappers' frames as roles of the SAME five launches, one native call
+# (Mapper.integrate_frame_multi).  On by default; MMF_PAIR_MAPPERS=0 issues the two integrate_frame calls one after the other.
+PAIR_MAPPERS = os.environ.get("MMF_PAIR_MAPPERS", "1") != "0"
 _SIDE_STREAMS: Dict[torch.device, "torch.cuda.Stream"] = {}
 
 
@@ -196,6 +199,31 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
             input_mask_erosion_iterations=cfg.dynamic_mask_erosion_iterations,
             valid_depth_mask_erosion_iterations=cfg.valid_depth_mask_erosion_iterations, mapper_id=MAPPER_TO_ID.DYNAMIC)
 
+    Hf, Wf = feature_frame.shape[0], feature_frame.shape[1]
+    if include_dynamic and PAIR_MAPPERS and not OVERLAP_MAPPERS and depth_frame.is_cuda and (Hf, Wf) == tuple(depth_frame.shape):
+        # Both mappers in ONE native call: the two frames are roles of the same five launches (one latency chain, one enqueue;
+        # bit-identical to the two integrate_frame calls below).
+        feat16 = feature_frame if feature_frame.dtype == torch.float16 else feature_frame.to(torch.float16)
+        jobs = [
+            {"mapper_id": MAPPER_TO_ID.STATIC, "input_mask": dynamic_mask if use_dyn else torch.ones_like(dynamic_mask),
+             "invert_input_mask": use_dyn, "input_mask_erosion_iterations": cfg.static_mask_erosion_iterations,
+             "valid_depth_mask_erosion_iterations": cfg.valid_depth_mask_erosion_iterations},
+            {"mapper_id": MAPPER_TO_ID.DYNAMIC, "input_mask": dynamic_mask, "invert_input_mask": False,
+             "input_mask_erosion_iterations": cfg.dynamic_mask_erosion_iterations,
+             "valid_depth_mask_erosion_iterations": cfg.valid_depth_mask_erosion_iterations},
+        ]
+        masks = mapper.integrate_frame_multi(depth_frame, rgb, feat16, camera_pose, intrinsics, cfg.min_integration_distance_m,
+                                             cfg.feature_mask_border_percent, jobs)
+        for job, (dm_u8, fm) in zip(jobs, masks):
+            dm = dm_u8.view(torch.bool)
+            items = {"depth_frame": depth_frame, "depth_mask": dm, "rgb_mask": dm, "feature_frame": feature_frame, "feature_mask": fm}
+            im = job["input_mask"]
+            if job["invert_input_mask"]:
+                out[MAPPER_TO_ID(job["mapper_id"]).name] = _IntegrationImages(items, rgb, {"input_mask": lambda im=im: ~im})
+            else:
+                items["input_mask"] = im
+                out[MAPPER_TO_ID(job["mapper_id"]).name] = _IntegrationImages(items, rgb)
+        return out
     if include_dynamic and OVERLAP_MAPPERS and depth_frame.is_cuda:
         # The two mappers share nothing but the (read-only) input images, and a frame is a chain of five latency-bound
         # launches that leaves most of the chip idle: the dynamic mapper's chain runs on a second stream beside the static

@@ -370,10 +370,9 @@ class Mapper:
                                                            T.ctypes.data, K.ctypes.data, self._stream()),
                    "mmf_add_feature_frame_lowres")
 
-    def _integrate_frame_desc(self, depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
-                              min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, border_percent,
-                              mapper_id, invert_input_mask):
-        mapper_id = self._check_id(mapper_id)
+    def _frame_desc(self, depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
+                    min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, border_percent, invert_input_mask):
+        """Fill an ``mmf_frame``; returns (descriptor, objects to keep alive until the call returned, depth mask, feature mask)."""
         depth = _check_dev(depth_frame, "depth_frame", torch.float32, 2)
         rgb = _check_dev(color_frame, "color_frame", torch.uint8, 3)
         H, W = depth.shape
@@ -408,9 +407,41 @@ class Mapper:
         f.valid_depth_mask_erosion_iterations = int(valid_depth_mask_erosion_iterations)
         f.border_percent = int(border_percent)
         f.depth_mask_out, f.feature_mask_out = dm.data_ptr(), fm.data_ptr()
+        return f, (keep, depth, rgb, mask, T, K), dm, fm
+
+    def _integrate_frame_desc(self, depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
+                              min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations, border_percent,
+                              mapper_id, invert_input_mask):
+        mapper_id = self._check_id(mapper_id)
+        f, keep, dm, fm = self._frame_desc(depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
+                                           min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
+                                           border_percent, invert_input_mask)
         _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
         del keep
         return dm, fm
+
+    def integrate_frame_multi(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor, t_w_c, intrinsics,
+                              min_depth_m: float, border_percent: int, jobs, lowres_features: Optional[torch.Tensor] = None):
+        """One camera frame into SEVERAL mappers with one native call (``mmf_integrate_frame_multi``): what the reference's
+        ``nvblox_integrate(include_dynamic=True)`` does with two ``integrate_frame`` calls (nvblox_mapping_helpers.py:128-156).
+        ``jobs``: one dict per mapper -- ``mapper_id``, ``input_mask`` [H,W] bool/u8, ``input_mask_erosion_iterations``,
+        ``valid_depth_mask_erosion_iterations`` and optionally ``invert_input_mask``.  Pairs of jobs run as roles of the same five
+        launches (bit-identical to the calls in sequence).  Returns [(depth_mask, feature_mask), ...] in job order."""
+        n = len(jobs)
+        descs = (_lib.MmfFrame * n)()
+        ids = (C.c_int * n)()
+        keep, out = [], []
+        for i, job in enumerate(jobs):
+            ids[i] = self._check_id(job["mapper_id"])
+            f, k, dm, fm = self._frame_desc(depth_frame, color_frame, None if lowres_features is not None else feature_frame, lowres_features,
+                                            job["input_mask"], t_w_c, intrinsics, min_depth_m, job["input_mask_erosion_iterations"],
+                                            job["valid_depth_mask_erosion_iterations"], border_percent, bool(job.get("invert_input_mask", False)))
+            descs[i] = f
+            keep.append(k)
+            out.append((dm, fm))
+        _lib.check(_lib.lib().mmf_integrate_frame_multi(self._h, n, ids, descs, self._stream()), "mmf_integrate_frame_multi")
+        del keep
+        return out
 
     def integrate_frame_lowres(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, lowres_features: torch.Tensor,
                                input_mask: torch.Tensor, t_w_c, intrinsics, min_depth_m: float,

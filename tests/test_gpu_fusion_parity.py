@@ -767,3 +767,79 @@ def test_two_mappers_on_two_streams_equal_sequential(monkeypatch):
         assert ta[1].shape[0] > 20 and torch.equal(ta[0], tb[0]) and torch.equal(ta[1], tb[1])
         fa, fb = a.feature_layer_view(mid).get_all_blocks_split(), b.feature_layer_view(mid).get_all_blocks_split()
         assert all(torch.equal(x, y) for x, y in zip(fa, fb))
+
+
+def test_two_mappers_in_one_call_equal_sequential_and_oracle(oracle_mod, monkeypatch):
+    """nvblox_integrate(include_dynamic=True) through mmf_integrate_frame_multi (both mappers' frames as roles of the same five
+    launches: k_front2 ... k_feature_flat2) against the two integrate_frame calls in sequence -- same maps, same masks, bit for
+    bit -- and against the oracle driven mapper by mapper.  Full size (640x480, reference erosions), decay every frame, the
+    dynamic region moves, so both mappers allocate and deallocate along the way."""
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
+    from oracle import image_ops as IO
+
+    cfg = S.StreamConfig(hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    C = 16
+    a, b = (H.get_nvblox_mapper(mcfg, feature_channels=C) for _ in range(2))
+    orcs = [make_oracle(oracle_mod, C, tsdf_decay_factor=mcfg.tsdf_decay_factor) for _ in range(2)]
+
+    class Extractor:
+        def compute(self, rgb):
+            return self.next.unsqueeze(0)
+
+    ex = Extractor()
+    for k, i in enumerate([0, 6, 12, 40, 46, 52]):
+        f = S.frame(cfg, i, C)
+        dyn = np.zeros(f["depth"].shape, dtype=bool)
+        dyn[80 + 7 * k: 300, 150 + 9 * k: 420] = True
+        ex.next = dev(f["features"])
+        outs = []
+        for m, pair in ((a, True), (b, False)):
+            monkeypatch.setattr(H, "PAIR_MAPPERS", pair)
+            m.decay()
+            outs.append(H.nvblox_integrate(m, mcfg, ex, dev(f["depth"]), torch.from_numpy(f["K"]), torch.from_numpy(f["T_W_C"]),
+                                           dev(f["rgb"]), dev(dyn), include_dynamic=True))
+        for name in ("STATIC", "DYNAMIC"):
+            assert set(outs[0][name].keys()) == set(outs[1][name].keys())
+            for key in ("depth_mask", "feature_mask", "input_mask"):
+                assert torch.equal(outs[0][name][key], outs[1][name][key]), (name, key)
+        for orc, mask, k_in in ((orcs[0], ~dyn, mcfg.static_mask_erosion_iterations), (orcs[1], dyn, mcfg.dynamic_mask_erosion_iterations)):
+            odm, ofm = IO.frame_masks(mask, f["depth"], mcfg.min_integration_distance_m, k_in, mcfg.valid_depth_mask_erosion_iterations,
+                                      mcfg.feature_mask_border_percent, cfg.height, cfg.width)
+            orc.decay()
+            orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+            orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+            orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+    torch.cuda.synchronize()
+    for mid, orc in ((MAPPER_TO_ID.STATIC, orcs[0]), (MAPPER_TO_ID.DYNAMIC, orcs[1])):
+        ta, tb = a.tsdf_layer_view(mid).get_all_blocks(), b.tsdf_layer_view(mid).get_all_blocks()
+        assert ta[1].shape[0] > 20 and torch.equal(ta[0], tb[0]) and torch.equal(ta[1], tb[1])
+        fa, fb = a.feature_layer_view(mid).get_all_blocks_split(), b.feature_layer_view(mid).get_all_blocks_split()
+        assert all(torch.equal(x, y) for x, y in zip(fa, fb))
+        ca, cb = a.color_layer_view(mid).get_all_blocks_split(), b.color_layer_view(mid).get_all_blocks_split()
+        assert all(torch.equal(x, y) for x, y in zip(ca, cb))
+        assert np.array_equal(ta[1].cpu().numpy(), orc.block_indices(0))
+        assert np.abs(ta[0].cpu().numpy() - orc.all_tsdf()).max() <= 1e-5
+        fo, wo = orc.all_features()
+        assert np.array_equal(fa[2].cpu().numpy(), orc.block_indices(2)) and np.array_equal(fa[1].cpu().numpy(), wo)
+        assert np.abs(fa[0].cpu().numpy().astype(np.float32) - fo.astype(np.float32)).max() <= 1e-5
+    assert a.stats(MAPPER_TO_ID.DYNAMIC)["feature_voxels_updated"] > 0 and a.stats(MAPPER_TO_ID.STATIC)["feature_voxels_updated"] > 0
+
+
+def test_integrate_frame_multi_argument_checks():
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg
+
+    m = get_nvblox_mapper(NvbloxMappingCfg("DRILL_IN_BOX"), feature_channels=8)
+    cfg = small_cfg(4)
+    f = S.frame(cfg, 0, 8)
+    ones = dev(np.ones(f["depth"].shape, dtype=bool))
+    job = {"mapper_id": 0, "input_mask": ones, "input_mask_erosion_iterations": 1, "valid_depth_mask_erosion_iterations": 1}
+    with pytest.raises(RuntimeError, match="different mapper"):
+        m.integrate_frame_multi(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]),
+                                0.3, 0, [job, dict(job)])
+    # a single job and a trio (pair + single) are fine
+    out = m.integrate_frame_multi(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]),
+                                  0.3, 0, [job])
+    assert len(out) == 1 and out[0][0].shape == f["depth"].shape
