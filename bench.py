@@ -742,7 +742,11 @@ def pmc_traffic():
         with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
             pmc = json.load(f)
         src = pmc.get("__source__", "profiles/latest_pmc.json (builder's rocprofv3 --pmc passes of this command)")
-        return {k: (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 for k, v in pmc.items() if isinstance(v, dict) and "FETCH_SIZE_KB" in v}, src
+        out = {}
+        for k, v in pmc.items():  # keys carry the template arguments (k_front<true>): fold them onto the kernel's base name
+            if isinstance(v, dict) and "FETCH_SIZE_KB" in v:
+                out.setdefault(k.split("<")[0], (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0)
+        return out, src
     except Exception:
         return {}, None
 

@@ -52,7 +52,9 @@ struct Mapper {
   int sc_cap[3] = {0, 0, 0};
   uint8_t* mask_tmp = nullptr;  // bit-row scratch of the mask kernels
   size_t mask_tmp_cap = 0;
+  size_t patch_cap = 0;
   float* masked_depth = nullptr;
+  uint8_t* patch_flags = nullptr;  // [(H/16+1) * (W/16+1)] tagged like the grid flags: 16x16-pixel patches that hold a depth-mask pixel
   int* hints = nullptr;  // pinned host ints the device publishes counts to: [0..2] candidates of sc[0..2], [3..5] live blocks  // depth with invalid / masked pixels zeroed (written by the mask row pass)
   uint8_t* kill = nullptr;
   int* any_kill = nullptr;
@@ -446,6 +448,7 @@ void destroy_mapper(Mapper* m) {
   }
   (void)hipFree(m->mask_tmp);
   (void)hipFree(m->masked_depth);
+  (void)hipFree(m->patch_flags);
   (void)hipFree(m->inv_mask);
   (void)hipFree(m->timeline);
   (void)hipFree(m->flat.rec);
@@ -644,10 +647,15 @@ int ensure_mask_scratch(Mapper& m, int H, int W) {
   HIP_TRY(hipDeviceSynchronize());
   (void)hipFree(m.mask_tmp);
   (void)hipFree(m.masked_depth);
+  (void)hipFree(m.patch_flags);
   m.mask_tmp = nullptr;
   m.masked_depth = nullptr;
+  m.patch_flags = nullptr;
   HIP_TRY(hipMalloc(&m.mask_tmp, (size_t)H * W + 8));
   HIP_TRY(hipMalloc(&m.masked_depth, sizeof(float) * (size_t)H * W));
+  m.patch_cap = (size_t)(H / 16 + 1) * (W / 16 + 1);
+  HIP_TRY(hipMalloc(&m.patch_flags, m.patch_cap));
+  HIP_TRY(hipMemset(m.patch_flags, 0, m.patch_cap));
   m.mask_tmp_cap = (size_t)H * W + 8;
   return MMF_OK;
 }
@@ -694,6 +702,7 @@ int next_grid_tag(Mapper& m, hipStream_t s, int* tag) {
   m.grid_tagged = true;
   if (++m.grid_tag > 255) {
     HIP_TRY(hipMemsetAsync(m.sc[0].flags, 0, (size_t)m.sc_cap[0], s));
+    if (m.patch_flags) HIP_TRY(hipMemsetAsync(m.patch_flags, 0, m.patch_cap, s));  // tagged with the same counter
     m.grid_tag = 1;
   }
   *tag = m.grid_tag;
@@ -1318,6 +1327,15 @@ static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, c
   m.pending_decay = false;
   int grid_tag = 1;
   MMF_TRY(next_grid_tag(m, s, &grid_tag));
+  // Two frames share every launch, so the chip is oversubscribed where one frame alone fills it (2 x 1 200 ray patches): the
+  // sphere tracer of a paired frame skips the patches no gate can read (for the dynamic mapper most of the image).
+  const bool skip_patches = m.mc.st_sf == 4 && m.patch_flags != nullptr;
+  if (skip_patches) {
+    M.patch_flags = m.patch_flags;
+    M.patches_x = (in.W / 4 + 3) / 4;
+    M.patches_y = (in.H / 4 + 3) / 4;
+    M.patch_tag = grid_tag;
+  }
   F.front = make_front_args(m.mc, cam, T_L_C, in.depth, in.input_mask, in.min_depth_m, sub, vg, m.sc[0].flags, M,
                             do_decay ? &m.tsdf.d : nullptr, do_decay, m.kill, m.any_kill, m.tsdf.d.ctr, grid_tag);
   KeySrc ks0{};
@@ -1364,6 +1382,11 @@ static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, c
   MMF_TRY(synth_prepare(m, cam, in.T16, in.K9, &Ws, &Hs, &need));  // (need: the TSDF epoch moved on in this call)
   F.sphere = make_sphere_args(m.tsdf.d, m.mc, cam, T_L_C, m.synth, Ws, Hs, jobs, 2, m.stats);
   synth_commit(m, cam, in.T16, in.K9, Ws, Hs);
+  if (skip_patches) {
+    F.sphere.patch_flags = m.patch_flags;
+    F.sphere.patch_tag = grid_tag;
+    m.synth_epoch = -1;  // the image is partial: never reused by a later stand-alone appearance call
+  }
   F.app = make_app_frame_args(m.color.d, cam, in.rgb, in.depth_mask_out, m.sc[1], m.feat.d, (const __half*)in.feat, in.feature_mask_out,
                               m.sc[2], m.mc, T_C_L, m.synth, m.synth_W, m.synth_H, m.feat.d.cap, m.stats,
                               in.has_low ? &in.low : nullptr, &m.flat);

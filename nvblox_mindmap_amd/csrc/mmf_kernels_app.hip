@@ -299,6 +299,18 @@ __device__ inline void sphere_alloc_role(const SphereArgs& A, SphereLds& Q, int 
 
 __device__ inline void sphere_patch_role(const SphereArgs& A, SphereLds& Q, int patch) {
   const long long tr0 = wg_trace_begin();
+  if (A.patch_flags && patch < A.n_patches) {  // (workgroup-uniform) skip patches no gate of this frame can read
+    int mine = 0;
+    if (threadIdx.x < 9) {
+      const int patches_y = A.n_patches / A.patches_x;
+      const int px = patch % A.patches_x + (int)(threadIdx.x % 3) - 1, py = patch / A.patches_x + (int)(threadIdx.x / 3) - 1;
+      if (px >= 0 && py >= 0 && px < A.patches_x && py < patches_y) mine = A.patch_flags[py * A.patches_x + px] == (uint8_t)A.patch_tag;
+    }
+    if (!__syncthreads_or(mine)) {
+      wg_trace_end(tr0, kTrSphereTrace);
+      return;
+    }
+  }
   if (wg_trace_on()) {  // diagnostics only: longest wide / narrow iteration counts of the workgroup ride in the record id
     if (threadIdx.x < 2) Q.lds[threadIdx.x] = 0;
     __syncthreads();

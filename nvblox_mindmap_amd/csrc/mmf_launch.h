@@ -117,6 +117,12 @@ struct SphereArgs {
   AllocJob J0, J1;
   int njobs;
   long long* stats;
+  // optional (MaskJob::patch_flags of the same frame, 16x16-pixel patches = 4x4 ray patches at sphere-tracing subsampling 4):
+  // a ray patch is traced only if it or one of its 8 neighbours holds a pixel of the depth mask -- the synthetic depth of the
+  // others is never read by a gate that can pass (a voxel's synthetic-depth taps lie within 2 pixels of its mask footprint,
+  // and the gate needs the whole footprint inside the mask).  The image is then PARTIAL: the caller invalidates its cache.
+  const uint8_t* patch_flags = nullptr;
+  int patch_tag = 0;
 };
 
 // a frame's share of the colour-update + feature-gating launch (one camera for both layers)

@@ -29,6 +29,11 @@ struct MaskJob {
   float sh, sw;            // H/Hf, W/Wf
   int bh, bw;              // border in pixels
   uint8_t* out;            // [Hf,Wf] feature mask
+  // optional: which 16x16-pixel patches hold a pixel of the depth mask.  The row pass stores `patch_tag` into
+  // patch_flags[(y >> 4) * patches_x + (x >> 4)] for every such patch (nobody clears: a patch is marked iff its byte equals
+  // this frame's tag).  Consumer: the sphere tracer of a paired frame skips ray patches no gate can read (SphereArgs).
+  uint8_t* patch_flags = nullptr;
+  int patches_x = 0, patches_y = 0, patch_tag = 0;
 };
 
 __device__ inline u64 row_word(const u64* w, int j, int nw) { return (j >= 0 && j < nw) ? w[j] : 0ull; }
@@ -51,6 +56,12 @@ __device__ inline void mask_rowbits_row(const MaskJob& J, int y, u64* s_in, u64*
     if (lane == 0 && (x >> 6) < J.nw) {
       s_in[x >> 6] = b_in;
       s_d[x >> 6] = b_d;
+    }
+    if (J.patch_flags && (lane & 15) == 0 && x < J.W) {  // one lane per 16-pixel group: any pixel of the depth mask in it?
+      const int nb = J.W - x < 16 ? J.W - x : 16;
+      const u64 valid = (~(b_in | b_d) >> lane) & ((1ull << nb) - 1ull);
+      const int pxx = x >> 4, pyy = y >> 4;
+      if (valid && pxx < J.patches_x && pyy < J.patches_y) J.patch_flags[pyy * J.patches_x + pxx] = (uint8_t)J.patch_tag;
     }
   }
   __syncthreads();

@@ -15,9 +15,12 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\(.*$", "", name)          # parameters
-    name = re.sub(r"<.*$", "", name)           # template arguments
-    name = name.replace("void ", "").strip()
-    return name.split("::")[-1].replace(".kd", "")
+    name = name.replace("void ", "").strip().replace(".kd", "")
+    base = re.sub(r"<.*$", "", name).split("::")[-1]
+    targs = re.search(r"<(.*)>$", name)
+    # libmmfusion kernels keep their template arguments (k_feature_flat<false> reads the materialised image, <true> the low-res
+    # map: different traffic); library kernels (at::native::...) are shortened to the function name
+    return f"{base}<{targs.group(1)}>" if (targs and base.startswith("k_")) else base
 
 
 def main(out, source, paths):
