@@ -19,22 +19,9 @@ from ...nvblox_torch.timer import Timer
 from ..nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
 
 
-# nvblox_integrate(include_dynamic=True): MMF_OVERLAP_MAPPERS=1 runs the two mappers' frames on two streams.  Off by default: it
-# pays when both mappers see comparable work (two full frames: 134 -> ~112 us), not when the dynamic mask is a small region
-# (the fork / join costs more than the short dynamic chain it hides; bench.py `two_mappers`).
-OVERLAP_MAPPERS = os.environ.get("MMF_OVERLAP_MAPPERS", "0") == "1"
 # nvblox_integrate(include_dynamic=True): both mappers' frames as roles of the SAME five launches, one native call
 # (Mapper.integrate_frame_multi).  On by default; MMF_PAIR_MAPPERS=0 issues the two integrate_frame calls one after the other.
 PAIR_MAPPERS = os.environ.get("MMF_PAIR_MAPPERS", "1") != "0"
-_SIDE_STREAMS: Dict[torch.device, "torch.cuda.Stream"] = {}
-
-
-def _side_stream(device: torch.device) -> "torch.cuda.Stream":
-    s = _SIDE_STREAMS.get(device)
-    if s is None:
-        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return s
-
 
 class _IntegrationImages(dict):
     """The images dictionary integrate_frame returns (:263-271).  Entries only the visualiser consumes are computed on
@@ -200,7 +187,7 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
             valid_depth_mask_erosion_iterations=cfg.valid_depth_mask_erosion_iterations, mapper_id=MAPPER_TO_ID.DYNAMIC)
 
     Hf, Wf = feature_frame.shape[0], feature_frame.shape[1]
-    if include_dynamic and PAIR_MAPPERS and not OVERLAP_MAPPERS and depth_frame.is_cuda and (Hf, Wf) == tuple(depth_frame.shape):
+    if include_dynamic and PAIR_MAPPERS and depth_frame.is_cuda and (Hf, Wf) == tuple(depth_frame.shape):
         # Both mappers in ONE native call: the two frames are roles of the same five launches (one latency chain, one enqueue;
         # bit-identical to the two integrate_frame calls below).
         feat16 = feature_frame if feature_frame.dtype == torch.float16 else feature_frame.to(torch.float16)
@@ -223,23 +210,6 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
             else:
                 items["input_mask"] = im
                 out[MAPPER_TO_ID(job["mapper_id"]).name] = _IntegrationImages(items, rgb)
-        return out
-    if include_dynamic and OVERLAP_MAPPERS and depth_frame.is_cuda:
-        # The two mappers share nothing but the (read-only) input images, and a frame is a chain of five latency-bound
-        # launches that leaves most of the chip idle: the dynamic mapper's chain runs on a second stream beside the static
-        # one's (134 -> ~112 us per frame pair at the benchmark shape).  Fork after the inputs, join before returning, so the
-        # caller sees ordinary stream-ordered semantics on its own stream.
-        main = torch.cuda.current_stream(depth_frame.device)
-        side = _side_stream(depth_frame.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            dyn = dynamic_half()
-        out[MAPPER_TO_ID.STATIC.name] = static_half()
-        main.wait_stream(side)
-        for v in dict.values(dyn):
-            if torch.is_tensor(v) and v.is_cuda:
-                v.record_stream(main)  # allocated while `side` was current, used by the caller on `main`
-        out[MAPPER_TO_ID.DYNAMIC.name] = dyn
         return out
     out[MAPPER_TO_ID.STATIC.name] = static_half()
     if include_dynamic:

@@ -730,45 +730,6 @@ def test_grid_tag_wraps_and_merged_path_equals_separate_launches(monkeypatch):
     assert all(torch.equal(x, y) for x, y in zip(fa, fb))
 
 
-def test_two_mappers_on_two_streams_equal_sequential(monkeypatch):
-    """nvblox_integrate(include_dynamic=True): the dynamic mapper's frame on a second stream beside the static one's (fork after
-    the inputs, join before returning) gives the same maps and masks as the two calls in sequence."""
-    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
-    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
-
-    cfg = S.StreamConfig(hole_mode="patches")
-    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
-    a, b = (H.get_nvblox_mapper(mcfg, feature_channels=16) for _ in range(2))
-    if a.num_mappers() < 2:
-        pytest.skip("configuration has a single mapper")
-
-    class Extractor:
-        def compute(self, rgb):
-            return self.next.unsqueeze(0)
-
-    ex = Extractor()
-    for k, i in enumerate([0, 6, 12, 40, 46]):
-        f = S.frame(cfg, i, 16)
-        dyn = np.zeros(f["depth"].shape, dtype=bool)
-        dyn[80 + 7 * k: 260, 180 + 5 * k: 380] = True
-        ex.next = dev(f["features"])
-        outs = []
-        for m, overlap in ((a, True), (b, False)):
-            monkeypatch.setattr(H, "OVERLAP_MAPPERS", overlap)
-            m.decay()
-            outs.append(H.nvblox_integrate(m, mcfg, ex, dev(f["depth"]), torch.from_numpy(f["K"]), torch.from_numpy(f["T_W_C"]),
-                                           dev(f["rgb"]), dev(dyn), include_dynamic=True))
-        for name in ("STATIC", "DYNAMIC"):
-            for key in ("depth_mask", "feature_mask"):
-                assert torch.equal(outs[0][name][key], outs[1][name][key])
-    torch.cuda.synchronize()
-    for mid in (MAPPER_TO_ID.STATIC, MAPPER_TO_ID.DYNAMIC):
-        ta, tb = a.tsdf_layer_view(mid).get_all_blocks(), b.tsdf_layer_view(mid).get_all_blocks()
-        assert ta[1].shape[0] > 20 and torch.equal(ta[0], tb[0]) and torch.equal(ta[1], tb[1])
-        fa, fb = a.feature_layer_view(mid).get_all_blocks_split(), b.feature_layer_view(mid).get_all_blocks_split()
-        assert all(torch.equal(x, y) for x, y in zip(fa, fb))
-
-
 def test_two_mappers_in_one_call_equal_sequential_and_oracle(oracle_mod, monkeypatch):
     """nvblox_integrate(include_dynamic=True) through mmf_integrate_frame_multi (both mappers' frames as roles of the same five
     launches: k_front2 ... k_feature_flat2) against the two integrate_frame calls in sequence -- same maps, same masks, bit for
