@@ -179,8 +179,8 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
     const int nl = *ks.n_live;
     ncells = ncells < nl ? ncells : nl;
   }
+  if (J.zero_me && (int)threadIdx.x < J.zero_n) J.zero_me[threadIdx.x * J.zero_stride] = 0;
   if (threadIdx.x == 0) {
-    if (J.zero_me) *J.zero_me = 0;
     carry[0] = 0;
     carry[1] = 0;
     ctx[0] = L.ctr[0];
@@ -342,8 +342,8 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
   const int ncells = J.ncells;
   long long* tl = (J.timeline && w == nwg - 1 && threadIdx.x == 0) ? J.timeline : nullptr;  // diagnostics: the last workgroup
   if (tl) tl[0] = tl[1] = wall_clock64();
+  if (w == 0 && J.zero_me && (int)threadIdx.x < J.zero_n) J.zero_me[threadIdx.x * J.zero_stride] = 0;
   if (threadIdx.x == 0) {
-    if (w == 0 && J.zero_me) *J.zero_me = 0;
     ctx[0] = L.ctr[0];
     ctx[1] = L.ctr[1];
     ctx[2] = L.ctr[2];

@@ -554,13 +554,15 @@ int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w) {
   if (has_w && !m.flat.rec) {
     // survivor list of a feature frame: every voxel of every block may survive.  Bounded workspaces (what the
     // reference configures) need a few tens of MB; very large pools keep phase 2 inside the gating workgroups.
-    const size_t recs = (size_t)m.app_cap * kVPB;
+    // (sub-list k takes the blocks in pool slots k, k + 64, ...: at most ceil(app_cap / 64) blocks of 512 voxels each)
+    const size_t recs = (size_t)((m.app_cap + kFlatSubLists - 1) / kFlatSubLists) * kVPB * kFlatSubLists;
     if (m.app_cap < (1 << 22) && recs * 20 <= ((size_t)256 << 20)) {
       HIP_TRY(hipMalloc(&m.flat.rec, sizeof(uint4) * recs));
       HIP_TRY(hipMalloc(&m.flat.w, sizeof(float) * recs));
-      HIP_TRY(hipMalloc(&m.flat.count, sizeof(int)));
-      HIP_TRY(hipMemset(m.flat.count, 0, sizeof(int)));
+      HIP_TRY(hipMalloc(&m.flat.count, sizeof(int) * kFlatSubLists * kFlatCountStride));
+      HIP_TRY(hipMemset(m.flat.count, 0, sizeof(int) * kFlatSubLists * kFlatCountStride));
       m.flat.cap = (int)recs;
+      m.flat.seg_cap = (int)(recs / kFlatSubLists);
       m.flat.hint = m.hints ? m.hints + 6 : nullptr;
     }
   }
@@ -993,7 +995,7 @@ static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat,
   rigid_inverse(T_L_C, T_C_L);
   m->frames[2]++;
   MMF_TRY(app_prepare(h, *m, 2, m->feat, cam, T_L_C, T_C_L, T16, K9, 6, 7, s));
-  if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
+  if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int) * kFlatSubLists * kFlatCountStride, s));
   {
     ProfScope ps(h, MMF_K_FEATURE, s);
     launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc[2],
@@ -1001,7 +1003,7 @@ static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat,
   }
   {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);
-    launch_feature_flat(m->feat.d, m->mc, cam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
+    launch_feature_flat(m->feat.d, m->mc, cam, (const __half*)feat, low, m->flat, m->stats, s, pe.a(), pe.b());
   }
   return check_launch();
 }
@@ -1100,10 +1102,10 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                            m->color.d.cap, s);
     m->frames[2]++;
     MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
-    if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int), s));
+    if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int) * kFlatSubLists * kFlatCountStride, s));
     launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
                              m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
-    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s);
+    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s);
     return check_launch();
   }
   m->last_vg = vg;
@@ -1202,7 +1204,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     jobs[1].ncells = m->tsdf.d.cap;
     jobs[1].stat_upd = 6;
     jobs[1].stat_new = 7;
-    jobs[1].zero_me = m->flat.count;  // survivor counter of this frame's feature update
+    jobs[1].zero_me = m->flat.count;  // survivor counters of this frame's feature update
+    jobs[1].zero_n = kFlatSubLists;
+    jobs[1].zero_stride = kFlatCountStride;
     int Ws, Hs;
     bool need;
     MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
@@ -1224,7 +1228,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   }
   {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);
-    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, s, pe.a(), pe.b());
+    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s, pe.a(), pe.b());
   }
   return check_launch();
 }
@@ -1377,6 +1381,8 @@ static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, c
   jobs[1].stat_upd = 6;
   jobs[1].stat_new = 7;
   jobs[1].zero_me = m.flat.count;
+  jobs[1].zero_n = kFlatSubLists;
+  jobs[1].zero_stride = kFlatCountStride;
   int Ws, Hs;
   bool need;
   MMF_TRY(synth_prepare(m, cam, in.T16, in.K9, &Ws, &Hs, &need));  // (need: the TSDF epoch moved on in this call)
@@ -1450,7 +1456,8 @@ int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids,
     }
     {
       ProfExt pe(h, MMF_K_FEATURE_FLAT);
-      launch_feature_flat2(ms[i]->feat.d, ms[i]->mc, ms[i]->flat, ms[i + 1]->feat.d, ms[i + 1]->mc, ms[i + 1]->flat, cam[0],
+      launch_feature_flat2(ms[i]->feat.d, ms[i]->mc, ms[i]->flat, ms[i]->stats, ms[i + 1]->feat.d, ms[i + 1]->mc, ms[i + 1]->flat,
+                           ms[i + 1]->stats, cam[0],
                            (const __half*)ins[i].feat, ins[i].has_low ? &ins[i].low : nullptr, s, pe.a(), pe.b());
     }
     MMF_TRY(check_launch());

@@ -127,7 +127,8 @@ struct AllocJob {
   int stamp = 0;           // != 0: mark every candidate slot in L.stamp (see LayerDev::stamp)
   uint8_t* kill = nullptr; // != null: first apply the kill flags of a decay pass (live_compact_body)
   int* any_kill = nullptr;
-  int* zero_me = nullptr;  // != null: an int this job resets (the frame's feature survivor counter)
+  int* zero_me = nullptr;  // != null: counters this job resets: zero_me[k * zero_stride], k < zero_n (the frame's survivor sub-lists)
+  int zero_n = 0, zero_stride = 0;
   long long* timeline = nullptr;  // != null: thread 0 stores wall_clock64() (100 MHz) at 6 points of the job (diagnostics)
   u64* pub = nullptr;      // alloc_grid_multi_body: [16 + 3 * cap + 2 + kNewBlockWgs] published counts, new blocks (see there) and
                            // the control words of k_alloc_tsdf's hand-over (TsdfFrameArgs::ctl)

@@ -633,12 +633,16 @@ __device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, Feat
 // rows evenly over the whole chip.  Blocks on a surface have up to 512 survivors, the average is ~50: done inside the
 // gating workgroup, the heavy blocks set the kernel time (16 serial rounds vs 1.6 on average).
 // Returns false (workgroup-uniform) when the list is not in use; contains a barrier.
-__device__ inline bool feature_publish(const AppArgs& A, FeatLds& S, int slot, bool is_new) {
+__device__ inline bool feature_publish(const AppArgs& A, FeatLds& S, int slot, bool is_new, int cand) {
   if (!A.flat.rec) return false;
   const int nv = S.n;
-  if (threadIdx.x == 0) S.base = nv ? atomicAdd(A.flat.count, nv) : 0;
+  // by pool slot, not by candidate position: slots are unique, so a sub-list can never hold more than ceil(cap / 64) blocks
+  // (its region's size) whatever the candidate list looks like
+  (void)cand;
+  const int sub = slot & (kFlatSubLists - 1);
+  if (threadIdx.x == 0) S.base = nv ? atomicAdd(A.flat.count + sub * kFlatCountStride, nv) : 0;
   __syncthreads();
-  const int base = S.base;
+  const int base = sub * A.flat.seg_cap + S.base;
   const unsigned hi = ((unsigned)slot << 9) | (is_new ? 0x80000000u : 0u);
   for (int v = threadIdx.x; v < nv; v += 256) {
     A.flat.rec[base + v] = make_uint4(hi | S.lin[v], S.pix[v], __float_as_uint(S.wx[v]), __float_as_uint(S.wy[v]));
@@ -664,25 +668,48 @@ __device__ inline void feature_zero_fill(const AppArgs& A, const MapConsts& mc, 
 
 // tail of both gating bodies once the survivor list of the block is complete in LDS (callers synchronised before)
 template <bool LOW>
-__device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
-  if (threadIdx.x == 0 && A.stats && S.n) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
-  if (!feature_publish(A, S, slot, is_new)) feature_apply<LOW>(A, mc, S, slot, is_new);
+__device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new, int cand) {
+  // statistics: with the survivor list the frame's total is added once by k_feature_flat (one more same-address atomic per
+  // gating workgroup otherwise)
+  if (threadIdx.x == 0 && A.stats && S.n && !A.flat.rec) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
+  if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW>(A, mc, S, slot, is_new);
   if (is_new) feature_zero_fill(A, mc, S, slot);
 }
 
 // Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size (workgroup bid of nb).
 template <bool LOW>
-__device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, int lpv, int bid, int nb) {
+__device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, int lpv, int bid, int nb, int* s_prefix) {
   const long long tr0 = wg_trace_begin();
-  const int total = *A.flat.count;
-  if (bid == 0 && threadIdx.x == 0 && A.flat.hint) *A.flat.hint = total;
+  // prefix sums of the sub-list counters (one wave, shuffles): flat position v lives in sub-list k with prefix[k] <= v < prefix[k+1]
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x < kFlatSubLists ? A.flat.count[threadIdx.x * kFlatCountStride] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if ((int)threadIdx.x >= off) incl += o;
+    }
+    s_prefix[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) s_prefix[0] = 0;
+  }
+  __syncthreads();
+  const int total = s_prefix[kFlatSubLists];
+  if (bid == 0 && threadIdx.x == 0) {
+    if (A.flat.hint) *A.flat.hint = total;
+    if (A.stats && total) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)total);
+  }
   const int vpw = 256 / lpv;
   const int group = threadIdx.x / lpv, gl = threadIdx.x % lpv;
   const int C = mc.C;
   __half* pool = reinterpret_cast<__half*>(A.L.pool);
   for (int v = bid * vpw + group; v < total; v += nb * vpw) {
-    const uint4 r = A.flat.rec[v];
-    const float Wv = A.flat.w[v];
+    int k = 0;  // binary search over 64 sub-lists: largest k with prefix[k] <= v
+#pragma unroll
+    for (int step = kFlatSubLists / 2; step > 0; step >>= 1)
+      if (s_prefix[k + step] <= v) k += step;
+    const int at = k * A.flat.seg_cap + (v - s_prefix[k]);
+    const uint4 r = A.flat.rec[at];
+    const float Wv = A.flat.w[at];
     const size_t row = (size_t)(r.x & 0x7fffffffu);  // slot * 512 + lin
     feature_voxel<LOW>(A, mc, pool + row * C, (r.x >> 31) != 0u, r.y, __uint_as_float(r.z), __uint_as_float(r.w), Wv, gl, lpv);
   }
@@ -691,16 +718,18 @@ __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, 
 
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
-  feature_flat_role<LOW>(A, mc, lpv, (int)blockIdx.x, (int)gridDim.x);
+  __shared__ int s_prefix[kFlatSubLists + 1];
+  feature_flat_role<LOW>(A, mc, lpv, (int)blockIdx.x, (int)gridDim.x, s_prefix);
 }
 
 // two frames' survivor lists in one launch: the first nb0 workgroups walk list 0, the rest list 1
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_feature_flat2(AppArgs A0, MapConsts mc0, AppArgs A1, MapConsts mc1, int lpv, int nb0) {
+  __shared__ int s_prefix[kFlatSubLists + 1];
   if ((int)blockIdx.x < nb0)
-    feature_flat_role<LOW>(A0, mc0, lpv, (int)blockIdx.x, nb0);
+    feature_flat_role<LOW>(A0, mc0, lpv, (int)blockIdx.x, nb0, s_prefix);
   else
-    feature_flat_role<LOW>(A1, mc1, lpv, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+    feature_flat_role<LOW>(A1, mc1, lpv, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, s_prefix);
 }
 
 template <bool LOW>
@@ -760,7 +789,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
     }
     __syncthreads();
 
-    feature_finish<LOW>(A, mc, S, slot, is_new);
+    feature_finish<LOW>(A, mc, S, slot, is_new, i);
     __syncthreads();
   }
 }
@@ -855,7 +884,7 @@ __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, cons
     if (cslot >= 0 && (c_upd || c_new)) *vox2 = e2;
     if (fslot >= 0 && (f_upd || f_new)) *reinterpret_cast<float2*>(wts + 2 * tid) = w2;
     __syncthreads();
-    if (fslot >= 0) feature_finish<LOW>(Af, mc, S, fslot, f_new);
+    if (fslot >= 0) feature_finish<LOW>(Af, mc, S, fslot, f_new, i);
     __syncthreads();
   }
 }
@@ -982,10 +1011,10 @@ static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C
 
 // balanced phase 2 over the frame's survivor list (enqueued right behind the gating launch)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* lowres,
-                         const FlatList& fl, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                         const FlatList& fl, long long* stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (!fl.rec) return;
   const bool low = lowres != nullptr;
-  const AppArgs Af = make_app_args(L, cam, Rigid{}, feat, nullptr, Scratch{}, nullptr, lowres, &fl);
+  const AppArgs Af = make_app_args(L, cam, Rigid{}, feat, nullptr, Scratch{}, stats, lowres, &fl);
   const int nch = mc.C >> 3;
   const int lpv = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);  // lanes per voxel row
   const int vpw = 256 / lpv;
@@ -1072,11 +1101,11 @@ static int flat_wgs(const MapConsts& mc, const FlatList& fl, int& lpv) {
   return grid8((int)wgs, 16384);
 }
 
-void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, const LayerDev& L1, const MapConsts& mc1,
-                          const FlatList& fl1, const Cam& cam, const __half* feat, const LowRes* lowres, hipStream_t s,
-                          hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const AppArgs A0 = make_app_args(L0, cam, Rigid{}, feat, nullptr, Scratch{}, nullptr, lowres, &fl0);
-  const AppArgs A1 = make_app_args(L1, cam, Rigid{}, feat, nullptr, Scratch{}, nullptr, lowres, &fl1);
+void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, long long* stats0, const LayerDev& L1,
+                          const MapConsts& mc1, const FlatList& fl1, long long* stats1, const Cam& cam, const __half* feat,
+                          const LowRes* lowres, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const AppArgs A0 = make_app_args(L0, cam, Rigid{}, feat, nullptr, Scratch{}, stats0, lowres, &fl0);
+  const AppArgs A1 = make_app_args(L1, cam, Rigid{}, feat, nullptr, Scratch{}, stats1, lowres, &fl1);
   int lpv0, lpv1;
   const int nb0 = flat_wgs(mc0, fl0, lpv0), nb1 = flat_wgs(mc1, fl1, lpv1);
   const dim3 grid(nb0 + nb1);  // (both mappers of one Mapper object hold the same channel count: lpv0 == lpv1)

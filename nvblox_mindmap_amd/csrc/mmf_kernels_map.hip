@@ -928,21 +928,25 @@ __device__ inline void tsdf_new_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, in
   wg_trace_end(tr0, kTrTsdfNew);
 }
 
-// grid: [allocation | mask columns | padding to `lead` (a multiple of 8) | existing-block pairs | new-block waiters]
+// grid: [allocation | new-block waiters | padding to `lead` (a multiple of 8) | existing-block pairs | mask columns]
+// The waiters poll for words of the allocation workgroups of their own launch: producers first, in dispatch order.  They
+// follow them directly -- resident from the start, asleep between polls -- so that a new block is integrated as soon as it
+// is published (at the end of the grid they only got a slot when earlier workgroups retired, and closed the launch ~2 us
+// after the pass over the existing blocks had ended).  The mask columns, short and needed by nobody in this launch, come
+// last: the TSDF pairs take every free slot at once and the columns fill in behind them.
 __global__ __launch_bounds__(256) void k_alloc_tsdf(AllocTsdfArgs A, int lead) {
   __shared__ AllocTsdfLds Q;
   const int b = (int)blockIdx.x;
   if (b < A.alloc_wgs) return alloc_role(A, Q, b);
-  if (b - A.alloc_wgs < A.mask_rows) return mask_cols_role(A, Q, b - A.alloc_wgs);
-  if (b < lead) return;  // padding: the TSDF workgroups start at a multiple of 8 (workgroup -> XCD residue)
+  if (b - A.alloc_wgs < A.P.n_new_wgs) return tsdf_new_role(A, Q, b - A.alloc_wgs);
+  if (b < lead) return;  // padding: the TSDF pairs start at a multiple of 8 (workgroup -> XCD residue)
   const int c = b - lead;
   if (c < A.P.n_pair_wgs) return tsdf_pairs_role(A, Q, c);
-  tsdf_new_role(A, Q, c - A.P.n_pair_wgs);
+  if (c - A.P.n_pair_wgs < A.mask_rows) mask_cols_role(A, Q, c - A.P.n_pair_wgs);
 }
 
-// Two frames in one launch (mmf_integrate_frame_multi).  Workgroups are dispatched in index order and the new-block waiters
-// poll for words of the allocation workgroups of their own launch, so BOTH frames' producers lead the grid and both frames'
-// waiters close it:  [alloc 0 | alloc 1 | mask columns 0 | mask columns 1 | padding | pairs 0 | pairs 1 | new 0 | new 1].
+// Two frames in one launch (mmf_integrate_frame_multi): BOTH frames' producers lead the grid,
+//   [alloc 0 | alloc 1 | new 0 | new 1 | padding | pairs 0 | pairs 1 | mask columns 0 | mask columns 1].
 __global__ __launch_bounds__(256) void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdfArgs A1, int lead) {
   __shared__ AllocTsdfLds Q;
   int b = (int)blockIdx.x;
@@ -950,17 +954,18 @@ __global__ __launch_bounds__(256) void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdf
   b -= A0.alloc_wgs;
   if (b < A1.alloc_wgs) return alloc_role(A1, Q, b);
   b -= A1.alloc_wgs;
-  if (b < A0.mask_rows) return mask_cols_role(A0, Q, b);
-  b -= A0.mask_rows;
-  if (b < A1.mask_rows) return mask_cols_role(A1, Q, b);
+  if (b < A0.P.n_new_wgs) return tsdf_new_role(A0, Q, b);
+  b -= A0.P.n_new_wgs;
+  if (b < A1.P.n_new_wgs) return tsdf_new_role(A1, Q, b);
   if ((int)blockIdx.x < lead) return;
   int c = (int)blockIdx.x - lead;
   if (c < A0.P.n_pair_wgs) return tsdf_pairs_role(A0, Q, c);
   c -= A0.P.n_pair_wgs;
   if (c < A1.P.n_pair_wgs) return tsdf_pairs_role(A1, Q, c);
   c -= A1.P.n_pair_wgs;
-  if (c < A0.P.n_new_wgs) return tsdf_new_role(A0, Q, c);
-  tsdf_new_role(A1, Q, c - A0.P.n_new_wgs);
+  if (c < A0.mask_rows) return mask_cols_role(A0, Q, c);
+  c -= A0.mask_rows;
+  if (c < A1.mask_rows) mask_cols_role(A1, Q, c);
 }
 
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_map)
@@ -1371,7 +1376,13 @@ AllocTsdfArgs make_alloc_tsdf_args(const AllocJob& job, long long* stats, const 
   P.pub = job.pub;
   P.tag = job.pub_tag;
   P.err = job.L.ctr + 3;
-  P.n_pair_wgs = grid_for((hinted(job.L.hint_live, job.L.cap) + 1) / 2, 8192);
+  {
+    // the live count moves by a few dozen blocks per frame and the role strides over the list: 6 % headroom, not the 25 % of
+    // the kernels whose work list can double from one frame to the next (idle workgroups still cost a dispatch slot each)
+    const int v = job.L.hint_live ? *reinterpret_cast<const volatile int*>(job.L.hint_live) : 0;
+    const int n = v > 0 ? (v + v / 16 + 16 < job.L.cap ? v + v / 16 + 16 : job.L.cap) : job.L.cap;
+    P.n_pair_wgs = grid_for((n + 1) / 2, 8192);
+  }
   P.n_new_wgs = kNewBlockWgs;
   P.ctl = job.pub + kPubRec + 3 * (size_t)job.L.cap;
   P.host_err = job.host_err;
@@ -1383,11 +1394,11 @@ AllocTsdfArgs make_alloc_tsdf_args(const AllocJob& job, long long* stats, const 
 
 void launch_alloc_tsdf(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (n == 1) {
-    const int lead = (A[0].alloc_wgs + A[0].mask_rows + 7) & ~7;
-    hipExtLaunchKernelGGL(k_alloc_tsdf, dim3(lead + A[0].P.n_pair_wgs + A[0].P.n_new_wgs), dim3(256), 0, s, ev_start, ev_stop, 0, A[0], lead);
+    const int lead = (A[0].alloc_wgs + A[0].P.n_new_wgs + 7) & ~7;
+    hipExtLaunchKernelGGL(k_alloc_tsdf, dim3(lead + A[0].P.n_pair_wgs + A[0].mask_rows), dim3(256), 0, s, ev_start, ev_stop, 0, A[0], lead);
   } else {
-    const int lead = (A[0].alloc_wgs + A[1].alloc_wgs + A[0].mask_rows + A[1].mask_rows + 7) & ~7;
-    const int total = lead + A[0].P.n_pair_wgs + A[1].P.n_pair_wgs + A[0].P.n_new_wgs + A[1].P.n_new_wgs;
+    const int lead = (A[0].alloc_wgs + A[1].alloc_wgs + A[0].P.n_new_wgs + A[1].P.n_new_wgs + 7) & ~7;
+    const int total = lead + A[0].P.n_pair_wgs + A[1].P.n_pair_wgs + A[0].mask_rows + A[1].mask_rows;
     hipExtLaunchKernelGGL(k_alloc_tsdf2, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1], lead);
   }
 }

@@ -15,12 +15,19 @@ struct LowRes {
 
 // Survivor list of one feature frame: voxels that passed the gate, appended by the gating workgroups and consumed by
 // k_feature_flat.  rec = {is_new << 31 | slot << 9 | voxel, top-left tap pixel, wx, wy}, w = weight before the update.
+// The list is kFlatSubLists sub-lists with a counter each (a block appends to sub-list (pool slot) % kFlatSubLists): one
+// counter for ~800 gating workgroups serialised their appends at the L2 (~20 ns per same-address atomic: the tail of
+// k_app_frame was twice its mean workgroup).  Sub-list k owns records [k * seg_cap, (k + 1) * seg_cap) and counter
+// count[k * kFlatCountStride] (a cache line apart).  k_feature_flat walks the concatenation (prefix sums of the counters).
+constexpr int kFlatSubLists = 64;
+constexpr int kFlatCountStride = 16;
 struct FlatList {
   uint4* rec = nullptr;
   float* w = nullptr;
-  int* count = nullptr;  // device counter, zero before the gating launch
-  int* hint = nullptr;   // pinned host int: last count (sizes the next grid)
-  int cap = 0;
+  int* count = nullptr;  // [kFlatSubLists * kFlatCountStride] device counters, zero before the gating launch
+  int* hint = nullptr;   // pinned host int: last total (sizes the next grid)
+  int cap = 0;           // kFlatSubLists * seg_cap records
+  int seg_cap = 0;
 };
 
 struct ViewGrid {
@@ -183,9 +190,9 @@ AppFrameArgs make_app_frame_args(const LayerDev& Lc, const Cam& cam, const uint8
                                  const FlatList* flat);
 void launch_app_frame2(const AppFrameArgs& F0, const AppFrameArgs& F1, bool low, hipStream_t s, hipEvent_t ev_start = nullptr,
                        hipEvent_t ev_stop = nullptr);
-void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, const LayerDev& L1, const MapConsts& mc1,
-                          const FlatList& fl1, const Cam& cam, const __half* feat, const LowRes* lowres, hipStream_t s,
-                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, long long* stats0, const LayerDev& L1,
+                          const MapConsts& mc1, const FlatList& fl1, long long* stats1, const Cam& cam, const __half* feat,
+                          const LowRes* lowres, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s);
@@ -201,7 +208,8 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
 
 // balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,
-                         const FlatList& fl, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                         const FlatList& fl, long long* stats, hipStream_t s, hipEvent_t ev_start = nullptr,
+                         hipEvent_t ev_stop = nullptr);  // stats: the frame's survivor total is added to stats[8] here
 
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,
