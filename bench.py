@@ -626,7 +626,7 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     return out
 
 
-def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=4, workers=None,
+def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=6, workers=None,
                           vertex_count_range=(10000, 14000)):
     """Is the training step loader-bound?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader keeping the GPUs
     fed, not the 10.9 MB all-reduce.)  A demo in the reference's on-disk layout -- 512x512 rgb + u16 depth PNGs, pose /
@@ -640,7 +640,7 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
 
     from torch.utils.data import DataLoader
 
-    from nvblox_mindmap_amd.data_loading.dataset import MindmapFrameDataset, gpu_unpack, write_synthetic_demo
+    from nvblox_mindmap_amd.data_loading.dataset import DevicePrefetcher, MindmapFrameDataset, write_synthetic_demo
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
     from nvblox_mindmap_amd.training import build_model, build_optimizer, train_one_step
 
@@ -679,19 +679,19 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
         model = build_model(cfg, device=device)
         opt = build_optimizer(model)
 
-        def batches():
+        def batches():  # device batches, copies + GPU-side transforms one step ahead on a side stream
             while True:
-                for b in dl:
-                    if b["rgb_u8"].shape[0] == per_gpu_batch:
+                for b in DevicePrefetcher(dl, device):
+                    if b["rgbs"].shape[0] == per_gpu_batch:
                         yield b
 
         it = batches()
         for _ in range(2):
-            train_one_step(cfg, model, opt, gpu_unpack(next(it), device))
+            train_one_step(cfg, model, opt, next(it))
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
-            train_one_step(cfg, model, opt, gpu_unpack(next(it), device))
+            train_one_step(cfg, model, opt, next(it))
         torch.cuda.synchronize(device)
         fed = steps / (time.perf_counter() - t0)
         del dl, it, model, opt

@@ -118,6 +118,45 @@ def gpu_unpack(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor
     return out
 
 
+class DevicePrefetcher:
+    """Iterates a DataLoader of ``MindmapFrameDataset`` batches and hands out ``gpu_unpack``-ed batches one step ahead: the
+    host -> device copies (pinned memory) and the GPU-side transforms of batch i+1 are issued on a side stream while the
+    training step of batch i runs on the main one.  (At batch 32 a loader batch is ~150 MB: ~6 ms of copies per step that
+    would otherwise sit on the compute stream.)"""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._it = None
+        self._next = None
+
+    def _load(self):
+        try:
+            host = next(self._it)
+        except StopIteration:
+            self._next = None
+            return
+        with torch.cuda.stream(self.stream):
+            self._next = gpu_unpack(host, self.device)
+
+    def __iter__(self):
+        self._it = iter(self.loader)
+        self._load()
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self.stream)
+        batch = self._next
+        for t in batch.values():
+            if torch.is_tensor(t):
+                t.record_stream(main)
+        self._load()
+        return batch
+
+
 def write_synthetic_demo(directory: str, n_frames: int, image_size=(64, 64), feature_dim: int = 16, num_history: int = 3,
                          prediction_horizon: int = 1, ngrippers: int = 1, camera: str = "pov", seed: int = 0,
                          vertex_count_range=(200, 3000)) -> None:

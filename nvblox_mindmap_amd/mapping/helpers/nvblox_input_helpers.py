@@ -3,14 +3,17 @@
 Same function names, argument meaning, returned tuple and assertions as the reference.  Two differences:
   * the reference hard-codes 512x512 in its shape assertions (:55,74); here the image size is whatever the sample holds (the
     layout ``[1, num_cams, ...]`` is asserted all the same), so the 640x480 benchmark stream goes through the same door;
-  * the 7-vector pose -> 4x4 conversion and the back-projection run on the GPU (geometry/transforms.py, HIP
-    ``mmf_backproject_depth``) instead of numpy on the host + batched matmuls.
+  * the back-projection is the HIP kernel (``mmf_backproject_depth``) instead of batched matmuls; the single pose is
+    converted on the host like in the reference (quat2mat in float64, backprojection.py:34-36) and the 4x4 is RETURNED ON THE
+    HOST: every consumer of it takes it there (``integrate_frame`` calls ``camera_pose.cpu()``, nvblox_mapping_helpers.py:208),
+    so the reference's device round trip (host -> device -> ``.cpu()``) and its synchronisation are saved.
 """
 from typing import Dict, List, Tuple
 
 import torch
 
-from ...image_processing.backprojection import get_camera_pointcloud, pose_to_homo
+from ...geometry.transforms import _pose_to_homo_host
+from ...image_processing.backprojection import _backproject_chw
 
 
 def get_nvblox_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index: int
@@ -19,7 +22,7 @@ def get_nvblox_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index:
 
     sample: ``depths`` (1,ncam,H,W) f32 metres; ``intrinsics`` (1,ncam,3,3) f32; ``camera_poses`` (1,ncam,7) f32
     ``[x,y,z,qw,qx,qy,qz]``; ``rgbs`` (1,ncam,3,H,W) f32 in [0,1]; ``segmentation_masks`` (1,ncam,H,W) bool.
-    Returns (depth_frame (H,W) f32, intrinsics (3,3) f32, camera_pose (4,4) f32, rgb (H,W,3) u8 -- ``(rgb * 255)`` TRUNCATED to
+    Returns (depth_frame (H,W) f32, intrinsics (3,3) f32, camera_pose (4,4) f32 ON THE HOST, rgb (H,W,3) u8 -- ``(rgb * 255)`` TRUNCATED to
     uint8 as the reference does (:69), dynamic_mask (H,W) bool, pointcloud (3,H,W) f32 world frame)."""
     num_cams = sample["depths"].shape[1]
     assert camera_index < num_cams
@@ -36,18 +39,21 @@ def get_nvblox_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index:
     assert sample["camera_poses"].shape == torch.Size([1, num_cams, 7]), f"camera_poses shape is {sample['camera_poses'].shape}"
     assert sample["camera_poses"].dtype == torch.float32
     camera_pose = sample["camera_poses"].squeeze(0)[camera_index, ...]
-    camera_pose_homo = pose_to_homo(camera_pose).squeeze(0)
+    camera_pose_homo = torch.from_numpy(_pose_to_homo_host(camera_pose.detach().to("cpu").numpy()))  # (4,4) float32, host
 
     assert sample["rgbs"].shape == torch.Size([1, num_cams, 3, H, W]), f"rgbs shape is {sample['rgbs'].shape}"
     assert sample["rgbs"].dtype == torch.float32
-    assert torch.all(sample["rgbs"] >= 0) and torch.all(sample["rgbs"] <= 1)
+    lo_hi = torch.stack(torch.aminmax(sample["rgbs"])).tolist()  # the reference's two range assertions (:68) with ONE sync
+    assert lo_hi[0] >= 0 and lo_hi[1] <= 1
     rgb = (sample["rgbs"].squeeze(0)[camera_index, ...].permute(1, 2, 0) * 255).to(torch.uint8)
 
     assert sample["segmentation_masks"].shape == torch.Size([1, num_cams, H, W])
     assert sample["segmentation_masks"].dtype == torch.bool
     dynamic_mask = sample["segmentation_masks"].squeeze(0)[camera_index]
 
-    pointcloud = get_camera_pointcloud(intrinsics=intrinsics, depth=depth_frame, position=camera_pose[:3], orientation=camera_pose[3:])
+    # get_camera_pointcloud(intrinsics, depth, position, orientation) (:76-81) with the transform already in hand
+    pointcloud = _backproject_chw(depth_frame.unsqueeze(0), intrinsics.unsqueeze(0),
+                                  camera_pose_homo.to(depth_frame.device, non_blocking=True).unsqueeze(0)).squeeze(0)
     return (depth_frame, intrinsics, camera_pose_homo, rgb, dynamic_mask, pointcloud)
 
 

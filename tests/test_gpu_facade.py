@@ -39,7 +39,7 @@ def test_get_nvblox_inputs_from_sample_matches_the_reference_semantics():
     assert rgb[0, 0].tolist() == [254, 127, 255]
     assert torch.equal(rgb, (sample["rgbs"][0, 1].permute(1, 2, 0) * 255).to(torch.uint8))
     pose7 = sample["camera_poses"][0, 1].cpu().numpy()
-    assert np.abs(Th.cpu().numpy() - IMG.pose_to_homo(pose7)[0]).max() <= 1e-6
+    assert not Th.is_cuda and np.abs(Th.numpy() - IMG.pose_to_homo(pose7)[0]).max() <= 1e-6
     assert np.abs(Th.cpu().numpy() - T).max() <= 1e-5  # quaternion round trip of the stream's pose
     ref = IMG.get_camera_pointcloud(cfg.intrinsics()[None], depth[None], pose7[None, :3], pose7[None, 3:])[0]
     assert np.abs(pcd.cpu().numpy() - ref).max() <= 1e-5

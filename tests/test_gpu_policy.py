@@ -113,6 +113,27 @@ def test_file_fed_training_step(tmp_path):
     assert torch.isfinite(losses[0])
 
 
+def test_device_prefetcher_hands_out_the_same_batches(tmp_path):
+    """DevicePrefetcher (copies + GPU-side transforms of batch i+1 on a side stream) == gpu_unpack batch by batch."""
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.data_loading.dataset import DevicePrefetcher, MindmapFrameDataset, gpu_unpack, write_synthetic_demo
+
+    write_synthetic_demo(str(tmp_path / "demo_00000"), 6, image_size=(64, 64), feature_dim=16, ngrippers=2)
+    ds = MindmapFrameDataset(str(tmp_path), num_vertices=128, seed=0)
+    dl = DataLoader(ds, batch_size=2, shuffle=False, num_workers=0, pin_memory=True)
+    direct = [gpu_unpack(b, "cuda") for b in dl]
+    ahead = []
+    for b in DevicePrefetcher(dl, "cuda"):
+        ahead.append({k: v.clone() for k, v in b.items()})  # consumed on the main stream, like a training step would
+    torch.cuda.synchronize()
+    assert len(ahead) == len(direct) == 3
+    for a, d in zip(ahead, direct):
+        assert set(a) == set(d)
+        for k in a:
+            assert torch.equal(a[k], d[k]), k
+
+
 def test_graph_sampling_matches_eager_sampling():
     """The denoising loop replayed as one HIP graph == the eager loop, bit for bit (same pre-drawn noise); a second call
     with other inputs reuses the captured graph."""
