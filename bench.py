@@ -700,7 +700,8 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
     torch.cuda.empty_cache()
     need = compute_bound_step_per_s * per_gpu_batch
     return {"file_fed_step_per_s": fed, "compute_bound_step_per_s": compute_bound_step_per_s, "loader_only_samples_per_s": loader_sps,
-            "samples_per_s_needed_by_one_gpu": need, "loader_headroom": loader_sps / need, "bound": "loader" if loader_sps < need else "compute",
+            "samples_per_s_needed_by_one_gpu": need, "loader_headroom": loader_sps / need, "file_fed_over_compute_bound": fed / compute_bound_step_per_s,
+            "bound": "loader / host side" if (loader_sps < need or fed < 0.95 * compute_bound_step_per_s) else "compute",
             "workers": workers, "host_threads": ncpu, "per_gpu_batch": per_gpu_batch, "MB_on_disk_per_sample": mb,
             "frames_on_disk": n_frames, "vertices_per_frame": list(vertex_count_range), "dataset_write_s": t_write,
             "note": "one GPU's loader; an 8-GPU node runs 8 such loaders on the same host cores (the reference: 8 x 20 workers)"}
