@@ -247,6 +247,12 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
     nbytes = vox * flat_bytes_per_voxel(C)
     out = {"image": [cfg.height, cfg.width], "feature_channels": C, "frames_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
            "feature_blocks_per_frame": fb, "feature_voxels_updated_per_frame": vox}
+    # whole-frame roofline at this shape, same byte model as the headline (frame_byte_model): here the feature rows dominate
+    n_live = int(mapper.tsdf_layer_view(MAPPER_TO_ID.STATIC).num_allocated_blocks())
+    model = frame_byte_model(cfg, C, n_live, st["tsdf_blocks_updated"] / max(st["depth_frames"], 1), cb, vox)
+    b_frame = sum(model.values())
+    out["whole_frame"] = {"algorithmic_bytes_per_frame": b_frame, "per_launch_bytes": model, "achieved_GBps": b_frame / (dt / steps) / 1e9,
+                          "frac_of_hbm_peak": b_frame / (dt / steps) / HBM_PEAK_BYTES_PER_S, "tsdf_live_blocks": n_live}
     if n:
         out["k_feature_flat_us"] = ms / n * 1e3
         out["k_feature_flat_algorithmic_bytes"] = nbytes
