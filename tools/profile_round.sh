@@ -23,7 +23,7 @@ run_passes() {  # $1 = sub-directory, rest = bench arguments
   find $out -name "*.db" -delete
 }
 if [ "$which" = "bl" ] || [ "$which" = "both" ]; then
-  run_passes bl --only-fusion --no-profile --steps 100 --warmup 10 --repeats 1
+  run_passes bl --only-fusion --no-profile --steps 400 --warmup 10 --repeats 1
 fi
 if [ "$which" = "ref" ] || [ "$which" = "both" ]; then
   run_passes ref --ref-shape-only
