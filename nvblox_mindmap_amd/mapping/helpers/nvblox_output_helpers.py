@@ -23,36 +23,25 @@ def get_vertices_and_features(mapper: Mapper, mapper_id: int, nvblox_mapping_con
     assert vertices.shape[0] != 0, "No vertices found in the mesh."
     assert vertices.is_cuda and features.is_cuda
 
-    aabb_min_m = nvblox_mapping_config.aabb_min_m.to(vertices.device)
-    aabb_max_m = nvblox_mapping_config.aabb_max_m.to(vertices.device)
-    mask = torch.all(torch.logical_and(vertices > aabb_min_m, vertices < aabb_max_m), dim=1)
-    if (sample_vertices and number_of_vertices_to_sample is not None
-            and vertex_sampling_method not in (None, VertexSamplingMethod.NONE)):
-        # Same rows, same order, same RNG draws as the step-by-step form below -- but ONE gather of the N sampled rows instead
-        # of two boolean-mask copies of the whole [V, C] feature matrix (80 MB at V = 26 k, C = 768): the two filters are
-        # combined into one mask over the ORIGINAL rows and the sampled indices are mapped through the kept-row list.
-        used = features if num_excess_features <= 0 else features[..., :-num_excess_features]
-        keep = mask & torch.any(used != 0, dim=1) if remove_zero_features else mask
-        kept = torch.nonzero(keep).squeeze(1)
-        n = int(kept.shape[0])
-        if n > number_of_vertices_to_sample:
-            sel = select_vertex_indices(n, number_of_vertices_to_sample, vertex_sampling_method, vertices.device,
-                                        z=vertices[kept, 2] if vertex_sampling_method == VertexSamplingMethod.LOWEST else None)
-            rows = kept[sel]
-            valid_mask = torch.ones(number_of_vertices_to_sample, device=vertices.device, dtype=torch.bool)
-            return vertices[rows].unsqueeze(0), used[rows].unsqueeze(0), valid_mask.unsqueeze(0)
-    vertices = vertices[mask]
-    features = features[mask]
-    if num_excess_features > 0:
-        features = features[..., :-num_excess_features]
+    # One combined row filter over the ORIGINAL mesh rows, then ONE gather -- same rows, same order and same RNG draws as the
+    # reference's chain of boolean-mask copies (nvblox_output_helpers.py:57-74: AABB, strip the pad channels, drop all-zero
+    # rows), without copying the whole [V, C] feature matrix twice (80 MB at V = 26 k, C = 768).
+    lo = nvblox_mapping_config.aabb_min_m.to(vertices.device)
+    hi = nvblox_mapping_config.aabb_max_m.to(vertices.device)
+    keep = ((vertices > lo) & (vertices < hi)).all(dim=1)  # strict on both sides
+    used = features[..., :-num_excess_features] if num_excess_features > 0 else features
     if remove_zero_features:
-        zero_feature_mask = torch.all(features == 0, dim=1)
-        vertices = vertices[~zero_feature_mask]
-        features = features[~zero_feature_mask]
+        keep &= (used != 0).any(dim=1)
+    rows = torch.nonzero(keep).squeeze(1)
+
     if not sample_vertices:
-        valid_mask = torch.ones(vertices.shape[0], dtype=torch.bool, device=vertices.device).unsqueeze(0)
-    else:
-        vertices, features, valid_mask = sample_to_n_vertices(vertices, features, number_of_vertices_to_sample, vertex_sampling_method)
-        if valid_mask.ndim == 1:
-            vertices, features, valid_mask = vertices.unsqueeze(0), features.unsqueeze(0), valid_mask.unsqueeze(0)
-    return vertices, features, valid_mask
+        # the reference hands back un-batched rows with a [1, V] mask in this case (:76-80)
+        return vertices[rows], used[rows], torch.ones((1, rows.shape[0]), dtype=torch.bool, device=vertices.device)
+
+    n, want = int(rows.shape[0]), number_of_vertices_to_sample
+    if n > want and vertex_sampling_method != VertexSamplingMethod.NONE:
+        z = vertices[rows, 2] if vertex_sampling_method == VertexSamplingMethod.LOWEST else None
+        rows = rows[select_vertex_indices(n, want, vertex_sampling_method, vertices.device, z=z)]
+    # n <= want (pad + mask), NONE, or already exactly `want` rows: sample_to_n_vertices finishes the job without drawing
+    v, f, valid_mask = sample_to_n_vertices(vertices[rows], used[rows], want, vertex_sampling_method)
+    return v.unsqueeze(0), f.unsqueeze(0), valid_mask.unsqueeze(0)

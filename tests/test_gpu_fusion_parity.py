@@ -290,6 +290,13 @@ def test_integrate_frame_fused_matches_oracle(oracle_mod, scale, channels):
         va, fa, _ = get_vertices_and_features(gpu, MAPPER_TO_ID.STATIC, mcfg, remove_zero_features=True, num_excess_features=1,
                                               sample_vertices=False)
         assert va.shape[0] > 300
+        # the un-sampled rows are the reference's chain of boolean-mask copies (nvblox_output_helpers.py:57-74), restated in numpy
+        mesh = gpu.get_feature_mesh(MAPPER_TO_ID.STATIC)
+        mv, mf = mesh.vertices().cpu().numpy(), mesh.vertex_features().cpu().numpy()
+        box = np.all((mv > mcfg.aabb_min_m.numpy()) & (mv < mcfg.aabb_max_m.numpy()), axis=1)
+        mv, mf = mv[box], mf[box][:, :-1]
+        nz = ~np.all(mf == 0, axis=1)
+        assert np.array_equal(va.cpu().numpy(), mv[nz]) and np.array_equal(fa.cpu().numpy(), mf[nz])
         v2, f2, m2 = sample_to_n_vertices(va, fa, 300, method)
         assert torch.equal(v1[0], v2) and torch.equal(f1[0], f2) and torch.equal(m1[0], m2)
 

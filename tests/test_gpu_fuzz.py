@@ -1,0 +1,102 @@
+"""Randomised differential test of the fused frame (mmf_integrate_frame_desc / mmf_integrate_frame_multi) against the CPU
+oracle: every seed draws an image size (incl. sizes that are not multiples of the 16-pixel mask groups or the 8-pixel
+sphere-trace patches), a feature width, a voxel size, the three mask parameters, a decay factor, a camera path and a moving
+dynamic region, then runs the reference's call sequence (nvblox_mapping_helpers.py:79-156) -- single mapper or static +
+dynamic pair -- on the HIP path and the same frames through the oracle's add_depth/add_color/add_feature chain.
+
+Bar: block index lists equal in ORDER, TSDF within 1e-5 abs, feature halves and weights bit-equal, colours bit-equal, masks
+bit-equal.  Seeds are fixed: a failure reproduces."""
+import numpy as np
+import pytest
+import torch
+
+from nvblox_mindmap_amd import synthetic as S
+
+from fusion_common import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(96, 72), (128, 96), (136, 104), (160, 120), (200, 152), (216, 168), (320, 240), (328, 248)]
+CHANNELS = [8, 16, 24, 40, 64, 128]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def draw(seed):
+    r = np.random.default_rng(1000 + seed)
+    w, h = SIZES[r.integers(len(SIZES))]
+    k_depth = int(r.integers(0, 7))
+    # 1 % isolated invalid pixels + an erosion of the valid-depth mask by more than a pixel or two leaves no feature mask at all
+    hole_mode = str(r.choice(["patches", "pixels"])) if k_depth <= 1 else "patches"
+    return dict(
+        w=w, h=h, C=int(CHANNELS[r.integers(len(CHANNELS))]), voxel=float(r.choice([0.01, 0.0125, 0.02])),
+        k_static=int(r.integers(0, 6)), k_dynamic=int(r.integers(0, 4)), k_depth=k_depth, border=int(r.choice([0, 5, 12])),
+        decay=float(r.choice([0.98, 0.8, 0.4])), min_d=float(r.choice([0.1, 0.3, 0.37])), weight=float(r.choice([1.0, 0.5])),
+        frames=[int(i) for i in r.integers(0, 200, size=int(r.integers(3, 7)))], pair=bool(r.integers(2)),
+        rect=[int(v) for v in (r.integers(0, h // 2), r.integers(h // 2, h), r.integers(0, w // 2), r.integers(w // 2, w))],
+        drift=[int(v) for v in r.integers(-5, 6, size=2)], hole_mode=hole_mode)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_matches_oracle(oracle_mod, seed, monkeypatch):
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
+    from oracle import image_ops as IO
+
+    p = draw(seed)
+    print(p)
+    f0 = 525.0 * p["w"] / 640.0
+    cfg = S.StreamConfig(width=p["w"], height=p["h"], fx=f0, fy=f0, cx=p["w"] / 2 - 0.5, cy=p["h"] / 2 - 0.5, hole_mode=p["hole_mode"])
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX", voxel_size_m_override=p["voxel"], measurement_weight_override=p["weight"])
+    mcfg.tsdf_decay_factor = p["decay"]
+    mcfg.static_mask_erosion_iterations, mcfg.dynamic_mask_erosion_iterations = p["k_static"], p["k_dynamic"]
+    mcfg.valid_depth_mask_erosion_iterations, mcfg.feature_mask_border_percent = p["k_depth"], p["border"]
+    mcfg.min_integration_distance_m = p["min_d"]
+    gpu = H.get_nvblox_mapper(mcfg, feature_channels=p["C"])
+    over = dict(voxel_size=p["voxel"], tsdf_decay_factor=p["decay"], appearance_measurement_weight=p["weight"])
+    orcs = [make_oracle(oracle_mod, p["C"], **over) for _ in range(2 if p["pair"] else 1)]
+    monkeypatch.setattr(H, "PAIR_MAPPERS", True)
+
+    class Extractor:
+        def compute(self, rgb):
+            return self.next.unsqueeze(0)
+
+    ex = Extractor()
+    for k, i in enumerate(p["frames"]):
+        f = S.frame(cfg, i, p["C"])
+        dyn = np.zeros(f["depth"].shape, dtype=bool)
+        r0, r1, c0, c1 = p["rect"]
+        dr, dc = p["drift"][0] * k, p["drift"][1] * k
+        dyn[max(r0 + dr, 0): max(r1 + dr, 0), max(c0 + dc, 0): max(c1 + dc, 0)] = True
+        ex.next = dev(f["features"])
+        gpu.decay()
+        out = H.nvblox_integrate(gpu, mcfg, ex, dev(f["depth"]), torch.from_numpy(f["K"]), torch.from_numpy(f["T_W_C"]), dev(f["rgb"]),
+                                 dev(dyn), include_dynamic=p["pair"])
+        jobs = [("STATIC", ~dyn, p["k_static"])] + ([("DYNAMIC", dyn, p["k_dynamic"])] if p["pair"] else [])
+        for orc, (name, mask, k_in) in zip(orcs, jobs):
+            odm, ofm = IO.frame_masks(mask, f["depth"], p["min_d"], k_in, p["k_depth"], p["border"], cfg.height, cfg.width)
+            assert np.array_equal(out[name]["depth_mask"].cpu().numpy().astype(bool), odm), (name, k, "depth mask")
+            assert np.array_equal(out[name]["feature_mask"].cpu().numpy().astype(bool), ofm), (name, k, "feature mask")
+            orc.decay()
+            orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+            orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+            orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+    total = 0
+    for mid, orc in zip((MAPPER_TO_ID.STATIC, MAPPER_TO_ID.DYNAMIC), orcs):
+        t, ti = gpu.tsdf_layer_view(mid).get_all_blocks()
+        assert np.array_equal(ti.cpu().numpy(), orc.block_indices(0)), "TSDF block indices / order"
+        if ti.shape[0]:
+            assert np.abs(t.cpu().numpy() - orc.all_tsdf()).max() <= 1e-5
+        fv, fw, fi = gpu.feature_layer_view(mid).get_all_blocks_split()
+        of, ow = orc.all_features()
+        assert np.array_equal(fi.cpu().numpy(), orc.block_indices(2)), "feature block indices / order"
+        assert np.array_equal(fw.cpu().numpy(), ow), "feature weights"
+        assert np.array_equal(fv.cpu().numpy().view(np.uint16), of.view(np.uint16)), "feature values"
+        rgb, cw, ci = gpu.color_layer_view(mid).get_all_blocks_split()
+        orgb, ocw = orc.all_colors()
+        assert np.array_equal(ci.cpu().numpy(), orc.block_indices(1)), "colour block indices / order"
+        assert np.array_equal(cw.cpu().numpy(), ocw) and np.array_equal(rgb.cpu().numpy(), orgb), "colours"
+        total += int(ti.shape[0])
+    assert total > 0, "the drawn stream integrated nothing"

@@ -79,8 +79,8 @@ def test_backprojection_golden():
         out = get_camera_pointcloud(K, depth, pos, quat)
         ref = g[f"{nm}_out"]
         assert tuple(out.shape) == ref.shape
-        # float32; the reference accumulates in BLAS order: 1e-5 relative to the coordinate scale
-        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        # north_star's tolerance: 1e-5 ABSOLUTE (metres), float32 against the reference's BLAS-ordered accumulation
+        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
         # unbatched call signature
         out1 = get_camera_pointcloud(K[0], depth[0], pos[0], quat[0])
         assert out1.shape == ref.shape[1:] and torch.equal(out1, out[0])
@@ -104,7 +104,7 @@ def test_backprojection_full_size_vs_oracle():
     quat /= np.linalg.norm(quat, axis=1, keepdims=True)
     ref = IO.get_camera_pointcloud(K, depth, pos, quat)
     out = get_camera_pointcloud(cu(K), cu(depth), cu(pos), cu(quat)).cpu().numpy()
-    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 1e-5  # absolute, metres (coordinates reach ~5 m here)
 
 
 def test_feature_upsample_golden():
