@@ -22,6 +22,8 @@ from .fps import farthest_point_sampling, farthest_point_sampling_reference
 from . import layers as layers_mod
 from .layers import AttentionBlock, AttentionStack, FeedForwardBlock, rotary3d, sinusoidal_embedding
 from .loss import LossWeights, compute_loss
+from .relative_conversions import (get_current_pose_from_gripper_history, to_absolute_trajectory, to_relative_gripper_history,
+                                   to_relative_pcd, to_relative_trajectory)
 from .rotations import normalize_pointcloud, normalize_pos, normalize_trajectory, unnormalize_trajectory
 from .scheduler import DDPMScheduler
 
@@ -48,6 +50,7 @@ class DiffuserActorConfig:
     quaternion_format: str = "wxyz"
     rotation_parametrization: str = "6D_from_query"  # reference default (cli/args.py); see rotations.unnormalize_trajectory
     add_external_cam: bool = False
+    relative_action: bool = False           # poses relative to the newest gripper pose (the reference's ``relative``, diffuser_actor.py:46)
     dropout: float = 0.0
     backbone: str = "vit_b16"               # random-init stand-in for the frozen RADIO v2.5-B ("none": rgb tokens are given)
     backbone_matmul_dtype: str = "float32"  # "float16": frozen backbone under fp16 autocast (the reference's TF32 mantissa)
@@ -478,7 +481,18 @@ class DiffuserActor(nn.Module):
         Inference: returns (trajectory (B,L,ngrip,8), head_yaw, losses or None, encoded inputs, None)."""
         cfg, wb = self.cfg, self.workspace_bounds
         closedness = gripper_history[..., 7:8]
-        history = normalize_trajectory(gripper_history[..., :7], wb, cfg.quaternion_format)
+        history = gripper_history[..., :7]
+        current_pose = None
+        if cfg.relative_action:
+            # reference :554-566 -- the point cloud and the history are translated to the newest gripper pose, the target
+            # trajectory is translated and rotated; the map's vertices stay in the world frame there, so they do here
+            current_pose = get_current_pose_from_gripper_history(history)
+            if pcd_obs is not None:
+                pcd_obs = to_relative_pcd(pcd_obs, current_pose)
+            history = to_relative_gripper_history(history, current_pose)
+            if gt_gripper_pred is not None:
+                gt_gripper_pred = to_relative_trajectory(gt_gripper_pred, current_pose)
+        history = normalize_trajectory(history, wb, cfg.quaternion_format)
         if pcd_obs is not None:
             pcd_obs, inside = normalize_pointcloud(pcd_obs, wb)
             pcd_valid_mask = pcd_valid_mask & inside
@@ -499,6 +513,8 @@ class DiffuserActor(nn.Module):
             if gt is not None:
                 losses = compute_loss(traj, head_yaw, gt, gt_open, gt_head_yaw, cfg.loss_weights, cfg.predict_head_yaw)
             traj = unnormalize_trajectory(traj, wb, cfg.quaternion_format, cfg.rotation_parametrization)
+            if cfg.relative_action:
+                traj = to_absolute_trajectory(traj, current_pose)  # reference :509-510
             if head_yaw is not None:
                 head_yaw = head_yaw.clamp(-torch.pi, torch.pi - 1e-6)
             return traj, head_yaw, losses, enc, None

@@ -176,6 +176,70 @@ def test_model_single_forward_cpu_plumbing():
     assert l2 is not None and torch.isfinite(l2[0])
 
 
+def test_relative_conversions_match_reference():
+    """model_utils/relative_conversions.py:15-133, vectors from the imported reference (tests/golden/make_golden_relative.py);
+    the reference's own test is the round trip (tests/test_relative_conversions.py:33)."""
+    from nvblox_mindmap_amd.diffuser_actor import relative_conversions as RC
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "relative_conversions.npz"))
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    assert torch.equal(RC.quaternion_invert(t("qa")), t("q_inv"))
+    assert np.allclose(RC.quaternion_multiply(t("qa"), t("qb")).numpy(), g["q_ab"], atol=1e-6)
+    assert bool((RC.quaternion_multiply(t("qa"), t("qb"))[..., 0] >= 0).all())
+    for tag in ("arm", "humanoid"):
+        cur = RC.get_current_pose_from_gripper_history(t(f"{tag}_history"))
+        assert torch.equal(cur, t(f"{tag}_current"))
+        hist = t(f"{tag}_history")
+        keep = hist.clone()
+        assert np.allclose(RC.to_relative_gripper_history(hist, cur).numpy(), g[f"{tag}_history_rel"], atol=1e-6)
+        assert torch.equal(hist, keep), "the caller's history must not be modified"
+        rel = RC.to_relative_trajectory(t(f"{tag}_trajectory"), cur)
+        assert np.allclose(rel.numpy(), g[f"{tag}_trajectory_rel"], atol=1e-6)
+        back = RC.to_absolute_trajectory(rel, cur)
+        assert np.allclose(back.numpy(), g[f"{tag}_trajectory_back"], atol=1e-6)
+        # the round trip: positions / state exact to float error, rotation equal up to the quaternion's sign
+        tr = g[f"{tag}_trajectory"]
+        assert np.allclose(back[..., :3].numpy(), tr[..., :3], atol=1e-6) and np.array_equal(back[..., 7].numpy(), tr[..., 7])
+        assert np.allclose(np.abs((back[..., 3:7].numpy() * tr[..., 3:7]).sum(-1)), 1.0, atol=1e-5)
+    assert np.allclose(RC.to_relative_pcd(t("pcd"), t("pcd_pose")).numpy(), g["pcd_rel"], atol=1e-6)
+    with pytest.raises(RuntimeError):  # per-gripper poses have no single origin (the reference's view() raises as well)
+        RC.to_relative_pcd(t("pcd"), t("humanoid_current")[:3])
+
+
+def test_relative_action_model_equals_the_absolute_model_on_shifted_inputs():
+    """cfg.relative_action (reference ``relative``, diffuser_actor.py:554-566, :509): the relative model on world inputs ==
+    the absolute model fed the hand-converted history / target, its prediction mapped back by the current pose."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActor
+    from nvblox_mindmap_amd.diffuser_actor import relative_conversions as RC
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import get_workspace_bounds
+    from nvblox_mindmap_amd.training.trainer import unpack_batch
+
+    torch.manual_seed(0)
+    cfg = _tiny_cfg()
+    absolute = DiffuserActor(cfg, get_workspace_bounds("DRILL_IN_BOX")).eval()
+    import copy
+    import dataclasses
+
+    relative = copy.deepcopy(absolute)
+    relative.cfg = dataclasses.replace(cfg, relative_action=True)
+    s = unpack_batch(cfg, _tiny_batch(cfg, 2, 0))
+    cur = RC.get_current_pose_from_gripper_history(s["gripper_history"][..., :7])
+    hist_rel = torch.cat([RC.to_relative_gripper_history(s["gripper_history"][..., :7], cur), s["gripper_history"][..., 7:]], dim=-1)
+    gt_rel = RC.to_relative_trajectory(s["gt_gripper_pred"], cur)
+    args = (None, None, None, s["vertex_features"], s["vertices"], s["vertices_valid_mask"], None)
+    torch.manual_seed(3)
+    la = absolute(gt_rel, s["gt_head_yaw"], *args, hist_rel)[0]
+    torch.manual_seed(3)
+    lr = relative(s["gt_gripper_pred"], s["gt_head_yaw"], *args, s["gripper_history"])[0]
+    assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(la, lr))
+    torch.manual_seed(4)
+    ta, ya = absolute(None, None, *args, hist_rel, run_inference=True)[:2]
+    torch.manual_seed(4)
+    tr, yr = relative(None, None, *args, s["gripper_history"], run_inference=True)[:2]
+    assert torch.allclose(RC.to_absolute_trajectory(ta, cur), tr, atol=1e-6) and torch.allclose(ya, yr, atol=1e-6)
+    assert not torch.allclose(ta, tr, atol=1e-3)
+
+
 def test_model_image_branch_shapes_cpu():
     from nvblox_mindmap_amd.diffuser_actor.model import DiffuserActorConfig, Encoder
 
