@@ -160,6 +160,29 @@ def thread_settings():
     return sorted({t for t in CPU_THREAD_SWEEP if t < ncpu} | {ncpu})
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup's CPU bandwidth quota (a container on a 256-thread host is often capped
+    well below os.cpu_count()), else the affinity mask.  Every CPU-side figure of the line (cpu_baseline, the loader) is
+    bounded by it."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    try:
+        return float(len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return float(os.cpu_count() or 1)
+
+
 def cpu_baseline(cfg, mcfg, frames, channels, n_sample, budget_s=25.0):
     """Same steps on the CPU oracle (test infrastructure used here only as the reported baseline): C + OpenMP (raycast rows,
     TSDF / colour / feature blocks and sphere-traced rows in parallel).  Swept over thread counts -- on a many-core host the
@@ -209,6 +232,7 @@ def cpu_baseline(cfg, mcfg, frames, channels, n_sample, budget_s=25.0):
                   f"best of the thread sweep",
         "thread_sweep_frames_per_s": {str(k): v for k, v in sweep.items()},
         "host_threads": os.cpu_count(),
+        "cpu_quota": cpu_quota(),
     }
 
 
@@ -632,7 +656,7 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     return out
 
 
-def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=6, workers=None,
+def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=12, workers=None,
                           vertex_count_range=(10000, 14000)):
     """Is the training step loader-bound?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader keeping the GPUs
     fed, not the 10.9 MB all-reduce.)  A demo in the reference's on-disk layout -- 512x512 rgb + u16 depth PNGs, pose /
@@ -692,7 +716,9 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
                         yield b
 
         it = batches()
-        for _ in range(2):
+        # untimed: the new epoch's workers have to refill their prefetch queues (each needs ~0.5 s for its first batch); timing
+        # from the first batch on measures that start-up transient, not the steady state
+        for _ in range(8):
             train_one_step(cfg, model, opt, next(it))
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
@@ -707,8 +733,8 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
     need = compute_bound_step_per_s * per_gpu_batch
     return {"file_fed_step_per_s": fed, "compute_bound_step_per_s": compute_bound_step_per_s, "loader_only_samples_per_s": loader_sps,
             "samples_per_s_needed_by_one_gpu": need, "loader_headroom": loader_sps / need, "file_fed_over_compute_bound": fed / compute_bound_step_per_s,
-            "bound": "loader / host side" if (loader_sps < need or fed < 0.95 * compute_bound_step_per_s) else "compute",
-            "workers": workers, "host_threads": ncpu, "per_gpu_batch": per_gpu_batch, "MB_on_disk_per_sample": mb,
+            "bound": "loader (CPU-side decode: see cpu_quota)" if (loader_sps < need or fed < 0.95 * compute_bound_step_per_s) else "compute",
+            "workers": workers, "host_threads": ncpu, "cpu_quota": cpu_quota(), "per_gpu_batch": per_gpu_batch, "MB_on_disk_per_sample": mb,
             "frames_on_disk": n_frames, "vertices_per_frame": list(vertex_count_range), "dataset_write_s": t_write,
             "note": "one GPU's loader; an 8-GPU node runs 8 such loaders on the same host cores (the reference: 8 x 20 workers)"}
 
