@@ -100,3 +100,70 @@ def test_random_configuration_matches_oracle(oracle_mod, seed, monkeypatch):
         assert np.array_equal(cw.cpu().numpy(), ocw) and np.array_equal(rgb.cpu().numpy(), orgb), "colours"
         total += int(ti.shape[0])
     assert total > 0, "the drawn stream integrated nothing"
+
+
+def draw_parameters(seed):
+    r = np.random.default_rng(5000 + seed)
+    w, h = SIZES[r.integers(len(SIZES))]
+    bounds = int(r.choice([0, 1, 2, 2]))  # kUnbounded (hash table, frustum view grid) | kHeightBounds | kBoundingBox (dense table)
+    voxel = float(r.choice([0.02, 0.04])) if bounds != 2 else float(r.choice([0.01, 0.0125, 0.02]))
+    over = dict(
+        voxel_size=voxel, workspace_bounds_type=bounds, max_integration_distance_m=float(r.choice([2.0, 3.0, 5.0])),
+        truncation_distance_vox=float(r.choice([2.0, 4.0, 6.0])), weighting_mode=int(r.integers(2)), max_weight=float(r.choice([5.0, 100.0])),
+        st_subsampling=int(r.choice([2, 4, 4, 8])), raycast_subsampling=int(r.choice([1, 1, 2, 4])),
+        tsdf_decay_factor=float(r.choice([0.98, 0.5, 0.1])), decayed_weight_threshold=float(r.choice([1e-3, 1e-2])),
+        appearance_measurement_weight=float(r.choice([1.0, 0.25])))
+    return dict(w=w, h=h, C=int(CHANNELS[r.integers(len(CHANNELS))]), over=over, frames=[int(i) for i in r.integers(0, 200, size=int(r.integers(2, 6)))],
+                use_mask=bool(r.integers(2)), color=bool(r.integers(2)), decay=bool(r.integers(2)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_parameters_stand_alone_calls_match_oracle(oracle_mod, seed):
+    """The nvblox_torch surface call by call (decay / add_depth_frame / add_color_frame / add_feature_frame, then the feature
+    mesh and a rendered depth image) with integrator parameters off the reference's defaults: truncation distance, weighting
+    mode, maximum weight, sphere-trace and raycast subsampling, workspace bounds type (hash table vs dense table), decay."""
+    from fusion_common import frame_masks, make_mapper
+
+    p = draw_parameters(seed)
+    print(p)
+    f0 = 525.0 * p["w"] / 640.0
+    cfg = S.StreamConfig(width=p["w"], height=p["h"], fx=f0, fy=f0, cx=p["w"] / 2 - 0.5, cy=p["h"] / 2 - 0.5)
+    orc, gpu = make_oracle(oracle_mod, p["C"], **p["over"]), make_mapper(p["C"], **p["over"])
+    for k, i in enumerate(p["frames"]):
+        f = S.frame(cfg, i, p["C"])
+        mask = frame_masks(f["depth"], k) if p["use_mask"] else None
+        T, K = torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"])
+        dmask = None if mask is None else dev(mask)
+        if p["decay"]:
+            orc.decay()
+            gpu.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], mask)
+        gpu.add_depth_frame(dev(f["depth"]), T, K, dmask, 0)
+        if p["color"]:
+            orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], mask)
+            gpu.add_color_frame(dev(f["rgb"]), T, K, mask_frame=dmask, mapper_id=0)
+        orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], mask)
+        gpu.add_feature_frame(dev(f["features"]), T, K, dmask, 0)
+    t, ti = gpu.tsdf_layer_view(0).get_all_blocks()
+    assert np.array_equal(ti.cpu().numpy(), orc.block_indices(0)), "TSDF block indices / order"
+    assert ti.shape[0] > 0
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), orc.all_tsdf().view(np.uint32)), "TSDF values"
+    fv, fw, fi = gpu.feature_layer_view(0).get_all_blocks_split()
+    of, ow = orc.all_features()
+    assert np.array_equal(fi.cpu().numpy(), orc.block_indices(2)) and np.array_equal(fw.cpu().numpy(), ow)
+    assert np.array_equal(fv.cpu().numpy().view(np.uint16), of.view(np.uint16)), "feature values"
+    if p["color"]:
+        rgb, cw, ci = gpu.color_layer_view(0).get_all_blocks_split()
+        orgb, ocw = orc.all_colors()
+        assert np.array_equal(ci.cpu().numpy(), orc.block_indices(1)) and np.array_equal(cw.cpu().numpy(), ocw)
+        assert np.array_equal(rgb.cpu().numpy(), orgb)
+    f = S.frame(cfg, p["frames"][-1], 0)
+    so = orc.render_synthetic_depth(cfg.height, cfg.width, f["T_W_C"], f["K"])
+    sg = gpu.render_synthetic_depth(cfg.height, cfg.width, f["T_W_C"], f["K"]).cpu().numpy()
+    assert np.array_equal(so.view(np.uint32), sg.view(np.uint32)), "sphere-traced depth"
+    ov, ofeat = orc.feature_mesh()
+    gpu.update_feature_mesh(0)
+    mesh = gpu.get_feature_mesh(0)
+    gv, gf = mesh.vertices().cpu().numpy(), mesh.vertex_features().cpu().numpy()
+    assert gv.shape == ov.shape and np.array_equal(gv.view(np.uint32), ov.view(np.uint32)), "mesh vertices"
+    assert np.array_equal(gf.view(np.uint16), ofeat.view(np.uint16)), "mesh vertex features"
