@@ -527,6 +527,13 @@ __device__ __forceinline__ Low8 low_load8(const float* __restrict__ low, int w, 
   r.hi = p[1];
   return r;
 }
+__device__ __forceinline__ Low8 low_ptr8(const float* __restrict__ p) {
+  Low8 r;
+  r.lo = reinterpret_cast<const float4*>(p)[0];
+  r.hi = reinterpret_cast<const float4*>(p)[1];
+  return r;
+}
+__device__ __forceinline__ float f4_at(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 __device__ __forceinline__ float low_at(const Low8& v, int k) {
   return k == 0 ? v.lo.x : k == 1 ? v.lo.y : k == 2 ? v.lo.z : k == 3 ? v.lo.w : k == 4 ? v.hi.x : k == 5 ? v.hi.y : k == 6 ? v.hi.z : v.hi.w;
 }
@@ -541,81 +548,101 @@ __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const
   return o;
 }
 
+// One tap from its own four texels: the rare case of a footprint that straddles a low-res cell border.  A real call, not
+// inlined: inlined four times it doubles the register count of every kernel that updates rows from a low-res map (and halves
+// the rows in flight per SIMD) for the sake of 1 voxel in ~8.
+__device__ __noinline__ half8 low_tap_at(const float* __restrict__ low, int w, int Cin, int c0, LowAxis X, LowAxis Y) {
+  return low_tap(low_load8(low, w, Cin, Y.i0, X.i0, c0), low_load8(low, w, Cin, Y.i0, X.i1, c0), low_load8(low, w, Cin, Y.i1, X.i0, c0),
+                 low_load8(low, w, Cin, Y.i1, X.i1, c0), X, Y);
+}
+
 // One surviving voxel: blend its channel row with the bilinear sample of the feature image (or of the virtual up-sampled
 // low-res map).  `lanes` lanes (gl = 0..lanes-1) share the row in 16-byte pieces.
 template <bool LOW>
 __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts& mc, __half* __restrict__ A, bool is_new, size_t pix,
                                               float wx, float wy, float Wv, int gl, int lanes) {
   const Cam& cam = Aa.cam;
-  const __half* __restrict__ feat = reinterpret_cast<const __half*>(Aa.image);
-  const LowRes LR = Aa.low;
   const int C = mc.C, nch = C >> 3;
   const float wm = mc.app_wm;
   const float inv = 1.0f / (Wv + wm);
-  const __half* t00 = feat + pix * C;
-  const __half* t10 = t00 + C;
-  const __half* t01 = t00 + (size_t)cam.W * C;
-  const __half* t11 = t01 + C;
-      // LOW: the four taps are pixels (px,py) (px+1,py) (px,py+1) (px+1,py+1) of the virtual up-sampled image
-      LowAxis X0, X1, Y0, Y1;
-      bool one_cell = false;
-      if constexpr (LOW) {
-        const int py = (int)(pix / (size_t)cam.W), px = (int)(pix - (size_t)py * cam.W);
-        X0 = low_axis(LR.sw, px, LR.w);
-        X1 = low_axis(LR.sw, px + 1, LR.w);
-        Y0 = low_axis(LR.sh, py, LR.h);
-        Y1 = low_axis(LR.sh, py + 1, LR.h);
-        one_cell = X0.i0 == X1.i0 && X0.i1 == X1.i1 && Y0.i0 == Y1.i0 && Y0.i1 == Y1.i1;  // usual case: 4 loads serve 4 taps
-      }
-      for (int ch = gl; ch < nch; ch += lanes) {
-        half8 a00, a10, a01, a11;
-        if constexpr (LOW) {
-          const int c0 = ch * 8;
-          if (c0 >= LR.cin) {  // zero-padded channels of the feature array
+  // the voxel's piece `ch` (8 channels) blended with the four taps of the footprint
+  auto blend = [&](int ch, const half8& a00, const half8& a10, const half8& a01, const half8& a11) {
+    half8 av;
+    if (is_new) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a00[k] = a10[k] = a01[k] = a11[k] = (_Float16)0.0f;
-          } else if (one_cell) {
-            const Low8 c00 = low_load8(LR.data, LR.w, LR.cin, Y0.i0, X0.i0, c0), c01 = low_load8(LR.data, LR.w, LR.cin, Y0.i0, X0.i1, c0);
-            const Low8 c10 = low_load8(LR.data, LR.w, LR.cin, Y0.i1, X0.i0, c0), c11 = low_load8(LR.data, LR.w, LR.cin, Y0.i1, X0.i1, c0);
-            a00 = low_tap(c00, c01, c10, c11, X0, Y0);
-            a10 = low_tap(c00, c01, c10, c11, X1, Y0);
-            a01 = low_tap(c00, c01, c10, c11, X0, Y1);
-            a11 = low_tap(c00, c01, c10, c11, X1, Y1);
-          } else {
+      for (int k = 0; k < 8; ++k) av[k] = (_Float16)0.0f;
+    } else {
+      av = *reinterpret_cast<const half8*>(A + ch * 8);
+    }
+    half8 o;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const LowAxis& X = (t & 1) ? X1 : X0;
-              const LowAxis& Y = (t & 2) ? Y1 : Y0;
-              const half8 v = low_tap(low_load8(LR.data, LR.w, LR.cin, Y.i0, X.i0, c0), low_load8(LR.data, LR.w, LR.cin, Y.i0, X.i1, c0),
-                                      low_load8(LR.data, LR.w, LR.cin, Y.i1, X.i0, c0), low_load8(LR.data, LR.w, LR.cin, Y.i1, X.i1, c0), X, Y);
-              if (t == 0) a00 = v;
-              else if (t == 1) a10 = v;
-              else if (t == 2) a01 = v;
-              else a11 = v;
-            }
+    for (int k = 0; k < 8; ++k) {
+      const float a = bilin((float)a00[k], (float)a10[k], (float)a01[k], (float)a11[k], wx, wy);
+      const float An = ((float)av[k] * Wv + a * wm) * inv;
+      o[k] = (_Float16)An;
+    }
+    *reinterpret_cast<half8*>(A + ch * 8) = o;
+  };
+  if constexpr (!LOW) {
+    const __half* __restrict__ feat = reinterpret_cast<const __half*>(Aa.image);
+    const __half* t00 = feat + pix * C;
+    const __half* t10 = t00 + C;
+    const __half* t01 = t00 + (size_t)cam.W * C;
+    const __half* t11 = t01 + C;
+    for (int ch = gl; ch < nch; ch += lanes)
+      blend(ch, *reinterpret_cast<const half8*>(t00 + ch * 8), *reinterpret_cast<const half8*>(t10 + ch * 8),
+            *reinterpret_cast<const half8*>(t01 + ch * 8), *reinterpret_cast<const half8*>(t11 + ch * 8));
+  } else {
+    // LOW: the four taps are pixels (px,py) (px+1,py) (px,py+1) (px+1,py+1) of the virtual up-sampled image.  Three loops,
+    // none unrolled: the register count of this kernel decides how many rows are in flight per SIMD (it is latency-bound on
+    // the L2-resident low-res map), and one loop with every case inside cost 170 VGPRs = 2 waves per SIMD.
+    const LowRes LR = Aa.low;
+    const int py = (int)(pix / (size_t)cam.W), px = (int)(pix - (size_t)py * cam.W);
+    const LowAxis X0 = low_axis(LR.sw, px, LR.w), X1 = low_axis(LR.sw, px + 1, LR.w);
+    const LowAxis Y0 = low_axis(LR.sh, py, LR.h), Y1 = low_axis(LR.sh, py + 1, LR.h);
+    const int nin = LR.cin >> 3 < nch ? LR.cin >> 3 : nch;  // pieces that exist in the map; the rest are the zero pad channels
+    const bool one_cell = X0.i0 == X1.i0 && X0.i1 == X1.i1 && Y0.i0 == Y1.i0 && Y0.i1 == Y1.i1;
+    if (one_cell) {  // usual case: the footprint lies inside one low-res cell, 4 texels serve 4 taps
+      const float* r0 = LR.data + ((size_t)Y0.i0 * LR.w) * LR.cin;
+      const float* r1 = LR.data + ((size_t)Y0.i1 * LR.w) * LR.cin;
+      const float *p00 = r0 + (size_t)X0.i0 * LR.cin, *p01 = r0 + (size_t)X0.i1 * LR.cin;
+      const float *p10 = r1 + (size_t)X0.i0 * LR.cin, *p11 = r1 + (size_t)X0.i1 * LR.cin;
+#pragma unroll 1
+      for (int ch = gl; ch < nin; ch += lanes) {
+        const int c0 = ch * 8;
+        half8 t00, t10, t01, t11;
+        // four channels at a time: 4 x 16 B of texels live instead of 4 x 32 B (same arithmetic as low_tap, channel by channel)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 q00 = reinterpret_cast<const float4*>(p00 + c0)[h], q01 = reinterpret_cast<const float4*>(p01 + c0)[h];
+          const float4 q10 = reinterpret_cast<const float4*>(p10 + c0)[h], q11 = reinterpret_cast<const float4*>(p11 + c0)[h];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float a = f4_at(q00, k), b = f4_at(q01, k), c = f4_at(q10, k), d = f4_at(q11, k);
+            t00[4 * h + k] = (_Float16)(Y0.l0 * (X0.l0 * a + X0.l1 * b) + Y0.l1 * (X0.l0 * c + X0.l1 * d));
+            t10[4 * h + k] = (_Float16)(Y0.l0 * (X1.l0 * a + X1.l1 * b) + Y0.l1 * (X1.l0 * c + X1.l1 * d));
+            t01[4 * h + k] = (_Float16)(Y1.l0 * (X0.l0 * a + X0.l1 * b) + Y1.l1 * (X0.l0 * c + X0.l1 * d));
+            t11[4 * h + k] = (_Float16)(Y1.l0 * (X1.l0 * a + X1.l1 * b) + Y1.l1 * (X1.l0 * c + X1.l1 * d));
           }
-        } else {
-          a00 = *reinterpret_cast<const half8*>(t00 + ch * 8);
-          a10 = *reinterpret_cast<const half8*>(t10 + ch * 8);
-          a01 = *reinterpret_cast<const half8*>(t01 + ch * 8);
-          a11 = *reinterpret_cast<const half8*>(t11 + ch * 8);
+          if (h == 0) __builtin_amdgcn_sched_barrier(0);
         }
-        half8 av;
-        if (is_new) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) av[k] = (_Float16)0.0f;
-        } else {
-          av = *reinterpret_cast<const half8*>(A + ch * 8);
-        }
-        half8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float a = bilin((float)a00[k], (float)a10[k], (float)a01[k], (float)a11[k], wx, wy);
-          const float An = ((float)av[k] * Wv + a * wm) * inv;
-          o[k] = (_Float16)An;
-        }
-        *reinterpret_cast<half8*>(A + ch * 8) = o;
+        blend(ch, t00, t10, t01, t11);
       }
+    } else {  // the footprint straddles a cell border (1 in ~8 at 16x up-sampling): one tap at a time, each a call
+#pragma unroll 1
+      for (int ch = gl; ch < nin; ch += lanes) {
+        const int c0 = ch * 8;
+        const half8 a00 = low_tap_at(LR.data, LR.w, LR.cin, c0, X0, Y0), a10 = low_tap_at(LR.data, LR.w, LR.cin, c0, X1, Y0),
+                    a01 = low_tap_at(LR.data, LR.w, LR.cin, c0, X0, Y1), a11 = low_tap_at(LR.data, LR.w, LR.cin, c0, X1, Y1);
+        blend(ch, a00, a10, a01, a11);
+      }
+    }
+    half8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (_Float16)0.0f;
+#pragma unroll 1
+    for (int ch = nin + gl; ch < nch; ch += lanes) blend(ch, z, z, z, z);
+  }
 }
 
 // Phase 2 inside the workgroup that gated the block: 32 groups of 8 lanes walk the survivor list in LDS.
@@ -667,12 +694,18 @@ __device__ inline void feature_zero_fill(const AppArgs& A, const MapConsts& mc, 
 }
 
 // tail of both gating bodies once the survivor list of the block is complete in LDS (callers synchronised before)
-template <bool LOW>
+// PUBLISH_ONLY: the caller guarantees a survivor list (A.flat.rec != nullptr), so the in-workgroup row update is not even
+// compiled in -- it is the register-hungriest code of the gating kernels (LOW: 175 VGPRs = 2 waves per SIMD, against 5).
+template <bool LOW, bool PUBLISH_ONLY = false>
 __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new, int cand) {
-  // statistics: with the survivor list the frame's total is added once by k_feature_flat (one more same-address atomic per
-  // gating workgroup otherwise)
-  if (threadIdx.x == 0 && A.stats && S.n && !A.flat.rec) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
-  if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW>(A, mc, S, slot, is_new);
+  if constexpr (PUBLISH_ONLY) {
+    feature_publish(A, S, slot, is_new, cand);
+  } else {
+    // statistics: with the survivor list the frame's total is added once by k_feature_flat (one more same-address atomic per
+    // gating workgroup otherwise)
+    if (threadIdx.x == 0 && A.stats && S.n && !A.flat.rec) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
+    if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW>(A, mc, S, slot, is_new);
+  }
   if (is_new) feature_zero_fill(A, mc, S, slot);
 }
 
@@ -817,7 +850,7 @@ __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Af
 // frame both layers see the same camera and the same candidate list (the allocation jobs read the same flags), so the
 // projection, the two bilinear footprints and the occlusion test against the synthetic depth are evaluated once; only
 // the masks (depth mask for colour, eroded feature mask for features) differ.  Voxel order: thread t owns voxels 2t, 2t+1.
-template <bool LOW>
+template <bool LOW, bool PUB = false>
 __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, const MapConsts& mc, const float* __restrict__ synth,
                                       int Ws, int Hs, int bid, int nb, FeatLds& S) {
   const Cam& cam = Ac.cam;
@@ -884,17 +917,18 @@ __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, cons
     if (cslot >= 0 && (c_upd || c_new)) *vox2 = e2;
     if (fslot >= 0 && (f_upd || f_new)) *reinterpret_cast<float2*>(wts + 2 * tid) = w2;
     __syncthreads();
-    if (fslot >= 0) feature_finish<LOW>(Af, mc, S, fslot, f_new, i);
+    if (fslot >= 0) feature_finish<LOW, PUB>(Af, mc, S, fslot, f_new, i);
     __syncthreads();
   }
 }
 
-template <bool LOW>
+// PUB: the frame has a survivor list (every fused frame): publish-only gating, independent of LOW (launched as <false, true>)
+template <bool LOW, bool PUB>
 __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                   int Hs) {
   __shared__ FeatLds S;
   const long long tr0 = wg_trace_begin();
-  app_frame_body<LOW>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+  app_frame_body<LOW, PUB>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 #ifdef MMF_WG_TRACE
   {  // diagnostics: survivors of the (last) block and whether it was new ride in the record id
     const int n = *Acol.sc.cand_count;
@@ -908,14 +942,14 @@ __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, 
 }
 
 // two frames' candidate lists in one launch (mmf_integrate_frame_multi)
-template <bool LOW>
+template <bool LOW, bool PUB>
 __global__ __launch_bounds__(256) void k_app_frame2(AppFrameArgs F0, AppFrameArgs F1, int nb0) {
   __shared__ FeatLds S;
   const long long tr0 = wg_trace_begin();
   if ((int)blockIdx.x < nb0)
-    app_frame_body<LOW>(F0.Ac, F0.Af, F0.mc, F0.synth, F0.Ws, F0.Hs, (int)blockIdx.x, nb0, S);
+    app_frame_body<LOW, PUB>(F0.Ac, F0.Af, F0.mc, F0.synth, F0.Ws, F0.Hs, (int)blockIdx.x, nb0, S);
   else
-    app_frame_body<LOW>(F1.Ac, F1.Af, F1.mc, F1.synth, F1.Ws, F1.Hs, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, S);
+    app_frame_body<LOW, PUB>(F1.Ac, F1.Af, F1.mc, F1.synth, F1.Ws, F1.Hs, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, S);
   wg_trace_end(tr0, kTrAppFrame);
 }
 
@@ -1054,10 +1088,12 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                         ccam.cx == fcam.cx && ccam.cy == fcam.cy;
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
-    if (low)
-      hipExtLaunchKernelGGL(k_app_frame<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
+    if (flat && flat->rec)
+      hipExtLaunchKernelGGL((k_app_frame<false, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
+    else if (low)
+      hipExtLaunchKernelGGL((k_app_frame<true, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
     else
-      hipExtLaunchKernelGGL(k_app_frame<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
+      hipExtLaunchKernelGGL((k_app_frame<false, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
   } else {
     const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
     if (low)
@@ -1085,10 +1121,12 @@ AppFrameArgs make_app_frame_args(const LayerDev& Lc, const Cam& cam, const uint8
 
 void launch_app_frame2(const AppFrameArgs& F0, const AppFrameArgs& F1, bool low, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const dim3 grid(F0.nb + F1.nb);
-  if (low)
-    hipExtLaunchKernelGGL(k_app_frame2<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
+  if (F0.Af.flat.rec && F1.Af.flat.rec)
+    hipExtLaunchKernelGGL((k_app_frame2<false, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
+  else if (low)
+    hipExtLaunchKernelGGL((k_app_frame2<true, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
   else
-    hipExtLaunchKernelGGL(k_app_frame2<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
+    hipExtLaunchKernelGGL((k_app_frame2<false, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
 }
 
 static int flat_wgs(const MapConsts& mc, const FlatList& fl, int& lpv) {
