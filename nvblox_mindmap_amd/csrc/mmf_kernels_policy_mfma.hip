@@ -523,14 +523,9 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(OutFfnArgs A, int L, long 
 // Two independent stacks of identical shape (the rotation and the position stack of the diffusion head) in ONE launch:
 // blockIdx.z / the upper half of blockIdx.x selects the stack's operands.  Activations and head-major outputs are stack-major
 // ([2, B, ...]), so the attention kernel sees the pair as a batch of 2 B.
-__global__ __launch_bounds__(256) void k_qkv_heads2(const float* __restrict__ x0, const float* __restrict__ x1, QkvArgs Q0, QkvArgs Q1,
-                                                   int L, int L16) {
-  const bool second = blockIdx.z != 0;
-  const float* x = second ? x1 : x0;
-  const QkvArgs& Q = second ? Q1 : Q0;
+__device__ __forceinline__ void qkv_heads_body(const float* __restrict__ x, const QkvArgs& Q, int L, int L16, int role) {
   const int tpb = L16 / 16;
   const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
-  const int role = (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
   float a[kKSteps];
   const int tok = l0 + j;
@@ -538,6 +533,17 @@ __global__ __launch_bounds__(256) void k_qkv_heads2(const float* __restrict__ x0
   load_row_share(x + ((size_t)b * L + min(tok, L - 1)) * kD, s, ok, a);
   if (role == 0 && Q.ss != nullptr && ok) modulate_share(Q.ss, b, s, a);
   qkv_role_tile(a, role, Q, b, l0, L, L16, w, j, s);
+}
+
+// (The stack's argument block is chosen by a BRANCH around two calls, not by `second ? Q1 : Q0`: a reference picked at run
+// time makes the compiler copy the 168-byte block to scratch memory and read every pointer back from there.)
+__global__ __launch_bounds__(256) void k_qkv_heads2(const float* __restrict__ x0, const float* __restrict__ x1, QkvArgs Q0, QkvArgs Q1,
+                                                   int L, int L16) {
+  const int role = (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
+  if (blockIdx.z != 0)
+    qkv_heads_body(x1, Q1, L, L16, role);
+  else
+    qkv_heads_body(x0, Q0, L, L16, role);
 }
 
 __global__ __launch_bounds__(256) void k_out_ffn_mfma2(OutFfnArgs A0, OutFfnArgs A1, int L, long long tokens, int tiles) {
