@@ -466,7 +466,8 @@ def run_closed_loop(device, steps=5):
     mapper.decay() + update_reconstruction_from_sample (input helpers: pose 7-vector -> 4x4, rgb float -> u8, back-projection;
     then the fused RGB-D/feature frame, 512x512, 768 feature channels) -> get_nvblox_model_inputs (surface vertices + features
     sampled to 2048) -> policy inference (encoder + 100 denoising steps, fused ops + HIP graph).  The image backbone runs once,
-    inside the policy encoder (random-init ViT-B/16); the mapper's extractor hands the stream's pre-computed feature image over."""
+    inside the policy encoder (random-init ViT-B/16); the mapper's extractor hands the stream's pre-computed backbone output
+    (16x16x768) over, which the fused frame samples itself (mapping/helpers/nvblox_mapping_helpers.py: compute_lowres)."""
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
     from nvblox_mindmap_amd.image_processing.backprojection import get_camera_pointcloud
     from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
@@ -476,11 +477,14 @@ def run_closed_loop(device, steps=5):
     cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
     frames = build_stream(cfg, 4, C, device)
 
-    class Extractor:
-        next = None
+    class Extractor:  # the DNN is out of scope: hands the stream's pre-computed backbone output (or feature image) over
+        next = low = None
 
         def compute(self, rgb):
             return self.next.unsqueeze(0)
+
+        def compute_lowres(self, rgb):  # the hand-over nvblox_integrate prefers: the 16x16x768 map, sampled inside the kernel
+            return self.low, (cfg.height, cfg.width)
 
         def num_excess_features(self):
             return 0
@@ -508,7 +512,7 @@ def run_closed_loop(device, steps=5):
 
     def control_step(i, record):
         fr, smp = frames[i % 4], samples[i % 4]
-        ex.next = fr["features"]
+        ex.next, ex.low = fr["features"], fr["lowres"]
         t = [time.perf_counter()]
         facade.decay()
         facade.update_reconstruction_from_sample(smp, "pov")

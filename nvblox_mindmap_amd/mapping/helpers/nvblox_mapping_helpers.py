@@ -22,6 +22,11 @@ from ..nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
 # nvblox_integrate(include_dynamic=True): both mappers' frames as roles of the SAME five launches, one native call
 # (Mapper.integrate_frame_multi).  On by default; MMF_PAIR_MAPPERS=0 issues the two integrate_frame calls one after the other.
 PAIR_MAPPERS = os.environ.get("MMF_PAIR_MAPPERS", "1") != "0"
+# A feature extractor may offer ``compute_lowres(rgb) -> (low [h, w, C] float32, (Hf, Wf))`` next to the reference's
+# ``compute``: the backbone's own output and the size ``compute`` would resize it to.  nvblox_integrate then hands the LOW-RES
+# map to the native call, which evaluates f16(bilinear(low)) at each tap itself -- bit-identical to integrating compute()'s
+# image (tests/test_gpu_facade.py), without ever materialising it (403 MB at 512x512x768).  MMF_LOWRES_FEATURES=0: always compute().
+LOWRES_FEATURES = os.environ.get("MMF_LOWRES_FEATURES", "1") != "0"
 
 class _IntegrationImages(dict):
     """The images dictionary integrate_frame returns (:263-271).  Entries only the visualiser consumes are computed on
@@ -165,11 +170,55 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
     """Extract features and integrate the frame into the STATIC (and optionally DYNAMIC) mapper (:79-159)."""
     assert dynamic_mask.dtype == torch.bool
     cfg = nvblox_mapping_config
-    with Timer("nvblox_mapper/compute_features"):
-        feature_frame = feature_extractor.compute(rgb=rgb.unsqueeze(0)).squeeze(0)
     out = {}
     # static_mask = ~dynamic_mask (:116-117): the native call reads the dynamic mask inverted instead
     use_dyn = bool(cfg.use_dynamic_mask)
+
+    def jobs_for(masks_static, masks_dynamic):
+        jobs = [{"mapper_id": MAPPER_TO_ID.STATIC, "input_mask": masks_static, "invert_input_mask": use_dyn,
+                 "input_mask_erosion_iterations": cfg.static_mask_erosion_iterations,
+                 "valid_depth_mask_erosion_iterations": cfg.valid_depth_mask_erosion_iterations}]
+        if include_dynamic:
+            jobs.append({"mapper_id": MAPPER_TO_ID.DYNAMIC, "input_mask": masks_dynamic, "invert_input_mask": False,
+                         "input_mask_erosion_iterations": cfg.dynamic_mask_erosion_iterations,
+                         "valid_depth_mask_erosion_iterations": cfg.valid_depth_mask_erosion_iterations})
+        return jobs
+
+    def images_of(jobs, masks, feature_frame, lazy_feature_frame=None):
+        for job, (dm_u8, fm) in zip(jobs, masks):
+            dm = dm_u8.view(torch.bool)
+            items = {"depth_frame": depth_frame, "depth_mask": dm, "rgb_mask": dm, "feature_mask": fm}
+            lazy = {}
+            if lazy_feature_frame is not None:
+                lazy["feature_frame"] = lazy_feature_frame
+            else:
+                items["feature_frame"] = feature_frame
+            im = job["input_mask"]
+            if job["invert_input_mask"]:
+                lazy["input_mask"] = lambda im=im: ~im
+            else:
+                items["input_mask"] = im
+            out[MAPPER_TO_ID(job["mapper_id"]).name] = _IntegrationImages(items, rgb, lazy)
+        return out
+
+    static_in = dynamic_mask if use_dyn else torch.ones_like(dynamic_mask)
+    if LOWRES_FEATURES and depth_frame.is_cuda and hasattr(feature_extractor, "compute_lowres"):
+        with Timer("nvblox_mapper/compute_features"):
+            low, feature_size = feature_extractor.compute_lowres(rgb=rgb.unsqueeze(0))
+        if low is not None and tuple(feature_size) == tuple(depth_frame.shape):
+            # (the feature image of the returned dictionaries -- read by the visualiser only -- is materialised on first access)
+            jobs = jobs_for(static_in, dynamic_mask)
+            if len(jobs) == 1:  # (the single-frame entry point: less host work than a one-element job list)
+                masks = [mapper.integrate_frame_lowres(depth_frame, rgb, low, static_in, camera_pose, intrinsics,
+                                                       cfg.min_integration_distance_m, cfg.static_mask_erosion_iterations,
+                                                       cfg.valid_depth_mask_erosion_iterations, cfg.feature_mask_border_percent,
+                                                       MAPPER_TO_ID.STATIC, invert_input_mask=use_dyn)]
+            else:
+                masks = mapper.integrate_frame_multi(depth_frame, rgb, None, camera_pose, intrinsics, cfg.min_integration_distance_m,
+                                                     cfg.feature_mask_border_percent, jobs, lowres_features=low)
+            return images_of(jobs, masks, None, lambda: feature_extractor.compute(rgb=rgb.unsqueeze(0)).squeeze(0))
+    with Timer("nvblox_mapper/compute_features"):
+        feature_frame = feature_extractor.compute(rgb=rgb.unsqueeze(0)).squeeze(0)
 
     def static_half():
         return integrate_frame(
@@ -191,26 +240,10 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
         # Both mappers in ONE native call: the two frames are roles of the same five launches (one latency chain, one enqueue;
         # bit-identical to the two integrate_frame calls below).
         feat16 = feature_frame if feature_frame.dtype == torch.float16 else feature_frame.to(torch.float16)
-        jobs = [
-            {"mapper_id": MAPPER_TO_ID.STATIC, "input_mask": dynamic_mask if use_dyn else torch.ones_like(dynamic_mask),
-             "invert_input_mask": use_dyn, "input_mask_erosion_iterations": cfg.static_mask_erosion_iterations,
-             "valid_depth_mask_erosion_iterations": cfg.valid_depth_mask_erosion_iterations},
-            {"mapper_id": MAPPER_TO_ID.DYNAMIC, "input_mask": dynamic_mask, "invert_input_mask": False,
-             "input_mask_erosion_iterations": cfg.dynamic_mask_erosion_iterations,
-             "valid_depth_mask_erosion_iterations": cfg.valid_depth_mask_erosion_iterations},
-        ]
+        jobs = jobs_for(static_in, dynamic_mask)
         masks = mapper.integrate_frame_multi(depth_frame, rgb, feat16, camera_pose, intrinsics, cfg.min_integration_distance_m,
                                              cfg.feature_mask_border_percent, jobs)
-        for job, (dm_u8, fm) in zip(jobs, masks):
-            dm = dm_u8.view(torch.bool)
-            items = {"depth_frame": depth_frame, "depth_mask": dm, "rgb_mask": dm, "feature_frame": feature_frame, "feature_mask": fm}
-            im = job["input_mask"]
-            if job["invert_input_mask"]:
-                out[MAPPER_TO_ID(job["mapper_id"]).name] = _IntegrationImages(items, rgb, {"input_mask": lambda im=im: ~im})
-            else:
-                items["input_mask"] = im
-                out[MAPPER_TO_ID(job["mapper_id"]).name] = _IntegrationImages(items, rgb)
-        return out
+        return images_of(jobs, masks, feature_frame)
     out[MAPPER_TO_ID.STATIC.name] = static_half()
     if include_dynamic:
         out[MAPPER_TO_ID.DYNAMIC.name] = dynamic_half()

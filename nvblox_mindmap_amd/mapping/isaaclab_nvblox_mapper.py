@@ -46,15 +46,28 @@ class BackboneFeatureExtractor:
         self.input_size = input_size
         self._channels = None
 
-    @torch.no_grad()
-    def compute(self, rgb: torch.Tensor) -> torch.Tensor:
+    def _backbone_output(self, rgb: torch.Tensor) -> torch.Tensor:
         assert rgb.ndim == 4 and rgb.shape[0] == 1 and rgb.shape[-1] == 3
         x = rgb.permute(0, 3, 1, 2).to(torch.float32) / 255.0
         if self.input_size is not None and tuple(x.shape[-2:]) != tuple(self.input_size):
             x = F.interpolate(x, self.input_size, mode="bilinear", align_corners=False)
         low = self.backbone(x)
         self._channels = int(low.shape[1])
-        return upsample_features(low[0], self.desired_output_size, self.pad_to_channels).unsqueeze(0)
+        return low[0]
+
+    @torch.no_grad()
+    def compute(self, rgb: torch.Tensor) -> torch.Tensor:
+        return upsample_features(self._backbone_output(rgb), self.desired_output_size, self.pad_to_channels).unsqueeze(0)
+
+    @torch.no_grad()
+    def compute_lowres(self, rgb: torch.Tensor):
+        """Extension read by ``nvblox_integrate``: (the backbone's own output as [h, w, C] float32, the size ``compute`` would
+        resize it to).  The native integration samples the low-res map itself -- same result as integrating ``compute(rgb)``,
+        bit for bit, without the [Hf, Wf, C_pad] float16 image ever existing."""
+        low = self._backbone_output(rgb)
+        if low.shape[0] % 8 != 0:  # the fused path moves 8 channels at a time
+            return None, self.desired_output_size
+        return low.permute(1, 2, 0).to(torch.float32).contiguous(), self.desired_output_size
 
     def num_excess_features(self) -> int:
         return 0 if self._channels is None else self.pad_to_channels - self._channels

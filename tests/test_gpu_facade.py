@@ -133,3 +133,57 @@ def test_facade_closed_loop_at_the_reference_shape_matches_the_oracle():
     assert traj.shape == (1, pcfg.prediction_horizon, pcfg.ngrippers, 8) and torch.isfinite(traj).all() and torch.isfinite(head_yaw).all()
     facade.clear()
     assert m.tsdf_layer_view(0).num_allocated_blocks() == 0
+
+
+@pytest.mark.parametrize("include_dynamic", [False, True])
+def test_facade_hands_the_backbone_output_to_the_native_call(include_dynamic, monkeypatch):
+    """BackboneFeatureExtractor.compute_lowres + nvblox_integrate: the backbone's 16x16 output goes to the native call, which
+    samples it itself -- the maps are the ones built from compute()'s up-sampled image, bit for bit (static and dynamic mapper),
+    and the feature image of the returned dictionaries still is that image (materialised on access)."""
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import BackboneFeatureExtractor, IsaacLabNvbloxMapper
+
+    C, size = 64, 256
+    cfg = S.StreamConfig(width=size, height=size, fx=293.2, fy=293.2, cx=127.5, cy=127.5, hole_mode="patches")
+    torch.manual_seed(0)
+    backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 48, 16, stride=16), torch.nn.Tanh()).cuda()  # 48 channels: 16 are padding
+    calls = {"lowres": 0, "compute": 0}
+
+    class Counting(BackboneFeatureExtractor):
+        def compute(self, rgb):
+            calls["compute"] += 1
+            return super().compute(rgb)
+
+        def compute_lowres(self, rgb):
+            calls["lowres"] += 1
+            return super().compute_lowres(rgb)
+
+    def build():
+        ex = Counting(backbone, (size, size), C)
+        return IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
+                                    include_dynamic=include_dynamic), ex
+
+    (low_facade, low_ex), (img_facade, img_ex) = build(), build()
+    for k, idx in enumerate((0, 6, 12, 40)):
+        dyn = np.zeros((size, size), dtype=bool)
+        dyn[60 + 5 * k: 150, 80: 200 - 7 * k] = True
+        sample, _, _ = make_sample(cfg, idx, "cuda", dynamic=dyn)
+        for facade, lowres in ((low_facade, True), (img_facade, False)):
+            monkeypatch.setattr(H, "LOWRES_FEATURES", lowres)
+            facade.decay()
+            facade.update_reconstruction_from_sample(sample, "pov")
+    assert calls == {"lowres": 4, "compute": 4}  # the low-res facade never built the image ...
+    low_images = low_facade.last_nvblox_integration_images["pov"]["STATIC"]
+    img_images = img_facade.last_nvblox_integration_images["pov"]["STATIC"]
+    assert torch.equal(low_images["feature_frame"], img_images["feature_frame"]) and calls["compute"] == 5  # ... until asked for it
+    assert low_images["feature_frame"].shape == (size, size, C) and low_ex.num_excess_features() == 16
+    assert torch.equal(low_images["feature_mask"], img_images["feature_mask"])
+    for mid in ((0, 1) if include_dynamic else (0,)):
+        a, b = low_facade.mapper, img_facade.mapper
+        for x, y in zip(a.tsdf_layer_view(mid).get_all_blocks(), b.tsdf_layer_view(mid).get_all_blocks()):
+            assert torch.equal(x, y)
+        fa, fb = a.feature_layer_view(mid).get_all_blocks_split(), b.feature_layer_view(mid).get_all_blocks_split()
+        assert fa[2].shape[0] > 20 and all(torch.equal(x, y) for x, y in zip(fa, fb))
+        assert float(fa[0].float().abs().max()) > 0
+        ca, cb = a.color_layer_view(mid).get_all_blocks_split(), b.color_layer_view(mid).get_all_blocks_split()
+        assert all(torch.equal(x, y) for x, y in zip(ca, cb))
