@@ -167,3 +167,129 @@ def test_random_parameters_stand_alone_calls_match_oracle(oracle_mod, seed):
     gv, gf = mesh.vertices().cpu().numpy(), mesh.vertex_features().cpu().numpy()
     assert gv.shape == ov.shape and np.array_equal(gv.view(np.uint32), ov.view(np.uint32)), "mesh vertices"
     assert np.array_equal(gf.view(np.uint16), ofeat.view(np.uint16)), "mesh vertex features"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path):
+    """A random walk over the Mapper's entry points on a two-mapper Mapper -- decay, the fused frame, the same frame call by
+    call, the fused frame from a low-res feature map, both mappers in one call, clear, mesh update, save + load into a NEW
+    mapper that carries on, point queries, depth rendering -- against two oracle maps driven with the equivalent calls.  What
+    this exercises is the STATE between calls: pending lazy decay, grid / hand-over tags, slot reuse after clear and
+    deallocation, hints sized by earlier frames, a restored map continuing."""
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+    from nvblox_mindmap_amd.image_processing import upsample_features
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg
+    from nvblox_mindmap_amd.nvblox_torch.mapper import QueryType
+    from oracle import image_ops as IO
+
+    r = np.random.default_rng(9000 + seed)
+    W, Hh, C = 160, 120, 16
+    cfg = S.StreamConfig(width=W, height=Hh, fx=525.0 / 4, fy=525.0 / 4, cx=W / 2 - 0.5, cy=Hh / 2 - 0.5, hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    mcfg.tsdf_decay_factor = float(r.choice([0.98, 0.6, 0.2]))
+    k_in, k_depth, border, min_d = 2, 3, mcfg.feature_mask_border_percent, mcfg.min_integration_distance_m
+    gpu = H.get_nvblox_mapper(mcfg, feature_channels=C)
+    orcs = [make_oracle(oracle_mod, C, tsdf_decay_factor=mcfg.tsdf_decay_factor) for _ in range(2)]
+
+    def frame_inputs():
+        i = int(r.integers(0, 200))
+        f = S.frame(cfg, i, C)
+        low = r.standard_normal((8, 8, C)).astype(np.float32)  # a backbone output; its up-sampled image replaces the stream's
+        img = upsample_features(dev(low).permute(2, 0, 1).contiguous(), (Hh, W), C)
+        f["low"], f["features"] = dev(low), img.cpu().numpy()
+        m = np.ones((Hh, W), dtype=bool)
+        y0, x0 = int(r.integers(0, Hh - 30)), int(r.integers(0, W - 40))
+        m[y0: y0 + int(r.integers(5, 30)), x0: x0 + int(r.integers(5, 40))] = False
+        return f, m
+
+    def oracle_frame(orc, f, mask):
+        odm, ofm = IO.frame_masks(mask, f["depth"], min_d, k_in, k_depth, border, Hh, W)
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+        return odm, ofm
+
+    def check(mid):
+        orc = orcs[mid]
+        t, ti = gpu.tsdf_layer_view(mid).get_all_blocks()
+        assert np.array_equal(ti.cpu().numpy(), orc.block_indices(0)), ("TSDF blocks", mid, log)
+        if ti.shape[0]:
+            assert np.array_equal(t.cpu().numpy().view(np.uint32), orc.all_tsdf().view(np.uint32)), ("TSDF values", mid, log)
+        fv, fw, fi = gpu.feature_layer_view(mid).get_all_blocks_split()
+        of, ow = orc.all_features()
+        assert np.array_equal(fi.cpu().numpy(), orc.block_indices(2)) and np.array_equal(fw.cpu().numpy(), ow), ("feature blocks", mid, log)
+        assert np.array_equal(fv.cpu().numpy().view(np.uint16), of.view(np.uint16)), ("feature values", mid, log)
+        rgb, cw, ci = gpu.color_layer_view(mid).get_all_blocks_split()
+        orgb, ocw = orc.all_colors()
+        assert np.array_equal(ci.cpu().numpy(), orc.block_indices(1)) and np.array_equal(cw.cpu().numpy(), ocw), ("colour blocks", mid, log)
+        assert np.array_equal(rgb.cpu().numpy(), orgb), ("colours", mid, log)
+
+    log = []
+    ops = ["decay", "fused", "calls", "lowres", "pair", "clear", "mesh", "reload", "query", "render"]
+    weights = np.array([3, 4, 2, 3, 4, 0.6, 1.5, 1, 1, 1], dtype=np.float64)
+    for step in range(28):
+        op = str(r.choice(ops, p=weights / weights.sum())) if step > 1 else "fused"
+        mid = int(r.integers(2))
+        log.append((op, mid))
+        if op == "decay":  # Mapper.decay() decays every mapper (nvblox_torch: mapper_id = -1)
+            gpu.decay()
+            orcs[0].decay(), orcs[1].decay()
+        elif op in ("fused", "lowres"):
+            f, m = frame_inputs()
+            T, K = torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"])
+            if op == "fused":
+                dm, fm = gpu.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), dev(~m), T, K, min_d, k_in, k_depth, border,
+                                             mid, invert_input_mask=True)
+            else:
+                dm, fm = gpu.integrate_frame_lowres(dev(f["depth"]), dev(f["rgb"]), f["low"], dev(m), T, K, min_d, k_in, k_depth, border, mid)
+            odm, ofm = oracle_frame(orcs[mid], f, m)
+            assert np.array_equal(dm.cpu().numpy().astype(bool), odm) and np.array_equal(fm.cpu().numpy().astype(bool), ofm), log
+        elif op == "calls":
+            f, m = frame_inputs()
+            T, K = torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"])
+            odm, ofm = oracle_frame(orcs[mid], f, m)
+            gpu.add_depth_frame(dev(f["depth"]), T, K, dev(odm.astype(np.uint8)), mid)
+            gpu.add_color_frame(dev(f["rgb"]), T, K, mask_frame=dev(odm.astype(np.uint8)), mapper_id=mid)
+            gpu.add_feature_frame(dev(f["features"]), T, K, dev(ofm.astype(np.uint8)), mid)
+        elif op == "pair":
+            f, m = frame_inputs()
+            T, K = torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"])
+            jobs = [{"mapper_id": 0, "input_mask": dev(~m), "invert_input_mask": True, "input_mask_erosion_iterations": k_in,
+                     "valid_depth_mask_erosion_iterations": k_depth},
+                    {"mapper_id": 1, "input_mask": dev(~m), "invert_input_mask": False, "input_mask_erosion_iterations": k_in,
+                     "valid_depth_mask_erosion_iterations": k_depth}]
+            use_low = bool(r.integers(2))
+            gpu.integrate_frame_multi(dev(f["depth"]), dev(f["rgb"]), None if use_low else dev(f["features"]), T, K, min_d, border, jobs,
+                                      lowres_features=f["low"] if use_low else None)
+            oracle_frame(orcs[0], f, m)
+            oracle_frame(orcs[1], f, ~m)
+        elif op == "clear":
+            gpu.clear(mid)
+            orcs[mid].clear()
+        elif op == "mesh":
+            ov, ofeat = orcs[mid].feature_mesh()
+            gpu.update_feature_mesh(mid)
+            mesh = gpu.get_feature_mesh(mid)
+            gv = mesh.vertices().cpu().numpy()
+            assert gv.shape == ov.shape and np.array_equal(gv.view(np.uint32), ov.view(np.uint32)), ("mesh", log)
+            assert np.array_equal(mesh.vertex_features().cpu().numpy().view(np.uint16), ofeat.view(np.uint16)), ("mesh features", log)
+        elif op == "reload":  # both mappers to disk, a NEW Mapper reads them and carries on
+            paths = [str(tmp_path / f"s{seed}_{step}_{j}.nvblx") for j in range(2)]
+            for j in range(2):
+                gpu.save_map(paths[j], j)
+            gpu = H.get_nvblox_mapper(mcfg, feature_channels=C)
+            for j in range(2):
+                gpu.load_from_file(paths[j], j)
+        elif op == "query":
+            pts = r.uniform(-0.4, 0.9, size=(257, 3)).astype(np.float32)
+            assert np.array_equal(gpu.query_layer(QueryType.TSDF, dev(pts), mid).cpu().numpy(), orcs[mid].query_tsdf(pts)), log
+            assert np.array_equal(gpu.query_layer(QueryType.FEATURE, dev(pts), mid).cpu().numpy(), orcs[mid].query_features(pts)), log
+        elif op == "render":
+            f = S.frame(cfg, int(r.integers(0, 200)), 0)
+            so = orcs[mid].render_synthetic_depth(Hh, W, f["T_W_C"], f["K"])
+            sg = gpu.render_synthetic_depth(Hh, W, f["T_W_C"], f["K"], mapper_id=mid).cpu().numpy()
+            assert np.array_equal(so.view(np.uint32), sg.view(np.uint32)), log
+        if step % 5 == 4:
+            check(0), check(1)
+    check(0), check(1)
+    assert orcs[0].num_blocks(0) + orcs[1].num_blocks(0) > 0 or ("clear", 0) in log or ("clear", 1) in log
