@@ -293,3 +293,50 @@ def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path):
             check(0), check(1)
     check(0), check(1)
     assert orcs[0].num_blocks(0) + orcs[1].num_blocks(0) > 0 or ("clear", 0) in log or ("clear", 1) in log
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_policy_shapes_fused_inference_matches_composite(seed):
+    """The policy's inference kernels (whole-layer matrix-core kernels, split cross-attention, paired output stacks, step
+    prologue / tail, HIP FPS) against the composite torch ops over drawn shapes: batch 1-3, 1-2 grippers, horizon 1-2, context
+    lengths that are not multiples of the 16-token tiles, random vertex padding (one sample fully padded now and then), a few
+    denoising steps.  Float-rounding agreement (different summation orders), identical graph replay."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, synthetic_batch
+    from nvblox_mindmap_amd.training.trainer import unpack_batch
+
+    r = np.random.default_rng(7000 + seed)
+    B, G, L = int(r.integers(1, 4)), int(r.integers(1, 3)), int(r.integers(1, 3))
+    n_vert = int(r.choice([45, 160, 333, 1000, 2048, 3072]))
+    cfg = DiffuserActorConfig(data_type="mesh", feature_dim=int(r.choice([32, 64])), diffusion_timesteps=int(r.integers(3, 7)), ngrippers=G,
+                              prediction_horizon=L, predict_head_yaw=bool(r.integers(2)), fps_subsampling_factor=int(r.choice([3, 5])))
+    print(dict(B=B, G=G, L=L, n_vert=n_vert, steps=cfg.diffusion_timesteps, yaw=cfg.predict_head_yaw, fps=cfg.fps_subsampling_factor))
+    torch.manual_seed(seed)
+    model = build_model(cfg, device="cuda").eval()
+    for p in model.parameters():  # AdaLN / output layers start at zero: perturb so that every path matters
+        if p.requires_grad:
+            p.data.add_(0.02 * torch.randn_like(p))
+    s = unpack_batch(cfg, synthetic_batch(cfg, B, "cuda", num_vertices=n_vert, seed=seed))
+    valid = torch.from_numpy(r.uniform(size=(B, n_vert)) > r.uniform(0.0, 0.6)).cuda()
+    if B > 1 and r.integers(3) == 0:
+        valid[int(r.integers(B))] = False
+    valid[0, 0] = True
+
+    def infer():
+        torch.manual_seed(11)
+        with torch.no_grad():
+            return model(None, None, None, None, None, s["vertex_features"], s["vertices"], valid, None, s["gripper_history"], run_inference=True)[:2]
+
+    ref, ref_yaw = infer()
+    try:
+        DiffuserActor.enable_fused_inference(True)
+        fused, fused_yaw = infer()
+        model.enable_graph_sampling(True)
+        graph, graph_yaw = infer()
+    finally:
+        DiffuserActor.enable_fused_inference(False)
+        model.enable_graph_sampling(False)
+    assert torch.isfinite(ref).all() and torch.equal(fused, graph)
+    assert torch.allclose(fused, ref, rtol=1e-3, atol=2e-4), float((fused - ref).abs().max())
+    if cfg.predict_head_yaw:
+        assert torch.equal(fused_yaw, graph_yaw) and torch.allclose(fused_yaw, ref_yaw, rtol=1e-3, atol=2e-4)
