@@ -139,6 +139,9 @@ class DevicePrefetcher:
         with torch.cuda.stream(self.stream):
             self._next = gpu_unpack(host, self.device)
 
+    def __len__(self):
+        return len(self.loader)
+
     def __iter__(self):
         self._it = iter(self.loader)
         self._load()

@@ -141,11 +141,11 @@ class BackbonePrefetcher:
 
 
 def train_one_step(cfg: DiffuserActorConfig, model: nn.Module, optimizer, batch: Dict[str, torch.Tensor], scheduler=None,
-                   backbone_feats: Optional[torch.Tensor] = None):
+                   backbone_feats: Optional[torch.Tensor] = None, unpack=None):
     """unpack -> forward (losses) -> backward (DDP all-reduce overlaps) -> AdamW step.  Returns the detached losses.
     ``backbone_feats``: the frozen backbone's output for this batch when a BackbonePrefetcher computed it ahead."""
     with Timer("step/train/unpack_batch"):
-        s = unpack_batch(cfg, batch)
+        s = (unpack or unpack_batch)(cfg, batch)
     optimizer.zero_grad(set_to_none=True)
     with Timer("step/train/compute_losses"):
         losses, _, _ = model(s["gt_gripper_pred"], s["gt_head_yaw"], s["rgbs"], s["pcds"], s["pcd_valid_mask"], s["vertex_features"],

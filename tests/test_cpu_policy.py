@@ -328,6 +328,113 @@ def test_ddp_two_ranks_gloo():
     assert tmax == 2.0
 
 
+def test_compute_metrics_matches_reference():
+    """model_utils/loss.py:83-139 (vectors from the imported reference, tests/golden/make_golden_metrics.py): an exact hit
+    exercises the small-angle branch, a sign-flipped quaternion the double cover."""
+    from nvblox_mindmap_amd.diffuser_actor.loss import compute_metrics
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics.npz"))
+    for tag in ("arm", "humanoid"):
+        t = lambda k: torch.from_numpy(g[f"{tag}_{k}"])  # noqa: E731
+        m = compute_metrics(t("pred"), t("yaw_pred"), t("gt"), t("yaw_gt"), predict_head_yaw=True)
+        names = [k[len(tag) + 3:] for k in g.files if k.startswith(f"{tag}_m_")]
+        assert set(names) == set(m.keys()) and len(names) == 13
+        for k in names:
+            assert np.allclose(m[k].numpy(), g[f"{tag}_m_{k}"], rtol=1e-5, atol=1e-5), (tag, k, m[k], g[f"{tag}_m_{k}"])
+        assert "head_yaw_error_deg" not in compute_metrics(t("pred"), None, t("gt"), None, predict_head_yaw=False)
+
+
+class _MemoryDataset(torch.utils.data.Dataset):
+    """Per-sample dicts cut out of synthetic batches (default collate stacks them back)."""
+
+    def __init__(self, cfg, n, seed):
+        from nvblox_mindmap_amd.training import synthetic_batch
+
+        b = synthetic_batch(cfg, n, "cpu", num_vertices=48, seed=seed)
+        self.items = [{k: v[i] for k, v in b.items() if torch.is_tensor(v)} for i in range(n)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _loop_worker(rank, world, port, out, ckpt_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import dataclasses
+
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.training import (DistributedWeightedSampler, ProcessGroup, build_optimizer, load_train_checkpoint, run_training,
+                                             wrap_ddp)
+    from nvblox_mindmap_amd.training.trainer import build_model
+
+    with ProcessGroup(backend="gloo"):
+        cfg = dataclasses.replace(_tiny_cfg(), diffusion_timesteps=3)
+        train_set, val_set = _MemoryDataset(cfg, 12, 1), _MemoryDataset(cfg, 8, 2)
+        ts = DistributedWeightedSampler(torch.ones(len(train_set)), len(train_set), seed=3)
+        vs = DistributedWeightedSampler(torch.ones(len(val_set)), len(val_set), seed=4)
+        train_loader, val_loader = DataLoader(train_set, batch_size=2, sampler=ts), DataLoader(val_set, batch_size=2, sampler=vs)
+        assert len(train_loader) == 3  # 12 samples / 2 ranks / batch 2: the loop crosses epoch boundaries
+
+        def fresh():
+            torch.manual_seed(0)
+            model = build_model(cfg, device="cpu")
+            ddp = wrap_ddp(model, "cpu")
+            return model, ddp, build_optimizer(ddp, lr=1e-3)
+
+        evals = []
+        model, ddp, opt = fresh()
+        torch.manual_seed(50 + rank)
+        done, best = run_training(cfg, ddp, opt, train_loader, val_loader, train_iters=4, val_freq=2, train_sampler=ts, validation_sampler=vs,
+                                  checkpoint_dir=ckpt_dir, num_batches_per_test_eval=1, num_batches_per_train_eval=1,
+                                  on_eval=lambda step, split, v: evals.append((step, split, v)))
+        assert done == 4 and ddp.training
+        # resume from what rank 0 wrote (every rank reads it after the loop's barrier) and carry on to iteration 6
+        model2, ddp2, opt2 = fresh()
+        start, best2 = load_train_checkpoint(os.path.join(ckpt_dir, "last.pth"), ddp2, opt2, initial_learning_rate=1e-3)
+        same = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))
+        torch.manual_seed(70 + rank)
+        done2, best3 = run_training(cfg, ddp2, opt2, train_loader, val_loader, train_iters=6, val_freq=2, train_sampler=ts, validation_sampler=vs,
+                                    start_iter=start, best_loss=best2, checkpoint_dir=ckpt_dir, num_batches_per_test_eval=-1)
+        vec = torch.cat([p.detach().flatten() for p in model2.parameters() if p.requires_grad])
+        from nvblox_mindmap_amd.training import all_gather_objects
+
+        gathered = all_gather_objects({"evals": evals, "best": (best, best2, best3), "start": start, "done2": done2, "same": same,
+                                       "checksum": float(vec.double().sum()), "lr": opt2.param_groups[0]["lr"]})
+        if rank == 0:
+            out.put(gathered)
+
+
+def test_training_loop_two_ranks_gloo(tmp_path):
+    """training.run_training on 2 ranks (gloo): iteration-based loop over epoch boundaries, evaluation in inference mode with the
+    per-rank means all-gathered and averaged (run_training.py:371-375), rank 0 writes last.pth / best.pth, every rank resumes
+    from it and carries on."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = g
+    assert [(s, split) for s, split, _ in a["evals"]] == [(1, "train-val"), (1, "val"), (3, "train-val"), (3, "val")]
+    for (_, _, va), (_, _, vb) in zip(a["evals"], b["evals"]):
+        assert va == vb and np.isfinite(list(va.values())).all()  # the averaged values are the same on every rank
+        assert {"mean_total_loss", "mean_pos_loss", "mean_distance_m", "mean_rot_error_deg", "mean_bias_z", "mean_head_yaw_error_deg"} <= set(va)
+    assert a["best"][0] is not None and b["best"][0] is None  # rank 0 (the writer) tracks the best loss ...
+    assert a["best"][1] == b["best"][1] == min(v["mean_total_loss"] for s, split, v in a["evals"] if split == "val")  # ... the file carries it
+    assert a["start"] == b["start"] == 4 and a["done2"] == b["done2"] == 6 and a["same"] and b["same"]
+    assert a["checksum"] == b["checksum"]  # DDP kept the ranks in step after the resume
+    assert abs(a["lr"] - 7.5e-4) < 1e-12  # the ramp (1.0 -> 0.5 over 75 % of 6 iterations) restarted at the resume, 2 steps in
+    assert os.path.exists(tmp_path / "best.pth") and os.path.exists(tmp_path / "last.pth")
+
+
 def test_training_checkpoint_resume(tmp_path):
     """save_checkpoint / load_train_checkpoint (model_utils/checkpoint.py:30-52,117-136): resuming reproduces the run that
     never stopped, bit for bit; best.pth only moves when the validation loss improves."""

@@ -3,6 +3,7 @@ the full input pipeline (HIP back-projection inside unpack_batch) on cuda:0."""
 import math
 
 import pytest
+import numpy as np
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -111,6 +112,40 @@ def test_file_fed_training_step(tmp_path):
     model = build_model(cfg, device="cuda")
     losses = train_one_step(cfg, model, build_optimizer(model), b)
     assert torch.isfinite(losses[0])
+
+
+def test_training_loop_on_the_file_fed_loader(tmp_path):
+    """training.run_training (run_training.py:640-770) on one GPU: demo files -> DataLoader workers -> DevicePrefetcher ->
+    iterations across an epoch boundary, an evaluation in inference mode, checkpoint, resume."""
+    import dataclasses
+
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.data_loading.dataset import DevicePrefetcher, MindmapFrameDataset, write_synthetic_demo
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import build_model, build_optimizer, load_train_checkpoint, run_training
+
+    cfg = DiffuserActorConfig(data_type="rgbd_and_mesh", image_size=(128, 128), feature_dim=768, diffusion_timesteps=4)
+    write_synthetic_demo(str(tmp_path / "demo_00000"), 6, image_size=(128, 128), feature_dim=768, num_history=cfg.num_history,
+                         prediction_horizon=cfg.prediction_horizon, ngrippers=cfg.ngrippers)
+    ds = MindmapFrameDataset(str(tmp_path), num_vertices=256, seed=0)
+    loader = DevicePrefetcher(DataLoader(ds, batch_size=2, shuffle=True, num_workers=2, pin_memory=True), "cuda")
+    assert len(loader) == 3
+    torch.manual_seed(0)
+    model = build_model(cfg, device="cuda")
+    opt = build_optimizer(model, lr=1e-3)
+    seen = []
+    done, best = run_training(cfg, model, opt, loader, loader, train_iters=4, val_freq=2, checkpoint_dir=str(tmp_path / "ckpt"),
+                              num_batches_per_test_eval=1, on_eval=lambda step, split, v: seen.append((step, split, v)))
+    assert done == 4 and [s[:2] for s in seen] == [(1, "val"), (3, "val")] and model.training
+    assert best == min(v["mean_total_loss"] for _, _, v in seen) and all(np.isfinite(list(v.values())).all() for _, _, v in seen)
+    model2 = build_model(dataclasses.replace(cfg), device="cuda")
+    opt2 = build_optimizer(model2, lr=1e-3)
+    start, best2 = load_train_checkpoint(str(tmp_path / "ckpt" / "last.pth"), model2, opt2, initial_learning_rate=1e-3)
+    assert (start, best2) == (4, best)
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))
+    done2, _ = run_training(cfg, model2, opt2, loader, loader, train_iters=5, val_freq=10, start_iter=start, best_loss=best2)
+    assert done2 == 5
 
 
 def test_device_prefetcher_hands_out_the_same_batches(tmp_path):
