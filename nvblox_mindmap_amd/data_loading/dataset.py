@@ -28,7 +28,12 @@ from .vertex_sampling import VertexSamplingMethod, sample_to_n_vertices
 class MindmapFrameDataset(Dataset):
     def __init__(self, dataset_path: str, cameras: Sequence[str] = ("pov",), num_vertices: int = 2048,
                  vertex_sampling_method: VertexSamplingMethod = VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT,
-                 with_vertex_features: bool = True, seed: Optional[int] = None):
+                 with_vertex_features: bool = True, seed: Optional[int] = None, geometry_augmentor=None, geometry_noiser=None):
+        """``geometry_augmentor`` / ``geometry_noiser``: sample_transformer.GeometryAugmentor / GeometryNoiser, wired as the
+        reference does (dataset_files_by_encoding_method.py:258-279): ONE random rigid transform per sample applied to the mesh
+        vertices, the gripper history and the target poses; independent Gaussian pose noise on the history and the vertices,
+        not on the target; both before the vertices are sampled."""
+        self.augmentor, self.noiser = geometry_augmentor, geometry_noiser
         self.cameras = list(cameras)
         self.num_vertices = num_vertices
         self.method = vertex_sampling_method
@@ -64,6 +69,16 @@ class MindmapFrameDataset(Dataset):
     def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
         it = self.samples[idx]
         out = {}
+        if self.augmentor is not None:
+            self.augmentor.reset()  # a new transform for this sample, shared by all its geometric items (dataset.py:451-454)
+
+        def geometric(x, noisy: bool):
+            if self.augmentor is not None:
+                x = self.augmentor(x)
+            if noisy and self.noiser is not None:
+                x = self.noiser(x)
+            return x
+
         rgb, depth, pose, intr = [], [], [], []
         for cam in self.cameras:
             rgb.append(D.read_png(it[f"{cam}_rgb"]))                                   # [H,W,3] u8
@@ -74,12 +89,14 @@ class MindmapFrameDataset(Dataset):
         out["depth_mm"] = torch.stack(depth)
         out["camera_poses"] = torch.stack(pose)
         out["intrinsics"] = torch.stack(intr)
-        out["gripper_history"] = torch.as_tensor(np.load(it["gripper_history"])).to(torch.float32)
-        out["gt_gripper_pred"] = torch.as_tensor(np.load(it["gt_gripper_pred"])).to(torch.float32)
+        out["gripper_history"] = geometric(torch.as_tensor(np.load(it["gripper_history"])).to(torch.float32), noisy=True)
+        out["gt_gripper_pred"] = geometric(torch.as_tensor(np.load(it["gt_gripper_pred"])).to(torch.float32), noisy=False)
         if "gt_head_yaw" in it:
             out["gt_head_yaw"] = torch.as_tensor(np.load(it["gt_head_yaw"])).to(torch.float32)
         if self.with_vertex_features:
             s = D.read_vertex_features(it["vertex_features"])
+            if self.augmentor is not None or self.noiser is not None:
+                s["vertices"] = geometric(s["vertices"].to(torch.float32), noisy=True)
             # sample the stored f16 rows, convert afterwards: the same N rows as sampling the float32 copy (selection / padding
             # do no arithmetic), without a float32 copy of the whole [V, C] matrix (37 MB at V = 12 k, C = 768) per sample
             v, f, valid = sample_to_n_vertices(s["vertices"], s["features"], self.num_vertices, self.method,

@@ -145,3 +145,64 @@ def test_frame_dataset_reads_the_reference_layout(tmp_path):
     assert batch["rgb_u8"].shape == (2, 1, 32, 48, 3) and batch["vertices"].shape == (2, 512, 3)
     with pytest.raises(FileNotFoundError):
         MindmapFrameDataset(str(tmp_path / "demo_00001"))
+
+
+def test_geometry_augmentation_matches_reference():
+    """data_loading/sample_transformer.py:76-300 (GeometryAugmentor / GeometryNoiser / random_transform_* /
+    apply_random_transform_to_sample), vectors from the imported reference (tests/golden/make_golden_augmentation.py): same
+    seeds => same draws => same transforms; quaternions compared up to sign where the reference does not standardise them."""
+    import random
+
+    from nvblox_mindmap_amd.data_loading import sample_transformer as ST
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augmentation.npz"))
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    t_range, rpy_range = (g["t_lo"].tolist(), g["t_hi"].tolist()), (g["rpy_lo"].tolist(), g["rpy_hi"].tolist())
+
+    def same_rotation(a, b):
+        return np.allclose(np.abs((a * b).sum(-1)), 1.0, atol=1e-6)
+
+    random.seed(11)
+    tr, q = ST.random_transform_uniform(t_range, rpy_range)
+    assert np.allclose(tr.numpy(), g["uniform_t"], atol=1e-7) and same_rotation(q.numpy(), g["uniform_q"])
+    random.seed(12)
+    aug = ST.GeometryAugmentor(t_range, rpy_range)
+    poses = aug(t("poses"))
+    assert np.allclose(poses.numpy(), g["aug_poses"], atol=1e-6)
+    assert np.allclose(aug({"vertices": t("vertices")})["vertices"].numpy(), g["aug_vertices"], atol=1e-6)  # the SAME transform
+    aug.reset()
+    assert np.allclose(aug(t("vertices")).numpy(), g["aug_vertices_after_reset"], atol=1e-6)
+    assert not np.allclose(g["aug_vertices"], g["aug_vertices_after_reset"], atol=1e-3)
+    torch.manual_seed(21)
+    tr, q = ST.random_transform_gaussian(0.01, 2.0, 7)
+    assert np.allclose(tr.numpy(), g["gauss_t"], atol=1e-7) and same_rotation(q.numpy(), g["gauss_q"])
+    torch.manual_seed(22)
+    noiser = ST.GeometryNoiser(0.02, 3.0)
+    assert np.allclose(noiser({"vertices": t("vertices")})["vertices"].numpy(), g["noisy_vertices"], atol=1e-6)
+    assert np.allclose(noiser(t("flat_poses")).numpy(), g["noisy_flat_poses"], atol=1e-6)
+    # a [nhist, ngrippers, 8] history: one transform per history entry, positions move by about the standard deviation
+    torch.manual_seed(23)
+    hist = noiser(t("poses"))
+    assert hist.shape == (3, 2, 8) and 0 < float((hist[..., :3] - t("poses")[..., :3]).abs().max()) < 0.2
+    assert torch.equal(hist[..., 7], t("poses")[..., 7])
+
+
+def test_dataset_applies_the_same_augmentation_to_every_geometric_item(tmp_path):
+    import random
+
+    from nvblox_mindmap_amd.data_loading.dataset import MindmapFrameDataset, write_synthetic_demo
+    from nvblox_mindmap_amd.data_loading.sample_transformer import GeometryAugmentor, apply_random_transform_to_sample
+    from nvblox_mindmap_amd.data_loading.vertex_sampling import VertexSamplingMethod
+
+    write_synthetic_demo(str(tmp_path / "demo_00000"), 2, image_size=(32, 32), feature_dim=8, ngrippers=2, vertex_count_range=(40, 41))
+    plain = MindmapFrameDataset(str(tmp_path), num_vertices=40, vertex_sampling_method=VertexSamplingMethod.NONE)
+    aug = GeometryAugmentor(([0.1, 0.1, 0.1], [0.2, 0.2, 0.2]), ([-20.0, -20.0, -20.0], [20.0, 20.0, 20.0]))
+    moved = MindmapFrameDataset(str(tmp_path), num_vertices=40, vertex_sampling_method=VertexSamplingMethod.NONE, geometry_augmentor=aug)
+    a = plain[1]
+    random.seed(3)
+    b = moved[1]
+    tr, q = aug._transform  # the transform drawn for this sample (reset() inside __getitem__)
+    for key in ("vertices", "gripper_history", "gt_gripper_pred"):
+        assert torch.allclose(b[key], apply_random_transform_to_sample(a[key], tr, q), atol=1e-6), key
+        assert not torch.allclose(b[key][..., :3], a[key][..., :3], atol=1e-2)
+    assert torch.equal(b["vertex_features"], a["vertex_features"]) and torch.equal(b["rgb_u8"], a["rgb_u8"])
