@@ -459,7 +459,7 @@ class Mapper:
                         invert_input_mask: bool = False):
         """Extension: the reference's ``integrate_frame`` (mapping/helpers/nvblox_mapping_helpers.py:162-273) as one
         native call -- mask algebra + add_depth_frame + add_color_frame + add_feature_frame with identical results in
-        six fused launches (a preceding ``decay()`` is folded into the first two).  Needs the feature image at the depth
+        five fused launches (a preceding ``decay()`` is folded into the first two).  Needs the feature image at the depth
         resolution.  ``invert_input_mask``: use ``~input_mask`` (the reference's static mask from the dynamic mask,
         :116-117) without materialising it.  Returns (depth_mask uint8 [H,W], feature_mask uint8 [Hf,Wf])."""
         return self._integrate_frame_desc(depth_frame, color_frame, feature_frame, None, input_mask, t_w_c, intrinsics,

@@ -222,7 +222,7 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize("scale,channels", [(4, 16), (1, 64)])
 def test_integrate_frame_fused_matches_oracle(oracle_mod, scale, channels):
-    """The reference's integrate_frame as one native call (masks + depth + colour + feature, six fused launches, lazy
+    """The reference's integrate_frame as one native call (masks + depth + colour + feature, five fused launches, lazy
     decay folded in) against the oracle driven with the numpy-oracle masks, over several frames with decay."""
     from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper, integrate_frame
     from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
