@@ -430,14 +430,34 @@ class Mapper:
         n = len(jobs)
         descs = (_lib.MmfFrame * n)()
         ids = (C.c_int * n)()
-        keep, out = [], []
+        # the jobs share the camera frame: its checks, host copies of pose / intrinsics and descriptor fields are done once
+        # (first job) and copied; per job only the mask, the erosions and the two output masks differ
+        first = jobs[0]
+        base, keep, dm0, fm0 = self._frame_desc(depth_frame, color_frame, None if lowres_features is not None else feature_frame,
+                                                lowres_features, first["input_mask"], t_w_c, intrinsics, min_depth_m,
+                                                first["input_mask_erosion_iterations"], first["valid_depth_mask_erosion_iterations"],
+                                                border_percent, bool(first.get("invert_input_mask", False)))
+        H, W, Hf, Wf = base.H, base.W, base.Hf, base.Wf
+        out = [(dm0, fm0)]
+        keep = [keep]
+        if n > 1:
+            dms = torch.empty((n - 1, H, W), dtype=torch.uint8, device=self.device)
+            fms = torch.empty((n - 1, Hf, Wf), dtype=torch.uint8, device=self.device)
         for i, job in enumerate(jobs):
             ids[i] = self._check_id(job["mapper_id"])
-            f, k, dm, fm = self._frame_desc(depth_frame, color_frame, None if lowres_features is not None else feature_frame, lowres_features,
-                                            job["input_mask"], t_w_c, intrinsics, min_depth_m, job["input_mask_erosion_iterations"],
-                                            job["valid_depth_mask_erosion_iterations"], border_percent, bool(job.get("invert_input_mask", False)))
-            descs[i] = f
-            keep.append(k)
+            if i == 0:
+                descs[0] = base
+                continue
+            C.memmove(C.byref(descs[i]), C.byref(base), C.sizeof(_lib.MmfFrame))
+            f = descs[i]
+            mask = _mask_u8(job["input_mask"], (H, W))
+            f.input_mask = mask.data_ptr()
+            f.invert_input_mask = 1 if job.get("invert_input_mask", False) else 0
+            f.input_mask_erosion_iterations = int(job["input_mask_erosion_iterations"])
+            f.valid_depth_mask_erosion_iterations = int(job["valid_depth_mask_erosion_iterations"])
+            dm, fm = dms[i - 1], fms[i - 1]
+            f.depth_mask_out, f.feature_mask_out = dm.data_ptr(), fm.data_ptr()
+            keep.append(mask)
             out.append((dm, fm))
         _lib.check(_lib.lib().mmf_integrate_frame_multi(self._h, n, ids, descs, self._stream()), "mmf_integrate_frame_multi")
         del keep
