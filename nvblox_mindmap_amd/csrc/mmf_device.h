@@ -84,7 +84,8 @@ struct LayerDev {
 };
 
 __device__ inline int dense_cell(const LayerDev& L, int x, int y, int z) {
-  return ((x - L.d_lo[0]) * L.d_ny + (y - L.d_lo[1])) * L.d_nz + (z - L.d_lo[2]);
+  // 24-bit multiplies: full rate (a 32-bit v_mul_lo is quarter rate); the offsets and extents of a dense table are far below 2^23
+  return __mul24(__mul24(x - L.d_lo[0], L.d_ny) + (y - L.d_lo[1]), L.d_nz) + (z - L.d_lo[2]);
 }
 __device__ inline void dense_set(const LayerDev& L, unsigned long long key, int slot_plus_1);
 
