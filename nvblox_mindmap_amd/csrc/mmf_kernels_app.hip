@@ -82,6 +82,23 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
   float dL[3];
   rotate(T_L_C, dC, dL);
   const float o[3] = {T_L_C.t[0], T_L_C.t[1], T_L_C.t[2]};
+  // Loop constants of the march live in VECTOR registers: the kernel has VGPRs to spare (55 of 72 at its occupancy) and is out of
+  // scalar registers -- the compiler was parking loop-invariant scalars in VGPR lanes and fetching them back with
+  // v_readlane + s_nop inside the march (18 + 10 of the ~640 instructions of an iteration; the tracer is issue-bound).
+  float c_inv_bs = mc.inv_bs, c_bs = mc.bs, c_inv_v = mc.inv_v, c_trunc = mc.trunc, c_eps = mc.st_eps, c_max_len = mc.st_max_len,
+        c_half_v = 0.5f * mc.v;
+  asm volatile("" : "+v"(c_inv_bs), "+v"(c_bs), "+v"(c_inv_v), "+v"(c_trunc), "+v"(c_eps), "+v"(c_max_len), "+v"(c_half_v));
+  int w_lo0 = mc.ws_lo[0], w_lo1 = mc.ws_lo[1], w_lo2 = mc.ws_lo[2], w_hi0 = mc.ws_hi[0], w_hi1 = mc.ws_hi[1], w_hi2 = mc.ws_hi[2];
+  int d_lo0 = T.d_lo[0], d_lo1 = T.d_lo[1], d_lo2 = T.d_lo[2], d_ny = T.d_ny, d_nz = T.d_nz;
+  asm volatile("" : "+v"(w_lo0), "+v"(w_lo1), "+v"(w_lo2), "+v"(w_hi0), "+v"(w_hi1), "+v"(w_hi2));
+  asm volatile("" : "+v"(d_lo0), "+v"(d_lo1), "+v"(d_lo2), "+v"(d_ny), "+v"(d_nz));
+  auto inws = [&](int x, int y, int z) {  // in_workspace(mc, ...) on the pinned bounds
+    if (mc.ws_type == 0) return true;
+    if (z < w_lo2 || z > w_hi2) return false;
+    if (mc.ws_type == 1) return true;
+    return !(x < w_lo0 || x > w_hi0 || y < w_lo1 || y > w_hi1);
+  };
+  auto cell_of = [&](int x, int y, int z) { return __mul24(__mul24(x - d_lo0, d_ny) + (y - d_lo1), d_nz) + (z - d_lo2); };  // dense_cell(T, ...)
 
   // [t_enter, t_exit]: ray parameters at which the ray can be inside the workspace bounds padded by one block
   float t_enter = -3.0e38f, t_exit = 3.0e38f;
@@ -90,7 +107,7 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (mc.ws_type == 1 && a < 2) continue;
-      const float lo = (float)(mc.ws_lo[a] - 1) * mc.bs, hi = (float)(mc.ws_hi[a] + 2) * mc.bs;
+      const float lo = (float)(mc.ws_lo[a] - 1) * c_bs, hi = (float)(mc.ws_hi[a] + 2) * c_bs;
       if (fabsf(dL[a]) > 1e-9f) {
         const float t1 = (lo - o[a]) / dL[a], t2 = (hi - o[a]) / dL[a];
         tmin = fmaxf(tmin, fminf(t1, t2));
@@ -112,8 +129,8 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
   int i = 0;
   // fast-forward: before the padded bounds every sample is unobserved and (nothing observed yet) the step is trunc
   if (t_exit >= 0.0f)
-    while (i < mc.st_max_steps && t < mc.st_max_len && t < t_enter) {
-      t += mc.trunc;
+    while (i < mc.st_max_steps && t < c_max_len && t < t_enter) {
+      t += c_trunc;
       ++i;
     }
 
@@ -134,14 +151,14 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
   };
   auto locate = [&](float tt, int& b0, int& b1, int& b2, int& lin) {  // block / voxel containing the ray point at tt
     const float p0 = o[0] + tt * dL[0], p1 = o[1] + tt * dL[1], p2 = o[2] + tt * dL[2];
-    b0 = ifloor(p0 * mc.inv_bs), b1 = ifloor(p1 * mc.inv_bs), b2 = ifloor(p2 * mc.inv_bs);
-    int q0 = ifloor((p0 - (float)b0 * mc.bs) * mc.inv_v), q1 = ifloor((p1 - (float)b1 * mc.bs) * mc.inv_v),
-        q2 = ifloor((p2 - (float)b2 * mc.bs) * mc.inv_v);
+    b0 = ifloor(p0 * c_inv_bs), b1 = ifloor(p1 * c_inv_bs), b2 = ifloor(p2 * c_inv_bs);
+    int q0 = ifloor((p0 - (float)b0 * c_bs) * c_inv_v), q1 = ifloor((p1 - (float)b1 * c_bs) * c_inv_v),
+        q2 = ifloor((p2 - (float)b2 * c_bs) * c_inv_v);
     q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
     q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
     q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
     lin = (q0 * 8 + q1) * 8 + q2;
-    return in_workspace(mc, b0, b1, b2);  // blocks are only ever allocated inside the workspace bounds
+    return inws(b0, b1, b2);  // blocks are only ever allocated inside the workspace bounds
   };
   auto sample = [&](float tt) {
     Sample S;
@@ -149,12 +166,12 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
     S.D = 0.0f;
     S.inws = locate(tt, S.b0, S.b1, S.b2, S.lin);
     if (S.inws) {
-      const int slot = T.dense ? (int)T.dense[dense_cell(T, S.b0, S.b1, S.b2)] - 1 : hash_find(T, pack_key(S.b0, S.b1, S.b2));
+      const int slot = T.dense ? (int)T.dense[cell_of(S.b0, S.b1, S.b2)] - 1 : hash_find(T, pack_key(S.b0, S.b1, S.b2));
       if (slot >= 0) {
         S.exists = true;
         if (T.block_free[slot]) {
           S.valid = true;
-          S.D = mc.trunc;
+          S.D = c_trunc;
         } else {
           const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)slot * kVPB + S.lin];
           if (dw.y > 1e-4f) {
@@ -175,24 +192,24 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
 #ifdef MMF_WG_TRACE
       ++n_narrow;
 #endif
-      const Sample S = sample(k == 0 ? t : t + (float)k * (0.5f * mc.v));
+      const Sample S = sample(k == 0 ? t : t + (float)k * c_half_v);
       int hold = 0;  // the probe that holds the march's current sample (lane 0's at first); -1: a point outside the workspace
       for (int step = 0; step < kRayLanes; ++step) {
         const int src = gshift + (hold < 0 ? 0 : hold);
         const bool v_valid = hold >= 0 && __shfl((int)S.valid, src, 64) != 0;
         const float v_D = __shfl(S.D, src, 64);
-        if (!(i < mc.st_max_steps && t < mc.st_max_len) || !v_valid) {  // (last_pos holds in this mode: unobserved = failure)
+        if (!(i < mc.st_max_steps && t < c_max_len) || !v_valid) {  // (last_pos holds in this mode: unobserved = failure)
           done = true;
           break;
         }
-        if (v_D < mc.st_eps) {  // the surface, reached from a valid positive distance
+        if (v_D < c_eps) {  // the surface, reached from a valid positive distance
           t = t + v_D;
           ok = true;
           done = true;
           break;
         }
         const float tn = t + v_D;
-        const bool plain = tn == t + mc.trunc;
+        const bool plain = tn == t + c_trunc;
         t = tn;
         ++i;
         if (plain) {  // out of the band: speculate again
@@ -219,20 +236,20 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
     float tk = t;
 #pragma unroll
     for (int j = 0; j < kRayLanes - 1; ++j) {
-      const float nx = tk + mc.trunc;
+      const float nx = tk + c_trunc;
       tk = j < k ? nx : tk;
     }
-    const float tk_next_guess = tk + mc.trunc;  // == lane k+1's tk
+    const float tk_next_guess = tk + c_trunc;  // == lane k+1's tk
     const Sample S = sample(tk);
     const bool valid = S.valid;
     const float D = S.D;
-    const bool pos = valid && !(D < mc.st_eps);  // a sample that sets "previous sample was a valid positive distance"
+    const bool pos = valid && !(D < c_eps);  // a sample that sets "previous sample was a valid positive distance"
     const unsigned mpos = (unsigned)((__ballot(pos) >> gshift) & 0xffffu);
     const bool last_pos_k = last_pos || (mpos & ((1u << k) - 1u)) != 0u;
-    const bool bound = !((i + k) < mc.st_max_steps && tk < mc.st_max_len);
+    const bool bound = !((i + k) < mc.st_max_steps && tk < c_max_len);
     const bool fail_unobserved = !valid && (last_pos_k || tk > t_exit);
-    const bool surface = valid && D < mc.st_eps;
-    const float tnext = tk + (valid ? D : mc.trunc);
+    const bool surface = valid && D < c_eps;
+    const float tnext = tk + (valid ? D : c_trunc);
     const bool deviate = pos && !(tnext == tk_next_guess);
     const unsigned mev = (unsigned)((__ballot(bound || fail_unobserved || surface || deviate) >> gshift) & 0xffffu);
     if (mev == 0u) {  // 16 plain trunc-steps
