@@ -141,6 +141,26 @@ int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_
 /* Mapper.get_feature_mesh(mapper_id).vertices() / .vertex_features()  nvblox_output_helpers.py:50-52.
  * Writes V x 3 f32 and V x C f16 into caller-allocated buffers (V from the last update). */
 int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* vertices_dev, void* vertex_features_f16_dev, void* stream);
+/* get_vertices_and_features(mapper, mapper_id, cfg, remove_zero_features, num_excess_features, ...)
+ * nvblox_output_helpers.py:22-91, fused: update_feature_mesh + get_feature_mesh (:49-52) + strict AABB filter (:57-60) + strip
+ * of the pad channels (:63-66) + all-zero-row filter (:68-74) in ONE launch that never materialises a [V, C] matrix, then the
+ * rows the caller selects (sample_to_n_vertices, data_loading/vertex_sampling.py:29-82 -- the RNG draw stays with the caller,
+ * on the host, like in the reference) gathered by a second launch.
+ * prepare: synchronises `stream`; *num_kept = rows that pass the filters, in the order of the reference's filtered mesh
+ *   (= the order of mmf_get_feature_mesh).  used_channels = C - num_excess_features (1 .. C).
+ * gather: output row j < n_take is kept row rows_dev[j] (int64 ranks in [0, num_kept); null = j itself); rows
+ *   n_take <= j < n_out are zero padding.  vertices_out [n_out,3] f32; features_out [n_out, used_channels] f32
+ *   (features_f32 != 0) or f16, may be null (vertices only); valid_out [n_out] u8 (1 = a real row), may be null.
+ *   Fails with MMF_ERR_BAD_STATE if the map changed since prepare. */
+int mmf_model_inputs_prepare(mmf_handle h, int mapper_id, const float* aabb_min_host, const float* aabb_max_host, int used_channels,
+                             int remove_zero_features, void* stream, int* num_kept);
+int mmf_model_inputs_gather(mmf_handle h, int mapper_id, const int64_t* rows_dev, int n_take, int n_out, float* vertices_out_dev,
+                            void* features_out_dev, int features_f32, uint8_t* valid_out_dev, void* stream);
+/* Host only (no device work): out[0..k) = torch.randperm(n)[:k] as drawn from torch's CPU default generator
+ * (sample_to_n_vertices, data_loading/vertex_sampling.py:143-145), given that generator's serialised state
+ * (torch.get_rng_state(): 5056 bytes), which is advanced in place by the n - 1 draws torch.randperm(n) makes -- in O(k) swaps
+ * plus the engine advance.  Returns MMF_ERR_INVALID_ARG for a state blob of another size / layout (caller then uses torch). */
+int mmf_host_randperm_prefix(uint8_t* torch_cpu_rng_state, int64_t state_bytes, int64_t n, int64_t k, int64_t* out_host);
 
 /* ---- layer views (nvblox_torch tsdf_layer_view / feature_layer_view; paper/utils/utils.py:101-121) */
 /* Number of allocated blocks; synchronises `stream`. */
@@ -163,6 +183,14 @@ int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* points_
  * T [B,4,4] f32 device -> out [B,3,H,W] f32.  Integer pixel coordinates (u = col, v = row). */
 int mmf_backproject_depth(const float* depth_dev, const float* K_dev, const float* T_dev, int B, int H, int W,
                           float* out_dev, void* stream);
+/* get_nvblox_inputs_from_sample, the per-frame image work   mapping/helpers/nvblox_input_helpers.py:57-69.
+ * rgb_chw_dev (3,H,W) f32 in [0,1] -> rgb_hwc_out_dev (H,W,3) u8 = (rgb * 255) truncated; and into small_out_dev[20] f32:
+ * {min(rgb), max(rgb), 1 if a NaN was seen, 0, camera pose [x,y,z,qw,qx,qy,qz], intrinsics row-major 3x3} -- what the helper
+ * needs on the host (its two range assertions, quat2mat, the K the mapper takes on the host), for ONE device->host copy.
+ * scratch_dev: mmf_sample_inputs_scratch_floats() floats. */
+int mmf_sample_inputs_scratch_floats(void);
+int mmf_sample_frame_inputs(const float* rgb_chw_dev, int H, int W, const float* pose7_dev, const float* K_dev, uint8_t* rgb_hwc_out_dev,
+                            float* small_out_dev, float* scratch_dev, void* stream);
 /* erode_mask(mask, kernel_size=3, iterations=k) (image_processing/image_mask_operations.py:16-41):
  * out = NOT dilate_{(2k+1)x(2k+1)}(NOT mask).  mask/out [H,W] u8 (0/1), tmp [H,W] u8 scratch. */
 int mmf_erode_mask(const uint8_t* mask_dev, uint8_t* out_dev, uint8_t* tmp_dev, int H, int W, int iterations, void* stream);

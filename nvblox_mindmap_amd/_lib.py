@@ -100,6 +100,9 @@ SIGNATURES = {
     "mmf_clear": (_I, [_VP, _I, _VP]),
     "mmf_update_feature_mesh": (_I, [_VP, _I, _VP, _PI]),
     "mmf_get_feature_mesh": (_I, [_VP, _I, _VP, _VP, _VP]),
+    "mmf_model_inputs_prepare": (_I, [_VP, _I, _VP, _VP, _I, _I, _VP, _PI]),
+    "mmf_model_inputs_gather": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _I, _VP, _VP]),
+    "mmf_host_randperm_prefix": (_I, [_VP, C.c_int64, C.c_int64, C.c_int64, _VP]),
     "mmf_num_allocated_blocks": (_I, [_VP, _I, _I, _VP, _PI]),
     "mmf_get_block_indices": (_I, [_VP, _I, _I, _VP, _I, _VP]),
     "mmf_get_tsdf_blocks": (_I, [_VP, _I, _VP, _I, _VP]),
@@ -110,6 +113,8 @@ SIGNATURES = {
     "mmf_import_blocks": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _VP]),
     "mmf_query_layer": (_I, [_VP, _I, _I, _VP, _I, _VP, _VP]),
     "mmf_backproject_depth": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "mmf_sample_inputs_scratch_floats": (_I, []),
+    "mmf_sample_frame_inputs": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mmf_erode_mask": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_feature_mask": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "mmf_depth_mask": (_I, [_VP, _VP, _I, _I, _F, _VP, _VP]),

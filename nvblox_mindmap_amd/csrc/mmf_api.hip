@@ -97,6 +97,14 @@ struct Mapper {
   int* mesh_tout2 = nullptr;
   int mesh_T = 0;
   long long mesh_tepoch = -1;
+  // map -> model inputs (mmf_model_inputs_prepare / _gather)
+  int* mi_counts = nullptr;   // [cap] kept vertices per live block
+  int* mi_chunk = nullptr;    // [cap] start of the block's chunk in mi_list
+  int* mi_offsets = nullptr;  // [cap] prefix sums of mi_counts (only maps with more live blocks than the gather kernel scans in LDS)
+  int* mi_total = nullptr;    // device int[2]: kept rows, live blocks
+  uint4* mi_list = nullptr;   // {x, y, z, feature voxel} of every kept vertex
+  int mi_list_cap = 0, mi_n = 0, mi_nblocks = 0, mi_used = 0;
+  long long mi_epoch = -1, mi_feat_frames = -1;
   // last view grid (diagnostics)
   ViewGrid last_vg{};
   int app_cap = 0;
@@ -466,6 +474,11 @@ void destroy_mapper(Mapper* m) {
   (void)hipFree(m->mesh_tcounts);
   (void)hipFree(m->mesh_toffsets);
   (void)hipFree(m->mesh_tout2);
+  (void)hipFree(m->mi_counts);
+  (void)hipFree(m->mi_chunk);
+  (void)hipFree(m->mi_total);
+  (void)hipFree(m->mi_offsets);
+  (void)hipFree(m->mi_list);
   delete m;
 }
 
@@ -1535,6 +1548,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     if (m->feat.allocated) launch_layer_reset(m->feat.d, s);
     m->tsdf_epoch++;
     m->mesh_epoch = -1;
+    m->mi_epoch = -1;
     m->touched = false;
     for (int q = 0; q < 8; ++q) m->hints[q] = 0;
   }
@@ -1578,6 +1592,81 @@ int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* verts, void* vfeat,
   {
     ProfScope ps(h, MMF_K_MESH, s);
     launch_mesh_emit(m->tsdf.d, F, m->mc, m->mesh_offsets, m->mesh_nblocks, verts, (__half*)vfeat, m->mesh_V, s);
+  }
+  return check_launch();
+}
+
+int mmf_model_inputs_prepare(mmf_handle h, int mapper_id, const float* lo, const float* hi, int used, int remove_zero, void* stream,
+                             int* num_kept) {
+  Mapper* m;
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
+  if (!lo || !hi || !num_kept) return fail(MMF_ERR_INVALID_ARG, "null argument");
+  if (used < 1 || used > m->mc.C) return fail(MMF_ERR_INVALID_ARG, "used_channels must be in 1 .. feature_channels");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!m->mi_counts) {
+    HIP_TRY(hipMalloc(&m->mi_counts, sizeof(int) * (size_t)m->mesh_cap));
+    HIP_TRY(hipMalloc(&m->mi_chunk, sizeof(int) * (size_t)m->mesh_cap));
+    HIP_TRY(hipMalloc(&m->mi_offsets, sizeof(int) * ((size_t)m->mesh_cap + 2)));
+    HIP_TRY(hipMalloc(&m->mi_total, sizeof(int) * 2));
+    m->mi_list_cap = 1 << 16;
+    HIP_TRY(hipMalloc(&m->mi_list, sizeof(uint4) * (size_t)m->mi_list_cap));
+  }
+  LayerDev F = m->feat.allocated ? m->feat.d : LayerDev{};
+  for (int attempt = 0;; ++attempt) {
+    HIP_TRY(hipMemsetAsync(m->mi_total, 0, sizeof(int), s));
+    {
+      ProfScope ps(h, MMF_K_MESH, s);
+      launch_mesh_keep(m->tsdf.d, F, m->mc, lo, hi, used, remove_zero ? 1 : 0, m->mi_counts, m->mi_chunk, m->mi_total, m->mi_list,
+                       m->mi_list_cap, s);
+    }
+    HIP_TRY(hipMemcpyAsync(h->pinned, m->mi_total, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->pinned + 11, m->tsdf.d.ctr + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m->mi_n = h->pinned[0];
+    m->mi_nblocks = h->pinned[1];
+    if (m->mi_n <= m->mi_list_cap) break;
+    if (attempt) return fail(MMF_ERR_BAD_STATE, "model inputs: vertex list overflow after growing it");
+    // more kept vertices than the list holds (they were counted, not stored): grow and run the pass again
+    (void)hipFree(m->mi_list);
+    m->mi_list = nullptr;
+    size_t cap = (size_t)m->mi_list_cap;
+    while (cap < (size_t)m->mi_n + (size_t)m->mi_n / 2) cap *= 2;
+    if (cap > ((size_t)1 << 30)) return fail(MMF_ERR_INVALID_ARG, "model inputs: too many vertices");
+    HIP_TRY(hipMalloc(&m->mi_list, sizeof(uint4) * cap));
+    m->mi_list_cap = (int)cap;
+  }
+  if (m->mi_nblocks > model_inputs_lds_blocks())  // maps with more live blocks than the gather kernel scans in LDS
+    launch_mesh_scan_counts(m->tsdf.d, m->mi_counts, m->mi_offsets, m->mi_offsets + m->mesh_cap, s);
+  m->mi_epoch = m->tsdf_epoch;
+  m->mi_feat_frames = m->frames[2];
+  m->mi_used = used;
+  *num_kept = m->mi_n;
+  {
+    const int bits = h->pinned[11] & 2;
+    MMF_TRY(report_device_errors(h, *m, &m->tsdf, &bits, s));
+  }
+  return check_launch();
+}
+
+int mmf_model_inputs_gather(mmf_handle h, int mapper_id, const int64_t* rows, int n_take, int n_out, float* verts, void* feats,
+                            int features_f32, uint8_t* valid, void* stream) {
+  Mapper* m;
+  MMF_TRY(get_mapper(h, mapper_id, &m));
+  if (m->mi_epoch != m->tsdf_epoch || m->mi_feat_frames != m->frames[2] || m->pending_decay)
+    return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_model_inputs_prepare; call it again");
+  if (n_take < 0 || n_out < n_take) return fail(MMF_ERR_INVALID_ARG, "need 0 <= n_take <= n_out");
+  if (!rows && n_take > m->mi_n) return fail(MMF_ERR_INVALID_ARG, "n_take exceeds the kept rows");
+  if (n_take > 0 && m->mi_n == 0) return fail(MMF_ERR_INVALID_ARG, "no kept rows to take from");
+  if (n_out == 0) return MMF_OK;
+  if (!verts) return fail(MMF_ERR_INVALID_ARG, "null vertex buffer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  LayerDev F = m->feat.allocated ? m->feat.d : LayerDev{};
+  {
+    ProfScope ps(h, MMF_K_MESH, s);
+    launch_model_inputs_gather(m->mi_counts, m->mi_chunk, m->mi_offsets, m->mi_nblocks, m->mi_list, F, m->mc.C, m->mi_used,
+                               (const long long*)rows, n_take, n_out, verts, feats, features_f32 != 0, valid, s);
   }
   return check_launch();
 }
@@ -1711,6 +1800,7 @@ int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx
     m->touched = m->touched || n > 0;
     m->tsdf_epoch++;
     m->mesh_epoch = -1;
+    m->mi_epoch = -1;
   }
   // out-of-range indices are flagged on the device; report them now (loading is not a hot path)
   HIP_TRY(hipStreamSynchronize(s));
@@ -1745,6 +1835,16 @@ int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* pts, in
 int mmf_backproject_depth(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, void* stream) {
   if (!depth || !K || !T || !out || B < 0 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_backproject_depth");
   launch_backproject(depth, K, T, B, H, W, out, (hipStream_t)stream);
+  return check_launch();
+}
+
+int mmf_sample_inputs_scratch_floats(void) { return sample_inputs_scratch_floats(); }
+
+int mmf_sample_frame_inputs(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_hwc_out, float* small_out,
+                            float* scratch, void* stream) {
+  if (!rgb_chw || !pose7 || !K9 || !rgb_hwc_out || !small_out || !scratch || H <= 0 || W <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_sample_frame_inputs");
+  launch_sample_inputs(rgb_chw, H, W, pose7, K9, rgb_hwc_out, small_out, scratch, (hipStream_t)stream);
   return check_launch();
 }
 

@@ -83,6 +83,131 @@ __global__ __launch_bounds__(256) void k_backproject(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------
+// Loader sample -> frame inputs (mapping/helpers/nvblox_input_helpers.py:57-69): rgb (3,H,W) float in [0,1] ->
+// (H,W,3) uint8 as `(rgb * 255).to(torch.uint8)` (truncation), plus what the helper needs ON THE HOST, gathered into one
+// 20-float record so that a single device->host copy (one synchronisation) serves it: the operands of its two range
+// assertions (min, max, "a NaN was seen"), the camera pose 7-vector and the 3x3 intrinsics.
+// 12 B read + 3 B written per pixel.  k_rgb_u8: 4 pixels per thread (three 16 B loads, three 4 B stores) when H*W % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_rgb_u8(const float* __restrict__ rgb, size_t HW, uint8_t* __restrict__ out,
+                                               float* __restrict__ partial) {
+  __shared__ float s_lo[4], s_hi[4];
+  __shared__ int s_nan[4];
+  float lo = INFINITY, hi = -INFINITY;
+  int nan = 0;
+  for (size_t p0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; p0 < HW; p0 += (size_t)gridDim.x * 256 * VEC) {
+    float c[3][VEC];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      if (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(rgb + ch * HW + p0);
+        c[ch][0] = v.x;
+        c[ch][VEC > 1 ? 1 : 0] = v.y;
+        c[ch][VEC > 2 ? 2 : 0] = v.z;
+        c[ch][VEC > 3 ? 3 : 0] = v.w;
+      } else {
+        c[ch][0] = rgb[ch * HW + p0];
+      }
+    }
+    uint8_t b[3 * VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float v = c[ch][k];
+        nan |= (v != v) ? 1 : 0;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+        const float s = v * 255.0f;
+        b[3 * k + ch] = (uint8_t)(int)(s < 0.0f ? 0.0f : (s > 255.0f ? 255.0f : s));  // (out of range only if the assertion fails anyway)
+      }
+    if (VEC == 4) {
+      unsigned w[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        w[q] = (unsigned)b[(4 * q) % (3 * VEC)] | ((unsigned)b[(4 * q + 1) % (3 * VEC)] << 8) | ((unsigned)b[(4 * q + 2) % (3 * VEC)] << 16) |
+               ((unsigned)b[(4 * q + 3) % (3 * VEC)] << 24);
+      unsigned* o = reinterpret_cast<unsigned*>(out + 3 * p0);
+      o[0] = w[0];
+      o[1] = w[1];
+      o[2] = w[2];
+    } else {
+      out[3 * p0] = b[0];
+      out[3 * p0 + 1] = b[1 % (3 * VEC)];
+      out[3 * p0 + 2] = b[2 % (3 * VEC)];
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, d, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, d, 64));
+    nan |= __shfl_xor(nan, d, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+    s_nan[wave] = nan;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[3 * blockIdx.x] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    partial[3 * blockIdx.x + 1] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    partial[3 * blockIdx.x + 2] = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? 1.0f : 0.0f;
+  }
+}
+
+// one workgroup: small[0..3] = {min, max, saw NaN, 0}, small[4..10] = pose, small[11..19] = K
+__global__ __launch_bounds__(256) void k_sample_small(const float* __restrict__ partial, int n_partial, const float* __restrict__ pose7,
+                                                     const float* __restrict__ K9, float* __restrict__ small) {
+  __shared__ float s_lo[4], s_hi[4], s_nan[4];
+  float lo = INFINITY, hi = -INFINITY, nan = 0.0f;
+  for (int i = threadIdx.x; i < n_partial; i += 256) {
+    lo = fminf(lo, partial[3 * i]);
+    hi = fmaxf(hi, partial[3 * i + 1]);
+    nan = fmaxf(nan, partial[3 * i + 2]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, d, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, d, 64));
+    nan = fmaxf(nan, __shfl_xor(nan, d, 64));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+    s_nan[wave] = nan;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    small[0] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    small[1] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    small[2] = fmaxf(fmaxf(s_nan[0], s_nan[1]), fmaxf(s_nan[2], s_nan[3]));
+    small[3] = 0.0f;
+  }
+  if (threadIdx.x < 7) small[4 + threadIdx.x] = pose7[threadIdx.x];
+  if (threadIdx.x >= 64 && threadIdx.x < 73) small[11 + threadIdx.x - 64] = K9[threadIdx.x - 64];
+}
+
+int sample_inputs_scratch_floats() { return 3 * 1024; }
+
+void launch_sample_inputs(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_out, float* small,
+                          float* scratch, hipStream_t s) {
+  const size_t HW = (size_t)H * W;
+  const bool vec = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(rgb_chw) & 15) == 0 && (reinterpret_cast<uintptr_t>(rgb_out) & 3) == 0;
+  const size_t per = vec ? 1024 : 256;
+  int g = (int)((HW + per - 1) / per);
+  g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+  if (vec)
+    hipLaunchKernelGGL(k_rgb_u8<4>, dim3(g), dim3(256), 0, s, rgb_chw, HW, rgb_out, scratch);
+  else
+    hipLaunchKernelGGL(k_rgb_u8<1>, dim3(g), dim3(256), 0, s, rgb_chw, HW, rgb_out, scratch);
+  hipLaunchKernelGGL(k_sample_small, dim3(1), dim3(256), 0, s, (const float*)scratch, g, pose7, K9, small);
+}
+
+// ------------------------------------------------------------------------------------------------
 // erode_mask (image_processing/image_mask_operations.py:16-41): k iterations of a zero-padded 3x3
 // max-pool on the inverted mask == one (2k+1)x(2k+1) square dilation of the inverted mask, done
 // separably: row pass into tmp, column pass out.  Pixels outside the image never contribute.

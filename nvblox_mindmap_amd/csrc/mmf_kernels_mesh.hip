@@ -237,6 +237,263 @@ void launch_mesh_emit(const LayerDev& tsdf, const LayerDev& feat, const MapConst
 }
 
 // ------------------------------------------------------------------------------------------------
+// Map -> model-input tensors in two launches (mmf_model_inputs_prepare / _gather): what the reference does as
+// update_feature_mesh + get_feature_mesh + three boolean-mask copies of the [V, C_pad] feature matrix + the final row
+// selection (mindmap/mapping/helpers/nvblox_output_helpers.py:49-91) -- without materialising a feature row that is not kept.
+//
+// k_mesh_keep (workgroup per live TSDF block, lattice staged once): the block's vertices in canonical order -> strict AABB
+// test (:57-60) -> feature voxel of each vertex -> "row has a non-zero used channel" test (:68-74; 8 lanes per row, 16 B
+// pieces, stops at the first non-zero piece: one 128 B line per vertex in practice) -> the kept vertices {x, y, z, feature
+// voxel} are appended, in order, to a chunk of the list reserved with ONE atomic per block; counts[i] / chunk[i] record it.
+// The atomic counter's final value is the number of kept rows -- the only number the host needs (for its RNG draw).
+// k_model_inputs_gather: rank r of the kept rows (ranks follow block order, then canonical vertex order: the order of the
+// reference's filtered mesh) is found by a search in the prefix sums of counts (LDS) and its row written as f32 / f16.
+// ------------------------------------------------------------------------------------------------
+struct KeepArgs {
+  float lo[3], hi[3];
+  int used;         // leading feature channels the model uses (C - num_excess_features)
+  int remove_zero;  // drop vertices whose used channels are all zero (incl. vertices without a feature voxel)
+};
+
+__global__ __launch_bounds__(256) void k_mesh_keep(LayerDev T, LayerDev F, MapConsts mc, KeepArgs ka, int* __restrict__ counts,
+                                                  int* __restrict__ chunk, int* __restrict__ total, uint4* __restrict__ list,
+                                                  int list_cap) {
+  __shared__ MeshLds m;
+  __shared__ int s_vox[kEdges];        // feature voxel of vertex k of the block; -1 none, -2 vertex dropped
+  __shared__ float s_pos[3 * kEdges];
+  __shared__ int s_base;
+  const int n = T.ctr[0];
+  const int C = mc.C;
+  const int group = threadIdx.x >> 3, gl = threadIdx.x & 7, lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) total[1] = n;  // the host reads {kept rows, live blocks} in one copy
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = T.live[i];
+    int bx, by, bz;
+    unpack_key(T.slot_key[slot], bx, by, bz);
+    load_lattice(T, mc, slot, bx, by, bz, m);
+    int cnt = 0;
+    const int e0 = threadIdx.x * kEdgesPerThread;
+    for (int k = 0; k < kEdgesPerThread; ++k) {
+      const int e = e0 + k;
+      if (e >= kEdges) break;
+      int qx, qy, qz, a;
+      float t;
+      cnt += edge_vertex(m, e, qx, qy, qz, a, t) ? 1 : 0;
+    }
+    int ea, eb, nv, tb;
+    block_excl_scan2<4>(cnt, 0, m.scan, ea, eb, nv, tb);
+    if (nv == 0) {  // (uniform) most live blocks are free space
+      if (threadIdx.x == 0) {
+        counts[i] = 0;
+        chunk[i] = 0;
+      }
+      continue;
+    }
+    if (cnt > 0) {
+      int local = ea;
+      for (int k = 0; k < kEdgesPerThread; ++k) {
+        const int e = e0 + k;
+        if (e >= kEdges) break;
+        int qx, qy, qz, a;
+        float t;
+        if (!edge_vertex(m, e, qx, qy, qz, a, t)) continue;
+        // same position arithmetic as k_mesh_emit (the vertices of get_feature_mesh, bit for bit)
+        float pos[3] = {(float)bx * mc.bs + ((float)qx + 0.5f) * mc.v, (float)by * mc.bs + ((float)qy + 0.5f) * mc.v,
+                        (float)bz * mc.bs + ((float)qz + 0.5f) * mc.v};
+        const int qa = a == 0 ? qx : (a == 1 ? qy : qz);
+        const int ba = a == 0 ? bx : (a == 1 ? by : bz);
+        const float pa = a == 0 ? pos[0] : (a == 1 ? pos[1] : pos[2]);
+        const float pb = (float)ba * mc.bs + ((float)(qa + 1) + 0.5f) * mc.v;
+        const float pn = pa + t * (pb - pa);
+        if (a == 0) pos[0] = pn;
+        else if (a == 1) pos[1] = pn;
+        else pos[2] = pn;
+        const bool inside = pos[0] > ka.lo[0] && pos[0] < ka.hi[0] && pos[1] > ka.lo[1] && pos[1] < ka.hi[1] && pos[2] > ka.lo[2] &&
+                            pos[2] < ka.hi[2];  // strict on both sides, like the reference
+        int fv = -2;
+        if (inside) {
+          fv = -1;
+          if (F.pool) {
+            int lin;
+            const u64 key = voxel_at(mc, pos, lin);
+            const int fs = layer_lookup(F, key);
+            if (fs >= 0 && F.poolw[(size_t)fs * kVPB + lin] > 0.0f) fv = fs * kVPB + lin;
+          }
+          if (fv < 0 && ka.remove_zero) fv = -2;  // no feature voxel: an all-zero row
+        }
+        s_vox[local] = fv;
+        s_pos[3 * local] = pos[0];
+        s_pos[3 * local + 1] = pos[1];
+        s_pos[3 * local + 2] = pos[2];
+        local++;
+      }
+    }
+    __syncthreads();
+    if (ka.remove_zero) {
+      for (int v0 = 0; v0 < nv; v0 += 32) {
+        const int vi = v0 + group;
+        const int fv = vi < nv ? s_vox[vi] : -2;
+        if (fv >= 0) {  // (uniform over the 8 lanes of a group)
+          const unsigned short* row = reinterpret_cast<const unsigned short*>(F.pool) + (size_t)fv * C;
+          bool nzrow = false;
+          for (int p0 = 0; 8 * p0 < ka.used && !nzrow; p0 += 8) {
+            const int p = p0 + gl;
+            bool nz = false;
+            if (8 * p < ka.used) {
+              const uint4 q = *reinterpret_cast<const uint4*>(row + 8 * p);
+              const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {  // -0.0 == 0, like `!= 0` on the half values
+                if ((w[j] & 0x7fffu) != 0u && 8 * p + 2 * j < ka.used) nz = true;
+                if ((w[j] & 0x7fff0000u) != 0u && 8 * p + 2 * j + 1 < ka.used) nz = true;
+              }
+            }
+            const unsigned long long b = __ballot(nz);
+            nzrow = ((b >> (lane & ~7)) & 0xffull) != 0ull;
+          }
+          if (gl == 0 && !nzrow) s_vox[vi] = -2;
+        }
+      }
+      __syncthreads();
+    }
+    int kc = 0;
+    for (int k = 0; k < cnt; ++k) kc += s_vox[ea + k] != -2 ? 1 : 0;
+    int ka_off, kb_off, ktot, ktb;
+    block_excl_scan2<4>(kc, 0, m.scan, ka_off, kb_off, ktot, ktb);
+    if (threadIdx.x == 0) {
+      const int base = ktot > 0 ? atomicAdd(total, ktot) : 0;
+      s_base = base;
+      counts[i] = ktot;
+      chunk[i] = base;
+    }
+    __syncthreads();
+    int o = s_base + ka_off;
+    for (int k = 0; k < cnt; ++k) {
+      const int fv = s_vox[ea + k];
+      if (fv == -2) continue;
+      if (o < list_cap)
+        list[o] = make_uint4(__float_as_uint(s_pos[3 * (ea + k)]), __float_as_uint(s_pos[3 * (ea + k) + 1]),
+                             __float_as_uint(s_pos[3 * (ea + k) + 2]), (unsigned)fv);
+      o++;
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kGatherLdsBlocks = 8192;  // prefix sums of up to this many live blocks are rebuilt in LDS by every workgroup
+
+// rows: ranks (int64) among the kept vertices, or null = identity.  Output row j < n_take = kept vertex rows[j];
+// rows n_take <= j < n_out are zero padding (valid 0).  32 lanes per row, 8 channels per lane and step.
+template <bool F32>
+__global__ __launch_bounds__(256) void k_model_inputs_gather(const int* __restrict__ counts, const int* __restrict__ chunk,
+                                                            const int* __restrict__ goffsets, int n_blocks,
+                                                            const uint4* __restrict__ list, LayerDev F, int C, int U,
+                                                            const long long* __restrict__ rows, int n_take, int n_out,
+                                                            float* __restrict__ verts, void* __restrict__ feats,
+                                                            uint8_t* __restrict__ valid) {
+  __shared__ int s_off[kGatherLdsBlocks + 1];
+  __shared__ int s_scan[10];
+  const bool in_lds = goffsets == nullptr;
+  if (in_lds) {
+    // exclusive prefix sums of counts: a thread owns a run of consecutive blocks
+    const int per = (n_blocks + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) sum += (b0 + k < n_blocks) ? counts[b0 + k] : 0;
+    int ea, eb, ta, tb;
+    block_excl_scan2<4>(sum, 0, s_scan, ea, eb, ta, tb);
+    int run = ea;
+    for (int k = 0; k < per; ++k) {
+      if (b0 + k < n_blocks) {
+        s_off[b0 + k] = run;
+        run += counts[b0 + k];
+      }
+    }
+    if (threadIdx.x == 0) s_off[n_blocks] = ta;
+    __syncthreads();
+  }
+  const int* off = in_lds ? s_off : goffsets;
+  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+  for (int j = blockIdx.x * 8 + g; j < n_out; j += gridDim.x * 8) {
+    uint4 e = make_uint4(0u, 0u, 0u, 0xffffffffu);
+    const bool take = j < n_take;
+    if (take) {
+      const int r = rows ? (int)rows[j] : j;
+      int lo = 0, hi = n_blocks;  // largest b with off[b] <= r (blocks without kept vertices share their successor's offset)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= r) lo = mid;
+        else hi = mid;
+      }
+      e = list[chunk[lo] + (r - off[lo])];
+    }
+    if (l < 3) verts[3 * (size_t)j + l] = __uint_as_float(l == 0 ? e.x : (l == 1 ? e.y : e.z));
+    if (l == 3 && valid) valid[j] = take ? 1 : 0;
+    if (!feats) continue;
+    const int fv = (int)e.w;
+    const __half* src = fv >= 0 ? reinterpret_cast<const __half*>(F.pool) + (size_t)fv * C : nullptr;
+    for (int c0 = 8 * l; c0 < U; c0 += 256) {
+      half8 h;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) h[k] = (_Float16)0.0f;
+      if (src) h = *reinterpret_cast<const half8*>(src + c0);  // C is a multiple of 8 and c0 < U <= C: in range
+      if (F32) {
+        float* dst = reinterpret_cast<float*>(feats) + (size_t)j * U + c0;
+        if (c0 + 8 <= U && (U & 3) == 0) {
+          *reinterpret_cast<float4*>(dst) = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+        } else {
+          for (int k = 0; k < 8 && c0 + k < U; ++k) dst[k] = (float)h[k];
+        }
+      } else {
+        __half* dst = reinterpret_cast<__half*>(feats) + (size_t)j * U + c0;
+        if (c0 + 8 <= U && (U & 7) == 0) {
+          *reinterpret_cast<half8*>(dst) = h;
+        } else {
+          for (int k = 0; k < 8 && c0 + k < U; ++k) reinterpret_cast<_Float16*>(dst)[k] = h[k];
+        }
+      }
+    }
+  }
+}
+
+void launch_mesh_keep(const LayerDev& tsdf, const LayerDev& feat, const MapConsts& mc, const float* lo, const float* hi, int used,
+                      int remove_zero, int* counts, int* chunk, int* total, uint4* list, int list_cap, hipStream_t s) {
+  KeepArgs ka;
+  for (int a = 0; a < 3; ++a) {
+    ka.lo[a] = lo[a];
+    ka.hi[a] = hi[a];
+  }
+  ka.used = used;
+  ka.remove_zero = remove_zero;
+  int g = hinted(tsdf.hint_live, tsdf.cap);
+  g = g < 8192 ? g : 8192;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_mesh_keep, dim3(g), dim3(256), 0, s, tsdf, feat, mc, ka, counts, chunk, total, list, list_cap);
+}
+
+// offsets: device prefix sums of counts (k_mesh_scan) -- required when n_blocks > kGatherLdsBlocks, else pass null
+void launch_model_inputs_gather(const int* counts, const int* chunk, const int* offsets, int n_blocks, const uint4* list,
+                                const LayerDev& feat, int C, int used, const long long* rows, int n_take, int n_out, float* verts,
+                                void* feats, bool f32, uint8_t* valid, hipStream_t s) {
+  if (n_out <= 0) return;
+  int g = (n_out + 7) / 8;
+  g = g < 2048 ? g : 2048;
+  const int* goff = n_blocks > kGatherLdsBlocks ? offsets : nullptr;
+  if (f32)
+    hipLaunchKernelGGL(k_model_inputs_gather<true>, dim3(g), dim3(256), 0, s, counts, chunk, goff, n_blocks, list, feat, C, used, rows,
+                       n_take, n_out, verts, feats, valid);
+  else
+    hipLaunchKernelGGL(k_model_inputs_gather<false>, dim3(g), dim3(256), 0, s, counts, chunk, goff, n_blocks, list, feat, C, used, rows,
+                       n_take, n_out, verts, feats, valid);
+}
+
+int model_inputs_lds_blocks() { return kGatherLdsBlocks; }
+void launch_mesh_scan_counts(const LayerDev& tsdf, const int* counts, int* offsets, int* out2, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_scan, dim3(1), dim3(256), 0, s, tsdf, counts, offsets, out2);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Triangle connectivity + per-vertex colour (Mapper.get_color_mesh / FeatureMesh.triangles(), consumed by the
 // reference's visualiser: visualization/visualizer.py:656-672, paper/utils/utils.py:84-92).  Not on the per-frame path.
 // Per block: the vertex walk of k_mesh_emit gives every lattice edge its vertex index (LDS, u16); the 512 cubes, two per

@@ -217,12 +217,24 @@ void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, i
 void launch_mesh_emit(const LayerDev& tsdf, const LayerDev& feat, const MapConsts& mc, const int* offsets, int n_blocks,
                       float* verts, __half* vfeat, int V, hipStream_t s);
 
+// map -> model inputs (mmf_model_inputs_prepare / _gather): total = device int[2] {kept rows (zero before the launch), live blocks}
+void launch_mesh_keep(const LayerDev& tsdf, const LayerDev& feat, const MapConsts& mc, const float* lo, const float* hi, int used,
+                      int remove_zero, int* counts, int* chunk, int* total, uint4* list, int list_cap, hipStream_t s);
+void launch_model_inputs_gather(const int* counts, const int* chunk, const int* offsets, int n_blocks, const uint4* list,
+                                const LayerDev& feat, int C, int used, const long long* rows, int n_take, int n_out, float* verts,
+                                void* feats, bool f32, uint8_t* valid, hipStream_t s);
+int model_inputs_lds_blocks();
+void launch_mesh_scan_counts(const LayerDev& tsdf, const int* counts, int* offsets, int* out2, hipStream_t s);
+
 void launch_mesh_tri_count(const LayerDev& tsdf, const MapConsts& mc, int* tcounts, int* toffsets, int* out2, hipStream_t s);
 void launch_mesh_tri_emit(const LayerDev& tsdf, const LayerDev& color, const MapConsts& mc, const int* voffsets, const int* toffsets,
                           int n_blocks, int32_t* tris, uint8_t* vcolors, int V, int Tn, hipStream_t s);
 
 // mmf_kernels_image.hip
 void launch_backproject(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, hipStream_t s);
+int sample_inputs_scratch_floats();
+void launch_sample_inputs(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_out, float* small,
+                          float* scratch, hipStream_t s);
 void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int k, hipStream_t s);
 void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
                          int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, hipStream_t s);

@@ -6,6 +6,22 @@ from typing import Optional, Tuple
 
 import torch
 
+from .. import _lib
+
+
+def randperm_prefix(n: int, k: int) -> torch.Tensor:
+    """``torch.randperm(n)[:k]`` (CPU default generator; int64, host) with the same draws and the same generator state
+    afterwards, in O(k) swaps: ``mmf_host_randperm_prefix`` advances torch's own serialised generator state.  A generator
+    whose serialised state is not the 5056-byte mt19937 layout is left to ``torch.randperm``."""
+    state = torch.get_rng_state()
+    k = min(int(k), int(n))
+    out = torch.empty(k, dtype=torch.int64)
+    rc = _lib.lib().mmf_host_randperm_prefix(state.data_ptr(), state.numel(), int(n), k, out.data_ptr())
+    if rc != 0:
+        return torch.randperm(n)[:k]
+    torch.set_rng_state(state)
+    return out
+
 
 class VertexSamplingMethod(Enum):
     RANDOM_WITHOUT_REPLACEMENT = "random_without_replacement"
@@ -22,7 +38,7 @@ def select_vertex_indices(n: int, desired_num_vertices: int, method: VertexSampl
         if seed is not None:
             torch.manual_seed(seed)
         # CPU default generator, exactly like the reference (vertex_sampling.py:143-145)
-        return torch.randperm(n)[:desired_num_vertices].to(device)
+        return randperm_prefix(n, desired_num_vertices).to(device)
     if method == VertexSamplingMethod.RANDOM_WITH_REPLACEMENT:
         if seed is not None:
             torch.manual_seed(seed)

@@ -12,6 +12,7 @@ from typing import Dict, List, Tuple
 
 import torch
 
+from ... import _lib
 from ...geometry.transforms import _pose_to_homo_host
 from ...image_processing.backprojection import _backproject_chw
 
@@ -55,6 +56,76 @@ def get_nvblox_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index:
     pointcloud = _backproject_chw(depth_frame.unsqueeze(0), intrinsics.unsqueeze(0),
                                   camera_pose_homo.to(depth_frame.device, non_blocking=True).unsqueeze(0)).squeeze(0)
     return (depth_frame, intrinsics, camera_pose_homo, rgb, dynamic_mask, pointcloud)
+
+
+class _SampleScratch:
+    """Per-device buffers of ``frame_inputs_from_sample``: the 20-float record (device + pinned host) and kernel scratch."""
+
+    _by_device = {}
+
+    def __init__(self, device):
+        n = _lib.lib().mmf_sample_inputs_scratch_floats()
+        self.small = torch.empty(20, dtype=torch.float32, device=device)
+        self.scratch = torch.empty(n, dtype=torch.float32, device=device)
+        self.host = torch.empty(20, dtype=torch.float32).pin_memory()
+
+    @classmethod
+    def of(cls, device):
+        key = (device.type, device.index)
+        if key not in cls._by_device:
+            cls._by_device[key] = cls(device)
+        return cls._by_device[key]
+
+
+def frame_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index: int):
+    """``get_nvblox_inputs_from_sample`` for a caller that integrates the frame at once (the facade): same checks, same
+    values, but ONE native call (rgb -> uint8 HWC, the range check's operands, pose and intrinsics gathered into one record)
+    and ONE device->host copy instead of three synchronising reads (pose, range check, intrinsics); the intrinsics come back
+    ON THE HOST like the pose (the mapper takes both there), and the world-frame point cloud -- read by the visualiser only --
+    as a function that computes it on first use.
+    Returns (depth_frame, intrinsics (3,3) host, camera_pose (4,4) host, rgb (H,W,3) u8, dynamic_mask, pointcloud_fn)."""
+    num_cams = sample["depths"].shape[1]
+    assert camera_index < num_cams
+    H, W = sample["depths"].shape[-2:]
+    assert sample["depths"].shape == torch.Size([1, num_cams, H, W])
+    assert sample["depths"].dtype == torch.float32
+    assert sample["intrinsics"].shape == torch.Size([1, num_cams, 3, 3]), f"intrinsics shape is {sample['intrinsics'].shape}"
+    assert sample["intrinsics"].dtype == torch.float32
+    assert sample["camera_poses"].shape == torch.Size([1, num_cams, 7]), f"camera_poses shape is {sample['camera_poses'].shape}"
+    assert sample["camera_poses"].dtype == torch.float32
+    assert sample["rgbs"].shape == torch.Size([1, num_cams, 3, H, W]), f"rgbs shape is {sample['rgbs'].shape}"
+    assert sample["rgbs"].dtype == torch.float32
+    assert sample["segmentation_masks"].shape == torch.Size([1, num_cams, H, W])
+    assert sample["segmentation_masks"].dtype == torch.bool
+    depth_frame = sample["depths"][0, camera_index]
+    dynamic_mask = sample["segmentation_masks"][0, camera_index]
+    rgb_chw = sample["rgbs"][0, camera_index]
+    pose7 = sample["camera_poses"][0, camera_index]
+    k_dev = sample["intrinsics"][0, camera_index]
+    if not (rgb_chw.is_cuda and rgb_chw.is_contiguous() and pose7.is_contiguous() and k_dev.is_contiguous()):
+        d, K, T, rgb, dyn, pcd = get_nvblox_inputs_from_sample(sample, camera_index)
+        return d, K.detach().to("cpu"), T, rgb, dyn, (lambda: pcd)
+    dev = rgb_chw.device
+    sc = _SampleScratch.of(dev)
+    rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().mmf_sample_frame_inputs(_lib.dptr(rgb_chw), H, W, _lib.dptr(pose7), _lib.dptr(k_dev), _lib.dptr(rgb),
+                                                  _lib.dptr(sc.small), _lib.dptr(sc.scratch), _lib.stream_ptr(dev.index)),
+               "mmf_sample_frame_inputs")
+    sc.host.copy_(sc.small, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    rec = sc.host.numpy().copy()
+    # the reference's two range assertions (:68); a NaN fails them like it fails `min() >= 0`
+    assert rec[2] == 0.0 and rec[0] >= 0 and rec[1] <= 1
+    if num_cams > 1:  # the reference checks the range over every camera of the sample
+        lo_hi = torch.stack(torch.aminmax(sample["rgbs"])).tolist()
+        assert lo_hi[0] >= 0 and lo_hi[1] <= 1
+    camera_pose_homo = torch.from_numpy(_pose_to_homo_host(rec[4:11]))
+    intrinsics = torch.from_numpy(rec[11:20].reshape(3, 3))
+
+    def pointcloud():  # get_camera_pointcloud(intrinsics, depth, position, orientation) (:76-81), on first use
+        return _backproject_chw(depth_frame.unsqueeze(0), k_dev.unsqueeze(0), camera_pose_homo.to(dev).unsqueeze(0)).squeeze(0)
+
+    return depth_frame, intrinsics, camera_pose_homo, rgb, dynamic_mask, pointcloud
 
 
 def get_nvblox_inputs_from_camera_handler(camera_handler, dynamic_class_labels: List[str]

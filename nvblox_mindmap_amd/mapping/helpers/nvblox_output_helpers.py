@@ -3,7 +3,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ...data_loading.vertex_sampling import VertexSamplingMethod, sample_to_n_vertices, select_vertex_indices
+from ...data_loading.vertex_sampling import VertexSamplingMethod, select_vertex_indices
 from ...nvblox_torch.mapper import Mapper
 from ..nvblox_mapper_constants import NvbloxMappingCfg
 
@@ -11,37 +11,39 @@ from ..nvblox_mapper_constants import NvbloxMappingCfg
 def get_vertices_and_features(mapper: Mapper, mapper_id: int, nvblox_mapping_config: NvbloxMappingCfg,
                               remove_zero_features: bool, num_excess_features: int, sample_vertices: bool,
                               number_of_vertices_to_sample: Optional[int] = None,
-                              vertex_sampling_method: Optional[VertexSamplingMethod] = None
+                              vertex_sampling_method: Optional[VertexSamplingMethod] = None,
+                              features_dtype: Optional[torch.dtype] = None
                               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Surface vertices + features, AABB-filtered (strict), zero-pad channels stripped, all-zero rows dropped,
-    then sampled / padded to N."""
-    mapper.update_feature_mesh(mapper_id)
-    mesh = mapper.get_feature_mesh(mapper_id)
-    vertices = mesh.vertices()
-    features = mesh.vertex_features()
-    assert vertices.shape[0] == features.shape[0]
-    assert vertices.shape[0] != 0, "No vertices found in the mesh."
-    assert vertices.is_cuda and features.is_cuda
+    then sampled / padded to N (nvblox_output_helpers.py:22-91).
 
-    # One combined row filter over the ORIGINAL mesh rows, then ONE gather -- same rows, same order and same RNG draws as the
-    # reference's chain of boolean-mask copies (nvblox_output_helpers.py:57-74: AABB, strip the pad channels, drop all-zero
-    # rows), without copying the whole [V, C] feature matrix twice (80 MB at V = 26 k, C = 768).
-    lo = nvblox_mapping_config.aabb_min_m.to(vertices.device)
-    hi = nvblox_mapping_config.aabb_max_m.to(vertices.device)
-    keep = ((vertices > lo) & (vertices < hi)).all(dim=1)  # strict on both sides
-    used = features[..., :-num_excess_features] if num_excess_features > 0 else features
-    if remove_zero_features:
-        keep &= (used != 0).any(dim=1)
-    rows = torch.nonzero(keep).squeeze(1)
+    Two native launches (``Mapper.model_inputs_prepare`` / ``model_inputs_gather``): the row filters run inside the mesh
+    extraction, only the rows that are returned are ever gathered -- the [V, C_pad] matrix of the reference's
+    ``mesh.vertex_features()`` (66 MB at V = 43 k, C = 768) and its three boolean-mask copies never exist.  Same rows, same
+    order, same RNG draws as the reference (the random selection stays on the host generator).  ``features_dtype``:
+    float16 like ``mesh.vertex_features()`` (default) or float32 (what the model takes: the facade's cast, fused)."""
+    cfg = nvblox_mapping_config
+    dtype = torch.float16 if features_dtype is None else features_dtype
+    used = mapper.feature_channels - int(num_excess_features)
+    n = mapper.model_inputs_prepare(mapper_id, cfg.aabb_min_host, cfg.aabb_max_host, used, remove_zero_features)
+    # the reference asserts on the unfiltered mesh (:53-55) and would then index an empty tensor; an empty filtered mesh is
+    # reported here the same way
+    assert n != 0, "No vertices found in the mesh."
 
     if not sample_vertices:
         # the reference hands back un-batched rows with a [1, V] mask in this case (:76-80)
-        return vertices[rows], used[rows], torch.ones((1, rows.shape[0]), dtype=torch.bool, device=vertices.device)
+        v, f, valid = mapper.model_inputs_gather(mapper_id, None, n, n, dtype)
+        return v, f, valid.unsqueeze(0)
 
-    n, want = int(rows.shape[0]), number_of_vertices_to_sample
-    if n > want and vertex_sampling_method != VertexSamplingMethod.NONE:
-        z = vertices[rows, 2] if vertex_sampling_method == VertexSamplingMethod.LOWEST else None
-        rows = rows[select_vertex_indices(n, want, vertex_sampling_method, vertices.device, z=z)]
-    # n <= want (pad + mask), NONE, or already exactly `want` rows: sample_to_n_vertices finishes the job without drawing
-    v, f, valid_mask = sample_to_n_vertices(vertices[rows], used[rows], want, vertex_sampling_method)
-    return v.unsqueeze(0), f.unsqueeze(0), valid_mask.unsqueeze(0)
+    want, method = number_of_vertices_to_sample, vertex_sampling_method
+    if method == VertexSamplingMethod.NONE or n == want:
+        v, f, valid = mapper.model_inputs_gather(mapper_id, None, n, n, dtype)  # sample_to_n_vertices passes these through
+    elif n > want:
+        z = None
+        if method == VertexSamplingMethod.LOWEST:
+            z = mapper.model_inputs_gather(mapper_id, None, n, n, None)[0][:, 2]
+        rows = select_vertex_indices(n, want, method, mapper.device, z=z)
+        v, f, valid = mapper.model_inputs_gather(mapper_id, rows, want, want, dtype)
+    else:
+        v, f, valid = mapper.model_inputs_gather(mapper_id, None, n, want, dtype)  # zero rows + mask behind the n real ones
+    return v.unsqueeze(0), f.unsqueeze(0), valid.unsqueeze(0)

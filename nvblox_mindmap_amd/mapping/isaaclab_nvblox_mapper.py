@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from ..data_loading.vertex_sampling import VertexSamplingMethod
 from ..image_processing.feature_resize import upsample_features
-from .helpers.nvblox_input_helpers import get_nvblox_inputs_from_camera_handler, get_nvblox_inputs_from_sample
+from .helpers.nvblox_input_helpers import frame_inputs_from_sample, get_nvblox_inputs_from_camera_handler
 from .helpers.nvblox_mapping_helpers import get_nvblox_mapper, nvblox_integrate
 from .helpers.nvblox_output_helpers import get_vertices_and_features
 from .helpers.nvblox_to_disk_helpers import save_feature_mesh_to_disk, save_serialized_nvblox_map_to_disk
@@ -107,8 +107,8 @@ class IsaacLabNvbloxMapper:
     def update_reconstruction_from_sample(self, sample: Dict[str, torch.Tensor], camera_name: str) -> None:
         num_cams = sample["depths"].shape[1]
         camera_index = 0 if num_cams == 1 else CAMERA_NAME_TO_ID[camera_name]
-        inputs = get_nvblox_inputs_from_sample(sample, camera_index)
-        self._update_reconstruction(*inputs, camera_name)
+        # (get_nvblox_inputs_from_sample with one native call and one synchronisation; the point cloud on first use)
+        self._update_reconstruction(*frame_inputs_from_sample(sample, camera_index), camera_name)
 
     def _update_reconstruction(self, depth_frame, intrinsics, camera_pose, rgb, dynamic_mask, pointcloud, camera_name: str) -> None:
         images = nvblox_integrate(mapper=self.mapper, nvblox_mapping_config=self.mapping_config, feature_extractor=self.feature_extractor,
@@ -117,7 +117,8 @@ class IsaacLabNvbloxMapper:
         size = self.mapping_config.upscaled_feature_image_size
 
         def pcd_image():  # visualization/utils.py:17-23 -- only the visualiser asks for it
-            chw = pointcloud if pointcloud.shape[0] == 3 else pointcloud.permute(2, 0, 1)
+            pcd = pointcloud() if callable(pointcloud) else pointcloud
+            chw = pcd if pcd.shape[0] == 3 else pcd.permute(2, 0, 1)
             return F.interpolate(chw.unsqueeze(0), size, mode="bilinear").permute(0, 2, 3, 1)
 
         for mapper_name in [m.name for m in MAPPER_TO_ID]:
@@ -143,9 +144,10 @@ class IsaacLabNvbloxMapper:
         samples["vertices"], samples["vertex_features"], samples["vertices_valid_mask"] = get_vertices_and_features(
             self.mapper, mapper_id, self.mapping_config, remove_zero_features, self.feature_extractor.num_excess_features(),
             sample_vertices=True, number_of_vertices_to_sample=self.num_vertices_to_sample,
-            vertex_sampling_method=self.vertex_sampling_method)
-        samples["vertex_features"] = samples["vertex_features"].to(torch.float32).to(self.device)
-        samples["vertices"] = samples["vertices"].to(torch.float32).to(self.device)
+            vertex_sampling_method=self.vertex_sampling_method, features_dtype=torch.float32)
+        # (the reference's .to(torch.float32).to(self.device) of both tensors, :243-246: the gather writes float32 on the device)
+        samples["vertex_features"] = samples["vertex_features"].to(self.device)
+        samples["vertices"] = samples["vertices"].to(self.device)
         return samples
 
     def clear(self):

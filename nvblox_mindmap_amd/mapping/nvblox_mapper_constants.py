@@ -119,3 +119,12 @@ class NvbloxMappingCfg:
             self.voxel_size_m = self.voxel_size_m_override
         if self.measurement_weight_override is not None:
             self.projective_appearance_integrator_measurement_weight = self.measurement_weight_override
+
+    @property
+    def aabb_min_host(self):
+        """``aabb_min_m`` as three host floats (float32 values), for native calls that take the box by value."""
+        return [float(x) for x in self.aabb_min_m.to(torch.float32).tolist()]
+
+    @property
+    def aabb_max_host(self):
+        return [float(x) for x in self.aabb_max_m.to(torch.float32).tolist()]

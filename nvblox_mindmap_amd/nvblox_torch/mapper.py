@@ -560,6 +560,39 @@ class Mapper:
             break
         return FeatureMesh(verts, feats, self, mapper_id)
 
+    def model_inputs_prepare(self, mapper_id: int, aabb_min, aabb_max, used_channels: int, remove_zero_features: bool) -> int:
+        """Extension (mmf_model_inputs_prepare): the row filters of the reference's ``get_vertices_and_features``
+        (nvblox_output_helpers.py:49-74: mesh update, strict AABB, pad-channel strip, all-zero rows) in one launch; returns
+        the number of rows that pass, in the order of the reference's filtered mesh.  ``aabb_*``: 3 host floats each."""
+        mapper_id = self._check_id(mapper_id)
+        lo = (C.c_float * 3)(*[float(x) for x in aabb_min])
+        hi = (C.c_float * 3)(*[float(x) for x in aabb_max])
+        n = C.c_int(0)
+        _lib.check(_lib.lib().mmf_model_inputs_prepare(self._h, mapper_id, lo, hi, int(used_channels), int(bool(remove_zero_features)),
+                                                       self._stream(), C.byref(n)), "mmf_model_inputs_prepare")
+        self._mi_used = int(used_channels)
+        return n.value
+
+    def model_inputs_gather(self, mapper_id: int, rows: Optional[torch.Tensor], n_take: int, n_out: int,
+                            features_dtype: Optional[torch.dtype] = torch.float32):
+        """Extension (mmf_model_inputs_gather): rows of the last ``model_inputs_prepare`` -> (vertices [n_out,3] f32,
+        features [n_out,used] ``features_dtype`` (None: vertices only), valid [n_out] bool).  ``rows``: int64 ranks among the
+        kept rows on the device (None = the first ``n_take``); rows n_take .. n_out-1 are zero padding."""
+        mapper_id = self._check_id(mapper_id)
+        if rows is not None:
+            rows = _check_dev(rows, "rows", torch.int64, 1)
+            assert rows.shape[0] >= n_take
+        verts = torch.empty((n_out, 3), dtype=torch.float32, device=self.device)
+        feats = None
+        if features_dtype is not None:
+            assert features_dtype in (torch.float32, torch.float16)
+            feats = torch.empty((n_out, self._mi_used), dtype=features_dtype, device=self.device)
+        valid = torch.empty((n_out,), dtype=torch.bool, device=self.device)
+        _lib.check(_lib.lib().mmf_model_inputs_gather(self._h, mapper_id, _lib.dptr(rows), int(n_take), int(n_out), _lib.dptr(verts),
+                                                      _lib.dptr(feats), int(features_dtype == torch.float32), _lib.dptr(valid),
+                                                      self._stream()), "mmf_model_inputs_gather")
+        return verts, feats, valid
+
     def _mesh_topology(self, mapper_id: int, want_colors: bool):
         """(triangles [T,3] int32, colours [V,3] uint8 or None, V) of the current map."""
         L = _lib.lib()

@@ -51,6 +51,37 @@ def test_get_nvblox_inputs_from_sample_matches_the_reference_semantics():
         get_nvblox_inputs_from_sample(bad, 0)
 
 
+def test_frame_inputs_from_sample_equals_the_reference_shaped_helper():
+    """The facade's one-call / one-copy form returns what get_nvblox_inputs_from_sample returns (rgb bytes, pose, intrinsics,
+    lazily the point cloud) and fails the same assertions, incl. a NaN in the image."""
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_input_helpers import frame_inputs_from_sample, get_nvblox_inputs_from_sample
+
+    for (w, h) in ((64, 48), (67, 45), (512, 512)):  # 67x45: H*W not a multiple of 4 (scalar kernel form)
+        cfg = S.StreamConfig(width=w, height=h, fx=52.5, fy=52.5, cx=w / 2 - 0.5, cy=h / 2 - 0.5)
+        for ncam, cam in ((1, 0), (2, 1)):
+            sample, T, depth = make_sample(cfg, 5, "cuda", ncam=ncam)
+            g = torch.Generator().manual_seed(w + ncam)
+            sample["rgbs"] = torch.rand(sample["rgbs"].shape, generator=g).cuda()
+            sample["rgbs"][0, cam, :, 0, :3] = torch.tensor([[0.0, 1.0, 0.999], [0.5, 0.25, 1.0], [0.00392, 0.00393, 0.9961]], device="cuda")
+            d0, K0, T0, rgb0, dyn0, pcd0 = get_nvblox_inputs_from_sample(sample, cam)
+            d1, K1, T1, rgb1, dyn1, pcd1 = frame_inputs_from_sample(sample, cam)
+            assert torch.equal(d0, d1) and torch.equal(dyn0, dyn1) and torch.equal(rgb0, rgb1)
+            assert not K1.is_cuda and not T1.is_cuda and torch.equal(K0.cpu(), K1) and torch.equal(T0, T1)
+            assert torch.equal(pcd0, pcd1())
+            for bad_value in (1.5, -0.1, float("nan")):
+                bad = dict(sample)
+                bad["rgbs"] = sample["rgbs"].clone()
+                bad["rgbs"][0, cam, 1, h // 2, w // 3] = bad_value
+                with pytest.raises(AssertionError):
+                    frame_inputs_from_sample(bad, cam)
+            if ncam > 1:
+                bad = dict(sample)
+                bad["rgbs"] = sample["rgbs"].clone()
+                bad["rgbs"][0, 1 - cam, 0, 0, 0] = 2.0  # the OTHER camera is out of range: the reference's check covers it
+                with pytest.raises(AssertionError):
+                    frame_inputs_from_sample(bad, cam)
+
+
 class StreamFeatures:
     """Stand-in extractor: hands the synthetic stream's feature image over (the DNN is out of scope)."""
 
