@@ -460,6 +460,107 @@ def run_tsdf_only(device, steps=200, warmup=20):
     return {"frames_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "workload": "decay + add_depth_frame, 640x480, 1 cm voxels"}
 
 
+def build_facade(shape: str, device, n_frames: int):
+    """The object the reference's policy drives (IsaacLabNvbloxMapper) + a loader-shaped sample stream, at the reference's
+    shape ("ref": 512x512, 768 channels) or the benchmark shape ("bl": 640x480, 64 channels)."""
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
+    from scipy.spatial.transform import Rotation
+
+    if shape == "ref":
+        C = 768
+        cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
+    else:
+        C = 64
+        cfg = S.StreamConfig(hole_mode="patches")
+    frames = build_stream(cfg, n_frames, C, device)
+
+    class Extractor:  # the DNN is out of scope: hands the stream's pre-computed backbone output (or feature image) over
+        next = low = None
+
+        def compute(self, rgb):
+            return self.next.unsqueeze(0)
+
+        def compute_lowres(self, rgb):  # the hand-over nvblox_integrate prefers: the 16x16xC map, sampled inside the kernel
+            return self.low, (cfg.height, cfg.width)
+
+        def num_excess_features(self):
+            return 0
+
+    ex = Extractor()
+    facade = IsaacLabNvbloxMapper("rgbd_and_mesh", None, device, feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
+                                  num_vertices_to_sample=2048)
+    samples = []
+    for fr in frames:  # what the loader / simulator hands the policy: [1, ncam, ...] tensors on the device
+        T = fr["T_W_C"].numpy().astype(np.float64)
+        q = Rotation.from_matrix(T[:3, :3]).as_quat()
+        pose7 = torch.tensor(np.concatenate([T[:3, 3], [q[3], q[0], q[1], q[2]]]), dtype=torch.float32, device=device)
+        samples.append({"depths": fr["depth"][None, None], "intrinsics": fr["K"].to(device)[None, None], "camera_poses": pose7[None, None],
+                        "rgbs": (fr["rgb"].permute(2, 0, 1).float() / 255.0)[None, None].contiguous(),
+                        "segmentation_masks": fr["dynamic_mask"][None, None]})
+    return cfg, C, frames, samples, ex, facade
+
+
+def run_model_inputs(device, shape: str, iters=40, n_frames=12):
+    """The OUTPUT half of the hot path, alone (SURVEY 8(a) A11 + A12): ``IsaacLabNvbloxMapper.get_nvblox_model_inputs`` =
+    mesh extraction + AABB / zero-row filters + sampling to 2048 rows, on a map fused from `n_frames` frames, and the facade's
+    per-frame fusion call beside it.  Two native launches (k_mesh_keep, k_model_inputs_gather) and one synchronisation.
+    Algorithmic bytes per call: every live TSDF block read once (8 B/voxel) + one 128 B line of each in-box vertex's feature row
+    (the zero test stops at the first non-zero piece) + the kept-vertex list written and the sampled entries read (16 B) +
+    per sampled row 2C read, 12 + 4C written."""
+    import gc
+
+    cfg, C, frames, samples, ex, facade = build_facade(shape, device, n_frames)
+
+    def fuse(i):
+        fr, smp = frames[i % n_frames], samples[i % n_frames]
+        ex.next, ex.low = fr["features"], fr["lowres"]
+        facade.decay()
+        facade.update_reconstruction_from_sample(smp, "pov")
+
+    for i in range(n_frames):
+        fuse(i)
+    torch.cuda.synchronize(device)
+    gc.collect()
+    gc.freeze()  # (a full collection of the interpreter's heap costs tens of ms with torch + scipy loaded)
+    per = []
+    for i in range(iters):
+        t0 = time.perf_counter()
+        fuse(i)
+        torch.cuda.synchronize(device)
+        per.append((time.perf_counter() - t0) * 1e3)
+    fusion_ms = statistics.median(per)
+    m = facade.mapper
+    torch.manual_seed(0)
+    facade.get_nvblox_model_inputs(MAPPER_TO_ID.STATIC, remove_zero_features=True)
+    m.profile_reset()
+    m.profile_enable(True, kernels=["mesh"])
+    per = []
+    for i in range(iters):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        out = facade.get_nvblox_model_inputs(MAPPER_TO_ID.STATIC, remove_zero_features=True)
+        torch.cuda.synchronize(device)
+        per.append((time.perf_counter() - t0) * 1e3)
+    m.profile_enable(False)
+    ms, n = m.profile()["mesh"]
+    gc.unfreeze()
+    kernels_us = ms / max(n // 2, 1) * 1e3  # two bracketed launches per call
+    n_live = int(m.tsdf_layer_view(MAPPER_TO_ID.STATIC).num_allocated_blocks())
+    V = int(m.update_feature_mesh(MAPPER_TO_ID.STATIC))
+    kept = int(m.model_inputs_prepare(MAPPER_TO_ID.STATIC, facade.mapping_config.aabb_min_host, facade.mapping_config.aabb_max_host, C, True))
+    N = int(out["vertices"].shape[1])
+    alg = n_live * 512 * 8 + V * 128 + kept * 16 + N * (16 + 2 * C + 12 + 4 * C)
+    res = {"shape": f"{cfg.height}x{cfg.width}x{C}", "ms_per_call": statistics.median(per), "facade_fusion_ms_per_frame": fusion_ms,
+           "kernels_us_per_call": kernels_us, "launches_per_call": 2, "mesh_vertices": V, "kept_rows": kept, "sampled_rows": N,
+           "live_tsdf_blocks": n_live, "algorithmic_bytes": alg, "achieved_GBps": alg / (kernels_us * 1e-6) / 1e9 if kernels_us else None,
+           "frac": alg / (kernels_us * 1e-6) / HBM_PEAK_BYTES_PER_S if kernels_us else None,
+           "bound": "latency (one pass over the live blocks' lattices + a host round trip for the RNG draw)",
+           "through": "IsaacLabNvbloxMapper.get_nvblox_model_inputs(STATIC, remove_zero_features=True)"}
+    del facade, frames, samples
+    torch.cuda.empty_cache()
+    return res
+
+
 def run_closed_loop(device, steps=5):
     """BASELINE configs[3]: one control step of the closed loop on one GPU, end to end, through the object the reference's policy
     drives (mapping/isaaclab_nvblox_mapper.py; closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83,206-211):
@@ -473,35 +574,7 @@ def run_closed_loop(device, steps=5):
     from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
     from nvblox_mindmap_amd.training import build_model, synthetic_batch
 
-    C = 768
-    cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
-    frames = build_stream(cfg, 4, C, device)
-
-    class Extractor:  # the DNN is out of scope: hands the stream's pre-computed backbone output (or feature image) over
-        next = low = None
-
-        def compute(self, rgb):
-            return self.next.unsqueeze(0)
-
-        def compute_lowres(self, rgb):  # the hand-over nvblox_integrate prefers: the 16x16x768 map, sampled inside the kernel
-            return self.low, (cfg.height, cfg.width)
-
-        def num_excess_features(self):
-            return 0
-
-    ex = Extractor()
-    facade = IsaacLabNvbloxMapper("rgbd_and_mesh", None, device, feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
-                                  num_vertices_to_sample=2048)
-    from scipy.spatial.transform import Rotation
-
-    samples = []
-    for fr in frames:  # what the loader / simulator hands the policy: [1, ncam, ...] tensors on the device
-        T = fr["T_W_C"].numpy().astype(np.float64)
-        q = Rotation.from_matrix(T[:3, :3]).as_quat()
-        pose7 = torch.tensor(np.concatenate([T[:3, 3], [q[3], q[0], q[1], q[2]]]), dtype=torch.float32, device=device)
-        samples.append({"depths": fr["depth"][None, None], "intrinsics": fr["K"].to(device)[None, None], "camera_poses": pose7[None, None],
-                        "rgbs": (fr["rgb"].permute(2, 0, 1).float() / 255.0)[None, None].contiguous(),
-                        "segmentation_masks": fr["dynamic_mask"][None, None]})
+    cfg, C, frames, samples, ex, facade = build_facade("ref", device, 4)
     pcfg = DiffuserActorConfig()
     torch.manual_seed(0)
     model = build_model(pcfg, device=device).eval()
@@ -743,6 +816,111 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
             "note": "one GPU's loader; an 8-GPU node runs 8 such loaders on the same host cores (the reference: 8 x 20 workers)"}
 
 
+def get_unbounded_mapper(mcfg, channels):
+    """get_nvblox_mapper (nvblox_mapping_helpers.py:30-76) with nvblox's default view-calculator setting instead of the task's
+    bounding box: ``workspace_bounds_type = kUnbounded`` -- the block index is then the open-addressing HASH."""
+    from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
+    from nvblox_mindmap_amd.nvblox_torch.mapper_params import (
+        BlockMemoryPoolParams, MapperParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams, ViewCalculatorParams)
+    from nvblox_mindmap_amd.nvblox_torch.projective_integrator_types import ProjectiveIntegratorType
+
+    pi = ProjectiveIntegratorParams()
+    pi.projective_integrator_max_integration_distance_m = mcfg.projective_integrator_max_integration_distance_m
+    pi.projective_appearance_integrator_measurement_weight = mcfg.projective_appearance_integrator_measurement_weight
+    de = TsdfDecayIntegratorParams()
+    de.tsdf_decay_factor = mcfg.tsdf_decay_factor
+    vc = ViewCalculatorParams()
+    vc.raycast_subsampling_factor = 1
+    vc.workspace_bounds_type = "kUnbounded"
+    pool = BlockMemoryPoolParams()
+    pool.expansion_factor = 1.0
+    # the library's pools do not grow: 262 144 blocks per layer (TSDF 1 GB, 64-channel features 17 GB) hold what the orbit sees
+    # out to 5 m at 1 cm voxels; the run reports the live count and fails loudly on exhaustion
+    pool.num_preallocated_blocks = 262144
+    mp = MapperParams()
+    mp.set_projective_integrator_params(pi)
+    mp.set_tsdf_decay_integrator_params(de)
+    mp.set_view_calculator_params(vc)
+    mp.set_block_memory_pool_params(pool)
+    return Mapper(voxel_sizes_m=[mcfg.voxel_size_m], integrator_types=[ProjectiveIntegratorType.TSDF], mapper_parameters=mp,
+                  feature_channels=channels)
+
+
+UNBOUNDED_CLASSES = {"raycast": "k_raycast_mark", "alloc": "k_count_tiles + k_scan_tiles + k_emit (hash insertion; x3: TSDF, colour, feature)",
+                     "tsdf": "k_tsdf_integrate", "candidates": "k_app_candidates", "sphere": "k_sphere_trace", "color": "k_color_integrate",
+                     "feature": "k_feature_integrate (gating)", "feature_flat": "k_feature_flat", "decay": "k_decay + k_live_compact"}
+
+
+def run_unbounded(device, frames, channels, steps=100, warmup=30):
+    """The headline step (decay + fused depth / colour / feature frame, same 640x480 stream, same masks) in an UNBOUNDED workspace:
+    the block index is the open-addressing hash (CAS insertion by the allocation launch, tombstones from the decay's
+    deallocations, amortised rebuild) instead of the dense table of the task's bounding box, the view grid is the whole
+    frustum out to the 5 m integration distance, allocation and TSDF pass are separate launches.  North star: "voxel-block hash
+    allocation ... wavefront ballot/prefix-sum for hash insertion"."""
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    mapper = get_unbounded_mapper(mcfg, channels)
+    n_frames = len(frames)
+
+    def one(i):
+        step(mapper, mcfg, frames[i % n_frames])
+
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize(device)
+    mapper.reset_stats(0)
+    mapper.profile_reset()
+    mapper.profile_enable(True, kernels=list(UNBOUNDED_CLASSES), stride=4)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(warmup + i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    mapper.profile_enable(False)
+    prof = mapper.profile()
+    stats = mapper.stats(0)
+    hs = mapper.hash_state(0)
+    n_live = hs["live_blocks"]
+    if n_live >= 262144:
+        raise RuntimeError("unbounded leg: block pool exhausted")
+    nf = max(stats["feature_frames"], 1)
+    cfg = S.StreamConfig(hole_mode="patches")
+    n_upd = stats["tsdf_blocks_updated"] / max(stats["depth_frames"], 1)
+    n_new = stats["tsdf_blocks_allocated"] / max(stats["depth_frames"], 1)
+    model = frame_byte_model(cfg, channels, n_live, n_upd, stats["color_blocks_updated"] / max(stats["color_frames"], 1),
+                             stats["feature_voxels_updated"] / nf)
+    # hash traffic of the allocation launch: one 16 B probe per candidate block (+ one CAS + value store per new block)
+    ncand = stats["color_blocks_updated"] / max(stats["color_frames"], 1)
+    model = {
+        "k_raycast_mark": model["k_front"],
+        UNBOUNDED_CLASSES["alloc"]: (n_upd + 2 * ncand) * (16 + 13) + n_new * 24,
+        "k_tsdf_integrate": n_upd * 512 * 16 + cfg.height * cfg.width * 5,
+        "k_app_candidates": n_live * 512 * 8,
+        "k_sphere_trace": model["k_sphere_alloc"],
+        "k_color_integrate": ncand * 512 * 16 + cfg.height * cfg.width * 4,
+        "k_feature_integrate (gating)": ncand * 512 * 8 + cfg.height * cfg.width + 20 * stats["feature_voxels_updated"] / nf,
+        "k_feature_flat": model["k_feature_flat"],
+        "k_decay + k_live_compact": n_live * 512 * 16,
+    }
+    per = []
+    for cls, name in UNBOUNDED_CLASSES.items():
+        ms, n = prof.get(cls, (0.0, 0))
+        us = ms / n * 1e3 if n else None
+        b = model.get(name, 0.0)
+        calls = 3 if cls == "alloc" else 1  # bracketed launches of the class per frame
+        per.append({"kernel": name, "avg_us_per_frame": us * calls if us else None, "launches_timed": n, "algorithmic_bytes": b,
+                    "frac": (b / (us * calls * 1e-6) / HBM_PEAK_BYTES_PER_S) if (us and b) else None})
+    b_frame = sum(model.values())
+    out = {"frames_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "hash": hs,
+           "tsdf_blocks_integrated_per_frame": n_upd, "tsdf_blocks_allocated_per_frame": n_new,
+           "tsdf_blocks_deallocated_per_frame": n_new,  # steady state on the orbit: as many leave as arrive
+           "algorithmic_bytes_per_frame": b_frame, "frac": b_frame / dt / HBM_PEAK_BYTES_PER_S, "per_kernel": per,
+           "workload": "decay + integrate_frame (depth, colour, %d-ch features), 640x480, 1 cm voxels, workspace_bounds_type=kUnbounded, "
+                       "max integration distance 5 m" % channels}
+    del mapper
+    torch.cuda.empty_cache()
+    return out
+
+
 def frame_byte_model(cfg, C, n_live, n_tsdf_upd, n_cand, n_surv, with_decay=True):
     """ALGORITHMIC bytes per launch of the fused frame = what THIS implementation's algorithm has to move between HBM and the
     chip, counted from the run's own device counters (DESIGN.md section 5 states the same formulas):
@@ -806,6 +984,7 @@ def main():
     ap.add_argument("--no-file-fed", action="store_true", help="skip the file-fed training leg (loader-bound vs compute-bound step/s)")
     ap.add_argument("--only-fusion", action="store_true", help="headline fusion measurement only (what the rocprofv3 passes run)")
     ap.add_argument("--ref-shape-only", action="store_true", help="run only the 512x512x768 leg (rocprofv3 passes at the reference shape)")
+    ap.add_argument("--unbounded-only", action="store_true", help="run only the unbounded-workspace (hash path) leg (rocprofv3 passes)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the multi-rank control flow only")
     args = ap.parse_args()
     if args.only_fusion:
@@ -842,6 +1021,11 @@ def main():
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     n_frames = args.frames or min(max(args.steps, 1), 200)
     frames = build_stream(cfg, n_frames, args.channels, device)
+    if args.unbounded_only:
+        out = run_unbounded(device, frames, args.channels, steps=args.steps, warmup=args.warmup)
+        if rank == 0:
+            print(json.dumps({"unbounded_workspace": out}), flush=True)
+        return
     mapper = get_nvblox_mapper(mcfg, feature_channels=args.channels)
 
     for i in range(args.warmup):
@@ -908,8 +1092,12 @@ def main():
             train["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=train["step_per_s"])
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
+    model_inputs = None
+    if rank == 0 and not args.no_ref_shape:
+        model_inputs = {"ref": run_model_inputs(device, "ref"), "bl": run_model_inputs(device, "bl")}
     tsdf_only = run_tsdf_only(device) if (rank == 0 and not args.no_ref_shape) else None
     two_mappers = run_two_mappers(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
+    unbounded = run_unbounded(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
@@ -1001,8 +1189,10 @@ def main():
             "reference_shape": ref_shape,
             "policy_inference": infer,
             "closed_loop": closed_loop,
+            "model_inputs": model_inputs,
             "tsdf_only": tsdf_only,
             "two_mappers": two_mappers,
+            "unbounded_workspace": unbounded,
             "backprojection": backproj,
             "train": train,
         }

@@ -149,6 +149,7 @@ __device__ inline void live_compact_body(const LayerDev& L, uint8_t* __restrict_
     L.ctr[0] = n_live;
     L.ctr[1] = carry[1];
     L.ctr[4] = rebuild ? 0 : n_tomb;
+    if (rebuild) L.ctr[5]++;  // diagnostics (mmf_debug_hash_state): table rebuilds since the layer was reset
     if (L.hint_live) *L.hint_live = n_live;
     if (!WMAX) *any_kill = 0;
   }

@@ -569,7 +569,8 @@ int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w) {
     // reference configures) need a few tens of MB; very large pools keep phase 2 inside the gating workgroups.
     // (sub-list k takes the blocks in pool slots k, k + 64, ...: at most ceil(app_cap / 64) blocks of 512 voxels each)
     const size_t recs = (size_t)((m.app_cap + kFlatSubLists - 1) / kFlatSubLists) * kVPB * kFlatSubLists;
-    if (m.app_cap < (1 << 22) && recs * 20 <= ((size_t)256 << 20)) {
+    // (20 B per record: 2.7 GB for a 262 144-block pool -- 1 % of the part's 288 GB)
+    if (m.app_cap < (1 << 22) && recs * 20 <= ((size_t)8 << 30)) {
       HIP_TRY(hipMalloc(&m.flat.rec, sizeof(uint4) * recs));
       HIP_TRY(hipMalloc(&m.flat.w, sizeof(float) * recs));
       HIP_TRY(hipMalloc(&m.flat.count, sizeof(int) * kFlatSubLists * kFlatCountStride));
@@ -1111,14 +1112,23 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     m->frames[1]++;
     MMF_TRY(app_alloc(h, *m, 1, m->color, cam, T_C_L, 4, -1, s));
     MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, s));
-    launch_color_integrate(m->color.d, m->mc, cam, T_C_L, rgb, depth_mask_out, m->synth, m->synth_W, m->synth_H, m->sc[1],
-                           m->color.d.cap, s);
+    {
+      ProfScope ps(h, MMF_K_COLOR, s);
+      launch_color_integrate(m->color.d, m->mc, cam, T_C_L, rgb, depth_mask_out, m->synth, m->synth_W, m->synth_H, m->sc[1],
+                             m->color.d.cap, s);
+    }
     m->frames[2]++;
     MMF_TRY(app_alloc(h, *m, 2, m->feat, fcam, T_C_L, 6, 7, s));
     if (m->flat.rec) HIP_TRY(hipMemsetAsync(m->flat.count, 0, sizeof(int) * kFlatSubLists * kFlatCountStride, s));
-    launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
-                             m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
-    launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s);
+    {
+      ProfScope ps(h, MMF_K_FEATURE, s);
+      launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
+                               m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
+    }
+    {
+      ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
+      launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s);
+    }
     return check_launch();
   }
   m->last_vg = vg;
@@ -2219,6 +2229,24 @@ int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_
   HIP_TRY(hipMemcpyAsync(&v, m->pub + kPubRec + 3 * (size_t)m->tsdf.d.cap + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   *out = (int64_t)v;
+  return MMF_OK;
+}
+
+int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out4) {
+  Mapper* m;
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
+  Layer* L = pick_layer(m, layer);
+  if (!L || !out4) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (!L->allocated) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  int c[8];
+  HIP_TRY(hipMemcpyAsync(c, L->d.ctr, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  out4[0] = L->d.dense ? 0 : (int64_t)L->d.hmask + 1;  // 0: the layer is indexed by its dense table, the hash is not maintained
+  out4[1] = c[4];
+  out4[2] = c[5];
+  out4[3] = c[0];
   return MMF_OK;
 }
 

@@ -59,7 +59,7 @@ struct LayerDev {
   u64* slot_key;   // [cap] key stored in each pool slot
   int* live;       // [cap] pool slots in allocation order
   int* free_stack; // [cap]
-  int* ctr;        // [0] n_live  [1] n_free  [2] bump (first never-used slot)  [3] error flags  [4] tombstones
+  int* ctr;        // [0] n_live  [1] n_free  [2] bump (first never-used slot)  [3] error flags  [4] tombstones  [5] hash rebuilds  [6] live count snapshot of k_front
   char* pool;      // payload A: cap * block_bytes
   float* poolw;    // payload B: cap * 512 floats (feature layer weights) or nullptr
   int cap;

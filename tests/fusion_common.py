@@ -19,6 +19,7 @@ REF_PARAMS = dict(  # what get_nvblox_mapper sets for DRILL_IN_BOX (nvblox_mappi
 def make_oracle(O, channels, **over):
     kw = dict(REF_PARAMS)
     kw.update(over)
+    kw.pop("num_preallocated_blocks", None)  # the oracle's block store grows on demand: pool sizing is a device-side matter
     return O.OracleMapper(O.default_params(feature_channels=channels, **kw))
 
 
@@ -26,7 +27,7 @@ def make_mapper(channels, **over):
     """HIP Mapper configured like the oracle (same parameter names as oracle.OrcParams)."""
     from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
     from nvblox_mindmap_amd.nvblox_torch.mapper_params import (
-        MapperParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams, ViewCalculatorParams)
+        BlockMemoryPoolParams, MapperParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams, ViewCalculatorParams)
 
     kw = dict(REF_PARAMS)
     kw.update(over)
@@ -58,6 +59,10 @@ def make_mapper(channels, **over):
     mp.set_projective_integrator_params(pi)
     mp.set_tsdf_decay_integrator_params(de)
     mp.set_view_calculator_params(vc)
+    if "num_preallocated_blocks" in kw:
+        pool = BlockMemoryPoolParams()
+        pool.num_preallocated_blocks = int(kw["num_preallocated_blocks"])
+        mp.set_block_memory_pool_params(pool)
     return Mapper(voxel_sizes_m=kw["voxel_size"], mapper_parameters=mp, feature_channels=channels)
 
 

@@ -1,0 +1,87 @@
+"""The voxel-block HASH path (kUnbounded workspace: open-addressing table, CAS insertion, tombstones, amortised rebuild) at
+BASELINE's full size -- 640x480 depth + 64-channel features, 1 cm voxels -- against the CPU oracle, bit for bit.  The reference's
+tasks configure a bounding-box workspace (nvblox_mapping_helpers.py:53-59), where the block index is a dense table and the hash is
+not kept at all; nvblox's own default (``Mapper(voxel_sizes_m=0.01)``, paper/teaser/convert_maps_usd.py:38) is unbounded."""
+import numpy as np
+import pytest
+import torch
+
+from fusion_common import make_mapper, make_oracle
+from nvblox_mindmap_amd import synthetic as S
+from test_gpu_fusion_parity import compare_features, compare_tsdf, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def fused_frame(gpu, orc, cfg, index, channels, k_in, k_depth, border, min_d=0.3):
+    """decay + the reference's integrate_frame (mask algebra + depth + colour + features) on both sides."""
+    from oracle import image_ops as IO
+
+    f = S.frame(cfg, index, channels)
+    static = np.ones(f["depth"].shape, dtype=bool)
+    odm, ofm = IO.frame_masks(static, f["depth"], min_d, k_in, k_depth, border, cfg.height, cfg.width)
+    orc.decay()
+    orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+    orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+    orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+    gpu.decay()
+    gpu.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), dev(static), torch.from_numpy(f["T_W_C"]),
+                        torch.from_numpy(f["K"]), min_d, k_in, k_depth, border, 0)
+
+
+def test_unbounded_full_size_fused_frames_match_oracle(oracle_mod):
+    """Six fused frames of the benchmark stream in an UNBOUNDED workspace (5 m integration distance as the reference sets it,
+    reference mask algebra: 17 / 20-pixel erosions, 5 % border)."""
+    cfg = S.StreamConfig(hole_mode="patches")
+    over = dict(workspace_bounds_type=0)
+    gpu, orc = make_mapper(64, **over), make_oracle(oracle_mod, 64, **over)
+    for i in (0, 7, 14, 21, 28, 35):
+        fused_frame(gpu, orc, cfg, i, 64, 17, 20, 5)
+    st = gpu.hash_state(0)
+    assert st["table_entries"] >= 2 * st["live_blocks"] > 0, st
+    mx, exact = compare_tsdf(orc, gpu)
+    assert exact
+    compare_features(orc, gpu)
+    rgb, w, idx = gpu.color_layer_view(0).get_all_blocks_split()
+    orgb, ow = orc.all_colors()
+    assert np.array_equal(idx.cpu().numpy(), orc.block_indices(1))
+    assert np.array_equal(w.cpu().numpy(), ow) and np.array_equal(rgb.cpu().numpy(), orgb)
+    ov, of = orc.feature_mesh()
+    mesh = gpu.get_feature_mesh(0)
+    assert np.array_equal(mesh.vertices().cpu().numpy(), ov)
+    assert np.array_equal(mesh.vertex_features().cpu().numpy().view(np.uint16), of.view(np.uint16))
+
+
+def test_unbounded_full_size_decay_churn_rebuilds_the_table(oracle_mod):
+    """Strong decay on a moving camera: every frame deallocates the blocks that left the view (tombstones in the table) and
+    allocates new ones into reused slots, long enough for the tombstones to exceed a quarter of the table -- the amortised
+    rebuild -- at least once.  Pool of 16 384 blocks -> 32 768 table entries.  TSDF + features, stand-alone and fused calls
+    mixed (the stand-alone decay is the eager two-launch form, the fused frame folds it in)."""
+    cfg = S.StreamConfig(hole_mode="patches")
+    over = dict(workspace_bounds_type=0, tsdf_decay_factor=0.2, decayed_weight_threshold=1e-3, max_integration_distance_m=2.5,
+                num_preallocated_blocks=16384)
+    gpu, orc = make_mapper(64, **over), make_oracle(oracle_mod, 64, **over)
+    rebuilds_seen = 0
+    for k in range(24):
+        index = (k * 23) % cfg.num_poses
+        if k % 3 == 2:  # stand-alone calls: eager decay, three-kernel allocation
+            f = S.frame(cfg, index, 64)
+            orc.decay()
+            gpu.decay()
+            orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"])
+            gpu.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+            orc.add_feature_frame(f["features"], f["T_W_C"], f["K"])
+            gpu.add_feature_frame(dev(f["features"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+        else:
+            fused_frame(gpu, orc, cfg, index, 64, 3, 4, 5)
+        st = gpu.hash_state(0)
+        rebuilds_seen = max(rebuilds_seen, st["rebuilds"])
+        assert st["live_blocks"] == orc.num_blocks(0), (k, st)
+        if k % 6 == 5:
+            compare_tsdf(orc, gpu)
+    assert rebuilds_seen >= 1, f"no tombstone rebuild in 24 frames: {gpu.hash_state(0)}"
+    mx, exact = compare_tsdf(orc, gpu)
+    assert exact
+    compare_features(orc, gpu)
+    stats = gpu.stats(0)
+    assert stats["tsdf_blocks_allocated"] - gpu.hash_state(0)["live_blocks"] > 8192, "the churn must exceed a quarter of the table"

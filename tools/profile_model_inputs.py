@@ -19,46 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import bench  # noqa: E402
-from nvblox_mindmap_amd import synthetic as S  # noqa: E402
-from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper  # noqa: E402
 from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID  # noqa: E402
 
 
 def build(shape: str, device, n_frames: int):
-    if shape == "ref":
-        C = 768
-        cfg = S.StreamConfig(width=512, height=512, fx=586.4, fy=586.4, cx=255.5, cy=255.5, hole_mode="patches")
-    else:
-        C = 64
-        cfg = S.StreamConfig(hole_mode="patches")
-    frames = bench.build_stream(cfg, n_frames, C, device)
-
-    class Extractor:
-        next = low = None
-
-        def compute(self, rgb):
-            return self.next.unsqueeze(0)
-
-        def compute_lowres(self, rgb):
-            return self.low, (cfg.height, cfg.width)
-
-        def num_excess_features(self):
-            return 0
-
-    ex = Extractor()
-    facade = IsaacLabNvbloxMapper("rgbd_and_mesh", None, device, feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
-                                  num_vertices_to_sample=2048)
-    from scipy.spatial.transform import Rotation
-
-    samples = []
-    for fr in frames:
-        T = fr["T_W_C"].numpy().astype(np.float64)
-        q = Rotation.from_matrix(T[:3, :3]).as_quat()
-        pose7 = torch.tensor(np.concatenate([T[:3, 3], [q[3], q[0], q[1], q[2]]]), dtype=torch.float32, device=device)
-        samples.append({"depths": fr["depth"][None, None], "intrinsics": fr["K"].to(device)[None, None], "camera_poses": pose7[None, None],
-                        "rgbs": (fr["rgb"].permute(2, 0, 1).float() / 255.0)[None, None].contiguous(),
-                        "segmentation_masks": fr["dynamic_mask"][None, None]})
-    return cfg, C, frames, samples, ex, facade
+    return bench.build_facade(shape, device, n_frames)
 
 
 def main():
