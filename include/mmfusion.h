@@ -57,7 +57,9 @@ typedef struct {
   float max_integration_distance_m;    /* projective_integrator_max_integration_distance_m   */
   float truncation_distance_vox;       /* projective_integrator_truncation_distance_vox      */
   float max_weight;                    /* projective_integrator_max_weight                   */
-  int32_t weighting_mode;              /* 0 constant, 1 inverse-square                       */
+  int32_t weighting_mode;              /* upstream's WeightingFunctionType family (recalled; oracle/mmf_oracle.c tsdf_weight):
+                                          0 constant, 1 inverse-square (default), 2 constant-dropoff, 3 inverse-square-dropoff,
+                                          4 inverse-square-TSDF-distance-penalty, 5 linear-with-max                          */
   float lin_interp_max_diff_vox;       /* bilinear depth only where the 4 taps agree         */
   float appearance_measurement_weight; /* projective_appearance_integrator_measurement_weight */
   float appearance_max_weight;
@@ -82,6 +84,9 @@ typedef struct {
   /* BlockMemoryPoolParams */
   int32_t num_preallocated_blocks; /* 0: size from the workspace bounds / built-in default   */
   float expansion_factor;          /* kept for API parity; pools grow by doubling            */
+  /* spec switches (items of the integrator that are code-level choices upstream; defaults = this spec, tests/pin_report.py flips them) */
+  int32_t raycast_to_truncation;   /* 1 (default): blocks in view are marked up to depth + truncation; 0: up to the depth     */
+  int32_t decay_appearance_layers; /* 0 (default): decay() leaves colour / feature weights alone; 1: multiplies them as well   */
 } mmf_params;
 
 /* sizeof(mmf_params) as compiled into the library (binding self-check). */

@@ -51,6 +51,8 @@ class MmfParams(C.Structure):
         ("feature_channels", C.c_int32),
         ("num_preallocated_blocks", C.c_int32),
         ("expansion_factor", C.c_float),
+        ("raycast_to_truncation", C.c_int32),
+        ("decay_appearance_layers", C.c_int32),
     ]
 
 

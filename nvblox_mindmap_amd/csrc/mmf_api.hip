@@ -260,6 +260,7 @@ void derive_consts(const mmf_params& P, MapConsts& mc) {
   mc.st_max_len = P.st_max_ray_length_m;
   mc.st_eps = P.st_surface_eps_vox * mc.v;
   mc.C = P.feature_channels;
+  mc.reach = P.raycast_to_truncation ? mc.trunc : 0.0f;
 }
 
 int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
@@ -431,6 +432,7 @@ int create_mapper(const mmf_params& P, Mapper** out) {
     return fail(MMF_ERR_INVALID_ARG, "feature_channels must be a positive multiple of 8");
   if (P.workspace_bounds_type < 0 || P.workspace_bounds_type > 2)
     return fail(MMF_ERR_INVALID_ARG, "workspace_bounds_type must be 0, 1 or 2");
+  if (P.weighting_mode < 0 || P.weighting_mode > 5) return fail(MMF_ERR_INVALID_ARG, "weighting_mode must be 0 .. 5");
   if (P.workspace_bounds_type != 2 && !(P.max_integration_distance_m > 0.f))
     return fail(MMF_ERR_INVALID_ARG, "max_integration_distance_m must be > 0 unless the workspace is a bounding box");
   Mapper* m = new Mapper();
@@ -826,6 +828,8 @@ int mmf_default_params(mmf_params* p) {
   p->feature_channels = 768;
   p->num_preallocated_blocks = 0;
   p->expansion_factor = 1.5f;
+  p->raycast_to_truncation = 1;
+  p->decay_appearance_layers = 0;
   return MMF_OK;
 }
 
@@ -1537,6 +1541,11 @@ int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
     flush_decay(h, *m, s);  // an earlier decay that nothing consumed
     m->pending_decay = true;
     m->tsdf_epoch++;
+    if (m->P.decay_appearance_layers) {  // spec switch: the appearance weights fade too (eager; independent of the TSDF layer)
+      if (m->color.allocated) launch_decay_app_weights(m->color.d, m->mc.decay_factor, false, s);
+      if (m->feat.allocated) launch_decay_app_weights(m->feat.d, m->mc.decay_factor, true, s);
+      m->frames[2]++;  // (cached model-input rows read feature weights)
+    }
   }
   if (mapper_id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
   return check_launch();

@@ -49,6 +49,7 @@ struct MapConsts {
   int st_sf, st_max_steps;
   float st_max_len, st_eps;
   int C;
+  float reach;  // how far past the measured depth the raycast marks blocks: trunc (default) or 0
 };
 
 // Device view of one block layer: open-addressing hash (packed 64-bit keys -> pool slot),
@@ -273,6 +274,19 @@ __device__ inline float bilin(float a00, float a10, float a01, float a11, float 
   float top = (1.0f - wx) * a00 + wx * a10;
   float bot = (1.0f - wx) * a01 + wx * a11;
   return (1.0f - wy) * top + wy * bot;
+}
+
+// Measurement weight of a TSDF update: upstream nvblox's WeightingFunctionType family as restated in oracle/mmf_oracle.c
+// (tsdf_weight: same operations in the same order).  Mode 1 (1/d^2) is this spec's default.
+__device__ inline float tsdf_measurement_weight(const MapConsts& mc, float d, float sdf) {
+  const int mode = mc.weighting_mode;
+  if (mode == 1) return 1.0f / (d * d);
+  if (mode == 0) return 1.0f;
+  const float trunc = mc.trunc;
+  if (mode == 2) return sdf >= 0.0f ? 1.0f : fmaxf((trunc + sdf) / trunc, 0.0f);
+  if (mode == 3) return (1.0f / (d * d)) * (sdf >= 0.0f ? 1.0f : fmaxf((trunc + sdf) / trunc, 0.0f));
+  if (mode == 4) return (1.0f / (d * d)) * (1.0f - 0.5f * (fminf(fabsf(sdf), trunc) / trunc));
+  return fminf(1.0f / d, 1.0f);
 }
 
 __device__ inline bool in_workspace(const MapConsts& mc, int x, int y, int z) {

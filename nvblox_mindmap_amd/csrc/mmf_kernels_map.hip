@@ -107,7 +107,7 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
   }
   if (active) {
     if (mc.max_dist > 0.0f && d > mc.max_dist) d = mc.max_dist;
-    float s = d + mc.trunc;
+    float s = d + mc.reach;
     float ray[3] = {((float)c + 0.5f - cam.cx) / cam.fx, ((float)r + 0.5f - cam.cy) / cam.fy, 1.0f};
     float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
     float pL[3];
@@ -502,12 +502,14 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
       if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
         float sdf = d - p[2];
         if (!(sdf < -mc.trunc)) {
-          float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
-          float Dn = (sdf * wm + dw.x * dw.y) / (wm + dw.y);
-          Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-          dw.x = Dn;
-          dw.y = fminf(dw.y + wm, mc.max_weight);
-          upd = true;
+          const float wm = tsdf_measurement_weight(mc, d, sdf);
+          if (wm > 0.0f) {
+            float Dn = (sdf * wm + dw.x * dw.y) / (wm + dw.y);
+            Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+            dw.x = Dn;
+            dw.y = fminf(dw.y + wm, mc.max_weight);
+            upd = true;
+          }
         }
       }
     }
@@ -582,12 +584,14 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
         if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
           float sdf = d - p[2];
           if (!(sdf < -mc.trunc)) {
-            float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
-            float Dn = (sdf * wm + D * W) / (wm + W);
-            Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-            D = Dn;
-            W = fminf(W + wm, mc.max_weight);
-            upd = true;
+            const float wm = tsdf_measurement_weight(mc, d, sdf);
+            if (wm > 0.0f) {
+              float Dn = (sdf * wm + D * W) / (wm + W);
+              Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+              D = Dn;
+              W = fminf(W + wm, mc.max_weight);
+              upd = true;
+            }
           }
         }
       }
@@ -687,12 +691,14 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
         if (sample_depth(mc, P.depth, nullptr, 0.0f, P.cam, u, v, d)) {
           float sdf = d - p[2];
           if (!(sdf < -mc.trunc)) {
-            float wm = mc.weighting_mode == 0 ? 1.0f : 1.0f / (d * d);
-            float Dn = (sdf * wm + D * W) / (wm + W);
-            Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-            D = Dn;
-            W = fminf(W + wm, mc.max_weight);
-            upd = true;
+            const float wm = tsdf_measurement_weight(mc, d, sdf);
+            if (wm > 0.0f) {
+              float Dn = (sdf * wm + D * W) / (wm + W);
+              Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+              D = Dn;
+              W = fminf(W + wm, mc.max_weight);
+              upd = true;
+            }
           }
         }
       }
@@ -1407,6 +1413,28 @@ void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* an
   // any_kill is zero on entry (initialised at creation, reset by k_live_compact)
   hipLaunchKernelGGL(k_decay, dim3(grid_for(hinted(L.hint_live, L.cap), 4096)), dim3(256), 0, s, L, mc, kill, any_kill);
   if (mc.dealloc_decayed) hipLaunchKernelGGL(k_live_compact, dim3(1), dim3(1024), 0, s, L, kill, any_kill);
+}
+
+// Option decay_appearance_layers: W *= f on the colour / feature weights of every live block (no deallocation).
+// has_w: feature layer (weights in poolw); else colour layer ({rgba, w} pairs in pool).
+__global__ __launch_bounds__(256) void k_decay_app_weights(LayerDev L, float f, int has_w) {
+  const int n = L.ctr[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = L.live[i];
+    for (int lin = threadIdx.x; lin < kVPB; lin += 256) {
+      if (has_w) {
+        float* w = L.poolw + (size_t)slot * kVPB + lin;
+        *w = *w * f;
+      } else {
+        uint2* e = reinterpret_cast<uint2*>(L.pool) + (size_t)slot * kVPB + lin;
+        e->y = __float_as_uint(__uint_as_float(e->y) * f);
+      }
+    }
+  }
+}
+
+void launch_decay_app_weights(const LayerDev& L, float f, bool has_w, hipStream_t s) {
+  hipLaunchKernelGGL(k_decay_app_weights, dim3(grid_for(L.cap, 4096)), dim3(256), 0, s, L, f, has_w ? 1 : 0);
 }
 
 void launch_layer_reset(const LayerDev& L, hipStream_t s) {

@@ -18,9 +18,12 @@ def farthest_point_sampling(x: torch.Tensor, npoints: int, start_idx: int = 0) -
     return out
 
 
-def farthest_point_sampling_reference(x: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:
-    """Same algorithm in plain torch (any device): used by the CPU plumbing test of the model (BASELINE configs[0]) and as
-    the checker of the HIP kernel in tests.  O(npoints) sequential steps."""
+def farthest_point_sampling_cpu(x: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:
+    """The same selection for a model that runs on the CPU (BASELINE configs[0]: "diffuser_actor single forward ... PyTorch CPU,
+    plumbing only"), CPU tensors only -- a GPU tensor takes the HIP kernel, and the kernel's checker is an independent numpy
+    restatement under tests/ (tests/fps_restatement.py), not this function.  O(npoints) sequential steps."""
+    if x.is_cuda:
+        raise RuntimeError("farthest_point_sampling_cpu is the CPU model's path; GPU tensors take farthest_point_sampling")
     B, N, C = x.shape
     xx = x.detach().to(torch.float32)
     dist = torch.full((B, N), float("inf"), device=x.device)

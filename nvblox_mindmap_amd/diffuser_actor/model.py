@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from ..nvblox_torch.timer import Timer
 from .backbone import VitBackbone
-from .fps import farthest_point_sampling, farthest_point_sampling_reference
+from .fps import farthest_point_sampling, farthest_point_sampling_cpu
 from . import layers as layers_mod
 from .layers import AttentionBlock, AttentionStack, FeedForwardBlock, rotary3d, sinusoidal_embedding
 from .loss import LossWeights, compute_loss
@@ -150,7 +150,7 @@ class Encoder(nn.Module):
         B, N, D = context_feats.shape
         masked = context_feats * context_mask[..., None]
         n_keep = max(N // self.cfg.fps_subsampling_factor, 1)
-        fps = farthest_point_sampling if masked.is_cuda else farthest_point_sampling_reference
+        fps = farthest_point_sampling if masked.is_cuda else farthest_point_sampling_cpu
         idx = fps(masked, n_keep, 0)
         feats = torch.gather(masked, 1, idx[..., None].expand(-1, -1, D))
         pos = torch.gather(context_pos, 1, idx[..., None].expand(-1, -1, 3))

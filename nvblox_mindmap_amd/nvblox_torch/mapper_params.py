@@ -36,6 +36,10 @@ class ProjectiveIntegratorParams(_Bag):
         "projective_appearance_integrator_measurement_weight": 1.0,
         "projective_appearance_integrator_max_weight": 5.0,
         "projective_appearance_integrator_sphere_tracing_ray_subsampling_factor": 4,
+        # the sphere tracer's remaining constants (upstream: members of its SphereTracer, not exposed as parameters)
+        "projective_appearance_integrator_sphere_tracing_max_steps": 100,
+        "projective_appearance_integrator_sphere_tracing_max_ray_length_m": 15.0,
+        "projective_appearance_integrator_sphere_tracing_surface_epsilon_vox": 0.1,
     }
 
 
@@ -44,6 +48,8 @@ class TsdfDecayIntegratorParams(_Bag):
         "tsdf_decay_factor": 0.95,
         "tsdf_decayed_weight_threshold": 1e-3,
         "decay_integrator_deallocate_decayed_blocks": True,
+        # spec switch (not an upstream field): whether Mapper.decay() also fades the colour / feature weights
+        "decay_appearance_layers": False,
     }
 
 
@@ -57,6 +63,8 @@ class ViewCalculatorParams(_Bag):
         "workspace_bounds_max_corner_x_m": 0.0,
         "workspace_bounds_max_corner_y_m": 0.0,
         "workspace_bounds_max_height_m": 0.0,
+        # spec switch (not an upstream field): blocks in view are marked along each ray up to depth + truncation (True) or depth
+        "raycast_to_truncation_distance": True,
     }
 
 
@@ -75,7 +83,9 @@ class MeshIntegratorParams(_Bag):
 
 
 _WS_TYPES = {"kUnbounded": 0, "kHeightBounds": 1, "kBoundingBox": 2}
-_WEIGHT_MODES = {"kConstantWeight": 0, "kInverseSquareWeight": 1}
+# upstream's WeightingFunctionType members (recalled); the int is mmf_params.weighting_mode
+_WEIGHT_MODES = {"kConstantWeight": 0, "kInverseSquareWeight": 1, "kConstantDropoffWeight": 2, "kInverseSquareDropoffWeight": 3,
+                 "kInverseSquareTsdfDistancePenalty": 4, "kLinearWithMax": 5}
 
 
 class MapperParams:
@@ -126,6 +136,8 @@ class MapperParams:
         p.max_weight = float(pi.projective_integrator_max_weight)
         wm = pi.projective_integrator_weighting_mode
         wm = getattr(wm, "name", wm)
+        if isinstance(wm, int) and wm in _WEIGHT_MODES.values():
+            wm = next(k for k, v in _WEIGHT_MODES.items() if v == wm)
         if wm not in _WEIGHT_MODES:
             raise ValueError(f"unsupported projective_integrator_weighting_mode: {wm}")
         p.weighting_mode = _WEIGHT_MODES[wm]
@@ -133,6 +145,9 @@ class MapperParams:
         p.appearance_measurement_weight = float(pi.projective_appearance_integrator_measurement_weight)
         p.appearance_max_weight = float(pi.projective_appearance_integrator_max_weight)
         p.st_subsampling = int(pi.projective_appearance_integrator_sphere_tracing_ray_subsampling_factor)
+        p.st_max_steps = int(pi.projective_appearance_integrator_sphere_tracing_max_steps)
+        p.st_max_ray_length_m = float(pi.projective_appearance_integrator_sphere_tracing_max_ray_length_m)
+        p.st_surface_eps_vox = float(pi.projective_appearance_integrator_sphere_tracing_surface_epsilon_vox)
         p.raycast_subsampling = int(vc.raycast_subsampling_factor)
         ws = getattr(vc.workspace_bounds_type, "name", vc.workspace_bounds_type)
         if ws not in _WS_TYPES:
@@ -151,4 +166,6 @@ class MapperParams:
         p.feature_channels = int(feature_channels)
         p.num_preallocated_blocks = int(po.num_preallocated_blocks)
         p.expansion_factor = float(po.expansion_factor)
+        p.raycast_to_truncation = 1 if vc.raycast_to_truncation_distance else 0
+        p.decay_appearance_layers = 1 if de.decay_appearance_layers else 0
         return p

@@ -66,7 +66,9 @@ typedef struct {
   float max_integration_distance_m;    /* nvblox default 7.0; reference sets 5.0            */
   float truncation_distance_vox;       /* 4.0                                               */
   float max_weight;                    /* 5.0                                               */
-  int weighting_mode;                  /* 0 constant(1.0), 1 inverse-square 1/d^2           */
+  int weighting_mode;                  /* upstream's WeightingFunctionType family, see tsdf_weight(): 0 constant, 1 inverse-square,
+                                          2 constant-dropoff, 3 inverse-square-dropoff, 4 inverse-square-TSDF-distance-penalty,
+                                          5 linear-with-max                                                                  */
   float lin_interp_max_diff_vox;       /* 2.0: bilinear depth only if taps agree, else NN   */
   float appearance_measurement_weight; /* 1.0  (nvblox_mapper_constants.py:41)              */
   float appearance_max_weight;         /* 5.0                                               */
@@ -83,6 +85,8 @@ typedef struct {
   float st_max_ray_length_m;           /* 15.0                                              */
   float st_surface_eps_vox;            /* 0.1                                               */
   int feature_channels;                /* C (compile-time 768 in the reference build)       */
+  int raycast_to_truncation;           /* 1: blocks in view are marked up to depth + truncation; 0: up to the depth    */
+  int decay_appearance_layers;         /* 0: decay() leaves colour / feature weights alone; 1: multiplies them too      */
 } orc_params;
 
 void orc_default_params(orc_params* p) {
@@ -101,6 +105,8 @@ void orc_default_params(orc_params* p) {
   p->decayed_weight_threshold = 1e-3f;
   p->deallocate_decayed_blocks = 1;
   p->mesh_min_weight = 1e-4f;
+  p->raycast_to_truncation = 1;
+  p->decay_appearance_layers = 0;
   p->st_subsampling = 4;
   p->st_max_steps = 100;
   p->st_max_ray_length_m = 15.0f;
@@ -584,7 +590,7 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
         if (mask && !mask[(size_t)r * cam->W + c]) continue;
         if (P->max_integration_distance_m > 0.0f && d > P->max_integration_distance_m)
           d = P->max_integration_distance_m;
-        float s = d + m->trunc;
+        float s = m->P.raycast_to_truncation ? d + m->trunc : d;
         float ray[3] = {((float)c + 0.5f - cam->cx) / cam->fx, ((float)r + 0.5f - cam->cy) / cam->fy, 1.0f};
         float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
         float pL[3];
@@ -669,9 +675,32 @@ static inline int sample_depth(const orc_mapper* m, const float* depth, const ui
   return 1;
 }
 
-static inline float tsdf_weight(const orc_mapper* m, float d) {
-  if (m->P.weighting_mode == 0) return 1.0f;
-  return 1.0f / (d * d);
+/*
+ * Measurement weight of a TSDF update: upstream nvblox's WeightingFunctionType family (RECALLED; the reference leaves
+ * projective_integrator_weighting_mode at upstream's default, nvblox_mapping_helpers.py:40-46).  d = sampled depth of the
+ * pixel, sdf = d - voxel depth, trunc = truncation distance.
+ *   0 kConstantWeight                     1
+ *   1 kInverseSquareWeight                1 / d^2                                         (this spec's default)
+ *   2 kConstantDropoffWeight              dropoff(sdf)
+ *   3 kInverseSquareDropoffWeight         (1 / d^2) * dropoff(sdf)
+ *   4 kInverseSquareTsdfDistancePenalty   (1 / d^2) * penalty(sdf)
+ *   5 kLinearWithMax                      min(1 / d, 1)
+ *   dropoff(sdf) = 1 in front of the surface, falling linearly to 0 at -trunc behind it: sdf >= 0 ? 1 : max((trunc + sdf) / trunc, 0)
+ *   penalty(sdf) = 1 - 0.5 * min(|sdf|, trunc) / trunc        (voxels far from the measured surface count half)
+ * The shapes of dropoff / penalty / linear-with-max are low-confidence recollections: they exist so that the pin kit
+ * (tests/pin_report.py) can tell which member upstream's default is, not as a claim about its constants.
+ * A measurement of weight <= 0 is skipped (the blend would divide by W alone).
+ */
+static inline float tsdf_weight(const orc_mapper* m, float d, float sdf) {
+  const float trunc = m->trunc;
+  switch (m->P.weighting_mode) {
+    case 0: return 1.0f;
+    case 1: return 1.0f / (d * d);
+    case 2: return sdf >= 0.0f ? 1.0f : fmaxf((trunc + sdf) / trunc, 0.0f);
+    case 3: return (1.0f / (d * d)) * (sdf >= 0.0f ? 1.0f : fmaxf((trunc + sdf) / trunc, 0.0f));
+    case 4: return (1.0f / (d * d)) * (1.0f - 0.5f * (fminf(fabsf(sdf), trunc) / trunc));
+    default: return fminf(1.0f / d, 1.0f);
+  }
 }
 
 /*
@@ -699,7 +728,8 @@ static void tsdf_integrate(orc_mapper* m, const float* depth, const uint8_t* mas
       if (!sample_depth(m, depth, mask, cam, u, v, &d)) continue;
       float sdf = d - p[2];
       if (sdf < -m->trunc) continue;
-      float wm = tsdf_weight(m, d);
+      float wm = tsdf_weight(m, d, sdf);
+      if (!(wm > 0.0f)) continue;
       float D = tb->d[lin], W = tb->w[lin];
       float Dn = (sdf * wm + D * W) / (wm + W);
       Dn = Dn > 0.0f ? fminf(m->trunc, Dn) : fmaxf(-m->trunc, Dn);
@@ -1002,6 +1032,16 @@ void orc_decay(orc_mapper* m) {
   }
   if (any) layer_remove(&m->tsdf, kill);
   free(kill);
+  if (m->P.decay_appearance_layers) { /* option: the appearance weights fade with the same factor (no deallocation) */
+    for (int i = 0; i < m->color.n; ++i) {
+      color_block* cb = (color_block*)m->color.blocks[i].data;
+      for (int lin = 0; lin < VPB; ++lin) cb->w[lin] = cb->w[lin] * m->P.tsdf_decay_factor;
+    }
+    for (int i = 0; i < m->feat.n; ++i) {
+      float* w = featw_ptr(m->feat.blocks[i].data, m->P.feature_channels);
+      for (int lin = 0; lin < VPB; ++lin) w[lin] = w[lin] * m->P.tsdf_decay_factor;
+    }
+  }
 }
 
 /* ------------------------------------------------------------------------------- */

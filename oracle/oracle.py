@@ -39,6 +39,8 @@ class OrcParams(C.Structure):
         ("st_max_ray_length_m", C.c_float),
         ("st_surface_eps_vox", C.c_float),
         ("feature_channels", C.c_int),
+        ("raycast_to_truncation", C.c_int),
+        ("decay_appearance_layers", C.c_int),
     ]
 
 

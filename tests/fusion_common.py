@@ -24,30 +24,45 @@ def make_oracle(O, channels, **over):
 
 
 def make_mapper(channels, **over):
-    """HIP Mapper configured like the oracle (same parameter names as oracle.OrcParams)."""
+    """HIP Mapper configured like the oracle: same parameter names as oracle.OrcParams, every one of them honoured
+    (an unknown name raises -- a silently ignored override would make a spec flip a no-op)."""
     from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
     from nvblox_mindmap_amd.nvblox_torch.mapper_params import (
-        BlockMemoryPoolParams, MapperParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams, ViewCalculatorParams)
+        BlockMemoryPoolParams, MapperParams, MeshIntegratorParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams,
+        ViewCalculatorParams)
 
     kw = dict(REF_PARAMS)
     kw.update(over)
-    pi = ProjectiveIntegratorParams()
-    pi.projective_integrator_max_integration_distance_m = kw["max_integration_distance_m"]
-    pi.projective_appearance_integrator_measurement_weight = kw["appearance_measurement_weight"]
-    if "truncation_distance_vox" in kw:
-        pi.projective_integrator_truncation_distance_vox = kw["truncation_distance_vox"]
-    if "weighting_mode" in kw:
-        pi.projective_integrator_weighting_mode = ["kConstantWeight", "kInverseSquareWeight"][kw["weighting_mode"]]
-    if "max_weight" in kw:
-        pi.projective_integrator_max_weight = kw["max_weight"]
-    if "st_subsampling" in kw:
-        pi.projective_appearance_integrator_sphere_tracing_ray_subsampling_factor = kw["st_subsampling"]
-    de = TsdfDecayIntegratorParams()
-    de.tsdf_decay_factor = kw["tsdf_decay_factor"]
-    if "decayed_weight_threshold" in kw:
-        de.tsdf_decayed_weight_threshold = kw["decayed_weight_threshold"]
-    vc = ViewCalculatorParams()
-    vc.raycast_subsampling_factor = kw["raycast_subsampling"]
+    pi, de, vc, me, pool = (ProjectiveIntegratorParams(), TsdfDecayIntegratorParams(), ViewCalculatorParams(), MeshIntegratorParams(),
+                            BlockMemoryPoolParams())
+    routes = {
+        "max_integration_distance_m": (pi, "projective_integrator_max_integration_distance_m", float),
+        "appearance_measurement_weight": (pi, "projective_appearance_integrator_measurement_weight", float),
+        "appearance_max_weight": (pi, "projective_appearance_integrator_max_weight", float),
+        "truncation_distance_vox": (pi, "projective_integrator_truncation_distance_vox", float),
+        "weighting_mode": (pi, "projective_integrator_weighting_mode", int),
+        "max_weight": (pi, "projective_integrator_max_weight", float),
+        "lin_interp_max_diff_vox": (pi, "projective_tsdf_integrator_linear_interpolation_max_allowable_difference_vox", float),
+        "st_subsampling": (pi, "projective_appearance_integrator_sphere_tracing_ray_subsampling_factor", int),
+        "st_max_steps": (pi, "projective_appearance_integrator_sphere_tracing_max_steps", int),
+        "st_max_ray_length_m": (pi, "projective_appearance_integrator_sphere_tracing_max_ray_length_m", float),
+        "st_surface_eps_vox": (pi, "projective_appearance_integrator_sphere_tracing_surface_epsilon_vox", float),
+        "tsdf_decay_factor": (de, "tsdf_decay_factor", float),
+        "decayed_weight_threshold": (de, "tsdf_decayed_weight_threshold", float),
+        "deallocate_decayed_blocks": (de, "decay_integrator_deallocate_decayed_blocks", bool),
+        "decay_appearance_layers": (de, "decay_appearance_layers", bool),
+        "raycast_subsampling": (vc, "raycast_subsampling_factor", int),
+        "raycast_to_truncation": (vc, "raycast_to_truncation_distance", bool),
+        "mesh_min_weight": (me, "mesh_integrator_min_weight", float),
+        "num_preallocated_blocks": (pool, "num_preallocated_blocks", int),
+    }
+    for k, v in kw.items():
+        if k in ("voxel_size", "ws_min", "ws_max", "workspace_bounds_type"):
+            continue
+        if k not in routes:
+            raise KeyError(f"make_mapper: no route for parameter '{k}'")
+        bag, name, cast = routes[k]
+        setattr(bag, name, cast(v))
     vc.workspace_bounds_type = ["kUnbounded", "kHeightBounds", "kBoundingBox"][kw["workspace_bounds_type"]]
     vc.workspace_bounds_min_corner_x_m = float(kw["ws_min"][0])
     vc.workspace_bounds_min_corner_y_m = float(kw["ws_min"][1])
@@ -59,10 +74,8 @@ def make_mapper(channels, **over):
     mp.set_projective_integrator_params(pi)
     mp.set_tsdf_decay_integrator_params(de)
     mp.set_view_calculator_params(vc)
-    if "num_preallocated_blocks" in kw:
-        pool = BlockMemoryPoolParams()
-        pool.num_preallocated_blocks = int(kw["num_preallocated_blocks"])
-        mp.set_block_memory_pool_params(pool)
+    mp.set_mesh_integrator_params(me)
+    mp.set_block_memory_pool_params(pool)
     return Mapper(voxel_sizes_m=kw["voxel_size"], mapper_parameters=mp, feature_channels=channels)
 
 

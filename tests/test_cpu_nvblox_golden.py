@@ -61,6 +61,33 @@ def test_kit_round_trip_on_the_cpu_oracle(tmp_path):
     assert not NG.passes_north_star(flipped), flipped
 
 
+def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
+    """tests/pin_report.py on a file dumped from the oracle itself: "as specified" reproduces it, at least twelve spec items are
+    parameters (flipped with zero code edits), and the flips are not no-ops -- all but a few change the replay."""
+    import pin_report
+
+    kit = NG.load_kit()
+    out = kit.replay(NG.oracle_backend(), "small", "patches", 3, True, True, device="cpu")
+    path = tmp_path / "nvblox_small_patches.npz"
+    np.savez_compressed(path, **out)
+    meta = json.loads(str(np.load(path, allow_pickle=False)["meta"]))
+    items = [it for it in meta["spec_items"] if it.get("param") is not None]
+    assert len(items) >= 12, [it["item"] for it in items]
+    assert {"weighting_mode", "raycast_to_truncation", "decay_appearance_layers"} <= {it["param"] for it in items}
+    wm = next(it for it in items if it["param"] == "weighting_mode")
+    assert sorted(wm["flips"] + [wm["ours"]]) == [0, 1, 2, 3, 4, 5], "upstream's six weighting functions"
+    results = pin_report.main([str(path)])
+    capsys.readouterr()
+    name0, r0 = results[0]
+    assert name0 == "as specified" and NG.passes_north_star(r0)
+    changed = {name for name, r in results[1:] if not NG.passes_north_star(r)}
+    params_changed = {n.split("=")[0] for n in changed}
+    # (three frames cannot saturate the maximum weights or reach the ray-length limit: those flips need a longer stream)
+    assert len(params_changed) >= 9, sorted(params_changed)
+    for mode in (0, 2, 3, 4, 5):
+        assert f"weighting_mode={mode}" in changed, "every member of the weighting family must give a different map"
+
+
 @pytest.mark.parametrize("path", NG.golden_files() or [None])
 def test_oracle_matches_dumped_nvblox_vectors(path):
     if path is None:

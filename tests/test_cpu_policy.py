@@ -121,17 +121,17 @@ def test_attention_ignores_masked_keys():
 
 
 def test_fps_reference_semantics():
-    from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling_reference
+    from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling_cpu
 
     x = torch.tensor([[[0.0, 0], [1, 0], [10, 0], [10.5, 0], [-3, 0], [0, 0], [0, 0]]])
-    idx = farthest_point_sampling_reference(x, 4, 0)[0].tolist()
+    idx = farthest_point_sampling_cpu(x, 4, 0)[0].tolist()
     assert idx[0] == 0 and idx[1] == 3 and idx[2] == 4 and idx[3] == 1  # farthest from {0}, then from {0, 3}, ...
     torch.manual_seed(1)
     y = torch.randn(3, 200, 16)
-    i2 = farthest_point_sampling_reference(y, 40, 0)
+    i2 = farthest_point_sampling_cpu(y, 40, 0)
     assert i2.shape == (3, 40) and all(len(set(r.tolist())) == 40 for r in i2)
     z = torch.zeros(1, 5, 3)  # all ties: first index every time
-    assert farthest_point_sampling_reference(z, 3, 0)[0].tolist() == [0, 0, 0]
+    assert farthest_point_sampling_cpu(z, 3, 0)[0].tolist() == [0, 0, 0]
 
 
 def _tiny_cfg(**kw):

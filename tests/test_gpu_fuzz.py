@@ -109,10 +109,12 @@ def draw_parameters(seed):
     voxel = float(r.choice([0.02, 0.04])) if bounds != 2 else float(r.choice([0.01, 0.0125, 0.02]))
     over = dict(
         voxel_size=voxel, workspace_bounds_type=bounds, max_integration_distance_m=float(r.choice([2.0, 3.0, 5.0])),
-        truncation_distance_vox=float(r.choice([2.0, 4.0, 6.0])), weighting_mode=int(r.integers(2)), max_weight=float(r.choice([5.0, 100.0])),
+        truncation_distance_vox=float(r.choice([2.0, 4.0, 6.0])), weighting_mode=int(r.integers(6)), max_weight=float(r.choice([5.0, 100.0])),
         st_subsampling=int(r.choice([2, 4, 4, 8])), raycast_subsampling=int(r.choice([1, 1, 2, 4])),
         tsdf_decay_factor=float(r.choice([0.98, 0.5, 0.1])), decayed_weight_threshold=float(r.choice([1e-3, 1e-2])),
-        appearance_measurement_weight=float(r.choice([1.0, 0.25])))
+        appearance_measurement_weight=float(r.choice([1.0, 0.25])), raycast_to_truncation=int(r.choice([1, 1, 0])),
+        decay_appearance_layers=int(r.choice([0, 0, 1])), lin_interp_max_diff_vox=float(r.choice([2.0, 2.0, 0.0, 1e9])),
+        mesh_min_weight=float(r.choice([1e-4, 1e-2])), appearance_max_weight=float(r.choice([5.0, 100.0])))
     return dict(w=w, h=h, C=int(CHANNELS[r.integers(len(CHANNELS))]), over=over, frames=[int(i) for i in r.integers(0, 200, size=int(r.integers(2, 6)))],
                 use_mask=bool(r.integers(2)), color=bool(r.integers(2)), decay=bool(r.integers(2)))
 

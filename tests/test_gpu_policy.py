@@ -12,16 +12,17 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(4, 3072, 120, 614), (2, 500, 7, 100), (1, 8192, 16, 33), (3, 64, 1024, 64),
                                    (200, 3072, 120, 40)])  # more batch elements than can be co-resident: launched in chunks
 def test_fps_kernel_matches_reference(shape):
-    from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling, farthest_point_sampling_reference
+    from fps_restatement import farthest_point_sampling_numpy  # independent numpy restatement of the dgl op (tests/)
+    from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling
 
     B, N, C, n = shape
     torch.manual_seed(N)
     x = torch.randn(B, N, C, device="cuda")
     x[:, N // 3: N // 3 + N // 10] = 0  # masked-out tokens are zeroed by the encoder: many identical points
     got = farthest_point_sampling(x, n, 0)
-    ref = farthest_point_sampling_reference(x, n, 0)
+    ref = torch.from_numpy(farthest_point_sampling_numpy(x.cpu().numpy(), n, 0))
     assert got.dtype == torch.int64 and got.shape == (B, n)
-    assert torch.equal(got, ref)
+    assert torch.equal(got.cpu(), ref)
     assert torch.equal(farthest_point_sampling(x, min(n, 5), 3)[:, 0], torch.full((B,), 3, device="cuda"))
 
 

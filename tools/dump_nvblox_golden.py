@@ -116,7 +116,8 @@ CONFIGS = {
 SPEC_ITEMS = [
     dict(item="depth sampling rule", param="lin_interp_max_diff_vox", ours=2.0, flips=[0.0, 1e9],
          note="0 = nearest tap only, 1e9 = always bilinear, 2 = bilinear where the four taps agree within 2 voxels"),
-    dict(item="TSDF measurement weight", param="weighting_mode", ours=1, flips=[0], note="1 = 1/depth^2, 0 = constant 1"),
+    dict(item="TSDF measurement weight (upstream's WeightingFunctionType)", param="weighting_mode", ours=1, flips=[0, 2, 3, 4, 5],
+         note="0 constant, 1 inverse-square, 2 constant-dropoff, 3 inverse-square-dropoff, 4 inverse-square-TSDF-distance-penalty, 5 linear-with-max"),
     dict(item="TSDF max weight", param="max_weight", ours=5.0, flips=[100.0, 1e4]),
     dict(item="truncation distance (voxels)", param="truncation_distance_vox", ours=4.0, flips=[2.0, 8.0]),
     dict(item="appearance max weight", param="appearance_max_weight", ours=5.0, flips=[100.0, 1e4]),
@@ -125,10 +126,13 @@ SPEC_ITEMS = [
     dict(item="mesh minimum weight", param="mesh_min_weight", ours=1e-4, flips=[1e-6, 1e-2]),
     dict(item="sphere-tracing ray subsampling (occlusion test)", param="st_subsampling", ours=4, flips=[1, 2]),
     dict(item="sphere-tracing surface epsilon (voxels)", param="st_surface_eps_vox", ours=0.1, flips=[0.5]),
-    dict(item="raycast marks blocks up to depth + truncation", param=None, flips=None, note="code: k_front / orc_raycast_mark"),
+    dict(item="sphere-tracing maximum steps", param="st_max_steps", ours=100, flips=[25, 400]),
+    dict(item="sphere-tracing maximum ray length (m)", param="st_max_ray_length_m", ours=15.0, flips=[4.0]),
+    dict(item="raycast marks blocks up to depth + truncation (0: up to the depth)", param="raycast_to_truncation", ours=1, flips=[0]),
+    dict(item="decay leaves the colour / feature layers untouched (1: their weights fade too)", param="decay_appearance_layers", ours=0,
+         flips=[1]),
     dict(item="appearance blend uses one reciprocal per voxel", param=None, flips=None, note="code: <= 1 f16 ulp either way"),
     dict(item="feature storage rounding (RNE)", param=None, flips=None, note="code: __float2half_rn"),
-    dict(item="decay leaves the colour / feature layers untouched", param=None, flips=None, note="code: mmf_decay"),
     dict(item="feature-mesh vertex takes the feature of the voxel containing it", param=None, flips=None, note="code: k_mesh_emit"),
 ]
 

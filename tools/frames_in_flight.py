@@ -56,9 +56,11 @@ def main():
     ap.add_argument("--n", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--switch-interval", type=float, default=2e-5)
     args = ap.parse_args()
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
+    sys.setswitchinterval(args.switch_interval)  # the workers hand the GIL over at every native call; 5 ms (the default) convoys them
     cfg = S.StreamConfig(hole_mode="patches")
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     frames = bench.build_stream(cfg, 100, 64, device)
