@@ -2,7 +2,7 @@
 # Collects the per-round rocprofv3 evidence on the GPU box: kernel trace + two PMC passes (FETCH_SIZE, WRITE_SIZE -- separate
 # passes, kernel-trace/stats only, as the guide prescribes) of the same bench command, for the benchmark shape (640x480x64:
 # `bench.py --only-fusion`) and for the reference's shape (512x512x768: `bench.py --ref-shape-only`).
-# Usage (through gpurun): bash tools/profile_round.sh r02a [bl|ref|both]   -> gpurun_out/prof_<tag>/{bl,ref}/...
+# Usage (through gpurun): bash tools/profile_round.sh r02a [bl|ref|both|unbounded]   -> gpurun_out/prof_<tag>/{bl,ref}/...
 set -u
 tag=${1:-rXX}
 which=${2:-both}
@@ -27,5 +27,8 @@ if [ "$which" = "bl" ] || [ "$which" = "both" ]; then
 fi
 if [ "$which" = "ref" ] || [ "$which" = "both" ]; then
   run_passes ref --ref-shape-only
+fi
+if [ "$which" = "unbounded" ]; then  # the hash path: same stream, workspace_bounds_type = kUnbounded
+  run_passes unbounded --unbounded-only --steps 100 --warmup 60
 fi
 ls -la gpurun_out/prof_$tag/* | head -40
