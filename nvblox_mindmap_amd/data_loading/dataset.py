@@ -21,19 +21,25 @@ import torch
 from torch.utils.data import Dataset
 
 from ..io import dataset_files as D
+from ..io import vertex_cache as VC
 from ..mapping.nvblox_mapper_constants import DEPTH_SCALE_FACTOR
-from .vertex_sampling import VertexSamplingMethod, sample_to_n_vertices
+from .vertex_sampling import VertexSamplingMethod, sample_to_n_vertices, select_vertex_indices
 
 
 class MindmapFrameDataset(Dataset):
     def __init__(self, dataset_path: str, cameras: Sequence[str] = ("pov",), num_vertices: int = 2048,
                  vertex_sampling_method: VertexSamplingMethod = VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT,
-                 with_vertex_features: bool = True, seed: Optional[int] = None, geometry_augmentor=None, geometry_noiser=None):
+                 with_vertex_features: bool = True, seed: Optional[int] = None, geometry_augmentor=None, geometry_noiser=None,
+                 use_raw_vertex_cache: bool = True):
         """``geometry_augmentor`` / ``geometry_noiser``: sample_transformer.GeometryAugmentor / GeometryNoiser, wired as the
         reference does (dataset_files_by_encoding_method.py:258-279): ONE random rigid transform per sample applied to the mesh
         vertices, the gripper history and the target poses; independent Gaussian pose noise on the history and the vertices,
         not on the target; both before the vertices are sampled."""
         self.augmentor, self.noiser = geometry_augmentor, geometry_noiser
+        # ``use_raw_vertex_cache``: where ``io.vertex_cache.convert_dataset`` has left a memory-mappable copy of a frame's vertex
+        # features, map it and read only the sampled rows (same selection, same values; 3 MB of page cache instead of 18 MB of
+        # zstd + pickle per sample at the reference's shape)
+        self.use_raw_vertex_cache = use_raw_vertex_cache
         self.cameras = list(cameras)
         self.num_vertices = num_vertices
         self.method = vertex_sampling_method
@@ -66,6 +72,31 @@ class MindmapFrameDataset(Dataset):
     def __len__(self) -> int:
         return len(self.samples)
 
+    def _sample_from_raw(self, raw_path: str, geometric, seed):
+        """``sample_to_n_vertices`` on the mapped file: ALL vertices are read (6 B each) and augmented / noised exactly as on
+        the decompressed path (same RNG draws), the selection is drawn on the same V, and only the selected FEATURE rows are
+        touched.  Returns what the decompressed path returns."""
+        v_map, f_map = VC.open_raw(raw_path)
+        vertices = torch.from_numpy(np.array(v_map))  # [V,3] float16 copy
+        if self.augmentor is not None or self.noiser is not None:
+            vertices = geometric(vertices.to(torch.float32), noisy=True)
+        n, want, method = vertices.shape[0], self.num_vertices, self.method
+        if method == VertexSamplingMethod.NONE or n == want:
+            return vertices.to(torch.float32), torch.from_numpy(np.array(f_map)), torch.ones(n, dtype=torch.bool)
+        if n > want:
+            sel = select_vertex_indices(n, want, method, "cpu", seed, vertices[:, 2])
+            rows = sel.numpy()
+            order = np.argsort(rows, kind="stable")  # ascending file offsets for the page cache; undone below
+            feats = np.empty((want, f_map.shape[1]), dtype=np.float16)
+            feats[order] = f_map[rows[order]]
+            return vertices[sel].to(torch.float32), torch.from_numpy(feats), torch.ones(want, dtype=torch.bool)
+        pad = want - n
+        feats = torch.cat([torch.from_numpy(np.array(f_map)), torch.zeros((pad, f_map.shape[1]), dtype=torch.float16)], dim=0)
+        verts = torch.cat([vertices, torch.zeros((pad, 3), dtype=vertices.dtype)], dim=0)
+        valid = torch.ones(want, dtype=torch.bool)
+        valid[n:] = False
+        return verts.to(torch.float32), feats, valid
+
     def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
         it = self.samples[idx]
         out = {}
@@ -94,14 +125,18 @@ class MindmapFrameDataset(Dataset):
         if "gt_head_yaw" in it:
             out["gt_head_yaw"] = torch.as_tensor(np.load(it["gt_head_yaw"])).to(torch.float32)
         if self.with_vertex_features:
-            s = D.read_vertex_features(it["vertex_features"])
-            if self.augmentor is not None or self.noiser is not None:
-                s["vertices"] = geometric(s["vertices"].to(torch.float32), noisy=True)
-            # sample the stored f16 rows, convert afterwards: the same N rows as sampling the float32 copy (selection / padding
-            # do no arithmetic), without a float32 copy of the whole [V, C] matrix (37 MB at V = 12 k, C = 768) per sample
-            v, f, valid = sample_to_n_vertices(s["vertices"], s["features"], self.num_vertices, self.method,
-                                               None if self.seed is None else self.seed + idx)
-            out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = v.to(torch.float32), f.to(torch.float16), valid
+            seed = None if self.seed is None else self.seed + idx
+            raw = VC.raw_path_of(it["vertex_features"]) if self.use_raw_vertex_cache else None
+            if raw is not None and os.path.exists(raw):
+                out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = self._sample_from_raw(raw, geometric, seed)
+            else:
+                s = D.read_vertex_features(it["vertex_features"])
+                if self.augmentor is not None or self.noiser is not None:
+                    s["vertices"] = geometric(s["vertices"].to(torch.float32), noisy=True)
+                # sample the stored f16 rows, convert afterwards: the same N rows as sampling the float32 copy (selection / padding
+                # do no arithmetic), without a float32 copy of the whole [V, C] matrix (37 MB at V = 12 k, C = 768) per sample
+                v, f, valid = sample_to_n_vertices(s["vertices"], s["features"], self.num_vertices, self.method, seed)
+                out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = v.to(torch.float32), f.to(torch.float16), valid
         return out
 
 

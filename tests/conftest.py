@@ -19,4 +19,7 @@ def oracle_mod():
 
     O.build()
     O.lib()
+    # a frame's work is a few thousand blocks: beyond ~16 threads the OpenMP fan-out costs more than it buys (bench.py's thread
+    # sweep: 39 frames/s on 16 threads, 1.6 on the GPU box's 256), and that box gives the container a 16-CPU quota anyway
+    O.set_num_threads(min(16, os.cpu_count() or 1))
     return O

@@ -218,3 +218,67 @@ def test_facade_hands_the_backbone_output_to_the_native_call(include_dynamic, mo
         assert float(fa[0].float().abs().max()) > 0
         ca, cb = a.color_layer_view(mid).get_all_blocks_split(), b.color_layer_view(mid).get_all_blocks_split()
         assert all(torch.equal(x, y) for x, y in zip(ca, cb))
+
+
+def test_mirrored_feature_extractor_through_the_facade(monkeypatch):
+    """image_processing.feature_extraction (the reference's extractor contract, golden-pinned on the CPU) driving the facade:
+    an extractor with a normalisation hook and a 3 -> 16 channel stand-in network.  ``compute`` returns float32 like the
+    reference; the facade prefers ``compute_lowres`` (the model's 16x16 output, sampled inside the integration kernel) and
+    the map equals the one built from ``compute(rgb)`` cast to float16 (nvblox_mapping_helpers.py:256): same blocks and
+    weights, features within two float16 ulps (``compute`` resizes with torch's bilinear kernel, whose float32 products are
+    contracted into FMAs; the integration kernel's are not -- tests/golden/feature_upsample.npz pins that difference)."""
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+    from nvblox_mindmap_amd.image_processing import feature_extraction as FE
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
+    from nvblox_mindmap_amd.nvblox_torch.constants import constants
+
+    size, C = 256, 24
+    cfg = S.StreamConfig(width=size, height=size, fx=293.2, fy=293.2, cx=127.5, cy=127.5, hole_mode="patches")
+
+    class Tiny(FE.FeatureExtractor):
+        @staticmethod
+        def embedding_dim():
+            return 16
+
+        def model_input_size(self):
+            return (64, 64)
+
+        def model_output_size(self):
+            return (16, 16)
+
+        def load_model(self):
+            torch.manual_seed(4)
+            return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 4, stride=4), torch.nn.Tanh(), torch.nn.Conv2d(8, 16, 1))
+
+        def _extract_features_impl(self, rgb_bchw):
+            with torch.no_grad():
+                return self.model(rgb_bchw)
+
+        def train_dataset_mean_and_std(self):
+            return torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+
+    constants.set_feature_array_num_elements(C)
+    try:
+        facades = []
+        for lowres in (True, False):
+            ex = Tiny(pad_to_nvblox_dim=True, desired_output_size=(size, size))
+            assert ex.num_excess_features() == 8
+            facades.append((IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=ex, task="DRILL_IN_BOX",
+                                                 feature_channels=C), lowres))
+        for idx in (0, 8, 16):
+            sample, _, _ = make_sample(cfg, idx, "cuda")
+            for facade, lowres in facades:
+                monkeypatch.setattr(H, "LOWRES_FEATURES", lowres)
+                facade.decay()
+                facade.update_reconstruction_from_sample(sample, "pov")
+        a, b = facades[0][0].mapper, facades[1][0].mapper
+        fa, fb = a.feature_layer_view(0).get_all_blocks_split(), b.feature_layer_view(0).get_all_blocks_split()
+        assert fa[2].shape[0] > 20 and torch.equal(fa[1], fb[1]) and torch.equal(fa[2], fb[2])
+        assert torch.allclose(fa[0].float(), fb[0].float(), rtol=2e-3, atol=2e-3)
+        assert float(fa[0][..., :16].float().abs().max()) > 0 and float(fa[0][..., 16:].float().abs().max()) == 0
+        img = facades[1][0].last_nvblox_integration_images["pov"]["STATIC"]["feature_frame"]
+        assert img.dtype == torch.float32 and img.shape == (size, size, C)  # compute() keeps the reference's dtype
+        out = facades[0][0].get_nvblox_model_inputs(0, remove_zero_features=True)
+        assert out["vertex_features"].shape == (1, 2048, 16) and out["vertex_features"].dtype == torch.float32
+    finally:
+        constants.set_feature_array_num_elements(768)
