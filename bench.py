@@ -733,15 +733,16 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     return out
 
 
-def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=12, workers=None,
+def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=12, workers=6,
                           vertex_count_range=(10000, 14000)):
     """Is the training step loader-bound?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader keeping the GPUs
     fed, not the 10.9 MB all-reduce.)  A demo in the reference's on-disk layout -- 512x512 rgb + u16 depth PNGs, pose /
     intrinsics .npy, one UNSAMPLED vertex-feature .zst per frame (10-14 k vertices x 768 f16 channels, ~20 MB: what
-    save_feature_mesh_to_disk writes) -- is read by MindmapFrameDataset through a torch DataLoader (workers decode PNG / zstd,
-    unpickle and sample 2048 vertices; uint8 / uint16 images go to the GPU, transforms + back-projection run there) and fed to
-    train_one_step at per-GPU batch 32.  Reported: loader-only samples/s at that worker count, file-fed step/s, and the
-    compute-bound step/s of the synthetic-resident leg beside it."""
+    save_feature_mesh_to_disk writes) -- is read by MindmapFrameDataset through a torch DataLoader with `workers` = 6 worker
+    processes (6 host cores per GPU: an 8-GPU node has to run 8 such loaders) and fed to train_one_step at per-GPU batch 32.
+    The loader reads the vertex features from the memory-mapped raw copy ``io.vertex_cache.convert_dataset`` leaves next to every
+    .zst (only the 2048 sampled rows are touched; same selection, same values); the decompress-everything path the reference's
+    loader takes is timed beside it, loader only, at the same worker count and at the reference's 20."""
     import shutil
     import tempfile
 
@@ -749,11 +750,11 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
 
     from nvblox_mindmap_amd.data_loading.dataset import DevicePrefetcher, MindmapFrameDataset, write_synthetic_demo
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.io import vertex_cache
     from nvblox_mindmap_amd.training import build_model, build_optimizer, train_one_step
 
     cfg = DiffuserActorConfig()
     ncpu = os.cpu_count() or 1
-    workers = workers if workers is not None else max(1, min(20, ncpu - 2))  # the reference's default: 20 loader workers per GPU
     root = tempfile.mkdtemp(prefix="mmf_file_fed_")
     try:
         t0 = time.perf_counter()
@@ -761,26 +762,36 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
                              num_history=cfg.num_history, prediction_horizon=cfg.prediction_horizon, ngrippers=cfg.ngrippers,
                              vertex_count_range=vertex_count_range)
         t_write = time.perf_counter() - t0
-        ds = MindmapFrameDataset(root, num_vertices=2048)
-        mb = sum(os.path.getsize(p) for smp in ds.samples for p in smp.values()) / len(ds) / 1e6
-        # a DataLoader hands whole batches to workers: an epoch must hold several batches per worker or most workers idle.  The
-        # frames on disk are revisited (page-cache reads; a real dataset adds storage latency on top of what is measured here)
-        ds.samples = ds.samples * max(1, -(-3 * workers * per_gpu_batch // len(ds.samples)))
-
-        def loader():
-            return DataLoader(ds, batch_size=per_gpu_batch, shuffle=True, num_workers=workers, drop_last=False, pin_memory=True,
-                              persistent_workers=True, prefetch_factor=2)
-
-        dl = loader()
-        n = 0
-        for i, b in enumerate(dl):  # page cache + worker start-up, untimed
-            if i >= workers:
-                break
         t0 = time.perf_counter()
-        n = 0
-        for b in dl:
-            n += b["rgb_u8"].shape[0]
-        loader_sps = n / (time.perf_counter() - t0)
+        n_raw = vertex_cache.convert_dataset(root)
+        t_convert = time.perf_counter() - t0
+
+        def make(raw: bool, nw: int):
+            ds = MindmapFrameDataset(root, num_vertices=2048, use_raw_vertex_cache=raw)
+            mb = sum(os.path.getsize(p) for smp in ds.samples for p in smp.values()) / len(ds) / 1e6
+            # a DataLoader hands whole batches to workers: an epoch must hold several batches per worker or most workers idle.  The
+            # frames on disk are revisited (page-cache reads; a real dataset adds storage latency on top of what is measured here)
+            ds.samples = ds.samples * max(1, -(-3 * nw * per_gpu_batch // len(ds.samples)))
+            return DataLoader(ds, batch_size=per_gpu_batch, shuffle=True, num_workers=nw, drop_last=False, pin_memory=True,
+                              persistent_workers=True, prefetch_factor=2), mb
+
+        def loader_rate(dl, nw):
+            for i, b in enumerate(dl):  # page cache + worker start-up, untimed
+                if i >= nw:
+                    break
+            t0 = time.perf_counter()
+            n = 0
+            for b in dl:
+                n += b["rgb_u8"].shape[0]
+            return n / (time.perf_counter() - t0)
+
+        zst = {}
+        for nw in sorted({workers, max(1, min(20, ncpu - 2))}):  # the reference's loader: 20 workers per GPU
+            dl, mb = make(False, nw)
+            zst[str(nw)] = loader_rate(dl, nw)
+            del dl
+        dl, _ = make(True, workers)
+        loader_sps = loader_rate(dl, workers)
 
         torch.manual_seed(0)
         model = build_model(cfg, device=device)
@@ -811,9 +822,11 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
     return {"file_fed_step_per_s": fed, "compute_bound_step_per_s": compute_bound_step_per_s, "loader_only_samples_per_s": loader_sps,
             "samples_per_s_needed_by_one_gpu": need, "loader_headroom": loader_sps / need, "file_fed_over_compute_bound": fed / compute_bound_step_per_s,
             "bound": "loader (CPU-side decode: see cpu_quota)" if (loader_sps < need or fed < 0.95 * compute_bound_step_per_s) else "compute",
-            "workers": workers, "host_threads": ncpu, "cpu_quota": cpu_quota(), "per_gpu_batch": per_gpu_batch, "MB_on_disk_per_sample": mb,
-            "frames_on_disk": n_frames, "vertices_per_frame": list(vertex_count_range), "dataset_write_s": t_write,
-            "note": "one GPU's loader; an 8-GPU node runs 8 such loaders on the same host cores (the reference: 8 x 20 workers)"}
+            "workers": workers, "vertex_features_from": "memory-mapped raw cache (io/vertex_cache.py), sampled rows only",
+            "zst_path_loader_only_samples_per_s_by_workers": zst, "host_threads": ncpu, "cpu_quota": cpu_quota(), "per_gpu_batch": per_gpu_batch,
+            "MB_on_disk_per_sample": mb, "frames_on_disk": n_frames, "vertices_per_frame": list(vertex_count_range), "dataset_write_s": t_write,
+            "raw_cache_files_written": n_raw, "raw_cache_convert_s": t_convert,
+            "note": "one GPU's loader at 6 worker processes; an 8-GPU node runs 8 such loaders on the same host (48 cores)"}
 
 
 def get_unbounded_mapper(mcfg, channels):

@@ -1,0 +1,108 @@
+"""The loader's memory-mapped vertex-feature cache (io/vertex_cache.py): a sample read through it is the sample the
+decompress-everything path returns (the reference's: dataset.py:410-415 + sample_transformer.py:150-186) -- same rows, same RNG
+draws, same values, with every sampling method and with the geometry augmentation / noise of the reference's loader switched
+on -- and eight loader instances running side by side (what an 8-GPU node asks of its host) are timed."""
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from nvblox_mindmap_amd.data_loading.dataset import MindmapFrameDataset, write_synthetic_demo
+from nvblox_mindmap_amd.data_loading.sample_transformer import GeometryAugmentor, GeometryNoiser
+from nvblox_mindmap_amd.data_loading.vertex_sampling import VertexSamplingMethod
+from nvblox_mindmap_amd.io import vertex_cache as VC
+
+
+@pytest.fixture(scope="module")
+def dataset_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("cache_ds"))
+    write_synthetic_demo(os.path.join(d, "demo_00000"), 5, image_size=(48, 48), feature_dim=32, vertex_count_range=(1500, 3000))
+    write_synthetic_demo(os.path.join(d, "demo_00001"), 3, image_size=(48, 48), feature_dim=32, vertex_count_range=(100, 900), seed=5)
+    assert VC.convert_dataset(d) == 8 and VC.convert_dataset(d) == 0  # idempotent
+    return d
+
+
+def same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("method", list(VertexSamplingMethod))
+def test_raw_cache_returns_the_same_samples(dataset_dir, method):
+    plain = MindmapFrameDataset(dataset_dir, num_vertices=1024, vertex_sampling_method=method, seed=3, use_raw_vertex_cache=False)
+    cached = MindmapFrameDataset(dataset_dir, num_vertices=1024, vertex_sampling_method=method, seed=3, use_raw_vertex_cache=True)
+    assert len(plain) == len(cached) == 8
+    for i in range(len(plain)):
+        same(plain[i], cached[i])  # 5 frames with more vertices than asked for (selection), 3 with fewer (padding + mask)
+
+
+def test_raw_cache_with_geometry_augmentation_and_noise(dataset_dir):
+    def build(raw):
+        return MindmapFrameDataset(dataset_dir, num_vertices=512, seed=None, use_raw_vertex_cache=raw,
+                                   geometry_augmentor=GeometryAugmentor([[-0.1, -0.1, -0.05], [0.1, 0.1, 0.05]], [[-5.0, -5.0, -30.0], [5.0, 5.0, 30.0]]),
+                                   geometry_noiser=GeometryNoiser(0.002, 0.5))
+
+    plain, cached = build(False), build(True)
+    for i in range(len(plain)):
+        import random
+
+        torch.manual_seed(100 + i)
+        np.random.seed(100 + i)
+        random.seed(100 + i)
+        a = plain[i]
+        state = torch.get_rng_state()
+        torch.manual_seed(100 + i)
+        np.random.seed(100 + i)
+        random.seed(100 + i)
+        b = cached[i]
+        same(a, b)
+        assert torch.equal(torch.get_rng_state(), state), "both paths must consume the same random numbers"
+
+
+def test_raw_file_is_validated(tmp_path):
+    p = str(tmp_path / "0000.nvblox_vertex_features.raw")
+    VC.write_raw(p, torch.rand(10, 3), torch.randn(10, 16))
+    v, f = VC.open_raw(p)
+    assert v.shape == (10, 3) and f.shape == (10, 16) and f.dtype == np.float16
+    with open(p, "r+b") as fh:
+        fh.seek(8)
+        fh.write((10 ** 9).to_bytes(8, "little"))  # a vertex count the file cannot hold
+    with pytest.raises(ValueError):
+        VC.open_raw(p)
+    with open(p, "wb") as fh:
+        fh.write(b"not a cache file")
+    with pytest.raises(ValueError):
+        VC.open_raw(p)
+
+
+def _drain(args):
+    path, raw, n, seed = args
+    torch.set_num_threads(1)
+    ds = MindmapFrameDataset(path, num_vertices=2048, use_raw_vertex_cache=raw, seed=seed)
+    t0 = time.perf_counter()
+    for i in range(n):
+        ds[i % len(ds)]
+    return n / (time.perf_counter() - t0)
+
+
+def test_eight_loader_instances_side_by_side(tmp_path, capsys):
+    """Eight single-process loaders at once on the reference's sample shape (512x512 PNGs, 768-channel rows; vertex count cut
+    to 4-5 k to keep the fixture small): aggregate samples/s with and without the cache, printed against what 8 GPUs consume
+    (8 x 343 samples/s at 10.7 step/s x 32).  Asserts only the direction: the cache must not be slower."""
+    d = str(tmp_path / "ds")
+    write_synthetic_demo(os.path.join(d, "demo_00000"), 4, image_size=(512, 512), feature_dim=768, ngrippers=2, vertex_count_range=(4000, 5000))
+    VC.convert_dataset(d)
+    n_proc = min(8, os.cpu_count() or 1)
+    rates = {}
+    with mp.get_context("spawn").Pool(n_proc) as pool:
+        for raw in (False, True):
+            pool.map(_drain, [(d, raw, 2, k) for k in range(n_proc)])  # page cache, imports
+            rates[raw] = sum(pool.map(_drain, [(d, raw, 8, k) for k in range(n_proc)]))
+    with capsys.disabled():
+        print(f"\n[{n_proc} loader processes] aggregate samples/s: decompress-all {rates[False]:.0f}, memory-mapped cache {rates[True]:.0f} "
+              f"(8 GPUs consume {8 * 343}; {os.cpu_count()} host threads here)")
+    assert rates[True] >= rates[False]
