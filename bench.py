@@ -430,6 +430,52 @@ def run_two_mappers(device, frames, channels, steps=100, warmup=20):
     return out
 
 
+def run_frames_in_flight(device, frames, channels, counts=(1, 2, 4, 8), steps=150, warmup=30):
+    """N independent replicas of the headline step on ONE GPU -- N Mapper objects, each fed its own stream -- issued as ONE
+    native call per round (``mmf_integrate_frame_batch``: the N frames are roles of the same five launches).  Per-frame fusion
+    does not shard, but a single frame's five dependent launches leave half the chip idle; replicas (data generation over several
+    demos, several environments per GPU: SURVEY 8(e)) can use it.  The headline metric stays the single stream."""
+    from nvblox_mindmap_amd.nvblox_torch.mapper import integrate_frames_batch
+
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    out = {}
+    for n in counts:
+        mappers = [get_nvblox_mapper(mcfg, feature_channels=channels) for _ in range(n)]
+
+        def one(i):
+            entries = []
+            for q, m in enumerate(mappers):
+                fr = frames[(i + 13 * q) % len(frames)]
+                m.decay()
+                entries.append(dict(mapper=m, mapper_id=MAPPER_TO_ID.STATIC, depth_frame=fr["depth"], color_frame=fr["rgb"],
+                                    feature_frame=fr["features"], input_mask=fr["dynamic_mask"], t_w_c=fr["T_W_C"], intrinsics=fr["K"],
+                                    min_depth_m=mcfg.min_integration_distance_m,
+                                    input_mask_erosion_iterations=mcfg.static_mask_erosion_iterations,
+                                    valid_depth_mask_erosion_iterations=mcfg.valid_depth_mask_erosion_iterations,
+                                    border_percent=mcfg.feature_mask_border_percent, invert_input_mask=True))
+            integrate_frames_batch(entries)
+
+        for i in range(warmup):
+            one(i)
+        torch.cuda.synchronize(device)
+        mappers[0].profile_reset()
+        mappers[0].profile_enable(True, kernels=list(KERNEL_OF_CLASS), stride=4)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(warmup + i)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        mappers[0].profile_enable(False)
+        prof = mappers[0].profile()
+        out[str(n)] = {"aggregate_frames_per_s": n * steps / dt, "ms_per_round": dt / steps * 1e3, "host_enqueue_ms_per_round": t_enq / steps * 1e3,
+                       "launch_us": {KERNEL_OF_CLASS[c]: (ms / k * 1e3 if k else None) for c, (ms, k) in prof.items() if c in KERNEL_OF_CLASS}}
+        del mappers
+        torch.cuda.empty_cache()
+    out["workload"] = "N x (decay + fused frame, 640x480, C=%d, DRILL_IN_BOX), one mmf_integrate_frame_batch call per round" % channels
+    return out
+
+
 def run_tsdf_only(device, steps=200, warmup=20):
     """BASELINE configs[1]: TSDF-only integration (decay + add_depth_frame: raycast, allocation, TSDF update) of the 640x480
     stream at 1 cm voxels, through the reference's stand-alone Mapper calls."""
@@ -997,6 +1043,7 @@ def main():
     ap.add_argument("--no-file-fed", action="store_true", help="skip the file-fed training leg (loader-bound vs compute-bound step/s)")
     ap.add_argument("--only-fusion", action="store_true", help="headline fusion measurement only (what the rocprofv3 passes run)")
     ap.add_argument("--ref-shape-only", action="store_true", help="run only the 512x512x768 leg (rocprofv3 passes at the reference shape)")
+    ap.add_argument("--in-flight-only", action="store_true", help="run only the frames-in-flight leg (N replicas in one set of launches)")
     ap.add_argument("--unbounded-only", action="store_true", help="run only the unbounded-workspace (hash path) leg (rocprofv3 passes)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the multi-rank control flow only")
     args = ap.parse_args()
@@ -1034,6 +1081,11 @@ def main():
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     n_frames = args.frames or min(max(args.steps, 1), 200)
     frames = build_stream(cfg, n_frames, args.channels, device)
+    if args.in_flight_only:
+        out = run_frames_in_flight(device, frames, args.channels)
+        if rank == 0:
+            print(json.dumps({"frames_in_flight": out}), flush=True)
+        return
     if args.unbounded_only:
         out = run_unbounded(device, frames, args.channels, steps=args.steps, warmup=args.warmup)
         if rank == 0:
@@ -1111,6 +1163,7 @@ def main():
     tsdf_only = run_tsdf_only(device) if (rank == 0 and not args.no_ref_shape) else None
     two_mappers = run_two_mappers(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     unbounded = run_unbounded(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
+    in_flight = run_frames_in_flight(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
@@ -1206,6 +1259,7 @@ def main():
             "tsdf_only": tsdf_only,
             "two_mappers": two_mappers,
             "unbounded_workspace": unbounded,
+            "frames_in_flight": in_flight,
             "backprojection": backproj,
             "train": train,
         }

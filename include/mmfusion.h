@@ -281,6 +281,14 @@ int mmf_integrate_frame_desc(mmf_handle h, int mapper_id, const mmf_frame* frame
  * the order given, which is also what the call does for frames that cannot be paired (odd count, a mapper whose scratch is
  * not sized yet, unbounded workspace, MMF_NO_ALLOC_TSDF=1, a decay that needs its voxel pass). */
 int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids, const mmf_frame* frames, void* stream);
+/* N independent frames -- any mappers, of any Mapper objects on one device, each with its own camera, images and masks --
+ * as roles of ONE set of five launches (up to 8 frames per set; more are issued as further sets, in order).  What several
+ * replicas of the fusion path on one GPU call instead of mmf_integrate_frame_desc per replica (data generation over several
+ * demos, run_isaaclab_datagen.py:213-216; several environments per GPU): a single frame's five dependent launches leave
+ * half the chip idle, N frames fill it.  Every map is bit-identical to the one the calls in sequence build; a pending
+ * mmf_decay of a mapper is folded in as in the single call.  handles[i] / mapper_ids[i] / frames[i] describe frame i; every
+ * frame must address a different mapper. */
+int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int* mapper_ids, const mmf_frame* frames, void* stream);
 
 /* ---- policy-side op ---------------------------------------------------- */
 /* dgl.geometry.farthest_point_sampler(x, npoints, start_idx) (diffuser_actor/encoder.py:366-370): farthest-point

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mmf_add_feature_frame_lowres": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
     "mmf_integrate_frame_lowres": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _I, _I, _I, _I, _VP, _VP, _F, _I, _I, _I, _VP, _VP,
                                          _VP]),
+    "mmf_integrate_frame_batch": (_I, [_I, C.POINTER(_VP), C.POINTER(_I), C.POINTER(MmfFrame), _VP]),
     "mmf_integrate_frame_desc": (_I, [_VP, _I, C.POINTER(MmfFrame), _VP]),
     "mmf_decay": (_I, [_VP, _I, _VP]),
     "mmf_clear": (_I, [_VP, _I, _VP]),

@@ -1493,6 +1493,99 @@ int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids,
   return MMF_OK;
 }
 
+// ---- N independent frames, ONE set of launches (mmf_integrate_frame_batch) --------------------------------------------
+// Generalises the pair above from {static, dynamic} mapper of one Mapper object to up to kMaxBatch frames of ANY mappers
+// (different handles, different cameras, different images): replicas of the fusion path on one GPU -- data generation over
+// several demos (run_isaaclab_datagen.py:213-216), several environments per GPU -- fill the chip that a single
+// latency-bound chain leaves half idle.  Same role code as the single frame, so every map is bit-identical to the one the
+// calls in sequence build.  Frames that cannot take the merged five-launch path are integrated on their own.
+int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int* mapper_ids, const mmf_frame* frames, void* stream) {
+  if (n_frames <= 0 || !handles || !mapper_ids || !frames) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_integrate_frame_batch");
+  std::vector<Mapper*> ms(n_frames);
+  std::vector<FrameIn> ins(n_frames);
+  for (int i = 0; i < n_frames; ++i) {
+    if (!handles[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_batch: null handle");
+    if (handles[i]->device != handles[0]->device) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_batch: all mappers must live on one device");
+    MMF_TRY(get_mapper(handles[i], mapper_ids[i], &ms[i]));
+    MMF_TRY(frame_in_from_desc(*ms[i], &frames[i], ins[i]));
+    for (int j = 0; j < i; ++j)
+      if (ms[j] == ms[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_batch: every frame must go to a different mapper");
+  }
+  HIP_TRY(hipSetDevice(handles[0]->device));
+  hipStream_t s = (hipStream_t)stream;
+  struct Prep {
+    MaskJob M;
+    ViewGrid vg;
+    Cam cam;
+    Rigid T_L_C, T_C_L;
+  };
+  std::vector<Prep> pp(n_frames);
+  std::vector<int> batch;  // indices of the frames that share launches
+  auto flush = [&]() -> int {
+    if (batch.empty()) return MMF_OK;
+    if (batch.size() == 1) {
+      const int i = batch[0];
+      batch.clear();
+      return integrate_frame_in(handles[i], mapper_ids[i], ins[i], stream);
+    }
+    const int nb = (int)batch.size();
+    mmf_handle h0 = handles[batch[0]];  // (the profile of a batch is booked on the first frame's handle)
+    PairFrame F[kMaxBatch];
+    for (int q = 0; q < nb; ++q) {
+      const int i = batch[q];
+      MMF_TRY(report_device_errors(handles[i], *ms[i], nullptr, nullptr, s));
+      MMF_TRY(pair_prepare(handles[i], *ms[i], ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L, s, F[q]));
+    }
+    {
+      ProfExt pe(h0, MMF_K_RAYCAST);
+      FrontArgs A[kMaxBatch];
+      for (int q = 0; q < nb; ++q) A[q] = F[q].front;
+      launch_front_batch(A, nb, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h0, MMF_K_TSDF);
+      AllocTsdfArgs A[kMaxBatch];
+      for (int q = 0; q < nb; ++q) A[q] = F[q].at;
+      launch_alloc_tsdf_batch(A, nb, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h0, MMF_K_SPHERE);
+      SphereArgs A[kMaxBatch];
+      for (int q = 0; q < nb; ++q) A[q] = F[q].sphere;
+      launch_sphere_alloc_batch(A, nb, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h0, MMF_K_FEATURE);
+      AppFrameArgs A[kMaxBatch];
+      for (int q = 0; q < nb; ++q) A[q] = F[q].app;
+      launch_app_frame_batch(A, nb, ins[batch[0]].has_low, s, pe.a(), pe.b());
+    }
+    {
+      ProfExt pe(h0, MMF_K_FEATURE_FLAT);
+      FlatFrame A[kMaxBatch];
+      for (int q = 0; q < nb; ++q) {
+        const int i = batch[q];
+        A[q] = FlatFrame{ms[i]->feat.d, ms[i]->mc, ms[i]->flat, ms[i]->stats, pp[i].cam, (const __half*)ins[i].feat,
+                         ins[i].has_low ? &ins[i].low : nullptr};
+      }
+      launch_feature_flat_batch(A, nb, s, pe.a(), pe.b());
+    }
+    batch.clear();
+    return check_launch();
+  };
+  for (int i = 0; i < n_frames; ++i) {
+    const bool ok = pair_eligible(*ms[i], ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L);
+    if (!ok) {  // (its first frame, an unbounded workspace, a decay that needs its voxel pass, ...): on its own, in order
+      MMF_TRY(flush());
+      MMF_TRY(integrate_frame_in(handles[i], mapper_ids[i], ins[i], stream));
+      continue;
+    }
+    if (!batch.empty() && (ins[batch[0]].has_low != ins[i].has_low || (int)batch.size() == kMaxBatch)) MMF_TRY(flush());
+    batch.push_back(i);
+  }
+  return flush();
+}
+
 int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,
                         const uint8_t* input_mask, int H, int W, int Hf, int Wf, int C, const float* T16, const float* K9,
                         float min_depth_m, int k_in, int k_depth, int border_percent, uint8_t* depth_mask_out,

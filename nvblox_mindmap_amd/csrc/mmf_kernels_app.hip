@@ -359,6 +359,21 @@ __global__ __launch_bounds__(256, 5) void k_sphere_alloc2(SphereArgs A0, SphereA
   sphere_patch_role(A1, Q, b - A0.n_patches);
 }
 
+// N frames (mmf_integrate_frame_batch): [allocation jobs 0 .. n-1 | ray patches 0 .. n-1]
+template <bool DENSE, int MODE>
+__global__ __launch_bounds__(256, 5) void k_sphere_alloc_batch(SphereBatch P) {
+  __shared__ SphereLds Q;
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.a[q].njobs) return sphere_alloc_role<DENSE, MODE>(P.a[q], Q, b);
+    b -= P.a[q].njobs;
+  }
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.a[q].n_patches) return sphere_patch_role(P.a[q], Q, b);
+    b -= P.a[q].n_patches;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Shared per-voxel gate (projection, occlusion test against the synthetic depth, bilinear footprint,
 // mask).  Same operation order as oracle/mmf_oracle.c:app_gate.
@@ -782,6 +797,17 @@ __global__ __launch_bounds__(256) void k_feature_flat2(AppArgs A0, MapConsts mc0
     feature_flat_role<LOW>(A1, mc1, lpv, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, s_prefix);
 }
 
+// N frames' survivor lists in one launch: frame q's list is walked by its own nb[q] workgroups
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_feature_flat_batch(FlatBatch P) {
+  __shared__ int s_prefix[kFlatSubLists + 1];
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.nb[q]) return feature_flat_role<LOW>(P.a[q], P.mc[q], P.lpv[q], b, P.nb[q], s_prefix);
+    b -= P.nb[q];
+  }
+}
+
 template <bool LOW>
 __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
                                     int bid, int nb, FeatLds& S) {
@@ -970,6 +996,23 @@ __global__ __launch_bounds__(256) void k_app_frame2(AppFrameArgs F0, AppFrameArg
   wg_trace_end(tr0, kTrAppFrame);
 }
 
+// N frames' candidate lists in one launch
+template <bool LOW, bool PUB>
+__global__ __launch_bounds__(256) void k_app_frame_batch(AppFrameBatch P) {
+  __shared__ FeatLds S;
+  const long long tr0 = wg_trace_begin();
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    const AppFrameArgs& F = P.a[q];
+    if (b < F.nb) {
+      app_frame_body<LOW, PUB>(F.Ac, F.Af, F.mc, F.synth, F.Ws, F.Hs, b, F.nb, S);
+      break;
+    }
+    b -= F.nb;
+  }
+  wg_trace_end(tr0, kTrAppFrame);
+}
+
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_app)
 
 // ------------------------------------------------------------------------------------------------
@@ -1032,6 +1075,22 @@ void launch_sphere_alloc(const SphereArgs* A, int n, hipStream_t s, hipEvent_t e
     else
       hipExtLaunchKernelGGL((k_sphere_alloc2<false, -1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1]);
   }
+}
+
+void launch_sphere_alloc_batch(const SphereArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  SphereBatch P;
+  P.n = n;
+  int total = 0;
+  bool dense = true;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = A[q];
+    total += A[q].njobs + A[q].n_patches;
+    dense = dense && sphere_dense(A[q]);
+  }
+  if (dense)
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch<true, 1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+  else
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch<false, -1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
@@ -1146,6 +1205,24 @@ void launch_app_frame2(const AppFrameArgs& F0, const AppFrameArgs& F1, bool low,
     hipExtLaunchKernelGGL((k_app_frame2<false, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, F0, F1, F0.nb);
 }
 
+void launch_app_frame_batch(const AppFrameArgs* F, int n, bool low, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  AppFrameBatch P;
+  P.n = n;
+  int total = 0;
+  bool pub = true;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = F[q];
+    total += F[q].nb;
+    pub = pub && F[q].Af.flat.rec != nullptr;
+  }
+  if (pub)
+    hipExtLaunchKernelGGL((k_app_frame_batch<false, true>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+  else if (low)
+    hipExtLaunchKernelGGL((k_app_frame_batch<true, false>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+  else
+    hipExtLaunchKernelGGL((k_app_frame_batch<false, false>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+}
+
 static int flat_wgs(const MapConsts& mc, const FlatList& fl, int& lpv) {
   const int nch = mc.C >> 3;
   lpv = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);  // lanes per voxel row
@@ -1168,6 +1245,23 @@ void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatLi
     hipExtLaunchKernelGGL(k_feature_flat2<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A0, mc0, A1, mc1, lpv0, nb0);
   else
     hipExtLaunchKernelGGL(k_feature_flat2<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A0, mc0, A1, mc1, lpv0, nb0);
+}
+
+// (every frame of a batch has the same kind of feature source: all images or all low-res maps)
+void launch_feature_flat_batch(const FlatFrame* F, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  FlatBatch P;
+  P.n = n;
+  int total = 0;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = make_app_args(F[q].L, F[q].cam, Rigid{}, F[q].feat, nullptr, Scratch{}, F[q].stats, F[q].low, &F[q].fl);
+    P.mc[q] = F[q].mc;
+    P.nb[q] = flat_wgs(F[q].mc, F[q].fl, P.lpv[q]);
+    total += P.nb[q];
+  }
+  if (F[0].low)
+    hipExtLaunchKernelGGL(k_feature_flat_batch<true>, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+  else
+    hipExtLaunchKernelGGL(k_feature_flat_batch<false>, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
 }
 
 }  // namespace mmf

@@ -241,6 +241,20 @@ __global__ __launch_bounds__(256) void k_front2(FrontArgs A0, FrontArgs A1) {
     front_role<LDSFLAGS>(A1, b - A0.n_wgs, s_words, S);
 }
 
+// N frames (independent mappers: mmf_integrate_frame_batch): frame q's workgroups follow frame q-1's.
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256) void k_front_batch(FrontBatch P) {  // (83 VGPRs against the single frame's 63: bounding it to 7-8
+                                                                     // waves per SIMD spills 9-14 registers; 6 waves it is)
+  extern __shared__ unsigned s_words[];
+  __shared__ FrontLds S;
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    const int nw = P.a[q].n_wgs;
+    if (b < nw) return front_role<LDSFLAGS>(P.a[q], b, s_words, S);
+    b -= nw;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. Flag compaction + hash lookup / insertion (shared by TSDF, colour and feature allocation).
 //    count tiles -> scan tiles -> emit.  A tile is 1024 cells (256 threads x 4 flag bytes).
@@ -974,6 +988,31 @@ __global__ __launch_bounds__(256) void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdf
   if (c < A1.mask_rows) mask_cols_role(A1, Q, c);
 }
 
+// N frames: every frame's producers lead the grid,
+//   [alloc 0 .. alloc n-1 | new 0 .. new n-1 | padding | pairs 0 .. pairs n-1 | mask columns 0 .. n-1].
+__global__ __launch_bounds__(256) void k_alloc_tsdf_batch(AllocTsdfBatch P) {
+  __shared__ AllocTsdfLds Q;
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.a[q].alloc_wgs) return alloc_role(P.a[q], Q, b);
+    b -= P.a[q].alloc_wgs;
+  }
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.a[q].P.n_new_wgs) return tsdf_new_role(P.a[q], Q, b);
+    b -= P.a[q].P.n_new_wgs;
+  }
+  if ((int)blockIdx.x < P.lead) return;
+  int c = (int)blockIdx.x - P.lead;
+  for (int q = 0; q < P.n; ++q) {
+    if (c < P.a[q].P.n_pair_wgs) return tsdf_pairs_role(P.a[q], Q, c);
+    c -= P.a[q].P.n_pair_wgs;
+  }
+  for (int q = 0; q < P.n; ++q) {
+    if (c < P.a[q].mask_rows) return mask_cols_role(P.a[q], Q, c);
+    c -= P.a[q].mask_rows;
+  }
+}
+
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_map)
 
 // ------------------------------------------------------------------------------------------------
@@ -1209,6 +1248,22 @@ void launch_front(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start,
   }
 }
 
+void launch_front_batch(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  FrontBatch P;
+  P.n = n;
+  int ncells = 0, total = 0;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = A[q];
+    ncells = front_cells(A[q]) > ncells ? front_cells(A[q]) : ncells;
+    total += A[q].n_wgs;
+  }
+  const bool lds = ncells <= kRaycastLdsCells;
+  if (lds)
+    hipExtLaunchKernelGGL(k_front_batch<true>, dim3(total), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, ev_start, ev_stop, 0, P);
+  else
+    hipExtLaunchKernelGGL(k_front_batch<false>, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+}
+
 constexpr int kFusedAllocMaxCells = 16384;
 
 static AllocJob make_alloc_job(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, int stat_upd, int stat_new) {
@@ -1407,6 +1462,19 @@ void launch_alloc_tsdf(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t 
     const int total = lead + A[0].P.n_pair_wgs + A[1].P.n_pair_wgs + A[0].mask_rows + A[1].mask_rows;
     hipExtLaunchKernelGGL(k_alloc_tsdf2, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1], lead);
   }
+}
+
+void launch_alloc_tsdf_batch(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  AllocTsdfBatch P;
+  P.n = n;
+  int lead = 0, rest = 0;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = A[q];
+    lead += A[q].alloc_wgs + A[q].P.n_new_wgs;
+    rest += A[q].P.n_pair_wgs + A[q].mask_rows;
+  }
+  P.lead = (lead + 7) & ~7;
+  hipExtLaunchKernelGGL(k_alloc_tsdf_batch, dim3(P.lead + rest), dim3(256), 0, s, ev_start, ev_stop, 0, P);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

@@ -141,8 +141,38 @@ struct AppFrameArgs {
   int nb;  // workgroups
 };
 
+// ---- N independent frames (different mappers, possibly of different Mapper objects) as roles of the SAME five launches ----
+// (mmf_integrate_frame_batch).  The per-frame argument blocks travel by value, as arrays: a workgroup finds its frame by
+// walking the n role sizes (scalar loads from the kernel-argument segment); the role code is the single frame's.
+constexpr int kMaxBatch = 8;
+struct FrontBatch {
+  FrontArgs a[kMaxBatch];
+  int n;
+};
+struct AllocTsdfBatch {
+  AllocTsdfArgs a[kMaxBatch];
+  int n, lead;  // lead: first workgroup of the existing-block pairs (a multiple of 8)
+};
+struct SphereBatch {
+  SphereArgs a[kMaxBatch];
+  int n;
+};
+struct AppFrameBatch {
+  AppFrameArgs a[kMaxBatch];
+  int n;
+};
+struct FlatBatch {
+  AppArgs a[kMaxBatch];
+  MapConsts mc[kMaxBatch];
+  int nb[kMaxBatch];  // workgroups of each frame's list
+  int lpv[kMaxBatch];
+  int n;
+};
+
 // mmf_kernels_map.hip
 int hinted(const int* hint, int upper);
+void launch_front_batch(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_alloc_tsdf_batch(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, const float* depth, const uint8_t* mask, float min_d,
                     int sub, const ViewGrid& vg, uint8_t* flags, hipStream_t s);
 void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, long long* stats, int stat_upd,
@@ -189,6 +219,19 @@ AppFrameArgs make_app_frame_args(const LayerDev& Lc, const Cam& cam, const uint8
                                  const LayerDev& Lf, const __half* feat, const uint8_t* fmask, const Scratch& fsc, const MapConsts& mc,
                                  const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats, const LowRes* low,
                                  const FlatList* flat);
+void launch_sphere_alloc_batch(const SphereArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_app_frame_batch(const AppFrameArgs* F, int n, bool low, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// per frame: its feature layer, constants, survivor list, statistics, feature camera and feature source (image or low-res map)
+struct FlatFrame {
+  LayerDev L;
+  MapConsts mc;
+  FlatList fl;
+  long long* stats;
+  Cam cam;
+  const __half* feat;
+  const LowRes* low;
+};
+void launch_feature_flat_batch(const FlatFrame* F, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_app_frame2(const AppFrameArgs& F0, const AppFrameArgs& F1, bool low, hipStream_t s, hipEvent_t ev_start = nullptr,
                        hipEvent_t ev_stop = nullptr);
 void launch_feature_flat2(const LayerDev& L0, const MapConsts& mc0, const FlatList& fl0, long long* stats0, const LayerDev& L1,

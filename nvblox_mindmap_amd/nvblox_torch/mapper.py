@@ -710,3 +710,39 @@ class Mapper:
             _lib.check(_lib.lib().mmf_profile_get(self._h, kid, C.byref(ms), C.byref(n)), "mmf_profile_get")
             out[name] = (ms.value, n.value)
         return out
+
+
+def integrate_frames_batch(frames) -> list:
+    """Extension (``mmf_integrate_frame_batch``): N independent frames -- each for a different mapper, of the same or of
+    different ``Mapper`` objects on one device, each with its own camera, images and masks -- as roles of ONE set of five
+    launches (up to eight frames per set).  What several replicas of the fusion path on one GPU call instead of one
+    ``integrate_frame`` each (data generation over several demos, several environments per GPU): bit-identical maps, the chip
+    filled instead of half idle.  A ``decay()`` pending on a mapper is folded in as in the single call.
+
+    ``frames``: one dict per frame with the arguments of ``Mapper.integrate_frame`` -- ``mapper`` (the Mapper), ``mapper_id``,
+    ``depth_frame``, ``color_frame``, ``feature_frame`` (or ``lowres_features``), ``input_mask``, ``t_w_c``, ``intrinsics``,
+    ``min_depth_m``, ``input_mask_erosion_iterations``, ``valid_depth_mask_erosion_iterations``, ``border_percent`` and
+    optionally ``invert_input_mask``.  Returns [(depth_mask, feature_mask), ...] in frame order."""
+    n = len(frames)
+    if n == 0:
+        return []
+    descs = (_lib.MmfFrame * n)()
+    ids = (C.c_int * n)()
+    handles = (C.c_void_p * n)()
+    keep, out = [], []
+    for i, fr in enumerate(frames):
+        m = fr["mapper"]
+        if m.device != frames[0]["mapper"].device:
+            raise ValueError("integrate_frames_batch: all mappers must live on one device")
+        f, k, dm, fm = m._frame_desc(fr["depth_frame"], fr["color_frame"], None if fr.get("lowres_features") is not None else fr["feature_frame"],
+                                     fr.get("lowres_features"), fr["input_mask"], fr["t_w_c"], fr["intrinsics"], fr["min_depth_m"],
+                                     fr["input_mask_erosion_iterations"], fr["valid_depth_mask_erosion_iterations"], fr["border_percent"],
+                                     bool(fr.get("invert_input_mask", False)))
+        descs[i] = f
+        ids[i] = m._check_id(fr.get("mapper_id", 0))
+        handles[i] = m._h
+        keep.append(k)
+        out.append((dm, fm))
+    _lib.check(_lib.lib().mmf_integrate_frame_batch(n, handles, ids, descs, frames[0]["mapper"]._stream()), "mmf_integrate_frame_batch")
+    del keep
+    return out
