@@ -1006,6 +1006,30 @@ def frame_byte_model(cfg, C, n_live, n_tsdf_upd, n_cand, n_surv, with_decay=True
 
 KERNEL_OF_CLASS = {"raycast": "k_front", "tsdf": "k_alloc_tsdf", "sphere": "k_sphere_alloc", "feature": "k_app_frame",
                    "feature_flat": "k_feature_flat"}
+# What bounds each launch, with the counter evidence it rests on (tools/profile_sq.sh -> profiles/*_sq_summary.json: SQ counters of
+# the same bench command, fractions of SQ_WAVE_CYCLES).  valu_issue: the achieved rate is VALU wave-instructions/s against the
+# chip's issue peak (1 024 SIMDs x clock / 4 cycles per wave64 instruction); latency: most wave-cycles are parked in s_waitcnt on
+# dependent loads at full occupancy; hbm: bytes/s against the HBM peak.
+VALU_ISSUE_PEAK_PER_S = 1024 * 2.4e9 / 4.0
+BOUND_OF_KERNEL = {"k_front": "valu_issue", "k_alloc_tsdf": "latency", "k_sphere_alloc": "valu_issue", "k_app_frame": "latency",
+                   "k_feature_flat": "hbm"}
+
+
+def sq_evidence():
+    """Per-kernel SQ summary of the latest committed counter run (a replayed constant like roofline.traffic: labelled)."""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_summary.json"))
+    if not files:
+        return {}, None
+    with open(os.path.join(ROOT, "profiles", files[-1])) as fh:
+        raw = json.load(fh)
+    out = {}
+    for name, v in raw.items():
+        if not isinstance(v, dict) or "SQ_WAVES" not in v:
+            continue
+        base = name.split("<")[0]
+        if base in BOUND_OF_KERNEL and base not in out:
+            out[base] = {k: v.get(k) for k in ("SQ_WAVES", "valu_per_wave", "salu_per_wave", "frac_parked", "frac_issuing", "frac_issue_stall")}
+    return out, f"profiles/{files[-1]} ({raw.get('__source__', '')})"
 
 
 def pmc_traffic():
@@ -1178,15 +1202,24 @@ def main():
         model = frame_byte_model(cfg, C, n_live, tsdf_blocks_per_frame, col_blocks_per_frame, feat_voxels_per_frame)
         b_frame = sum(model.values())
         traffic, traffic_src = pmc_traffic()
+        sq, sq_src = sq_evidence()
         per_kernel, busy_us = [], 0.0
         for cls, kname in KERNEL_OF_CLASS.items():
             ms, n = prof.get(cls, (0.0, 0))
             us = ms / n * 1e3 if n else None
             busy_us += us or 0.0
+            hbm_frac = (model[kname] / (us * 1e-6) / HBM_PEAK_BYTES_PER_S) if us else None
+            bound = BOUND_OF_KERNEL[kname]
+            ev = sq.get(kname)
+            frac_of_bound = hbm_frac
+            if bound == "valu_issue" and ev and us:
+                frac_of_bound = ev["SQ_WAVES"] * ev["valu_per_wave"] / (us * 1e-6) / VALU_ISSUE_PEAK_PER_S
+            elif bound == "latency" and ev:
+                frac_of_bound = None  # no throughput peak to divide by: the evidence is the parked fraction
             per_kernel.append({
                 "kernel": kname, "avg_us": us, "launches_timed": n, "algorithmic_bytes": model[kname],
                 "achieved_GBps": (model[kname] / (us * 1e-6) / 1e9) if us else None,
-                "frac": (model[kname] / (us * 1e-6) / HBM_PEAK_BYTES_PER_S) if us else None,
+                "frac": hbm_frac, "bound": bound, "frac_of_bound": frac_of_bound, "sq_counters": ev,
                 "traffic": traffic.get(kname)})
         timed = [k_ for k_ in per_kernel if k_["avg_us"]]
         dominant = max(timed, key=lambda k_: k_["avg_us"])["kernel"] if timed else None
@@ -1202,6 +1235,7 @@ def main():
             "frac": b_frame / t_frame / HBM_PEAK_BYTES_PER_S,
             "traffic": sum(traffic.get(k_, 0.0) for k_ in model) if traffic else None,
             "traffic_source": traffic_src,
+            "sq_counters_source": sq_src,
             "algorithmic_bytes_per_frame": b_frame,
             "formula": "sum over the five launches of frame_byte_model() (bench.py; DESIGN.md section 5), counts from this run",
             "frame_us": t_frame * 1e6,

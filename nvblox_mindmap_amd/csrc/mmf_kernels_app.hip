@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 5) void k_sphere_alloc2(SphereArgs A0, SphereA
 
 // N frames (mmf_integrate_frame_batch): [allocation jobs 0 .. n-1 | ray patches 0 .. n-1]
 template <bool DENSE, int MODE>
-__global__ __launch_bounds__(256, 5) void k_sphere_alloc_batch(SphereBatch P) {
+__global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch(SphereBatch P) {
   __shared__ SphereLds Q;
   int b = (int)blockIdx.x;
   for (int q = 0; q < P.n; ++q) {

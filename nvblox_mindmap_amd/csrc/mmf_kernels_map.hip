@@ -114,6 +114,32 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     xform(T_L_C, pC, pL);
     float s0[3] = {T_L_C.t[0] * mc.inv_bs, T_L_C.t[1] * mc.inv_bs, T_L_C.t[2] * mc.inv_bs};
     float e[3] = {pL[0] * mc.inv_bs, pL[1] * mc.inv_bs, pL[2] * mc.inv_bs};
+    // Only blocks inside the workspace bounds can be in view: the walk starts where the ray enters them, two cells early
+    // (oracle/mmf_oracle.c clip_walk_start: same operations in the same order), not at the camera -- a quarter of the steps of a
+    // camera that orbits the task's box.
+    if (mc.ws_type != 0) {
+      float r[3], t0 = 0.0f, big = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        r[a] = e[a] - s0[a];
+        const float ar = fabsf(r[a]);
+        if (ar > big) big = ar;
+        if (mc.ws_type == 1 && a < 2) continue;
+        const float lo = (float)mc.ws_lo[a], hi = (float)(mc.ws_hi[a] + 1);
+        float ta = 0.0f;
+        if (r[a] > 0.0f) ta = (lo - s0[a]) / r[a];
+        else if (r[a] < 0.0f) ta = (hi - s0[a]) / r[a];
+        if (ta > t0) t0 = ta;
+      }
+      if (t0 > 0.0f && big > 0.0f) {
+        t0 = t0 - 2.0f / big;
+        if (t0 > 0.0f) {
+          if (t0 > 1.0f) t0 = 1.0f;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) s0[a] = s0[a] + t0 * r[a];
+        }
+      }
+    }
     Walk w;
     walk_init(w, s0, e);
     // The walk is monotone along every axis: once it is past the view grid in its direction of travel (or off the grid
@@ -243,8 +269,7 @@ __global__ __launch_bounds__(256) void k_front2(FrontArgs A0, FrontArgs A1) {
 
 // N frames (independent mappers: mmf_integrate_frame_batch): frame q's workgroups follow frame q-1's.
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_front_batch(FrontBatch P) {  // (83 VGPRs against the single frame's 63: bounding it to 7-8
-                                                                     // waves per SIMD spills 9-14 registers; 6 waves it is)
+__global__ __launch_bounds__(256, 7) void k_front_batch(FrontBatch P) {  // 72 VGPRs (natural: 83 = 6 waves per SIMD; 8 waves spill too much): 86 -> 80 us at N = 8
   extern __shared__ unsigned s_words[];
   __shared__ FrontLds S;
   int b = (int)blockIdx.x;
@@ -990,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdf
 
 // N frames: every frame's producers lead the grid,
 //   [alloc 0 .. alloc n-1 | new 0 .. new n-1 | padding | pairs 0 .. pairs n-1 | mask columns 0 .. n-1].
-__global__ __launch_bounds__(256) void k_alloc_tsdf_batch(AllocTsdfBatch P) {
+__global__ __launch_bounds__(256, 8) void k_alloc_tsdf_batch(AllocTsdfBatch P) {
   __shared__ AllocTsdfLds Q;
   int b = (int)blockIdx.x;
   for (int q = 0; q < P.n; ++q) {

@@ -562,10 +562,45 @@ static inline void walk_step(walk_t* w) {
 }
 
 /*
+ * Where the grid walk of a ray starts.  Only blocks inside the workspace bounds can be in view, so the part of the segment
+ * camera -> end point that lies before the bounds is not walked: per bounded axis the slab parameter of the face the ray enters
+ * through, t0 = max over the axes (0 if the camera is inside), stepped back by two cells along the ray's dominant axis so that
+ * the walk enters the bounds with the cell sequence of the full walk (the traversed cells inside the bounds are the same
+ * either way; what is saved are the steps outside -- a quarter of them for a camera that orbits the box).
+ *   kUnbounded: start at the camera.  kHeightBounds: z only.  kBoundingBox: all three axes.
+ *   lo_a = (float)ws_lo_a, hi_a = (float)(ws_hi_a + 1)  [block units];  r = e - s0;
+ *   t_a = r_a > 0 ? (lo_a - s0_a) / r_a : (r_a < 0 ? (hi_a - s0_a) / r_a : 0);  t0 = max(0, t_a ...);
+ *   if t0 > 0: t0 = t0 - 2 / max_a |r_a|;  t0 = clamp(t0, 0, 1);  start = s0 + t0 * r
+ */
+static void clip_walk_start(const orc_mapper* m, const float* s0, const float* e, float* out) {
+  out[0] = s0[0];
+  out[1] = s0[1];
+  out[2] = s0[2];
+  const int type = m->P.workspace_bounds_type;
+  if (type == 0) return;
+  float r[3], t0 = 0.0f, big = 0.0f;
+  for (int a = 0; a < 3; ++a) {
+    r[a] = e[a] - s0[a];
+    float ar = fabsf(r[a]);
+    if (ar > big) big = ar;
+    if (type == 1 && a < 2) continue;
+    float lo = (float)ifloor(m->P.ws_min[a] * m->inv_bs), hi = (float)(ifloor(m->P.ws_max[a] * m->inv_bs) + 1), ta = 0.0f;
+    if (r[a] > 0.0f) ta = (lo - s0[a]) / r[a];
+    else if (r[a] < 0.0f) ta = (hi - s0[a]) / r[a];
+    if (ta > t0) t0 = ta;
+  }
+  if (!(t0 > 0.0f) || !(big > 0.0f)) return;
+  t0 = t0 - 2.0f / big;
+  if (!(t0 > 0.0f)) return;
+  if (t0 > 1.0f) t0 = 1.0f;
+  for (int a = 0; a < 3; ++a) out[a] = s0[a] + t0 * r[a];
+}
+
+/*
  * For every raycast_subsampling-th pixel with depth > 0 and mask != 0:
  *   d = min(depth, max_integration_distance) (if max > 0);  s = d + trunc
  *   ray_C = ((col + .5 - cx)/fx, (row + .5 - cy)/fy, 1);  p_C = s * ray_C;  p_L = T_L_C p_C
- *   walk from t_L_C*inv_bs to p_L*inv_bs; every visited block inside the workspace is in view.
+ *   walk from clip_walk_start(t_L_C*inv_bs, p_L*inv_bs) to p_L*inv_bs; every visited block inside the workspace is in view.
  * The result is sorted lexicographically (x, then y, then z).
  */
 static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mask, const cam_t* cam,
@@ -596,8 +631,10 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
         float pL[3];
         xform(T_L_C, pC, pL);
         float e[3] = {pL[0] * m->inv_bs, pL[1] * m->inv_bs, pL[2] * m->inv_bs};
+        float sc[3];
+        clip_walk_start(m, s0, e, sc);
         walk_t w;
-        walk_init(&w, s0, e);
+        walk_init(&w, sc, e);
         for (int i = 0; i <= w.n; ++i) {
           if (in_workspace(m, w.c[0], w.c[1], w.c[2])) set3_insert(&Sl, w.c[0], w.c[1], w.c[2]);
           walk_step(&w);
