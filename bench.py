@@ -905,9 +905,11 @@ def get_unbounded_mapper(mcfg, channels):
                   feature_channels=channels)
 
 
-UNBOUNDED_CLASSES = {"raycast": "k_raycast_mark", "alloc": "k_count_tiles + k_scan_tiles + k_emit (hash insertion; x3: TSDF, colour, feature)",
-                     "tsdf": "k_tsdf_integrate", "candidates": "k_app_candidates", "sphere": "k_sphere_trace", "color": "k_color_integrate",
-                     "feature": "k_feature_integrate (gating)", "feature_flat": "k_feature_flat", "decay": "k_decay + k_live_compact"}
+UNBOUNDED_CLASSES = {"decay": "k_live_compact_big<wmax> + conditional hash rebuild (light decay: deallocation, tombstones)",
+                     "raycast": "k_front (raycast | mask rows)",
+                     "alloc": "k_alloc_big x2 (TSDF: hash lookups + CAS insertion | mask columns; colour | feature allocation)",
+                     "tsdf": "k_tsdf_pass (every live block: W *= f, integration of the stamped ones, appearance-candidate flags)",
+                     "sphere": "k_sphere_trace", "feature": "k_app_frame (colour update + feature gating)", "feature_flat": "k_feature_flat"}
 
 
 def run_unbounded(device, frames, channels, steps=100, warmup=30):
@@ -938,6 +940,8 @@ def run_unbounded(device, frames, channels, steps=100, warmup=30):
     prof = mapper.profile()
     stats = mapper.stats(0)
     hs = mapper.hash_state(0)
+    hs_cells = hs["view_grid"][0] * hs["view_grid"][1] * hs["view_grid"][2]
+    hs["view_grid_cells"] = hs_cells
     n_live = hs["live_blocks"]
     if n_live >= 262144:
         raise RuntimeError("unbounded leg: block pool exhausted")
@@ -949,23 +953,23 @@ def run_unbounded(device, frames, channels, steps=100, warmup=30):
                              stats["feature_voxels_updated"] / nf)
     # hash traffic of the allocation launch: one 16 B probe per candidate block (+ one CAS + value store per new block)
     ncand = stats["color_blocks_updated"] / max(stats["color_frames"], 1)
+    base = model
     model = {
-        "k_raycast_mark": model["k_front"],
-        UNBOUNDED_CLASSES["alloc"]: (n_upd + 2 * ncand) * (16 + 13) + n_new * 24,
-        "k_tsdf_integrate": n_upd * 512 * 16 + cfg.height * cfg.width * 5,
-        "k_app_candidates": n_live * 512 * 8,
-        "k_sphere_trace": model["k_sphere_alloc"],
-        "k_color_integrate": ncand * 512 * 16 + cfg.height * cfg.width * 4,
-        "k_feature_integrate (gating)": ncand * 512 * 8 + cfg.height * cfg.width + 20 * stats["feature_voxels_updated"] / nf,
-        "k_feature_flat": model["k_feature_flat"],
-        "k_decay + k_live_compact": n_live * 512 * 16,
+        UNBOUNDED_CLASSES["decay"]: n_live * (4 + 4 + 8) + n_new * 40,  # live entry + wmax + slot key per block; erase / free push per dead block
+        UNBOUNDED_CLASSES["raycast"]: base["k_front"],
+        # view-grid flags read + cleared, one 16 B probe per candidate (twice: count, assign), 13 B of candidate list, CAS + value per new block
+        UNBOUNDED_CLASSES["alloc"]: hs_cells * 2 + (n_upd + 2 * ncand) * (2 * 16 + 13) + n_new * 24 + 2 * n_live,
+        UNBOUNDED_CLASSES["tsdf"]: n_live * 512 * 16 + cfg.height * cfg.width * 4 + 32 * n_live,
+        "k_sphere_trace": base["k_sphere_alloc"],
+        UNBOUNDED_CLASSES["feature"]: base["k_app_frame"],
+        "k_feature_flat": base["k_feature_flat"],
     }
     per = []
     for cls, name in UNBOUNDED_CLASSES.items():
         ms, n = prof.get(cls, (0.0, 0))
         us = ms / n * 1e3 if n else None
         b = model.get(name, 0.0)
-        calls = 3 if cls == "alloc" else 1  # bracketed launches of the class per frame
+        calls = 2 if cls == "alloc" else 1  # bracketed launches of the class per frame
         per.append({"kernel": name, "avg_us_per_frame": us * calls if us else None, "launches_timed": n, "algorithmic_bytes": b,
                     "frac": (b / (us * calls * 1e-6) / HBM_PEAK_BYTES_PER_S) if (us and b) else None})
     b_frame = sum(model.values())

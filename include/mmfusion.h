@@ -445,9 +445,10 @@ int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out
  * operation; the environment variable MMF_DEBUG_FORCE_ALLOC_TIMEOUT=1 at mapper creation makes half of the waiters abandon
  * at once, =2 makes the sweeper fail too: the next call on the mapper then returns MMF_ERR_BAD_STATE once).  Synchronises. */
 int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_t* out);
-/* Diagnostics of a layer's block index: out4 = {hash table entries (0: bounded workspace, the dense block table is the index and
- * no hash is kept), tombstones in the table, table rebuilds since the layer was created / cleared, live blocks}.  Synchronises. */
-int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out4);
+/* Diagnostics of a layer's block index: out8 = {hash table entries (0: bounded workspace, the dense block table is the index and
+ * no hash is kept), tombstones in the table, table rebuilds since the layer was created / cleared, live blocks, and the last depth
+ * frame's view grid nx, ny, nz (cells = blocks), 0}.  Synchronises. */
+int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out8);
 /* Diagnostics: per-workgroup timeline of the fused frame kernels.  buffer_dev: uint64 [3 * capacity_records] on the device
  * (capacity_records >= 6 * 8192; the caller zeroes it), records {role id, start, end} in 100 MHz ticks at slot
  * (role id / 10 - 1) * 8192 + workgroup index; null = off (the default).

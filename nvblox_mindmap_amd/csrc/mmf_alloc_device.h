@@ -480,4 +480,264 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Scalable, single-launch forms (any number of cells / live blocks): the view grid of an UNBOUNDED workspace holds ~10^6
+// cells and its pools 10^5 blocks, where one workgroup (alloc_job_body, live_compact_body) would take dozens of serial
+// passes and the three-kernel count / scan / emit path three launches per layer.  Every workgroup takes ONE chunk; what a
+// chunk needs from the chunks before it -- how many candidates / new blocks (kept / dead list entries) they hold -- comes from
+// an in-launch exclusive scan over self-validating 64-bit words
+//     [63:42] launch tag   [41:40] status: 1 = the chunk's own counts, 2 = its exclusive prefix   [39:20] a   [19:0] b
+// written and polled with relaxed agent-scope atomics (no fences; a stale word carries an old tag):
+//   every chunk publishes its counts and arrives on one counter; the chunk that arrives LAST scans all counts (its whole
+//   workgroup, 256 chunks per step), publishes every chunk's prefix and resets the counter; every chunk polls ITS prefix word.
+// (First version: a decoupled look-back, every chunk's wave 0 polling its 64 predecessors.  With more chunks than one window
+// -- 90 .. 256 here -- the launch took 15 to 190 us: thousands of lanes spinning on agent-scope loads starve the very stores
+// they wait for.  One poller per chunk and one scanner: the cost is two memory round trips after the last chunk has counted.)
+// Counts are 20 bits: pools below 2^20 blocks (the host falls back to the three-kernel path above that).
+// lb: [0] arrival counter, [2 .. 2 + nwg) counts, [2 + nwg .. 2 + 2 nwg) prefixes.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kBigChunk = 1024;  // cells / list entries per workgroup and group: 256 threads x 4
+constexpr unsigned kLbCountMax = (1u << 20) - 1u;
+
+__device__ inline u64 lb_pack(unsigned tag, unsigned status, unsigned a, unsigned b) {
+  return ((u64)(tag & 0x3fffffu) << 42) | ((u64)(status & 3u) << 40) | ((u64)(a & kLbCountMax) << 20) | (u64)(b & kLbCountMax);
+}
+
+__device__ inline u64 lb_poll(const u64* word, unsigned tag, unsigned status, int* err) {
+  u64 x = 0;
+  for (int spins = 0; spins < (1 << 22); ++spins) {
+    x = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(x >> 42) == (tag & 0x3fffffu) && (unsigned)((x >> 40) & 3ull) == status) return x;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  atomicOr(err, 2);  // (never observed) the launch's hand-over failed: reported like k_alloc_tsdf's
+  return lb_pack(tag, status, 0u, 0u);
+}
+
+// Exclusive prefix (pa, pb) of (ta, tb) over the chunks before w -> out2[0], out2[1] (LDS); called by every thread of the
+// workgroup (256 threads) with workgroup-uniform arguments; scan: >= 10 ints of LDS, out2: >= 7 ints (out2[6] is scratch).
+__device__ inline void lookback_exclusive(u64* lb, unsigned tag, int w, int nwg, int ta, int tb, int* scan, int* out2, int* err) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(lb + 2 + w, lb_pack(tag, 1u, (unsigned)ta, (unsigned)tb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long old = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(lb), 1ull, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+    out2[6] = (old == (unsigned long long)(nwg - 1)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (out2[6]) {  // the last chunk to arrive: every count is published (a word not yet visible is polled for)
+    int ca = 0, cb = 0;
+    for (int base = 0; base < nwg; base += 256) {
+      const int v = base + (int)threadIdx.x;
+      int a = 0, b = 0;
+      if (v < nwg) {
+        const u64 x = lb_poll(lb + 2 + v, tag, 1u, err);
+        a = (int)((x >> 20) & kLbCountMax);
+        b = (int)(x & kLbCountMax);
+      }
+      int ea, eb, sa, sb;
+      block_excl_scan2<4>(a, b, scan, ea, eb, sa, sb);
+      if (v < nwg)
+        __hip_atomic_store(lb + 2 + nwg + v, lb_pack(tag, 2u, (unsigned)(ca + ea), (unsigned)(cb + eb)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      ca += sa;
+      cb += sb;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(lb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+  }
+  if (threadIdx.x == 0) {
+    const u64 x = lb_poll(lb + 2 + nwg + w, tag, 2u, err);
+    out2[0] = (int)((x >> 20) & kLbCountMax);
+    out2[1] = (int)(x & kLbCountMax);
+  }
+  __syncthreads();
+}
+
+// Allocation job J, chunk w of nwg: 1024 G cells (G <= 4; the launcher picks G so that a job is at most ~128 chunks where it can:
+// every look-back hop is a memory round trip, ~1-2 us across XCDs, and the inclusive prefixes travel 64 chunks per hop).
+//   1. every thread reads the flags of its 4 G consecutive cells; the FLAGGED cells of the chunk are compacted, in cell order, into
+//      an LDS list (workgroup scan).  Flagged cells cluster (blocks along a surface are neighbours in the grid): left with their
+//      threads, one thread would walk a dozen dependent lookups / insertions in sequence while its neighbours idle.
+//   2. the list is walked 256 items per round, one item per thread: index lookup (hash probe or dense table), a workgroup scan of
+//      "is new" per round -> the chunk's candidate and new-block counts and every item's rank among the chunk's new blocks.
+//   3. look back for the counts of the chunks before this one.
+//   4. every item is assigned: candidate position = prefix + list position, new blocks take their pool slot by rank (free stack
+//      first, then the bump pointer), are inserted into the index and appended to the live list.
+// Same candidate order, slot assignment and outputs as alloc_job_body / the three-kernel path.  Hash layers: lookups and the CAS
+// insertions of other chunks run concurrently -- safe, because a chunk only ever looks up the keys of ITS cells, an inserted key
+// is never one another chunk looks up, and a probe that passes a freshly claimed entry simply continues to the next.
+constexpr int kBigMaxG = 4;
+struct AllocBigLds {
+  int scan[10];
+  int sh[8];
+  uint16_t cell[kBigChunk * kBigMaxG];  // flagged cells of the chunk (offset within the chunk), cell order
+  int slot[kBigChunk * kBigMaxG];       // their pool slots (-1 - rank among the chunk's new blocks for a new block)
+};
+
+template <int MODE>
+__device__ inline void alloc_big_body(const AllocJob& J, long long* stats, AllocBigLds& S, int w, int nwg, int G) {
+  const LayerDev& L = J.L;
+  const KeySrc& ks = J.ks;
+  const Scratch& sc = J.sc;
+  int* sh = S.sh;
+  int ncells = J.ncells;
+  if (MODE == 1) {
+    const int nl = *ks.n_live;
+    ncells = ncells < nl ? ncells : nl;
+  }
+  if (w == 0 && J.zero_me && (int)threadIdx.x < J.zero_n) J.zero_me[threadIdx.x * J.zero_stride] = 0;
+  if (threadIdx.x == 0) {
+    sh[2] = L.ctr[0];
+    sh[3] = L.ctr[1];
+    sh[4] = L.ctr[2];
+    sh[5] = L.ctr[1] + (L.cap - L.ctr[2]);  // room
+  }
+  const int chunk0 = w * kBigChunk * G;
+  const int t0 = (int)threadIdx.x * 4 * G;  // the thread's first cell, chunk-relative
+  uint32_t fw[kBigMaxG];
+#pragma unroll
+  for (int g = 0; g < kBigMaxG; ++g) {
+    fw[g] = 0u;
+    const int cell = chunk0 + t0 + 4 * g;
+    if (g < G && cell < ncells) fw[g] = *reinterpret_cast<const uint32_t*>(sc.flags + cell);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cell + k >= ncells) fw[g] &= ~(0xffu << (8 * k));  // stale flags beyond the grid / the live count
+  }
+  int nf = 0;
+#pragma unroll
+  for (int g = 0; g < kBigMaxG; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nf += ((fw[g] >> (8 * k)) & 0xffu) ? 1 : 0;
+  int ea, eb, n_items, tb;
+  block_excl_scan2<4>(nf, 0, S.scan, ea, eb, n_items, tb);
+  {
+    int at = ea;
+#pragma unroll
+    for (int g = 0; g < kBigMaxG; ++g) {
+      if (!fw[g]) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((fw[g] >> (8 * k)) & 0xffu) S.cell[at++] = (uint16_t)(t0 + 4 * g + k);
+      if (MODE == 0) *reinterpret_cast<uint32_t*>(sc.flags + chunk0 + t0 + 4 * g) = 0u;  // grid flags: all-zero for the next frame
+    }
+  }
+  __syncthreads();
+  auto key_of = [&](int cell) -> u64 { return MODE == 0 ? grid_cell_key(ks, cell) : sc.cell_key[cell]; };
+  int n_new = 0;
+  for (int base = 0; base < n_items; base += 256) {  // (uniform trip count)
+    const int j = base + (int)threadIdx.x;
+    int slot = 0;
+    if (j < n_items) slot = layer_lookup(L, key_of(chunk0 + (int)S.cell[j]));
+    const int is_new = (j < n_items && slot < 0) ? 1 : 0;
+    int ra, rb, ta, tb2;
+    block_excl_scan2<4>(is_new, 0, S.scan, ra, rb, ta, tb2);
+    if (j < n_items) S.slot[j] = is_new ? -1 - (n_new + ra) : slot;
+    n_new += ta;
+  }
+  lookback_exclusive(sc.lb, J.lb_tag, w, nwg, n_items, n_new, S.scan, sh, &L.ctr[3]);
+  const int old_live = sh[2], old_free = sh[3], old_bump = sh[4], room = sh[5];
+  for (int j = (int)threadIdx.x; j < n_items; j += 256) {
+    const int cell = chunk0 + (int)S.cell[j];
+    const u64 key = key_of(cell);
+    int slot = S.slot[j];
+    const bool is_new = slot < 0;
+    if (is_new) {
+      const int rnk = sh[1] + (-1 - slot);
+      slot = -1;
+      if (rnk < room) {
+        slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
+        hash_insert(L, key, slot);
+        dense_set(L, key, slot + 1);
+        L.slot_key[slot] = key;
+        L.live[old_live + rnk] = slot;
+      }
+    }
+    const int pos = sh[0] + j;
+    sc.cand_slot[pos] = slot;
+    sc.cand_key[pos] = key;
+    sc.cand_new[pos] = is_new ? 1 : 0;
+    if (J.stamp && slot >= 0) L.stamp[slot] = (J.stamp << 1) | (is_new ? 1 : 0);
+  }
+  if (w == nwg - 1 && threadIdx.x == 0) {  // the last chunk knows the totals
+    const int n_cand = sh[0] + n_items, n_newt = sh[1] + n_new;
+    const int granted = n_newt < room ? n_newt : room;
+    if (granted < n_newt) atomicOr(&L.ctr[3], 1);
+    const int from_free = granted < old_free ? granted : old_free;
+    L.ctr[0] = old_live + granted;
+    L.ctr[1] = old_free - from_free;
+    L.ctr[2] = old_bump + (granted - from_free);
+    *sc.cand_count = n_cand;
+    if (sc.hint_cand) *sc.hint_cand = n_cand;
+    if (L.hint_live) *L.hint_live = old_live + granted;
+    if (stats) {
+      if (J.stat_upd >= 0) stats[J.stat_upd] += n_cand;
+      if (J.stat_new >= 0) stats[J.stat_new] += granted;
+    }
+  }
+}
+
+// Deallocation of dead blocks, chunk w of nwg (256 threads, 4 list entries each): order-preserving, in place -- a chunk
+// writes its survivors at or before its own first entry, into positions whose owners published their counts (hence loaded
+// their entries) before this chunk could learn its offset.  WMAX: dead <=> wmax[slot] * decay_f < decay_thr (the light decay
+// of a fused frame), else the kill flags of a voxel pass (cleared here).  The dead blocks leave the index here (hash
+// tombstone / dense table / slot key); the last chunk books the tombstones and raises *rebuild when they exceed a quarter
+// of the table -- the caller follows with k_hash_clear_if / k_hash_insert_live_if on that flag.
+template <bool WMAX>
+__device__ inline void live_compact_big_body(const LayerDev& L, uint8_t* __restrict__ kill, u64* lb, unsigned tag, int* rebuild,
+                                             int* snap6, float decay_f, float decay_thr, int* lds, int* sh, int w, int nwg) {
+  const bool dense = L.dense != nullptr;
+  const int n = L.ctr[0];
+  const int free0 = L.ctr[1];
+  const int i0 = w * kBigChunk + (int)threadIdx.x * 4;
+  int slot[4];
+  bool dead[4];
+  int keep = 0, nd = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    slot[q] = -1;
+    dead[q] = false;
+    if (i0 + q < n) {
+      slot[q] = L.live[i0 + q];
+      if (WMAX) {
+        dead[q] = L.wmax[slot[q]] * decay_f < decay_thr;
+      } else if (kill[i0 + q]) {
+        dead[q] = true;
+        kill[i0 + q] = 0;
+      }
+      if (dead[q]) nd++;
+      else keep++;
+    }
+  }
+  int ea, eb, ta, tb;
+  block_excl_scan2<4>(keep, nd, lds, ea, eb, ta, tb);
+  lookback_exclusive(lb, tag, w, nwg, ta, tb, lds, sh, &L.ctr[3]);
+  int wk = sh[0] + ea, wd = free0 + sh[1] + eb;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (slot[q] < 0) continue;
+    if (dead[q]) {
+      L.free_stack[wd++] = slot[q];
+      const u64 key = L.slot_key[slot[q]];
+      if (!dense) hash_erase(L, key);
+      dense_set(L, key, 0);
+      L.slot_key[slot[q]] = kEmptyKey;
+    } else {
+      L.live[wk++] = slot[q];
+    }
+  }
+  if (w == nwg - 1 && threadIdx.x == 0) {
+    const int n_live = sh[0] + ta, n_dead = sh[1] + tb;
+    const int n_tomb = dense ? 0 : L.ctr[4] + n_dead;
+    const bool rb = !dense && (unsigned)n_tomb * 4u > L.hmask + 1u;
+    L.ctr[0] = n_live;
+    L.ctr[1] = free0 + n_dead;
+    L.ctr[4] = rb ? 0 : n_tomb;
+    if (rb) L.ctr[5]++;
+    if (rebuild) *rebuild = rb ? 1 : 0;
+    if (snap6) *snap6 = n_live;
+    if (L.hint_live) *L.hint_live = n_live;
+  }
+}
+
 }  // namespace mmf

@@ -69,6 +69,11 @@ struct Mapper {
   u64* pub = nullptr;          // [16 + 3 * cap + 2 + kNewBlockWgs] new blocks published by the allocation workgroups of k_alloc_tsdf to
                                // their own launch + the control words of the hand-over (AllocJob::pub)
   unsigned pub_tag = 0;        // tag of the last k_alloc_tsdf launch (30 bits, incremented by those launches only; 0 is never used)
+  // scalable allocation / deallocation of large grids and pools (mmf_alloc_device.h: alloc_big_body, live_compact_big_body)
+  u64* lb_compact = nullptr;   // [cap / 1024 + 4] look-back words of the list compaction
+  size_t lb_compact_words = 0;
+  int* rebuild_flag = nullptr; // device int: the compaction's last chunk asks for a hash rebuild
+  unsigned lb_tag = 0;         // tag of the last scalable launch (22 bits; 0 is never used; every look-back buffer is zeroed on wrap)
   int debug_abandon = 0;       // environment MMF_DEBUG_FORCE_ALLOC_TIMEOUT at creation (test hook of the hand-over's recovery)
   long long* stats = nullptr;  // device [MMF_NUM_STATS]
   long long frames[3] = {0, 0, 0};
@@ -309,6 +314,8 @@ void free_scratch(Scratch& sc) {
   (void)hipFree(sc.cand_slot);
   (void)hipFree(sc.cand_key);
   (void)hipFree(sc.cand_new);
+  (void)hipFree(sc.lb);
+  sc.lb = nullptr;
   sc.flags = nullptr;
 }
 
@@ -332,6 +339,8 @@ int ensure_scratch(Mapper& m, int which, int ncells) {
   HIP_TRY(hipMalloc(&sc.cand_slot, sizeof(int) * (size_t)n));
   HIP_TRY(hipMalloc(&sc.cand_key, sizeof(u64) * (size_t)n));
   HIP_TRY(hipMalloc(&sc.cand_new, (size_t)n));
+  HIP_TRY(hipMalloc(&sc.lb, sizeof(u64) * (2 * ((size_t)n / 1024 + 2) + 8)));
+  HIP_TRY(hipMemset(sc.lb, 0, sizeof(u64) * (2 * ((size_t)n / 1024 + 2) + 8)));
   if (!cand_count) {
     HIP_TRY(hipMalloc(&cand_count, sizeof(int)));
     HIP_TRY(hipMemset(cand_count, 0, sizeof(int)));
@@ -414,6 +423,11 @@ int create_mapper_impl(const mmf_params& P, Mapper* m) {
   }
   HIP_TRY(hipMalloc(&m->any_kill, sizeof(int)));
   HIP_TRY(hipMemset(m->any_kill, 0, sizeof(int)));
+  m->lb_compact_words = 2 * ((size_t)cap / 1024 + 2) + 8;
+  HIP_TRY(hipMalloc(&m->lb_compact, sizeof(u64) * m->lb_compact_words));
+  HIP_TRY(hipMemset(m->lb_compact, 0, sizeof(u64) * m->lb_compact_words));
+  HIP_TRY(hipMalloc(&m->rebuild_flag, sizeof(int)));
+  HIP_TRY(hipMemset(m->rebuild_flag, 0, sizeof(int)));
   HIP_TRY(hipMalloc(&m->stats, sizeof(long long) * MMF_NUM_STATS));
   HIP_TRY(hipMemset(m->stats, 0, sizeof(long long) * MMF_NUM_STATS));
   HIP_TRY(hipMalloc(&m->mesh_counts, sizeof(int) * (size_t)cap));
@@ -468,6 +482,8 @@ void destroy_mapper(Mapper* m) {
   (void)hipFree(m->kill);
   (void)hipFree(m->pub);
   (void)hipFree(m->any_kill);
+  (void)hipFree(m->lb_compact);
+  (void)hipFree(m->rebuild_flag);
   (void)hipFree(m->stats);
   (void)hipFree(m->synth);
   (void)hipFree(m->mesh_counts);
@@ -546,11 +562,24 @@ int get_mapper(mmf_handle h, int id, Mapper** out) {
 }
 
 // A pending decay is applied now, as its own launches (every consumer of the map except the fused frame path).
+int next_lb_tag(Mapper& m, hipStream_t s, unsigned* tag);
+bool big_mode(const Mapper& m, int ncells);
+int alloc_big_one(Mapper& m, const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, int stat_upd, int stat_new, hipStream_t s);
+
 void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
   if (!m.pending_decay) return;
   m.pending_decay = false;
   m.wmax_valid = false;  // the stand-alone decay does not maintain wmax
   ProfScope ps(h, MMF_K_DECAY, s);
+  if (m.tsdf.d.cap > 16384 && alloc_big_supported(m.tsdf.d) && m.mc.dealloc_decayed) {
+    // large pools: the voxel pass marks the dead blocks, the scalable compaction drops them (one launch instead of a single
+    // workgroup's dozens of passes over the live list)
+    unsigned tag = 1;
+    (void)next_lb_tag(m, s, &tag);
+    launch_decay_mark(m.tsdf.d, m.mc, m.kill, m.any_kill, s);
+    launch_live_compact_big(m.tsdf.d, false, m.kill, m.any_kill, m.lb_compact, tag, m.rebuild_flag, nullptr, 0.0f, 0.0f, m.tsdf.d.cap, s);
+    return;
+  }
   launch_decay(m.tsdf.d, m.mc, m.kill, m.any_kill, s);
 }
 
@@ -647,7 +676,10 @@ int app_alloc(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, cons
     KeySrc ks{};
     ks.mode = 1;
     ks.n_live = m.tsdf.d.ctr;
-    launch_compact_alloc(L.d, ks, m.sc[which], m.tsdf.d.cap, m.stats, stat_upd, stat_new, s);
+    if (big_mode(m, m.tsdf.d.cap) && alloc_big_supported(L.d))
+      MMF_TRY(alloc_big_one(m, L.d, ks, m.sc[which], m.tsdf.d.cap, stat_upd, stat_new, s));
+    else
+      launch_compact_alloc(L.d, ks, m.sc[which], m.tsdf.d.cap, m.stats, stat_upd, stat_new, s);
   }
   return MMF_OK;
 }
@@ -687,6 +719,38 @@ int next_pub_tag(Mapper& m, hipStream_t s, unsigned* tag) {
     m.pub_tag = 1;
   }
   *tag = m.pub_tag;
+  return MMF_OK;
+}
+
+// Tag of the next scalable (look-back) launch of this mapper: 22 bits, 0 never used; the words of earlier launches stay in the
+// buffers and are told apart by their tag, so every look-back buffer is zeroed when the counter wraps.
+int next_lb_tag(Mapper& m, hipStream_t s, unsigned* tag) {
+  m.lb_tag = (m.lb_tag + 1) & 0x3fffffu;
+  if (m.lb_tag == 0) {
+    HIP_TRY(hipMemsetAsync(m.lb_compact, 0, sizeof(u64) * m.lb_compact_words, s));
+    for (int w = 0; w < 3; ++w)
+      if (m.sc[w].lb) HIP_TRY(hipMemsetAsync(m.sc[w].lb, 0, sizeof(u64) * (2 * ((size_t)m.sc_cap[w] / 1024 + 2) + 8), s));
+    m.lb_tag = 1;
+  }
+  *tag = m.lb_tag;
+  return MMF_OK;
+}
+
+// Large view grids / pools (an unbounded workspace, a bounding box of more than 16 384 blocks): the scalable single-launch
+// allocation and list compaction instead of the single-workgroup roles.
+bool big_mode(const Mapper& m, int ncells) { return !alloc_jobs_fusable(ncells, m.tsdf.d.cap) && alloc_big_supported(m.tsdf.d); }
+
+// one allocation job through the scalable kernel (the replacement of the three-kernel count / scan / emit path)
+int alloc_big_one(Mapper& m, const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, int stat_upd, int stat_new, hipStream_t s) {
+  AllocJob J;
+  J.L = L;
+  J.ks = ks;
+  J.sc = sc;
+  J.ncells = ncells;
+  J.stat_upd = stat_upd;
+  J.stat_new = stat_new;
+  MMF_TRY(next_lb_tag(m, s, &J.lb_tag));
+  launch_alloc_big(&J, 1, m.stats, nullptr, s);
   return MMF_OK;
 }
 
@@ -758,7 +822,10 @@ int depth_chain(mmf_handle h, Mapper& m, const float* depth, const uint8_t* mask
     ks.oz = vg.oz;
     ks.ny = vg.ny;
     ks.nz = vg.nz;
-    launch_compact_alloc(m.tsdf.d, ks, m.sc[0], ncells, m.stats, 1, 2, s);
+    if (big_mode(m, ncells))
+      MMF_TRY(alloc_big_one(m, m.tsdf.d, ks, m.sc[0], ncells, 1, 2, s));
+    else
+      launch_compact_alloc(m.tsdf.d, ks, m.sc[0], ncells, m.stats, 1, 2, s);
   }
   {
     ProfScope ps(h, MMF_K_TSDF, s);
@@ -1093,7 +1160,10 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   ViewGrid vg;
   MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
   const int ncells = vg.nx * vg.ny * vg.nz;
-  const bool fusable = packed && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
+  // big: a view grid / pool beyond the single-workgroup allocation roles (an unbounded workspace, a very large box): the same
+  // fused frame with the scalable allocation and list compaction as launches of their own (mmf_alloc_device.h)
+  const bool big = packed && ncells > 0 && big_mode(*m, ncells) && alloc_big_supported(m->color.d) && alloc_big_supported(m->feat.d);
+  const bool fusable = packed && ncells > 0 && (alloc_jobs_fusable(ncells, m->tsdf.d.cap) || big);
   if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
   if (fusable) M.invert = invert_mask ? 1 : 0;
   if (!fusable && invert_mask) {  // stand-alone kernels take the mask as it is: invert it once into scratch
@@ -1144,6 +1214,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   const int stamp = (int)(m->tsdf_epoch & 0x3fffffff) ? (int)(m->tsdf_epoch & 0x3fffffff) : 1;
   MMF_TRY(ensure_scratch(*m, 0, ncells));
   const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
+  if (big && m->pending_decay && !m->wmax_valid) flush_decay(h, *m, s);  // that decay needs its voxel pass: eager, scalable compaction
   const bool do_decay = m->pending_decay;
   m->pending_decay = false;
   // wmax current (the previous writer of the TSDF weights was a fused frame): the decay's deallocations are decided from it by
@@ -1151,7 +1222,16 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   const bool light_decay = do_decay && m->wmax_valid;
   // Merged launch 2 (k_alloc_tsdf): bounded workspace and no voxel-pass decay in this frame -- the live list is final when
   // k_front ends, so the TSDF pass of the existing blocks runs beside the allocation workgroup instead of after it.
-  const bool merged = m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
+  const bool merged = !big && m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
+  if (big && light_decay && m->mc.dealloc_decayed) {
+    // the light decay's deallocations for a large pool: the scalable compaction (decided from wmax, no voxel touched) as a launch
+    // of its own -- k_front's single decay workgroup would need dozens of serial passes over 10^5 list entries
+    ProfScope ps(h, MMF_K_DECAY, s);
+    unsigned tag = 1;
+    MMF_TRY(next_lb_tag(*m, s, &tag));
+    launch_live_compact_big(m->tsdf.d, true, nullptr, nullptr, m->lb_compact, tag, m->rebuild_flag, nullptr, m->mc.decay_factor,
+                            m->mc.decay_thr, m->tsdf.d.cap, s);
+  }
   int grid_tag = 1;
   if (merged)
     MMF_TRY(next_grid_tag(*m, s, &grid_tag));
@@ -1161,7 +1241,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     // raycast tiles | mask row pass | pending decay of the TSDF layer
     ProfExt pe(h, MMF_K_RAYCAST);
     const FrontArgs FA = make_front_args(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M,
-                                         do_decay ? &m->tsdf.d : nullptr, light_decay, m->kill, m->any_kill,
+                                         (do_decay && !big) ? &m->tsdf.d : nullptr, light_decay, m->kill, m->any_kill,
                                          merged ? m->tsdf.d.ctr : nullptr, grid_tag);
     launch_front(&FA, 1, s, pe.a(), pe.b());
   }
@@ -1201,7 +1281,12 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
         job0.kill = m->kill;
         job0.any_kill = m->any_kill;
       }
-      launch_alloc_jobs(&job0, 1, m->stats, &M, s);
+      if (big) {
+        MMF_TRY(next_lb_tag(*m, s, &job0.lb_tag));
+        launch_alloc_big(&job0, 1, m->stats, &M, s);  // TSDF allocation (hash lookups + CAS insertion) | mask columns
+      } else {
+        launch_alloc_jobs(&job0, 1, m->stats, &M, s);
+      }
     }
     {
       // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
@@ -1237,7 +1322,17 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     int Ws, Hs;
     bool need;
     MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
-    if (need) {
+    if (big) {
+      if (need) {
+        ProfScope ps(h, MMF_K_SPHERE, s);
+        launch_sphere_trace(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, s);
+        synth_commit(*m, cam, T16, K9, Ws, Hs);
+      }
+      ProfScope ps(h, MMF_K_ALLOC, s);
+      MMF_TRY(next_lb_tag(*m, s, &jobs[0].lb_tag));
+      jobs[1].lb_tag = jobs[0].lb_tag;
+      launch_alloc_big(jobs, 2, m->stats, nullptr, s);  // colour allocation | feature allocation
+    } else if (need) {
       ProfExt pe(h, MMF_K_SPHERE);
       const SphereArgs SA = make_sphere_args(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats);
       launch_sphere_alloc(&SA, 1, s, pe.a(), pe.b());
@@ -2334,21 +2429,24 @@ int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_
   return MMF_OK;
 }
 
-int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out4) {
+int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out8) {
   Mapper* m;
   MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
   Layer* L = pick_layer(m, layer);
-  if (!L || !out4) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
-  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (!L || !out8) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  out8[4] = m->last_vg.nx;
+  out8[5] = m->last_vg.ny;
+  out8[6] = m->last_vg.nz;
   if (!L->allocated) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
   int c[8];
   HIP_TRY(hipMemcpyAsync(c, L->d.ctr, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  out4[0] = L->d.dense ? 0 : (int64_t)L->d.hmask + 1;  // 0: the layer is indexed by its dense table, the hash is not maintained
-  out4[1] = c[4];
-  out4[2] = c[5];
-  out4[3] = c[0];
+  out8[0] = L->d.dense ? 0 : (int64_t)L->d.hmask + 1;  // 0: the layer is indexed by its dense table, the hash is not maintained
+  out8[1] = c[4];
+  out8[2] = c[5];
+  out8[3] = c[0];
   return MMF_OK;
 }
 

@@ -7,6 +7,8 @@
 // mindmap/mapping/isaaclab_nvblox_mapper.py:252-258.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "mmf_launch.h"
 #include "mmf_trace_device.h"
 #include "mmf_alloc_device.h"
@@ -1076,6 +1078,39 @@ __global__ __launch_bounds__(256) void k_decay(LayerDev L, MapConsts mc, uint8_t
   decay_body<false>(L, mc, kill, any_kill, blockIdx.x, gridDim.x);
 }
 
+// Scalable allocation (alloc_big_body): roles [job 0: nwg0 chunks | job 1: nwg1 chunks | mask column rows].  One launch for the
+// TSDF allocation of a large view grid (+ the frame's mask columns) or for the colour + feature allocation of a large pool.
+__global__ __launch_bounds__(256) void k_alloc_big(AllocJob J0, AllocJob J1, int nwg0, int nwg1, int G0, int G1, long long* stats, MaskJob M,
+                                                  int mask_rows) {
+  __shared__ AllocBigLds S;
+  __shared__ u64 s_bad[kMaxMaskWords];
+  int b = (int)blockIdx.x;
+  if (b < nwg0) {
+    if (J0.ks.mode == 0) alloc_big_body<0>(J0, stats, S, b, nwg0, G0);
+    else alloc_big_body<1>(J0, stats, S, b, nwg0, G0);
+    return;
+  }
+  b -= nwg0;
+  if (b < nwg1) {
+    if (J1.ks.mode == 0) alloc_big_body<0>(J1, stats, S, b, nwg1, G1);
+    else alloc_big_body<1>(J1, stats, S, b, nwg1, G1);
+    return;
+  }
+  b -= nwg1;
+  if (b < mask_rows) mask_colemit_row(M, b, s_bad);
+}
+
+// Scalable deallocation (live_compact_big_body): the dead blocks of a decay leave the live list / the index in one launch of
+// ceil(live / 1024) workgroups.  WMAX: decided from the blocks' largest weights (the light decay of a fused frame).
+template <bool WMAX>
+__global__ __launch_bounds__(256) void k_live_compact_big(LayerDev L, uint8_t* kill, u64* lb, unsigned tag, int* rebuild, int* snap6,
+                                                         float decay_f, float decay_thr, int* any_kill) {
+  __shared__ int lds[10];
+  __shared__ int sh[8];
+  live_compact_big_body<WMAX>(L, kill, lb, tag, rebuild, snap6, decay_f, decay_thr, lds, sh, (int)blockIdx.x, (int)gridDim.x);
+  if (!WMAX && any_kill && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *any_kill = 0;
+}
+
 __global__ __launch_bounds__(1024) void k_live_compact(LayerDev L, uint8_t* __restrict__ kill, int* any_kill) {
   __shared__ int lds[34];
   __shared__ int carry[2];
@@ -1318,6 +1353,46 @@ void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc
   hipLaunchKernelGGL(k_emit, dim3(ntiles), dim3(256), 0, s, L, ks, sc, ncells);
 }
 
+int alloc_big_wgs(int ncells) { return ncells <= 0 ? 1 : (ncells + kBigChunk - 1) / kBigChunk; }
+// groups of 4 cells per thread so that a job is at most ~128 chunks where it can (look-back hops are memory round trips)
+static int alloc_big_groups(int ncells) {
+  static const int forced = std::getenv("MMF_DEBUG_BIG_G") ? std::atoi(std::getenv("MMF_DEBUG_BIG_G")) : 0;
+  if (forced > 0) return forced > kBigMaxG ? kBigMaxG : forced;
+  int G = (alloc_big_wgs(ncells) + 127) / 128;
+  return G < 1 ? 1 : (G > kBigMaxG ? kBigMaxG : G);
+}
+bool alloc_big_supported(const LayerDev& L) { return L.cap < (int)kLbCountMax; }
+
+// jobs: 1 or 2 allocation jobs (AllocJob::sc.lb / lb_tag set by the caller); M: the frame's mask job whose column pass rides
+// along (may be null)
+void launch_alloc_big(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s) {
+  MaskJob mj{};
+  int rows = 0;
+  if (M) {
+    mj = *M;
+    rows = M->Hf;
+  }
+  const int G0 = alloc_big_groups(jobs[0].ncells), G1 = njobs > 1 ? alloc_big_groups(jobs[1].ncells) : 1;
+  const int n0 = (alloc_big_wgs(jobs[0].ncells) + G0 - 1) / G0, n1 = njobs > 1 ? (alloc_big_wgs(jobs[1].ncells) + G1 - 1) / G1 : 0;
+  hipLaunchKernelGGL(k_alloc_big, dim3(n0 + n1 + rows), dim3(256), 0, s, jobs[0], jobs[njobs > 1 ? 1 : 0], n0, n1, G0, G1, stats, mj, rows);
+}
+
+// live_upper: an upper bound of the live count known to the host (the pool capacity if nothing better)
+void launch_live_compact_big(const LayerDev& L, bool wmax, uint8_t* kill, int* any_kill, u64* lb, unsigned tag, int* rebuild, int* snap6,
+                             float decay_f, float decay_thr, int live_upper, hipStream_t s) {
+  const int nwg = alloc_big_wgs(live_upper);
+  if (wmax)
+    hipLaunchKernelGGL(k_live_compact_big<true>, dim3(nwg), dim3(256), 0, s, L, kill, lb, tag, rebuild, snap6, decay_f, decay_thr, any_kill);
+  else
+    hipLaunchKernelGGL(k_live_compact_big<false>, dim3(nwg), dim3(256), 0, s, L, kill, lb, tag, rebuild, snap6, decay_f, decay_thr, any_kill);
+  if (!L.dense) {  // the amortised rebuild, on the flag the last chunk raised
+    int hb = (int)((L.hmask + 1 + 255) / 256);
+    if (hb > 1024) hb = 1024;
+    hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)rebuild);
+    hipLaunchKernelGGL(k_hash_insert_live_if, dim3(grid_for((L.cap + 255) / 256, 1024)), dim3(256), 0, s, L, (const int*)rebuild);
+  }
+}
+
 bool alloc_jobs_fusable(int ncells0, int ncells1) { return ncells0 <= kFusedAllocMaxCells && ncells1 <= kFusedAllocMaxCells; }
 
 // njobs (1 or 2) allocation jobs + (optionally) the mask column pass in one launch
@@ -1500,6 +1575,11 @@ void launch_alloc_tsdf_batch(const AllocTsdfArgs* A, int n, hipStream_t s, hipEv
   }
   P.lead = (lead + 7) & ~7;
   hipExtLaunchKernelGGL(k_alloc_tsdf_batch, dim3(P.lead + rest), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+}
+
+// the voxel pass of a decay alone (W *= f, dead blocks flagged in kill[]); the caller compacts
+void launch_decay_mark(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {
+  hipLaunchKernelGGL(k_decay, dim3(grid_for(hinted(L.hint_live, L.cap), 4096)), dim3(256), 0, s, L, mc, kill, any_kill);
 }
 
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s) {

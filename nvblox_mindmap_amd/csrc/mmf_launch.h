@@ -187,6 +187,12 @@ AllocTsdfArgs make_alloc_tsdf_args(const AllocJob& job, long long* stats, const 
                                    float decay_f);
 void launch_alloc_tsdf(const AllocTsdfArgs* A, int n, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 bool alloc_jobs_fusable(int ncells0, int ncells1);
+// scalable single-launch forms for large view grids / pools (mmf_alloc_device.h: alloc_big_body, live_compact_big_body)
+int alloc_big_wgs(int ncells);
+bool alloc_big_supported(const LayerDev& L);
+void launch_alloc_big(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
+void launch_live_compact_big(const LayerDev& L, bool wmax, uint8_t* kill, int* any_kill, u64* lb, unsigned tag, int* rebuild, int* snap6,
+                             float decay_f, float decay_thr, int live_upper, hipStream_t s);
 void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s);
@@ -197,6 +203,7 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s);
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
+void launch_decay_mark(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
 void launch_decay_app_weights(const LayerDev& L, float f, bool has_w, hipStream_t s);
 void launch_layer_reset(const LayerDev& L, hipStream_t s);
 void launch_hash_rebuild(const LayerDev& L, hipStream_t s);

@@ -682,9 +682,11 @@ class Mapper:
 
     def hash_state(self, mapper_id: int = 0, layer: int = _lib.MMF_LAYER_TSDF) -> dict:
         """Diagnostics of a layer's block index: hash table size (0 = dense table of a bounded workspace), tombstones, rebuilds, live blocks."""
-        buf = (C.c_int64 * 4)()
+        buf = (C.c_int64 * 8)()
         _lib.check(_lib.lib().mmf_debug_hash_state(self._h, mapper_id, int(layer), self._stream(), buf), "mmf_debug_hash_state")
-        return dict(zip(["table_entries", "tombstones", "rebuilds", "live_blocks"], [int(x) for x in buf]))
+        out = dict(zip(["table_entries", "tombstones", "rebuilds", "live_blocks"], [int(x) for x in buf[:4]]))
+        out["view_grid"] = [int(buf[4]), int(buf[5]), int(buf[6])]
+        return out
 
     def reset_stats(self, mapper_id: int = 0) -> None:
         _lib.check(_lib.lib().mmf_reset_stats(self._h, mapper_id, self._stream()), "mmf_reset_stats")
