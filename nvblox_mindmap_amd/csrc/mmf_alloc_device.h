@@ -404,24 +404,37 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
     // (ctx above is complete: thread 0 passed the scan's barriers after writing it)
     __hip_atomic_store(J.pub + 1 + w, tg | ((u64)(unsigned)ta << 16) | (u64)(unsigned)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int pa = 0, pb = 0;
+    bool failed = false;
+    const long long t_start = wall_clock64();  // 100 MHz: a predecessor that has not published within 50 ms never will
     for (int v = 0; v < w; ++v) {
       u64 x = 0;
-      for (int spins = 0; spins < (1 << 22); ++spins) {
+      for (;;) {
         x = __hip_atomic_load(J.pub + 1 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(x >> 32) == J.pub_tag) break;
+        if (wall_clock64() - t_start > 5000000ll) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      if ((unsigned)(x >> 32) != J.pub_tag) atomicOr(&L.ctr[3], 2);  // gave up waiting (never observed)
+      if ((unsigned)(x >> 32) != J.pub_tag) {  // gave up waiting (never observed): the word is stale -- its counts are NOT used
+        failed = true;
+        continue;
+      }
       pa += (int)((x >> 16) & 0xffffu);
       pb += (int)(x & 0xffffu);
     }
+    if (failed) {  // this workgroup grants nothing and lists nothing (in-bounds by construction); the frame is reported as failed
+      atomicOr(&L.ctr[3], 2);
+      if (J.host_err) *J.host_err = 1;
+      pa = pb = 0;
+    }
     carry[0] = pa;
     carry[1] = pb;
+    carry[2] = failed ? 1 : 0;
   }
   __syncthreads();
   if (tl) tl[4] = wall_clock64();  // counts of the earlier workgroups collected
-  const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
-  if (nf) {
+  const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2];
+  const int room = carry[2] ? 0 : ctx[3];  // a failed prefix wait: no slot is granted by this workgroup
+  if (nf && !carry[2]) {
     int pos = carry[0] + ea, rnk = carry[1] + eb;
     int gx = gx0, gy = gy0, gz = gz0;
 #pragma unroll
@@ -506,9 +519,11 @@ __device__ inline u64 lb_pack(unsigned tag, unsigned status, unsigned a, unsigne
 
 __device__ inline u64 lb_poll(const u64* word, unsigned tag, unsigned status, int* err) {
   u64 x = 0;
-  for (int spins = 0; spins < (1 << 22); ++spins) {
+  const long long t_start = wall_clock64();  // 100 MHz: 50 ms
+  for (;;) {
     x = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((unsigned)(x >> 42) == (tag & 0x3fffffu) && (unsigned)((x >> 40) & 3ull) == status) return x;
+    if (wall_clock64() - t_start > 5000000ll) break;
     __builtin_amdgcn_s_sleep(4);
   }
   atomicOr(err, 2);  // (never observed) the launch's hand-over failed: reported like k_alloc_tsdf's

@@ -693,7 +693,9 @@ int app_prepare(mmf_handle h, Mapper& m, int which, Layer& L, const Cam& cam, co
 
 // bit-row scratch of the mask kernels + the masked depth image of a frame
 int ensure_mask_scratch(Mapper& m, int H, int W) {
-  if ((size_t)H * W + 8 <= m.mask_tmp_cap) return MMF_OK;
+  // (the 16x16-pixel patch flags are sized by the image's ASPECT, not its area: an equal-area image of another shape needs more)
+  const size_t patches = (size_t)(H / 16 + 1) * (W / 16 + 1);
+  if ((size_t)H * W + 8 <= m.mask_tmp_cap && patches <= m.patch_cap) return MMF_OK;
   HIP_TRY(hipDeviceSynchronize());
   (void)hipFree(m.mask_tmp);
   (void)hipFree(m.masked_depth);
@@ -701,12 +703,13 @@ int ensure_mask_scratch(Mapper& m, int H, int W) {
   m.mask_tmp = nullptr;
   m.masked_depth = nullptr;
   m.patch_flags = nullptr;
-  HIP_TRY(hipMalloc(&m.mask_tmp, (size_t)H * W + 8));
-  HIP_TRY(hipMalloc(&m.masked_depth, sizeof(float) * (size_t)H * W));
-  m.patch_cap = (size_t)(H / 16 + 1) * (W / 16 + 1);
+  const size_t area = (size_t)H * W + 8 > m.mask_tmp_cap ? (size_t)H * W + 8 : m.mask_tmp_cap;
+  HIP_TRY(hipMalloc(&m.mask_tmp, area));
+  HIP_TRY(hipMalloc(&m.masked_depth, sizeof(float) * area));
+  m.patch_cap = patches > m.patch_cap ? patches : m.patch_cap;
   HIP_TRY(hipMalloc(&m.patch_flags, m.patch_cap));
   HIP_TRY(hipMemset(m.patch_flags, 0, m.patch_cap));
-  m.mask_tmp_cap = (size_t)H * W + 8;
+  m.mask_tmp_cap = area;
   return MMF_OK;
 }
 
@@ -761,11 +764,12 @@ int report_device_errors(mmf_handle h, Mapper& m, Layer* layer, const int* err_b
   int bits = err_bits ? *err_bits : 0;
   if (m.hints && m.hints[7]) bits |= 2;
   if (!(bits & 3)) return MMF_OK;
+  // only the bits that are being reported are cleared (an unreported pool exhaustion stays for mmf_num_allocated_blocks)
   if (m.hints[7]) {
     m.hints[7] = 0;
-    HIP_TRY(hipMemsetAsync(m.tsdf.d.ctr + 3, 0, sizeof(int), s));
+    launch_clear_bits(m.tsdf.d.ctr + 3, 2, s);
   }
-  if (layer && layer->allocated) HIP_TRY(hipMemsetAsync(layer->d.ctr + 3, 0, sizeof(int), s));
+  if (layer && layer->allocated) launch_clear_bits(layer->d.ctr + 3, bits & 3, s);
   if (bits & 2)
     return fail(MMF_ERR_BAD_STATE, "k_alloc_tsdf: the in-launch hand-over of new blocks failed (waiters and sweeper timed out waiting for the "
                                    "allocation workgroups of their launch); the TSDF map is incomplete -- clear() it, and set "
@@ -1408,7 +1412,8 @@ static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGr
       !in.feature_mask_out || in.H <= 1 || in.W <= 1 || in.Hf != in.H || in.Wf != in.W || in.k_in < 0 || in.k_depth < 0 ||
       !(in.min_depth_m >= 0.0f) || in.C != m.P.feature_channels || ((uintptr_t)in.feat & 15) != 0)
     return false;
-  if (!m.mask_tmp || (size_t)in.H * in.W + 8 > m.mask_tmp_cap) return false;  // (first frame of a mapper: the single path sizes the scratch)
+  if (!m.mask_tmp || (size_t)in.H * in.W + 8 > m.mask_tmp_cap || (size_t)(in.H / 16 + 1) * (in.W / 16 + 1) > m.patch_cap)
+    return false;  // (first frame of a mapper / a new image shape: the single path sizes the scratch)
   if (!m.color.allocated || !m.feat.allocated || !m.flat.rec) return false;
   cam = cam_from_K(in.K9, in.W, in.H);
   rigid_from_T(in.T16, T_L_C);
@@ -1455,7 +1460,8 @@ static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, c
   MMF_TRY(next_grid_tag(m, s, &grid_tag));
   // Two frames share every launch, so the chip is oversubscribed where one frame alone fills it (2 x 1 200 ray patches): the
   // sphere tracer of a paired frame skips the patches no gate can read (for the dynamic mapper most of the image).
-  const bool skip_patches = m.mc.st_sf == 4 && m.patch_flags != nullptr;
+  const bool skip_patches = m.mc.st_sf == 4 && m.patch_flags != nullptr &&
+                            (size_t)((in.W / 4 + 3) / 4) * ((in.H / 4 + 3) / 4) <= m.patch_cap;
   if (skip_patches) {
     M.patch_flags = m.patch_flags;
     M.patches_x = (in.W / 4 + 3) / 4;

@@ -920,7 +920,7 @@ __device__ inline void new_blocks_role(const LayerDev& L, const TsdfFrameArgs& P
 
 struct AllocTsdfLds {
   int lds[34];
-  int carry[2];
+  int carry[4];  // [2]: the allocation workgroup's wait for its predecessors failed
   int ctx[4];
   u64 s_bad[kMaxMaskWords];
   TsdfPairLds S;
@@ -1138,6 +1138,8 @@ __global__ void k_reset_layer(LayerDev L) {
 }
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
+__global__ void k_clear_bits(int* p, int bits) { atomicAnd(p, ~bits); }
+void launch_clear_bits(int* word, int bits, hipStream_t s) { hipLaunchKernelGGL(k_clear_bits, dim3(1), dim3(1), 0, s, word, bits); }
 
 __global__ __launch_bounds__(256) void k_invert_mask(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -30,11 +30,17 @@ class MindmapFrameDataset(Dataset):
     def __init__(self, dataset_path: str, cameras: Sequence[str] = ("pov",), num_vertices: int = 2048,
                  vertex_sampling_method: VertexSamplingMethod = VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT,
                  with_vertex_features: bool = True, seed: Optional[int] = None, geometry_augmentor=None, geometry_noiser=None,
-                 use_raw_vertex_cache: bool = True):
+                 use_raw_vertex_cache: bool = True, allow_untransformed_cameras: bool = False):
         """``geometry_augmentor`` / ``geometry_noiser``: sample_transformer.GeometryAugmentor / GeometryNoiser, wired as the
         reference does (dataset_files_by_encoding_method.py:258-279): ONE random rigid transform per sample applied to the mesh
         vertices, the gripper history and the target poses; independent Gaussian pose noise on the history and the vertices,
         not on the target; both before the vertices are sampled."""
+        if geometry_augmentor is not None and not allow_untransformed_cameras:
+            # the reference refuses random transforms unless the data type is MESH (dataset_files_by_encoding_method.py:258-279):
+            # the rigid transform moves the mesh, the gripper history and the targets, NOT the camera poses / depth images that
+            # every sample of this dataset also carries -- an RGBD_AND_MESH model would see a point cloud and a mesh in two frames
+            raise NotImplementedError("geometry augmentation transforms the mesh, history and targets but not the cameras: pass "
+                                      "allow_untransformed_cameras=True for a model that reads the mesh only (data type MESH)")
         self.augmentor, self.noiser = geometry_augmentor, geometry_noiser
         # ``use_raw_vertex_cache``: where ``io.vertex_cache.convert_dataset`` has left a memory-mappable copy of a frame's vertex
         # features, map it and read only the sampled rows (same selection, same values; 3 MB of page cache instead of 18 MB of

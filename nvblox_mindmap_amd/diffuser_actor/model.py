@@ -12,6 +12,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -347,6 +349,10 @@ class DiffusionHead(nn.Module):
         return pred, head_yaw, None
 
     def can_denoise_fused(self, P, traj) -> bool:
+        if self.cfg.use_instruction and layers_mod._fused(traj) and not getattr(self, "_warned_instruction", False):
+            self._warned_instruction = True
+            warnings.warn("use_instruction: the matrix-core inference kernels have no trajectory-language attention; the denoising "
+                          "loop runs on the composite ops (about 10x slower)")
         return (P.get("seq") is not None and layers_mod._fused(traj) and traj.shape[1] * traj.shape[2] == P["pos_table"].shape[0]
                 and traj.shape[2] <= 4 and not self.cfg.use_instruction)
 

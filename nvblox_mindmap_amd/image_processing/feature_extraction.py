@@ -74,7 +74,14 @@ class FeatureExtractor(ABC):
     def _features_bchw(self, rgb: torch.Tensor) -> torch.Tensor:
         assert rgb.ndim == 4
         assert rgb.shape[3] == 3
-        return self._extract_features_impl(self.preprocess_image(rgb, self.train_dataset_mean_and_std()))
+        # compute_lowres followed by compute on the SAME image (nvblox_integrate's fallback when the low-res hand-over does not
+        # apply) must not run the network twice: the last model output is kept, keyed by the image tensor's identity + version
+        key = (rgb.data_ptr(), rgb._version, tuple(rgb.shape), rgb.dtype)
+        if getattr(self, "_last_key", None) == key:
+            return self._last_out
+        out = self._extract_features_impl(self.preprocess_image(rgb, self.train_dataset_mean_and_std()))
+        self._last_key, self._last_out = key, out
+        return out
 
     def compute(self, rgb: torch.Tensor):
         """rgb (b,h,w,3) -> features (b,H,W,F), float32 like the reference (:170-196)."""

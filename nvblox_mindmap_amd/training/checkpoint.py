@@ -9,6 +9,7 @@ a checkpoint written by the reference is recognised by its key names and convert
 reference's names.  Optimizer state is NOT interchangeable (parameter order and grouping differ): loading a reference
 checkpoint for training restores the weights and restarts the optimizer."""
 import os
+import warnings
 import pathlib
 from typing import Optional, Tuple
 
@@ -48,7 +49,17 @@ def _load_weights(model, state: dict) -> bool:
     if RW.is_reference_state_dict(state):
         RW.load_reference_state_dict(model, state)
         return True
-    model.load_state_dict(_match_prefix(state, model))
+    state = _match_prefix(state, model)
+    # checkpoints written before the trajectory-language attention existed (use_instruction models only use it) lack its
+    # parameters: they keep their initial values; any OTHER missing or unexpected key is an error
+    result = model.load_state_dict(state, strict=False)
+    optional = ("traj_lang_attention", "traj_lang_ffn")
+    missing = [k for k in result.missing_keys if not any(o in k for o in optional)]
+    if missing or result.unexpected_keys:
+        raise RuntimeError(f"checkpoint does not fit the model: missing {missing}, unexpected {list(result.unexpected_keys)}")
+    if result.missing_keys:
+        warnings.warn(f"checkpoint has no trajectory-language attention weights ({len(result.missing_keys)} tensors keep their "
+                      "initial values); irrelevant unless use_instruction is set")
     return False
 
 

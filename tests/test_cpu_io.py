@@ -197,7 +197,10 @@ def test_dataset_applies_the_same_augmentation_to_every_geometric_item(tmp_path)
     write_synthetic_demo(str(tmp_path / "demo_00000"), 2, image_size=(32, 32), feature_dim=8, ngrippers=2, vertex_count_range=(40, 41))
     plain = MindmapFrameDataset(str(tmp_path), num_vertices=40, vertex_sampling_method=VertexSamplingMethod.NONE)
     aug = GeometryAugmentor(([0.1, 0.1, 0.1], [0.2, 0.2, 0.2]), ([-20.0, -20.0, -20.0], [20.0, 20.0, 20.0]))
-    moved = MindmapFrameDataset(str(tmp_path), num_vertices=40, vertex_sampling_method=VertexSamplingMethod.NONE, geometry_augmentor=aug)
+    with pytest.raises(NotImplementedError):  # cameras are not moved: refused unless the caller says the model is mesh-only
+        MindmapFrameDataset(str(tmp_path), num_vertices=40, vertex_sampling_method=VertexSamplingMethod.NONE, geometry_augmentor=aug)
+    moved = MindmapFrameDataset(str(tmp_path), num_vertices=40, vertex_sampling_method=VertexSamplingMethod.NONE, geometry_augmentor=aug,
+                                allow_untransformed_cameras=True)
     a = plain[1]
     random.seed(3)
     b = moved[1]

@@ -44,7 +44,7 @@ def test_raw_cache_with_geometry_augmentation_and_noise(dataset_dir):
     def build(raw):
         return MindmapFrameDataset(dataset_dir, num_vertices=512, seed=None, use_raw_vertex_cache=raw,
                                    geometry_augmentor=GeometryAugmentor([[-0.1, -0.1, -0.05], [0.1, 0.1, 0.05]], [[-5.0, -5.0, -30.0], [5.0, 5.0, 30.0]]),
-                                   geometry_noiser=GeometryNoiser(0.002, 0.5))
+                                   geometry_noiser=GeometryNoiser(0.002, 0.5), allow_untransformed_cameras=True)
 
     plain, cached = build(False), build(True)
     for i in range(len(plain)):
