@@ -44,7 +44,7 @@ class MindmapFrameDataset(Dataset):
         self.augmentor, self.noiser = geometry_augmentor, geometry_noiser
         # ``use_raw_vertex_cache``: where ``io.vertex_cache.convert_dataset`` has left a memory-mappable copy of a frame's vertex
         # features, map it and read only the sampled rows (same selection, same values; 3 MB of page cache instead of 18 MB of
-        # zstd + pickle per sample at the reference's shape)
+        # zstd + pickle per sample at the reference's shape); likewise raw copies of the two PNGs (same pixels, no inflate)
         self.use_raw_vertex_cache = use_raw_vertex_cache
         self.cameras = list(cameras)
         self.num_vertices = num_vertices
@@ -118,8 +118,8 @@ class MindmapFrameDataset(Dataset):
 
         rgb, depth, pose, intr = [], [], [], []
         for cam in self.cameras:
-            rgb.append(D.read_png(it[f"{cam}_rgb"]))                                   # [H,W,3] u8
-            depth.append(D.read_png(it[f"{cam}_depth"]).to(torch.int16))               # u16 bit pattern, 2 B / pixel
+            rgb.append(D.read_png(it[f"{cam}_rgb"], self.use_raw_vertex_cache))                          # [H,W,3] u8
+            depth.append(D.read_png(it[f"{cam}_depth"], self.use_raw_vertex_cache).to(torch.int16))      # u16 bit pattern, 2 B / pixel
             pose.append(torch.as_tensor(np.load(it[f"{cam}_pose"])).to(torch.float32))
             intr.append(torch.as_tensor(np.load(it[f"{cam}_intrinsics"])).to(torch.float32))
         out["rgb_u8"] = torch.stack(rgb)

@@ -91,12 +91,18 @@ def write_depth_png(path: str, depth_m: torch.Tensor) -> None:
     Image.fromarray(arr).save(path)
 
 
-def read_png(path: str) -> torch.Tensor:
-    """``torch.as_tensor(imageio.imread(path))`` (dataset.py:463-465): u16 [H,W] for depth, u8 [H,W,3] for rgb."""
-    from PIL import Image
+def read_png(path: str, use_raw_cache: bool = False) -> torch.Tensor:
+    """``torch.as_tensor(imageio.imread(path))`` (dataset.py:463-465): u16 [H,W] for depth, u8 [H,W,3] for rgb.
+    ``use_raw_cache``: read ``<path>.raw`` (io/vertex_cache.py: the same pixels, no inflate) when it exists."""
+    if use_raw_cache and os.path.exists(path + ".raw"):
+        from .vertex_cache import read_raw_image
 
-    with Image.open(path) as im:
-        arr = np.array(im)
+        arr = read_raw_image(path + ".raw")
+    else:
+        from PIL import Image
+
+        with Image.open(path) as im:
+            arr = np.array(im)
     if arr.dtype == np.int32:  # PIL mode "I" for 16-bit PNGs on some versions
         arr = arr.astype(np.uint16)
     if arr.dtype == np.uint16:

@@ -71,9 +71,59 @@ def open_raw(path: str) -> Tuple[np.ndarray, np.ndarray]:
     return v, f
 
 
-def convert_dataset(dataset_path: str, overwrite: bool = False) -> int:
-    """Write the raw copy next to every ``*.nvblox_vertex_features.zst`` under ``dataset_path``; returns the number written."""
+# ---- images: the same idea for the two PNGs of a frame ------------------------------------------------------------------------
+# ``NNNN.<cam>_rgb.png`` / ``NNNN.<cam>_depth.png`` (isaaclab_utils/isaaclab_writer.py:80-109) cost ~11 ms of inflate + defilter
+# per sample at 512x512 -- after the vertex features the largest term of the loader's per-sample time.  ``<name>.png.raw``:
+#     offset 0  8 bytes magic b"MMFIMG01";  int32 H, W, C;  int32 itemsize (1: uint8, 2: uint16);  data at offset 32
+IMG_MAGIC = b"MMFIMG01"
+
+
+def write_raw_image(path: str, arr: np.ndarray) -> None:
+    a = np.ascontiguousarray(arr)
+    assert a.dtype in (np.uint8, np.uint16) and a.ndim in (2, 3)
+    H, W = a.shape[:2]
+    C = a.shape[2] if a.ndim == 3 else 0
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as fh:
+        fh.write(IMG_MAGIC + struct.pack("<iiii", H, W, C, a.dtype.itemsize) + b"\0" * 8)
+        fh.write(a.tobytes())
+    os.replace(tmp, path)
+
+
+def read_raw_image(path: str) -> np.ndarray:
+    """The pixel array of the PNG it was made from (uint8 [H,W,3] / uint16 [H,W]), as a fresh array."""
+    with open(path, "rb") as fh:
+        head = fh.read(32)
+        if len(head) < 32 or head[:8] != IMG_MAGIC:
+            raise ValueError(f"{path}: not a raw image file")
+        H, W, C, item = struct.unpack("<iiii", head[8:24])
+        if H <= 0 or W <= 0 or C not in (0, 3, 4) or item not in (1, 2):
+            raise ValueError(f"{path}: inconsistent header")
+        n = H * W * max(C, 1) * item
+        data = fh.read(n)
+    if len(data) != n:
+        raise ValueError(f"{path}: truncated")
+    a = np.frombuffer(data, dtype=np.uint8 if item == 1 else np.uint16)
+    return a.reshape((H, W, C) if C else (H, W)).copy()
+
+
+def convert_dataset(dataset_path: str, overwrite: bool = False, images: bool = True) -> int:
+    """Write the raw copy next to every ``*.nvblox_vertex_features.zst`` (and, with ``images``, next to every ``*.png``) under
+    ``dataset_path``; returns the number of files written."""
     n = 0
+    if images:
+        from PIL import Image
+
+        for png in sorted(glob.glob(os.path.join(dataset_path, "**", "*.png"), recursive=True)):
+            raw = png + ".raw"
+            if os.path.exists(raw) and not overwrite and os.path.getmtime(raw) >= os.path.getmtime(png):
+                continue
+            with Image.open(png) as im:
+                arr = np.array(im)
+            if arr.dtype == np.int32:
+                arr = arr.astype(np.uint16)
+            write_raw_image(raw, arr)
+            n += 1
     for zst in sorted(glob.glob(os.path.join(dataset_path, "**", f"*.{VERTEX_FEATURES_FILE_NAME}"), recursive=True)):
         raw = raw_path_of(zst)
         if os.path.exists(raw) and not overwrite and os.path.getmtime(raw) >= os.path.getmtime(zst):

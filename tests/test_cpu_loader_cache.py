@@ -21,7 +21,7 @@ def dataset_dir(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("cache_ds"))
     write_synthetic_demo(os.path.join(d, "demo_00000"), 5, image_size=(48, 48), feature_dim=32, vertex_count_range=(1500, 3000))
     write_synthetic_demo(os.path.join(d, "demo_00001"), 3, image_size=(48, 48), feature_dim=32, vertex_count_range=(100, 900), seed=5)
-    assert VC.convert_dataset(d) == 8 and VC.convert_dataset(d) == 0  # idempotent
+    assert VC.convert_dataset(d) == 8 + 16 and VC.convert_dataset(d) == 0  # 8 vertex files + 8 x (rgb, depth) PNGs; idempotent
     return d
 
 

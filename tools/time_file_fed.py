@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--workers", type=int, default=None)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--raw-cache", action="store_true", help="convert the demo's vertex features to the memory-mapped raw cache first")
+    ap.add_argument("--host-threads", type=int, default=0, help="torch.set_num_threads of the training process (0: leave)")
+    ap.add_argument("--prefetch", type=int, default=2)
     a = ap.parse_args()
     from torch.utils.data import DataLoader
 
@@ -37,10 +40,16 @@ def main():
         write_synthetic_demo(os.path.join(root, "demo_00000"), a.frames, image_size=cfg.image_size, feature_dim=cfg.feature_dim,
                              num_history=cfg.num_history, prediction_horizon=cfg.prediction_horizon, ngrippers=cfg.ngrippers,
                              vertex_count_range=(10000, 14000))
-        ds = MindmapFrameDataset(root, num_vertices=2048)
+        if a.raw_cache:
+            from nvblox_mindmap_amd.io import vertex_cache
+
+            vertex_cache.convert_dataset(root)
+        if a.host_threads:
+            torch.set_num_threads(a.host_threads)
+        ds = MindmapFrameDataset(root, num_vertices=2048, use_raw_vertex_cache=a.raw_cache)
         ds.samples = ds.samples * max(1, -(-3 * workers * a.batch // len(ds.samples)))
         dl = DataLoader(ds, batch_size=a.batch, shuffle=True, num_workers=workers, drop_last=True, pin_memory=True,
-                        persistent_workers=True, prefetch_factor=2)
+                        persistent_workers=True, prefetch_factor=a.prefetch)
         torch.manual_seed(0)
         model = build_model(cfg, device=dev)
         opt = build_optimizer(model)
