@@ -17,10 +17,11 @@ def convert_layer_to_dense_tensor(layer, aabb_min_m, aabb_max_m, unobserved_valu
     dims = (hi - lo + 1).tolist()
     F = blocks.shape[-1]
     dense = torch.full((dims[0] * 8, dims[1] * 8, dims[2] * 8, F), float(unobserved_value), dtype=blocks.dtype, device=blocks.device)
-    idx64 = idx.to(torch.int64).cpu()
-    for i in range(idx64.shape[0]):
-        b = idx64[i] - lo
-        if bool(((b >= 0) & (b < torch.tensor(dims))).all()):
-            x, y, z = (b * 8).tolist()
-            dense[x:x + 8, y:y + 8, z:z + 8] = blocks[i]
+    # one scatter for all blocks (a Python loop with a device slice per block was ~3 000 launches for a task's map)
+    b = idx.to(torch.int64).to(blocks.device) - lo.to(blocks.device)
+    inside = ((b >= 0) & (b < torch.tensor(dims, device=blocks.device))).all(dim=1)
+    b, kept = b[inside], blocks[inside]
+    if b.shape[0]:
+        view = dense.view(dims[0], 8, dims[1], 8, dims[2], 8, F)  # [bx, vx, by, vy, bz, vz, F]: a block is view[bx, :, by, :, bz, :]
+        view[b[:, 0], :, b[:, 1], :, b[:, 2], :, :] = kept
     return dense
