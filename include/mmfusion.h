@@ -324,7 +324,9 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
                       const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev,
                       const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev, const float* ln2_bias_dev, float ln2_eps,
                       float* out_dev, int B, int L, int D, void* stream);
-/* Matrix-core (v_mfma_f32_16x16x4_f32, exact f32) forms of the per-layer kernels, built for D = 120, H = 8 (head_dim 15):
+/* Matrix-core (v_mfma_f32_16x16x4_f32, exact f32) forms of the per-layer kernels, built for D = 120, H = 8 (head_dim 15).
+ * UNLIKE the block kernels above these take the weights AS torch.nn.Linear STORES THEM, [out, in] row-major (Wq, Wo, W1, W2
+ * [D, D]; Wkv [2 D, D]): a lane's share of an MFMA B operand is then one aligned 16-byte piece of a weight row:
  *   mmf_qkv_heads        the projections of mmf_qkv_block written head-major and padded to 16 channels:
  *                        q_heads, k_heads [B, H, L16, 16], v_heads_t [B, H, 16, L16] (L16 = L rounded up to 16; padding = 0).
  *                        roles: 7 = q | k | v, 1 = q alone (Wkv / k / v may be null), 6 = k | v alone (Wq / q may be null)

@@ -2250,8 +2250,9 @@ int mmf_debug_wg_trace(uint64_t* buffer_dev, int capacity_records) {
   if (buffer_dev && capacity_records <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_debug_wg_trace");
   const int r0 = set_wg_trace_map(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
   const int r1 = set_wg_trace_app(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
-  if (r0 == 2 || r1 == 2) return fail(MMF_ERR_INVALID_ARG, "mmf_debug_wg_trace: this library was built without the hooks (make WG_TRACE=1)");
-  if (r0 != 0 || r1 != 0) return fail(MMF_ERR_HIP, "mmf_debug_wg_trace: hipMemcpyToSymbol failed");
+  const int r2 = set_wg_trace_policy(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
+  if (r0 == 2 || r1 == 2 || r2 == 2) return fail(MMF_ERR_INVALID_ARG, "mmf_debug_wg_trace: this library was built without the hooks (make WG_TRACE=1)");
+  if (r0 != 0 || r1 != 0 || r2 != 0) return fail(MMF_ERR_HIP, "mmf_debug_wg_trace: hipMemcpyToSymbol failed");
   return MMF_OK;
 }
 

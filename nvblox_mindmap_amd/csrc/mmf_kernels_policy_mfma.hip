@@ -22,8 +22,27 @@
 //                     16-token tile, the tile moves between them through LDS (D layout -> A layout)
 #include "mmf_device.h"
 #include "mmf_launch.h"
+#include "mmf_trace_device.h"
 
 namespace mmf {
+
+// Phase marks of the instrumented build (`make WG_TRACE=1`, tools/policy_phase_trace.py): thread 0 of a workgroup stores the
+// 100 MHz wall clock at up to 8 points, behind the 6 x 8192 frame records of the trace buffer, at record (8 u64) `base` +
+// linear workgroup index.  `dep` pins the mark behind the value's producer.  Compiled out of the default build.
+#ifdef MMF_WG_TRACE
+constexpr int kPtQkv = 0, kPtAtt = 256, kPtOutFfn = 1024;
+__device__ __forceinline__ void pt_mark(int base, int i, float dep) {
+  asm volatile("" ::"v"(dep));
+  if (g_wg_trace && threadIdx.x == 0) {
+    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    const long long off = 3ll * 6 * 8192 + 8 * (base + blk) + i;
+    if (off < 3ll * g_wg_trace_cap) g_wg_trace[off] = (unsigned long long)wall_clock64();
+  }
+}
+#define MMF_PT(base, i, dep) pt_mark(base, i, dep)
+#else
+#define MMF_PT(base, i, dep)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -36,30 +55,52 @@ constexpr int kKSteps = 32;                 // 8 x 4 reduction steps cover 128 >
 // guarded load compiles to a branch plus register copies, and these kernels run once through straight-line code fetched
 // through a cold instruction cache -- their duration follows their code size.
 
+// Loads are written REQUEST FIRST, USE LATER: the compiler keeps the program order of loads and puts a wait in front of the
+// first use, and waits count in issue order -- a select on a loaded value between two groups of loads makes the second group a
+// second round trip (1.1 us here: the first touch of a kernel goes to HBM), and a value requested late but used early drags
+// every earlier request into its wait.  So: every kernel issues its loads in the order of their first use, all of them before
+// the first use of any.
+
+// Offset of the 16-byte piece of reduction steps 4 m .. 4 m + 3 in a 120-float row: 16 m + 4 s; the pieces of m = 7, s >= 2
+// lie beyond D (their A values are zero) and are read from 112 + 4 (s & 1) instead.  (Written as arithmetic: from
+// `min(c0, D - 4)` the compiler builds a two-way select of loaded vectors that it indexes through scratch memory.)
+__device__ __forceinline__ int piece_offset(int m, int s) { return 16 * m + 4 * (m < 7 ? s : (s & 1)); }
+
 // A-operand share of one token row: a[4 m + kk] = row[16 m + 4 s + kk] (0 beyond D, 0 if !ok; `row` must be readable)
-__device__ __forceinline__ void load_row_share(const float* __restrict__ row, int s, bool ok, float (&a)[kKSteps]) {
+struct RowRaw {
+  float4 v[8];
+};
+__device__ __forceinline__ RowRaw load_row_raw(const float* __restrict__ row, int s) {
+  RowRaw R;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const int c0 = 16 * m + 4 * s;
-    const float4 v = *reinterpret_cast<const float4*>(row + (m < 7 ? c0 : min(c0, kD - 4)));
-    const bool keep = ok && (m < 7 || c0 < kD);
-    a[4 * m] = keep ? v.x : 0.0f;
-    a[4 * m + 1] = keep ? v.y : 0.0f;
-    a[4 * m + 2] = keep ? v.z : 0.0f;
-    a[4 * m + 3] = keep ? v.w : 0.0f;
+    R.v[m] = *reinterpret_cast<const float4*>(row + piece_offset(m, s));
+  }
+  return R;
+}
+__device__ __forceinline__ void row_share(const RowRaw& R, int s, bool ok, float (&a)[kKSteps]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const bool keep = ok && (m < 7 || 16 * m + 4 * s < kD);
+    a[4 * m] = keep ? R.v[m].x : 0.0f;
+    a[4 * m + 1] = keep ? R.v[m].y : 0.0f;
+    a[4 * m + 2] = keep ? R.v[m].z : 0.0f;
+    a[4 * m + 3] = keep ? R.v[m].w : 0.0f;
   }
 }
 
-// B-operand share of one output column: w[4 m + kk] = Wt[(16 m + 4 s + kk) * ld + col] (Wt = transposed weights [in, out];
-// `col` must be a valid column; rows beyond D are read from row D - 1: their A values are zero)
-__device__ __forceinline__ void load_col_share(const float* __restrict__ Wt, int ld, int col, int s, float (&w)[kKSteps]) {
+// B-operand share of one output column: w[4 m + kk] = W[col][16 m + 4 s + kk] -- W = the Linear's own [out, in] weight matrix,
+// so a lane's share of a reduction step is ONE aligned 16-byte piece (the transposed [in, out] layout needs four 4-byte loads
+// for it: 64 instead of 16 load instructions per wave and tile, and the load unit's issue rate, not the latency, set the
+// time to the first MFMA).  `col` must be a valid row of W; pieces beyond D are read from the row's last 16 bytes: their A
+// values are zero.
+__device__ __forceinline__ void load_col_share(const float* __restrict__ W, int col, int s, float (&w)[kKSteps]) {
+  const float* row = W + (size_t)col * kD;
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = 16 * m + 4 * s + kk;
-      w[4 * m + kk] = Wt[(size_t)(m < 7 ? c : min(c, kD - 1)) * ld + col];
-    }
+  for (int m = 0; m < 8; ++m) {
+    const float4 v = *reinterpret_cast<const float4*>(row + piece_offset(m, s));
+    w[4 * m] = v.x, w[4 * m + 1] = v.y, w[4 * m + 2] = v.z, w[4 * m + 3] = v.w;
+  }
 }
 
 __device__ __forceinline__ f32x4 tile_gemm(const float (&a)[kKSteps], const float (&w)[kKSteps]) {
@@ -75,62 +116,88 @@ __device__ __forceinline__ f32x4 tile_gemm(const float (&a)[kKSteps], const floa
 
 // ---- q | k | v projections, rotary, head-major outputs ---------------------------------------------------------------------
 struct QkvArgs {
-  const float *ss, *WqT, *bq, *WkvT, *bkv, *cs, *sn;  // ss: AdaLN (scale | shift) [B, 2 D] of the query input or null; cs / sn [B, L, D] or null
+  const float *ss, *Wq, *bq, *Wkv, *bkv, *cs, *sn;  // Wq [D, D], Wkv [2 D, D]: the Linears' [out, in] weights; ss: AdaLN (scale | shift) [B, 2 D] of the query input or null; cs / sn [B, L, D] or null
   float *Qp, *Kp, *Vt;
 };
 
-// AdaLN modulation of an A-operand share (token of batch element b)
-__device__ __forceinline__ void modulate_share(const float* __restrict__ ss, int b, int s, float (&a)[kKSteps]) {
-  const float* sc = ss + (size_t)b * 2 * kD;
+// AdaLN modulation of an A-operand share: a <- a (1 + scale) + shift with the lane's pieces of (scale | shift) [2 D]
+struct ModRaw {
+  float4 g[8], h[8];
+};
+__device__ __forceinline__ ModRaw load_mod_raw(const float* __restrict__ sc, int s) {  // sc: 2 D readable floats
+  ModRaw M;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const int c0 = 16 * m + 4 * s;
-    if (c0 < kD) {
-      const float4 g = *reinterpret_cast<const float4*>(sc + c0), h = *reinterpret_cast<const float4*>(sc + kD + c0);
-      a[4 * m] = a[4 * m] * (1.0f + g.x) + h.x;
-      a[4 * m + 1] = a[4 * m + 1] * (1.0f + g.y) + h.y;
-      a[4 * m + 2] = a[4 * m + 2] * (1.0f + g.z) + h.z;
-      a[4 * m + 3] = a[4 * m + 3] * (1.0f + g.w) + h.w;
-    }
+    const int c0 = piece_offset(m, s);
+    M.g[m] = *reinterpret_cast<const float4*>(sc + c0);
+    M.h[m] = *reinterpret_cast<const float4*>(sc + kD + c0);
+  }
+  return M;
+}
+__device__ __forceinline__ void modulate_share(const ModRaw& M, int s, bool apply, float (&a)[kKSteps]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const bool ap = apply && (m < 7 || 16 * m + 4 * s < kD);  // pieces beyond D stay zero
+    a[4 * m] = ap ? a[4 * m] * (1.0f + M.g[m].x) + M.h[m].x : a[4 * m];
+    a[4 * m + 1] = ap ? a[4 * m + 1] * (1.0f + M.g[m].y) + M.h[m].y : a[4 * m + 1];
+    a[4 * m + 2] = ap ? a[4 * m + 2] * (1.0f + M.g[m].z) + M.h[m].z : a[4 * m + 2];
+    a[4 * m + 3] = ap ? a[4 * m + 3] * (1.0f + M.g[m].w) + M.h[m].w : a[4 * m + 3];
   }
 }
 
 // One role (0 = q, 1 = k, 2 = v) of a 16-token tile (batch element b, first token l0) for the wave's two heads 2 w, 2 w + 1
 // (30 channels: rotary pairs never leave the wave); `a` = the wave's A-operand share of the (modulated / raw) input rows.
-__device__ __forceinline__ void qkv_role_tile(const float (&a)[kKSteps], int role, const QkvArgs& Q, int b, int l0, int L, int L16, int w,
-                                              int j, int s) {
-  const float* Wt = role == 0 ? Q.WqT : Q.WkvT;
-  const int ld = role == 0 ? kD : 2 * kD, off = role == 2 ? kD : 0;
-  const float* bias = role == 0 ? Q.bq : Q.bkv + off;
-
-  // epilogue operands are fetched up front: their latency hides behind the weight loads and the GEMM.  Lanes of the padding
-  // column (j = 15) and of rows beyond L compute on clamped addresses; their results are zeroed at the store.
-  const bool rotary = role < 2 && Q.cs != nullptr;
-  const int jc = min(j, kDH - 1);
+// Lanes of the padding column (j = 15) and of rows beyond L compute on clamped addresses; their results are zeroed at the store.
+// ROLE / ROT (rotary tables present) / MOD (AdaLN on the query input) are TEMPLATE parameters and the kernels branch ONCE, at
+// the top, into a straight-line body: a run-time condition around a group of loads makes the compiler split the request
+// sequence at the branch, wait there, and start a second round trip behind it.
+struct QkvOps {  // the role's operands: weights of the two heads' columns, bias, rotary cos / sin of the lane's outputs
+  float wv[2][kKSteps];
   float bb[2], cv[2][4], sv[2][4];
+};
+template <int ROLE>
+__device__ __forceinline__ const float* qkv_role_weights(const QkvArgs& Q) {
+  return ROLE == 0 ? Q.Wq : Q.Wkv + (ROLE == 2 ? (size_t)kD * kD : 0);  // the value projection: rows D .. 2 D - 1 of Wkv
+}
+template <int ROLE, bool ROT>
+__device__ __forceinline__ void qkv_role_loads(const QkvArgs& Q, int b, int l0, int L, int w, int j, int s, QkvOps& O) {
+  const float* W = qkv_role_weights<ROLE>(Q);
+  const float* bias = ROLE == 0 ? Q.bq : Q.bkv + (ROLE == 2 ? kD : 0);
+  const int jc = min(j, kDH - 1);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(W, kDH * (2 * w + n) + jc, s, O.wv[n]);
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = kDH * (2 * w + n) + jc;
-    bb[n] = bias[col];
-    if (rotary) {
+    O.bb[n] = bias[col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {
+      if (ROLE < 2 && ROT) {
         const size_t e = ((size_t)b * L + min(l0 + 4 * s + r, L - 1)) * kD + col;
-        cv[n][r] = Q.cs[e];
-        sv[n][r] = Q.sn[e];
+        O.cv[n][r] = Q.cs[e];
+        O.sv[n][r] = Q.sn[e];
+      } else {
+        O.cv[n][r] = 1.0f;
+        O.sv[n][r] = 0.0f;
       }
     }
   }
+}
+
+template <int ROLE, bool ROT>
+__device__ __forceinline__ void qkv_role_compute(const float (&a)[kKSteps], const QkvOps& O, const QkvArgs& Q, int b, int l0, int L,
+                                                 int L16, int w, int j, int s) {
+  MMF_PT(kPtQkv, 2, O.wv[0][31]);
   f32x4 y[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    float wv[kKSteps];
-    load_col_share(Wt + off, ld, kDH * (2 * w + n) + jc, s, wv);
-    y[n] = tile_gemm(a, wv);
-    y[n] += bb[n];
+    y[n] = tile_gemm(a, O.wv[n]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[n][r] += O.bb[n];  // (element by element: `vector += scalar` keeps the operand block in scratch)
   }
+  MMF_PT(kPtQkv, 3, y[1][0]);
 
-  if (rotary) {
+  if (ROLE < 2 && ROT) {
     // rotary over the 120-vector: out[c] = y[c] cos[c] + (c odd ? y[c-1] : -y[c+1]) sin[c].  Within the wave's 30 channels
     // p = 15 n + j the partner is p ^ 1, held by lane (s, j') of tile n'.
     f32x4 part[2];
@@ -149,7 +216,7 @@ __device__ __forceinline__ void qkv_role_tile(const float (&a)[kKSteps], int rol
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) y[n][r] = y[n][r] * cv[n][r] + part[n][r] * sv[n][r];
+      for (int r = 0; r < 4; ++r) y[n][r] = y[n][r] * O.cv[n][r] + part[n][r] * O.sv[n][r];
   }
 
 #pragma unroll
@@ -158,28 +225,85 @@ __device__ __forceinline__ void qkv_role_tile(const float (&a)[kKSteps], int rol
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = (j < kDH && l0 + 4 * s + r < L) ? y[n][r] : 0.0f;  // padding stays finite (zero)
-    if (role == 2) {
+    if (ROLE == 2) {
       *reinterpret_cast<f32x4*>(Q.Vt + (((size_t)b * kH + h) * 16 + j) * L16 + l0 + 4 * s) = o;
     } else {
-      float* P = (role == 0 ? Q.Qp : Q.Kp) + (((size_t)b * kH + h) * L16 + l0 + 4 * s) * 16 + j;
+      float* P = (ROLE == 0 ? Q.Qp : Q.Kp) + (((size_t)b * kH + h) * L16 + l0 + 4 * s) * 16 + j;
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[r * 16] = o[r];
     }
   }
 }
 
-// grid (B * L16 / 16, roles), 256 threads
-__global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, QkvArgs Q, int L, int L16, int role0) {
+// a role on an A-operand share that is already in registers (the tile of k_out_ffn_qkv); MOD: modulate it first (in place)
+template <int ROLE, bool ROT, bool MOD>
+__device__ __forceinline__ void qkv_role_tile(float (&a)[kKSteps], const QkvArgs& Q, int b, int l0, int L, int L16, int w, int j, int s) {
+  QkvOps O;
+  qkv_role_loads<ROLE, ROT>(Q, b, l0, L, w, j, s, O);
+  if (MOD) {
+    const ModRaw M = load_mod_raw(Q.ss + (size_t)b * 2 * kD, s);
+    __builtin_amdgcn_sched_barrier(0);
+    modulate_share(M, s, l0 + j < L, a);
+  } else {
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  qkv_role_compute<ROLE, ROT>(a, O, Q, b, l0, L, L16, w, j, s);
+}
+
+// One (tile, role) of k_qkv_heads / k_qkv_heads2: every load is requested before the first use (weights first: the largest)
+template <int ROLE, bool ROT, bool MOD>
+__device__ __forceinline__ void qkv_heads_tile(const float* __restrict__ x, const QkvArgs& Q, int L, int L16) {
   const int tpb = L16 / 16;
   const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
-  const int role = role0 + (int)blockIdx.y;  // 0 = q, 1 = k, 2 = v
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
-  float a[kKSteps];
   const int tok = l0 + j;
   const bool ok = tok < L;
-  load_row_share(x + ((size_t)b * L + min(tok, L - 1)) * kD, s, ok, a);
-  if (role == 0 && Q.ss != nullptr && ok) modulate_share(Q.ss, b, s, a);  // AdaLN modulation of the query input
-  qkv_role_tile(a, role, Q, b, l0, L, L16, w, j, s);
+  MMF_PT(kPtQkv, 0, 0.0f);
+  QkvOps O;
+  qkv_role_loads<ROLE, ROT>(Q, b, l0, L, w, j, s, O);
+  const RowRaw R = load_row_raw(x + ((size_t)b * L + min(tok, L - 1)) * kD, s);
+  float a[kKSteps];
+  if (MOD) {  // AdaLN modulation of the query input
+    const ModRaw M = load_mod_raw(Q.ss + (size_t)b * 2 * kD, s);
+    __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks each load to its use: one round trip per MFMA group
+    row_share(R, s, ok, a);
+    modulate_share(M, s, ok, a);
+  } else {
+    __builtin_amdgcn_sched_barrier(0);
+    row_share(R, s, ok, a);
+  }
+  MMF_PT(kPtQkv, 1, a[31]);
+  qkv_role_compute<ROLE, ROT>(a, O, Q, b, l0, L, L16, w, j, s);
+  MMF_PT(kPtQkv, 4, 0.0f);
+}
+
+__device__ __forceinline__ void qkv_heads_body(const float* __restrict__ x, const QkvArgs& Q, int L, int L16, int role) {
+  const bool rot = Q.cs != nullptr, mod = Q.ss != nullptr;
+  if (role == 0) {
+    if (rot) {
+      if (mod)
+        qkv_heads_tile<0, true, true>(x, Q, L, L16);
+      else
+        qkv_heads_tile<0, true, false>(x, Q, L, L16);
+    } else {
+      if (mod)
+        qkv_heads_tile<0, false, true>(x, Q, L, L16);
+      else
+        qkv_heads_tile<0, false, false>(x, Q, L, L16);
+    }
+  } else if (role == 1) {
+    if (rot)
+      qkv_heads_tile<1, true, false>(x, Q, L, L16);
+    else
+      qkv_heads_tile<1, false, false>(x, Q, L, L16);
+  } else {
+    qkv_heads_tile<2, false, false>(x, Q, L, L16);
+  }
+}
+
+// grid (B * L16 / 16, roles), 256 threads
+__global__ __launch_bounds__(256) void k_qkv_heads(const float* __restrict__ x, QkvArgs Q, int L, int L16, int role0) {
+  qkv_heads_body(x, Q, L, L16, role0 + (int)blockIdx.y);  // 0 = q, 1 = k, 2 = v
 }
 
 // ---- attention over head-major operands -------------------------------------------------------------------------------------
@@ -204,6 +328,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
   const size_t bh = (size_t)b * kH + h;
 
+  MMF_PT(kPtAtt, 0, 0.0f);
   float q[4];
   {
     const float4 v = *reinterpret_cast<const float4*>(Qp + (bh * Lq16 + q0 + j) * 16 + 4 * s);
@@ -230,6 +355,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
       if (pb) word = *reinterpret_cast<const uint32_t*>(pb + tc * 16 + 4 * s);
       pw[i] = t < ntiles ? word : 0xffffffffu;
     }
+    MMF_PT(kPtAtt, 1, kv[CH - 1].x + vv[CH - 1].x + q[0]);
     f32x4 S[CH];
     float cmax = -INFINITY;
 #pragma unroll
@@ -251,6 +377,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
     }
     cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+    MMF_PT(kPtAtt, 2, cmax);
     const float m_new = fmaxf(m_run, cmax);
     const float corr = (m_run == -INFINITY) ? 0.0f : __expf(m_run - m_new);
     l_run *= corr;
@@ -278,6 +405,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
     }
     m_run = m_new;
   }
+  MMF_PT(kPtAtt, 3, O0[0] + O1[0]);
   // merge the four key ranges
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -289,6 +417,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
 #pragma unroll
   for (int r = 0; r < 4; ++r) sO[w][4 * s + r][j] = O[r];
   __syncthreads();
+  MMF_PT(kPtAtt, 4, 0.0f);
   if (w == 0) {
     float M = sM[0][j];
 #pragma unroll
@@ -317,39 +446,46 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
       part[17 * 16 + j] = l;
     }
   }
+  MMF_PT(kPtAtt, 5, 0.0f);
 }
 
 // ---- out_proj + LayerNorm + feed-forward block -----------------------------------------------------------------------------
 constexpr int kRS = 132;  // LDS row stride of a 16-token tile (floats)
 
-// LayerNorm of the 16 x 120 tile in `src` (wave w: tokens 4 w .. 4 w + 3, 16 lanes per token, channels q + 16 i per lane);
-// gamma / beta / (scale, shift) of the lane's 8 channels arrive in registers (fetched at kernel start).  The result
-// (optionally AdaLN-modulated) goes to `dst` (LDS) and / or `gout` (global, row stride D)
+// LayerNorm of the 16 x 120 tile in `src` (wave w: tokens 4 w .. 4 w + 3, 16 lanes per token; lane q < 15 owns the 8 adjacent
+// channels 8 q .. 8 q + 7, lane 15 idles): every operand of a lane -- gamma / beta / (scale, shift) / the residual row, fetched
+// at kernel start -- and its LDS traffic are 16-byte pieces.  `add`: a second summand per channel (the residual input, or
+// zeros).  The result (optionally AdaLN-modulated) goes to `dst` (LDS) and / or `gout` (global, row stride D)
 struct LnShare {
   float g[8], b[8];
 };
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&v)[8]) {
+  const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+}
 __device__ __forceinline__ LnShare load_ln_share(const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
   LnShare P;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = min(q + 16 * i, kD - 1);  // lanes q >= 8 hold no channel for i = 7: the value is not used
-    P.g[i] = gamma[c];
-    P.b[i] = beta[c];
-  }
+  const int c0 = 8 * min(q, 14);  // lane 15 reads lane 14's pieces: the values are not used
+  load8(gamma + c0, P.g);
+  load8(beta + c0, P.b);
   return P;
 }
 
 __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (*dst)[kRS], float* __restrict__ gout, long long t0,
                                                 long long tokens, const LnShare& P, float eps, bool modulate, const float (&sc)[8],
-                                                const float (&sh)[8], int lane, int w) {
+                                                const float (&sh)[8], const float (&add)[8], int lane, int w) {
   const int tl = 4 * w + (lane >> 4), q = lane & 15;
+  const bool own = q < 15;
+  const int c0 = 8 * min(q, 14);
   float v[8];
+  {
+    const float4 lo = *reinterpret_cast<const float4*>(&src[tl][c0]), hi = *reinterpret_cast<const float4*>(&src[tl][c0 + 4]);
+    v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+  }
   float sum = 0.0f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = q + 16 * i;
-    const float x = src[tl][c];
-    v[i] = (i < 7 || c < kD) ? x : 0.0f;
+    v[i] = own ? v[i] + add[i] : 0.0f;
     sum += v[i];
   }
 #pragma unroll
@@ -358,8 +494,7 @@ __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (
   float var = 0.0f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = q + 16 * i;
-    const float d = (i < 7 || c < kD) ? v[i] - mean : 0.0f;
+    const float d = own ? v[i] - mean : 0.0f;
     v[i] = d;
     var += d * d;
   }
@@ -367,14 +502,21 @@ __device__ __forceinline__ void tile_layer_norm(const float (*src)[kRS], float (
   for (int off = 8; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
   const float inv = rsqrtf(var / (float)kD + eps);
   const long long tok = t0 + tl;
-  const bool live = tok < tokens;
+  float o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = q + 16 * i;
-    float o = v[i] * inv * P.g[i] + P.b[i];
-    if (modulate) o = o * (1.0f + sc[i]) + sh[i];
-    if (dst) dst[tl][c] = o;  // columns 120 .. 127 of the LDS tile exist and are never read
-    if (gout && live && (i < 7 || c < kD)) gout[tok * kD + c] = o;
+    o[i] = v[i] * inv * P.g[i] + P.b[i];
+    if (modulate) o[i] = o[i] * (1.0f + sc[i]) + sh[i];
+  }
+  if (own) {
+    if (dst) {
+      *reinterpret_cast<float4*>(&dst[tl][c0]) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(&dst[tl][c0 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (gout && tok < tokens) {
+      *reinterpret_cast<float4*>(gout + tok * kD + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(gout + tok * kD + c0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
   }
 }
 
@@ -397,7 +539,7 @@ struct AttPartials {  // k_attention_heads<.., SPLIT > 1> output to merge instea
 };
 
 struct OutFfnArgs {
-  const float *att, *res, *WoT, *bo, *g1, *be1, *ss, *W1T, *b1, *W2T, *b2, *g2, *be2;  // ss: AdaLN (scale | shift) of the FFN or null
+  const float *att, *res, *Wo, *bo, *g1, *be1, *ss, *W1, *b1, *W2, *b2, *g2, *be2;  // ss: AdaLN (scale | shift) of the FFN or null
   float eps1, eps2;
   float* out;
 };
@@ -408,7 +550,45 @@ struct OutFfnArgs {
 __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, long long tokens, int L, float (*sH)[kRS], float (*sU)[kRS],
                                              float (*sY)[kRS], float (*keep)[kRS], int lane, int w, int j, int s,
                                              const AttPartials& AP = AttPartials{nullptr, 0, 0}) {
-  float a[kKSteps], wv[2][kKSteps];
+  MMF_PT(kPtOutFfn, 0, 0.0f);
+  // Requests in the order of first use (see the note at load_row_raw), all before the first use: out_proj weights and the input
+  // rows | LayerNorm 1 operands | fc1 weights | fc2 weights | LayerNorm 2 operands.  The wave runs alone on its SIMD: 192
+  // registers of weights are free, and nothing but LDS traffic and MFMAs sits between the barriers below.
+  // (Output columns 120 .. 127 -- the last 8 lanes of wave 3's second tile -- compute on row 119's operands; their results land
+  // in LDS columns that are never read.)
+  const int colc[2] = {min(32 * w + j, kD - 1), min(32 * w + 16 + j, kD - 1)};
+  float wo[2][kKSteps], w1[2][kKSteps], w2[2][kKSteps];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(A.Wo, colc[n], s, wo[n]);
+  const long long atok = t0 + j;
+  RowRaw R;
+  if (AP.part == nullptr) R = load_row_raw(A.att + min(atok, tokens - 1) * kD, s);
+  float bbo[2], bb1[2], bb2[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bbo[n] = A.bo[colc[n]];
+  const int ln_q = lane & 15, ln_c0 = 8 * min(ln_q, 14);
+  const LnShare P1 = load_ln_share(A.g1, A.be1, ln_q);
+  float sc[8], sh[8], rs[8];
+  const float zero8[8] = {};
+  const long long ltok = t0 + 4 * w + (lane >> 4), ltokc = min(ltok, tokens - 1);
+  load8(A.res + ltokc * kD + ln_c0, rs);  // the residual row of this lane's LayerNorm token
+  {
+    const float* sp = A.ss != nullptr ? A.ss + (size_t)((int)ltokc / L) * 2 * kD : A.g1;  // (no AdaLN: any readable floats, zeroed below)
+    load8(sp + ln_c0, sc);
+    load8(sp + (A.ss != nullptr ? kD : 0) + ln_c0, sh);
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(A.W1, colc[n], s, w1[n]);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bb1[n] = A.b1[colc[n]];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) load_col_share(A.W2, colc[n], s, w2[n]);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bb2[n] = A.b2[colc[n]];
+  const LnShare P2 = load_ln_share(A.g2, A.be2, ln_q);
+  __builtin_amdgcn_sched_barrier(0);  // every request above is issued before anything below (the scheduler sinks loads to uses)
+
+  float a[kKSteps];
   if (AP.part != nullptr) {
     // the attention output of this tile, merged from the key splits: element (token, channel c = 15 h + ch) =
     // sum_sp e^(m_sp - M) O_sp[ch][row] / sum_sp e^(m_sp - M) l_sp, M = max_sp m_sp
@@ -436,79 +616,52 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     lds_row_share(sU, j, s, a);
     __syncthreads();  // sU is reused below
   } else {
-    const long long tok = t0 + j;
-    load_row_share(A.att + min(tok, tokens - 1) * kD, s, tok < tokens, a);
+    row_share(R, s, atok < tokens, a);
   }
-  // output columns 120 .. 127 (the last 8 lanes of wave 3's second tile) compute on column 119's operands; their results
-  // land in LDS columns that are never read
-  const int colc[2] = {min(32 * w + j, kD - 1), min(32 * w + 16 + j, kD - 1)};
 #pragma unroll
-  for (int n = 0; n < 2; ++n) load_col_share(A.WoT, kD, colc[n], s, wv[n]);
-  // every small operand of the later stages is fetched now: nothing but LDS traffic and MFMAs between the barriers below
-  float bbo[2], bb1[2], bb2[2], rs[2][4];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    bbo[n] = A.bo[colc[n]];
-    bb1[n] = A.b1[colc[n]];
-    bb2[n] = A.b2[colc[n]];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long tok = t0 + 4 * s + r;
-      const float v = A.res[min(tok, tokens - 1) * kD + colc[n]];
-      rs[n][r] = tok < tokens ? v : 0.0f;
-    }
-  }
-  const int ln_q = lane & 15;
-  const LnShare P1 = load_ln_share(A.g1, A.be1, ln_q), P2 = load_ln_share(A.g2, A.be2, ln_q);
-  float sc[8] = {}, sh[8] = {};
-  {
-    const long long tok = min(t0 + 4 * w + (lane >> 4), tokens - 1);
-    if (A.ss != nullptr) {
-      const float* sp = A.ss + (size_t)(tok / L) * 2 * kD;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = min(ln_q + 16 * i, kD - 1);
-        sc[i] = sp[c];
-        sh[i] = sp[kD + c];
-      }
-    }
+  for (int i = 0; i < 8; ++i) {
+    if (ltok >= tokens) rs[i] = 0.0f;
+    if (A.ss == nullptr) sc[i] = 0.0f, sh[i] = 0.0f;  // x (1 + 0) + 0 = x exactly
   }
   // ---- x1 = LN1(res + out_proj(att)), h = modulate(x1)
+  MMF_PT(kPtOutFfn, 1, a[31] + wo[1][31]);
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
-    const f32x4 y = tile_gemm(a, wv[n]);
+    const f32x4 y = tile_gemm(a, wo[n]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = y[r] + bbo[n] + rs[n][r];
+    for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = y[r] + bbo[n];
+    if (n == 1) MMF_PT(kPtOutFfn, 2, y[0]);
   }
-#pragma unroll
-  for (int n = 0; n < 2; ++n) load_col_share(A.W1T, kD, colc[n], s, wv[n]);  // in flight over the LN
   __syncthreads();
-  tile_layer_norm(sY, sH, nullptr, t0, tokens, P1, A.eps1, A.ss != nullptr, sc, sh, lane, w);
+  tile_layer_norm(sY, sH, nullptr, t0, tokens, P1, A.eps1, true, sc, sh, rs, lane, w);
   __syncthreads();
   // ---- u = relu(fc1(h))
   lds_row_share(sH, j, s, a);
+  MMF_PT(kPtOutFfn, 3, a[31] + w1[1][31]);
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
-    const f32x4 y = tile_gemm(a, wv[n]);
+    const f32x4 y = tile_gemm(a, w1[n]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) sU[4 * s + r][col] = fmaxf(y[r] + bb1[n], 0.0f);
+    if (n == 1) MMF_PT(kPtOutFfn, 4, y[0]);
   }
-#pragma unroll
-  for (int n = 0; n < 2; ++n) load_col_share(A.W2T, kD, colc[n], s, wv[n]);
   __syncthreads();
   // ---- out = LN2(h + fc2(u))
   lds_row_share(sU, j, s, a);
+  MMF_PT(kPtOutFfn, 5, a[31] + w2[1][31]);
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = 32 * w + 16 * n + j;
-    const f32x4 y = tile_gemm(a, wv[n]);
+    const f32x4 y = tile_gemm(a, w2[n]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) sY[4 * s + r][col] = sH[4 * s + r][col] + (y[r] + bb2[n]);
+    if (n == 1) MMF_PT(kPtOutFfn, 6, y[0]);
   }
   __syncthreads();  // also: every read of sH / sU above is done, `keep` may alias them
-  tile_layer_norm(sY, keep, A.out, t0, tokens, P2, A.eps2, false, sc, sh, lane, w);
+  tile_layer_norm(sY, keep, A.out, t0, tokens, P2, A.eps2, false, sc, sh, zero8, lane, w);
+  MMF_PT(kPtOutFfn, 7, 0.0f);
 }
 
 // grid = 16-token tiles of the flattened [B L] token axis
@@ -523,18 +676,6 @@ __global__ __launch_bounds__(256) void k_out_ffn_mfma(OutFfnArgs A, int L, long 
 // Two independent stacks of identical shape (the rotation and the position stack of the diffusion head) in ONE launch:
 // blockIdx.z / the upper half of blockIdx.x selects the stack's operands.  Activations and head-major outputs are stack-major
 // ([2, B, ...]), so the attention kernel sees the pair as a batch of 2 B.
-__device__ __forceinline__ void qkv_heads_body(const float* __restrict__ x, const QkvArgs& Q, int L, int L16, int role) {
-  const int tpb = L16 / 16;
-  const int b = (int)blockIdx.x / tpb, l0 = ((int)blockIdx.x % tpb) * 16;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
-  float a[kKSteps];
-  const int tok = l0 + j;
-  const bool ok = tok < L;
-  load_row_share(x + ((size_t)b * L + min(tok, L - 1)) * kD, s, ok, a);
-  if (role == 0 && Q.ss != nullptr && ok) modulate_share(Q.ss, b, s, a);
-  qkv_role_tile(a, role, Q, b, l0, L, L16, w, j, s);
-}
-
 // (The stack's argument block is chosen by a BRANCH around two calls, not by `second ? Q1 : Q0`: a reference picked at run
 // time makes the compiler copy the 168-byte block to scratch memory and read every pointer back from there.)
 __global__ __launch_bounds__(256) void k_qkv_heads2(const float* __restrict__ x0, const float* __restrict__ x1, QkvArgs Q0, QkvArgs Q1,
@@ -578,28 +719,44 @@ __global__ __launch_bounds__(256) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, in
 #pragma unroll
     for (int i = 0; i < kKSteps; ++i) a[i] = 0.0f;
   }
-  if (roles & 2) qkv_role_tile(a, 1, Q, b, l0, L, L16, w, j, s);
-  if (roles & 4) qkv_role_tile(a, 2, Q, b, l0, L, L16, w, j, s);
-  if (roles & 1) {
-    if (Q.ss != nullptr && l0 + j < L) modulate_share(Q.ss, b, s, a);
-    qkv_role_tile(a, 0, Q, b, l0, L, L16, w, j, s);
+  const bool rot = Q.cs != nullptr, mod = Q.ss != nullptr;
+  if (rot) {
+    if (roles & 2) qkv_role_tile<1, true, false>(a, Q, b, l0, L, L16, w, j, s);
+    if (roles & 4) qkv_role_tile<2, false, false>(a, Q, b, l0, L, L16, w, j, s);
+    if (roles & 1) {
+      if (mod)
+        qkv_role_tile<0, true, true>(a, Q, b, l0, L, L16, w, j, s);
+      else
+        qkv_role_tile<0, true, false>(a, Q, b, l0, L, L16, w, j, s);
+    }
+  } else {
+    if (roles & 2) qkv_role_tile<1, false, false>(a, Q, b, l0, L, L16, w, j, s);
+    if (roles & 4) qkv_role_tile<2, false, false>(a, Q, b, l0, L, L16, w, j, s);
+    if (roles & 1) {
+      if (mod)
+        qkv_role_tile<0, false, true>(a, Q, b, l0, L, L16, w, j, s);
+      else
+        qkv_role_tile<0, false, false>(a, Q, b, l0, L, L16, w, j, s);
+    }
   }
 }
 
+MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_policy)
+
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
-int launch_qkv_heads(const float* x, const float* ss, const float* WqT, const float* bq, const float* WkvT, const float* bkv,
+int launch_qkv_heads(const float* x, const float* ss, const float* Wq, const float* bq, const float* Wkv, const float* bkv,
                      const float* cs, const float* sn, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H, int roles,
                      hipStream_t s) {
   if (D != kD || H != kH) return 1;
   const int L16 = (L + 15) / 16 * 16;
   // roles: 7 = q | k | v (self-attention), 1 = q alone, 6 = k | v alone (a memory whose keys / values are cached)
   const int role0 = (roles & 1) ? 0 : 1, nroles = roles == 7 ? 3 : (roles == 1 ? 1 : 2);
-  QkvArgs Q{ss, WqT, bq, WkvT, bkv, cs, sn, Qp, Kp, Vt};
+  QkvArgs Q{ss, Wq, bq, Wkv, bkv, cs, sn, Qp, Kp, Vt};
   hipLaunchKernelGGL(k_qkv_heads, dim3(B * (L16 / 16), nroles), dim3(256), 0, s, x, Q, L, L16, role0);
   return 0;
 }
 
-// q14: {ss, WqT, bq, WkvT, bkv, cs, sn} of stack 0 then of stack 1; Qp / Kp / Vt: stack-major [2, B, H, ...] outputs
+// q14: {ss, Wq, bq, Wkv, bkv, cs, sn} of stack 0 then of stack 1; Qp / Kp / Vt: stack-major [2, B, H, ...] outputs
 int launch_qkv_heads2(const float* x0, const float* x1, const float* const* q14, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H,
                       hipStream_t s) {
   if (D != kD || H != kH) return 1;
@@ -646,29 +803,29 @@ int launch_attention_heads_split(const float* Qp, const float* Kp, const float* 
   return kAttSplit << 8;  // (number of splits << 8): the caller sizes / passes on the partial buffer with it
 }
 
-int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, const float* bo, const float* g1, const float* be1,
-                        float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T, const float* b2,
+int launch_out_ffn_mfma(const float* att, const float* res, const float* Wo, const float* bo, const float* g1, const float* be1,
+                        float eps1, const float* ss, const float* W1, const float* b1, const float* W2, const float* b2,
                         const float* g2, const float* be2, float eps2, float* out, int B, int L, int D, hipStream_t s) {
   if (D != kD) return 1;
   const long long tokens = (long long)B * L;
-  OutFfnArgs A{att, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2, eps1, eps2, out};
+  OutFfnArgs A{att, res, Wo, bo, g1, be1, ss, W1, b1, W2, b2, g2, be2, eps1, eps2, out};
   hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, A, L, tokens, AttPartials{nullptr, 0, 0});
   return 0;
 }
 
 // the same with the attention output given as the key-split partials of launch_attention_heads_split (L = Lq <= 16)
-int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float* res, const float* WoT, const float* bo, const float* g1,
-                                 const float* be1, float eps1, const float* ss, const float* W1T, const float* b1, const float* W2T,
+int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float* res, const float* Wo, const float* bo, const float* g1,
+                                 const float* be1, float eps1, const float* ss, const float* W1, const float* b1, const float* W2,
                                  const float* b2, const float* g2, const float* be2, float eps2, float* out, int B, int L, int D,
                                  hipStream_t s) {
   if (D != kD || L > 16 || n_split < 1) return 1;
   const long long tokens = (long long)B * L;
-  OutFfnArgs A{partials, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2, eps1, eps2, out};
+  OutFfnArgs A{partials, res, Wo, bo, g1, be1, ss, W1, b1, W2, b2, g2, be2, eps1, eps2, out};
   hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(256), 0, s, A, L, tokens, AttPartials{partials, n_split, L});
   return 0;
 }
 
-// args13: att, res, WoT, bo, g1, be1, ss, W1T, b1, W2T, b2, g2, be2 (OutFfnArgs order); next7: ss, WqT, bq, WkvT, bkv, cs, sn
+// args13: att, res, Wo, bo, g1, be1, ss, W1, b1, W2, b2, g2, be2 (OutFfnArgs order); next7: ss, Wq, bq, Wkv, bkv, cs, sn
 int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp,
                        float* Vt, int B, int L, int D, int H, int roles, const float* partials, int n_split, hipStream_t s) {
   if (D != kD || H != kH || (partials && L > 16)) return 1;

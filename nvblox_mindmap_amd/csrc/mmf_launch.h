@@ -359,5 +359,6 @@ int launch_step_tail(const float* rot_seq, const float* pos_seq, long long seq_b
 // diagnostics: per-workgroup timeline buffer of the fused frame kernels (mmf_trace_device.h); one setter per translation unit
 int set_wg_trace_map(unsigned long long* buf, int cap);
 int set_wg_trace_app(unsigned long long* buf, int cap);
+int set_wg_trace_policy(unsigned long long* buf, int cap);
 
 }  // namespace mmf

@@ -182,6 +182,11 @@ MFMA_DIMS = (120, 8)  # (embedding dim, heads) the MFMA kernels are built for
 FUSE_OUT_FFN_QKV = False  # (measured: no faster than the two launches at the policy shape) layer i's tail and layer i + 1's q | k | v in one launch (mmf_out_ffn_qkv)
 
 
+def _w(linear) -> torch.Tensor:
+    """A Linear's own [out, in] weight, contiguous: what the matrix-core kernels read (16-byte pieces of a weight row)."""
+    return linear.weight.detach().contiguous()
+
+
 def _l16(n: int) -> int:
     return (n + 15) // 16 * 16
 
@@ -199,8 +204,8 @@ def qkv_heads(x, scale_shift, q_proj, kv_proj, rot, heads: int, roles: int = 7):
     v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev) if roles & 6 else None
     ss = _c(scale_shift) if roles & 1 else None
     cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
-    wq, bq = (_wt(q_proj), _c(q_proj.bias)) if roles & 1 else (None, None)
-    wkv, bkv = (_wt(kv_proj), _c(kv_proj.bias)) if roles & 6 else (None, None)
+    wq, bq = (_w(q_proj), _c(q_proj.bias)) if roles & 1 else (None, None)
+    wkv, bkv = (_w(kv_proj), _c(kv_proj.bias)) if roles & 6 else (None, None)
     _lib.check(_lib.lib().mmf_qkv_heads(_lib.dptr(x), _lib.dptr(ss), _lib.dptr(wq), _lib.dptr(bq), _lib.dptr(wkv), _lib.dptr(bkv), _lib.dptr(cs),
                                         _lib.dptr(sn), _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, roles,
                                         _lib.stream_ptr(dev)), "mmf_qkv_heads")
@@ -260,18 +265,18 @@ def out_ffn_mfma(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, o
         assert out.shape == residual.shape and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() != residual.data_ptr()
     if att.dim() == 5:  # key-split partials of attention_heads_split: merged by the kernel while it loads its input
         part = att.contiguous()
-        _lib.check(_lib.lib().mmf_out_ffn_mfma_partials(_lib.dptr(part), part.shape[2], _lib.dptr(residual), _lib.dptr(_wt(out_proj)),
+        _lib.check(_lib.lib().mmf_out_ffn_mfma_partials(_lib.dptr(part), part.shape[2], _lib.dptr(residual), _lib.dptr(_w(out_proj)),
                                                         _lib.dptr(_c(out_proj.bias)), _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)),
-                                                        float(norm1.eps), _lib.dptr(_c(scale_shift)), _lib.dptr(_wt(fc1)),
-                                                        _lib.dptr(_c(fc1.bias)), _lib.dptr(_wt(fc2)), _lib.dptr(_c(fc2.bias)),
+                                                        float(norm1.eps), _lib.dptr(_c(scale_shift)), _lib.dptr(_w(fc1)),
+                                                        _lib.dptr(_c(fc1.bias)), _lib.dptr(_w(fc2)), _lib.dptr(_c(fc2.bias)),
                                                         _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out),
                                                         B, L, D, _lib.stream_ptr(residual.device)), "mmf_out_ffn_mfma_partials")
         return out
     att = att.contiguous()
     ss = _c(scale_shift)
-    _lib.check(_lib.lib().mmf_out_ffn_mfma(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_wt(out_proj)), _lib.dptr(_c(out_proj.bias)),
+    _lib.check(_lib.lib().mmf_out_ffn_mfma(_lib.dptr(att), _lib.dptr(residual), _lib.dptr(_w(out_proj)), _lib.dptr(_c(out_proj.bias)),
                                            _lib.dptr(_c(norm1.weight)), _lib.dptr(_c(norm1.bias)), float(norm1.eps), _lib.dptr(ss),
-                                           _lib.dptr(_wt(fc1)), _lib.dptr(_c(fc1.bias)), _lib.dptr(_wt(fc2)), _lib.dptr(_c(fc2.bias)),
+                                           _lib.dptr(_w(fc1)), _lib.dptr(_c(fc1.bias)), _lib.dptr(_w(fc2)), _lib.dptr(_c(fc2.bias)),
                                            _lib.dptr(_c(norm2.weight)), _lib.dptr(_c(norm2.bias)), float(norm2.eps), _lib.dptr(out), B, L, D,
                                            _lib.stream_ptr(att.device)), "mmf_out_ffn_mfma")
     return out
@@ -299,9 +304,9 @@ def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, ne
     k = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev) if roles == 7 else None
     v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev) if roles == 7 else None
     cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
-    layer = [att, residual, _wt(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(scale_shift), _wt(fc1), _c(fc1.bias),
-             _wt(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
-    nxt = [_c(next_scale_shift), _wt(next_q_proj), _c(next_q_proj.bias), None if roles == 1 else _wt(next_kv_proj),
+    layer = [att, residual, _w(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(scale_shift), _w(fc1), _c(fc1.bias),
+             _w(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+    nxt = [_c(next_scale_shift), _w(next_q_proj), _c(next_q_proj.bias), None if roles == 1 else _w(next_kv_proj),
            None if roles == 1 else _c(next_kv_proj.bias), cs, sn]
     a13 = (Ct.c_void_p * 13)(*[None if t is None else t.data_ptr() for t in layer])
     a7 = (Ct.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in nxt])
@@ -331,7 +336,7 @@ def qkv_heads2(x0, x1, ss01, q_proj01, kv_proj01, rot, heads: int):
     cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
     ops = []
     for st in range(2):
-        ops += [_c(ss01[st]), _wt(q_proj01[st]), _c(q_proj01[st].bias), _wt(kv_proj01[st]), _c(kv_proj01[st].bias), cs, sn]
+        ops += [_c(ss01[st]), _w(q_proj01[st]), _c(q_proj01[st].bias), _w(kv_proj01[st]), _c(kv_proj01[st].bias), cs, sn]
     ptr, _keep = _ptr_array(ops)
     _lib.check(_lib.lib().mmf_qkv_heads2(_lib.dptr(x0), _lib.dptr(x1), ptr, _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads,
                                          _lib.stream_ptr(dev)), "mmf_qkv_heads2")
@@ -351,8 +356,8 @@ def out_ffn_mfma2(att2, res0, res1, blocks01) -> torch.Tensor:
     ops, eps = [], []
     for st, res in enumerate((res0, res1)):
         out_proj, norm1, ss, fc1, fc2, norm2 = blocks01[st]
-        ops += [att2[st * B:(st + 1) * B], res, _wt(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(ss), _wt(fc1),
-                _c(fc1.bias), _wt(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+        ops += [att2[st * B:(st + 1) * B], res, _w(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(ss), _w(fc1),
+                _c(fc1.bias), _w(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
         eps += [float(norm1.eps), float(norm2.eps)]
     ptr, _keep = _ptr_array(ops)
     e4 = (Ct.c_float * 4)(*eps)
