@@ -324,9 +324,14 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
                       const float* ln1_bias_dev, float ln1_eps, const float* scale_shift_dev, const float* W1_dev, const float* b1_dev,
                       const float* W2_dev, const float* b2_dev, const float* ln2_weight_dev, const float* ln2_bias_dev, float ln2_eps,
                       float* out_dev, int B, int L, int D, void* stream);
-/* Matrix-core (v_mfma_f32_16x16x4_f32, exact f32) forms of the per-layer kernels, built for D = 120, H = 8 (head_dim 15).
- * UNLIKE the block kernels above these take the weights AS torch.nn.Linear STORES THEM, [out, in] row-major (Wq, Wo, W1, W2
- * [D, D]; Wkv [2 D, D]): a lane's share of an MFMA B operand is then one aligned 16-byte piece of a weight row:
+/* Matrix-core forms of the per-layer kernels, built for D = 120, H = 8 (head_dim 15).  The attention kernel multiplies in
+ * exact f32 (v_mfma_f32_16x16x4_f32); the projections and the out_proj + LayerNorm + feed-forward block compute every f32 GEMM
+ * as three fp16 matrix-core products of operands split x = hi + lo / 2048 (22-bit mantissas, f32 accumulation: deviation from
+ * the reference's outputs as small as the f32 form's, tests/test_gpu_policy_golden.py).  UNLIKE the block kernels above they
+ * take every weight matrix (Wq, Wo, W1, W2 [D, D]; Wkv [2 D, D] as torch.nn.Linear stores them, [out, in]) PRE-SPLIT by
+ *   mmf_split_linear_weight  weight [out_features, in_features = 120] f32 -> split: 512 bytes per output row
+ *                        ([chunk 4][s 4][8 hi | 8 lo] halves, zero beyond in_features); call once per weight
+ * and passed through the `const float*` weight parameters below as opaque device pointers:
  *   mmf_qkv_heads        the projections of mmf_qkv_block written head-major and padded to 16 channels:
  *                        q_heads, k_heads [B, H, L16, 16], v_heads_t [B, H, 16, L16] (L16 = L rounded up to 16; padding = 0).
  *                        roles: 7 = q | k | v, 1 = q alone (Wkv / k / v may be null), 6 = k | v alone (Wq / q may be null)
@@ -343,6 +348,8 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  *                        rotation and the position stack of the diffusion head).  next14 / layer26: the next7 / layer13 arrays of
  *                        mmf_out_ffn_qkv for stack 0 then stack 1; eps4 = {ln1, ln2} of stack 0 then stack 1 (HOST array);
  *                        activations and outputs are stack-major ([2, B, ...]: mmf_attention_heads runs the pair as batch 2 B)
+ *   mmf_out_ffn_qkv2     mmf_out_ffn_qkv (roles 7, no partials) for the two stacks in one launch: layer26 / eps4 / out as
+ *                        mmf_out_ffn_mfma2, next14 / q / k / v as mmf_qkv_heads2
  *   mmf_out_ffn_qkv      mmf_out_ffn_mfma of layer i followed, in the same launch, by mmf_qkv_heads (roles 7) of layer i + 1 on
  *                        its output.  layer13 (HOST array of device pointers): att, residual, Wo, bo, ln1_weight, ln1_bias,
  *                        scale_shift (or null), W1, b1, W2, b2, ln2_weight, ln2_bias; next7: scale_shift of the next layer's
@@ -394,6 +401,9 @@ int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, f
 int mmf_qkv_heads2(const float* x0_dev, const float* x1_dev, const float* const* next14, float* q_heads_dev, float* k_heads_dev,
                    float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
 int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out_dev, int B, int L, int D, void* stream);
+int mmf_out_ffn_qkv2(const float* const* layer26, const float* eps4, float* out_dev, const float* const* next14, float* q_heads_dev,
+                     float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
+int mmf_split_linear_weight(const float* weight_dev, int out_features, int in_features, void* split_dev, void* stream);
 int mmf_attention_heads_split(const float* q_heads_dev, const float* k_heads_dev, const float* v_heads_t_dev, const uint8_t* key_padding_dev,
                               float* partials_dev, int B, int Lq, int Lk, int H, int head_dim, int* n_split_out, void* stream);
 int mmf_out_ffn_mfma_partials(const float* partials_dev, int n_split, const float* residual_dev, const float* Wo_dev, const float* bo_dev,

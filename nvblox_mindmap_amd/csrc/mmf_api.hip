@@ -2250,7 +2250,8 @@ int mmf_debug_wg_trace(uint64_t* buffer_dev, int capacity_records) {
   if (buffer_dev && capacity_records <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_debug_wg_trace");
   const int r0 = set_wg_trace_map(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
   const int r1 = set_wg_trace_app(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
-  const int r2 = set_wg_trace_policy(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
+  int r2 = set_wg_trace_policy(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
+  if (r2 == 0) r2 = set_wg_trace_policy_layer(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
   if (r0 == 2 || r1 == 2 || r2 == 2) return fail(MMF_ERR_INVALID_ARG, "mmf_debug_wg_trace: this library was built without the hooks (make WG_TRACE=1)");
   if (r0 != 0 || r1 != 0 || r2 != 0) return fail(MMF_ERR_HIP, "mmf_debug_wg_trace: hipMemcpyToSymbol failed");
   return MMF_OK;
@@ -2276,6 +2277,29 @@ int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out
     if (i % 13 != 6 && !layer26[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma2: missing operand");  // [6]: scale_shift, optional
   if (launch_out_ffn_mfma2(layer26, eps4, out, B, L, D, (hipStream_t)stream) != 0)
     return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma2 is built for D = 120");
+  return check_launch();
+}
+
+int mmf_out_ffn_qkv2(const float* const* layer26, const float* eps4, float* out, const float* const* next14, float* q_heads, float* k_heads,
+                     float* v_heads_t, int B, int L, int D, int H, void* stream) {
+  if (!layer26 || !eps4 || !out || !next14 || !q_heads || !k_heads || !v_heads_t || B <= 0 || L <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_qkv2");
+  for (int i = 0; i < 26; ++i)
+    if (i % 13 != 6 && !layer26[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv2: missing layer operand");  // [6]: scale_shift, optional
+  for (int st = 0; st < 2; ++st) {
+    const float* const* q = next14 + 7 * st;
+    if (!q[1] || !q[2] || !q[3] || !q[4] || ((q[5] == nullptr) != (q[6] == nullptr)))
+      return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv2: missing next-layer operand");
+  }
+  if (launch_out_ffn_qkv2(layer26, eps4, out, next14, q_heads, k_heads, v_heads_t, B, L, D, H, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv2 is built for D = 120, H = 8");
+  return check_launch();
+}
+
+int mmf_split_linear_weight(const float* weight, int out_features, int in_features, void* split, void* stream) {
+  if (!weight || !split || out_features <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_linear_weight");
+  if (launch_split_weight(weight, out_features, in_features, split, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_split_linear_weight is built for in_features = 120");
   return check_launch();
 }
 

@@ -339,6 +339,9 @@ int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float
 int launch_qkv_heads2(const float* x0, const float* x1, const float* const* q14, float* Qp, float* Kp, float* Vt, int B, int L, int D, int H,
                       hipStream_t s);
 int launch_out_ffn_mfma2(const float* const* a26, const float* eps4, float* out, int B, int L, int D, hipStream_t s);
+int launch_out_ffn_qkv2(const float* const* a26, const float* eps4, float* out, const float* const* q14, float* Qp, float* Kp, float* Vt,
+                        int B, int L, int D, int H, hipStream_t s);
+int launch_split_weight(const float* W, int rows, int cols, void* dst, hipStream_t s);
 int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, const uint8_t* pad, float* out, int B, int Lq, int Lk,
                            int H, int dh, hipStream_t s);
 int launch_out_ffn_mfma(const float* att, const float* res, const float* WoT, const float* bo, const float* g1, const float* be1,
@@ -360,5 +363,6 @@ int launch_step_tail(const float* rot_seq, const float* pos_seq, long long seq_b
 int set_wg_trace_map(unsigned long long* buf, int cap);
 int set_wg_trace_app(unsigned long long* buf, int cap);
 int set_wg_trace_policy(unsigned long long* buf, int cap);
+int set_wg_trace_policy_layer(unsigned long long* buf, int cap);
 
 }  // namespace mmf

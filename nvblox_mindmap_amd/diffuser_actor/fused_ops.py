@@ -179,12 +179,28 @@ def out_ffn_block(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) 
 
 # ---- matrix-core forms (mmf_kernels_policy_mfma.hip): head-major q / k / v, attention over them, out_proj + LN + FFN ----------
 MFMA_DIMS = (120, 8)  # (embedding dim, heads) the MFMA kernels are built for
-FUSE_OUT_FFN_QKV = False  # (measured: no faster than the two launches at the policy shape) layer i's tail and layer i + 1's q | k | v in one launch (mmf_out_ffn_qkv)
+FUSE_OUT_FFN_QKV = True  # layer i's tail and layer i + 1's q | k | v in one launch (mmf_out_ffn_qkv / mmf_out_ffn_qkv2)
+
+
+_W16_CACHE = {}  # id(weight Parameter) -> (weak reference to it, version, split copy); dropped when the parameter dies
 
 
 def _w(linear) -> torch.Tensor:
-    """A Linear's own [out, in] weight, contiguous: what the matrix-core kernels read (16-byte pieces of a weight row)."""
-    return linear.weight.detach().contiguous()
+    """A Linear's weight in the form the matrix-core layer kernels read (mmf_split_linear_weight: every f32 entry as two fp16
+    values hi + lo / 2048, [out, 4, 4, 2, 8] halves, 512 bytes per output row), made once per weight TENSOR OBJECT and cached until
+    the weight is modified (version counter) or moved -- the rules of ``_wt``."""
+    w = linear.weight
+    key = id(w)
+    hit = _W16_CACHE.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[2].device != w.device:
+        src = w.detach().contiguous()
+        assert src.dtype == torch.float32 and src.dim() == 2
+        dst = torch.empty((src.shape[0], 256), dtype=torch.float16, device=src.device)
+        _lib.check(_lib.lib().mmf_split_linear_weight(_lib.dptr(src), src.shape[0], src.shape[1], _lib.dptr(dst), _lib.stream_ptr(src.device)),
+                   "mmf_split_linear_weight")
+        hit = (weakref.ref(w, lambda _r, k=key: _W16_CACHE.pop(k, None)), w._version, dst)
+        _W16_CACHE[key] = hit
+    return hit[2]
 
 
 def _l16(n: int) -> int:
@@ -384,6 +400,12 @@ def paired_self_attention_stacks(stack0, stack1, x, ss_of, rot, key_padding_mask
             blk, ffw = st.attn[li], st.ffw[li]
             blocks.append((blk.attn.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm))
         att2 = attention_heads(qh, kh, vt, None, L, L, key_padding_mask2_16)
+        if li + 1 < n and FUSE_OUT_FFN_QKV:
+            N0, N1 = stack0.attn[li + 1], stack1.attn[li + 1]
+            y2, qh, kh, vt = out_ffn_qkv2(att2, x0, x1, blocks, (ss_of(N0.adaln), ss_of(N1.adaln)), (N0.attn.q_proj, N1.attn.q_proj),
+                                          (N0.attn.kv_proj, N1.attn.kv_proj), rot, heads)
+            x0, x1 = y2[:B], y2[B:]
+            continue
         y2 = out_ffn_mfma2(att2, x0, x1, blocks)
         x0, x1 = y2[:B], y2[B:]
         if li + 1 < n:
@@ -391,6 +413,37 @@ def paired_self_attention_stacks(stack0, stack1, x, ss_of, rot, key_padding_mask
             qh, kh, vt = qkv_heads2(x0, x1, (ss_of(N0.adaln), ss_of(N1.adaln)), (N0.attn.q_proj, N1.attn.q_proj),
                                     (N0.attn.kv_proj, N1.attn.kv_proj), rot, heads)
     return x0, x1
+
+
+def out_ffn_qkv2(att2, res0, res1, blocks01, next_ss01, next_q_proj01, next_kv_proj01, rot, heads: int):
+    """``out_ffn_mfma2`` followed, in the same launch, by ``qkv_heads2`` of the stacks' NEXT layers on the result.  Returns
+    (out [2B, L, D], q_heads, k_heads, v_heads_t) -- the latter stack-major, leading dimension 2 B."""
+    import ctypes as Ct
+
+    att2 = att2.contiguous()
+    res0, res1 = res0.contiguous(), res1.contiguous()
+    B2, L, D = att2.shape
+    B = B2 // 2
+    L16 = _l16(L)
+    dev = att2.device
+    out = torch.empty_like(att2)
+    q = torch.empty((2 * B, heads, L16, 16), dtype=torch.float32, device=dev)
+    k = torch.empty((2 * B, heads, L16, 16), dtype=torch.float32, device=dev)
+    v = torch.empty((2 * B, heads, 16, L16), dtype=torch.float32, device=dev)
+    cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+    ops, eps, nxt = [], [], []
+    for st, res in enumerate((res0, res1)):
+        out_proj, norm1, ss, fc1, fc2, norm2 = blocks01[st]
+        ops += [att2[st * B:(st + 1) * B], res, _w(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(ss), _w(fc1),
+                _c(fc1.bias), _w(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+        eps += [float(norm1.eps), float(norm2.eps)]
+        nxt += [_c(next_ss01[st]), _w(next_q_proj01[st]), _c(next_q_proj01[st].bias), _w(next_kv_proj01[st]), _c(next_kv_proj01[st].bias), cs, sn]
+    ptr, _keep = _ptr_array(ops)
+    nptr, _keep2 = _ptr_array(nxt)
+    e4 = (Ct.c_float * 4)(*eps)
+    _lib.check(_lib.lib().mmf_out_ffn_qkv2(ptr, Ct.cast(e4, Ct.c_void_p), _lib.dptr(out), nptr, _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D,
+                                           heads, _lib.stream_ptr(dev)), "mmf_out_ffn_qkv2")
+    return out, q, k, v
 
 
 # ---- head and tail of a denoising step (mmf_kernels_policy_head.hip) -----------------------------------------------------------
