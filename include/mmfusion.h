@@ -329,8 +329,9 @@ int mmf_out_ffn_block(const float* att_dev, const float* residual_dev, const flo
  * as three fp16 matrix-core products of operands split x = hi + lo / 2048 (22-bit mantissas, f32 accumulation: deviation from
  * the reference's outputs as small as the f32 form's, tests/test_gpu_policy_golden.py).  UNLIKE the block kernels above they
  * take every weight matrix (Wq, Wo, W1, W2 [D, D]; Wkv [2 D, D] as torch.nn.Linear stores them, [out, in]) PRE-SPLIT by
- *   mmf_split_linear_weight  weight [out_features, in_features = 120] f32 -> split: 512 bytes per output row
- *                        ([chunk 4][s 4][8 hi | 8 lo] halves, zero beyond in_features); call once per weight
+ *   mmf_split_linear_weight  weight [out_features = 120 n, in_features = 120] f32 -> split: one block of 65 536 bytes per 120
+ *                        output rows (n = 2 for the stacked key | value projection), in the order in which the kernels' waves
+ *                        load their operands; call once per weight
  * and passed through the `const float*` weight parameters below as opaque device pointers:
  *   mmf_qkv_heads        the projections of mmf_qkv_block written head-major and padded to 16 channels:
  *                        q_heads, k_heads [B, H, L16, 16], v_heads_t [B, H, 16, L16] (L16 = L rounded up to 16; padding = 0).

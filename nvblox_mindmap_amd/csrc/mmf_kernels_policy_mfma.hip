@@ -13,6 +13,8 @@
 //                     O^T = V^T P^T needs, and makes the softmax statistics of a query row lane-aligned with the columns of
 //                     O^T: no transposes, no LDS, two shuffles per reduction.  The keys of a (query tile, head) are split over
 //                     the 4 waves of the workgroup and merged once through LDS
+#include <cstdlib>
+
 #include "mmf_device.h"
 #include "mmf_launch.h"
 #include "mmf_trace_device.h"
@@ -195,8 +197,15 @@ int launch_attention_heads(const float* Qp, const float* Kp, const float* Vt, co
   const float scale = 1.0f / sqrtf((float)dh);
   if (Lk16 / 16 > 80 && Lq16 / 16 * H * B < 128)  // long key axis, few workgroups: spread the keys over 16 waves
     hipLaunchKernelGGL((k_attention_heads<16, 6, 1>), dim3(Lq16 / 16, H, B), dim3(1024), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
-  else
-    hipLaunchKernelGGL((k_attention_heads<4, 10, 1>), dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+  else {
+    static const int nw = getenv("MMF_DEBUG_ATT_NW") ? atoi(getenv("MMF_DEBUG_ATT_NW")) : 8;  // 8 waves: 7.9 us at the policy shape (4: 8.6, 16: 10.1)
+    if (nw == 8)
+      hipLaunchKernelGGL((k_attention_heads<8, 5, 1>), dim3(Lq16 / 16, H, B), dim3(512), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+    else if (nw == 16)
+      hipLaunchKernelGGL((k_attention_heads<16, 3, 1>), dim3(Lq16 / 16, H, B), dim3(1024), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+    else
+      hipLaunchKernelGGL((k_attention_heads<4, 10, 1>), dim3(Lq16 / 16, H, B), dim3(256), 0, s, Qp, Kp, Vt, pad, out, Lq, Lq16, Lk, Lk16, scale);
+  }
   return 0;
 }
 

@@ -187,15 +187,16 @@ _W16_CACHE = {}  # id(weight Parameter) -> (weak reference to it, version, split
 
 def _w(linear) -> torch.Tensor:
     """A Linear's weight in the form the matrix-core layer kernels read (mmf_split_linear_weight: every f32 entry as two fp16
-    values hi + lo / 2048, [out, 4, 4, 2, 8] halves, 512 bytes per output row), made once per weight TENSOR OBJECT and cached until
-    the weight is modified (version counter) or moved -- the rules of ``_wt``."""
+    values hi + lo / 2048, in the order in which the kernels' waves load them, one 64 KB block per 120 output rows), made once
+    per weight TENSOR OBJECT and cached until the weight is modified (version counter) or moved -- the rules of ``_wt``."""
     w = linear.weight
     key = id(w)
     hit = _W16_CACHE.get(key)
     if hit is None or hit[0]() is not w or hit[1] != w._version or hit[2].device != w.device:
         src = w.detach().contiguous()
         assert src.dtype == torch.float32 and src.dim() == 2
-        dst = torch.empty((src.shape[0], 256), dtype=torch.float16, device=src.device)
+        assert src.shape[1] == 120 and src.shape[0] % 120 == 0
+        dst = torch.empty((src.shape[0] // 120, 128 * 256), dtype=torch.float16, device=src.device)  # one 64 KB block per 120 rows
         _lib.check(_lib.lib().mmf_split_linear_weight(_lib.dptr(src), src.shape[0], src.shape[1], _lib.dptr(dst), _lib.stream_ptr(src.device)),
                    "mmf_split_linear_weight")
         hit = (weakref.ref(w, lambda _r, k=key: _W16_CACHE.pop(k, None)), w._version, dst)

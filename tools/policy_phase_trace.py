@@ -17,7 +17,7 @@ from nvblox_mindmap_amd.diffuser_actor import layers as Ly  # noqa: E402
 
 BASES = {"k_qkv_heads": (0, 5, ["entry", "x tile in LDS", "-", "GEMMs done", "end"]),
          "k_attention_heads": (256, 6, ["entry", "K/V/q in", "S done", "PV done", "merged (barrier)", "end"]),
-         "k_out_ffn_mfma": (1024, 8, ["entry", "att tile in LDS", "GEMM1", "LN1", "GEMM2 + u tile", "barrier", "GEMM3", "LN2, end"])}
+         "k_out_ffn_mfma": (1024, 8, ["entry", "att tile + operands in LDS", "GEMM1", "LN1", "GEMM2", "u tile", "GEMM3", "LN2, end"])}
 
 
 def main():
