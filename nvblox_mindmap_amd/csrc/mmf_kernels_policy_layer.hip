@@ -18,8 +18,9 @@
 //             and B alike
 //   D tiles   row = 4 s + r, col = l & 15 (as every gfx950 MFMA)
 //
-//   k_qkv_heads      q = rotary(q_proj(modulated x)) | k = rotary(k_proj(x)) | v = v_proj(x), written HEAD-MAJOR and padded to
-//                    16 channels: Qp, Kp [B, H, L16, 16], Vt [B, H, 16, L16] -- the layouts k_attention_heads loads from
+//   k_qkv_heads      q = rotary(q_proj(modulated x)) | k = rotary(k_proj(x)) | v = v_proj(x), written HEAD-MAJOR, padded to 16
+//                    channels and SPLIT (see role_store): Qp, Kp [B, H, L16, 16], Vt [B, H, 16, L16] -- what k_attention_heads
+//                    loads as MFMA operands
 //   k_out_ffn_mfma   x1 = LN(res + out_proj(att)); h = modulate(x1); out = LN(h + fc2(relu(fc1(h))))
 //   k_out_ffn_qkv    the same, then the NEXT layer's q | k | v on the tile, which never leaves the workgroup
 //   ...2             two independent stacks of identical shape (the rotation and the position stack) in one launch
@@ -190,15 +191,15 @@ __device__ __forceinline__ void take_acc(const float (*acc)[16][kRS], int tl, in
   v[4] = b.x + d.x, v[5] = b.y + d.y, v[6] = b.z + d.z, v[7] = b.w + d.w;
 }
 
-// role (0 = q, 1 = k, 2 = v) epilogue of a piece lane: y = acc + bias [rotary], written HEAD-MAJOR and padded to 16 channels
-// (Qp, Kp [B, H, L16, 16], Vt [B, H, 16, L16]); rows beyond L and the padding channel are written as zeros (lane 15 writes the
-// padding channel of the 8 heads of its token).  bias / cs / sn: the lane's pieces of the role's bias and rotary tables.
+// role (0 = q, 1 = k, 2 = v) epilogue, first half, by a piece lane: y = acc + bias [rotary] written back IN PLACE into half
+// tile 0 of the role's accumulation pair (rows beyond L as zeros).  bias / cs / sn: the lane's pieces of the role's bias and
+// rotary tables.
 template <int ROLE, bool ROT>
-__device__ __forceinline__ void role_store(const float (*acc)[16][kRS], const float (&bias)[8], const float (&cs)[8], const float (&sn)[8],
-                                           const QkvArgs& Q, int b, int l0, int L, int L16, int tl, int q) {
+__device__ __forceinline__ void role_finish(float (*acc)[16][kRS], const float (&bias)[8], const float (&cs)[8], const float (&sn)[8], int l0,
+                                            int L, int tl, int q) {
   float y[8];
   take_acc(acc, tl, q, y);
-  const bool live = l0 + tl < L;
+  const bool live = l0 + tl < L && q < 15;
 #pragma unroll
   for (int t = 0; t < 8; ++t) y[t] += bias[t];
   if (ROLE < 2 && ROT) {  // out[c] = y[c] cos[c] + (c odd ? y[c-1] : -y[c+1]) sin[c]: the pairs lie inside a piece
@@ -211,26 +212,34 @@ __device__ __forceinline__ void role_store(const float (*acc)[16][kRS], const fl
 #pragma unroll
     for (int t = 0; t < 8; ++t) y[t] = o[t];
   }
-  const int row = l0 + tl;
-  if (q < 15) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int c = 8 * q + t, h = c / kDH, ch = c - h * kDH;
-      const float v = live ? y[t] : 0.0f;
-      if (ROLE == 2)
-        Q.Vt[(((size_t)b * kH + h) * 16 + ch) * L16 + row] = v;
-      else
-        (ROLE == 0 ? Q.Qp : Q.Kp)[(((size_t)b * kH + h) * L16 + row) * 16 + ch] = v;
-    }
-  } else {
+  for (int t = 0; t < 8; ++t) y[t] = live ? y[t] : 0.0f;
+  float4* p = reinterpret_cast<float4*>(&acc[0][tl][8 * q]);
+  p[0] = make_float4(y[0], y[1], y[2], y[3]);
+  p[1] = make_float4(y[4], y[5], y[6], y[7]);
+}
+
+// ... second half, by 512 GROUP lanes per role (after a barrier): the operand layouts of k_attention_heads -- HEAD-MAJOR, the
+// head's 15 channels padded to 16, every aligned group of four values stored as {4 fp16 hi | 4 fp16 lo} in the 16 bytes four
+// floats would take:
+//   Qp, Kp [B, H, L16, 16]: group = 4 channels of a token;  Vt [B, H, 16, L16]: group = 4 tokens of a channel.
+// Group lane u: q / k  (head h = u >> 6, token tl = (u >> 2) & 15, channel group g = u & 3): one head's 16 tokens are 1 KB of
+// contiguous stores;  v  (head h = u >> 6, channel ch = (u >> 2) & 15, token group g = u & 3).
+template <int ROLE>
+__device__ __forceinline__ void role_store(const float (*tile)[kRS], const QkvArgs& Q, int b, int l0, int L16, int u) {
+  const int h = u >> 6, mid = (u >> 2) & 15, g = u & 3;
+  float v[4];
 #pragma unroll
-    for (int h = 0; h < kH; ++h) {
-      if (ROLE == 2)
-        Q.Vt[(((size_t)b * kH + h) * 16 + 15) * L16 + row] = 0.0f;
-      else
-        (ROLE == 0 ? Q.Qp : Q.Kp)[(((size_t)b * kH + h) * L16 + row) * 16 + 15] = 0.0f;
-    }
+  for (int p = 0; p < 4; ++p) {
+    const int tl = ROLE == 2 ? 4 * g + p : mid, ch = ROLE == 2 ? mid : 4 * g + p;
+    v[p] = ch < kDH ? tile[tl][kDH * h + ch] : 0.0f;  // (channel 15: the padding)
   }
+  uint4 o;
+  split2(v[0], v[1], o.x, o.z);
+  split2(v[2], v[3], o.y, o.w);
+  float* dst = ROLE == 2 ? Q.Vt + (((size_t)b * kH + h) * 16 + mid) * L16 + l0 + 4 * g
+                         : (ROLE == 0 ? Q.Qp : Q.Kp) + (((size_t)b * kH + h) * L16 + l0 + mid) * 16 + 4 * g;
+  *reinterpret_cast<uint4*>(dst) = o;
 }
 
 __device__ __forceinline__ const _Float16* role_weights(const QkvArgs& Q, int role) {
@@ -286,7 +295,9 @@ __device__ __forceinline__ void qkv_heads_tile(const float* __restrict__ x, cons
   gemm_half(S.P, B, ct, kh, j, s, S.acc);
   __syncthreads();
   MMF_PT(kPtQkv, 3, 0.0f);
-  if (piece) role_store<ROLE, ROT>(S.acc, rb, rc, rn, Q, b, l0, L, L16, tl, q);
+  if (piece) role_finish<ROLE, ROT>(S.acc, rb, rc, rn, l0, L, tl, q);
+  __syncthreads();
+  if (tid < 512) role_store<ROLE>(S.acc[0], Q, b, l0, L16, tid);
   MMF_PT(kPtQkv, 4, 0.0f);
 }
 
@@ -512,7 +523,6 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
-  MMF_PT(kPtOutFfn, 2, 0.0f);
   if (grp == 0) {
     float v[8], o[8], x0[8], x1[8], x2[8], x3[8];
     take_acc(S.acc, tl, q, v);
@@ -530,7 +540,7 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     store_piece(S.P1, tl, 8 * q, o);
   }
   __syncthreads();
-  MMF_PT(kPtOutFfn, 3, 0.0f);
+  MMF_PT(kPtOutFfn, 2, 0.0f);
 
   // ---- u = relu(fc1(h))
   gemm_half(S.P1, B1, ct, kh, j, s, S.acc);
@@ -539,7 +549,6 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
-  MMF_PT(kPtOutFfn, 4, 0.0f);
   if (grp == 0) {
     float v[8], x0[8];
     take_acc(S.acc, tl, q, v);
@@ -549,7 +558,7 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     store_piece(S.P0, tl, 8 * q, v);
   }
   __syncthreads();
-  MMF_PT(kPtOutFfn, 5, 0.0f);
+  MMF_PT(kPtOutFfn, 3, 0.0f);
 
   // ---- out = LN2(h + fc2(u))
   gemm_half(S.P0, B2, ct, kh, j, s, S.acc);
@@ -558,7 +567,6 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
-  MMF_PT(kPtOutFfn, 6, 0.0f);
   if (grp == 0) {
     const float zero8[8] = {};
     float v[8], o[8], x0[8], x1[8];
@@ -587,7 +595,7 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
       }
     }
   }
-  MMF_PT(kPtOutFfn, 7, 0.0f);
+  MMF_PT(kPtOutFfn, 4, 0.0f);
   if (!QKV) return;
   __syncthreads();
   // ---- the next layer's projections: three GEMMs into three pairs of half tiles, one barrier, then three groups of piece lanes
@@ -597,18 +605,27 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
   }
   gemm_half(QMOD ? S.P0 : S.P1, B2, ct, kh, j, s, S.acc);
   __syncthreads();
+  MMF_PT(kPtOutFfn, 5, 0.0f);
   if (grp < 3 && (grp == 0 || (roles & 2))) {
     float bias[8], cs[8], sn[8];
     load8(&S.vec[grp == 0 ? kVBq : (grp == 1 ? kVBk : kVBv)][c0], bias);
     load8(&S.tok[kTCos][tl][c0], cs);
     load8(&S.tok[kTSin][tl][c0], sn);
     if (grp == 0)
-      role_store<0, QROT>(S.acc, bias, cs, sn, Q, b, l0, L, L16, tl, q);
+      role_finish<0, QROT>(S.acc, bias, cs, sn, l0, L, tl, q);
     else if (grp == 1)
-      role_store<1, QROT>(S.accK, bias, cs, sn, Q, b, l0, L, L16, tl, q);
+      role_finish<1, QROT>(S.accK, bias, cs, sn, l0, L, tl, q);
     else
-      role_store<2, false>(S.accV, bias, cs, sn, Q, b, l0, L, L16, tl, q);
+      role_finish<2, false>(S.accV, bias, cs, sn, l0, L, tl, q);
   }
+  __syncthreads();
+  if (tid < 512) {
+    role_store<0>(S.acc[0], Q, b, l0, L16, tid);
+    if (roles & 2) role_store<2>(S.accV[0], Q, b, l0, L16, tid);
+  } else if (roles & 2) {
+    role_store<1>(S.accK[0], Q, b, l0, L16, tid - 512);
+  }
+  MMF_PT(kPtOutFfn, 6, 0.0f);
 }
 
 // grid = 16-token tiles of the flattened [B L] token axis; 1024 threads

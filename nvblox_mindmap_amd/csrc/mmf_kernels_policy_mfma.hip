@@ -1,18 +1,20 @@
 // The attention kernel of the diffusion head's inference path on the matrix cores (the projections and the out_proj +
 // LayerNorm + feed-forward block around it: mmf_kernels_policy_layer.hip; thread-per-channel forms: mmf_kernels_policy.hip).
 //
-// A denoising step works on ~616 tokens x 120 channels, 8 heads of 15 channels.  v_mfma_f32_16x16x4_f32 (exact f32 products,
-// f32 accumulation: an fmaf chain) on tiles of 16 queries x 16 keys:
+// A denoising step works on ~616 tokens x 120 channels, 8 heads of 15 channels.  Tiles of 16 queries x 16 keys on
+// v_mfma_f32_16x16x16_f16; every f32 product is three fp16 products of operands split x = hi + lo / 2048 (22-bit mantissas, f32
+// accumulation, the two cross terms in their own accumulator: see mmf_kernels_policy_layer.hip) -- q, k, v arrive split from the
+// projection kernels, the probabilities are split in registers.
 //
-//   operand maps (lane l, j = l & 15, s = l >> 4):   A[i = j][k = s]   B[k = s][col = j]   D[row = 4 s + r][col = j], r = 0..3
+//   operand maps (lane l, j = l & 15, s = l >> 4):   A[i = j][k = 4 s + t]   B[k = 4 s + t][col = j]   D[row = 4 s + r][col = j]
 //
 //   k_attention_heads softmax(q k^T / sqrt(dh) + padding) v over HEAD-MAJOR operands padded to 16 channels (Qp, Kp
-//                     [B, H, L16, 16], Vt [B, H, 16, L16]: every operand is one aligned 16-byte access per lane; the 16-key
-//                     (16-channel) reductions use key (channel) 4 s + kk).  Scores are produced TRANSPOSED (S^T = K Q^T), which
-//                     leaves each lane holding, for its query row, exactly the four probabilities the B operand of
-//                     O^T = V^T P^T needs, and makes the softmax statistics of a query row lane-aligned with the columns of
-//                     O^T: no transposes, no LDS, two shuffles per reduction.  The keys of a (query tile, head) are split over
-//                     the 4 waves of the workgroup and merged once through LDS
+//                     [B, H, L16, 16], Vt [B, H, 16, L16], every aligned group of four values = {4 hi | 4 lo} halves in 16
+//                     bytes: an operand of a tile is one aligned 16-byte access per lane).  Scores are produced TRANSPOSED
+//                     (S^T = K Q^T), which leaves each lane holding, for its query row, exactly the four probabilities the B
+//                     operand of O^T = V^T P^T needs, and makes the softmax statistics of a query row lane-aligned with the
+//                     columns of O^T: no transposes, no LDS, two shuffles per reduction.  The keys of a (query tile, head)
+//                     are split over the waves of the workgroup and merged once through LDS
 #include <cstdlib>
 
 #include "mmf_device.h"
@@ -22,8 +24,34 @@
 namespace mmf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(h4 a, h4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+
+struct HiLo {  // four values as {4 hi | 4 lo} halves: value = hi + lo / 2048
+  h4 hi, lo;
+};
+struct U2 {
+  uint32_t a, b;
+};
+__device__ __forceinline__ HiLo load_hilo(const float* __restrict__ p) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  HiLo v;
+  v.hi = __builtin_bit_cast(h4, U2{r.x, r.y});
+  v.lo = __builtin_bit_cast(h4, U2{r.z, r.w});
+  return v;
+}
+__device__ __forceinline__ HiLo split4(const float (&p)[4]) {
+  const hp2 h01 = __builtin_amdgcn_cvt_pkrtz(p[0], p[1]), h23 = __builtin_amdgcn_cvt_pkrtz(p[2], p[3]);
+  const hp2 l01 = __builtin_amdgcn_cvt_pkrtz((p[0] - (float)h01[0]) * kLoScale, (p[1] - (float)h01[1]) * kLoScale);
+  const hp2 l23 = __builtin_amdgcn_cvt_pkrtz((p[2] - (float)h23[0]) * kLoScale, (p[3] - (float)h23[1]) * kLoScale);
+  HiLo v;
+  v.hi = __builtin_bit_cast(h4, U2{__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)});
+  v.lo = __builtin_bit_cast(h4, U2{__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23)});
+  return v;
+}
 
 constexpr int kH = 8, kDH = 15, kD = 120;  // the policy's heads / head dim / embedding dim (the kernel is built for these)
 
@@ -68,45 +96,43 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
   const size_t bh = (size_t)b * kH + h;
 
   MMF_PT(kPtAtt, 0, 0.0f);
-  float q[4];
-  {
-    const float4 v = *reinterpret_cast<const float4*>(Qp + (bh * Lq16 + q0 + j) * 16 + 4 * s);
-    q[0] = v.x * scale, q[1] = v.y * scale, q[2] = v.z * scale, q[3] = v.w * scale;
-  }
+  const HiLo q = load_hilo(Qp + (bh * Lq16 + q0 + j) * 16 + 4 * s);
   const float* Kb = Kp + bh * Lk16 * 16;
   const float* Vb = Vt + (bh * 16 + j) * Lk16;
   // key padding: [B, Lk16] bytes (1 = ignore; keys >= Lk are marked too), one aligned 32-bit word per (tile, lane)
   const uint8_t* pb = pad ? pad + (size_t)b * Lk16 : nullptr;
 
   float m_run = -INFINITY, l_run = 0.0f;
-  f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f};  // O^T: rows = channel 4 s + r, column = query row j
+  // O^T: rows = channel 4 s + r, column = query row j; main and cross-term accumulators, two sets alternating between tiles
+  f32x4 Om0 = {0.f, 0.f, 0.f, 0.f}, Ox0 = Om0, Om1 = Om0, Ox1 = Om0;
   const int all_tiles = Lk16 / 16, per_split = (all_tiles + SPLIT - 1) / SPLIT;
   const int t_begin = split * per_split, ntiles = min(t_begin + per_split, all_tiles);  // this workgroup's key tiles
   for (int tb = t_begin + w; tb < ntiles; tb += NW * CH) {  // this wave's tiles: tb, tb + NW, ...
-    float4 kv[CH], vv[CH];
+    HiLo kv[CH], vv[CH];
     uint32_t pw[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int t = tb + NW * i, tc = min(t, all_tiles - 1);  // tiles beyond the end: a valid tile's data, every key marked dead
-      kv[i] = *reinterpret_cast<const float4*>(Kb + ((size_t)tc * 16 + j) * 16 + 4 * s);
-      vv[i] = *reinterpret_cast<const float4*>(Vb + tc * 16 + 4 * s);
+      kv[i] = load_hilo(Kb + ((size_t)tc * 16 + j) * 16 + 4 * s);
+      vv[i] = load_hilo(Vb + tc * 16 + 4 * s);
       uint32_t word = 0u;
       if (pb) word = *reinterpret_cast<const uint32_t*>(pb + tc * 16 + 4 * s);
       pw[i] = t < ntiles ? word : 0xffffffffu;
     }
-    MMF_PT(kPtAtt, 1, kv[CH - 1].x + vv[CH - 1].x + q[0]);
+    MMF_PT(kPtAtt, 1, (float)kv[CH - 1].hi[0] + (float)vv[CH - 1].hi[0]);
     f32x4 S[CH];
     float cmax = -INFINITY;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      f32x4 c = {0.f, 0.f, 0.f, 0.f};
-      c = mfma4(kv[i].x, q[0], c);
-      c = mfma4(kv[i].y, q[1], c);
-      c = mfma4(kv[i].z, q[2], c);
-      c = mfma4(kv[i].w, q[3], c);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 cm = mfma16(kv[i].hi, q.hi, z);
+      f32x4 cx = mfma16(kv[i].hi, q.lo, z);
+      cx = mfma16(kv[i].lo, q.hi, cx);
+      f32x4 c;
       const int t = tb + NW * i;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        c[r] = (cm[r] + cx[r] * kLoInv) * scale;
         const int key = t * 16 + 4 * s + r;
         const bool dead = key >= Lk || ((pw[i] >> (8 * r)) & 0xffu) != 0u;
         c[r] = dead ? -INFINITY : c[r];
@@ -120,8 +146,10 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
     const float m_new = fmaxf(m_run, cmax);
     const float corr = (m_run == -INFINITY) ? 0.0f : __expf(m_run - m_new);
     l_run *= corr;
-    O0 *= corr;
-    O1 *= corr;
+    Om0 *= corr;
+    Ox0 *= corr;
+    Om1 *= corr;
+    Ox1 *= corr;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       float p[4];
@@ -130,19 +158,24 @@ __global__ __launch_bounds__(64 * NW) void k_attention_heads(const float* __rest
         p[r] = (S[i][r] == -INFINITY) ? 0.0f : __expf(S[i][r] - m_new);
         l_run += p[r];
       }
+      const HiLo P = split4(p);
       if (i & 1) {
-        O1 = mfma4(vv[i].x, p[0], O1);
-        O1 = mfma4(vv[i].y, p[1], O1);
-        O1 = mfma4(vv[i].z, p[2], O1);
-        O1 = mfma4(vv[i].w, p[3], O1);
+        Om1 = mfma16(vv[i].hi, P.hi, Om1);
+        Ox1 = mfma16(vv[i].hi, P.lo, Ox1);
+        Ox1 = mfma16(vv[i].lo, P.hi, Ox1);
       } else {
-        O0 = mfma4(vv[i].x, p[0], O0);
-        O0 = mfma4(vv[i].y, p[1], O0);
-        O0 = mfma4(vv[i].z, p[2], O0);
-        O0 = mfma4(vv[i].w, p[3], O0);
+        Om0 = mfma16(vv[i].hi, P.hi, Om0);
+        Ox0 = mfma16(vv[i].hi, P.lo, Ox0);
+        Ox0 = mfma16(vv[i].lo, P.hi, Ox0);
       }
     }
     m_run = m_new;
+  }
+  f32x4 O0, O1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    O0[r] = Om0[r] + Ox0[r] * kLoInv;
+    O1[r] = Om1[r] + Ox1[r] * kLoInv;
   }
   MMF_PT(kPtAtt, 3, O0[0] + O1[0]);
   // merge the four key ranges

@@ -209,7 +209,8 @@ def _l16(n: int) -> int:
 
 
 def qkv_heads(x, scale_shift, q_proj, kv_proj, rot, heads: int, roles: int = 7):
-    """The projections of ``qkv_block`` written head-major, padded to 16 channels per head (padding = 0):
+    """The projections of ``qkv_block`` written head-major, padded to 16 channels per head (padding = 0), in the split form the
+    attention kernel multiplies (``unpack_heads`` gives the float values):
     (q_heads [B,H,L16,16], k_heads [B,H,L16,16], v_heads_t [B,H,16,L16]).  roles: 7 = q|k|v, 1 = q alone (kv_proj unused),
     6 = k|v alone (q_proj / scale_shift unused): entries that are not produced are None."""
     x = x.contiguous()
@@ -227,6 +228,14 @@ def qkv_heads(x, scale_shift, q_proj, kv_proj, rot, heads: int, roles: int = 7):
                                         _lib.dptr(sn), _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, roles,
                                         _lib.stream_ptr(dev)), "mmf_qkv_heads")
     return q, k, v
+
+
+def unpack_heads(t: torch.Tensor) -> torch.Tensor:
+    """The float32 values of a head-major operand of ``qkv_heads`` (q_heads / k_heads [B,H,L16,16] or v_heads_t [B,H,16,L16]):
+    the kernels store every aligned group of four values of the LAST axis as {4 fp16 hi | 4 fp16 lo} in the 16 bytes four floats
+    would take, value = hi + lo / 2048 (the split operands of the attention kernel's matrix-core products).  For tests / debugging."""
+    h = t.contiguous().view(torch.float16).reshape(*t.shape[:-1], t.shape[-1] // 4, 2, 4).to(torch.float32)
+    return (h[..., 0, :] + h[..., 1, :] / 2048.0).reshape(t.shape)
 
 
 def pad_mask16(key_padding_mask: torch.Tensor) -> torch.Tensor:

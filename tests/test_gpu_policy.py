@@ -364,7 +364,7 @@ def test_mfma_layer_kernels_match_the_channel_kernels(B, L):
     with torch.no_grad():
         for ss, r in ((ss1, rot), (None, None), (ss1, None), (None, rot)):
             q, k, v = FO.qkv_block(x, ss, A.q_proj, A.kv_proj, r)
-            qh, kh, vt = FO.qkv_heads(x, ss, A.q_proj, A.kv_proj, r, H)
+            qh, kh, vt = (FO.unpack_heads(t) for t in FO.qkv_heads(x, ss, A.q_proj, A.kv_proj, r, H))  # split storage -> values
             assert qh.shape == (B, H, L16, 16) and vt.shape == (B, H, 16, L16)
             close(qh[:, :, :L, :15].permute(0, 2, 1, 3).reshape(B, L, D), q, "q")
             close(kh[:, :, :L, :15].permute(0, 2, 1, 3).reshape(B, L, D), k, "k")

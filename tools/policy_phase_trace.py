@@ -17,7 +17,7 @@ from nvblox_mindmap_amd.diffuser_actor import layers as Ly  # noqa: E402
 
 BASES = {"k_qkv_heads": (0, 5, ["entry", "x tile in LDS", "-", "GEMMs done", "end"]),
          "k_attention_heads": (256, 6, ["entry", "K/V/q in", "S done", "PV done", "merged (barrier)", "end"]),
-         "k_out_ffn_mfma": (1024, 8, ["entry", "att tile + operands in LDS", "GEMM1", "LN1", "GEMM2", "u tile", "GEMM3", "LN2, end"])}
+         "k_out_ffn_mfma": (1024, 7, ["entry", "att tile + operands in LDS", "GEMM1 + LN1", "GEMM2 + u tile", "GEMM3 + LN2", "(fused) projections", "(fused) stores"])}
 
 
 def main():
@@ -40,6 +40,8 @@ def main():
             def layer(xin):
                 qh, kh, vt = FO.qkv_heads(xin, ss, A.q_proj, A.kv_proj, rot, H)
                 a = FO.attention_heads(qh, kh, vt, None, L, L)
+                if os.environ.get("FUSED"):
+                    return FO.out_ffn_qkv(a, xin, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm, ss, A.q_proj, A.kv_proj, rot, H)[0]
                 return FO.out_ffn_mfma(a, xin, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
 
             g = torch.cuda.CUDAGraph()
