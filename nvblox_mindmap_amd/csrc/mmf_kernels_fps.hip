@@ -23,6 +23,7 @@
 //     Launches are chunked so that the whole grid is co-resident; the spin is bounded (writes -1 and leaves).
 // Fallback kernel (k_fps_stream) for larger N or C: one 1024-thread workgroup per batch element, points streamed.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mmf_launch.h"
 
@@ -256,6 +257,293 @@ static int fps_groups(const float* x, int B, int N, int C, int npoints, int star
   return 0;
 }
 
+// ---- several picks per exchange ------------------------------------------------------------------------------------------------
+// A pick costs one cross-workgroup exchange (an L2 round trip of ~1 us plus the barriers around it) on top of the distance
+// update, and with more workgroups per batch element the update shrinks while the exchange does not.  So an exchange carries
+// more than one pick, EXACTLY:
+//   * every workgroup publishes its K best points by key (key = distance bits | ~index: a total order, first index on ties), keys
+//     and rows;
+//   * T = the largest K-th key of any workgroup bounds the key of every point that was NOT published (a point's key only ever
+//     decreases); the candidates with key >= T are fetched by everybody (rows: they are few);
+//   * pick 1 is the largest key (it is among each workgroup's best).  Then every workgroup applies the pick to its own points and,
+//     on a fourth wave, to the fetched candidates -- the same channel-by-channel sum their owners compute -- and the best
+//     candidate is pick 2 if its NEW key is still >= T: no unpublished point can beat it.  And so on, until the best candidate
+//     falls below T (or K picks are made): then the next exchange.
+// On the policy's shape (3 072 x 120, 16 workgroups of 3 + 1 waves, K = 4) 3.8 - 4.0 picks ride on one exchange.
+constexpr int kFpsMultiGroups = 16, kFpsElig = 40;  // (candidates above the bound: 21 on average, 35 at most on random data)
+
+// max of a 64-bit key over the wave, the result in every lane (as a scalar): four cross-lane steps inside the 16-lane rows
+// (pairs, quads, mirrored half, mirrored row), two row broadcasts, one read of lane 63 -- data-parallel-primitive moves instead
+// of the six ds_bpermute round trips of the butterfly (0.6 us each time on one wave; an exchange takes ten such maxima).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_max_step(u64 v) {
+  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  const u64 o = ((u64)ohi << 32) | olo;
+  return o > v ? o : v;
+}
+__device__ __forceinline__ u64 wave_max_u64_dpp(u64 v) {
+  v = dpp_max_step<0xB1, 0xf>(v);   // quad_perm [1, 0, 3, 2]
+  v = dpp_max_step<0x4E, 0xf>(v);   // quad_perm [2, 3, 0, 1]
+  v = dpp_max_step<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_max_step<0x140, 0xf>(v);  // row_mirror: every lane holds its row's maximum
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave's maximum
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((u64)hi << 32) | lo;
+}
+
+template <int CP, int NWV, int K>
+__global__ __launch_bounds__(64 * (NWV + 1)) void k_fps_multi(const float* __restrict__ xp, int b0, int bend, int N, int G, int npoints,
+                                                             int start, u64* pub, long long* __restrict__ out_idx) {
+  constexpr int NT = 64 * (NWV + 1), RS = CP + 4;
+  __shared__ u64 s_wkey[2][NWV];
+  __shared__ __attribute__((aligned(16))) float s_pub[K][CP];
+  __shared__ u64 s_pubkey[K];
+  __shared__ u64 s_keys[64];
+  __shared__ __attribute__((aligned(16))) float s_rows[kFpsElig][RS];
+  __shared__ int s_elig[kFpsElig];
+  __shared__ int s_nelig, s_fail;
+  __shared__ int s_pick[2];
+  const int id = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = id >> 3;
+  const int b = b0 + (id & 7) + 8 * (r / G);  // batch element: its G workgroups share id % 8 (one XCD)
+  const int g = r % G;
+  if (b >= bend) return;  // rounded-up tail of this launch
+  const bool main_wave = wave < NWV;
+  const int p = (g * NWV + wave) * 64 + lane;  // main waves: the lane's point
+  const bool valid = main_wave && p < N;
+  const float* xb = xp + (size_t)b * N * CP;
+  float v[CP];
+  if (main_wave) {
+    const float4* src = reinterpret_cast<const float4*>(xb + (size_t)(valid ? p : 0) * CP);
+#pragma unroll
+    for (int c = 0; c < CP / 4; ++c) {
+      const float4 q = src[c];
+      v[4 * c] = q.x, v[4 * c + 1] = q.y, v[4 * c + 2] = q.z, v[4 * c + 3] = q.w;
+    }
+  }
+  for (int c = tid; c < CP; c += NT) s_rows[0][c] = xb[(size_t)start * CP + c];  // the first selected row
+  if (tid == 0) s_fail = 0, s_pick[0] = 0, s_nelig = 1;
+  __syncthreads();
+  u64* mypub = pub + (size_t)b * 2 * G * K * (CP + 1);
+  long long* ob = out_idx + (size_t)b * npoints;
+  float dist = INFINITY;
+  if (g == 0 && tid == 0) ob[0] = start;
+  const u64 pidx = (u64)(0xFFFu - (unsigned)p) << 20;
+  int it = 1;                // picks made so far
+  u64 ck = 0, T_eff = 0;     // aux wave: the lane's candidate key (slot = lane), the bound of everything not fetched
+  int n = 0, pick = 0;       // picks of the current exchange; slot of the pick being applied
+  bool first = true;         // the start point is applied like a pick
+  for (unsigned round = 1;; ++round) {
+    // ---- apply picks: slot `pick` of s_rows, then ask the aux wave for the next one
+    for (;;) {
+      if (main_wave) {
+        const float* row = s_rows[pick];
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CP; c += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(row + c);
+          float d = v[c] - q.x;
+          acc += d * d;
+          d = v[c + 1] - q.y;
+          acc += d * d;
+          d = v[c + 2] - q.z;
+          acc += d * d;
+          d = v[c + 3] - q.w;
+          acc += d * d;
+        }
+        dist = fminf(dist, acc);
+      } else {
+        // the candidates (one per lane) against the pick: what their owners compute for them
+        int nxt = -1;
+        if (!first) {
+          const int ne = s_nelig;
+          const float* mine = s_rows[lane < ne ? lane : 0];
+          const float* row = s_rows[pick];
+          float acc = 0.0f;
+#pragma unroll 4
+          for (int c = 0; c < CP; c += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(mine + c), q = *reinterpret_cast<const float4*>(row + c);
+            float d = a.x - q.x;
+            acc += d * d;
+            d = a.y - q.y;
+            acc += d * d;
+            d = a.z - q.z;
+            acc += d * d;
+            d = a.w - q.w;
+            acc += d * d;
+          }
+          if (lane < ne) {
+            const float dn = fminf(__uint_as_float((unsigned)(ck >> 32)), acc);
+            ck = ((u64)__float_as_uint(dn) << 32) | (ck & 0xFFFFFFFFull);
+          }
+          // the next pick of this exchange: the best candidate, if nothing outside the fetched set can beat it
+          const u64 best = wave_max_u64_dpp(lane < ne ? ck : 0ull);
+          if (n < K && it + n < npoints && best >= T_eff) {
+            const unsigned long long m = __ballot(lane < ne && ck == best);
+            nxt = __ffsll((long long)m) - 1;
+            if (g == 0 && lane == 0) ob[it + n] = 0xFFF - (int)((best >> 20) & 0xFFF);
+          }
+        }
+        if (lane == 0) s_pick[(n + 1) & 1] = nxt;
+      }
+      __syncthreads();
+      if (first) break;
+      const int nxt = s_pick[(n + 1) & 1];
+      if (nxt < 0) break;
+      pick = nxt;
+      ++n;
+    }
+    if (!first) it += n;
+    first = false;
+    if (it >= npoints) return;
+    // ---- this workgroup's K best points: keys and rows
+    const u64 tag = (u64)(round & 0xFFFFF);
+    bool sel = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (main_wave) {
+        u64 key = (valid && !sel) ? (((u64)__float_as_uint(dist) << 32) | pidx | tag) : tag;
+        key = wave_max_u64_dpp(key);
+        if (lane == 0) s_wkey[k & 1][wave] = key;
+      }
+      __syncthreads();
+      u64 best = s_wkey[k & 1][0];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) best = s_wkey[k & 1][w] > best ? s_wkey[k & 1][w] : best;
+      const int best_p = 0xFFF - (int)((best >> 20) & 0xFFF);
+      if (valid && !sel && p == best_p && (best >> 32) == (u64)__float_as_uint(dist)) {  // the owner hands its row over
+        sel = true;
+#pragma unroll
+        for (int c = 0; c < CP; c += 4) *reinterpret_cast<float4*>(&s_pub[k][c]) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+      }
+      if (tid == 0) s_pubkey[k] = best;
+    }
+    __syncthreads();
+    u64* slot_row = mypub + (size_t)(round & 1) * G * K * (CP + 1);
+    for (int e = tid; e < K * (CP + 1); e += NT) {
+      const int k = e / (CP + 1), c = e - k * (CP + 1);
+      const u64 word = c < CP ? (((u64)round << 32) | (u64)__float_as_uint(s_pub[k][c])) : s_pubkey[k];
+      __hip_atomic_store(slot_row + (size_t)(g * K + k) * (CP + 1) + c, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- everybody's keys; the bound T; the candidates to fetch (aux wave)
+    if (!main_wave) {
+      u64 key = 0;
+      if (lane < G * K) {
+        unsigned spins = 0;
+        for (;;) {
+          key = __hip_atomic_load(slot_row + (size_t)lane * (CP + 1) + CP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((key & 0xFFFFF) == tag) break;
+          if (++spins > kFpsSpinLimit) {
+            s_fail = 1;  // a peer workgroup is not running: give up (flagged below)
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const u64 T = wave_max_u64_dpp((lane < G * K && lane % K == K - 1) ? key : 0ull);
+      bool elig = lane < G * K && key >= T;
+      unsigned long long m = __ballot(elig);
+      u64 bound = T;
+      if (__popcll(m) > kFpsElig) {  // (not seen in practice) too many to fetch: one pick in this exchange
+        const u64 top = wave_max_u64_dpp(lane < G * K ? key : 0ull);
+        elig = lane < G * K && key == top;
+        m = __ballot(elig);
+        bound = ~0ull;
+      }
+      const int slot = __popcll(m & ((1ull << lane) - 1ull));
+      if (elig) s_elig[slot] = lane;
+      if (lane == 0) s_nelig = __popcll(m);
+      s_keys[lane] = key;
+      T_eff = bound;
+    }
+    __syncthreads();
+    if (s_fail) {
+      if (g == 0 && tid == 0) ob[it] = -1;
+      return;
+    }
+    // ---- their rows
+    // (requested eight words per thread at a time, checked afterwards: one dependent round trip per word made this the longest
+    // part of an exchange; the rows were stored before the keys that have been seen, a stale word is the exception)
+    const int ne = s_nelig;
+    for (int e0 = tid; e0 < ne * CP; e0 += 8 * NT) {
+      u64 got[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = min(e0 + i * NT, ne * CP - 1), sl = e / CP, c = e - sl * CP;
+        got[i] = __hip_atomic_load(slot_row + (size_t)s_elig[sl] * (CP + 1) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = e0 + i * NT;
+        if (e < ne * CP) {
+          const int sl = e / CP, c = e - sl * CP;
+          unsigned spins = 0;
+          while ((unsigned)(got[i] >> 32) != round) {
+            if (++spins > kFpsSpinLimit) {
+              s_fail = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            got[i] = __hip_atomic_load(slot_row + (size_t)s_elig[sl] * (CP + 1) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          s_rows[sl][c] = __uint_as_float((unsigned)got[i]);
+        }
+      }
+    }
+    // ---- the first pick of the exchange: the largest key (aux wave)
+    n = 0;
+    if (!main_wave) {
+      ck = lane < ne ? s_keys[s_elig[lane]] : 0ull;
+      const u64 best = wave_max_u64_dpp(ck);
+      const unsigned long long m = __ballot(lane < ne && ck == best);
+      const int first_slot = __ffsll((long long)m) - 1;
+      if (lane == 0) s_pick[1] = first_slot;  // (the apply loop's first iteration, n = 1, writes s_pick[0])
+      if (g == 0 && lane == 0) ob[it] = 0xFFF - (int)((best >> 20) & 0xFFF);
+    }
+    __syncthreads();
+    if (s_fail) {
+      if (g == 0 && tid == 0) ob[it] = -1;
+      return;
+    }
+    pick = s_pick[1];
+    n = 1;
+  }
+}
+
+template <int CP, int NWV, int K>
+static int fps_multi(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+  const int G = (N + 64 * NWV - 1) / (64 * NWV);
+  if (G * K > 64 || G > kFpsMultiGroups || N > 4096 || N - (G - 1) * 64 * NWV < K) return 1;  // (every workgroup publishes K real points)
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fps_multi<CP, NWV, K>, 64 * (NWV + 1), 0) != hipSuccess || per_cu <= 0)
+    return 2;
+  int chunk = (int)((long long)cus * per_cu / G) / 8 * 8;  // batch elements per launch: the whole grid must be co-resident
+  if (chunk < 8) return 1;
+  float* xp = nullptr;
+  u64* pub = nullptr;
+  const size_t xp_bytes = sizeof(float) * (size_t)B * N * CP, pub_bytes = sizeof(u64) * (size_t)B * 2 * G * K * (CP + 1);
+  if (hipMallocAsync((void**)&xp, xp_bytes, s) != hipSuccess) return 2;
+  if (hipMallocAsync((void**)&pub, pub_bytes, s) != hipSuccess) {
+    (void)hipFreeAsync(xp, s);
+    return 2;
+  }
+  (void)hipMemsetAsync(pub, 0, pub_bytes, s);
+  const long long rows = (long long)B * N;
+  hipLaunchKernelGGL(k_fps_pad<CP>, dim3((unsigned)((rows * CP + 255) / 256)), dim3(256), 0, s, x, rows, C, xp);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = (B - b0 < chunk ? B - b0 : chunk);
+    hipLaunchKernelGGL((k_fps_multi<CP, NWV, K>), dim3(8 * G * ((nb + 7) / 8)), dim3(64 * (NWV + 1)), 0, s, xp, b0, b0 + nb, N, G, npoints, start,
+                       pub, out_idx);
+  }
+  (void)hipFreeAsync(pub, s);
+  (void)hipFreeAsync(xp, s);
+  return 0;
+}
+
 constexpr int kFpsThreads = 1024;
 constexpr int kFpsMaxPerThread = 8;  // N <= 8192
 constexpr int kFpsMaxC = 1024;
@@ -361,8 +649,11 @@ static int fps_resident(const float* x, int B, int N, int C, int npoints, int st
 
 // 0 = launched, 1 = unsupported shape, 2 = HIP runtime error
 int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
-  if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120): grouped form
-    const int rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);  // (8 groups of 6 waves: 7 % slower)
+  if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120)
+    static const int single = getenv("MMF_DEBUG_FPS_SINGLE") ? 1 : 0;  // (diagnostics: one pick per exchange)
+    int rc = single ? 1 : (C <= 120 ? fps_multi<120, 3, 4>(x, B, N, C, npoints, start, out_idx, s)
+                                     : fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s));
+    if (rc == 1) rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);  // (8 groups of 6 waves: 7 % slower)
     if (rc != 1) return rc;
   }
   if (N <= kFpsMaxResidentN && C <= kFpsMaxResidentC) {
