@@ -269,7 +269,9 @@ static int fps_groups(const float* x, int B, int N, int C, int npoints, int star
 //     on a fourth wave, to the fetched candidates -- the same channel-by-channel sum their owners compute -- and the best
 //     candidate is pick 2 if its NEW key is still >= T: no unpublished point can beat it.  And so on, until the best candidate
 //     falls below T (or K picks are made): then the next exchange.
-// On the policy's shape (3 072 x 120, 16 workgroups of 3 + 1 waves, K = 4) 3.8 - 4.0 picks ride on one exchange.
+// On the policy's shape (3 072 x 120, 16 workgroups of 3 + 1 waves, K = 4) 3.8 - 4.0 picks ride on one exchange, 21 candidates
+// are fetched on average; 614 picks: 2.5 ms (one pick per exchange, 4 workgroups of 12 waves) -> 2.0 ms.  An exchange still costs
+// ~9 us beside its picks (publish -> keys -> rows are three dependent trips through the L2, at the clock a 16-CU job gets).
 constexpr int kFpsMultiGroups = 16, kFpsElig = 40;  // (candidates above the bound: 21 on average, 35 at most on random data)
 
 // max of a 64-bit key over the wave, the result in every lane (as a scalar): four cross-lane steps inside the 16-lane rows
@@ -651,8 +653,7 @@ static int fps_resident(const float* x, int B, int N, int C, int npoints, int st
 int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
   if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120)
     static const int single = getenv("MMF_DEBUG_FPS_SINGLE") ? 1 : 0;  // (diagnostics: one pick per exchange)
-    int rc = single ? 1 : (C <= 120 ? fps_multi<120, 3, 4>(x, B, N, C, npoints, start, out_idx, s)
-                                     : fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s));
+    int rc = single ? 1 : fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s);
     if (rc == 1) rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);  // (8 groups of 6 waves: 7 % slower)
     if (rc != 1) return rc;
   }
