@@ -320,14 +320,36 @@ __device__ inline u64 voxel_at(const MapConsts& mc, const float* p, int& lin) {
 }
 
 // ---- wave / workgroup scans (wave64) ---------------------------------------------------------
+// Six data-parallel-primitive adds: shifts by 1, 2, 4, 8 inside the 16-lane rows (lanes without a source add 0), then the
+// total of row 0 / 2 into rows 1 / 3 and the total of rows 0 - 1 into rows 2 - 3.  (__shfl_up goes through ds_bpermute: six of
+// them in a chain are ~0.6 us, and the allocation chain of a frame runs several scans.)
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_shifted(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
 __device__ inline int wave_incl_scan(int v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
+  v += dpp_shifted<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_shifted<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_shifted<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_shifted<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_shifted<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_shifted<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
   return v;
+}
+// maximum of a non-negative float over the wave, in every lane
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_max_f32_step(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ inline float wave_max_f32(float v) {
+  v = dpp_max_f32_step<0xB1, 0xf>(v);   // quad_perm [1, 0, 3, 2]
+  v = dpp_max_f32_step<0x4E, 0xf>(v);   // quad_perm [2, 3, 0, 1]
+  v = dpp_max_f32_step<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_max_f32_step<0x140, 0xf>(v);  // row_mirror
+  v = dpp_max_f32_step<0x142, 0xa>(v);  // row_bcast:15
+  v = dpp_max_f32_step<0x143, 0xc>(v);  // row_bcast:31: lane 63 holds the maximum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Exclusive scan of two ints over a workgroup of NW waves; `lds` holds 2*NW+2 ints.

@@ -748,12 +748,7 @@ __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, 
   // prefix sums of the sub-list counters (one wave, shuffles): flat position v lives in sub-list k with prefix[k] <= v < prefix[k+1]
   if (threadIdx.x < 64) {
     const int c = threadIdx.x < kFlatSubLists ? A.flat.count[threadIdx.x * kFlatCountStride] : 0;
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl, off, 64);
-      if ((int)threadIdx.x >= off) incl += o;
-    }
+    const int incl = wave_incl_scan(c);
     s_prefix[threadIdx.x + 1] = incl;
     if (threadIdx.x == 0) s_prefix[0] = 0;
   }

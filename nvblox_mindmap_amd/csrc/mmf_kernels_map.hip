@@ -655,8 +655,7 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
       const int all_free = __syncthreads_and(freev);
       if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, off, 64));
+    wmx = wave_max_f32(wmx);
     if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmx;
     const int any = __syncthreads_or(hit);  // (also orders s_wmax)
     if (threadIdx.x == 0) {
@@ -760,8 +759,7 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
     }
   }
   const int w_free = __all(freev), w_hit = __any(hit);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, off, 64));
+  wmx = wave_max_f32(wmx);
   if ((threadIdx.x & 63) == 0) {
     S.free_[par][wv] = w_free;
     S.hit[par][wv] = w_hit;
