@@ -15,7 +15,7 @@ from nvblox_mindmap_amd import _lib  # noqa: E402
 from nvblox_mindmap_amd.diffuser_actor import fused_ops as FO  # noqa: E402
 from nvblox_mindmap_amd.diffuser_actor import layers as Ly  # noqa: E402
 
-BASES = {"k_qkv_heads": (0, 5, ["entry", "x tile in LDS", "-", "GEMMs done", "end"]),
+BASES = {"k_qkv_heads": (0, 5, ["entry", "x tile in LDS", None, "GEMM halves in LDS", "end"]),
          "k_attention_heads": (256, 6, ["entry", "K/V/q in", "S done", "PV done", "merged (barrier)", "end"]),
          "k_out_ffn_mfma": (1024, 7, ["entry", "att tile + operands in LDS", "GEMM1 + LN1", "GEMM2 + u tile", "GEMM3 + LN2", "(fused) projections", "(fused) stores"])}
 
@@ -75,9 +75,14 @@ def main():
             continue
         med = np.median(np.stack(acc[name][5:]), axis=0)
         sp = np.median(np.array(spans[name][5:]), axis=0)
-        print(f"{name}: {int(sp[2])} workgroups, last start +{sp[0]:.2f} us, last end +{sp[1]:.2f} us after the first start")
+        end = f"{sp[1]:.2f}" if 0 <= sp[1] < 1e6 else "?"
+        print(f"{name}: {int(sp[2])} workgroups, last start +{sp[0]:.2f} us, last end +{end} us after the first start")
+        prev = 0.0
         for i in range(n):
-            print(f"    {labels[i]:<20} +{med[i]:6.2f} us" + (f"   (step {med[i] - med[i - 1]:5.2f})" if i else ""))
+            if labels[i] is None or med[i] < 0 or med[i] > 1e6:  # a mark this kernel (or this variant of it) does not set
+                continue
+            print(f"    {labels[i]:<28} +{med[i]:6.2f} us" + (f"   (step {med[i] - prev:5.2f})" if i else ""))
+            prev = med[i]
 
 
 if __name__ == "__main__":
