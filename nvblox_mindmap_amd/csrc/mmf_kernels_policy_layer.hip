@@ -469,8 +469,6 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
   const uint32_t woff = bhalf_offset(ct, kh, lane);
   BHalf Bo, B1, B2;
   load_bhalf(A.Wo, woff, Bo);
-  load_bhalf(A.W1, woff, B1);
-  load_bhalf(A.W2, woff, B2);
   __builtin_amdgcn_sched_barrier(0);
 
   if (AP.part != nullptr) {
@@ -516,12 +514,14 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
   MMF_PT(kPtOutFfn, 1, 0.0f);
 
   // ---- x1 = LN1(res + out_proj(att)), h = modulate(x1)
+  load_bhalf(A.W1, woff, B1);
+  __builtin_amdgcn_sched_barrier(0);
   gemm_half(S.P0, Bo, ct, kh, j, s, S.acc);
-  // the next layer's key weights are requested into the registers of Bo: they arrive behind fc1 / fc2
-  if (QKV && (roles & 2)) {
-    load_bhalf(role_weights(Q, 1), woff, Bo);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  // fc2's weights are requested now -- two matrices ahead: everything up front is 192 KB through the CU before the first MFMA --
+  // and the next layer's key weights into the registers of Bo
+  load_bhalf(A.W2, woff, B2);
+  if (QKV && (roles & 2)) load_bhalf(role_weights(Q, 1), woff, Bo);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   if (grp == 0) {
     float v[8], o[8], x0[8], x1[8], x2[8], x3[8];
