@@ -26,6 +26,31 @@ def test_fps_kernel_matches_reference(shape):
     assert torch.equal(farthest_point_sampling(x, min(n, 5), 3)[:, 0], torch.full((B,), 3, device="cuda"))
 
 
+@pytest.mark.parametrize("shape", [(1, 3000, 120, 700), (2, 2890, 100, 64), (1, 1100, 128, 1100), (1, 4000, 120, 300), (3, 3072, 97, 20)])
+@pytest.mark.parametrize("kind", ["gauss", "clusters", "constant"])
+def test_fps_several_picks_per_exchange_is_exact(shape, kind):
+    """k_fps_multi (N in (1024, 3072], C in (96, 128]: several picks per cross-workgroup exchange) against the
+    sequential restatement on inputs that stress its bound: clustered points (candidates close to each other: picks that must NOT
+    be taken early), all points identical (every key ties: the first index repeats), a last workgroup with a handful of points,
+    as many picks as points; N = 4000 takes the one-pick-per-exchange form (more than 16 workgroups)."""
+    from fps_restatement import farthest_point_sampling_numpy
+    from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling
+
+    B, N, C, n = shape
+    g = torch.Generator().manual_seed(N + C)
+    if kind == "gauss":
+        x = torch.randn(B, N, C, generator=g)
+    elif kind == "clusters":
+        x = torch.randn(B, 12, C, generator=g)[:, torch.randint(0, 12, (N,), generator=g)] + 1e-3 * torch.randn(B, N, C, generator=g)
+        x[:, 5::7] = x[:, 4::7][:, : x[:, 5::7].shape[1]]  # exact duplicates inside the clusters
+    else:
+        x = torch.full((B, N, C), 0.25)
+    x = x.cuda()
+    got = farthest_point_sampling(x, n, 0)
+    ref = torch.from_numpy(farthest_point_sampling_numpy(x.cpu().numpy(), n, 0))
+    assert torch.equal(got.cpu(), ref), int((got.cpu() != ref).sum())
+
+
 def test_fps_rejects_bad_arguments():
     from nvblox_mindmap_amd.diffuser_actor.fps import farthest_point_sampling
 
