@@ -405,6 +405,17 @@ int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out
 int mmf_out_ffn_qkv2(const float* const* layer26, const float* eps4, float* out_dev, const float* const* next14, float* q_heads_dev,
                      float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
 int mmf_split_linear_weight(const float* weight_dev, int out_features, int in_features, void* split_dev, void* stream);
+/* mmf_cross_layer: mmf_attention_heads_split and the block kernel that consumes its partials (mmf_out_ffn_mfma_partials, or with
+ * next7 != NULL mmf_out_ffn_qkv with roles 1) in ONE launch: the attention workgroups lead the grid and hand their partials to
+ * the block workgroup of their batch element as self-validating 64-bit words, which that workgroup polls after it has requested
+ * its weights (its start-up runs beside the attention).  layer13 / next7: as mmf_out_ffn_qkv (layer13[0] unused); qkv3 (HOST
+ * array): q_heads [B, H, 16, 16] of this layer, the context's k_heads [B, H, Lk16, 16] and v_heads_t [B, H, 16, Lk16];
+ * handover: B * H * 4 * 18 * 16 + 1 uint64 words on the device, zeroed by the caller once -- the last word becomes non-zero if
+ * a wait expired (a peer workgroup was not running: results undefined); tag: non-zero and different from every tag used on this
+ * buffer since it was zeroed (count the launches).  Lq <= 16. */
+int mmf_cross_layer(const float* const* layer13, float ln1_eps, float ln2_eps, float* out_dev, const float* const* next7,
+                    float* q_heads_next_dev, const float* const* qkv3, const uint8_t* key_padding16_dev, uint64_t* handover_dev, uint32_t tag,
+                    int B, int Lq, int Lk, int D, int H, void* stream);
 int mmf_attention_heads_split(const float* q_heads_dev, const float* k_heads_dev, const float* v_heads_t_dev, const uint8_t* key_padding_dev,
                               float* partials_dev, int B, int Lq, int Lk, int H, int head_dim, int* n_split_out, void* stream);
 int mmf_out_ffn_mfma_partials(const float* partials_dev, int n_split, const float* residual_dev, const float* Wo_dev, const float* bo_dev,

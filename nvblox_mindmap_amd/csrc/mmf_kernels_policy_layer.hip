@@ -30,6 +30,7 @@
 #include "mmf_device.h"
 #include "mmf_launch.h"
 #include "mmf_trace_device.h"
+#include "mmf_policy_attention.h"
 
 namespace mmf {
 
@@ -348,7 +349,11 @@ constexpr int kPartRows = 18;  // rows of one key-split attention partial: 16 ch
 struct AttPartials {            // k_attention_heads<.., SPLIT > 1> output to merge instead of reading `att` (null: read att)
   const float* part;            // [B, H, n_split, 18, 16]
   int n_split, Lq;              // Lq <= 16 query rows per batch element
+  const unsigned long long* tagged;  // the same as self-validating words {tag | f32 bits}, written by workgroups of THIS launch
+  unsigned tag;                      // (k_cross_layer); `part` is then any non-null pointer
+  int* fail;                         // set when the words do not arrive (a peer workgroup is not running)
 };
+constexpr unsigned kCrossSpinLimit = 1u << 22;
 
 struct OutFfnArgs {
   const float *att, *res;
@@ -472,6 +477,43 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
   __builtin_amdgcn_sched_barrier(0);
 
   if (AP.part != nullptr) {
+    const float* pbase = AP.part;
+    if (AP.tagged != nullptr) {
+      // the partials of this batch element come from workgroups of the same launch: poll their words (requested nine per thread
+      // at a time, checked afterwards; stale ones again) into the accumulation tiles' LDS, which nobody uses before GEMM 1
+      // (only the columns of the Lq live query rows are written and read)
+      float* stage = &S.acc[0][0][0];
+      const int words = kH * AP.n_split * kPartRows * 16, eb = (int)(t0 / AP.Lq), live = kH * AP.n_split * kPartRows * AP.Lq;
+      const unsigned long long* src = AP.tagged + (size_t)eb * words;
+      for (int e0 = tid; e0 < live; e0 += 9 * kNT) {
+        unsigned long long got[9];
+        int at[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const int e = min(e0 + i * kNT, live - 1);
+          at[i] = (e / AP.Lq) * 16 + e % AP.Lq;
+          got[i] = __hip_atomic_load(src + at[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          if (e0 + i * kNT < live) {
+            unsigned spins = 0;
+            while ((unsigned)(got[i] >> 32) != AP.tag) {
+              if (++spins > kCrossSpinLimit) {
+                *AP.fail = 1;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+              got[i] = __hip_atomic_load(src + at[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            stage[at[i]] = __uint_as_float((unsigned)got[i]);
+          }
+        }
+      }
+      __syncthreads();
+      pbase = stage;
+    }
+    const int eb_stage = AP.tagged != nullptr ? (int)(t0 / AP.Lq) : 0;  // (the staged partials are this batch element's alone)
     // the attention output of this tile, merged from the key splits: element (token, channel c = 15 h + ch) =
     // sum_sp e^(m_sp - M) O_sp[ch][row] / sum_sp e^(m_sp - M) l_sp, M = max_sp m_sp
     for (int e = tid; e < 16 * 128; e += kNT) {
@@ -480,7 +522,7 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
       float v = 0.0f;
       if (c < kD && tok < tokens) {
         const int eb = (int)(tok / AP.Lq), row = (int)(tok - (long long)eb * AP.Lq), h = c / kDH, ch = c - h * kDH;
-        const float* Pp = AP.part + ((size_t)eb * kH + h) * AP.n_split * kPartRows * 16;
+        const float* Pp = pbase + ((size_t)(eb - eb_stage) * kH + h) * AP.n_split * kPartRows * 16;
         float M = -INFINITY;
         for (int sp = 0; sp < AP.n_split; ++sp) M = fmaxf(M, Pp[(sp * kPartRows + 16) * 16 + row]);
         float num = 0.0f, den = 0.0f;
@@ -636,7 +678,7 @@ __global__ __launch_bounds__(kNT) void k_out_ffn_mfma(OutFfnArgs A, int L, long 
 
 __global__ __launch_bounds__(kNT) void k_out_ffn_mfma2(OutFfnArgs A0, OutFfnArgs A1, int L, long long tokens, int tiles) {
   __shared__ __attribute__((aligned(16))) TileLds S;
-  const AttPartials none{nullptr, 0, 0};
+  const AttPartials none{nullptr, 0, 0, nullptr, 0u, nullptr};
   if ((int)blockIdx.x >= tiles)
     out_ffn_tile<false, false, false>(A1, (long long)((int)blockIdx.x - tiles) * 16, tokens, L, S, none, QkvArgs{}, 0, 0, 0, 0);
   else
@@ -676,11 +718,47 @@ __global__ __launch_bounds__(kNT) void k_out_ffn_qkv(OutFfnArgs A, QkvArgs Q, in
 // two stacks: blocks [0, tiles) serve stack 0, [tiles, 2 tiles) stack 1
 __global__ __launch_bounds__(kNT) void k_out_ffn_qkv2(OutFfnArgs A0, OutFfnArgs A1, QkvArgs Q0, QkvArgs Q1, int L, int L16, int tiles) {
   __shared__ __attribute__((aligned(16))) TileLds S;
-  const AttPartials none{nullptr, 0, 0};
+  const AttPartials none{nullptr, 0, 0, nullptr, 0u, nullptr};
   if ((int)blockIdx.x >= tiles)
     out_ffn_qkv_body(A1, Q1, L, L16, 7, none, (int)blockIdx.x - tiles, S);
   else
     out_ffn_qkv_body(A0, Q0, L, L16, 7, none, (int)blockIdx.x, S);
+}
+
+// A cross-attention layer of a handful of query rows (Lq <= 16 per batch element) over a long cached context in ONE launch:
+//   blocks [0, B H kCrossSplit)   attention: k_attention_heads<16, 3, kCrossSplit> of (batch element, head, key split), the
+//                                 partial written as self-validating words {tag | f32 bits}
+//   blocks behind them, one per batch element: the block kernel (out_proj + LN + FFN + LN [+ the next layer's queries]), which
+//                                 requests its weights and operands, THEN polls the partials of its batch element -- its 2 us of
+//                                 start-up run beside the attention instead of behind a kernel boundary.
+// The producers never wait and lead the grid (workgroups are dispatched in index order), so a waiting consumer cannot keep a
+// producer off the chip; the wait is bounded and raises *fail.  `tag` must differ from every tag the buffer has seen since it was
+// last zeroed (the caller counts launches).
+constexpr int kCrossSplit = 4;
+struct CrossAtt {
+  const float *Qp, *Kp, *Vt;
+  const uint8_t* pad;
+  int Lq, Lk, Lk16;
+  float scale;
+};
+__global__ __launch_bounds__(kNT) void k_cross_layer(OutFfnArgs A, QkvArgs Q, CrossAtt C, unsigned long long* tagged, unsigned tag, int* fail,
+                                                    int B, int roles) {
+  __shared__ __attribute__((aligned(16))) TileLds S;
+  const int n_att = B * kH * kCrossSplit;
+  if ((int)blockIdx.x < n_att) {
+    const int split = (int)blockIdx.x % kCrossSplit, h = ((int)blockIdx.x / kCrossSplit) % kH, b = (int)blockIdx.x / (kCrossSplit * kH);
+    att::attention_body<16, 3, kCrossSplit>(C.Qp, C.Kp, C.Vt, C.pad, nullptr, tagged, tag, C.Lq, 16, C.Lk, C.Lk16, C.scale, split, 0, h, b,
+                                            *reinterpret_cast<att::AttLds*>(&S));
+    return;
+  }
+  const AttPartials AP{reinterpret_cast<const float*>(tagged), kCrossSplit, C.Lq, tagged, tag, fail};
+  const int tile = (int)blockIdx.x - n_att;  // = batch element: its Lq <= 16 rows are one tile
+  if (roles == 0) {
+    const long long t0 = (long long)tile * C.Lq;
+    out_ffn_tile<false, false, false>(A, t0, t0 + C.Lq, C.Lq, S, AP, QkvArgs{}, 0, 0, 0, 0);
+  } else {
+    out_ffn_qkv_body(A, Q, C.Lq, 16, roles, AP, tile, S);
+  }
 }
 
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_policy_layer)
@@ -734,7 +812,7 @@ int launch_out_ffn_mfma(const float* att, const float* res, const float* Wo, con
   if (D != kD) return 1;
   const long long tokens = (long long)B * L;
   OutFfnArgs A{att, res, W16(Wo), bo, g1, be1, ss, W16(W1), b1, W16(W2), b2, g2, be2, eps1, eps2, out};
-  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(kNT), 0, s, A, L, tokens, AttPartials{nullptr, 0, 0});
+  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(kNT), 0, s, A, L, tokens, AttPartials{nullptr, 0, 0, nullptr, 0u, nullptr});
   return 0;
 }
 
@@ -746,7 +824,7 @@ int launch_out_ffn_mfma_partials(const float* partials, int n_split, const float
   if (D != kD || L > 16 || n_split < 1) return 1;
   const long long tokens = (long long)B * L;
   OutFfnArgs A{partials, res, W16(Wo), bo, g1, be1, ss, W16(W1), b1, W16(W2), b2, g2, be2, eps1, eps2, out};
-  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(kNT), 0, s, A, L, tokens, AttPartials{partials, n_split, L});
+  hipLaunchKernelGGL(k_out_ffn_mfma, dim3((unsigned)((tokens + 15) / 16)), dim3(kNT), 0, s, A, L, tokens, AttPartials{partials, n_split, L, nullptr, 0u, nullptr});
   return 0;
 }
 
@@ -757,7 +835,21 @@ int launch_out_ffn_qkv(const float* const* args13, float eps1, float eps2, float
   const int L16 = (L + 15) / 16 * 16;
   const OutFfnArgs A = out_ffn_args(args13, eps1, eps2, out);
   const QkvArgs Q = qkv_args(next7, Qp, Kp, Vt);
-  hipLaunchKernelGGL(k_out_ffn_qkv, dim3(B * (L16 / 16)), dim3(kNT), 0, s, A, Q, L, L16, roles, AttPartials{partials, n_split, L});
+  hipLaunchKernelGGL(k_out_ffn_qkv, dim3(B * (L16 / 16)), dim3(kNT), 0, s, A, Q, L, L16, roles, AttPartials{partials, n_split, L, nullptr, 0u, nullptr});
+  return 0;
+}
+
+// args13 / next7 as launch_out_ffn_qkv (args13[0] unused; next7 null: no projection, roles 0); qkv3: the layer's head-major q,
+// the context's cached k, v (launch_qkv_heads roles 1 / 6); tagged: [B, H, 4, 18, 16] 64-bit words, zeroed once
+int launch_cross_layer(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp_next,
+                       const float* const* qkv3, const uint8_t* pad, unsigned long long* tagged, unsigned tag, int* fail, int B, int Lq,
+                       int Lk, int D, int H, hipStream_t s) {
+  if (D != kD || H != kH || Lq > 16 || Lq < 1) return 1;
+  const OutFfnArgs A = out_ffn_args(args13, eps1, eps2, out);
+  QkvArgs Q{};
+  if (next7) Q = qkv_args(next7, Qp_next, nullptr, nullptr);
+  const CrossAtt C{qkv3[0], qkv3[1], qkv3[2], pad, Lq, Lk, (Lk + 15) / 16 * 16, 1.0f / sqrtf((float)kDH)};
+  hipLaunchKernelGGL(k_cross_layer, dim3(B * kH * kCrossSplit + B), dim3(kNT), 0, s, A, Q, C, tagged, tag, fail, B, next7 ? 1 : 0);
   return 0;
 }
 

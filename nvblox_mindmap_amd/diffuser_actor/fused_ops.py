@@ -179,6 +179,7 @@ def out_ffn_block(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) 
 
 # ---- matrix-core forms (mmf_kernels_policy_mfma.hip): head-major q / k / v, attention over them, out_proj + LN + FFN ----------
 MFMA_DIMS = (120, 8)  # (embedding dim, heads) the MFMA kernels are built for
+FUSE_CROSS_LAYER = True  # split cross-attention + the block kernel behind it in one launch (mmf_cross_layer)
 FUSE_OUT_FFN_QKV = True  # layer i's tail and layer i + 1's q | k | v in one launch (mmf_out_ffn_qkv / mmf_out_ffn_qkv2)
 
 
@@ -340,6 +341,56 @@ def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, ne
                                           _lib.dptr(q), _lib.dptr(k), _lib.dptr(v), B, L, D, heads, roles, _lib.dptr(partials),
                                           0 if partials is None else partials.shape[2], _lib.stream_ptr(dev)), "mmf_out_ffn_qkv")
     return out, q, k, v
+
+
+class CrossHandover:
+    """The hand-over buffer of ``cross_layer`` (B x H x 4 partials as self-validating 64-bit words + a failure word) and the
+    launch counter that tags them.  One per attention stack and inference shape; zeroed when made."""
+
+    def __init__(self, B: int, heads: int, device):
+        self.words = torch.zeros(B * heads * 4 * 18 * 16 + 1, dtype=torch.int64, device=device)
+        self.tag = 0
+        self.B = B
+
+    def next_tag(self) -> int:
+        self.tag = self.tag % 0x7FFFFFFF + 1
+        return self.tag
+
+    def failed(self) -> bool:
+        return bool(self.words[-1].item())
+
+
+def cross_layer(q_heads, k_heads, v_heads_t, Lq: int, Lk: int, mask16, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, handover,
+                next_scale_shift=None, next_q_proj=None, rot=None, heads: int = 8, out: Optional[torch.Tensor] = None):
+    """``attention_heads_split`` + ``out_ffn_mfma`` (or, with ``next_q_proj``, ``out_ffn_qkv`` producing the next layer's queries)
+    in ONE launch (mmf_cross_layer): Lq <= 16 query rows per batch element over a cached context.  Returns out [B, Lq, D] or
+    (out, next q_heads)."""
+    import ctypes as Ct
+
+    residual = residual.contiguous()
+    B, L, D = residual.shape
+    assert L == Lq and Lq <= 16 and handover.B == B
+    dev = residual.device
+    if out is None:
+        out = torch.empty_like(residual)
+    else:
+        assert out.shape == residual.shape and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() != residual.data_ptr()
+    layer = [None, residual, _w(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(scale_shift), _w(fc1), _c(fc1.bias),
+             _w(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+    a13 = (Ct.c_void_p * 13)(*[None if t is None else t.data_ptr() for t in layer])
+    qn = None
+    a7 = None
+    if next_q_proj is not None:
+        qn = torch.empty((B, heads, 16, 16), dtype=torch.float32, device=dev)
+        cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+        nxt = [_c(next_scale_shift), _w(next_q_proj), _c(next_q_proj.bias), None, None, cs, sn]
+        a7 = (Ct.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in nxt])
+    q3 = (Ct.c_void_p * 3)(q_heads.data_ptr(), k_heads.data_ptr(), v_heads_t.data_ptr())
+    _lib.check(_lib.lib().mmf_cross_layer(Ct.cast(a13, Ct.c_void_p), float(norm1.eps), float(norm2.eps), _lib.dptr(out),
+                                          None if a7 is None else Ct.cast(a7, Ct.c_void_p), _lib.dptr(qn), Ct.cast(q3, Ct.c_void_p), _lib.dptr(mask16),
+                                          _lib.dptr(handover.words), handover.next_tag(), B, Lq, Lk, D, heads, _lib.stream_ptr(dev)),
+               "mmf_cross_layer")
+    return out if qn is None else (out, qn)
 
 
 def _ptr_array(tensors):

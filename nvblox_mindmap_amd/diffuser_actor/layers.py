@@ -245,9 +245,11 @@ class AttentionStack(nn.Module):
         self.ffw = nn.ModuleList([FeedForwardBlock(dim, dim, dropout, use_adaln) for _ in range(num_layers)])
 
     def forward(self, query, memory=None, cond=None, q_rot=None, kv_rot=None, key_padding_mask=None, need_weights=False,
-                cond_act=None, kv_caches=None, key_padding_mask16=None, out_last=None):
+                cond_act=None, kv_caches=None, key_padding_mask16=None, out_last=None, handover=None):
         """out_last: contiguous [B, L, D] destination of the last layer's output (matrix-core cross-attention path only; the
         caller checks that the returned tensor is it).
+        handover: a fused_ops.CrossHandover made (zeroed) for THIS inference: the split cross-attention of a layer and the block
+        kernel behind it run as one launch (fused_ops.cross_layer).
         key_padding_mask16: fused_ops.pad_mask16(key_padding_mask) if the caller keeps it (matrix-core attention path).
         cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
         is constant across calls (cross-attention at inference)."""
@@ -293,6 +295,19 @@ class AttentionStack(nn.Module):
                         qh, _, _ = FO.qkv_heads(query, ss_of(blk.adaln), A.q_proj, None, q_rot, A.heads, roles=1)
                     else:
                         qh = qh_next
+                    last = li + 1 == len(self.attn)
+                    if (handover is not None and FO.FUSE_CROSS_LAYER and query.shape[1] <= 16 and Lk >= 1536
+                            and (key_padding_mask is None or key_padding_mask16 is not None)):
+                        # ... and the block kernel behind the split attention in the same launch
+                        if last:
+                            query = FO.cross_layer(qh, kh, vt, query.shape[1], Lk, key_padding_mask16, query, A.out_proj, blk.norm,
+                                                   ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm, handover, heads=A.heads, out=out_last)
+                        else:
+                            nb = self.attn[li + 1]
+                            query, qh_next = FO.cross_layer(qh, kh, vt, query.shape[1], Lk, key_padding_mask16, query, A.out_proj, blk.norm,
+                                                            ss_of(ffw.adaln), ffw.fc1, ffw.fc2, ffw.norm, handover, ss_of(nb.adaln),
+                                                            nb.attn.q_proj, q_rot, A.heads)
+                        continue
                     if query.shape[1] <= 16 and Lk >= 1536 and (key_padding_mask is None or key_padding_mask16 is not None):
                         # a handful of query rows over a long context: keys split over several workgroups, merged by the next launch
                         att = FO.attention_heads_split(qh, kh, vt, query.shape[1], Lk, key_padding_mask16)

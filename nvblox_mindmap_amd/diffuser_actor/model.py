@@ -212,6 +212,9 @@ class DiffusionHead(nn.Module):
 
                 P["cross_kv"] = [blk.attn.project_kv_heads(ctx_feats, P["ctx_rot"]) for blk in self.cross_attn.attn]
                 P["ctx_pad16"] = pad_mask16(P["ctx_pad"])
+                from .fused_ops import CrossHandover
+
+                P["cross_handover"] = CrossHandover(ctx_feats.shape[0], self.cfg.num_attn_heads, ctx_feats.device)  # zeroed per inference
             if D in layers_mod._block_dims():
                 # step-invariant parts of the step's sequence-wide tensors: the sub-sampled context rows of the token
                 # sequence, of its rotary tables and of its padding mask are filled once; a step rewrites the trajectory rows
@@ -307,7 +310,7 @@ class DiffusionHead(nn.Module):
         head_rows = seq[:, :nt]  # batch 1: a contiguous view -- the cross-attention stack's last launch writes it directly
         tokens, _ = self.cross_attn(tokens, P["ctx_feats"], cond, traj_rot, P["ctx_rot"], key_padding_mask=P["ctx_pad"], cond_act=ada,
                                     kv_caches=P["cross_kv"], key_padding_mask16=P.get("ctx_pad16"),
-                                    out_last=head_rows if head_rows.is_contiguous() else None)
+                                    out_last=head_rows if head_rows.is_contiguous() else None, handover=P.get("cross_handover"))
         if tokens.data_ptr() != head_rows.data_ptr():
             head_rows.copy_(tokens)
         seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)

@@ -524,6 +524,17 @@ def test_mfma_cross_attention_over_a_long_context():
             a = FO.out_ffn_mfma(full, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
             b = FO.out_ffn_mfma(part, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm)
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+            # ... and both halves in ONE launch (mmf_cross_layer: the partials handed over inside the launch): identical, call
+            # after call on the same hand-over buffer, with and without the next layer's query projection
+            ho = FO.CrossHandover(B, H, x.device)
+            for _ in range(3):
+                c = FO.cross_layer(qh, kh, vt, Lq, n, mask16, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm, ho, heads=H)
+                assert torch.equal(c, b)
+                b2, q2, _, _ = FO.out_ffn_qkv(part, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm, ss, A.q_proj, None, q_rot, H)
+                c2, cq = FO.cross_layer(qh, kh, vt, Lq, n, mask16, x, blk.attn.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm, ho, ss,
+                                        A.q_proj, q_rot, H)
+                assert torch.equal(c2, b2) and torch.equal(cq, q2)
+            assert not ho.failed()
 
 
 def test_paired_stacks_equal_the_two_stacks_run_separately():
