@@ -413,6 +413,12 @@ int mmf_split_linear_weight(const float* weight_dev, int out_features, int in_fe
  * handover: B * H * 4 * 18 * 16 + 1 uint64 words on the device, zeroed by the caller once -- the last word becomes non-zero if
  * a wait expired (a peer workgroup was not running: results undefined); tag: non-zero and different from every tag used on this
  * buffer since it was zeroed (count the launches).  Lq <= 16. */
+/* mmf_self_layer: a SELF-attention layer in one launch, the same way -- mmf_attention_heads of this layer's q / k / v (qkv3), its
+ * output rows handed to the block workgroups (mmf_out_ffn_mfma, or with next7 != NULL mmf_out_ffn_qkv with roles 7 producing the
+ * NEXT layer's q / k / v) as self-validating words.  handover: B * L * D + 1 uint64 words, zeroed once; tag as below. */
+int mmf_self_layer(const float* const* layer13, float ln1_eps, float ln2_eps, float* out_dev, const float* const* next7, float* q_heads_next_dev,
+                   float* k_heads_next_dev, float* v_heads_t_next_dev, const float* const* qkv3, const uint8_t* key_padding16_dev,
+                   uint64_t* handover_dev, uint32_t tag, int B, int L, int D, int H, void* stream);
 int mmf_cross_layer(const float* const* layer13, float ln1_eps, float ln2_eps, float* out_dev, const float* const* next7,
                     float* q_heads_next_dev, const float* const* qkv3, const uint8_t* key_padding16_dev, uint64_t* handover_dev, uint32_t tag,
                     int B, int Lq, int Lk, int D, int H, void* stream);

@@ -2313,6 +2313,24 @@ int mmf_cross_layer(const float* const* layer13, float ln1_eps, float ln2_eps, f
   return check_launch();
 }
 
+int mmf_self_layer(const float* const* layer13, float ln1_eps, float ln2_eps, float* out, const float* const* next7, float* q_heads_next,
+                   float* k_heads_next, float* v_heads_t_next, const float* const* qkv3, const uint8_t* key_padding16, uint64_t* handover,
+                   uint32_t tag, int B, int L, int D, int H, void* stream) {
+  if (!layer13 || !out || !qkv3 || !qkv3[0] || !qkv3[1] || !qkv3[2] || !handover || tag == 0 || B <= 0 || L <= 0 ||
+      (next7 && (!q_heads_next || !k_heads_next || !v_heads_t_next)))
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_self_layer");
+  for (int i = 1; i < 13; ++i)
+    if (i != 6 && !layer13[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_self_layer: missing layer operand");  // [0] unused, [6] = scale_shift, optional
+  if (next7 && (!next7[1] || !next7[2] || !next7[3] || !next7[4] || ((next7[5] == nullptr) != (next7[6] == nullptr))))
+    return fail(MMF_ERR_INVALID_ARG, "mmf_self_layer: missing next-layer operand");
+  const size_t words = (size_t)B * L * D;
+  if (launch_self_layer(layer13, ln1_eps, ln2_eps, out, next7, q_heads_next, k_heads_next, v_heads_t_next, qkv3, key_padding16,
+                        reinterpret_cast<unsigned long long*>(handover), tag, reinterpret_cast<int*>(handover + words), B, L, D, H,
+                        (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_self_layer is built for D = 120, H = 8");
+  return check_launch();
+}
+
 int mmf_split_linear_weight(const float* weight, int out_features, int in_features, void* split, void* stream) {
   if (!weight || !split || out_features <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_linear_weight");
   if (launch_split_weight(weight, out_features, in_features, split, (hipStream_t)stream) != 0)

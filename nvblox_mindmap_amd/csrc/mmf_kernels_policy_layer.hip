@@ -445,7 +445,8 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
   // of 128 floats, two floats per lane, so that the choice of the row's source is scalar work), the wave's share of the three
   // weight matrices (12 pieces per lane).
   float av[8];
-  if (grp == 0 && AP.part == nullptr) load8(A.att + ltokc * kD + c0, av);
+  const bool att_tagged = AP.part == nullptr && AP.tagged != nullptr;  // the attention output arrives inside this launch (k_self_layer)
+  if (grp == 0 && AP.part == nullptr && !att_tagged) load8(A.att + ltokc * kD + c0, av);
   constexpr int kNVec = QKV ? kVecRows : 7, kNTok = QKV ? kTokRows : 3, kRows = kNVec + 16 * kNTok, kPer = (kRows + 15) / 16;
   const int wv = __builtin_amdgcn_readfirstlane(w);
   float2 opv[kPer];
@@ -540,6 +541,25 @@ __device__ __forceinline__ void out_ffn_tile(const OutFfnArgs& A, long long t0, 
     if (grp == 0) load8(&S.sH[tl][c0], av);
   }
   if (grp == 0) {
+    if (att_tagged && live) {  // the lane's 8 channels: 8 words from (up to 2) attention workgroups of this launch
+      const unsigned long long* src = AP.tagged + ltok * kD + 8 * q;
+      unsigned long long got[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) got[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        unsigned spins = 0;
+        while ((unsigned)(got[i] >> 32) != AP.tag) {
+          if (++spins > kCrossSpinLimit) {
+            *AP.fail = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          got[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        av[i] = __uint_as_float((unsigned)got[i]);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) av[t] = live ? av[t] : 0.0f;
     store_piece(S.P0, tl, 8 * q, av);
@@ -761,6 +781,44 @@ __global__ __launch_bounds__(kNT) void k_cross_layer(OutFfnArgs A, QkvArgs Q, Cr
   }
 }
 
+// A SELF-attention layer in one launch, the same way: the attention workgroups lead the grid -- two (query tile, head) units of 8
+// waves each per 16-wave workgroup -- and write their output rows as tagged words; the block workgroup of a tile sits behind
+// them, requests its weights and operands, and then each of its piece lanes polls the 8 words it owns.
+struct SelfAtt {
+  const float *Qp, *Kp, *Vt;
+  const uint8_t* pad;
+  int L, L16;
+  float scale;
+};
+__device__ __forceinline__ void self_layer_attention(const SelfAtt& C, unsigned long long* tagged, unsigned tag, int units, int blk, TileLds& S) {
+  const int tiles = C.L16 / 16, half = (int)threadIdx.x >> 9;
+  const int u = min(2 * blk + half, units - 1);  // (an odd count: the last unit is computed twice, with identical stores)
+  const int tile = u % tiles, h = (u / tiles) % kH, b = u / (tiles * kH);
+  att::AttLds* LD = reinterpret_cast<att::AttLds*>(&S) + half;
+  att::attention_body<8, 5, 1>(C.Qp, C.Kp, C.Vt, C.pad, nullptr, tagged, tag, C.L, C.L16, C.L, C.L16, C.scale, 0, tile * 16, h, b, *LD, half * 8);
+}
+__global__ __launch_bounds__(kNT) void k_self_layer(OutFfnArgs A, QkvArgs Q, SelfAtt C, unsigned long long* tagged, unsigned tag, int* fail,
+                                                   int B, int roles) {
+  __shared__ __attribute__((aligned(16))) TileLds S;
+  const int tiles = C.L16 / 16, units = tiles * kH * B, n_att = (units + 1) / 2;
+  if ((int)blockIdx.x < n_att) {
+    self_layer_attention(C, tagged, tag, units, (int)blockIdx.x, S);
+    return;
+  }
+  const AttPartials AP{nullptr, 0, 0, tagged, tag, fail};
+  const int tile = (int)blockIdx.x - n_att;
+  if (roles == 0) {
+    const int b = tile / tiles, l0 = (tile % tiles) * 16;
+    out_ffn_tile<false, false, false>(A, (long long)b * C.L + l0, (long long)(b + 1) * C.L, C.L, S, AP, QkvArgs{}, 0, 0, 0, 0);
+  } else {
+    out_ffn_qkv_body(A, Q, C.L, C.L16, roles, AP, tile, S);
+  }
+}
+
+// (The two-stack form of this was built and measured: 624 attention units = 312 workgroups of 1 024 threads + 78 block workgroups
+// do not fit the chip at once, the block workgroups -- last in the grid -- start behind the first attention workgroups instead of
+// beside them: 23.4 us against 22.4 / 15.9 us for the separate launches.  Removed.)
+
 MMF_DEFINE_WG_TRACE_SETTER(set_wg_trace_policy_layer)
 
 // ---- launchers (weights: split fp16 matrices of launch_split_weight) ------------------------------------------------------------
@@ -850,6 +908,21 @@ int launch_cross_layer(const float* const* args13, float eps1, float eps2, float
   if (next7) Q = qkv_args(next7, Qp_next, nullptr, nullptr);
   const CrossAtt C{qkv3[0], qkv3[1], qkv3[2], pad, Lq, Lk, (Lk + 15) / 16 * 16, 1.0f / sqrtf((float)kDH)};
   hipLaunchKernelGGL(k_cross_layer, dim3(B * kH * kCrossSplit + B), dim3(kNT), 0, s, A, Q, C, tagged, tag, fail, B, next7 ? 1 : 0);
+  return 0;
+}
+
+// A self-attention layer: args13 / next7 as launch_out_ffn_qkv (args13[0] unused; next7 null: no projections), qkv3: this
+// layer's head-major q, k, v; Qp / Kp / Vt: the next layer's; tagged: [B, L, D] 64-bit words, zeroed once
+int launch_self_layer(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp, float* Vt,
+                      const float* const* qkv3, const uint8_t* pad, unsigned long long* tagged, unsigned tag, int* fail, int B, int L, int D,
+                      int H, hipStream_t s) {
+  if (D != kD || H != kH) return 1;
+  const int L16 = (L + 15) / 16 * 16, tiles = L16 / 16;
+  const OutFfnArgs A = out_ffn_args(args13, eps1, eps2, out);
+  QkvArgs Q{};
+  if (next7) Q = qkv_args(next7, Qp, Kp, Vt);
+  const SelfAtt C{qkv3[0], qkv3[1], qkv3[2], pad, L, L16, 1.0f / sqrtf((float)kDH)};
+  hipLaunchKernelGGL(k_self_layer, dim3((tiles * kH * B + 1) / 2 + tiles * B), dim3(kNT), 0, s, A, Q, C, tagged, tag, fail, B, next7 ? 7 : 0);
   return 0;
 }
 

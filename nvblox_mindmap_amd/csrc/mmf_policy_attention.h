@@ -62,18 +62,20 @@ struct AttLds {
   float sO[16][16][17];
 };
 
-// One (query tile, head[, key split]) of a batch element by the NW waves of a workgroup.  SPLIT > 1: partial {O^T, maxima, sums} to
-// `out` ([B, H, SPLIT, 18, 16] floats), or -- `tagged` != null -- to the same positions of a buffer of self-validating 64-bit
-// words {tag | f32 bits} that a workgroup of the SAME launch polls (relaxed agent-scope stores, no fence: k_cross_layer).
+// One (query tile, head[, key split]) of a batch element by NW waves of a workgroup (its waves wave_base .. wave_base + NW - 1;
+// every wave of the workgroup must run a unit: the merge has a workgroup barrier).  SPLIT > 1: partial {O^T, maxima, sums} to
+// `out` ([B, H, SPLIT, 18, 16] floats); SPLIT == 1: the output rows to `out` [B, Lq, D].  `tagged` != null: to the same positions
+// of a buffer of self-validating 64-bit words {tag | f32 bits} instead, which a workgroup of the SAME launch polls (relaxed
+// agent-scope stores, no fence: k_cross_layer, k_self_layer).
 template <int NW, int CH, int SPLIT>
 __device__ __forceinline__ void attention_body(const float* __restrict__ Qp, const float* __restrict__ Kp, const float* __restrict__ Vt,
                                                const uint8_t* __restrict__ pad, float* __restrict__ out, unsigned long long* tagged,
                                                unsigned tag, int Lq, int Lq16, int Lk, int Lk16, float scale, int split, int q0, int h,
-                                               int b, AttLds& LD) {
+                                               int b, AttLds& LD, int wave_base = 0) {
   float (&sM)[16][16] = LD.sM;
   float (&sL)[16][16] = LD.sL;
   float (&sO)[16][16][17] = LD.sO;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, s = lane >> 4;
+  const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6) - wave_base, j = lane & 15, s = lane >> 4;  // (wave_base: the unit's first wave)
   const size_t bh = (size_t)b * kH + h;
 
   MMF_PT(kPtAtt, 0, 0.0f);
@@ -196,8 +198,13 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ Qp, con
                                ((unsigned long long)tag << 32) | __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else
           part[ch * 16 + j] = o;
-      } else if (ch < kDH && row < Lq)
-        out[((size_t)b * Lq + row) * kD + h * kDH + ch] = o / l;
+      } else if (ch < kDH && row < Lq) {
+        const size_t at = ((size_t)b * Lq + row) * kD + h * kDH + ch;
+        if (tagged)  // (SPLIT == 1: the attention output itself, handed to a block workgroup of the same launch)
+          __hip_atomic_store(tagged + at, ((unsigned long long)tag << 32) | __float_as_uint(o / l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          out[at] = o / l;
+      }
     }
     if (SPLIT > 1 && s == 0) {
       if (tagged && j >= Lq) {

@@ -179,6 +179,7 @@ def out_ffn_block(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2) 
 
 # ---- matrix-core forms (mmf_kernels_policy_mfma.hip): head-major q / k / v, attention over them, out_proj + LN + FFN ----------
 MFMA_DIMS = (120, 8)  # (embedding dim, heads) the MFMA kernels are built for
+FUSE_SELF_LAYER = True  # self-attention + the block kernel behind it (+ the next projections) in one launch (mmf_self_layer)
 FUSE_CROSS_LAYER = True  # split cross-attention + the block kernel behind it in one launch (mmf_cross_layer)
 FUSE_OUT_FFN_QKV = True  # layer i's tail and layer i + 1's q | k | v in one launch (mmf_out_ffn_qkv / mmf_out_ffn_qkv2)
 
@@ -343,12 +344,13 @@ def out_ffn_qkv(att, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, ne
     return out, q, k, v
 
 
-class CrossHandover:
-    """The hand-over buffer of ``cross_layer`` (B x H x 4 partials as self-validating 64-bit words + a failure word) and the
-    launch counter that tags them.  One per attention stack and inference shape; zeroed when made."""
+class Handover:
+    """A hand-over buffer of the one-launch layer kernels (``cross_layer`` / ``self_layer``: self-validating 64-bit
+    words + a failure word) and the launch counter that tags them.  Make (= zero) one per inference and stack: a replayed HIP graph
+    repeats its tags, so the zeroing must be part of what is replayed."""
 
-    def __init__(self, B: int, heads: int, device):
-        self.words = torch.zeros(B * heads * 4 * 18 * 16 + 1, dtype=torch.int64, device=device)
+    def __init__(self, nwords: int, B: int, device):
+        self.words = torch.zeros(nwords + 1, dtype=torch.int64, device=device)
         self.tag = 0
         self.B = B
 
@@ -358,6 +360,47 @@ class CrossHandover:
 
     def failed(self) -> bool:
         return bool(self.words[-1].item())
+
+
+def CrossHandover(B: int, heads: int, device) -> Handover:
+    """for ``cross_layer``: B x H x 4 partials of 18 x 16 words"""
+    return Handover(B * heads * 4 * 18 * 16, B, device)
+
+
+def SelfHandover(B: int, L: int, D: int, device) -> Handover:
+    """for ``self_layer``: the attention output rows [B, L, D] as words"""
+    return Handover(B * L * D, B, device)
+
+
+def self_layer(q_heads, k_heads, v_heads_t, L: int, mask16, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, handover,
+               next_scale_shift=None, next_q_proj=None, next_kv_proj=None, rot=None, heads: int = 8):
+    """``attention_heads`` + ``out_ffn_mfma`` (or, with ``next_q_proj`` / ``next_kv_proj``, ``out_ffn_qkv`` producing the next
+    layer's q | k | v) in ONE launch (mmf_self_layer).  Returns out [B, L, D] or (out, q_heads, k_heads, v_heads_t)."""
+    import ctypes as Ct
+
+    residual = residual.contiguous()
+    B, L_, D = residual.shape
+    assert L_ == L and handover.B == B and handover.words.numel() == B * L * D + 1
+    dev = residual.device
+    L16 = _l16(L)
+    out = torch.empty_like(residual)
+    layer = [None, residual, _w(out_proj), _c(out_proj.bias), _c(norm1.weight), _c(norm1.bias), _c(scale_shift), _w(fc1), _c(fc1.bias),
+             _w(fc2), _c(fc2.bias), _c(norm2.weight), _c(norm2.bias)]
+    a13 = (Ct.c_void_p * 13)(*[None if t is None else t.data_ptr() for t in layer])
+    q = k = v = a7 = None
+    if next_q_proj is not None:
+        q = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev)
+        k = torch.empty((B, heads, L16, 16), dtype=torch.float32, device=dev)
+        v = torch.empty((B, heads, 16, L16), dtype=torch.float32, device=dev)
+        cs, sn = (None, None) if rot is None else (rot[0].expand(B, L, D).contiguous(), rot[1].expand(B, L, D).contiguous())
+        nxt = [_c(next_scale_shift), _w(next_q_proj), _c(next_q_proj.bias), _w(next_kv_proj), _c(next_kv_proj.bias), cs, sn]
+        a7 = (Ct.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in nxt])
+    q3 = (Ct.c_void_p * 3)(q_heads.data_ptr(), k_heads.data_ptr(), v_heads_t.data_ptr())
+    _lib.check(_lib.lib().mmf_self_layer(Ct.cast(a13, Ct.c_void_p), float(norm1.eps), float(norm2.eps), _lib.dptr(out),
+                                         None if a7 is None else Ct.cast(a7, Ct.c_void_p), _lib.dptr(q), _lib.dptr(k), _lib.dptr(v),
+                                         Ct.cast(q3, Ct.c_void_p), _lib.dptr(mask16), _lib.dptr(handover.words), handover.next_tag(), B, L, D, heads,
+                                         _lib.stream_ptr(dev)), "mmf_self_layer")
+    return out if q is None else (out, q, k, v)
 
 
 def cross_layer(q_heads, k_heads, v_heads_t, Lq: int, Lk: int, mask16, residual, out_proj, norm1, scale_shift, fc1, fc2, norm2, handover,

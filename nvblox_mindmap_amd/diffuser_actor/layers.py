@@ -248,8 +248,8 @@ class AttentionStack(nn.Module):
                 cond_act=None, kv_caches=None, key_padding_mask16=None, out_last=None, handover=None):
         """out_last: contiguous [B, L, D] destination of the last layer's output (matrix-core cross-attention path only; the
         caller checks that the returned tensor is it).
-        handover: a fused_ops.CrossHandover made (zeroed) for THIS inference: the split cross-attention of a layer and the block
-        kernel behind it run as one launch (fused_ops.cross_layer).
+        handover: a fused_ops.CrossHandover (cross-attention stack) / SelfHandover (self-attention stack) made (zeroed) for THIS
+        inference: the attention of a layer and the block kernel behind it run as one launch (fused_ops.cross_layer / self_layer).
         key_padding_mask16: fused_ops.pad_mask16(key_padding_mask) if the caller keeps it (matrix-core attention path).
         cond_act: F.silu(cond), shared by every AdaLN of the pass; kv_caches: per-layer (keys, values) of a memory that
         is constant across calls (cross-attention at inference)."""
@@ -272,6 +272,17 @@ class AttentionStack(nn.Module):
                 qh, kh, vt = FO.qkv_heads(query, ss_of(self.attn[0].adaln), A0.q_proj, A0.kv_proj, q_rot, A0.heads)
                 for li, (blk, ffw) in enumerate(zip(self.attn, self.ffw)):
                     A = blk.attn
+                    if handover is not None and FO.FUSE_SELF_LAYER and (key_padding_mask is None or key_padding_mask16 is not None):
+                        # attention + block (+ the next layer's projections) in one launch
+                        if li + 1 < n:
+                            nb = self.attn[li + 1]
+                            query, qh, kh, vt = FO.self_layer(qh, kh, vt, L_, key_padding_mask16, query, A.out_proj, blk.norm, ss_of(ffw.adaln),
+                                                              ffw.fc1, ffw.fc2, ffw.norm, handover, ss_of(nb.adaln), nb.attn.q_proj,
+                                                              nb.attn.kv_proj, q_rot, A.heads)
+                        else:
+                            query = FO.self_layer(qh, kh, vt, L_, key_padding_mask16, query, A.out_proj, blk.norm, ss_of(ffw.adaln), ffw.fc1,
+                                                  ffw.fc2, ffw.norm, handover, heads=A.heads)
+                        continue
                     att = FO.attention_heads(qh, kh, vt, key_padding_mask, L_, L_, key_padding_mask16)
                     if li + 1 < n and FO.FUSE_OUT_FFN_QKV:
                         nb = self.attn[li + 1]

@@ -225,6 +225,10 @@ class DiffusionHead(nn.Module):
                 P["seq_cos"] = torch.cat([head, P["fps_rot"][0].expand(B, -1, D)], dim=1)
                 P["seq_sin"] = torch.cat([head, P["fps_rot"][1].expand(B, -1, D)], dim=1)
                 P["seq_pad"] = torch.cat([torch.zeros((B, nt), dtype=torch.bool, device=dev), P["fps_pad"]], dim=1)
+                if P.get("cross_handover") is not None:  # (matrix-core path) hand-over buffers of the one-launch self-attention layers
+                    from .fused_ops import SelfHandover
+
+                    P["self_handover"] = SelfHandover(B, P["seq"].shape[1], D, dev)
                 if P.get("ctx_pad16") is not None:
                     from .fused_ops import pad_mask16
 
@@ -313,7 +317,8 @@ class DiffusionHead(nn.Module):
                                     out_last=head_rows if head_rows.is_contiguous() else None, handover=P.get("cross_handover"))
         if tokens.data_ptr() != head_rows.data_ptr():
             head_rows.copy_(tokens)
-        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)
+        seq, _ = self.self_attn(seq, None, cond, seq_rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16,
+                                handover=P.get("self_handover"))
         # the two output stacks are independent and of identical shape
         from . import fused_ops as FO
 

@@ -420,6 +420,21 @@ def test_mfma_layer_kernels_match_the_channel_kernels(B, L):
                 out2, q2, k2, v2 = FO.out_ffn_qkv(att, x, A.out_proj, blk.norm, ss, ffw.fc1, ffw.fc2, ffw.norm, nss, A.q_proj, A.kv_proj, r, H)
                 q3, k3, v3 = FO.qkv_heads(got, nss, A.q_proj, A.kv_proj, r, H)
                 assert torch.equal(out2, got) and torch.equal(q2, q3) and torch.equal(k2, k3) and torch.equal(v2, v3)
+        # ... and the attention in the same launch as well (mmf_self_layer: its output rows handed over inside the launch):
+        # identical to the separate launches, call after call on one hand-over buffer
+        ho = FO.SelfHandover(B, L, D, x.device)
+        mask16 = FO.pad_mask16(pad)
+        for m16 in (mask16, None):
+            a3 = FO.attention_heads(qh, kh, vt, None if m16 is None else pad, L, L, m16)
+            ref1 = FO.out_ffn_mfma(a3, x, A.out_proj, blk.norm, ss2, ffw.fc1, ffw.fc2, ffw.norm)
+            ref2 = FO.out_ffn_qkv(a3, x, A.out_proj, blk.norm, ss2, ffw.fc1, ffw.fc2, ffw.norm, ss1, A.q_proj, A.kv_proj, rot, H)
+            for _ in range(2):
+                got1 = FO.self_layer(qh, kh, vt, L, m16, x, A.out_proj, blk.norm, ss2, ffw.fc1, ffw.fc2, ffw.norm, ho, heads=H)
+                assert torch.equal(got1, ref1), float((got1 - ref1).abs().max())
+                got2 = FO.self_layer(qh, kh, vt, L, m16, x, A.out_proj, blk.norm, ss2, ffw.fc1, ffw.fc2, ffw.norm, ho, ss1, A.q_proj, A.kv_proj,
+                                     rot, H)
+                assert all(torch.equal(g, r_) for g, r_ in zip(got2, ref2))
+        assert not ho.failed()
 
 
 @pytest.mark.parametrize("B,G", [(1, 2), (2, 1), (2, 3)])
@@ -561,9 +576,13 @@ def test_paired_stacks_equal_the_two_stacks_run_separately():
             ref = [st(x, None, cond, rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16)[0] for st in stacks]
             got = FO.paired_self_attention_stacks(stacks[0], stacks[1], x, lambda a: None if a is None else ada.lookup(a), rot,
                                                   torch.cat([pad16, pad16], dim=0), H)
+            # ... with every layer's attention in the same launch as its block (mmf_self_layer) through the stack's own forward
+            ho1 = FO.SelfHandover(B, L, D, x.device)
+            ref_one_launch = [st(x, None, cond, rot, key_padding_mask=pad, cond_act=ada, key_padding_mask16=pad16, handover=ho1)[0] for st in stacks]
+            assert not ho1.failed()
         finally:
             Ly.FUSED_INFERENCE = False
         composite = [st(x, None, cond, rot, key_padding_mask=pad)[0] for st in stacks]
-    for g, r, c in zip(got, ref, composite):
-        assert torch.equal(g, r)
+    for g, r, c, r1 in zip(got, ref, composite, ref_one_launch):
+        assert torch.equal(g, r) and torch.equal(r1, r)
         assert torch.allclose(g, c, rtol=2e-4, atol=2e-5), float((g - c).abs().max())
