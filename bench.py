@@ -732,7 +732,7 @@ def measure_d2d_copy(device, mib=1024, iters=10):
     return 2.0 * mib * 1024 * 1024 / sec / 1e9
 
 
-def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_matmul_dtype="float32", prefetch_backbone=False):
+def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_matmul_dtype="float16x3", prefetch_backbone=False):
     """Policy training step/s (second half of the BASELINE metric; config 5): diffuser_actor, RGBD_AND_MESH, per-GPU batch 32,
     one 512x512 camera, 2048 vertices x 768 features, frozen ViT-B/16-shaped backbone (random-init stand-in for RADIO v2.5-B),
     fp32, synthetic cached-sample-shaped batches resident on the GPU; DDP (RCCL all-reduce) when world > 1."""
@@ -772,6 +772,7 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     out = {"step_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "samples_per_s": steps * per_gpu_batch * world / dt,
            "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup,
            "trainable_params": n_train, "frozen_backbone_params": n_frozen, "dtype": "f32", "backbone_prefetch": bool(prefetch_backbone),
+           "backbone_matmuls": backbone_matmul_dtype,
            "allreduce_payload_MB": n_train * 4 / 1e6, "parallelism": f"dp{world}" if world > 1 else "single",
            "model": "diffuser_actor RGBD_AND_MESH, 1 cam 512x512, 2048 vertices x 768, frozen ViT-B/16-shaped backbone (random init)"}
     del model, ddp, opt, batches
@@ -1202,6 +1203,10 @@ def main():
             # stream beside the trainable pass of the current one (training.BackbonePrefetcher, bit-identical results)
             pre = run_training(device, world, steps=args.train_steps, prefetch_backbone=True)
             train["with_backbone_prefetch"] = {"step_per_s": pre["step_per_s"], "ms_per_step": pre["ms_per_step"]}
+        # the frozen backbone's Linears on rocBLAS's f32 GEMM instead of one fp16 GEMM of split operands each (split_linear.py: the
+        # default, f32 accuracy): what the split buys
+        t32 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float32")
+        train["f32_gemm_backbone"] = {"step_per_s": t32["step_per_s"], "ms_per_step": t32["ms_per_step"]}
         # secondary figure, not the headline: the frozen backbone's matmuls with float16 inputs / fp32 accumulation -- the
         # mantissa width of the TF32 mode the reference runs its backbone in (feature_extraction.py:322); gfx950 has no TF32
         t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16", prefetch_backbone=(world == 1))

@@ -140,6 +140,7 @@ SIGNATURES = {
     "mmf_out_ffn_mfma2": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_out_ffn_qkv2": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "mmf_split_linear_weight": (_I, [_VP, _I, _I, _VP, _VP]),
+    "mmf_split_activations3": (_I, [_VP, C.c_int64, _I, _VP, _VP]),
     "mmf_self_layer": (_I, [_VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _I, _I, _I, _I, _VP]),
     "mmf_cross_layer": (_I, [_VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _I, _I, _I, _I, _I, _VP]),
     "mmf_attention_heads_split": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, C.POINTER(C.c_int), _VP]),

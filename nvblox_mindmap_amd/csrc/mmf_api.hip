@@ -2331,6 +2331,13 @@ int mmf_self_layer(const float* const* layer13, float ln1_eps, float ln2_eps, fl
   return check_launch();
 }
 
+int mmf_split_activations3(const float* x, int64_t rows, int K, void* out, void* stream) {
+  if (!x || !out) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_activations3");
+  if (launch_split_act3(x, rows, K, out, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_split_activations3: rows > 0 and K a positive multiple of 8");
+  return check_launch();
+}
+
 int mmf_split_linear_weight(const float* weight, int out_features, int in_features, void* split, void* stream) {
   if (!weight || !split || out_features <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_linear_weight");
   if (launch_split_weight(weight, out_features, in_features, split, (hipStream_t)stream) != 0)

@@ -171,6 +171,31 @@ int launch_split_weight(const float* W, int rows, int cols, void* dst, hipStream
   return 0;
 }
 
+// Activations [rows, K] f32 -> [rows, 3 K] fp16 = [hi | hi | lo] (lo scaled by 2048) for LARGE GEMMs on a library kernel: with
+// the weight matrix stored as [2048 hi | lo | hi] along K, ONE fp16 GEMM with f32 accumulation and alpha = 1 / 2048 returns the f32
+// product (x_hi w_hi + (x_hi w_lo + x_lo w_hi) / 2048: 22-bit mantissas; needs |w| < 32 and |x| < 65 504).  One thread per 8 values.
+__global__ __launch_bounds__(256) void k_split_act3(const float* __restrict__ x, long long pieces, int K, _Float16* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= pieces) return;
+  const int ppr = K / 8;  // pieces per row
+  const long long r = e / ppr;
+  const int c = (int)(e - r * ppr) * 8;
+  float v[8];
+  load8(x + r * K + c, v);
+  const Split8 S = split8(v);
+  _Float16* o = out + r * 3 * K + c;
+  *reinterpret_cast<h8*>(o) = S.hi;
+  *reinterpret_cast<h8*>(o + K) = S.hi;
+  *reinterpret_cast<h8*>(o + 2 * K) = S.lo;
+}
+
+int launch_split_act3(const float* x, long long rows, int K, void* out, hipStream_t s) {
+  if (rows <= 0 || K <= 0 || K % 8 != 0) return 1;
+  const long long pieces = rows * (K / 8);
+  hipLaunchKernelGGL(k_split_act3, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, x, pieces, K, reinterpret_cast<_Float16*>(out));
+  return 0;
+}
+
 // ---- q | k | v projections, rotary, head-major outputs ---------------------------------------------------------------------
 struct QkvArgs {
   const float* ss;       // AdaLN (scale | shift) [B, 2 D] of the query input or null

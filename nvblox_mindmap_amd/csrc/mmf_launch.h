@@ -342,6 +342,7 @@ int launch_out_ffn_mfma2(const float* const* a26, const float* eps4, float* out,
 int launch_out_ffn_qkv2(const float* const* a26, const float* eps4, float* out, const float* const* q14, float* Qp, float* Kp, float* Vt,
                         int B, int L, int D, int H, hipStream_t s);
 int launch_split_weight(const float* W, int rows, int cols, void* dst, hipStream_t s);
+int launch_split_act3(const float* x, long long rows, int K, void* out, hipStream_t s);
 int launch_self_layer(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp, float* Vt,
                       const float* const* qkv3, const uint8_t* pad, unsigned long long* tagged, unsigned tag, int* fail, int B, int L, int D,
                       int H, hipStream_t s);

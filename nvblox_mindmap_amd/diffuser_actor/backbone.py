@@ -9,6 +9,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .split_linear import split_linear
+
+
+def _lin(x, layer, split):
+    """``layer(x)``; ``split``: as one fp16 GEMM of split operands at f32 accuracy (split_linear.py; frozen inference only)."""
+    return split_linear(x, layer) if split else layer(x)
+
 
 class _Block(nn.Module):
     def __init__(self, dim, heads, mlp_ratio=4):
@@ -18,11 +25,11 @@ class _Block(nn.Module):
         self.fc1, self.fc2 = nn.Linear(dim, mlp_ratio * dim), nn.Linear(mlp_ratio * dim, dim)
         self.heads = heads
 
-    def forward(self, x):
+    def forward(self, x, split=False):
         B, L, D = x.shape
-        q, k, v = self.qkv(self.n1(x)).view(B, L, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
-        x = x + self.proj(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D))
-        return x + self.fc2(F.gelu(self.fc1(self.n2(x))))
+        q, k, v = _lin(self.n1(x), self.qkv, split).view(B, L, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        x = x + _lin(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D), self.proj, split)
+        return x + _lin(F.gelu(_lin(self.n2(x), self.fc1, split)), self.fc2, split)
 
 
 class VitBackbone(nn.Module):
@@ -36,6 +43,7 @@ class VitBackbone(nn.Module):
         nn.init.trunc_normal_(self.pos, std=0.02)
         self.blocks = nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim)
+        self.split_gemm = False  # frozen inference on a GPU: every Linear as one fp16 GEMM of split operands (split_linear.py)
 
     def forward(self, x):
         B, _, H, W = x.shape
@@ -46,6 +54,7 @@ class VitBackbone(nn.Module):
         patches = x.reshape(B, 3, h, P, w, P).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, 3 * P * P)
         t = F.linear(patches, self.embed.weight.reshape(self.dim, 3 * P * P), self.embed.bias)
         t = t + self.pos[:, : h * w]
+        split = self.split_gemm and t.is_cuda and t.dtype == torch.float32 and not torch.is_grad_enabled()
         for blk in self.blocks:
-            t = blk(t)
+            t = blk(t, split)
         return self.norm(t).transpose(1, 2).reshape(B, self.dim, h, w)

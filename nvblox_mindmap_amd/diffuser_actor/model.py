@@ -55,7 +55,10 @@ class DiffuserActorConfig:
     relative_action: bool = False           # poses relative to the newest gripper pose (the reference's ``relative``, diffuser_actor.py:46)
     dropout: float = 0.0
     backbone: str = "vit_b16"               # random-init stand-in for the frozen RADIO v2.5-B ("none": rgb tokens are given)
-    backbone_matmul_dtype: str = "float32"  # "float16": frozen backbone under fp16 autocast (the reference's TF32 mantissa)
+    # matmuls of the FROZEN image backbone: "float32"; "float16x3": every Linear as one fp16 GEMM of operands split into two fp16
+    # values each (22-bit mantissas, f32 accumulation: f32 accuracy at ~2x the speed, split_linear.py); "float16": fp16 autocast
+    # (a 10-bit mantissa, what the reference's TF32 setting keeps, feature_extraction.py:322)
+    backbone_matmul_dtype: str = "float16x3"
     loss_weights: LossWeights = field(default_factory=LossWeights)
 
 
@@ -99,8 +102,13 @@ class Encoder(nn.Module):
         so a trainer may evaluate it for the NEXT batch on a second stream while the trainable part of the current batch
         runs (training.trainer.BackbonePrefetcher)."""
         # The reference runs the frozen backbone under AllowMatMulTf32 (image_processing/feature_extraction.py:322): 10-bit
-        # mantissa inputs, fp32 accumulation.  gfx950 has no TF32 MFMA; float16 inputs carry the same mantissa.  Default: fp32.
+        # mantissa inputs, fp32 accumulation.  gfx950 has no TF32 MFMA; float16 inputs carry the same mantissa ("float16").
+        # Default: f32 accuracy from split fp16 operands ("float16x3"), ~2x the speed of the f32 GEMMs.
         fp16 = self.cfg.backbone_matmul_dtype == "float16" and rgb.is_cuda
+        if hasattr(self.backbone, "split_gemm"):
+            from .split_linear import supported
+
+            self.backbone.split_gemm = self.cfg.backbone_matmul_dtype == "float16x3" and rgb.is_cuda and supported()
         with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
             feats = self.backbone(rgb.flatten(0, 1))
         return feats.float()

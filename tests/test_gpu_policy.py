@@ -586,3 +586,33 @@ def test_paired_stacks_equal_the_two_stacks_run_separately():
     for g, r, c, r1 in zip(got, ref, composite, ref_one_launch):
         assert torch.equal(g, r) and torch.equal(r1, r)
         assert torch.allclose(g, c, rtol=2e-4, atol=2e-5), float((g - c).abs().max())
+
+
+def test_frozen_backbone_on_split_fp16_gemms_keeps_f32_accuracy():
+    """VitBackbone.split_gemm (split_linear.py: every Linear as ONE fp16 GEMM over [x_hi | x_hi | x_lo] x [2048 w_hi | w_lo | w_hi],
+    f32 accumulation): within float rounding of the f32 GEMMs -- fp16 autocast, the reference's TF32 mantissa, is 500x further --
+    and a weight beyond the representable range keeps its layer on the f32 GEMM."""
+    from nvblox_mindmap_amd.diffuser_actor import split_linear as SL
+    from nvblox_mindmap_amd.diffuser_actor.backbone import VitBackbone
+
+    if not SL.supported():
+        pytest.skip("torch.addmm(out_dtype=float32) is not available")
+    torch.manual_seed(3)
+    bb = VitBackbone(depth=3).cuda().eval()
+    x = torch.rand(6, 3, 512, 512, device="cuda")  # 6 144 tokens: above split_linear.kMinRows
+    with torch.no_grad():
+        ref = bb(x)
+        bb.split_gemm = True
+        got = bb(x)
+        with torch.autocast("cuda", dtype=torch.float16):
+            bb.split_gemm = False
+            half = bb(x).float()
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, float((got - ref).abs().max())
+        assert float((half - ref).abs().max()) > 50 * float((got - ref).abs().max())
+        lin = torch.nn.Linear(64, 32).cuda()
+        xs = torch.randn(5000, 64, device="cuda")
+        a = SL.split_linear(xs, lin)
+        assert torch.allclose(a, lin(xs), rtol=1e-5, atol=1e-5)
+        lin.weight[3, 5] = 40.0  # (under no_grad: bumps the version the cache watches) 2048 x 40 does not fit fp16: the f32 GEMM, exactly
+        assert torch.equal(SL.split_linear(xs, lin), lin(xs))

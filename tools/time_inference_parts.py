@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--backbone-dtype", default="float32")
+    ap.add_argument("--backbone-dtype", default="float16x3")
     a = ap.parse_args()
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActor, DiffuserActorConfig
     from nvblox_mindmap_amd.training import build_model, synthetic_batch
