@@ -405,10 +405,11 @@ int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out
 int mmf_out_ffn_qkv2(const float* const* layer26, const float* eps4, float* out_dev, const float* const* next14, float* q_heads_dev,
                      float* k_heads_dev, float* v_heads_t_dev, int B, int L, int D, int H, void* stream);
 int mmf_split_linear_weight(const float* weight_dev, int out_features, int in_features, void* split_dev, void* stream);
-/* The same split for LARGE GEMMs on a library kernel (the frozen image backbone, mindmap/image_processing/feature_extraction.py:322
- * runs its matmuls under TF32; this keeps 22 bits): x [rows, K] f32 -> out [rows, 3 K] fp16 = [hi | hi | lo * 2048].  With the
- * weight stored as [2048 hi | lo * 2048 | hi] along K (split_linear.py), ONE fp16 GEMM with f32 accumulation and alpha = 1 / 2048
- * returns the f32 product.  K a multiple of 8; |x| < 65 504, |w| < 32. */
+/* The same split for LARGE GEMMs on a library kernel (the frozen image backbone; mindmap/image_processing/feature_extraction.py:322
+ * runs its matmuls under TF32, this keeps 22 bits): x [rows, K] f32 -> out [rows, 3 K + 64] fp16 = [hi | hi / 2048 | lo | 1, 1 / 2048,
+ * 0 x 62].  With the weight stored as [hi | lo * 2048 | hi | bias hi, bias lo * 2048, 0 x 62] along the reduction axis
+ * (diffuser_actor/split_linear.py), ONE plain fp16 GEMM with f32 accumulation returns x w^T + bias at f32 accuracy.  K >= 64, a multiple
+ * of 8; |x| < 65 504. */
 int mmf_split_activations3(const float* x_dev, int64_t rows, int K, void* out_dev, void* stream);
 /* mmf_cross_layer: mmf_attention_heads_split and the block kernel that consumes its partials (mmf_out_ffn_mfma_partials, or with
  * next7 != NULL mmf_out_ffn_qkv with roles 1) in ONE launch: the attention workgroups lead the grid and hand their partials to

@@ -171,26 +171,42 @@ int launch_split_weight(const float* W, int rows, int cols, void* dst, hipStream
   return 0;
 }
 
-// Activations [rows, K] f32 -> [rows, 3 K] fp16 = [hi | hi | lo] (lo scaled by 2048) for LARGE GEMMs on a library kernel: with
-// the weight matrix stored as [2048 hi | lo | hi] along K, ONE fp16 GEMM with f32 accumulation and alpha = 1 / 2048 returns the f32
-// product (x_hi w_hi + (x_hi w_lo + x_lo w_hi) / 2048: 22-bit mantissas; needs |w| < 32 and |x| < 65 504).  One thread per 8 values.
+// Activations [rows, K] f32 -> [rows, 3 K + 64] fp16 = [hi | hi / 2048 | lo | 1, 1 / 2048, 0 ..] (lo = fp16((x - hi) * 2048) / 2048,
+// i.e. the true low part, still a normal number for |x| > 0.125 and within 2^-24 absolutely below that) for LARGE GEMMs on a library
+// kernel: with the weight matrix stored as [hi | lo * 2048 | hi | bias hi, bias lo * 2048, 0 ..] along the reduction axis, ONE plain
+// fp16 GEMM with f32 accumulation returns x w^T + bias at f32 accuracy (x_hi w_hi + x_hi w_lo + x_lo w_hi: 22-bit mantissas) -- no
+// scaling, no epilogue.  Needs |x| < 65 504.  One thread per 8 values (and the last thread of a row: the bias columns).
+constexpr int kTail = 64;  // columns behind the three parts: 1, 1 / 2048 (the bias), zeros -- 64 keeps a row a multiple of 128 bytes
 __global__ __launch_bounds__(256) void k_split_act3(const float* __restrict__ x, long long pieces, int K, _Float16* __restrict__ out) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= pieces) return;
   const int ppr = K / 8;  // pieces per row
   const long long r = e / ppr;
-  const int c = (int)(e - r * ppr) * 8;
+  const int p = (int)(e - r * ppr), c = p * 8;
   float v[8];
   load8(x + r * K + c, v);
-  const Split8 S = split8(v);
-  _Float16* o = out + r * 3 * K + c;
-  *reinterpret_cast<h8*>(o) = S.hi;
-  *reinterpret_cast<h8*>(o + K) = S.hi;
-  *reinterpret_cast<h8*>(o + 2 * K) = S.lo;
+  h8 hi, hs, lo;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    hi[t] = (_Float16)v[t];
+    const _Float16 l = (_Float16)((v[t] - (float)hi[t]) * kLoScale);
+    hs[t] = (_Float16)((float)hi[t] * kLoInv);  // exact power-of-two scaling (down to the subnormal grid)
+    lo[t] = (_Float16)((float)l * kLoInv);
+  }
+  _Float16* o = out + r * (3 * K + kTail) + c;
+  *reinterpret_cast<h8*>(o) = hi;
+  *reinterpret_cast<h8*>(o + K) = hs;
+  *reinterpret_cast<h8*>(o + 2 * K) = lo;
+  if (p >= ppr - kTail / 8) {  // (a row has at least kTail / 8 pieces: K >= 64)
+    const int tp = p - (ppr - kTail / 8);
+    h8 one = {(_Float16)(tp == 0 ? 1.0f : 0.0f), (_Float16)(tp == 0 ? kLoInv : 0.0f), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+              (_Float16)0.f, (_Float16)0.f};
+    *reinterpret_cast<h8*>(out + r * (3 * K + kTail) + 3 * K + 8 * tp) = one;
+  }
 }
 
 int launch_split_act3(const float* x, long long rows, int K, void* out, hipStream_t s) {
-  if (rows <= 0 || K <= 0 || K % 8 != 0) return 1;
+  if (rows <= 0 || K < kTail || K % 8 != 0) return 1;
   const long long pieces = rows * (K / 8);
   hipLaunchKernelGGL(k_split_act3, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, x, pieces, K, reinterpret_cast<_Float16*>(out));
   return 0;

@@ -1,17 +1,21 @@
 """f32 Linear layers of a FROZEN module as one fp16 library GEMM each, at f32 accuracy.
 
-Every f32 operand is split x = hi + lo / 2048 (hi = fp16(x), lo = fp16((x - hi) * 2048): 22 bits of mantissa) and
+Every f32 operand is split into two fp16 values, x = x_hi + x_lo (x_hi = fp16(x), x_lo the remainder: 22 bits of mantissa), and
 
-    x w^T  =  ( x_hi (2048 w_hi)^T  +  x_hi w_lo^T  +  x_lo w_hi^T ) / 2048        (the lo.lo term is 2^-22 of the product)
+    x w^T + b  =  x_hi w_hi^T  +  x_hi w_lo^T  +  x_lo w_hi^T  +  b                     (the lo.lo term is 2^-22 of the product)
 
-is ONE GEMM over the concatenated reduction axis: [x_hi | x_hi | x_lo] (mmf_split_activations3, one pass over the activations)
-times [2048 w_hi | w_lo | w_hi] (made once per weight), fp16 inputs, f32 accumulation and output, alpha = 1 / 2048, the bias as
-the addend.  On MI355X the f32 matrix rate is 1/16 of the fp16 rate, so three fp16 products are ~2x faster than one f32 GEMM
-(32 768 x 768 x 3 072: 1.31 ms -> 0.68 ms) and closer to the f64 result than rocBLAS's f32 kernel (2.4e-6 vs 7.2e-6 on that shape).
-The reference runs its frozen backbone under TF32 (mindmap/image_processing/feature_extraction.py:322), a 10-bit mantissa.
+is ONE plain GEMM over a concatenated reduction axis, fp16 inputs, f32 accumulation and output:
 
-Requires |w| < 32 (2048 w_hi must stay below 65 504) -- checked when a weight is split, the layer then stays on the f32 GEMM --
-and |x| < 65 504 (activations of a LayerNorm-ed transformer are; not checked per call).  Inference only: no autograd."""
+    [ x_hi | x_hi / 2048 | x_lo | 1, 1 / 2048, 0 x 62 ]  x  [ w_hi | 2048 w_lo | w_hi | b_hi, 2048 b_lo, 0 x 62 ]^T
+
+(the low parts of the CONSTANT operands are stored scaled by 2048 so that they are normal fp16 numbers; the activations carry the
+inverse scale, exact as a power of two -- mmf_split_activations3 writes them in one pass).  On MI355X the f32 matrix rate is 1/16
+of the fp16 rate, so the tripled reduction is ~2x faster than the f32 GEMM (the backbone's four shapes at 32 768 tokens: 1.0 - 1.25 ms -> 0.45 - 0.5 ms) and closer to
+the f64 result than rocBLAS's f32 kernel.  The reference runs its frozen backbone under TF32
+(mindmap/image_processing/feature_extraction.py:322), a 10-bit mantissa.
+
+Requires |w|, |b| < 65 504 (checked when a weight is split; the layer otherwise stays on the f32
+GEMM) and |x| < 65 504 (activations of a LayerNorm-ed transformer are; not checked per call).  Inference only: no autograd."""
 import weakref
 
 import torch
@@ -19,29 +23,36 @@ import torch.nn.functional as F
 
 from .. import _lib
 
+kTail = 64  # columns behind the three parts (mmf_split_activations3): the bias pair + zeros, a row stays a multiple of 128 bytes
 kMinRows = 4096  # (one 512 x 512 image is 1 024 tokens: 3.24 ms on the f32 GEMMs, 3.37 ms split)
-_W3_CACHE = {}  # id(weight) -> (weak reference, version, [N, 3K] fp16 or None when the weight is out of range)
+_W3_CACHE = {}  # id(weight) -> (weak reference, versions of weight and bias, [N, 3 K + 64] fp16 or None when out of range)
 
 
 def _w3(linear):
     w = linear.weight
     key = id(w)
     hit = _W3_CACHE.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != w._version or (hit[2] is not None and hit[2].device != w.device):
+    ver = (w._version, None if linear.bias is None else linear.bias._version)
+    if hit is None or hit[0]() is not w or hit[1] != ver or (hit[2] is not None and hit[2].device != w.device):
         src = w.detach().float()
         w3 = None
-        if float(src.abs().max()) < 31.0 and src.shape[1] % 8 == 0:
+        bias = linear.bias.detach().float() if linear.bias is not None else torch.zeros(src.shape[0], device=src.device)
+        if float(src.abs().max()) < 6.0e4 and float(bias.abs().max()) < 6.0e4 and src.shape[1] % 8 == 0 and src.shape[1] >= kTail:
             hi = src.half()
             lo = ((src - hi.float()) * 2048.0).half()
-            w3 = torch.cat([(hi.float() * 2048.0).half(), lo, hi], dim=1).contiguous()
-        hit = (weakref.ref(w, lambda _r, k=key: _W3_CACHE.pop(k, None)), w._version, w3)
+            bh = bias.half()
+            bl = ((bias - bh.float()) * 2048.0).half()
+            tail = torch.zeros((src.shape[0], kTail), dtype=torch.float16, device=src.device)
+            tail[:, 0], tail[:, 1] = bh, bl
+            w3 = torch.cat([hi, lo, hi, tail], dim=1).contiguous()  # [N, 3 K + 64]
+        hit = (weakref.ref(w, lambda _r, k=key: _W3_CACHE.pop(k, None)), ver, w3)
         _W3_CACHE[key] = hit
     return hit[2]
 
 
 def supported() -> bool:
-    """torch.addmm with a float32 result from half inputs (PyTorch >= 2.8) is what the single GEMM needs."""
-    return "out_dtype" in (torch.addmm.__doc__ or "")
+    """torch.mm with a float32 result from half inputs (PyTorch >= 2.8) is what the single GEMM needs."""
+    return "out_dtype" in (torch.mm.__doc__ or "")
 
 
 def split_linear(x: torch.Tensor, linear) -> torch.Tensor:
@@ -53,10 +64,7 @@ def split_linear(x: torch.Tensor, linear) -> torch.Tensor:
     if x.numel() // K < kMinRows:  # a small GEMM is launch-bound: the split pass costs more than the matrix rate returns
         return F.linear(x, linear.weight, linear.bias)
     x2 = x.reshape(-1, K).contiguous()
-    a3 = torch.empty((x2.shape[0], 3 * K), dtype=torch.float16, device=x.device)
+    a3 = torch.empty((x2.shape[0], 3 * K + kTail), dtype=torch.float16, device=x.device)
     _lib.check(_lib.lib().mmf_split_activations3(_lib.dptr(x2), x2.shape[0], K, _lib.dptr(a3), _lib.stream_ptr(x.device)), "mmf_split_activations3")
-    if linear.bias is not None:
-        y = torch.addmm(linear.bias.detach().float(), a3, w3.t(), alpha=1.0 / 2048.0, out_dtype=torch.float32)
-    else:
-        y = torch.mm(a3, w3.t(), out_dtype=torch.float32) * (1.0 / 2048.0)
+    y = torch.mm(a3, w3.t(), out_dtype=torch.float32)
     return y.reshape(*x.shape[:-1], w3.shape[0])

@@ -589,8 +589,8 @@ def test_paired_stacks_equal_the_two_stacks_run_separately():
 
 
 def test_frozen_backbone_on_split_fp16_gemms_keeps_f32_accuracy():
-    """VitBackbone.split_gemm (split_linear.py: every Linear as ONE fp16 GEMM over [x_hi | x_hi | x_lo] x [2048 w_hi | w_lo | w_hi],
-    f32 accumulation): within float rounding of the f32 GEMMs -- fp16 autocast, the reference's TF32 mantissa, is 500x further --
+    """VitBackbone.split_gemm (split_linear.py: every Linear as ONE fp16 GEMM over [x_hi | x_hi / 2048 | x_lo | 1 ..] x
+    [w_hi | 2048 w_lo | w_hi | bias ..], f32 accumulation): within float rounding of the f32 GEMMs -- fp16 autocast, the reference's TF32 mantissa, is 500x further --
     and a weight beyond the representable range keeps its layer on the f32 GEMM."""
     from nvblox_mindmap_amd.diffuser_actor import split_linear as SL
     from nvblox_mindmap_amd.diffuser_actor.backbone import VitBackbone
@@ -614,5 +614,5 @@ def test_frozen_backbone_on_split_fp16_gemms_keeps_f32_accuracy():
         xs = torch.randn(5000, 64, device="cuda")
         a = SL.split_linear(xs, lin)
         assert torch.allclose(a, lin(xs), rtol=1e-5, atol=1e-5)
-        lin.weight[3, 5] = 40.0  # (under no_grad: bumps the version the cache watches) 2048 x 40 does not fit fp16: the f32 GEMM, exactly
+        lin.weight[3, 5] = 7.0e4  # (under no_grad: bumps the version the cache watches) does not fit fp16: the f32 GEMM, exactly
         assert torch.equal(SL.split_linear(xs, lin), lin(xs))
