@@ -391,6 +391,11 @@ class DiffusionHead(nn.Module):
             rot_seq, pos_seq = self._stacks_fused(tokens, P, ada)
             pred, head_yaw, traj, tokens = FO.step_tail(self, rot_seq, pos_seq, traj, noise[1 + k], coefs[k][0], coefs[k][1],
                                                         P["pos_table"], P["rot_freq"], P["seq_cos"], P["seq_sin"], last=(k == T - 1))
+        # an in-launch hand-over that timed out (a peer workgroup was not running: fused_ops.Handover) must not pass for a result
+        for key in ("cross_handover", "self_handover"):
+            ho = P.get(key)
+            if ho is not None:
+                traj = torch.where(ho.words[-1] != 0, torch.full_like(traj, float("nan")), traj)
         return traj, pred, head_yaw
 
 
