@@ -607,7 +607,7 @@ def run_model_inputs(device, shape: str, iters=40, n_frames=12):
     return res
 
 
-def run_closed_loop(device, steps=5):
+def run_closed_loop(device, steps=8):
     """BASELINE configs[3]: one control step of the closed loop on one GPU, end to end, through the object the reference's policy
     drives (mapping/isaaclab_nvblox_mapper.py; closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83,206-211):
     mapper.decay() + update_reconstruction_from_sample (input helpers: pose 7-vector -> 4x4, rgb float -> u8, back-projection;
@@ -654,6 +654,10 @@ def run_closed_loop(device, steps=5):
     try:
         for i in range(3):
             control_step(i, False)  # warm-up: fills the map, captures the graph
+        import gc
+
+        gc.collect()
+        gc.freeze()  # (a generation-2 collection inside a 0.3 ms phase of a handful of steps is the whole phase)
         t0 = time.perf_counter()
         for i in range(steps):
             control_step(3 + i, True)
