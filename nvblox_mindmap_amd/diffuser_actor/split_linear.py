@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from .. import _lib
 
 kTail = 64  # columns behind the three parts (mmf_split_activations3): the bias pair + zeros, a row stays a multiple of 128 bytes
-kMinRows = 4096  # (one 512 x 512 image is 1 024 tokens: 3.24 ms on the f32 GEMMs, 3.37 ms split)
+kMinRows = 2048  # (one 512 x 512 image = 1 024 tokens: 3.2 ms on the f32 GEMMs, 3.3 ms split -- launch-bound either way; two images: 4.8 -> 3.9 ms)
 _W3_CACHE = {}  # id(weight) -> (weak reference, versions of weight and bias, [N, 3 K + 64] fp16 or None when out of range)
 
 
