@@ -300,7 +300,7 @@ template <int CP, int NWV, int K>
 __global__ __launch_bounds__(64 * (NWV + 1)) void k_fps_multi(const float* __restrict__ xp, int b0, int bend, int N, int G, int npoints,
                                                              int start, u64* pub, long long* __restrict__ out_idx) {
   constexpr int NT = 64 * (NWV + 1), RS = CP + 4;
-  __shared__ u64 s_wkey[2][NWV];
+  __shared__ u64 s_wtop[NWV][K];
   __shared__ __attribute__((aligned(16))) float s_pub[K][CP];
   __shared__ u64 s_pubkey[K];
   __shared__ u64 s_keys[64];
@@ -401,27 +401,31 @@ __global__ __launch_bounds__(64 * (NWV + 1)) void k_fps_multi(const float* __res
     if (!first) it += n;
     first = false;
     if (it >= npoints) return;
-    // ---- this workgroup's K best points: keys and rows
+    // ---- this workgroup's K best points: keys and rows.  Every main wave takes ITS K best (K wave maxima, no barrier in
+    // between); a point is among the workgroup's K best iff fewer than K of the NWV K wave candidates exceed it -- its rank is
+    // its slot.  (K rounds of {wave maximum, barrier, owner writes its row} were a fifth of an exchange.)
     const u64 tag = (u64)(round & 0xFFFFF);
+    const u64 mykey = valid ? (((u64)__float_as_uint(dist) << 32) | pidx | tag) : tag;
     bool sel = false;
+    if (main_wave) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (main_wave) {
-        u64 key = (valid && !sel) ? (((u64)__float_as_uint(dist) << 32) | pidx | tag) : tag;
-        key = wave_max_u64_dpp(key);
-        if (lane == 0) s_wkey[k & 1][wave] = key;
+      for (int k = 0; k < K; ++k) {
+        const u64 m = wave_max_u64_dpp(sel ? tag : mykey);
+        if (lane == 0) s_wtop[wave][k] = m;
+        if (valid && !sel && mykey == m) sel = true;  // (keys of valid points are distinct)
       }
-      __syncthreads();
-      u64 best = s_wkey[k & 1][0];
+    }
+    if (tid < K) s_pubkey[tid] = tag;  // (a slot without a point: the empty key)
+    __syncthreads();
+    if (sel) {
+      int rank = 0;
 #pragma unroll
-      for (int w = 1; w < NWV; ++w) best = s_wkey[k & 1][w] > best ? s_wkey[k & 1][w] : best;
-      const int best_p = 0xFFF - (int)((best >> 20) & 0xFFF);
-      if (valid && !sel && p == best_p && (best >> 32) == (u64)__float_as_uint(dist)) {  // the owner hands its row over
-        sel = true;
+      for (int e = 0; e < NWV * K; ++e) rank += (&s_wtop[0][0])[e] > mykey ? 1 : 0;
+      if (rank < K) {  // the owner hands its row over
+        s_pubkey[rank] = mykey;
 #pragma unroll
-        for (int c = 0; c < CP; c += 4) *reinterpret_cast<float4*>(&s_pub[k][c]) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+        for (int c = 0; c < CP; c += 4) *reinterpret_cast<float4*>(&s_pub[rank][c]) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       }
-      if (tid == 0) s_pubkey[k] = best;
     }
     __syncthreads();
     u64* slot_row = mypub + (size_t)(round & 1) * G * K * (CP + 1);
@@ -467,18 +471,18 @@ __global__ __launch_bounds__(64 * (NWV + 1)) void k_fps_multi(const float* __res
       return;
     }
     // ---- their rows
-    // (requested eight words per thread at a time, checked afterwards: one dependent round trip per word made this the longest
+    // (requested sixteen words per thread at a time, checked afterwards: one dependent round trip per word made this the longest
     // part of an exchange; the rows were stored before the keys that have been seen, a stale word is the exception)
     const int ne = s_nelig;
-    for (int e0 = tid; e0 < ne * CP; e0 += 8 * NT) {
-      u64 got[8];
+    for (int e0 = tid; e0 < ne * CP; e0 += 16 * NT) {
+      u64 got[16];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 16; ++i) {
         const int e = min(e0 + i * NT, ne * CP - 1), sl = e / CP, c = e - sl * CP;
         got[i] = __hip_atomic_load(slot_row + (size_t)s_elig[sl] * (CP + 1) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 16; ++i) {
         const int e = e0 + i * NT;
         if (e < ne * CP) {
           const int sl = e / CP, c = e - sl * CP;
