@@ -784,7 +784,7 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     return out
 
 
-def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=12, workers=10,
+def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=16, workers=10,
                           vertex_count_range=(10000, 14000)):
     """Is the training step loader-bound?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader keeping the GPUs
     fed, not the 10.9 MB all-reduce.)  A demo in the reference's on-disk layout -- 512x512 rgb + u16 depth PNGs, pose /
@@ -884,13 +884,27 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
         wall = time.perf_counter() - t0
         fed = steps / wall
         loader_cores = cpu_ms_per_sample * 1e-3 * fed * per_gpu_batch  # CPU seconds of loader work per wall second
-        del dl, it, model, opt
+        # the comparator under the SAME conditions: this process, this model, the loader's workers alive but idle, one batch
+        # resident on the device (the training leg's figure comes from another model instance and 8 steps: +-3 % between runs)
+        resident_batch = next(it)
+        for _ in range(3):
+            train_one_step(cfg, model, opt, resident_batch)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            train_one_step(cfg, model, opt, resident_batch)
+        torch.cuda.synchronize(device)
+        resident = steps / (time.perf_counter() - t0)
+        training_leg_step_per_s, compute_bound_step_per_s = compute_bound_step_per_s, resident
+        del dl, it, model, opt, resident_batch
     finally:
         shutil.rmtree(root, ignore_errors=True)
         torch.set_num_threads(host_threads_before)
     torch.cuda.empty_cache()
     need = compute_bound_step_per_s * per_gpu_batch
-    return {"file_fed_step_per_s": fed, "compute_bound_step_per_s": compute_bound_step_per_s, "loader_only_samples_per_s": loader_sps,
+    return {"file_fed_step_per_s": fed, "compute_bound_step_per_s": compute_bound_step_per_s,
+            "compute_bound_is": "the same process, model and loader (workers idle) stepping on one resident batch, timed right after the file-fed steps",
+            "training_leg_step_per_s": training_leg_step_per_s, "loader_only_samples_per_s": loader_sps,
             "samples_per_s_needed_by_one_gpu": need, "loader_headroom": loader_sps / need, "file_fed_over_compute_bound": fed / compute_bound_step_per_s,
             "bound": "loader (CPU-side decode: see cpu_quota)" if (loader_sps < need or fed < 0.95 * compute_bound_step_per_s) else "compute",
             "workers": workers, "loader_cpu_ms_per_sample": cpu_ms_per_sample, "loader_cpu_cores_used": loader_cores, "vertex_features_from": "memory-mapped raw cache (io/vertex_cache.py), sampled rows only; images from their raw copies (no PNG inflate)",
