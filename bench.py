@@ -1113,6 +1113,7 @@ def main():
     ap.add_argument("--file-fed-only", action="store_true", help="run only the file-fed training leg (loader-bound vs compute-bound step/s)")
     ap.add_argument("--in-flight-only", action="store_true", help="run only the frames-in-flight leg (N replicas in one set of launches)")
     ap.add_argument("--unbounded-only", action="store_true", help="run only the unbounded-workspace (hash path) leg (rocprofv3 passes)")
+    ap.add_argument("--eager-rows", action="store_true", help="headline without the deferred feature-row update (every frame runs its five launches before the next starts)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the multi-rank control flow only")
     args = ap.parse_args()
     if args.only_fusion:
@@ -1166,6 +1167,10 @@ def main():
             print(json.dumps({"unbounded_workspace": out}), flush=True)
         return
     mapper = get_nvblox_mapper(mcfg, feature_channels=args.channels)
+    # consecutive frames software-pipelined (mmf_set_deferred_feature_rows): a frame's last launch rides in the next frame's
+    # sphere-trace launch; the frames of this stream are resident and never modified (the contract), and every timed region
+    # ends with a flush -- all the work of its frames is inside it
+    mapper.set_deferred_feature_rows(not args.eager_rows)
 
     for i in range(args.warmup):
         step(mapper, mcfg, frames[i % n_frames])
@@ -1188,6 +1193,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(mapper, mcfg, frames[(k + i) % n_frames])
+        mapper.flush()  # the last frame's deferred row update
         t_enq = time.perf_counter() - t0  # host time to enqueue all steps (the GPU may lag behind)
         torch.cuda.synchronize(device)
         if dist is not None:

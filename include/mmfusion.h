@@ -137,6 +137,20 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth_dev, con
  * mmf_decay is lazy: it is applied inside the next mmf_integrate_frame* on the same mapper, or as stand-alone launches
  * by the first other call that reads or writes the map -- observable results are those of an immediate decay. */
 int mmf_decay(mmf_handle h, int mapper_id, void* stream);
+/* Software pipelining of consecutive fused frames (no counterpart in the reference: nvblox consumes a frame before the call
+ * returns the stream to the caller; this is the same trick as the lazy mmf_decay, on the other end of the frame).  With
+ * on != 0, mmf_integrate_frame / _desc with a FULL-RESOLUTION feature image leave their last launch -- the feature-row update of
+ * the voxels that passed the gate -- pending; the next mmf_integrate_frame / _desc on the same mapper and stream runs it as one
+ * more role of its sphere-trace launch (a latency-bound launch with idle workgroup slots: the 8 us bandwidth stream disappears
+ * behind it), and ANY other entry point that takes this mapper first runs it as the stand-alone launch it would have been, on
+ * the stream of the frame it belongs to.  Every observable result is bit-identical to the undeferred sequence.
+ * CONTRACT while on: the feature image handed to a frame must stay allocated and UNCHANGED until the next call on this mapper
+ * (or mmf_flush) has been enqueued.  mapper_id < 0: all mappers.  Turning it off flushes.  Default: off. */
+int mmf_set_deferred_feature_rows(mmf_handle h, int mapper_id, int on);
+/* 1: a frame's row update is pending on the mapper (its feature image is still in use), 0: not, < 0: error code. */
+int mmf_deferred_feature_rows_pending(mmf_handle h, int mapper_id);
+/* Enqueues whatever is pending on the mapper (a deferred row update on its frame's stream, a lazy decay on `stream`). */
+int mmf_flush(mmf_handle h, int mapper_id, void* stream);
 int mmf_clear(mmf_handle h, int mapper_id, void* stream);
 
 /* ---- map -> model input --------------------------------------------------------------------- */

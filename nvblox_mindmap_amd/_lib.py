@@ -100,6 +100,9 @@ SIGNATURES = {
     "mmf_integrate_frame_batch": (_I, [_I, C.POINTER(_VP), C.POINTER(_I), C.POINTER(MmfFrame), _VP]),
     "mmf_integrate_frame_desc": (_I, [_VP, _I, C.POINTER(MmfFrame), _VP]),
     "mmf_decay": (_I, [_VP, _I, _VP]),
+    "mmf_set_deferred_feature_rows": (_I, [_VP, _I, _I]),
+    "mmf_flush": (_I, [_VP, _I, _VP]),
+    "mmf_deferred_feature_rows_pending": (_I, [_VP, _I]),
     "mmf_clear": (_I, [_VP, _I, _VP]),
     "mmf_update_feature_mesh": (_I, [_VP, _I, _VP, _PI]),
     "mmf_get_feature_mesh": (_I, [_VP, _I, _VP, _VP, _VP]),

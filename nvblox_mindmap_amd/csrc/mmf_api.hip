@@ -88,6 +88,14 @@ struct Mapper {
   size_t inv_mask_cap = 0;
   long long* timeline = nullptr;  // 8 device int64: timestamps of the last TSDF allocation job (mmf_get_alloc_timeline)
   FlatList flat;               // survivor list of a feature frame (balanced phase 2); rec == null: not in use
+  // Deferred row update (mmf_set_deferred_feature_rows): a fused frame leaves its last launch -- the rows of its survivor list --
+  // to the NEXT fused frame, which runs it as a role of its sphere-trace launch; whatever else touches the mapper first runs it
+  // as the stand-alone launch it would have been (get_mapper flushes).  Two lists: frame N's is read while frame N + 1's fills.
+  FlatList flat_other;
+  bool defer_rows = false;     // the caller keeps a frame's feature image valid and unchanged until the next call on this mapper
+  bool rows_pending = false;
+  AppArgs rows_args{};         // argument block of the pending row update (list, image, pool)
+  hipStream_t rows_stream = nullptr;
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
   bool wmax_valid = true;      // (an empty map trivially) tsdf.d.wmax holds every live block's largest weight (set by a fused frame, cleared by whatever
                                // else writes TSDF weights): a pending decay can then take the light path
@@ -478,6 +486,9 @@ void destroy_mapper(Mapper* m) {
   (void)hipFree(m->flat.rec);
   (void)hipFree(m->flat.w);
   (void)hipFree(m->flat.count);
+  (void)hipFree(m->flat_other.rec);
+  (void)hipFree(m->flat_other.w);
+  (void)hipFree(m->flat_other.count);
   if (m->hints) (void)hipHostFree(m->hints);
   (void)hipFree(m->kill);
   (void)hipFree(m->pub);
@@ -554,11 +565,38 @@ int compute_view_grid(const Mapper& m, const Cam& cam, const Rigid& T_L_C, ViewG
   return MMF_OK;
 }
 
-int get_mapper(mmf_handle h, int id, Mapper** out) {
+// experiment switch: which launch of the next frame hosts a deferred row update (3 = sphere trace, 4 = gating)
+static int rows_host() {
+  static const int v = [] {
+    const char* e = getenv("MMF_DEBUG_ROWS_HOST");
+    return e ? atoi(e) : 3;
+  }();
+  return v;
+}
+
+// A deferred row update runs now, as the launch it would have been, on the stream of the frame it belongs to (where the
+// undeferred launch would have been enqueued: the ordering against later work is what it would have been).
+int flush_rows(mmf_handle h, Mapper& m) {
+  if (!m.rows_pending) return MMF_OK;
+  m.rows_pending = false;
+  HIP_TRY(hipSetDevice(h->device));
+  ProfExt pe(h, MMF_K_FEATURE_FLAT);
+  launch_feature_flat_args(m.rows_args, m.mc, m.rows_stream, pe.a(), pe.b());
+  return MMF_OK;
+}
+
+// the fused frame's accessor: a pending row update stays pending (the frame hosts it)
+int get_mapper_keep_rows(mmf_handle h, int id, Mapper** out) {
   if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
   if (id < 0 || id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
   *out = h->mappers[id];
   return MMF_OK;
+}
+
+// every other entry point: whatever it reads or writes, the map is what the calls so far made it
+int get_mapper(mmf_handle h, int id, Mapper** out) {
+  MMF_TRY(get_mapper_keep_rows(h, id, out));
+  return flush_rows(h, **out);
 }
 
 // A pending decay is applied now, as its own launches (every consumer of the map except the fused frame path).
@@ -613,6 +651,28 @@ int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w) {
   }
   return attach_dense_table(m, L);
 }
+
+// second survivor list (first deferred frame): same size, same hint
+int ensure_flat_other(Mapper& m) {
+  if (m.flat_other.rec || !m.flat.rec) return MMF_OK;
+  const size_t recs = (size_t)m.flat.cap;
+  FlatList f = m.flat;
+  f.rec = nullptr;
+  f.w = nullptr;
+  f.count = nullptr;
+  if (hipMalloc(&f.rec, sizeof(uint4) * recs) != hipSuccess || hipMalloc(&f.w, sizeof(float) * recs) != hipSuccess ||
+      hipMalloc(&f.count, sizeof(int) * kFlatSubLists * kFlatCountStride) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(f.rec);
+    (void)hipFree(f.w);
+    (void)hipFree(f.count);
+    return MMF_OK;  // no room: frames keep their own row update
+  }
+  HIP_TRY(hipMemset(f.count, 0, sizeof(int) * kFlatSubLists * kFlatCountStride));
+  m.flat_other = f;
+  return MMF_OK;
+}
+
 
 // Is the cached synthetic depth image valid for this camera and TSDF state?
 bool synth_cached(const Mapper& m, const Cam& cam, const float* T16, const float* K9) {
@@ -1115,9 +1175,12 @@ int mmf_add_feature_frame_lowres(mmf_handle h, int mapper_id, const float* lowre
 static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth, const uint8_t* rgb, const void* feat,
                                 const LowRes* low, const uint8_t* input_mask, int H, int W, int Hf, int Wf, int C, const float* T16,
                                 const float* K9, float min_depth_m, int k_in, int k_depth, int border_percent,
-                                uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream, bool invert_mask = false) {
+                                uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream, bool invert_mask = false,
+                                bool may_defer = true) {
+  // may_defer: false for the frames mmf_integrate_frame_multi / _batch hand on one by one -- the contract of the deferred row
+  // update (the feature image stays valid until the next call) is made with the callers of mmf_integrate_frame / _desc only
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_keep_rows(h, mapper_id, &m));  // (a deferred row update of the previous frame rides in this one's launch 3)
   if (!depth || !rgb || (!feat && !low) || !input_mask || !T16 || !K9 || !depth_mask_out || !feature_mask_out || H <= 1 || W <= 1 ||
       Hf <= 1 || Wf <= 1 || k_in < 0 || k_depth < 0 || !(min_depth_m >= 0.0f))
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_integrate_frame");
@@ -1130,6 +1193,17 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                                      "use the separate add_*_frame calls otherwise");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
+  if (m->rows_pending && m->rows_stream != s) {
+    // another stream: the update goes where it would have been enqueued, and -- it is enqueued later than it would have been, after
+    // whatever synchronisation the caller placed between the two streams -- this stream waits for it
+    hipStream_t old_stream = m->rows_stream;
+    MMF_TRY(flush_rows(h, *m));
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, old_stream));
+    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+    HIP_TRY(hipEventDestroy(ev));
+  }
   MMF_TRY(report_device_errors(h, *m, nullptr, nullptr, s));  // an earlier frame's hand-over failed for good: do not integrate on top
   MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
   MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)C, true));
@@ -1181,6 +1255,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     launch_invert_mask(input_mask, m->inv_mask, (size_t)H * W, s);
     input_mask = m->inv_mask;
   }
+  if (!fusable || big) MMF_TRY(flush_rows(h, *m));  // no launch of this frame can host it
+  if (m->defer_rows && fusable && !big && !low) MMF_TRY(ensure_flat_other(*m));
   if (!fusable) {
     // odd shapes / very large grids: the plain sequence of stand-alone launches
     flush_decay(h, *m, s);
@@ -1339,20 +1415,37 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     } else if (need) {
       ProfExt pe(h, MMF_K_SPHERE);
       const SphereArgs SA = make_sphere_args(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats);
-      launch_sphere_alloc(&SA, 1, s, pe.a(), pe.b());
+      if (m->rows_pending && rows_host() == 3) {  // ... | the previous frame's row update (its list is the other one of the pair: nobody zeroes it here)
+        m->rows_pending = false;
+        launch_sphere_alloc_flat(SA, m->rows_args, s, pe.a(), pe.b());
+      } else {
+        launch_sphere_alloc(&SA, 1, s, pe.a(), pe.b());
+      }
       synth_commit(*m, cam, T16, K9, Ws, Hs);
     } else {
+      if (rows_host() == 3) MMF_TRY(flush_rows(h, *m));
       ProfScope ps(h, MMF_K_SPHERE, s);
       launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
     }
   }
   {
-    ProfExt pe(h, MMF_K_FEATURE);
-    launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
-                          pe.a(), pe.b());
+    bool hosted = false;
+    {
+      ProfExt pe(h, MMF_K_FEATURE);
+      launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
+                            pe.a(), pe.b(), m->rows_pending ? &m->rows_args : nullptr, &hosted);
+    }
+    if (hosted) m->rows_pending = false;
+    MMF_TRY(flush_rows(h, *m));  // (nothing hosted it: before this frame's own)
   }
-  {
+  if (may_defer && m->defer_rows && !big && !low && m->flat.rec && m->flat_other.rec) {
+    // the rows of this frame's survivors: left to the next fused frame's launch 3 (or to whatever touches the mapper first)
+    m->rows_args = make_flat_args(m->feat.d, fcam, (const __half*)feat, nullptr, m->flat, m->stats);
+    m->rows_stream = s;
+    m->rows_pending = true;
+    std::swap(m->flat, m->flat_other);  // the next frame fills (and its launch 3 zeroes) the other list
+  } else {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);
     launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s, pe.a(), pe.b());
   }
@@ -1403,7 +1496,7 @@ static int frame_in_from_desc(const Mapper& m, const mmf_frame* f, FrameIn& in) 
 static int integrate_frame_in(mmf_handle h, int mapper_id, const FrameIn& in, void* stream) {
   return integrate_frame_impl(h, mapper_id, in.depth, in.rgb, in.feat, in.has_low ? &in.low : nullptr, in.input_mask, in.H, in.W, in.Hf,
                               in.Wf, in.C, in.T16, in.K9, in.min_depth_m, in.k_in, in.k_depth, in.border_percent, in.depth_mask_out,
-                              in.feature_mask_out, stream, in.invert_mask);
+                              in.feature_mask_out, stream, in.invert_mask, false);
 }
 
 // Can this frame take the five-launch merged path (the only one the pair kernels implement)?  No side effects.
@@ -1701,7 +1794,7 @@ int mmf_integrate_frame_lowres(mmf_handle h, int mapper_id, const float* depth, 
                                const float* K9, float min_depth_m, int k_in, int k_depth, int border_percent,
                                uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_keep_rows(h, mapper_id, &m));
   LowRes lr;
   MMF_TRY(make_lowres(*m, lowres, lh, lw, Cin, Hf, Wf, lr));
   return integrate_frame_impl(h, mapper_id, depth, rgb, nullptr, &lr, input_mask, H, W, Hf, Wf, m->P.feature_channels, T16, K9,
@@ -1713,7 +1806,7 @@ int mmf_integrate_frame_desc(mmf_handle h, int mapper_id, const mmf_frame* f, vo
   if ((f->features_f16 != nullptr) == (f->lowres_features != nullptr))
     return fail(MMF_ERR_INVALID_ARG, "mmf_frame: give exactly one of features_f16 / lowres_features");
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_keep_rows(h, mapper_id, &m));
   LowRes lr;
   if (f->lowres_features) MMF_TRY(make_lowres(*m, f->lowres_features, f->lowres_h, f->lowres_w, f->lowres_channels, f->Hf, f->Wf, lr));
   return integrate_frame_impl(h, mapper_id, f->depth, f->rgb, f->features_f16, f->lowres_features ? &lr : nullptr, f->input_mask, f->H,
@@ -1745,6 +1838,37 @@ int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
   return check_launch();
 }
 
+int mmf_set_deferred_feature_rows(mmf_handle h, int mapper_id, int on) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  if (mapper_id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
+  for (int i = 0; i < (int)h->mappers.size(); ++i) {
+    if (mapper_id >= 0 && i != mapper_id) continue;
+    Mapper* m = h->mappers[i];
+    if (!on) MMF_TRY(flush_rows(h, *m));
+    m->defer_rows = on != 0;
+  }
+  return check_launch();
+}
+
+int mmf_deferred_feature_rows_pending(mmf_handle h, int mapper_id) {
+  Mapper* m;
+  if (get_mapper_keep_rows(h, mapper_id, &m) != MMF_OK) return MMF_ERR_INVALID_ARG;
+  return m->rows_pending ? 1 : 0;
+}
+
+int mmf_flush(mmf_handle h, int mapper_id, void* stream) {
+  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
+  if (mapper_id >= (int)h->mappers.size()) return fail(MMF_ERR_INVALID_ARG, "mapper_id out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  for (int i = 0; i < (int)h->mappers.size(); ++i) {
+    if (mapper_id >= 0 && i != mapper_id) continue;
+    Mapper* m = h->mappers[i];
+    MMF_TRY(flush_rows(h, *m));
+    flush_decay(h, *m, (hipStream_t)stream);
+  }
+  return check_launch();
+}
+
 int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
   if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
   HIP_TRY(hipSetDevice(h->device));
@@ -1754,6 +1878,7 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
     m->pending_decay = false;  // decaying blocks that are about to be dropped is a no-op
+    m->rows_pending = false;   // and so is updating their rows
     m->hints[7] = 0;           // (k_reset_layer zeroes the layer's error bits)
     launch_layer_reset(m->tsdf.d, s);
     m->wmax_valid = true;  // no live block

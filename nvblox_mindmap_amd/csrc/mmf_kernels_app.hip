@@ -792,6 +792,23 @@ __global__ __launch_bounds__(256) void k_feature_flat2(AppArgs A0, MapConsts mc0
     feature_flat_role<LOW>(A1, mc1, lpv, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, s_prefix);
 }
 
+// The PREVIOUS frame's row update as a role of this frame's sphere-trace launch (mmf_set_deferred_feature_rows): the rows of
+// frame N are independent of everything frame N + 1 does before its own row update (they are read by map consumers only, and
+// those flush first), the tracer is a chain of dependent rounds at 53 registers on 1 202 of the chip's 2 048 workgroup slots
+// and 0.03 of the HBM rate, the row update is a bandwidth stream of ~1 200 short workgroups at 60 registers: they fill the
+// empty slots and end long before the slowest ray patch.  Grid: [allocation jobs | ray patches | row-update workgroups] --
+// the patches first, each is as long as the launch.
+template <bool DENSE, int MODE>
+__global__ __launch_bounds__(256, 5) void k_sphere_alloc_flat(SphereArgs A, AppArgs F, int lpv, int n_flat) {
+  __shared__ SphereLds Q;
+  __shared__ int s_prefix[kFlatSubLists + 1];
+  int b = (int)blockIdx.x;
+  if (b < A.njobs) return sphere_alloc_role<DENSE, MODE>(A, Q, b);
+  b -= A.njobs;
+  if (b < A.n_patches) return sphere_patch_role(A, Q, b);
+  feature_flat_role<false>(F, A.mc, lpv, b - A.n_patches, n_flat, s_prefix);
+}
+
 // N frames' survivor lists in one launch: frame q's list is walked by its own nb[q] workgroups
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_feature_flat_batch(FlatBatch P) {
@@ -979,6 +996,15 @@ __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, 
 #endif
 }
 
+// ... | the PREVIOUS frame's row update (experiment: the gating launch as host instead of the sphere trace)
+__global__ __launch_bounds__(256) void k_app_frame_flat(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
+                                                       int Hs, AppArgs F, int lpv, int nb_gate, int n_flat) {
+  __shared__ FeatLds S;
+  __shared__ int s_prefix[kFlatSubLists + 1];
+  if ((int)blockIdx.x < nb_gate) return app_frame_body<false, true>(Acol, Afeat, mc, synth, Ws, Hs, (int)blockIdx.x, nb_gate, S);
+  feature_flat_role<false>(F, mc, lpv, (int)blockIdx.x - nb_gate, n_flat, s_prefix);
+}
+
 // two frames' candidate lists in one launch (mmf_integrate_frame_multi)
 template <bool LOW, bool PUB>
 __global__ __launch_bounds__(256) void k_app_frame2(AppFrameArgs F0, AppFrameArgs F1, int nb0) {
@@ -1113,20 +1139,56 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
                              const Scratch& sc, long long* stats, const LowRes* low, const FlatList* flat);
+static int flat_lanes_per_voxel(const MapConsts& mc);
+static int flat_grid(const FlatList& fl, int lpv);
 
 // balanced phase 2 over the frame's survivor list (enqueued right behind the gating launch)
+static int flat_lanes_per_voxel(const MapConsts& mc) {
+  const int nch = mc.C >> 3;
+  return nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);
+}
+static int flat_grid(const FlatList& fl, int lpv) {
+  const int vpw = 256 / lpv;
+  const long long vox = hinted(fl.hint, fl.cap);
+  long long wgs = (vox + vpw - 1) / vpw;
+  wgs = wgs > 16384 ? 16384 : wgs;
+  return grid8((int)wgs, 16384);
+}
+
+AppArgs make_flat_args(const LayerDev& L, const Cam& cam, const __half* feat, const LowRes* lowres, const FlatList& fl, long long* stats) {
+  return make_app_args(L, cam, Rigid{}, feat, nullptr, Scratch{}, stats, lowres, &fl);
+}
+
+// the stand-alone row update from a saved argument block (the flush of a deferred one)
+void launch_feature_flat_args(const AppArgs& Af, const MapConsts& mc, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (!Af.flat.rec) return;
+  const int lpv = flat_lanes_per_voxel(mc);
+  const dim3 grid((unsigned)flat_grid(Af.flat, lpv));
+  if (Af.low.data)
+    hipExtLaunchKernelGGL(k_feature_flat<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+  else
+    hipExtLaunchKernelGGL(k_feature_flat<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+}
+
+// sphere trace | colour allocation | feature allocation of this frame | row update of the previous one (full-resolution
+// feature image only: the low-res form needs 101 registers and would take the tracer's slots)
+void launch_sphere_alloc_flat(const SphereArgs& A, const AppArgs& F, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int lpv = flat_lanes_per_voxel(A.mc);
+  const int n_flat = flat_grid(F.flat, lpv);
+  const dim3 grid(A.njobs + A.n_patches + n_flat);
+  if (sphere_dense(A))
+    hipExtLaunchKernelGGL((k_sphere_alloc_flat<true, 1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
+  else
+    hipExtLaunchKernelGGL((k_sphere_alloc_flat<false, -1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
+}
+
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* lowres,
                          const FlatList& fl, long long* stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (!fl.rec) return;
   const bool low = lowres != nullptr;
   const AppArgs Af = make_app_args(L, cam, Rigid{}, feat, nullptr, Scratch{}, stats, lowres, &fl);
-  const int nch = mc.C >> 3;
-  const int lpv = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : (nch % 64 == 0 ? 64 : 32);  // lanes per voxel row
-  const int vpw = 256 / lpv;
-  const long long vox = hinted(fl.hint, fl.cap);
-  long long wgs = (vox + vpw - 1) / vpw;
-  wgs = wgs > 16384 ? 16384 : wgs;
-  const dim3 grid((unsigned)grid8((int)wgs, 16384));
+  const int lpv = flat_lanes_per_voxel(mc);
+  const dim3 grid((unsigned)flat_grid(fl, lpv));
   // with events: the extension launch stamps them with the dispatch's own begin / end times (what rocprofv3 reports as
   // the kernel duration), no marker packets around the kernel
   if (low)
@@ -1151,7 +1213,8 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
                            hipStream_t s, const LowRes* low, const FlatList* flat, bool same_candidates, hipEvent_t ev_start,
-                           hipEvent_t ev_stop) {
+                           hipEvent_t ev_stop, const AppArgs* rows, bool* rows_hosted) {
+  if (rows_hosted) *rows_hosted = false;
   const AppArgs Ac = make_app_args(Lc, ccam, T_C_L, rgb, cmask, csc),
                 Af = make_app_args(Lf, fcam, T_C_L, feat, fmask, fsc, stats, low, flat);
   // same_candidates: both allocation jobs compacted the same flag array, so candidate i is the same block in both lists
@@ -1159,7 +1222,13 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                         ccam.cx == fcam.cx && ccam.cy == fcam.cy;
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
-    if (flat && flat->rec)
+    if (flat && flat->rec && rows && rows_hosted && !low) {
+      const int lpv = flat_lanes_per_voxel(mc);
+      const int n_flat = flat_grid(rows->flat, lpv);
+      hipExtLaunchKernelGGL(k_app_frame_flat, dim3(grid.x + n_flat), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs,
+                            *rows, lpv, (int)grid.x, n_flat);
+      *rows_hosted = true;
+    } else if (flat && flat->rec)
       hipExtLaunchKernelGGL((k_app_frame<false, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
     else if (low)
       hipExtLaunchKernelGGL((k_app_frame<true, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);

@@ -256,12 +256,20 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
                            hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr, bool same_candidates = false,
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const AppArgs* rows = nullptr,
+                           bool* rows_hosted = nullptr);  // rows: a pending row update of the previous frame to run beside the gating
 
 // balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,
                          const FlatList& fl, long long* stats, hipStream_t s, hipEvent_t ev_start = nullptr,
                          hipEvent_t ev_stop = nullptr);  // stats: the frame's survivor total is added to stats[8] here
+// the same from a saved argument block (a deferred row update: mmf_set_deferred_feature_rows), stand-alone or as a role of the
+// NEXT frame's sphere-trace launch
+AppArgs make_flat_args(const LayerDev& L, const Cam& cam, const __half* feat, const LowRes* low, const FlatList& fl, long long* stats);
+void launch_feature_flat_args(const AppArgs& Af, const MapConsts& mc, hipStream_t s, hipEvent_t ev_start = nullptr,
+                              hipEvent_t ev_stop = nullptr);
+void launch_sphere_alloc_flat(const SphereArgs& A, const AppArgs& F, hipStream_t s, hipEvent_t ev_start = nullptr,
+                              hipEvent_t ev_stop = nullptr);
 
 // mmf_kernels_mesh.hip
 void launch_mesh_count(const LayerDev& tsdf, const MapConsts& mc, int* counts, int* offsets, int* total_host_mapped,

@@ -277,6 +277,7 @@ class Mapper:
         self._h = h
         self._n = n
         self._mesh_V = {}
+        self._held_rows = {}  # mapper_id -> (feature image of a frame whose row update is deferred, its version counter)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -416,9 +417,38 @@ class Mapper:
         f, keep, dm, fm = self._frame_desc(depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
                                            min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
                                            border_percent, invert_input_mask)
+        self._check_held_rows(mapper_id)
         _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
+        if feature_frame is not None and _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
+            self._held_rows[mapper_id] = (keep[0], keep[0]._version)  # the native side still reads it: keep it allocated
         del keep
         return dm, fm
+
+    def _check_held_rows(self, mapper_id: int) -> None:
+        held = self._held_rows.pop(mapper_id, None)
+        if held is None or _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) != 1:
+            return
+        if held[0]._version != held[1]:
+            raise RuntimeError(
+                "the feature image of the previous frame was modified in place while its row update was deferred "
+                "(set_deferred_feature_rows): the map would differ from the undeferred sequence.  Hand every frame its own "
+                "tensor, or call flush() before reusing the buffer.")
+
+    def set_deferred_feature_rows(self, on: bool = True, mapper_id: int = -1) -> None:
+        """Extension (``mmf_set_deferred_feature_rows``): consecutive ``integrate_frame`` calls are software-pipelined -- a
+        frame's last launch (the feature-row update of the voxels that passed the gate) rides in the NEXT frame's sphere-trace
+        launch; anything else that touches the mapper runs it first, so every result is bit-identical to the undeferred
+        sequence.  While on, the feature image of a frame must not be modified in place before the next call on the mapper
+        (this object keeps the tensor alive and checks its version counter).  Off by default."""
+        _lib.check(_lib.lib().mmf_set_deferred_feature_rows(self._h, int(mapper_id), 1 if on else 0), "mmf_set_deferred_feature_rows")
+        if not on:
+            self._held_rows.clear()
+
+    def flush(self, mapper_id: int = -1) -> None:
+        """Enqueue whatever is pending on the mapper (a deferred row update, a lazy ``decay()``)."""
+        for i in ([int(mapper_id)] if int(mapper_id) >= 0 else list(self._held_rows)):
+            self._check_held_rows(i)
+        _lib.check(_lib.lib().mmf_flush(self._h, int(mapper_id), self._stream()), "mmf_flush")
 
     def integrate_frame_multi(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor, t_w_c, intrinsics,
                               min_depth_m: float, border_percent: int, jobs, lowres_features: Optional[torch.Tensor] = None):

@@ -1,0 +1,182 @@
+"""Deferred feature rows (``mmf_set_deferred_feature_rows`` / ``Mapper.set_deferred_feature_rows``): a fused frame leaves its last
+launch -- the row update of its survivor list -- to the next fused frame, which runs it beside its sphere trace; anything else
+that takes the mapper runs it first.  Every observable state must be bit-identical to the undeferred sequence: at the end of a
+stream, in the middle of it, and whatever call comes between two frames."""
+import numpy as np
+import pytest
+import torch
+
+from fusion_common import make_mapper, make_oracle, small_cfg
+from nvblox_mindmap_amd import _lib
+from nvblox_mindmap_amd import synthetic as S
+from nvblox_mindmap_amd.nvblox_torch.mapper import integrate_frames_batch
+from test_gpu_frame_batch import frame_args, same_maps, single
+from test_gpu_fusion_parity import compare_features, compare_tsdf
+
+pytestmark = pytest.mark.gpu
+
+
+def pending(m, mapper_id=0):
+    return _lib.lib().mmf_deferred_feature_rows_pending(m._h, mapper_id)
+
+
+def stream_cfg(scale):
+    base = small_cfg(scale)
+    return S.StreamConfig(width=base.width, height=base.height, fx=base.fx, fy=base.fy, cx=base.cx, cy=base.cy, hole_mode="patches")
+
+
+def pair(C, **kw):
+    a, b = make_mapper(C, **kw), make_mapper(C, **kw)
+    a.set_deferred_feature_rows(True)
+    return a, b
+
+
+def feed(cfg, mappers, index, C, k, decay=True):
+    """the same frame into every mapper (each gets its own tensors: the deferred one keeps its feature image in use)"""
+    out = []
+    for m in mappers:
+        e, f, dyn = frame_args(cfg, m, index, C, k)
+        if decay:
+            m.decay()
+        out.append(single(e))
+    for (dm, fm) in out[1:]:
+        assert torch.equal(dm, out[0][0]) and torch.equal(fm, out[0][1])
+    return f, dyn
+
+
+def test_stream_equals_the_undeferred_one_and_the_oracle(oracle_mod):
+    from oracle import image_ops as IO
+
+    cfg, C = stream_cfg(2), 16
+    d, e = pair(C)
+    orc = make_oracle(oracle_mod, C)
+    for step in range(6):
+        f, dyn = feed(cfg, (d, e), (9 * step) % 200, C, step)
+        assert pending(d) == 1 and pending(e) == 0
+        odm, ofm = IO.frame_masks(~dyn, f["depth"], 0.3, 3, 4, 5, cfg.height, cfg.width)
+        orc.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+        if step == 2:  # a reader in the middle of the stream sees the frame complete (and leaves nothing pending)
+            same_maps(d, e)
+            assert pending(d) == 0
+    same_maps(d, e)
+    assert pending(d) == 0
+    compare_tsdf(orc, d)
+    compare_features(orc, d)
+    assert d.stats() == e.stats()
+
+
+def test_full_size_stream():
+    """BASELINE configs[2] at full size (640x480, C = 64): 8 frames with a decay() before each, deferred against undeferred."""
+    cfg, C = S.StreamConfig(hole_mode="patches"), 64
+    d, e = pair(C)
+    for step in range(8):
+        feed(cfg, (d, e), 5 * step, C, step)
+    assert pending(d) == 1
+    d.flush()
+    assert pending(d) == 0
+    same_maps(d, e)
+
+
+def _standalone_feature(cfg, C, m):
+    f = S.frame(cfg, 11, C)
+    m.add_feature_frame(torch.from_numpy(np.ascontiguousarray(f["features"])).cuda(), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]))
+
+
+def _lowres_frame(cfg, C, m):
+    ea, f, dyn = frame_args(cfg, m, 17, C, 3)
+    low = torch.rand(15, 20, 16, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    m.integrate_frame_lowres(ea["depth_frame"], ea["color_frame"], low, ea["input_mask"], ea["t_w_c"], ea["intrinsics"], 0.3, 3, 4, 5)
+
+
+def _batch_call(cfg, C, m):
+    ea, _, _ = frame_args(cfg, m, 23, C, 4)
+    integrate_frames_batch([ea])
+
+
+def _multi_call(cfg, C, m):
+    ea, _, _ = frame_args(cfg, m, 29, C, 5)
+    m.integrate_frame_multi(ea["depth_frame"], ea["color_frame"], ea["feature_frame"], ea["t_w_c"], ea["intrinsics"], 0.3, 5,
+                            [dict(mapper_id=0, input_mask=ea["input_mask"], input_mask_erosion_iterations=3,
+                                  valid_depth_mask_erosion_iterations=4)])
+
+
+def _other_stream(cfg, C, m):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ea, _, _ = frame_args(cfg, m, 31, C, 6)
+        single(ea)
+    torch.cuda.current_stream().wait_stream(s)
+
+
+def _same_pose_twice(cfg, C, m):  # the second frame finds its synthetic depth cached: no sphere-trace launch to ride in
+    for _ in range(2):
+        ea, _, _ = frame_args(cfg, m, 37, C, 7)
+        single(ea)
+
+
+BETWEEN = {"add_feature_frame": _standalone_feature, "lowres_frame": _lowres_frame, "frame_batch": _batch_call, "frame_multi": _multi_call,
+           "other_stream": _other_stream, "same_pose_twice": _same_pose_twice, "decay": lambda cfg, C, m: m.decay(),
+           "mesh": lambda cfg, C, m: m.update_feature_mesh(), "clear": lambda cfg, C, m: m.clear(),
+           "color_frame": lambda cfg, C, m: m.add_color_frame(frame_args(cfg, m, 3, C, 1)[0]["color_frame"],
+                                                              torch.from_numpy(S.frame(cfg, 3, C)["T_W_C"]), torch.from_numpy(S.frame(cfg, 3, C)["K"]))}
+
+
+@pytest.mark.parametrize("what", sorted(BETWEEN))
+def test_whatever_comes_between_two_frames(what):
+    cfg, C = stream_cfg(2), 16
+    d, e = pair(C)
+    feed(cfg, (d, e), 0, C, 0)
+    feed(cfg, (d, e), 4, C, 1)
+    assert pending(d) == 1
+    for m in (d, e):
+        BETWEEN[what](cfg, C, m)
+    feed(cfg, (d, e), 7, C, 2)
+    feed(cfg, (d, e), 10, C, 3, decay=False)
+    assert pending(d) == 1
+    same_maps(d, e)
+
+
+def test_switching_it_off_runs_what_is_pending():
+    cfg, C = stream_cfg(2), 16
+    d, e = pair(C)
+    feed(cfg, (d, e), 100, C, 9)
+    assert pending(d) == 1
+    d.set_deferred_feature_rows(False)
+    assert pending(d) == 0
+    feed(cfg, (d, e), 104, C, 10)
+    assert pending(d) == 0
+    same_maps(d, e)
+
+
+def test_checkpoint_of_a_deferred_stream(tmp_path):
+    cfg, C = stream_cfg(2), 16
+    d, e = pair(C)
+    for step in range(3):
+        feed(cfg, (d, e), 13 * step, C, step)
+    d.save_map(str(tmp_path / "d.nvblx"))
+    r = make_mapper(C)
+    r.load_from_file(str(tmp_path / "d.nvblx"))
+    same_maps(r, e)
+
+
+def test_feature_image_modified_in_place_is_reported():
+    cfg, C = stream_cfg(4), 16
+    d = make_mapper(C)
+    d.set_deferred_feature_rows(True)
+    ea, _, _ = frame_args(cfg, d, 0, C, 0)
+    single(ea)
+    ea["feature_frame"].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        single(ea)
+    # ... unless the update has run in the meantime
+    d2 = make_mapper(C)
+    d2.set_deferred_feature_rows(True)
+    eb, _, _ = frame_args(cfg, d2, 0, C, 0)
+    single(eb)
+    d2.flush()
+    eb["feature_frame"].mul_(2.0)
+    single(eb)
