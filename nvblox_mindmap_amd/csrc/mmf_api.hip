@@ -96,6 +96,8 @@ struct Mapper {
   bool rows_pending = false;
   AppArgs rows_args{};         // argument block of the pending row update (list, image, pool)
   hipStream_t rows_stream = nullptr;
+  bool tail_pending = false;   // the frame's launch 4 (colour update + feature gating) is pending too: it fills rows_args' list
+  AppTail tail{};
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
   bool wmax_valid = true;      // (an empty map trivially) tsdf.d.wmax holds every live block's largest weight (set by a fused frame, cleared by whatever
                                // else writes TSDF weights): a pending decay can then take the light path
@@ -565,21 +567,18 @@ int compute_view_grid(const Mapper& m, const Cam& cam, const Rigid& T_L_C, ViewG
   return MMF_OK;
 }
 
-// experiment switch: which launch of the next frame hosts a deferred row update (3 = sphere trace, 4 = gating)
-static int rows_host() {
-  static const int v = [] {
-    const char* e = getenv("MMF_DEBUG_ROWS_HOST");
-    return e ? atoi(e) : 3;
-  }();
-  return v;
-}
-
 // A deferred row update runs now, as the launch it would have been, on the stream of the frame it belongs to (where the
 // undeferred launch would have been enqueued: the ordering against later work is what it would have been).
 int flush_rows(mmf_handle h, Mapper& m) {
-  if (!m.rows_pending) return MMF_OK;
-  m.rows_pending = false;
+  if (!m.rows_pending && !m.tail_pending) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
+  if (m.tail_pending) {
+    m.tail_pending = false;
+    m.rows_pending = true;
+    ProfExt pe(h, MMF_K_FEATURE);
+    launch_app_tail(m.tail, m.rows_stream, pe.a(), pe.b());
+  }
+  m.rows_pending = false;
   ProfExt pe(h, MMF_K_FEATURE_FLAT);
   launch_feature_flat_args(m.rows_args, m.mc, m.rows_stream, pe.a(), pe.b());
   return MMF_OK;
@@ -1193,7 +1192,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                                      "use the separate add_*_frame calls otherwise");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  if (m->rows_pending && m->rows_stream != s) {
+  if ((m->rows_pending || m->tail_pending) && m->rows_stream != s) {
     // another stream: the update goes where it would have been enqueued, and -- it is enqueued later than it would have been, after
     // whatever synchronisation the caller placed between the two streams -- this stream waits for it
     hipStream_t old_stream = m->rows_stream;
@@ -1323,7 +1322,13 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     const FrontArgs FA = make_front_args(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M,
                                          (do_decay && !big) ? &m->tsdf.d : nullptr, light_decay, m->kill, m->any_kill,
                                          merged ? m->tsdf.d.ctr : nullptr, grid_tag);
-    launch_front(&FA, 1, s, pe.a(), pe.b());
+    if (m->tail_pending) {  // ... | the previous frame's colour update + feature gating
+      m->tail_pending = false;
+      m->rows_pending = true;
+      launch_front_app(FA, m->tail, s, pe.a(), pe.b());
+    } else {
+      launch_front(&FA, 1, s, pe.a(), pe.b());
+    }
   }
   KeySrc ks0{};
   ks0.mode = 0;
@@ -1415,7 +1420,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     } else if (need) {
       ProfExt pe(h, MMF_K_SPHERE);
       const SphereArgs SA = make_sphere_args(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, 2, m->stats);
-      if (m->rows_pending && rows_host() == 3) {  // ... | the previous frame's row update (its list is the other one of the pair: nobody zeroes it here)
+      if (m->rows_pending) {  // ... | the previous frame's row update (its list is the other one of the pair: nobody zeroes it here)
         m->rows_pending = false;
         launch_sphere_alloc_flat(SA, m->rows_args, s, pe.a(), pe.b());
       } else {
@@ -1423,29 +1428,30 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       }
       synth_commit(*m, cam, T16, K9, Ws, Hs);
     } else {
-      if (rows_host() == 3) MMF_TRY(flush_rows(h, *m));
+      MMF_TRY(flush_rows(h, *m));
       ProfScope ps(h, MMF_K_SPHERE, s);
       launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
     }
   }
-  {
-    bool hosted = false;
-    {
-      ProfExt pe(h, MMF_K_FEATURE);
-      launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
-                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
-                            pe.a(), pe.b(), m->rows_pending ? &m->rows_args : nullptr, &hosted);
-    }
-    if (hosted) m->rows_pending = false;
-    MMF_TRY(flush_rows(h, *m));  // (nothing hosted it: before this frame's own)
-  }
   if (may_defer && m->defer_rows && !big && !low && m->flat.rec && m->flat_other.rec) {
-    // the rows of this frame's survivors: left to the next fused frame's launch 3 (or to whatever touches the mapper first)
+    // launches 4 and 5 are left to the next fused frame (roles of its launches 1 and 3) or to whatever takes the mapper first
+    MMF_TRY(flush_rows(h, *m));  // (nothing hosted the previous frame's: before this frame's own)
+    m->tail = make_app_tail(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
+                            m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, m->flat);
     m->rows_args = make_flat_args(m->feat.d, fcam, (const __half*)feat, nullptr, m->flat, m->stats);
     m->rows_stream = s;
-    m->rows_pending = true;
+    m->tail_pending = true;
     std::swap(m->flat, m->flat_other);  // the next frame fills (and its launch 3 zeroes) the other list
-  } else {
+    return check_launch();
+  }
+  MMF_TRY(flush_rows(h, *m));
+  {
+    ProfExt pe(h, MMF_K_FEATURE);
+    launch_app_integrate2(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
+                          m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, s, low, &m->flat, true,
+                          pe.a(), pe.b());
+  }
+  {
     ProfExt pe(h, MMF_K_FEATURE_FLAT);
     launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s, pe.a(), pe.b());
   }
@@ -1829,6 +1835,7 @@ int mmf_decay(mmf_handle h, int mapper_id, void* stream) {
     m->pending_decay = true;
     m->tsdf_epoch++;
     if (m->P.decay_appearance_layers) {  // spec switch: the appearance weights fade too (eager; independent of the TSDF layer)
+      MMF_TRY(flush_rows(h, *m));        // (after the weights of a deferred frame)
       if (m->color.allocated) launch_decay_app_weights(m->color.d, m->mc.decay_factor, false, s);
       if (m->feat.allocated) launch_decay_app_weights(m->feat.d, m->mc.decay_factor, true, s);
       m->frames[2]++;  // (cached model-input rows read feature weights)
@@ -1853,7 +1860,7 @@ int mmf_set_deferred_feature_rows(mmf_handle h, int mapper_id, int on) {
 int mmf_deferred_feature_rows_pending(mmf_handle h, int mapper_id) {
   Mapper* m;
   if (get_mapper_keep_rows(h, mapper_id, &m) != MMF_OK) return MMF_ERR_INVALID_ARG;
-  return m->rows_pending ? 1 : 0;
+  return (m->rows_pending || m->tail_pending) ? 1 : 0;
 }
 
 int mmf_flush(mmf_handle h, int mapper_id, void* stream) {
@@ -1878,7 +1885,8 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
     m->pending_decay = false;  // decaying blocks that are about to be dropped is a no-op
-    m->rows_pending = false;   // and so is updating their rows
+    m->rows_pending = false;   // and so is updating their appearance
+    m->tail_pending = false;
     m->hints[7] = 0;           // (k_reset_layer zeroes the layer's error bits)
     launch_layer_reset(m->tsdf.d, s);
     m->wmax_valid = true;  // no live block

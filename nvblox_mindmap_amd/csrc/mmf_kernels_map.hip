@@ -13,6 +13,7 @@
 #include "mmf_trace_device.h"
 #include "mmf_alloc_device.h"
 #include "mmf_mask_device.h"
+#include "mmf_app_device.h"
 
 namespace mmf {
 
@@ -267,6 +268,20 @@ __global__ __launch_bounds__(256) void k_front2(FrontArgs A0, FrontArgs A1) {
     front_role<LDSFLAGS>(A0, b, s_words, S);
   else
     front_role<LDSFLAGS>(A1, b - A0.n_wgs, s_words, S);
+}
+
+// Deferred mode: the colour update + feature gating of the PREVIOUS frame as one more role of this frame's first launch.  It
+// reads the previous frame's candidate lists, synthetic depth, masks and images and writes the appearance layers; the raycast,
+// the mask rows and the decay touch the depth image, the view grid and the TSDF layer's lists -- nothing in common.  The
+// gating workgroups follow the frame's own (the longest rays decide when the launch ends; in front of the mask rows they cost
+// 1.7 us more); their LDS is the launch's dynamic block.
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256) void k_front_app(FrontArgs A, AppArgs Acol, AppArgs Afeat, const float* __restrict__ synth, int Ws, int Hs,
+                                                  int nb_gate) {
+  extern __shared__ unsigned s_words[];
+  __shared__ FrontLds S;
+  if ((int)blockIdx.x < A.n_wgs) return front_role<LDSFLAGS>(A, (int)blockIdx.x, s_words, S);
+  app_frame_body<false, true>(Acol, Afeat, A.R.mc, synth, Ws, Hs, (int)blockIdx.x - A.n_wgs, nb_gate, *reinterpret_cast<FeatLds*>(s_words));
 }
 
 // N frames (independent mappers: mmf_integrate_frame_batch): frame q's workgroups follow frame q-1's.
@@ -1306,6 +1321,19 @@ void launch_front(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start,
     else
       hipExtLaunchKernelGGL(k_front2<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, A[0], A[1]);
   }
+}
+
+void launch_front_app(const FrontArgs& A, const AppTail& T, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int ncells = front_cells(A);
+  const bool lds = ncells <= kRaycastLdsCells;
+  size_t shm = lds ? (size_t)((ncells + 3) / 4) * 4 : 0;
+  shm = shm < sizeof(FeatLds) ? sizeof(FeatLds) : shm;
+  const int nb_gate = app_tail_grid(T);
+  const dim3 grid(A.n_wgs + nb_gate);
+  if (lds)
+    hipExtLaunchKernelGGL(k_front_app<true>, grid, dim3(256), shm, s, ev_start, ev_stop, 0, A, T.Ac, T.Af, T.synth, T.Ws, T.Hs, nb_gate);
+  else
+    hipExtLaunchKernelGGL(k_front_app<false>, grid, dim3(256), shm, s, ev_start, ev_stop, 0, A, T.Ac, T.Af, T.synth, T.Ws, T.Hs, nb_gate);
 }
 
 void launch_front_batch(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {

@@ -256,15 +256,29 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
                            const LayerDev& Lf, const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc,
                            const MapConsts& mc, const Rigid& T_C_L, const float* synth, int Ws, int Hs, int max_cand, long long* stats,
                            hipStream_t s, const LowRes* low = nullptr, const FlatList* flat = nullptr, bool same_candidates = false,
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const AppArgs* rows = nullptr,
-                           bool* rows_hosted = nullptr);  // rows: a pending row update of the previous frame to run beside the gating
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // balanced phase 2 of a feature update whose gating launch was given the survivor list `fl` (no-op without a list)
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* low,
                          const FlatList& fl, long long* stats, hipStream_t s, hipEvent_t ev_start = nullptr,
                          hipEvent_t ev_stop = nullptr);  // stats: the frame's survivor total is added to stats[8] here
-// the same from a saved argument block (a deferred row update: mmf_set_deferred_feature_rows), stand-alone or as a role of the
-// NEXT frame's sphere-trace launch
+// The appearance tail of a fused frame -- launch 4 (colour update + feature gating) and launch 5 (rows of the survivors) -- as
+// saved argument blocks: in deferred mode (mmf_set_deferred_feature_rows) the NEXT fused frame runs them as roles of its
+// launches 1 and 3, anything else that takes the mapper runs them stand-alone first.
+struct AppTail {
+  AppArgs Ac, Af;
+  MapConsts mc;
+  const float* synth;
+  int Ws, Hs, max_cand;
+};
+AppTail make_app_tail(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc, const LayerDev& Lf,
+                      const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc, const MapConsts& mc, const Rigid& T_C_L,
+                      const float* synth, int Ws, int Hs, int max_cand, long long* stats, const FlatList& flat);
+int app_tail_grid(const AppTail& T);
+void launch_app_tail(const AppTail& T, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// raycast | mask rows | pending decay of THIS frame | colour update + feature gating of the PREVIOUS one
+void launch_front_app(const FrontArgs& A, const AppTail& T, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// the row update from a saved argument block, stand-alone or as a role of the NEXT frame's sphere-trace launch
 AppArgs make_flat_args(const LayerDev& L, const Cam& cam, const __half* feat, const LowRes* low, const FlatList& fl, long long* stats);
 void launch_feature_flat_args(const AppArgs& Af, const MapConsts& mc, hipStream_t s, hipEvent_t ev_start = nullptr,
                               hipEvent_t ev_stop = nullptr);

@@ -420,7 +420,10 @@ class Mapper:
         self._check_held_rows(mapper_id)
         _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
         if feature_frame is not None and _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
-            self._held_rows[mapper_id] = (keep[0], keep[0]._version)  # the native side still reads it: keep it allocated
+            # the native side still reads the feature image, the colour image and the two masks it has just written: keep them
+            # allocated, and remember their version counters
+            held = (keep[0], keep[2], dm, fm)
+            self._held_rows[mapper_id] = (held, tuple(t._version for t in held))
         del keep
         return dm, fm
 
@@ -428,18 +431,19 @@ class Mapper:
         held = self._held_rows.pop(mapper_id, None)
         if held is None or _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) != 1:
             return
-        if held[0]._version != held[1]:
+        if tuple(t._version for t in held[0]) != held[1]:
             raise RuntimeError(
-                "the feature image of the previous frame was modified in place while its row update was deferred "
-                "(set_deferred_feature_rows): the map would differ from the undeferred sequence.  Hand every frame its own "
-                "tensor, or call flush() before reusing the buffer.")
+                "an image of the previous frame (features, colour or one of the returned masks) was modified in place while its "
+                "appearance update was deferred (set_deferred_feature_rows): the map would differ from the undeferred sequence.  "
+                "Hand every frame its own tensors, or call flush() before reusing the buffers.")
 
     def set_deferred_feature_rows(self, on: bool = True, mapper_id: int = -1) -> None:
         """Extension (``mmf_set_deferred_feature_rows``): consecutive ``integrate_frame`` calls are software-pipelined -- a
         frame's last launch (the feature-row update of the voxels that passed the gate) rides in the NEXT frame's sphere-trace
-        launch; anything else that touches the mapper runs it first, so every result is bit-identical to the undeferred
-        sequence.  While on, the feature image of a frame must not be modified in place before the next call on the mapper
-        (this object keeps the tensor alive and checks its version counter).  Off by default."""
+        launch, and its colour update + feature gating in the next frame's first launch; anything else that touches the mapper
+        runs them first, so every result is bit-identical to the undeferred sequence.  While on, the feature image, the colour
+        image and the two returned masks of a frame must not be modified in place before the next call on the mapper (this
+        object keeps the tensors alive and checks their version counters).  Off by default."""
         _lib.check(_lib.lib().mmf_set_deferred_feature_rows(self._h, int(mapper_id), 1 if on else 0), "mmf_set_deferred_feature_rows")
         if not on:
             self._held_rows.clear()
