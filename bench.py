@@ -1055,7 +1055,14 @@ KERNEL_OF_CLASS = {"raycast": "k_front", "tsdf": "k_alloc_tsdf", "sphere": "k_sp
 # dependent loads at full occupancy; hbm: bytes/s against the HBM peak.
 VALU_ISSUE_PEAK_PER_S = 1024 * 2.4e9 / 4.0
 BOUND_OF_KERNEL = {"k_front": "valu_issue", "k_alloc_tsdf": "latency", "k_sphere_alloc": "valu_issue", "k_app_frame": "latency",
-                   "k_feature_flat": "hbm"}
+                   "k_feature_flat": "hbm", "k_front_app": "valu_issue", "k_sphere_alloc_flat": "valu_issue"}
+# The launches of a frame: (profile class, kernel, the roles whose algorithmic bytes it moves).  Deferred mode (the headline:
+# mmf_set_deferred_feature_rows): the colour update + feature gating and the row update of frame N are roles of launches 1 and 3
+# of frame N + 1 -- three launches per frame in a stream.
+LAUNCHES_EAGER = [("raycast", "k_front", ["k_front"]), ("tsdf", "k_alloc_tsdf", ["k_alloc_tsdf"]), ("sphere", "k_sphere_alloc", ["k_sphere_alloc"]),
+                  ("feature", "k_app_frame", ["k_app_frame"]), ("feature_flat", "k_feature_flat", ["k_feature_flat"])]
+LAUNCHES_DEFERRED = [("raycast", "k_front_app", ["k_front", "k_app_frame"]), ("tsdf", "k_alloc_tsdf", ["k_alloc_tsdf"]),
+                     ("sphere", "k_sphere_alloc_flat", ["k_sphere_alloc", "k_feature_flat"])]
 
 
 def sq_evidence():
@@ -1211,6 +1218,22 @@ def main():
 
     mapper.profile_enable(False)
     prof = mapper.profile()
+    undeferred = None
+    if not args.eager_rows:
+        # the same stream with every frame's five launches run before the next frame starts (what a caller gets who cannot keep
+        # a frame's images untouched until the next call): two regions, untimed per launch
+        mapper.set_deferred_feature_rows(False)
+        und = []
+        for _ in range(2):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(mapper, mcfg, frames[(k + i) % n_frames])
+            torch.cuda.synchronize(device)
+            und.append(time.perf_counter() - t0)
+            k += args.steps
+        undeferred = {"frames_per_s": args.steps / min(und), "ms_per_step": min(und) / args.steps * 1e3,
+                      "launches_per_frame": 5}
     stats = mapper.stats(MAPPER_TO_ID.STATIC)
     n_live = int(mapper.tsdf_layer_view(MAPPER_TO_ID.STATIC).num_allocated_blocks())
 
@@ -1260,14 +1283,16 @@ def main():
         fps = world * args.steps / elapsed
         t_frame = elapsed / args.steps
         model = frame_byte_model(cfg, C, n_live, tsdf_blocks_per_frame, col_blocks_per_frame, feat_voxels_per_frame)
-        b_frame = sum(model.values())
+        b_frame = sum(model.values())  # (the five roles; the launches that carry them are named below)
         traffic, traffic_src = pmc_traffic()
         sq, sq_src = sq_evidence()
         per_kernel, busy_us = [], 0.0
-        for cls, kname in KERNEL_OF_CLASS.items():
+        launches = LAUNCHES_EAGER if args.eager_rows else LAUNCHES_DEFERRED
+        for cls, kname, roles in launches:
             ms, n = prof.get(cls, (0.0, 0))
             us = ms / n * 1e3 if n else None
             busy_us += us or 0.0
+            model[kname] = sum(model[r] for r in roles)
             hbm_frac = (model[kname] / (us * 1e-6) / HBM_PEAK_BYTES_PER_S) if us else None
             bound = BOUND_OF_KERNEL[kname]
             ev = sq.get(kname)
@@ -1277,7 +1302,7 @@ def main():
             elif bound == "latency" and ev:
                 frac_of_bound = None  # no throughput peak to divide by: the evidence is the parked fraction
             per_kernel.append({
-                "kernel": kname, "avg_us": us, "launches_timed": n, "algorithmic_bytes": model[kname],
+                "kernel": kname, "roles": roles, "avg_us": us, "launches_timed": n, "algorithmic_bytes": model[kname],
                 "achieved_GBps": (model[kname] / (us * 1e-6) / 1e9) if us else None,
                 "frac": hbm_frac, "bound": bound, "frac_of_bound": frac_of_bound, "sq_counters": ev,
                 "traffic": traffic.get(kname)})
@@ -1288,16 +1313,19 @@ def main():
                         + feat_blocks_per_frame * 512 * 2 * (2 * C + 4) + cfg.height * cfg.width * (3 + 1) + col_blocks_per_frame * 512 * 16)
         roofline = {
             "bound": "hbm",
-            "kernel": "whole frame = 5 launches (k_front, k_alloc_tsdf, k_sphere_alloc, k_app_frame, k_feature_flat)",
+            "kernel": ("whole frame = 5 launches (k_front, k_alloc_tsdf, k_sphere_alloc, k_app_frame, k_feature_flat)" if args.eager_rows else
+                       "whole frame = 3 launches of a software-pipelined stream (k_front_app = raycast | mask rows | decay | colour update + "
+                       "feature gating of the previous frame; k_alloc_tsdf; k_sphere_alloc_flat = sphere trace | appearance allocation | "
+                       "feature rows of the previous frame)"),
             "achieved": b_frame / t_frame / 1e9,
             "peak": HBM_PEAK_BYTES_PER_S / 1e9,
             "unit": "GB/s",
             "frac": b_frame / t_frame / HBM_PEAK_BYTES_PER_S,
-            "traffic": sum(traffic.get(k_, 0.0) for k_ in model) if traffic else None,
+            "traffic": sum(traffic.get(k_, 0.0) for _, k_, _ in launches) if traffic else None,
             "traffic_source": traffic_src,
             "sq_counters_source": sq_src,
             "algorithmic_bytes_per_frame": b_frame,
-            "formula": "sum over the five launches of frame_byte_model() (bench.py; DESIGN.md section 5), counts from this run",
+            "formula": "sum over the five roles of frame_byte_model() (bench.py; DESIGN.md section 5), counts from this run",
             "frame_us": t_frame * 1e6,
             "kernels_busy_us": busy_us if timed else None,
             "dominant_launch": dominant,
@@ -1306,8 +1334,9 @@ def main():
                                  "appearance_candidate_blocks": col_blocks_per_frame, "feature_blocks_updated": feat_blocks_per_frame,
                                  "feature_voxels_updated": feat_voxels_per_frame},
             "measured_d2d_copy_GBps": measure_d2d_copy(device),  # read + write rate of a 1 GiB copy on this box
-            "note": "the frame is five dependent launches of 7-17 us, each latency- or issue-bound; only k_feature_flat is "
-                    "bandwidth-bound (and dominates at the reference shape: reference_shape.k_feature_flat_*)",
+            "note": "a frame's five roles are latency- or issue-bound but the feature rows (bandwidth-bound; they dominate at the "
+                    "reference shape: reference_shape.k_feature_flat_*); in a stream the two appearance roles of frame N run beside "
+                    "the raycast and the sphere trace of frame N + 1",
             "survey_8d_model_bytes_per_frame": survey_bytes,
             "survey_8d_model_frac": survey_bytes / t_frame / HBM_PEAK_BYTES_PER_S,
         }
@@ -1343,7 +1372,14 @@ def main():
                 "distinct_frames": n_frames,
                 "tsdf_blocks_per_frame": tsdf_blocks_per_frame,
                 "feature_blocks_per_frame": feat_blocks_per_frame,
+                "frame_pipelining": ("off: every frame's five launches run before the next frame's" if args.eager_rows else
+                                     "mmf_set_deferred_feature_rows: launches 4 and 5 of frame N (colour update + feature gating, feature "
+                                     "rows) run as roles of launches 1 and 3 of frame N + 1; the stream's frames are resident and "
+                                     "unmodified (the mode's contract); every timed region ends with mmf_flush, so all the work of "
+                                     "its frames is inside it; maps bit-identical to the unpipelined sequence "
+                                     "(tests/test_gpu_deferred_rows.py); the unpipelined rate is `undeferred`"),
             },
+            "undeferred": undeferred,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "reference_shape": ref_shape,
