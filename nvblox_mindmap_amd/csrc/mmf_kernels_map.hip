@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256) void k_front_app(FrontArgs A, AppArgs Acol, Ap
   extern __shared__ unsigned s_words[];
   __shared__ FrontLds S;
   if ((int)blockIdx.x < A.n_wgs) return front_role<LDSFLAGS>(A, (int)blockIdx.x, s_words, S);
+  const long long tr0 = wg_trace_begin();
   app_frame_body<false, true>(Acol, Afeat, A.R.mc, synth, Ws, Hs, (int)blockIdx.x - A.n_wgs, nb_gate, *reinterpret_cast<FeatLds*>(s_words));
+  wg_trace_end(tr0, kTrAppFrame);
 }
 
 // N frames (independent mappers: mmf_integrate_frame_batch): frame q's workgroups follow frame q-1's.

@@ -17,16 +17,19 @@ from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox
 from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg  # noqa: E402
 
 NAMES = {10: "k_front raycast", 11: "k_front mask rows", 12: "k_front decay", 20: "allocation workgroups", 21: "mask cols",
-         30: "TSDF pass (existing blocks)", 31: "TSDF pass (new blocks)", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame", 60: "k_feature_flat"}
+         30: "TSDF pass (existing blocks)", 31: "TSDF pass (new blocks)", 40: "k_sphere_alloc allocation", 41: "k_sphere_alloc trace", 50: "k_app_frame (deferred: role of k_front_app)", 60: "k_feature_flat (deferred: role of k_sphere_alloc_flat)"}
 
 
 def main():
-    nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    nframes = int(args[0]) if args else 3
+    deferred = "--deferred" in sys.argv  # the software-pipelined stream: a call = 3 launches, the previous frame's tail inside
     dev = torch.device("cuda", 0)
     cfg = S.StreamConfig(hole_mode="patches")
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     frames = B.build_stream(cfg, 40, 64, dev)
     m = get_nvblox_mapper(mcfg, feature_channels=64)
+    m.set_deferred_feature_rows(deferred)
     for i in range(24):
         B.step(m, mcfg, frames[i])
     torch.cuda.synchronize()
