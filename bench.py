@@ -284,6 +284,21 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
         out["k_feature_flat_frac_of_hbm_peak"] = nbytes / (ms / n * 1e-3) / HBM_PEAK_BYTES_PER_S
     if gate_n:
         out["k_app_frame_gating_us"] = gate_ms / gate_n * 1e3
+    # the same stream software-pipelined (mmf_set_deferred_feature_rows: the 313 MB row stream of frame N beside the sphere trace of
+    # frame N + 1, its gating beside the raycast); flushed inside the timed region
+    mapper.set_deferred_feature_rows(True)
+    for i in range(warmup):
+        step(mapper, mcfg, frames[i % n_frames])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(mapper, mcfg, frames[(warmup + i) % n_frames])
+    mapper.flush()
+    torch.cuda.synchronize(device)
+    dtp = time.perf_counter() - t0
+    mapper.set_deferred_feature_rows(False)
+    out["pipelined"] = {"frames_per_s": steps / dtp, "ms_per_step": dtp / steps * 1e3,
+                        "frac_of_hbm_peak": b_frame / (dtp / steps) / HBM_PEAK_BYTES_PER_S}
 
     # The whole per-frame pipeline from the backbone's 16x16xC output (what the reference's FeatureExtractor hands over
     # before its own resize, feature_extraction.py:188-191): (a) up-sample to [512,512,768] f16 then integrate (two steps,
@@ -295,6 +310,7 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
         t0 = time.perf_counter()
         for i in range(steps):
             fn(frames[(warmup + i) % n_frames])
+        mapper.flush()  # (a deferred tail, when the mode is on)
         torch.cuda.synchronize(device)
         return (time.perf_counter() - t0) / steps
 
@@ -318,6 +334,14 @@ def run_reference_shape(device, steps=24, warmup=6, n_frames=4):
     dt_low = timed(fused_lowres)
     mapper.profile_enable(False)
     ms, n = mapper.profile()["feature_flat"]
+    mapper.clear()
+    mapper.set_deferred_feature_rows(True)  # the same two pipelines with consecutive frames software-pipelined
+    dt_low_p = timed(fused_lowres)
+    mapper.clear()
+    dt_up_p = timed(with_upsample)
+    mapper.set_deferred_feature_rows(False)
+    out["from_backbone_output_pipelined"] = {"fused_lowres_frames_per_s": 1.0 / dt_low_p, "fused_lowres_ms": dt_low_p * 1e3,
+                                             "upsample_then_integrate_frames_per_s": 1.0 / dt_up_p, "upsample_then_integrate_ms": dt_up_p * 1e3}
     out["from_backbone_output"] = {
         "upsample_then_integrate_frames_per_s": 1.0 / dt_up, "upsample_then_integrate_ms": dt_up * 1e3,
         "fused_lowres_frames_per_s": 1.0 / dt_low, "fused_lowres_ms": dt_low * 1e3,

@@ -139,13 +139,15 @@ int mmf_integrate_frame(mmf_handle h, int mapper_id, const float* depth_dev, con
 int mmf_decay(mmf_handle h, int mapper_id, void* stream);
 /* Software pipelining of consecutive fused frames (no counterpart in the reference: nvblox consumes a frame before the call
  * returns the stream to the caller; this is the same trick as the lazy mmf_decay, on the other end of the frame).  With
- * on != 0, mmf_integrate_frame / _desc with a FULL-RESOLUTION feature image leave their last launch -- the feature-row update of
- * the voxels that passed the gate -- pending; the next mmf_integrate_frame / _desc on the same mapper and stream runs it as one
- * more role of its sphere-trace launch (a latency-bound launch with idle workgroup slots: the 8 us bandwidth stream disappears
- * behind it), and ANY other entry point that takes this mapper first runs it as the stand-alone launch it would have been, on
- * the stream of the frame it belongs to.  Every observable result is bit-identical to the undeferred sequence.
- * CONTRACT while on: the feature image handed to a frame must stay allocated and UNCHANGED until the next call on this mapper
- * (or mmf_flush) has been enqueued.  mapper_id < 0: all mappers.  Turning it off flushes.  Default: off. */
+ * on != 0, mmf_integrate_frame / _lowres / _desc on a bounded workspace leave their last TWO launches -- the colour update +
+ * feature gating and the feature-row update of the voxels that passed the gate -- pending; the next such call on the same mapper
+ * and stream runs them as roles of its first (raycast) and third (sphere trace) launch: three launches per frame instead of five,
+ * the appearance half of frame N beside the geometry half of frame N + 1.  ANY other entry point that takes this mapper first runs
+ * them as the stand-alone launches they would have been, on the stream of the frame they belong to.  Every observable result is
+ * bit-identical to the undeferred sequence.
+ * CONTRACT while on: the feature image (or low-res feature map), the colour image and the two mask outputs of a frame must stay
+ * allocated and UNCHANGED until the next call on this mapper (or mmf_flush) has been enqueued.  Frames handed on by
+ * mmf_integrate_frame_multi / _batch never defer.  mapper_id < 0: all mappers.  Turning it off flushes.  Default: off. */
 int mmf_set_deferred_feature_rows(mmf_handle h, int mapper_id, int on);
 /* 1: a frame's row update is pending on the mapper (its feature image is still in use), 0: not, < 0: error code. */
 int mmf_deferred_feature_rows_pending(mmf_handle h, int mapper_id);

@@ -1255,7 +1255,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     input_mask = m->inv_mask;
   }
   if (!fusable || big) MMF_TRY(flush_rows(h, *m));  // no launch of this frame can host it
-  if (m->defer_rows && fusable && !big && !low) MMF_TRY(ensure_flat_other(*m));
+  if (m->defer_rows && fusable && !big) MMF_TRY(ensure_flat_other(*m));
   if (!fusable) {
     // odd shapes / very large grids: the plain sequence of stand-alone launches
     flush_decay(h, *m, s);
@@ -1433,12 +1433,12 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
     }
   }
-  if (may_defer && m->defer_rows && !big && !low && m->flat.rec && m->flat_other.rec) {
+  if (may_defer && m->defer_rows && !big && m->flat.rec && m->flat_other.rec) {
     // launches 4 and 5 are left to the next fused frame (roles of its launches 1 and 3) or to whatever takes the mapper first
     MMF_TRY(flush_rows(h, *m));  // (nothing hosted the previous frame's: before this frame's own)
     m->tail = make_app_tail(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
                             m->sc[2], m->mc, T_C_L, m->synth, m->synth_W, m->synth_H, m->feat.d.cap, m->stats, m->flat);
-    m->rows_args = make_flat_args(m->feat.d, fcam, (const __half*)feat, nullptr, m->flat, m->stats);
+    m->rows_args = make_flat_args(m->feat.d, fcam, (const __half*)feat, low, m->flat, m->stats);
     m->rows_stream = s;
     m->tail_pending = true;
     std::swap(m->flat, m->flat_other);  // the next frame fills (and its launch 3 zeroes) the other list

@@ -399,7 +399,9 @@ __global__ __launch_bounds__(256) void k_feature_flat2(AppArgs A0, MapConsts mc0
 // and 0.03 of the HBM rate, the row update is a bandwidth stream of ~1 200 short workgroups at 60 registers: they fill the
 // empty slots and end long before the slowest ray patch.  Grid: [allocation jobs | ray patches | row-update workgroups] --
 // the patches first, each is as long as the launch.
-template <bool DENSE, int MODE>
+// LOW: the row update samples a low-res feature map (101 registers: five workgroups per CU -- the ray patches still all start at
+// once, the rows take the slots they leave; at 768 channels the rows are the longer role and the trace disappears behind THEM).
+template <bool DENSE, int MODE, bool LOW>
 __global__ __launch_bounds__(256, 5) void k_sphere_alloc_flat(SphereArgs A, AppArgs F, int lpv, int n_flat) {
   __shared__ SphereLds Q;
   __shared__ int s_prefix[kFlatSubLists + 1];
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256, 5) void k_sphere_alloc_flat(SphereArgs A, AppA
   if (b < A.njobs) return sphere_alloc_role<DENSE, MODE>(A, Q, b);
   b -= A.njobs;
   if (b < A.n_patches) return sphere_patch_role(A, Q, b);
-  feature_flat_role<false>(F, A.mc, lpv, b - A.n_patches, n_flat, s_prefix);
+  feature_flat_role<LOW>(F, A.mc, lpv, b - A.n_patches, n_flat, s_prefix);
 }
 
 // N frames' survivor lists in one launch: frame q's list is walked by its own nb[q] workgroups
@@ -626,16 +628,20 @@ void launch_feature_flat_args(const AppArgs& Af, const MapConsts& mc, hipStream_
     hipExtLaunchKernelGGL(k_feature_flat<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
 }
 
-// sphere trace | colour allocation | feature allocation of this frame | row update of the previous one (full-resolution
-// feature image only: the low-res form needs 101 registers and would take the tracer's slots)
+// sphere trace | colour allocation | feature allocation of this frame | row update of the previous one
 void launch_sphere_alloc_flat(const SphereArgs& A, const AppArgs& F, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int lpv = flat_lanes_per_voxel(A.mc);
   const int n_flat = flat_grid(F.flat, lpv);
   const dim3 grid(A.njobs + A.n_patches + n_flat);
-  if (sphere_dense(A))
-    hipExtLaunchKernelGGL((k_sphere_alloc_flat<true, 1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
+  const bool low = F.low.data != nullptr;
+  if (sphere_dense(A) && !low)
+    hipExtLaunchKernelGGL((k_sphere_alloc_flat<true, 1, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
+  else if (sphere_dense(A))
+    hipExtLaunchKernelGGL((k_sphere_alloc_flat<true, 1, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
+  else if (!low)
+    hipExtLaunchKernelGGL((k_sphere_alloc_flat<false, -1, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
   else
-    hipExtLaunchKernelGGL((k_sphere_alloc_flat<false, -1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
+    hipExtLaunchKernelGGL((k_sphere_alloc_flat<false, -1, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, F, lpv, n_flat);
 }
 
 void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam, const __half* feat, const LowRes* lowres,

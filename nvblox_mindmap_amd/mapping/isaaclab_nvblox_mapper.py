@@ -154,6 +154,15 @@ class IsaacLabNvbloxMapper:
         samples["vertices"] = samples["vertices"].to(self.device)
         return samples
 
+    def set_frame_pipelining(self, on: bool = True) -> None:
+        """Extension for streams that do not read the map after every frame (dataset generation over a recorded demo, replay):
+        consecutive single-mapper updates are software-pipelined in the native library (``Mapper.set_deferred_feature_rows``, DESIGN.md
+        4.11) -- the appearance half of a frame runs beside the geometry half of the next one.  Results are bit-identical; whatever
+        reads the map (``get_nvblox_model_inputs``, ``save_nvblox_map_to_disk``) completes the last frame first.  Every update makes its
+        own image tensors, which is all the mode asks for.  With ``include_dynamic`` both mappers go through the two-mapper call,
+        which does not defer."""
+        self.mapper.set_deferred_feature_rows(bool(on))
+
     def clear(self):
         self.mapper.clear()
 

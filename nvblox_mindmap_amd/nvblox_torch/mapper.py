@@ -419,8 +419,8 @@ class Mapper:
                                            border_percent, invert_input_mask)
         self._check_held_rows(mapper_id)
         _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
-        if feature_frame is not None and _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
-            # the native side still reads the feature image, the colour image and the two masks it has just written: keep them
+        if _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
+            # the native side still reads the feature image (or low-res map), the colour image and the two masks it has just written: keep them
             # allocated, and remember their version counters
             held = (keep[0], keep[2], dm, fm)
             self._held_rows[mapper_id] = (held, tuple(t._version for t in held))

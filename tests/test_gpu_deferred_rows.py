@@ -68,6 +68,24 @@ def test_stream_equals_the_undeferred_one_and_the_oracle(oracle_mod):
     assert d.stats() == e.stats()
 
 
+def test_lowres_feature_source_streams_too():
+    """The facade's default feature source (the backbone's low-res map, sampled inside the row update) defers like the image."""
+    cfg, C = stream_cfg(2), 16
+    d, e = pair(C)
+    gen = torch.Generator("cuda").manual_seed(11)
+    for step in range(6):
+        low = torch.rand(15, 20, 16, device="cuda", generator=gen)
+        for m in (d, e):
+            ea, _, _ = frame_args(cfg, m, 9 * step, C, step)
+            m.decay()
+            m.integrate_frame_lowres(ea["depth_frame"], ea["color_frame"], low.clone(), ea["input_mask"], ea["t_w_c"], ea["intrinsics"], 0.3,
+                                     3, 4, 5, invert_input_mask=True)
+        assert pending(d) == 1 and pending(e) == 0
+        if step == 3:  # a full-resolution frame in between rides / hosts the same way
+            feed(cfg, (d, e), 50, C, 7)
+    same_maps(d, e)
+
+
 def test_full_size_stream():
     """BASELINE configs[2] at full size (640x480, C = 64): 8 frames with a decay() before each, deferred against undeferred."""
     cfg, C = S.StreamConfig(hole_mode="patches"), 64

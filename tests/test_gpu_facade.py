@@ -220,6 +220,47 @@ def test_facade_hands_the_backbone_output_to_the_native_call(include_dynamic, mo
         assert all(torch.equal(x, y) for x, y in zip(ca, cb))
 
 
+def test_facade_frame_pipelining_changes_nothing_but_the_schedule():
+    """``set_frame_pipelining``: the facade's default path (backbone output handed to the native call) with consecutive frames
+    software-pipelined -- same maps and same model inputs (same RNG draws) as the unpipelined facade, read in the middle and at the end."""
+    from nvblox_mindmap_amd import _lib
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import BackboneFeatureExtractor, IsaacLabNvbloxMapper
+
+    C, size = 64, 256
+    cfg = S.StreamConfig(width=size, height=size, fx=293.2, fy=293.2, cx=127.5, cy=127.5, hole_mode="patches")
+    torch.manual_seed(0)
+    backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 16, stride=16), torch.nn.Tanh()).cuda()
+
+    def build(pipelined):
+        f = IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=BackboneFeatureExtractor(backbone, (size, size), C),
+                                 task="DRILL_IN_BOX", feature_channels=C, include_dynamic=False, num_vertices_to_sample=512)
+        f.set_frame_pipelining(pipelined)
+        return f
+
+    p, e = build(True), build(False)
+    for k, idx in enumerate((0, 4, 8, 12, 16, 20, 24)):
+        dyn = np.zeros((size, size), dtype=bool)
+        dyn[60 + 5 * k: 150, 80: 200 - 7 * k] = True
+        sample, _, _ = make_sample(cfg, idx, "cuda", dynamic=dyn)
+        for f in (p, e):
+            f.decay()
+            f.update_reconstruction_from_sample(sample, "pov")
+        assert _lib.lib().mmf_deferred_feature_rows_pending(p.mapper._h, 0) == 1
+        if k in (3, 6):
+            outs = []
+            for f in (p, e):
+                torch.manual_seed(100 + k)
+                outs.append(f.get_nvblox_model_inputs(0, remove_zero_features=True))
+            for key in ("vertices", "vertex_features", "vertices_valid_mask"):
+                assert torch.equal(outs[0][key], outs[1][key]), key
+            assert float(outs[0]["vertex_features"].abs().max()) > 0
+            assert _lib.lib().mmf_deferred_feature_rows_pending(p.mapper._h, 0) == 0
+    for x, y in zip(p.mapper.feature_layer_view(0).get_all_blocks_split(), e.mapper.feature_layer_view(0).get_all_blocks_split()):
+        assert torch.equal(x, y)
+    for x, y in zip(p.mapper.color_layer_view(0).get_all_blocks_split(), e.mapper.color_layer_view(0).get_all_blocks_split()):
+        assert torch.equal(x, y)
+
+
 def test_mirrored_feature_extractor_through_the_facade(monkeypatch):
     """image_processing.feature_extraction (the reference's extractor contract, golden-pinned on the CPU) driving the facade:
     an extractor with a normalisation hook and a 3 -> 16 channel stand-in network.  ``compute`` returns float32 like the
