@@ -69,10 +69,14 @@ def pose_index(k):
     return (11 * k) % 200
 
 
-def test_soak_bounded_2000_frames_with_checkpoint(oracle_mod, tmp_path):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_soak_bounded_2000_frames_with_checkpoint(oracle_mod, tmp_path, pipelined):
+    """pipelined: consecutive frames software-pipelined (set_deferred_feature_rows: the appearance half of a frame as roles of the
+    next frame's launches) -- the periodic comparisons and the checkpoint are the readers that complete the pending frame."""
     n_frames = int(os.environ.get("MMF_SOAK_FRAMES", "2000"))
     cache = FrameCache(stream_cfg())
     gpu, orc = make_mapper(C), make_oracle(oracle_mod, C)  # DRILL_IN_BOX box, 1 cm voxels, decay 0.98: the reference's mapper
+    gpu.set_deferred_feature_rows(pipelined)
     live = []
     for k in range(n_frames):
         fused(gpu, orc, cache, pose_index(k), k)
@@ -89,6 +93,7 @@ def test_soak_bounded_2000_frames_with_checkpoint(oracle_mod, tmp_path):
             gpu.save_map(path, 0)
             fresh = make_mapper(C)
             fresh.load_from_file(path, 0)
+            fresh.set_deferred_feature_rows(pipelined)
             gpu = fresh
     mx, exact = compare_tsdf(orc, gpu)
     assert exact
