@@ -463,8 +463,12 @@ def run_frames_in_flight(device, frames, channels, counts=(1, 2, 4, 8), steps=15
 
     mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
     out = {}
-    for n in counts:
+    for n, pipelined in [(c, True) for c in counts] + [(counts[-1], False)]:
+        # pipelined: every replica's stream software-pipelined (mmf_set_deferred_feature_rows: launches 4 and 5 of a replica's frame
+        # are roles of launches 1 and 3 of the next round); the last count also unpipelined (five launches per round)
         mappers = [get_nvblox_mapper(mcfg, feature_channels=channels) for _ in range(n)]
+        for m in mappers:
+            m.set_deferred_feature_rows(pipelined)
 
         def one(i):
             entries = []
@@ -487,16 +491,20 @@ def run_frames_in_flight(device, frames, channels, counts=(1, 2, 4, 8), steps=15
         t0 = time.perf_counter()
         for i in range(steps):
             one(warmup + i)
+        for m in mappers:
+            m.flush()
         t_enq = time.perf_counter() - t0
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         mappers[0].profile_enable(False)
         prof = mappers[0].profile()
-        out[str(n)] = {"aggregate_frames_per_s": n * steps / dt, "ms_per_round": dt / steps * 1e3, "host_enqueue_ms_per_round": t_enq / steps * 1e3,
+        out[str(n) if pipelined else f"{n}_unpipelined"] = {"aggregate_frames_per_s": n * steps / dt, "ms_per_round": dt / steps * 1e3, "host_enqueue_ms_per_round": t_enq / steps * 1e3,
                        "launch_us": {KERNEL_OF_CLASS[c]: (ms / k * 1e3 if k else None) for c, (ms, k) in prof.items() if c in KERNEL_OF_CLASS}}
         del mappers
         torch.cuda.empty_cache()
-    out["workload"] = "N x (decay + fused frame, 640x480, C=%d, DRILL_IN_BOX), one mmf_integrate_frame_batch call per round" % channels
+    out["workload"] = ("N x (decay + fused frame, 640x480, C=%d, DRILL_IN_BOX), one mmf_integrate_frame_batch call per round; every replica's "
+                       "stream software-pipelined (launch_us: k_front / k_sphere_alloc then carry the previous round's k_app_frame / "
+                       "k_feature_flat), flushed inside the timed region" % channels)
     return out
 
 

@@ -584,6 +584,21 @@ int flush_rows(mmf_handle h, Mapper& m) {
   return MMF_OK;
 }
 
+// A frame on stream s is about to host what is pending: fine on the stream it was deferred on.  On another stream the tail goes
+// where it would have been enqueued, and -- it is enqueued later than it would have been, after whatever synchronisation the
+// caller placed between the two streams -- stream s waits for it.
+int adopt_pending(mmf_handle h, Mapper& m, hipStream_t s) {
+  if (!(m.rows_pending || m.tail_pending) || m.rows_stream == s) return MMF_OK;
+  hipStream_t old_stream = m.rows_stream;
+  MMF_TRY(flush_rows(h, m));
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ev, old_stream));
+  HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+  HIP_TRY(hipEventDestroy(ev));
+  return MMF_OK;
+}
+
 // the fused frame's accessor: a pending row update stays pending (the frame hosts it)
 int get_mapper_keep_rows(mmf_handle h, int id, Mapper** out) {
   if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
@@ -1176,8 +1191,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                                 const float* K9, float min_depth_m, int k_in, int k_depth, int border_percent,
                                 uint8_t* depth_mask_out, uint8_t* feature_mask_out, void* stream, bool invert_mask = false,
                                 bool may_defer = true) {
-  // may_defer: false for the frames mmf_integrate_frame_multi / _batch hand on one by one -- the contract of the deferred row
-  // update (the feature image stays valid until the next call) is made with the callers of mmf_integrate_frame / _desc only
+  // may_defer: false for the frames mmf_integrate_frame_multi hands on one by one (that call completes what is pending and does
+  // not defer)
   Mapper* m;
   MMF_TRY(get_mapper_keep_rows(h, mapper_id, &m));  // (a deferred row update of the previous frame rides in this one's launch 3)
   if (!depth || !rgb || (!feat && !low) || !input_mask || !T16 || !K9 || !depth_mask_out || !feature_mask_out || H <= 1 || W <= 1 ||
@@ -1192,17 +1207,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
                                      "use the separate add_*_frame calls otherwise");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  if ((m->rows_pending || m->tail_pending) && m->rows_stream != s) {
-    // another stream: the update goes where it would have been enqueued, and -- it is enqueued later than it would have been, after
-    // whatever synchronisation the caller placed between the two streams -- this stream waits for it
-    hipStream_t old_stream = m->rows_stream;
-    MMF_TRY(flush_rows(h, *m));
-    hipEvent_t ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ev, old_stream));
-    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
-    HIP_TRY(hipEventDestroy(ev));
-  }
+  MMF_TRY(adopt_pending(h, *m, s));
   MMF_TRY(report_device_errors(h, *m, nullptr, nullptr, s));  // an earlier frame's hand-over failed for good: do not integrate on top
   MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
   MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)C, true));
@@ -1499,10 +1504,10 @@ static int frame_in_from_desc(const Mapper& m, const mmf_frame* f, FrameIn& in) 
   return MMF_OK;
 }
 
-static int integrate_frame_in(mmf_handle h, int mapper_id, const FrameIn& in, void* stream) {
+static int integrate_frame_in(mmf_handle h, int mapper_id, const FrameIn& in, void* stream, bool may_defer = false) {
   return integrate_frame_impl(h, mapper_id, in.depth, in.rgb, in.feat, in.has_low ? &in.low : nullptr, in.input_mask, in.H, in.W, in.Hf,
                               in.Wf, in.C, in.T16, in.K9, in.min_depth_m, in.k_in, in.k_depth, in.border_percent, in.depth_mask_out,
-                              in.feature_mask_out, stream, in.invert_mask, false);
+                              in.feature_mask_out, stream, in.invert_mask, may_defer);
 }
 
 // Can this frame take the five-launch merged path (the only one the pair kernels implement)?  No side effects.
@@ -1706,7 +1711,7 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
   for (int i = 0; i < n_frames; ++i) {
     if (!handles[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_batch: null handle");
     if (handles[i]->device != handles[0]->device) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_batch: all mappers must live on one device");
-    MMF_TRY(get_mapper(handles[i], mapper_ids[i], &ms[i]));
+    MMF_TRY(get_mapper_keep_rows(handles[i], mapper_ids[i], &ms[i]));  // (a deferred tail rides in this call's launches)
     MMF_TRY(frame_in_from_desc(*ms[i], &frames[i], ins[i]));
     for (int j = 0; j < i; ++j)
       if (ms[j] == ms[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_batch: every frame must go to a different mapper");
@@ -1726,21 +1731,38 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
     if (batch.size() == 1) {
       const int i = batch[0];
       batch.clear();
-      return integrate_frame_in(handles[i], mapper_ids[i], ins[i], stream);
+      return integrate_frame_in(handles[i], mapper_ids[i], ins[i], stream, true);
     }
     const int nb = (int)batch.size();
     mmf_handle h0 = handles[batch[0]];  // (the profile of a batch is booked on the first frame's handle)
     PairFrame F[kMaxBatch];
     for (int q = 0; q < nb; ++q) {
       const int i = batch[q];
-      MMF_TRY(report_device_errors(handles[i], *ms[i], nullptr, nullptr, s));
-      MMF_TRY(pair_prepare(handles[i], *ms[i], ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L, s, F[q]));
+      Mapper& m = *ms[i];
+      MMF_TRY(adopt_pending(handles[i], m, s));
+      if (m.defer_rows && !ins[i].has_low) MMF_TRY(ensure_flat_other(m));
+      MMF_TRY(report_device_errors(handles[i], m, nullptr, nullptr, s));
+      MMF_TRY(pair_prepare(handles[i], m, ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L, s, F[q]));
     }
     {
+      // ... | the pending colour update + feature gating of the previous frame of every mapper that deferred it (section 4.11)
       ProfExt pe(h0, MMF_K_RAYCAST);
       FrontArgs A[kMaxBatch];
-      for (int q = 0; q < nb; ++q) A[q] = F[q].front;
-      launch_front_batch(A, nb, s, pe.a(), pe.b());
+      AppFrameArgs G[kMaxBatch];
+      int ng = 0;
+      for (int q = 0; q < nb; ++q) {
+        A[q] = F[q].front;
+        Mapper& m = *ms[batch[q]];
+        if (m.tail_pending) {
+          G[ng++] = app_frame_args_of(m.tail);
+          m.tail_pending = false;
+          m.rows_pending = true;
+        }
+      }
+      if (ng)
+        launch_front_batch_app(A, nb, G, ng, s, pe.a(), pe.b());
+      else
+        launch_front_batch(A, nb, s, pe.a(), pe.b());
     }
     {
       ProfExt pe(h0, MMF_K_TSDF);
@@ -1749,26 +1771,54 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
       launch_alloc_tsdf_batch(A, nb, s, pe.a(), pe.b());
     }
     {
-      ProfExt pe(h0, MMF_K_SPHERE);
+      // ... | the pending row updates (a low-res one -- 101 registers -- runs on its own in front)
       SphereArgs A[kMaxBatch];
-      for (int q = 0; q < nb; ++q) A[q] = F[q].sphere;
-      launch_sphere_alloc_batch(A, nb, s, pe.a(), pe.b());
-    }
-    {
-      ProfExt pe(h0, MMF_K_FEATURE);
-      AppFrameArgs A[kMaxBatch];
-      for (int q = 0; q < nb; ++q) A[q] = F[q].app;
-      launch_app_frame_batch(A, nb, ins[batch[0]].has_low, s, pe.a(), pe.b());
-    }
-    {
-      ProfExt pe(h0, MMF_K_FEATURE_FLAT);
-      FlatFrame A[kMaxBatch];
+      AppArgs R[kMaxBatch];
+      MapConsts RM[kMaxBatch];
+      int nr = 0;
       for (int q = 0; q < nb; ++q) {
-        const int i = batch[q];
-        A[q] = FlatFrame{ms[i]->feat.d, ms[i]->mc, ms[i]->flat, ms[i]->stats, pp[i].cam, (const __half*)ins[i].feat,
-                         ins[i].has_low ? &ins[i].low : nullptr};
+        A[q] = F[q].sphere;
+        Mapper& m = *ms[batch[q]];
+        if (!m.rows_pending) continue;
+        if (m.rows_args.low.data) {
+          MMF_TRY(flush_rows(handles[batch[q]], m));
+          continue;
+        }
+        R[nr] = m.rows_args;
+        RM[nr++] = m.mc;
+        m.rows_pending = false;
       }
-      launch_feature_flat_batch(A, nb, s, pe.a(), pe.b());
+      ProfExt pe(h0, MMF_K_SPHERE);
+      if (nr)
+        launch_sphere_alloc_batch_flat(A, nb, R, RM, nr, s, pe.a(), pe.b());
+      else
+        launch_sphere_alloc_batch(A, nb, s, pe.a(), pe.b());
+    }
+    // launches 4 and 5: of the frames whose mapper does not defer them
+    AppFrameArgs A4[kMaxBatch];
+    FlatFrame A5[kMaxBatch];
+    int n45 = 0;
+    for (int q = 0; q < nb; ++q) {
+      const int i = batch[q];
+      Mapper& m = *ms[i];
+      if (m.defer_rows && !ins[i].has_low && m.flat.rec && m.flat_other.rec) {
+        m.tail = app_tail_of(F[q].app, m.feat.d.cap);
+        m.rows_args = make_flat_args(m.feat.d, pp[i].cam, (const __half*)ins[i].feat, nullptr, m.flat, m.stats);
+        m.rows_stream = s;
+        m.tail_pending = true;
+        std::swap(m.flat, m.flat_other);
+        continue;
+      }
+      A4[n45] = F[q].app;
+      A5[n45++] = FlatFrame{m.feat.d, m.mc, m.flat, m.stats, pp[i].cam, (const __half*)ins[i].feat, ins[i].has_low ? &ins[i].low : nullptr};
+    }
+    if (n45) {
+      {
+        ProfExt pe(h0, MMF_K_FEATURE);
+        launch_app_frame_batch(A4, n45, ins[batch[0]].has_low, s, pe.a(), pe.b());
+      }
+      ProfExt pe(h0, MMF_K_FEATURE_FLAT);
+      launch_feature_flat_batch(A5, n45, s, pe.a(), pe.b());
     }
     batch.clear();
     return check_launch();
@@ -1777,7 +1827,7 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
     const bool ok = pair_eligible(*ms[i], ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L);
     if (!ok) {  // (its first frame, an unbounded workspace, a decay that needs its voxel pass, ...): on its own, in order
       MMF_TRY(flush());
-      MMF_TRY(integrate_frame_in(handles[i], mapper_ids[i], ins[i], stream));
+      MMF_TRY(integrate_frame_in(handles[i], mapper_ids[i], ins[i], stream, true));
       continue;
     }
     if (!batch.empty() && (ins[batch[0]].has_low != ins[i].has_low || (int)batch.size() == kMaxBatch)) MMF_TRY(flush());

@@ -412,6 +412,26 @@ __global__ __launch_bounds__(256, 5) void k_sphere_alloc_flat(SphereArgs A, AppA
   feature_flat_role<LOW>(F, A.mc, lpv, b - A.n_patches, n_flat, s_prefix);
 }
 
+// N frames: [allocation jobs 0 .. n-1 | ray patches 0 .. n-1 | pending row updates of the previous frames of the batch's mappers]
+template <bool DENSE, int MODE>
+__global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch_flat(SphereBatch P, FlatBatch F) {
+  __shared__ SphereLds Q;
+  __shared__ int s_prefix[kFlatSubLists + 1];
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.a[q].njobs) return sphere_alloc_role<DENSE, MODE>(P.a[q], Q, b);
+    b -= P.a[q].njobs;
+  }
+  for (int q = 0; q < P.n; ++q) {
+    if (b < P.a[q].n_patches) return sphere_patch_role(P.a[q], Q, b);
+    b -= P.a[q].n_patches;
+  }
+  for (int q = 0; q < F.n; ++q) {
+    if (b < F.nb[q]) return feature_flat_role<false>(F.a[q], F.mc[q], F.lpv[q], b, F.nb[q], s_prefix);
+    b -= F.nb[q];
+  }
+}
+
 // N frames' survivor lists in one launch: frame q's list is walked by its own nb[q] workgroups
 template <bool LOW>
 __global__ __launch_bounds__(256) void k_feature_flat_batch(FlatBatch P) {
@@ -572,6 +592,36 @@ void launch_sphere_alloc_batch(const SphereArgs* A, int n, hipStream_t s, hipEve
     hipExtLaunchKernelGGL((k_sphere_alloc_batch<false, -1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
 }
 
+static int flat_lanes_per_voxel(const MapConsts& mc);
+static int flat_grid(const FlatList& fl, int lpv);
+
+// (rows: full-resolution feature images only -- the low-res row update needs 101 registers, this launch runs at 64)
+void launch_sphere_alloc_batch_flat(const SphereArgs* A, int n, const AppArgs* rows, const MapConsts* mcs, int nr, hipStream_t s,
+                                    hipEvent_t ev_start, hipEvent_t ev_stop) {
+  SphereBatch P;
+  FlatBatch F;
+  P.n = n;
+  F.n = nr;
+  int total = 0;
+  bool dense = true;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = A[q];
+    total += A[q].njobs + A[q].n_patches;
+    dense = dense && sphere_dense(A[q]);
+  }
+  for (int q = 0; q < nr; ++q) {
+    F.a[q] = rows[q];
+    F.mc[q] = mcs[q];
+    F.lpv[q] = flat_lanes_per_voxel(mcs[q]);
+    F.nb[q] = flat_grid(rows[q].flat, F.lpv[q]);
+    total += F.nb[q];
+  }
+  if (dense)
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<true, 1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
+  else
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<false, -1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
+}
+
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
                              const Scratch& sc, long long* stats = nullptr, const LowRes* low = nullptr,
                              const FlatList* flat = nullptr) {
@@ -680,6 +730,30 @@ AppTail make_app_tail(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, c
   T.synth = synth;
   T.Ws = Ws;
   T.Hs = Hs;
+  T.max_cand = max_cand;
+  return T;
+}
+
+AppFrameArgs app_frame_args_of(const AppTail& T) {
+  AppFrameArgs F;
+  F.Ac = T.Ac;
+  F.Af = T.Af;
+  F.mc = T.mc;
+  F.synth = T.synth;
+  F.Ws = T.Ws;
+  F.Hs = T.Hs;
+  F.nb = app_tail_grid(T);
+  return F;
+}
+
+AppTail app_tail_of(const AppFrameArgs& F, int max_cand) {
+  AppTail T;
+  T.Ac = F.Ac;
+  T.Af = F.Af;
+  T.mc = F.mc;
+  T.synth = F.synth;
+  T.Ws = F.Ws;
+  T.Hs = F.Hs;
   T.max_cand = max_cand;
   return T;
 }

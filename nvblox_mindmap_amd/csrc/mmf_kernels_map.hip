@@ -299,6 +299,24 @@ __global__ __launch_bounds__(256, 7) void k_front_batch(FrontBatch P) {  // 72 V
   }
 }
 
+// ... | the pending colour update + feature gating of the PREVIOUS frame of every mapper of the batch that has one (deferred mode)
+template <bool LDSFLAGS>
+__global__ __launch_bounds__(256, 7) void k_front_batch_app(FrontBatch P, AppFrameBatch G) {
+  extern __shared__ unsigned s_words[];
+  __shared__ FrontLds S;
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < P.n; ++q) {
+    const int nw = P.a[q].n_wgs;
+    if (b < nw) return front_role<LDSFLAGS>(P.a[q], b, s_words, S);
+    b -= nw;
+  }
+  for (int q = 0; q < G.n; ++q) {
+    const AppFrameArgs& F = G.a[q];
+    if (b < F.nb) return app_frame_body<false, true>(F.Ac, F.Af, F.mc, F.synth, F.Ws, F.Hs, b, F.nb, *reinterpret_cast<FeatLds*>(s_words));
+    b -= F.nb;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. Flag compaction + hash lookup / insertion (shared by TSDF, colour and feature allocation).
 //    count tiles -> scan tiles -> emit.  A tile is 1024 cells (256 threads x 4 flag bytes).
@@ -1352,6 +1370,30 @@ void launch_front_batch(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_
     hipExtLaunchKernelGGL(k_front_batch<true>, dim3(total), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, ev_start, ev_stop, 0, P);
   else
     hipExtLaunchKernelGGL(k_front_batch<false>, dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P);
+}
+
+void launch_front_batch_app(const FrontArgs* A, int n, const AppFrameArgs* G, int ng, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  FrontBatch P;
+  AppFrameBatch Q;
+  P.n = n;
+  Q.n = ng;
+  int ncells = 0, total = 0;
+  for (int q = 0; q < n; ++q) {
+    P.a[q] = A[q];
+    ncells = front_cells(A[q]) > ncells ? front_cells(A[q]) : ncells;
+    total += A[q].n_wgs;
+  }
+  for (int q = 0; q < ng; ++q) {
+    Q.a[q] = G[q];
+    total += G[q].nb;
+  }
+  const bool lds = ncells <= kRaycastLdsCells;
+  size_t shm = lds ? (size_t)((ncells + 3) / 4) * 4 : 0;
+  shm = shm < sizeof(FeatLds) ? sizeof(FeatLds) : shm;
+  if (lds)
+    hipExtLaunchKernelGGL(k_front_batch_app<true>, dim3(total), dim3(256), shm, s, ev_start, ev_stop, 0, P, Q);
+  else
+    hipExtLaunchKernelGGL(k_front_batch_app<false>, dim3(total), dim3(256), shm, s, ev_start, ev_stop, 0, P, Q);
 }
 
 constexpr int kFusedAllocMaxCells = 16384;

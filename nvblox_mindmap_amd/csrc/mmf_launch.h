@@ -275,6 +275,13 @@ AppTail make_app_tail(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, c
                       const Cam& fcam, const __half* feat, const uint8_t* fmask, const Scratch& fsc, const MapConsts& mc, const Rigid& T_C_L,
                       const float* synth, int Ws, int Hs, int max_cand, long long* stats, const FlatList& flat);
 int app_tail_grid(const AppTail& T);
+AppFrameArgs app_frame_args_of(const AppTail& T);
+AppTail app_tail_of(const AppFrameArgs& F, int max_cand);
+// the batch forms of the two hosting launches: n frames + the pending tails / row updates of (some of) their mappers
+void launch_front_batch_app(const FrontArgs* A, int n, const AppFrameArgs* G, int ng, hipStream_t s, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr);
+void launch_sphere_alloc_batch_flat(const SphereArgs* A, int n, const AppArgs* rows, const MapConsts* mcs, int nr, hipStream_t s,
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_app_tail(const AppTail& T, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // raycast | mask rows | pending decay of THIS frame | colour update + feature gating of the PREVIOUS one
 void launch_front_app(const FrontArgs& A, const AppTail& T, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

@@ -417,8 +417,9 @@ class Mapper:
         f, keep, dm, fm = self._frame_desc(depth_frame, color_frame, feature_frame, lowres_features, input_mask, t_w_c, intrinsics,
                                            min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
                                            border_percent, invert_input_mask)
-        self._check_held_rows(mapper_id)
+        previous = self._check_held_rows(mapper_id)
         _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
+        del previous
         if _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
             # the native side still reads the feature image (or low-res map), the colour image and the two masks it has just written: keep them
             # allocated, and remember their version counters
@@ -427,15 +428,19 @@ class Mapper:
         del keep
         return dm, fm
 
-    def _check_held_rows(self, mapper_id: int) -> None:
+    def _check_held_rows(self, mapper_id: int):
+        """Returns the tensors of the previous frame that were kept alive for the native side: the caller holds them until its own
+        native call has returned (the kernels that read them are enqueued by that call; nothing allocated in between may land in
+        their memory)."""
         held = self._held_rows.pop(mapper_id, None)
         if held is None or _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) != 1:
-            return
+            return held
         if tuple(t._version for t in held[0]) != held[1]:
             raise RuntimeError(
                 "an image of the previous frame (features, colour or one of the returned masks) was modified in place while its "
                 "appearance update was deferred (set_deferred_feature_rows): the map would differ from the undeferred sequence.  "
                 "Hand every frame its own tensors, or call flush() before reusing the buffers.")
+        return held
 
     def set_deferred_feature_rows(self, on: bool = True, mapper_id: int = -1) -> None:
         """Extension (``mmf_set_deferred_feature_rows``): consecutive ``integrate_frame`` calls are software-pipelined -- a
@@ -450,9 +455,9 @@ class Mapper:
 
     def flush(self, mapper_id: int = -1) -> None:
         """Enqueue whatever is pending on the mapper (a deferred row update, a lazy ``decay()``)."""
-        for i in ([int(mapper_id)] if int(mapper_id) >= 0 else list(self._held_rows)):
-            self._check_held_rows(i)
+        previous = [self._check_held_rows(i) for i in ([int(mapper_id)] if int(mapper_id) >= 0 else list(self._held_rows))]
         _lib.check(_lib.lib().mmf_flush(self._h, int(mapper_id), self._stream()), "mmf_flush")
+        del previous
 
     def integrate_frame_multi(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, feature_frame: torch.Tensor, t_w_c, intrinsics,
                               min_depth_m: float, border_percent: int, jobs, lowres_features: Optional[torch.Tensor] = None):
@@ -779,6 +784,13 @@ def integrate_frames_batch(frames) -> list:
         handles[i] = m._h
         keep.append(k)
         out.append((dm, fm))
+        keep.append(m._check_held_rows(ids[i]))  # (the previous frame's tensors: until the call below has enqueued their readers)
     _lib.check(_lib.lib().mmf_integrate_frame_batch(n, handles, ids, descs, frames[0]["mapper"]._stream()), "mmf_integrate_frame_batch")
+    for i, fr in enumerate(frames):  # mappers in deferred mode (set_deferred_feature_rows) still read this frame's images
+        m = fr["mapper"]
+        if _lib.lib().mmf_deferred_feature_rows_pending(m._h, ids[i]) == 1:
+            k = keep[2 * i]
+            held = (k[0], k[2], out[i][0], out[i][1])
+            m._held_rows[ids[i]] = (held, tuple(t._version for t in held))
     del keep
     return out

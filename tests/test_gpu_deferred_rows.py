@@ -86,6 +86,42 @@ def test_lowres_feature_source_streams_too():
     same_maps(d, e)
 
 
+@pytest.mark.parametrize("n", [2, 5, 8])
+def test_batches_of_deferring_mappers(n):
+    """``integrate_frames_batch`` with some mappers in deferred mode and some not: the deferring ones leave their tails to the next
+    batch (roles of its launches 1 and 3), the others run launches 4 and 5 of the same batch; a single ``integrate_frame`` between
+    two batches hosts / defers the same way."""
+    cfg, C = stream_cfg(2), 16
+    batched = [make_mapper(C) for _ in range(n)]
+    alone = [make_mapper(C) for _ in range(n)]
+    for q, m in enumerate(batched):
+        m.set_deferred_feature_rows(q % 3 != 2)  # every third mapper does not defer
+    for step in range(5):
+        entries_b, entries_a = [], []
+        for q in range(n):
+            eb, _, _ = frame_args(cfg, batched[q], (17 * q + 9 * step) % 200, C, q + step)
+            ea, _, _ = frame_args(cfg, alone[q], (17 * q + 9 * step) % 200, C, q + step)
+            entries_b.append(eb)
+            entries_a.append(ea)
+        for m in batched + alone:
+            m.decay()
+        if step == 2:  # one mapper takes the single call in between
+            single(entries_b[0])
+            masks_b = [None] + integrate_frames_batch(entries_b[1:]) if n > 1 else [None]
+        else:
+            masks_b = integrate_frames_batch(entries_b)
+        masks_a = [single(e) for e in entries_a]
+        for mb, ma in zip(masks_b, masks_a):
+            if mb is not None:
+                assert torch.equal(mb[0], ma[0]) and torch.equal(mb[1], ma[1])
+        for q, m in enumerate(batched):
+            assert pending(m) == (1 if q % 3 != 2 else 0)
+        if step == 3:
+            same_maps(batched[0], alone[0])  # a reader completes one mapper's frame, the others stay pending
+    for q in range(n):
+        same_maps(batched[q], alone[q])
+
+
 def test_full_size_stream():
     """BASELINE configs[2] at full size (640x480, C = 64): 8 frames with a decay() before each, deferred against undeferred."""
     cfg, C = S.StreamConfig(hole_mode="patches"), 64
