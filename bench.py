@@ -425,11 +425,13 @@ def run_two_mappers(device, frames, channels, steps=100, warmup=20):
     dyn[dyn.shape[0] // 4: 3 * dyn.shape[0] // 4, dyn.shape[1] // 3: 2 * dyn.shape[1] // 3] = True  # a sixth of the image is "dynamic"
     saved = H.PAIR_MAPPERS
     try:
-        for name, pair in (("one_call", True), ("sequential", False)):
+        for name, pair in (("one_call", True), ("sequential", False), ("one_call_pipelined", True)):
             H.PAIR_MAPPERS = pair
             mapper = get_nvblox_mapper(mcfg, feature_channels=channels)
             if mapper.num_mappers() < 2:
                 return None
+            # pipelined: consecutive camera frames software-pipelined on both mappers (mmf_set_deferred_feature_rows)
+            mapper.set_deferred_feature_rows(name.endswith("pipelined"))
 
             def step(i):
                 fr = frames[i % len(frames)]
@@ -443,6 +445,7 @@ def run_two_mappers(device, frames, channels, steps=100, warmup=20):
             t0 = time.perf_counter()
             for i in range(steps):
                 step(warmup + i)
+            mapper.flush()
             t_enq = time.perf_counter() - t0
             torch.cuda.synchronize(device)
             out[name + "_ms_per_frame"] = (time.perf_counter() - t0) / steps * 1e3

@@ -147,8 +147,8 @@ int mmf_decay(mmf_handle h, int mapper_id, void* stream);
  * bit-identical to the undeferred sequence.
  * CONTRACT while on: the feature image (or low-res feature map), the colour image and the two mask outputs of a frame must stay
  * allocated and UNCHANGED until the next call on this mapper (or mmf_flush) has been enqueued.  mmf_integrate_frame_batch defers
- * and hosts per mapper in the same way (full-resolution feature images); mmf_integrate_frame_multi completes what is pending and
- * does not defer.  mapper_id < 0: all mappers.  Turning it off flushes.  Default: off. */
+ * and hosts per mapper in the same way (full-resolution feature images), and so does mmf_integrate_frame_multi when the mode is on
+ * for one of its mappers (it then takes the batch entry point's launches).  mapper_id < 0: all mappers.  Turning it off flushes.  Default: off. */
 int mmf_set_deferred_feature_rows(mmf_handle h, int mapper_id, int on);
 /* 1: a frame's row update is pending on the mapper (its feature image is still in use), 0: not, < 0: error code. */
 int mmf_deferred_feature_rows_pending(mmf_handle h, int mapper_id);

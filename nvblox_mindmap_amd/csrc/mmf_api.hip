@@ -1633,6 +1633,12 @@ static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, c
 
 int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids, const mmf_frame* frames, void* stream) {
   if (!h || n_frames <= 0 || !mapper_ids || !frames) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_integrate_frame_multi");
+  // deferred mode on one of the mappers: the batch entry point hosts and defers per mapper (same role code, same results)
+  for (int i = 0; i < n_frames; ++i)
+    if (mapper_ids[i] >= 0 && mapper_ids[i] < (int)h->mappers.size() && h->mappers[mapper_ids[i]]->defer_rows) {
+      std::vector<mmf_handle> hs(n_frames, h);
+      return mmf_integrate_frame_batch(n_frames, hs.data(), mapper_ids, frames, stream);
+    }
   std::vector<Mapper*> ms(n_frames);
   std::vector<FrameIn> ins(n_frames);
   for (int i = 0; i < n_frames; ++i) {
@@ -1740,7 +1746,7 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
       const int i = batch[q];
       Mapper& m = *ms[i];
       MMF_TRY(adopt_pending(handles[i], m, s));
-      if (m.defer_rows && !ins[i].has_low) MMF_TRY(ensure_flat_other(m));
+      if (m.defer_rows) MMF_TRY(ensure_flat_other(m));
       MMF_TRY(report_device_errors(handles[i], m, nullptr, nullptr, s));
       MMF_TRY(pair_prepare(handles[i], m, ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L, s, F[q]));
     }
@@ -1771,7 +1777,8 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
       launch_alloc_tsdf_batch(A, nb, s, pe.a(), pe.b());
     }
     {
-      // ... | the pending row updates (a low-res one -- 101 registers -- runs on its own in front)
+      // ... | the pending row updates (of one kind -- from feature images or from low-res maps: two instantiations --, the first
+      // mapper's; the others' run on their own in front)
       SphereArgs A[kMaxBatch];
       AppArgs R[kMaxBatch];
       MapConsts RM[kMaxBatch];
@@ -1780,7 +1787,7 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
         A[q] = F[q].sphere;
         Mapper& m = *ms[batch[q]];
         if (!m.rows_pending) continue;
-        if (m.rows_args.low.data) {
+        if (nr && (m.rows_args.low.data != nullptr) != (R[0].low.data != nullptr)) {
           MMF_TRY(flush_rows(handles[batch[q]], m));
           continue;
         }
@@ -1801,9 +1808,9 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
     for (int q = 0; q < nb; ++q) {
       const int i = batch[q];
       Mapper& m = *ms[i];
-      if (m.defer_rows && !ins[i].has_low && m.flat.rec && m.flat_other.rec) {
+      if (m.defer_rows && m.flat.rec && m.flat_other.rec) {
         m.tail = app_tail_of(F[q].app, m.feat.d.cap);
-        m.rows_args = make_flat_args(m.feat.d, pp[i].cam, (const __half*)ins[i].feat, nullptr, m.flat, m.stats);
+        m.rows_args = make_flat_args(m.feat.d, pp[i].cam, (const __half*)ins[i].feat, ins[i].has_low ? &ins[i].low : nullptr, m.flat, m.stats);
         m.rows_stream = s;
         m.tail_pending = true;
         std::swap(m.flat, m.flat_other);

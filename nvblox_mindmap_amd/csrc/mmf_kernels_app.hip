@@ -413,8 +413,8 @@ __global__ __launch_bounds__(256, 5) void k_sphere_alloc_flat(SphereArgs A, AppA
 }
 
 // N frames: [allocation jobs 0 .. n-1 | ray patches 0 .. n-1 | pending row updates of the previous frames of the batch's mappers]
-template <bool DENSE, int MODE>
-__global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch_flat(SphereBatch P, FlatBatch F) {
+template <bool DENSE, int MODE, bool LOW>
+__global__ __launch_bounds__(256, LOW ? 5 : 8) void k_sphere_alloc_batch_flat(SphereBatch P, FlatBatch F) {
   __shared__ SphereLds Q;
   __shared__ int s_prefix[kFlatSubLists + 1];
   int b = (int)blockIdx.x;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch_flat(SphereBatch 
     b -= P.a[q].n_patches;
   }
   for (int q = 0; q < F.n; ++q) {
-    if (b < F.nb[q]) return feature_flat_role<false>(F.a[q], F.mc[q], F.lpv[q], b, F.nb[q], s_prefix);
+    if (b < F.nb[q]) return feature_flat_role<LOW>(F.a[q], F.mc[q], F.lpv[q], b, F.nb[q], s_prefix);
     b -= F.nb[q];
   }
 }
@@ -595,7 +595,7 @@ void launch_sphere_alloc_batch(const SphereArgs* A, int n, hipStream_t s, hipEve
 static int flat_lanes_per_voxel(const MapConsts& mc);
 static int flat_grid(const FlatList& fl, int lpv);
 
-// (rows: full-resolution feature images only -- the low-res row update needs 101 registers, this launch runs at 64)
+// (rows: all from full-resolution feature images or all from low-res maps -- the two row updates are different instantiations)
 void launch_sphere_alloc_batch_flat(const SphereArgs* A, int n, const AppArgs* rows, const MapConsts* mcs, int nr, hipStream_t s,
                                     hipEvent_t ev_start, hipEvent_t ev_stop) {
   SphereBatch P;
@@ -616,10 +616,15 @@ void launch_sphere_alloc_batch_flat(const SphereArgs* A, int n, const AppArgs* r
     F.nb[q] = flat_grid(rows[q].flat, F.lpv[q]);
     total += F.nb[q];
   }
-  if (dense)
-    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<true, 1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
+  const bool low = nr > 0 && rows[0].low.data != nullptr;
+  if (dense && !low)
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<true, 1, false>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
+  else if (dense)
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<true, 1, true>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
+  else if (!low)
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<false, -1, false>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
   else
-    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<false, -1>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
+    hipExtLaunchKernelGGL((k_sphere_alloc_batch_flat<false, -1, true>), dim3(total), dim3(256), 0, s, ev_start, ev_stop, 0, P, F);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,

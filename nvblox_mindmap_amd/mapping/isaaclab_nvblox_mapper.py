@@ -159,8 +159,7 @@ class IsaacLabNvbloxMapper:
         consecutive single-mapper updates are software-pipelined in the native library (``Mapper.set_deferred_feature_rows``, DESIGN.md
         4.11) -- the appearance half of a frame runs beside the geometry half of the next one.  Results are bit-identical; whatever
         reads the map (``get_nvblox_model_inputs``, ``save_nvblox_map_to_disk``) completes the last frame first.  Every update makes its
-        own image tensors, which is all the mode asks for.  With ``include_dynamic`` both mappers go through the two-mapper call,
-        which does not defer."""
+        own image tensors, which is all the mode asks for (with ``include_dynamic`` both mappers' frames share them)."""
         self.mapper.set_deferred_feature_rows(bool(on))
 
     def clear(self):

@@ -498,8 +498,13 @@ class Mapper:
             f.depth_mask_out, f.feature_mask_out = dm.data_ptr(), fm.data_ptr()
             keep.append(mask)
             out.append((dm, fm))
+        previous = [self._check_held_rows(ids[i]) for i in range(n)]
         _lib.check(_lib.lib().mmf_integrate_frame_multi(self._h, n, ids, descs, self._stream()), "mmf_integrate_frame_multi")
-        del keep
+        for i in range(n):  # mappers in deferred mode still read the frame's images and their own two masks
+            if _lib.lib().mmf_deferred_feature_rows_pending(self._h, ids[i]) == 1:
+                held = (keep[0][0], keep[0][2], out[i][0], out[i][1])
+                self._held_rows[ids[i]] = (held, tuple(t._version for t in held))
+        del keep, previous
         return out
 
     def integrate_frame_lowres(self, depth_frame: torch.Tensor, color_frame: torch.Tensor, lowres_features: torch.Tensor,

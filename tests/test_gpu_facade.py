@@ -220,7 +220,8 @@ def test_facade_hands_the_backbone_output_to_the_native_call(include_dynamic, mo
         assert all(torch.equal(x, y) for x, y in zip(ca, cb))
 
 
-def test_facade_frame_pipelining_changes_nothing_but_the_schedule():
+@pytest.mark.parametrize("include_dynamic", [False, True])
+def test_facade_frame_pipelining_changes_nothing_but_the_schedule(include_dynamic):
     """``set_frame_pipelining``: the facade's default path (backbone output handed to the native call) with consecutive frames
     software-pipelined -- same maps and same model inputs (same RNG draws) as the unpipelined facade, read in the middle and at the end."""
     from nvblox_mindmap_amd import _lib
@@ -233,7 +234,7 @@ def test_facade_frame_pipelining_changes_nothing_but_the_schedule():
 
     def build(pipelined):
         f = IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=BackboneFeatureExtractor(backbone, (size, size), C),
-                                 task="DRILL_IN_BOX", feature_channels=C, include_dynamic=False, num_vertices_to_sample=512)
+                                 task="DRILL_IN_BOX", feature_channels=C, include_dynamic=include_dynamic, num_vertices_to_sample=512)
         f.set_frame_pipelining(pipelined)
         return f
 
@@ -255,10 +256,13 @@ def test_facade_frame_pipelining_changes_nothing_but_the_schedule():
                 assert torch.equal(outs[0][key], outs[1][key]), key
             assert float(outs[0]["vertex_features"].abs().max()) > 0
             assert _lib.lib().mmf_deferred_feature_rows_pending(p.mapper._h, 0) == 0
-    for x, y in zip(p.mapper.feature_layer_view(0).get_all_blocks_split(), e.mapper.feature_layer_view(0).get_all_blocks_split()):
-        assert torch.equal(x, y)
-    for x, y in zip(p.mapper.color_layer_view(0).get_all_blocks_split(), e.mapper.color_layer_view(0).get_all_blocks_split()):
-        assert torch.equal(x, y)
+    for mid in ((0, 1) if include_dynamic else (0,)):  # (with include_dynamic both mappers go through one native call per frame)
+        for x, y in zip(p.mapper.feature_layer_view(mid).get_all_blocks_split(), e.mapper.feature_layer_view(mid).get_all_blocks_split()):
+            assert torch.equal(x, y)
+        for x, y in zip(p.mapper.color_layer_view(mid).get_all_blocks_split(), e.mapper.color_layer_view(mid).get_all_blocks_split()):
+            assert torch.equal(x, y)
+        for x, y in zip(p.mapper.tsdf_layer_view(mid).get_all_blocks(), e.mapper.tsdf_layer_view(mid).get_all_blocks()):
+            assert torch.equal(x, y)
 
 
 def test_mirrored_feature_extractor_through_the_facade(monkeypatch):
