@@ -171,13 +171,16 @@ def test_random_parameters_stand_alone_calls_match_oracle(oracle_mod, seed):
     assert np.array_equal(gf.view(np.uint16), ofeat.view(np.uint16)), "mesh vertex features"
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("seed", range(12))
-def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path):
+def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path, pipelined):
     """A random walk over the Mapper's entry points on a two-mapper Mapper -- decay, the fused frame, the same frame call by
     call, the fused frame from a low-res feature map, both mappers in one call, clear, mesh update, save + load into a NEW
     mapper that carries on, point queries, depth rendering -- against two oracle maps driven with the equivalent calls.  What
     this exercises is the STATE between calls: pending lazy decay, grid / hand-over tags, slot reuse after clear and
-    deallocation, hints sized by earlier frames, a restored map continuing."""
+    deallocation, hints sized by earlier frames, a restored map continuing.  ``pipelined``: the same walk with the appearance
+    half of every fused frame deferred to the next one (``set_deferred_feature_rows``): whatever call comes next either hosts it or
+    completes it first."""
     import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
     from nvblox_mindmap_amd.image_processing import upsample_features
     from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg
@@ -191,6 +194,7 @@ def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path):
     mcfg.tsdf_decay_factor = float(r.choice([0.98, 0.6, 0.2]))
     k_in, k_depth, border, min_d = 2, 3, mcfg.feature_mask_border_percent, mcfg.min_integration_distance_m
     gpu = H.get_nvblox_mapper(mcfg, feature_channels=C)
+    gpu.set_deferred_feature_rows(pipelined)
     orcs = [make_oracle(oracle_mod, C, tsdf_decay_factor=mcfg.tsdf_decay_factor) for _ in range(2)]
 
     def frame_inputs():
@@ -280,6 +284,7 @@ def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path):
             for j in range(2):
                 gpu.save_map(paths[j], j)
             gpu = H.get_nvblox_mapper(mcfg, feature_channels=C)
+            gpu.set_deferred_feature_rows(pipelined)
             for j in range(2):
                 gpu.load_from_file(paths[j], j)
         elif op == "query":
