@@ -13,6 +13,7 @@ namespace mmf {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load with dword alignment
 typedef unsigned short ushort_u __attribute__((aligned(1)));             // 2-byte load with byte alignment
+typedef float f32x2 __attribute__((ext_vector_type(2)));                 // a channel pair: v_pk_mul_f32 / v_pk_add_f32
 
 // ------------------------------------------------------------------------------------------------
 // Shared per-voxel gate (projection, occlusion test against the synthetic depth, bilinear footprint,
@@ -242,12 +243,22 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
     } else {
       av = *reinterpret_cast<const half8*>(A + ch * 8);
     }
+    // two channels per instruction (v_pk_mul_f32 / v_pk_add_f32: the same multiplications and additions in the same order, element
+    // by element -- no contraction): this loop is the instruction count of the row update, which is issue-bound as a guest of the
+    // sphere-trace launch and, from a low-res map, on its own
     half8 o;
+    const float ux = 1.0f - wx, uy = 1.0f - wy;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float a = bilin((float)a00[k], (float)a10[k], (float)a01[k], (float)a11[k], wx, wy);
-      const float An = ((float)av[k] * Wv + a * wm) * inv;
-      o[k] = (_Float16)An;
+    for (int k = 0; k < 8; k += 2) {
+      const f32x2 v00 = {(float)a00[k], (float)a00[k + 1]}, v10 = {(float)a10[k], (float)a10[k + 1]};
+      const f32x2 v01 = {(float)a01[k], (float)a01[k + 1]}, v11 = {(float)a11[k], (float)a11[k + 1]};
+      const f32x2 top = ux * v00 + wx * v10;
+      const f32x2 bot = ux * v01 + wx * v11;
+      const f32x2 a = uy * top + wy * bot;
+      const f32x2 old = {(float)av[k], (float)av[k + 1]};
+      const f32x2 An = (old * Wv + a * wm) * inv;
+      o[k] = (_Float16)An.x;
+      o[k + 1] = (_Float16)An.y;
     }
     *reinterpret_cast<half8*>(A + ch * 8) = o;
   };
@@ -285,12 +296,17 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
           const float4 q00 = reinterpret_cast<const float4*>(p00 + c0)[h], q01 = reinterpret_cast<const float4*>(p01 + c0)[h];
           const float4 q10 = reinterpret_cast<const float4*>(p10 + c0)[h], q11 = reinterpret_cast<const float4*>(p11 + c0)[h];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float a = f4_at(q00, k), b = f4_at(q01, k), c = f4_at(q10, k), d = f4_at(q11, k);
-            t00[4 * h + k] = (_Float16)(Y0.l0 * (X0.l0 * a + X0.l1 * b) + Y0.l1 * (X0.l0 * c + X0.l1 * d));
-            t10[4 * h + k] = (_Float16)(Y0.l0 * (X1.l0 * a + X1.l1 * b) + Y0.l1 * (X1.l0 * c + X1.l1 * d));
-            t01[4 * h + k] = (_Float16)(Y1.l0 * (X0.l0 * a + X0.l1 * b) + Y1.l1 * (X0.l0 * c + X0.l1 * d));
-            t11[4 * h + k] = (_Float16)(Y1.l0 * (X1.l0 * a + X1.l1 * b) + Y1.l1 * (X1.l0 * c + X1.l1 * d));
+          for (int k = 0; k < 4; k += 2) {  // channel pairs: packed f32 multiplies / adds, the arithmetic of low_tap element by element
+            const f32x2 a = {f4_at(q00, k), f4_at(q00, k + 1)}, b = {f4_at(q01, k), f4_at(q01, k + 1)};
+            const f32x2 c = {f4_at(q10, k), f4_at(q10, k + 1)}, d = {f4_at(q11, k), f4_at(q11, k + 1)};
+            const f32x2 r0x0 = X0.l0 * a + X0.l1 * b, r0x1 = X1.l0 * a + X1.l1 * b;  // upper texel row at the two tap columns
+            const f32x2 r1x0 = X0.l0 * c + X0.l1 * d, r1x1 = X1.l0 * c + X1.l1 * d;  // lower texel row
+            const f32x2 v00 = Y0.l0 * r0x0 + Y0.l1 * r1x0, v10 = Y0.l0 * r0x1 + Y0.l1 * r1x1;
+            const f32x2 v01 = Y1.l0 * r0x0 + Y1.l1 * r1x0, v11 = Y1.l0 * r0x1 + Y1.l1 * r1x1;
+            t00[4 * h + k] = (_Float16)v00.x, t00[4 * h + k + 1] = (_Float16)v00.y;
+            t10[4 * h + k] = (_Float16)v10.x, t10[4 * h + k + 1] = (_Float16)v10.y;
+            t01[4 * h + k] = (_Float16)v01.x, t01[4 * h + k + 1] = (_Float16)v01.y;
+            t11[4 * h + k] = (_Float16)v11.x, t11[4 * h + k + 1] = (_Float16)v11.y;
           }
           if (h == 0) __builtin_amdgcn_sched_barrier(0);
         }
