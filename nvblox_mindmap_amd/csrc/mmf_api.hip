@@ -1746,6 +1746,10 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
       const int i = batch[q];
       Mapper& m = *ms[i];
       MMF_TRY(adopt_pending(handles[i], m, s));
+      // (a larger image re-allocates the synthetic depth image while the frames are prepared, before launch 1 is enqueued: a pending
+      // gating that reads the old one runs first.  The single-frame path prepares it after its launch 1.)
+      if ((m.tail_pending || m.rows_pending) && (ins[i].W / m.mc.st_sf) * (ins[i].H / m.mc.st_sf) > m.synth_cap)
+        MMF_TRY(flush_rows(handles[i], m));
       if (m.defer_rows) MMF_TRY(ensure_flat_other(m));
       MMF_TRY(report_device_errors(handles[i], m, nullptr, nullptr, s));
       MMF_TRY(pair_prepare(handles[i], m, ins[i], pp[i].M, pp[i].vg, pp[i].cam, pp[i].T_L_C, pp[i].T_C_L, s, F[q]));

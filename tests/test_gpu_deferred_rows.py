@@ -122,6 +122,29 @@ def test_batches_of_deferring_mappers(n):
         same_maps(batched[q], alone[q])
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_image_size_changes_in_mid_stream(batched):
+    """A larger image re-allocates internal images (synthetic depth, mask scratch) while a frame's appearance tail is pending."""
+    C = 16
+    d, e = pair(C)
+    d2, e2 = pair(C)
+    k = 0
+    for scale in (4, 4, 2, 2, 4, 1, 2):
+        cfg = stream_cfg(scale)
+        if not batched:
+            feed(cfg, (d, e), 11 * k, C, k)
+        else:
+            for m in (d, d2, e, e2):
+                m.decay()
+            integrate_frames_batch([frame_args(cfg, d, 11 * k, C, k)[0], frame_args(cfg, d2, 11 * k + 5, C, k + 1)[0]])
+            single(frame_args(cfg, e, 11 * k, C, k)[0])
+            single(frame_args(cfg, e2, 11 * k + 5, C, k + 1)[0])
+        k += 1
+    same_maps(d, e)
+    if batched:
+        same_maps(d2, e2)
+
+
 def test_full_size_stream():
     """BASELINE configs[2] at full size (640x480, C = 64): 8 frames with a decay() before each, deferred against undeferred."""
     cfg, C = S.StreamConfig(hole_mode="patches"), 64
