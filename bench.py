@@ -1346,6 +1346,8 @@ def main():
         # SURVEY.md section 8(d) model, kept for comparison (it charges the whole feature image and every voxel of every candidate block)
         survey_bytes = (cfg.height * cfg.width * (4 + 1) + tsdf_blocks_per_frame * 512 * 16 + cfg.height * cfg.width * (2 * C + 1)
                         + feat_blocks_per_frame * 512 * 2 * (2 * C + 4) + cfg.height * cfg.width * (3 + 1) + col_blocks_per_frame * 512 * 16)
+        if undeferred is not None:  # the same algorithmic bytes over the unpipelined frame time (what earlier rounds' lines report)
+            undeferred["frac_of_hbm_peak"] = b_frame / (undeferred["ms_per_step"] * 1e-3) / HBM_PEAK_BYTES_PER_S
         roofline = {
             "bound": "hbm",
             "kernel": ("whole frame = 5 launches (k_front, k_alloc_tsdf, k_sphere_alloc, k_app_frame, k_feature_flat)" if args.eager_rows else
