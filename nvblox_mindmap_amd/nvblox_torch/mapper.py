@@ -277,7 +277,8 @@ class Mapper:
         self._h = h
         self._n = n
         self._mesh_V = {}
-        self._held_rows = {}  # mapper_id -> (feature image of a frame whose row update is deferred, its version counter)
+        self._held_rows = {}  # mapper_id -> (tensors of a frame whose appearance tail is deferred, their version counters)
+        self._deferred_mode = {}  # mapper_id -> set_deferred_feature_rows state
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -450,8 +451,37 @@ class Mapper:
         image and the two returned masks of a frame must not be modified in place before the next call on the mapper (this
         object keeps the tensors alive and checks their version counters).  Off by default."""
         _lib.check(_lib.lib().mmf_set_deferred_feature_rows(self._h, int(mapper_id), 1 if on else 0), "mmf_set_deferred_feature_rows")
+        for i in (range(self._n) if int(mapper_id) < 0 else [int(mapper_id)]):
+            self._deferred_mode[i] = bool(on)
         if not on:
-            self._held_rows.clear()
+            for i in (list(self._held_rows) if int(mapper_id) < 0 else [int(mapper_id)]):
+                self._held_rows.pop(i, None)
+
+    def integrate_frame_sequence(self, frames, mapper_id: int = 0, decay_before_each: bool = True) -> list:
+        """Extension: a recorded stream into one mapper -- ``frames`` yields dicts with the arguments of ``integrate_frame``
+        (``depth_frame``, ``color_frame``, ``feature_frame`` or ``lowres_features``, ``input_mask``, ``t_w_c``, ``intrinsics``,
+        ``min_depth_m``, ``input_mask_erosion_iterations``, ``valid_depth_mask_erosion_iterations``, ``border_percent``, optionally
+        ``invert_input_mask``), each preceded by ``decay()`` as in the reference's control step.  Consecutive frames are
+        software-pipelined (``set_deferred_feature_rows``) for the duration of the call and the last one is completed before it
+        returns; the mode the mapper was in is restored.  Returns [(depth_mask, feature_mask), ...]."""
+        mapper_id = self._check_id(mapper_id)
+        was_on = bool(self._deferred_mode.get(mapper_id, False))
+        self.set_deferred_feature_rows(True, mapper_id)
+        out = []
+        try:
+            for fr in frames:
+                if decay_before_each:
+                    self.decay(mapper_id)
+                out.append(self._integrate_frame_desc(
+                    fr["depth_frame"], fr["color_frame"], None if fr.get("lowres_features") is not None else fr["feature_frame"],
+                    fr.get("lowres_features"), fr["input_mask"], fr["t_w_c"], fr["intrinsics"], fr["min_depth_m"],
+                    fr["input_mask_erosion_iterations"], fr["valid_depth_mask_erosion_iterations"], fr["border_percent"], mapper_id,
+                    bool(fr.get("invert_input_mask", False))))
+        finally:
+            self.flush(mapper_id)
+            if not was_on:
+                self.set_deferred_feature_rows(False, mapper_id)
+        return out
 
     def flush(self, mapper_id: int = -1) -> None:
         """Enqueue whatever is pending on the mapper (a deferred row update, a lazy ``decay()``)."""

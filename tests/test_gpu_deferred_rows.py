@@ -145,6 +145,23 @@ def test_image_size_changes_in_mid_stream(batched):
         same_maps(d2, e2)
 
 
+def test_sequence_call_leaves_the_mapper_as_the_single_calls_do():
+    cfg, C = stream_cfg(2), 16
+    d, e = make_mapper(C), make_mapper(C)
+    frames = [frame_args(cfg, d, 7 * k, C, k)[0] for k in range(6)]
+    keys = ("depth_frame", "color_frame", "feature_frame", "input_mask", "t_w_c", "intrinsics", "min_depth_m",
+            "input_mask_erosion_iterations", "valid_depth_mask_erosion_iterations", "border_percent", "invert_input_mask")
+    masks = d.integrate_frame_sequence([{k: f[k] for k in keys} for f in frames])
+    assert pending(d) == 0
+    for f, (dm, fm) in zip(frames, masks):
+        e.decay()
+        dm2, fm2 = single(dict(f, mapper=e))
+        assert torch.equal(dm, dm2) and torch.equal(fm, fm2)
+    same_maps(d, e)
+    single(dict(frames[0], mapper=d))  # the mode is off again
+    assert pending(d) == 0
+
+
 def test_full_size_stream():
     """BASELINE configs[2] at full size (640x480, C = 64): 8 frames with a decay() before each, deferred against undeferred."""
     cfg, C = S.StreamConfig(hole_mode="patches"), 64
