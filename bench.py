@@ -819,6 +819,71 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     return out
 
 
+def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, backbone_matmul_dtype="float16x3", overlap_backbone=True):
+    """The same training step as run_training (same model, batch, dtype, optimizer rule), arranged so that the GPU -- not the
+    interpreter -- bounds it (training.GraphedTrainStep): forward + backward as ONE captured HIP graph with the next batch's frozen
+    backbone as a parallel branch, gradients in ONE flat buffer, ONE explicit RCCL all-reduce of it between the graphs (world > 1),
+    AdamW over the flat segments as a second graph.  Every timed step runs one backbone forward, one trainable forward / backward,
+    one all-reduce and one optimizer step.  Reports what the host and the collective cost: host time to enqueue a step, the
+    all-reduce's duration (HIP events on the stream it is issued from, a second short region), the number of ranks an all-reduce of
+    ones reaches, and every rank's own step time."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import GraphedTrainStep, all_gather_objects, build_model, synthetic_batch
+    from nvblox_mindmap_amd.training.distributed import barrier, max_over_ranks
+
+    torch.manual_seed(0)
+    cfg = DiffuserActorConfig(backbone_matmul_dtype=backbone_matmul_dtype)
+    model = build_model(cfg, device=device)
+    rank = int(os.environ.get("RANK", "0"))
+    batches = [synthetic_batch(cfg, per_gpu_batch, device, seed=1000 * rank + i) for i in range(2)]
+    t_c = time.perf_counter()
+    g = GraphedTrainStep(cfg, model, batches[0], overlap_backbone=overlap_backbone)
+    torch.cuda.synchronize(device)
+    capture_s = time.perf_counter() - t_c
+    observed = g.observed_world()
+
+    def run(n, first):
+        for i in range(first, first + n):
+            g.step(batches[i % 2], batches[(i + 1) % 2])
+
+    run(warmup, 0)
+    barrier()
+    torch.cuda.synchronize(device)
+    g.host_enqueue_s = 0.0
+    t0 = time.perf_counter()
+    run(steps, warmup)
+    host_s = g.host_enqueue_s
+    torch.cuda.synchronize(device)
+    mine = time.perf_counter() - t0
+    barrier()
+    el = time.perf_counter() - t0
+    nccl = world > 1 and torch.distributed.get_backend() == "nccl"
+    dt = max_over_ranks(el, device if nccl else None) if world > 1 else el
+    per_rank = [r["ms"] for r in all_gather_objects({"ms": mine / steps * 1e3})]
+    allreduce = None
+    if world > 1:  # a second, short region with HIP events around the collective (kept out of the headline region)
+        g.time_allreduce = True
+        run(6, warmup + steps)
+        ms = g.collect_allreduce_ms()
+        g.time_allreduce = False
+        allreduce = {"mean_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms), "payload_MB": g.flat_grad.numel() * 4 / 1e6,
+                     "timed_with": "HIP events recorded on the issuing stream around dist.all_reduce(flat_grad) (includes the wait for "
+                                   "the slowest rank's backward)"}
+    out = {"step_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "samples_per_s": steps * per_gpu_batch * world / dt,
+           "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup, "dtype": "f32",
+           "backbone_matmuls": backbone_matmul_dtype, "backbone_overlap": bool(g.overlap),
+           "host_enqueue_ms_per_step": host_s / steps * 1e3, "host_enqueue_frac": host_s / mine,
+           "rccl_world_observed": observed, "allreduce": allreduce, "allreduce_payload_MB": g.flat_grad.numel() * 4 / 1e6,
+           "per_rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank), "all": per_rank},
+           "trainable_params_in_flat_buffer": int(g.n_total), "unused_parameter_tensors": len(g.unused_names),
+           "capture_s": capture_s, "parallelism": f"dp{world}" if world > 1 else "single",
+           "how": "training.GraphedTrainStep: forward+backward = one captured HIP graph (next batch's frozen backbone as a parallel "
+                  "branch), one flat gradient buffer, one explicit all-reduce, AdamW over two flat segments as a second graph"}
+    del g, model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=16, workers=10,
                           vertex_count_range=(10000, 14000)):
     """Is the training step loader-bound?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader keeping the GPUs
@@ -1146,7 +1211,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="no per-launch timing inside the timed region")
     ap.add_argument("--no-ref-shape", action="store_true", help="skip the short run at the reference's real shape (512x512x768)")
     ap.add_argument("--no-train", action="store_true", help="skip the policy training-step measurement")
-    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-steps", type=int, default=16)
     ap.add_argument("--no-infer", action="store_true", help="skip the policy inference latency leg")
     ap.add_argument("--no-backproj", action="store_true", help="skip the back-projection leg (GPU kernel + torch-CPU baseline)")
     ap.add_argument("--no-file-fed", action="store_true", help="skip the file-fed training leg (loader-bound vs compute-bound step/s)")
@@ -1156,6 +1221,7 @@ def main():
     ap.add_argument("--in-flight-only", action="store_true", help="run only the frames-in-flight leg (N replicas in one set of launches)")
     ap.add_argument("--unbounded-only", action="store_true", help="run only the unbounded-workspace (hash path) leg (rocprofv3 passes)")
     ap.add_argument("--eager-rows", action="store_true", help="headline without the deferred feature-row update (every frame runs its five launches before the next starts)")
+    ap.add_argument("--train-only", action="store_true", help="run only the captured training step (rocprofv3 passes of the training half)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the multi-rank control flow only")
     args = ap.parse_args()
     if args.only_fusion:
@@ -1187,6 +1253,16 @@ def main():
         out = run_training_file_fed(device, compute_bound_step_per_s=base["step_per_s"])
         if rank == 0:
             print(json.dumps({"file_fed": out}), flush=True)
+        return
+    if args.train_only:
+        out = run_training_graphed(device, world, steps=args.train_steps,
+                                   backbone_matmul_dtype=os.environ.get("BENCH_BACKBONE_MATMULS", "float16x3"),
+                                   overlap_backbone=os.environ.get("BENCH_TRAIN_OVERLAP", "1") != "0")
+        if rank == 0:
+            print(json.dumps({"train": out}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if args.ref_shape_only:
         out = run_reference_shape(device)
@@ -1276,27 +1352,28 @@ def main():
     if rank == 0 and not args.no_ref_shape:
         ref_shape = run_reference_shape(device)
     train = None
-    if not args.no_train:  # every rank takes part (DDP)
+    if not args.no_train:  # every rank takes part (data parallel)
         if dist is not None:
             dist.barrier()
-        train = run_training(device, world, steps=args.train_steps)  # strictly serial order: the figure compared across N
-        if world == 1:
-            # single GPU only (measured there; not exercised next to RCCL): the frozen backbone of the next batch on a second
-            # stream beside the trainable pass of the current one (training.BackbonePrefetcher, bit-identical results)
-            pre = run_training(device, world, steps=args.train_steps, prefetch_backbone=True)
-            train["with_backbone_prefetch"] = {"step_per_s": pre["step_per_s"], "ms_per_step": pre["ms_per_step"]}
-        # the frozen backbone's Linears on rocBLAS's f32 GEMM instead of one fp16 GEMM of split operands each (split_linear.py: the
-        # default, f32 accuracy): what the split buys
-        t32 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float32")
-        train["f32_gemm_backbone"] = {"step_per_s": t32["step_per_s"], "ms_per_step": t32["ms_per_step"]}
+        # headline: the captured step (HIP graphs, flat gradient buffer, one explicit all-reduce); f32 accuracy throughout
+        train = run_training_graphed(device, world, steps=args.train_steps)
+        train["model"] = "diffuser_actor RGBD_AND_MESH, 1 cam 512x512, 2048 vertices x 768, frozen ViT-B/16-shaped backbone (random init)"
+        if dist is not None:
+            dist.barrier()
+        # the reference-shaped step beside it: eager PyTorch, DistributedDataParallel(find_unused_parameters=True), AdamW over
+        # the individual parameters (mindmap/run_training.py:155-217,608-613) -- host-bound on this machine
+        eager = run_training(device, world, steps=max(args.train_steps // 2, 4))
+        train["eager_ddp_reference_shaped"] = {k: eager[k] for k in ("step_per_s", "ms_per_step", "trainable_params", "frozen_backbone_params",
+                                                                      "backbone_matmuls", "parallelism")}
         # secondary figure, not the headline: the frozen backbone's matmuls with float16 inputs / fp32 accumulation -- the
         # mantissa width of the TF32 mode the reference runs its backbone in (feature_extraction.py:322); gfx950 has no TF32
-        t16 = run_training(device, world, steps=args.train_steps, backbone_matmul_dtype="float16", prefetch_backbone=(world == 1))
+        t16 = run_training_graphed(device, world, steps=args.train_steps, backbone_matmul_dtype="float16")
         train["fp16_backbone_matmuls"] = {"step_per_s": t16["step_per_s"], "ms_per_step": t16["ms_per_step"],
+                                          "host_enqueue_ms_per_step": t16["host_enqueue_ms_per_step"],
                                           "note": "frozen backbone under float16 autocast (10-bit mantissa like the reference's TF32 "
                                                   "backbone, fp32 accumulate); everything trainable stays float32"}
         if rank == 0 and not args.no_file_fed:
-            train["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=train["step_per_s"])
+            train["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=eager["step_per_s"])
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     model_inputs = None

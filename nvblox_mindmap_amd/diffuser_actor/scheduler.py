@@ -39,9 +39,21 @@ class DDPMScheduler:
         ratio = self.num_train_timesteps // num_inference_steps
         self.timesteps = (torch.arange(0, num_inference_steps) * ratio).flip(0)
 
+    def _acp_on(self, device) -> torch.Tensor:
+        """alphas_cumprod on `device`, copied there once (a host-to-device copy per call would synchronise, and cannot be
+        captured in a HIP graph: training.graphed captures the whole training forward)."""
+        device = torch.device(device)
+        if device.type == "cpu":
+            return self.alphas_cumprod
+        cache = self.__dict__.setdefault("_acp_cache", {})
+        t = cache.get(device)
+        if t is None:
+            t = cache[device] = self.alphas_cumprod.to(device)
+        return t
+
     def add_noise(self, original: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
         """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps, per-sample timestep (B,)."""
-        acp = self.alphas_cumprod.to(original.device)[timesteps]
+        acp = self._acp_on(original.device)[timesteps]
         shape = (-1,) + (1,) * (original.ndim - 1)
         return acp.sqrt().reshape(shape) * original + (1.0 - acp).sqrt().reshape(shape) * noise
 

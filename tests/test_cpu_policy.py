@@ -328,6 +328,75 @@ def test_ddp_two_ranks_gloo():
     assert tmax == 2.0
 
 
+def _flat_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from nvblox_mindmap_amd.training import (GraphedTrainStep, ProcessGroup, all_gather_objects, build_optimizer, train_one_step,
+                                             wrap_ddp)
+    from nvblox_mindmap_amd.training.trainer import build_lr_scheduler, build_model
+
+    with ProcessGroup(backend="gloo"):
+        cfg = _tiny_cfg()
+        steps, lr = 4, 1e-3
+        batches = [_tiny_batch(cfg, 2, seed=10 * rank + it) for it in range(steps)]
+        # (a) the reference-shaped step: DDP(find_unused_parameters) + AdamW over the individual parameters + LinearLR
+        torch.manual_seed(0)
+        ref = build_model(cfg, device="cpu")
+        ddp = wrap_ddp(ref, "cpu")
+        opt = build_optimizer(ddp, lr=lr)
+        sched = build_lr_scheduler(opt, train_iters=8)
+        torch.manual_seed(100 + rank)
+        ref_losses = [[float(x) for x in train_one_step(cfg, ddp, opt, b, scheduler=sched)] for b in batches]
+        # (b) flat buffers + one explicit all-reduce + AdamW over the two flat segments (the eager form of the captured step)
+        torch.manual_seed(0)
+        model = build_model(cfg, device="cpu")
+        flat = GraphedTrainStep(cfg, model, batches[0], lr=lr, use_graphs=False)
+        flat.linear_lr(train_iters=8)
+        torch.manual_seed(100 + rank)
+        flat_losses = []
+        for b in batches:
+            flat_losses.append([float(x) for x in flat.step(b)])
+            flat.scheduler_step()
+        names = dict(model.named_parameters())
+        diff = max(float((p - names[n]).abs().max()) for n, p in ref.named_parameters())
+        equal = all(torch.equal(p, names[n]) for n, p in ref.named_parameters())
+        unused_ref = sorted(n for n, p in ref.named_parameters() if p.requires_grad and p.grad is None)
+        vec = torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad])
+        gathered = all_gather_objects({"diff": diff, "equal": equal, "ref_losses": ref_losses, "flat_losses": flat_losses,
+                                       "unused": (unused_ref, sorted(flat.unused_names)), "checksum": float(vec.double().sum()),
+                                       "lr": (opt.param_groups[0]["lr"], flat.lr), "world": flat.observed_world(),
+                                       "payload": flat.flat_grad.numel(), "steps": flat.steps_done})
+        if rank == 0:
+            out.put(gathered)
+
+
+def test_flat_allreduce_step_matches_ddp_two_ranks_gloo():
+    """training.GraphedTrainStep (flat gradient buffer, ONE explicit all-reduce, AdamW over two flat segments, unused parameters
+    found by a probe) against the reference-shaped DDP step on 2 gloo ranks that see different data: the same losses, the same
+    weights after 4 steps with a LinearLR ramp, the same set of parameters left without a gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = g
+    for r in (a, b):
+        assert r["unused"][0] == r["unused"][1] and len(r["unused"][0]) > 0  # the instruction branch, on both paths
+        assert r["world"] == 2 and r["steps"] == 4 and r["payload"] > 0
+        assert r["lr"][0] == r["lr"][1] < 1e-3
+        # losses: 5 values x 4 steps (total, position, rotation, gripper, head yaw)
+        assert np.allclose(np.array(r["ref_losses"], dtype=np.float64), np.array(r["flat_losses"], dtype=np.float64), rtol=1e-6, atol=1e-7)
+        assert r["diff"] <= 1e-7, r["diff"]  # elementwise-identical arithmetic (bit-equal on this build: see "equal")
+    assert a["checksum"] == b["checksum"]  # the explicit all-reduce kept the ranks in step
+    assert a["flat_losses"] != b["flat_losses"]  # (they saw different data)
+    assert a["equal"] and b["equal"], (a["diff"], b["diff"])
+
+
 def test_compute_metrics_matches_reference():
     """model_utils/loss.py:83-139 (vectors from the imported reference, tests/golden/make_golden_metrics.py): an exact hit
     exercises the small-angle branch, a sign-flipped quaternion the double cover."""

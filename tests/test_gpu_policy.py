@@ -114,6 +114,63 @@ def test_backbone_prefetch_trains_like_the_serial_order():
     assert torch.equal(results[0][1], results[1][1])
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_captured_training_step_matches_the_eager_step(overlap):
+    """training.GraphedTrainStep: forward + backward as one captured HIP graph (the next batch's frozen backbone as a parallel
+    branch of it when `overlap`), flat gradient buffer, AdamW over the flat segments as a second graph -- against the eager
+    train_one_step on the same batches with the same noise / timestep draws: same losses and same weights to float32 rounding
+    (the captured AdamW keeps its step count and learning rate on the device in float32; torch's eager one in Python floats)."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import GraphedTrainStep, build_model, build_optimizer, synthetic_batch, train_one_step
+    from nvblox_mindmap_amd.training.trainer import build_lr_scheduler
+
+    cfg = DiffuserActorConfig(data_type="rgbd_and_mesh", image_size=(128, 128), feature_dim=768)
+    batches = [synthetic_batch(cfg, 2, "cuda", num_vertices=256, seed=i) for i in range(5)]
+    torch.manual_seed(0)
+    ref = build_model(cfg, device="cuda")
+    opt = build_optimizer(ref, lr=1e-3)
+    sched = build_lr_scheduler(opt, train_iters=8)
+    torch.manual_seed(1)
+    ref_losses = [torch.stack([x for x in train_one_step(cfg, ref, opt, b, scheduler=sched)]).clone() for b in batches]
+
+    torch.manual_seed(0)
+    model = build_model(cfg, device="cuda")
+    g = GraphedTrainStep(cfg, model, batches[0], lr=1e-3, overlap_backbone=overlap)
+    assert g.graph_fb is not None and g.graph_opt is not None and g.overlap == overlap
+    g.linear_lr(train_iters=8)
+    torch.manual_seed(1)
+    losses = []
+    for i, b in enumerate(batches):
+        # (the last step of a stream has nothing to announce; step 2 is handed an unannounced batch on purpose: it re-primes)
+        nxt = batches[i + 1] if (i + 1 < len(batches) and i != 1) else None
+        losses.append(g.step(b, nxt).clone())
+        g.scheduler_step()
+    torch.cuda.synchronize()
+    assert g.steps_done == 5 and sorted(g.unused_names) == sorted(n for n, p in ref.named_parameters() if p.requires_grad and p.grad is None)
+    for a, b in zip(ref_losses, losses):
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-5), (a, b)
+    names = dict(model.named_parameters())
+    worst = max(float((p - names[n]).abs().max()) for n, p in ref.named_parameters())
+    assert worst < 2e-5, worst  # 5 steps at lr 1e-3: an update is ~1e-3 per step, the two paths differ by float32 rounding of Adam's ratio
+    moved = max(float((p - q).abs().max()) for p, q in zip(ref.parameters(), build_model(cfg, device="cuda").parameters()))
+    assert moved > 1e-3
+    # the flat views ARE the model's parameters: a state_dict round trip through a fresh captured step continues identically
+    state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()}
+    opt_state = g.state_dict()
+    torch.manual_seed(5)
+    l_a = g.step(batches[0], None).clone()
+    torch.manual_seed(0)
+    model2 = build_model(cfg, device="cuda")
+    model2.load_state_dict(state)
+    g2 = GraphedTrainStep(cfg, model2, batches[0], lr=1e-3, overlap_backbone=overlap)
+    g2.load_state_dict(opt_state)
+    torch.manual_seed(5)
+    l_b = g2.step(batches[0], None).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(l_a, l_b)
+    assert all(torch.equal(p, q) for p, q in zip(model.parameters(), model2.parameters()))
+
+
 def test_file_fed_training_step(tmp_path):
     """Demo on disk (reference layout) -> DataLoader -> gpu_unpack (transforms on the GPU) -> training step; the GPU
     transforms equal the reference's CPU transformers bit for bit."""
