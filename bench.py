@@ -29,8 +29,13 @@ import time
 import statistics
 import subprocess
 
-import numpy as np
-import torch
+# The captured training step (training/graphed.py) is one HIP graph of ~2 400 kernel nodes: with the runtime's default AQL ring
+# (16 384 packets) hipGraphLaunch blocks the host until the previous step has drained enough of it (measured: 26 of 73 ms per step;
+# 0.7 ms with the larger ring).  Read by the HIP runtime when it initialises, i.e. at the first GPU call of this process.
+os.environ.setdefault("ROC_AQL_QUEUE_SIZE", "65536")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -849,10 +854,10 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
     run(warmup, 0)
     barrier()
     torch.cuda.synchronize(device)
-    g.host_enqueue_s = 0.0
+    g.host_enqueue_s = g.host_cpu_s = 0.0
     t0 = time.perf_counter()
     run(steps, warmup)
-    host_s = g.host_enqueue_s
+    host_s, host_cpu_s = g.host_enqueue_s, g.host_cpu_s
     torch.cuda.synchronize(device)
     mine = time.perf_counter() - t0
     barrier()
@@ -873,10 +878,11 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
            "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup, "dtype": "f32",
            "backbone_matmuls": backbone_matmul_dtype, "backbone_overlap": bool(g.overlap),
            "host_enqueue_ms_per_step": host_s / steps * 1e3, "host_enqueue_frac": host_s / mine,
+           "host_cpu_ms_per_step": host_cpu_s / steps * 1e3,
            "rccl_world_observed": observed, "allreduce": allreduce, "allreduce_payload_MB": g.flat_grad.numel() * 4 / 1e6,
            "per_rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank), "all": per_rank},
            "trainable_params_in_flat_buffer": int(g.n_total), "unused_parameter_tensors": len(g.unused_names),
-           "capture_s": capture_s, "parallelism": f"dp{world}" if world > 1 else "single",
+           "capture_s": capture_s, "tuned_gemms": bool(g.tuned_gemms), "runtime_env": {"ROC_AQL_QUEUE_SIZE": os.environ.get("ROC_AQL_QUEUE_SIZE")}, "parallelism": f"dp{world}" if world > 1 else "single",
            "how": "training.GraphedTrainStep: forward+backward = one captured HIP graph (next batch's frozen backbone as a parallel "
                   "branch), one flat gradient buffer, one explicit all-reduce, AdamW over two flat segments as a second graph"}
     del g, model, batches

@@ -313,6 +313,12 @@ int mmf_integrate_frame_batch(int n_frames, const mmf_handle* handles, const int
  * out_idx [B,npoints] i64.  N <= 8192, C <= 1024. */
 int mmf_farthest_point_sampling(const float* x_dev, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx_dev,
                                 void* stream);
+/* The same sampling with its scratch in a caller-owned device buffer of >= mmf_fps_workspace_bytes(B, N, C) bytes: no runtime
+ * allocation inside the call, so it can be captured in a HIP graph without memory nodes (the training step's graph,
+ * nvblox_mindmap_amd/training/graphed.py: a graph with hipMallocAsync nodes is executed synchronously from the host). */
+int64_t mmf_fps_workspace_bytes(int B, int N, int C);
+int mmf_farthest_point_sampling_ws(const float* x_dev, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx_dev,
+                                   void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* Inference-side fused ops of the diffusion head (no autograd; the training path keeps the composite torch ops).
  * mmf_rotary_apply: apply_rotary of diffuser_actor/position_encodings.py (x*cos + rotate_pairs(x)*sin), x [rows,D] with a

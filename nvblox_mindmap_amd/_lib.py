@@ -155,6 +155,8 @@ SIGNATURES = {
     "mmf_ddpm_step": (_I, [_VP, _VP, C.c_longlong, _VP, _VP, C.c_longlong, _I, _I, _VP, _VP, _VP]),
     "mmf_attention_small": (_I, [_VP, _VP, C.c_longlong, _VP, C.c_longlong, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmf_farthest_point_sampling": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "mmf_fps_workspace_bytes": (C.c_int64, [_I, _I, _I]),
+    "mmf_farthest_point_sampling_ws": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, C.c_int64, _VP]),
     "mmf_get_synthetic_depth_dims": (_I, [_VP, _I, _PI, _PI]),
     "mmf_get_synthetic_depth": (_I, [_VP, _I, _VP, _VP]),
     "mmf_render_synthetic_depth": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),

@@ -2292,13 +2292,27 @@ int mmf_upsample_features(const float* lowres, int hh, int ww, int Cin, void* ou
   return check_launch();
 }
 
-int mmf_farthest_point_sampling(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* stream) {
+static int fps_entry(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                     void* stream) {
   if (!x || !out_idx || B <= 0 || N <= 0 || C <= 0 || npoints <= 0 || npoints > N || start_idx < 0 || start_idx >= N)
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_farthest_point_sampling");
-  const int rc = launch_fps(x, B, N, C, npoints, start_idx, reinterpret_cast<long long*>(out_idx), (hipStream_t)stream);
+  const int rc = launch_fps(x, B, N, C, npoints, start_idx, reinterpret_cast<long long*>(out_idx), (hipStream_t)stream, workspace, workspace_bytes);
   if (rc == 1) return fail(MMF_ERR_INVALID_ARG, "mmf_farthest_point_sampling supports N <= 8192 and C <= 1024");
-  if (rc != 0) return fail(MMF_ERR_HIP, "mmf_farthest_point_sampling: HIP runtime call failed");
+  if (rc != 0) return fail(MMF_ERR_HIP, "mmf_farthest_point_sampling: HIP runtime call failed (or the workspace is too small)");
   return check_launch();
+}
+
+int mmf_farthest_point_sampling(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* stream) {
+  return fps_entry(x, B, N, C, npoints, start_idx, out_idx, nullptr, 0, stream);
+}
+
+int64_t mmf_fps_workspace_bytes(int B, int N, int C) { return (B <= 0 || N <= 0 || C <= 0) ? 0 : (int64_t)fps_workspace_bytes(B, N, C); }
+
+int mmf_farthest_point_sampling_ws(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  if (!workspace || workspace_bytes < mmf_fps_workspace_bytes(B, N, C))
+    return fail(MMF_ERR_INVALID_ARG, "mmf_farthest_point_sampling_ws: workspace smaller than mmf_fps_workspace_bytes(B, N, C)");
+  return fps_entry(x, B, N, C, npoints, start_idx, out_idx, workspace, (size_t)workspace_bytes, stream);
 }
 
 // ---- inference-side fused ops of the diffusion head ------------------------------------------------------------------

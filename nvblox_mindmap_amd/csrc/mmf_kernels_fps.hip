@@ -226,8 +226,48 @@ __global__ __launch_bounds__(64 * NWV) void k_fps_groups(const float* __restrict
   }
 }
 
+// Scratch of a launcher: either carved out of the caller's workspace (mmf_farthest_point_sampling_ws: no runtime allocation, so the
+// call can sit inside a captured HIP graph without memory nodes -- those make hipGraphLaunch execute the graph synchronously from the
+// host) or stream-ordered allocations of its own.
+struct FpsScratch {
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  bool own = false;
+  void* a = nullptr;
+  void* b = nullptr;
+  hipStream_t s = nullptr;
+  bool get(size_t bytes_a, size_t bytes_b) {
+    if (base) {
+      const size_t oa = (used + 255) & ~(size_t)255, ob = (oa + bytes_a + 255) & ~(size_t)255;
+      if (ob + bytes_b > cap) return false;
+      a = base + oa;
+      b = base + ob;
+      return true;
+    }
+    own = true;
+    if (hipMallocAsync(&a, bytes_a, s) != hipSuccess) return false;
+    if (hipMallocAsync(&b, bytes_b, s) != hipSuccess) {
+      (void)hipFreeAsync(a, s);
+      a = nullptr;
+      return false;
+    }
+    return true;
+  }
+  void release() {
+    if (own) {
+      (void)hipFreeAsync(b, s);
+      (void)hipFreeAsync(a, s);
+    }
+  }
+};
+
+size_t fps_workspace_bytes(int B, int N, int C) {
+  // padded rows (the resident / grouped kernels, C <= 128) + the largest publication area of any launcher + alignment slack
+  return sizeof(float) * (size_t)B * N * 128 + sizeof(unsigned long long) * (size_t)B * 2 * 64 * 129 + 1024;
+}
+
 template <int CP, int NWV>
-static int fps_groups(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+static int fps_groups(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s, FpsScratch sc) {
   const int G = (N + 64 * NWV - 1) / (64 * NWV);
   if (G > kFpsMaxGroups || CP + 1 > 64 * NWV) return 1;
   int dev = 0, cus = 0, per_cu = 0;
@@ -239,11 +279,9 @@ static int fps_groups(const float* x, int B, int N, int C, int npoints, int star
   float* xp = nullptr;
   u64* pub = nullptr;
   const size_t xp_bytes = sizeof(float) * (size_t)B * N * CP, pub_bytes = sizeof(u64) * (size_t)B * 2 * G * (CP + 1);
-  if (hipMallocAsync((void**)&xp, xp_bytes, s) != hipSuccess) return 2;
-  if (hipMallocAsync((void**)&pub, pub_bytes, s) != hipSuccess) {
-    (void)hipFreeAsync(xp, s);
-    return 2;
-  }
+  if (!sc.get(xp_bytes, pub_bytes)) return 2;
+  xp = (float*)sc.a;
+  pub = (u64*)sc.b;
   (void)hipMemsetAsync(pub, 0, pub_bytes, s);
   const long long rows = (long long)B * N;
   hipLaunchKernelGGL(k_fps_pad<CP>, dim3((unsigned)((rows * CP + 255) / 256)), dim3(256), 0, s, x, rows, C, xp);
@@ -252,8 +290,7 @@ static int fps_groups(const float* x, int B, int N, int C, int npoints, int star
     hipLaunchKernelGGL((k_fps_groups<CP, NWV>), dim3(8 * G * ((nb + 7) / 8)), dim3(64 * NWV), 0, s, xp, b0, b0 + nb, N, G, npoints, start, pub,
                        out_idx);
   }
-  (void)hipFreeAsync(pub, s);
-  (void)hipFreeAsync(xp, s);
+  sc.release();
   return 0;
 }
 
@@ -520,7 +557,7 @@ __global__ __launch_bounds__(64 * (NWV + 1)) void k_fps_multi(const float* __res
 }
 
 template <int CP, int NWV, int K>
-static int fps_multi(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+static int fps_multi(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s, FpsScratch sc) {
   const int G = (N + 64 * NWV - 1) / (64 * NWV);
   if (G * K > 64 || G > kFpsMultiGroups || N > 4096 || N - (G - 1) * 64 * NWV < K) return 1;  // (every workgroup publishes K real points)
   int dev = 0, cus = 0, per_cu = 0;
@@ -532,11 +569,9 @@ static int fps_multi(const float* x, int B, int N, int C, int npoints, int start
   float* xp = nullptr;
   u64* pub = nullptr;
   const size_t xp_bytes = sizeof(float) * (size_t)B * N * CP, pub_bytes = sizeof(u64) * (size_t)B * 2 * G * K * (CP + 1);
-  if (hipMallocAsync((void**)&xp, xp_bytes, s) != hipSuccess) return 2;
-  if (hipMallocAsync((void**)&pub, pub_bytes, s) != hipSuccess) {
-    (void)hipFreeAsync(xp, s);
-    return 2;
-  }
+  if (!sc.get(xp_bytes, pub_bytes)) return 2;
+  xp = (float*)sc.a;
+  pub = (u64*)sc.b;
   (void)hipMemsetAsync(pub, 0, pub_bytes, s);
   const long long rows = (long long)B * N;
   hipLaunchKernelGGL(k_fps_pad<CP>, dim3((unsigned)((rows * CP + 255) / 256)), dim3(256), 0, s, x, rows, C, xp);
@@ -545,8 +580,7 @@ static int fps_multi(const float* x, int B, int N, int C, int npoints, int start
     hipLaunchKernelGGL((k_fps_multi<CP, NWV, K>), dim3(8 * G * ((nb + 7) / 8)), dim3(64 * (NWV + 1)), 0, s, xp, b0, b0 + nb, N, G, npoints, start,
                        pub, out_idx);
   }
-  (void)hipFreeAsync(pub, s);
-  (void)hipFreeAsync(xp, s);
+  sc.release();
   return 0;
 }
 
@@ -623,7 +657,7 @@ __global__ __launch_bounds__(kFpsThreads) void k_fps_stream(const float* __restr
 }
 
 template <int CP>
-static int fps_resident(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+static int fps_resident(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s, FpsScratch sc) {
   const int W = (N + 63) / 64;
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -635,11 +669,9 @@ static int fps_resident(const float* x, int B, int N, int C, int npoints, int st
   float* xp = nullptr;
   u64* slots = nullptr;
   const size_t xp_bytes = sizeof(float) * (size_t)B * N * CP, slot_bytes = sizeof(u64) * (size_t)B * 2 * 64;
-  if (hipMallocAsync((void**)&xp, xp_bytes, s) != hipSuccess) return 2;
-  if (hipMallocAsync((void**)&slots, slot_bytes, s) != hipSuccess) {
-    (void)hipFreeAsync(xp, s);
-    return 2;
-  }
+  if (!sc.get(xp_bytes, slot_bytes)) return 2;
+  xp = (float*)sc.a;
+  slots = (u64*)sc.b;
   (void)hipMemsetAsync(slots, 0, slot_bytes, s);
   const long long rows = (long long)B * N;
   hipLaunchKernelGGL(k_fps_pad<CP>, dim3((unsigned)((rows * CP + 255) / 256)), dim3(256), 0, s, x, rows, C, xp);
@@ -648,25 +680,29 @@ static int fps_resident(const float* x, int B, int N, int C, int npoints, int st
     hipLaunchKernelGGL(k_fps_resident<CP>, dim3(8 * W * ((nb + 7) / 8)), dim3(64), 0, s, xp, b0, b0 + nb, N, W, npoints, start, slots,
                        out_idx);
   }
-  (void)hipFreeAsync(slots, s);
-  (void)hipFreeAsync(xp, s);
+  sc.release();
   return 0;
 }
 
 // 0 = launched, 1 = unsupported shape, 2 = HIP runtime error
-int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s) {
+int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s, void* workspace,
+               size_t workspace_bytes) {
+  FpsScratch sc;
+  sc.s = s;
+  sc.base = (char*)workspace;
+  sc.cap = workspace_bytes;
   if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120)
     static const int single = getenv("MMF_DEBUG_FPS_SINGLE") ? 1 : 0;  // (diagnostics: one pick per exchange)
-    int rc = single ? 1 : fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s);
-    if (rc == 1) rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s);  // (8 groups of 6 waves: 7 % slower)
+    int rc = single ? 1 : fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s, sc);
+    if (rc == 1) rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s, sc);  // (8 groups of 6 waves: 7 % slower)
     if (rc != 1) return rc;
   }
   if (N <= kFpsMaxResidentN && C <= kFpsMaxResidentC) {
-    const int rc = C <= 16   ? fps_resident<16>(x, B, N, C, npoints, start, out_idx, s)
-                   : C <= 32 ? fps_resident<32>(x, B, N, C, npoints, start, out_idx, s)
-                   : C <= 64 ? fps_resident<64>(x, B, N, C, npoints, start, out_idx, s)
-                   : C <= 96 ? fps_resident<96>(x, B, N, C, npoints, start, out_idx, s)
-                             : fps_resident<128>(x, B, N, C, npoints, start, out_idx, s);
+    const int rc = C <= 16   ? fps_resident<16>(x, B, N, C, npoints, start, out_idx, s, sc)
+                   : C <= 32 ? fps_resident<32>(x, B, N, C, npoints, start, out_idx, s, sc)
+                   : C <= 64 ? fps_resident<64>(x, B, N, C, npoints, start, out_idx, s, sc)
+                   : C <= 96 ? fps_resident<96>(x, B, N, C, npoints, start, out_idx, s, sc)
+                             : fps_resident<128>(x, B, N, C, npoints, start, out_idx, s, sc);
     if (rc != 1) return rc;  // 1: the waves of 8 batch elements cannot be co-resident on this device -> stream
   }
   if (N > kFpsThreads * kFpsMaxPerThread || C > kFpsMaxC) return 1;

@@ -329,7 +329,9 @@ void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int
 void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s);
 
 // mmf_kernels_fps.hip
-int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s);
+int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long long* out_idx, hipStream_t s, void* workspace = nullptr,
+               size_t workspace_bytes = 0);
+size_t fps_workspace_bytes(int B, int N, int C);
 
 // mmf_kernels_policy.hip (inference-side fused ops of the diffusion head)
 void launch_rotary_apply(const float* x, long long x_stride, const float* cs, const float* sn, float* out, long long rows, int D,

@@ -13,8 +13,13 @@ def farthest_point_sampling(x: torch.Tensor, npoints: int, start_idx: int = 0) -
     B, N, C = x.shape
     xx = x.detach().to(torch.float32).contiguous()
     out = torch.empty((B, npoints), dtype=torch.int64, device=x.device)
-    _lib.check(_lib.lib().mmf_farthest_point_sampling(_lib.dptr(xx), B, N, C, int(npoints), int(start_idx), _lib.dptr(out),
-                                                     _lib.stream_ptr(x.device)), "mmf_farthest_point_sampling")
+    # scratch from torch's allocator (inside a HIP-graph capture: from the graph's pool), not from the runtime: a captured
+    # hipMallocAsync makes hipGraphLaunch run the whole graph synchronously from the host
+    L = _lib.lib()
+    nbytes = int(L.mmf_fps_workspace_bytes(B, N, C))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    _lib.check(L.mmf_farthest_point_sampling_ws(_lib.dptr(xx), B, N, C, int(npoints), int(start_idx), _lib.dptr(out), _lib.dptr(ws), nbytes,
+                                                _lib.stream_ptr(x.device)), "mmf_farthest_point_sampling")
     return out
 
 

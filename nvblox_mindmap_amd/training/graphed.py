@@ -12,7 +12,9 @@ arithmetic arranged for the machine:
     embedding: why the reference needs ``find_unused_parameters``) are found ONCE by a probe backward and stay out of the buffers
     and of the optimizer -- exactly what DDP + AdamW do with a ``None`` gradient: nothing;
   * forward + backward is ONE captured HIP graph (static shapes: batch 32, 2 048 vertices); the frozen backbone of the NEXT batch
-    runs as a parallel branch of the same graph (it is frozen: its output does not depend on this step's update);
+    is a second graph replayed beside it on another stream (it is frozen: its output does not depend on this step's update).  Both
+    are single-stream graphs without memory nodes: measured on this runtime, a graph that forks streams or holds a captured
+    hipMallocAsync is walked node by node from the HOST by hipGraphLaunch (tools/microbench/graph_block_probe.py);
   * the data-parallel exchange is ONE explicit ``all_reduce`` of ``flat_grad`` over RCCL (pre-scaled by 1 / world like DDP's
     bucket) between the two graphs -- no bucketing, no hooks;
   * AdamW (the reference's two groups: no weight decay for names containing "bias" / "LayerNorm.*", run_training.py:140-153) is
@@ -34,6 +36,47 @@ from ..diffuser_actor import DiffuserActorConfig
 from .distributed import get_world_size
 from .trainer import unpack_batch
 
+AQL_QUEUE_PACKETS = 65536
+
+
+def configure_runtime_for_graphs() -> None:
+    """Call BEFORE the process touches the GPU (the HIP runtime reads its flags when it initialises).  The captured step is a
+    graph of ~2 400 kernel nodes, several AQL packets each: with the runtime's default ring of 16 384 packets, launching step
+    t + 1 while step t is still running blocks the host inside hipGraphLaunch until the ring has room (measured on MI355X: 26 ms of
+    a 73 ms step; 0.7 ms with ROC_AQL_QUEUE_SIZE = 65536, tools/microbench/graph_block_probe.py and DESIGN.md section 7)."""
+    import os
+
+    os.environ.setdefault("ROC_AQL_QUEUE_SIZE", str(AQL_QUEUE_PACKETS))
+
+
+TUNED_GEMMS_FILE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms(path: str = TUNED_GEMMS_FILE) -> bool:
+    """Let PyTorch's TunableOp pick, per GEMM shape, the hipBLASLt / rocBLAS solution recorded in ``path`` (tuned once on an
+    MI355X with tools/tune_train_gemms.sh; no tuning at run time).  The trainable half of the policy is full of tall-skinny float32
+    GEMMs (98 304 x 120 -> 240 key / value projections, 65 536 x 768 -> 120 vertex embeddings) for which the libraries' default
+    heuristic picks kernels 5 - 7x slower than their best (0.60 -> 0.08 ms for the projection; 73.0 -> 68.1 ms per step).  The
+    file's validators (PyTorch, HIP, hipBLASLt, rocBLAS versions, gfx950) must match the running stack: otherwise it is ignored
+    with torch's warning and the library defaults stay.  Returns whether TunableOp is on with entries loaded."""
+    import os
+
+    if not (torch.cuda.is_available() and os.path.exists(path)):
+        return False
+    import torch.cuda.tunable as tunable
+
+    if os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") == "1":  # a tuning run (tools/tune_train_gemms.sh): the environment rules
+        return tunable.is_enabled()
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.record_untuned_enable(False)
+    try:
+        ok = bool(tunable.read_file(path))
+    except Exception:
+        ok = False
+    return ok and len(tunable.get_results()) > 0
+
+
 _NO_DECAY = ("bias", "LayerNorm.weight", "LayerNorm.bias")  # run_training.py:140-153
 
 
@@ -54,7 +97,7 @@ class GraphedTrainStep:
 
     def __init__(self, cfg: DiffuserActorConfig, model: nn.Module, example_batch: Dict[str, torch.Tensor], lr: float = 1e-4,
                  weight_decay: float = 5e-4, use_graphs: Optional[bool] = None, overlap_backbone: bool = True,
-                 unpack: Optional[Callable] = None, process_group=None):
+                 unpack: Optional[Callable] = None, process_group=None, tuned_gemms: bool = True):
         self.cfg, self.model = cfg, model
         self.unpack = unpack or unpack_batch
         self.group = process_group
@@ -69,22 +112,30 @@ class GraphedTrainStep:
         self.overlap = bool(overlap_backbone and self.has_backbone and self.device.type == "cuda")
         self.static = {k: v.to(self.device).clone() for k, v in example_batch.items() if torch.is_tensor(v)}
         self.steps_done = 0
-        self.host_enqueue_s = 0.0       # host time spent inside step() (enqueue only: step() never synchronises)
+        self.host_enqueue_s = 0.0       # host wall time spent inside step() (enqueue only: step() never synchronises)
+        self.host_cpu_s = 0.0           # CPU time of the calling thread inside step()
         self._ev = None                 # (start, end) HIP events around the last all-reduce when timing is on
         self.time_allreduce = False
         self.allreduce_ms: List[float] = []
         self._primed = None             # the batch dict whose backbone features are in ``self.feats`` (held: ids are not reused)
 
+        self.tuned_gemms = bool(tuned_gemms and self.device.type == "cuda" and enable_tuned_gemms())
         model.train()
         self._find_used_parameters()
         self._flatten(lr, weight_decay)
         self.losses = torch.zeros(5, dtype=torch.float32, device=self.device)
-        self.feats = self.next_rgbs = None
+        self.feats = self.next_feats = self.next_rgbs = None
         if self.overlap:
             self.next_rgbs = self.static["rgbs"].clone()
             self._side = torch.cuda.Stream(device=self.device)
-        self.graph_fb = self.graph_opt = None
+        self.graph_fb = self.graph_opt = self.graph_bb = None
         if self.use_graphs:
+            import os
+            import warnings
+
+            if int(os.environ.get("ROC_AQL_QUEUE_SIZE", "16384")) < AQL_QUEUE_PACKETS:
+                warnings.warn("ROC_AQL_QUEUE_SIZE is below 65536: hipGraphLaunch of the captured step will block the host while the previous "
+                              "step runs (call training.configure_runtime_for_graphs() before the first GPU call, or export it)")
             self._capture()
 
     # -- layout ---------------------------------------------------------------------------------------------------------------
@@ -137,17 +188,20 @@ class GraphedTrainStep:
             self.optimizer = torch.optim.AdamW(groups, lr=float(lr))
         self.lr = float(lr)
 
-    # -- the two halves of a step (captured or eager) ------------------------------------------------------------------------------
+    # -- the pieces of a step (captured or eager) --------------------------------------------------------------------------------
+    def _backbone_next(self) -> None:
+        """self.next_feats <- frozen backbone of self.next_rgbs (its own graph, replayed on the side stream: two single-stream
+        graphs side by side instead of one forked graph -- hipGraphLaunch walks a forked graph from the host, blocking it)."""
+        out = self.model.encoder.backbone_features(self.next_rgbs)
+        if self.next_feats is None:
+            self.next_feats = out
+        else:
+            self.next_feats.copy_(out)
+
     def _forward_backward(self) -> None:
         """flat_grad <- d loss / d parameters of the batch in ``self.static`` (scaled by 1 / world), ``self.losses`` <- the
-        losses.  With ``overlap``: the frozen backbone of ``self.next_rgbs`` beside it, ``self.feats`` <- its output at the end."""
+        losses.  With ``overlap`` the image tokens come from ``self.feats`` (the backbone's output for this batch)."""
         self.flat_grad.zero_()
-        main = None
-        if self.overlap:
-            main = torch.cuda.current_stream(self.device)
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                nxt = self.model.encoder.backbone_features(self.next_rgbs)
         s = self.unpack(self.cfg, self.static)
         feats = self.feats if self.overlap else None
         losses = _forward_losses(self.cfg, self.model, s, backbone_feats=feats)
@@ -157,9 +211,6 @@ class GraphedTrainStep:
         with torch.no_grad():
             zero = losses[0].detach().new_zeros(())
             self.losses.copy_(torch.stack([zero if x is None else x.detach().to(torch.float32) for x in losses]))
-            if self.overlap:
-                main.wait_stream(self._side)
-                self.feats.copy_(nxt)  # 100 MB at batch 32: ~50 us, after both branches are done with their buffers
 
     def _optimizer_step(self) -> None:
         self.optimizer.step()
@@ -170,10 +221,9 @@ class GraphedTrainStep:
             self.feats = self.model.encoder.backbone_features(self.static["rgbs"]).clone()
         # Warm-up on a side stream (lazy initialisation of the GEMM library, the split-weight caches, autograd's buffers), as
         # torch's whole-network capture recipe asks; forward + backward only: no weight changes before the first real step.
-        devs = [dev]
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
-        with torch.random.fork_rng(devices=devs):
+        with torch.random.fork_rng(devices=[dev]):
             with torch.cuda.stream(warm):
                 for _ in range(2):
                     self._forward_backward()
@@ -187,6 +237,10 @@ class GraphedTrainStep:
                 self.lr_tensor.fill_(self.lr)
             torch.cuda.current_stream(dev).wait_stream(warm)
             torch.cuda.synchronize(dev)
+            if self.overlap:
+                self.graph_bb = torch.cuda.CUDAGraph()  # (its own memory pool: it runs BESIDE the other two graphs)
+                with torch.cuda.graph(self.graph_bb):
+                    self._backbone_next()
             self.graph_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_fb):
                 self._forward_backward()
@@ -239,13 +293,21 @@ class GraphedTrainStep:
         self._primed = batch
 
     def step(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.thread_time()
+        announce = self.overlap and next_batch is not None
         if self.overlap:
             if self._primed is not batch:
                 self.prime(batch)
-            if next_batch is not None:
+            main = torch.cuda.current_stream(self.device)
+            if announce:  # the next batch's frozen backbone, beside everything below
                 self.next_rgbs.copy_(next_batch["rgbs"], non_blocking=True)
-            self._primed = next_batch  # after this step ``self.feats`` holds the features of ``next_batch`` (None: stale, re-primed)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    if self.graph_bb is not None:
+                        self.graph_bb.replay()
+                    else:
+                        with torch.no_grad():
+                            self._backbone_next()
         self._load(batch)
         if self.graph_fb is not None:
             self.graph_fb.replay()
@@ -264,8 +326,14 @@ class GraphedTrainStep:
             self.graph_opt.replay()
         else:
             self._optimizer_step()
+        if self.overlap:
+            if announce:
+                main.wait_stream(self._side)
+                self.feats.copy_(self.next_feats)  # 100 MB at batch 32 (~50 us), after both sides are done with their buffers
+            self._primed = next_batch  # ``self.feats`` now holds the features of ``next_batch`` (None: stale, re-primed next time)
         self.steps_done += 1
         self.host_enqueue_s += time.perf_counter() - t0
+        self.host_cpu_s += time.thread_time() - c0
         return self.losses
 
     def collect_allreduce_ms(self) -> List[float]:

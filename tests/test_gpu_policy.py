@@ -131,7 +131,11 @@ def test_captured_training_step_matches_the_eager_step(overlap):
     opt = build_optimizer(ref, lr=1e-3)
     sched = build_lr_scheduler(opt, train_iters=8)
     torch.manual_seed(1)
-    ref_losses = [torch.stack([x for x in train_one_step(cfg, ref, opt, b, scheduler=sched)]).clone() for b in batches]
+    ref_losses, ref_grads = [], None
+    for b in batches:
+        ref_losses.append(torch.stack([x for x in train_one_step(cfg, ref, opt, b, scheduler=sched)]).clone())
+        if ref_grads is None:
+            ref_grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
 
     torch.manual_seed(0)
     model = build_model(cfg, device="cuda")
@@ -145,18 +149,30 @@ def test_captured_training_step_matches_the_eager_step(overlap):
         nxt = batches[i + 1] if (i + 1 < len(batches) and i != 1) else None
         losses.append(g.step(b, nxt).clone())
         g.scheduler_step()
+        if i == 0:  # the first step's gradients, parameter by parameter (views of the flat buffer)
+            mine = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            assert set(mine) == set(ref_grads)
+            for n, gr in ref_grads.items():
+                assert torch.allclose(mine[n], gr, rtol=1e-3, atol=1e-6 + 1e-4 * float(gr.abs().max())), n
     torch.cuda.synchronize()
     assert g.steps_done == 5 and sorted(g.unused_names) == sorted(n for n, p in ref.named_parameters() if p.requires_grad and p.grad is None)
     for a, b in zip(ref_losses, losses):
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-5), (a, b)
     names = dict(model.named_parameters())
-    worst = max(float((p - names[n]).abs().max()) for n, p in ref.named_parameters())
-    assert worst < 2e-5, worst  # 5 steps at lr 1e-3: an update is ~1e-3 per step, the two paths differ by float32 rounding of Adam's ratio
-    moved = max(float((p - q).abs().max()) for p, q in zip(ref.parameters(), build_model(cfg, device="cuda").parameters()))
+    # Adam's update is lr * m / (sqrt(v) + eps): where a gradient is rounding noise its SIGN decides a full-size update, so a
+    # few elements may differ by whole updates between two float32-equivalent paths; everything else agrees to rounding
+    with torch.no_grad():
+        diff = torch.cat([(p - names[n]).abs().flatten() for n, p in ref.named_parameters() if n not in g.unused_names])
+    assert float((diff > 1e-5).float().mean()) < 0.01, float((diff > 1e-5).float().mean())
+    assert float(diff.max()) < 2.5 * 1e-3 * 5, float(diff.max())
+    with torch.no_grad():
+        moved = max(float((p - q).abs().max()) for p, q in zip(ref.parameters(), build_model(cfg, device="cuda").parameters()))
     assert moved > 1e-3
     # the flat views ARE the model's parameters: a state_dict round trip through a fresh captured step continues identically
     state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()}
-    opt_state = g.state_dict()
+    import copy
+
+    opt_state = copy.deepcopy(g.state_dict())  # (a snapshot, as torch.save would take: the dict holds the live state tensors)
     torch.manual_seed(5)
     l_a = g.step(batches[0], None).clone()
     torch.manual_seed(0)
