@@ -587,16 +587,10 @@ int flush_rows(mmf_handle h, Mapper& m) {
 // A frame on stream s is about to host what is pending: fine on the stream it was deferred on.  On another stream the tail goes
 // where it would have been enqueued, and -- it is enqueued later than it would have been, after whatever synchronisation the
 // caller placed between the two streams -- stream s waits for it.
+int flush_rows_for(mmf_handle h, Mapper& m, hipStream_t s);
 int adopt_pending(mmf_handle h, Mapper& m, hipStream_t s) {
   if (!(m.rows_pending || m.tail_pending) || m.rows_stream == s) return MMF_OK;
-  hipStream_t old_stream = m.rows_stream;
-  MMF_TRY(flush_rows(h, m));
-  hipEvent_t ev;
-  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(ev, old_stream));
-  HIP_TRY(hipStreamWaitEvent(s, ev, 0));
-  HIP_TRY(hipEventDestroy(ev));
-  return MMF_OK;
+  return flush_rows_for(h, m, s);
 }
 
 // the fused frame's accessor: a pending row update stays pending (the frame hosts it)
@@ -611,6 +605,27 @@ int get_mapper_keep_rows(mmf_handle h, int id, Mapper** out) {
 int get_mapper(mmf_handle h, int id, Mapper** out) {
   MMF_TRY(get_mapper_keep_rows(h, id, out));
   return flush_rows(h, **out);
+}
+
+// ... and an entry point that knows the stream it works on: the tail goes onto the stream it was deferred on (where the
+// undeferred launches would be), and when that is another stream, the caller's stream waits for it -- a caller that ordered
+// its stream after the frame's (event / wait) sees the finished frame, exactly as without deferral.
+int flush_rows_for(mmf_handle h, Mapper& m, hipStream_t s) {
+  if (!m.rows_pending && !m.tail_pending) return MMF_OK;
+  hipStream_t old_stream = m.rows_stream;
+  MMF_TRY(flush_rows(h, m));
+  if (old_stream == s) return MMF_OK;
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ev, old_stream));
+  HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+  HIP_TRY(hipEventDestroy(ev));
+  return MMF_OK;
+}
+
+int get_mapper_on(mmf_handle h, int id, Mapper** out, void* stream) {
+  MMF_TRY(get_mapper_keep_rows(h, id, out));
+  return flush_rows_for(h, **out, (hipStream_t)stream);
 }
 
 // A pending decay is applied now, as its own launches (every consumer of the map except the fused frame path).
@@ -636,7 +651,7 @@ void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
 }
 
 int get_mapper_ready(mmf_handle h, int id, Mapper** out, void* stream) {
-  MMF_TRY(get_mapper(h, id, out));
+  MMF_TRY(get_mapper_on(h, id, out, stream));
   if ((*out)->pending_decay) {
     HIP_TRY(hipSetDevice(h->device));
     flush_decay(h, **out, (hipStream_t)stream);
@@ -1024,7 +1039,7 @@ int mmf_num_mappers(mmf_handle h) { return h ? (int)h->mappers.size() : 0; }
 int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const uint8_t* mask, int H, int W, const float* T16,
                         const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   if (!depth || !T16 || !K9 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_add_depth_frame");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1180,7 +1195,7 @@ int mmf_add_feature_frame(mmf_handle h, int mapper_id, const void* feat, const u
 int mmf_add_feature_frame_lowres(mmf_handle h, int mapper_id, const float* lowres, int lh, int lw, int Cin, const uint8_t* mask,
                                  int Hf, int Wf, const float* T16, const float* K9, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   LowRes lr;
   MMF_TRY(make_lowres(*m, lowres, lh, lw, Cin, Hf, Wf, lr));
   return add_feature_frame_impl(h, mapper_id, nullptr, &lr, mask, Hf, Wf, m->P.feature_channels, T16, K9, stream);
@@ -1642,7 +1657,7 @@ int mmf_integrate_frame_multi(mmf_handle h, int n_frames, const int* mapper_ids,
   std::vector<Mapper*> ms(n_frames);
   std::vector<FrameIn> ins(n_frames);
   for (int i = 0; i < n_frames; ++i) {
-    MMF_TRY(get_mapper(h, mapper_ids[i], &ms[i]));
+    MMF_TRY(get_mapper_on(h, mapper_ids[i], &ms[i], stream));
     MMF_TRY(frame_in_from_desc(*ms[i], &frames[i], ins[i]));
     for (int j = 0; j < i; ++j)
       if (ms[j] == ms[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_integrate_frame_multi: every frame must go to a different mapper");
@@ -1931,7 +1946,7 @@ int mmf_flush(mmf_handle h, int mapper_id, void* stream) {
   for (int i = 0; i < (int)h->mappers.size(); ++i) {
     if (mapper_id >= 0 && i != mapper_id) continue;
     Mapper* m = h->mappers[i];
-    MMF_TRY(flush_rows(h, *m));
+    MMF_TRY(flush_rows_for(h, *m, (hipStream_t)stream));
     flush_decay(h, *m, (hipStream_t)stream);
   }
   return check_launch();
@@ -2059,7 +2074,7 @@ int mmf_model_inputs_prepare(mmf_handle h, int mapper_id, const float* lo, const
 int mmf_model_inputs_gather(mmf_handle h, int mapper_id, const int64_t* rows, int n_take, int n_out, float* verts, void* feats,
                             int features_f32, uint8_t* valid, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   if (m->mi_epoch != m->tsdf_epoch || m->mi_feat_frames != m->frames[2] || m->pending_decay)
     return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_model_inputs_prepare; call it again");
   if (n_take < 0 || n_out < n_take) return fail(MMF_ERR_INVALID_ARG, "need 0 <= n_take <= n_out");
@@ -2082,7 +2097,7 @@ int mmf_update_mesh_topology(mmf_handle h, int mapper_id, void* stream, int* num
   if (!num_vertices || !num_triangles) return fail(MMF_ERR_INVALID_ARG, "null output");
   MMF_TRY(mmf_update_feature_mesh(h, mapper_id, stream, num_vertices));  // vertex counts / offsets (flushes a pending decay)
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope ps(h, MMF_K_MESH, s);
@@ -2177,7 +2192,7 @@ int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb, float* weigh
 int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx, const void* payload, const float* weights, int n,
                       void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   if (n < 0 || (n > 0 && (!idx || !payload))) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_import_blocks");
   if (layer < MMF_LAYER_TSDF || layer > MMF_LAYER_FEATURE) return fail(MMF_ERR_INVALID_ARG, "bad layer id");
   if (layer != MMF_LAYER_TSDF && n > 0 && !weights) return fail(MMF_ERR_INVALID_ARG, "appearance layers need the weight plane");
@@ -2644,7 +2659,7 @@ int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws) 
 
 int mmf_get_synthetic_depth(mmf_handle h, int mapper_id, float* out, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   if (!m->synth || m->synth_W * m->synth_H == 0) return fail(MMF_ERR_BAD_STATE, "no synthetic depth rendered yet");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(out, m->synth, sizeof(float) * (size_t)m->synth_W * m->synth_H, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -2665,7 +2680,7 @@ int mmf_render_synthetic_depth(mmf_handle h, int mapper_id, int H, int W, const 
 
 int mmf_last_view_block_count(mmf_handle h, int mapper_id, void* stream, int* out) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(h->pinned + 16, m->sc[0].cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2676,7 +2691,7 @@ int mmf_last_view_block_count(mmf_handle h, int mapper_id, void* stream, int* ou
 
 int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* out, int n, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   if (n <= 0) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_unpack_keys, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const mmf::u64*)m->sc[0].cand_key, n, out);
@@ -2685,7 +2700,7 @@ int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* out, int n, v
 
 int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   long long* host = reinterpret_cast<long long*>(h->pinned + 32);
@@ -2700,7 +2715,7 @@ int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
 
 int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_t* out) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   if (!out) return fail(MMF_ERR_INVALID_ARG, "null out");
   HIP_TRY(hipSetDevice(h->device));
   unsigned long long v = 0;
@@ -2759,7 +2774,7 @@ int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out
 
 int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream) {
   Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
+  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemsetAsync(m->stats, 0, sizeof(long long) * MMF_NUM_STATS, (hipStream_t)stream));
   m->frames[0] = m->frames[1] = m->frames[2] = 0;

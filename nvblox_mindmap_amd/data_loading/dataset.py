@@ -78,11 +78,11 @@ class MindmapFrameDataset(Dataset):
     def __len__(self) -> int:
         return len(self.samples)
 
-    def _sample_from_raw(self, raw_path: str, geometric, seed):
+    def _sample_from_raw(self, raw_path: str, geometric, seed, source: str = None):
         """``sample_to_n_vertices`` on the mapped file: ALL vertices are read (6 B each) and augmented / noised exactly as on
         the decompressed path (same RNG draws), the selection is drawn on the same V, and only the selected FEATURE rows are
         touched.  Returns what the decompressed path returns."""
-        v_map, f_map = VC.open_raw(raw_path)
+        v_map, f_map = VC.open_raw(raw_path, source)  # (StaleRawCopy when the .zst changed after the copy was made)
         vertices = torch.from_numpy(np.array(v_map))  # [V,3] float16 copy
         if self.augmentor is not None or self.noiser is not None:
             vertices = geometric(vertices.to(torch.float32), noisy=True)
@@ -133,8 +133,14 @@ class MindmapFrameDataset(Dataset):
         if self.with_vertex_features:
             seed = None if self.seed is None else self.seed + idx
             raw = VC.raw_path_of(it["vertex_features"]) if self.use_raw_vertex_cache else None
+            sampled = None
             if raw is not None and os.path.exists(raw):
-                out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = self._sample_from_raw(raw, geometric, seed)
+                try:
+                    sampled = self._sample_from_raw(raw, geometric, seed, it["vertex_features"])
+                except VC.StaleRawCopy as e:  # a regenerated dataset with old copies lying around: the .zst is the truth
+                    D._warn_stale(str(e))
+            if sampled is not None:
+                out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = sampled
             else:
                 s = D.read_vertex_features(it["vertex_features"])
                 if self.augmentor is not None or self.noiser is not None:

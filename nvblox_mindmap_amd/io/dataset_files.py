@@ -91,14 +91,30 @@ def write_depth_png(path: str, depth_m: torch.Tensor) -> None:
     Image.fromarray(arr).save(path)
 
 
+_STALE_WARNED = [0]
+
+
+def _warn_stale(what: str) -> None:
+    """A raw loader copy (io/vertex_cache.py) that no longer matches its source is skipped, loudly but not once per sample."""
+    import warnings
+
+    _STALE_WARNED[0] += 1
+    if _STALE_WARNED[0] <= 3:
+        warnings.warn(f"stale raw loader copy ignored ({what}); re-run `python -m nvblox_mindmap_amd.io.vertex_cache <dataset>`")
+
+
 def read_png(path: str, use_raw_cache: bool = False) -> torch.Tensor:
     """``torch.as_tensor(imageio.imread(path))`` (dataset.py:463-465): u16 [H,W] for depth, u8 [H,W,3] for rgb.
     ``use_raw_cache``: read ``<path>.raw`` (io/vertex_cache.py: the same pixels, no inflate) when it exists."""
+    arr = None
     if use_raw_cache and os.path.exists(path + ".raw"):
-        from .vertex_cache import read_raw_image
+        from .vertex_cache import StaleRawCopy, read_raw_image
 
-        arr = read_raw_image(path + ".raw")
-    else:
+        try:
+            arr = read_raw_image(path + ".raw", source=path)
+        except StaleRawCopy as e:  # the PNG was rewritten after the copy was made: the PNG is the truth
+            _warn_stale(str(e))
+    if arr is None:
         from PIL import Image
 
         with Image.open(path) as im:

@@ -6,11 +6,13 @@ decompresses and unpickles all of it to keep ``num_vertices_to_sample`` = 2 048 
 sample_transformer.py:150-186).  At 8 GPUs x 343 samples/s that is the decode cost that decides the scaling of the training
 step.  ``convert_dataset`` writes, next to every such file, ``NNNN.nvblox_vertex_features.raw``:
 
-    offset 0     8 bytes  magic  b"MMFVTX01"
+    offset 0     8 bytes  magic  b"MMFVTX02"
            8     int64    V   (vertices)
            16    int64    C   (feature channels)
            24    int64    offset of the vertex array   (4096)
            32    int64    offset of the feature array  (page aligned)
+           40    int64    size of the .zst it was made from      } the source's stamp: a reader that is given the source path
+           48    int64    its modification time in nanoseconds   } refuses a copy whose source has changed since (StaleRawCopy)
     vertices  float16 [V, 3]   row-major
     features  float16 [V, C]   row-major
 
@@ -28,9 +30,33 @@ import torch
 
 from .dataset_files import VERTEX_FEATURES_FILE_NAME, read_vertex_features
 
-MAGIC = b"MMFVTX01"
+MAGIC = b"MMFVTX02"
+MAGIC_V1 = b"MMFVTX01"  # (round-3 files: no source stamp; accepted only while the copy is not older than its source)
 RAW_SUFFIX = "nvblox_vertex_features.raw"
 _PAGE = 4096
+
+
+class StaleRawCopy(ValueError):
+    """The raw copy does not belong to the source file next to it (regenerated / overwritten dataset): use the source."""
+
+
+def _stamp(source: str) -> Tuple[int, int]:
+    st = os.stat(source)
+    return int(st.st_size), int(st.st_mtime_ns)
+
+
+def _check_stamp(path: str, source, size: int, mtime_ns: int) -> None:
+    """``source``: the file the copy was made from, or None (no check: the caller vouches for it)."""
+    if source is None:
+        return
+    if not os.path.exists(source):
+        return  # a dataset shipped as raw copies only
+    if (size, mtime_ns) == (0, 0):  # a copy without a stamp: as fresh as its modification time says
+        if os.path.getmtime(path) < os.path.getmtime(source):
+            raise StaleRawCopy(f"{path} is older than {source}")
+        return
+    if (size, mtime_ns) != _stamp(source):
+        raise StaleRawCopy(f"{path} was made from another version of {source}")
 
 
 def raw_path_of(zst_path: str) -> str:
@@ -38,7 +64,7 @@ def raw_path_of(zst_path: str) -> str:
     return zst_path[: -len(VERTEX_FEATURES_FILE_NAME)] + RAW_SUFFIX
 
 
-def write_raw(path: str, vertices: torch.Tensor, features: torch.Tensor) -> None:
+def write_raw(path: str, vertices: torch.Tensor, features: torch.Tensor, source: str = None) -> None:
     v = np.ascontiguousarray(vertices.detach().to("cpu", torch.float16).numpy())
     f = np.ascontiguousarray(features.detach().to("cpu", torch.float16).numpy())
     assert v.ndim == 2 and v.shape[1] == 3 and f.ndim == 2 and f.shape[0] == v.shape[0]
@@ -46,7 +72,7 @@ def write_raw(path: str, vertices: torch.Tensor, features: torch.Tensor) -> None
     off_f = (off_v + v.nbytes + _PAGE - 1) // _PAGE * _PAGE
     tmp = path + ".tmp"
     with open(tmp, "wb") as fh:
-        fh.write(MAGIC + struct.pack("<qqqq", v.shape[0], f.shape[1], off_v, off_f))
+        fh.write(MAGIC + struct.pack("<qqqq", v.shape[0], f.shape[1], off_v, off_f) + struct.pack("<qq", *(_stamp(source) if source else (0, 0))))
         fh.seek(off_v)
         fh.write(v.tobytes())
         fh.seek(off_f)
@@ -54,13 +80,16 @@ def write_raw(path: str, vertices: torch.Tensor, features: torch.Tensor) -> None
     os.replace(tmp, path)
 
 
-def open_raw(path: str) -> Tuple[np.ndarray, np.ndarray]:
-    """(vertices [V,3] float16, features [V,C] float16) as read-only memory maps."""
+def open_raw(path: str, source: str = None) -> Tuple[np.ndarray, np.ndarray]:
+    """(vertices [V,3] float16, features [V,C] float16) as read-only memory maps.  ``source``: the .zst the copy stands for --
+    StaleRawCopy if it has changed since the copy was written."""
     with open(path, "rb") as fh:
-        head = fh.read(40)
-    if len(head) < 40 or head[:8] != MAGIC:
+        head = fh.read(56)
+    if len(head) < 40 or head[:8] not in (MAGIC, MAGIC_V1):
         raise ValueError(f"{path}: not a raw vertex-feature file")
-    V, C, off_v, off_f = struct.unpack("<qqqq", head[8:])
+    V, C, off_v, off_f = struct.unpack("<qqqq", head[8:40])
+    size_src, mtime_src = struct.unpack("<qq", head[40:56]) if (head[:8] == MAGIC and len(head) >= 56) else (0, 0)
+    _check_stamp(path, source, size_src, mtime_src)
     size = os.path.getsize(path)
     if V < 0 or C <= 0 or off_v < 40 or off_f < off_v + V * 6 or off_f + V * C * 2 > size:
         raise ValueError(f"{path}: inconsistent header")
@@ -74,29 +103,37 @@ def open_raw(path: str) -> Tuple[np.ndarray, np.ndarray]:
 # ---- images: the same idea for the two PNGs of a frame ------------------------------------------------------------------------
 # ``NNNN.<cam>_rgb.png`` / ``NNNN.<cam>_depth.png`` (isaaclab_utils/isaaclab_writer.py:80-109) cost ~11 ms of inflate + defilter
 # per sample at 512x512 -- after the vertex features the largest term of the loader's per-sample time.  ``<name>.png.raw``:
-#     offset 0  8 bytes magic b"MMFIMG01";  int32 H, W, C;  int32 itemsize (1: uint8, 2: uint16);  data at offset 32
-IMG_MAGIC = b"MMFIMG01"
+#     offset 0  8 bytes magic b"MMFIMG02";  int32 H, W, C;  int32 itemsize (1: uint8, 2: uint16);  int64 size, int64 mtime_ns of the
+#     PNG it was made from;  8 bytes reserved;  data at offset 48            (MMFIMG01, round 3: no stamp, data at offset 32)
+IMG_MAGIC = b"MMFIMG02"
+IMG_MAGIC_V1 = b"MMFIMG01"
 
 
-def write_raw_image(path: str, arr: np.ndarray) -> None:
+def write_raw_image(path: str, arr: np.ndarray, source: str = None) -> None:
     a = np.ascontiguousarray(arr)
     assert a.dtype in (np.uint8, np.uint16) and a.ndim in (2, 3)
     H, W = a.shape[:2]
     C = a.shape[2] if a.ndim == 3 else 0
     tmp = path + ".tmp"
     with open(tmp, "wb") as fh:
-        fh.write(IMG_MAGIC + struct.pack("<iiii", H, W, C, a.dtype.itemsize) + b"\0" * 8)
+        fh.write(IMG_MAGIC + struct.pack("<iiii", H, W, C, a.dtype.itemsize) + struct.pack("<qq", *(_stamp(source) if source else (0, 0))) + b"\0" * 8)
         fh.write(a.tobytes())
     os.replace(tmp, path)
 
 
-def read_raw_image(path: str) -> np.ndarray:
-    """The pixel array of the PNG it was made from (uint8 [H,W,3] / uint16 [H,W]), as a fresh array."""
+def read_raw_image(path: str, source: str = None) -> np.ndarray:
+    """The pixel array of the PNG it was made from (uint8 [H,W,3] / uint16 [H,W]), as a fresh array.  ``source``: that PNG --
+    StaleRawCopy if it has changed since."""
     with open(path, "rb") as fh:
         head = fh.read(32)
-        if len(head) < 32 or head[:8] != IMG_MAGIC:
+        if len(head) < 32 or head[:8] not in (IMG_MAGIC, IMG_MAGIC_V1):
             raise ValueError(f"{path}: not a raw image file")
         H, W, C, item = struct.unpack("<iiii", head[8:24])
+        size_src = mtime_src = 0
+        if head[:8] == IMG_MAGIC:
+            size_src, mtime_src = struct.unpack("<qq", head[24:32] + fh.read(8))
+            fh.read(8)
+        _check_stamp(path, source, size_src, mtime_src)
         if H <= 0 or W <= 0 or C not in (0, 3, 4) or item not in (1, 2):
             raise ValueError(f"{path}: inconsistent header")
         n = H * W * max(C, 1) * item
@@ -105,6 +142,14 @@ def read_raw_image(path: str) -> np.ndarray:
         raise ValueError(f"{path}: truncated")
     a = np.frombuffer(data, dtype=np.uint8 if item == 1 else np.uint16)
     return a.reshape((H, W, C) if C else (H, W)).copy()
+
+
+def _fresh(read) -> bool:
+    try:
+        read()
+        return True
+    except ValueError:  # stale, truncated or foreign: rewrite it
+        return False
 
 
 def convert_dataset(dataset_path: str, overwrite: bool = False, images: bool = True) -> int:
@@ -116,20 +161,20 @@ def convert_dataset(dataset_path: str, overwrite: bool = False, images: bool = T
 
         for png in sorted(glob.glob(os.path.join(dataset_path, "**", "*.png"), recursive=True)):
             raw = png + ".raw"
-            if os.path.exists(raw) and not overwrite and os.path.getmtime(raw) >= os.path.getmtime(png):
+            if os.path.exists(raw) and not overwrite and _fresh(lambda: read_raw_image(raw, png)):
                 continue
             with Image.open(png) as im:
                 arr = np.array(im)
             if arr.dtype == np.int32:
                 arr = arr.astype(np.uint16)
-            write_raw_image(raw, arr)
+            write_raw_image(raw, arr, source=png)
             n += 1
     for zst in sorted(glob.glob(os.path.join(dataset_path, "**", f"*.{VERTEX_FEATURES_FILE_NAME}"), recursive=True)):
         raw = raw_path_of(zst)
-        if os.path.exists(raw) and not overwrite and os.path.getmtime(raw) >= os.path.getmtime(zst):
+        if os.path.exists(raw) and not overwrite and _fresh(lambda: open_raw(raw, zst)):
             continue
         s = read_vertex_features(zst)
-        write_raw(raw, s["vertices"], s["features"])
+        write_raw(raw, s["vertices"], s["features"], source=zst)
         n += 1
     return n
 

@@ -164,6 +164,13 @@ def integrate_frame(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, dep
     }, rgb)
 
 
+def _release(feature_extractor) -> None:
+    """End of a frame: an extractor that held its network output between compute_lowres and compute lets go of it."""
+    rel = getattr(feature_extractor, "release_lowres", None)
+    if rel is not None:
+        rel()
+
+
 def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, feature_extractor, depth_frame: torch.Tensor,
                      intrinsics: torch.Tensor, camera_pose: torch.Tensor, rgb: torch.Tensor, dynamic_mask: torch.Tensor,
                      include_dynamic: bool) -> Dict[str, Dict[str, torch.Tensor]]:
@@ -202,9 +209,10 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
         return out
 
     static_in = dynamic_mask if use_dyn else torch.ones_like(dynamic_mask)
+    rgb1 = rgb.unsqueeze(0)  # ONE tensor object for compute_lowres and the fallback compute: the extractor's hand-over is by identity
     if LOWRES_FEATURES and depth_frame.is_cuda and hasattr(feature_extractor, "compute_lowres"):
         with Timer("nvblox_mapper/compute_features"):
-            low, feature_size = feature_extractor.compute_lowres(rgb=rgb.unsqueeze(0))
+            low, feature_size = feature_extractor.compute_lowres(rgb=rgb1)
         if low is not None and tuple(feature_size) == tuple(depth_frame.shape):
             # (the feature image of the returned dictionaries -- read by the visualiser only -- is materialised on first access)
             jobs = jobs_for(static_in, dynamic_mask)
@@ -216,9 +224,11 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
             else:
                 masks = mapper.integrate_frame_multi(depth_frame, rgb, None, camera_pose, intrinsics, cfg.min_integration_distance_m,
                                                      cfg.feature_mask_border_percent, jobs, lowres_features=low)
+            _release(feature_extractor)
             return images_of(jobs, masks, None, lambda: feature_extractor.compute(rgb=rgb.unsqueeze(0)).squeeze(0))
     with Timer("nvblox_mapper/compute_features"):
-        feature_frame = feature_extractor.compute(rgb=rgb.unsqueeze(0)).squeeze(0)
+        feature_frame = feature_extractor.compute(rgb=rgb1).squeeze(0)  # (takes compute_lowres's held network output, if any)
+    _release(feature_extractor)
 
     def static_half():
         return integrate_frame(

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from ..data_loading.vertex_sampling import VertexSamplingMethod
+from ..image_processing.feature_extraction import _held_output
 from ..image_processing.feature_resize import upsample_features
 from .helpers.nvblox_input_helpers import frame_inputs_from_sample, get_nvblox_inputs_from_camera_handler
 from .helpers.nvblox_mapping_helpers import get_nvblox_mapper, nvblox_integrate
@@ -46,18 +47,22 @@ class BackboneFeatureExtractor:
         self.input_size = input_size
         self._channels = None
 
-    def _backbone_output(self, rgb: torch.Tensor) -> torch.Tensor:
+    def _backbone_output(self, rgb: torch.Tensor, hold: bool = False) -> torch.Tensor:
         assert rgb.ndim == 4 and rgb.shape[0] == 1 and rgb.shape[-1] == 3
-        key = (rgb.data_ptr(), rgb._version, tuple(rgb.shape), rgb.dtype)  # compute_lowres then compute on one image: one backbone run
-        if getattr(self, "_last_key", None) == key:
-            return self._last_out
-        x = rgb.permute(0, 3, 1, 2).to(torch.float32) / 255.0
-        if self.input_size is not None and tuple(x.shape[-2:]) != tuple(self.input_size):
-            x = F.interpolate(x, self.input_size, mode="bilinear", align_corners=False)
-        low = self.backbone(x)
-        self._channels = int(low.shape[1])
-        self._last_key, self._last_out = key, low[0]
-        return low[0]
+
+        def run():
+            x = rgb.permute(0, 3, 1, 2).to(torch.float32) / 255.0
+            if self.input_size is not None and tuple(x.shape[-2:]) != tuple(self.input_size):
+                x = F.interpolate(x, self.input_size, mode="bilinear", align_corners=False)
+            low = self.backbone(x)
+            self._channels = int(low.shape[1])
+            return low[0]
+
+        # compute_lowres then compute on one image object: one backbone run (feature_extraction._held_output: explicit, one-shot)
+        return _held_output(self, rgb, hold, run)
+
+    def release_lowres(self) -> None:
+        self._held = None
 
     @torch.no_grad()
     def compute(self, rgb: torch.Tensor) -> torch.Tensor:
@@ -68,7 +73,7 @@ class BackboneFeatureExtractor:
         """Extension read by ``nvblox_integrate``: (the backbone's own output as [h, w, C] float32, the size ``compute`` would
         resize it to).  The native integration samples the low-res map itself -- same result as integrating ``compute(rgb)``,
         bit for bit, without the [Hf, Wf, C_pad] float16 image ever existing."""
-        low = self._backbone_output(rgb)
+        low = self._backbone_output(rgb, hold=True)
         if low.shape[0] % 8 != 0:  # the fused path moves 8 channels at a time
             return None, self.desired_output_size
         return low.permute(1, 2, 0).to(torch.float32).contiguous(), self.desired_output_size

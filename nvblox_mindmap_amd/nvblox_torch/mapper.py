@@ -419,7 +419,14 @@ class Mapper:
                                            min_depth_m, input_mask_erosion_iterations, valid_depth_mask_erosion_iterations,
                                            border_percent, invert_input_mask)
         previous = self._check_held_rows(mapper_id)
-        _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
+        try:
+            _lib.check(_lib.lib().mmf_integrate_frame_desc(self._h, mapper_id, C.byref(f), self._stream()), "mmf_integrate_frame_desc")
+        except Exception:
+            # the call failed (bad argument, HIP error) but the PREVIOUS frame's tail may still be pending with pointers into
+            # `previous`: keep those tensors alive until something runs it
+            if previous is not None and _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
+                self._held_rows[mapper_id] = previous
+            raise
         del previous
         if _lib.lib().mmf_deferred_feature_rows_pending(self._h, mapper_id) == 1:
             # the native side still reads the feature image (or low-res map), the colour image and the two masks it has just written: keep them
@@ -449,13 +456,15 @@ class Mapper:
         launch, and its colour update + feature gating in the next frame's first launch; anything else that touches the mapper
         runs them first, so every result is bit-identical to the undeferred sequence.  While on, the feature image, the colour
         image and the two returned masks of a frame must not be modified in place before the next call on the mapper (this
-        object keeps the tensors alive and checks their version counters).  Off by default."""
+        object keeps the tensors alive and checks their version counters -- which see torch's in-place operations only: a write
+        through a raw pointer, e.g. by another native library or a DLPack consumer, goes unnoticed).  Off by default."""
+        previous = []
+        if not on:  # switching it off runs what is pending: the same in-place check as before any other consumer of the held images
+            previous = [self._check_held_rows(i) for i in (list(self._held_rows) if int(mapper_id) < 0 else [int(mapper_id)])]
         _lib.check(_lib.lib().mmf_set_deferred_feature_rows(self._h, int(mapper_id), 1 if on else 0), "mmf_set_deferred_feature_rows")
         for i in (range(self._n) if int(mapper_id) < 0 else [int(mapper_id)]):
             self._deferred_mode[i] = bool(on)
-        if not on:
-            for i in (list(self._held_rows) if int(mapper_id) < 0 else [int(mapper_id)]):
-                self._held_rows.pop(i, None)
+        del previous
 
     def integrate_frame_sequence(self, frames, mapper_id: int = 0, decay_before_each: bool = True) -> list:
         """Extension: a recorded stream into one mapper -- ``frames`` yields dicts with the arguments of ``integrate_frame``

@@ -88,6 +88,20 @@ _WEIGHT_MODES = {"kConstantWeight": 0, "kInverseSquareWeight": 1, "kConstantDrop
                  "kInverseSquareTsdfDistancePenalty": 4, "kLinearWithMax": 5}
 
 
+class MmfWeightingMode(int):
+    """An index in THIS library's numbering of the weighting functions (``mmf_params.weighting_mode``, the order of
+    ``_WEIGHT_MODES``) -- the oracle's numbering, used by the tests and the pin kit.  A BARE int is refused by ``to_c``: upstream's
+    ``WeightingFunctionType`` may number its members differently (its source is not in the reference tree), and a caller passing
+    upstream's integer would silently get another weighting function.  Names and enum members (``.name``) are unambiguous."""
+
+    @property
+    def name(self) -> str:
+        for k, v in _WEIGHT_MODES.items():
+            if v == int(self):
+                return k
+        raise ValueError(f"no weighting mode with index {int(self)}")
+
+
 class MapperParams:
     def __init__(self):
         self._projective = ProjectiveIntegratorParams()
@@ -136,8 +150,10 @@ class MapperParams:
         p.max_weight = float(pi.projective_integrator_max_weight)
         wm = pi.projective_integrator_weighting_mode
         wm = getattr(wm, "name", wm)
-        if isinstance(wm, int) and wm in _WEIGHT_MODES.values():
-            wm = next(k for k, v in _WEIGHT_MODES.items() if v == wm)
+        if isinstance(wm, int):
+            raise ValueError(f"projective_integrator_weighting_mode = {wm}: a bare integer is ambiguous (this library's numbering is not "
+                             f"known to be upstream's); pass the member's name ({', '.join(_WEIGHT_MODES)}), an enum member, or "
+                             "mapper_params.MmfWeightingMode(index) for this library's own numbering")
         if wm not in _WEIGHT_MODES:
             raise ValueError(f"unsupported projective_integrator_weighting_mode: {wm}")
         p.weighting_mode = _WEIGHT_MODES[wm]

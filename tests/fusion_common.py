@@ -28,7 +28,7 @@ def make_mapper(channels, **over):
     (an unknown name raises -- a silently ignored override would make a spec flip a no-op)."""
     from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
     from nvblox_mindmap_amd.nvblox_torch.mapper_params import (
-        BlockMemoryPoolParams, MapperParams, MeshIntegratorParams, ProjectiveIntegratorParams, TsdfDecayIntegratorParams,
+        BlockMemoryPoolParams, MapperParams, MeshIntegratorParams, MmfWeightingMode, ProjectiveIntegratorParams, TsdfDecayIntegratorParams,
         ViewCalculatorParams)
 
     kw = dict(REF_PARAMS)
@@ -40,7 +40,7 @@ def make_mapper(channels, **over):
         "appearance_measurement_weight": (pi, "projective_appearance_integrator_measurement_weight", float),
         "appearance_max_weight": (pi, "projective_appearance_integrator_max_weight", float),
         "truncation_distance_vox": (pi, "projective_integrator_truncation_distance_vox", float),
-        "weighting_mode": (pi, "projective_integrator_weighting_mode", int),
+        "weighting_mode": (pi, "projective_integrator_weighting_mode", MmfWeightingMode),  # (the oracle's numbering, said so explicitly)
         "max_weight": (pi, "projective_integrator_max_weight", float),
         "lin_interp_max_diff_vox": (pi, "projective_tsdf_integrator_linear_interpolation_max_allowable_difference_vox", float),
         "st_subsampling": (pi, "projective_appearance_integrator_sphere_tracing_ray_subsampling_factor", int),

@@ -131,3 +131,31 @@ def test_nvblox_torch_surface():
     v = cubes.vertices[cubes.triangles.long()].double()
     vol = (v[:, 0] * torch.linalg.cross(v[:, 1], v[:, 2])).sum(-1).reshape(5, 12).sum(-1) / 6.0
     assert torch.allclose(vol, torch.full((5,), 1e-6, dtype=torch.float64), rtol=1e-4)
+
+
+def test_weighting_mode_takes_names_not_bare_integers():
+    """Round-3 advisor finding: an integer is ambiguous (upstream's enum order is not known here); names, enum members and the
+    explicit MmfWeightingMode index are not."""
+    import enum
+
+    import pytest
+
+    from nvblox_mindmap_amd.nvblox_torch.mapper_params import MapperParams, MmfWeightingMode, ProjectiveIntegratorParams
+
+    def mode_of(value):
+        pi = ProjectiveIntegratorParams()
+        pi.projective_integrator_weighting_mode = value
+        mp = MapperParams()
+        mp.set_projective_integrator_params(pi)
+        return mp.to_c(0.01, 16).weighting_mode
+
+    class Upstream(enum.Enum):  # whatever VALUES upstream gives its members, the NAME decides
+        kConstantDropoffWeight = 1
+        kInverseSquareWeight = 2
+
+    assert mode_of("kInverseSquareWeight") == 1 and mode_of(Upstream.kInverseSquareWeight) == 1
+    assert mode_of(Upstream.kConstantDropoffWeight) == 2 and mode_of(MmfWeightingMode(5)) == 5
+    with pytest.raises(ValueError, match="bare integer"):
+        mode_of(2)
+    with pytest.raises(ValueError):
+        mode_of("kNoSuchWeight")

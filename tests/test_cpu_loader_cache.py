@@ -79,6 +79,51 @@ def test_raw_file_is_validated(tmp_path):
         VC.open_raw(p)
 
 
+def test_regenerated_dataset_does_not_train_on_stale_copies(tmp_path):
+    """Round-3 advisor finding: the loader used the raw copies whenever they existed.  A dataset that is regenerated in place keeps
+    its old ``.raw`` files; they carry their source's (size, mtime) now and a copy whose source has changed is skipped (with a
+    warning) in favour of the source -- and ``convert_dataset`` rewrites exactly those."""
+    import shutil
+    import warnings
+
+    d = str(tmp_path / "ds")
+    write_synthetic_demo(os.path.join(d, "demo_00000"), 3, image_size=(32, 32), feature_dim=16, vertex_count_range=(300, 600), seed=1)
+    assert VC.convert_dataset(d) == 3 + 6
+    before = [MindmapFrameDataset(d, num_vertices=128, seed=2, use_raw_vertex_cache=True)[i] for i in range(3)]
+    # regenerate the demo with other content; the old raw copies stay where they are
+    raws = {}
+    for root, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(".raw"):
+                raws[os.path.join(root, f)] = open(os.path.join(root, f), "rb").read()
+    shutil.rmtree(os.path.join(d, "demo_00000"))
+    write_synthetic_demo(os.path.join(d, "demo_00000"), 3, image_size=(32, 32), feature_dim=16, vertex_count_range=(300, 600), seed=9)
+    for path, blob in raws.items():
+        with open(path, "wb") as fh:
+            fh.write(blob)
+        os.utime(path, (time.time() + 100, time.time() + 100))  # NEWER than the new sources: a modification-time test alone passes them
+    truth = [MindmapFrameDataset(d, num_vertices=128, seed=2, use_raw_vertex_cache=False)[i] for i in range(3)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = [MindmapFrameDataset(d, num_vertices=128, seed=2, use_raw_vertex_cache=True)[i] for i in range(3)]
+    assert any("stale raw loader copy" in str(x.message) for x in w)
+    for a, b, old in zip(truth, got, before):
+        same(a, b)
+        assert not torch.equal(old["vertex_features"], b["vertex_features"]) and not torch.equal(old["rgb_u8"], b["rgb_u8"])
+    assert VC.convert_dataset(d) == 3 + 6 and VC.convert_dataset(d) == 0  # the stale ones are rewritten, then it is idempotent again
+    for a, b in zip(truth, [MindmapFrameDataset(d, num_vertices=128, seed=2, use_raw_vertex_cache=True)[i] for i in range(3)]):
+        same(a, b)
+    # a round-3 copy (no stamp) is still read while it is not older than its source ...
+    p = str(tmp_path / "0000.nvblox_vertex_features.raw")
+    src = str(tmp_path / "0000.nvblox_vertex_features.zst")
+    open(src, "wb").write(b"x")
+    VC.write_raw(p, torch.rand(4, 3), torch.randn(4, 8))  # written without a source: the stamp fields are zero
+    assert VC.open_raw(p, src)[1].shape == (4, 8)
+    os.utime(src, (time.time() + 100, time.time() + 100))
+    with pytest.raises(VC.StaleRawCopy):  # ... and refused once the source is newer
+        VC.open_raw(p, src)
+
+
 def _drain(args):
     path, raw, n, seed = args
     torch.set_num_threads(1)

@@ -234,6 +234,42 @@ def test_whatever_comes_between_two_frames(what):
     same_maps(d, e)
 
 
+def test_reader_on_another_stream_sees_the_frame_complete():
+    """A caller integrates on stream 1, records an event, makes stream 2 wait for it and reads the map on stream 2 -- valid without
+    deferral.  With it, the frame's tail is enqueued on stream 1 only when the reader arrives (after the event): the reader's
+    stream must then wait for that tail (round-3 advisor finding).  Stream 1 is kept busy behind the event, so an unordered
+    read would run long before the tail."""
+    cfg, C = stream_cfg(2), 16
+    d, e = pair(C)
+    feed(cfg, (d, e), 0, C, 0)
+    feed(cfg, (d, e), 4, C, 1)
+    assert pending(d) == 1
+    s1, s2 = torch.cuda.current_stream(), torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record(s1)
+    big = torch.randn(8192, 8192, device="cuda")
+    for _ in range(12):
+        big = (big @ big).clamp_(-1.0, 1.0)  # ~100 ms of work on stream 1 behind the event
+    s2.wait_event(ev)
+    with torch.cuda.stream(s2):
+        fd, wd, idd = d.feature_layer_view(0).get_all_blocks_split()
+        fe, we, ide = e.feature_layer_view(0).get_all_blocks_split()
+    assert pending(d) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(idd, ide) and torch.equal(wd, we) and torch.equal(fd.view(torch.int16), fe.view(torch.int16))
+    # mmf_flush on another stream orders that stream after the tail as well
+    feed(cfg, (d, e), 9, C, 2)
+    ev.record(s1)
+    for _ in range(12):
+        big = (big @ big).clamp_(-1.0, 1.0)
+    s2.wait_event(ev)
+    with torch.cuda.stream(s2):
+        d.flush()
+        wd2 = d.feature_layer_view(0).get_all_blocks_split()[1].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(wd2, e.feature_layer_view(0).get_all_blocks_split()[1])
+
+
 def test_switching_it_off_runs_what_is_pending():
     cfg, C = stream_cfg(2), 16
     d, e = pair(C)
