@@ -87,6 +87,12 @@ typedef struct {
   /* spec switches (items of the integrator that are code-level choices upstream; defaults = this spec, tests/pin_report.py flips them) */
   int32_t raycast_to_truncation;   /* 1 (default): blocks in view are marked up to depth + truncation; 0: up to the depth     */
   int32_t decay_appearance_layers; /* 0 (default): decay() leaves colour / feature weights alone; 1: multiplies them as well   */
+  /* the two places where the spec was arranged for the GPU, switchable so that a pin against CUDA nvblox
+   * can tell which form upstream has; defaults 0 = the arranged form */
+  int32_t raycast_walk_from_camera;  /* 1: a ray's block walk starts at the camera instead of where it enters the workspace bounds
+                                        (the same block sets by construction) */
+  int32_t appearance_blend_division; /* 1: A' = (A W + a w) / (W + w) per channel instead of one reciprocal per voxel; frames then take
+                                        the stand-alone appearance kernels (the fused / pipelined launches implement the default only) */
 } mmf_params;
 
 /* sizeof(mmf_params) as compiled into the library (binding self-check). */

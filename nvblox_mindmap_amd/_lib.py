@@ -53,6 +53,8 @@ class MmfParams(C.Structure):
         ("expansion_factor", C.c_float),
         ("raycast_to_truncation", C.c_int32),
         ("decay_appearance_layers", C.c_int32),
+        ("raycast_walk_from_camera", C.c_int32),
+        ("appearance_blend_division", C.c_int32),
     ]
 
 

@@ -1,21 +1,13 @@
-// mmf_api.hip -- host side of libmmfusion.so: the C ABI declared in include/mmfusion.h.
+// mmf_api.hip -- host side of libmmfusion.so: the C ABI declared in include/mmfusion.h (this file: handles, parameters, the
+// frame entry points, decay / flush / clear; see mmf_api_internal.h for the other translation units).
 // Owns the block pools / hash tables of every mapper and sequences the kernels of one frame on the
 // caller's HIP stream.  No device->host synchronisation on the per-frame path.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/mmfusion.h"
-#include "mmf_launch.h"
+#include "mmf_api_internal.h"
 
 using namespace mmf;
+using namespace mmf_host;
 
-namespace {
+namespace mmf_host {
 
 thread_local std::string g_err;
 
@@ -23,180 +15,6 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                                  \
-  do {                                                                                                 \
-    hipError_t e__ = (expr);                                                                           \
-    if (e__ != hipSuccess)                                                                             \
-      return fail(MMF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                   \
-  } while (0)
-
-#define MMF_TRY(expr)          \
-  do {                         \
-    int rc__ = (expr);         \
-    if (rc__ != MMF_OK) return rc__; \
-  } while (0)
-
-struct Layer {
-  LayerDev d{};
-  size_t block_bytes = 0;
-  bool has_w = false;
-  bool allocated = false;
-};
-
-struct Mapper {
-  mmf_params P{};
-  MapConsts mc{};
-  Layer tsdf, color, feat;
-  Scratch sc[3]{};  // compaction scratch of the three chains: 0 TSDF, 1 colour, 2 feature
-  int sc_cap[3] = {0, 0, 0};
-  uint8_t* mask_tmp = nullptr;  // bit-row scratch of the mask kernels
-  size_t mask_tmp_cap = 0;
-  size_t patch_cap = 0;
-  float* masked_depth = nullptr;
-  uint8_t* patch_flags = nullptr;  // [(H/16+1) * (W/16+1)] tagged like the grid flags: 16x16-pixel patches that hold a depth-mask pixel
-  int* hints = nullptr;  // pinned host ints the device publishes counts to: [0..2] candidates of sc[0..2], [3..5] live blocks  // depth with invalid / masked pixels zeroed (written by the mask row pass)
-  uint8_t* kill = nullptr;
-  int* any_kill = nullptr;
-  // Raycast flags of the view grid (sc[0].flags).  Stand-alone chains set a touched cell to 1 and their allocation clears the
-  // grid again (all-zero between calls).  k_alloc_tsdf frames have two readers of the flags in one launch, so nobody clears:
-  // the raycast writes the frame's tag (1 .. 255) and the readers compare for equality; the buffer is zeroed when the tag
-  // wraps and when a stand-alone chain follows (untag_grid).
-  bool grid_tagged = false;
-  int grid_tag = 0;
-  bool allow_merged = true;    // false: environment MMF_NO_ALLOC_TSDF=1 at creation -- keep allocation and TSDF pass as separate launches
-                               // (the reference point of the parity tests of k_alloc_tsdf)
-  u64* pub = nullptr;          // [16 + 3 * cap + 2 + kNewBlockWgs] new blocks published by the allocation workgroups of k_alloc_tsdf to
-                               // their own launch + the control words of the hand-over (AllocJob::pub)
-  unsigned pub_tag = 0;        // tag of the last k_alloc_tsdf launch (30 bits, incremented by those launches only; 0 is never used)
-  // scalable allocation / deallocation of large grids and pools (mmf_alloc_device.h: alloc_big_body, live_compact_big_body)
-  u64* lb_compact = nullptr;   // [cap / 1024 + 4] look-back words of the list compaction
-  size_t lb_compact_words = 0;
-  int* rebuild_flag = nullptr; // device int: the compaction's last chunk asks for a hash rebuild
-  unsigned lb_tag = 0;         // tag of the last scalable launch (22 bits; 0 is never used; every look-back buffer is zeroed on wrap)
-  int debug_abandon = 0;       // environment MMF_DEBUG_FORCE_ALLOC_TIMEOUT at creation (test hook of the hand-over's recovery)
-  long long* stats = nullptr;  // device [MMF_NUM_STATS]
-  long long frames[3] = {0, 0, 0};
-  // synthetic depth + cache key
-  float* synth = nullptr;
-  int synth_cap = 0, synth_W = 0, synth_H = 0;
-  long long synth_epoch = -1;
-  float synth_T[16]{}, synth_K[9]{};
-  int synth_iw = 0, synth_ih = 0;
-  long long tsdf_epoch = 0;
-  uint8_t* inv_mask = nullptr;  // scratch for an inverted input mask (stand-alone kernel path only)
-  size_t inv_mask_cap = 0;
-  long long* timeline = nullptr;  // 8 device int64: timestamps of the last TSDF allocation job (mmf_get_alloc_timeline)
-  FlatList flat;               // survivor list of a feature frame (balanced phase 2); rec == null: not in use
-  // Deferred row update (mmf_set_deferred_feature_rows): a fused frame leaves its last launch -- the rows of its survivor list --
-  // to the NEXT fused frame, which runs it as a role of its sphere-trace launch; whatever else touches the mapper first runs it
-  // as the stand-alone launch it would have been (get_mapper flushes).  Two lists: frame N's is read while frame N + 1's fills.
-  FlatList flat_other;
-  bool defer_rows = false;     // the caller keeps a frame's feature image valid and unchanged until the next call on this mapper
-  bool rows_pending = false;
-  AppArgs rows_args{};         // argument block of the pending row update (list, image, pool)
-  hipStream_t rows_stream = nullptr;
-  bool tail_pending = false;   // the frame's launch 4 (colour update + feature gating) is pending too: it fills rows_args' list
-  AppTail tail{};
-  bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
-  bool wmax_valid = true;      // (an empty map trivially) tsdf.d.wmax holds every live block's largest weight (set by a fused frame, cleared by whatever
-                               // else writes TSDF weights): a pending decay can then take the light path
-  // mesh
-  int* mesh_counts = nullptr;
-  int* mesh_offsets = nullptr;
-  int* mesh_out2 = nullptr;
-  int mesh_cap = 0, mesh_V = 0, mesh_nblocks = 0;
-  long long mesh_epoch = -1;
-  int* mesh_tcounts = nullptr;   // triangle counts / offsets per live block (mmf_update_mesh_topology)
-  int* mesh_toffsets = nullptr;
-  int* mesh_tout2 = nullptr;
-  int mesh_T = 0;
-  long long mesh_tepoch = -1;
-  // map -> model inputs (mmf_model_inputs_prepare / _gather)
-  int* mi_counts = nullptr;   // [cap] kept vertices per live block
-  int* mi_chunk = nullptr;    // [cap] start of the block's chunk in mi_list
-  int* mi_offsets = nullptr;  // [cap] prefix sums of mi_counts (only maps with more live blocks than the gather kernel scans in LDS)
-  int* mi_total = nullptr;    // device int[2]: kept rows, live blocks
-  uint4* mi_list = nullptr;   // {x, y, z, feature voxel} of every kept vertex
-  int mi_list_cap = 0, mi_n = 0, mi_nblocks = 0, mi_used = 0;
-  long long mi_epoch = -1, mi_feat_frames = -1;
-  // last view grid (diagnostics)
-  ViewGrid last_vg{};
-  int app_cap = 0;
-  bool touched = false;  // a depth frame was integrated since creation / clear
-};
-
-struct ProfRec {
-  hipEvent_t a, b;
-  int id;
-};
-
-}  // namespace
-
-struct mmf_mapper_s {
-  int device = 0;
-  std::vector<Mapper*> mappers;
-  int* pinned = nullptr;  // host pinned scratch (16 ints)
-  unsigned prof = 0;  // bitmask of kernel ids to time
-  std::vector<ProfRec> prof_recs;
-  std::vector<hipEvent_t> ev_pool;
-  unsigned prof_stride = 1;   // time every prof_stride-th eligible launch of a kernel class (mmf_profile_set_stride)
-  unsigned prof_seen[MMF_NUM_KERNEL_IDS] = {0};
-  double prof_ms[MMF_NUM_KERNEL_IDS] = {0};
-  long long prof_n[MMF_NUM_KERNEL_IDS] = {0};
-};
-
-namespace {
-
-struct ProfScope {
-  mmf_mapper_s* h;
-  hipStream_t s;
-  ProfRec r{};
-  bool on;
-  ProfScope(mmf_mapper_s* h_, int id, hipStream_t s_) : h(h_), s(s_), on(id >= 0 && ((h_->prof >> id) & 1u) != 0) {
-    if (on) on = (h->prof_seen[id]++ % h->prof_stride) == 0;
-    if (!on) return;
-    r.id = id;
-    r.a = take();
-    r.b = take();
-    (void)hipEventRecord(r.a, s);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(r.b, s);
-    h->prof_recs.push_back(r);
-  }
-  hipEvent_t take() {
-    if (!h->ev_pool.empty()) {
-      hipEvent_t e = h->ev_pool.back();
-      h->ev_pool.pop_back();
-      return e;
-    }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
-  }
-};
-
-// Timing of ONE kernel with the events of an extension launch (hipExtLaunchKernelGGL): the launcher receives a() / b().
-struct ProfExt {
-  mmf_mapper_s* h;
-  ProfRec r{};
-  bool on;
-  ProfExt(mmf_mapper_s* h_, int id) : h(h_), on(((h_->prof >> id) & 1u) != 0) {
-    if (on) on = (h->prof_seen[id]++ % h->prof_stride) == 0;
-    if (!on) return;
-    ProfScope tmp(h_, -1, nullptr);  // only for its event pool accessor
-    r.id = id;
-    r.a = tmp.take();
-    r.b = tmp.take();
-  }
-  ~ProfExt() {
-    if (on) h->prof_recs.push_back(r);
-  }
-  hipEvent_t a() const { return on ? r.a : nullptr; }
-  hipEvent_t b() const { return on ? r.b : nullptr; }
-};
 
 int prof_collect(mmf_mapper_s* h) {
   for (auto& r : h->prof_recs) {
@@ -276,6 +94,7 @@ void derive_consts(const mmf_params& P, MapConsts& mc) {
   mc.st_eps = P.st_surface_eps_vox * mc.v;
   mc.C = P.feature_channels;
   mc.reach = P.raycast_to_truncation ? mc.trunc : 0.0f;
+  mc.spec_flags = (P.raycast_walk_from_camera ? 1 : 0) | (P.appearance_blend_division ? 2 : 0);
 }
 
 int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
@@ -928,23 +747,14 @@ int depth_chain(mmf_handle h, Mapper& m, const float* depth, const uint8_t* mask
   return MMF_OK;
 }
 
-__global__ void k_unpack_keys(const mmf::u64* keys, int n, int32_t* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int x, y, z;
-  mmf::unpack_key(keys[i], x, y, z);
-  out[3 * i] = x;
-  out[3 * i + 1] = y;
-  out[3 * i + 2] = z;
-}
-
 int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MMF_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return MMF_OK;
 }
 
-}  // namespace
+}  // namespace mmf_host
+
 
 // =================================================================================================
 // C ABI
@@ -990,6 +800,8 @@ int mmf_default_params(mmf_params* p) {
   p->expansion_factor = 1.5f;
   p->raycast_to_truncation = 1;
   p->decay_appearance_layers = 0;
+  p->raycast_walk_from_camera = 0;
+  p->appearance_blend_division = 0;
   return MMF_OK;
 }
 
@@ -1179,7 +991,7 @@ static int add_feature_frame_impl(mmf_handle h, int mapper_id, const void* feat,
     launch_feature_integrate(m->feat.d, m->mc, cam, T_C_L, (const __half*)feat, mask, m->synth, m->synth_W, m->synth_H, m->sc[2],
                              m->feat.d.cap, m->stats, s, low, &m->flat);
   }
-  {
+  if (!(m->mc.spec_flags & 2)) {  // (appearance_blend_division: the gating workgroups updated the rows themselves)
     ProfExt pe(h, MMF_K_FEATURE_FLAT);
     launch_feature_flat(m->feat.d, m->mc, cam, (const __half*)feat, low, m->flat, m->stats, s, pe.a(), pe.b());
   }
@@ -1260,7 +1072,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   // big: a view grid / pool beyond the single-workgroup allocation roles (an unbounded workspace, a very large box): the same
   // fused frame with the scalable allocation and list compaction as launches of their own (mmf_alloc_device.h)
   const bool big = packed && ncells > 0 && big_mode(*m, ncells) && alloc_big_supported(m->color.d) && alloc_big_supported(m->feat.d);
-  const bool fusable = packed && ncells > 0 && (alloc_jobs_fusable(ncells, m->tsdf.d.cap) || big);
+  // (spec switch appearance_blend_division: only the stand-alone appearance kernels are built with the per-channel division)
+  const bool fusable = packed && ncells > 0 && (alloc_jobs_fusable(ncells, m->tsdf.d.cap) || big) && !(m->mc.spec_flags & 2);
   if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
   if (fusable) M.invert = invert_mask ? 1 : 0;
   if (!fusable && invert_mask) {  // stand-alone kernels take the mask as it is: invert it once into scratch
@@ -1298,7 +1111,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       launch_feature_integrate(m->feat.d, m->mc, fcam, T_C_L, (const __half*)feat, feature_mask_out, m->synth, m->synth_W,
                                m->synth_H, m->sc[2], m->feat.d.cap, m->stats, s, low, &m->flat);
     }
-    {
+    if (!(m->mc.spec_flags & 2)) {
       ProfScope ps(h, MMF_K_FEATURE_FLAT, s);
       launch_feature_flat(m->feat.d, m->mc, fcam, (const __half*)feat, low, m->flat, m->stats, s);
     }
@@ -1545,7 +1358,7 @@ static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGr
   if (ncells <= 0 || !alloc_jobs_fusable(ncells, m.tsdf.d.cap) || ncells > m.sc_cap[0] || m.tsdf.d.cap > m.sc_cap[1] ||
       m.tsdf.d.cap > m.sc_cap[2])
     return false;
-  if (!m.allow_merged || !m.tsdf.d.dense) return false;
+  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & 2)) return false;
   if (m.pending_decay && !m.wmax_valid) return false;  // that decay needs its voxel pass: separate launches
   const int sf = m.mc.st_sf;
   if (in.W / sf <= 0 || in.H / sf <= 0 || (in.W / sf) * (in.H / sf) > m.synth_cap) return false;
@@ -1975,852 +1788,6 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     for (int q = 0; q < 8; ++q) m->hints[q] = 0;
   }
   return check_launch();
-}
-
-int mmf_update_feature_mesh(mmf_handle h, int mapper_id, void* stream, int* num_vertices) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (!num_vertices) return fail(MMF_ERR_INVALID_ARG, "null num_vertices");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  {
-    ProfScope ps(h, MMF_K_MESH, s);
-    launch_mesh_count(m->tsdf.d, m->mc, m->mesh_counts, m->mesh_offsets, m->mesh_out2, s);
-  }
-  HIP_TRY(hipMemcpyAsync(h->pinned, m->mesh_out2, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->pinned + 11, m->tsdf.d.ctr + 3, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  m->mesh_V = h->pinned[0];
-  m->mesh_nblocks = h->pinned[1];
-  m->mesh_epoch = m->tsdf_epoch;
-  *num_vertices = m->mesh_V;
-  {  // a natural synchronisation point: asynchronous device errors (hand-over failure, pool exhaustion) surface here, once
-    const int bits = h->pinned[11] & 2;  // (exhaustion keeps its own reporting point: mmf_num_allocated_blocks)
-    MMF_TRY(report_device_errors(h, *m, &m->tsdf, &bits, s));
-  }
-  return check_launch();
-}
-
-int mmf_get_feature_mesh(mmf_handle h, int mapper_id, float* verts, void* vfeat, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (m->mesh_epoch != m->tsdf_epoch)
-    return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_update_feature_mesh; call it again");
-  if (m->mesh_V == 0) return MMF_OK;
-  if (!verts || !vfeat) return fail(MMF_ERR_INVALID_ARG, "null output buffer");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  LayerDev F = m->feat.allocated ? m->feat.d : LayerDev{};
-  {
-    ProfScope ps(h, MMF_K_MESH, s);
-    launch_mesh_emit(m->tsdf.d, F, m->mc, m->mesh_offsets, m->mesh_nblocks, verts, (__half*)vfeat, m->mesh_V, s);
-  }
-  return check_launch();
-}
-
-int mmf_model_inputs_prepare(mmf_handle h, int mapper_id, const float* lo, const float* hi, int used, int remove_zero, void* stream,
-                             int* num_kept) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (!lo || !hi || !num_kept) return fail(MMF_ERR_INVALID_ARG, "null argument");
-  if (used < 1 || used > m->mc.C) return fail(MMF_ERR_INVALID_ARG, "used_channels must be in 1 .. feature_channels");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  if (!m->mi_counts) {
-    HIP_TRY(hipMalloc(&m->mi_counts, sizeof(int) * (size_t)m->mesh_cap));
-    HIP_TRY(hipMalloc(&m->mi_chunk, sizeof(int) * (size_t)m->mesh_cap));
-    HIP_TRY(hipMalloc(&m->mi_offsets, sizeof(int) * ((size_t)m->mesh_cap + 2)));
-    HIP_TRY(hipMalloc(&m->mi_total, sizeof(int) * 2));
-    m->mi_list_cap = 1 << 16;
-    HIP_TRY(hipMalloc(&m->mi_list, sizeof(uint4) * (size_t)m->mi_list_cap));
-  }
-  LayerDev F = m->feat.allocated ? m->feat.d : LayerDev{};
-  for (int attempt = 0;; ++attempt) {
-    HIP_TRY(hipMemsetAsync(m->mi_total, 0, sizeof(int), s));
-    {
-      ProfScope ps(h, MMF_K_MESH, s);
-      launch_mesh_keep(m->tsdf.d, F, m->mc, lo, hi, used, remove_zero ? 1 : 0, m->mi_counts, m->mi_chunk, m->mi_total, m->mi_list,
-                       m->mi_list_cap, s);
-    }
-    HIP_TRY(hipMemcpyAsync(h->pinned, m->mi_total, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->pinned + 11, m->tsdf.d.ctr + 3, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    m->mi_n = h->pinned[0];
-    m->mi_nblocks = h->pinned[1];
-    if (m->mi_n <= m->mi_list_cap) break;
-    if (attempt) return fail(MMF_ERR_BAD_STATE, "model inputs: vertex list overflow after growing it");
-    // more kept vertices than the list holds (they were counted, not stored): grow and run the pass again
-    (void)hipFree(m->mi_list);
-    m->mi_list = nullptr;
-    size_t cap = (size_t)m->mi_list_cap;
-    while (cap < (size_t)m->mi_n + (size_t)m->mi_n / 2) cap *= 2;
-    if (cap > ((size_t)1 << 30)) return fail(MMF_ERR_INVALID_ARG, "model inputs: too many vertices");
-    HIP_TRY(hipMalloc(&m->mi_list, sizeof(uint4) * cap));
-    m->mi_list_cap = (int)cap;
-  }
-  if (m->mi_nblocks > model_inputs_lds_blocks())  // maps with more live blocks than the gather kernel scans in LDS
-    launch_mesh_scan_counts(m->tsdf.d, m->mi_counts, m->mi_offsets, m->mi_offsets + m->mesh_cap, s);
-  m->mi_epoch = m->tsdf_epoch;
-  m->mi_feat_frames = m->frames[2];
-  m->mi_used = used;
-  *num_kept = m->mi_n;
-  {
-    const int bits = h->pinned[11] & 2;
-    MMF_TRY(report_device_errors(h, *m, &m->tsdf, &bits, s));
-  }
-  return check_launch();
-}
-
-int mmf_model_inputs_gather(mmf_handle h, int mapper_id, const int64_t* rows, int n_take, int n_out, float* verts, void* feats,
-                            int features_f32, uint8_t* valid, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  if (m->mi_epoch != m->tsdf_epoch || m->mi_feat_frames != m->frames[2] || m->pending_decay)
-    return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_model_inputs_prepare; call it again");
-  if (n_take < 0 || n_out < n_take) return fail(MMF_ERR_INVALID_ARG, "need 0 <= n_take <= n_out");
-  if (!rows && n_take > m->mi_n) return fail(MMF_ERR_INVALID_ARG, "n_take exceeds the kept rows");
-  if (n_take > 0 && m->mi_n == 0) return fail(MMF_ERR_INVALID_ARG, "no kept rows to take from");
-  if (n_out == 0) return MMF_OK;
-  if (!verts) return fail(MMF_ERR_INVALID_ARG, "null vertex buffer");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  LayerDev F = m->feat.allocated ? m->feat.d : LayerDev{};
-  {
-    ProfScope ps(h, MMF_K_MESH, s);
-    launch_model_inputs_gather(m->mi_counts, m->mi_chunk, m->mi_offsets, m->mi_nblocks, m->mi_list, F, m->mc.C, m->mi_used,
-                               (const long long*)rows, n_take, n_out, verts, feats, features_f32 != 0, valid, s);
-  }
-  return check_launch();
-}
-
-int mmf_update_mesh_topology(mmf_handle h, int mapper_id, void* stream, int* num_vertices, int* num_triangles) {
-  if (!num_vertices || !num_triangles) return fail(MMF_ERR_INVALID_ARG, "null output");
-  MMF_TRY(mmf_update_feature_mesh(h, mapper_id, stream, num_vertices));  // vertex counts / offsets (flushes a pending decay)
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  hipStream_t s = (hipStream_t)stream;
-  {
-    ProfScope ps(h, MMF_K_MESH, s);
-    launch_mesh_tri_count(m->tsdf.d, m->mc, m->mesh_tcounts, m->mesh_toffsets, m->mesh_tout2, s);
-  }
-  HIP_TRY(hipMemcpyAsync(h->pinned, m->mesh_tout2, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  m->mesh_T = h->pinned[0];
-  m->mesh_tepoch = m->tsdf_epoch;
-  *num_triangles = m->mesh_T;
-  return check_launch();
-}
-
-int mmf_get_mesh_topology(mmf_handle h, int mapper_id, int32_t* triangles, uint8_t* vertex_colors, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (m->mesh_tepoch != m->tsdf_epoch || m->mesh_epoch != m->tsdf_epoch)
-    return fail(MMF_ERR_BAD_STATE, "the map changed since mmf_update_mesh_topology; call it again");
-  if (m->mesh_V == 0) return MMF_OK;
-  if (!triangles && m->mesh_T > 0) return fail(MMF_ERR_INVALID_ARG, "null triangle buffer");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  LayerDev Cl = m->color.allocated ? m->color.d : LayerDev{};
-  {
-    ProfScope ps(h, MMF_K_MESH, s);
-    launch_mesh_tri_emit(m->tsdf.d, Cl, m->mc, m->mesh_offsets, m->mesh_toffsets, m->mesh_nblocks, triangles, vertex_colors,
-                         m->mesh_V, m->mesh_T, s);
-  }
-  return check_launch();
-}
-
-static Layer* pick_layer(Mapper* m, int layer) {
-  return layer == MMF_LAYER_TSDF ? &m->tsdf : (layer == MMF_LAYER_COLOR ? &m->color : (layer == MMF_LAYER_FEATURE ? &m->feat : nullptr));
-}
-
-int mmf_num_allocated_blocks(mmf_handle h, int mapper_id, int layer, void* stream, int* out) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  Layer* L = pick_layer(m, layer);
-  if (!L || !out) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
-  if (!L->allocated) {
-    *out = 0;
-    return MMF_OK;
-  }
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(h->pinned + 8, L->d.ctr, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  *out = h->pinned[8];
-  return report_device_errors(h, *m, L, &h->pinned[11], s);
-}
-
-int mmf_get_block_indices(mmf_handle h, int mapper_id, int layer, int32_t* out, int n, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  Layer* L = pick_layer(m, layer);
-  if (!L) return fail(MMF_ERR_INVALID_ARG, "bad layer");
-  if (n <= 0 || !L->allocated) return MMF_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  launch_get_indices(L->d, out, n, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_get_tsdf_blocks(mmf_handle h, int mapper_id, float* out, int n, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (n <= 0) return MMF_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  launch_gather_pool(m->tsdf.d, m->tsdf.block_bytes, out, n, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_get_feature_blocks(mmf_handle h, int mapper_id, void* feats, float* weights, int n, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (n <= 0 || !m->feat.allocated) return MMF_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  launch_gather_pool(m->feat.d, m->feat.block_bytes, feats, n, (hipStream_t)stream);
-  launch_gather_poolw(m->feat.d, weights, n, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_get_color_blocks(mmf_handle h, int mapper_id, uint8_t* rgb, float* weights, int n, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (n <= 0 || !m->color.allocated) return MMF_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  launch_gather_color(m->color.d, rgb, weights, n, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx, const void* payload, const float* weights, int n,
-                      void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  if (n < 0 || (n > 0 && (!idx || !payload))) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_import_blocks");
-  if (layer < MMF_LAYER_TSDF || layer > MMF_LAYER_FEATURE) return fail(MMF_ERR_INVALID_ARG, "bad layer id");
-  if (layer != MMF_LAYER_TSDF && n > 0 && !weights) return fail(MMF_ERR_INVALID_ARG, "appearance layers need the weight plane");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  if (layer == MMF_LAYER_COLOR) MMF_TRY(ensure_app_layer(*m, m->color, sizeof(uint2) * kVPB, false));
-  if (layer == MMF_LAYER_FEATURE)
-    MMF_TRY(ensure_app_layer(*m, m->feat, sizeof(__half) * kVPB * (size_t)m->P.feature_channels, true));
-  Layer& L = layer == MMF_LAYER_TSDF ? m->tsdf : layer == MMF_LAYER_COLOR ? m->color : m->feat;
-  if (n > L.d.cap)
-    return fail(MMF_ERR_POOL_EXHAUSTED, "saved layer has " + std::to_string(n) + " blocks, the pool holds " + std::to_string(L.d.cap));
-  if (layer == MMF_LAYER_TSDF) m->pending_decay = false;  // the content it would have decayed is replaced
-  if (layer == MMF_LAYER_TSDF) m->wmax_valid = false;  // imported weights: wmax is rebuilt by the next fused frame
-  launch_layer_reset(L.d, s);
-  launch_import_index(L.d, idx, n, s);
-  if (n > 0) {
-    if (layer == MMF_LAYER_COLOR) {
-      launch_import_color(L.d, (const uint8_t*)payload, weights, n, s);
-    } else {
-      HIP_TRY(hipMemcpyAsync(L.d.pool, payload, L.block_bytes * (size_t)n, hipMemcpyDeviceToDevice, s));
-      if (layer == MMF_LAYER_FEATURE)
-        HIP_TRY(hipMemcpyAsync(L.d.poolw, weights, sizeof(float) * kVPB * (size_t)n, hipMemcpyDeviceToDevice, s));
-    }
-    if (layer == MMF_LAYER_TSDF) launch_block_free_all(L.d, m->mc, n, s);
-  }
-  if (layer == MMF_LAYER_TSDF) {
-    m->touched = m->touched || n > 0;
-    m->tsdf_epoch++;
-    m->mesh_epoch = -1;
-    m->mi_epoch = -1;
-  }
-  // out-of-range indices are flagged on the device; report them now (loading is not a hot path)
-  HIP_TRY(hipStreamSynchronize(s));
-  int err = 0;
-  HIP_TRY(hipMemcpy(&err, L.d.ctr + 3, sizeof(int), hipMemcpyDeviceToHost));
-  if (err & 2) return fail(MMF_ERR_INVALID_ARG, "saved block indices lie outside this mapper's workspace bounds / key range");
-  return check_launch();
-}
-
-int mmf_query_layer(mmf_handle h, int mapper_id, int layer, const float* pts, int n, float* out, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  if (n <= 0) return MMF_OK;
-  if (!pts || !out) return fail(MMF_ERR_INVALID_ARG, "null buffer");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  if (layer == MMF_LAYER_TSDF) {
-    launch_query_tsdf(m->tsdf.d, m->mc, pts, n, out, s);
-  } else if (layer == MMF_LAYER_FEATURE) {
-    if (!m->feat.allocated) {
-      HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * (m->mc.C + 1), s));
-      return MMF_OK;
-    }
-    launch_query_feature(m->feat.d, m->mc, pts, n, out, s);
-  } else {
-    return fail(MMF_ERR_INVALID_ARG, "query_layer supports the TSDF and feature layers");
-  }
-  return check_launch();
-}
-
-// ---- image-side ops -----------------------------------------------------------------------------
-int mmf_backproject_depth(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, void* stream) {
-  if (!depth || !K || !T || !out || B < 0 || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_backproject_depth");
-  launch_backproject(depth, K, T, B, H, W, out, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_sample_inputs_scratch_floats(void) { return sample_inputs_scratch_floats(); }
-
-int mmf_sample_frame_inputs(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_hwc_out, float* small_out,
-                            float* scratch, void* stream) {
-  if (!rgb_chw || !pose7 || !K9 || !rgb_hwc_out || !small_out || !scratch || H <= 0 || W <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_sample_frame_inputs");
-  launch_sample_inputs(rgb_chw, H, W, pose7, K9, rgb_hwc_out, small_out, scratch, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_erode_mask(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int iterations, void* stream) {
-  if (!mask || !out || !tmp || H <= 0 || W <= 0 || iterations < 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_erode_mask");
-  launch_erode(mask, out, tmp, H, W, iterations, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_depth_m, int k_in, int k_depth,
-                     int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, void* stream) {
-  if (!input_mask || !depth || !out || !tmp || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || k_in < 0 || k_depth < 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_feature_mask");
-  launch_feature_mask(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, out, tmp, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_frame_masks(const uint8_t* input_mask, const float* depth, int H, int W, float min_depth_m, int k_in, int k_depth,
-                    int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
-                    void* stream) {
-  if (!input_mask || !depth || !feature_mask_out || !tmp || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || k_in < 0 || k_depth < 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_frame_masks");
-  launch_frame_masks(input_mask, depth, H, W, min_depth_m, k_in, k_depth, border_percent, Hf, Wf, depth_mask_out, feature_mask_out,
-                     tmp, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_depth_m, uint8_t* out, void* stream) {
-  if (!depth || !out || H <= 0 || W <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_depth_mask");
-  launch_depth_mask(input_mask, depth, H, W, min_depth_m, out, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_upsample_features(const float* lowres, int hh, int ww, int Cin, void* out, int Hf, int Wf, int Cpad, void* stream) {
-  if (!lowres || !out || hh <= 0 || ww <= 0 || Cin <= 0 || Hf <= 0 || Wf <= 0 || Cpad < Cin || Cpad % 8 != 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_upsample_features (Cpad must be a multiple of 8 and >= Cin)");
-  launch_upsample_features(lowres, hh, ww, Cin, (__half*)out, Hf, Wf, Cpad, (hipStream_t)stream);
-  return check_launch();
-}
-
-static int fps_entry(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* workspace, size_t workspace_bytes,
-                     void* stream) {
-  if (!x || !out_idx || B <= 0 || N <= 0 || C <= 0 || npoints <= 0 || npoints > N || start_idx < 0 || start_idx >= N)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_farthest_point_sampling");
-  const int rc = launch_fps(x, B, N, C, npoints, start_idx, reinterpret_cast<long long*>(out_idx), (hipStream_t)stream, workspace, workspace_bytes);
-  if (rc == 1) return fail(MMF_ERR_INVALID_ARG, "mmf_farthest_point_sampling supports N <= 8192 and C <= 1024");
-  if (rc != 0) return fail(MMF_ERR_HIP, "mmf_farthest_point_sampling: HIP runtime call failed (or the workspace is too small)");
-  return check_launch();
-}
-
-int mmf_farthest_point_sampling(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* stream) {
-  return fps_entry(x, B, N, C, npoints, start_idx, out_idx, nullptr, 0, stream);
-}
-
-int64_t mmf_fps_workspace_bytes(int B, int N, int C) { return (B <= 0 || N <= 0 || C <= 0) ? 0 : (int64_t)fps_workspace_bytes(B, N, C); }
-
-int mmf_farthest_point_sampling_ws(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
-  if (!workspace || workspace_bytes < mmf_fps_workspace_bytes(B, N, C))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_farthest_point_sampling_ws: workspace smaller than mmf_fps_workspace_bytes(B, N, C)");
-  return fps_entry(x, B, N, C, npoints, start_idx, out_idx, workspace, (size_t)workspace_bytes, stream);
-}
-
-// ---- inference-side fused ops of the diffusion head ------------------------------------------------------------------
-int mmf_rotary_apply(const float* x, long long x_row_stride, const float* cos_, const float* sin_, float* out, long long rows, int D,
-                     void* stream) {
-  if (!x || !cos_ || !sin_ || !out || rows < 0 || D <= 0 || (D & 1) || x_row_stride < D)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_rotary_apply");
-  launch_rotary_apply(x, x_row_stride, cos_, sin_, out, rows, D, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_adaln_modulate(const float* x, const float* scale_shift, float* out, int B, int L, int D, void* stream) {
-  if (!x || !scale_shift || !out || B <= 0 || L <= 0 || D <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_adaln_modulate");
-  launch_adaln_modulate(x, scale_shift, out, B, L, D, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_qkv_block(const float* x, const float* scale_shift, const float* Wq, const float* bq, const float* Wkv, const float* bkv,
-                  const float* cos_, const float* sin_, float* q_out, float* k_out, float* v_out, int B, int L, int D, void* stream) {
-  if (!x || !Wq || !bq || !Wkv || !bkv || !q_out || !k_out || !v_out || B <= 0 || L <= 0 || ((cos_ == nullptr) != (sin_ == nullptr)))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_qkv_block");
-  if (launch_qkv_block(x, scale_shift, Wq, bq, Wkv, bkv, cos_, sin_, q_out, k_out, v_out, B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_block is built for D = 120");
-  return check_launch();
-}
-
-int mmf_out_ffn_block(const float* att, const float* residual, const float* Wo, const float* bo, const float* ln1_weight,
-                      const float* ln1_bias, float ln1_eps, const float* scale_shift, const float* W1, const float* b1, const float* W2,
-                      const float* b2, const float* ln2_weight, const float* ln2_bias, float ln2_eps, float* out, int B, int L, int D,
-                      void* stream) {
-  if (!att || !residual || !Wo || !bo || !ln1_weight || !ln1_bias || !W1 || !b1 || !W2 || !b2 || !ln2_weight || !ln2_bias || !out || B <= 0 ||
-      L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_block");
-  if (launch_out_ffn_block(att, residual, Wo, bo, ln1_weight, ln1_bias, ln1_eps, scale_shift, W1, b1, W2, b2, ln2_weight, ln2_bias, ln2_eps, out,
-                           B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_block is built for D = 120");
-  return check_launch();
-}
-
-int mmf_qkv_heads(const float* x, const float* scale_shift, const float* Wq, const float* bq, const float* Wkv, const float* bkv,
-                  const float* cos_, const float* sin_, float* q_heads, float* k_heads, float* v_heads_t, int B, int L, int D, int H, int roles,
-                  void* stream) {
-  const bool need_q = (roles & 1) != 0, need_kv = (roles & 6) != 0;
-  if (!x || B <= 0 || L <= 0 || (roles != 7 && roles != 1 && roles != 6) || (need_q && (!Wq || !bq || !q_heads)) ||
-      (need_kv && (!Wkv || !bkv || !k_heads || !v_heads_t)) || ((cos_ == nullptr) != (sin_ == nullptr)))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_qkv_heads");
-  if (launch_qkv_heads(x, scale_shift, Wq, bq, Wkv, bkv, cos_, sin_, q_heads, k_heads, v_heads_t, B, L, D, H, roles, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_heads is built for D = 120, H = 8");
-  return check_launch();
-}
-
-int mmf_attention_heads(const float* q_heads, const float* k_heads, const float* v_heads_t, const uint8_t* key_padding, float* out, int B,
-                        int Lq, int Lk, int H, int head_dim, void* stream) {
-  if (!q_heads || !k_heads || !v_heads_t || !out || B <= 0 || Lq <= 0 || Lk <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_heads");
-  if (launch_attention_heads(q_heads, k_heads, v_heads_t, key_padding, out, B, Lq, Lk, H, head_dim, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_attention_heads is built for H = 8, head_dim = 15");
-  return check_launch();
-}
-
-int mmf_out_ffn_mfma(const float* att, const float* residual, const float* Wo, const float* bo, const float* ln1_weight,
-                     const float* ln1_bias, float ln1_eps, const float* scale_shift, const float* W1, const float* b1, const float* W2,
-                     const float* b2, const float* ln2_weight, const float* ln2_bias, float ln2_eps, float* out, int B, int L, int D,
-                     void* stream) {
-  if (!att || !residual || !Wo || !bo || !ln1_weight || !ln1_bias || !W1 || !b1 || !W2 || !b2 || !ln2_weight || !ln2_bias || !out || B <= 0 ||
-      L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_mfma");
-  if (launch_out_ffn_mfma(att, residual, Wo, bo, ln1_weight, ln1_bias, ln1_eps, scale_shift, W1, b1, W2, b2, ln2_weight, ln2_bias, ln2_eps, out,
-                          B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma is built for D = 120");
-  return check_launch();
-}
-
-int mmf_step_prologue(const float* trajectory, int B, int num_tokens, const float* traj_encoder_wt, const float* traj_encoder_bias,
-                      const float* position_table, const float* time_embedding, const float* history, const float* rotary_freq,
-                      const float* adaln_wt, const float* adaln_bias, int adaln_width, float* tokens_out, float* adaln_out, float* cos_out,
-                      float* sin_out, long long rotary_batch_stride, int D, void* stream) {
-  const bool ada = adaln_width > 0;  // adaln_width 0: tokens and rotary codes only
-  if (!trajectory || !traj_encoder_wt || !traj_encoder_bias || !position_table || !rotary_freq || !tokens_out || !cos_out || !sin_out ||
-      B <= 0 || num_tokens <= 0 || adaln_width < 0 || (ada && (!time_embedding || !history || !adaln_wt || !adaln_bias || !adaln_out)))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_step_prologue");
-  if (D != 120) return fail(MMF_ERR_INVALID_ARG, "mmf_step_prologue is built for D = 120");
-  launch_step_prologue(trajectory, B, num_tokens, traj_encoder_wt, traj_encoder_bias, position_table, time_embedding, history, rotary_freq,
-                       adaln_wt, adaln_bias, adaln_width, tokens_out, adaln_out, cos_out, sin_out, rotary_batch_stride, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_head_outputs(const float* rotation_seq, const float* position_seq, long long seq_batch_stride, int B, int L, int G,
-                     const float* const* weights20, float* pred_out, float* head_yaw_out, int D, void* stream) {
-  if (!rotation_seq || !position_seq || !weights20 || !pred_out || B <= 0 || L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_head_outputs");
-  for (int i = 0; i < 16; ++i)
-    if (!weights20[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_head_outputs: missing weight");
-  if (weights20[16] && (!weights20[17] || !weights20[18] || !weights20[19] || !head_yaw_out))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_head_outputs: incomplete head-yaw arguments");
-  if (D != 120 || launch_head_outputs(rotation_seq, position_seq, seq_batch_stride, B, L, G, weights20, pred_out, head_yaw_out,
-                                      (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_head_outputs is built for D = 120 and at most 4 grippers");
-  return check_launch();
-}
-
-int mmf_step_tail(const float* rotation_seq, const float* position_seq, long long seq_batch_stride, int B, int L, int G,
-                  const float* const* weights20, float* pred_out, float* head_yaw_out, const float* trajectory, const float* noise,
-                  const float* coef_pos6, const float* coef_rot6, float* trajectory_out, const float* traj_encoder_wt,
-                  const float* traj_encoder_bias, const float* position_table, const float* rotary_freq, float* tokens_out, float* cos_out,
-                  float* sin_out, long long rotary_batch_stride, int D, void* stream) {
-  if (!rotation_seq || !position_seq || !weights20 || !pred_out || !trajectory || !noise || !coef_pos6 || !coef_rot6 || !trajectory_out ||
-      B <= 0 || L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_step_tail");
-  if (tokens_out && (!traj_encoder_wt || !traj_encoder_bias || !position_table || !rotary_freq || !cos_out || !sin_out))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail: incomplete next-step arguments");
-  for (int i = 0; i < 16; ++i)
-    if (!weights20[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail: missing weight");
-  if (weights20[16] && (!weights20[17] || !weights20[18] || !weights20[19] || !head_yaw_out))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail: incomplete head-yaw arguments");
-  if (D != 120 || launch_step_tail(rotation_seq, position_seq, seq_batch_stride, B, L, G, weights20, pred_out, head_yaw_out, trajectory, noise,
-                                   coef_pos6, coef_rot6, trajectory_out, traj_encoder_wt, traj_encoder_bias, position_table, rotary_freq,
-                                   tokens_out, cos_out, sin_out, rotary_batch_stride, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_step_tail is built for D = 120 and at most 4 grippers");
-  return check_launch();
-}
-
-int mmf_out_ffn_qkv(const float* const* layer13, float ln1_eps, float ln2_eps, float* out, const float* const* next7, float* q_heads,
-                    float* k_heads, float* v_heads_t, int B, int L, int D, int H, int roles, const float* att_partials, int n_split,
-                    void* stream) {
-  const bool need_q = (roles & 1) != 0, need_kv = (roles & 6) != 0;
-  if (!layer13 || !next7 || !out || B <= 0 || L <= 0 || (roles != 7 && roles != 1) || (need_q && !q_heads) ||
-      (need_kv && (!k_heads || !v_heads_t)) || (att_partials && n_split < 1))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_qkv");
-  for (int i = att_partials ? 1 : 0; i < 13; ++i)
-    if (i != 6 && !layer13[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv: missing layer operand");  // [6] = scale_shift, optional
-  if (!next7[1] || !next7[2] || (need_kv && (!next7[3] || !next7[4])) || ((next7[5] == nullptr) != (next7[6] == nullptr)))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv: missing next-layer operand");
-  if (launch_out_ffn_qkv(layer13, ln1_eps, ln2_eps, out, next7, q_heads, k_heads, v_heads_t, B, L, D, H, roles, att_partials, n_split,
-                         (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv is built for D = 120, H = 8 (and L <= 16 with partials)");
-  return check_launch();
-}
-
-int mmf_debug_wg_trace(uint64_t* buffer_dev, int capacity_records) {
-  // buffer: {id, start, end} triples in 100 MHz ticks at slot (id / 10 - 1) * 8192 + workgroup index (zero it before the frame of
-  // interest); null switches the trace off.  Synchronises the device (symbol copies).
-  if (buffer_dev && capacity_records <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_debug_wg_trace");
-  const int r0 = set_wg_trace_map(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
-  const int r1 = set_wg_trace_app(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
-  int r2 = set_wg_trace_policy(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
-  if (r2 == 0) r2 = set_wg_trace_policy_layer(reinterpret_cast<unsigned long long*>(buffer_dev), capacity_records);
-  if (r0 == 2 || r1 == 2 || r2 == 2) return fail(MMF_ERR_INVALID_ARG, "mmf_debug_wg_trace: this library was built without the hooks (make WG_TRACE=1)");
-  if (r0 != 0 || r1 != 0 || r2 != 0) return fail(MMF_ERR_HIP, "mmf_debug_wg_trace: hipMemcpyToSymbol failed");
-  return MMF_OK;
-}
-
-int mmf_qkv_heads2(const float* x0, const float* x1, const float* const* next14, float* q_heads, float* k_heads, float* v_heads_t, int B,
-                   int L, int D, int H, void* stream) {
-  if (!x0 || !x1 || !next14 || !q_heads || !k_heads || !v_heads_t || B <= 0 || L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_qkv_heads2");
-  for (int st = 0; st < 2; ++st) {
-    const float* const* q = next14 + 7 * st;
-    if (!q[1] || !q[2] || !q[3] || !q[4] || ((q[5] == nullptr) != (q[6] == nullptr)))
-      return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_heads2: missing operand");
-  }
-  if (launch_qkv_heads2(x0, x1, next14, q_heads, k_heads, v_heads_t, B, L, D, H, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_qkv_heads2 is built for D = 120, H = 8");
-  return check_launch();
-}
-
-int mmf_out_ffn_mfma2(const float* const* layer26, const float* eps4, float* out, int B, int L, int D, void* stream) {
-  if (!layer26 || !eps4 || !out || B <= 0 || L <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_mfma2");
-  for (int i = 0; i < 26; ++i)
-    if (i % 13 != 6 && !layer26[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma2: missing operand");  // [6]: scale_shift, optional
-  if (launch_out_ffn_mfma2(layer26, eps4, out, B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma2 is built for D = 120");
-  return check_launch();
-}
-
-int mmf_out_ffn_qkv2(const float* const* layer26, const float* eps4, float* out, const float* const* next14, float* q_heads, float* k_heads,
-                     float* v_heads_t, int B, int L, int D, int H, void* stream) {
-  if (!layer26 || !eps4 || !out || !next14 || !q_heads || !k_heads || !v_heads_t || B <= 0 || L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_qkv2");
-  for (int i = 0; i < 26; ++i)
-    if (i % 13 != 6 && !layer26[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv2: missing layer operand");  // [6]: scale_shift, optional
-  for (int st = 0; st < 2; ++st) {
-    const float* const* q = next14 + 7 * st;
-    if (!q[1] || !q[2] || !q[3] || !q[4] || ((q[5] == nullptr) != (q[6] == nullptr)))
-      return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv2: missing next-layer operand");
-  }
-  if (launch_out_ffn_qkv2(layer26, eps4, out, next14, q_heads, k_heads, v_heads_t, B, L, D, H, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_qkv2 is built for D = 120, H = 8");
-  return check_launch();
-}
-
-int mmf_cross_layer(const float* const* layer13, float ln1_eps, float ln2_eps, float* out, const float* const* next7, float* q_heads_next,
-                    const float* const* qkv3, const uint8_t* key_padding16, uint64_t* handover, uint32_t tag, int B, int Lq, int Lk, int D,
-                    int H, void* stream) {
-  if (!layer13 || !out || !qkv3 || !qkv3[0] || !qkv3[1] || !qkv3[2] || !handover || tag == 0 || B <= 0 || Lq <= 0 || Lk <= 0 ||
-      (next7 && !q_heads_next))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_cross_layer");
-  for (int i = 1; i < 13; ++i)
-    if (i != 6 && !layer13[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_cross_layer: missing layer operand");  // [0] unused, [6] = scale_shift, optional
-  if (next7 && (!next7[1] || !next7[2] || ((next7[5] == nullptr) != (next7[6] == nullptr))))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_cross_layer: missing next-layer operand");
-  const size_t words = (size_t)B * H * 4 * 18 * 16;
-  if (launch_cross_layer(layer13, ln1_eps, ln2_eps, out, next7, q_heads_next, qkv3, key_padding16, reinterpret_cast<unsigned long long*>(handover), tag,
-                         reinterpret_cast<int*>(handover + words), B, Lq, Lk, D, H, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_cross_layer is built for D = 120, H = 8, Lq <= 16");
-  return check_launch();
-}
-
-int mmf_self_layer(const float* const* layer13, float ln1_eps, float ln2_eps, float* out, const float* const* next7, float* q_heads_next,
-                   float* k_heads_next, float* v_heads_t_next, const float* const* qkv3, const uint8_t* key_padding16, uint64_t* handover,
-                   uint32_t tag, int B, int L, int D, int H, void* stream) {
-  if (!layer13 || !out || !qkv3 || !qkv3[0] || !qkv3[1] || !qkv3[2] || !handover || tag == 0 || B <= 0 || L <= 0 ||
-      (next7 && (!q_heads_next || !k_heads_next || !v_heads_t_next)))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_self_layer");
-  for (int i = 1; i < 13; ++i)
-    if (i != 6 && !layer13[i]) return fail(MMF_ERR_INVALID_ARG, "mmf_self_layer: missing layer operand");  // [0] unused, [6] = scale_shift, optional
-  if (next7 && (!next7[1] || !next7[2] || !next7[3] || !next7[4] || ((next7[5] == nullptr) != (next7[6] == nullptr))))
-    return fail(MMF_ERR_INVALID_ARG, "mmf_self_layer: missing next-layer operand");
-  const size_t words = (size_t)B * L * D;
-  if (launch_self_layer(layer13, ln1_eps, ln2_eps, out, next7, q_heads_next, k_heads_next, v_heads_t_next, qkv3, key_padding16,
-                        reinterpret_cast<unsigned long long*>(handover), tag, reinterpret_cast<int*>(handover + words), B, L, D, H,
-                        (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_self_layer is built for D = 120, H = 8");
-  return check_launch();
-}
-
-int mmf_split_activations3(const float* x, int64_t rows, int K, void* out, void* stream) {
-  if (!x || !out) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_activations3");
-  if (launch_split_act3(x, rows, K, out, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_split_activations3: rows > 0 and K a positive multiple of 8");
-  return check_launch();
-}
-
-int mmf_split_linear_weight(const float* weight, int out_features, int in_features, void* split, void* stream) {
-  if (!weight || !split || out_features <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_linear_weight");
-  if (launch_split_weight(weight, out_features, in_features, split, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_split_linear_weight is built for in_features = 120");
-  return check_launch();
-}
-
-int mmf_attention_heads_split(const float* q_heads, const float* k_heads, const float* v_heads_t, const uint8_t* key_padding, float* partials,
-                              int B, int Lq, int Lk, int H, int head_dim, int* n_split_out, void* stream) {
-  if (!q_heads || !k_heads || !v_heads_t || !n_split_out || B <= 0 || Lq <= 0 || Lk <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_heads_split");
-  if (!partials) {  // size query: partials = float [B, H, n_split, 18, 16]
-    *n_split_out = 4;
-    return MMF_OK;
-  }
-  const int rc = launch_attention_heads_split(q_heads, k_heads, v_heads_t, key_padding, partials, B, Lq, Lk, H, head_dim, (hipStream_t)stream);
-  if (rc == 1) return fail(MMF_ERR_INVALID_ARG, "mmf_attention_heads_split is built for H = 8, head_dim = 15, Lq <= 16");
-  *n_split_out = rc >> 8;
-  return check_launch();
-}
-
-int mmf_out_ffn_mfma_partials(const float* partials, int n_split, const float* residual, const float* Wo, const float* bo,
-                              const float* ln1_weight, const float* ln1_bias, float ln1_eps, const float* scale_shift, const float* W1,
-                              const float* b1, const float* W2, const float* b2, const float* ln2_weight, const float* ln2_bias, float ln2_eps,
-                              float* out, int B, int L, int D, void* stream) {
-  if (!partials || !residual || !Wo || !bo || !ln1_weight || !ln1_bias || !W1 || !b1 || !W2 || !b2 || !ln2_weight || !ln2_bias || !out ||
-      B <= 0 || L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_out_ffn_mfma_partials");
-  if (launch_out_ffn_mfma_partials(partials, n_split, residual, Wo, bo, ln1_weight, ln1_bias, ln1_eps, scale_shift, W1, b1, W2, b2, ln2_weight,
-                                   ln2_bias, ln2_eps, out, B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_out_ffn_mfma_partials is built for D = 120, L <= 16");
-  return check_launch();
-}
-
-int mmf_ffn_block(const float* x, const float* scale_shift, const float* W1, const float* b1, const float* W2, const float* b2,
-                  const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int B, int L, int D, void* stream) {
-  if (!x || !W1 || !b1 || !W2 || !b2 || !ln_weight || !ln_bias || !out || B <= 0 || L <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_ffn_block");
-  if (launch_ffn_block(x, scale_shift, W1, b1, W2, b2, ln_weight, ln_bias, ln_eps, out, B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_ffn_block is built for D = 120");
-  return check_launch();
-}
-
-int mmf_q_block(const float* x, const float* scale_shift, const float* Wq, const float* bq, const float* cos_, const float* sin_,
-                float* out, int B, int L, int D, void* stream) {
-  if (!x || !Wq || !bq || !out || B <= 0 || L <= 0 || ((cos_ == nullptr) != (sin_ == nullptr)))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_q_block");
-  if (launch_q_block(x, scale_shift, Wq, bq, cos_, sin_, out, B, L, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_q_block is built for D = 120");
-  return check_launch();
-}
-
-int mmf_kv_block(const float* memory, const float* Wkv, const float* bkv, const float* cos_, const float* sin_, float* k_out,
-                 float* v_out, long long tokens, int D, void* stream) {
-  if (!memory || !Wkv || !bkv || !k_out || !v_out || tokens <= 0 || ((cos_ == nullptr) != (sin_ == nullptr)))
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_kv_block");
-  if (launch_kv_block(memory, Wkv, bkv, cos_, sin_, k_out, v_out, tokens, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_kv_block is built for D = 120");
-  return check_launch();
-}
-
-int mmf_attn_out_block(const float* att, const float* residual, const float* Wo, const float* bo, const float* ln_weight,
-                       const float* ln_bias, float ln_eps, float* out, long long tokens, int D, void* stream) {
-  if (!att || !residual || !Wo || !bo || !ln_weight || !ln_bias || !out || tokens <= 0)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attn_out_block");
-  if (launch_attn_out_block(att, residual, Wo, bo, ln_weight, ln_bias, ln_eps, out, tokens, D, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_attn_out_block is built for D = 120");
-  return check_launch();
-}
-
-int mmf_ddpm_step(const float* x, const float* eps, long long eps_row_stride, const float* noise, float* out, long long rows, int C,
-                  int split, const float* coef_a_host6, const float* coef_b_host6, void* stream) {
-  if (!x || !eps || !noise || !out || !coef_a_host6 || !coef_b_host6 || rows < 0 || C <= 0 || split < 0 || split > C || eps_row_stride < C)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_ddpm_step");
-  launch_ddpm_step(x, eps, eps_row_stride, noise, out, rows, C, split, coef_a_host6, coef_b_host6, (hipStream_t)stream);
-  return check_launch();
-}
-
-int mmf_attention_small(const float* q, const float* k, long long k_row_stride, const float* v, long long v_row_stride,
-                        const uint8_t* key_padding, float* out, int B, int Lq, int Lk, int heads, int head_dim, void* stream) {
-  if (!q || !k || !v || !out || k_row_stride < (long long)heads * head_dim || v_row_stride < (long long)heads * head_dim)
-    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_small");
-  if (launch_attention_small(q, k, k_row_stride, v, v_row_stride, key_padding, out, B, Lq, Lk, heads, head_dim, (hipStream_t)stream) != 0)
-    return fail(MMF_ERR_INVALID_ARG, "mmf_attention_small supports head_dim 8, 15, 16, 20, 24, 32");
-  return check_launch();
-}
-
-// ---- diagnostics ----------------------------------------------------------------------------------
-int mmf_get_synthetic_depth_dims(mmf_handle h, int mapper_id, int* Hs, int* Ws) {
-  Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
-  *Hs = m->synth_H;
-  *Ws = m->synth_W;
-  return MMF_OK;
-}
-
-int mmf_get_synthetic_depth(mmf_handle h, int mapper_id, float* out, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  if (!m->synth || m->synth_W * m->synth_H == 0) return fail(MMF_ERR_BAD_STATE, "no synthetic depth rendered yet");
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpyAsync(out, m->synth, sizeof(float) * (size_t)m->synth_W * m->synth_H, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  return MMF_OK;
-}
-
-int mmf_render_synthetic_depth(mmf_handle h, int mapper_id, int H, int W, const float* T16, const float* K9, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  HIP_TRY(hipSetDevice(h->device));
-  Cam cam = cam_from_K(K9, W, H);
-  Rigid T_L_C;
-  rigid_from_T(T16, T_L_C);
-  m->synth_epoch = -1;  // force
-  MMF_TRY(ensure_synth(h, *m, cam, T_L_C, T16, K9, (hipStream_t)stream));
-  return check_launch();
-}
-
-int mmf_last_view_block_count(mmf_handle h, int mapper_id, void* stream, int* out) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(h->pinned + 16, m->sc[0].cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  *out = h->pinned[16];
-  return MMF_OK;
-}
-
-int mmf_get_last_view_blocks(mmf_handle h, int mapper_id, int32_t* out, int n, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  if (n <= 0) return MMF_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_unpack_keys, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const mmf::u64*)m->sc[0].cand_key, n, out);
-  return check_launch();
-}
-
-int mmf_get_stats(mmf_handle h, int mapper_id, void* stream, int64_t* out8) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
-  long long* host = reinterpret_cast<long long*>(h->pinned + 32);
-  HIP_TRY(hipMemcpyAsync(host, m->stats, sizeof(long long) * MMF_NUM_STATS, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  for (int i = 0; i < MMF_NUM_STATS; ++i) out8[i] = host[i];
-  out8[0] = m->frames[0];
-  out8[3] = m->frames[1];
-  out8[5] = m->frames[2];
-  return MMF_OK;
-}
-
-int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_t* out) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  if (!out) return fail(MMF_ERR_INVALID_ARG, "null out");
-  HIP_TRY(hipSetDevice(h->device));
-  unsigned long long v = 0;
-  HIP_TRY(hipMemcpyAsync(&v, m->pub + kPubRec + 3 * (size_t)m->tsdf.d.cap + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  *out = (int64_t)v;
-  return MMF_OK;
-}
-
-int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out8) {
-  Mapper* m;
-  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
-  Layer* L = pick_layer(m, layer);
-  if (!L || !out8) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
-  for (int i = 0; i < 8; ++i) out8[i] = 0;
-  out8[4] = m->last_vg.nx;
-  out8[5] = m->last_vg.ny;
-  out8[6] = m->last_vg.nz;
-  if (!L->allocated) return MMF_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  int c[8];
-  HIP_TRY(hipMemcpyAsync(c, L->d.ctr, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  out8[0] = L->d.dense ? 0 : (int64_t)L->d.hmask + 1;  // 0: the layer is indexed by its dense table, the hash is not maintained
-  out8[1] = c[4];
-  out8[2] = c[5];
-  out8[3] = c[0];
-  return MMF_OK;
-}
-
-int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out6) {
-  // out6 is really out8: [6] latest end / [7] earliest start of the mask column workgroups sharing the launch
-  Mapper* m;
-  MMF_TRY(get_mapper(h, mapper_id, &m));
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipDeviceSynchronize());
-  if (out6) {
-    for (int i = 0; i < 10; ++i) out6[i] = 0;
-    if (m->timeline) {
-      HIP_TRY(hipMemcpy(out6, m->timeline, sizeof(long long) * 10, hipMemcpyDeviceToHost));
-      const long long reset[4] = {0, 0x7fffffffffffffffll, 0, 0};
-      HIP_TRY(hipMemcpy(m->timeline + 6, reset, sizeof(reset), hipMemcpyHostToDevice));
-    }
-  }
-  if (enable && !m->timeline) {
-    HIP_TRY(hipMalloc(&m->timeline, sizeof(long long) * 16));
-    HIP_TRY(hipMemset(m->timeline, 0, sizeof(long long) * 16));
-    const long long big = 0x7fffffffffffffffll;
-    HIP_TRY(hipMemcpy(m->timeline + 7, &big, sizeof(big), hipMemcpyHostToDevice));
-  } else if (!enable && m->timeline) {
-    (void)hipFree(m->timeline);
-    m->timeline = nullptr;
-  }
-  return MMF_OK;
-}
-
-int mmf_reset_stats(mmf_handle h, int mapper_id, void* stream) {
-  Mapper* m;
-  MMF_TRY(get_mapper_on(h, mapper_id, &m, stream));
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemsetAsync(m->stats, 0, sizeof(long long) * MMF_NUM_STATS, (hipStream_t)stream));
-  m->frames[0] = m->frames[1] = m->frames[2] = 0;
-  return MMF_OK;
-}
-
-int mmf_profile_enable(mmf_handle h, int enable) {
-  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
-  h->prof = (unsigned)enable;
-  return MMF_OK;
-}
-
-int mmf_profile_set_stride(mmf_handle h, int stride) {
-  if (!h || stride < 1) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_profile_set_stride");
-  h->prof_stride = (unsigned)stride;
-  for (int i = 0; i < MMF_NUM_KERNEL_IDS; ++i) h->prof_seen[i] = 0;
-  return MMF_OK;
-}
-
-int mmf_profile_get(mmf_handle h, int kernel_id, double* total_ms, int64_t* launches) {
-  if (!h || kernel_id < 0 || kernel_id >= MMF_NUM_KERNEL_IDS) return fail(MMF_ERR_INVALID_ARG, "bad kernel id");
-  HIP_TRY(hipSetDevice(h->device));
-  MMF_TRY(prof_collect(h));
-  if (total_ms) *total_ms = h->prof_ms[kernel_id];
-  if (launches) *launches = h->prof_n[kernel_id];
-  return MMF_OK;
-}
-
-int mmf_profile_reset(mmf_handle h) {
-  if (!h) return fail(MMF_ERR_INVALID_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
-  MMF_TRY(prof_collect(h));
-  for (int i = 0; i < MMF_NUM_KERNEL_IDS; ++i) {
-    h->prof_ms[i] = 0;
-    h->prof_n[i] = 0;
-  }
-  return MMF_OK;
-}
-
-const char* mmf_kernel_name(int id) {
-  static const char* names[MMF_NUM_KERNEL_IDS] = {
-      "k_raycast_mark / k_front",  "k_alloc_jobs / k_count_tiles+k_scan_tiles+k_emit", "k_tsdf_integrate / k_tsdf_pass",
-      "k_app_candidates",          "k_sphere_trace / k_sphere_alloc",                  "k_color_integrate",
-      "k_feature_integrate / k_app_frame (gating)", "k_decay(+compact)",              "k_mesh_count/emit",
-      "k_feature_flat"};
-  return (id >= 0 && id < MMF_NUM_KERNEL_IDS) ? names[id] : "?";
 }
 
 }  // extern "C"

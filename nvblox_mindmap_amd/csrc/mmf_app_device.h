@@ -86,6 +86,8 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
 // ------------------------------------------------------------------------------------------------
 
 // blend one colour voxel {rgb_, w} with the bilinear sample at footprint (x0,y0,wx,wy)
+// DIV: the spec switch mmf_params.appearance_blend_division (stand-alone kernels only; every fused launch is built with the default)
+template <bool DIV = false>
 __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, const MapConsts& mc, int x0, int y0, float wx, float wy,
                                     unsigned& ex, unsigned& ey) {
   // the two pixels of a footprint row are 6 consecutive bytes: one 4-byte + one 2-byte load (byte-aligned) instead of six
@@ -104,13 +106,15 @@ __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, cons
     const float a = bilin((float)((top >> (8 * k)) & 0xffu), (float)((top >> (8 * (k + 3))) & 0xffu), (float)((bot >> (8 * k)) & 0xffu),
                           (float)((bot >> (8 * (k + 3))) & 0xffu), wx, wy);
     const float Aold = (float)((ex >> (8 * k)) & 0xffu);
-    const float An = (Aold * Wv + a * wm) * inv;
+    const float num = Aold * Wv + a * wm;
+    const float An = DIV ? num / (Wv + wm) : num * inv;
     out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
   }
   ex = out;
   ey = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
 }
 
+template <bool DIV = false>
 __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs, int bid,
                                   int nb) {
   const LayerDev& L = A.L;
@@ -136,7 +140,7 @@ __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const f
       int x0, y0;
       float wx, wy;
       if (app_gate(mc, cam, A.T_C_L, A.mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
-        color_update(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
+        color_update<DIV>(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
         upd = true;
       }
       if (r) {
@@ -227,7 +231,7 @@ __device__ __noinline__ half8 low_tap_at(const float* __restrict__ low, int w, i
 
 // One surviving voxel: blend its channel row with the bilinear sample of the feature image (or of the virtual up-sampled
 // low-res map).  `lanes` lanes (gl = 0..lanes-1) share the row in 16-byte pieces.
-template <bool LOW>
+template <bool LOW, bool DIV = false>
 __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts& mc, __half* __restrict__ A, bool is_new, size_t pix,
                                               float wx, float wy, float Wv, int gl, int lanes) {
   const Cam& cam = Aa.cam;
@@ -256,7 +260,8 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
       const f32x2 bot = ux * v01 + wx * v11;
       const f32x2 a = uy * top + wy * bot;
       const f32x2 old = {(float)av[k], (float)av[k + 1]};
-      const f32x2 An = (old * Wv + a * wm) * inv;
+      const f32x2 num = old * Wv + a * wm;
+      const f32x2 An = DIV ? num / (Wv + wm) : num * inv;
       o[k] = (_Float16)An.x;
       o[k + 1] = (_Float16)An.y;
     }
@@ -330,14 +335,14 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
 }
 
 // Phase 2 inside the workgroup that gated the block: 32 groups of 8 lanes walk the survivor list in LDS.
-template <bool LOW>
+template <bool LOW, bool DIV = false>
 __device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
   const int C = mc.C;
   const int group = threadIdx.x >> 3, gl = threadIdx.x & 7;
   const int nv = S.n;
   __half* blk = reinterpret_cast<__half*>(A.L.pool) + (size_t)slot * kVPB * C;
   for (int vi = group; vi < nv; vi += 32)
-    feature_voxel<LOW>(A, mc, blk + (size_t)S.lin[vi] * C, is_new, S.pix[vi], S.wx[vi], S.wy[vi], S.W[vi], gl, 8);
+    feature_voxel<LOW, DIV>(A, mc, blk + (size_t)S.lin[vi] * C, is_new, S.pix[vi], S.wx[vi], S.wy[vi], S.W[vi], gl, 8);
 }
 
 // Phase 2 deferred: append the survivor list to the frame's global list (FlatList); k_feature_flat then spreads the
@@ -380,7 +385,7 @@ __device__ inline void feature_zero_fill(const AppArgs& A, const MapConsts& mc, 
 // tail of both gating bodies once the survivor list of the block is complete in LDS (callers synchronised before)
 // PUBLISH_ONLY: the caller guarantees a survivor list (A.flat.rec != nullptr), so the in-workgroup row update is not even
 // compiled in -- it is the register-hungriest code of the gating kernels (LOW: 175 VGPRs = 2 waves per SIMD, against 5).
-template <bool LOW, bool PUBLISH_ONLY = false>
+template <bool LOW, bool PUBLISH_ONLY = false, bool DIV = false>
 __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new, int cand) {
   if constexpr (PUBLISH_ONLY) {
     feature_publish(A, S, slot, is_new, cand);
@@ -388,7 +393,7 @@ __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, Fea
     // statistics: with the survivor list the frame's total is added once by k_feature_flat (one more same-address atomic per
     // gating workgroup otherwise)
     if (threadIdx.x == 0 && A.stats && S.n && !A.flat.rec) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
-    if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW>(A, mc, S, slot, is_new);
+    if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW, DIV>(A, mc, S, slot, is_new);
   }
   if (is_new) feature_zero_fill(A, mc, S, slot);
 }
@@ -428,7 +433,7 @@ __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, 
   wg_trace_end(tr0, kTrFeatureFlat);
 }
 
-template <bool LOW>
+template <bool LOW, bool DIV = false>
 __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
                                     int bid, int nb, FeatLds& S) {
   const LayerDev& L = A.L;
@@ -485,7 +490,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
     }
     __syncthreads();
 
-    feature_finish<LOW>(A, mc, S, slot, is_new, i);
+    feature_finish<LOW, false, DIV>(A, mc, S, slot, is_new, i);
     __syncthreads();
   }
 }

@@ -50,6 +50,7 @@ struct MapConsts {
   float st_max_len, st_eps;
   int C;
   float reach;  // how far past the measured depth the raycast marks blocks: trunc (default) or 0
+  int spec_flags;  // bit 0: raycast walks from the camera; bit 1: appearance blend divides per channel (mmf_params spec switches)
 };
 
 // Device view of one block layer: open-addressing hash (packed 64-bit keys -> pool slot),

@@ -372,8 +372,9 @@ __global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch(SphereBatch P) {
 }
 
 
+template <bool DIV>
 __global__ __launch_bounds__(256) void k_color_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws, int Hs) {
-  color_body(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x);
+  color_body<DIV>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x);
 }
 
 
@@ -444,11 +445,11 @@ __global__ __launch_bounds__(256) void k_feature_flat_batch(FlatBatch P) {
 }
 
 
-template <bool LOW>
+template <bool LOW, bool DIV>
 __global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                           int Hs) {
   __shared__ FeatLds S;
-  feature_body<LOW>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+  feature_body<LOW, DIV>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 }
 
 // Horizontal fusion: colour and feature update of one frame in ONE launch (different layers, same TSDF / synthetic
@@ -646,8 +647,11 @@ static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C
 void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* rgb,
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s) {
-  hipLaunchKernelGGL(k_color_integrate, dim3(grid8(hinted(sc.hint_cand, max_cand), 8192)), dim3(256), 0, s,
-                     make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
+  const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
+  if (mc.spec_flags & 2)  // mmf_params.appearance_blend_division
+    hipLaunchKernelGGL(k_color_integrate<true>, grid, dim3(256), 0, s, make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
+  else
+    hipLaunchKernelGGL(k_color_integrate<false>, grid, dim3(256), 0, s, make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
@@ -718,11 +722,16 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
                               const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                               long long* stats, hipStream_t s, const LowRes* low, const FlatList* flat) {
   const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
-  const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low, flat);
-  if (low)
-    hipLaunchKernelGGL(k_feature_integrate<true>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  const bool div = (mc.spec_flags & 2) != 0;  // mmf_params.appearance_blend_division: rows are updated inside the gating workgroup
+  const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low, div ? nullptr : flat);
+  if (low && div)
+    hipLaunchKernelGGL((k_feature_integrate<true, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  else if (low)
+    hipLaunchKernelGGL((k_feature_integrate<true, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  else if (div)
+    hipLaunchKernelGGL((k_feature_integrate<false, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
   else
-    hipLaunchKernelGGL(k_feature_integrate<false>, grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+    hipLaunchKernelGGL((k_feature_integrate<false, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
 }
 
 AppTail make_app_tail(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc, const LayerDev& Lf,

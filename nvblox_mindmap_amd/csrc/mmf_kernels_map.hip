@@ -120,7 +120,7 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     // Only blocks inside the workspace bounds can be in view: the walk starts where the ray enters them, two cells early
     // (oracle/mmf_oracle.c clip_walk_start: same operations in the same order), not at the camera -- a quarter of the steps of a
     // camera that orbits the task's box.
-    if (mc.ws_type != 0) {
+    if (mc.ws_type != 0 && !(mc.spec_flags & 1)) {
       float r[3], t0 = 0.0f, big = 0.0f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -553,6 +553,87 @@ __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict
   return true;
 }
 
+// ---- THE projective TSDF update of one voxel (spec: oracle/mmf_oracle.c, "TSDF update"): the only copy; k_tsdf_integrate (stand-alone
+// add_depth_frame), k_tsdf_pass (hash path / unfused) and tsdf_frame_block (k_alloc_tsdf*, the fused frame) all come here.
+//   in_view <- the voxel centre projects into the image, not beyond the maximum integration distance (evaluated when `want_view`);
+//   if `cand` (the block is integrated this frame) and in view and the depth sample is valid and sdf >= -trunc and w > 0:
+//     D <- clamp((sdf w + D W) / (w + W), +-trunc),  W <- min(W + w, max_weight);  returns true iff D / W changed.
+template <bool MASKED>
+__device__ inline bool tsdf_voxel_update(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
+                                         const uint8_t* __restrict__ mask, float min_d, int bx, int by, int bz, int lin, bool cand,
+                                         bool want_view, float& D, float& W, bool& in_view) {
+  float c[3], p[3], u, v;
+  in_view = false;
+  if (!want_view) return false;
+  voxel_centre(mc, bx, by, bz, lin, c);
+  xform(T_C_L, c, p);
+  in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+  if (!(cand && in_view)) return false;
+  float d;
+  if (!sample_depth(mc, depth, MASKED ? mask : nullptr, min_d, cam, u, v, d)) return false;
+  const float sdf = d - p[2];
+  if (sdf < -mc.trunc) return false;
+  const float wm = tsdf_measurement_weight(mc, d, sdf);
+  if (!(wm > 0.0f)) return false;
+  float Dn = (sdf * wm + D * W) / (wm + W);
+  Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+  D = Dn;
+  W = fminf(W + wm, mc.max_weight);
+  return true;
+}
+
+// What a pass learns about a block while it holds its voxels: an appearance-candidate voxel in view (hit), every voxel observed
+// free space (freev: the sphere tracer's empty-space summary), the largest weight (wmx: the lazy decay's deallocation test).
+struct TsdfBlockAcc {
+  int hit = 0, freev = 1;
+  float wmx = 0.0f;
+};
+
+// VPT z-adjacent voxels of one thread (VPT / 2 float4 = {D, W, D, W}): load (or zeros for a new block), the pending decay's
+// W *= f, the update above per voxel, write back when anything changed.  The only copy of the per-thread voxel loop.
+template <int VPT, bool MASKED>
+__device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
+                                        const uint8_t* __restrict__ mask, float min_d, float decay_f, int bx, int by, int bz, int lin0,
+                                        bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc) {
+  constexpr int NP = VPT / 2;
+  float4 av[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
+  const bool decayed = decay_f > 0.0f;  // uniform
+  if (decayed) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      av[q].y = av[q].y * decay_f;
+      av[q].w = av[q].w * decay_f;
+    }
+  }
+  bool upd = false;
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    float4& a = av[r >> 1];
+    const bool hi = (r & 1) != 0;
+    float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
+    // the projection is needed by the update (cand) and by the appearance flag of a near-surface voxel only
+    bool in_view;
+    upd |= tsdf_voxel_update<MASKED>(mc, cam, T_C_L, depth, mask, min_d, bx, by, bz, lin0 + r, cand, cand || (W > 0.0f && fabsf(D) < mc.trunc), D,
+                                     W, in_view);
+    if (hi) {
+      a.z = D;
+      a.w = W;
+    } else {
+      a.x = D;
+      a.y = W;
+    }
+    acc.hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
+    acc.freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
+    acc.wmx = fmaxf(acc.wmx, W);
+  }
+  if (upd || is_new || decayed) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) vox[q] = av[q];
+  }
+}
+
 __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        const float* __restrict__ depth,
                                                        const uint8_t* __restrict__ mask, float min_d, Scratch sc) {
@@ -569,26 +650,8 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
     unpack_key(sc.cand_key[i], bx, by, bz);
     float2* vox = reinterpret_cast<float2*>(L.pool) + (size_t)slot * kVPB + lin;
     float2 dw = is_new ? make_float2(0.0f, 0.0f) : *vox;
-    bool upd = false;
-    float c[3], p[3], u, v;
-    voxel_centre(mc, bx, by, bz, lin, c);
-    xform(T_C_L, c, p);
-    if (project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist)) {
-      float d;
-      if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
-        float sdf = d - p[2];
-        if (!(sdf < -mc.trunc)) {
-          const float wm = tsdf_measurement_weight(mc, d, sdf);
-          if (wm > 0.0f) {
-            float Dn = (sdf * wm + dw.x * dw.y) / (wm + dw.y);
-            Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-            dw.x = Dn;
-            dw.y = fminf(dw.y + wm, mc.max_weight);
-            upd = true;
-          }
-        }
-      }
-    }
+    bool in_view;
+    const bool upd = tsdf_voxel_update<true>(mc, cam, T_C_L, depth, mask, min_d, bx, by, bz, lin, true, true, dw.x, dw.y, in_view);
     if (upd || is_new) *vox = dw;
     // block summary for the sphere tracer's empty-space skipping
     const int all_free = __syncthreads_and((dw.y > 1e-4f && dw.x == mc.trunc) ? 1 : 0);
@@ -628,64 +691,11 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x * NP;
-    float4 av[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
     const bool decayed = decay_f > 0.0f;  // uniform
-    if (decayed) {
-#pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        av[q].y = av[q].y * decay_f;
-        av[q].w = av[q].w * decay_f;
-      }
-    }
-    bool upd = false;
-    float wmx = 0.0f;
-    int hit = 0, freev = 1;
-#pragma unroll
-    for (int r = 0; r < VPT; ++r) {
-      float4& a = av[r >> 1];
-      const bool hi = (r & 1) != 0;
-      float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
-      float c[3], p[3], u, v;
-      // the projection is needed by the update (cand) and by the appearance flag of a near-surface voxel only
-      bool in_view = false;
-      if (cand || (W > 0.0f && fabsf(D) < mc.trunc)) {
-        voxel_centre(mc, bx, by, bz, threadIdx.x * VPT + r, c);
-        xform(T_C_L, c, p);
-        in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
-      }
-      if (cand && in_view) {
-        float d;
-        if (sample_depth(mc, depth, mask, min_d, cam, u, v, d)) {
-          float sdf = d - p[2];
-          if (!(sdf < -mc.trunc)) {
-            const float wm = tsdf_measurement_weight(mc, d, sdf);
-            if (wm > 0.0f) {
-              float Dn = (sdf * wm + D * W) / (wm + W);
-              Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-              D = Dn;
-              W = fminf(W + wm, mc.max_weight);
-              upd = true;
-            }
-          }
-        }
-      }
-      if (hi) {
-        a.z = D;
-        a.w = W;
-      } else {
-        a.x = D;
-        a.y = W;
-      }
-      hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
-      freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
-      wmx = fmaxf(wmx, W);
-    }
-    if (upd || is_new || decayed) {
-#pragma unroll
-      for (int q = 0; q < NP; ++q) vox[q] = av[q];
-    }
+    TsdfBlockAcc acc;
+    tsdf_voxel_group<VPT, MASKED>(mc, cam, T_C_L, depth, mask, min_d, decay_f, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
+    const int hit = acc.hit, freev = acc.freev;
+    float wmx = acc.wmx;
     if (cand || decayed) {  // workgroup-uniform: the block's voxels changed -> its empty-space summary may have
       const int all_free = __syncthreads_and(freev);
       if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
@@ -738,60 +748,11 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + t * 2;
-    float4 av[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
-    if (decayed) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        av[q].y = av[q].y * P.decay_f;
-        av[q].w = av[q].w * P.decay_f;
-      }
-    }
-    bool upd = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float4& a = av[r >> 1];
-      const bool hi = (r & 1) != 0;
-      float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
-      float c[3], p[3], u, v;
-      bool in_view = false;
-      if (cand || (W > 0.0f && fabsf(D) < mc.trunc)) {
-        voxel_centre(mc, bx, by, bz, t * 4 + r, c);
-        xform(P.T_C_L, c, p);
-        in_view = project(P.cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
-      }
-      if (cand && in_view) {
-        float d;
-        if (sample_depth(mc, P.depth, nullptr, 0.0f, P.cam, u, v, d)) {
-          float sdf = d - p[2];
-          if (!(sdf < -mc.trunc)) {
-            const float wm = tsdf_measurement_weight(mc, d, sdf);
-            if (wm > 0.0f) {
-              float Dn = (sdf * wm + D * W) / (wm + W);
-              Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
-              D = Dn;
-              W = fminf(W + wm, mc.max_weight);
-              upd = true;
-            }
-          }
-        }
-      }
-      if (hi) {
-        a.z = D;
-        a.w = W;
-      } else {
-        a.x = D;
-        a.y = W;
-      }
-      hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
-      freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
-      wmx = fmaxf(wmx, W);
-    }
-    if (upd || is_new || decayed) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) vox[q] = av[q];
-    }
+    TsdfBlockAcc acc;
+    tsdf_voxel_group<4, false>(mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, bx, by, bz, t * 4, cand, is_new, vox, acc);
+    hit = acc.hit;
+    freev = acc.freev;
+    wmx = acc.wmx;
   }
   const int w_free = __all(freev), w_hit = __any(hit);
   wmx = wave_max_f32(wmx);

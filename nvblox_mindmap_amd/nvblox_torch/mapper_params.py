@@ -40,6 +40,8 @@ class ProjectiveIntegratorParams(_Bag):
         "projective_appearance_integrator_sphere_tracing_max_steps": 100,
         "projective_appearance_integrator_sphere_tracing_max_ray_length_m": 15.0,
         "projective_appearance_integrator_sphere_tracing_surface_epsilon_vox": 0.1,
+        # spec switch (not an upstream field): (A W + a w) / (W + w) per channel (True) or one reciprocal per voxel (False)
+        "projective_appearance_integrator_blend_division": False,
     }
 
 
@@ -65,6 +67,8 @@ class ViewCalculatorParams(_Bag):
         "workspace_bounds_max_height_m": 0.0,
         # spec switch (not an upstream field): blocks in view are marked along each ray up to depth + truncation (True) or depth
         "raycast_to_truncation_distance": True,
+        # spec switch (not an upstream field): a ray's block walk starts at the camera (True) or where it enters the workspace bounds
+        "raycast_walk_from_camera": False,
     }
 
 
@@ -184,4 +188,6 @@ class MapperParams:
         p.expansion_factor = float(po.expansion_factor)
         p.raycast_to_truncation = 1 if vc.raycast_to_truncation_distance else 0
         p.decay_appearance_layers = 1 if de.decay_appearance_layers else 0
+        p.raycast_walk_from_camera = 1 if vc.raycast_walk_from_camera else 0
+        p.appearance_blend_division = 1 if pi.projective_appearance_integrator_blend_division else 0
         return p

@@ -87,6 +87,12 @@ typedef struct {
   int feature_channels;                /* C (compile-time 768 in the reference build)       */
   int raycast_to_truncation;           /* 1: blocks in view are marked up to depth + truncation; 0: up to the depth    */
   int decay_appearance_layers;         /* 0: decay() leaves colour / feature weights alone; 1: multiplies them too      */
+  /* the two places where this spec was arranged for the GPU, kept switchable so that a pin against CUDA
+   * nvblox can tell which form upstream has (tests/pin_report.py flips them):                                              */
+  int raycast_walk_from_camera;        /* 0: the block walk of a ray starts where it enters the workspace bounds; 1: at the camera
+                                          (the same block sets by construction: tests/test_cpu_raycast_walk.py)             */
+  int appearance_blend_division;       /* 0: A' = (A W + a w) * (1 / (W + w)), one reciprocal per voxel; 1: (A W + a w) / (W + w)
+                                          per channel (<= 1 ulp of the stored type apart)                                   */
 } orc_params;
 
 void orc_default_params(orc_params* p) {
@@ -107,6 +113,8 @@ void orc_default_params(orc_params* p) {
   p->mesh_min_weight = 1e-4f;
   p->raycast_to_truncation = 1;
   p->decay_appearance_layers = 0;
+  p->raycast_walk_from_camera = 0;
+  p->appearance_blend_division = 0;
   p->st_subsampling = 4;
   p->st_max_steps = 100;
   p->st_max_ray_length_m = 15.0f;
@@ -577,7 +585,7 @@ static void clip_walk_start(const orc_mapper* m, const float* s0, const float* e
   out[1] = s0[1];
   out[2] = s0[2];
   const int type = m->P.workspace_bounds_type;
-  if (type == 0) return;
+  if (type == 0 || m->P.raycast_walk_from_camera) return;
   float r[3], t0 = 0.0f, big = 0.0f;
   for (int a = 0; a < 3; ++a) {
     r[a] = e[a] - s0[a];
@@ -992,7 +1000,8 @@ int orc_add_feature_frame(orc_mapper* m, const uint16_t* feat, const uint8_t* ma
       uint16_t* Av = A + (size_t)lin * C;
       for (int k = 0; k < C; ++k) {
         float a = bilin(h2f(t00[k]), h2f(t10[k]), h2f(t01[k]), h2f(t11[k]), wx, wy);
-        float An = (h2f(Av[k]) * Wv + a * wm) * inv;
+        float num = h2f(Av[k]) * Wv + a * wm;
+        float An = m->P.appearance_blend_division ? num / (Wv + wm) : num * inv;
         Av[k] = f2h(An);
       }
       Wt[lin] = fminf(Wv + wm, m->P.appearance_max_weight);
@@ -1033,7 +1042,8 @@ int orc_add_color_frame(orc_mapper* m, const uint8_t* rgb, const uint8_t* mask, 
       float inv = 1.0f / (Wv + wm);
       for (int k = 0; k < 3; ++k) {
         float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
-        float An = ((float)cb->rgb[lin * 3 + k] * Wv + a * wm) * inv;
+        float num = (float)cb->rgb[lin * 3 + k] * Wv + a * wm;
+        float An = m->P.appearance_blend_division ? num / (Wv + wm) : num * inv;
         cb->rgb[lin * 3 + k] = (uint8_t)floorf(An + 0.5f);
       }
       cb->w[lin] = fminf(Wv + wm, m->P.appearance_max_weight);

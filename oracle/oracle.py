@@ -41,6 +41,8 @@ class OrcParams(C.Structure):
         ("feature_channels", C.c_int),
         ("raycast_to_truncation", C.c_int),
         ("decay_appearance_layers", C.c_int),
+        ("raycast_walk_from_camera", C.c_int),
+        ("appearance_blend_division", C.c_int),
     ]
 
 

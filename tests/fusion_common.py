@@ -53,6 +53,8 @@ def make_mapper(channels, **over):
         "decay_appearance_layers": (de, "decay_appearance_layers", bool),
         "raycast_subsampling": (vc, "raycast_subsampling_factor", int),
         "raycast_to_truncation": (vc, "raycast_to_truncation_distance", bool),
+        "raycast_walk_from_camera": (vc, "raycast_walk_from_camera", bool),
+        "appearance_blend_division": (pi, "projective_appearance_integrator_blend_division", bool),
         "mesh_min_weight": (me, "mesh_integrator_min_weight", float),
         "num_preallocated_blocks": (pool, "num_preallocated_blocks", int),
     }

@@ -530,6 +530,21 @@ def test_fused_call_falls_back_for_unbounded_workspaces(oracle_mod, invert):
     _fused_vs_oracle(oracle_mod, make_mapper(16, **over), make_oracle(oracle_mod, 16, **over), cfg, [0, 6, 40, 46], 16, invert=invert)
 
 
+@pytest.mark.parametrize("flip", ["raycast_walk_from_camera", "appearance_blend_division"])
+def test_switchable_spec_arrangements_match_the_oracle(oracle_mod, flip):
+    """The two places where the spec was arranged for the GPU are parameters of both implementations
+    (tests/pin_report.py flips them): with either flipped, HIP and oracle still agree bit for bit -- and walking from the camera
+    gives the very map the default gives."""
+    cfg = small_cfg(4)
+    over = {flip: True}
+    gpu, orc = make_mapper(16, **over), make_oracle(oracle_mod, 16, **over)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 6, 40, 46, 90], 16)
+    if flip == "raycast_walk_from_camera":
+        ref = make_oracle(oracle_mod, 16)
+        _fused_vs_oracle(oracle_mod, make_mapper(16), ref, cfg, [0, 6, 40, 46, 90], 16)
+        assert np.array_equal(ref.block_indices(0), orc.block_indices(0)) and np.array_equal(ref.all_tsdf().view(np.uint32), orc.all_tsdf().view(np.uint32))
+
+
 def test_fused_call_on_images_too_narrow_for_the_bit_packed_masks(oracle_mod):
     """W < 16: the bit-packed mask job does not fit its scratch, the byte kernels run instead."""
     cfg = S.StreamConfig(width=12, height=40, fx=10.0, fy=10.0, cx=5.5, cy=19.5)

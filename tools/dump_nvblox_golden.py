@@ -131,7 +131,11 @@ SPEC_ITEMS = [
     dict(item="raycast marks blocks up to depth + truncation (0: up to the depth)", param="raycast_to_truncation", ours=1, flips=[0]),
     dict(item="decay leaves the colour / feature layers untouched (1: their weights fade too)", param="decay_appearance_layers", ours=0,
          flips=[1]),
-    dict(item="appearance blend uses one reciprocal per voxel", param=None, flips=None, note="code: <= 1 f16 ulp either way"),
+    # the two places where the spec was arranged for the GPU: switchable, so that the pin decides
+    dict(item="appearance blend: one reciprocal per voxel (1: a division per channel)", param="appearance_blend_division", ours=0, flips=[1],
+         note="<= 1 ulp of the stored type either way; with 1 frames take the stand-alone appearance kernels"),
+    dict(item="raycast block walk starts where the ray enters the workspace bounds (1: at the camera)", param="raycast_walk_from_camera",
+         ours=0, flips=[1], note="the same block sets by construction (tests/test_cpu_raycast_walk.py): a flip that changes anything is a bug"),
     dict(item="feature storage rounding (RNE)", param=None, flips=None, note="code: __float2half_rn"),
     dict(item="feature-mesh vertex takes the feature of the voxel containing it", param=None, flips=None, note="code: k_mesh_emit"),
 ]
