@@ -276,8 +276,48 @@ class DinoV2Vits14FeatureExtractor(_InjectedModelExtractor):
         return torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
 
 
+class ClipResNet50FpnFeatureExtractor(_InjectedModelExtractor):
+    """CLIP ResNet-50 + feature pyramid (:373-468): 120 channels from pyramid level "res3", 256 -> 16, WebImageText statistics.
+    ``model``: ``(backbone, pyramid_network)`` -- the CLIP visual trunk returning its five stages as a dict {"res1" .. "res5"} and the
+    FPN over them (the reference builds both from ``clip.load("RN50")`` and torchvision) -- or one module doing both,
+    ``model(rgb_bchw) -> {"res3": [b, 120, h, w], ...}``.  ``fpn_path``: a state dict for the pyramid network; as in the reference, a
+    loaded FPN is frozen and one without a checkpoint stays trainable (:425-443)."""
+
+    _what = "(CLIP RN50 trunk returning {'res1'..'res5'}, feature pyramid network) or one module returning {'res3': [b,120,h,w]}"
+
+    def __init__(self, feature_image_size=None, pad_to_nvblox_dim=False, desired_output_size=None, fpn_path: Optional[str] = None,
+                 model=None, device: str = "cuda"):
+        pair = isinstance(model, (tuple, list))
+        self.backbone, self.pyramid_network = (model[0], model[1]) if pair else (None, None)
+        super().__init__(feature_image_size, pad_to_nvblox_dim, desired_output_size, model=torch.nn.ModuleList(model) if pair else model,
+                         device=device)
+        if pair:  # FeatureExtractor.__init__ froze everything: the pyramid is trainable unless its checkpoint was given (:431-441)
+            if fpn_path is not None:
+                self.pyramid_network.load_state_dict(torch.load(fpn_path, map_location=device, weights_only=True))
+            for p in self.pyramid_network.parameters():
+                p.requires_grad = fpn_path is None
+
+    @staticmethod
+    def embedding_dim():
+        return 120
+
+    def model_input_size(self):
+        return (256, 256)
+
+    def model_output_size(self):
+        return (16, 16)
+
+    def train_dataset_mean_and_std(self):
+        return torch.tensor([0.48145466, 0.4578275, 0.40821073]), torch.tensor([0.26862954, 0.26130258, 0.27577711])
+
+    @torch.no_grad()
+    def _extract_features_impl(self, rgb_bchw: torch.Tensor):
+        encoded = self.pyramid_network(self.backbone(rgb_bchw)) if self.backbone is not None else self.model(rgb_bchw)
+        return encoded["res3"]
+
+
 def get_nvblox_feature_dim(feature_extractor_type: FeatureExtractorType):
-    dims = {FeatureExtractorType.CLIP_RESNET50_FPN: 120, FeatureExtractorType.RADIO_V25_B: RadioV25BFeatureExtractor.embedding_dim(),
+    dims = {FeatureExtractorType.CLIP_RESNET50_FPN: ClipResNet50FpnFeatureExtractor.embedding_dim(), FeatureExtractorType.RADIO_V25_B: RadioV25BFeatureExtractor.embedding_dim(),
             FeatureExtractorType.DINO_V2_VITS14: DinoV2Vits14FeatureExtractor.embedding_dim(),
             FeatureExtractorType.RGB: RgbFeatureExtractor.embedding_dim()}
     if feature_extractor_type not in dims:
@@ -298,6 +338,5 @@ def get_feature_extractor(feature_extractor_type: FeatureExtractorType, feature_
     if feature_extractor_type == FeatureExtractorType.RGB:
         return RgbFeatureExtractor(**kw)
     if feature_extractor_type == FeatureExtractorType.CLIP_RESNET50_FPN:
-        raise NotImplementedError("the CLIP ResNet-50 + FPN extractor (clip, torchvision) is outside this package: pass any "
-                                  "FeatureExtractor subclass of your own to IsaacLabNvbloxMapper(feature_extractor=...)")
+        return ClipResNet50FpnFeatureExtractor(fpn_path=fpn_path, model=model, **kw)
     raise ValueError(f"Invalid feature extractor type: {feature_extractor_type}")
