@@ -440,6 +440,16 @@ int mmf_split_linear_weight(const float* weight_dev, int out_features, int in_fe
  * (diffuser_actor/split_linear.py), ONE plain fp16 GEMM with f32 accumulation returns x w^T + bias at f32 accuracy.  K >= 64, a multiple
  * of 8; |x| < 65 504. */
 int mmf_split_activations3(const float* x_dev, int64_t rows, int K, void* out_dev, void* stream);
+/* The element-wise passes between the frozen backbone's GEMMs, fused with that split (one HBM round trip each instead of two or three):
+ *   mmf_gelu_split_activations3:      out = split3(gelu(x)), exact (erf) GELU;
+ *   mmf_split_attention_heads3:       out = split3 of the attention output att [B, heads, L, head_dim] read as rows (b, l) of
+ *                                     heads * head_dim channels (the layout the next Linear wants, without the transpose copy);
+ *   mmf_layernorm_split_activations3: s = x (+ residual, then sum_out <- s);  out = split3(LayerNorm(s; gamma, beta, eps)), two-pass
+ *                                     float32 statistics; K in {256, 512, 768, 1024}. */
+int mmf_gelu_split_activations3(const float* x_dev, int64_t rows, int K, void* out_dev, void* stream);
+int mmf_split_attention_heads3(const float* att_dev, int64_t B, int heads, int L, int head_dim, void* out_dev, void* stream);
+int mmf_layernorm_split_activations3(const float* x_dev, const float* residual_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                                     int64_t rows, int K, float* sum_out_dev, void* out_dev, void* stream);
 /* mmf_cross_layer: mmf_attention_heads_split and the block kernel that consumes its partials (mmf_out_ffn_mfma_partials, or with
  * next7 != NULL mmf_out_ffn_qkv with roles 1) in ONE launch: the attention workgroups lead the grid and hand their partials to
  * the block workgroup of their batch element as self-validating 64-bit words, which that workgroup polls after it has requested

@@ -24,6 +24,23 @@ KERNEL_IDS = {
 }
 
 
+def source_hash() -> str:
+    """16 hex digits identifying the native sources a build was made from (sha256 over csrc/*.hip, csrc/*.h, include/*.h in name
+    order).  The counter summaries under profiles/ carry the hash of the sources they were collected on; bench.py compares it
+    with the running tree's and marks replayed counters as stale when they differ (`roofline.counters_stale`)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.h"))
+                   + glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class MmfParams(C.Structure):
     """``mmf_params`` of include/mmfusion.h (field order and types must match)."""
 
@@ -146,6 +163,9 @@ SIGNATURES = {
     "mmf_out_ffn_qkv2": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "mmf_split_linear_weight": (_I, [_VP, _I, _I, _VP, _VP]),
     "mmf_split_activations3": (_I, [_VP, C.c_int64, _I, _VP, _VP]),
+    "mmf_gelu_split_activations3": (_I, [_VP, C.c_int64, _I, _VP, _VP]),
+    "mmf_split_attention_heads3": (_I, [_VP, C.c_int64, _I, _I, _I, _VP, _VP]),
+    "mmf_layernorm_split_activations3": (_I, [_VP, _VP, _VP, _VP, _F, C.c_int64, _I, _VP, _VP, _VP]),
     "mmf_self_layer": (_I, [_VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _I, _I, _I, _I, _VP]),
     "mmf_cross_layer": (_I, [_VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _I, _I, _I, _I, _I, _VP]),
     "mmf_attention_heads_split": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, C.POINTER(C.c_int), _VP]),

@@ -314,6 +314,28 @@ int mmf_split_activations3(const float* x, int64_t rows, int K, void* out, void*
   return check_launch();
 }
 
+int mmf_gelu_split_activations3(const float* x, int64_t rows, int K, void* out, void* stream) {
+  if (!x || !out) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_gelu_split_activations3");
+  if (launch_split_act3_src(1, x, rows, K, 0, 0, out, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_gelu_split_activations3: rows > 0 and K >= 64 a multiple of 8");
+  return check_launch();
+}
+
+int mmf_split_attention_heads3(const float* att, int64_t B, int heads, int L, int head_dim, void* out, void* stream) {
+  if (!att || !out || B <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_attention_heads3");
+  if (launch_split_act3_src(2, att, B * (int64_t)L, heads * head_dim, heads, L, out, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_split_attention_heads3: head_dim a multiple of 8, heads * head_dim >= 64");
+  return check_launch();
+}
+
+int mmf_layernorm_split_activations3(const float* x, const float* residual, const float* gamma, const float* beta, float eps, int64_t rows,
+                                     int K, float* sum_out, void* out, void* stream) {
+  if (!x || !gamma || !beta || !out) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_layernorm_split_activations3");
+  if (launch_ln_split3(x, residual, gamma, beta, eps, rows, K, sum_out, out, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_layernorm_split_activations3: K in {256, 512, 768, 1024}; residual and sum_out come together");
+  return check_launch();
+}
+
 int mmf_split_linear_weight(const float* weight, int out_features, int in_features, void* split, void* stream) {
   if (!weight || !split || out_features <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_linear_weight");
   if (launch_split_weight(weight, out_features, in_features, split, (hipStream_t)stream) != 0)

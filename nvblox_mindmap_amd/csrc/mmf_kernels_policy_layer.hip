@@ -212,6 +212,155 @@ int launch_split_act3(const float* x, long long rows, int K, void* out, hipStrea
   return 0;
 }
 
+// ---- the frozen backbone's element-wise passes, fused with the split (training step: every one of them is an HBM round trip of a
+// [32 768, 768 .. 3 072] float32 activation) ------------------------------------------------------------------
+// One thread per 8 values like k_split_act3; SRC: 0 plain rows, 1 exact GELU of the input (0.5 x (1 + erf(x / sqrt 2)), torch's
+// default) first, 2 the input is the attention output [B, H, L, d] (what SDPA returns) read as rows (b, l) of H d channels -- the
+// transpose-and-reshape copy the composite ops make is skipped.
+__device__ __forceinline__ void split3_store(const float (&v)[8], long long r, int c, int p, int K, _Float16* __restrict__ out) {
+  h8 hi, hs, lo;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    hi[t] = (_Float16)v[t];
+    const _Float16 l = (_Float16)((v[t] - (float)hi[t]) * kLoScale);
+    hs[t] = (_Float16)((float)hi[t] * kLoInv);
+    lo[t] = (_Float16)((float)l * kLoInv);
+  }
+  _Float16* o = out + r * (3 * K + kTail) + c;
+  *reinterpret_cast<h8*>(o) = hi;
+  *reinterpret_cast<h8*>(o + K) = hs;
+  *reinterpret_cast<h8*>(o + 2 * K) = lo;
+  const int ppr = K / 8;
+  if (p >= ppr - kTail / 8) {
+    const int tp = p - (ppr - kTail / 8);
+    h8 one = {(_Float16)(tp == 0 ? 1.0f : 0.0f), (_Float16)(tp == 0 ? kLoInv : 0.0f), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+              (_Float16)0.f, (_Float16)0.f};
+    *reinterpret_cast<h8*>(out + r * (3 * K + kTail) + 3 * K + 8 * tp) = one;
+  }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_split_act3_src(const float* __restrict__ x, long long pieces, int K, int heads, int L,
+                                                      _Float16* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= pieces) return;
+  const int ppr = K / 8;
+  const long long r = e / ppr;
+  const int p = (int)(e - r * ppr), c = p * 8;
+  float v[8];
+  if (SRC == 2) {
+    const int d = K / heads, hh = c / d, j = c - hh * d;  // d is a multiple of 8: a piece lies inside one head
+    const long long b = r / L, l = r - b * L;
+    load8(x + ((b * heads + hh) * L + l) * d + j, v);
+  } else {
+    load8(x + r * K + c, v);
+  }
+  if (SRC == 1) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752440f));
+      // ONE value per element from here on: without the barrier the compiler re-evaluates the expression for the hi and for the
+      // lo part (not bit-identically -- seen as hi and lo disagreeing by a whole fp16 ulp on exact ties)
+      asm volatile("" : "+v"(v[t]));
+    }
+  }
+  split3_store(v, r, c, p, K, out);
+}
+
+int launch_split_act3_src(int src, const float* x, long long rows, int K, int heads, int L, void* out, hipStream_t s) {
+  if (rows <= 0 || K < kTail || K % 8 != 0) return 1;
+  if (src == 2 && (heads <= 0 || L <= 0 || K % heads != 0 || (K / heads) % 8 != 0 || rows % L != 0)) return 1;
+  const long long pieces = rows * (K / 8);
+  const dim3 grid((unsigned)((pieces + 255) / 256));
+  _Float16* o = reinterpret_cast<_Float16*>(out);
+  if (src == 1)
+    hipLaunchKernelGGL(k_split_act3_src<1>, grid, dim3(256), 0, s, x, pieces, K, heads, L, o);
+  else if (src == 2)
+    hipLaunchKernelGGL(k_split_act3_src<2>, grid, dim3(256), 0, s, x, pieces, K, heads, L, o);
+  else
+    return 1;
+  return 0;
+}
+
+// LayerNorm (+ the residual add in front of it) + split: s = x (+ y);  [sum_out <- s];  out <- split3((s - mean) rstd gamma + beta).
+// One wave per row, the row in registers (K = 256 NCH, NCH float4 per lane): two-pass mean / variance like torch's
+// (sum of squared deviations from the mean: no cancellation), float32 throughout.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_ln_split3(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float eps, long long rows, float* __restrict__ sum_out,
+                                                  _Float16* __restrict__ out) {
+  constexpr int K = 256 * NCH;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float4 v[NCH];
+  float sum = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int c = q * 256 + lane * 4;
+    v[q] = *reinterpret_cast<const float4*>(x + r * K + c);
+    if (y) {
+      const float4 w = *reinterpret_cast<const float4*>(y + r * K + c);
+      v[q].x += w.x, v[q].y += w.y, v[q].z += w.z, v[q].w += w.w;
+      *reinterpret_cast<float4*>(sum_out + r * K + c) = v[q];
+    }
+    sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum * (1.0f / K);
+  float sq = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const float a = v[q].x - mean, b = v[q].y - mean, c = v[q].z - mean, d = v[q].w - mean;
+    sq += (a * a + b * b) + (c * c + d * d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + eps);
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  _Float16* o = out + r * (3 * K + kTail);
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int c = q * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+    float n[4] = {(v[q].x - mean) * rstd * g.x + bt.x, (v[q].y - mean) * rstd * g.y + bt.y, (v[q].z - mean) * rstd * g.z + bt.z,
+                  (v[q].w - mean) * rstd * g.w + bt.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(n[t]));  // (one value per element for the hi and the lo part, see the GELU kernel)
+    h4 hi, hs, lo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      hi[t] = (_Float16)n[t];
+      const _Float16 l = (_Float16)((n[t] - (float)hi[t]) * kLoScale);
+      hs[t] = (_Float16)((float)hi[t] * kLoInv);
+      lo[t] = (_Float16)((float)l * kLoInv);
+    }
+    *reinterpret_cast<h4*>(o + c) = hi;
+    *reinterpret_cast<h4*>(o + K + c) = hs;
+    *reinterpret_cast<h4*>(o + 2 * K + c) = lo;
+  }
+  if (lane < kTail / 8) {
+    h8 one = {(_Float16)(lane == 0 ? 1.0f : 0.0f), (_Float16)(lane == 0 ? kLoInv : 0.0f), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+              (_Float16)0.f, (_Float16)0.f};
+    *reinterpret_cast<h8*>(o + 3 * K + 8 * lane) = one;
+  }
+}
+
+int launch_ln_split3(const float* x, const float* y, const float* gamma, const float* beta, float eps, long long rows, int K, float* sum_out,
+                     void* out, hipStream_t s) {
+  if (rows <= 0 || K % 256 != 0 || K < 256 || K > 1024 || (y != nullptr) != (sum_out != nullptr)) return 1;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  _Float16* o = reinterpret_cast<_Float16*>(out);
+  switch (K / 256) {
+    case 1: hipLaunchKernelGGL(k_ln_split3<1>, grid, dim3(256), 0, s, x, y, gamma, beta, eps, rows, sum_out, o); break;
+    case 2: hipLaunchKernelGGL(k_ln_split3<2>, grid, dim3(256), 0, s, x, y, gamma, beta, eps, rows, sum_out, o); break;
+    case 3: hipLaunchKernelGGL(k_ln_split3<3>, grid, dim3(256), 0, s, x, y, gamma, beta, eps, rows, sum_out, o); break;
+    default: hipLaunchKernelGGL(k_ln_split3<4>, grid, dim3(256), 0, s, x, y, gamma, beta, eps, rows, sum_out, o); break;
+  }
+  return 0;
+}
+
 // ---- q | k | v projections, rotary, head-major outputs ---------------------------------------------------------------------
 struct QkvArgs {
   const float* ss;       // AdaLN (scale | shift) [B, 2 D] of the query input or null

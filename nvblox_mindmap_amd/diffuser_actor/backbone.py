@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import split_linear as SL
 from .split_linear import split_linear
 
 
@@ -31,6 +32,18 @@ class _Block(nn.Module):
         x = x + _lin(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D), self.proj, split)
         return x + _lin(F.gelu(_lin(self.n2(x), self.fc1, split)), self.fc2, split)
 
+    def forward_fused(self, x, pending):
+        """The same block on the fused element-wise kernels (split_linear.py: LayerNorm / GELU / head transpose write the split
+        operands of the next GEMM directly; the residual adds ride in the LayerNorm passes).  ``pending``: the previous block's last
+        branch, not yet added to ``x``.  Returns (x after the attention branch, this block's MLP branch -- the next ``pending``)."""
+        B, L, D = x.shape
+        x, a3 = SL.ln_split3(x, pending, self.n1)
+        qkv = SL.mm3(a3, self.qkv, (B, L, 3, self.heads, D // self.heads)).permute(2, 0, 3, 1, 4)
+        att = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        x, a3 = SL.ln_split3(x, SL.mm3(SL.split3_heads(att), self.proj, (B, L, D)), self.n2)
+        h = SL.mm3(a3, self.fc1, (B * L, self.fc1.out_features))
+        return x, SL.mm3(SL.gelu_split3(h), self.fc2, (B, L, D))
+
 
 class VitBackbone(nn.Module):
     """ViT-B/16-shaped encoder: (B,3,H,W) in [0,1] -> (B,dim,H/16,W/16)."""
@@ -44,6 +57,7 @@ class VitBackbone(nn.Module):
         self.blocks = nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim)
         self.split_gemm = False  # frozen inference on a GPU: every Linear as one fp16 GEMM of split operands (split_linear.py)
+        self.fused_elementwise = True  # ... and the LayerNorm / GELU / residual / transpose passes between them fused with the split
 
     def forward(self, x):
         B, _, H, W = x.shape
@@ -55,6 +69,12 @@ class VitBackbone(nn.Module):
         t = F.linear(patches, self.embed.weight.reshape(self.dim, 3 * P * P), self.embed.bias)
         t = t + self.pos[:, : h * w]
         split = self.split_gemm and t.is_cuda and t.dtype == torch.float32 and not torch.is_grad_enabled()
-        for blk in self.blocks:
-            t = blk(t, split)
+        if split and self.fused_elementwise and all(SL.can_fuse(t, blk) for blk in self.blocks):
+            pending = None
+            for blk in self.blocks:
+                t, pending = blk.forward_fused(t, pending)
+            t = t + pending
+        else:
+            for blk in self.blocks:
+                t = blk(t, split)
         return self.norm(t).transpose(1, 2).reshape(B, self.dim, h, w)

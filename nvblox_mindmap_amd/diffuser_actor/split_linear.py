@@ -68,3 +68,60 @@ def split_linear(x: torch.Tensor, linear) -> torch.Tensor:
     _lib.check(_lib.lib().mmf_split_activations3(_lib.dptr(x2), x2.shape[0], K, _lib.dptr(a3), _lib.stream_ptr(x.device)), "mmf_split_activations3")
     y = torch.mm(a3, w3.t(), out_dtype=torch.float32)
     return y.reshape(*x.shape[:-1], w3.shape[0])
+
+
+# ---- the element-wise passes between the split GEMMs, fused with the split (csrc/mmf_kernels_policy_layer.hip) -----------------------
+def mm3(a3: torch.Tensor, linear, shape) -> torch.Tensor:
+    """The one fp16 GEMM of ``split_linear`` on activations that are already split ([rows, 3 K + 64] fp16) -> float32 ``shape``."""
+    return torch.mm(a3, _w3(linear).t(), out_dtype=torch.float32).reshape(shape)
+
+
+def can_fuse(x: torch.Tensor, block) -> bool:
+    """The fused per-block path: CUDA float32 inference, every Linear of the block splittable, enough rows, LayerNorm width the
+    kernel is built for."""
+    if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and supported()):
+        return False
+    K = x.shape[-1]
+    if K not in (256, 512, 768, 1024) or x.numel() // K < kMinRows:
+        return False
+    return all(_w3(lin) is not None for lin in (block.qkv, block.proj, block.fc1, block.fc2))
+
+
+def _a3(rows: int, K: int, device) -> torch.Tensor:
+    return torch.empty((rows, 3 * K + kTail), dtype=torch.float16, device=device)
+
+
+def ln_split3(x: torch.Tensor, residual, ln):
+    """(x + residual, split3(LayerNorm(x + residual))) in one pass over the rows (``residual`` None: (x, split3(LayerNorm(x))))."""
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    a3 = _a3(x2.shape[0], K, x.device)
+    s_out, y_ptr, s_ptr = x, None, None
+    if residual is not None:
+        y2 = residual.reshape(-1, K)
+        y2 = y2 if y2.is_contiguous() else y2.contiguous()
+        s_out = torch.empty_like(x2)
+        y_ptr, s_ptr = _lib.dptr(y2), _lib.dptr(s_out)
+    _lib.check(_lib.lib().mmf_layernorm_split_activations3(_lib.dptr(x2), y_ptr, _lib.dptr(ln.weight), _lib.dptr(ln.bias), float(ln.eps), x2.shape[0], K,
+                                                          s_ptr, _lib.dptr(a3), _lib.stream_ptr(x.device)), "mmf_layernorm_split_activations3")
+    return s_out.reshape(x.shape), a3
+
+
+def gelu_split3(h: torch.Tensor) -> torch.Tensor:
+    K = h.shape[-1]
+    h2 = h.reshape(-1, K)
+    a3 = _a3(h2.shape[0], K, h.device)
+    _lib.check(_lib.lib().mmf_gelu_split_activations3(_lib.dptr(h2), h2.shape[0], K, _lib.dptr(a3), _lib.stream_ptr(h.device)),
+               "mmf_gelu_split_activations3")
+    return a3
+
+
+def split3_heads(att: torch.Tensor) -> torch.Tensor:
+    """att [B, heads, L, d] (contiguous: what SDPA returns) -> split3 of its [B L, heads d] view, without the transpose copy."""
+    B, H, L, d = att.shape
+    att = att if att.is_contiguous() else att.contiguous()
+    a3 = _a3(B * L, H * d, att.device)
+    _lib.check(_lib.lib().mmf_split_attention_heads3(_lib.dptr(att), B, H, L, d, _lib.dptr(a3), _lib.stream_ptr(att.device)),
+               "mmf_split_attention_heads3")
+    return a3

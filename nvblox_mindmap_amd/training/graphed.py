@@ -127,6 +127,8 @@ class GraphedTrainStep:
         self.feats = self.next_feats = self.next_rgbs = None
         if self.overlap:
             self.next_rgbs = self.static["rgbs"].clone()
+            # (Stream priorities were tried and dropped: the trainable chain on a high-priority queue slows the backbone's GEMMs so much
+            # that a step takes 100 ms instead of 60; the backbone on the high-priority queue changes nothing.  DESIGN.md section 7.)
             self._side = torch.cuda.Stream(device=self.device)
         self.graph_fb = self.graph_opt = self.graph_bb = None
         if self.use_graphs:

@@ -683,6 +683,38 @@ def test_frozen_backbone_on_split_fp16_gemms_keeps_f32_accuracy():
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-5 * scale, float((got - ref).abs().max())
         assert float((half - ref).abs().max()) > 50 * float((got - ref).abs().max())
+        # `got` ran the fused element-wise kernels (LayerNorm / GELU / residual / head transpose write the split operands directly);
+        # the unfused split path gives the same to rounding
+        bb.split_gemm, bb.fused_elementwise = True, False
+        unfused = bb(x)
+        assert float((got - unfused).abs().max()) <= 2e-5 * scale and not torch.equal(got, unfused)
+        # the fused ops one by one against the composite ops + mmf_split_activations3
+        blk = bb.blocks[0]
+        t = torch.randn(4, 1024, 768, device="cuda")
+        y = torch.randn(4, 1024, 768, device="cuda")
+
+        def split3(v):
+            out = torch.empty((v.numel() // v.shape[-1], 3 * v.shape[-1] + 64), dtype=torch.float16, device="cuda")
+            _lib.check(_lib.lib().mmf_split_activations3(_lib.dptr(v.contiguous()), out.shape[0], v.shape[-1], _lib.dptr(out), _lib.stream_ptr(v.device)), "split")
+            return out
+
+        def as_f32(a3, K):  # hi + lo: the value the GEMM sees (22-bit mantissa)
+            return a3[:, :K].float() + a3[:, 2 * K:3 * K].float()
+
+        from nvblox_mindmap_amd import _lib
+
+        s_out, a3 = SL.ln_split3(t, y, blk.n1)
+        assert torch.equal(s_out, t + y)
+        want = blk.n1(t + y).reshape(-1, 768)
+        assert float((as_f32(a3, 768) - want).abs().max()) <= 4e-6 * float(want.abs().max())
+        assert torch.equal(a3[:, 3 * 768:], split3(want)[:, 3 * 768:])  # the bias columns
+        s2, a3b = SL.ln_split3(t, None, blk.n1)
+        assert s2.data_ptr() == t.data_ptr() and float((as_f32(a3b, 768) - blk.n1(t).reshape(-1, 768)).abs().max()) <= 4e-6 * 6.0
+        hcol = torch.randn(4096, 3072, device="cuda") * 2.0
+        g3 = SL.gelu_split3(hcol)
+        assert float((as_f32(g3, 3072) - torch.nn.functional.gelu(hcol)).abs().max()) <= 2e-6 * 8.0
+        att = torch.randn(4, 12, 1024, 64, device="cuda")
+        assert torch.equal(SL.split3_heads(att), split3(att.transpose(1, 2).reshape(4 * 1024, 768)))
         lin = torch.nn.Linear(64, 32).cuda()
         xs = torch.randn(5000, 64, device="cuda")
         a = SL.split_linear(xs, lin)

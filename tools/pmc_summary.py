@@ -13,6 +13,13 @@ import sys
 from collections import defaultdict
 
 
+def _source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nvblox_mindmap_amd._lib import source_hash
+
+    return source_hash()
+
+
 def short(name):
     name = re.sub(r"\(.*$", "", name)          # parameters
     name = name.replace("void ", "").strip().replace(".kd", "")
@@ -42,6 +49,7 @@ def main(out, source, paths):
             res[k][c + ("_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = tot / n
             res[k]["dispatches"] = n
     res["__source__"] = source
+    res["__csrc_sha16__"] = _source_hash()  # the native sources these counters were collected on (bench.py: counters_stale)
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     print(f"{len(res)} kernels -> {out}")

@@ -9,6 +9,13 @@ import sys
 from collections import defaultdict
 
 
+def _source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nvblox_mindmap_amd._lib import source_hash
+
+    return source_hash()
+
+
 def short(name):
     name = re.sub(r"\(.*$", "", name).replace("void ", "").strip().replace(".kd", "")
     base = re.sub(r"<.*$", "", name).split("::")[-1]
@@ -48,6 +55,7 @@ def main(out, source, root):
                 d["wave_cycles_per_busy_cycle"] = wc / v["SQ_BUSY_CYCLES"]
         res[k] = d
     res["__source__"] = source
+    res["__csrc_sha16__"] = _source_hash()  # the native sources these counters were collected on (bench.py: counters_stale)
     res["__units__"] = "SQ_*_CYCLES / WAIT / ACTIVE counters count quad-cycles summed over waves (MI355X_MICROARCH.md); fractions are of SQ_WAVE_CYCLES"
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
