@@ -1129,6 +1129,47 @@ def run_unbounded(device, frames, channels, steps=100, warmup=30):
     return out
 
 
+def run_pixel_holes(device, channels, steps=100, warmup=20, n_frames=40):
+    """SURVEY.md section 8(d)'s stream AS PRESCRIBED: invalid depth at the 1 %-density single pixels (u * 73856093 ^ v * 19349663) % 97 == 0.
+    With the reference's 20-pixel valid-depth erosion those holes erase the whole feature mask (a pixel survives iff its 41 x 41
+    window holds no hole: (1 - 1/97)^1681 = 3e-8), so this stream has TSDF and colour work and NO feature work -- which is why the
+    headline uses 16 x 16 hole patches instead (config.workload).  Same call sequence, same pipelining, own mapper; two regions of
+    `steps` frames, the faster one reported, with the algorithmic bytes of what the frames actually did."""
+    cfg = S.StreamConfig(hole_mode="pixels")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    frames = build_stream(cfg, n_frames, channels, device)
+    mapper = get_nvblox_mapper(mcfg, feature_channels=channels)
+    mapper.set_deferred_feature_rows(True)
+    for i in range(warmup):
+        step(mapper, mcfg, frames[i % n_frames])
+    mapper.flush()
+    torch.cuda.synchronize(device)
+    mapper.reset_stats(MAPPER_TO_ID.STATIC)
+    regions, k = [], warmup
+    for _ in range(2):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(mapper, mcfg, frames[(k + i) % n_frames])
+        mapper.flush()
+        torch.cuda.synchronize(device)
+        regions.append(time.perf_counter() - t0)
+        k += steps
+    st = mapper.stats(MAPPER_TO_ID.STATIC)
+    n_live = int(mapper.tsdf_layer_view(MAPPER_TO_ID.STATIC).num_allocated_blocks())
+    nf = max(st["depth_frames"], 1)
+    surv = st["feature_voxels_updated"] / max(st["feature_frames"], 1)
+    model = frame_byte_model(cfg, channels, n_live, st["tsdf_blocks_updated"] / nf, st["color_blocks_updated"] / max(st["color_frames"], 1), surv)
+    t = min(regions) / steps
+    out = {"frames_per_s": 1.0 / t, "ms_per_step": t * 1e3, "steps": steps, "hole_mode": "pixels", "feature_voxels_updated_per_frame": surv,
+           "tsdf_blocks_per_frame": st["tsdf_blocks_updated"] / nf, "algorithmic_bytes_per_frame": sum(model.values()),
+           "frac_of_hbm_peak": sum(model.values()) / t / HBM_PEAK_BYTES_PER_S,
+           "note": "SURVEY 8(d)'s prescribed holes: the 20-pixel erosion leaves no feature pixel, the frame is TSDF + colour work"}
+    del mapper, frames
+    torch.cuda.empty_cache()
+    return out
+
+
 def frame_byte_model(cfg, C, n_live, n_tsdf_upd, n_cand, n_surv, with_decay=True):
     """ALGORITHMIC bytes per launch of the fused frame = what THIS implementation's algorithm has to move between HBM and the
     chip, counted from the run's own device counters (DESIGN.md section 5 states the same formulas):
@@ -1169,6 +1210,16 @@ LAUNCHES_EAGER = [("raycast", "k_front", ["k_front"]), ("tsdf", "k_alloc_tsdf", 
                   ("feature", "k_app_frame", ["k_app_frame"]), ("feature_flat", "k_feature_flat", ["k_feature_flat"])]
 LAUNCHES_DEFERRED = [("raycast", "k_front_app", ["k_front", "k_app_frame"]), ("tsdf", "k_alloc_tsdf", ["k_alloc_tsdf"]),
                      ("sphere", "k_sphere_alloc_flat", ["k_sphere_alloc", "k_feature_flat"])]
+
+
+def counters_stamp(path):
+    """The `__csrc_sha16__` a counter summary under profiles/ carries (the native sources it was collected on), or None (an older
+    summary without a stamp)."""
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("__csrc_sha16__")
+    except Exception:
+        return None
 
 
 def sq_evidence():
@@ -1301,10 +1352,7 @@ def main():
     torch.cuda.synchronize(device)
     mapper.reset_stats(MAPPER_TO_ID.STATIC)
     mapper.profile_reset()
-    if not args.no_profile:
-        # all five launches of every 8th frame are stamped with their dispatch's own begin / end times (extension-launch
-        # events: no marker packets), inside the timed regions
-        mapper.profile_enable(True, kernels=list(KERNEL_OF_CLASS), stride=8)
+    # (per-launch durations are taken in a region of their own behind the headline regions: the headline is not event-stamped)
 
     # K timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides; max over ranks per
     # region; the MEDIAN region is the reported one (a 14 ms region is at the mercy of one scheduler hiccup)
@@ -1333,8 +1381,19 @@ def main():
     elapsed = statistics.median(regions)
     t_enqueued = statistics.median(enqueue)
 
-    mapper.profile_enable(False)
-    prof = mapper.profile()
+    prof = {}
+    if not args.no_profile:
+        # one more region of the same steps, NOT part of the headline: every launch of every 2nd frame is stamped with its dispatch's
+        # own begin / end times (extension-launch events: no marker packets) -> roofline.per_kernel / kernels_busy_us
+        mapper.profile_reset()
+        mapper.profile_enable(True, kernels=list(KERNEL_OF_CLASS), stride=2)
+        for i in range(args.steps):
+            step(mapper, mcfg, frames[(k + i) % n_frames])
+        mapper.flush()
+        torch.cuda.synchronize(device)
+        k += args.steps
+        mapper.profile_enable(False)
+        prof = mapper.profile()
     undeferred = None
     if not args.eager_rows:
         # the same stream with every frame's five launches run before the next frame starts (what a caller gets who cannot keep
@@ -1389,6 +1448,7 @@ def main():
     two_mappers = run_two_mappers(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     unbounded = run_unbounded(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     in_flight = run_frames_in_flight(device, frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
+    pixel_holes = run_pixel_holes(device, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
 
     if rank == 0:
@@ -1460,9 +1520,49 @@ def main():
             "survey_8d_model_bytes_per_frame": survey_bytes,
             "survey_8d_model_frac": survey_bytes / t_frame / HBM_PEAK_BYTES_PER_S,
         }
+        # which build do the replayed counters (traffic, sq_counters) belong to?
+        from nvblox_mindmap_amd._lib import source_hash
+
+        build = source_hash()
+        pmc_stamp = counters_stamp(os.path.join(ROOT, "profiles", "latest_pmc.json"))
+        sq_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_summary.json"))
+        sq_stamp = counters_stamp(os.path.join(ROOT, "profiles", sq_files[-1])) if sq_files else None
+        roofline["build_csrc_sha16"] = build
+        roofline["traffic_csrc_sha16"] = pmc_stamp
+        roofline["sq_counters_csrc_sha16"] = sq_stamp
+        roofline["counters_stale"] = bool(pmc_stamp != build or sq_stamp != build)  # True: collected on other sources than the timed build
+        # the other shapes / paths of the same hot path, compactly (their full records are the top-level keys of the same names)
+        legs = {}
+        if ref_shape:
+            legs["reference_shape_512x512x768"] = {
+                "frames_per_s": ref_shape["frames_per_s"], "whole_frame_frac": ref_shape["whole_frame"]["frac_of_hbm_peak"],
+                "pipelined_frames_per_s": ref_shape["pipelined"]["frames_per_s"], "pipelined_whole_frame_frac": ref_shape["pipelined"]["frac_of_hbm_peak"],
+                "k_feature_flat_us": ref_shape.get("k_feature_flat_us"), "k_feature_flat_frac": ref_shape.get("k_feature_flat_frac_of_hbm_peak"),
+                "fused_lowres_ms": ref_shape["from_backbone_output"]["fused_lowres_ms"],
+                "fused_lowres_k_feature_flat_us": ref_shape["from_backbone_output"]["fused_lowres_k_feature_flat_us"],
+                "fused_lowres_pipelined_ms": ref_shape["from_backbone_output_pipelined"]["fused_lowres_ms"]}
+        if unbounded:
+            legs["unbounded_workspace_hash_path"] = {"frames_per_s": unbounded["frames_per_s"], "frac": unbounded["frac"],
+                                                     "live_blocks": unbounded["hash"]["live_blocks"]}
+        if pixel_holes:
+            legs["survey_8d_pixel_holes"] = {k_: pixel_holes[k_] for k_ in ("frames_per_s", "ms_per_step", "frac_of_hbm_peak",
+                                                                           "feature_voxels_updated_per_frame", "algorithmic_bytes_per_frame")}
+        if undeferred:
+            legs["undeferred_5_launches"] = {"frames_per_s": undeferred["frames_per_s"], "frac": undeferred.get("frac_of_hbm_peak")}
+        if train:
+            legs["train_step"] = {k_: train.get(k_) for k_ in ("step_per_s", "ms_per_step", "host_enqueue_ms_per_step", "host_enqueue_frac",
+                                                               "rccl_world_observed", "allreduce", "per_rank_ms_per_step", "parallelism",
+                                                               "backbone_matmuls", "tuned_gemms")}
+            legs["train_step"]["eager_ddp_ms_per_step"] = (train.get("eager_ddp_reference_shaped") or {}).get("ms_per_step")
+            legs["train_step"]["fp16_backbone_ms_per_step"] = (train.get("fp16_backbone_matmuls") or {}).get("ms_per_step")
+        if closed_loop:
+            legs["closed_loop_ms"] = closed_loop.get("ms_per_control_step") if isinstance(closed_loop, dict) else None
+        roofline["legs"] = legs
         cpu = None
         if args.cpu_sample > 0:
             cpu = cpu_baseline(cfg, mcfg, frames, C, min(args.cpu_sample, n_frames))
+        if cpu is not None and backproj:
+            cpu["backprojection"] = backproj  # the reference's CPU back-projection path beside the HIP kernel
         out = {
             "metric": "RGB-D+feature frames/s fused @1 cm voxels",
             "value": fps,
@@ -1511,6 +1611,7 @@ def main():
             "unbounded_workspace": unbounded,
             "frames_in_flight": in_flight,
             "backprojection": backproj,
+            "pixel_holes": pixel_holes,
             "train": train,
         }
         print(json.dumps(out), flush=True)
