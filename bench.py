@@ -1053,7 +1053,7 @@ def get_unbounded_mapper(mcfg, channels):
 UNBOUNDED_CLASSES = {"decay": "k_live_compact_big<wmax> + conditional hash rebuild (light decay: deallocation, tombstones)",
                      "raycast": "k_front (raycast | mask rows)",
                      "alloc": "k_alloc_big x2 (TSDF: hash lookups + CAS insertion | mask columns; colour | feature allocation)",
-                     "tsdf": "k_tsdf_pass (every live block: W *= f, integration of the stamped ones, appearance-candidate flags)",
+                     "tsdf": "k_tsdf_classify + k_tsdf_pass<lazy> (the frame's blocks: missed decays, integration; appearance-candidate flags)",
                      "sphere": "k_sphere_trace", "feature": "k_app_frame (colour update + feature gating)", "feature_flat": "k_feature_flat"}
 
 
@@ -1100,11 +1100,15 @@ def run_unbounded(device, frames, channels, steps=100, warmup=30):
     ncand = stats["color_blocks_updated"] / max(stats["color_frames"], 1)
     base = model
     model = {
-        UNBOUNDED_CLASSES["decay"]: n_live * (4 + 4 + 8) + n_new * 40,  # live entry + wmax + slot key per block; erase / free push per dead block
+        # live entry + wmax / wmin read and written (the lazy decay: one multiplication per live BLOCK) + slot key; erase / free push per dead block
+        UNBOUNDED_CLASSES["decay"]: n_live * (4 + 8 + 8 + 1 + 8) + n_new * 40,
         UNBOUNDED_CLASSES["raycast"]: base["k_front"],
         # view-grid flags read + cleared, one 16 B probe per candidate (twice: count, assign), 13 B of candidate list, CAS + value per new block
         UNBOUNDED_CLASSES["alloc"]: hs_cells * 2 + (n_upd + 2 * ncand) * (2 * 16 + 13) + n_new * 24 + 2 * n_live,
-        UNBOUNDED_CLASSES["tsdf"]: n_live * 512 * 16 + cfg.height * cfg.width * 4 + 32 * n_live,
+        # lazy decay: the pass reads and writes the blocks the frame integrates (a near-surface block it only
+        # looks at -- appearance flag -- is read; not counted: their number is not in the statistics); 10 B of list / stamp / band
+        # words per live block for the classification
+        UNBOUNDED_CLASSES["tsdf"]: n_upd * 512 * 16 + cfg.height * cfg.width * 4 + 10 * n_live + 36 * n_upd,
         "k_sphere_trace": base["k_sphere_alloc"],
         UNBOUNDED_CLASSES["feature"]: base["k_app_frame"],
         "k_feature_flat": base["k_feature_flat"],

@@ -715,7 +715,16 @@ __device__ inline void live_compact_big_body(const LayerDev& L, uint8_t* __restr
     if (i0 + q < n) {
       slot[q] = L.live[i0 + q];
       if (WMAX) {
-        dead[q] = L.wmax[slot[q]] * decay_f < decay_thr;
+        const float wm = L.wmax[slot[q]] * decay_f;
+        dead[q] = wm < decay_thr;
+        if (L.epoch && !dead[q]) {
+          // lazy decay (LayerDev::epoch): the voxels of this block stay behind; its summaries are brought forward here, one
+          // multiplication per decay like the voxels' own -- max / min commute with the monotone W -> W f exactly
+          L.wmax[slot[q]] = wm;
+          const float wn = L.wmin[slot[q]] * decay_f;
+          L.wmin[slot[q]] = wn;
+          if (!(wn > 1e-4f) && L.block_free[slot[q]]) L.block_free[slot[q]] = 0;  // all-free needs every W > 1e-4
+        }
       } else if (kill[i0 + q]) {
         dead[q] = true;
         kill[i0 + q] = 0;

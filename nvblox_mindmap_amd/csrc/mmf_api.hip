@@ -131,7 +131,7 @@ void free_layer(Layer& L) {
   if (L.d.block_free) (void)hipFree(L.d.block_free);
   if (L.d.wmax) (void)hipFree(L.d.wmax);
   if (L.d.stamp) (void)hipFree(L.d.stamp);
-  L = Layer{};
+  L = Layer{};  // (a mapper's lazy-decay arrays are its own: destroy_mapper)
 }
 
 void free_scratch(Scratch& sc) {
@@ -299,6 +299,10 @@ void destroy_mapper(Mapper* m) {
     (void)hipFree(m->sc[w].cand_count);
     (void)hipFree(m->sc[w].alloc_ctx);
   }
+  (void)hipFree(m->lazy_epoch_of);
+  (void)hipFree(m->lazy_wmin);
+  (void)hipFree(m->lazy_band);
+  (void)hipFree(m->lazy_work);
   (void)hipFree(m->mask_tmp);
   (void)hipFree(m->masked_depth);
   (void)hipFree(m->patch_flags);
@@ -452,10 +456,48 @@ int next_lb_tag(Mapper& m, hipStream_t s, unsigned* tag);
 bool big_mode(const Mapper& m, int ncells);
 int alloc_big_one(Mapper& m, const LayerDev& L, const KeySrc& ks, const Scratch& sc, int ncells, int stat_upd, int stat_new, hipStream_t s);
 
+// ---- lazy decay of large maps (Mapper::lazy_*) ------------------------------------------------------------------------------------
+int ensure_lazy(Mapper& m) {
+  if (m.lazy_epoch_of) return MMF_OK;
+  const size_t cap = (size_t)m.tsdf.d.cap;
+  HIP_TRY(hipMalloc(&m.lazy_epoch_of, sizeof(int) * cap));
+  HIP_TRY(hipMalloc(&m.lazy_wmin, sizeof(float) * cap));
+  HIP_TRY(hipMalloc(&m.lazy_band, cap));
+  HIP_TRY(hipMalloc(&m.lazy_work, sizeof(int) * (cap + 1)));
+  HIP_TRY(hipMemset(m.lazy_epoch_of, 0, sizeof(int) * cap));
+  HIP_TRY(hipMemset(m.lazy_wmin, 0, sizeof(float) * cap));
+  HIP_TRY(hipMemset(m.lazy_band, 0, cap));
+  return MMF_OK;
+}
+
+// the TSDF layer as the lazy-aware kernels see it
+LayerDev lazy_view(const Mapper& m) {
+  LayerDev L = m.tsdf.d;
+  L.epoch = m.lazy_epoch_of;
+  L.wmin = m.lazy_wmin;
+  L.band = m.lazy_band;
+  L.cur_epoch = m.lazy_epoch;
+  L.lag_f = m.mc.decay_factor;
+  return L;
+}
+
+int flush_lazy(mmf_handle h, Mapper& m, hipStream_t s) {
+  if (!m.lazy_lag) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  ProfScope ps(h, MMF_K_DECAY, s);
+  launch_lazy_catchup(lazy_view(m), s);
+  m.lazy_lag = false;
+  return MMF_OK;
+}
+
+void drop_lazy(Mapper& m) { m.lazy_valid = false; }
+
 void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
   if (!m.pending_decay) return;
+  (void)flush_lazy(h, m, s);  // (the eager decay multiplies the voxels as they are)
   m.pending_decay = false;
   m.wmax_valid = false;  // the stand-alone decay does not maintain wmax
+  m.lazy_valid = false;
   ProfScope ps(h, MMF_K_DECAY, s);
   if (m.tsdf.d.cap > 16384 && alloc_big_supported(m.tsdf.d) && m.mc.dealloc_decayed) {
     // large pools: the voxel pass marks the dead blocks, the scalable compaction drops them (one launch instead of a single
@@ -471,6 +513,7 @@ void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
 
 int get_mapper_ready(mmf_handle h, int id, Mapper** out, void* stream) {
   MMF_TRY(get_mapper_on(h, id, out, stream));
+  MMF_TRY(flush_lazy(h, **out, (hipStream_t)stream));
   if ((*out)->pending_decay) {
     HIP_TRY(hipSetDevice(h->device));
     flush_decay(h, **out, (hipStream_t)stream);
@@ -742,6 +785,7 @@ int depth_chain(mmf_handle h, Mapper& m, const float* depth, const uint8_t* mask
   {
     ProfScope ps(h, MMF_K_TSDF, s);
     m.wmax_valid = false;  // the stand-alone integrator does not maintain wmax
+    m.lazy_valid = false;
     launch_tsdf_integrate(m.tsdf.d, m.mc, cam, T_C_L, depth, mask, min_d, m.sc[0], ncells < m.tsdf.d.cap ? ncells : m.tsdf.d.cap, s);
   }
   return MMF_OK;
@@ -876,6 +920,8 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
     MMF_TRY(depth_chain(h, *m, depth, mask, 0.0f, cam, T_L_C, T_C_L, s));
     return check_launch();
   }
+  MMF_TRY(flush_lazy(h, *m, s));
+  m->lazy_valid = false;  // (this launch does not maintain the lazy summaries)
   if (m->pending_decay && !m->wmax_valid) flush_decay(h, *m, s);  // wmax stale: the decay needs its pass over the voxels
   const bool do_decay = m->pending_decay;                          // (else: light -- decided from wmax, W *= f in the TSDF pass)
   m->pending_decay = false;
@@ -1127,6 +1173,14 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   MMF_TRY(ensure_scratch(*m, 0, ncells));
   const int sub = m->P.raycast_subsampling < 1 ? 1 : m->P.raycast_subsampling;
   if (big && m->pending_decay && !m->wmax_valid) flush_decay(h, *m, s);  // that decay needs its voxel pass: eager, scalable compaction
+  // Lazy decay (large maps): with the per-block summaries in place (a previous fused frame of this kind
+  // established them) a decay costs one multiplication per live block, the TSDF pass visits only the blocks the frame integrates
+  // and the near-surface blocks whose appearance flag needs their voxels, and a block's voxels catch up when it is next visited.
+  // Needs the decay's deallocation rule (the compaction launch is what brings the summaries forward).
+  if (big) MMF_TRY(ensure_lazy(*m));
+  const bool lazy = big && m->lazy_valid && m->wmax_valid && m->mc.dealloc_decayed && m->mc.decay_thr > 0.0f && m->mc.decay_factor > 0.0f;
+  if (!lazy) MMF_TRY(flush_lazy(h, *m, s));
+  if (!big) m->lazy_valid = false;  // (the bounded launches do not maintain the lazy summaries)
   const bool do_decay = m->pending_decay;
   m->pending_decay = false;
   // wmax current (the previous writer of the TSDF weights was a fused frame): the decay's deallocations are decided from it by
@@ -1141,8 +1195,13 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     ProfScope ps(h, MMF_K_DECAY, s);
     unsigned tag = 1;
     MMF_TRY(next_lb_tag(*m, s, &tag));
-    launch_live_compact_big(m->tsdf.d, true, nullptr, nullptr, m->lb_compact, tag, m->rebuild_flag, nullptr, m->mc.decay_factor,
-                            m->mc.decay_thr, m->tsdf.d.cap, s);
+    // (lazy: the same launch multiplies the survivors' wmax / wmin and keeps block_free current -- their voxels stay behind)
+    launch_live_compact_big(lazy ? lazy_view(*m) : m->tsdf.d, true, nullptr, nullptr, m->lb_compact, tag, m->rebuild_flag, nullptr,
+                            m->mc.decay_factor, m->mc.decay_thr, m->tsdf.d.cap, s);
+    if (lazy) {
+      m->lazy_epoch++;
+      m->lazy_lag = true;
+    }
   }
   int grid_tag = 1;
   if (merged)
@@ -1209,9 +1268,15 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     {
       // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
       ProfScope ps(h, MMF_K_TSDF, s);
-      launch_tsdf_pass(m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags, m->sc[1].cell_key,
-                       light_decay ? m->mc.decay_factor : 0.0f, s);
-      m->wmax_valid = true;  // k_tsdf_pass refreshed it for every live block
+      if (lazy) {
+        launch_tsdf_pass_lazy(lazy_view(*m), m->mc, cam, T_C_L, m->masked_depth, stamp, m->sc[1].flags, m->sc[1].cell_key, m->lazy_work, s);
+      } else {
+        // (a large map's full pass also establishes the lazy summaries: the next fused frame can decay lazily)
+        launch_tsdf_pass(big ? lazy_view(*m) : m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags,
+                         m->sc[1].cell_key, light_decay ? m->mc.decay_factor : 0.0f, s);
+        m->lazy_valid = big;
+      }
+      m->wmax_valid = true;  // k_tsdf_pass refreshed it for every live block (lazy: the compaction keeps it current)
     }
   }
   {
@@ -1243,7 +1308,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     if (big) {
       if (need) {
         ProfScope ps(h, MMF_K_SPHERE, s);
-        launch_sphere_trace(m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, s);
+        launch_sphere_trace(m->lazy_lag ? lazy_view(*m) : m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, s);
         synth_commit(*m, cam, T16, K9, Ws, Hs);
       }
       ProfScope ps(h, MMF_K_ALLOC, s);
@@ -1358,7 +1423,7 @@ static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGr
   if (ncells <= 0 || !alloc_jobs_fusable(ncells, m.tsdf.d.cap) || ncells > m.sc_cap[0] || m.tsdf.d.cap > m.sc_cap[1] ||
       m.tsdf.d.cap > m.sc_cap[2])
     return false;
-  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & 2)) return false;
+  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & 2) || m.lazy_lag) return false;
   if (m.pending_decay && !m.wmax_valid) return false;  // that decay needs its voxel pass: separate launches
   const int sf = m.mc.st_sf;
   if (in.W / sf <= 0 || in.H / sf <= 0 || (in.W / sf) * (in.H / sf) > m.synth_cap) return false;
@@ -1422,6 +1487,7 @@ static int pair_prepare(mmf_handle h, Mapper& m, const FrameIn& in, MaskJob M, c
   F.at = make_alloc_tsdf_args(job0, m.stats, M, m.mc, cam, T_C_L, m.masked_depth, vg, m.sc[1].flags, m.sc[1].cell_key,
                               do_decay ? m.mc.decay_factor : 0.0f);
   m.wmax_valid = true;
+  m.lazy_valid = false;
   KeySrc ks{};
   ks.mode = 1;
   ks.n_live = m.tsdf.d.ctr;
@@ -1779,6 +1845,8 @@ int mmf_clear(mmf_handle h, int mapper_id, void* stream) {
     m->hints[7] = 0;           // (k_reset_layer zeroes the layer's error bits)
     launch_layer_reset(m->tsdf.d, s);
     m->wmax_valid = true;  // no live block
+    m->lazy_valid = m->lazy_epoch_of != nullptr;  // (ditto: the summaries hold trivially)
+    m->lazy_lag = false;
     if (m->color.allocated) launch_layer_reset(m->color.d, s);
     if (m->feat.allocated) launch_layer_reset(m->feat.d, s);
     m->tsdf_epoch++;

@@ -98,6 +98,16 @@ struct Mapper {
   bool pending_decay = false;  // Mapper.decay() not applied yet: consumed by the next fused frame or flushed eagerly
   bool wmax_valid = true;      // (an empty map trivially) tsdf.d.wmax holds every live block's largest weight (set by a fused frame, cleared by whatever
                                // else writes TSDF weights): a pending decay can then take the light path
+  // Lazy decay of a large (hash-indexed) map, fused frames only (LayerDev::epoch): a decay is one multiplication
+  // per live BLOCK (its summaries, in the list compaction) instead of one per voxel; a block's voxels catch up when the block is next
+  // integrated, or all at once (flush_lazy) before anything else reads or writes voxel weights.
+  int* lazy_epoch_of = nullptr;   // [cap] device: LayerDev::epoch
+  float* lazy_wmin = nullptr;     // [cap] device: LayerDev::wmin
+  uint8_t* lazy_band = nullptr;   // [cap] device: LayerDev::band
+  int* lazy_work = nullptr;       // [cap + 1] device: work list of the lazy pass
+  int lazy_epoch = 0;             // decays applied lazily so far
+  bool lazy_valid = false;        // the three summaries hold for every live block (established by a full pass, kept by lazy passes)
+  bool lazy_lag = false;          // some block's voxels may be behind lazy_epoch
   // mesh
   int* mesh_counts = nullptr;
   int* mesh_offsets = nullptr;
@@ -209,5 +219,7 @@ int ensure_synth(mmf_handle h, Mapper& m, const Cam& cam, const Rigid& T_L_C, co
 int report_device_errors(mmf_handle h, Mapper& m, Layer* layer, const int* err_bits, hipStream_t s);
 int ensure_app_layer(Mapper& m, Layer& L, size_t block_bytes, bool has_w);
 int attach_dense_table(const Mapper& m, Layer& L);
+int flush_lazy(mmf_handle h, Mapper& m, hipStream_t s);  // voxels of a lazily decayed map brought up to date (no-op otherwise)
+void drop_lazy(Mapper& m);                               // something else wrote TSDF weights: the lazy summaries no longer hold
 
 }  // namespace mmf_host

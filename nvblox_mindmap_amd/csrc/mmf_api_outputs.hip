@@ -249,7 +249,11 @@ int mmf_import_blocks(mmf_handle h, int mapper_id, int layer, const int32_t* idx
   if (n > L.d.cap)
     return fail(MMF_ERR_POOL_EXHAUSTED, "saved layer has " + std::to_string(n) + " blocks, the pool holds " + std::to_string(L.d.cap));
   if (layer == MMF_LAYER_TSDF) m->pending_decay = false;  // the content it would have decayed is replaced
-  if (layer == MMF_LAYER_TSDF) m->wmax_valid = false;  // imported weights: wmax is rebuilt by the next fused frame
+  if (layer == MMF_LAYER_TSDF) {
+    m->wmax_valid = false;  // imported weights: wmax is rebuilt by the next fused frame
+    m->lazy_lag = false;    // (the voxels that were behind are replaced)
+    drop_lazy(*m);
+  }
   launch_layer_reset(L.d, s);
   launch_import_index(L.d, idx, n, s);
   if (n > 0) {
@@ -384,6 +388,7 @@ int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, i
   out8[4] = m->last_vg.nx;
   out8[5] = m->last_vg.ny;
   out8[6] = m->last_vg.nz;
+  out8[7] = m->lazy_epoch;  // decays applied lazily so far (large maps: one multiplication per live block, voxels catch up later)
   if (!L->allocated) return MMF_OK;
   HIP_TRY(hipSetDevice(h->device));
   int c[8];

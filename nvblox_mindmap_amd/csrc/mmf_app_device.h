@@ -13,6 +13,7 @@ namespace mmf {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load with dword alignment
 typedef unsigned short ushort_u __attribute__((aligned(1)));             // 2-byte load with byte alignment
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));                 // a channel pair: v_pk_mul_f32 / v_pk_add_f32
 
 // ------------------------------------------------------------------------------------------------
@@ -308,10 +309,13 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
             const f32x2 r1x0 = X0.l0 * c + X0.l1 * d, r1x1 = X1.l0 * c + X1.l1 * d;  // lower texel row
             const f32x2 v00 = Y0.l0 * r0x0 + Y0.l1 * r1x0, v10 = Y0.l0 * r0x1 + Y0.l1 * r1x1;
             const f32x2 v01 = Y1.l0 * r0x0 + Y1.l1 * r1x0, v11 = Y1.l0 * r0x1 + Y1.l1 * r1x1;
-            t00[4 * h + k] = (_Float16)v00.x, t00[4 * h + k + 1] = (_Float16)v00.y;
-            t10[4 * h + k] = (_Float16)v10.x, t10[4 * h + k + 1] = (_Float16)v10.y;
-            t01[4 * h + k] = (_Float16)v01.x, t01[4 * h + k + 1] = (_Float16)v01.y;
-            t11[4 * h + k] = (_Float16)v11.x, t11[4 * h + k + 1] = (_Float16)v11.y;
+            // (two channels per conversion: v_cvt_pk_f16_f32, round to nearest even like the scalar cast)
+            const half2v c00 = __builtin_convertvector(v00, half2v), c10 = __builtin_convertvector(v10, half2v);
+            const half2v c01 = __builtin_convertvector(v01, half2v), c11 = __builtin_convertvector(v11, half2v);
+            t00[4 * h + k] = c00.x, t00[4 * h + k + 1] = c00.y;
+            t10[4 * h + k] = c10.x, t10[4 * h + k + 1] = c10.y;
+            t01[4 * h + k] = c01.x, t01[4 * h + k + 1] = c01.y;
+            t11[4 * h + k] = c11.x, t11[4 * h + k + 1] = c11.y;
           }
           if (h == 0) __builtin_amdgcn_sched_barrier(0);
         }

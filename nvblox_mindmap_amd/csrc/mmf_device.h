@@ -83,6 +83,19 @@ struct LayerDev {
   int* hint_live;  // pinned host int (may be null): last live-block count, read by the host to size later grids
   int d_lo[3];
   int d_ny, d_nz, d_ncells;
+  // TSDF layer only: LAZY DECAY of large hash-indexed maps.  A decay multiplies every voxel weight by f; in a
+  // map of 10^5 live blocks of which a frame touches a fifth, that is the frame's dominant traffic.  Instead a block's voxels
+  // stay `cur_epoch - epoch[slot]` decays behind until the block is next integrated (the TSDF pass applies the missing
+  // multiplications first, one by one: the same float operations as the eager decays) or read (k_lazy_catchup before any
+  // consumer of voxel weights; the sphere tracer applies them to the weight it samples).  The per-block summaries are kept
+  // CURRENT by the decay's list compaction, which touches one word per live block anyway: wmax (deallocation: all W f < thr
+  // <=> max W f < thr), wmin and block_free (all-free needs min W > 1e-4); multiplication by f > 0 is monotone, so max / min
+  // commute with it exactly.  epoch == nullptr: the layer is not in lazy mode (every kernel then behaves as before).
+  int* epoch;            // [cap] the decay epoch the block's voxel weights are current to
+  float* wmin;           // [cap] smallest voxel weight of the block, current
+  unsigned char* band;   // [cap] 1 iff a voxel had W > 0 and |D| < trunc when the block was last written (appearance candidates)
+  int cur_epoch;         // decays applied lazily so far
+  float lag_f;           // their factor
 };
 
 __device__ inline int dense_cell(const LayerDev& L, int x, int y, int z) {

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
 constexpr int kRayLanes = 16;
 
 // One 4x4 ray patch = 256 threads (4 whole waves; no LDS, no barriers: the body may share a workgroup with other roles).
+// LAZY: the map is lazily decayed (LayerDev::epoch): a sampled voxel's weight may be cur_epoch - epoch[slot] decays behind -- the
+// missing multiplications are applied to the sampled value (block_free is kept current by the decay's compaction).
+template <bool LAZY = false>
 __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C,
                                     float* __restrict__ synth, int Ws, int Hs, int patches_x, int patch, int tid,
                                     int* trace_iters = nullptr) {
@@ -171,7 +174,11 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
           S.D = c_trunc;
         } else {
           const float2 dw = reinterpret_cast<const float2*>(T.pool)[(size_t)slot * kVPB + S.lin];
-          if (dw.y > 1e-4f) {
+          float w = dw.y;
+          if (LAZY) {
+            for (int lag = T.cur_epoch - T.epoch[slot]; lag > 0; --lag) w = w * T.lag_f;
+          }
+          if (w > 1e-4f) {
             S.valid = true;
             S.D = dw.x;
           }
@@ -286,9 +293,10 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
 #endif
 }
 
+template <bool LAZY>
 __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
                                                      int Ws, int Hs, int patches_x) {
-  sphere_patch(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, blockIdx.x, threadIdx.x);
+  sphere_patch<LAZY>(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, blockIdx.x, threadIdx.x);
 }
 
 // Horizontal fusion: the sphere trace (reads the TSDF layer) and the block allocation of the colour and the feature layer
@@ -535,7 +543,10 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
   const int n = patches_x * patches_y;
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_sphere_trace, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+  if (tsdf.epoch)  // a lazily decayed map: sampled weights are brought up to date on the fly
+    hipLaunchKernelGGL(k_sphere_trace<true>, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+  else
+    hipLaunchKernelGGL(k_sphere_trace<false>, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
 }
 
 SphereArgs make_sphere_args(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,

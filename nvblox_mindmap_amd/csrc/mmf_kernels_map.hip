@@ -585,22 +585,34 @@ __device__ inline bool tsdf_voxel_update(const MapConsts& mc, const Cam& cam, co
 // What a pass learns about a block while it holds its voxels: an appearance-candidate voxel in view (hit), every voxel observed
 // free space (freev: the sphere tracer's empty-space summary), the largest weight (wmx: the lazy decay's deallocation test).
 struct TsdfBlockAcc {
-  int hit = 0, freev = 1;
-  float wmx = 0.0f;
+  int hit = 0, freev = 1, band = 0;
+  float wmx = 0.0f, wmn = 3.0e38f;
 };
 
 // VPT z-adjacent voxels of one thread (VPT / 2 float4 = {D, W, D, W}): load (or zeros for a new block), the pending decay's
 // W *= f, the update above per voxel, write back when anything changed.  The only copy of the per-thread voxel loop.
-template <int VPT, bool MASKED>
+// `lag` (block-uniform): how many decays the stored weights are behind -- applied one multiplication at a time, exactly as the
+// eager decays would have been (1 for the pending decay of a bounded map, cur_epoch - epoch[slot] in lazy mode, 0: none).
+// `may_write` false: a read-only visit (lazy mode, a block this frame does not integrate: only its appearance flag is wanted).
+// LAGLOOP false: lag is 0 or 1 (the hot bounded kernels: one predicated multiplication, no loop).
+template <int VPT, bool MASKED, bool LAGLOOP = false>
 __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
-                                        const uint8_t* __restrict__ mask, float min_d, float decay_f, int bx, int by, int bz, int lin0,
-                                        bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc) {
+                                        const uint8_t* __restrict__ mask, float min_d, float decay_f, int lag, bool may_write, int bx, int by,
+                                        int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc) {
   constexpr int NP = VPT / 2;
   float4 av[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
-  const bool decayed = decay_f > 0.0f;  // uniform
-  if (decayed) {
+  const bool decayed = lag > 0;  // uniform
+  if (LAGLOOP) {
+    for (int l = 0; l < lag; ++l) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        av[q].y = av[q].y * decay_f;
+        av[q].w = av[q].w * decay_f;
+      }
+    }
+  } else if (decayed) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       av[q].y = av[q].y * decay_f;
@@ -624,11 +636,14 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
       a.x = D;
       a.y = W;
     }
-    acc.hit |= (W > 0.0f && fabsf(D) < mc.trunc && in_view) ? 1 : 0;
+    const bool near = W > 0.0f && fabsf(D) < mc.trunc;
+    acc.hit |= (near && in_view) ? 1 : 0;
+    acc.band |= near ? 1 : 0;
     acc.freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
     acc.wmx = fmaxf(acc.wmx, W);
+    acc.wmn = fminf(acc.wmn, W);
   }
-  if (upd || is_new || decayed) {
+  if (may_write && (upd || is_new || decayed)) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) vox[q] = av[q];
   }
@@ -667,23 +682,35 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // live block of a bounded workspace is resident at once (at four waves per block 1 792 of ~2 300 fitted and the rest formed a
 // second round).
 // MASKED = false: the depth image is already masked (the fused frame's masked depth): the mask taps are compiled out.
-template <int VPT, bool MASKED>
+// LAZY (large hash-indexed maps): the pass walks the WORK LIST k_tsdf_classify made of the live list --
+// the blocks this frame integrates plus the near-surface blocks whose appearance flag needs their voxels -- instead of every live
+// block; a block's missing decays (cur_epoch - epoch[slot]) are applied before it is integrated, a block that is only looked at
+// is not written.  Not LAZY on a layer with lazy summaries (L.epoch != nullptr): the full pass that (re)establishes them.
+template <int VPT, bool MASKED, bool LAZY>
 __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                         const float* __restrict__ depth, const uint8_t* __restrict__ mask_arg,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
-                                                        u64* __restrict__ cell_key, float decay_f) {
+                                                        u64* __restrict__ cell_key, float decay_f, const int* __restrict__ work) {
   // decay_f > 0: a Mapper.decay() is pending whose deallocations k_front already made from L.wmax -- its W *= f is applied
   // here, on the voxels this pass loads anyway (and every block is written back).  L.wmax is refreshed for every live block.
   static_assert(VPT == 2 || VPT == 4 || VPT == 8, "one, two or four 16-byte voxel pairs per thread");
-  __shared__ float s_wmax[512 / VPT / 64];
+  // (two sets, alternating: thread 0 reads an iteration's set after the barrier while the other waves may already fill the next one)
+  __shared__ float s_wmax2[2][512 / VPT / 64], s_wmin2[2][512 / VPT / 64];
+  __shared__ int s_band2[2][512 / VPT / 64];
+  int par = 0;
   constexpr int NP = VPT / 2;  // float4 = two {distance, weight} voxels
   const uint8_t* __restrict__ mask = MASKED ? mask_arg : nullptr;
   const long long tr0 = wg_trace_begin();
-  const int n = L.ctr[0];
+  const int n = LAZY ? work[0] : L.ctr[0];
   const int chunk = (n + 7) >> 3;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
-    const int i = xcd_candidate(j, chunk);
-    if (i >= n) continue;
+    const int iw = xcd_candidate(j, chunk);
+    if (iw >= n) continue;
+    par ^= 1;
+    float* s_wmax = s_wmax2[par];
+    float* s_wmin = s_wmin2[par];
+    int* s_band = s_band2[par];
+    const int i = LAZY ? work[1 + iw] : iw;
     const int slot = L.live[i];
     const u64 key = L.slot_key[slot];
     const int st = L.stamp[slot];
@@ -691,28 +718,102 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x * NP;
-    const bool decayed = decay_f > 0.0f;  // uniform
+    const int lag = LAZY ? (is_new ? 0 : L.cur_epoch - L.epoch[slot]) : (decay_f > 0.0f ? 1 : 0);  // uniform
+    const float f = LAZY ? L.lag_f : decay_f;
+    const bool writes = !LAZY || cand;
     TsdfBlockAcc acc;
-    tsdf_voxel_group<VPT, MASKED>(mc, cam, T_C_L, depth, mask, min_d, decay_f, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
+    tsdf_voxel_group<VPT, MASKED, LAZY>(mc, cam, T_C_L, depth, mask, min_d, f, lag, writes, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
     const int hit = acc.hit, freev = acc.freev;
-    float wmx = acc.wmx;
-    if (cand || decayed) {  // workgroup-uniform: the block's voxels changed -> its empty-space summary may have
+    float wmx = acc.wmx, wmn = acc.wmn;
+    if (writes && (cand || lag > 0)) {  // workgroup-uniform: the block's voxels changed -> its empty-space summary may have
       const int all_free = __syncthreads_and(freev);
       if (threadIdx.x == 0) L.block_free[slot] = all_free ? 1 : 0;
     }
     wmx = wave_max_f32(wmx);
-    if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmx;
-    const int any = __syncthreads_or(hit);  // (also orders s_wmax)
+    wmn = -wave_max_f32(-wmn);
+    const int w_band = __any(acc.band) ? 1 : 0;
+    if ((threadIdx.x & 63) == 0) {
+      s_wmax[threadIdx.x >> 6] = wmx;
+      s_wmin[threadIdx.x >> 6] = wmn;
+      s_band[threadIdx.x >> 6] = w_band;
+    }
+    const int any = __syncthreads_or(hit);  // (also orders s_wmax / s_wmin / s_band)
     if (threadIdx.x == 0) {
+      int any2 = 0;
+#pragma unroll
+      for (int q = 0; q < 512 / VPT / 64; ++q) any2 |= s_band[q];
+      any2 <<= 1;
       flags[i] = any ? 1 : 0;
       if (any) cell_key[i] = key;
-      float m = s_wmax[0];
+      if (writes) {
+        float m = s_wmax[0], mn = s_wmin[0];
 #pragma unroll
-      for (int q = 1; q < 512 / VPT / 64; ++q) m = fmaxf(m, s_wmax[q]);
-      L.wmax[slot] = m;
+        for (int q = 1; q < 512 / VPT / 64; ++q) {
+          m = fmaxf(m, s_wmax[q]);
+          mn = fminf(mn, s_wmin[q]);
+        }
+        L.wmax[slot] = m;
+        if (L.epoch) {  // the lazy summaries of a large map
+          L.wmin[slot] = mn;
+          L.band[slot] = (unsigned char)(any2 >> 1);
+          L.epoch[slot] = L.cur_epoch;
+        }
+      }
     }
   }
   wg_trace_end(tr0, kTrTsdfPass);
+}
+
+// The work list of a lazy pass: one thread per live block.  A block the frame integrates (its allocation job stamped it), or one
+// with near-surface voxels (band: its appearance flag depends on which of them are in view), goes on the list; any other block's
+// flag is 0 and its voxels are not touched.  work[0] = count (zeroed by the host), work[1 ..] = live-list positions, in no
+// particular order (blocks are independent).
+__global__ __launch_bounds__(256) void k_tsdf_classify(LayerDev L, int stamp, uint8_t* __restrict__ flags, int* __restrict__ work) {
+  __shared__ int s_cnt[4], s_base;
+  const int n = L.ctr[0];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i0 = (int)blockIdx.x * 256; i0 < n; i0 += (int)gridDim.x * 256) {  // workgroup-uniform trip count
+    const int i = i0 + (int)threadIdx.x;
+    bool take = false;
+    if (i < n) {
+      const int slot = L.live[i];
+      take = (L.stamp[slot] >> 1) == stamp || L.band[slot] != 0;
+      if (!take) flags[i] = 0;
+    }
+    // one atomic per workgroup (1 500 same-address atomics, one per wave, cost more than the rest of the kernel)
+    const unsigned long long b = __ballot(take);
+    if (lane == 0) s_cnt[wv] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      s_base = tot ? atomicAdd(work, tot) : 0;
+    }
+    __syncthreads();
+    int base = s_base;
+    for (int q = 0; q < wv; ++q) base += s_cnt[q];
+    if (take) work[1 + base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();  // (s_cnt / s_base are rewritten by the next round)
+  }
+}
+
+// Every live block's voxels brought up to the current decay epoch (before anything reads voxel weights of a lazily decayed map,
+// or writes them outside the lazy pass): the missing multiplications, one by one.
+__global__ __launch_bounds__(128) void k_lazy_catchup(LayerDev L) {
+  const int n = L.ctr[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = L.live[i];
+    const int lag = L.cur_epoch - L.epoch[slot];  // uniform
+    if (lag <= 0) continue;
+    float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + threadIdx.x * 2;
+    float4 a = vox[0], b = vox[1];
+    for (int l = 0; l < lag; ++l) {
+      a.y = a.y * L.lag_f, a.w = a.w * L.lag_f;
+      b.y = b.y * L.lag_f, b.w = b.w * L.lag_f;
+    }
+    vox[0] = a, vox[1] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) L.epoch[slot] = L.cur_epoch;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -749,7 +850,8 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
     unpack_key(key, bx, by, bz);
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + t * 2;
     TsdfBlockAcc acc;
-    tsdf_voxel_group<4, false>(mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, bx, by, bz, t * 4, cand, is_new, vox, acc);
+    tsdf_voxel_group<4, false>(mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, decayed ? 1 : 0, true, bx, by, bz, t * 4, cand, is_new, vox,
+                               acc);
     hit = acc.hit;
     freev = acc.freev;
     wmx = acc.wmx;
@@ -1542,9 +1644,25 @@ void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, co
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
   const dim3 grid(grid_for(hinted(L.hint_live, L.cap), 8192));
   if (mask)
-    hipLaunchKernelGGL((k_tsdf_pass<4, true>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
+    hipLaunchKernelGGL((k_tsdf_pass<4, true, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
+                       (const int*)nullptr);
   else
-    hipLaunchKernelGGL((k_tsdf_pass<4, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f);
+    hipLaunchKernelGGL((k_tsdf_pass<4, false, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
+                       (const int*)nullptr);
+}
+
+// the lazy form (L.epoch / L.cur_epoch / L.lag_f set): classify the live list, then pass over the work list only
+void launch_tsdf_pass_lazy(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth, int stamp,
+                           uint8_t* flags, u64* cell_key, int* work, hipStream_t s) {
+  const int live = hinted(L.hint_live, L.cap);
+  (void)hipMemsetAsync(work, 0, sizeof(int), s);
+  hipLaunchKernelGGL(k_tsdf_classify, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, s, L, stamp, flags, work);
+  hipLaunchKernelGGL((k_tsdf_pass<4, false, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr, 0.0f,
+                     stamp, flags, cell_key, 0.0f, (const int*)work);
+}
+
+void launch_lazy_catchup(const LayerDev& L, hipStream_t s) {
+  hipLaunchKernelGGL(k_lazy_catchup, dim3(grid_for(hinted(L.hint_live, L.cap), 8192)), dim3(128), 0, s, L);
 }
 
 // allocation | mask columns | TSDF pass (existing blocks beside the allocation, new blocks behind it): a frame's share of k_alloc_tsdf

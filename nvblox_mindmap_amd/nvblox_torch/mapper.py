@@ -769,6 +769,7 @@ class Mapper:
         _lib.check(_lib.lib().mmf_debug_hash_state(self._h, mapper_id, int(layer), self._stream(), buf), "mmf_debug_hash_state")
         out = dict(zip(["table_entries", "tombstones", "rebuilds", "live_blocks"], [int(x) for x in buf[:4]]))
         out["view_grid"] = [int(buf[4]), int(buf[5]), int(buf[6])]
+        out["lazy_decays"] = int(buf[7])
         return out
 
     def reset_stats(self, mapper_id: int = 0) -> None:

@@ -85,3 +85,37 @@ def test_unbounded_full_size_decay_churn_rebuilds_the_table(oracle_mod):
     compare_features(orc, gpu)
     stats = gpu.stats(0)
     assert stats["tsdf_blocks_allocated"] - gpu.hash_state(0)["live_blocks"] > 8192, "the churn must exceed a quarter of the table"
+
+
+def test_lazy_decay_of_a_large_map_matches_the_eager_oracle(oracle_mod):
+    """Fused frames into an unbounded map decay LAZILY: a decay multiplies the per-block summaries, a block's
+    voxels catch up -- multiplication by multiplication -- when the block is next integrated, sampled by the sphere tracer, or read.
+    A camera hopping around the orbit under a strong decay (blocks leave the view, stay behind for several decays, die or come
+    back) against the oracle's eager decay, bit for bit: with a mesh read and a stand-alone call in mid-stream (both force the
+    catch-up and the second drops the lazy state), and the laziness really engaged."""
+    cfg = S.StreamConfig(hole_mode="patches")
+    over = dict(workspace_bounds_type=0, tsdf_decay_factor=0.4, decayed_weight_threshold=1e-3, max_integration_distance_m=2.5,
+                num_preallocated_blocks=32768)
+    gpu, orc = make_mapper(16, **over), make_oracle(oracle_mod, 16, **over)
+    for k in range(16):
+        index = (k * 37) % cfg.num_poses
+        if k == 9:  # a stand-alone call between fused frames: eager decay + three-kernel chain on caught-up voxels
+            f = S.frame(cfg, index, 16)
+            orc.decay()
+            gpu.decay()
+            orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"])
+            gpu.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+            continue
+        fused_frame(gpu, orc, cfg, index, 16, 3, 4, 5)
+        if k == 5:  # a reader in mid-stream sees current weights
+            ov, _ = orc.feature_mesh()
+            assert np.array_equal(gpu.get_feature_mesh(0).vertices().cpu().numpy(), ov)
+    st = gpu.hash_state(0)
+    assert st["lazy_decays"] >= 10 and st["live_blocks"] == orc.num_blocks(0), st
+    assert gpu.stats(0)["tsdf_blocks_allocated"] > st["live_blocks"] + 500, "blocks must have died along the way"
+    mx, exact = compare_tsdf(orc, gpu)
+    assert exact
+    compare_features(orc, gpu)
+    ov, of = orc.feature_mesh()
+    mesh = gpu.get_feature_mesh(0)
+    assert np.array_equal(mesh.vertices().cpu().numpy(), ov)
