@@ -901,9 +901,7 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
     values) and next to every .png (same pixels, no inflate); the decompress-everything path the reference's loader takes is timed
     beside it, loader only, at the same worker count and at the reference's 20.  What counts for "8 loaders on one host" is the
     CPU the workers BURN, not how many processes wait on a queue: `loader_cpu_cores_used` = CPU milliseconds per sample (decode +
-    sampling + collation, process time of a probe in this process) x the samples per second the timed steps consumed.  (The processes are kept at 10: the training step is host-bound -- ~95 ms of
-    kernel launches per step under the interpreter lock -- and the loader's pinning thread in the same process only gets the lock
-    in slices; a deeper queue of finished batches rides that out, 6 processes reach 0.83 of the compute-bound rate, 10 reach 0.99.)"""
+    sampling + collation, process time of a probe in this process) x the samples per second the timed steps consumed.  (The step is the captured one, training.GraphedTrainStep: its host side is ~1 ms per step, so the loader's pinning thread in the same process is no longer starved of the interpreter lock as it was under the eager step's ~70 ms of launches.)"""
     import shutil
     import tempfile
 
@@ -978,31 +976,44 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
         del probe
 
         it = batches()
+        # the captured step (training.GraphedTrainStep: the training leg's headline form), fed from files: it reads one batch
+        # ahead (the next batch's frozen backbone runs beside the current batch's trainable pass)
+        from nvblox_mindmap_amd.training import GraphedTrainStep
+
+        cur = next(it)
+        g = GraphedTrainStep(cfg, model, cur)
+        del opt
+
+        def fed_steps(n, cur):
+            for _ in range(n):
+                nxt = next(it)
+                g.step(cur, nxt)
+                cur = nxt
+            return cur
+
         # untimed: the new epoch's workers have to refill their prefetch queues (each needs ~0.5 s for its first batch); timing
         # from the first batch on measures that start-up transient, not the steady state
-        for _ in range(8):
-            train_one_step(cfg, model, opt, next(it))
+        cur = fed_steps(8, cur)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            train_one_step(cfg, model, opt, next(it))
+        cur = fed_steps(steps, cur)
         torch.cuda.synchronize(device)
         wall = time.perf_counter() - t0
         fed = steps / wall
         loader_cores = cpu_ms_per_sample * 1e-3 * fed * per_gpu_batch  # CPU seconds of loader work per wall second
-        # the comparator under the SAME conditions: this process, this model, the loader's workers alive but idle, one batch
-        # resident on the device (the training leg's figure comes from another model instance and 8 steps: +-3 % between runs)
-        resident_batch = next(it)
-        for _ in range(3):
-            train_one_step(cfg, model, opt, resident_batch)
+        # the comparator under the SAME conditions: this process, this model, the loader's workers alive but idle, two batches
+        # resident on the device (the training leg's figure comes from another model instance: +-3 % between runs)
+        pair = [cur, next(it)]
+        for i in range(3):
+            g.step(pair[i % 2], pair[(i + 1) % 2])
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            train_one_step(cfg, model, opt, resident_batch)
+        for i in range(3, 3 + steps):
+            g.step(pair[i % 2], pair[(i + 1) % 2])
         torch.cuda.synchronize(device)
         resident = steps / (time.perf_counter() - t0)
         training_leg_step_per_s, compute_bound_step_per_s = compute_bound_step_per_s, resident
-        del dl, it, model, opt, resident_batch
+        del dl, it, model, g, pair, cur
     finally:
         shutil.rmtree(root, ignore_errors=True)
         torch.set_num_threads(host_threads_before)
@@ -1442,7 +1453,7 @@ def main():
                                           "note": "frozen backbone under float16 autocast (10-bit mantissa like the reference's TF32 "
                                                   "backbone, fp32 accumulate); everything trainable stays float32"}
         if rank == 0 and not args.no_file_fed:
-            train["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=eager["step_per_s"])
+            train["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=train["step_per_s"])
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     model_inputs = None

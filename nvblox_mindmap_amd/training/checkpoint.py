@@ -89,6 +89,9 @@ def load_train_checkpoint(checkpoint_path: str, model, optimizer, initial_learni
     if "optimizer" in model_dict and not from_reference:
         optimizer.load_state_dict(model_dict["optimizer"])
         if initial_learning_rate is not None:
-            for g in optimizer.param_groups:
-                g["lr"] = initial_learning_rate
+            if hasattr(optimizer, "set_lr"):  # a training.GraphedTrainStep (its rate lives in one device scalar)
+                optimizer.set_lr(initial_learning_rate)
+            else:
+                for g in optimizer.param_groups:
+                    g["lr"] = initial_learning_rate
     return model_dict.get("iter", 0), model_dict.get("best_loss", None)

@@ -69,16 +69,25 @@ def run_training(cfg, model, optimizer, train_loader, validation_loader, train_i
                  validation_sampler=None, start_iter: int = 0, best_loss: Optional[float] = None, checkpoint_dir: Optional[str] = None,
                  num_batches_per_test_eval: int = -1, num_batches_per_train_eval: int = 0, lr_scheduler=None,
                  learning_rate_convergence_percentage: float = 0.75, learning_rate_end_factor: float = 0.5,
-                 on_eval: Optional[Callable[[int, str, Dict[str, float]], None]] = None, unpack: Callable = unpack_batch):
+                 on_eval: Optional[Callable[[int, str, Dict[str, float]], None]] = None, unpack: Callable = unpack_batch,
+                 graphed=None):
     """Iterations ``start_iter .. train_iters - 1`` (resume: pass what ``load_train_checkpoint(..., initial_learning_rate=)``
     returned).  ``model`` is the
     (DDP-wrapped) policy.  Returns (iterations done, best validation loss).  ``on_eval(step_id, split, values)`` receives every
     evaluation result (the reference logs them to wandb); ``num_batches_per_train_eval`` > 0 or -1 also evaluates on the
-    training loader first, like ``skip_train_val=False``."""
+    training loader first, like ``skip_train_val=False``.
+
+    ``graphed``: a ``training.GraphedTrainStep`` built on ``model`` (the BARE policy, not DDP-wrapped): the iteration's step is
+    then its captured form -- flat gradient buffer, one explicit all-reduce, HIP graphs on a GPU -- instead of ``train_one_step``
+    on a DDP wrapper; ``optimizer`` is ignored for stepping (pass ``graphed`` itself: it has the ``state_dict`` /
+    ``load_state_dict`` the checkpoints use) and the LinearLR ramp is the step's own (``graphed.linear_lr``).  The loop reads one
+    batch ahead so that the step can run the next batch's frozen backbone beside the current batch's trainable pass."""
     epoch_len = len(train_loader)
     assert epoch_len != 0, "Train loader contains less than one batch."
     assert len(validation_loader) != 0, "Validation loader contains less than one batch."
-    if lr_scheduler is None:
+    if graphed is not None:
+        graphed.linear_lr(train_iters, learning_rate_convergence_percentage, learning_rate_end_factor)
+    elif lr_scheduler is None:
         # (a resumed run restarts the ramp from the initial learning rate, like the reference: load_train_checkpoint resets the
         # rate, checkpoint.py:124-127, and :603-611 builds a fresh LinearLR)
         lr_scheduler = build_lr_scheduler(optimizer, train_iters, learning_rate_convergence_percentage, learning_rate_end_factor)
@@ -87,18 +96,37 @@ def run_training(cfg, model, optimizer, train_loader, validation_loader, train_i
     model.train()
     it = None
     step_id = start_iter - 1
+    ahead = None  # (graphed) the batch read one iteration early
+
+    def next_batch(at_step):
+        """The batch of iteration `at_step` (None past the end): a fresh iterator at every epoch boundary, as the reference does."""
+        nonlocal it
+        if at_step >= train_iters:
+            return None
+        if at_step % epoch_len == 0 or at_step == start_iter:
+            if train_sampler is not None and get_world_size() > 1 and (at_step // epoch_len) % 5 == 0:
+                train_sampler.set_epoch(at_step // epoch_len)
+            it = iter(train_loader)
+        return next(it)
+
     for step_id in range(start_iter, train_iters):
-        epoch = step_id // epoch_len
         with Timer("step"):
-            if step_id % epoch_len == 0 or step_id == start_iter:
-                if train_sampler is not None and get_world_size() > 1 and epoch % 5 == 0:
-                    train_sampler.set_epoch(epoch)
-                it = iter(train_loader)
             with Timer("step/load_batch"):
-                batch = next(it)
+                batch = ahead if ahead is not None else next_batch(step_id)
+                ahead = None
+                # One batch ahead for the captured step -- but not across an evaluation: it re-reads the training loader (a second
+                # live iterator of the same workers), and the reference's loop starts its next iterator only afterwards.
+                if graphed is not None and (step_id + 1) % val_freq != 0 and (step_id + 1) % epoch_len != 0:
+                    ahead = next_batch(step_id + 1)
             with Timer("step/train"):
-                train_one_step(cfg, model, optimizer, batch, unpack=unpack)
-            lr_scheduler.step()
+                if graphed is not None:
+                    graphed.step(batch, ahead)
+                else:
+                    train_one_step(cfg, model, optimizer, batch, unpack=unpack)
+            if graphed is not None:
+                graphed.scheduler_step()
+            else:
+                lr_scheduler.step()
             if (step_id + 1) % val_freq == 0:
                 if num_batches_per_train_eval:
                     with Timer("step/eval/train-val"):
@@ -110,7 +138,8 @@ def run_training(cfg, model, optimizer, train_loader, validation_loader, train_i
                 if on_eval is not None:
                     on_eval(step_id, "val", values)
                 if get_rank() == 0 and checkpoint_dir is not None:
-                    best_loss = save_checkpoint(checkpoint_dir, model, optimizer, step_id, values["mean_total_loss"], best_loss)
+                    best_loss = save_checkpoint(checkpoint_dir, model, graphed if graphed is not None else optimizer, step_id,
+                                                values["mean_total_loss"], best_loss)
                 if torch.cuda.is_available():
                     torch.cuda.synchronize()
                 barrier()  # nobody trains on while rank 0 is still writing the checkpoint another rank may resume from

@@ -504,6 +504,78 @@ def test_training_loop_two_ranks_gloo(tmp_path):
     assert os.path.exists(tmp_path / "best.pth") and os.path.exists(tmp_path / "last.pth")
 
 
+def _graphed_loop_worker(rank, world, port, out, ckpt_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import dataclasses
+
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.training import (DistributedWeightedSampler, GraphedTrainStep, ProcessGroup, all_gather_objects, build_optimizer,
+                                             load_train_checkpoint, run_training, wrap_ddp)
+    from nvblox_mindmap_amd.training.trainer import build_model
+
+    with ProcessGroup(backend="gloo"):
+        cfg = dataclasses.replace(_tiny_cfg(), diffusion_timesteps=3)
+        train_set, val_set = _MemoryDataset(cfg, 12, 1), _MemoryDataset(cfg, 8, 2)
+
+        def loaders():
+            ts = DistributedWeightedSampler(torch.ones(len(train_set)), len(train_set), seed=3)
+            vs = DistributedWeightedSampler(torch.ones(len(val_set)), len(val_set), seed=4)
+            return DataLoader(train_set, batch_size=2, sampler=ts), DataLoader(val_set, batch_size=2, sampler=vs), ts, vs
+
+        def run(graphed: bool, directory):
+            torch.manual_seed(0)
+            model = build_model(cfg, device="cpu")
+            tl, vl, ts, vs = loaders()
+            evals = []
+            if graphed:
+                step = GraphedTrainStep(cfg, model, next(iter(tl)), lr=1e-3, use_graphs=False)
+                wrapped, opt = model, step
+            else:
+                step, wrapped = None, wrap_ddp(model, "cpu")
+                opt = build_optimizer(wrapped, lr=1e-3)
+            torch.manual_seed(50 + rank)
+            done, best = run_training(cfg, wrapped, opt, tl, vl, train_iters=5, val_freq=2, train_sampler=ts, validation_sampler=vs,
+                                      checkpoint_dir=directory, num_batches_per_test_eval=1, graphed=step,
+                                      on_eval=lambda s_, split, v: evals.append((s_, v["mean_total_loss"])))
+            return model, opt, evals, done
+
+        ref, _, ref_evals, _ = run(False, os.path.join(ckpt_dir, "ddp"))
+        got, step, got_evals, done = run(True, os.path.join(ckpt_dir, "flat"))
+        same = all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), got.state_dict().values()))
+        # resume the captured-step run from its own checkpoint (written by rank 0 after iteration 4 = the second evaluation)
+        torch.manual_seed(0)
+        model2 = build_model(cfg, device="cpu")
+        tl, vl, ts, vs = loaders()
+        step2 = GraphedTrainStep(cfg, model2, next(iter(tl)), lr=1e-3, use_graphs=False)
+        start, best = load_train_checkpoint(os.path.join(ckpt_dir, "flat", "last.pth"), model2, step2, initial_learning_rate=1e-3)
+        gathered = all_gather_objects({"same": same, "evals": (ref_evals, got_evals), "done": done, "start": start, "lr": step2.lr,
+                                       "moments": float(sum(v["exp_avg"].abs().sum() for v in step2.optimizer.state.values()))})
+        if rank == 0:
+            out.put(gathered)
+
+
+def test_training_loop_on_the_flat_step_equals_the_ddp_loop(tmp_path):
+    """training.run_training(graphed=GraphedTrainStep) on 2 gloo ranks: the iteration loop with its read-ahead, the LinearLR ramp, the
+    evaluations and rank 0's checkpoints gives the weights and the evaluation values of the reference-shaped loop (DDP + AdamW over
+    the individual parameters), bit for bit; its checkpoint resumes (weights, Adam moments, iteration)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graphed_loop_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in g:
+        assert r["same"], "weights after 5 iterations differ between the flat step and DDP"
+        assert r["evals"][0] == r["evals"][1] and [s for s, _ in r["evals"][0]] == [1, 3]
+        assert r["done"] == 5 and r["start"] == 4 and r["lr"] == 1e-3 and r["moments"] > 0.0
+
+
 def test_training_checkpoint_resume(tmp_path):
     """save_checkpoint / load_train_checkpoint (model_utils/checkpoint.py:30-52,117-136): resuming reproduces the run that
     never stopped, bit for bit; best.pth only moves when the validation loss improves."""
