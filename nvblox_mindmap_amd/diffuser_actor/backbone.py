@@ -18,7 +18,20 @@ def _lin(x, layer, split):
     return split_linear(x, layer) if split else layer(x)
 
 
+def split_linear_rows(x):
+    """split3 of a contiguous float32 [.., K] tensor (mmf_split_activations3)."""
+    from .. import _lib
+
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    a3 = torch.empty((x2.shape[0], 3 * K + SL.kTail), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().mmf_split_activations3(_lib.dptr(x2), x2.shape[0], K, _lib.dptr(a3), _lib.stream_ptr(x.device)), "mmf_split_activations3")
+    return a3
+
+
 class _Block(nn.Module):
+    split_attention = True  # the fused path's attention on the split-operand matrix-core kernel (False: torch's f32 SDPA)
+
     def __init__(self, dim, heads, mlp_ratio=4):
         super().__init__()
         self.n1, self.n2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
@@ -38,9 +51,15 @@ class _Block(nn.Module):
         branch, not yet added to ``x``.  Returns (x after the attention branch, this block's MLP branch -- the next ``pending``)."""
         B, L, D = x.shape
         x, a3 = SL.ln_split3(x, pending, self.n1)
-        qkv = SL.mm3(a3, self.qkv, (B, L, 3, self.heads, D // self.heads)).permute(2, 0, 3, 1, 4)
-        att = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
-        x, a3 = SL.ln_split3(x, SL.mm3(SL.split3_heads(att), self.proj, (B, L, D)), self.n2)
+        hd = D // self.heads
+        qkv = SL.mm3(a3, self.qkv, (B, L, 3, self.heads, hd))
+        if self.split_attention and SL.attention_split_ok(B, L, self.heads, hd):
+            # f32-accurate attention on the fp16 matrix cores, output already in the [B, L, D] layout the projection reads
+            a3 = split_linear_rows(SL.attention_split(qkv, B, L, self.heads, hd))
+        else:
+            q, k, v = qkv.permute(2, 0, 3, 1, 4)
+            a3 = SL.split3_heads(F.scaled_dot_product_attention(q, k, v))
+        x, a3 = SL.ln_split3(x, SL.mm3(a3, self.proj, (B, L, D)), self.n2)
         h = SL.mm3(a3, self.fc1, (B * L, self.fc1.out_features))
         return x, SL.mm3(SL.gelu_split3(h), self.fc2, (B, L, D))
 

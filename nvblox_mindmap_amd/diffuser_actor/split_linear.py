@@ -125,3 +125,19 @@ def split3_heads(att: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().mmf_split_attention_heads3(_lib.dptr(att), B, H, L, d, _lib.dptr(a3), _lib.stream_ptr(att.device)),
                "mmf_split_attention_heads3")
     return a3
+
+
+def attention_split_ok(B: int, L: int, H: int, d: int) -> bool:
+    return d == 64 and L % 128 == 0 and L > 0
+
+
+def attention_split(qkv: torch.Tensor, B: int, L: int, H: int, d: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d)) v of a packed projection qkv [B, L, 3, H, d] (float32, contiguous) -> [B, L, H d] float32, at
+    float32 accuracy on the fp16 matrix cores (mmf_attention_split: split operands, f32 accumulation and statistics)."""
+    assert qkv.is_contiguous() and qkv.dtype == torch.float32 and qkv.numel() == B * L * 3 * H * d
+    out = torch.empty((B, L, H * d), dtype=torch.float32, device=qkv.device)
+    base = qkv.data_ptr()
+    rs = 3 * H * d
+    _lib.check(_lib.lib().mmf_attention_split(base, base + 4 * H * d, base + 8 * H * d, rs, L * rs, B, H, L, d, 1.0 / (d ** 0.5), _lib.dptr(out),
+                                              _lib.stream_ptr(qkv.device)), "mmf_attention_split")
+    return out

@@ -721,3 +721,30 @@ def test_frozen_backbone_on_split_fp16_gemms_keeps_f32_accuracy():
         assert torch.allclose(a, lin(xs), rtol=1e-5, atol=1e-5)
         lin.weight[3, 5] = 7.0e4  # (under no_grad: bumps the version the cache watches) does not fit fp16: the f32 GEMM, exactly
         assert torch.equal(SL.split_linear(xs, lin), lin(xs))
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 12, 64), (1, 1024, 3, 64), (3, 128, 2, 64)])
+def test_split_operand_attention_keeps_f32_accuracy(shape):
+    """mmf_attention_split (the frozen backbone's self-attention on the fp16 matrix cores: every product as hi hi + (hi lo + lo hi) / 2048
+    of split operands, f32 accumulation, f32 softmax) against a float64 evaluation: as close as torch's float32 SDPA is, three
+    orders of magnitude closer than fp16 inputs; asymmetric random q / k / v with different scales, so that a transposed tile, a
+    wrong key order in the second product or a missing low part cannot pass."""
+    from nvblox_mindmap_amd.diffuser_actor import split_linear as SL
+
+    B, L, H, d = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = torch.randn(B, L, 3, H, d, device="cuda", generator=g)
+    qkv[:, :, 0] *= 2.5   # queries: logits of a few units, a peaked softmax
+    qkv[:, :, 2] = qkv[:, :, 2] * 3.0 + torch.arange(d, device="cuda") * 0.05  # values: asymmetric in d
+    qkv[:, L // 3, 1] += 1.5  # one key the queries like
+    q, k, v = (t.permute(0, 2, 1, 3) for t in qkv.unbind(2))  # [B, H, L, d]
+    ref = torch.softmax((q.double() @ k.double().transpose(-1, -2)) / d ** 0.5, dim=-1) @ v.double()
+    ref = ref.permute(0, 2, 1, 3).reshape(B, L, H * d)
+    got = SL.attention_split(qkv.contiguous(), B, L, H, d)
+    torch.cuda.synchronize()
+    f32 = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(B, L, H * d)
+    f16 = torch.nn.functional.scaled_dot_product_attention(q.half(), k.half(), v.half()).float().permute(0, 2, 1, 3).reshape(B, L, H * d)
+    scale = float(ref.abs().max())
+    e_got, e_f32, e_f16 = (float((t.double() - ref).abs().max()) for t in (got, f32, f16))
+    assert e_got <= 4e-6 * scale, (e_got, e_f32, scale)
+    assert e_got <= 4 * e_f32 + 1e-6 * scale and e_f16 > 100 * e_got, (e_got, e_f32, e_f16)
