@@ -450,10 +450,11 @@ int mmf_split_activations3(const float* x_dev, int64_t rows, int K, void* out_de
  * scale) v per (batch, head), every product as hi hi + (hi lo + lo hi) / 2048 of operands split into two fp16 values (22-bit
  * mantissas, f32 accumulation), statistics and exponentials in f32.  q / k / v: rows of `head_dim` floats of head h at
  * base + b batch_stride + l row_stride + h head_dim (e.g. the three slices of a [B, L, 3, H, 64] projection); out [B, L, H head_dim].
- * head_dim = 64, L a multiple of 128.  Replaces F.scaled_dot_product_attention inside the backbone the reference runs under TF32
- * (image_processing/feature_extraction.py:318-323). */
+ * head_dim = 64, L a multiple of 128.  split_out != 0: out is written as mmf_split_activations3 would split that result
+ * ([B L, 3 H head_dim + 64] fp16: the operand of the next Linear's GEMM).  Replaces F.scaled_dot_product_attention inside the
+ * backbone the reference runs under TF32 (image_processing/feature_extraction.py:318-323). */
 int mmf_attention_split(const float* q_dev, const float* k_dev, const float* v_dev, int64_t row_stride, int64_t batch_stride, int B, int H,
-                        int L, int head_dim, float scale, float* out_dev, void* stream);
+                        int L, int head_dim, float scale, void* out_dev, int split_out, void* stream);
 int mmf_gelu_split_activations3(const float* x_dev, int64_t rows, int K, void* out_dev, void* stream);
 int mmf_split_attention_heads3(const float* att_dev, int64_t B, int heads, int L, int head_dim, void* out_dev, void* stream);
 int mmf_layernorm_split_activations3(const float* x_dev, const float* residual_dev, const float* gamma_dev, const float* beta_dev, float eps,

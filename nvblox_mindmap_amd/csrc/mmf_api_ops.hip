@@ -337,9 +337,9 @@ int mmf_layernorm_split_activations3(const float* x, const float* residual, cons
 }
 
 int mmf_attention_split(const float* q, const float* k, const float* v, int64_t row_stride, int64_t batch_stride, int B, int H, int L,
-                        int head_dim, float scale, float* out, void* stream) {
+                        int head_dim, float scale, void* out, int split_out, void* stream) {
   if (!q || !k || !v || !out) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_attention_split");
-  if (launch_attention_split(q, k, v, row_stride, batch_stride, B, H, L, head_dim, scale, out, (hipStream_t)stream) != 0)
+  if (launch_attention_split(q, k, v, row_stride, batch_stride, B, H, L, head_dim, scale, out, split_out, (hipStream_t)stream) != 0)
     return fail(MMF_ERR_INVALID_ARG, "mmf_attention_split: head_dim 64, L a multiple of 128, strides multiples of 4 floats");
   return check_launch();
 }

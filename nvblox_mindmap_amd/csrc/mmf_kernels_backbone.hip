@@ -41,10 +41,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
   }
 }
 
-// LDS addressing, in halves.  K tile: [key 64][d 64], the 16-byte chunk index XORed with key & 7.  V tile: [d 64][slot 64] (slot =
-// the position of a key in the MFMA operand order, key_slot below), chunk index XORed with d & 7.
-__device__ __forceinline__ int k_addr(int key, int chunk) { return key * kD + ((chunk ^ (key & 7)) << 3); }
-__device__ __forceinline__ int v_addr(int d, int chunk) { return d * kTK + ((chunk ^ (d & 7)) << 3); }
+// LDS addressing, in halves.  K tile: [key 64][d 64], the 16-byte chunk index XORed with (key >> 1) & 7.  V tile: [d 64][slot 64]
+// (slot = the position of a key in the MFMA operand order, key_slot below), chunk index XORed with (d >> 1) & 7.
+// (a row is 128 bytes = half the 64 banks: two consecutive rows tile the banks, so the swizzle runs over row >> 1 -- with row & 7 the
+// rows 2 apart met in the same banks and SQ_LDS_BANK_CONFLICT was 64 % of the LDS cycles)
+__device__ __forceinline__ int k_addr(int key, int chunk) { return key * kD + ((chunk ^ ((key >> 1) & 7)) << 3); }
+__device__ __forceinline__ int v_addr(int d, int chunk) { return d * kTK + ((chunk ^ ((d >> 1) & 7)) << 3); }
 // A 32 x 32 accumulator holds, in lane (col, half) register r, row (r & 3) + 8 (r >> 2) + 4 half.  The second product consumes a
 // sub-tile's 16 registers as two operands of 8 (registers 8 u .. 8 u + 7): step s = 2 sub + u covers keys 16 s .. 16 s + 15, and
 // operand element (half, j) is key 16 s + 8 (j >> 2) + 4 half + (j & 3).  slot = 16 s + 8 half + j is where V^T keeps that key.
@@ -54,14 +56,15 @@ __device__ __forceinline__ int key_slot(int key) {
 
 struct Tile {  // one thread's share of a K / V tile on its way from global memory to LDS
   float4 k[4];  // K[key = tid >> 2][16 (tid & 3) ..]
-  float4 v[4];  // V[keys 2 p, 2 p + 1 (p = tid >> 3)][8 (tid & 7) ..]: v[0..1] the even key, v[2..3] the odd one
+  float4 v[4];  // V[keys 2 p, 2 p + 1 (p = tid & 31)][8 (tid >> 5) ..]: v[0..1] the even key, v[2..3] the odd one (a wave's lanes then
+                // write 32 different words of two rows of V^T per store: 2-way bank conflicts instead of 8-way)
 };
 
 __device__ __forceinline__ void tile_load(Tile& T, const float* __restrict__ K, const float* __restrict__ V, long long rs, int k0, int tid) {
   const float* kp = K + (long long)(k0 + (tid >> 2)) * rs + (tid & 3) * 16;
 #pragma unroll
   for (int i = 0; i < 4; ++i) T.k[i] = reinterpret_cast<const float4*>(kp)[i];
-  const float* vp = V + (long long)(k0 + 2 * (tid >> 3)) * rs + (tid & 7) * 8;
+  const float* vp = V + (long long)(k0 + 2 * (tid & 31)) * rs + (tid >> 5) * 8;
   T.v[0] = reinterpret_cast<const float4*>(vp)[0];
   T.v[1] = reinterpret_cast<const float4*>(vp)[1];
   T.v[2] = reinterpret_cast<const float4*>(vp + rs)[0];
@@ -82,8 +85,8 @@ __device__ __forceinline__ void tile_store(const Tile& T, _Float16* __restrict__
     }
   }
   {
-    const int slot = key_slot(2 * (tid >> 3));  // even: the odd key of the pair sits in slot + 1
-    const int d0 = (tid & 7) * 8;
+    const int slot = key_slot(2 * (tid & 31));  // even: the odd key of the pair sits in slot + 1
+    const int d0 = (tid >> 5) * 8;
     const float a[8] = {T.v[0].x, T.v[0].y, T.v[0].z, T.v[0].w, T.v[1].x, T.v[1].y, T.v[1].z, T.v[1].w};
     const float b[8] = {T.v[2].x, T.v[2].y, T.v[2].z, T.v[2].w, T.v[3].x, T.v[3].y, T.v[3].z, T.v[3].w};
 #pragma unroll
@@ -100,6 +103,9 @@ __device__ __forceinline__ void tile_store(const Tile& T, _Float16* __restrict__
 
 // q / k / v: [B, L, ...] rows of one head at stride `rs` floats between consecutive l, `bs` between batches; head h at + 64 h.
 // out: [B, L, H 64] (the layout the next Linear reads: no transpose copy).  L % 128 == 0.
+// SPLIT_OUT: the output is written as the split operand of the next Linear's GEMM (mmf_split_activations3's layout: rows of
+// [hi | hi / 2048 | lo | 1, 1 / 2048, 0 x 62] fp16 over K = 64 H channels) instead of float32 -- one pass over the activation less.
+template <bool SPLIT_OUT>
 __global__ __launch_bounds__(256, 2) void k_attn_split64(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                         long long rs, long long bs, int H, int L, float scale, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) _Float16 sK[2][2][kTK * kD];
@@ -118,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_split64(const float* __restrict
   for (int kk = 0; kk < 4; ++kk) {
     const float4* p = reinterpret_cast<const float4*>(Qb + (long long)q * rs + kk * 16 + half * 8);
     const float4 a = p[0], c = p[1];
-    const float x[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+    // (log2 e rides in the scale: the exponentials below are bare v_exp_f32; one more rounding of q at 2^-24)
+    const float sc = scale * 1.44269504088896340736f;
+    const float x[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, c.x * sc, c.y * sc, c.z * sc, c.w * sc};
     split8(x, qh[kk], ql[kk]);
   }
 
@@ -168,18 +176,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_split64(const float* __restrict
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.0f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[sub][r] = __expf(s[sub][r] - m_new);
+        s[sub][r] = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
         psum += s[sub][r];
       }
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
-    m_run = m_new;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_split64(const float* __restrict
         om[db][r] *= alpha;
         ox[db][r] *= alpha;
       }
+    m_run = m_new;
     // O^T += V^T P^T: four steps of 16 keys
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -212,28 +220,62 @@ __global__ __launch_bounds__(256, 2) void k_attn_split64(const float* __restrict
   }
   // O^T[d][q] -> out[b, q, 64 h + d]; the lane holds d = 32 db + (r & 3) + 8 (r >> 2) + 4 half: four consecutive d per register quad
   const float inv_l = 1.0f / l_run;
-  float* op = out + ((long long)b * L + q) * ((long long)H * kD) + h * kD;
+  const int KC = H * kD;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  float* op = out + ((long long)b * L + q) * (long long)KC + h * kD;
+  _Float16* sp = reinterpret_cast<_Float16*>(out) + ((long long)b * L + q) * (long long)(3 * KC + 64) + h * kD;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float4 o;
-      o.x = (om[db][4 * g + 0] + ox[db][4 * g + 0] * kLoInv) * inv_l;
-      o.y = (om[db][4 * g + 1] + ox[db][4 * g + 1] * kLoInv) * inv_l;
-      o.z = (om[db][4 * g + 2] + ox[db][4 * g + 2] * kLoInv) * inv_l;
-      o.w = (om[db][4 * g + 3] + ox[db][4 * g + 3] * kLoInv) * inv_l;
-      *reinterpret_cast<float4*>(op + 32 * db + 8 * g + 4 * half) = o;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (om[db][4 * g + e] + ox[db][4 * g + e] * kLoInv) * inv_l;
+        asm volatile("" : "+v"(o[e]));  // (one value for the hi and the lo part: see k_split_act3_src)
+      }
+      const int dd = 32 * db + 8 * g + 4 * half;
+      if (SPLIT_OUT) {
+        h4 hi, hs, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = (_Float16)o[e];
+          const _Float16 l = (_Float16)((o[e] - (float)hi[e]) * kLo);
+          hs[e] = (_Float16)((float)hi[e] * kLoInv);
+          lo[e] = (_Float16)((float)l * kLoInv);
+        }
+        *reinterpret_cast<h4*>(sp + dd) = hi;
+        *reinterpret_cast<h4*>(sp + KC + dd) = hs;
+        *reinterpret_cast<h4*>(sp + 2 * KC + dd) = lo;
+      } else {
+        *reinterpret_cast<float4*>(op + dd) = make_float4(o[0], o[1], o[2], o[3]);
+      }
     }
+  if (SPLIT_OUT && h == 0) {  // the row's bias columns: 1, 1 / 2048, zeros (lane half 0: the first 32, half 1: the rest)
+    _Float16* tp = sp + 3 * KC + 32 * half;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      h8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      if (c == 0 && half == 0) {
+        z[0] = (_Float16)1.0f;
+        z[1] = (_Float16)kLoInv;
+      }
+      *reinterpret_cast<h8*>(tp + 8 * c) = z;
+    }
+  }
 }
 
 }  // namespace
 
 // 0 = launched, 1 = unsupported shape
 int launch_attention_split(const float* q, const float* k, const float* v, long long row_stride, long long batch_stride, int B, int H, int L,
-                           int head_dim, float scale, float* out, hipStream_t s) {
+                           int head_dim, float scale, void* out, int split_out, hipStream_t s) {
   if (head_dim != kD || L <= 0 || L % kQB != 0 || B <= 0 || H <= 0 || (row_stride & 3) || (batch_stride & 3)) return 1;
-  hipLaunchKernelGGL(k_attn_split64, dim3((unsigned)(L / kQB), (unsigned)(B * H)), dim3(256), 0, s, q, k, v, row_stride, batch_stride, H, L, scale,
-                     out);
+  const dim3 grid((unsigned)(L / kQB), (unsigned)(B * H));
+  if (split_out)
+    hipLaunchKernelGGL(k_attn_split64<true>, grid, dim3(256), 0, s, q, k, v, row_stride, batch_stride, H, L, scale, reinterpret_cast<float*>(out));
+  else
+    hipLaunchKernelGGL(k_attn_split64<false>, grid, dim3(256), 0, s, q, k, v, row_stride, batch_stride, H, L, scale, reinterpret_cast<float*>(out));
   return 0;
 }
 

@@ -378,7 +378,7 @@ int launch_out_ffn_qkv2(const float* const* a26, const float* eps4, float* out, 
 int launch_split_weight(const float* W, int rows, int cols, void* dst, hipStream_t s);
 int launch_split_act3(const float* x, long long rows, int K, void* out, hipStream_t s);
 int launch_attention_split(const float* q, const float* k, const float* v, long long row_stride, long long batch_stride, int B, int H, int L,
-                           int head_dim, float scale, float* out, hipStream_t s);
+                           int head_dim, float scale, void* out, int split_out, hipStream_t s);
 int launch_split_act3_src(int src, const float* x, long long rows, int K, int heads, int L, void* out, hipStream_t s);
 int launch_ln_split3(const float* x, const float* y, const float* gamma, const float* beta, float eps, long long rows, int K, float* sum_out,
                      void* out, hipStream_t s);

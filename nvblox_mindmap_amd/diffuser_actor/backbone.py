@@ -55,7 +55,7 @@ class _Block(nn.Module):
         qkv = SL.mm3(a3, self.qkv, (B, L, 3, self.heads, hd))
         if self.split_attention and SL.attention_split_ok(B, L, self.heads, hd):
             # f32-accurate attention on the fp16 matrix cores, output already in the [B, L, D] layout the projection reads
-            a3 = split_linear_rows(SL.attention_split(qkv, B, L, self.heads, hd))
+            a3 = SL.attention_split(qkv, B, L, self.heads, hd, split_out=True)
         else:
             q, k, v = qkv.permute(2, 0, 3, 1, 4)
             a3 = SL.split3_heads(F.scaled_dot_product_attention(q, k, v))

@@ -131,13 +131,18 @@ def attention_split_ok(B: int, L: int, H: int, d: int) -> bool:
     return d == 64 and L % 128 == 0 and L > 0
 
 
-def attention_split(qkv: torch.Tensor, B: int, L: int, H: int, d: int) -> torch.Tensor:
+def attention_split(qkv: torch.Tensor, B: int, L: int, H: int, d: int, split_out: bool = False) -> torch.Tensor:
     """softmax(q k^T / sqrt(d)) v of a packed projection qkv [B, L, 3, H, d] (float32, contiguous) -> [B, L, H d] float32, at
-    float32 accuracy on the fp16 matrix cores (mmf_attention_split: split operands, f32 accumulation and statistics)."""
+    float32 accuracy on the fp16 matrix cores (mmf_attention_split: split operands, f32 accumulation and statistics).
+    ``split_out``: the result as the split operand of the next Linear's GEMM instead ([B L, 3 H d + 64] fp16, what
+    mmf_split_activations3 would make of it)."""
     assert qkv.is_contiguous() and qkv.dtype == torch.float32 and qkv.numel() == B * L * 3 * H * d
-    out = torch.empty((B, L, H * d), dtype=torch.float32, device=qkv.device)
+    if split_out:
+        out = torch.empty((B * L, 3 * H * d + kTail), dtype=torch.float16, device=qkv.device)
+    else:
+        out = torch.empty((B, L, H * d), dtype=torch.float32, device=qkv.device)
     base = qkv.data_ptr()
     rs = 3 * H * d
     _lib.check(_lib.lib().mmf_attention_split(base, base + 4 * H * d, base + 8 * H * d, rs, L * rs, B, H, L, d, 1.0 / (d ** 0.5), _lib.dptr(out),
-                                              _lib.stream_ptr(qkv.device)), "mmf_attention_split")
+                                              1 if split_out else 0, _lib.stream_ptr(qkv.device)), "mmf_attention_split")
     return out

@@ -748,3 +748,10 @@ def test_split_operand_attention_keeps_f32_accuracy(shape):
     e_got, e_f32, e_f16 = (float((t.double() - ref).abs().max()) for t in (got, f32, f16))
     assert e_got <= 4e-6 * scale, (e_got, e_f32, scale)
     assert e_got <= 4 * e_f32 + 1e-6 * scale and e_f16 > 100 * e_got, (e_got, e_f32, e_f16)
+    # the same result written as the next GEMM's split operand: bit-identical to splitting the float32 output
+    from nvblox_mindmap_amd import _lib
+
+    a3 = SL.attention_split(qkv.contiguous(), B, L, H, d, split_out=True)
+    want = torch.empty_like(a3)
+    _lib.check(_lib.lib().mmf_split_activations3(_lib.dptr(got), B * L, H * d, _lib.dptr(want), _lib.stream_ptr(got.device)), "split")
+    assert torch.equal(a3, want)
