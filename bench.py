@@ -74,6 +74,12 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_from_argv
     # before anything that could initialise the GPU in this process (the children are fresh processes, not a re-exec)
     sys.exit(spawn_ranks(_gpus_from_argv(sys.argv[1:]), sys.argv[1:]))
 
+if os.environ.get("BENCH_HANG_DUMP_S"):
+    # diagnostics: every thread's Python stack on stderr after this many seconds, then exit (a multi-rank hang otherwise says nothing)
+    import faulthandler
+
+    faulthandler.dump_traceback_later(float(os.environ["BENCH_HANG_DUMP_S"]), exit=True)
+
 from nvblox_mindmap_amd import synthetic as S  # noqa: E402
 from nvblox_mindmap_amd.image_processing.feature_resize import upsample_features  # noqa: E402
 from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper, integrate_frame  # noqa: E402
@@ -981,7 +987,7 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
         from nvblox_mindmap_amd.training import GraphedTrainStep
 
         cur = next(it)
-        g = GraphedTrainStep(cfg, model, cur)
+        g = GraphedTrainStep(cfg, model, cur, data_parallel=False)  # a rank-0-only leg: no collective, the other ranks are not here
         del opt
 
         def fed_steps(n, cur):

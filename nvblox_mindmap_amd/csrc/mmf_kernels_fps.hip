@@ -308,8 +308,9 @@ static int fps_groups(const float* x, int B, int N, int C, int npoints, int star
 //     falls below T (or K picks are made): then the next exchange.
 // On the policy's shape (3 072 x 120, 16 workgroups of 3 + 1 waves, K = 4) 3.8 - 4.0 picks ride on one exchange, 21 candidates
 // are fetched on average; 614 picks: 2.5 ms (one pick per exchange, 4 workgroups of 12 waves) -> 2.0 ms.  An exchange still costs
-// ~9 us beside its picks (publish -> keys -> rows are three dependent trips through the L2, at the clock a 16-CU job gets).
-constexpr int kFpsMultiGroups = 16, kFpsElig = 40;  // (candidates above the bound: 21 on average, 35 at most on random data)
+// ~9 us beside its picks (publish -> keys -> rows are three dependent trips through the L2, at the clock a 16-CU job gets), so
+// the shipped arrangement offers more picks per exchange: 8 workgroups of 6 + 1 waves, K = 8 -> 1.6 ms.
+constexpr int kFpsMultiGroups = 16, kFpsElig = 64;  // (one candidate per lane of the auxiliary wave)
 
 // max of a 64-bit key over the wave, the result in every lane (as a scalar): four cross-lane steps inside the 16-lane rows
 // (pairs, quads, mirrored half, mirrored row), two row broadcasts, one read of lane 63 -- data-parallel-primitive moves instead
@@ -693,7 +694,13 @@ int launch_fps(const float* x, int B, int N, int C, int npoints, int start, long
   sc.cap = workspace_bytes;
   if (N > 1024 && N <= kFpsMaxResidentN && C > 96 && C <= kFpsMaxResidentC) {  // the policy's shape (3072 x 120)
     static const int single = getenv("MMF_DEBUG_FPS_SINGLE") ? 1 : 0;  // (diagnostics: one pick per exchange)
-    int rc = single ? 1 : fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s, sc);
+    // 8 workgroups of 6 + 1 waves, 8 picks offered per exchange (round 4: 1.81 -> 1.61 ms at B = 1, 2.19 -> 1.72 ms at B = 32 against
+    // 16 workgroups of 3 + 1 waves with 4 picks: an exchange costs the same, more picks ride on it); MMF_DEBUG_FPS_VARIANT=1 is the
+    // former arrangement (diagnostics)
+    static const int variant = getenv("MMF_DEBUG_FPS_VARIANT") ? atoi(getenv("MMF_DEBUG_FPS_VARIANT")) : 0;
+    int rc = single         ? 1
+             : variant == 1 ? fps_multi<128, 3, 4>(x, B, N, C, npoints, start, out_idx, s, sc)
+                            : fps_multi<128, 6, 8>(x, B, N, C, npoints, start, out_idx, s, sc);
     if (rc == 1) rc = fps_groups<128, 12>(x, B, N, C, npoints, start, out_idx, s, sc);  // (8 groups of 6 waves: 7 % slower)
     if (rc != 1) return rc;
   }

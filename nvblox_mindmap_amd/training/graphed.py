@@ -93,15 +93,20 @@ class GraphedTrainStep:
     ``model`` is the BARE policy (not DDP-wrapped) on its device, every rank starting from the same weights.  ``example_batch``: a
     loader-shaped batch (``synthetic_batch`` / the dataset's collate output) of the shapes every later batch has.
     ``overlap_backbone``: evaluate the frozen image backbone of ``next_batch`` beside the trainable pass of ``batch`` (graph
-    branch / side stream); the caller then hands batch t + 1 to step t, and the SAME dict object to step t + 1."""
+    branch / side stream); the caller then hands batch t + 1 to step t, and the SAME dict object to step t + 1.
+    ``data_parallel=False``: this rank steps ALONE although a process group exists (a measurement or an evaluation that only one
+    rank runs): no collective is issued -- with the default every rank of the group must call ``step`` the same number of times."""
 
     def __init__(self, cfg: DiffuserActorConfig, model: nn.Module, example_batch: Dict[str, torch.Tensor], lr: float = 1e-4,
                  weight_decay: float = 5e-4, use_graphs: Optional[bool] = None, overlap_backbone: bool = True,
-                 unpack: Optional[Callable] = None, process_group=None, tuned_gemms: bool = True):
+                 unpack: Optional[Callable] = None, process_group=None, tuned_gemms: bool = True, data_parallel: bool = True):
         self.cfg, self.model = cfg, model
         self.unpack = unpack or unpack_batch
         self.group = process_group
-        self.world = get_world_size() if process_group is None else dist.get_world_size(process_group)
+        if not data_parallel:
+            self.world = 1
+        else:
+            self.world = get_world_size() if process_group is None else dist.get_world_size(process_group)
         p0 = next(model.parameters())
         self.device = p0.device
         self.use_graphs = (self.device.type == "cuda") if use_graphs is None else bool(use_graphs)

@@ -360,12 +360,20 @@ def _flat_worker(rank, world, port, out):
         names = dict(model.named_parameters())
         diff = max(float((p - names[n]).abs().max()) for n, p in ref.named_parameters())
         equal = all(torch.equal(p, names[n]) for n, p in ref.named_parameters())
+        # (c) a step that ONE rank takes alone while the group exists (bench.py's rank-0-only file-fed leg): data_parallel=False
+        # issues no collective -- a collective here would wait for rank 1 forever
+        alone_world = None
+        if rank == 0:
+            torch.manual_seed(0)
+            alone = GraphedTrainStep(cfg, build_model(cfg, device="cpu"), batches[0], lr=lr, use_graphs=False, data_parallel=False)
+            alone.step(batches[0])
+            alone_world = (alone.world, alone.observed_world())
         unused_ref = sorted(n for n, p in ref.named_parameters() if p.requires_grad and p.grad is None)
         vec = torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad])
         gathered = all_gather_objects({"diff": diff, "equal": equal, "ref_losses": ref_losses, "flat_losses": flat_losses,
                                        "unused": (unused_ref, sorted(flat.unused_names)), "checksum": float(vec.double().sum()),
                                        "lr": (opt.param_groups[0]["lr"], flat.lr), "world": flat.observed_world(),
-                                       "payload": flat.flat_grad.numel(), "steps": flat.steps_done})
+                                       "payload": flat.flat_grad.numel(), "steps": flat.steps_done, "alone": alone_world})
         if rank == 0:
             out.put(gathered)
 
@@ -393,6 +401,7 @@ def test_flat_allreduce_step_matches_ddp_two_ranks_gloo():
         assert np.allclose(np.array(r["ref_losses"], dtype=np.float64), np.array(r["flat_losses"], dtype=np.float64), rtol=1e-6, atol=1e-7)
         assert r["diff"] <= 1e-7, r["diff"]  # elementwise-identical arithmetic (bit-equal on this build: see "equal")
     assert a["checksum"] == b["checksum"]  # the explicit all-reduce kept the ranks in step
+    assert tuple(a["alone"]) == (1, 1) and b["alone"] is None
     assert a["flat_losses"] != b["flat_losses"]  # (they saw different data)
     assert a["equal"] and b["equal"], (a["diff"], b["diff"])
 
