@@ -533,6 +533,10 @@ int mmf_debug_alloc_recoveries(mmf_handle h, int mapper_id, void* stream, int64_
  * no hash is kept), tombstones in the table, table rebuilds since the layer was created / cleared, live blocks, and the last depth
  * frame's view grid nx, ny, nz (cells = blocks), 0}.  Synchronises. */
 int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out8);
+/* Diagnostics: the number of tombstone entries that ARE in a layer's hash table (a scan of the table), to hold against the
+ * counter mmf_debug_hash_state reports (out8[1]) -- the two are equal: insertion takes a reused tombstone off the count.  0 for a
+ * layer indexed by its dense table.  Synchronises. */
+int mmf_debug_count_tombstones(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out);
 /* Diagnostics: per-workgroup timeline of the fused frame kernels.  buffer_dev: uint64 [3 * capacity_records] on the device
  * (capacity_records >= 6 * 8192; the caller zeroes it), records {role id, start, end} in 100 MHz ticks at slot
  * (role id / 10 - 1) * 8192 + workgroup index; null = off (the default).

@@ -191,6 +191,7 @@ SIGNATURES = {
     "mmf_get_alloc_timeline": (_I, [_VP, _I, _I, C.POINTER(C.c_int64)]),
     "mmf_debug_alloc_recoveries": (_I, [_VP, _I, _VP, C.POINTER(C.c_int64)]),
     "mmf_debug_hash_state": (_I, [_VP, _I, _I, _VP, C.POINTER(C.c_int64)]),
+    "mmf_debug_count_tombstones": (_I, [_VP, _I, _I, _VP, C.POINTER(C.c_int64)]),
     "mmf_profile_enable": (_I, [_VP, _I]),
     "mmf_profile_set_stride": (_I, [_VP, _I]),
     "mmf_profile_get": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

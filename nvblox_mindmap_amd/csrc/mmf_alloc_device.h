@@ -269,7 +269,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
     if (J.timeline && threadIdx.x == 0) J.timeline[3] = wall_clock64();  // scan done
     const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2], room = ctx[3];
     if (f4) {
-      int pos = carry[0] + ea, rnk = carry[1] + eb;
+      int pos = carry[0] + ea, rnk = carry[1] + eb, reused = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (!((f4 >> (8 * k)) & 0xffu)) continue;
@@ -278,7 +278,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
         if (is_new) {
           if (rnk < room) {
             slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
-            if (!dense) hash_insert(L, key4[k], slot);
+            if (!dense) reused += hash_insert(L, key4[k], slot);
             dense_set(L, key4[k], slot + 1);
             L.slot_key[slot] = key4[k];
             L.live[old_live + rnk] = slot;
@@ -292,6 +292,7 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
         pos++;
       }
       if (mode == 0) *reinterpret_cast<uint32_t*>(sc.flags + cell0) = 0u;  // grid flags: all-zero for the next frame
+      if (reused) atomicSub(&L.ctr[4], reused);  // tombstones that became keys again
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -662,7 +663,7 @@ __device__ inline void alloc_big_body(const AllocJob& J, long long* stats, Alloc
       slot = -1;
       if (rnk < room) {
         slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
-        hash_insert(L, key, slot);
+        if (hash_insert(L, key, slot)) atomicSub(&L.ctr[4], 1);  // a tombstone became a key again (few per frame)
         dense_set(L, key, slot + 1);
         L.slot_key[slot] = key;
         L.live[old_live + rnk] = slot;

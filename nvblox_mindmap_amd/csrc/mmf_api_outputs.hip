@@ -401,6 +401,29 @@ int mmf_debug_hash_state(mmf_handle h, int mapper_id, int layer, void* stream, i
   return MMF_OK;
 }
 
+int mmf_debug_count_tombstones(mmf_handle h, int mapper_id, int layer, void* stream, int64_t* out) {
+  Mapper* m;
+  MMF_TRY(get_mapper_ready(h, mapper_id, &m, stream));
+  Layer* L = pick_layer(m, layer);
+  if (!L || !out) return fail(MMF_ERR_INVALID_ARG, "bad layer / null out");
+  *out = 0;
+  if (!L->allocated || L->d.dense) return MMF_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned long long* n_dev = nullptr;
+  HIP_TRY(hipMalloc(&n_dev, sizeof(*n_dev)));
+  unsigned long long n = 0;
+  hipError_t e = hipMemsetAsync(n_dev, 0, sizeof(*n_dev), (hipStream_t)stream);
+  if (e == hipSuccess) {
+    mmf::launch_count_tombstones(L->d, n_dev, (hipStream_t)stream);
+    e = hipMemcpyAsync(&n, n_dev, sizeof(n), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(n_dev);
+  HIP_TRY(e);
+  *out = (int64_t)n;
+  return MMF_OK;
+}
+
 int mmf_get_alloc_timeline(mmf_handle h, int mapper_id, int enable, int64_t* out6) {
   // out6 is really out8: [6] latest end / [7] earliest start of the mask column workgroups sharing the launch
   Mapper* m;

@@ -208,18 +208,25 @@ __device__ inline int hash_find(const LayerDev& L, u64 key) {
 // the chains of the few thousand keys that cycle grew to dozens of dependent probes between two rebuilds (the unbounded bench
 // stream: allocation 31 -> 198 us, deallocation 23 -> 240 us as the tombstones went 0 -> 120 k).  Safe beside concurrent lookups
 // of OTHER keys: an entry goes tombstone -> key, both of which a probe for another key walks past.
-__device__ inline void hash_insert(const LayerDev& L, u64 key, int slot) {
-  if (L.dense) return;
+// Returns 1 when the claimed entry was a tombstone: the caller takes it off the layer's tombstone count (ctr[4]; one aggregated
+// atomic per thread that reused any), so that the amortised rebuild is triggered by the tombstones that ARE in the table.
+__device__ inline int hash_insert(const LayerDev& L, u64 key, int slot) {
+  if (L.dense) return 0;
   unsigned h = hash_key(key) & L.hmask;
   for (unsigned probe = 0; probe <= L.hmask; ++probe) {
     u64 prev = atomicCAS(&L.htab[h].key, kEmptyKey, key);
-    if (prev == kTombKey) prev = atomicCAS(&L.htab[h].key, kTombKey, key) == kTombKey ? kEmptyKey : 0ull;
+    int reused = 0;
+    if (prev == kTombKey) {
+      reused = atomicCAS(&L.htab[h].key, kTombKey, key) == kTombKey ? 1 : 0;
+      prev = reused ? kEmptyKey : 0ull;
+    }
     if (prev == kEmptyKey) {
       L.htab[h].val = slot;
-      return;
+      return reused;
     }
     h = (h + 1) & L.hmask;
   }
+  return 0;
 }
 
 // Mark the entry of `key` deleted (no-op if absent).

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_emit(LayerDev L, KeySrc ks, Scratch sc,
     if (is_new) {
       if (rnk < granted) {
         slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
-        hash_insert(L, key, slot);
+        if (hash_insert(L, key, slot)) atomicSub(&L.ctr[4], 1);  // a tombstone became a key again
         dense_set(L, key, slot + 1);
         L.slot_key[slot] = key;
         L.live[old_live + rnk] = slot;
@@ -1218,6 +1218,13 @@ __global__ __launch_bounds__(256) void k_hash_clear_if(LayerDev L, const int* co
   for (unsigned h = blockIdx.x * blockDim.x + threadIdx.x; h <= L.hmask; h += gridDim.x * blockDim.x) L.htab[h].key = kEmptyKey;
 }
 
+// diagnostics (mmf_debug_count_tombstones): the tombstones that are in the table, to hold against the layer's counter
+__global__ __launch_bounds__(256) void k_count_tombstones(LayerDev L, unsigned long long* out) {
+  unsigned n = 0;
+  for (unsigned h = blockIdx.x * 256 + threadIdx.x; h <= L.hmask; h += gridDim.x * 256) n += L.htab[h].key == kTombKey ? 1u : 0u;
+  if (n) atomicAdd(out, (unsigned long long)n);
+}
+
 __global__ __launch_bounds__(256) void k_hash_insert_live_if(LayerDev L, const int* cond) {
   if (cond && !*cond) return;
   const int n = L.ctr[0];
@@ -1766,6 +1773,10 @@ void launch_layer_reset(const LayerDev& L, hipStream_t s) {
   if (hb > 1024) hb = 1024;
   hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)nullptr);
   hipLaunchKernelGGL(k_reset_layer, dim3(L.dense ? 64 : 1), dim3(256), 0, s, L);
+}
+
+void launch_count_tombstones(const LayerDev& L, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_tombstones, dim3(grid_for((int)((L.hmask + 256) / 256), 1024)), dim3(256), 0, s, L, out);
 }
 
 void launch_hash_rebuild(const LayerDev& L, hipStream_t s) {

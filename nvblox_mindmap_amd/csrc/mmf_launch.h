@@ -211,6 +211,7 @@ void launch_decay_app_weights(const LayerDev& L, float f, bool has_w, hipStream_
 void launch_layer_reset(const LayerDev& L, hipStream_t s);
 void launch_clear_bits(int* word, int bits, hipStream_t s);
 void launch_hash_rebuild(const LayerDev& L, hipStream_t s);
+void launch_count_tombstones(const LayerDev& L, unsigned long long* out, hipStream_t s);
 void launch_get_indices(const LayerDev& L, int32_t* out, int n, hipStream_t s);
 void launch_gather_pool(const LayerDev& L, size_t bytes_per_block, void* out, int n, hipStream_t s);
 void launch_gather_poolw(const LayerDev& L, float* out, int n, hipStream_t s);

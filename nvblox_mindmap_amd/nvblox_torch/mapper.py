@@ -772,6 +772,12 @@ class Mapper:
         out["lazy_decays"] = int(buf[7])
         return out
 
+    def count_tombstones(self, mapper_id: int = 0, layer: int = _lib.MMF_LAYER_TSDF) -> int:
+        """Diagnostics: tombstone entries found by a scan of the layer's hash table (== ``hash_state()["tombstones"]``)."""
+        out = C.c_int64(0)
+        _lib.check(_lib.lib().mmf_debug_count_tombstones(self._h, mapper_id, int(layer), self._stream(), C.byref(out)), "mmf_debug_count_tombstones")
+        return int(out.value)
+
     def reset_stats(self, mapper_id: int = 0) -> None:
         _lib.check(_lib.lib().mmf_reset_stats(self._h, mapper_id, self._stream()), "mmf_reset_stats")
 

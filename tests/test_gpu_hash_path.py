@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from fusion_common import make_mapper, make_oracle
+from nvblox_mindmap_amd import _lib
 from nvblox_mindmap_amd import synthetic as S
 from test_gpu_fusion_parity import compare_features, compare_tsdf, dev
 
@@ -77,6 +78,9 @@ def test_unbounded_full_size_decay_churn_rebuilds_the_table(oracle_mod):
         st = gpu.hash_state(0)
         rebuilds_seen = max(rebuilds_seen, st["rebuilds"])
         assert st["live_blocks"] == orc.num_blocks(0), (k, st)
+        # the counter behind the amortised rebuild is exact: insertion takes a reused tombstone off it (a scan of the table agrees)
+        for layer in (_lib.MMF_LAYER_TSDF, _lib.MMF_LAYER_FEATURE):
+            assert gpu.count_tombstones(0, layer) == gpu.hash_state(0, layer)["tombstones"], (k, layer, gpu.hash_state(0, layer))
         if k % 6 == 5:
             compare_tsdf(orc, gpu)
     assert rebuilds_seen >= 1, f"no tombstone rebuild in 24 frames: {gpu.hash_state(0)}"

@@ -148,5 +148,6 @@ def test_soak_unbounded_500_frames_hash_churn(oracle_mod, tmp_path):
     assert exact
     compare_features(orc, gpu)
     compare_colors(orc, gpu)
-    if n_frames >= 500:
-        assert rebuilds + st["rebuilds"] >= 1, (rebuilds, st)
+    # the amortised rebuild keeps the tombstones under a quarter of the table, and its counter is exact (a scan of the table agrees):
+    # keys that leave and re-enter the view take their tombstones back, so on an orbit a rebuild may never be needed
+    assert gpu.count_tombstones(0) == st["tombstones"] and st["tombstones"] * 4 <= st["table_entries"], (rebuilds, st)
