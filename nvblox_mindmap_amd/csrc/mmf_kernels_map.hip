@@ -110,6 +110,9 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
   }
   if (active) {
     if (mc.max_dist > 0.0f && d > mc.max_dist) d = mc.max_dist;
+    if (!(d <= 3.4028235e38f)) active = false;  // +inf ("the ray hit nothing") without a maximum distance to clamp it to: no ray
+  }
+  if (active) {
     float s = d + mc.reach;
     float ray[3] = {((float)c + 0.5f - cam.cx) / cam.fx, ((float)r + 0.5f - cam.cy) / cam.fy, 1.0f};
     float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};

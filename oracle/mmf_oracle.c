@@ -605,7 +605,8 @@ static void clip_walk_start(const orc_mapper* m, const float* s0, const float* e
 }
 
 /*
- * For every raycast_subsampling-th pixel with depth > 0 and mask != 0:
+ * For every raycast_subsampling-th pixel with depth > 0 and mask != 0 (NaN fails "depth > 0"; +inf -- a simulated camera's
+ * "no return" -- passes it and is clamped like any far depth; with no maximum distance set, +inf casts no ray):
  *   d = min(depth, max_integration_distance) (if max > 0);  s = d + trunc
  *   ray_C = ((col + .5 - cx)/fx, (row + .5 - cy)/fy, 1);  p_C = s * ray_C;  p_L = T_L_C p_C
  *   walk from clip_walk_start(t_L_C*inv_bs, p_L*inv_bs) to p_L*inv_bs; every visited block inside the workspace is in view.
@@ -633,6 +634,7 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
         if (mask && !mask[(size_t)r * cam->W + c]) continue;
         if (P->max_integration_distance_m > 0.0f && d > P->max_integration_distance_m)
           d = P->max_integration_distance_m;
+        if (!(d <= 3.4028235e38f)) continue; /* +inf with no maximum distance to clamp it to: the pixel casts no ray */
         float s = m->P.raycast_to_truncation ? d + m->trunc : d;
         float ray[3] = {((float)c + 0.5f - cam->cx) / cam->fx, ((float)r + 0.5f - cam->cy) / cam->fy, 1.0f};
         float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};

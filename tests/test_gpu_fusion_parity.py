@@ -576,6 +576,48 @@ def test_degenerate_frames(oracle_mod):
     assert gpu.tsdf_layer_view(0).num_allocated_blocks() > 100
 
 
+@pytest.mark.parametrize("route", ["fused", "hash", "no_max_distance"])
+def test_non_finite_depth_pixels(oracle_mod, route):
+    """What a simulated depth camera delivers for rays that hit nothing: +inf (Isaac Lab's distance_to_image_plane), and NaN /
+    -inf / negative values from upstream arithmetic.  The spec (oracle): a tap is valid iff depth > 0 -- NaN, -inf and negative
+    pixels are no measurement; +inf is one: the ray is walked to the maximum integration distance and the voxels in front are
+    free space wherever the weighting function gives inf a weight; with no maximum distance set (a bounded workspace without
+    one: the third route) a +inf pixel casts no ray.  HIP == oracle bit for bit, nothing non-finite in the map."""
+    cfg = small_cfg(4)
+    rng = np.random.default_rng(7)
+
+    def frame(i):
+        def make():
+            f = dict(S.frame(cfg, i, 16))
+            d = f["depth"].copy()
+            h, w = d.shape
+            d[: h // 5] = np.inf                                 # sky
+            d[h // 2: h // 2 + 6, w // 3: w // 3 + 9] = np.inf    # a hole inside the scene (bilinear taps straddle its rim)
+            ys, xs = rng.integers(0, h, 40), rng.integers(0, w, 40)
+            d[ys[:20], xs[:20]] = np.nan
+            d[ys[20:30], xs[20:30]] = -np.inf
+            d[ys[30:], xs[30:]] = -1.0
+            f["depth"] = d
+            return f
+        return make
+
+    over = {"fused": {}, "hash": dict(workspace_bounds_type=0, max_integration_distance_m=2.5), "no_max_distance": dict(max_integration_distance_m=0.0)}[route]
+    gpu, orc = make_mapper(16, **over), make_oracle(oracle_mod, 16, **over)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [frame(0), frame(6), frame(40)], 16)
+    vox, idx = gpu.tsdf_layer_view(0).get_all_blocks()
+    assert idx.shape[0] > 50 and bool(torch.isfinite(vox).all())
+    # the stand-alone call and a constant weight (inf gets a weight: free space in front of the hole)
+    over2 = dict(over, weighting_mode=0)  # (the oracle's numbering: kConstantWeight)
+    gpu, orc = make_mapper(16, **over2), make_oracle(oracle_mod, 16, **over2)
+    for i in (0, 6):
+        f = frame(i)()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"])
+        gpu.add_depth_frame(dev(f["depth"]), torch.from_numpy(f["T_W_C"]), torch.from_numpy(f["K"]), None, 0)
+    compare_tsdf(orc, gpu)
+    vox, _ = gpu.tsdf_layer_view(0).get_all_blocks()
+    assert bool(torch.isfinite(vox).all())
+
+
 def test_pool_exhaustion_is_reported():
     from nvblox_mindmap_amd.nvblox_torch.mapper import Mapper
     from nvblox_mindmap_amd.nvblox_torch.mapper_params import BlockMemoryPoolParams, MapperParams
