@@ -455,6 +455,19 @@ int mmf_split_activations3(const float* x_dev, int64_t rows, int K, void* out_de
  * backbone the reference runs under TF32 (image_processing/feature_extraction.py:318-323). */
 int mmf_attention_split(const float* q_dev, const float* k_dev, const float* v_dev, int64_t row_stride, int64_t batch_stride, int B, int H,
                         int L, int head_dim, float scale, void* out_dev, int split_out, void* stream);
+/* Attention of the TRAINABLE transformer stacks, forward and backward, float32 on the f32 matrix cores: heads of up to 16 channels
+ * (the policy's: 8 heads x 15), any Lq / Lk, optional key-padding mask ([B, Lk] bytes, != 0: ignore the key).  q / k / v: the rows of
+ * head h at base + b * batch_stride + l * row_stride + h * head_dim (element strides in strides6 = {q_row, q_batch, k_row, k_batch,
+ * v_row, v_batch}: the projections' own [B, L, heads * head_dim] layout or a chunk view of a wider projection -- no head transpose,
+ * no channel padding).  forward: out [B, Lq, H * head_dim], lse [B, H, Lq] (base-2 log-sum-exp of the scaled logits, kept for the
+ * backward).  backward: dq [B, Lq, H hd], dk / dv [B, Lk, H hd] from out, dout (both contiguous) and lse; P is recomputed.
+ * Replaces F.scaled_dot_product_attention + its autograd in the reference's attention layers when they train
+ * (mindmap/diffuser_actor/layers.py / multihead_custom_attention.py; torch has no kernel shaped for a 15-channel head). */
+int mmf_train_attention_forward(const float* q_dev, const float* k_dev, const float* v_dev, const int64_t* strides6, const uint8_t* key_padding_dev,
+                                int B, int H, int Lq, int Lk, int head_dim, float scale, float* out_dev, float* lse_dev, void* stream);
+int mmf_train_attention_backward(const float* q_dev, const float* k_dev, const float* v_dev, const int64_t* strides6, const uint8_t* key_padding_dev,
+                                 int B, int H, int Lq, int Lk, int head_dim, float scale, const float* out_dev, const float* dout_dev,
+                                 const float* lse_dev, float* dsum_scratch_dev, float* dq_dev, float* dk_dev, float* dv_dev, void* stream);
 int mmf_gelu_split_activations3(const float* x_dev, int64_t rows, int K, void* out_dev, void* stream);
 int mmf_split_attention_heads3(const float* att_dev, int64_t B, int heads, int L, int head_dim, void* out_dev, void* stream);
 int mmf_layernorm_split_activations3(const float* x_dev, const float* residual_dev, const float* gamma_dev, const float* beta_dev, float eps,

@@ -344,6 +344,26 @@ int mmf_attention_split(const float* q, const float* k, const float* v, int64_t 
   return check_launch();
 }
 
+int mmf_train_attention_forward(const float* q, const float* k, const float* v, const int64_t* strides6, const uint8_t* key_padding, int B, int H,
+                                int Lq, int Lk, int head_dim, float scale, float* out, float* lse, void* stream) {
+  if (!q || !k || !v || !strides6 || !out || !lse) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_train_attention_forward");
+  const long long st[6] = {strides6[0], strides6[1], strides6[2], strides6[3], strides6[4], strides6[5]};
+  if (launch_train_attention_fwd(q, k, v, st, key_padding, B, H, Lq, Lk, head_dim, scale, out, lse, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_train_attention_forward: 1 <= head_dim <= 16, positive sizes");
+  return check_launch();
+}
+
+int mmf_train_attention_backward(const float* q, const float* k, const float* v, const int64_t* strides6, const uint8_t* key_padding, int B, int H,
+                                 int Lq, int Lk, int head_dim, float scale, const float* out, const float* dout, const float* lse, float* dsum,
+                                 float* dq, float* dk, float* dv, void* stream) {
+  if (!q || !k || !v || !strides6 || !out || !dout || !lse || !dsum || !dq || !dk || !dv)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_train_attention_backward");
+  const long long st[6] = {strides6[0], strides6[1], strides6[2], strides6[3], strides6[4], strides6[5]};
+  if (launch_train_attention_bwd(q, k, v, st, key_padding, B, H, Lq, Lk, head_dim, scale, out, dout, lse, dsum, dq, dk, dv, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_train_attention_backward: 1 <= head_dim <= 16, positive sizes");
+  return check_launch();
+}
+
 int mmf_split_linear_weight(const float* weight, int out_features, int in_features, void* split, void* stream) {
   if (!weight || !split || out_features <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_split_linear_weight");
   if (launch_split_weight(weight, out_features, in_features, split, (hipStream_t)stream) != 0)

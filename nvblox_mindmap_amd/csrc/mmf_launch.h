@@ -381,6 +381,11 @@ int launch_split_act3(const float* x, long long rows, int K, void* out, hipStrea
 int launch_attention_split(const float* q, const float* k, const float* v, long long row_stride, long long batch_stride, int B, int H, int L,
                            int head_dim, float scale, void* out, int split_out, hipStream_t s);
 int launch_split_act3_src(int src, const float* x, long long rows, int K, int heads, int L, void* out, hipStream_t s);
+int launch_train_attention_fwd(const float* q, const float* k, const float* v, const long long* strides6, const uint8_t* pad, int B, int H,
+                               int Lq, int Lk, int hd, float scale, float* out, float* lse, hipStream_t s);
+int launch_train_attention_bwd(const float* q, const float* k, const float* v, const long long* strides6, const uint8_t* pad, int B, int H,
+                               int Lq, int Lk, int hd, float scale, const float* out, const float* dout, const float* lse, float* dsum,
+                               float* dq, float* dk, float* dv, hipStream_t s);
 int launch_ln_split3(const float* x, const float* y, const float* gamma, const float* beta, float eps, long long rows, int K, float* sum_out,
                      void* out, hipStream_t s);
 int launch_self_layer(const float* const* args13, float eps1, float eps2, float* out, const float* const* next7, float* Qp, float* Kp, float* Vt,

@@ -151,6 +151,12 @@ class RelativeAttention(nn.Module):
             q = apply_rotary(q, *q_rot)
             k = apply_rotary(k, *kv_rot)
         h = self.heads
+        if not need_weights and Lq >= 64 and (self.dropout == 0.0 or not self.training):
+            from . import train_attention as TA
+
+            if TA.usable(q, D // h):
+                # the training step: forward + backward on the f32 matrix cores, straight from the [B, L, D] projections
+                return self.out_proj(TA.train_attention(q, k, v, key_padding_mask, h)), None
         q = q.view(B, Lq, h, D // h).transpose(1, 2)
         k = k.view(B, Lk, h, D // h).transpose(1, 2)
         v = v.view(B, Lk, h, D // h).transpose(1, 2)

@@ -755,3 +755,86 @@ def test_split_operand_attention_keeps_f32_accuracy(shape):
     want = torch.empty_like(a3)
     _lib.check(_lib.lib().mmf_split_activations3(_lib.dptr(got), B * L, H * d, _lib.dptr(want), _lib.stream_ptr(got.device)), "split")
     assert torch.equal(a3, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 8, 15, 616, 616, True, False), (3, 4, 16, 70, 200, False, True), (1, 2, 8, 64, 129, True, True),
+                                  (2, 3, 5, 300, 17, True, False), (4, 8, 15, 129, 616, False, True)])
+def test_training_attention_forward_and_backward_match_float64(case):
+    """mmf_train_attention_forward / _backward (the trainable stacks' attention: heads of <= 16 channels on the f32 matrix cores,
+    operands read from the [B, L, H hd] projections or chunk views of a wider one, key-padding mask) against the float64
+    softmax(q k^T / sqrt(hd) + mask) v and ITS autograd: output and the three gradients to float32 rounding."""
+    import math
+
+    from nvblox_mindmap_amd.diffuser_actor.train_attention import train_attention
+
+    B, H, hd, Lq, Lk, masked, chunk = case
+    D = H * hd
+    gen = torch.Generator(device="cuda").manual_seed(sum(case[:5]))
+    q = torch.randn(B, Lq, D, device="cuda", generator=gen, requires_grad=True)
+    if chunk:  # k, v = the two halves of one projection: rows 2 D apart
+        kv = torch.randn(B, Lk, 2 * D, device="cuda", generator=gen, requires_grad=True)
+        k, v = kv.chunk(2, dim=-1)
+    else:
+        k = torch.randn(B, Lk, D, device="cuda", generator=gen, requires_grad=True)
+        v = torch.randn(B, Lk, D, device="cuda", generator=gen, requires_grad=True)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        mask[:, Lk - Lk // 5:] = True
+        mask[0, min(5, Lk - 1)] = True
+    g = torch.randn(B, Lq, D, device="cuda", generator=gen)
+    out = train_attention(q, k, v, mask, H)
+    (out * g).sum().backward()
+    got = [out.detach(), q.grad] + ([kv.grad] if chunk else [k.grad, v.grad])
+
+    q2 = q.detach().double().requires_grad_(True)
+    if chunk:
+        kv2 = kv.detach().double().requires_grad_(True)
+        k2, v2 = kv2.chunk(2, dim=-1)
+    else:
+        k2, v2 = k.detach().double().requires_grad_(True), v.detach().double().requires_grad_(True)
+    heads = lambda t, L: t.reshape(B, L, H, hd).transpose(1, 2)  # noqa: E731
+    s = heads(q2, Lq) @ heads(k2, Lk).transpose(-1, -2) / math.sqrt(hd)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (s.softmax(-1) @ heads(v2, Lk)).transpose(1, 2).reshape(B, Lq, D)
+    (ref * g.double()).sum().backward()
+    want = [ref.detach(), q2.grad] + ([kv2.grad] if chunk else [k2.grad, v2.grad])
+    for name, a, b in zip(("out", "dq", "dkv" if chunk else "dk", "dv"), got, want):
+        err = float((a.double() - b).abs().max() / b.abs().max())
+        assert err < 1e-5, (case, name, err)
+
+
+@pytest.mark.gpu
+def test_attention_layer_trains_through_the_matrix_core_attention():
+    """RelativeAttention under autograd takes the matrix-core attention (CUDA, float32, no dropout); switched off
+    (train_attention.ENABLED) it takes torch's SDPA: same output, same parameter gradients to float32 rounding -- with rotary
+    embeddings and a key-padding mask as the diffusion head uses them."""
+    from nvblox_mindmap_amd.diffuser_actor import train_attention as TA
+    from nvblox_mindmap_amd.diffuser_actor.layers import RelativeAttention
+
+    torch.manual_seed(3)
+    B, L, D, H = 3, 200, 120, 8
+    layer = RelativeAttention(D, H).cuda().train()
+    x = torch.randn(B, L, D, device="cuda")
+    ang = torch.randn(B, L, D // 2, device="cuda")
+    rot = (ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1))
+    pad = torch.zeros(B, L, dtype=torch.bool, device="cuda")
+    pad[:, -13:] = True
+    g = torch.randn(B, L, D, device="cuda")
+
+    def run(enabled):
+        TA.ENABLED = enabled
+        try:
+            layer.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            out, _ = layer(xin, xin, q_rot=rot, kv_rot=rot, key_padding_mask=pad)
+            (out * g).sum().backward()
+            return [out.detach().clone(), xin.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            TA.ENABLED = True
+
+    mine, ref = run(True), run(False)
+    for a, b in zip(mine, ref):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
