@@ -509,6 +509,10 @@ int mmf_ddpm_step(const float* x_dev, const float* eps_dev, long long eps_row_st
                   long long rows, int C, int split, const float* coef_a_host6, const float* coef_b_host6, void* stream);
 int mmf_rotary_apply(const float* x_dev, long long x_row_stride, const float* cos_dev, const float* sin_dev, float* out_dev,
                      long long rows, int D, void* stream);
+/* The gradient of mmf_rotary_apply with respect to x (the training step): grad_out, cos, sin, grad_x all [rows, D] contiguous; the
+ * same floats autograd computes for x * cos + rotate_pairs(x) * sin. */
+int mmf_rotary_apply_grad(const float* grad_out_dev, const float* cos_dev, const float* sin_dev, float* grad_x_dev, long long rows, int D,
+                          void* stream);
 int mmf_adaln_modulate(const float* x_dev, const float* scale_shift_dev, float* out_dev, int B, int L, int D, void* stream);
 int mmf_attention_small(const float* q_dev, const float* k_dev, long long k_row_stride, const float* v_dev, long long v_row_stride,
                         const uint8_t* key_padding_dev, float* out_dev, int B, int Lq, int Lk, int heads, int head_dim, void* stream);

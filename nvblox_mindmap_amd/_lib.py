@@ -146,6 +146,7 @@ SIGNATURES = {
     "mmf_frame_masks": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "mmf_upsample_features": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _VP]),
     "mmf_rotary_apply": (_I, [_VP, C.c_longlong, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
+    "mmf_rotary_apply_grad": (_I, [_VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
     "mmf_adaln_modulate": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_qkv_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_out_ffn_block": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP]),

@@ -92,6 +92,13 @@ int mmf_rotary_apply(const float* x, long long x_row_stride, const float* cos_, 
   return check_launch();
 }
 
+int mmf_rotary_apply_grad(const float* grad_out, const float* cos_, const float* sin_, float* grad_x, long long rows, int D, void* stream) {
+  if (!grad_out || !cos_ || !sin_ || !grad_x || rows < 0 || D <= 0 || (D & 1))
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_rotary_apply_grad");
+  launch_rotary_apply_grad(grad_out, cos_, sin_, grad_x, rows, D, (hipStream_t)stream);
+  return check_launch();
+}
+
 int mmf_adaln_modulate(const float* x, const float* scale_shift, float* out, int B, int L, int D, void* stream) {
   if (!x || !scale_shift || !out || B <= 0 || L <= 0 || D <= 0) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_adaln_modulate");
   launch_adaln_modulate(x, scale_shift, out, B, L, D, (hipStream_t)stream);

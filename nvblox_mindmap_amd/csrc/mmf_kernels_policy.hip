@@ -26,6 +26,19 @@ __global__ __launch_bounds__(256) void k_rotary_apply(const float* __restrict__ 
   out[r * D + k + 1] = x1 * c1 + x0 * s1;
 }
 
+// The gradient of k_rotary_apply with respect to x (training): dx_{2k} = g_{2k} cos_{2k} + g_{2k+1} sin_{2k+1},
+// dx_{2k+1} = g_{2k+1} cos_{2k+1} + (-g_{2k}) sin_{2k} -- the floats autograd computes for x * cos + rotate_pairs(x) * sin.
+__global__ __launch_bounds__(256) void k_rotary_apply_grad(const float* __restrict__ g, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                          float* __restrict__ dx, long long n_pairs) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pairs) return;
+  const float2 gg = reinterpret_cast<const float2*>(g)[i], c = reinterpret_cast<const float2*>(cs)[i], sv = reinterpret_cast<const float2*>(sn)[i];
+  float2 o;
+  o.x = gg.x * c.x + gg.y * sv.y;
+  o.y = gg.y * c.y + (-gg.x) * sv.x;
+  reinterpret_cast<float2*>(dx)[i] = o;
+}
+
 // x, out: [B, L, D]; ss: [B, 2D] = (scale | shift)
 __global__ __launch_bounds__(256) void k_adaln_modulate(const float* __restrict__ x, const float* __restrict__ ss,
                                                        float* __restrict__ out, int L, int D, long long total) {
@@ -561,6 +574,11 @@ void launch_rotary_apply(const float* x, long long x_stride, const float* cs, co
                          hipStream_t s) {
   const long long n = rows * (D / 2);
   if (n > 0) hipLaunchKernelGGL(k_rotary_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, x_stride, cs, sn, out, rows, D);
+}
+
+void launch_rotary_apply_grad(const float* g, const float* cs, const float* sn, float* dx, long long rows, int D, hipStream_t s) {
+  const long long n = rows * (D / 2);
+  if (n > 0) hipLaunchKernelGGL(k_rotary_apply_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, cs, sn, dx, n);
 }
 
 void launch_adaln_modulate(const float* x, const float* ss, float* out, int B, int L, int D, hipStream_t s) {

@@ -340,6 +340,7 @@ size_t fps_workspace_bytes(int B, int N, int C);
 // mmf_kernels_policy.hip (inference-side fused ops of the diffusion head)
 void launch_rotary_apply(const float* x, long long x_stride, const float* cs, const float* sn, float* out, long long rows, int D,
                          hipStream_t s);
+void launch_rotary_apply_grad(const float* g, const float* cs, const float* sn, float* dx, long long rows, int D, hipStream_t s);
 void launch_adaln_modulate(const float* x, const float* ss, float* out, int B, int L, int D, hipStream_t s);
 int launch_qkv_block(const float* x, const float* ss, const float* Wq, const float* bq, const float* Wkv, const float* bkv, const float* cs,
                      const float* sn, float* qout, float* kout, float* vout, int B, int L, int D, hipStream_t s);

@@ -24,6 +24,32 @@ def rotary_apply(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch
     return out
 
 
+class _RotaryTrain(torch.autograd.Function):
+    """apply_rotary with its gradient, one kernel each way (forward: ``mmf_rotary_apply``, the composite's own float operations;
+    backward: ``mmf_rotary_apply_grad``, the floats autograd computes for it).  cos / sin carry no gradient (rotary3d)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        cos = cos.expand(x.shape).contiguous()
+        sin = sin.expand(x.shape).contiguous()
+        ctx.save_for_backward(cos, sin)
+        return rotary_apply(x, cos, sin)
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        g = g.contiguous()
+        D = g.shape[-1]
+        dx = torch.empty_like(g)
+        _lib.check(_lib.lib().mmf_rotary_apply_grad(_lib.dptr(g), _lib.dptr(cos), _lib.dptr(sin), _lib.dptr(dx), g.numel() // D, D,
+                                                    _lib.stream_ptr(g.device)), "mmf_rotary_apply_grad")
+        return dx, None, None
+
+
+def rotary_apply_train(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    return _RotaryTrain.apply(x, cos, sin)
+
+
 def adaln_modulate(x: torch.Tensor, scale_shift: torch.Tensor) -> torch.Tensor:
     """x * (1 + scale[:, None]) + shift[:, None] with scale_shift = (scale | shift) [B, 2D], x [B, L, D]."""
     x = x.contiguous()

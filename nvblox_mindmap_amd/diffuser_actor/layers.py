@@ -2,6 +2,7 @@
 blocks (counterparts of mindmap/diffuser_actor/{layers,multihead_custom_attention,position_encodings}.py;
 batch-first, ``F.scaled_dot_product_attention``)."""
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -23,6 +24,9 @@ def _block_dims():
     from .fused_ops import BLOCK_DIMS
 
     return BLOCK_DIMS
+
+
+FUSED_ROTARY_TRAINING = os.environ.get("MMF_FUSED_ROTARY", "1") != "0"  # apply_rotary as one kernel each way on CUDA float32
 
 
 def sinusoidal_embedding(x: torch.Tensor, dim: int) -> torch.Tensor:
@@ -47,6 +51,11 @@ def rotary3d(xyz: torch.Tensor, dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def apply_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """Rotate channel pairs (x_{2k}, x_{2k+1}) by the pair's angle."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and FUSED_ROTARY_TRAINING and not (cos.requires_grad or sin.requires_grad):
+        # one kernel each way instead of seven forward + their autograd (same float operations, forward and backward)
+        from .fused_ops import rotary_apply_train
+
+        return rotary_apply_train(x, cos, sin)
     x_rot = torch.stack([-x[..., 1::2], x[..., 0::2]], dim=-1).flatten(-2)
     return x * cos + x_rot * sin
 

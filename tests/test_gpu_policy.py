@@ -838,3 +838,32 @@ def test_attention_layer_trains_through_the_matrix_core_attention():
     mine, ref = run(True), run(False)
     for a, b in zip(mine, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+
+
+@pytest.mark.gpu
+def test_rotary_training_op_equals_the_composite_bit_for_bit():
+    """layers.apply_rotary on CUDA float32 = one kernel forward (mmf_rotary_apply) and one backward (mmf_rotary_apply_grad): the
+    same floats as x * cos + rotate_pairs(x) * sin and as autograd's gradient of it -- contiguous input and the key half of a fused
+    key / value projection (rows 2 D apart)."""
+    from nvblox_mindmap_amd.diffuser_actor import layers as LY
+
+    torch.manual_seed(5)
+    B, L, D = 3, 77, 120
+    cos, sin = LY.rotary3d(torch.randn(B, L, 3, device="cuda"), D)
+    g = torch.randn(B, L, D, device="cuda")
+    for chunked in (False, True):
+        base = torch.randn(B, L, 2 * D if chunked else D, device="cuda")
+
+        def run(fused):
+            LY.FUSED_ROTARY_TRAINING = fused
+            try:
+                src = base.clone().requires_grad_(True)
+                x = src.chunk(2, dim=-1)[0] if chunked else src
+                out = LY.apply_rotary(x, cos, sin)
+                (out * g).sum().backward()
+                return out.detach().clone(), src.grad.clone()
+            finally:
+                LY.FUSED_ROTARY_TRAINING = True
+
+        (o1, g1), (o0, g0) = run(True), run(False)
+        assert torch.equal(o1, o0) and torch.equal(g1, g0), chunked
