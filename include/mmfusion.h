@@ -455,6 +455,16 @@ int mmf_split_activations3(const float* x_dev, int64_t rows, int K, void* out_de
  * backbone the reference runs under TF32 (image_processing/feature_extraction.py:318-323). */
 int mmf_attention_split(const float* q_dev, const float* k_dev, const float* v_dev, int64_t row_stride, int64_t batch_stride, int B, int H,
                         int L, int head_dim, float scale, void* out_dev, int split_out, void* stream);
+/* LayerNorm(a + b) of the trainable post-norm blocks (mindmap/diffuser_actor/layers.py: D = 120), forward and backward, rows of
+ * D <= 128 channels (D a multiple of 4), float32.  forward: b may be null (plain LayerNorm(a)); with b, sum_out receives a + b (the
+ * backward pass wants the normalised input); y, mean [rows], rstd [rows].  backward: grad_x (= the gradient of a AND of b), grad_gamma,
+ * grad_beta [D] from grad_y, x (= a, or sum_out), gamma, mean, rstd; scratch: mmf_layernorm_train_scratch_bytes() bytes (per-workgroup
+ * column partials, added in a fixed order: deterministic). */
+int64_t mmf_layernorm_train_scratch_bytes(void);
+int mmf_layernorm_train_forward(const float* a_dev, const float* b_dev, const float* gamma_dev, const float* beta_dev, float eps, int64_t rows, int D,
+                                float* sum_out_dev, float* y_dev, float* mean_dev, float* rstd_dev, void* stream);
+int mmf_layernorm_train_backward(const float* grad_y_dev, const float* x_dev, const float* gamma_dev, const float* mean_dev, const float* rstd_dev,
+                                 int64_t rows, int D, float* grad_x_dev, float* grad_gamma_dev, float* grad_beta_dev, float* scratch_dev, void* stream);
 /* Attention of the TRAINABLE transformer stacks, forward and backward, float32 on the f32 matrix cores: heads of up to 16 channels
  * (the policy's: 8 heads x 15), any Lq / Lk, optional key-padding mask ([B, Lk] bytes, != 0: ignore the key).  q / k / v: the rows of
  * head h at base + b * batch_stride + l * row_stride + h * head_dim (element strides in strides6 = {q_row, q_batch, k_row, k_batch,

@@ -351,6 +351,25 @@ int mmf_attention_split(const float* q, const float* k, const float* v, int64_t 
   return check_launch();
 }
 
+int64_t mmf_layernorm_train_scratch_bytes(void) { return (int64_t)ln_train_partials_bytes(); }
+
+int mmf_layernorm_train_forward(const float* a, const float* b, const float* gamma, const float* beta, float eps, int64_t rows, int D,
+                                float* sum_out, float* y, float* mean, float* rstd, void* stream) {
+  if (!a || !gamma || !beta || !y || !mean || !rstd) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_layernorm_train_forward");
+  if (launch_ln_train_fwd(a, b, gamma, beta, eps, rows, D, sum_out, y, mean, rstd, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_layernorm_train_forward: D a multiple of 4 up to 128; sum_out comes with b");
+  return check_launch();
+}
+
+int mmf_layernorm_train_backward(const float* grad_y, const float* x, const float* gamma, const float* mean, const float* rstd, int64_t rows, int D,
+                                 float* grad_x, float* grad_gamma, float* grad_beta, float* scratch, void* stream) {
+  if (!grad_y || !x || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_layernorm_train_backward");
+  if (launch_ln_train_bwd(grad_y, x, gamma, mean, rstd, rows, D, grad_x, grad_gamma, grad_beta, scratch, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_layernorm_train_backward: D a multiple of 4 up to 128");
+  return check_launch();
+}
+
 int mmf_train_attention_forward(const float* q, const float* k, const float* v, const int64_t* strides6, const uint8_t* key_padding, int B, int H,
                                 int Lq, int Lk, int head_dim, float scale, float* out, float* lse, void* stream) {
   if (!q || !k || !v || !strides6 || !out || !lse) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_train_attention_forward");

@@ -1,0 +1,137 @@
+// mmf_kernels_train_ops.hip -- element-wise / normalisation passes of the policy's TRAINING step, forward and backward.
+//
+// LayerNorm(a + b) over rows of D <= 128 channels (the diffusion head's post-norm blocks: mindmap/diffuser_actor/layers.py, D = 120):
+// torch's native_layer_norm spends 67 us forward + 53 us backward on a [19 712, 120] input (a block per 120-float row); here half a
+// wave takes a row (32 lanes x float4), the residual add rides in the forward pass, and the backward pass produces dx and the
+// per-workgroup column partials of dgamma / dbeta in one sweep (a second small kernel adds the partials in a fixed order:
+// deterministic).  float32 throughout; mean / variance by the two-pass formula on registers.
+#include <hip/hip_runtime.h>
+
+#include "mmf_launch.h"
+
+namespace mmf {
+namespace {
+
+constexpr int kLnMaxWgs = 512;
+
+__device__ __forceinline__ float half_wave_sum(float x) {  // over the 32 lanes of a half wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o, 32);
+  return x;
+}
+
+// y = LN(a + b) gamma + beta; writes s = a + b (when b), mean and rstd per row for the backward pass.
+__global__ __launch_bounds__(256) void k_ln_train_fwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, long long rows, int D, float* __restrict__ s_out,
+                                                     float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int l = threadIdx.x & 31, c = 4 * l;
+  if (row >= rows) return;
+  const bool on = c < D;
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (on) {
+    v = *reinterpret_cast<const float4*>(a + row * D + c);
+    if (b) {
+      const float4 w = *reinterpret_cast<const float4*>(b + row * D + c);
+      v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+      *reinterpret_cast<float4*>(s_out + row * D + c) = v;
+    }
+  }
+  const float inv_d = 1.0f / (float)D;
+  const float mean = half_wave_sum((v.x + v.y) + (v.z + v.w)) * inv_d;
+  float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (on) d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+  const float var = half_wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * inv_d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (on) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = d.x * rstd * g.x + be.x;
+    o.y = d.y * rstd * g.y + be.y;
+    o.z = d.z * rstd * g.z + be.z;
+    o.w = d.w * rstd * g.w + be.w;
+    *reinterpret_cast<float4*>(y + row * D + c) = o;
+  }
+  if (l == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+// dx = (g gamma - mean_D(g gamma) - xhat mean_D(g gamma xhat)) rstd; column partials of dgamma = sum g xhat, dbeta = sum g.
+__global__ __launch_bounds__(256) void k_ln_train_bwd(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, long long rows, int D,
+                                                     float* __restrict__ dx, float* __restrict__ partials) {
+  __shared__ float s_part[8][2][128];
+  const int hw = threadIdx.x >> 5, l = threadIdx.x & 31, c = 4 * l;
+  const bool on = c < D;
+  const float inv_d = 1.0f / (float)D;
+  float4 gm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (on) gm = *reinterpret_cast<const float4*>(gamma + c);
+  float4 ag = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (long long row = (long long)blockIdx.x * 8 + hw; row < rows; row += (long long)gridDim.x * 8) {
+    float4 gv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), xv = gv;
+    const float mu = mean[row], rs = rstd[row];
+    if (on) {
+      gv = *reinterpret_cast<const float4*>(g + row * D + c);
+      xv = *reinterpret_cast<const float4*>(x + row * D + c);
+      xv = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    }
+    const float4 gg = make_float4(gv.x * gm.x, gv.y * gm.y, gv.z * gm.z, gv.w * gm.w);
+    const float c1 = half_wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * inv_d;
+    const float c2 = half_wave_sum((gg.x * xv.x + gg.y * xv.y) + (gg.z * xv.z + gg.w * xv.w)) * inv_d;
+    if (on) {
+      float4 o;
+      o.x = (gg.x - c1 - xv.x * c2) * rs;
+      o.y = (gg.y - c1 - xv.y * c2) * rs;
+      o.z = (gg.z - c1 - xv.z * c2) * rs;
+      o.w = (gg.w - c1 - xv.w * c2) * rs;
+      *reinterpret_cast<float4*>(dx + row * D + c) = o;
+    }
+    ag.x += gv.x * xv.x, ag.y += gv.y * xv.y, ag.z += gv.z * xv.z, ag.w += gv.w * xv.w;
+    ab.x += gv.x, ab.y += gv.y, ab.z += gv.z, ab.w += gv.w;
+  }
+  *reinterpret_cast<float4*>(&s_part[hw][0][c]) = ag;
+  *reinterpret_cast<float4*>(&s_part[hw][1][c]) = ab;
+  __syncthreads();
+  {  // 256 threads = 2 x 128 columns: add the eight half waves in a fixed order
+    const int which = threadIdx.x >> 7, col = threadIdx.x & 127;
+    float t = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) t += s_part[h][which][col];
+    partials[((long long)blockIdx.x * 2 + which) * 128 + col] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ln_train_bwd_reduce(const float* __restrict__ partials, int n_wgs, int D, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  const int which = threadIdx.x >> 7, col = threadIdx.x & 127;
+  if (col >= D) return;
+  float t = 0.0f;
+  for (int w = 0; w < n_wgs; ++w) t += partials[((long long)w * 2 + which) * 128 + col];
+  (which ? dbeta : dgamma)[col] = t;
+}
+
+}  // namespace
+
+size_t ln_train_partials_bytes() { return sizeof(float) * (size_t)kLnMaxWgs * 2 * 128; }
+
+// 0 = launched, 1 = unsupported shape
+int launch_ln_train_fwd(const float* a, const float* b, const float* gamma, const float* beta, float eps, long long rows, int D, float* s_out,
+                        float* y, float* mean, float* rstd, hipStream_t s) {
+  if (D <= 0 || D > 128 || (D & 3) || rows <= 0 || (b && !s_out)) return 1;
+  hipLaunchKernelGGL(k_ln_train_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, a, b, gamma, beta, eps, rows, D, s_out, y, mean, rstd);
+  return 0;
+}
+
+int launch_ln_train_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, long long rows, int D, float* dx,
+                        float* dgamma, float* dbeta, float* partials, hipStream_t s) {
+  if (D <= 0 || D > 128 || (D & 3) || rows <= 0) return 1;
+  long long want = (rows + 31) / 32;  // >= 4 rows per half wave
+  const int n_wgs = (int)(want < 1 ? 1 : (want > kLnMaxWgs ? kLnMaxWgs : want));
+  hipLaunchKernelGGL(k_ln_train_bwd, dim3(n_wgs), dim3(256), 0, s, g, x, gamma, mean, rstd, rows, D, dx, partials);
+  hipLaunchKernelGGL(k_ln_train_bwd_reduce, dim3(1), dim3(256), 0, s, partials, n_wgs, D, dgamma, dbeta);
+  return 0;
+}
+
+}  // namespace mmf

@@ -382,6 +382,11 @@ int launch_split_act3(const float* x, long long rows, int K, void* out, hipStrea
 int launch_attention_split(const float* q, const float* k, const float* v, long long row_stride, long long batch_stride, int B, int H, int L,
                            int head_dim, float scale, void* out, int split_out, hipStream_t s);
 int launch_split_act3_src(int src, const float* x, long long rows, int K, int heads, int L, void* out, hipStream_t s);
+size_t ln_train_partials_bytes();
+int launch_ln_train_fwd(const float* a, const float* b, const float* gamma, const float* beta, float eps, long long rows, int D, float* s_out,
+                        float* y, float* mean, float* rstd, hipStream_t s);
+int launch_ln_train_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, long long rows, int D, float* dx,
+                        float* dgamma, float* dbeta, float* partials, hipStream_t s);
 int launch_train_attention_fwd(const float* q, const float* k, const float* v, const long long* strides6, const uint8_t* pad, int B, int H,
                                int Lq, int Lk, int hd, float scale, float* out, float* lse, hipStream_t s);
 int launch_train_attention_bwd(const float* q, const float* k, const float* v, const long long* strides6, const uint8_t* pad, int B, int H,

@@ -9,6 +9,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .train_ops import add_layer_norm
+
 
 # Inference fast path (DiffuserActor.enable_fused_inference): fused HIP ops instead of the composite torch ops wherever a
 # block runs without autograd on CUDA float32 tensors.  Rotary / AdaLN are the same float operations; the attention core
@@ -160,7 +162,7 @@ class RelativeAttention(nn.Module):
             q = apply_rotary(q, *q_rot)
             k = apply_rotary(k, *kv_rot)
         h = self.heads
-        if not need_weights and Lq >= 64 and (self.dropout == 0.0 or not self.training):
+        if not need_weights and (self.dropout == 0.0 or not self.training):
             from . import train_attention as TA
 
             if TA.usable(q, D // h):
@@ -220,7 +222,7 @@ class AttentionBlock(nn.Module):
             return FO.attn_out_block(att, query, A.out_proj, self.norm), None
         q_in = self.adaln(query, cond, cond_act) if (self.adaln is not None and cond is not None) else query
         out, w = self.attn(q_in, memory, q_rot, kv_rot, key_padding_mask, need_weights, kv_cache)
-        return self.norm(query + self.drop(out)), w
+        return add_layer_norm(query, self.drop(out), self.norm), w
 
 
 class FeedForwardBlock(nn.Module):
@@ -245,7 +247,7 @@ class FeedForwardBlock(nn.Module):
             return FO.ffn_block(x, ss, self.fc1, self.fc2, self.norm)
         if self.adaln is not None and cond is not None:
             x = self.adaln(x, cond, cond_act)
-        return self.norm(x + self.drop(self.fc2(self.drop(F.relu(self.fc1(x))))))
+        return add_layer_norm(x, self.drop(self.fc2(self.drop(F.relu(self.fc1(x))))), self.norm)
 
 
 class AttentionStack(nn.Module):

@@ -1,0 +1,64 @@
+"""Normalisation of the trainable post-norm blocks with its backward on libmmfusion kernels (csrc/mmf_kernels_train_ops.hip):
+``add_layer_norm(a, b, norm)`` = ``norm(a + b)`` of mindmap/diffuser_actor/layers.py's attention / feed-forward blocks, one kernel
+forward (the residual add rides in it), two backward (dx + column partials, then the partials' sum in a fixed order)."""
+import os
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+ENABLED = os.environ.get("MMF_TRAIN_LAYERNORM", "1") != "0"
+
+
+def usable(x: torch.Tensor, norm) -> bool:
+    D = x.shape[-1]
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and D <= 128 and D % 4 == 0
+            and tuple(norm.normalized_shape) == (D,) and norm.weight is not None and norm.bias is not None)
+
+
+def _partials(device) -> torch.Tensor:
+    # per call, from torch's caching allocator: safe inside a captured graph (its private pool) and across streams
+    return torch.empty(int(_lib.lib().mmf_layernorm_train_scratch_bytes()) // 4, dtype=torch.float32, device=device)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, eps: float):
+        a = a.contiguous()
+        D = a.shape[-1]
+        rows = a.numel() // D
+        y = torch.empty_like(a)
+        mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+        s = None
+        if b is not None:
+            b = b.contiguous()
+            s = torch.empty_like(a)
+        _lib.check(_lib.lib().mmf_layernorm_train_forward(_lib.dptr(a), _lib.dptr(b), _lib.dptr(weight), _lib.dptr(bias), float(eps), rows, D,
+                                                          _lib.dptr(s), _lib.dptr(y), _lib.dptr(mean), _lib.dptr(rstd), _lib.stream_ptr(a.device)),
+                   "mmf_layernorm_train_forward")
+        ctx.save_for_backward(a if s is None else s, weight, mean, rstd)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, rstd = ctx.saved_tensors
+        g = g.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mmf_layernorm_train_backward(_lib.dptr(g), _lib.dptr(x), _lib.dptr(weight), _lib.dptr(mean), _lib.dptr(rstd), rows, D,
+                                                           _lib.dptr(dx), _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(_partials(x.device)),
+                                                           _lib.stream_ptr(x.device)), "mmf_layernorm_train_backward")
+        return dx, (dx if ctx.has_b else None), dgamma, dbeta, None
+
+
+def add_layer_norm(a: torch.Tensor, b: Optional[torch.Tensor], norm) -> torch.Tensor:
+    """``norm(a + b)`` (``b`` None: ``norm(a)``) for an ``nn.LayerNorm`` over the last dimension."""
+    if usable(a, norm):
+        return _AddLayerNorm.apply(a, b, norm.weight, norm.bias, norm.eps)
+    return norm(a if b is None else a + b)

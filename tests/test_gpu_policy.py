@@ -759,7 +759,7 @@ def test_split_operand_attention_keeps_f32_accuracy(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 8, 15, 616, 616, True, False), (3, 4, 16, 70, 200, False, True), (1, 2, 8, 64, 129, True, True),
-                                  (2, 3, 5, 300, 17, True, False), (4, 8, 15, 129, 616, False, True)])
+                                  (2, 3, 5, 300, 17, True, False), (4, 8, 15, 129, 616, False, True), (2, 8, 15, 3, 3072, False, True)])
 def test_training_attention_forward_and_backward_match_float64(case):
     """mmf_train_attention_forward / _backward (the trainable stacks' attention: heads of <= 16 channels on the f32 matrix cores,
     operands read from the [B, L, H hd] projections or chunk views of a wider one, key-padding mask) against the float64
@@ -867,3 +867,40 @@ def test_rotary_training_op_equals_the_composite_bit_for_bit():
 
         (o1, g1), (o0, g0) = run(True), run(False)
         assert torch.equal(o1, o0) and torch.equal(g1, g0), chunked
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows_shape", [(32, 616), (3, 7), (1, 1), (2, 3072)])
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_training_layernorm_matches_torch(rows_shape, with_residual):
+    """train_ops.add_layer_norm (LayerNorm(a + b) of the post-norm blocks, D = 120: one kernel forward, dx + deterministic column
+    partials backward) against nn.LayerNorm(a + b) and its autograd in float64."""
+    from nvblox_mindmap_amd.diffuser_actor.train_ops import add_layer_norm
+
+    torch.manual_seed(11)
+    D = 120
+    norm = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.3, 0.3)
+    a = (torch.randn(*rows_shape, D, device="cuda") * 2.0 + 0.7).requires_grad_(True)
+    b = torch.randn(*rows_shape, D, device="cuda").requires_grad_(True) if with_residual else None
+    g = torch.randn(*rows_shape, D, device="cuda")
+    y = add_layer_norm(a, b, norm)
+    (y * g).sum().backward()
+    got = [y.detach(), a.grad] + ([b.grad] if with_residual else []) + [norm.weight.grad.clone(), norm.bias.grad.clone()]
+    n64 = torch.nn.LayerNorm(D).cuda().double()
+    n64.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    a2 = a.detach().double().requires_grad_(True)
+    b2 = b.detach().double().requires_grad_(True) if with_residual else None
+    y2 = n64(a2 + b2 if with_residual else a2)
+    (y2 * g.double()).sum().backward()
+    want = [y2.detach(), a2.grad] + ([b2.grad] if with_residual else []) + [n64.weight.grad, n64.bias.grad]
+    for u, w in zip(got, want):
+        assert float((u.double() - w).abs().max()) <= 3e-6 * max(float(w.abs().max()), 1.0), rows_shape
+    # deterministic: the same gradients bit for bit on a second run
+    norm.zero_grad(set_to_none=True)
+    a3 = a.detach().clone().requires_grad_(True)
+    b3 = b.detach().clone().requires_grad_(True) if with_residual else None
+    (add_layer_norm(a3, b3, norm) * g).sum().backward()
+    assert torch.equal(a3.grad, a.grad) and torch.equal(norm.weight.grad, got[-2]) and torch.equal(norm.bias.grad, got[-1])
