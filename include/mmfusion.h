@@ -455,6 +455,12 @@ int mmf_split_activations3(const float* x_dev, int64_t rows, int K, void* out_de
  * backbone the reference runs under TF32 (image_processing/feature_extraction.py:318-323). */
 int mmf_attention_split(const float* q_dev, const float* k_dev, const float* v_dev, int64_t row_stride, int64_t batch_stride, int B, int H,
                         int L, int head_dim, float scale, void* out_dev, int split_out, void* stream);
+/* The gradient of mmf_adaln_modulate (y = x (1 + scale_b) + shift_b, (scale | shift) = scale_shift [B, 2 D]) for the training step:
+ * grad_x [B, L, D] = grad_out (1 + scale), grad_scale_shift [B, 2 D] = (sum_L grad_out x | sum_L grad_out); D a multiple of 4 up to 128;
+ * scratch: mmf_adaln_modulate_grad_scratch_bytes(B) bytes (column partials, added in a fixed order). */
+int64_t mmf_adaln_modulate_grad_scratch_bytes(int B);
+int mmf_adaln_modulate_grad(const float* grad_out_dev, const float* x_dev, const float* scale_shift_dev, int B, int L, int D, float* grad_x_dev,
+                            float* grad_scale_shift_dev, float* scratch_dev, void* stream);
 /* LayerNorm(a + b) of the trainable post-norm blocks (mindmap/diffuser_actor/layers.py: D = 120), forward and backward, rows of
  * D <= 128 channels (D a multiple of 4), float32.  forward: b may be null (plain LayerNorm(a)); with b, sum_out receives a + b (the
  * backward pass wants the normalised input); y, mean [rows], rstd [rows].  backward: grad_x (= the gradient of a AND of b), grad_gamma,

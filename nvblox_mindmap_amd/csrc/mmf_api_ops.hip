@@ -370,6 +370,17 @@ int mmf_layernorm_train_backward(const float* grad_y, const float* x, const floa
   return check_launch();
 }
 
+int64_t mmf_adaln_modulate_grad_scratch_bytes(int B) { return B > 0 ? (int64_t)adaln_train_scratch_bytes(B) : 0; }
+
+int mmf_adaln_modulate_grad(const float* grad_out, const float* x, const float* scale_shift, int B, int L, int D, float* grad_x,
+                            float* grad_scale_shift, float* scratch, void* stream) {
+  if (!grad_out || !x || !scale_shift || !grad_x || !grad_scale_shift || !scratch)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_adaln_modulate_grad");
+  if (launch_adaln_train_bwd(grad_out, x, scale_shift, B, L, D, grad_x, grad_scale_shift, scratch, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_adaln_modulate_grad: D a multiple of 4 up to 128");
+  return check_launch();
+}
+
 int mmf_train_attention_forward(const float* q, const float* k, const float* v, const int64_t* strides6, const uint8_t* key_padding, int B, int H,
                                 int Lq, int Lk, int head_dim, float scale, float* out, float* lse, void* stream) {
   if (!q || !k || !v || !strides6 || !out || !lse) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_train_attention_forward");

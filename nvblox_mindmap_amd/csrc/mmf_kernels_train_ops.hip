@@ -112,6 +112,48 @@ __global__ __launch_bounds__(256) void k_ln_train_bwd_reduce(const float* __rest
   (which ? dbeta : dgamma)[col] = t;
 }
 
+// ---- AdaLN modulation, backward: y = x (1 + scale_b) + shift_b with (scale | shift) [B, 2 D] broadcast over the L rows of a batch element.
+// dx = g (1 + scale); dscale_b = sum_L g x; dshift_b = sum_L g -- one sweep, column partials per (batch element, row chunk), added in
+// a fixed order by the second kernel.  (The forward pass is mmf_adaln_modulate.)
+constexpr int kAdaChunks = 8;
+
+__global__ __launch_bounds__(256) void k_adaln_train_bwd(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ ss, int L,
+                                                        int D, float* __restrict__ dx, float* __restrict__ partials) {
+  __shared__ float s_part[8][2][128];
+  const int b = blockIdx.x / kAdaChunks, ch = blockIdx.x % kAdaChunks;
+  const int hw = threadIdx.x >> 5, l = threadIdx.x & 31, c = 4 * l;
+  const bool on = c < D;
+  float4 sc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (on) sc = *reinterpret_cast<const float4*>(ss + (long long)b * 2 * D + c);
+  sc = make_float4(1.0f + sc.x, 1.0f + sc.y, 1.0f + sc.z, 1.0f + sc.w);
+  float4 as = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ah = as;
+  if (on)
+    for (int row = ch * 8 + hw; row < L; row += kAdaChunks * 8) {
+      const long long o = ((long long)b * L + row) * D + c;
+      const float4 gv = *reinterpret_cast<const float4*>(g + o), xv = *reinterpret_cast<const float4*>(x + o);
+      *reinterpret_cast<float4*>(dx + o) = make_float4(gv.x * sc.x, gv.y * sc.y, gv.z * sc.z, gv.w * sc.w);
+      as.x += gv.x * xv.x, as.y += gv.y * xv.y, as.z += gv.z * xv.z, as.w += gv.w * xv.w;
+      ah.x += gv.x, ah.y += gv.y, ah.z += gv.z, ah.w += gv.w;
+    }
+  *reinterpret_cast<float4*>(&s_part[hw][0][c]) = as;
+  *reinterpret_cast<float4*>(&s_part[hw][1][c]) = ah;
+  __syncthreads();
+  const int which = threadIdx.x >> 7, col = threadIdx.x & 127;
+  float t = 0.0f;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) t += s_part[h][which][col];
+  partials[((long long)blockIdx.x * 2 + which) * 128 + col] = t;
+}
+
+__global__ __launch_bounds__(256) void k_adaln_train_bwd_reduce(const float* __restrict__ partials, int D, float* __restrict__ dss) {
+  const int b = blockIdx.x, which = threadIdx.x >> 7, col = threadIdx.x & 127;
+  if (col >= D) return;
+  float t = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < kAdaChunks; ++ch) t += partials[(((long long)b * kAdaChunks + ch) * 2 + which) * 128 + col];
+  dss[(long long)b * 2 * D + which * D + col] = t;
+}
+
 }  // namespace
 
 size_t ln_train_partials_bytes() { return sizeof(float) * (size_t)kLnMaxWgs * 2 * 128; }
@@ -134,4 +176,16 @@ int launch_ln_train_bwd(const float* g, const float* x, const float* gamma, cons
   return 0;
 }
 
+}  // namespace mmf
+
+namespace mmf {
+size_t adaln_train_scratch_bytes(int B) { return sizeof(float) * (size_t)B * kAdaChunks * 2 * 128; }
+
+int launch_adaln_train_bwd(const float* g, const float* x, const float* ss, int B, int L, int D, float* dx, float* dss, float* partials,
+                           hipStream_t s) {
+  if (D <= 0 || D > 128 || (D & 3) || B <= 0 || L <= 0) return 1;
+  hipLaunchKernelGGL(k_adaln_train_bwd, dim3((unsigned)(B * kAdaChunks)), dim3(256), 0, s, g, x, ss, L, D, dx, partials);
+  hipLaunchKernelGGL(k_adaln_train_bwd_reduce, dim3((unsigned)B), dim3(256), 0, s, partials, D, dss);
+  return 0;
+}
 }  // namespace mmf

@@ -383,6 +383,9 @@ int launch_attention_split(const float* q, const float* k, const float* v, long 
                            int head_dim, float scale, void* out, int split_out, hipStream_t s);
 int launch_split_act3_src(int src, const float* x, long long rows, int K, int heads, int L, void* out, hipStream_t s);
 size_t ln_train_partials_bytes();
+size_t adaln_train_scratch_bytes(int B);
+int launch_adaln_train_bwd(const float* g, const float* x, const float* ss, int B, int L, int D, float* dx, float* dss, float* partials,
+                           hipStream_t s);
 int launch_ln_train_fwd(const float* a, const float* b, const float* gamma, const float* beta, float eps, long long rows, int D, float* s_out,
                         float* y, float* mean, float* rstd, hipStream_t s);
 int launch_ln_train_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, long long rows, int D, float* dx,

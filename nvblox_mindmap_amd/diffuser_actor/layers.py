@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .train_ops import add_layer_norm
+from .train_ops import adaln_modulate_train, adaln_usable, add_layer_norm
 
 
 # Inference fast path (DiffuserActor.enable_fused_inference): fused HIP ops instead of the composite torch ops wherever a
@@ -103,6 +103,8 @@ class AdaLN(nn.Module):
             from .fused_ops import adaln_modulate
 
             return adaln_modulate(x, ss)
+        if adaln_usable(x) and ss.dim() == 2:
+            return adaln_modulate_train(x, ss)  # the training step: one kernel forward, one sweep + a small sum backward
         scale, shift = ss.chunk(2, dim=-1)
         return x * (1 + scale[:, None, :]) + shift[:, None, :]
 

@@ -62,3 +62,36 @@ def add_layer_norm(a: torch.Tensor, b: Optional[torch.Tensor], norm) -> torch.Te
     if usable(a, norm):
         return _AddLayerNorm.apply(a, b, norm.weight, norm.bias, norm.eps)
     return norm(a if b is None else a + b)
+
+
+class _AdaLNModulate(torch.autograd.Function):
+    """x * (1 + scale[:, None]) + shift[:, None]: forward = mmf_adaln_modulate (the composite's float operations), backward = one sweep
+    (dx and the per-batch-element column sums of g x and g) + the partials' sum."""
+
+    @staticmethod
+    def forward(ctx, x, ss):
+        from .fused_ops import adaln_modulate
+
+        x, ss = x.contiguous(), ss.contiguous()
+        ctx.save_for_backward(x, ss)
+        return adaln_modulate(x, ss)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ss = ctx.saved_tensors
+        g = g.contiguous()
+        B, L, D = x.shape
+        dx, dss = torch.empty_like(x), torch.empty_like(ss)
+        scratch = torch.empty(int(_lib.lib().mmf_adaln_modulate_grad_scratch_bytes(B)) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mmf_adaln_modulate_grad(_lib.dptr(g), _lib.dptr(x), _lib.dptr(ss), B, L, D, _lib.dptr(dx), _lib.dptr(dss),
+                                                      _lib.dptr(scratch), _lib.stream_ptr(x.device)), "mmf_adaln_modulate_grad")
+        return dx, dss
+
+
+def adaln_usable(x: torch.Tensor) -> bool:
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and torch.is_grad_enabled() and x.shape[-1] <= 128
+            and x.shape[-1] % 4 == 0)
+
+
+def adaln_modulate_train(x: torch.Tensor, scale_shift: torch.Tensor) -> torch.Tensor:
+    return _AdaLNModulate.apply(x, scale_shift)

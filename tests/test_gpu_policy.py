@@ -904,3 +904,38 @@ def test_training_layernorm_matches_torch(rows_shape, with_residual):
     b3 = b.detach().clone().requires_grad_(True) if with_residual else None
     (add_layer_norm(a3, b3, norm) * g).sum().backward()
     assert torch.equal(a3.grad, a.grad) and torch.equal(norm.weight.grad, got[-2]) and torch.equal(norm.bias.grad, got[-1])
+
+
+@pytest.mark.gpu
+def test_training_adaln_matches_the_composite():
+    """AdaLN's modulation under autograd on CUDA (train_ops.adaln_modulate_train): the composite's output bit for bit, its gradients
+    (dx, and the sums over L for scale and shift) to float32 rounding against float64."""
+    from nvblox_mindmap_amd.diffuser_actor import train_ops as TO
+    from nvblox_mindmap_amd.diffuser_actor.layers import AdaLN
+
+    torch.manual_seed(13)
+    B, L, D = 5, 616, 120
+    mod = AdaLN(D).cuda()
+    with torch.no_grad():
+        mod.proj.weight.normal_(0, 0.05)
+        mod.proj.bias.normal_(0, 0.05)
+    x0, cond, g = torch.randn(B, L, D, device="cuda"), torch.randn(B, D, device="cuda"), torch.randn(B, L, D, device="cuda")
+
+    def run(enabled, dtype=torch.float32):
+        TO.ENABLED = enabled
+        try:
+            m = mod if dtype == torch.float32 else AdaLN(D).cuda().to(dtype)
+            if dtype != torch.float32:
+                m.load_state_dict({k: v.to(dtype) for k, v in mod.state_dict().items()})
+            m.zero_grad(set_to_none=True)
+            x = x0.detach().clone().to(dtype).requires_grad_(True)
+            y = m(x, cond.to(dtype))
+            (y * g.to(dtype)).sum().backward()
+            return y.detach().clone(), x.grad.clone(), m.proj.weight.grad.clone(), m.proj.bias.grad.clone()
+        finally:
+            TO.ENABLED = True
+
+    mine, comp, ref = run(True), run(False), run(False, torch.float64)
+    assert torch.equal(mine[0], comp[0])
+    for a, b in zip(mine[1:], ref[1:]):
+        assert float((a.double() - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1.0)
