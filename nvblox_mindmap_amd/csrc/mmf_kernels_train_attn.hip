@@ -92,14 +92,18 @@ __device__ __forceinline__ float key_bias(const AttnArgs& A, int b, int kk) {
 
 // ---- forward --------------------------------------------------------------------------------------------------------------------
 // grid: B H ceil(Lq / 128) workgroups of 8 waves; wave w of query tile t owns queries 128 t + 16 w + (0..15).
+// FEW (Lq <= 16: the cross-attention of a few query tokens over a long memory): one workgroup per (batch, head), every wave holds
+// the SAME 16 query columns and takes every kNW-th 16-key tile of a chunk; the waves' (maximum, sum, accumulator) are merged through
+// LDS at the end.
+template <bool FEW>
 __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) float sK[kC][kRS];
   __shared__ __attribute__((aligned(16))) float sVt[16][kTS];
   __shared__ __attribute__((aligned(16))) float sBias[kC];
-  const int nqt = (A.Lq + 16 * kNW - 1) / (16 * kNW);
+  const int nqt = FEW ? 1 : (A.Lq + 16 * kNW - 1) / (16 * kNW);
   const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, b = bh / A.H, h = bh % A.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, grp = lane >> 4;
-  const int qi = qt * 16 * kNW + wave * 16 + col;
+  const int qi = FEW ? col : qt * 16 * kNW + wave * 16 + col;
   const bool qok = qi < A.Lq;
   const int D = A.H * A.hd;
   float qreg[4];
@@ -130,10 +134,11 @@ __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict
       if (threadIdx.x < kC) rbias = key_bias(A, b, k0 + kC + (int)threadIdx.x);
     }
     const int nk = min(kC, A.Lk - k0);
-    for (int t0 = 0; t0 < nk; t0 += 64) {  // 64 keys: four 16 x 16 tiles
-      f4 s[4];
+    constexpr int NTL = FEW ? 1 : 4;  // tiles of 16 keys per softmax update
+    for (int t0 = FEW ? 16 * wave : 0; t0 < nk; t0 += FEW ? 16 * kNW : 64) {
+      f4 s[NTL];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NTL; ++t) {
         const f4 ka = *reinterpret_cast<const f4*>(&sK[t0 + 16 * t + col][4 * grp]);
         f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         acc = mfma4(ka.x, qreg[0], acc);
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict
       }
       float mx = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t].x, s[t].y), fmaxf(s[t].z, s[t].w)));
+      for (int t = 0; t < NTL; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t].x, s[t].y), fmaxf(s[t].z, s[t].w)));
       mx = xmax(mx);
       const float m_new = fmaxf(m_run, mx);
       const float m_use = m_new == -INFINITY ? 0.0f : m_new;  // every key so far is masked: all p are exp2(-inf) = 0
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict
       m_run = m_new;
       float ps = 0.0f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NTL; ++t) {
         s[t].x = ex2(s[t].x - m_use);
         s[t].y = ex2(s[t].y - m_use);
         s[t].z = ex2(s[t].z - m_use);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict
       l_run = l_run * alpha + ps;
       o *= alpha;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NTL; ++t) {
         const f4 va = *reinterpret_cast<const f4*>(&sVt[col][t0 + 16 * t + 4 * grp]);
         o = mfma4(va.x, s[t].x, o);
         o = mfma4(va.y, s[t].y, o);
@@ -171,7 +176,28 @@ __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict
       }
     }
   }
-  const float l_tot = xsum(l_run);
+  float l_tot = xsum(l_run);
+  if (FEW) {  // merge the waves' partial softmax states (all over the same queries, disjoint keys)
+    __shared__ float s_m[kNW][16], s_l[kNW][16];
+    __shared__ __attribute__((aligned(16))) float s_o[kNW][64][4];
+    if (grp == 0) s_m[wave][col] = m_run, s_l[wave][col] = l_tot;
+    *reinterpret_cast<f4*>(&s_o[wave][lane][0]) = o;
+    __syncthreads();
+    if (wave != 0) return;
+    float m_all = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) m_all = fmaxf(m_all, s_m[w][col]);
+    const float m_use = m_all == -INFINITY ? 0.0f : m_all;
+    l_tot = 0.0f;
+    o = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) {
+      const float f = ex2(s_m[w][col] - m_use);
+      l_tot += s_l[w][col] * f;
+      o += *reinterpret_cast<const f4*>(&s_o[w][lane][0]) * f;
+    }
+    m_run = m_all;
+  }
   const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   if (qok) {
     float* op = out + ((long long)b * A.Lq + qi) * D + h * A.hd;
@@ -185,16 +211,17 @@ __global__ __launch_bounds__(kNT) void k_tattn_fwd(AttnArgs A, float* __restrict
 
 // ---- backward: dQ ---------------------------------------------------------------------------------------------------------------
 // Also writes D[b, h, q] = sum_c dO[q, c] O[q, c] (dsum) for the dK / dV kernel that follows it on the stream.
+template <bool FEW>
 __global__ __launch_bounds__(kNT) void k_tattn_dq(AttnArgs A, const float* __restrict__ out, const float* __restrict__ dout,
                                                   const float* __restrict__ lse, float* __restrict__ dq, float* __restrict__ dsum_out) {
   __shared__ __attribute__((aligned(16))) float sK[kC][kRS];
   __shared__ __attribute__((aligned(16))) float sKt[16][kTS];
   __shared__ __attribute__((aligned(16))) float sV[kC][kRS];
   __shared__ __attribute__((aligned(16))) float sBias[kC];
-  const int nqt = (A.Lq + 16 * kNW - 1) / (16 * kNW);
+  const int nqt = FEW ? 1 : (A.Lq + 16 * kNW - 1) / (16 * kNW);
   const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, b = bh / A.H, h = bh % A.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, grp = lane >> 4;
-  const int qi = qt * 16 * kNW + wave * 16 + col;
+  const int qi = FEW ? col : qt * 16 * kNW + wave * 16 + col;
   const bool qok = qi < A.Lq;
   const int D = A.H * A.hd;
   float qreg[4], doreg[4], dsum = 0.0f;
@@ -211,7 +238,7 @@ __global__ __launch_bounds__(kNT) void k_tattn_dq(AttnArgs A, const float* __res
     }
   }
   dsum = xsum(dsum);  // D[q] = sum_c dO[q, c] O[q, c]
-  if (qok && grp == 0) dsum_out[((long long)b * A.H + h) * A.Lq + qi] = dsum;
+  if (qok && grp == 0 && (!FEW || wave == 0)) dsum_out[((long long)b * A.H + h) * A.Lq + qi] = dsum;
   const float my_lse = qok ? lse[((long long)b * A.H + h) * A.Lq + qi] : INFINITY;
   const float* kb = A.k + (long long)b * A.k_bs + h * A.hd;
   const float* vb = A.v + (long long)b * A.v_bs + h * A.hd;
@@ -233,7 +260,7 @@ __global__ __launch_bounds__(kNT) void k_tattn_dq(AttnArgs A, const float* __res
       if (threadIdx.x < kC) rbias = key_bias(A, b, k0 + kC + (int)threadIdx.x);
     }
     const int nk = min(kC, A.Lk - k0);
-    for (int t0 = 0; t0 < nk; t0 += 16) {
+    for (int t0 = FEW ? 16 * wave : 0; t0 < nk; t0 += FEW ? 16 * kNW : 16) {
       const f4 ka = *reinterpret_cast<const f4*>(&sK[t0 + col][4 * grp]);
       const f4 va = *reinterpret_cast<const f4*>(&sV[t0 + col][4 * grp]);
       f4 s = {0.0f, 0.0f, 0.0f, 0.0f}, dp = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -257,6 +284,15 @@ __global__ __launch_bounds__(kNT) void k_tattn_dq(AttnArgs A, const float* __res
       acc_q = mfma4(kt.z, ds.z, acc_q);
       acc_q = mfma4(kt.w, ds.w, acc_q);
     }
+  }
+  if (FEW) {  // the waves hold partial sums over disjoint keys: add them in a fixed order
+    __shared__ __attribute__((aligned(16))) float s_q[kNW][64][4];
+    *reinterpret_cast<f4*>(&s_q[wave][lane][0]) = acc_q;
+    __syncthreads();
+    if (wave != 0) return;
+    acc_q = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) acc_q += *reinterpret_cast<const f4*>(&s_q[w][lane][0]);
   }
   if (qok) {
     float* dp_ = dq + ((long long)b * A.Lq + qi) * D + h * A.hd;
@@ -379,7 +415,10 @@ int launch_train_attention_fwd(const float* q, const float* k, const float* v, c
                                int Lq, int Lk, int hd, float scale, float* out, float* lse, hipStream_t s) {
   AttnArgs A{q, k, v, strides6[0], strides6[1], strides6[2], strides6[3], strides6[4], strides6[5], pad, B, H, Lq, Lk, hd, scale};
   if (!args_ok(A)) return 1;
-  hipLaunchKernelGGL(k_tattn_fwd, dim3((unsigned)(B * H * ((Lq + 16 * kNW - 1) / (16 * kNW)))), dim3(kNT), 0, s, A, out, lse);
+  if (Lq <= 16)
+    hipLaunchKernelGGL(k_tattn_fwd<true>, dim3((unsigned)(B * H)), dim3(kNT), 0, s, A, out, lse);
+  else
+    hipLaunchKernelGGL(k_tattn_fwd<false>, dim3((unsigned)(B * H * ((Lq + 16 * kNW - 1) / (16 * kNW)))), dim3(kNT), 0, s, A, out, lse);
   return 0;
 }
 
@@ -388,7 +427,10 @@ int launch_train_attention_bwd(const float* q, const float* k, const float* v, c
                                float* dq, float* dk, float* dv, hipStream_t s) {
   AttnArgs A{q, k, v, strides6[0], strides6[1], strides6[2], strides6[3], strides6[4], strides6[5], pad, B, H, Lq, Lk, hd, scale};
   if (!args_ok(A)) return 1;
-  hipLaunchKernelGGL(k_tattn_dq, dim3((unsigned)(B * H * ((Lq + 16 * kNW - 1) / (16 * kNW)))), dim3(kNT), 0, s, A, out, dout, lse, dq, dsum);
+  if (Lq <= 16)
+    hipLaunchKernelGGL(k_tattn_dq<true>, dim3((unsigned)(B * H)), dim3(kNT), 0, s, A, out, dout, lse, dq, dsum);
+  else
+    hipLaunchKernelGGL(k_tattn_dq<false>, dim3((unsigned)(B * H * ((Lq + 16 * kNW - 1) / (16 * kNW)))), dim3(kNT), 0, s, A, out, dout, lse, dq, dsum);
   hipLaunchKernelGGL(k_tattn_dkv, dim3((unsigned)(B * H * ((Lk + 16 * kNW - 1) / (16 * kNW)))), dim3(kNT), 0, s, A, dout, lse, dsum, dk, dv);
   return 0;
 }

@@ -12,7 +12,7 @@
 namespace mmf {
 namespace {
 
-constexpr int kLnMaxWgs = 512;
+constexpr int kLnMaxWgs = 256;  // one per CU: the sweep is short, the partials' sum is what must stay small
 
 __device__ __forceinline__ float half_wave_sum(float x) {  // over the 32 lanes of a half wave
 #pragma unroll
@@ -103,13 +103,26 @@ __global__ __launch_bounds__(256) void k_ln_train_bwd(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void k_ln_train_bwd_reduce(const float* __restrict__ partials, int n_wgs, int D, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
-  const int which = threadIdx.x >> 7, col = threadIdx.x & 127;
-  if (col >= D) return;
-  float t = 0.0f;
-  for (int w = 0; w < n_wgs; ++w) t += partials[((long long)w * 2 + which) * 128 + col];
-  (which ? dbeta : dgamma)[col] = t;
+// 1024 threads = 4 parts x (2 x 128 columns): a part adds its quarter of the workgroups' partials (independent loads, unrolled),
+// the four parts are added in a fixed order through LDS: deterministic, a few dependent rounds instead of n_wgs.
+__global__ __launch_bounds__(1024) void k_ln_train_bwd_reduce(const float* __restrict__ partials, int n_wgs, int D, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  __shared__ float s_sum[4][256];
+  const int part = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int per = (n_wgs + 3) >> 2, w0 = part * per, w1 = min(n_wgs, w0 + per);
+  float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  int w = w0;
+  for (; w + 8 <= w1; w += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += partials[(long long)(w + u) * 256 + t];
+  }
+  for (; w < w1; ++w) acc[0] += partials[(long long)w * 256 + t];
+  s_sum[part][t] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (part == 0) {
+    const int which = t >> 7, col = t & 127;
+    if (col < D) (which ? dbeta : dgamma)[col] = (s_sum[0][t] + s_sum[1][t]) + (s_sum[2][t] + s_sum[3][t]);
+  }
 }
 
 // ---- AdaLN modulation, backward: y = x (1 + scale_b) + shift_b with (scale | shift) [B, 2 D] broadcast over the L rows of a batch element.
@@ -172,7 +185,7 @@ int launch_ln_train_bwd(const float* g, const float* x, const float* gamma, cons
   long long want = (rows + 31) / 32;  // >= 4 rows per half wave
   const int n_wgs = (int)(want < 1 ? 1 : (want > kLnMaxWgs ? kLnMaxWgs : want));
   hipLaunchKernelGGL(k_ln_train_bwd, dim3(n_wgs), dim3(256), 0, s, g, x, gamma, mean, rstd, rows, D, dx, partials);
-  hipLaunchKernelGGL(k_ln_train_bwd_reduce, dim3(1), dim3(256), 0, s, partials, n_wgs, D, dgamma, dbeta);
+  hipLaunchKernelGGL(k_ln_train_bwd_reduce, dim3(1), dim3(1024), 0, s, partials, n_wgs, D, dgamma, dbeta);
   return 0;
 }
 

@@ -759,7 +759,8 @@ def test_split_operand_attention_keeps_f32_accuracy(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 8, 15, 616, 616, True, False), (3, 4, 16, 70, 200, False, True), (1, 2, 8, 64, 129, True, True),
-                                  (2, 3, 5, 300, 17, True, False), (4, 8, 15, 129, 616, False, True), (2, 8, 15, 3, 3072, False, True)])
+                                  (2, 3, 5, 300, 17, True, False), (4, 8, 15, 129, 616, False, True), (2, 8, 15, 3, 3072, False, True),
+                                  (3, 4, 16, 16, 50, True, True), (1, 8, 15, 6, 200, True, False), (2, 2, 15, 17, 40, True, False)])
 def test_training_attention_forward_and_backward_match_float64(case):
     """mmf_train_attention_forward / _backward (the trainable stacks' attention: heads of <= 16 channels on the f32 matrix cores,
     operands read from the [B, L, H hd] projections or chunk views of a wider one, key-padding mask) against the float64
