@@ -171,6 +171,7 @@ class GraphedTrainStep:
         self.flat_grad = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         off = 0
         self.layout = []
+        self.grad_views = []
         with torch.no_grad():
             for name, p in self.used:
                 n = p.numel()
@@ -178,6 +179,7 @@ class GraphedTrainStep:
                 self.flat_param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
+                self.grad_views.append(p.grad)
                 self.layout.append((name, off, n))
                 off += n
         a = self.n_no_decay
@@ -208,11 +210,24 @@ class GraphedTrainStep:
     def _forward_backward(self) -> None:
         """flat_grad <- d loss / d parameters of the batch in ``self.static`` (scaled by 1 / world), ``self.losses`` <- the
         losses.  With ``overlap`` the image tokens come from ``self.feats`` (the backbone's output for this batch)."""
-        self.flat_grad.zero_()
+        # autograd HANDS OVER a parameter's gradient when the parameter has none yet (no kernel); into existing .grad views it would
+        # accumulate -- one small add_ per parameter tensor (177 launches) plus the buffer's memset.  So: backward into fresh
+        # tensors, then ONE multi-tensor copy into the flat buffer's views (every view is overwritten: no zeroing; the same values
+        # as 0 + g).
+        for _, p in self.used:
+            p.grad = None
         s = self.unpack(self.cfg, self.static)
         feats = self.feats if self.overlap else None
         losses = _forward_losses(self.cfg, self.model, s, backbone_feats=feats)
         losses[0].backward()
+        with torch.no_grad():
+            got = [(v, p.grad) for v, (_, p) in zip(self.grad_views, self.used)]
+            torch._foreach_copy_([v for v, g in got if g is not None], [g for _, g in got if g is not None])
+            for v, g in got:
+                if g is None:
+                    v.zero_()  # (a parameter the probe saw a gradient for: not expected)
+            for v, (_, p) in zip(self.grad_views, self.used):
+                p.grad = v
         if self.world > 1:
             self.flat_grad.mul_(1.0 / self.world)  # DDP scales the bucket before its all-reduce (sum)
         with torch.no_grad():
