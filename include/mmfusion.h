@@ -461,6 +461,13 @@ int mmf_attention_split(const float* q_dev, const float* k_dev, const float* v_d
 int64_t mmf_adaln_modulate_grad_scratch_bytes(int B);
 int mmf_adaln_modulate_grad(const float* grad_out_dev, const float* x_dev, const float* scale_shift_dev, int B, int L, int D, float* grad_x_dev,
                             float* grad_scale_shift_dev, float* scratch_dev, void* stream);
+/* The parameter gradients of a Linear layer y = x W^T + b over many rows (the trainable stacks' 120 -> 120 / 240 projections over
+ * 19 712 or 98 304 token rows): grad_weight [out, in] = grad_out^T x, grad_bias [out] = column sums of grad_out (null: not wanted);
+ * grad_out [rows, out], x [rows, in] contiguous; out_features <= 256, in_features <= 128.  Rows split over the chip, f32 matrix
+ * cores, splits added in a fixed order (deterministic).  scratch: mmf_linear_weight_grad_scratch_bytes(rows, out, in) bytes. */
+int64_t mmf_linear_weight_grad_scratch_bytes(int64_t rows, int out_features, int in_features);
+int mmf_linear_weight_grad(const float* grad_out_dev, const float* x_dev, int64_t rows, int out_features, int in_features, float* grad_weight_dev,
+                           float* grad_bias_dev, float* scratch_dev, void* stream);
 /* LayerNorm(a + b) of the trainable post-norm blocks (mindmap/diffuser_actor/layers.py: D = 120), forward and backward, rows of
  * D <= 128 channels (D a multiple of 4), float32.  forward: b may be null (plain LayerNorm(a)); with b, sum_out receives a + b (the
  * backward pass wants the normalised input); y, mean [rows], rstd [rows].  backward: grad_x (= the gradient of a AND of b), grad_gamma,

@@ -167,6 +167,8 @@ SIGNATURES = {
     "mmf_attention_split": (_I, [_VP, _VP, _VP, C.c_int64, C.c_int64, _I, _I, _I, _I, _F, _VP, _I, _VP]),
     "mmf_adaln_modulate_grad_scratch_bytes": (C.c_int64, [_I]),
     "mmf_adaln_modulate_grad": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "mmf_linear_weight_grad_scratch_bytes": (C.c_int64, [C.c_int64, _I, _I]),
+    "mmf_linear_weight_grad": (_I, [_VP, _VP, C.c_int64, _I, _I, _VP, _VP, _VP, _VP]),
     "mmf_layernorm_train_scratch_bytes": (C.c_int64, []),
     "mmf_layernorm_train_forward": (_I, [_VP, _VP, _VP, _VP, _F, C.c_int64, _I, _VP, _VP, _VP, _VP, _VP]),
     "mmf_layernorm_train_backward": (_I, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _I, _VP, _VP, _VP, _VP, _VP]),

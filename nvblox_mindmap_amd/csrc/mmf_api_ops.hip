@@ -381,6 +381,18 @@ int mmf_adaln_modulate_grad(const float* grad_out, const float* x, const float* 
   return check_launch();
 }
 
+int64_t mmf_linear_weight_grad_scratch_bytes(int64_t rows, int out_features, int in_features) {
+  return (rows > 0 && out_features > 0 && in_features > 0) ? (int64_t)linear_wgrad_scratch_bytes(rows, out_features, in_features) : 0;
+}
+
+int mmf_linear_weight_grad(const float* grad_out, const float* x, int64_t rows, int out_features, int in_features, float* grad_weight,
+                           float* grad_bias, float* scratch, void* stream) {
+  if (!grad_out || !x || !grad_weight || !scratch) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_linear_weight_grad");
+  if (launch_linear_wgrad(grad_out, x, rows, out_features, in_features, grad_weight, grad_bias, scratch, (hipStream_t)stream) != 0)
+    return fail(MMF_ERR_INVALID_ARG, "mmf_linear_weight_grad: out_features <= 256, in_features <= 128");
+  return check_launch();
+}
+
 int mmf_train_attention_forward(const float* q, const float* k, const float* v, const int64_t* strides6, const uint8_t* key_padding, int B, int H,
                                 int Lq, int Lk, int head_dim, float scale, float* out, float* lse, void* stream) {
   if (!q || !k || !v || !strides6 || !out || !lse) return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_train_attention_forward");

@@ -167,6 +167,94 @@ __global__ __launch_bounds__(256) void k_adaln_train_bwd_reduce(const float* __r
   dss[(long long)b * 2 * D + which * D + col] = t;
 }
 
+// ---- Linear layer, backward with respect to its parameters: dW [N, K] = g^T x, db [N] = column sums of g, for g [R, N], x [R, K] with
+// R in the tens of thousands and N, K <= 256 (the trainable stacks: 120 -> 120 / 240 over 19 712 or 98 304 token rows).  The BLAS
+// libraries' best solution for these "short and very deep" products runs at 20 - 36 TFLOP/s (28 us / 157 us); here the rows are split
+// over the chip, every split multiplies on the f32 matrix cores (M = 16 outputs, N = 16 inputs, K = 4 rows per instruction, operands
+// straight from global memory: a lane's A value is g[row][o], its B value x[row][i]) and writes its partial [N K + N] once; a second
+// kernel adds the splits in a fixed order (deterministic).  The bias gradient costs nothing extra: the A operands are the g values.
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int kWgSplitsMax = 128;
+
+template <int NIT>  // 16-wide input tiles (ceil(K / 16))
+__global__ __launch_bounds__(512) void k_linear_wgrad(const float* __restrict__ g, const float* __restrict__ x, long long R, int N, int K,
+                                                     int rows_per_split, float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, rr = lane >> 4;
+  const int otile = blockIdx.y * 8 + wave;
+  if (otile * 16 >= N) return;
+  const int o = otile * 16 + col;
+  const bool o_ok = o < N;
+  const long long r_begin = (long long)blockIdx.x * rows_per_split;
+  const long long r_end = r_begin + rows_per_split < R ? r_begin + rows_per_split : R;
+  f4v acc[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) acc[j] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+  float bsum = 0.0f;
+  for (long long r = r_begin; r < r_end; r += 16) {  // 16 rows = four matrix instructions per tile: all loads first
+    float a[4], bv[4][NIT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long row = r + 4 * u + rr;
+      const bool ok = row < r_end;
+      a[u] = (ok && o_ok) ? g[row * N + o] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int i = 16 * j + col;
+        bv[u][j] = (ok && i < K) ? x[row * K + i] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bsum += a[u];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u][j], acc[j], 0, 0, 0);
+    }
+  }
+  float* part = partials + (long long)blockIdx.x * ((long long)N * K + N);
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int i = 16 * j + col;
+    if (i < K) {
+      const float v[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int oo = otile * 16 + 4 * rr + t;
+        if (oo < N) part[(long long)oo * K + i] = v[t];
+      }
+    }
+  }
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (rr == 0 && o_ok) part[(long long)N * K + o] = bsum;
+}
+
+// dW | db = sum over the splits: 1024 threads = 4 parts x 256 elements, the parts added in a fixed order through LDS
+__global__ __launch_bounds__(1024) void k_linear_wgrad_reduce(const float* __restrict__ partials, int n_splits, long long E, long long NK,
+                                                             float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float s_sum[4][256];
+  const int part = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const long long e = (long long)blockIdx.x * 256 + t;
+  const int per = (n_splits + 3) >> 2, w0 = part * per, w1 = min(n_splits, w0 + per);
+  float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (e < E) {
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += partials[(long long)(w + u) * E + e];
+    }
+    for (; w < w1; ++w) acc[0] += partials[(long long)w * E + e];
+  }
+  s_sum[part][t] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (part == 0 && e < E) {
+    const float v = (s_sum[0][t] + s_sum[1][t]) + (s_sum[2][t] + s_sum[3][t]);
+    if (e < NK)
+      dW[e] = v;
+    else if (db)
+      db[e - NK] = v;
+  }
+}
+
 }  // namespace
 
 size_t ln_train_partials_bytes() { return sizeof(float) * (size_t)kLnMaxWgs * 2 * 128; }
@@ -199,6 +287,40 @@ int launch_adaln_train_bwd(const float* g, const float* x, const float* ss, int 
   if (D <= 0 || D > 128 || (D & 3) || B <= 0 || L <= 0) return 1;
   hipLaunchKernelGGL(k_adaln_train_bwd, dim3((unsigned)(B * kAdaChunks)), dim3(256), 0, s, g, x, ss, L, D, dx, partials);
   hipLaunchKernelGGL(k_adaln_train_bwd_reduce, dim3((unsigned)B), dim3(256), 0, s, partials, D, dss);
+  return 0;
+}
+}  // namespace mmf
+
+namespace mmf {
+static int wgrad_splits(long long R, int N) {
+  const int gy = (N + 127) / 128;
+  long long s = 256 / gy;
+  if (s > kWgSplitsMax) s = kWgSplitsMax;
+  const long long by_rows = (R + 63) / 64;  // at least 64 rows per split
+  if (s > by_rows) s = by_rows;
+  return (int)(s < 1 ? 1 : s);
+}
+size_t linear_wgrad_scratch_bytes(long long R, int N, int K) { return sizeof(float) * (size_t)wgrad_splits(R, N) * ((size_t)N * K + N); }
+
+int launch_linear_wgrad(const float* g, const float* x, long long R, int N, int K, float* dW, float* db, float* partials, hipStream_t s) {
+  if (R <= 0 || N <= 0 || K <= 0 || N > 256 || K > 128) return 1;
+  const int S = wgrad_splits(R, N);
+  int rps = (int)((R + S - 1) / S);
+  rps = (rps + 15) & ~15;
+  const dim3 grid((unsigned)S, (unsigned)((N + 127) / 128));
+  const int nit = (K + 15) / 16;
+  switch (nit) {
+    case 1: hipLaunchKernelGGL(k_linear_wgrad<1>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    case 2: hipLaunchKernelGGL(k_linear_wgrad<2>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    case 3: hipLaunchKernelGGL(k_linear_wgrad<3>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    case 4: hipLaunchKernelGGL(k_linear_wgrad<4>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    case 5: hipLaunchKernelGGL(k_linear_wgrad<5>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    case 6: hipLaunchKernelGGL(k_linear_wgrad<6>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    case 7: hipLaunchKernelGGL(k_linear_wgrad<7>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+    default: hipLaunchKernelGGL(k_linear_wgrad<8>, grid, dim3(512), 0, s, g, x, R, N, K, rps, partials); break;
+  }
+  const long long NK = (long long)N * K, E = NK + N;
+  hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((unsigned)((E + 255) / 256)), dim3(1024), 0, s, partials, S, E, NK, dW, db);
   return 0;
 }
 }  // namespace mmf

@@ -383,6 +383,8 @@ int launch_attention_split(const float* q, const float* k, const float* v, long 
                            int head_dim, float scale, void* out, int split_out, hipStream_t s);
 int launch_split_act3_src(int src, const float* x, long long rows, int K, int heads, int L, void* out, hipStream_t s);
 size_t ln_train_partials_bytes();
+size_t linear_wgrad_scratch_bytes(long long R, int N, int K);
+int launch_linear_wgrad(const float* g, const float* x, long long R, int N, int K, float* dW, float* db, float* partials, hipStream_t s);
 size_t adaln_train_scratch_bytes(int B);
 int launch_adaln_train_bwd(const float* g, const float* x, const float* ss, int B, int L, int D, float* dx, float* dss, float* partials,
                            hipStream_t s);

@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .train_ops import adaln_modulate_train, adaln_usable, add_layer_norm
+from .train_ops import linear as _tlin
 
 
 # Inference fast path (DiffuserActor.enable_fused_inference): fused HIP ops instead of the composite torch ops wherever a
@@ -158,8 +159,8 @@ class RelativeAttention(nn.Module):
                 q = rotary_apply(q, *q_rot)
             k, v = kv_cache if kv_cache is not None else self.project_kv(memory, kv_rot if q_rot is not None else None)
             return self.out_proj(attention_small(q, k, v, key_padding_mask, self.heads)), None
-        q = self.q_proj(query)
-        k, v = self.kv_proj(memory).chunk(2, dim=-1)
+        q = _tlin(self.q_proj, query)
+        k, v = _tlin(self.kv_proj, memory).chunk(2, dim=-1)
         if q_rot is not None:
             q = apply_rotary(q, *q_rot)
             k = apply_rotary(k, *kv_rot)
@@ -169,7 +170,7 @@ class RelativeAttention(nn.Module):
 
             if TA.usable(q, D // h):
                 # the training step: forward + backward on the f32 matrix cores, straight from the [B, L, D] projections
-                return self.out_proj(TA.train_attention(q, k, v, key_padding_mask, h)), None
+                return _tlin(self.out_proj, TA.train_attention(q, k, v, key_padding_mask, h)), None
         q = q.view(B, Lq, h, D // h).transpose(1, 2)
         k = k.view(B, Lk, h, D // h).transpose(1, 2)
         v = v.view(B, Lk, h, D // h).transpose(1, 2)
@@ -249,7 +250,7 @@ class FeedForwardBlock(nn.Module):
             return FO.ffn_block(x, ss, self.fc1, self.fc2, self.norm)
         if self.adaln is not None and cond is not None:
             x = self.adaln(x, cond, cond_act)
-        return add_layer_norm(x, self.drop(self.fc2(self.drop(F.relu(self.fc1(x))))), self.norm)
+        return add_layer_norm(x, self.drop(_tlin(self.fc2, self.drop(F.relu(_tlin(self.fc1, x))))), self.norm)
 
 
 class AttentionStack(nn.Module):

@@ -95,3 +95,45 @@ def adaln_usable(x: torch.Tensor) -> bool:
 
 def adaln_modulate_train(x: torch.Tensor, scale_shift: torch.Tensor) -> torch.Tensor:
     return _AdaLNModulate.apply(x, scale_shift)
+
+
+class _LinearTrain(torch.autograd.Function):
+    """y = x W^T + b with torch's GEMMs forward and for dx; dW and db by ``mmf_linear_weight_grad`` (rows split over the chip, f32
+    matrix cores, deterministic sum of the splits) -- the BLAS libraries' best kernels for these short-and-very-deep products run at a
+    fifth of that."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        g2 = g.reshape(-1, N)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        x2 = x.reshape(-1, K)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        rows = g2.shape[0]
+        dx = (g2 @ weight).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(N, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
+        scratch = torch.empty(int(_lib.lib().mmf_linear_weight_grad_scratch_bytes(rows, N, K)) // 4, dtype=torch.float32, device=weight.device)
+        _lib.check(_lib.lib().mmf_linear_weight_grad(_lib.dptr(g2), _lib.dptr(x2), rows, N, K, _lib.dptr(dW), _lib.dptr(db), _lib.dptr(scratch),
+                                                     _lib.stream_ptr(weight.device)), "mmf_linear_weight_grad")
+        return dx, dW, db
+
+
+MIN_ROWS_LINEAR = 2048
+
+
+def linear(module, x: torch.Tensor) -> torch.Tensor:
+    """``module(x)`` for an ``nn.Linear``; under autograd on CUDA float32 with many rows its parameter gradients come from the
+    matrix-core split kernel."""
+    w = module.weight
+    if (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and w.requires_grad and w.shape[1] <= 128
+            and w.shape[0] <= 256 and x.numel() // w.shape[1] >= MIN_ROWS_LINEAR and w.is_contiguous()):
+        return _LinearTrain.apply(x, w, module.bias)
+    return module(x)

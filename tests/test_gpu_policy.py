@@ -940,3 +940,39 @@ def test_training_adaln_matches_the_composite():
     assert torch.equal(mine[0], comp[0])
     for a, b in zip(mine[1:], ref[1:]):
         assert float((a.double() - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(19712, 120, 120), (98304, 240, 120), (19712, 240, 120), (2048, 120, 120), (5000, 100, 36), (4097, 256, 128),
+                                   (3000, 8, 4)])
+def test_linear_parameter_gradients_match_float64(shape):
+    """mmf_linear_weight_grad (dW = g^T x, db = column sums of g: rows split over the chip, f32 matrix cores, splits added in a fixed
+    order) against float64; and through train_ops.linear: the same output as nn.Linear, gradients to float32 rounding, twice the same
+    bits."""
+    from nvblox_mindmap_amd.diffuser_actor import train_ops as TO
+
+    R, N, K = shape
+    torch.manual_seed(R % 97)
+    lin = torch.nn.Linear(K, N).cuda()
+    x = torch.randn(R, K, device="cuda", requires_grad=True)
+    g = torch.randn(R, N, device="cuda")
+    old = TO.MIN_ROWS_LINEAR
+    TO.MIN_ROWS_LINEAR = 1
+    try:
+        runs = []
+        for _ in range(2):
+            lin.zero_grad(set_to_none=True)
+            x.grad = None
+            y = TO.linear(lin, x)
+            assert y.grad_fn is not None and "LinearTrain" in type(y.grad_fn).__name__
+            (y * g).sum().backward()
+            runs.append((y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+    finally:
+        TO.MIN_ROWS_LINEAR = old
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    assert torch.equal(runs[0][0], lin(x).detach())
+    dW = g.double().t() @ x.detach().double()
+    db = g.double().sum(0)
+    dx = g.double() @ lin.weight.detach().double()
+    for got, want in ((runs[0][2], dW), (runs[0][3], db), (runs[0][1], dx)):
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
