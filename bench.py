@@ -890,7 +890,11 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
            "trainable_params_in_flat_buffer": int(g.n_total), "unused_parameter_tensors": len(g.unused_names),
            "capture_s": capture_s, "tuned_gemms": bool(g.tuned_gemms), "runtime_env": {"ROC_AQL_QUEUE_SIZE": os.environ.get("ROC_AQL_QUEUE_SIZE")}, "parallelism": f"dp{world}" if world > 1 else "single",
            "how": "training.GraphedTrainStep: forward+backward = one captured HIP graph (next batch's frozen backbone as a parallel "
-                  "branch), one flat gradient buffer, one explicit all-reduce, AdamW over two flat segments as a second graph"}
+                  "branch), one flat gradient buffer, one explicit all-reduce, AdamW over two flat segments as a second graph",
+           "trainable_side_kernels": "libmmfusion, float32: attention forward + backward on the f32 matrix cores (8 heads x 15 channels, read "
+                                     "from the projections), rotary / LayerNorm(a + b) / AdaLN forward + backward, Linear dW + db by a row-split "
+                                     "matrix-core kernel (deterministic sums); MMF_TRAIN_ATTENTION=0 MMF_TRAIN_LAYERNORM=0 MMF_FUSED_ROTARY=0 "
+                                     "give torch's operators back"}
     del g, model, batches
     torch.cuda.empty_cache()
     return out
