@@ -1304,6 +1304,7 @@ def main():
     ap.add_argument("--unbounded-only", action="store_true", help="run only the unbounded-workspace (hash path) leg (rocprofv3 passes)")
     ap.add_argument("--eager-rows", action="store_true", help="headline without the deferred feature-row update (every frame runs its five launches before the next starts)")
     ap.add_argument("--train-only", action="store_true", help="run only the captured training step (rocprofv3 passes of the training half)")
+    ap.add_argument("--with-file-fed", action="store_true", help="with --train-only: also run the (rank-0-only) file-fed leg behind it")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the multi-rank control flow only")
     args = ap.parse_args()
     if args.only_fusion:
@@ -1340,8 +1341,15 @@ def main():
         out = run_training_graphed(device, world, steps=args.train_steps,
                                    backbone_matmul_dtype=os.environ.get("BENCH_BACKBONE_MATMULS", "float16x3"),
                                    overlap_backbone=os.environ.get("BENCH_TRAIN_OVERLAP", "1") != "0")
+        if args.with_file_fed:
+            # the rank-0-only leg behind the data-parallel ones, as in the full run (tests/test_gpu_bench_ranks.py: it must not issue
+            # a collective the other ranks are not in)
+            if dist is not None:
+                dist.barrier()
+            if rank == 0:
+                out["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=out["step_per_s"], steps=max(args.train_steps // 2, 2))
         if rank == 0:
-            print(json.dumps({"train": out}), flush=True)
+            print(json.dumps({"train": out, "n_gpus": world}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
