@@ -24,16 +24,28 @@ KERNEL_IDS = {
 }
 
 
-def source_hash() -> str:
-    """16 hex digits identifying the native sources a build was made from (sha256 over csrc/*.hip, csrc/*.h, include/*.h in name
-    order).  The counter summaries under profiles/ carry the hash of the sources they were collected on; bench.py compares it
-    with the running tree's and marks replayed counters as stale when they differ (`roofline.counters_stale`)."""
+# the sources the FUSION kernels (the frame's launches, the mesh / model-input and image kernels) and their host side are built from
+FUSION_SOURCES = ("mmf_kernels_map.hip", "mmf_kernels_app.hip", "mmf_kernels_mesh.hip", "mmf_kernels_image.hip", "mmf_api.hip",
+                  "mmf_api_outputs.hip", "mmf_api_internal.h", "mmf_alloc_device.h", "mmf_app_device.h", "mmf_device.h", "mmf_mask_device.h",
+                  "mmf_trace_device.h", "mmf_launch.h")
+
+
+def source_hash(scope: str = "fusion") -> str:
+    """16 hex digits identifying the native sources a build was made from.  ``scope="fusion"`` (the stamp of the counter summaries
+    under profiles/: the frame's kernels are what they count): sha256 over FUSION_SOURCES + include/mmf_mc_table.h -- the policy
+    side (FPS, the diffusion head's, the backbone's and the training step's kernels: mmf_kernels_{fps,policy*,backbone,train_*}.hip,
+    mmf_api_ops.hip, mmf_launch_policy.h) and the ABI header's declarations do not change the fusion kernels' code.  ``scope="all"``:
+    every csrc/*.hip, csrc/*.h and include/*.h.  bench.py compares a summary's stamp with the running tree's and marks replayed
+    counters as stale when they differ (`roofline.counters_stale`)."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.h"))
-                   + glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    if scope == "all":
+        files = sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.h"))
+                       + glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    else:
+        files = sorted([os.path.join(CSRC_DIR, f) for f in FUSION_SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "mmf_mc_table.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
