@@ -259,15 +259,19 @@ class GraphedTrainStep:
                 self.lr_tensor.fill_(self.lr)
             torch.cuda.current_stream(dev).wait_stream(warm)
             torch.cuda.synchronize(dev)
+            # capture_error_mode="thread_local": a loader's pin-memory / prefetch thread may allocate pinned memory or copy while this
+            # thread captures -- in the default "global" mode such a call from ANY thread invalidates the capture (seen as an
+            # intermittent hipErrorStreamCaptureInvalidated when the step is built while a DataLoader is already running)
+            mode = dict(capture_error_mode="thread_local")
             if self.overlap:
                 self.graph_bb = torch.cuda.CUDAGraph()  # (its own memory pool: it runs BESIDE the other two graphs)
-                with torch.cuda.graph(self.graph_bb):
+                with torch.cuda.graph(self.graph_bb, **mode):
                     self._backbone_next()
             self.graph_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_fb):
+            with torch.cuda.graph(self.graph_fb, **mode):
                 self._forward_backward()
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), **mode):
                 self._optimizer_step()
         torch.cuda.synchronize(dev)
 
