@@ -976,3 +976,39 @@ def test_linear_parameter_gradients_match_float64(shape):
     dx = g.double() @ lin.weight.detach().double()
     for got, want in ((runs[0][2], dW), (runs[0][3], db), (runs[0][1], dx)):
         assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_trainable_side_kernels_give_the_gradients_of_torchs_operators():
+    """One training step of the whole policy (reference model shape, batch 4) with libmmfusion's trainable-side kernels (attention
+    forward / backward on the f32 matrix cores, rotary, LayerNorm, AdaLN, Linear dW / db) against the same step on torch's own
+    operators (the switches of train_attention / train_ops / layers): the same losses and the same flat gradient to float32
+    rounding -- the kernels change where the arithmetic runs, not what is computed."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.diffuser_actor import layers as LY
+    from nvblox_mindmap_amd.diffuser_actor import train_attention as TA
+    from nvblox_mindmap_amd.diffuser_actor import train_ops as TO
+    from nvblox_mindmap_amd.training import GraphedTrainStep, build_model, synthetic_batch
+
+    cfg = DiffuserActorConfig()
+    batch = synthetic_batch(cfg, 4, "cuda", seed=3)
+
+    def run(on):
+        TA.ENABLED, TO.ENABLED, LY.FUSED_ROTARY_TRAINING = on, on, on
+        try:
+            torch.manual_seed(0)
+            model = build_model(cfg, device="cuda")
+            g = GraphedTrainStep(cfg, model, batch, lr=0.0, use_graphs=False, overlap_backbone=False)
+            torch.manual_seed(1)
+            losses = g.step(batch).clone()
+            return losses, g.flat_grad.clone(), list(g.unused_names)
+        finally:
+            TA.ENABLED = TO.ENABLED = LY.FUSED_ROTARY_TRAINING = True
+
+    (l1, g1, u1), (l0, g0, u0) = run(True), run(False)
+    assert u1 == u0 and g1.numel() == g0.numel() > 2_000_000
+    assert torch.allclose(l1, l0, rtol=1e-5, atol=1e-6), (l1, l0)
+    scale = float(g0.abs().max())
+    assert scale > 0 and float((g1 - g0).abs().max()) <= 2e-4 * scale, float((g1 - g0).abs().max()) / scale
+    # (per element: rounding-level everywhere, not just at the largest entries)
+    assert float(((g1 - g0).abs() > 1e-5 * scale + 1e-3 * g0.abs()).float().mean()) < 1e-3
