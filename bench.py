@@ -29,7 +29,7 @@ import time
 import statistics
 import subprocess
 
-# The captured training step (training/graphed.py) is one HIP graph of ~2 400 kernel nodes: with the runtime's default AQL ring
+# The captured training step (training/graphed.py) is one HIP graph of ~1 300 kernel nodes (2 400 before the trainable-side kernels): with the runtime's default AQL ring
 # (16 384 packets) hipGraphLaunch blocks the host until the previous step has drained enough of it (measured: 26 of 73 ms per step;
 # 0.7 ms with the larger ring).  Read by the HIP runtime when it initialises, i.e. at the first GPU call of this process.
 os.environ.setdefault("ROC_AQL_QUEUE_SIZE", "65536")
