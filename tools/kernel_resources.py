@@ -17,6 +17,7 @@ def main(src, flt=""):
         m = re.search(r"remark:\s+(?:Function )?Name: (\S+)", line)
         if m:
             cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+            cur = cur.replace("(anonymous namespace)::", "")  # (kernels in unnamed namespaces: keep the name, drop the tag)
             cur = re.sub(r"\(.*", "", cur)
             rows[cur] = {}
             continue
