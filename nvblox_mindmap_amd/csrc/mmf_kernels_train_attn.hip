@@ -27,8 +27,14 @@ namespace mmf {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int kC = 128;       // rows per LDS chunk
-constexpr int kNW = 8;        // waves per workgroup: 8 x 16 accumulator columns
+#ifndef MMF_TA_CHUNK
+#define MMF_TA_CHUNK 128
+#endif
+#ifndef MMF_TA_WAVES
+#define MMF_TA_WAVES 8
+#endif
+constexpr int kC = MMF_TA_CHUNK;   // rows per LDS chunk (tuning: -DMMF_TA_CHUNK=...)
+constexpr int kNW = MMF_TA_WAVES;  // waves per workgroup: kNW x 16 accumulator columns
 constexpr int kNT = 64 * kNW;
 constexpr int kRS = 20;       // floats per row of a row-major chunk (16 + 4: rows stay 16-byte aligned, bank spread)
 constexpr int kTS = kC + 4;   // floats per row of a transposed chunk
