@@ -463,7 +463,9 @@ int ensure_lazy(Mapper& m) {
   HIP_TRY(hipMalloc(&m.lazy_epoch_of, sizeof(int) * cap));
   HIP_TRY(hipMalloc(&m.lazy_wmin, sizeof(float) * cap));
   HIP_TRY(hipMalloc(&m.lazy_band, cap));
-  HIP_TRY(hipMalloc(&m.lazy_work, sizeof(int) * (cap + 1)));
+  HIP_TRY(hipMalloc(&m.lazy_work, sizeof(int) * (cap + 2)));  // {count (even frames), count (odd frames), list[cap]}
+  HIP_TRY(hipMemset(m.lazy_work, 0, sizeof(int) * 2));
+  m.lazy_parity = 0;
   HIP_TRY(hipMemset(m.lazy_epoch_of, 0, sizeof(int) * cap));
   HIP_TRY(hipMemset(m.lazy_wmin, 0, sizeof(float) * cap));
   HIP_TRY(hipMemset(m.lazy_band, 0, cap));
@@ -1269,7 +1271,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       // TSDF update of the stamped blocks + appearance-candidate flags of every live block: one pass
       ProfScope ps(h, MMF_K_TSDF, s);
       if (lazy) {
-        launch_tsdf_pass_lazy(lazy_view(*m), m->mc, cam, T_C_L, m->masked_depth, stamp, m->sc[1].flags, m->sc[1].cell_key, m->lazy_work, s);
+        launch_tsdf_pass_lazy(lazy_view(*m), m->mc, cam, T_C_L, m->masked_depth, stamp, m->sc[1].flags, m->sc[1].cell_key, m->lazy_work,
+                              m->lazy_parity++, s);
       } else {
         // (a large map's full pass also establishes the lazy summaries: the next fused frame can decay lazily)
         launch_tsdf_pass(big ? lazy_view(*m) : m->tsdf.d, m->mc, cam, T_C_L, m->masked_depth, nullptr, 0.0f, stamp, m->sc[1].flags,

@@ -104,7 +104,8 @@ struct Mapper {
   int* lazy_epoch_of = nullptr;   // [cap] device: LayerDev::epoch
   float* lazy_wmin = nullptr;     // [cap] device: LayerDev::wmin
   uint8_t* lazy_band = nullptr;   // [cap] device: LayerDev::band
-  int* lazy_work = nullptr;       // [cap + 1] device: work list of the lazy pass
+  int* lazy_work = nullptr;       // [cap + 2] device: work list of the lazy pass behind its two alternating counters
+  int lazy_parity = 0;            // which counter the next lazy frame uses (its classify kernel zeroes the other one)
   int lazy_epoch = 0;             // decays applied lazily so far
   bool lazy_valid = false;        // the three summaries hold for every live block (established by a full pass, kept by lazy passes)
   bool lazy_lag = false;          // some block's voxels may be behind lazy_epoch

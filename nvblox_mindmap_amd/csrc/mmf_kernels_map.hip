@@ -693,7 +693,8 @@ template <int VPT, bool MASKED, bool LAZY>
 __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                         const float* __restrict__ depth, const uint8_t* __restrict__ mask_arg,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
-                                                        u64* __restrict__ cell_key, float decay_f, const int* __restrict__ work) {
+                                                        u64* __restrict__ cell_key, float decay_f, const int* __restrict__ work_n,
+                                                        const int* __restrict__ work) {
   // decay_f > 0: a Mapper.decay() is pending whose deallocations k_front already made from L.wmax -- its W *= f is applied
   // here, on the voxels this pass loads anyway (and every block is written back).  L.wmax is refreshed for every live block.
   static_assert(VPT == 2 || VPT == 4 || VPT == 8, "one, two or four 16-byte voxel pairs per thread");
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
   constexpr int NP = VPT / 2;  // float4 = two {distance, weight} voxels
   const uint8_t* __restrict__ mask = MASKED ? mask_arg : nullptr;
   const long long tr0 = wg_trace_begin();
-  const int n = LAZY ? work[0] : L.ctr[0];
+  const int n = LAZY ? *work_n : L.ctr[0];
   const int chunk = (n + 7) >> 3;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
     const int iw = xcd_candidate(j, chunk);
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
     float* s_wmax = s_wmax2[par];
     float* s_wmin = s_wmin2[par];
     int* s_band = s_band2[par];
-    const int i = LAZY ? work[1 + iw] : iw;
+    const int i = LAZY ? work[iw] : iw;
     const int slot = L.live[i];
     const u64 key = L.slot_key[slot];
     const int st = L.stamp[slot];
@@ -769,13 +770,17 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
 
 // The work list of a lazy pass: one thread per live block.  A block the frame integrates (its allocation job stamped it), or one
 // with near-surface voxels (band: its appearance flag depends on which of them are in view), goes on the list; any other block's
-// flag is 0 and its voxels are not touched.  work[0] = count (zeroed by the host), work[1 ..] = live-list positions, in no
-// particular order (blocks are independent).
-__global__ __launch_bounds__(256) void k_tsdf_classify(LayerDev L, int stamp, uint8_t* __restrict__ flags, int* __restrict__ work) {
-  __shared__ int s_cnt[4], s_base;
+// flag is 0 and its voxels are not touched.  *count = the list's length, list[..] = live-list positions, in no particular order
+// (blocks are independent).  Two counters alternate between frames: this frame's was zeroed by the previous frame's classify
+// (*zero_next = 0 here, for the next one) -- no memset node per frame.  1 024 threads per workgroup: one same-address atomic per
+// workgroup, and those atomics (serialised at the L2) are most of this kernel's time.
+__global__ __launch_bounds__(1024) void k_tsdf_classify(LayerDev L, int stamp, uint8_t* __restrict__ flags, int* __restrict__ count,
+                                                       int* __restrict__ zero_next, int* __restrict__ list) {
+  __shared__ int s_cnt[16], s_base;
   const int n = L.ctr[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i0 = (int)blockIdx.x * 256; i0 < n; i0 += (int)gridDim.x * 256) {  // workgroup-uniform trip count
+  if (blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0;
+  for (int i0 = (int)blockIdx.x * 1024; i0 < n; i0 += (int)gridDim.x * 1024) {  // workgroup-uniform trip count
     const int i = i0 + (int)threadIdx.x;
     bool take = false;
     if (i < n) {
@@ -783,18 +788,19 @@ __global__ __launch_bounds__(256) void k_tsdf_classify(LayerDev L, int stamp, ui
       take = (L.stamp[slot] >> 1) == stamp || L.band[slot] != 0;
       if (!take) flags[i] = 0;
     }
-    // one atomic per workgroup (1 500 same-address atomics, one per wave, cost more than the rest of the kernel)
     const unsigned long long b = __ballot(take);
     if (lane == 0) s_cnt[wv] = __popcll(b);
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-      s_base = tot ? atomicAdd(work, tot) : 0;
+      int tot = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += s_cnt[q];
+      s_base = tot ? atomicAdd(count, tot) : 0;
     }
     __syncthreads();
     int base = s_base;
     for (int q = 0; q < wv; ++q) base += s_cnt[q];
-    if (take) work[1 + base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+    if (take) list[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
     __syncthreads();  // (s_cnt / s_base are rewritten by the next round)
   }
 }
@@ -1531,6 +1537,8 @@ void launch_live_compact_big(const LayerDev& L, bool wmax, uint8_t* kill, int* a
   else
     hipLaunchKernelGGL(k_live_compact_big<false>, dim3(nwg), dim3(256), 0, s, L, kill, lb, tag, rebuild, snap6, decay_f, decay_thr, any_kill);
   if (!L.dense) {  // the amortised rebuild, on the flag the last chunk raised
+    // (almost every frame these two launches find the flag down and leave: 4.7 us each, whatever their grid -- the cost is the
+    // launch and the flag's load, not the workgroup count)
     int hb = (int)((L.hmask + 1 + 255) / 256);
     if (hb > 1024) hb = 1024;
     hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)rebuild);
@@ -1655,20 +1663,22 @@ void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, co
   const dim3 grid(grid_for(hinted(L.hint_live, L.cap), 8192));
   if (mask)
     hipLaunchKernelGGL((k_tsdf_pass<4, true, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
-                       (const int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr);
   else
     hipLaunchKernelGGL((k_tsdf_pass<4, false, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
-                       (const int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr);
 }
 
 // the lazy form (L.epoch / L.cur_epoch / L.lag_f set): classify the live list, then pass over the work list only
 void launch_tsdf_pass_lazy(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth, int stamp,
-                           uint8_t* flags, u64* cell_key, int* work, hipStream_t s) {
+                           uint8_t* flags, u64* cell_key, int* work, int parity, hipStream_t s) {
+  // work = {count of even frames, count of odd frames, list ...}: both counters zero when the buffer is made (ensure_lazy)
   const int live = hinted(L.hint_live, L.cap);
-  (void)hipMemsetAsync(work, 0, sizeof(int), s);
-  hipLaunchKernelGGL(k_tsdf_classify, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, s, L, stamp, flags, work);
+  int* cnt = work + (parity & 1);
+  int* nxt = work + ((parity & 1) ^ 1);
+  hipLaunchKernelGGL(k_tsdf_classify, dim3((unsigned)((live + 1023) / 1024)), dim3(1024), 0, s, L, stamp, flags, cnt, nxt, work + 2);
   hipLaunchKernelGGL((k_tsdf_pass<4, false, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr, 0.0f,
-                     stamp, flags, cell_key, 0.0f, (const int*)work);
+                     stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
 }
 
 void launch_lazy_catchup(const LayerDev& L, hipStream_t s) {

@@ -203,7 +203,7 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s);
 void launch_tsdf_pass_lazy(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth, int stamp,
-                           uint8_t* flags, u64* cell_key, int* work, hipStream_t s);
+                           uint8_t* flags, u64* cell_key, int* work, int parity, hipStream_t s);
 void launch_lazy_catchup(const LayerDev& L, hipStream_t s);
 void launch_decay(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
 void launch_decay_mark(const LayerDev& L, const MapConsts& mc, uint8_t* kill, int* any_kill, hipStream_t s);
