@@ -70,7 +70,8 @@ def enable_tuned_gemms(path: str = TUNED_GEMMS_FILE) -> bool:
     tunable.enable(True)
     tunable.tuning_enable(False)
     tunable.record_untuned_enable(False)
-    tunable.write_file_on_exit(False)  # (read-only use: no results file written at exit, whatever the rank count)
+    if hasattr(tunable, "write_file_on_exit"):
+        tunable.write_file_on_exit(False)  # (read-only use: no results file written at exit, whatever the rank count)
     try:
         ok = bool(tunable.read_file(path))
     except Exception:
