@@ -12,13 +12,13 @@ Per-frame fusion does not shard: with --gpus N every ra
 replica (its own map, its own copy of the stream), no data-path collective; value = frames of all ranks /
 max-over-ranks time ("weak" scaling).
 
-Prints ONE JSON line (rank 0).  `roofline` is for k_feature_flat, the HBM-bound kernel that moves the feature rows of
-the voxels a frame updates (the dominant kernel at the reference's 512x512x768 shape; at C=64 the frame is six
-latency-bound launches, all listed in `kernel_us_per_launch`), timed with HIP events on the launch stream inside the
-timed region; `cpu_baseline` is the CPU oracle ("port") timed on the host cores on a bounded sample of the same frames
-(reported baseline, not the target).  Extra legs in the same line: `reference_shape` (512x512x768, with and without the
-fused low-res feature path), `train` (policy training step/s, DDP over RCCL when launched with N > 1) and
-`backprojection` (GPU kernel + torch-CPU baseline).
+Output (rank 0): the FULL record (every leg, tens of KB) is written to `bench_full.json` (repo root, and `gpurun_out/` when
+present) and printed on stderr; the LAST STDOUT LINE is the compact record built by `bench_record.compact_line` -- <= 4 KB, always:
+the driver's contract keys + `roofline` (whole pipelined frame = 3 launches against the 8 TB/s HBM peak: algorithmic bytes of
+`frame_byte_model()` / measured frame time, counter traffic, the dominant launch with its own time / bytes / fraction, the other
+shapes as `legs`) + `cpu_baseline` (the C + OpenMP oracle, kind "port", on a bounded sample of the same frames; the reference's
+torch-CPU back-projection beside the HIP kernel) + `train` (captured policy training step; steady-state file-fed ratio).  Per-launch
+durations are HIP-event stamps on the launch stream, taken in a region of their own behind the headline regions.
 """
 import argparse
 import json
@@ -80,6 +80,7 @@ if os.environ.get("BENCH_HANG_DUMP_S"):
 
     faulthandler.dump_traceback_later(float(os.environ["BENCH_HANG_DUMP_S"]), exit=True)
 
+import bench_record  # noqa: E402
 from nvblox_mindmap_amd import synthetic as S  # noqa: E402
 from nvblox_mindmap_amd.image_processing.feature_resize import upsample_features  # noqa: E402
 from nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers import get_nvblox_mapper, integrate_frame  # noqa: E402
@@ -87,6 +88,23 @@ from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, Nvb
 
 HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3e12 achievable
 CPU_THREAD_SWEEP = (8, 16, 32, 64)  # + all host threads; the best setting is the reported CPU baseline
+
+
+def emit(full: dict) -> None:
+    """full record -> bench_full.json (+ gpurun_out/) and stderr; compact record (<= 4 KB) = the last stdout line."""
+    text = json.dumps(full)
+    written = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(text + "\n")
+                written = written or os.path.relpath(os.path.join(d, "bench_full.json"), ROOT)
+            except OSError:
+                pass
+    full["full_record"] = written
+    print(text, file=sys.stderr, flush=True)
+    print(bench_record.compact_line(full), flush=True)
 
 
 def dry_run(args, world: int, rank: int) -> None:
@@ -114,11 +132,16 @@ def dry_run(args, world: int, rank: int) -> None:
         regions.append(float(t.item()))
     elapsed = statistics.median(regions)
     if rank == 0:
-        print(json.dumps({"metric": "RGB-D+feature frames/s fused @1 cm voxels", "value": world * args.steps / elapsed, "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
-                          "config": {"workload": "dry run: no GPU work, control flow only"}, "dry_run": True,
-                          "train": {"parallelism": f"dp{world}" if world > 1 else "single"}}), flush=True)
+        # the same shape as a real run's last line (bench_record.compact_line), from a record with the legs absent
+        print(bench_record.compact_line({
+            "metric": "RGB-D+feature frames/s fused @1 cm voxels", "value": world * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+            "config": {"workload": "dry run: no GPU work, control flow only"}, "dry_run": True,
+            "roofline": {"bound": "hbm", "kernel": "none (dry run)", "achieved": None, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                         "frac": None, "traffic": None},
+            "cpu_baseline": {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "none (dry run)"},
+            "train": {"parallelism": f"dp{world}" if world > 1 else "single"}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -1541,6 +1564,7 @@ def main():
             "formula": "sum over the five roles of frame_byte_model() (bench.py; DESIGN.md section 5), counts from this run",
             "frame_us": t_frame * 1e6,
             "kernels_busy_us": busy_us if timed else None,
+            "launches_per_frame": len(launches),
             "dominant_launch": dominant,
             "per_kernel": per_kernel,
             "counts_per_frame": {"tsdf_live_blocks": n_live, "tsdf_blocks_integrated": tsdf_blocks_per_frame,
@@ -1619,6 +1643,7 @@ def main():
                             "(those + the 20-pixel erosion erase the whole feature mask: no feature work at all); "
                             "replicas only for n_gpus>1",
                 "hole_mode": cfg.hole_mode,
+                "pipelined": not args.eager_rows,
                 "image": [cfg.height, cfg.width],
                 "feature_channels": C,
                 "voxel_size_m": mcfg.voxel_size_m,
@@ -1647,7 +1672,7 @@ def main():
             "pixel_holes": pixel_holes,
             "train": train,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()  # rank 0 runs its single-GPU legs after the timed regions: nobody tears the group down before it is done
         dist.destroy_process_group()
