@@ -923,35 +923,37 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
     return out
 
 
-def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=16, workers=10,
-                          vertex_count_range=(10000, 14000)):
-    """Is the training step loader-bound?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader keeping the GPUs
-    fed, not the 10.9 MB all-reduce.)  A demo in the reference's on-disk layout -- 512x512 rgb + u16 depth PNGs, pose /
-    intrinsics .npy, one UNSAMPLED vertex-feature .zst per frame (10-14 k vertices x 768 f16 channels, ~20 MB: what
-    save_feature_mesh_to_disk writes) -- is read by MindmapFrameDataset through a torch DataLoader with `workers` worker
-    processes and fed to train_one_step at per-GPU batch 32.  The loader reads the memory-mapped raw copies
-    ``io.vertex_cache.convert_dataset`` leaves next to every .zst (only the 2048 sampled rows are touched; same selection, same
-    values) and next to every .png (same pixels, no inflate); the decompress-everything path the reference's loader takes is timed
-    beside it, loader only, at the same worker count and at the reference's 20.  What counts for "8 loaders on one host" is the
-    CPU the workers BURN, not how many processes wait on a queue: `loader_cpu_cores_used` = CPU milliseconds per sample (decode +
-    sampling + collation, process time of a probe in this process) x the samples per second the timed steps consumed.  (The step is the captured one, training.GraphedTrainStep: its host side is ~1 ms per step, so the loader's pinning thread in the same process is no longer starved of the interpreter lock as it was under the eager step's ~70 ms of launches.)"""
+def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_frames=32, steps=48, threads=3, slots=4,
+                          vertex_count_range=(10000, 14000), reference_loader=True):
+    """Is the training step loader-bound IN STEADY STATE?  (the risk to ">= 0.9x linear over 8 GPUs" is the loader
+    keeping the GPUs fed, not the 8.6 MB all-reduce.)  A demo in the reference's on-disk layout -- 512x512 rgb + u16 depth PNGs,
+    pose / intrinsics .npy, one UNSAMPLED vertex-feature .zst per frame (10-14 k vertices x 768 f16 channels, ~20 MB: what
+    save_feature_mesh_to_disk writes) with the raw copies of io/vertex_cache.py beside them -- feeds the captured step
+    (training.GraphedTrainStep) at per-GPU batch 32 through data_loading.PinnedBatchLoader: `threads` loader threads write every
+    sample straight into its row of one of `slots` pinned batch buffers (one copy per byte), DevicePrefetcher copies a batch
+    ahead.  Steady state: the timed region starts after more batches than the pipeline can hold have been consumed and spans
+    >= 3x its capacity ((slots + 1) x batch samples), so a queue filled during graph capture cannot carry it (round 4's 0.99
+    was that artefact).  CPU the loader BURNS = the worker threads' own CPU clocks (thread_time: user + kernel, page faults
+    included) per sample.  Beside it: eight such loaders at once in eight processes (what an 8-GPU node asks of its host, under
+    this box's CPU quota), and the reference-shaped torch DataLoader (worker processes, default_collate, pin thread) on the
+    same files, loader only."""
     import shutil
     import tempfile
 
-    from torch.utils.data import DataLoader
-
     from nvblox_mindmap_amd.data_loading.dataset import DevicePrefetcher, MindmapFrameDataset, write_synthetic_demo
+    from nvblox_mindmap_amd.data_loading.pinned_loader import PinnedBatchLoader
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
     from nvblox_mindmap_amd.io import vertex_cache
-    from nvblox_mindmap_amd.training import build_model, build_optimizer, train_one_step
+    from nvblox_mindmap_amd.training import GraphedTrainStep, build_model
 
     cfg = DiffuserActorConfig()
     ncpu = os.cpu_count() or 1
-    # the step's host side is kernel launches: a handful of intra-op threads is plenty, and the default (one per hardware thread:
-    # 128-256 on the GPU box) spins the container's 16-CPU quota away from the loader's workers
+    # the step's host side is graph launches: a handful of intra-op threads is plenty, and the default (one per hardware thread:
+    # 128-256 on the GPU box) spins the container's 16-CPU quota away from the loader
     host_threads_before = torch.get_num_threads()
     torch.set_num_threads(2)
     root = tempfile.mkdtemp(prefix="mmf_file_fed_")
+    out = {}
     try:
         t0 = time.perf_counter()
         write_synthetic_demo(os.path.join(root, "demo_00000"), n_frames, image_size=cfg.image_size, feature_dim=cfg.feature_dim,
@@ -962,81 +964,60 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
         n_raw = vertex_cache.convert_dataset(root)
         t_convert = time.perf_counter() - t0
 
-        def make(raw: bool, nw: int):
-            ds = MindmapFrameDataset(root, num_vertices=2048, use_raw_vertex_cache=raw)
-            mb = sum(os.path.getsize(p) for smp in ds.samples for p in smp.values()) / len(ds) / 1e6
-            # a DataLoader hands whole batches to workers: an epoch must hold several batches per worker or most workers idle.  The
-            # frames on disk are revisited (page-cache reads; a real dataset adds storage latency on top of what is measured here)
-            ds.samples = ds.samples * max(1, -(-3 * nw * per_gpu_batch // len(ds.samples)))
-            return DataLoader(ds, batch_size=per_gpu_batch, shuffle=True, num_workers=nw, drop_last=False, pin_memory=True,
-                              persistent_workers=True, prefetch_factor=4), mb
+        ds = MindmapFrameDataset(root, num_vertices=2048, use_raw_vertex_cache=True)
+        mb = sum(os.path.getsize(p) for smp in ds.samples for p in smp.values()) / len(ds) / 1e6
+        # the frames on disk are revisited (page-cache reads; a real dataset adds storage latency on top of what is measured here)
+        ds.samples = ds.samples * max(1, -(-(steps + 4 * slots + 8) * per_gpu_batch // len(ds.samples)))
+        loader = PinnedBatchLoader(ds, per_gpu_batch, shuffle=True, drop_last=True, threads=threads, slots=slots)
 
-        def loader_rate(dl, nw):
-            for i, b in enumerate(dl):  # page cache + worker start-up, untimed
-                if i >= nw:
-                    break
-            t0 = time.perf_counter()
-            n = 0
-            for b in dl:
-                n += b["rgb_u8"].shape[0]
-            return n / (time.perf_counter() - t0)
-
-        zst = {}
-        for nw in sorted({workers, max(1, min(20, ncpu - 2))}):  # the reference's loader: 20 workers per GPU
-            dl, mb = make(False, nw)
-            zst[str(nw)] = loader_rate(dl, nw)
-            del dl
-        dl, _ = make(True, workers)
-        loader_sps = loader_rate(dl, workers)
+        # loader only: batches handed out as fast as the threads fill them
+        n = 0
+        for i, b in enumerate(loader):
+            if i >= 2 * slots:
+                break
+        loader.reset_stats()
+        t0 = time.perf_counter()
+        for i, b in enumerate(loader):
+            n += b["rgb_u8"].shape[0]
+            if i >= 24:
+                break
+        loader_sps = n / (time.perf_counter() - t0)
+        loader_only_cpu_ms = loader.stats()["cpu_ms_per_sample"]
 
         torch.manual_seed(0)
         model = build_model(cfg, device=device)
-        opt = build_optimizer(model)
 
         def batches():  # device batches, copies + GPU-side transforms one step ahead on a side stream
             while True:
-                for b in DevicePrefetcher(dl, device):
-                    if b["rgbs"].shape[0] == per_gpu_batch:
-                        yield b
-
-        # CPU seconds one sample costs a worker (decode + sampling + its share of the batch collation), measured in this process
-        probe = MindmapFrameDataset(root, num_vertices=2048, use_raw_vertex_cache=True)
-        from torch.utils.data import default_collate
-
-        c0 = time.process_time()
-        default_collate([probe[i % len(probe)] for i in range(per_gpu_batch)])
-        cpu_ms_per_sample = (time.process_time() - c0) / per_gpu_batch * 1e3
-        del probe
+                for b in DevicePrefetcher(loader, device):
+                    yield b
 
         it = batches()
-        # the captured step (training.GraphedTrainStep: the training leg's headline form), fed from files: it reads one batch
-        # ahead (the next batch's frozen backbone runs beside the current batch's trainable pass)
-        from nvblox_mindmap_amd.training import GraphedTrainStep
-
         cur = next(it)
         g = GraphedTrainStep(cfg, model, cur, data_parallel=False)  # a rank-0-only leg: no collective, the other ranks are not here
-        del opt
 
-        def fed_steps(n, cur):
-            for _ in range(n):
+        def fed_steps(k, cur):
+            for _ in range(k):
                 nxt = next(it)
                 g.step(cur, nxt)
                 cur = nxt
             return cur
 
-        # untimed: the new epoch's workers have to refill their prefetch queues (each needs ~0.5 s for its first batch); timing
-        # from the first batch on measures that start-up transient, not the steady state
-        cur = fed_steps(8, cur)
+        capacity = (slots + 1) * per_gpu_batch  # samples the pipeline can hold: the slots + the batch already on the device
+        # untimed: MORE batches than the pipeline holds (filled while the graphs were captured) are consumed first
+        cur = fed_steps(2 * (slots + 1) + 2, cur)
         torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
+        loader.reset_stats()
+        c0, t0 = time.process_time(), time.perf_counter()
         cur = fed_steps(steps, cur)
         torch.cuda.synchronize(device)
         wall = time.perf_counter() - t0
+        process_cpu = time.process_time() - c0  # every thread of this process: loader threads + the step's host side
+        st = loader.stats()
         fed = steps / wall
-        loader_cores = cpu_ms_per_sample * 1e-3 * fed * per_gpu_batch  # CPU seconds of loader work per wall second
-        # the comparator under the SAME conditions: this process, this model, the loader's workers alive but idle, two batches
+        # the comparator under the SAME conditions: this process, this model, the loader's threads alive but idle, two batches
         # resident on the device (the training leg's figure comes from another model instance: +-3 % between runs)
-        pair = [cur, next(it)]
+        pair = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in cur.items()}, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in next(it).items()}]
         for i in range(3):
             g.step(pair[i % 2], pair[(i + 1) % 2])
         torch.cuda.synchronize(device)
@@ -1045,23 +1026,69 @@ def run_training_file_fed(device, compute_bound_step_per_s, per_gpu_batch=32, n_
             g.step(pair[i % 2], pair[(i + 1) % 2])
         torch.cuda.synchronize(device)
         resident = steps / (time.perf_counter() - t0)
-        training_leg_step_per_s, compute_bound_step_per_s = compute_bound_step_per_s, resident
-        del dl, it, model, g, pair, cur
+        del it, model, g, pair, cur
+        loader.close()
+        need = resident * per_gpu_batch
+        cores = st["cpu_ms_per_sample"] * 1e-3 * fed * per_gpu_batch
+        out = {"steady_state_step_per_s": fed, "compute_bound_step_per_s": resident,
+               "steady_state_over_compute_bound": fed / resident, "file_fed_over_compute_bound": fed / resident,
+               "samples_timed": steps * per_gpu_batch, "prefetch_capacity_samples": capacity,
+               "samples_consumed_before_the_timed_region": (2 * (slots + 1) + 3) * per_gpu_batch,
+               "training_leg_step_per_s": compute_bound_step_per_s,
+               "loader": "data_loading.PinnedBatchLoader: rows written in place into pinned batch buffers by a thread pool",
+               "threads": threads, "slots": slots, "loader_only_samples_per_s": loader_sps, "samples_per_s_needed_by_one_gpu": need,
+               "loader_headroom": loader_sps / need, "loader_cpu_ms_per_sample": st["cpu_ms_per_sample"],
+               "loader_only_cpu_ms_per_sample": loader_only_cpu_ms, "loader_cpu_cores_used": cores,
+               "eight_gpus_loader_cores": 8 * cores, "process_cpu_cores_used": process_cpu / wall,
+               "slow_path_samples": st["slow_path_samples"], "stale_raw_copies": st["stale_raw_copies"],
+               "bound": "loader" if (loader_sps < need or fed < 0.95 * resident) else "gpu",
+               "host_threads": ncpu, "cpu_quota": cpu_quota(), "per_gpu_batch": per_gpu_batch, "MB_on_disk_per_sample": mb,
+               "frames_on_disk": n_frames, "vertices_per_frame": list(vertex_count_range), "dataset_write_s": t_write,
+               "raw_cache_files_written": n_raw, "raw_cache_convert_s": t_convert}
+        torch.cuda.empty_cache()
+
+        # eight loaders at once, one process each (no GPU in them): what an 8-GPU node asks of this host under this quota
+        procs = [subprocess.Popen([sys.executable, "-m", "nvblox_mindmap_amd.data_loading.pinned_loader", root, "4", "2"], cwd=ROOT,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(8)]
+        eight = []
+        for p in procs:
+            so, _ = p.communicate(timeout=300)
+            lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+            if p.returncode == 0 and lines:
+                eight.append(json.loads(lines[-1]))
+        if len(eight) == 8:
+            agg = sum(e["samples_per_s"] for e in eight)
+            out["eight_loaders"] = {"aggregate_samples_per_s": agg, "needed_by_8_gpus": 8 * need, "headroom": agg / (8 * need),
+                                    "threads_each": 2, "cpu_ms_per_sample": sum(e["cpu_ms_per_sample"] for e in eight) / 8,
+                                    "cores_burnt_at_the_needed_rate": 8 * need * sum(e["cpu_ms_per_sample"] for e in eight) / 8 * 1e-3}
+
+        if reference_loader:
+            # the reference-shaped loader on the same files, loader only: torch DataLoader, worker processes, default_collate, pin
+            # thread -- with the raw copies (round 4's loader) and without (decompress everything: the reference's own path)
+            from torch.utils.data import DataLoader
+
+            def rate(raw, nw):
+                d2 = MindmapFrameDataset(root, num_vertices=2048, use_raw_vertex_cache=raw)
+                d2.samples = d2.samples * max(1, -(-3 * nw * per_gpu_batch // len(d2.samples)))
+                dl = DataLoader(d2, batch_size=per_gpu_batch, shuffle=True, num_workers=nw, pin_memory=True, persistent_workers=True, prefetch_factor=4)
+                for i, b in enumerate(dl):  # page cache + worker start-up, untimed
+                    if i >= nw:
+                        break
+                t0 = time.perf_counter()
+                k = 0
+                for b in dl:
+                    k += b["rgb_u8"].shape[0]
+                r = k / (time.perf_counter() - t0)
+                del dl
+                return r
+
+            out["torch_dataloader_loader_only_samples_per_s"] = {
+                "raw_copies_10_workers": rate(True, 10), "zst_png_20_workers_reference_path": rate(False, max(1, min(20, ncpu - 2)))}
     finally:
         shutil.rmtree(root, ignore_errors=True)
         torch.set_num_threads(host_threads_before)
     torch.cuda.empty_cache()
-    need = compute_bound_step_per_s * per_gpu_batch
-    return {"file_fed_step_per_s": fed, "compute_bound_step_per_s": compute_bound_step_per_s,
-            "compute_bound_is": "the same process, model and loader (workers idle) stepping on one resident batch, timed right after the file-fed steps",
-            "training_leg_step_per_s": training_leg_step_per_s, "loader_only_samples_per_s": loader_sps,
-            "samples_per_s_needed_by_one_gpu": need, "loader_headroom": loader_sps / need, "file_fed_over_compute_bound": fed / compute_bound_step_per_s,
-            "bound": "loader (CPU-side decode: see cpu_quota)" if (loader_sps < need or fed < 0.95 * compute_bound_step_per_s) else "compute",
-            "workers": workers, "loader_cpu_ms_per_sample": cpu_ms_per_sample, "loader_cpu_cores_used": loader_cores, "vertex_features_from": "memory-mapped raw cache (io/vertex_cache.py), sampled rows only; images from their raw copies (no PNG inflate)",
-            "zst_path_loader_only_samples_per_s_by_workers": zst, "host_threads": ncpu, "cpu_quota": cpu_quota(), "per_gpu_batch": per_gpu_batch,
-            "MB_on_disk_per_sample": mb, "frames_on_disk": n_frames, "vertices_per_frame": list(vertex_count_range), "dataset_write_s": t_write,
-            "raw_cache_files_written": n_raw, "raw_cache_convert_s": t_convert,
-            "note": "one GPU's loader; an 8-GPU node runs 8 such loaders on the same host: 8 x loader_cpu_cores_used cores of decode"}
+    return out
 
 
 def get_unbounded_mapper(mcfg, channels):
@@ -1355,8 +1382,7 @@ def main():
         dist.init_process_group(backend=backend, init_method="env://")
 
     if args.file_fed_only:
-        base = run_training(device, world, steps=args.train_steps)
-        out = run_training_file_fed(device, compute_bound_step_per_s=base["step_per_s"])
+        out = run_training_file_fed(device, compute_bound_step_per_s=None)
         if rank == 0:
             print(json.dumps({"file_fed": out}), flush=True)
         return
@@ -1370,7 +1396,7 @@ def main():
             if dist is not None:
                 dist.barrier()
             if rank == 0:
-                out["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=out["step_per_s"], steps=max(args.train_steps // 2, 2))
+                out["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=out["step_per_s"], steps=max(args.train_steps // 2, 2), reference_loader=False)
         if rank == 0:
             print(json.dumps({"train": out, "n_gpus": world}), flush=True)
         if dist is not None:

@@ -189,6 +189,16 @@ int mmf_model_inputs_gather(mmf_handle h, int mapper_id, const int64_t* rows_dev
  * (torch.get_rng_state(): 5056 bytes), which is advanced in place by the n - 1 draws torch.randperm(n) makes -- in O(k) swaps
  * plus the engine advance.  Returns MMF_ERR_INVALID_ARG for a state blob of another size / layout (caller then uses torch). */
 int mmf_host_randperm_prefix(uint8_t* torch_cpu_rng_state, int64_t state_bytes, int64_t n, int64_t k, int64_t* out_host);
+/* Host only (no device work): the loader's two reads of a training sample, each ONE copy from the page cache into the caller's
+ * buffer -- a row of a pinned batch buffer (replaces, for a dataset with raw copies beside its files, the PNG inflate and the
+ * decompress-everything of NvbloxMindmapDataset.__getitem__, mindmap/data_loading/dataset.py:410-415,457-468, and the
+ * per-sample tensors of its collation).  `nbytes` at `offset` of `path` -> dst_host. */
+int mmf_host_read_file_at(const char* path, int64_t offset, void* dst_host, int64_t nbytes);
+/* Rows `rows_host[0..n_rows)` of a raw vertex-feature file (io/vertex_cache.py layout: vertices f16 [V,3] at off_vertices,
+ * features f16 [V,C] at off_features): vertices_f16_out_host [n_rows,3], features_f16_out_host [n_rows,C], in the order of
+ * rows_host (sample_to_n_vertices' selection, data_loading/vertex_sampling.py:143-152). */
+int mmf_host_sample_vertex_file(const char* path, int64_t off_vertices, int64_t off_features, int64_t num_vertices, int64_t channels,
+                                const int64_t* rows_host, int64_t n_rows, void* vertices_f16_out_host, void* features_f16_out_host);
 
 /* ---- layer views (nvblox_torch tsdf_layer_view / feature_layer_view; paper/utils/utils.py:101-121) */
 /* Number of allocated blocks; synchronises `stream`. */

@@ -140,6 +140,8 @@ SIGNATURES = {
     "mmf_model_inputs_prepare": (_I, [_VP, _I, _VP, _VP, _I, _I, _VP, _PI]),
     "mmf_model_inputs_gather": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _I, _VP, _VP]),
     "mmf_host_randperm_prefix": (_I, [_VP, C.c_int64, C.c_int64, C.c_int64, _VP]),
+    "mmf_host_read_file_at": (_I, [C.c_char_p, C.c_int64, _VP, C.c_int64]),
+    "mmf_host_sample_vertex_file": (_I, [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, C.c_int64, _VP, _VP]),
     "mmf_num_allocated_blocks": (_I, [_VP, _I, _I, _VP, _PI]),
     "mmf_get_block_indices": (_I, [_VP, _I, _I, _VP, _I, _VP]),
     "mmf_get_tsdf_blocks": (_I, [_VP, _I, _VP, _I, _VP]),

@@ -202,6 +202,12 @@ class DevicePrefetcher:
             return
         with torch.cuda.stream(self.stream):
             self._next = gpu_unpack(host, self.device)
+            release = getattr(self.loader, "release", None)
+            if release is not None and getattr(host, "slot", -1) >= 0:
+                # a PinnedBatchLoader batch is a view of one of its slots: the slot goes back to the pool once the copies have run
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                release(host, ev)
 
     def __len__(self):
         return len(self.loader)
