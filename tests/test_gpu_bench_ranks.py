@@ -26,4 +26,4 @@ def test_two_ranks_train_then_rank0_file_fed_leg():
     t = out["train"]
     assert out["n_gpus"] == 2 and t["parallelism"] == "dp2" and t["rccl_world_observed"] == 2 and t["global_batch"] == 64
     assert len(t["per_rank_ms_per_step"]["all"]) == 2 and t["allreduce"]["payload_MB"] > 1.0
-    assert t["file_fed"]["file_fed_step_per_s"] > 0
+    assert t["file_fed"]["steady_state_step_per_s"] > 0 and t["file_fed"]["slow_path_samples"] == 0
