@@ -93,6 +93,12 @@ typedef struct {
                                         (the same block sets by construction) */
   int32_t appearance_blend_division; /* 1: A' = (A W + a w) / (W + w) per channel instead of one reciprocal per voxel; frames then take
                                         the stand-alone appearance kernels (the fused / pipelined launches implement the default only) */
+  /* the library computes every a*b + c as two rounded operations (-ffp-contract=off); nvcc contracts by default, so CUDA nvblox's
+   * voxels almost certainly hold fused multiply-adds.  1: the contraction a LLVM-family compiler makes of the spec's expressions
+   * (a*b + c -> fma(a, b, c); a*x + b*y -> fma(a, x, b*y)) at the voxel projection, every bilinear sample (depth, synthetic depth,
+   * colour / feature taps, the low-res feature map), the TSDF update's and the appearance blend's numerator -- same tree in the
+   * oracle (fmaf).  Frames then take the un-merged launches (allocation | TSDF pass | sphere trace | gating | rows), not pipelined. */
+  int32_t fma_contraction;
 } mmf_params;
 
 /* sizeof(mmf_params) as compiled into the library (binding self-check). */
@@ -249,6 +255,10 @@ int mmf_depth_mask(const uint8_t* input_mask_dev, const float* depth_dev, int H,
  * image_processing/feature_extraction.py:188-191,198-210 and nvblox_mapping_helpers.py:256. */
 int mmf_upsample_features(const float* lowres_dev, int h, int w, int Cin, void* out_f16_dev, int Hf, int Wf, int Cpad,
                           void* stream);
+/* The same with the spec switch mmf_params.fma_contraction applied to its arithmetic (source index and the three blends): what a
+ * mapper created with fma_contraction = 1 computes at the taps of mmf_add_feature_frame_lowres / mmf_integrate_frame_lowres. */
+int mmf_upsample_features_spec(const float* lowres_dev, int h, int w, int Cin, void* out_f16_dev, int Hf, int Wf, int Cpad,
+                               int fma_contraction, void* stream);
 
 /* ---- fused up-sample + feature integration ("K11 inside the appearance kernel") ---------- */
 /* mmf_add_feature_frame without the materialised [Hf,Wf,C_pad] f16 image: the kernel samples the low-res backbone map

@@ -84,6 +84,7 @@ class MmfParams(C.Structure):
         ("decay_appearance_layers", C.c_int32),
         ("raycast_walk_from_camera", C.c_int32),
         ("appearance_blend_division", C.c_int32),
+        ("fma_contraction", C.c_int32),
     ]
 
 
@@ -159,6 +160,7 @@ SIGNATURES = {
     "mmf_depth_mask": (_I, [_VP, _VP, _I, _I, _F, _VP, _VP]),
     "mmf_frame_masks": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "mmf_upsample_features": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _VP]),
+    "mmf_upsample_features_spec": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _I, _VP]),
     "mmf_rotary_apply": (_I, [_VP, C.c_longlong, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
     "mmf_rotary_apply_grad": (_I, [_VP, _VP, _VP, _VP, C.c_longlong, _I, _VP]),
     "mmf_adaln_modulate": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),

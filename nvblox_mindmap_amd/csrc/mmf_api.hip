@@ -94,7 +94,7 @@ void derive_consts(const mmf_params& P, MapConsts& mc) {
   mc.st_eps = P.st_surface_eps_vox * mc.v;
   mc.C = P.feature_channels;
   mc.reach = P.raycast_to_truncation ? mc.trunc : 0.0f;
-  mc.spec_flags = (P.raycast_walk_from_camera ? 1 : 0) | (P.appearance_blend_division ? 2 : 0);
+  mc.spec_flags = (P.raycast_walk_from_camera ? 1 : 0) | (P.appearance_blend_division ? 2 : 0) | (P.fma_contraction ? kSpecFma : 0);
 }
 
 int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
@@ -848,6 +848,7 @@ int mmf_default_params(mmf_params* p) {
   p->decay_appearance_layers = 0;
   p->raycast_walk_from_camera = 0;
   p->appearance_blend_division = 0;
+  p->fma_contraction = 0;
   return MMF_OK;
 }
 
@@ -1136,7 +1137,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     input_mask = m->inv_mask;
   }
   if (!fusable || big) MMF_TRY(flush_rows(h, *m));  // no launch of this frame can host it
-  if (m->defer_rows && fusable && !big) MMF_TRY(ensure_flat_other(*m));
+  if (m->defer_rows && fusable && !big && !(m->mc.spec_flags & kSpecFma)) MMF_TRY(ensure_flat_other(*m));
   if (!fusable) {
     // odd shapes / very large grids: the plain sequence of stand-alone launches
     flush_decay(h, *m, s);
@@ -1190,7 +1191,10 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   const bool light_decay = do_decay && m->wmax_valid;
   // Merged launch 2 (k_alloc_tsdf): bounded workspace and no voxel-pass decay in this frame -- the live list is final when
   // k_front ends, so the TSDF pass of the existing blocks runs beside the allocation workgroup instead of after it.
-  const bool merged = !big && m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
+  // (spec switch fma_contraction: built into the un-merged launches only -- allocation, then k_tsdf_pass; the gating launch and the
+  // row update of this frame, not deferred)
+  const bool fma = (m->mc.spec_flags & kSpecFma) != 0;
+  const bool merged = !big && !fma && m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
   if (big && light_decay && m->mc.dealloc_decayed) {
     // the light decay's deallocations for a large pool: the scalable compaction (decided from wmax, no voxel touched) as a launch
     // of its own -- k_front's single decay workgroup would need dozens of serial passes over 10^5 list entries
@@ -1334,7 +1338,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
     }
   }
-  if (may_defer && m->defer_rows && !big && m->flat.rec && m->flat_other.rec) {
+  if (may_defer && m->defer_rows && !big && !fma && m->flat.rec && m->flat_other.rec) {
     // launches 4 and 5 are left to the next fused frame (roles of its launches 1 and 3) or to whatever takes the mapper first
     MMF_TRY(flush_rows(h, *m));  // (nothing hosted the previous frame's: before this frame's own)
     m->tail = make_app_tail(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,
@@ -1426,7 +1430,7 @@ static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGr
   if (ncells <= 0 || !alloc_jobs_fusable(ncells, m.tsdf.d.cap) || ncells > m.sc_cap[0] || m.tsdf.d.cap > m.sc_cap[1] ||
       m.tsdf.d.cap > m.sc_cap[2])
     return false;
-  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & 2) || m.lazy_lag) return false;
+  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & (2 | kSpecFma)) || m.lazy_lag) return false;
   if (m.pending_decay && !m.wmax_valid) return false;  // that decay needs its voxel pass: separate launches
   const int sf = m.mc.st_sf;
   if (in.W / sf <= 0 || in.H / sf <= 0 || (in.W / sf) * (in.H / sf) > m.synth_cap) return false;

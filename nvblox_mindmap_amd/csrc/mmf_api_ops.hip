@@ -53,11 +53,16 @@ int mmf_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, 
   return check_launch();
 }
 
-int mmf_upsample_features(const float* lowres, int hh, int ww, int Cin, void* out, int Hf, int Wf, int Cpad, void* stream) {
+int mmf_upsample_features_spec(const float* lowres, int hh, int ww, int Cin, void* out, int Hf, int Wf, int Cpad, int fma_contraction,
+                               void* stream) {
   if (!lowres || !out || hh <= 0 || ww <= 0 || Cin <= 0 || Hf <= 0 || Wf <= 0 || Cpad < Cin || Cpad % 8 != 0)
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_upsample_features (Cpad must be a multiple of 8 and >= Cin)");
-  launch_upsample_features(lowres, hh, ww, Cin, (__half*)out, Hf, Wf, Cpad, (hipStream_t)stream);
+  launch_upsample_features(lowres, hh, ww, Cin, (__half*)out, Hf, Wf, Cpad, (hipStream_t)stream, fma_contraction != 0);
   return check_launch();
+}
+
+int mmf_upsample_features(const float* lowres, int hh, int ww, int Cin, void* out, int Hf, int Wf, int Cpad, void* stream) {
+  return mmf_upsample_features_spec(lowres, hh, ww, Cin, out, Hf, Wf, Cpad, 0, stream);
 }
 
 static int fps_entry(const float* x, int B, int N, int C, int npoints, int start_idx, int64_t* out_idx, void* workspace, size_t workspace_bytes,

@@ -21,12 +21,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));                 // a ch
 // mask).  Same operation order as oracle/mmf_oracle.c:app_gate.
 // ------------------------------------------------------------------------------------------------
 // geometry + occlusion part: everything that does not depend on the integration mask
+template <bool FMA = false>
 __device__ inline bool app_gate_geo(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ synth, int Ws,
                                     int Hs, int bx, int by, int bz, int lin, int& x0, int& y0, float& wx, float& wy) {
   float c[3], p[3], u, v;
-  voxel_centre(mc, bx, by, bz, lin, c);
-  xform(T_C_L, c, p);
-  if (!project(cam, p, u, v)) return false;
+  voxel_centre<FMA>(mc, bx, by, bz, lin, c);
+  xform<FMA>(T_C_L, c, p);
+  if (!project<FMA>(cam, p, u, v)) return false;
   if (mc.max_dist > 0.0f && p[2] > mc.max_dist) return false;
   const float sf = (float)mc.st_sf;
   int sx, sy;
@@ -37,7 +38,7 @@ __device__ inline bool app_gate_geo(const MapConsts& mc, const Cam& cam, const R
   const float2_u s0 = *reinterpret_cast<const float2_u*>(synth + si);
   const float2_u s1 = *reinterpret_cast<const float2_u*>(synth + si + Ws);
   if (!(s0.x > 0.0f) || !(s0.y > 0.0f) || !(s1.x > 0.0f) || !(s1.y > 0.0f)) return false;
-  const float sd = bilin(s0.x, s0.y, s1.x, s1.y, swx, swy);
+  const float sd = bilin<FMA>(s0.x, s0.y, s1.x, s1.y, swx, swy);
   if (fabsf(sd - p[2]) > mc.trunc) return false;
   return true;
 }
@@ -51,13 +52,14 @@ __device__ inline bool app_gate_mask(const uint8_t* __restrict__ mask, int W, in
   return (m0 & 0xffu) && (m0 & 0xff00u) && (m1 & 0xffu) && (m1 & 0xff00u);
 }
 
+template <bool FMA = false>
 __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* __restrict__ mask,
                                 const float* __restrict__ synth, int Ws, int Hs, int bx, int by, int bz, int lin, int& x0,
                                 int& y0, float& wx, float& wy) {
   float c[3], p[3], u, v;
-  voxel_centre(mc, bx, by, bz, lin, c);
-  xform(T_C_L, c, p);
-  if (!project(cam, p, u, v)) return false;
+  voxel_centre<FMA>(mc, bx, by, bz, lin, c);
+  xform<FMA>(T_C_L, c, p);
+  if (!project<FMA>(cam, p, u, v)) return false;
   if (mc.max_dist > 0.0f && p[2] > mc.max_dist) return false;
   const float sf = (float)mc.st_sf;
   int sx, sy;
@@ -76,7 +78,7 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
     m1 = *reinterpret_cast<const ushort_u*>(mask + i + cam.W);
   }
   if (!(s0.x > 0.0f) || !(s0.y > 0.0f) || !(s1.x > 0.0f) || !(s1.y > 0.0f)) return false;
-  const float sd = bilin(s0.x, s0.y, s1.x, s1.y, swx, swy);
+  const float sd = bilin<FMA>(s0.x, s0.y, s1.x, s1.y, swx, swy);
   if (fabsf(sd - p[2]) > mc.trunc) return false;
   if (!(m0 & 0xffu) || !(m0 & 0xff00u) || !(m1 & 0xffu) || !(m1 & 0xff00u)) return false;
   return true;
@@ -88,7 +90,7 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
 
 // blend one colour voxel {rgb_, w} with the bilinear sample at footprint (x0,y0,wx,wy)
 // DIV: the spec switch mmf_params.appearance_blend_division (stand-alone kernels only; every fused launch is built with the default)
-template <bool DIV = false>
+template <bool DIV = false, bool FMA = false>
 __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, const MapConsts& mc, int x0, int y0, float wx, float wy,
                                     unsigned& ex, unsigned& ey) {
   // the two pixels of a footprint row are 6 consecutive bytes: one 4-byte + one 2-byte load (byte-aligned) instead of six
@@ -104,10 +106,10 @@ __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, cons
   unsigned out = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float a = bilin((float)((top >> (8 * k)) & 0xffu), (float)((top >> (8 * (k + 3))) & 0xffu), (float)((bot >> (8 * k)) & 0xffu),
+    const float a = bilin<FMA>((float)((top >> (8 * k)) & 0xffu), (float)((top >> (8 * (k + 3))) & 0xffu), (float)((bot >> (8 * k)) & 0xffu),
                           (float)((bot >> (8 * (k + 3))) & 0xffu), wx, wy);
     const float Aold = (float)((ex >> (8 * k)) & 0xffu);
-    const float num = Aold * Wv + a * wm;
+    const float num = madd2<FMA>(Aold, Wv, a, wm);
     const float An = DIV ? num / (Wv + wm) : num * inv;
     out |= ((unsigned)floorf(An + 0.5f) & 0xffu) << (8 * k);
   }
@@ -115,7 +117,7 @@ __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, cons
   ey = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
 }
 
-template <bool DIV = false>
+template <bool DIV = false, bool FMA = false>
 __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs, int bid,
                                   int nb) {
   const LayerDev& L = A.L;
@@ -140,8 +142,8 @@ __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const f
       unsigned ex = r ? e2.z : e2.x, ey = r ? e2.w : e2.y;
       int x0, y0;
       float wx, wy;
-      if (app_gate(mc, cam, A.T_C_L, A.mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
-        color_update<DIV>(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
+      if (app_gate<FMA>(mc, cam, A.T_C_L, A.mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy)) {
+        color_update<DIV, FMA>(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
         upd = true;
       }
       if (r) {
@@ -181,8 +183,9 @@ struct LowAxis {
   int i0, i1;
   float l0, l1;
 };
+template <bool FMA = false>
 __device__ __forceinline__ LowAxis low_axis(float scale, int out_idx, int n_in) {
-  float sv = scale * ((float)out_idx + 0.5f) - 0.5f;
+  float sv = madd<FMA>(scale, (float)out_idx + 0.5f, -0.5f);
   sv = sv < 0.0f ? 0.0f : sv;
   LowAxis a;
   a.i0 = (int)sv < n_in - 1 ? (int)sv : n_in - 1;
@@ -211,12 +214,13 @@ __device__ __forceinline__ float f4_at(const float4& v, int k) { return k == 0 ?
 __device__ __forceinline__ float low_at(const Low8& v, int k) {
   return k == 0 ? v.lo.x : k == 1 ? v.lo.y : k == 2 ? v.lo.z : k == 3 ? v.lo.w : k == 4 ? v.hi.x : k == 5 ? v.hi.y : k == 6 ? v.hi.z : v.hi.w;
 }
+template <bool FMA = false>
 __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const Low8& a10, const Low8& a11, const LowAxis& X,
                                          const LowAxis& Y) {
   half8 o;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float val = Y.l0 * (X.l0 * low_at(a00, k) + X.l1 * low_at(a01, k)) + Y.l1 * (X.l0 * low_at(a10, k) + X.l1 * low_at(a11, k));
+    const float val = madd2<FMA>(Y.l0, madd2<FMA>(X.l0, low_at(a00, k), X.l1, low_at(a01, k)), Y.l1, madd2<FMA>(X.l0, low_at(a10, k), X.l1, low_at(a11, k)));
     o[k] = (_Float16)val;
   }
   return o;
@@ -225,14 +229,35 @@ __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const
 // One tap from its own four texels: the rare case of a footprint that straddles a low-res cell border.  A real call, not
 // inlined: inlined four times it doubles the register count of every kernel that updates rows from a low-res map (and halves
 // the rows in flight per SIMD) for the sake of 1 voxel in ~8.
+template <bool FMA = false>
 __device__ __noinline__ half8 low_tap_at(const float* __restrict__ low, int w, int Cin, int c0, LowAxis X, LowAxis Y) {
-  return low_tap(low_load8(low, w, Cin, Y.i0, X.i0, c0), low_load8(low, w, Cin, Y.i0, X.i1, c0), low_load8(low, w, Cin, Y.i1, X.i0, c0),
+  return low_tap<FMA>(low_load8(low, w, Cin, Y.i0, X.i0, c0), low_load8(low, w, Cin, Y.i0, X.i1, c0), low_load8(low, w, Cin, Y.i1, X.i0, c0),
                  low_load8(low, w, Cin, Y.i1, X.i1, c0), X, Y);
 }
 
 // One surviving voxel: blend its channel row with the bilinear sample of the feature image (or of the virtual up-sampled
 // low-res map).  `lanes` lanes (gl = 0..lanes-1) share the row in 16-byte pieces.
-template <bool LOW, bool DIV = false>
+// packed forms of madd2 (two channels per instruction: v_pk_fma_f32 / v_pk_mul_f32 + v_pk_add_f32)
+template <bool FMA>
+__device__ __forceinline__ f32x2 pk_madd2(float a, f32x2 x, float b, f32x2 y) {
+  if constexpr (FMA) {
+    const f32x2 av = {a, a};
+    return __builtin_elementwise_fma(av, x, b * y);
+  } else {
+    return a * x + b * y;
+  }
+}
+template <bool FMA>
+__device__ __forceinline__ f32x2 pk_madd2(f32x2 a, float x, f32x2 b, float y) {
+  if constexpr (FMA) {
+    const f32x2 xv = {x, x};
+    return __builtin_elementwise_fma(a, xv, b * y);
+  } else {
+    return a * x + b * y;
+  }
+}
+
+template <bool LOW, bool DIV = false, bool FMA = false>
 __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts& mc, __half* __restrict__ A, bool is_new, size_t pix,
                                               float wx, float wy, float Wv, int gl, int lanes) {
   const Cam& cam = Aa.cam;
@@ -257,11 +282,11 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
     for (int k = 0; k < 8; k += 2) {
       const f32x2 v00 = {(float)a00[k], (float)a00[k + 1]}, v10 = {(float)a10[k], (float)a10[k + 1]};
       const f32x2 v01 = {(float)a01[k], (float)a01[k + 1]}, v11 = {(float)a11[k], (float)a11[k + 1]};
-      const f32x2 top = ux * v00 + wx * v10;
-      const f32x2 bot = ux * v01 + wx * v11;
-      const f32x2 a = uy * top + wy * bot;
+      const f32x2 top = pk_madd2<FMA>(ux, v00, wx, v10);
+      const f32x2 bot = pk_madd2<FMA>(ux, v01, wx, v11);
+      const f32x2 a = pk_madd2<FMA>(uy, top, wy, bot);
       const f32x2 old = {(float)av[k], (float)av[k + 1]};
-      const f32x2 num = old * Wv + a * wm;
+      const f32x2 num = pk_madd2<FMA>(old, Wv, a, wm);
       const f32x2 An = DIV ? num / (Wv + wm) : num * inv;
       o[k] = (_Float16)An.x;
       o[k + 1] = (_Float16)An.y;
@@ -283,8 +308,8 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
     // the L2-resident low-res map), and one loop with every case inside cost 170 VGPRs = 2 waves per SIMD.
     const LowRes LR = Aa.low;
     const int py = (int)(pix / (size_t)cam.W), px = (int)(pix - (size_t)py * cam.W);
-    const LowAxis X0 = low_axis(LR.sw, px, LR.w), X1 = low_axis(LR.sw, px + 1, LR.w);
-    const LowAxis Y0 = low_axis(LR.sh, py, LR.h), Y1 = low_axis(LR.sh, py + 1, LR.h);
+    const LowAxis X0 = low_axis<FMA>(LR.sw, px, LR.w), X1 = low_axis<FMA>(LR.sw, px + 1, LR.w);
+    const LowAxis Y0 = low_axis<FMA>(LR.sh, py, LR.h), Y1 = low_axis<FMA>(LR.sh, py + 1, LR.h);
     const int nin = LR.cin >> 3 < nch ? LR.cin >> 3 : nch;  // pieces that exist in the map; the rest are the zero pad channels
     const bool one_cell = X0.i0 == X1.i0 && X0.i1 == X1.i1 && Y0.i0 == Y1.i0 && Y0.i1 == Y1.i1;
     if (one_cell) {  // usual case: the footprint lies inside one low-res cell, 4 texels serve 4 taps
@@ -305,10 +330,10 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
           for (int k = 0; k < 4; k += 2) {  // channel pairs: packed f32 multiplies / adds, the arithmetic of low_tap element by element
             const f32x2 a = {f4_at(q00, k), f4_at(q00, k + 1)}, b = {f4_at(q01, k), f4_at(q01, k + 1)};
             const f32x2 c = {f4_at(q10, k), f4_at(q10, k + 1)}, d = {f4_at(q11, k), f4_at(q11, k + 1)};
-            const f32x2 r0x0 = X0.l0 * a + X0.l1 * b, r0x1 = X1.l0 * a + X1.l1 * b;  // upper texel row at the two tap columns
-            const f32x2 r1x0 = X0.l0 * c + X0.l1 * d, r1x1 = X1.l0 * c + X1.l1 * d;  // lower texel row
-            const f32x2 v00 = Y0.l0 * r0x0 + Y0.l1 * r1x0, v10 = Y0.l0 * r0x1 + Y0.l1 * r1x1;
-            const f32x2 v01 = Y1.l0 * r0x0 + Y1.l1 * r1x0, v11 = Y1.l0 * r0x1 + Y1.l1 * r1x1;
+            const f32x2 r0x0 = pk_madd2<FMA>(X0.l0, a, X0.l1, b), r0x1 = pk_madd2<FMA>(X1.l0, a, X1.l1, b);  // upper texel row at the two tap columns
+            const f32x2 r1x0 = pk_madd2<FMA>(X0.l0, c, X0.l1, d), r1x1 = pk_madd2<FMA>(X1.l0, c, X1.l1, d);  // lower texel row
+            const f32x2 v00 = pk_madd2<FMA>(Y0.l0, r0x0, Y0.l1, r1x0), v10 = pk_madd2<FMA>(Y0.l0, r0x1, Y0.l1, r1x1);
+            const f32x2 v01 = pk_madd2<FMA>(Y1.l0, r0x0, Y1.l1, r1x0), v11 = pk_madd2<FMA>(Y1.l0, r0x1, Y1.l1, r1x1);
             // (two channels per conversion: v_cvt_pk_f16_f32, round to nearest even like the scalar cast)
             const half2v c00 = __builtin_convertvector(v00, half2v), c10 = __builtin_convertvector(v10, half2v);
             const half2v c01 = __builtin_convertvector(v01, half2v), c11 = __builtin_convertvector(v11, half2v);
@@ -325,8 +350,8 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
 #pragma unroll 1
       for (int ch = gl; ch < nin; ch += lanes) {
         const int c0 = ch * 8;
-        const half8 a00 = low_tap_at(LR.data, LR.w, LR.cin, c0, X0, Y0), a10 = low_tap_at(LR.data, LR.w, LR.cin, c0, X1, Y0),
-                    a01 = low_tap_at(LR.data, LR.w, LR.cin, c0, X0, Y1), a11 = low_tap_at(LR.data, LR.w, LR.cin, c0, X1, Y1);
+        const half8 a00 = low_tap_at<FMA>(LR.data, LR.w, LR.cin, c0, X0, Y0), a10 = low_tap_at<FMA>(LR.data, LR.w, LR.cin, c0, X1, Y0),
+                    a01 = low_tap_at<FMA>(LR.data, LR.w, LR.cin, c0, X0, Y1), a11 = low_tap_at<FMA>(LR.data, LR.w, LR.cin, c0, X1, Y1);
         blend(ch, a00, a10, a01, a11);
       }
     }
@@ -339,14 +364,14 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
 }
 
 // Phase 2 inside the workgroup that gated the block: 32 groups of 8 lanes walk the survivor list in LDS.
-template <bool LOW, bool DIV = false>
+template <bool LOW, bool DIV = false, bool FMA = false>
 __device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
   const int C = mc.C;
   const int group = threadIdx.x >> 3, gl = threadIdx.x & 7;
   const int nv = S.n;
   __half* blk = reinterpret_cast<__half*>(A.L.pool) + (size_t)slot * kVPB * C;
   for (int vi = group; vi < nv; vi += 32)
-    feature_voxel<LOW, DIV>(A, mc, blk + (size_t)S.lin[vi] * C, is_new, S.pix[vi], S.wx[vi], S.wy[vi], S.W[vi], gl, 8);
+    feature_voxel<LOW, DIV, FMA>(A, mc, blk + (size_t)S.lin[vi] * C, is_new, S.pix[vi], S.wx[vi], S.wy[vi], S.W[vi], gl, 8);
 }
 
 // Phase 2 deferred: append the survivor list to the frame's global list (FlatList); k_feature_flat then spreads the
@@ -389,7 +414,7 @@ __device__ inline void feature_zero_fill(const AppArgs& A, const MapConsts& mc, 
 // tail of both gating bodies once the survivor list of the block is complete in LDS (callers synchronised before)
 // PUBLISH_ONLY: the caller guarantees a survivor list (A.flat.rec != nullptr), so the in-workgroup row update is not even
 // compiled in -- it is the register-hungriest code of the gating kernels (LOW: 175 VGPRs = 2 waves per SIMD, against 5).
-template <bool LOW, bool PUBLISH_ONLY = false, bool DIV = false>
+template <bool LOW, bool PUBLISH_ONLY = false, bool DIV = false, bool FMA = false>
 __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new, int cand) {
   if constexpr (PUBLISH_ONLY) {
     feature_publish(A, S, slot, is_new, cand);
@@ -397,13 +422,13 @@ __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, Fea
     // statistics: with the survivor list the frame's total is added once by k_feature_flat (one more same-address atomic per
     // gating workgroup otherwise)
     if (threadIdx.x == 0 && A.stats && S.n && !A.flat.rec) atomicAdd(reinterpret_cast<unsigned long long*>(A.stats + 8), (unsigned long long)S.n);
-    if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW, DIV>(A, mc, S, slot, is_new);
+    if (!feature_publish(A, S, slot, is_new, cand)) feature_apply<LOW, DIV, FMA>(A, mc, S, slot, is_new);
   }
   if (is_new) feature_zero_fill(A, mc, S, slot);
 }
 
 // Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size (workgroup bid of nb).
-template <bool LOW>
+template <bool LOW, bool FMA = false>
 __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, int lpv, int bid, int nb, int* s_prefix) {
   const long long tr0 = wg_trace_begin();
   // prefix sums of the sub-list counters (one wave, shuffles): flat position v lives in sub-list k with prefix[k] <= v < prefix[k+1]
@@ -432,12 +457,12 @@ __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, 
     const uint4 r = A.flat.rec[at];
     const float Wv = A.flat.w[at];
     const size_t row = (size_t)(r.x & 0x7fffffffu);  // slot * 512 + lin
-    feature_voxel<LOW>(A, mc, pool + row * C, (r.x >> 31) != 0u, r.y, __uint_as_float(r.z), __uint_as_float(r.w), Wv, gl, lpv);
+    feature_voxel<LOW, false, FMA>(A, mc, pool + row * C, (r.x >> 31) != 0u, r.y, __uint_as_float(r.z), __uint_as_float(r.w), Wv, gl, lpv);
   }
   wg_trace_end(tr0, kTrFeatureFlat);
 }
 
-template <bool LOW, bool DIV = false>
+template <bool LOW, bool DIV = false, bool FMA = false>
 __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
                                     int bid, int nb, FeatLds& S) {
   const LayerDev& L = A.L;
@@ -473,7 +498,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
       const int lin = tid + 256 * r;
       int x0, y0;
       float wx, wy;
-      const bool valid = app_gate(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
+      const bool valid = app_gate<FMA>(mc, cam, T_C_L, mask, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
       const u64 bal = __ballot(valid);
       int base = 0;
       if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
@@ -494,7 +519,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
     }
     __syncthreads();
 
-    feature_finish<LOW, false, DIV>(A, mc, S, slot, is_new, i);
+    feature_finish<LOW, false, DIV, FMA>(A, mc, S, slot, is_new, i);
     __syncthreads();
   }
 }
@@ -503,7 +528,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
 // frame both layers see the same camera and the same candidate list (the allocation jobs read the same flags), so the
 // projection, the two bilinear footprints and the occlusion test against the synthetic depth are evaluated once; only
 // the masks (depth mask for colour, eroded feature mask for features) differ.  Voxel order: thread t owns voxels 2t, 2t+1.
-template <bool LOW, bool PUB = false>
+template <bool LOW, bool PUB = false, bool FMA = false>
 __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, const MapConsts& mc, const float* __restrict__ synth,
                                       int Ws, int Hs, int bid, int nb, FeatLds& S) {
   const Cam& cam = Ac.cam;
@@ -534,12 +559,12 @@ __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, cons
       const int lin = tid * 2 + r;
       int x0 = 0, y0 = 0;
       float wx = 0.0f, wy = 0.0f;
-      const bool geo = app_gate_geo(mc, cam, Ac.T_C_L, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
+      const bool geo = app_gate_geo<FMA>(mc, cam, Ac.T_C_L, synth, Ws, Hs, bx, by, bz, lin, x0, y0, wx, wy);
       const bool c_ok = geo && cslot >= 0 && app_gate_mask(Ac.mask, cam.W, x0, y0);
       const bool f_ok = geo && fslot >= 0 && app_gate_mask(Af.mask, cam.W, x0, y0);
       if (c_ok) {
         unsigned ex = r ? e2.z : e2.x, ey = r ? e2.w : e2.y;
-        color_update(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
+        color_update<false, FMA>(rgb, cam.W, mc, x0, y0, wx, wy, ex, ey);
         if (r) {
           e2.z = ex;
           e2.w = ey;
@@ -570,7 +595,7 @@ __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, cons
     if (cslot >= 0 && (c_upd || c_new)) *vox2 = e2;
     if (fslot >= 0 && (f_upd || f_new)) *reinterpret_cast<float2*>(wts + 2 * tid) = w2;
     __syncthreads();
-    if (fslot >= 0) feature_finish<LOW, PUB>(Af, mc, S, fslot, f_new, i);
+    if (fslot >= 0) feature_finish<LOW, PUB, false, FMA>(Af, mc, S, fslot, f_new, i);
     __syncthreads();
   }
 }

@@ -50,8 +50,37 @@ struct MapConsts {
   float st_max_len, st_eps;
   int C;
   float reach;  // how far past the measured depth the raycast marks blocks: trunc (default) or 0
-  int spec_flags;  // bit 0: raycast walks from the camera; bit 1: appearance blend divides per channel (mmf_params spec switches)
+  int spec_flags;  // bit 0: raycast walks from the camera; bit 1: appearance blend divides per channel; bit 2: fma_contraction
+                   // (mmf_params spec switches)
 };
+constexpr int kSpecFma = 4;
+
+// ---- spec switch mmf_params.fma_contraction (MapConsts::spec_flags & kSpecFma) ---------------------------------------------------
+// The library is built with -ffp-contract=off: `a * b + c` is two rounded operations everywhere.  nvcc contracts by default
+// (-fmad=true), so CUDA nvblox's results almost certainly contain fused multiply-adds; which ones is not knowable from here (the
+// source is absent).  The switch applies the contraction a LLVM-family compiler makes to the spec's expressions as written:
+//   a*b + c        -> fma(a, b, c)
+//   a*x + b*y      -> fma(a, x, b*y)            (the left product is fused, the right one rounded)
+//   (X + e*f) + t  -> fma(e, f, X) + t
+// at the projection of a voxel centre (voxel_centre, xform, project), every bilinear sample (depth, synthetic depth, colour /
+// feature taps, the low-res feature map incl. its source-index computation), the TSDF update's numerator and the appearance
+// blend's numerator -- in the oracle (fmaf) and here (v_fma_f32 / v_pk_fma_f32), same tree.  FMA is a template parameter like DIV:
+// the default kernels are not touched by it.
+template <bool FMA>
+__device__ __forceinline__ float madd(float a, float b, float c) {
+  if constexpr (FMA)
+    return __builtin_fmaf(a, b, c);
+  else
+    return a * b + c;
+}
+// a*x + b*y
+template <bool FMA>
+__device__ __forceinline__ float madd2(float a, float x, float b, float y) {
+  if constexpr (FMA)
+    return __builtin_fmaf(a, x, b * y);
+  else
+    return a * x + b * y;
+}
 
 // Device view of one block layer: open-addressing hash (packed 64-bit keys -> pool slot),
 // pool of 8x8x8 blocks, live list (allocation order) and free-slot stack.
@@ -260,27 +289,30 @@ __device__ inline int layer_lookup(const LayerDev& L, u64 key) {
 
 __device__ inline int ifloor(float x) { return (int)floorf(x); }
 
+template <bool FMA = false>
 __device__ inline void xform(const Rigid& T, const float* p, float* q) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) q[i] = ((T.R[i * 3 + 0] * p[0] + T.R[i * 3 + 1] * p[1]) + T.R[i * 3 + 2] * p[2]) + T.t[i];
+  for (int i = 0; i < 3; ++i) q[i] = madd<FMA>(T.R[i * 3 + 2], p[2], madd2<FMA>(T.R[i * 3 + 0], p[0], T.R[i * 3 + 1], p[1])) + T.t[i];
 }
 __device__ inline void rotate(const Rigid& T, const float* p, float* q) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) q[i] = (T.R[i * 3 + 0] * p[0] + T.R[i * 3 + 1] * p[1]) + T.R[i * 3 + 2] * p[2];
 }
 
+template <bool FMA = false>
 __device__ inline void voxel_centre(const MapConsts& mc, int bx, int by, int bz, int lin, float* c) {
   int vx = lin >> 6, vy = (lin >> 3) & 7, vz = lin & 7;
-  c[0] = (float)bx * mc.bs + ((float)vx + 0.5f) * mc.v;
-  c[1] = (float)by * mc.bs + ((float)vy + 0.5f) * mc.v;
-  c[2] = (float)bz * mc.bs + ((float)vz + 0.5f) * mc.v;
+  c[0] = madd2<FMA>((float)bx, mc.bs, (float)vx + 0.5f, mc.v);
+  c[1] = madd2<FMA>((float)by, mc.bs, (float)vy + 0.5f, mc.v);
+  c[2] = madd2<FMA>((float)bz, mc.bs, (float)vz + 0.5f, mc.v);
 }
 
+template <bool FMA = false>
 __device__ inline bool project(const Cam& c, const float* p, float& u, float& v) {
   if (p[2] <= 1e-6f) return false;
   float iz = 1.0f / p[2];
-  float uu = c.fx * (p[0] * iz) + c.cx;
-  float vv = c.fy * (p[1] * iz) + c.cy;
+  float uu = madd<FMA>(c.fx, p[0] * iz, c.cx);
+  float vv = madd<FMA>(c.fy, p[1] * iz, c.cy);
   if (uu < 0.0f || vv < 0.0f || uu > (float)c.W || vv > (float)c.H) return false;
   u = uu;
   v = vv;
@@ -299,10 +331,11 @@ __device__ inline bool bilin_setup(float u, float v, int W, int H, int& x0, int&
   return true;
 }
 
+template <bool FMA = false>
 __device__ inline float bilin(float a00, float a10, float a01, float a11, float wx, float wy) {
-  float top = (1.0f - wx) * a00 + wx * a10;
-  float bot = (1.0f - wx) * a01 + wx * a11;
-  return (1.0f - wy) * top + wy * bot;
+  float top = madd2<FMA>(1.0f - wx, a00, wx, a10);
+  float bot = madd2<FMA>(1.0f - wx, a01, wx, a11);
+  return madd2<FMA>(1.0f - wy, top, wy, bot);
 }
 
 // Measurement weight of a TSDF update: upstream nvblox's WeightingFunctionType family as restated in oracle/mmf_oracle.c

@@ -17,6 +17,7 @@ namespace mmf {
 // Candidate blocks: live TSDF blocks with a voxel inside the truncation band (W > 0, |D| < trunc)
 // whose centre projects into the appearance image.  One workgroup per live block, 2 voxels/thread.
 // ------------------------------------------------------------------------------------------------
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        uint8_t* __restrict__ flags, u64* __restrict__ cell_key) {
   const int n = T.ctr[0];
@@ -32,9 +33,9 @@ __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc
       const float D = r ? a.z : a.x, W = r ? a.w : a.y;
       if (!(W > 0.0f) || !(fabsf(D) < mc.trunc)) continue;
       float c[3], p[3], u, v;
-      voxel_centre(mc, bx, by, bz, threadIdx.x * 2 + r, c);
-      xform(T_C_L, c, p);
-      if (!project(cam, p, u, v)) continue;
+      voxel_centre<FMA>(mc, bx, by, bz, threadIdx.x * 2 + r, c);
+      xform<FMA>(T_C_L, c, p);
+      if (!project<FMA>(cam, p, u, v)) continue;
       if (mc.max_dist > 0.0f && p[2] > mc.max_dist) continue;
       hit = 1;
     }
@@ -380,16 +381,16 @@ __global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch(SphereBatch P) {
 }
 
 
-template <bool DIV>
+template <bool DIV, bool FMA>
 __global__ __launch_bounds__(256) void k_color_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws, int Hs) {
-  color_body<DIV>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x);
+  color_body<DIV, FMA>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x);
 }
 
 
-template <bool LOW>
+template <bool LOW, bool FMA = false>
 __global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
   __shared__ int s_prefix[kFlatSubLists + 1];
-  feature_flat_role<LOW>(A, mc, lpv, (int)blockIdx.x, (int)gridDim.x, s_prefix);
+  feature_flat_role<LOW, FMA>(A, mc, lpv, (int)blockIdx.x, (int)gridDim.x, s_prefix);
 }
 
 // two frames' survivor lists in one launch: the first nb0 workgroups walk list 0, the rest list 1
@@ -453,33 +454,33 @@ __global__ __launch_bounds__(256) void k_feature_flat_batch(FlatBatch P) {
 }
 
 
-template <bool LOW, bool DIV>
+template <bool LOW, bool DIV, bool FMA>
 __global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                           int Hs) {
   __shared__ FeatLds S;
-  feature_body<LOW, DIV>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+  feature_body<LOW, DIV, FMA>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 }
 
 // Horizontal fusion: colour and feature update of one frame in ONE launch (different layers, same TSDF / synthetic
 // depth inputs): the first g_col workgroups walk the colour candidates, the rest the feature candidates.
-template <bool LOW>
+template <bool LOW, bool FMA>
 __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth,
                                                        int Ws, int Hs, int g_col) {
   __shared__ FeatLds S;
   if ((int)blockIdx.x < g_col)
-    color_body(Acol, mc, synth, Ws, Hs, blockIdx.x, g_col);
+    color_body<false, FMA>(Acol, mc, synth, Ws, Hs, blockIdx.x, g_col);
   else
-    feature_body<LOW>(Afeat, mc, synth, Ws, Hs, (int)blockIdx.x - g_col, (int)gridDim.x - g_col, S);
+    feature_body<LOW, false, FMA>(Afeat, mc, synth, Ws, Hs, (int)blockIdx.x - g_col, (int)gridDim.x - g_col, S);
 }
 
 
 // PUB: the frame has a survivor list (every fused frame): publish-only gating, independent of LOW (launched as <false, true>)
-template <bool LOW, bool PUB>
+template <bool LOW, bool PUB, bool FMA = false>
 __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                   int Hs) {
   __shared__ FeatLds S;
   const long long tr0 = wg_trace_begin();
-  app_frame_body<LOW, PUB>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
+  app_frame_body<LOW, PUB, FMA>(Acol, Afeat, mc, synth, Ws, Hs, blockIdx.x, gridDim.x, S);
 #ifdef MMF_WG_TRACE
   {  // diagnostics: survivors of the (last) block and whether it was new ride in the record id
     const int n = *Acol.sc.cand_count;
@@ -534,8 +535,12 @@ static inline int grid8(int upper, int cap) {
 
 void launch_app_candidates(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, uint8_t* flags,
                            u64* cell_key, hipStream_t s) {
-  hipLaunchKernelGGL(k_app_candidates, dim3(grid8(hinted(tsdf.hint_live, tsdf.cap), 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L,
-                     flags, cell_key);
+  if (mc.spec_flags & kSpecFma)
+    hipLaunchKernelGGL(k_app_candidates<true>, dim3(grid8(hinted(tsdf.hint_live, tsdf.cap), 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L,
+                       flags, cell_key);
+  else
+    hipLaunchKernelGGL(k_app_candidates<false>, dim3(grid8(hinted(tsdf.hint_live, tsdf.cap), 8192)), dim3(256), 0, s, tsdf, mc, cam, T_C_L,
+                       flags, cell_key);
 }
 
 void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws,
@@ -659,10 +664,16 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s) {
   const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
-  if (mc.spec_flags & 2)  // mmf_params.appearance_blend_division
-    hipLaunchKernelGGL(k_color_integrate<true>, grid, dim3(256), 0, s, make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
+  const bool div = (mc.spec_flags & 2) != 0, fma = (mc.spec_flags & kSpecFma) != 0;  // mmf_params.appearance_blend_division, .fma_contraction
+  const AppArgs A = make_app_args(L, cam, T_C_L, rgb, mask, sc);
+  if (div && fma)
+    hipLaunchKernelGGL((k_color_integrate<true, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  else if (div)
+    hipLaunchKernelGGL((k_color_integrate<true, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  else if (fma)
+    hipLaunchKernelGGL((k_color_integrate<false, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
   else
-    hipLaunchKernelGGL(k_color_integrate<false>, grid, dim3(256), 0, s, make_app_args(L, cam, T_C_L, rgb, mask, sc), mc, synth, Ws, Hs);
+    hipLaunchKernelGGL((k_color_integrate<false, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
@@ -687,15 +698,23 @@ AppArgs make_flat_args(const LayerDev& L, const Cam& cam, const __half* feat, co
   return make_app_args(L, cam, Rigid{}, feat, nullptr, Scratch{}, stats, lowres, &fl);
 }
 
+template <bool LOW>
+static void launch_flat_kernel(dim3 grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const AppArgs& Af, const MapConsts& mc, int lpv) {
+  if (mc.spec_flags & kSpecFma)  // mmf_params.fma_contraction
+    hipExtLaunchKernelGGL((k_feature_flat<LOW, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+  else
+    hipExtLaunchKernelGGL((k_feature_flat<LOW, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+}
+
 // the stand-alone row update from a saved argument block (the flush of a deferred one)
 void launch_feature_flat_args(const AppArgs& Af, const MapConsts& mc, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (!Af.flat.rec) return;
   const int lpv = flat_lanes_per_voxel(mc);
   const dim3 grid((unsigned)flat_grid(Af.flat, lpv));
   if (Af.low.data)
-    hipExtLaunchKernelGGL(k_feature_flat<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+    launch_flat_kernel<true>(grid, s, ev_start, ev_stop, Af, mc, lpv);
   else
-    hipExtLaunchKernelGGL(k_feature_flat<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+    launch_flat_kernel<false>(grid, s, ev_start, ev_stop, Af, mc, lpv);
 }
 
 // sphere trace | colour allocation | feature allocation of this frame | row update of the previous one
@@ -724,9 +743,9 @@ void launch_feature_flat(const LayerDev& L, const MapConsts& mc, const Cam& cam,
   // with events: the extension launch stamps them with the dispatch's own begin / end times (what rocprofv3 reports as
   // the kernel duration), no marker packets around the kernel
   if (low)
-    hipExtLaunchKernelGGL(k_feature_flat<true>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+    launch_flat_kernel<true>(grid, s, ev_start, ev_stop, Af, mc, lpv);
   else
-    hipExtLaunchKernelGGL(k_feature_flat<false>, grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+    launch_flat_kernel<false>(grid, s, ev_start, ev_stop, Af, mc, lpv);
 }
 
 void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const __half* feat,
@@ -735,14 +754,20 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
   const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
   const bool div = (mc.spec_flags & 2) != 0;  // mmf_params.appearance_blend_division: rows are updated inside the gating workgroup
   const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low, div ? nullptr : flat);
-  if (low && div)
-    hipLaunchKernelGGL((k_feature_integrate<true, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  else if (low)
-    hipLaunchKernelGGL((k_feature_integrate<true, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  else if (div)
-    hipLaunchKernelGGL((k_feature_integrate<false, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  else
-    hipLaunchKernelGGL((k_feature_integrate<false, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+  const bool fma = (mc.spec_flags & kSpecFma) != 0;  // mmf_params.fma_contraction
+#define MMF_FI(LOWV, DIVV, FMAV) hipLaunchKernelGGL((k_feature_integrate<LOWV, DIVV, FMAV>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs)
+  if (fma) {
+    if (low && div) MMF_FI(true, true, true);
+    else if (low) MMF_FI(true, false, true);
+    else if (div) MMF_FI(false, true, true);
+    else MMF_FI(false, false, true);
+  } else {
+    if (low && div) MMF_FI(true, true, false);
+    else if (low) MMF_FI(true, false, false);
+    else if (div) MMF_FI(false, true, false);
+    else MMF_FI(false, false, false);
+  }
+#undef MMF_FI
 }
 
 AppTail make_app_tail(const LayerDev& Lc, const Cam& ccam, const uint8_t* rgb, const uint8_t* cmask, const Scratch& csc, const LayerDev& Lf,
@@ -786,8 +811,12 @@ AppTail app_tail_of(const AppFrameArgs& F, int max_cand) {
 int app_tail_grid(const AppTail& T) { return grid8(hinted(T.Ac.sc.hint_cand, T.max_cand), 8192); }
 
 void launch_app_tail(const AppTail& T, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  hipExtLaunchKernelGGL((k_app_frame<false, true>), dim3(app_tail_grid(T)), dim3(256), 0, s, ev_start, ev_stop, 0, T.Ac, T.Af, T.mc, T.synth,
-                        T.Ws, T.Hs);
+  if (T.mc.spec_flags & kSpecFma)
+    hipExtLaunchKernelGGL((k_app_frame<false, true, true>), dim3(app_tail_grid(T)), dim3(256), 0, s, ev_start, ev_stop, 0, T.Ac, T.Af, T.mc,
+                          T.synth, T.Ws, T.Hs);
+  else
+    hipExtLaunchKernelGGL((k_app_frame<false, true>), dim3(app_tail_grid(T)), dim3(256), 0, s, ev_start, ev_stop, 0, T.Ac, T.Af, T.mc, T.synth,
+                          T.Ws, T.Hs);
 }
 
 // colour + feature update of one frame (gating launch, then the balanced feature pass when a survivor list is given)
@@ -801,20 +830,31 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
   // same_candidates: both allocation jobs compacted the same flag array, so candidate i is the same block in both lists
   const bool same_cam = same_candidates && ccam.W == fcam.W && ccam.H == fcam.H && ccam.fx == fcam.fx && ccam.fy == fcam.fy &&
                         ccam.cx == fcam.cx && ccam.cy == fcam.cy;
+  const bool fma = (mc.spec_flags & kSpecFma) != 0;
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
-    if (flat && flat->rec)
-      hipExtLaunchKernelGGL((k_app_frame<false, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
-    else if (low)
-      hipExtLaunchKernelGGL((k_app_frame<true, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
-    else
-      hipExtLaunchKernelGGL((k_app_frame<false, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs);
+#define MMF_AF(LOWV, PUBV, FMAV) hipExtLaunchKernelGGL((k_app_frame<LOWV, PUBV, FMAV>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs)
+    if (fma) {  // mmf_params.fma_contraction
+      if (flat && flat->rec) MMF_AF(false, true, true);
+      else if (low) MMF_AF(true, false, true);
+      else MMF_AF(false, false, true);
+    } else {
+      if (flat && flat->rec) MMF_AF(false, true, false);
+      else if (low) MMF_AF(true, false, false);
+      else MMF_AF(false, false, false);
+    }
+#undef MMF_AF
   } else {
     const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
-    if (low)
-      hipExtLaunchKernelGGL(k_app_integrate2<true>, dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc);
-    else
-      hipExtLaunchKernelGGL(k_app_integrate2<false>, dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc);
+#define MMF_AI(LOWV, FMAV) hipExtLaunchKernelGGL((k_app_integrate2<LOWV, FMAV>), dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc)
+    if (fma) {
+      if (low) MMF_AI(true, true);
+      else MMF_AI(false, true);
+    } else {
+      if (low) MMF_AI(true, false);
+      else MMF_AI(false, false);
+    }
+#undef MMF_AI
   }
 }
 

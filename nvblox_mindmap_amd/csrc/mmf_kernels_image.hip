@@ -317,7 +317,8 @@ __device__ __forceinline__ Up8 up_load8(const float* __restrict__ low, int w, in
   return r;
 }
 
-template <bool VEC>
+// FMA: the spec switch mmf_params.fma_contraction applied to this op (mmf_upsample_features_spec; see mmf_device.h)
+template <bool VEC, bool FMA>
 __global__ __launch_bounds__(256) void k_upsample_features(const float* __restrict__ low, int h, int w, int Cin,
                                                           __half* __restrict__ out, int Hf, int Wf, int Cpad, float sh,
                                                           float sw) {
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void k_upsample_features(const float* __restri
     for (int xf = xbeg; xf < xend; ++xf) *reinterpret_cast<half8*>(orow + (size_t)xf * Cpad) = z;
     return;
   }
-  float sy = sh * ((float)yf + 0.5f) - 0.5f;
+  float sy = madd<FMA>(sh, (float)yf + 0.5f, -0.5f);
   sy = sy < 0.0f ? 0.0f : sy;
   const int y0 = (int)sy < h - 1 ? (int)sy : h - 1;
   const int y1 = y0 < h - 1 ? y0 + 1 : y0;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void k_upsample_features(const float* __restri
   int cx0 = -1, cx1 = -1;
   Up8 a00, a01, a10, a11;
   for (int xf = xbeg; xf < xend; ++xf) {
-    float sx = sw * ((float)xf + 0.5f) - 0.5f;
+    float sx = madd<FMA>(sw, (float)xf + 0.5f, -0.5f);
     sx = sx < 0.0f ? 0.0f : sx;
     const int x0 = (int)sx < w - 1 ? (int)sx : w - 1;
     const int x1 = x0 < w - 1 ? x0 + 1 : x0;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void k_upsample_features(const float* __restri
     half8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float val = ly0 * (lx0 * a00.v[k] + lx1 * a01.v[k]) + ly1 * (lx0 * a10.v[k] + lx1 * a11.v[k]);
+      const float val = madd2<FMA>(ly0, madd2<FMA>(lx0, a00.v[k], lx1, a01.v[k]), ly1, madd2<FMA>(lx0, a10.v[k], lx1, a11.v[k]));
       o[k] = (_Float16)val;
     }
     *reinterpret_cast<half8*>(orow + (size_t)xf * Cpad) = o;
@@ -460,15 +461,20 @@ void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int
   hipLaunchKernelGGL(k_depth_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, input_mask, depth, n, min_d, out);
 }
 
-void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s) {
+void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s, bool fma) {
   const size_t total = (size_t)Hf * ((Wf + kUpRun - 1) / kUpRun) * (Cpad / 8);
   if (!total) return;
   const float sh = (float)h / (float)Hf, sw = (float)w / (float)Wf;
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (Cin % 8 == 0 && ((uintptr_t)lowres & 15) == 0)
-    hipLaunchKernelGGL(k_upsample_features<true>, grid, dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf, Cpad, sh, sw);
+  const bool vec = Cin % 8 == 0 && ((uintptr_t)lowres & 15) == 0;
+  if (vec && fma)
+    hipLaunchKernelGGL((k_upsample_features<true, true>), grid, dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf, Cpad, sh, sw);
+  else if (vec)
+    hipLaunchKernelGGL((k_upsample_features<true, false>), grid, dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf, Cpad, sh, sw);
+  else if (fma)
+    hipLaunchKernelGGL((k_upsample_features<false, true>), grid, dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf, Cpad, sh, sw);
   else
-    hipLaunchKernelGGL(k_upsample_features<false>, grid, dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf, Cpad, sh, sw);
+    hipLaunchKernelGGL((k_upsample_features<false, false>), grid, dim3(256), 0, s, lowres, h, w, Cin, out, Hf, Wf, Cpad, sh, sw);
 }
 
 }  // namespace mmf

@@ -510,6 +510,7 @@ typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 8-by
 // row-pair loads; the nearest tap (pixel floor(u), floor(v)) is one of the four whenever the footprint is inside
 // the image (u - 0.5 is exact in float32, so floor(u) = x0 + (wx >= 0.5)), which turns 5 scattered depth reads
 // (+5 mask reads) per voxel into 2.
+template <bool FMA = false>
 __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
                                     float min_d, const Cam& cam, float u, float v, float& out) {
   int x0, y0;
@@ -537,7 +538,7 @@ __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict
           ok = false;
       }
       if (ok) {
-        out = bilin(r0.x, r0.y, r1.x, r1.y, wx, wy);
+        out = bilin<FMA>(r0.x, r0.y, r1.x, r1.y, wx, wy);
         return true;
       }
     }
@@ -561,24 +562,24 @@ __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict
 //   in_view <- the voxel centre projects into the image, not beyond the maximum integration distance (evaluated when `want_view`);
 //   if `cand` (the block is integrated this frame) and in view and the depth sample is valid and sdf >= -trunc and w > 0:
 //     D <- clamp((sdf w + D W) / (w + W), +-trunc),  W <- min(W + w, max_weight);  returns true iff D / W changed.
-template <bool MASKED>
+template <bool MASKED, bool FMA = false>
 __device__ inline bool tsdf_voxel_update(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
                                          const uint8_t* __restrict__ mask, float min_d, int bx, int by, int bz, int lin, bool cand,
                                          bool want_view, float& D, float& W, bool& in_view) {
   float c[3], p[3], u, v;
   in_view = false;
   if (!want_view) return false;
-  voxel_centre(mc, bx, by, bz, lin, c);
-  xform(T_C_L, c, p);
-  in_view = project(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+  voxel_centre<FMA>(mc, bx, by, bz, lin, c);
+  xform<FMA>(T_C_L, c, p);
+  in_view = project<FMA>(cam, p, u, v) && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
   if (!(cand && in_view)) return false;
   float d;
-  if (!sample_depth(mc, depth, MASKED ? mask : nullptr, min_d, cam, u, v, d)) return false;
+  if (!sample_depth<FMA>(mc, depth, MASKED ? mask : nullptr, min_d, cam, u, v, d)) return false;
   const float sdf = d - p[2];
   if (sdf < -mc.trunc) return false;
   const float wm = tsdf_measurement_weight(mc, d, sdf);
   if (!(wm > 0.0f)) return false;
-  float Dn = (sdf * wm + D * W) / (wm + W);
+  float Dn = madd2<FMA>(sdf, wm, D, W) / (wm + W);
   Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
   D = Dn;
   W = fminf(W + wm, mc.max_weight);
@@ -598,7 +599,7 @@ struct TsdfBlockAcc {
 // eager decays would have been (1 for the pending decay of a bounded map, cur_epoch - epoch[slot] in lazy mode, 0: none).
 // `may_write` false: a read-only visit (lazy mode, a block this frame does not integrate: only its appearance flag is wanted).
 // LAGLOOP false: lag is 0 or 1 (the hot bounded kernels: one predicated multiplication, no loop).
-template <int VPT, bool MASKED, bool LAGLOOP = false>
+template <int VPT, bool MASKED, bool LAGLOOP = false, bool FMA = false>
 __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
                                         const uint8_t* __restrict__ mask, float min_d, float decay_f, int lag, bool may_write, int bx, int by,
                                         int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc) {
@@ -630,7 +631,7 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
     float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
     // the projection is needed by the update (cand) and by the appearance flag of a near-surface voxel only
     bool in_view;
-    upd |= tsdf_voxel_update<MASKED>(mc, cam, T_C_L, depth, mask, min_d, bx, by, bz, lin0 + r, cand, cand || (W > 0.0f && fabsf(D) < mc.trunc), D,
+    upd |= tsdf_voxel_update<MASKED, FMA>(mc, cam, T_C_L, depth, mask, min_d, bx, by, bz, lin0 + r, cand, cand || (W > 0.0f && fabsf(D) < mc.trunc), D,
                                      W, in_view);
     if (hi) {
       a.z = D;
@@ -652,6 +653,7 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
   }
 }
 
+template <bool FMA>
 __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        const float* __restrict__ depth,
                                                        const uint8_t* __restrict__ mask, float min_d, Scratch sc) {
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
     float2* vox = reinterpret_cast<float2*>(L.pool) + (size_t)slot * kVPB + lin;
     float2 dw = is_new ? make_float2(0.0f, 0.0f) : *vox;
     bool in_view;
-    const bool upd = tsdf_voxel_update<true>(mc, cam, T_C_L, depth, mask, min_d, bx, by, bz, lin, true, true, dw.x, dw.y, in_view);
+    const bool upd = tsdf_voxel_update<true, FMA>(mc, cam, T_C_L, depth, mask, min_d, bx, by, bz, lin, true, true, dw.x, dw.y, in_view);
     if (upd || is_new) *vox = dw;
     // block summary for the sphere tracer's empty-space skipping
     const int all_free = __syncthreads_and((dw.y > 1e-4f && dw.x == mc.trunc) ? 1 : 0);
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // the blocks this frame integrates plus the near-surface blocks whose appearance flag needs their voxels -- instead of every live
 // block; a block's missing decays (cur_epoch - epoch[slot]) are applied before it is integrated, a block that is only looked at
 // is not written.  Not LAZY on a layer with lazy summaries (L.epoch != nullptr): the full pass that (re)establishes them.
-template <int VPT, bool MASKED, bool LAZY>
+template <int VPT, bool MASKED, bool LAZY, bool FMA>
 __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                         const float* __restrict__ depth, const uint8_t* __restrict__ mask_arg,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
     const float f = LAZY ? L.lag_f : decay_f;
     const bool writes = !LAZY || cand;
     TsdfBlockAcc acc;
-    tsdf_voxel_group<VPT, MASKED, LAZY>(mc, cam, T_C_L, depth, mask, min_d, f, lag, writes, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
+    tsdf_voxel_group<VPT, MASKED, LAZY, FMA>(mc, cam, T_C_L, depth, mask, min_d, f, lag, writes, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
     const int hit = acc.hit, freev = acc.freev;
     float wmx = acc.wmx, wmn = acc.wmn;
     if (writes && (cand || lag > 0)) {  // workgroup-uniform: the block's voxels changed -> its empty-space summary may have
@@ -1585,8 +1587,12 @@ static inline int grid_for(int upper, int cap) {
 
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s) {
-  hipLaunchKernelGGL(k_tsdf_integrate, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
-                     mask, min_d, sc);
+  if (mc.spec_flags & kSpecFma)
+    hipLaunchKernelGGL(k_tsdf_integrate<true>, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
+                       mask, min_d, sc);
+  else
+    hipLaunchKernelGGL(k_tsdf_integrate<false>, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
+                       mask, min_d, sc);
 }
 
 // ---- import of a saved layer (Mapper.load_from_file): block i of the file takes pool slot i, live position i -----------
@@ -1658,15 +1664,23 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
   if (n) hipLaunchKernelGGL(k_invert_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 
-void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
-                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
+template <bool FMA>
+static void launch_tsdf_pass_t(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
+                               const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
   const dim3 grid(grid_for(hinted(L.hint_live, L.cap), 8192));
   if (mask)
-    hipLaunchKernelGGL((k_tsdf_pass<4, true, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
+    hipLaunchKernelGGL((k_tsdf_pass<4, true, false, FMA>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
                        (const int*)nullptr, (const int*)nullptr);
   else
-    hipLaunchKernelGGL((k_tsdf_pass<4, false, false>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
+    hipLaunchKernelGGL((k_tsdf_pass<4, false, false, FMA>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
                        (const int*)nullptr, (const int*)nullptr);
+}
+void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
+                      const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
+  if (mc.spec_flags & kSpecFma)
+    launch_tsdf_pass_t<true>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s);
+  else
+    launch_tsdf_pass_t<false>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s);
 }
 
 // the lazy form (L.epoch / L.cur_epoch / L.lag_f set): classify the live list, then pass over the work list only
@@ -1677,8 +1691,12 @@ void launch_tsdf_pass_lazy(const LayerDev& L, const MapConsts& mc, const Cam& ca
   int* cnt = work + (parity & 1);
   int* nxt = work + ((parity & 1) ^ 1);
   hipLaunchKernelGGL(k_tsdf_classify, dim3((unsigned)((live + 1023) / 1024)), dim3(1024), 0, s, L, stamp, flags, cnt, nxt, work + 2);
-  hipLaunchKernelGGL((k_tsdf_pass<4, false, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr, 0.0f,
-                     stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
+  if (mc.spec_flags & kSpecFma)
+    hipLaunchKernelGGL((k_tsdf_pass<4, false, true, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
+                       0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
+  else
+    hipLaunchKernelGGL((k_tsdf_pass<4, false, true, false>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
+                       0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
 }
 
 void launch_lazy_catchup(const LayerDev& L, hipStream_t s) {

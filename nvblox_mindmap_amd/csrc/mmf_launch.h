@@ -330,7 +330,8 @@ bool make_mask_job(const uint8_t* input_mask, const float* depth, int H, int W, 
                    int border_percent, int Hf, int Wf, uint8_t* depth_mask_out, uint8_t* feature_mask_out, uint8_t* tmp,
                    MaskJob& J);
 void launch_depth_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, uint8_t* out, hipStream_t s);
-void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s);
+void launch_upsample_features(const float* lowres, int h, int w, int Cin, __half* out, int Hf, int Wf, int Cpad, hipStream_t s,
+                              bool fma = false);
 
 }  // namespace mmf
 

@@ -5,7 +5,12 @@ Plain attribute bags with the nvblox field names and nvblox defaults (recalled f
 DESIGN.md section 3 for the list and their confidence).  Unknown attribute names raise, like the
 pybind classes upstream do.
 """
+import os
+
 from .. import _lib
+
+# default of the spec switch fma_contraction for every mapper of the process (benchmark legs / whole test suites under the switch)
+FMA_CONTRACTION_DEFAULT = os.environ.get("MMF_FMA_CONTRACTION", "0") == "1"
 
 
 class _Bag:
@@ -42,6 +47,10 @@ class ProjectiveIntegratorParams(_Bag):
         "projective_appearance_integrator_sphere_tracing_surface_epsilon_vox": 0.1,
         # spec switch (not an upstream field): (A W + a w) / (W + w) per channel (True) or one reciprocal per voxel (False)
         "projective_appearance_integrator_blend_division": False,
+        # spec switch (not an upstream field): contract a*b + c into fused multiply-adds at the projection, the bilinear samples and
+        # the two blends' numerators, as nvcc's default -fmad=true would (include/mmfusion.h: mmf_params.fma_contraction)
+        # (MMF_FMA_CONTRACTION=1 in the environment makes it the default of every mapper of the process: benchmarks / whole test suites)
+        "projective_integrator_fma_contraction": FMA_CONTRACTION_DEFAULT,
     }
 
 
@@ -190,4 +199,5 @@ class MapperParams:
         p.decay_appearance_layers = 1 if de.decay_appearance_layers else 0
         p.raycast_walk_from_camera = 1 if vc.raycast_walk_from_camera else 0
         p.appearance_blend_division = 1 if pi.projective_appearance_integrator_blend_division else 0
+        p.fma_contraction = 1 if pi.projective_integrator_fma_contraction else 0
         return p

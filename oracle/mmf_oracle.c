@@ -93,6 +93,14 @@ typedef struct {
                                           (the same block sets by construction: tests/test_cpu_raycast_walk.py)             */
   int appearance_blend_division;       /* 0: A' = (A W + a w) * (1 / (W + w)), one reciprocal per voxel; 1: (A W + a w) / (W + w)
                                           per channel (<= 1 ulp of the stored type apart)                                   */
+  /* This file is compiled with -ffp-contract=off: a*b + c is two rounded operations.  nvcc contracts by default (-fmad=true), so
+   * CUDA nvblox's voxels almost certainly hold fused multiply-adds; WHICH ones cannot be known here (its source is absent).
+   * 1: the contraction a LLVM-family compiler makes of the expressions of this spec as written,
+   *      a*b + c -> fma(a, b, c);   a*x + b*y -> fma(a, x, b*y);   (X + e*f) + t -> fma(e, f, X) + t
+   * at the projection of a voxel centre (voxel_centre, xform, project), every bilinear sample (depth, synthetic depth in the
+   * appearance gate, colour / feature taps), the TSDF update's numerator and the appearance blend's numerator -- MADD / MADD2
+   * below.  The raycast walk, the sphere tracer and the mesh stay as they are (they decide block sets and gates, not values). */
+  int fma_contraction;
 } orc_params;
 
 void orc_default_params(orc_params* p) {
@@ -115,6 +123,7 @@ void orc_default_params(orc_params* p) {
   p->decay_appearance_layers = 0;
   p->raycast_walk_from_camera = 0;
   p->appearance_blend_division = 0;
+  p->fma_contraction = 0;
   p->st_subsampling = 4;
   p->st_max_steps = 100;
   p->st_max_ray_length_m = 15.0f;
@@ -211,6 +220,10 @@ typedef struct {
 
 static inline int ifloor(float x) { return (int)floorf(x); }
 
+/* the two contraction forms of orc_params.fma_contraction (fmaf: one rounding; the build flags forbid any other contraction) */
+static inline float MADD(int fma, float a, float b, float c) { return fma ? fmaf(a, b, c) : a * b + c; }
+static inline float MADD2(int fma, float a, float x, float b, float y) { return fma ? fmaf(a, x, b * y) : a * x + b * y; }
+
 static void rigid_from_T(const float* T, rigid_t* o) {
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) o->R[i * 3 + j] = T[i * 4 + j];
@@ -229,6 +242,11 @@ static inline void xform(const rigid_t* T, const float* p, float* q) {
   for (int i = 0; i < 3; ++i)
     q[i] = ((T->R[i * 3 + 0] * p[0] + T->R[i * 3 + 1] * p[1]) + T->R[i * 3 + 2] * p[2]) + T->t[i];
 }
+/* the spec sites' form (voxel centre -> camera): (R0 p0 + R1 p1) + R2 p2, contracted when asked, then + t */
+static inline void xform_c(const rigid_t* T, const float* p, float* q, int fma) {
+  for (int i = 0; i < 3; ++i)
+    q[i] = MADD(fma, T->R[i * 3 + 2], p[2], MADD2(fma, T->R[i * 3 + 0], p[0], T->R[i * 3 + 1], p[1])) + T->t[i];
+}
 
 static inline void rotate(const rigid_t* T, const float* p, float* q) {
   for (int i = 0; i < 3; ++i)
@@ -245,11 +263,11 @@ static void cam_from_K(const float* K, int W, int H, cam_t* c) {
 }
 
 /* returns 1 if p_C projects into the image; u,v corner-referenced image-plane coords */
-static inline int project(const cam_t* c, const float* p, float* u, float* v) {
+static inline int project_c(const cam_t* c, const float* p, float* u, float* v, int fma) {
   if (p[2] <= 1e-6f) return 0;
   float iz = 1.0f / p[2];
-  float uu = c->fx * (p[0] * iz) + c->cx;
-  float vv = c->fy * (p[1] * iz) + c->cy;
+  float uu = MADD(fma, c->fx, p[0] * iz, c->cx);
+  float vv = MADD(fma, c->fy, p[1] * iz, c->cy);
   if (uu < 0.0f || vv < 0.0f || uu > (float)c->W || vv > (float)c->H) return 0;
   *u = uu;
   *v = vv;
@@ -269,10 +287,10 @@ static inline int bilin_setup(float u, float v, int W, int H, int* x0, int* y0, 
   return 1;
 }
 
-static inline float bilin(float a00, float a10, float a01, float a11, float wx, float wy) {
-  float top = (1.0f - wx) * a00 + wx * a10;
-  float bot = (1.0f - wx) * a01 + wx * a11;
-  return (1.0f - wy) * top + wy * bot;
+static inline float bilin_c(float a00, float a10, float a01, float a11, float wx, float wy, int fma) {
+  float top = MADD2(fma, 1.0f - wx, a00, wx, a10);
+  float bot = MADD2(fma, 1.0f - wx, a01, wx, a11);
+  return MADD2(fma, 1.0f - wy, top, wy, bot);
 }
 
 /* ------------------------------------------------------------------------------- */
@@ -452,10 +470,16 @@ void orc_clear(orc_mapper* m) {
   m->mesh_n = 0;
 }
 
-static inline void voxel_centre(const orc_mapper* m, int bx, int by, int bz, int vx, int vy, int vz, float* c) {
-  c[0] = (float)bx * m->bs + ((float)vx + 0.5f) * m->v;
-  c[1] = (float)by * m->bs + ((float)vy + 0.5f) * m->v;
-  c[2] = (float)bz * m->bs + ((float)vz + 0.5f) * m->v;
+/* voxel centre c = b * block_size + (v + 0.5) * voxel_size -> camera frame -> image plane, under orc_params.fma_contraction */
+static inline int project_voxel(const orc_mapper* m, const cam_t* cam, const rigid_t* T_C_L, int bx, int by, int bz, int lin, float* p,
+                                float* u, float* v) {
+  const int fma = m->P.fma_contraction;
+  float c[3];
+  c[0] = MADD2(fma, (float)bx, m->bs, (float)(lin >> 6) + 0.5f, m->v);
+  c[1] = MADD2(fma, (float)by, m->bs, (float)((lin >> 3) & 7) + 0.5f, m->v);
+  c[2] = MADD2(fma, (float)bz, m->bs, (float)(lin & 7) + 0.5f, m->v);
+  xform_c(T_C_L, c, p, fma);
+  return project_c(cam, p, u, v, fma);
 }
 
 /* workspace test on a block index (inclusive index range of the bounds' own blocks) */
@@ -713,7 +737,7 @@ static inline int sample_depth(const orc_mapper* m, const float* depth, const ui
         if (fabsf(a00 - dn) > md || fabsf(a10 - dn) > md || fabsf(a01 - dn) > md || fabsf(a11 - dn) > md) ok = 0;
       }
       if (ok) {
-        *out = bilin(a00, a10, a01, a11, wx, wy);
+        *out = bilin_c(a00, a10, a01, a11, wx, wy, m->P.fma_contraction);
         return 1;
       }
     }
@@ -765,11 +789,8 @@ static void tsdf_integrate(orc_mapper* m, const float* depth, const uint8_t* mas
     block_t* B = &m->tsdf.blocks[pos[i]];
     tsdf_block* tb = (tsdf_block*)B->data;
     for (int lin = 0; lin < VPB; ++lin) {
-      int vx = lin >> 6, vy = (lin >> 3) & 7, vz = lin & 7;
-      float c[3], p[3], u, v;
-      voxel_centre(m, B->bx, B->by, B->bz, vx, vy, vz, c);
-      xform(T_C_L, c, p);
-      if (!project(cam, p, &u, &v)) continue;
+      float p[3], u, v;
+      if (!project_voxel(m, cam, T_C_L, B->bx, B->by, B->bz, lin, p, &u, &v)) continue;
       if (P->max_integration_distance_m > 0.0f && p[2] > P->max_integration_distance_m) continue;
       float d;
       if (!sample_depth(m, depth, mask, cam, u, v, &d)) continue;
@@ -778,7 +799,7 @@ static void tsdf_integrate(orc_mapper* m, const float* depth, const uint8_t* mas
       float wm = tsdf_weight(m, d, sdf);
       if (!(wm > 0.0f)) continue;
       float D = tb->d[lin], W = tb->w[lin];
-      float Dn = (sdf * wm + D * W) / (wm + W);
+      float Dn = MADD2(P->fma_contraction, sdf, wm, D, W) / (wm + W);
       Dn = Dn > 0.0f ? fminf(m->trunc, Dn) : fmaxf(-m->trunc, Dn);
       tb->d[lin] = Dn;
       tb->w[lin] = fminf(W + wm, P->max_weight);
@@ -915,10 +936,8 @@ static int app_candidates(orc_mapper* m, const cam_t* cam, const rigid_t* T_C_L,
     int hit = 0;
     for (int lin = 0; lin < VPB && !hit; ++lin) {
       if (!(tb->w[lin] > 0.0f) || !(fabsf(tb->d[lin]) < m->trunc)) continue;
-      float c[3], p[3], u, v;
-      voxel_centre(m, B->bx, B->by, B->bz, lin >> 6, (lin >> 3) & 7, lin & 7, c);
-      xform(T_C_L, c, p);
-      if (!project(cam, p, &u, &v)) continue;
+      float p[3], u, v;
+      if (!project_voxel(m, cam, T_C_L, B->bx, B->by, B->bz, lin, p, &u, &v)) continue;
       if (P->max_integration_distance_m > 0.0f && p[2] > P->max_integration_distance_m) continue;
       hit = 1;
     }
@@ -939,10 +958,8 @@ static int app_candidates(orc_mapper* m, const cam_t* cam, const rigid_t* T_C_L,
 static inline int app_gate(const orc_mapper* m, const cam_t* cam, const rigid_t* T_C_L, const uint8_t* mask,
                            const block_t* B, int lin, int* x0, int* y0, float* wx, float* wy) {
   const orc_params* P = &m->P;
-  float c[3], p[3], u, v;
-  voxel_centre(m, B->bx, B->by, B->bz, lin >> 6, (lin >> 3) & 7, lin & 7, c);
-  xform(T_C_L, c, p);
-  if (!project(cam, p, &u, &v)) return 0;
+  float p[3], u, v;
+  if (!project_voxel(m, cam, T_C_L, B->bx, B->by, B->bz, lin, p, &u, &v)) return 0;
   if (P->max_integration_distance_m > 0.0f && p[2] > P->max_integration_distance_m) return 0;
   float sf = (float)(P->st_subsampling < 1 ? 1 : P->st_subsampling);
   int sx, sy;
@@ -952,7 +969,7 @@ static inline int app_gate(const orc_mapper* m, const cam_t* cam, const rigid_t*
   float s00 = S[(size_t)sy * m->synth_W + sx], s10 = S[(size_t)sy * m->synth_W + sx + 1];
   float s01 = S[(size_t)(sy + 1) * m->synth_W + sx], s11 = S[(size_t)(sy + 1) * m->synth_W + sx + 1];
   if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) return 0;
-  float s = bilin(s00, s10, s01, s11, swx, swy);
+  float s = bilin_c(s00, s10, s01, s11, swx, swy, P->fma_contraction);
   if (fabsf(s - p[2]) > m->trunc) return 0;
   if (!bilin_setup(u, v, cam->W, cam->H, x0, y0, wx, wy)) return 0;
   if (mask) {
@@ -1001,8 +1018,8 @@ int orc_add_feature_frame(orc_mapper* m, const uint16_t* feat, const uint8_t* ma
       float inv = 1.0f / (Wv + wm);
       uint16_t* Av = A + (size_t)lin * C;
       for (int k = 0; k < C; ++k) {
-        float a = bilin(h2f(t00[k]), h2f(t10[k]), h2f(t01[k]), h2f(t11[k]), wx, wy);
-        float num = h2f(Av[k]) * Wv + a * wm;
+        float a = bilin_c(h2f(t00[k]), h2f(t10[k]), h2f(t01[k]), h2f(t11[k]), wx, wy, m->P.fma_contraction);
+        float num = MADD2(m->P.fma_contraction, h2f(Av[k]), Wv, a, wm);
         float An = m->P.appearance_blend_division ? num / (Wv + wm) : num * inv;
         Av[k] = f2h(An);
       }
@@ -1043,8 +1060,8 @@ int orc_add_color_frame(orc_mapper* m, const uint8_t* rgb, const uint8_t* mask, 
       float Wv = cb->w[lin];
       float inv = 1.0f / (Wv + wm);
       for (int k = 0; k < 3; ++k) {
-        float a = bilin((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy);
-        float num = (float)cb->rgb[lin * 3 + k] * Wv + a * wm;
+        float a = bilin_c((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy, m->P.fma_contraction);
+        float num = MADD2(m->P.fma_contraction, (float)cb->rgb[lin * 3 + k], Wv, a, wm);
         float An = m->P.appearance_blend_division ? num / (Wv + wm) : num * inv;
         cb->rgb[lin * 3 + k] = (uint8_t)floorf(An + 0.5f);
       }
@@ -1372,6 +1389,39 @@ void orc_query_tsdf(orc_mapper* m, const float* pts, int n, float* out) {
     const tsdf_block* tb = (const tsdf_block*)m->tsdf.blocks[p].data;
     out[2 * i] = tb->d[lin];
     out[2 * i + 1] = tb->w[lin];
+  }
+}
+
+/*
+ * Feature image from the backbone's low-res map (image_processing/feature_extraction.py:188-191,198-210 + the f16 cast of
+ * nvblox_mapping_helpers.py:256): bilinear, align_corners = False, [h,w,Cin] f32 channels-last -> [Hf,Wf,Cpad] f16 with zero pad
+ * channels; float32 arithmetic in the order of torch's upsample_bilinear2d
+ *   s = scale * (dst + 0.5) - 0.5 (clamped at 0);  i0 = min((int)s, n - 1);  i1 = min(i0 + 1, n - 1);  l1 = s - i0;  l0 = 1 - l1;
+ *   val = ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11)
+ * with the contraction of orc_params.fma_contraction when `fma` (what a CUDA build of that kernel computes).
+ */
+void orc_upsample_features(const float* low, int h, int w, int Cin, uint16_t* out, int Hf, int Wf, int Cpad, int fma) {
+  const float sh = (float)h / (float)Hf, sw = (float)w / (float)Wf;
+#pragma omp parallel for schedule(static)
+  for (int yf = 0; yf < Hf; ++yf) {
+    float sy = MADD(fma, sh, (float)yf + 0.5f, -0.5f);
+    sy = sy < 0.0f ? 0.0f : sy;
+    const int y0 = (int)sy < h - 1 ? (int)sy : h - 1;
+    const int y1 = y0 < h - 1 ? y0 + 1 : y0;
+    const float ly1 = sy - (float)y0, ly0 = 1.0f - ly1;
+    for (int xf = 0; xf < Wf; ++xf) {
+      float sx = MADD(fma, sw, (float)xf + 0.5f, -0.5f);
+      sx = sx < 0.0f ? 0.0f : sx;
+      const int x0 = (int)sx < w - 1 ? (int)sx : w - 1;
+      const int x1 = x0 < w - 1 ? x0 + 1 : x0;
+      const float lx1 = sx - (float)x0, lx0 = 1.0f - lx1;
+      const float *a00 = low + ((size_t)y0 * w + x0) * Cin, *a01 = low + ((size_t)y0 * w + x1) * Cin;
+      const float *a10 = low + ((size_t)y1 * w + x0) * Cin, *a11 = low + ((size_t)y1 * w + x1) * Cin;
+      uint16_t* o = out + ((size_t)yf * Wf + xf) * Cpad;
+      for (int k = 0; k < Cin; ++k)
+        o[k] = f2h(MADD2(fma, ly0, MADD2(fma, lx0, a00[k], lx1, a01[k]), ly1, MADD2(fma, lx0, a10[k], lx1, a11[k])));
+      for (int k = Cin; k < Cpad; ++k) o[k] = 0;
+    }
   }
 }
 

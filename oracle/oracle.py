@@ -43,6 +43,7 @@ class OrcParams(C.Structure):
         ("decay_appearance_layers", C.c_int),
         ("raycast_walk_from_camera", C.c_int),
         ("appearance_blend_division", C.c_int),
+        ("fma_contraction", C.c_int),
     ]
 
 
@@ -77,7 +78,7 @@ def lib():
             "orc_get_block_indices", "orc_get_tsdf_block", "orc_get_all_tsdf", "orc_get_feature_block",
             "orc_get_all_features", "orc_get_color_block", "orc_get_all_colors", "orc_last_view_blocks",
             "orc_last_counts", "orc_get_synthetic_depth", "orc_render_synthetic_depth", "orc_query_features",
-            "orc_query_tsdf",
+            "orc_query_tsdf", "orc_upsample_features",
         ]:
             getattr(L, name).argtypes = None
         _lib = L
@@ -102,6 +103,17 @@ def set_params(p: OrcParams, **kw) -> OrcParams:
                 raise AttributeError(k)
             setattr(p, k, v)
     return p
+
+
+def upsample_features(low_hwc: np.ndarray, hf: int, wf: int, cpad: int, fma_contraction: bool = False) -> np.ndarray:
+    """[h,w,Cin] f32 (channels last) -> [Hf,Wf,cpad] f16 bit patterns (uint16): the C restatement of the feature up-sample,
+    exact under either setting of ``fma_contraction`` (oracle/image_ops.upsample_features is the numpy one, uncontracted)."""
+    low = np.ascontiguousarray(low_hwc, dtype=np.float32)
+    h, w, cin = low.shape
+    out = np.empty((hf, wf, cpad), dtype=np.uint16)
+    lib().orc_upsample_features(_ptr(low), C.c_int(h), C.c_int(w), C.c_int(cin), _ptr(out), C.c_int(hf), C.c_int(wf), C.c_int(cpad),
+                                C.c_int(1 if fma_contraction else 0))
+    return out
 
 
 def _ptr(a: Optional[np.ndarray]):

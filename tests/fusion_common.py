@@ -1,8 +1,14 @@
 """Shared helpers of the parity tests: run the same synthetic stream through the HIP Mapper and the
 CPU oracle and compare.  (The oracle is only ever the checker here.)"""
+import os
+
 import numpy as np
 
 from nvblox_mindmap_amd import synthetic as S
+
+# MMF_FMA_CONTRACTION=1: every mapper of the process (nvblox_torch/mapper_params.py) and every oracle built here carry the spec
+# switch fma_contraction (mmf_params / orc_params) -- the parity, fuzz and soak suites then check the contracted arithmetic
+FMA = os.environ.get("MMF_FMA_CONTRACTION", "0") == "1"
 
 REF_PARAMS = dict(  # what get_nvblox_mapper sets for DRILL_IN_BOX (nvblox_mapping_helpers.py:40-70)
     voxel_size=0.01,
@@ -13,6 +19,7 @@ REF_PARAMS = dict(  # what get_nvblox_mapper sets for DRILL_IN_BOX (nvblox_mappi
     ws_max=S.DRILL_IN_BOX_AABB_MAX,
     tsdf_decay_factor=0.98,
     appearance_measurement_weight=1.0,
+    **({"fma_contraction": 1} if FMA else {}),
 )
 
 
@@ -55,6 +62,7 @@ def make_mapper(channels, **over):
         "raycast_to_truncation": (vc, "raycast_to_truncation_distance", bool),
         "raycast_walk_from_camera": (vc, "raycast_walk_from_camera", bool),
         "appearance_blend_division": (pi, "projective_appearance_integrator_blend_division", bool),
+        "fma_contraction": (pi, "projective_integrator_fma_contraction", bool),
         "mesh_min_weight": (me, "mesh_integrator_min_weight", float),
         "num_preallocated_blocks": (pool, "num_preallocated_blocks", int),
     }

@@ -62,7 +62,7 @@ def test_kit_round_trip_on_the_cpu_oracle(tmp_path):
 
 
 def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
-    """tests/pin_report.py on a file dumped from the oracle itself: "as specified" reproduces it, at least sixteen spec items are
+    """tests/pin_report.py on a file dumped from the oracle itself: "as specified" reproduces it, at least seventeen spec items are
     parameters (flipped with zero code edits), and the flips are not no-ops -- all but a few change the replay."""
     import pin_report
 
@@ -72,9 +72,9 @@ def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
     np.savez_compressed(path, **out)
     meta = json.loads(str(np.load(path, allow_pickle=False)["meta"]))
     items = [it for it in meta["spec_items"] if it.get("param") is not None]
-    assert len(items) >= 16, [it["item"] for it in items]
+    assert len(items) >= 17, [it["item"] for it in items]
     assert {"weighting_mode", "raycast_to_truncation", "decay_appearance_layers", "raycast_walk_from_camera",
-            "appearance_blend_division"} <= {it["param"] for it in items}
+            "appearance_blend_division", "fma_contraction"} <= {it["param"] for it in items}
     wm = next(it for it in items if it["param"] == "weighting_mode")
     assert sorted(wm["flips"] + [wm["ours"]]) == [0, 1, 2, 3, 4, 5], "upstream's six weighting functions"
     results = pin_report.main([str(path)])
@@ -93,6 +93,13 @@ def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
     assert NG.passes_north_star(by_name["raycast_walk_from_camera=1"]) and by_name["raycast_walk_from_camera=1"]["tsdf_blocks_missing"] == 0
     assert by_name["raycast_walk_from_camera=1"]["tsdf_max_abs_distance_diff"] == 0.0
     assert by_name["appearance_blend_division=1"]["feature_max_abs_diff"] <= 2e-3  # <= 1 f16 ulp of values of magnitude ~2
+    # the arithmetic mode (round 5): contracting the multiply-adds changes last bits -- same blocks, TSDF inside the north star's 1e-5,
+    # features within one f16 ulp -- and NOT bit-identical: a dump from a contracting build is told apart from a non-contracting one
+    # by this flip alone (before it existed no flip could have explained such a difference)
+    fma = by_name["fma_contraction=1"]
+    assert fma["tsdf_blocks_missing"] == fma["tsdf_blocks_extra"] == fma["feature_blocks_missing"] == fma["feature_blocks_extra"] == 0, fma
+    assert 0.0 < fma["tsdf_max_abs_distance_diff"] <= 1e-5 and 0.0 < fma["feature_max_abs_diff"] <= 2e-3, fma
+    assert NG.passes_reference_tolerances(fma), fma
 
 
 @pytest.mark.parametrize("path", NG.golden_files() or [None])

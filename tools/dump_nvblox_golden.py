@@ -136,6 +136,10 @@ SPEC_ITEMS = [
          note="<= 1 ulp of the stored type either way; with 1 frames take the stand-alone appearance kernels"),
     dict(item="raycast block walk starts where the ray enters the workspace bounds (1: at the camera)", param="raycast_walk_from_camera",
          ours=0, flips=[1], note="the same block sets by construction (tests/test_cpu_raycast_walk.py): a flip that changes anything is a bug"),
+    # the arithmetic mode: this spec never fuses a multiply with an add; nvcc does by default (-fmad=true)
+    dict(item="multiply-adds contracted into FMAs (projection, bilinear samples, TSDF / appearance blend numerators)", param="fma_contraction",
+         ours=0, flips=[1], note="a contraction-only difference shows up in (nearly) every voxel at the last bits: if flipping this one item "
+                                 "removes it, upstream's build contracts where this restatement assumes it does"),
     dict(item="feature storage rounding (RNE)", param=None, flips=None, note="code: __float2half_rn"),
     dict(item="feature-mesh vertex takes the feature of the voxel containing it", param=None, flips=None, note="code: k_mesh_emit"),
 ]
