@@ -242,7 +242,8 @@ int create_mapper_impl(const mmf_params& P, Mapper* m) {
   HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
   {
     const char* e = std::getenv("MMF_NO_ALLOC_TSDF");
-    m->allow_merged = !(e && e[0] == '1');
+    // (spec switch fma_contraction: the merged launch k_alloc_tsdf is built with the default arithmetic only)
+    m->allow_merged = !(e && e[0] == '1') && !P.fma_contraction;
   }
   HIP_TRY(hipMalloc(&m->pub, sizeof(u64) * pub_words(*m)));
   HIP_TRY(hipMemset(m->pub, 0, sizeof(u64) * pub_words(*m)));

@@ -3,6 +3,7 @@ launch -- the row update of its survivor list -- to the next fused frame, which 
 that takes the mapper runs it first.  Every observable state must be bit-identical to the undeferred sequence: at the end of a
 stream, in the middle of it, and whatever call comes between two frames."""
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -13,7 +14,9 @@ from nvblox_mindmap_amd.nvblox_torch.mapper import integrate_frames_batch
 from test_gpu_frame_batch import frame_args, same_maps, single
 from test_gpu_fusion_parity import compare_features, compare_tsdf
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1",
+                                 reason="asserts the deferred-row schedule, which mappers with fma_contraction do not take")]
 
 
 def pending(m, mapper_id=0):

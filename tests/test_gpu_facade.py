@@ -2,6 +2,7 @@
 mindmap/mapping/isaaclab_nvblox_mapper.py:35-258) on the GPU, including the end-to-end check of BASELINE configs[3] at the
 reference's real shape: loader sample -> facade (fused 512x512x768 frames) == CPU oracle, -> model inputs -> policy."""
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -220,6 +221,7 @@ def test_facade_hands_the_backbone_output_to_the_native_call(include_dynamic, mo
         assert all(torch.equal(x, y) for x, y in zip(ca, cb))
 
 
+@pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1", reason="asserts a route (merged launch / deferred rows) that mappers with fma_contraction do not take")
 @pytest.mark.parametrize("include_dynamic", [False, True])
 def test_facade_frame_pipelining_changes_nothing_but_the_schedule(include_dynamic):
     """``set_frame_pipelining``: the facade's default path (backbone output handed to the native call) with consecutive frames

@@ -714,6 +714,7 @@ def test_merged_launch_with_churn_matches_oracle(oracle_mod):
     _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 90, 10, 200, 100, 20, 300, 110, 30], 8)
 
 
+@pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1", reason="asserts a route (merged launch / deferred rows) that mappers with fma_contraction do not take")
 def test_hand_over_recovery_yields_the_oracle_map(oracle_mod, monkeypatch):
     """MMF_DEBUG_FORCE_ALLOC_TIMEOUT=1: every second waiter workgroup of k_alloc_tsdf "times out" at once and abandons its rounds;
     the workgroup that terminates last sweeps them.  Same churn sequence as above (hundreds of new blocks per frame): block
@@ -738,6 +739,7 @@ def test_hand_over_recovery_yields_the_oracle_map(oracle_mod, monkeypatch):
     assert normal.debug_alloc_recoveries(0) == 0  # ordinary operation never needs the sweeper
 
 
+@pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1", reason="asserts a route (merged launch / deferred rows) that mappers with fma_contraction do not take")
 def test_hand_over_failure_is_reported_once_and_cleared(monkeypatch):
     """MMF_DEBUG_FORCE_ALLOC_TIMEOUT=2: the sweeper gives up as well -> the map is incomplete.  The next call on the mapper
     fails with MMF_ERR_BAD_STATE (no integration on top of a broken map), the error is then cleared, clear() gives a usable
