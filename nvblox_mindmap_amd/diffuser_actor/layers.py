@@ -54,7 +54,8 @@ def rotary3d(xyz: torch.Tensor, dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def apply_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """Rotate channel pairs (x_{2k}, x_{2k+1}) by the pair's angle."""
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and FUSED_ROTARY_TRAINING and not (cos.requires_grad or sin.requires_grad):
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.numel() > 0 and FUSED_ROTARY_TRAINING and not torch.is_autocast_enabled()
+            and cos.dtype == torch.float32 and sin.dtype == torch.float32 and not (cos.requires_grad or sin.requires_grad)):
         # one kernel each way instead of seven forward + their autograd (same float operations, forward and backward)
         from .fused_ops import rotary_apply_train
 

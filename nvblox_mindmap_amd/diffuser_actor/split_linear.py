@@ -28,26 +28,55 @@ kMinRows = 2048  # (one 512 x 512 image = 1 024 tokens: 3.2 ms on the f32 GEMMs,
 _W3_CACHE = {}  # id(weight) -> (weak reference, versions of weight and bias, [N, 3 K + 64] fp16 or None when out of range)
 
 
+def _split_weight(linear):
+    """[N, 3 K + 64] fp16 split of the layer's weight and bias, or None when a value is out of fp16's range / the shape unsupported."""
+    src = linear.weight.detach().float()
+    bias = linear.bias.detach().float() if linear.bias is not None else torch.zeros(src.shape[0], device=src.device)
+    if not (float(src.abs().max()) < 6.0e4 and float(bias.abs().max()) < 6.0e4 and src.shape[1] % 8 == 0 and src.shape[1] >= kTail):
+        return None
+    hi = src.half()
+    lo = ((src - hi.float()) * 2048.0).half()
+    bh = bias.half()
+    bl = ((bias - bh.float()) * 2048.0).half()
+    tail = torch.zeros((src.shape[0], kTail), dtype=torch.float16, device=src.device)
+    tail[:, 0], tail[:, 1] = bh, bl
+    return torch.cat([hi, lo, hi, tail], dim=1).contiguous()
+
+
+def _versions(linear):
+    return (linear.weight._version, None if linear.bias is None else linear.bias._version)
+
+
 def _w3(linear):
     w = linear.weight
     key = id(w)
     hit = _W3_CACHE.get(key)
-    ver = (w._version, None if linear.bias is None else linear.bias._version)
+    ver = _versions(linear)
     if hit is None or hit[0]() is not w or hit[1] != ver or (hit[2] is not None and hit[2].device != w.device):
-        src = w.detach().float()
-        w3 = None
-        bias = linear.bias.detach().float() if linear.bias is not None else torch.zeros(src.shape[0], device=src.device)
-        if float(src.abs().max()) < 6.0e4 and float(bias.abs().max()) < 6.0e4 and src.shape[1] % 8 == 0 and src.shape[1] >= kTail:
-            hi = src.half()
-            lo = ((src - hi.float()) * 2048.0).half()
-            bh = bias.half()
-            bl = ((bias - bh.float()) * 2048.0).half()
-            tail = torch.zeros((src.shape[0], kTail), dtype=torch.float16, device=src.device)
-            tail[:, 0], tail[:, 1] = bh, bl
-            w3 = torch.cat([hi, lo, hi, tail], dim=1).contiguous()  # [N, 3 K + 64]
-        hit = (weakref.ref(w, lambda _r, k=key: _W3_CACHE.pop(k, None)), ver, w3)
+        hit = (weakref.ref(w, lambda _r, k=key: _W3_CACHE.pop(k, None)), ver, _split_weight(linear))
         _W3_CACHE[key] = hit
     return hit[2]
+
+
+def stale(linear) -> bool:
+    """The layer's weight / bias changed (in place: load_state_dict, copy_) since its split copy was made."""
+    hit = _W3_CACHE.get(id(linear.weight))
+    return hit is not None and hit[0]() is linear.weight and hit[1] != _versions(linear)
+
+
+def refresh_in_place(linear) -> bool:
+    """Recompute the split copy of a layer whose weights changed INTO THE SAME STORAGE: a captured HIP graph that multiplies by the
+    copy (training.GraphedTrainStep's backbone graph) holds its address.  Returns False when that is impossible (no copy yet, or the
+    new weights cannot be split): the caller must re-capture."""
+    hit = _W3_CACHE.get(id(linear.weight))
+    if hit is None or hit[0]() is not linear.weight or hit[2] is None:
+        return False
+    new = _split_weight(linear)
+    if new is None or new.shape != hit[2].shape or new.device != hit[2].device:
+        return False
+    hit[2].copy_(new)
+    _W3_CACHE[id(linear.weight)] = (hit[0], _versions(linear), hit[2])
+    return True
 
 
 def supported() -> bool:

@@ -19,7 +19,8 @@ MAX_HEAD_DIM = 16
 
 def usable(q: torch.Tensor, head_dim: int) -> bool:
     """CUDA float32 tensors under autograd, head size the kernels are built for (the caller checks dropout)."""
-    return ENABLED and q.is_cuda and q.dtype == torch.float32 and head_dim <= MAX_HEAD_DIM and torch.is_grad_enabled()
+    return (ENABLED and q.is_cuda and q.dtype == torch.float32 and head_dim <= MAX_HEAD_DIM and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and q.numel() > 0)  # (raw float32 pointers: not under autocast)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:

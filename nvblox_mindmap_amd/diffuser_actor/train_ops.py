@@ -11,10 +11,17 @@ from .. import _lib
 ENABLED = os.environ.get("MMF_TRAIN_LAYERNORM", "1") != "0"
 
 
-def usable(x: torch.Tensor, norm) -> bool:
+def _f32_only() -> bool:
+    """the kernels behind these Functions read and write float32 through raw pointers: under autocast an incoming gradient (or an
+    F.linear result) would be fp16 -- the composite ops take over there."""
+    return not torch.is_autocast_enabled()
+
+
+def usable(x: torch.Tensor, norm, b: Optional[torch.Tensor] = None) -> bool:
     D = x.shape[-1]
-    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and D <= 128 and D % 4 == 0
-            and tuple(norm.normalized_shape) == (D,) and norm.weight is not None and norm.bias is not None)
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and _f32_only() and x.numel() > 0 and D <= 128
+            and D % 4 == 0 and tuple(norm.normalized_shape) == (D,) and norm.weight is not None and norm.bias is not None
+            and (b is None or (b.shape == x.shape and b.dtype == torch.float32 and b.is_cuda)))
 
 
 def _partials(device) -> torch.Tensor:
@@ -45,6 +52,7 @@ class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, mean, rstd = ctx.saved_tensors
+        assert g.dtype == torch.float32, "mmf_layernorm_train_backward reads float32 gradients"
         g = g.contiguous()
         D = x.shape[-1]
         rows = x.numel() // D
@@ -59,7 +67,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
 def add_layer_norm(a: torch.Tensor, b: Optional[torch.Tensor], norm) -> torch.Tensor:
     """``norm(a + b)`` (``b`` None: ``norm(a)``) for an ``nn.LayerNorm`` over the last dimension."""
-    if usable(a, norm):
+    if usable(a, norm, b):
         return _AddLayerNorm.apply(a, b, norm.weight, norm.bias, norm.eps)
     return norm(a if b is None else a + b)
 
@@ -79,6 +87,7 @@ class _AdaLNModulate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, ss = ctx.saved_tensors
+        assert g.dtype == torch.float32, "mmf_adaln_modulate_grad reads float32 gradients"
         g = g.contiguous()
         B, L, D = x.shape
         dx, dss = torch.empty_like(x), torch.empty_like(ss)
@@ -89,8 +98,8 @@ class _AdaLNModulate(torch.autograd.Function):
 
 
 def adaln_usable(x: torch.Tensor) -> bool:
-    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and torch.is_grad_enabled() and x.shape[-1] <= 128
-            and x.shape[-1] % 4 == 0)
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and torch.is_grad_enabled() and _f32_only() and x.numel() > 0
+            and x.shape[-1] <= 128 and x.shape[-1] % 4 == 0)
 
 
 def adaln_modulate_train(x: torch.Tensor, scale_shift: torch.Tensor) -> torch.Tensor:
@@ -111,6 +120,7 @@ class _LinearTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
+        assert g.dtype == torch.float32, "mmf_linear_weight_grad reads float32 gradients"
         N, K = weight.shape
         g2 = g.reshape(-1, N)
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
@@ -133,7 +143,7 @@ def linear(module, x: torch.Tensor) -> torch.Tensor:
     """``module(x)`` for an ``nn.Linear``; under autograd on CUDA float32 with many rows its parameter gradients come from the
     matrix-core split kernel."""
     w = module.weight
-    if (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and w.requires_grad and w.shape[1] <= 128
+    if (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and _f32_only() and w.requires_grad and w.shape[1] <= 128
             and w.shape[0] <= 256 and x.numel() // w.shape[1] >= MIN_ROWS_LINEAR and w.is_contiguous()):
         return _LinearTrain.apply(x, w, module.bias)
     return module(x)

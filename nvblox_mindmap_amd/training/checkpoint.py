@@ -87,7 +87,16 @@ def load_train_checkpoint(checkpoint_path: str, model, optimizer, initial_learni
     model_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     from_reference = _load_weights(model, model_dict["weight"])
     if "optimizer" in model_dict and not from_reference:
-        optimizer.load_state_dict(model_dict["optimizer"])
+        saved = model_dict["optimizer"]
+        flat_saved, flat_step = isinstance(saved, dict) and saved.get("format") == "flat-v1" or (isinstance(saved, dict) and "layout" in saved), hasattr(optimizer, "refresh_frozen_weights")
+        if flat_saved != flat_step:
+            # both loops write last.pth / best.pth: a checkpoint of one kind of step cannot restore the optimizer state of the other
+            raise ValueError(f"{checkpoint_path}: optimizer state written by {'training.GraphedTrainStep' if flat_saved else 'a per-parameter AdamW'}, "
+                             f"this run steps with {'training.GraphedTrainStep' if flat_step else 'a per-parameter AdamW'}: resume with the same kind of step "
+                             "(run_training(graphed=...)), or load the weights only")
+        optimizer.load_state_dict(saved)
+        if flat_step:
+            optimizer.refresh_frozen_weights()  # a captured backbone graph multiplies by split copies of the weights just loaded
         if initial_learning_rate is not None:
             if hasattr(optimizer, "set_lr"):  # a training.GraphedTrainStep (its rate lives in one device scalar)
                 optimizer.set_lr(initial_learning_rate)

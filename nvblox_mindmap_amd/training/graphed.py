@@ -130,6 +130,10 @@ class GraphedTrainStep:
         model.train()
         self._find_used_parameters()
         self._flatten(lr, weight_decay)
+        if self.world > 1:
+            # what DistributedDataParallel does in its constructor: every replica starts from rank 0's weights (a per-rank seed or a
+            # checkpoint loaded on rank 0 only would otherwise diverge silently -- the all-reduced gradients applied to different weights)
+            dist.broadcast(self.flat_param, src=0 if process_group is None else dist.get_global_rank(process_group, 0), group=process_group)
         self.losses = torch.zeros(5, dtype=torch.float32, device=self.device)
         self.feats = self.next_feats = self.next_rgbs = None
         if self.overlap:
@@ -301,6 +305,31 @@ class GraphedTrainStep:
         self._sched.step()
         self.set_lr(self._host_opt.param_groups[0]["lr"])
 
+    def _frozen_linears(self):
+        enc = getattr(self.model, "encoder", None)
+        bb = getattr(enc, "backbone", None) if self.has_backbone else None
+        return [m for m in bb.modules() if isinstance(m, nn.Linear)] if bb is not None else []
+
+    def refresh_frozen_weights(self) -> int:
+        """The frozen backbone's weights changed after capture (a checkpoint loaded into the model with load_state_dict: the documented
+        resume flow builds the step first): the captured backbone graph multiplies by fp16 SPLIT COPIES of its Linear weights whose
+        addresses it holds (diffuser_actor/split_linear.py) -- they are recomputed in place, the graph stays valid.  Called by
+        ``step()`` whenever a copy is stale (a version check of ~50 layers: microseconds); returns the number of layers refreshed."""
+        from ..diffuser_actor import split_linear as SL
+
+        n = 0
+        for lin in self._frozen_linears():
+            if SL.stale(lin):
+                if not SL.refresh_in_place(lin):
+                    if self.use_graphs:
+                        raise RuntimeError("a frozen backbone weight changed after graph capture and its split copy cannot be refreshed in "
+                                           "place (values beyond fp16's range?): build a new GraphedTrainStep")
+                    continue
+                n += 1
+        if n:
+            self._primed = None  # features computed with the old weights
+        return n
+
     def _load(self, batch: Dict[str, torch.Tensor]) -> None:
         for k, dst in self.static.items():
             if k == "rgbs" and self.overlap:
@@ -322,6 +351,8 @@ class GraphedTrainStep:
 
     def step(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         t0, c0 = time.perf_counter(), time.thread_time()
+        if self.has_backbone:
+            self.refresh_frozen_weights()
         announce = self.overlap and next_batch is not None
         if self.overlap:
             if self._primed is not batch:
@@ -383,19 +414,26 @@ class GraphedTrainStep:
 
     # -- checkpoints -----------------------------------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
-        return {"optimizer": self.optimizer.state_dict(), "layout": list(self.layout), "n_no_decay": self.n_no_decay,
+        return {"format": "flat-v1", "optimizer": self.optimizer.state_dict(), "layout": list(self.layout), "n_no_decay": self.n_no_decay,
                 "steps_done": self.steps_done, "lr": self.lr}
 
     def load_state_dict(self, state: dict) -> None:
         if [tuple(x) for x in state["layout"]] != [tuple(x) for x in self.layout]:
             raise ValueError("the checkpoint's flat parameter layout is not this model's")
         lr = self.lr
+        saved = state["optimizer"]["state"]
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
         if self.graph_opt is None:
-            self.optimizer.load_state_dict(state["optimizer"])
+            # eager step: only the moments and step counts are taken -- the checkpoint's param_groups may be a captured step's
+            # (capturable=True, device-side step / learning rate), which an eager AdamW on this device would refuse
+            for i, p in enumerate(params):
+                if i in saved:
+                    st = self.optimizer.state[p]
+                    for k, v in saved[i].items():
+                        v = torch.as_tensor(v)
+                        st[k] = v.detach().to("cpu", torch.float32).clone() if k == "step" else v.detach().to(p.device, p.dtype).clone()
         else:
             # the captured optimizer graph reads and writes THESE state tensors: copy into them (load_state_dict would replace them)
-            saved = state["optimizer"]["state"]
-            params = [p for g in self.optimizer.param_groups for p in g["params"]]
             for i, p in enumerate(params):
                 if i in saved:
                     for k, v in saved[i].items():

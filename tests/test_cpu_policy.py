@@ -622,3 +622,34 @@ def test_training_checkpoint_resume(tmp_path):
     wrapped = {"weight": {"module." + k: v for k, v in a.state_dict().items()}, "iter": 5}
     torch.save(wrapped, tmp_path / "ddp.pth")
     assert load_train_checkpoint(str(tmp_path / "ddp.pth"), b, ob)[0] == 5
+
+
+def test_checkpoint_of_the_other_kind_of_step_is_refused_by_name(tmp_path):
+    """Round-4 advisor finding: both loops write last.pth / best.pth; a flat-buffer step's optimizer state loaded into a per-parameter
+    AdamW failed with KeyError 'param_groups' (and the other way round with a layout error) at resume time.  Now: a clear message."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.training import GraphedTrainStep, build_model, build_optimizer, load_train_checkpoint, save_checkpoint, synthetic_batch
+
+    cfg = DiffuserActorConfig(data_type="mesh", feature_dim=16, embedding_dim=48, num_attn_heads=4, diffusion_timesteps=4)
+    batch = synthetic_batch(cfg, 2, "cpu", num_vertices=64, seed=0)
+    torch.manual_seed(0)
+    m = build_model(cfg, device="cpu")
+    g = GraphedTrainStep(cfg, m, batch, lr=1e-3, use_graphs=False, data_parallel=False)
+    g.step(batch)
+    save_checkpoint(str(tmp_path / "flat"), m, g, 0, 1.0, None)
+    assert torch.load(str(tmp_path / "flat" / "last.pth"), weights_only=True)["optimizer"]["format"] == "flat-v1"
+    m2 = build_model(cfg, device="cpu")
+    with pytest.raises(ValueError, match="GraphedTrainStep"):
+        load_train_checkpoint(str(tmp_path / "flat" / "last.pth"), m2, build_optimizer(m2))
+    # the same kind resumes; the eager flat step takes only the moments and step counts from the file
+    g2 = GraphedTrainStep(cfg, m2, batch, lr=1e-3, use_graphs=False, data_parallel=False)
+    assert load_train_checkpoint(str(tmp_path / "flat" / "last.pth"), m2, g2, initial_learning_rate=1e-3)[0] == 1
+    torch.manual_seed(3)
+    la = g.step(batch).clone()
+    torch.manual_seed(3)
+    lb = g2.step(batch).clone()
+    assert torch.equal(la, lb) and all(torch.equal(p, q) for p, q in zip(m.parameters(), m2.parameters()))
+    opt = build_optimizer(m)
+    save_checkpoint(str(tmp_path / "plain"), m, opt, 0, 1.0, None)
+    with pytest.raises(ValueError, match="per-parameter AdamW"):
+        load_train_checkpoint(str(tmp_path / "plain" / "last.pth"), m2, g2)

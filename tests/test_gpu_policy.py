@@ -1037,3 +1037,52 @@ def test_trainable_side_kernels_give_the_gradients_of_torchs_operators():
     assert scale > 0 and float((g1 - g0).abs().max()) <= 2e-4 * scale, float((g1 - g0).abs().max()) / scale
     # (per element: rounding-level everywhere, not just at the largest entries)
     assert float(((g1 - g0).abs() > 1e-5 * scale + 1e-3 * g0.abs()).float().mean()) < 1e-3
+
+
+def test_resume_into_a_model_built_with_another_seed_refreshes_the_captured_backbone(tmp_path):
+    """Round-4 advisor finding: the captured backbone graph multiplies by fp16 split copies of the frozen Linear weights whose
+    addresses it holds; the documented resume flow (build the step, THEN load_train_checkpoint into the model) left them at the
+    pre-checkpoint values -- silently, when the checkpoint's backbone differs from the freshly built one.  Now the copies are
+    recomputed in place: the resumed step computes what a step built AFTER the weights were loaded computes."""
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.diffuser_actor import split_linear as SL
+    from nvblox_mindmap_amd.training import GraphedTrainStep, build_model, load_train_checkpoint, save_checkpoint, synthetic_batch
+
+    cfg = DiffuserActorConfig(data_type="rgbd_and_mesh", image_size=(128, 128), feature_dim=768)
+    batches = [synthetic_batch(cfg, 2, "cuda", num_vertices=256, seed=i) for i in range(3)]
+    torch.manual_seed(0)
+    a = build_model(cfg, device="cuda")
+    ga = GraphedTrainStep(cfg, a, batches[0], lr=1e-3)
+    torch.manual_seed(1)
+    ga.step(batches[0], batches[1])
+    ga.step(batches[1], None)
+    torch.cuda.synchronize()
+    save_checkpoint(str(tmp_path), a, ga, 1, 1.0, None)  # step_id 1 -> "iter" 2
+
+    def resumed(seed, load_first):
+        torch.manual_seed(seed)
+        m = build_model(cfg, device="cuda")
+        if load_first:  # the order that always worked: weights, then capture
+            m.load_state_dict({k: v.to("cuda") for k, v in torch.load(str(tmp_path / "last.pth"), weights_only=True)["weight"].items()})
+        g = GraphedTrainStep(cfg, m, batches[0], lr=1e-3)
+        start, _ = load_train_checkpoint(str(tmp_path / "last.pth"), m, g, initial_learning_rate=1e-3)
+        assert start == 2
+        torch.manual_seed(7)
+        out = g.step(batches[2], None).clone()
+        torch.cuda.synchronize()
+        return m, g, out
+
+    m_ref, _, l_ref = resumed(0, True)
+    m_new, g_new, l_new = resumed(123, False)  # another backbone at construction; the checkpoint's arrives after the capture
+    lins = g_new._frozen_linears()
+    assert lins and not any(SL.stale(lin) for lin in lins)
+    assert torch.equal(l_ref, l_new), (l_ref, l_new)
+    assert all(torch.equal(p, q) for p, q in zip(m_ref.parameters(), m_new.parameters()))
+    # and the guard is live: an in-place change of a frozen weight is picked up by the next step
+    with torch.no_grad():
+        lins[0].weight.mul_(1.5)
+    assert SL.stale(lins[0])
+    torch.manual_seed(7)
+    l_changed = g_new.step(batches[2], None).clone()
+    torch.cuda.synchronize()
+    assert not SL.stale(lins[0]) and not torch.equal(l_changed, l_new)
