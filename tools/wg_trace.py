@@ -43,6 +43,23 @@ def main():
             B.step(m, mcfg, frames[i])
             torch.cuda.synchronize()
             rec = buf.cpu().numpy().reshape(cap, 3)
+            if "--starts" in sys.argv:  # when do the workgroups of launch 2 (k_alloc_tsdf) start, by dispatch index?
+                blk = rec[2 * 8192:3 * 8192]  # role ids 30 / 31 share the slot range of ids 3x; 2x: the range before
+                for lo, name in ((1, "ids 2x (allocation, mask columns)"), (2, "ids 3x (TSDF pairs, new-block waiters)")):
+                    r = rec[lo * 8192:(lo + 1) * 8192]
+                    idx = np.nonzero(r[:, 0])[0]
+                    if len(idx) == 0:
+                        continue
+                    t00 = rec[rec[:, 0] != 0][:, 1].min()
+                    st = (r[idx, 1] - t00) / 100.0
+                    en = (r[idx, 2] - t00) / 100.0
+                    print(f"  launch-2 {name}: {len(idx)} workgroups, blockIdx {idx.min()}..{idx.max()}")
+                    for a in range(0, len(idx), max(len(idx) // 12, 1)):
+                        b = min(a + max(len(idx) // 12, 1), len(idx))
+                        print(f"    blockIdx {idx[a]:5d}..{idx[b - 1]:5d}: start {st[a:b].min():5.1f} .. {st[a:b].max():5.1f} (median {np.median(st[a:b]):5.1f})  end median {np.median(en[a:b]):5.1f} max {en[a:b].max():5.1f}")
+                    late = idx[st > np.median(st) + 3.0]
+                    if len(late):
+                        print(f"    {len(late)} start > 3 us after the median; blockIdx mod 8 histogram {np.bincount(late % 8, minlength=8).tolist()}, first {late[:12].tolist()}")
             rec = rec[rec[:, 0] != 0]
             extra = rec[:, 0] >> 8
             rec[:, 0] &= 0xff
