@@ -73,6 +73,7 @@ def compact_record(full: dict) -> dict:
         "ref_fps": ref.get("frames_per_s"), "ref_pipelined_fps": ref.get("pipelined_frames_per_s"),
         "lowres_ms": ref.get("fused_lowres_ms"), "lowres_k_feature_flat_us": ref.get("fused_lowres_k_feature_flat_us"),
         "unbounded_fps": unb.get("frames_per_s"), "unbounded_frac": unb.get("frac"), "unbounded_launches": unb.get("launches_per_frame"),
+        "unbounded_pipelined_fps": unb.get("pipelined_frames_per_s"),
         "undeferred_fps": und.get("frames_per_s"), "undeferred_frac": und.get("frac"), "undeferred_launches": und.get("launches_per_frame"),
         "pixel_holes_fps": holes.get("frames_per_s"), "pixel_holes_frac": holes.get("frac_of_hbm_peak"),
         "closed_loop_ms": legs_in.get("closed_loop_ms"),

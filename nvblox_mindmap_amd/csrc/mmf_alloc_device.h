@@ -757,8 +757,10 @@ __device__ inline void live_compact_big_body(const LayerDev& L, uint8_t* __restr
     const bool rb = !dense && (unsigned)n_tomb * 4u > L.hmask + 1u;
     L.ctr[0] = n_live;
     L.ctr[1] = free0 + n_dead;
-    L.ctr[4] = rb ? 0 : n_tomb;
-    if (rb) L.ctr[5]++;
+    // The count stays where it is until the rebuild has RUN (k_hash_insert_live_if zeroes it): the conditional rebuild launches
+    // follow only every kRebuildEvery-th compaction, and a request that has not been served yet is raised again by the next
+    // compaction from the same count.
+    L.ctr[4] = n_tomb;
     if (rebuild) *rebuild = rb ? 1 : 0;
     if (snap6) *snap6 = n_live;
     if (L.hint_live) *L.hint_live = n_live;

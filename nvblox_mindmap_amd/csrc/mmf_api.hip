@@ -242,6 +242,10 @@ int create_mapper_impl(const mmf_params& P, Mapper* m) {
   HIP_TRY(hipMemset(m->kill, 0, (size_t)cap));
   {
     const char* e = std::getenv("MMF_NO_ALLOC_TSDF");
+    {
+      const char* e2 = std::getenv("MMF_NO_BIG_MERGE");
+      m->allow_big_merge = !(e2 && e2[0] == '1');
+    }
     // (spec switch fma_contraction: the merged launch k_alloc_tsdf is built with the default arithmetic only)
     m->allow_merged = !(e && e[0] == '1') && !P.fma_contraction;
   }
@@ -452,6 +456,12 @@ int get_mapper_on(mmf_handle h, int id, Mapper** out, void* stream) {
   return flush_rows_for(h, **out, (hipStream_t)stream);
 }
 
+// The two conditional hash-rebuild launches behind a list compaction find their request flag down on all but one frame in hundreds
+// and cost 4.5 us each: they are enqueued behind every kRebuildEvery-th compaction of a mapper only.  A request stays up until it
+// is served; in between the tombstones grow by what kRebuildEvery - 1 compactions deallocate (a few percent of the table).
+constexpr int kRebuildEvery = 16;
+bool serve_rebuild_now(Mapper& m) { return (m.compactions++ % kRebuildEvery) == 0; }
+
 // A pending decay is applied now, as its own launches (every consumer of the map except the fused frame path).
 int next_lb_tag(Mapper& m, hipStream_t s, unsigned* tag);
 bool big_mode(const Mapper& m, int ncells);
@@ -508,7 +518,8 @@ void flush_decay(mmf_handle h, Mapper& m, hipStream_t s) {
     unsigned tag = 1;
     (void)next_lb_tag(m, s, &tag);
     launch_decay_mark(m.tsdf.d, m.mc, m.kill, m.any_kill, s);
-    launch_live_compact_big(m.tsdf.d, false, m.kill, m.any_kill, m.lb_compact, tag, m.rebuild_flag, nullptr, 0.0f, 0.0f, m.tsdf.d.cap, s);
+    launch_live_compact_big(m.tsdf.d, false, m.kill, m.any_kill, m.lb_compact, tag, m.rebuild_flag, nullptr, 0.0f, 0.0f, m.tsdf.d.cap, s,
+                            serve_rebuild_now(m));
     return;
   }
   launch_decay(m.tsdf.d, m.mc, m.kill, m.any_kill, s);
@@ -1137,8 +1148,9 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     launch_invert_mask(input_mask, m->inv_mask, (size_t)H * W, s);
     input_mask = m->inv_mask;
   }
-  if (!fusable || big) MMF_TRY(flush_rows(h, *m));  // no launch of this frame can host it
-  if (m->defer_rows && fusable && !big && !(m->mc.spec_flags & kSpecFma)) MMF_TRY(ensure_flat_other(*m));
+  const bool can_host = fusable && (!big || m->allow_big_merge);  // (large maps: the merged launches of round 5 host a pending tail too)
+  if (!can_host) MMF_TRY(flush_rows(h, *m));  // no launch of this frame can host it
+  if (m->defer_rows && can_host && !(m->mc.spec_flags & kSpecFma)) MMF_TRY(ensure_flat_other(*m));
   if (!fusable) {
     // odd shapes / very large grids: the plain sequence of stand-alone launches
     flush_decay(h, *m, s);
@@ -1196,15 +1208,20 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   // row update of this frame, not deferred)
   const bool fma = (m->mc.spec_flags & kSpecFma) != 0;
   const bool merged = !big && !fma && m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
-  if (big && light_decay && m->mc.dealloc_decayed) {
-    // the light decay's deallocations for a large pool: the scalable compaction (decided from wmax, no voxel touched) as a launch
-    // of its own -- k_front's single decay workgroup would need dozens of serial passes over 10^5 list entries
-    ProfScope ps(h, MMF_K_DECAY, s);
-    unsigned tag = 1;
-    MMF_TRY(next_lb_tag(*m, s, &tag));
-    // (lazy: the same launch multiplies the survivors' wmax / wmin and keeps block_free current -- their voxels stay behind)
-    launch_live_compact_big(lazy ? lazy_view(*m) : m->tsdf.d, true, nullptr, nullptr, m->lb_compact, tag, m->rebuild_flag, nullptr,
-                            m->mc.decay_factor, m->mc.decay_thr, m->tsdf.d.cap, s);
+  // the light decay's deallocations for a large pool: the scalable compaction (decided from wmax, no voxel touched; k_front's single
+  // decay workgroup would need dozens of serial passes over 10^5 list entries) -- as roles of this frame's FIRST launch, beside the
+  // raycast and the mask rows (round 5; MMF_NO_BIG_MERGE=1: a launch of its own in front of it)
+  const bool compact_big = big && light_decay && m->mc.dealloc_decayed;
+  const bool compact_in_front = compact_big && m->allow_big_merge;
+  unsigned compact_tag = 1;
+  if (compact_big) {
+    MMF_TRY(next_lb_tag(*m, s, &compact_tag));
+    if (!compact_in_front) {
+      ProfScope ps(h, MMF_K_DECAY, s);
+      // (lazy: the same launch multiplies the survivors' wmax / wmin and keeps block_free current -- their voxels stay behind)
+      launch_live_compact_big(lazy ? lazy_view(*m) : m->tsdf.d, true, nullptr, nullptr, m->lb_compact, compact_tag, m->rebuild_flag, nullptr,
+                              m->mc.decay_factor, m->mc.decay_thr, m->tsdf.d.cap, s, serve_rebuild_now(*m));
+    }
     if (lazy) {
       m->lazy_epoch++;
       m->lazy_lag = true;
@@ -1221,7 +1238,18 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     const FrontArgs FA = make_front_args(m->mc, cam, T_L_C, depth, input_mask, min_depth_m, sub, vg, m->sc[0].flags, M,
                                          (do_decay && !big) ? &m->tsdf.d : nullptr, light_decay, m->kill, m->any_kill,
                                          merged ? m->tsdf.d.ctr : nullptr, grid_tag);
-    if (m->tail_pending) {  // ... | the previous frame's colour update + feature gating
+    if (big && m->allow_big_merge && (compact_in_front || m->tail_pending)) {
+      // large map: the decay's list compaction | ... | the previous frame's colour update + feature gating (pipelined stream)
+      const LayerDev Lc = lazy ? lazy_view(*m) : m->tsdf.d;
+      const bool tail = m->tail_pending;
+      if (tail) {
+        m->tail_pending = false;
+        m->rows_pending = true;
+      }
+      launch_front_compact_big(FA, compact_in_front ? &Lc : nullptr, m->lb_compact, compact_tag, m->rebuild_flag, m->mc.decay_factor,
+                               m->mc.decay_thr, m->tsdf.d.cap, compact_in_front && serve_rebuild_now(*m), tail ? &m->tail : nullptr, s, pe.a(),
+                               pe.b());
+    } else if (m->tail_pending) {  // ... | the previous frame's colour update + feature gating
       m->tail_pending = false;
       m->rows_pending = true;
       launch_front_app(FA, m->tail, s, pe.a(), pe.b());
@@ -1313,7 +1341,18 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
     int Ws, Hs;
     bool need;
     MMF_TRY(synth_prepare(*m, cam, T16, K9, &Ws, &Hs, &need));
-    if (big) {
+    if (big && need && m->allow_big_merge) {
+      // colour allocation | feature allocation | sphere trace: one launch (round 5)
+      ProfExt pe(h, MMF_K_SPHERE);
+      MMF_TRY(next_lb_tag(*m, s, &jobs[0].lb_tag));
+      jobs[1].lb_tag = jobs[0].lb_tag;
+      const bool rows = m->rows_pending;  // ... | the previous frame's row update (its list is the other one of the pair)
+      m->rows_pending = false;
+      launch_sphere_alloc_big(m->lazy_lag ? lazy_view(*m) : m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, jobs, m->stats,
+                              rows ? &m->rows_args : nullptr, s, pe.a(), pe.b());
+      synth_commit(*m, cam, T16, K9, Ws, Hs);
+    } else if (big) {
+      MMF_TRY(flush_rows(h, *m));
       if (need) {
         ProfScope ps(h, MMF_K_SPHERE, s);
         launch_sphere_trace(m->lazy_lag ? lazy_view(*m) : m->tsdf.d, m->mc, cam, T_L_C, m->synth, Ws, Hs, s);
@@ -1339,7 +1378,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
       launch_alloc_jobs(jobs, 2, m->stats, nullptr, s);
     }
   }
-  if (may_defer && m->defer_rows && !big && !fma && m->flat.rec && m->flat_other.rec) {
+  if (may_defer && m->defer_rows && (!big || m->allow_big_merge) && !fma && m->flat.rec && m->flat_other.rec) {
     // launches 4 and 5 are left to the next fused frame (roles of its launches 1 and 3) or to whatever takes the mapper first
     MMF_TRY(flush_rows(h, *m));  // (nothing hosted the previous frame's: before this frame's own)
     m->tail = make_app_tail(m->color.d, cam, rgb, depth_mask_out, m->sc[1], m->feat.d, fcam, (const __half*)feat, feature_mask_out,

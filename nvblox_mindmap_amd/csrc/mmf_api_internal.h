@@ -63,6 +63,8 @@ struct Mapper {
   int grid_tag = 0;
   bool allow_merged = true;    // false: environment MMF_NO_ALLOC_TSDF=1 at creation -- keep allocation and TSDF pass as separate launches
                                // (the reference point of the parity tests of k_alloc_tsdf)
+  bool allow_big_merge = true; // false: MMF_NO_BIG_MERGE=1 at creation -- a large map's list compaction / appearance allocation stay launches of their own
+  unsigned compactions = 0;    // scalable list compactions so far (serve_rebuild_now: the conditional rebuild rides on every 16th)
   u64* pub = nullptr;          // [16 + 3 * cap + 2 + kNewBlockWgs] new blocks published by the allocation workgroups of k_alloc_tsdf to
                                // their own launch + the control words of the hand-over (AllocJob::pub)
   unsigned pub_tag = 0;        // tag of the last k_alloc_tsdf launch (30 bits, incremented by those launches only; 0 is never used)

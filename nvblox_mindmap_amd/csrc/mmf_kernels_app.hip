@@ -300,6 +300,34 @@ __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, 
   sphere_patch<LAZY>(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, blockIdx.x, threadIdx.x);
 }
 
+// Large pools: the scalable colour + feature allocation (alloc_big_body: [job 0 chunks | job 1 chunks], look-back chains) and the
+// sphere trace as roles of ONE launch -- the allocation reads the candidate flags of the TSDF pass and touches only the appearance
+// layers' lists and index, the trace reads the TSDF layer: independent, as in the bounded workspace's k_sphere_alloc.  The chunks
+// lead the grid (their look-back needs its predecessors resident first).  FLAT (1: from the feature image, 2: from a low-res map): in a
+// pipelined stream the previous frame's row update follows as a fourth role (as in k_sphere_alloc_flat).
+template <bool LAZY, int FLAT>
+__global__ __launch_bounds__(256) void k_sphere_alloc_big(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth, int Ws, int Hs,
+                                                         int patches_x, int n_patches, AllocJob J0, AllocJob J1, int nwg0, int nwg1, int G0, int G1,
+                                                         long long* stats, AppArgs F, int lpv, int n_flat) {
+  __shared__ AllocBigLds S;
+  __shared__ int s_prefix[FLAT ? kFlatSubLists + 1 : 1];
+  int b = (int)blockIdx.x;
+  if (b < nwg0) {
+    if (J0.ks.mode == 0) alloc_big_body<0>(J0, stats, S, b, nwg0, G0);
+    else alloc_big_body<1>(J0, stats, S, b, nwg0, G0);
+    return;
+  }
+  b -= nwg0;
+  if (b < nwg1) {
+    if (J1.ks.mode == 0) alloc_big_body<0>(J1, stats, S, b, nwg1, G1);
+    else alloc_big_body<1>(J1, stats, S, b, nwg1, G1);
+    return;
+  }
+  b -= nwg1;
+  if (!FLAT || b < n_patches) return sphere_patch<LAZY>(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, b, threadIdx.x);
+  if constexpr (FLAT != 0) feature_flat_role<FLAT == 2>(F, mc, lpv, b - n_patches, n_flat, s_prefix);
+}
+
 // Horizontal fusion: the sphere trace (reads the TSDF layer) and the block allocation of the colour and the feature layer
 // (touch only their own hash / lists; inputs = the candidate flags) are independent once the TSDF update and the candidate
 // selection are done.  Workgroups [0, njobs) run one allocation job each, the others one 4x4 ray patch each.
@@ -552,6 +580,35 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
     hipLaunchKernelGGL(k_sphere_trace<true>, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
   else
     hipLaunchKernelGGL(k_sphere_trace<false>, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+}
+
+static int flat_lanes_per_voxel(const MapConsts& mc);
+static int flat_grid(const FlatList& fl, int lpv);
+void launch_sphere_alloc_big(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
+                             const AllocJob* jobs, long long* stats, const AppArgs* rows, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
+  const int n = patches_x * patches_y > 0 ? patches_x * patches_y : 0;
+  const int G0 = alloc_big_groups(jobs[0].ncells), G1 = alloc_big_groups(jobs[1].ncells);
+  const int n0 = (alloc_big_wgs(jobs[0].ncells) + G0 - 1) / G0, n1 = (alloc_big_wgs(jobs[1].ncells) + G1 - 1) / G1;
+  const bool lazy = tsdf.epoch != nullptr;  // a lazily decayed map: sampled weights are brought up to date on the fly
+  const int lpv = flat_lanes_per_voxel(mc);
+  const int n_flat = rows ? flat_grid(rows->flat, lpv) : 0;
+  const int flat = !rows ? 0 : (rows->low.data ? 2 : 1);
+  const AppArgs F = rows ? *rows : AppArgs{};
+  const dim3 grid(n0 + n1 + n + n_flat);
+#define MMF_SAB(LAZYV, FLATV)                                                                                                                  \
+  hipExtLaunchKernelGGL((k_sphere_alloc_big<LAZYV, FLATV>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x, n, \
+                        jobs[0], jobs[1], n0, n1, G0, G1, stats, F, lpv, n_flat)
+  if (lazy) {
+    if (flat == 0) MMF_SAB(true, 0);
+    else if (flat == 1) MMF_SAB(true, 1);
+    else MMF_SAB(true, 2);
+  } else {
+    if (flat == 0) MMF_SAB(false, 0);
+    else if (flat == 1) MMF_SAB(false, 1);
+    else MMF_SAB(false, 2);
+  }
+#undef MMF_SAB
 }
 
 SphereArgs make_sphere_args(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,

@@ -260,6 +260,30 @@ __global__ __launch_bounds__(256) void k_front(FrontArgs A) {
   front_role<LDSFLAGS>(A, (int)blockIdx.x, s_words, S);
 }
 
+// Large hash-indexed maps: the light decay's scalable list compaction (live_compact_big_body: decided from wmax, no voxel touched) as
+// one more role of the frame's first launch -- [n_compact compaction chunks | raycast tiles | mask rows].  The compaction touches the
+// TSDF layer's lists, index and summaries; the raycast and the mask rows the depth image and the view grid: nothing in common (the
+// bounded workspace's single decay workgroup rides in k_front the same way).  The chunks lead the grid: their look-back chain is
+// resident before the rays fill the chip, and long done when the last ray is.  APP: in a pipelined stream the previous frame's colour
+// update + feature gating follows as a fourth role (as in k_front_app); n_compact == 0: a frame without a pending decay.
+template <bool LDSFLAGS, bool APP>
+__global__ __launch_bounds__(256) void k_front_compact_big(FrontArgs A, LayerDev L, u64* lb, unsigned tag, int* rebuild, float decay_f, float decay_thr,
+                                                          int n_compact, AppArgs Acol, AppArgs Afeat, const float* __restrict__ synth, int Ws, int Hs,
+                                                          int nb_gate) {
+  extern __shared__ unsigned s_words[];
+  __shared__ FrontLds S;
+  __shared__ int sh[8];
+  int b = (int)blockIdx.x;
+  if (b < n_compact) return live_compact_big_body<true>(L, nullptr, lb, tag, rebuild, nullptr, decay_f, decay_thr, S.s_scan, sh, b, n_compact);
+  b -= n_compact;
+  if (!APP || b < A.n_wgs) return front_role<LDSFLAGS>(A, b, s_words, S);
+  if constexpr (APP) {
+    const long long tr0 = wg_trace_begin();
+    app_frame_body<false, true>(Acol, Afeat, A.R.mc, synth, Ws, Hs, b - A.n_wgs, nb_gate, *reinterpret_cast<FeatLds*>(s_words));
+    wg_trace_end(tr0, kTrAppFrame);
+  }
+}
+
 // Two frames (two mappers fed by the same camera frame: mmf_integrate_frame_multi) in ONE launch: the workgroups of the second
 // follow those of the first.  Same role code, same results; the launch is as long as its slower half instead of their sum.
 template <bool LDSFLAGS>
@@ -1238,6 +1262,10 @@ __global__ __launch_bounds__(256) void k_count_tombstones(LayerDev L, unsigned l
 
 __global__ __launch_bounds__(256) void k_hash_insert_live_if(LayerDev L, const int* cond) {
   if (cond && !*cond) return;
+  if (cond && blockIdx.x == 0 && threadIdx.x == 0) {  // the requested rebuild is being served: no tombstone is left (k_hash_clear_if ran)
+    L.ctr[4] = 0;
+    L.ctr[5]++;  // diagnostics (mmf_debug_hash_state): table rebuilds since the layer was reset
+  }
   const int n = L.ctr[0];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int slot = L.live[i];
@@ -1424,6 +1452,39 @@ void launch_front(const FrontArgs* A, int n, hipStream_t s, hipEvent_t ev_start,
   }
 }
 
+void launch_hash_rebuild_if(const LayerDev& L, const int* rebuild, hipStream_t s);
+
+// the light decay's scalable compaction | this frame's raycast + mask rows, then (serve_rebuild) the conditional rebuild pair
+void launch_front_compact_big(const FrontArgs& A, const LayerDev* compact, u64* lb, unsigned tag, int* rebuild, float decay_f, float decay_thr,
+                              int live_upper, bool serve_rebuild, const AppTail* tail, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int ncells = front_cells(A);
+  const bool lds = ncells <= kRaycastLdsCells;
+  size_t shm = lds ? (size_t)((ncells + 3) / 4) * 4 : 0;
+  const int nc = compact ? alloc_big_wgs(live_upper) : 0;
+  const LayerDev L = compact ? *compact : LayerDev{};
+  if (tail) {
+    shm = shm < sizeof(FeatLds) ? sizeof(FeatLds) : shm;
+    const int nb_gate = app_tail_grid(*tail);
+    const dim3 grid(nc + A.n_wgs + nb_gate);
+    if (lds)
+      hipExtLaunchKernelGGL((k_front_compact_big<true, true>), grid, dim3(256), shm, s, ev_start, ev_stop, 0, A, L, lb, tag, rebuild, decay_f, decay_thr, nc,
+                            tail->Ac, tail->Af, tail->synth, tail->Ws, tail->Hs, nb_gate);
+    else
+      hipExtLaunchKernelGGL((k_front_compact_big<false, true>), grid, dim3(256), shm, s, ev_start, ev_stop, 0, A, L, lb, tag, rebuild, decay_f, decay_thr, nc,
+                            tail->Ac, tail->Af, tail->synth, tail->Ws, tail->Hs, nb_gate);
+  } else {
+    const dim3 grid(nc + A.n_wgs);
+    const AppArgs none{};
+    if (lds)
+      hipExtLaunchKernelGGL((k_front_compact_big<true, false>), grid, dim3(256), shm, s, ev_start, ev_stop, 0, A, L, lb, tag, rebuild, decay_f, decay_thr, nc,
+                            none, none, (const float*)nullptr, 0, 0, 0);
+    else
+      hipExtLaunchKernelGGL((k_front_compact_big<false, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, A, L, lb, tag, rebuild, decay_f, decay_thr, nc,
+                            none, none, (const float*)nullptr, 0, 0, 0);
+  }
+  if (compact && !L.dense && serve_rebuild) launch_hash_rebuild_if(L, rebuild, s);
+}
+
 void launch_front_app(const FrontArgs& A, const AppTail& T, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int ncells = front_cells(A);
   const bool lds = ncells <= kRaycastLdsCells;
@@ -1508,7 +1569,7 @@ void launch_compact_alloc(const LayerDev& L, const KeySrc& ks, const Scratch& sc
 
 int alloc_big_wgs(int ncells) { return ncells <= 0 ? 1 : (ncells + kBigChunk - 1) / kBigChunk; }
 // groups of 4 cells per thread so that a job is at most ~128 chunks where it can (look-back hops are memory round trips)
-static int alloc_big_groups(int ncells) {
+int alloc_big_groups(int ncells) {
   static const int forced = std::getenv("MMF_DEBUG_BIG_G") ? std::atoi(std::getenv("MMF_DEBUG_BIG_G")) : 0;
   if (forced > 0) return forced > kBigMaxG ? kBigMaxG : forced;
   int G = (alloc_big_wgs(ncells) + 127) / 128;
@@ -1532,20 +1593,25 @@ void launch_alloc_big(const AllocJob* jobs, int njobs, long long* stats, const M
 
 // live_upper: an upper bound of the live count known to the host (the pool capacity if nothing better)
 void launch_live_compact_big(const LayerDev& L, bool wmax, uint8_t* kill, int* any_kill, u64* lb, unsigned tag, int* rebuild, int* snap6,
-                             float decay_f, float decay_thr, int live_upper, hipStream_t s) {
+                             float decay_f, float decay_thr, int live_upper, hipStream_t s, bool serve_rebuild) {
   const int nwg = alloc_big_wgs(live_upper);
   if (wmax)
     hipLaunchKernelGGL(k_live_compact_big<true>, dim3(nwg), dim3(256), 0, s, L, kill, lb, tag, rebuild, snap6, decay_f, decay_thr, any_kill);
   else
     hipLaunchKernelGGL(k_live_compact_big<false>, dim3(nwg), dim3(256), 0, s, L, kill, lb, tag, rebuild, snap6, decay_f, decay_thr, any_kill);
-  if (!L.dense) {  // the amortised rebuild, on the flag the last chunk raised
-    // (almost every frame these two launches find the flag down and leave: 4.7 us each, whatever their grid -- the cost is the
-    // launch and the flag's load, not the workgroup count)
-    int hb = (int)((L.hmask + 1 + 255) / 256);
-    if (hb > 1024) hb = 1024;
-    hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, (const int*)rebuild);
-    hipLaunchKernelGGL(k_hash_insert_live_if, dim3(grid_for((L.cap + 255) / 256, 1024)), dim3(256), 0, s, L, (const int*)rebuild);
+  if (!L.dense && serve_rebuild) {  // the amortised rebuild, on the flag the last chunk raised
+    // (these two launches almost always find the flag down and leave: 4.5 us each, whatever their grid -- the cost is the launch and
+    // the flag's load.  So the caller asks for them only every few compactions: the table's layout is not observable, a request
+    // stays up until it is served, and between two chances the tombstones can grow by a few frames' deallocations at most)
+    launch_hash_rebuild_if(L, rebuild, s);
   }
+}
+
+void launch_hash_rebuild_if(const LayerDev& L, const int* rebuild, hipStream_t s) {
+  int hb = (int)((L.hmask + 1 + 255) / 256);
+  if (hb > 1024) hb = 1024;
+  hipLaunchKernelGGL(k_hash_clear_if, dim3(hb), dim3(256), 0, s, L, rebuild);
+  hipLaunchKernelGGL(k_hash_insert_live_if, dim3(grid_for((L.cap + 255) / 256, 1024)), dim3(256), 0, s, L, rebuild);
 }
 
 bool alloc_jobs_fusable(int ncells0, int ncells1) { return ncells0 <= kFusedAllocMaxCells && ncells1 <= kFusedAllocMaxCells; }

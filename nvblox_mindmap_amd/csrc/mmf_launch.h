@@ -191,8 +191,21 @@ bool alloc_jobs_fusable(int ncells0, int ncells1);
 int alloc_big_wgs(int ncells);
 bool alloc_big_supported(const LayerDev& L);
 void launch_alloc_big(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
+// serve_rebuild: also enqueue the two conditional hash-rebuild launches behind it (the request flag stays up until they have run)
 void launch_live_compact_big(const LayerDev& L, bool wmax, uint8_t* kill, int* any_kill, u64* lb, unsigned tag, int* rebuild, int* snap6,
-                             float decay_f, float decay_thr, int live_upper, hipStream_t s);
+                             float decay_f, float decay_thr, int live_upper, hipStream_t s, bool serve_rebuild = true);
+int alloc_big_wgs(int ncells);
+int alloc_big_groups(int ncells);
+struct AppTail;
+// large maps: [light decay's list compaction (compact != null) | raycast | mask rows | the previous frame's colour update + feature
+// gating (tail != null)] as ONE launch (+ the conditional hash-rebuild pair when serve_rebuild)
+void launch_front_compact_big(const FrontArgs& A, const LayerDev* compact, u64* lb, unsigned tag, int* rebuild, float decay_f, float decay_thr,
+                              int live_upper, bool serve_rebuild, const AppTail* tail, hipStream_t s, hipEvent_t ev_start = nullptr,
+                              hipEvent_t ev_stop = nullptr);
+// large maps: [colour allocation | feature allocation | sphere trace | the previous frame's feature rows (rows != null)] as ONE launch
+void launch_sphere_alloc_big(const LayerDev& tsdf, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, float* synth, int Ws, int Hs,
+                             const AllocJob* jobs, long long* stats, const AppArgs* rows, hipStream_t s, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
 void launch_alloc_jobs(const AllocJob* jobs, int njobs, long long* stats, const MaskJob* M, hipStream_t s);
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s);

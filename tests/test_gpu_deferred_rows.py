@@ -47,13 +47,16 @@ def feed(cfg, mappers, index, C, k, decay=True):
     return f, dyn
 
 
-def test_stream_equals_the_undeferred_one_and_the_oracle(oracle_mod):
+@pytest.mark.parametrize("over", [{}, {"workspace_bounds_type": 0, "max_integration_distance_m": 2.5}], ids=["bounded", "hash_path"])
+def test_stream_equals_the_undeferred_one_and_the_oracle(oracle_mod, over):
+    """`hash_path` (round 5): an unbounded workspace -- the frame's launches are the scalable ones (k_front_compact_big, k_alloc_big,
+    k_tsdf_pass<lazy>, k_sphere_alloc_big), which host the previous frame's gating and rows as the bounded launches do."""
     from oracle import image_ops as IO
 
     cfg, C = stream_cfg(2), 16
-    d, e = pair(C)
-    orc = make_oracle(oracle_mod, C)
-    for step in range(6):
+    d, e = pair(C, **over)
+    orc = make_oracle(oracle_mod, C, **over)
+    for step in range(8 if over else 6):
         f, dyn = feed(cfg, (d, e), (9 * step) % 200, C, step)
         assert pending(d) == 1 and pending(e) == 0
         odm, ofm = IO.frame_masks(~dyn, f["depth"], 0.3, 3, 4, 5, cfg.height, cfg.width)
