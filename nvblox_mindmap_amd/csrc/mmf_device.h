@@ -73,6 +73,38 @@ __device__ __forceinline__ float madd(float a, float b, float c) {
   else
     return a * b + c;
 }
+// ---- uniform constants in VECTOR registers ---------------------------------------------------------------------------------------
+// The per-voxel kernels keep ~100 launch constants live (transform, intrinsics, map constants, a dozen layer pointers) beside the
+// exec masks of their nested early-outs: the scalar file (<= 102) overflows and the allocator spills scalars into lanes of a vector
+// register -- v_writelane / v_readlane, VALU instructions on the busiest port (12 % of k_tsdf_pass's).  A constant moved to a vector
+// register once costs one VGPR and no instruction per use; the float operations are the same (round 5: k_tsdf_pass 125 -> 120 us).
+__device__ __forceinline__ float vgpr(float x) {
+  float y;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "s"(x));
+  return y;
+}
+__device__ __forceinline__ void rigid_to_vgprs(Rigid& T) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) T.R[q] = vgpr(T.R[q]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) T.t[q] = vgpr(T.t[q]);
+}
+__device__ __forceinline__ void cam_to_vgprs(Cam& c) {
+  c.fx = vgpr(c.fx);
+  c.fy = vgpr(c.fy);
+  c.cx = vgpr(c.cx);
+  c.cy = vgpr(c.cy);
+}
+// the map constants of the projective update (voxel / block size, truncation, distance and weight limits, depth-interpolation limit)
+__device__ __forceinline__ void update_consts_to_vgprs(MapConsts& mc) {
+  mc.v = vgpr(mc.v);
+  mc.bs = vgpr(mc.bs);
+  mc.trunc = vgpr(mc.trunc);
+  mc.max_dist = vgpr(mc.max_dist);
+  mc.max_weight = vgpr(mc.max_weight);
+  mc.lin_md = vgpr(mc.lin_md);
+}
+
 // a*x + b*y
 template <bool FMA>
 __device__ __forceinline__ float madd2(float a, float x, float b, float y) {

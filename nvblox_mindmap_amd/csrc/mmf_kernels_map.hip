@@ -731,6 +731,10 @@ __global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts m
   constexpr int NP = VPT / 2;  // float4 = two {distance, weight} voxels
   const uint8_t* __restrict__ mask = MASKED ? mask_arg : nullptr;
   const long long tr0 = wg_trace_begin();
+  // (uniform constants of the voxel loop in vector registers: mmf_device.h vgpr())
+  rigid_to_vgprs(T_C_L);
+  cam_to_vgprs(cam);
+  update_consts_to_vgprs(mc);
   const int n = LAZY ? *work_n : L.ctr[0];
   const int chunk = (n + 7) >> 3;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
@@ -1074,7 +1078,8 @@ __device__ inline void mask_cols_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, i
 __device__ inline void tsdf_pairs_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, int c) {
   const long long tr0 = wg_trace_begin();
   const LayerDev& L = A.J.L;
-  const TsdfFrameArgs& P = A.P;
+  const TsdfFrameArgs& P = A.P;  // (its constants in vector registers -- as k_tsdf_pass keeps them -- measured: 15.05 -> 14.87 us, not taken:
+                                 // the batch form of this role is capped at 64 VGPRs)
   const int half = threadIdx.x >> 7;
   const int n_old = *P.n_old;
   const int npairs = (n_old + 1) >> 1;
