@@ -459,8 +459,13 @@ int get_mapper_on(mmf_handle h, int id, Mapper** out, void* stream) {
 // The two conditional hash-rebuild launches behind a list compaction find their request flag down on all but one frame in hundreds
 // and cost 4.5 us each: they are enqueued behind every kRebuildEvery-th compaction of a mapper only.  A request stays up until it
 // is served; in between the tombstones grow by what kRebuildEvery - 1 compactions deallocate (a few percent of the table).
+// Only for tables large enough that 15 frames' deallocations are a small part of them (>= 2^18 entries: a churn of thousands of
+// blocks per frame adds a few percent); a small table under heavy churn is checked behind every compaction, as before.
 constexpr int kRebuildEvery = 16;
-bool serve_rebuild_now(Mapper& m) { return (m.compactions++ % kRebuildEvery) == 0; }
+bool serve_rebuild_now(Mapper& m) {
+  const unsigned every = (m.tsdf.d.hmask + 1u >= (1u << 18)) ? (unsigned)kRebuildEvery : 1u;
+  return (m.compactions++ % every) == 0;
+}
 
 // A pending decay is applied now, as its own launches (every consumer of the map except the fused frame path).
 int next_lb_tag(Mapper& m, hipStream_t s, unsigned* tag);
