@@ -133,3 +133,32 @@ def test_an_abandoned_epoch_gives_its_slots_back(dataset_dir):
                 break  # two batches in flight / handed out when the consumer walks away
     assert sum(b["rgb_u8"].shape[0] for b in ld) == 10
     ld.close()
+
+
+def test_host_io_entry_points_fail_loudly(tmp_path):
+    """mmf_host_read_file_at / mmf_host_sample_vertex_file (csrc/mmf_host_io.hip): short files, missing files and out-of-range rows are
+    errors with a message, not silent garbage in a batch buffer."""
+    import ctypes as C
+
+    from nvblox_mindmap_amd import _lib
+
+    L = _lib.lib()
+    buf = np.zeros(64, dtype=np.uint8)
+    p = tmp_path / "f.bin"
+    p.write_bytes(bytes(range(32)))
+    assert L.mmf_host_read_file_at(str(p).encode(), 8, buf.ctypes.data, 16) == 0 and buf[:16].tolist() == list(range(8, 24))
+    assert L.mmf_host_read_file_at(str(p).encode(), 8, buf.ctypes.data, 64) != 0 and "short read" in _lib.last_error()
+    assert L.mmf_host_read_file_at(str(tmp_path / "missing").encode(), 0, buf.ctypes.data, 1) != 0 and "cannot open" in _lib.last_error()
+    raw = str(tmp_path / "0000.nvblox_vertex_features.raw")
+    verts, feats = torch.rand(10, 3), torch.randn(10, 16)
+    VC.write_raw(raw, verts, feats)
+    V, Cc, off_v, off_f = VC.raw_header(raw)
+    rows = np.array([7, 0, 9], dtype=np.int64)
+    v16, f16 = np.zeros((3, 3), np.float16), np.zeros((3, 16), np.float16)
+    assert L.mmf_host_sample_vertex_file(raw.encode(), off_v, off_f, V, Cc, rows.ctypes.data, 3, v16.ctypes.data, f16.ctypes.data) == 0
+    assert np.array_equal(v16, verts.half().numpy()[rows]) and np.array_equal(f16, feats.half().numpy()[rows])
+    bad = np.array([10], dtype=np.int64)
+    assert L.mmf_host_sample_vertex_file(raw.encode(), off_v, off_f, V, Cc, bad.ctypes.data, 1, v16.ctypes.data, f16.ctypes.data) != 0
+    assert "out of range" in _lib.last_error()
+    assert L.mmf_host_sample_vertex_file(raw.encode(), off_v, off_f, V + 1000, Cc, rows.ctypes.data, 3, v16.ctypes.data, f16.ctypes.data) != 0
+    assert "smaller than its header" in _lib.last_error()
