@@ -119,6 +119,10 @@ def compact_record(full: dict) -> dict:
             "file_fed_samples_timed": ff.get("samples_timed"), "file_fed_prefetch_capacity": ff.get("prefetch_capacity_samples"),
             "loader_cpu_ms_per_sample": ff.get("loader_cpu_ms_per_sample"), "loader_cores_used": ff.get("loader_cpu_cores_used"),
             "loader_only_samples_per_s": ff.get("loader_only_samples_per_s"), "loader_bound": ff.get("bound"),
+            "eight_loaders_samples_per_s": _get(ff, "eight_loaders", "aggregate_samples_per_s"),
+            "eight_gpus_need_samples_per_s": _get(ff, "eight_loaders", "needed_by_8_gpus"),
+            # the reference's own loader path on the same files and host cores (torch DataLoader, 20 workers, zstd + PNG), loader only
+            "reference_loader_samples_per_s": _get(ff, "torch_dataloader_loader_only_samples_per_s", "zst_png_20_workers_reference_path"),
         }
     out = {
         "metric": full.get("metric"), "value": full.get("value"), "unit": full.get("unit"), "n_gpus": full.get("n_gpus"),
