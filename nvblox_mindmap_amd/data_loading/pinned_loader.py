@@ -254,6 +254,8 @@ class PinnedBatchLoader:
         self._free = list(range(self.n_slots))
 
     def __iter__(self) -> Iterator[HostBatch]:
+        if self._closed:
+            raise RuntimeError("PinnedBatchLoader: closed")
         self._reclaim_all()
         order = self._order()
         self.epoch += 1

@@ -306,9 +306,11 @@ class GraphedTrainStep:
         self.set_lr(self._host_opt.param_groups[0]["lr"])
 
     def _frozen_linears(self):
-        enc = getattr(self.model, "encoder", None)
-        bb = getattr(enc, "backbone", None) if self.has_backbone else None
-        return [m for m in bb.modules() if isinstance(m, nn.Linear)] if bb is not None else []
+        if getattr(self, "_frozen_cache", None) is None:  # (walked once: step() checks these layers' version counters every call)
+            enc = getattr(self.model, "encoder", None)
+            bb = getattr(enc, "backbone", None) if self.has_backbone else None
+            self._frozen_cache = [m for m in bb.modules() if isinstance(m, nn.Linear)] if bb is not None else []
+        return self._frozen_cache
 
     def refresh_frozen_weights(self) -> int:
         """The frozen backbone's weights changed after capture (a checkpoint loaded into the model with load_state_dict: the documented
