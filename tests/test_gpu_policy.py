@@ -1086,3 +1086,42 @@ def test_resume_into_a_model_built_with_another_seed_refreshes_the_captured_back
     l_changed = g_new.step(batches[2], None).clone()
     torch.cuda.synchronize()
     assert not SL.stale(lins[0]) and not torch.equal(l_changed, l_new)
+
+
+def test_training_loop_on_the_pinned_batch_loader(tmp_path):
+    """data_loading.PinnedBatchLoader (rows written in place into pinned batch buffers) behind DevicePrefetcher: the device batches equal
+    the reference-shaped path's (torch DataLoader -> gpu_unpack) sample for sample, a slot is only refilled behind the event of its
+    copies (three epochs through two slots), and training.run_training iterates it across epoch boundaries."""
+    from torch.utils.data import DataLoader
+
+    from nvblox_mindmap_amd.data_loading.dataset import DevicePrefetcher, MindmapFrameDataset, gpu_unpack, write_synthetic_demo
+    from nvblox_mindmap_amd.data_loading.pinned_loader import PinnedBatchLoader
+    from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
+    from nvblox_mindmap_amd.io import vertex_cache
+    from nvblox_mindmap_amd.training import build_model, build_optimizer, run_training
+
+    cfg = DiffuserActorConfig(data_type="rgbd_and_mesh", image_size=(128, 128), feature_dim=768, diffusion_timesteps=4)
+    write_synthetic_demo(str(tmp_path / "demo_00000"), 6, image_size=(128, 128), feature_dim=768, num_history=cfg.num_history,
+                         prediction_horizon=cfg.prediction_horizon, ngrippers=cfg.ngrippers, vertex_count_range=(300, 900))
+    vertex_cache.convert_dataset(str(tmp_path))
+    ds = MindmapFrameDataset(str(tmp_path), num_vertices=256, seed=0)
+    want = [gpu_unpack(b, "cuda") for b in DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)]
+    ld = PinnedBatchLoader(ds, batch_size=2, shuffle=False, threads=2, slots=2)
+    assert ld.pinned
+    for epoch in range(3):
+        got = list(DevicePrefetcher(ld, "cuda"))
+        torch.cuda.synchronize()
+        assert len(got) == len(want) == 3
+        for a, b in zip(want, got):
+            assert a.keys() == b.keys()
+            for k in a:
+                assert torch.equal(a[k], b[k]), (epoch, k)
+    assert ld.stats()["slow_path_samples"] == 0
+    torch.manual_seed(0)
+    model = build_model(cfg, device="cuda")
+    loader = DevicePrefetcher(PinnedBatchLoader(ds, batch_size=2, shuffle=True, threads=2, slots=3), "cuda")
+    seen = []
+    done, _ = run_training(cfg, model, build_optimizer(model, lr=1e-3), loader, loader, train_iters=7, val_freq=3, num_batches_per_test_eval=1,
+                           on_eval=lambda step, split, v: seen.append(v["mean_total_loss"]))
+    assert done == 7 and len(seen) == 2 and all(np.isfinite(x) for x in seen)
+    ld.close()
