@@ -123,3 +123,36 @@ def test_lazy_decay_of_a_large_map_matches_the_eager_oracle(oracle_mod):
     ov, of = orc.feature_mesh()
     mesh = gpu.get_feature_mesh(0)
     assert np.array_equal(mesh.vertices().cpu().numpy(), ov)
+
+
+@pytest.mark.parametrize("merged", [True, False])
+def test_large_map_launch_arrangements_give_the_same_map(oracle_mod, monkeypatch, merged):
+    """Round 5: a large map's frame hosts the light decay's list compaction in its first launch and the appearance allocation beside the
+    sphere trace, the conditional hash rebuild follows a compaction only now and then, and a pipelined stream's tail rides in those launches.
+    MMF_NO_BIG_MERGE=1 (read when the mapper is created) keeps the round-4 sequence -- both must give the oracle's map, pipelined or not."""
+    if not merged:
+        monkeypatch.setenv("MMF_NO_BIG_MERGE", "1")
+    cfg = S.StreamConfig(hole_mode="patches")
+    over = dict(workspace_bounds_type=0, tsdf_decay_factor=0.9)
+    gpu, piped, orc = make_mapper(64, **over), make_mapper(64, **over), make_oracle(oracle_mod, 64, **over)
+    piped.set_deferred_feature_rows(True)
+    from oracle import image_ops as IO
+
+    for i in (0, 9, 18, 27, 36):
+        f = S.frame(cfg, i, 64)
+        static = np.ones(f["depth"].shape, dtype=bool)
+        odm, ofm = IO.frame_masks(static, f["depth"], 0.3, 17, 20, 5, cfg.height, cfg.width)
+        orc.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], odm.astype(np.uint8))
+        orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], ofm.astype(np.uint8))
+        for m in (gpu, piped):
+            m.decay()
+            m.integrate_frame(dev(f["depth"]), dev(f["rgb"]), dev(f["features"]), dev(static), torch.from_numpy(f["T_W_C"]),
+                              torch.from_numpy(f["K"]), 0.3, 17, 20, 5, 0)
+        pend = _lib.lib().mmf_deferred_feature_rows_pending(piped._h, 0)
+        assert pend == (1 if merged else 0)  # (without the merged launches a large map's frame is complete when the call returns)
+    for m in (gpu, piped):
+        _, exact = compare_tsdf(orc, m)
+        assert exact
+        compare_features(orc, m)
