@@ -107,14 +107,17 @@ def test_soak_bounded_2000_frames_with_checkpoint(oracle_mod, tmp_path, pipeline
     assert np.array_equal(mesh.vertex_features().cpu().numpy().view(np.uint16), of.view(np.uint16))
 
 
-def test_soak_unbounded_500_frames_hash_churn(oracle_mod, tmp_path):
-    """The hash path over 500 frames: 2 cm voxels, 3 m range, decay 0.9 (blocks die ~80 frames after they leave the view), a
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_soak_unbounded_500_frames_hash_churn(oracle_mod, tmp_path, pipelined):
+    """pipelined (round 5): set_deferred_feature_rows on a large map -- the scalable launches host the previous frame's gating and rows.
+    The hash path over 500 frames: 2 cm voxels, 3 m range, decay 0.9 (blocks die ~80 frames after they leave the view), a
     pool of 8 192 blocks (16 384 table entries: the tombstones force a rebuild every ~4 096 deallocations).  Fused frames with
     every fifth frame as the reference's stand-alone calls (eager decay, separate allocation launches)."""
     n_frames = int(os.environ.get("MMF_SOAK_FRAMES_UNBOUNDED", "500"))
     cache = FrameCache(stream_cfg())
     over = dict(workspace_bounds_type=0, voxel_size=0.02, max_integration_distance_m=3.0, tsdf_decay_factor=0.9, num_preallocated_blocks=8192)
     gpu, orc = make_mapper(C, **over), make_oracle(oracle_mod, C, **over)
+    gpu.set_deferred_feature_rows(pipelined)
     rebuilds = 0
     for k in range(n_frames):
         index = (13 * k) % 200 if (k // 60) % 2 == 0 else 100 + k % 5
@@ -141,6 +144,7 @@ def test_soak_unbounded_500_frames_hash_churn(oracle_mod, tmp_path):
             gpu.save_map(path, 0)
             fresh = make_mapper(C, **over)
             fresh.load_from_file(path, 0)
+            fresh.set_deferred_feature_rows(pipelined)
             gpu = fresh
     st = gpu.hash_state(0)
     assert st["table_entries"] == 16384 and st["live_blocks"] == orc.num_blocks(0)
