@@ -343,11 +343,11 @@ def main():
     if rank == 0 and not args.no_ref_shape:
         model_inputs = {"ref": run_model_inputs(device, "ref"), "bl": run_model_inputs(device, "bl")}
     tsdf_only = run_tsdf_only(device) if (rank == 0 and not args.no_ref_shape) else None
-    # the secondary legs run their own step counts: they get a stream of at least 100 distinct frames whatever --steps is (at the
+    # the secondary legs run their own step counts: they get the default 200-frame stream whatever --steps is (at the
     # driver's --steps 20 the headline's 20-frame stream would make them measure a shorter orbit than the numbers quoted for them)
     leg_frames = frames
-    if rank == 0 and not args.no_ref_shape and n_frames < 100:
-        leg_frames = build_stream(cfg, 100, args.channels, device)
+    if rank == 0 and not args.no_ref_shape and n_frames < 200:
+        leg_frames = build_stream(cfg, 200, args.channels, device)
     two_mappers = run_two_mappers(device, leg_frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     unbounded = run_unbounded(device, leg_frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     in_flight = run_frames_in_flight(device, leg_frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
