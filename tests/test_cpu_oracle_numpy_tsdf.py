@@ -228,3 +228,116 @@ def test_numpy_restatement_of_the_feature_update(oracle_mod):
         of, ow = orc.all_features()
         assert np.array_equal(ow.reshape(-1, 512).view(np.uint32), Wf.view(np.uint32)), f"feature weights differ after frame {k}"
         assert np.array_equal(of.reshape(-1, 512, C).view(np.uint16), A.view(np.uint16)), f"feature values differ after frame {k}"
+
+
+def test_numpy_restatement_of_the_sphere_traced_depth(oracle_mod):
+    """The synthetic depth image of the appearance gate (sphere tracing through the TSDF, one ray per 4 x 4 pixels): all rays marched in
+    lockstep in numpy float32 -- same samples, same steps, same termination rules as the spec -- against the C oracle's image, bit for bit."""
+    cfg = small_cfg(2)
+    orc = make_oracle(oracle_mod, 8)
+    for i in (0, 5, 11):
+        f = S.frame(cfg, i, 0)
+        orc.decay()
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], None)
+    f = S.frame(cfg, 14, 0)
+    H, Wd = f["depth"].shape
+    want = orc.render_synthetic_depth(H, Wd, f["T_W_C"], f["K"])
+    idx = orc.block_indices(0)
+    tsdf = orc.all_tsdf().reshape(-1, 512, 2)
+    lo = idx.min(axis=0)
+    ext = idx.max(axis=0) - lo + 1
+    table = -np.ones(tuple(ext), dtype=np.int64)
+    table[tuple((idx - lo).T)] = np.arange(idx.shape[0])
+    v = F(REF_PARAMS["voxel_size"])
+    bs = F(F(8.0) * v)
+    inv_bs, inv_v = F(F(1.0) / bs), F(F(1.0) / v)
+    trunc, eps = F(F(4.0) * v), F(F(0.1) * v)
+    sf, max_steps, max_len = 4, 100, F(15.0)
+    Ws, Hs = Wd // sf, H // sf
+    K, T = f["K"].astype(F), f["T_W_C"].astype(F)
+    cs, rs = np.meshgrid(np.arange(Ws, dtype=F), np.arange(Hs, dtype=F))
+    u, w = (cs + F(0.5)) * F(sf), (rs + F(0.5)) * F(sf)
+    x, y = (u - K[0, 2]) / K[0, 0], (w - K[1, 2]) / K[1, 1]
+    n = np.sqrt((x * x + y * y) + F(1.0)).astype(F)
+    dC = [x / n, y / n, F(1.0) / n]
+    R = T[:3, :3]
+    dL = [(R[i, 0] * dC[0] + R[i, 1] * dC[1]) + R[i, 2] * dC[2] for i in range(3)]
+    o = T[:3, 3]
+    t = np.zeros((Hs, Ws), F)
+    last_pos = np.zeros((Hs, Ws), bool)
+    alive = np.ones((Hs, Ws), bool)
+    success = np.zeros((Hs, Ws), bool)
+    for step in range(max_steps):
+        alive &= t < max_len
+        if not alive.any():
+            break
+        p = [o[i] + t * dL[i] for i in range(3)]
+        b = [np.floor(p[i] * inv_bs).astype(np.int64) for i in range(3)]
+        q = [np.clip(np.floor((p[i] - b[i].astype(F) * bs) * inv_v).astype(np.int64), 0, 7) for i in range(3)]
+        rel = [b[i] - lo[i] for i in range(3)]
+        inside = np.all([(rel[i] >= 0) & (rel[i] < ext[i]) for i in range(3)], axis=0)
+        row = np.where(inside, table[tuple(np.clip(rel[i], 0, ext[i] - 1) for i in range(3))], -1)
+        lin = (q[0] * 8 + q[1]) * 8 + q[2]
+        Wv = np.where(row >= 0, tsdf[np.maximum(row, 0), lin, 1], F(0))
+        Dv = np.where(row >= 0, tsdf[np.maximum(row, 0), lin, 0], F(0))
+        valid = (row >= 0) & (Wv > F(1e-4))
+        fail = alive & ((~valid & last_pos) | (valid & (Dv < eps) & ~last_pos))
+        hit = alive & valid & (Dv < eps) & last_pos
+        t = np.where(hit, t + Dv, t).astype(F)
+        success |= hit
+        alive &= ~(fail | hit)
+        stepv = np.where(valid, Dv, trunc).astype(F)
+        t = np.where(alive, t + stepv, t).astype(F)
+        last_pos |= alive & valid
+    got = np.where(success, t * dC[2], F(-1.0)).astype(F)
+    assert want.shape == got.shape and (want > 0).mean() > 0.3
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
+def test_numpy_restatement_of_the_colour_update(oracle_mod):
+    """Same gate, the colour blend: A' = floor((A W + a w) / (W + w) + 0.5) per channel as uint8, W' = min(W + w, max) -- two frames."""
+    cfg = small_cfg(4)
+    orc = make_oracle(oracle_mod, 8)
+    trunc = F(F(4.0) * F(REF_PARAMS["voxel_size"]))
+    wm, max_w, sf = F(REF_PARAMS["appearance_measurement_weight"]), F(5.0), F(4.0)
+    col_idx, A, Wc = np.zeros((0, 3), np.int32), np.zeros((0, 512, 3), np.uint8), np.zeros((0, 512), F)
+    for k, i in enumerate((0, 6)):
+        f = S.frame(cfg, i, 0)
+        orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], None)
+        orc.add_color_frame(f["rgb"], f["T_W_C"], f["K"], None)
+        H, Wd = f["depth"].shape
+        tsdf_idx = orc.block_indices(0)
+        tsdf = orc.all_tsdf().reshape(-1, 512, 2)
+        synth = orc.synthetic_depth()
+        Hs, Ws = synth.shape
+        u, w, z, proj = _project(tsdf_idx, f["T_W_C"], f["K"], REF_PARAMS["voxel_size"], H, Wd, REF_PARAMS["max_integration_distance_m"])
+        cand = np.any((tsdf[..., 1] > 0) & (np.abs(tsdf[..., 0]) < trunc) & proj, axis=1)
+        cand_idx = tsdf_idx[cand]
+        have = {tuple(r) for r in col_idx.tolist()}
+        new = [r for r in cand_idx.tolist() if tuple(r) not in have]
+        col_idx = np.concatenate([col_idx, np.array(new, np.int32).reshape(-1, 3)])
+        A = np.concatenate([A, np.zeros((len(new), 512, 3), np.uint8)])
+        Wc = np.concatenate([Wc, np.zeros((len(new), 512), F)])
+        assert np.array_equal(orc.block_indices(1), col_idx)
+        where = {tuple(r): j for j, r in enumerate(col_idx.tolist())}
+        rows = np.array([where[tuple(r)] for r in cand_idx.tolist()])
+        uu, ww, zz, ok = u[cand], w[cand], z[cand], proj[cand].copy()
+        sx, sy, swx, swy, s_in = _footprint(uu / sf, ww / sf, Ws, Hs)
+        ok &= s_in
+        s00, s10, s01, s11 = synth[sy, sx], synth[sy, sx + 1], synth[sy + 1, sx], synth[sy + 1, sx + 1]
+        ok &= (s00 > 0) & (s10 > 0) & (s01 > 0) & (s11 > 0)
+        ok &= ~(np.abs(_bilin(s00, s10, s01, s11, swx, swy) - zz) > trunc)
+        x0, y0, wx, wy, f_in = _footprint(uu, ww, Wd, H)
+        ok &= f_in
+        rgb = f["rgb"].astype(F)
+        a = _bilin(rgb[y0, x0], rgb[y0, x0 + 1], rgb[y0 + 1, x0], rgb[y0 + 1, x0 + 1], wx[..., None], wy[..., None])
+        Wv = Wc[rows]
+        inv = F(1.0) / (Wv + wm)
+        An = np.floor((A[rows].astype(F) * Wv[..., None] + a * wm) * inv[..., None] + F(0.5)).astype(np.uint8)
+        Ar, Wr = A[rows], Wc[rows]
+        Ar[ok] = An[ok]
+        Wr[ok] = np.minimum(Wv + wm, max_w)[ok]
+        A[rows], Wc[rows] = Ar, Wr
+        orgb, ow = orc.all_colors()
+        assert np.array_equal(ow.reshape(-1, 512).view(np.uint32), Wc.view(np.uint32)) and np.array_equal(orgb.reshape(-1, 512, 3), A), k
+    assert int((Wc > 0).sum()) > 3000
