@@ -134,10 +134,19 @@ def _drain(args):
     return n / (time.perf_counter() - t0)
 
 
+def _drain_pinned(args):
+    path, seconds = args
+    from nvblox_mindmap_amd.data_loading.pinned_loader import drain
+
+    return drain(path, seconds=seconds, batch_size=8, threads=2, repeat=8)
+
+
 def test_eight_loader_instances_side_by_side(tmp_path, capsys):
-    """Eight single-process loaders at once on the reference's sample shape (512x512 PNGs, 768-channel rows; vertex count cut
-    to 4-5 k to keep the fixture small): aggregate samples/s with and without the cache, printed against what 8 GPUs consume
-    (8 x 343 samples/s at 10.7 step/s x 32).  Asserts only the direction: the cache must not be slower."""
+    """Eight loaders at once on the reference's sample shape (512x512 PNGs, 768-channel rows; vertex count cut to 4-5 k to keep the
+    fixture small) -- what an 8-GPU node asks of its host: aggregate samples/s of the reference-shaped per-sample path without and
+    with the raw copies, and of data_loading.PinnedBatchLoader (rows written in place, 2 threads per loader), printed against what 8
+    GPUs consume at the captured step's rate (8 x 836 samples/s; bench.py's train.file_fed leg measures the same on the GPU box under
+    its 16-CPU quota).  Asserts the direction only: each stage must not be slower than the one before."""
     d = str(tmp_path / "ds")
     write_synthetic_demo(os.path.join(d, "demo_00000"), 4, image_size=(512, 512), feature_dim=768, ngrippers=2, vertex_count_range=(4000, 5000))
     VC.convert_dataset(d)
@@ -147,7 +156,13 @@ def test_eight_loader_instances_side_by_side(tmp_path, capsys):
         for raw in (False, True):
             pool.map(_drain, [(d, raw, 2, k) for k in range(n_proc)])  # page cache, imports
             rates[raw] = sum(pool.map(_drain, [(d, raw, 8, k) for k in range(n_proc)]))
+        pool.map(_drain_pinned, [(d, 0.3)] * n_proc)
+        pinned = pool.map(_drain_pinned, [(d, 1.5)] * n_proc)
+    rates["pinned"] = sum(r["samples_per_s"] for r in pinned)
+    cpu_ms = sum(r["cpu_ms_per_sample"] for r in pinned) / len(pinned)
     with capsys.disabled():
-        print(f"\n[{n_proc} loader processes] aggregate samples/s: decompress-all {rates[False]:.0f}, memory-mapped cache {rates[True]:.0f} "
-              f"(8 GPUs consume {8 * 343}; {os.cpu_count()} host threads here)")
-    assert rates[True] >= rates[False]
+        print(f"\n[{n_proc} loader processes, {os.cpu_count()} host threads here] aggregate samples/s: decompress-all {rates[False]:.0f}, per-sample "
+              f"reads of the raw copies {rates[True]:.0f}, PinnedBatchLoader {rates['pinned']:.0f} ({cpu_ms:.2f} ms of CPU per sample) -- 8 GPUs "
+              f"consume {8 * 836}")
+    assert rates[True] >= rates[False] and rates["pinned"] >= rates[True]
+    assert all(r["slow_path_samples"] == 0 for r in pinned)
