@@ -73,6 +73,16 @@ __device__ __forceinline__ float madd(float a, float b, float c) {
   else
     return a * b + c;
 }
+// ---- scalar-register cap -------------------------------------------------------------------------------------------------------
+// The CU admits floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD (MI355X_MICROARCH.md, "Residency"): the per-voxel kernels'
+// natural 101-106 scalar registers mean SIX 256-thread workgroups per CU whatever the compiler's occupancy line says (7), and the
+// grids of the fused frame are a little larger than 6 x 256: the surplus forms a second round (k_alloc_tsdf: 106 of its 1 608
+// pair workgroups started 5-8 us late).  96 admits seven.  Applied where it measured faster (round 5, profiles/r05l_sgpr_cap.txt):
+// k_front_app 18.3 -> 17.3 us, k_alloc_tsdf 15.0 -> 14.7, the hash path's k_tsdf_pass / k_front_compact_big (+2 % frames/s); NOT
+// on k_front (its grid fits six per CU: 12.8 -> 12.9), the sphere tracers (+0.2 .. +0.5 us) or k_app_frame (neutral); 80 (eight per CU)
+// was slower everywhere it was tried.
+#define MMF_SGPR96 __attribute__((amdgpu_num_sgpr(96)))
+
 // ---- uniform constants in VECTOR registers ---------------------------------------------------------------------------------------
 // The per-voxel kernels keep ~100 launch constants live (transform, intrinsics, map constants, a dozen layer pointers) beside the
 // exec masks of their nested early-outs: the scalar file (<= 102) overflows and the allocator spills scalars into lanes of a vector

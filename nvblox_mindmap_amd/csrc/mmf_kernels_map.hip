@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_front(FrontArgs A) {
 // resident before the rays fill the chip, and long done when the last ray is.  APP: in a pipelined stream the previous frame's colour
 // update + feature gating follows as a fourth role (as in k_front_app); n_compact == 0: a frame without a pending decay.
 template <bool LDSFLAGS, bool APP>
-__global__ __launch_bounds__(256) void k_front_compact_big(FrontArgs A, LayerDev L, u64* lb, unsigned tag, int* rebuild, float decay_f, float decay_thr,
+__global__ __launch_bounds__(256) MMF_SGPR96 void k_front_compact_big(FrontArgs A, LayerDev L, u64* lb, unsigned tag, int* rebuild, float decay_f, float decay_thr,
                                                           int n_compact, AppArgs Acol, AppArgs Afeat, const float* __restrict__ synth, int Ws, int Hs,
                                                           int nb_gate) {
   extern __shared__ unsigned s_words[];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_front_compact_big(FrontArgs A, LayerDev
 // Two frames (two mappers fed by the same camera frame: mmf_integrate_frame_multi) in ONE launch: the workgroups of the second
 // follow those of the first.  Same role code, same results; the launch is as long as its slower half instead of their sum.
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_front2(FrontArgs A0, FrontArgs A1) {
+__global__ __launch_bounds__(256) MMF_SGPR96 void k_front2(FrontArgs A0, FrontArgs A1) {
   extern __shared__ unsigned s_words[];
   __shared__ FrontLds S;
   const int b = (int)blockIdx.x;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_front2(FrontArgs A0, FrontArgs A1) {
 // gating workgroups follow the frame's own (the longest rays decide when the launch ends; in front of the mask rows they cost
 // 1.7 us more); their LDS is the launch's dynamic block.
 template <bool LDSFLAGS>
-__global__ __launch_bounds__(256) void k_front_app(FrontArgs A, AppArgs Acol, AppArgs Afeat, const float* __restrict__ synth, int Ws, int Hs,
+__global__ __launch_bounds__(256) MMF_SGPR96 void k_front_app(FrontArgs A, AppArgs Acol, AppArgs Afeat, const float* __restrict__ synth, int Ws, int Hs,
                                                   int nb_gate) {
   extern __shared__ unsigned s_words[];
   __shared__ FrontLds S;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // block; a block's missing decays (cur_epoch - epoch[slot]) are applied before it is integrated, a block that is only looked at
 // is not written.  Not LAZY on a layer with lazy summaries (L.epoch != nullptr): the full pass that (re)establishes them.
 template <int VPT, bool MASKED, bool LAZY, bool FMA>
-__global__ __launch_bounds__(512 / VPT) void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
+__global__ __launch_bounds__(512 / VPT) MMF_SGPR96 void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                         const float* __restrict__ depth, const uint8_t* __restrict__ mask_arg,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
                                                         u64* __restrict__ cell_key, float decay_f, const int* __restrict__ work_n,
@@ -1117,7 +1117,7 @@ __device__ inline void tsdf_new_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, in
 // is published (at the end of the grid they only got a slot when earlier workgroups retired, and closed the launch ~2 us
 // after the pass over the existing blocks had ended).  The mask columns, short and needed by nobody in this launch, come
 // last: the TSDF pairs take every free slot at once and the columns fill in behind them.
-__global__ __launch_bounds__(256) void k_alloc_tsdf(AllocTsdfArgs A, int lead) {
+__global__ __launch_bounds__(256) MMF_SGPR96 void k_alloc_tsdf(AllocTsdfArgs A, int lead) {
   __shared__ AllocTsdfLds Q;
   const int b = (int)blockIdx.x;
   if (b < A.alloc_wgs) return alloc_role(A, Q, b);
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_alloc_tsdf(AllocTsdfArgs A, int lead) {
 
 // Two frames in one launch (mmf_integrate_frame_multi): BOTH frames' producers lead the grid,
 //   [alloc 0 | alloc 1 | new 0 | new 1 | padding | pairs 0 | pairs 1 | mask columns 0 | mask columns 1].
-__global__ __launch_bounds__(256) void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdfArgs A1, int lead) {
+__global__ __launch_bounds__(256) MMF_SGPR96 void k_alloc_tsdf2(AllocTsdfArgs A0, AllocTsdfArgs A1, int lead) {
   __shared__ AllocTsdfLds Q;
   int b = (int)blockIdx.x;
   if (b < A0.alloc_wgs) return alloc_role(A0, Q, b);

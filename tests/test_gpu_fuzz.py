@@ -5,7 +5,10 @@ dynamic region, then runs the reference's call sequence (nvblox_mapping_helpers.
 dynamic pair -- on the HIP path and the same frames through the oracle's add_depth/add_color/add_feature chain.
 
 Bar: block index lists equal in ORDER, TSDF within 1e-5 abs, feature halves and weights bit-equal, colours bit-equal, masks
-bit-equal.  Seeds are fixed: a failure reproduces."""
+bit-equal.  Seeds are fixed: a failure reproduces.  ``MMF_FUZZ_SEEDS=first:count`` runs that seed range INSTEAD (a campaign:
+``MMF_FUZZ_SEEDS=100:400 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -n 4``; profiles/r05j_fuzz_campaign.txt)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +18,14 @@ from nvblox_mindmap_amd import synthetic as S
 from fusion_common import make_oracle
 
 pytestmark = pytest.mark.gpu
+
+def _seeds(default):
+    spec = os.environ.get("MMF_FUZZ_SEEDS")
+    if not spec:
+        return range(default)
+    first, count = (int(v) for v in spec.split(":"))
+    return range(first, first + count)
+
 
 SIZES = [(96, 72), (128, 96), (136, 104), (160, 120), (200, 152), (216, 168), (320, 240), (328, 248)]
 CHANNELS = [8, 16, 24, 40, 64, 128]
@@ -39,7 +50,7 @@ def draw(seed):
         drift=[int(v) for v in r.integers(-5, 6, size=2)], hole_mode=hole_mode)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24))
 def test_random_configuration_matches_oracle(oracle_mod, seed, monkeypatch):
     import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
     from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID, NvbloxMappingCfg
@@ -119,7 +130,7 @@ def draw_parameters(seed):
                 use_mask=bool(r.integers(2)), color=bool(r.integers(2)), decay=bool(r.integers(2)))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", _seeds(16))
 def test_random_parameters_stand_alone_calls_match_oracle(oracle_mod, seed):
     """The nvblox_torch surface call by call (decay / add_depth_frame / add_color_frame / add_feature_frame, then the feature
     mesh and a rendered depth image) with integrator parameters off the reference's defaults: truncation distance, weighting
@@ -172,7 +183,7 @@ def test_random_parameters_stand_alone_calls_match_oracle(oracle_mod, seed):
 
 
 @pytest.mark.parametrize("pipelined", [False, True])
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path, pipelined):
     """A random walk over the Mapper's entry points on a two-mapper Mapper -- decay, the fused frame, the same frame call by
     call, the fused frame from a low-res feature map, both mappers in one call, clear, mesh update, save + load into a NEW

@@ -33,7 +33,8 @@ def main():
     for i in range(24):
         B.step(m, mcfg, frames[i])
     torch.cuda.synchronize()
-    cap = 6 * 8192
+    phases = "--phases" in sys.argv  # in-workgroup phase marks of the TSDF pairs role (thread 0's block): slots 6 .. 8
+    cap = (9 if phases else 6) * 8192
     buf = torch.zeros(3 * cap, dtype=torch.int64, device=dev)
     _lib.check(_lib.lib().mmf_debug_wg_trace(_lib.dptr(buf), cap), "mmf_debug_wg_trace")
     try:
@@ -43,6 +44,21 @@ def main():
             B.step(m, mcfg, frames[i])
             torch.cuda.synchronize()
             rec = buf.cpu().numpy().reshape(cap, 3)
+            if phases:
+                a, b, c = rec[6 * 8192:7 * 8192], rec[7 * 8192:8 * 8192], rec[8 * 8192:9 * 8192]
+                rec = rec[:6 * 8192]
+                for kind, name in ((2, "integrated this frame (cand)"), (1, "looked at only (appearance flag)")):
+                    sel = a[:, 0] == kind
+                    if not sel.any():
+                        continue
+                    t_begin, t_known, t_vox, t_loop, t_store, t_end = a[sel, 1], a[sel, 2], b[sel, 0], b[sel, 1], b[sel, 2], c[sel, 0]
+                    us = lambda x: x / 100.0
+                    tot = us(t_end - t_begin)
+                    print(f"  TSDF pairs, blocks {name}: n={int(sel.sum())}  whole workgroup mean {tot.mean():.2f} us (p90 {np.percentile(tot, 90):.2f}, max {tot.max():.2f})")
+                    for label, d in (("list -> slot -> key -> raycast flag known", us(t_known - t_begin)), ("voxels arrived (16-byte loads)", us(t_vox - t_known)),
+                                     ("voxel loop (4 voxels: projection, depth taps, update)", us(t_loop - t_vox)), ("stores acknowledged", us(t_store - t_loop)),
+                                     ("reductions + barrier + summary writes", us(t_end - t_store))):
+                        print(f"      {label:56s} mean {d.mean():5.2f}  p90 {np.percentile(d, 90):5.2f}  max {d.max():5.2f} us")
             if "--starts" in sys.argv:  # when do the workgroups of launch 2 (k_alloc_tsdf) start, by dispatch index?
                 blk = rec[2 * 8192:3 * 8192]  # role ids 30 / 31 share the slot range of ids 3x; 2x: the range before
                 for lo, name in ((1, "ids 2x (allocation, mask columns)"), (2, "ids 3x (TSDF pairs, new-block waiters)")):
@@ -85,6 +101,18 @@ def main():
                       f"| mean iterations wide {wide.mean():.1f} narrow {narrow.mean():.1f}")
             t0 = rec[:, 1].min()
             print(f"frame {i}: {len(rec)} workgroup records, span {(rec[:, 2].max() - t0) / 100.0:.1f} us")
+            if "--waiters" in sys.argv:  # every new-block waiter / allocation workgroup of launch 2: start -> end, relative to the launch's first start
+                l2 = rec[(rec[:, 0] >= 20) & (rec[:, 0] < 40)]
+                if len(l2):
+                    t2 = l2[:, 1].min()
+                    for rid in (20, 31):
+                        r = l2[l2[:, 0] == rid]
+                        print(f"    {NAMES[rid]}: " + " ".join(f"{(a - t2) / 100.0:.1f}-{(b - t2) / 100.0:.1f}" for a, b in sorted(zip(r[:, 1].tolist(), r[:, 2].tolist()), key=lambda x: x[1])))
+                    pr = l2[l2[:, 0] == 30]
+                    en = np.sort((pr[:, 2] - t2) / 100.0)
+                    print(f"    existing-block pairs: ends at percentiles 50/90/99/100 = {np.percentile(en, 50):.1f} / {np.percentile(en, 90):.1f} / {np.percentile(en, 99):.1f} / {en.max():.1f} us; "
+                          f"{int(((pr[:, 1] - t2) / 100.0 > 3.0).sum())} of {len(pr)} start later than 3 us")
+                    pass
             for rid in sorted(set(rec[:, 0].tolist()), key=lambda r: rec[rec[:, 0] == r, 1].min()):
                 r = rec[rec[:, 0] == rid]
                 st, en = (r[:, 1] - t0) / 100.0, (r[:, 2] - t0) / 100.0
