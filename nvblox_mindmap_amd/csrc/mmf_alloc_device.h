@@ -330,9 +330,8 @@ __device__ inline void alloc_job_body(const AllocJob& J, long long* stats, int* 
 // workgroups are dispatched in index order and never wait on a later one), so the whole job is one load round trip + one
 // workgroup scan + the writes instead of a pass per 2 048 cells in sequence.  Same candidate order, slot assignment and
 // outputs as alloc_job_body<true, 0>.  Every granted new block is also published to the launch as it is assigned: three
-// self-validating 64-bit words {tag | slot}, {tag | key low}, {tag | key high} at J.pub[kPubRec + 3 * rank ..] -- the two key words as
-// soon as the block's rank is known, the slot word when its slot is (a free-stack pop later); the last workgroup publishes the number of
-// granted blocks {tag | n} at J.pub[0].  All with relaxed agent-scope atomics, no fences: a
+// self-validating 64-bit words {tag | slot}, {tag | key low}, {tag | key high} at J.pub[kPubRec + 3 * rank ..]; the last
+// workgroup publishes the number of granted blocks {tag | n} at J.pub[0].  All with relaxed agent-scope atomics, no fences: a
 // reader polls until the tag of the word it needs is this launch's.  The grid flags are left set: the launch's TSDF
 // workgroups read them too; a later launch of the frame clears them.
 // (kPubRec, kAllocMaxWgs: mmf_device.h)
@@ -437,37 +436,6 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
   const int old_live = ctx[0], old_free = ctx[1], old_bump = ctx[2];
   const int room = carry[2] ? 0 : ctx[3];  // a failed prefix wait: no slot is granted by this workgroup
   if (nf && !carry[2]) {
-    // Pass 0 -- the KEYS of the granted new blocks, the moment their ranks are known: a waiter of the launch integrates a new block
-    // from zeroed voxels and needs nothing but the key to do so; the slot (below: a free-stack pop, a dependent load, and the index /
-    // list stores) is only needed for its stores.  Pass 1 -- every free-stack pop in flight before the first is consumed.
-    int sl[CPT];
-    {
-      int rnk = carry[1] + eb;
-      int gx = gx0, gy = gy0, gz = gz0;
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          sl[4 * g + k] = d[4 * g + k] - 1;
-          if (((f[g] >> (8 * k)) & 0xffu) && d[4 * g + k] == 0) {
-            if (rnk < room) {
-              const u64 key = pack_key(gx + ks.ox, gy + ks.oy, gz + ks.oz);
-              u64* rec = J.pub + kPubRec + 3 * (size_t)rnk;
-              __hip_atomic_store(rec + 1, tg | (key & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(rec + 2, tg | (key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              sl[4 * g + k] = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
-            }
-            rnk++;
-          }
-          if (++gz == ks.nz) {
-            gz = 0;
-            if (++gy == ks.ny) {
-              gy = 0;
-              ++gx;
-            }
-          }
-        }
-    }
     int pos = carry[0] + ea, rnk = carry[1] + eb;
     int gx = gx0, gy = gy0, gz = gz0;
 #pragma unroll
@@ -480,11 +448,14 @@ __device__ inline void alloc_grid_multi_body(const AllocJob& J, long long* stats
           const bool is_new = slot < 0;
           if (is_new) {
             if (rnk < room) {
-              slot = sl[4 * g + k];
+              slot = rnk < old_free ? L.free_stack[old_free - 1 - rnk] : old_bump + (rnk - old_free);
               L.dense[dense_cell(L, gx + ks.ox, gy + ks.oy, gz + ks.oz)] = (unsigned short)(slot + 1);
               L.slot_key[slot] = key;
               L.live[old_live + rnk] = slot;
-              __hip_atomic_store(J.pub + kPubRec + 3 * (size_t)rnk, tg | (u64)(unsigned)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              u64* rec = J.pub + kPubRec + 3 * (size_t)rnk;
+              __hip_atomic_store(rec, tg | (u64)(unsigned)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(rec + 1, tg | (key & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(rec + 2, tg | (key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             rnk++;
           }

@@ -202,10 +202,7 @@ struct KeySrc {
 };
 
 // One compaction + allocation job (flags -> ordered candidate list, new blocks inserted) for one layer.
-#ifndef MMF_NEW_WGS
-#define MMF_NEW_WGS 32
-#endif
-constexpr int kNewBlockWgs = MMF_NEW_WGS;  // waiter workgroups of k_alloc_tsdf (new blocks of the frame)
+constexpr int kNewBlockWgs = 32;  // waiter workgroups of k_alloc_tsdf (new blocks of the frame)
 constexpr int kPubRec = 16;       // AllocJob::pub: [0] total, [1 .. 8] per-workgroup counts, [kPubRec ..] new-block records
 constexpr int kAllocMaxWgs = 8;   // kFusedAllocMaxCells / 2 048
 

@@ -626,19 +626,11 @@ struct TsdfBlockAcc {
 template <int VPT, bool MASKED, bool LAGLOOP = false, bool FMA = false>
 __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
                                         const uint8_t* __restrict__ mask, float min_d, float decay_f, int lag, bool may_write, int bx, int by,
-                                        int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc,
-                                        long long* ph = nullptr, float4* keep = nullptr, const float4* pre = nullptr) {
+                                        int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc) {
   constexpr int NP = VPT / 2;
   float4 av[NP];
-  // `pre`: the caller already holds vox[0 .. NP) (loaded beside the block's key: one dependent round earlier)
 #pragma unroll
-  for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : (pre ? pre[q] : vox[q]);
-#ifdef MMF_WG_TRACE
-  if (ph) {  // phase marks of tools/wg_trace.py --phases: the voxels have arrived
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    ph[1] = (long long)wall_clock64();
-  }
-#endif
+  for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
   const bool decayed = lag > 0;  // uniform
   if (LAGLOOP) {
     for (int l = 0; l < lag; ++l) {
@@ -679,22 +671,10 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
     acc.wmx = fmaxf(acc.wmx, W);
     acc.wmn = fminf(acc.wmn, W);
   }
-#ifdef MMF_WG_TRACE
-  if (ph) ph[2] = (long long)wall_clock64();  // the voxel loop is done
-#endif
-  if (keep) {  // the caller stores them itself (a new block whose slot is not known yet)
-#pragma unroll
-    for (int q = 0; q < NP; ++q) keep[q] = av[q];
-  } else if (may_write && (upd || is_new || decayed)) {
+  if (may_write && (upd || is_new || decayed)) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) vox[q] = av[q];
   }
-#ifdef MMF_WG_TRACE
-  if (ph) {  // the stores have been acknowledged
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    ph[3] = (long long)wall_clock64();
-  }
-#endif
 }
 
 template <bool FMA>
@@ -897,36 +877,26 @@ struct TsdfPairLds {
 
 // One block by one half (128 threads) of the workgroup; `par` alternates between consecutive calls of a workgroup so that
 // the reduction scratch of one call is not overwritten before everybody has read it.  Contains ONE barrier: call uniformly.
-// Two stages: the voxel update (tsdf_frame_compute; `keep` != nullptr: the voxels stay in registers, `slot` is not used) and the
-// block's summaries (tsdf_frame_finish: the barrier, flags / wmax / block_free writes).
-struct TsdfHalfAcc {
+__device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int par, bool act, int i,
+                                        int slot, u64 key, bool cand, bool is_new) {
+  const int t = threadIdx.x & 127, wv = threadIdx.x >> 6;
+  const MapConsts& mc = P.mc;
   int hit = 0, freev = 1;
   float wmx = 0.0f;
-};
-__device__ inline TsdfHalfAcc tsdf_frame_compute(const LayerDev& L, const TsdfFrameArgs& P, bool act, int slot, u64 key, bool cand, bool is_new,
-                                                 long long* ph = nullptr, float4* keep = nullptr, const float4* pre = nullptr) {
-  const int t = threadIdx.x & 127;
-  TsdfHalfAcc H;
   const bool decayed = P.decay_f > 0.0f;  // uniform
   if (act) {
     int bx, by, bz;
     unpack_key(key, bx, by, bz);
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + t * 2;
     TsdfBlockAcc acc;
-    tsdf_voxel_group<4, false>(P.mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, decayed ? 1 : 0, true, bx, by, bz, t * 4, cand, is_new, vox,
-                               acc, ph, keep, pre);
-    H.hit = acc.hit;
-    H.freev = acc.freev;
-    H.wmx = acc.wmx;
+    tsdf_voxel_group<4, false>(mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, decayed ? 1 : 0, true, bx, by, bz, t * 4, cand, is_new, vox,
+                               acc);
+    hit = acc.hit;
+    freev = acc.freev;
+    wmx = acc.wmx;
   }
-  return H;
-}
-__device__ inline void tsdf_frame_finish(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int par, bool act, int i, int slot, u64 key,
-                                         bool cand, const TsdfHalfAcc& H) {
-  const int t = threadIdx.x & 127, wv = threadIdx.x >> 6;
-  const bool decayed = P.decay_f > 0.0f;  // uniform
-  const int w_free = __all(H.freev), w_hit = __any(H.hit);
-  const float wmx = wave_max_f32(H.wmx);
+  const int w_free = __all(freev), w_hit = __any(hit);
+  wmx = wave_max_f32(wmx);
   if ((threadIdx.x & 63) == 0) {
     S.free_[par][wv] = w_free;
     S.hit[par][wv] = w_hit;
@@ -942,28 +912,21 @@ __device__ inline void tsdf_frame_finish(const LayerDev& L, const TsdfFrameArgs&
     L.wmax[slot] = fmaxf(S.wmax[par][h2], S.wmax[par][h2 + 1]);
   }
 }
-__device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int par, bool act, int i,
-                                        int slot, u64 key, bool cand, bool is_new, long long* ph = nullptr, const float4* pre = nullptr) {
-  const TsdfHalfAcc H = tsdf_frame_compute(L, P, act, slot, key, cand, is_new, ph, nullptr, pre);
-  tsdf_frame_finish(L, P, S, par, act, i, slot, key, cand, H);
-}
 
-// One round of the new-block hand-over: the two halves of the workgroup take ranks k0 and k0 + 1.  A rank's KEY words are published
-// as soon as the allocation knows the rank, its SLOT word a free-stack pop and a few stores later (alloc_grid_multi_body): the half
-// integrates the block from zeroed voxels INTO REGISTERS with the key alone, then fetches the slot (published by then) and stores.
-// Workgroup-uniform result: 1 = round done, 0 = the published total says there is no rank k0 (ranks are granted in
-// order: nothing beyond a missing one), -1 = a half did not see a word of its record within `bound` polls (nothing was stored).
+// One round of the new-block hand-over: the two halves of the workgroup take ranks k0 and k0 + 1 as soon as the allocation
+// workgroups of this launch have published them (they may still be scanning later cells) and integrate them from zeroed
+// voxels.  Workgroup-uniform result: 1 = round done, 0 = the published total says there is no rank k0 (ranks are granted in
+// order: nothing beyond a missing one), -1 = a half did not see its record within `bound` polls.
 __device__ inline int new_block_round(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int& par, int k0, int n_old, int bound,
                                       bool pretend_timeout) {
   const int half = threadIdx.x >> 7;
   const int k = k0 + half;
-  const u64* rec = P.pub + kPubRec + 3 * (size_t)k;
   if ((threadIdx.x & 127) == 0) {
     int got = 0;
-    u64 w1 = 0;
+    u64 w0 = 0;
     for (int spins = 0; spins < bound && !pretend_timeout; ++spins) {
-      w1 = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(w1 >> 32) == P.tag) {
+      w0 = __hip_atomic_load(P.pub + kPubRec + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(w0 >> 32) == P.tag) {
         got = 1;
         break;
       }
@@ -978,12 +941,14 @@ __device__ inline int new_block_round(const LayerDev& L, const TsdfFrameArgs& P,
       __builtin_amdgcn_s_sleep(4);
     }
     if (got == 1) {
-      u64 w2;
+      u64 w1, w2;
       int spins = 0;
       do {
-        w2 = __hip_atomic_load(rec + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((unsigned)(w2 >> 32) != P.tag && ++spins < bound);
-      if ((unsigned)(w2 >> 32) != P.tag) got = 0;
+        w1 = __hip_atomic_load(P.pub + kPubRec + 1 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w2 = __hip_atomic_load(P.pub + kPubRec + 2 + 3 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while (((unsigned)(w1 >> 32) != P.tag || (unsigned)(w2 >> 32) != P.tag) && ++spins < bound);
+      if ((unsigned)(w1 >> 32) != P.tag || (unsigned)(w2 >> 32) != P.tag) got = 0;
+      S.slot[half] = (int)(unsigned)(w0 & 0xffffffffull);
       S.klo[half] = (unsigned)(w1 & 0xffffffffull);
       S.khi[half] = (unsigned)(w2 & 0xffffffffull);
     }
@@ -998,31 +963,10 @@ __device__ inline int new_block_round(const LayerDev& L, const TsdfFrameArgs& P,
     status = 0;
   if (status == 1) {
     const bool act = S.act[half] != 0;
+    const int slot = S.slot[half];
     const u64 key = ((u64)S.khi[half] << 32) | (u64)S.klo[half];
-    float4 av[2];
-    const TsdfHalfAcc H = tsdf_frame_compute(L, P, act, 0, key, true, true, nullptr, av);
-    if ((threadIdx.x & 127) == 0 && act) {  // the slot: published while this half was integrating
-      u64 w0;
-      int spins = 0;
-      do {
-        w0 = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((unsigned)(w0 >> 32) != P.tag && ++spins < bound);
-      if ((unsigned)(w0 >> 32) != P.tag) S.act[half] = -1;
-      S.slot[half] = (int)(unsigned)(w0 & 0xffffffffull);
-    }
-    __syncthreads();
-    if (S.act[0] < 0 || S.act[1] < 0) {
-      status = -1;
-    } else {
-      const int slot = S.slot[half];
-      if (act) {
-        float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + (threadIdx.x & 127) * 2;
-        vox[0] = av[0];
-        vox[1] = av[1];
-      }
-      tsdf_frame_finish(L, P, S, par, act, n_old + k, slot, key, true, H);
-      par ^= 1;
-    }
+    tsdf_frame_block(L, P, S, par, act, n_old + k, slot, key, true, true);
+    par ^= 1;
   }
   __syncthreads();  // S.slot / klo / khi / act are rewritten by the next round
   return status;
@@ -1119,10 +1063,7 @@ struct AllocTsdfLds {
 
 __device__ inline void alloc_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, int w) {
   const long long tr0 = wg_trace_begin();
-#ifndef MMF_ALLOC_G
-#define MMF_ALLOC_G 2
-#endif
-  alloc_grid_multi_body<4, MMF_ALLOC_G>(A.J, A.stats, Q.lds, Q.carry, Q.ctx, w, A.alloc_wgs);
+  alloc_grid_multi_body<4, 2>(A.J, A.stats, Q.lds, Q.carry, Q.ctx, w, A.alloc_wgs);
   wg_trace_end(tr0, kTrAllocJob);
 }
 
@@ -1150,52 +1091,16 @@ __device__ inline void tsdf_pairs_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, 
     int slot = 0;
     u64 key = 0;
     bool cand = false;
-#ifdef MMF_PRELOAD_VOX
-    float4 pre[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-#endif
     if (act) {
       slot = L.live[i];
       key = L.slot_key[slot];
-#ifdef MMF_PRELOAD_VOX
-      // the block's voxels travel beside its key: their address needs the slot only (one dependent round less in front of the update)
-      const float4* vox = reinterpret_cast<const float4*>(L.pool) + (size_t)slot * (kVPB / 2) + (threadIdx.x & 127) * 2;
-      pre[0] = vox[0];
-      pre[1] = vox[1];
-#endif
       int bx, by, bz;
       unpack_key(key, bx, by, bz);
       const int gx = bx - P.ox, gy = by - P.oy, gz = bz - P.oz;
       if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.nx && gy < P.ny && gz < P.nz)
         cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] == (uint8_t)P.grid_tag;
     }
-#ifdef MMF_WG_TRACE
-    long long ph[5] = {0, 0, 0, 0, 0};
-    if (wg_trace_on()) {  // (thread 0's view: the first block of the pair)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      ph[0] = (long long)wall_clock64();  // slot, key and the raycast flag are known
-    }
-#ifdef MMF_PRELOAD_VOX
-    tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false, wg_trace_on() ? ph : nullptr, pre);
-#else
-    tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false, wg_trace_on() ? ph : nullptr);
-#endif
-    if (wg_trace_on() && threadIdx.x == 0 && blockIdx.x < 8192) {
-      ph[4] = (long long)wall_clock64();
-      // slots 6 .. 8 of the trace buffer (tools/wg_trace.py allocates 9 x 8192 records with --phases)
-      if (g_wg_trace_cap >= 9 * 8192) {
-        unsigned long long* r = g_wg_trace + 3 * (6 * 8192 + (int)blockIdx.x);
-        r[0] = (unsigned long long)(cand ? 2 : 1), r[1] = (unsigned long long)tr0, r[2] = (unsigned long long)ph[0];
-        r = g_wg_trace + 3 * (7 * 8192 + (int)blockIdx.x);
-        r[0] = (unsigned long long)ph[1], r[1] = (unsigned long long)ph[2], r[2] = (unsigned long long)ph[3];
-        r = g_wg_trace + 3 * (8 * 8192 + (int)blockIdx.x);
-        r[0] = (unsigned long long)ph[4];
-      }
-    }
-#elif defined(MMF_PRELOAD_VOX)
-    tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false, nullptr, pre);
-#else
     tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false);
-#endif
   }
   wg_trace_end(tr0, kTrTsdfPass);
 }
@@ -1904,7 +1809,7 @@ AllocTsdfArgs make_alloc_tsdf_args(const AllocJob& job, long long* stats, const 
   P.host_err = job.host_err;
   P.debug_abandon = job.debug_abandon;
   A.mask_rows = M.Hf;
-  A.alloc_wgs = (job.ncells + 1024 * MMF_ALLOC_G - 1) / (1024 * MMF_ALLOC_G);  // alloc_grid_multi_body<4, G>: 1 024 G cells per workgroup (<= kAllocMaxWgs)
+  A.alloc_wgs = (job.ncells + 2047) / 2048;  // alloc_grid_multi_body<4, 2>: 2 048 cells per workgroup (<= kAllocMaxWgs)
   return A;
 }
 
