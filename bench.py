@@ -430,8 +430,8 @@ def main():
 
         build = source_hash()
         pmc_stamp = counters_stamp(os.path.join(ROOT, "profiles", "latest_pmc.json"))
-        sq_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_summary.json"))
-        sq_stamp = counters_stamp(os.path.join(ROOT, "profiles", sq_files[-1])) if sq_files else None
+        sq_file = latest_sq_summary()
+        sq_stamp = counters_stamp(os.path.join(ROOT, "profiles", sq_file)) if sq_file else None
         roofline["build_csrc_sha16"] = build
         roofline["traffic_csrc_sha16"] = pmc_stamp
         roofline["sq_counters_csrc_sha16"] = sq_stamp

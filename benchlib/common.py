@@ -162,11 +162,30 @@ def counters_stamp(path):
     except Exception:
         return None
 
-def sq_evidence():
-    """Per-kernel SQ summary of the latest committed counter run (a replayed constant like roofline.traffic: labelled)."""
+def latest_sq_summary():
+    """File name (under profiles/) of the SQ counter summary the bench replays: the one collected on the sources of THIS build when
+    there is one (`__csrc_sha16__`), else the last by name -- which `counters_stale` then reports."""
     files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_summary.json"))
     if not files:
+        return None
+    try:
+        from nvblox_mindmap_amd._lib import source_hash
+
+        build = source_hash()
+        for f in reversed(files):
+            if counters_stamp(os.path.join(ROOT, "profiles", f)) == build:
+                return f
+    except Exception:
+        pass
+    return files[-1]
+
+
+def sq_evidence():
+    """Per-kernel SQ summary of the latest committed counter run (a replayed constant like roofline.traffic: labelled)."""
+    name = latest_sq_summary()
+    if not name:
         return {}, None
+    files = [name]
     with open(os.path.join(ROOT, "profiles", files[-1])) as fh:
         raw = json.load(fh)
     out = {}
