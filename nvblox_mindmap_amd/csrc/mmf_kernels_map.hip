@@ -626,11 +626,18 @@ struct TsdfBlockAcc {
 template <int VPT, bool MASKED, bool LAGLOOP = false, bool FMA = false>
 __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
                                         const uint8_t* __restrict__ mask, float min_d, float decay_f, int lag, bool may_write, int bx, int by,
-                                        int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc) {
+                                        int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc,
+                                        long long* ph = nullptr) {
   constexpr int NP = VPT / 2;
   float4 av[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
+#ifdef MMF_WG_TRACE
+  if (ph) {  // phase marks of tools/wg_trace.py --phases (instrumented build only): the voxels have arrived
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ph[1] = (long long)wall_clock64();
+  }
+#endif
   const bool decayed = lag > 0;  // uniform
   if (LAGLOOP) {
     for (int l = 0; l < lag; ++l) {
@@ -671,10 +678,19 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
     acc.wmx = fmaxf(acc.wmx, W);
     acc.wmn = fminf(acc.wmn, W);
   }
+#ifdef MMF_WG_TRACE
+  if (ph) ph[2] = (long long)wall_clock64();  // the voxel loop is done
+#endif
   if (may_write && (upd || is_new || decayed)) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) vox[q] = av[q];
   }
+#ifdef MMF_WG_TRACE
+  if (ph) {  // the stores have been acknowledged
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ph[3] = (long long)wall_clock64();
+  }
+#endif
 }
 
 template <bool FMA>
@@ -878,7 +894,7 @@ struct TsdfPairLds {
 // One block by one half (128 threads) of the workgroup; `par` alternates between consecutive calls of a workgroup so that
 // the reduction scratch of one call is not overwritten before everybody has read it.  Contains ONE barrier: call uniformly.
 __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& P, TsdfPairLds& S, int par, bool act, int i,
-                                        int slot, u64 key, bool cand, bool is_new) {
+                                        int slot, u64 key, bool cand, bool is_new, long long* ph = nullptr) {
   const int t = threadIdx.x & 127, wv = threadIdx.x >> 6;
   const MapConsts& mc = P.mc;
   int hit = 0, freev = 1;
@@ -890,7 +906,7 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + t * 2;
     TsdfBlockAcc acc;
     tsdf_voxel_group<4, false>(mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, decayed ? 1 : 0, true, bx, by, bz, t * 4, cand, is_new, vox,
-                               acc);
+                               acc, ph);
     hit = acc.hit;
     freev = acc.freev;
     wmx = acc.wmx;
@@ -1100,7 +1116,26 @@ __device__ inline void tsdf_pairs_role(const AllocTsdfArgs& A, AllocTsdfLds& Q, 
       if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.nx && gy < P.ny && gz < P.nz)
         cand = P.grid_flags[(gx * P.ny + gy) * P.nz + gz] == (uint8_t)P.grid_tag;
     }
+#ifdef MMF_WG_TRACE
+    // in-workgroup phases of thread 0's block (tools/wg_trace.py --phases): slots 6 .. 8 of a 9 x 8192-record trace buffer
+    long long ph[5] = {0, 0, 0, 0, 0};
+    if (wg_trace_on()) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      ph[0] = (long long)wall_clock64();  // slot, key and the raycast flag are known
+    }
+    tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false, wg_trace_on() ? ph : nullptr);
+    if (wg_trace_on() && threadIdx.x == 0 && blockIdx.x < 8192 && g_wg_trace_cap >= 9 * 8192) {
+      ph[4] = (long long)wall_clock64();
+      unsigned long long* r = g_wg_trace + 3 * (6 * 8192 + (int)blockIdx.x);
+      r[0] = (unsigned long long)(cand ? 2 : 1), r[1] = (unsigned long long)tr0, r[2] = (unsigned long long)ph[0];
+      r = g_wg_trace + 3 * (7 * 8192 + (int)blockIdx.x);
+      r[0] = (unsigned long long)ph[1], r[1] = (unsigned long long)ph[2], r[2] = (unsigned long long)ph[3];
+      r = g_wg_trace + 3 * (8 * 8192 + (int)blockIdx.x);
+      r[0] = (unsigned long long)ph[4];
+    }
+#else
     tsdf_frame_block(L, P, Q.S, par, act, i, slot, key, cand, false);
+#endif
   }
   wg_trace_end(tr0, kTrTsdfPass);
 }
