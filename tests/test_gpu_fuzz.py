@@ -298,6 +298,7 @@ def test_random_call_sequences_match_oracle(oracle_mod, seed, tmp_path, pipeline
             gpu.set_deferred_feature_rows(pipelined)
             for j in range(2):
                 gpu.load_from_file(paths[j], j)
+                os.remove(paths[j])  # (a campaign of thousands of seeds otherwise fills /tmp: pytest keeps tmp_path until the session ends)
         elif op == "query":
             pts = r.uniform(-0.4, 0.9, size=(257, 3)).astype(np.float32)
             assert np.array_equal(gpu.query_layer(QueryType.TSDF, dev(pts), mid).cpu().numpy(), orcs[mid].query_tsdf(pts)), log
