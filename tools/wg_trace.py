@@ -95,6 +95,13 @@ def main():
             tr = rec[:, 0] == 41
             if tr.any():  # sphere trace: longest wide / narrow iteration counts per workgroup ride in the record id
                 wide, narrow, dur = extra[tr] & 0xfff, extra[tr] >> 12, (rec[tr, 2] - rec[tr, 1]) / 100.0
+                if len(dur) > 50:  # what a round costs: least squares of the patch duration on its longest ray's round counts
+                    A = np.stack([np.ones_like(dur), wide.astype(np.float64), narrow.astype(np.float64)], axis=1)
+                    coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+                    res = dur - A @ coef
+                    print(f"  sphere trace: duration ~ {coef[0]:.2f} + {coef[1]:.2f} x wide rounds + {coef[2]:.2f} x narrow rounds us (rms residual {np.sqrt((res ** 2).mean()):.2f}); "
+                          f"histogram of (wide, narrow): " + ", ".join(f"({a},{b}): {int(((wide == a) & (narrow == b)).sum())} at {dur[(wide == a) & (narrow == b)].mean():.1f}"
+                                                                      for a in range(0, 7) for b in range(0, 5) if ((wide == a) & (narrow == b)).sum() >= 10))
                 order = np.argsort(-dur)[:6]
                 print("  sphere trace, slowest workgroups (us, wide iterations, narrow iterations):",
                       ", ".join(f"{dur[o]:.1f}/{wide[o]}/{narrow[o]}" for o in order),
