@@ -94,7 +94,14 @@ def main():
                     print(f"    correlation(duration, survivors) = {np.corrcoef(dur[live], surv[live])[0, 1]:.2f}")
             tr = rec[:, 0] == 41
             if tr.any():  # sphere trace: longest wide / narrow iteration counts per workgroup ride in the record id
-                wide, narrow, dur = extra[tr] & 0xfff, extra[tr] >> 12, (rec[tr, 2] - rec[tr, 1]) / 100.0
+                wide, narrow, dur = extra[tr] & 0xfff, (extra[tr] >> 12) & 0xfff, (rec[tr, 2] - rec[tr, 1]) / 100.0
+                hi = extra[tr] >> 24  # narrow rounds of the patch's 16 rays by how they ended, and their steps
+                miss, full, plain, fin, steps = hi & 63, (hi >> 6) & 63, (hi >> 12) & 63, (hi >> 18) & 63, (hi >> 24) & 255
+                nr = miss + full + plain + fin
+                if nr.sum() > 0:
+                    print(f"  narrow rounds of all rays: {int(nr.sum())} in {int((nr > 0).sum())} patches; ended by: voxel not among the 16 probes {miss.sum() / nr.sum():.2f}, "
+                          f"all 16 steps taken {full.sum() / nr.sum():.2f}, a plain step (back to wide) {plain.sum() / nr.sum():.2f}, ray finished {fin.sum() / nr.sum():.2f}; "
+                          f"steps per round {steps.sum() / max(nr.sum(), 1):.1f} (step counts saturate at 255 per patch)")
                 if len(dur) > 50:  # what a round costs: least squares of the patch duration on its longest ray's round counts
                     A = np.stack([np.ones_like(dur), wide.astype(np.float64), narrow.astype(np.float64)], axis=1)
                     coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
