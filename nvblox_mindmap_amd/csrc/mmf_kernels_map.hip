@@ -581,8 +581,9 @@ __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict
   return true;
 }
 
-// ---- THE projective TSDF update of one voxel (spec: oracle/mmf_oracle.c, "TSDF update"): the only copy; k_tsdf_integrate (stand-alone
-// add_depth_frame), k_tsdf_pass (hash path / unfused) and tsdf_frame_block (k_alloc_tsdf*, the fused frame) all come here.
+// ---- THE projective TSDF update of one voxel (spec: oracle/mmf_oracle.c, "TSDF update"), in its branching form: k_tsdf_integrate and the
+// MASKED passes (stand-alone add_depth_frame with a mask) come here; the unmasked passes of the fused frame and of the hash path run the
+// same rules branch-free (tsdf_voxel_group_bf below -- the second and last copy, bit-identical to this one over every suite).
 //   in_view <- the voxel centre projects into the image, not beyond the maximum integration distance (evaluated when `want_view`);
 //   if `cand` (the block is integrated this frame) and in view and the depth sample is valid and sdf >= -trunc and w > 0:
 //     D <- clamp((sdf w + D W) / (w + W), +-trunc),  W <- min(W + w, max_weight);  returns true iff D / W changed.
@@ -693,6 +694,118 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
 #endif
 }
 
+// ---- the same voxel loop BRANCH-FREE (unmasked depth image only: the fused frame's / the hash path's) -----------------------------
+// tsdf_voxel_update is a cascade of early-outs: per voxel ~60 scalar instructions of exec-mask management and ~15 branches around
+// ~144 vector instructions that nearly every wave executes anyway (some lane needs them).  Here every voxel of a block that is
+// integrated runs the whole update and the result is SELECTED: the 2 x 2 footprint is clamped into the image (it always contains the
+// nearest tap and IS the bilinear footprint whenever that exists), voxels that are not updated compute on garbage that is discarded
+// (no trap on this target).  The same float operations on every voxel that is updated: bit-identical to tsdf_voxel_group over the parity,
+// fuzz, soak and hash suites.  Measured (round 5, profiles/r05p_branch_free.txt): k_alloc_tsdf 14.6 -> 14.3 us, the lazy pass of the hash
+// path 116 -> 112 us.  tsdf_voxel_group stays for the masked stand-alone calls (its mask taps are worth skipping).
+template <int VPT, bool LAGLOOP, bool FMA>
+__device__ inline void tsdf_voxel_group_bf(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth, float min_d,
+                                           float decay_f, int lag, bool may_write, int bx, int by, int bz, int lin0, bool cand, bool is_new,
+                                           float4* __restrict__ vox, TsdfBlockAcc& acc, long long* ph = nullptr) {
+  constexpr int NP = VPT / 2;
+  float4 av[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) av[q] = is_new ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : vox[q];
+#ifdef MMF_WG_TRACE
+  if (ph) {  // phase marks of tools/wg_trace.py --phases (instrumented build only): the voxels have arrived
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ph[1] = (long long)wall_clock64();
+  }
+#endif
+  const bool decayed = lag > 0;  // uniform
+  if (LAGLOOP) {
+    for (int l = 0; l < lag; ++l) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        av[q].y = av[q].y * decay_f;
+        av[q].w = av[q].w * decay_f;
+      }
+    }
+  } else if (decayed) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      av[q].y = av[q].y * decay_f;
+      av[q].w = av[q].w * decay_f;
+    }
+  }
+  bool upd_any = false;
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    float4& a = av[r >> 1];
+    const bool hi = (r & 1) != 0;
+    float D = hi ? a.z : a.x, W = hi ? a.w : a.y;
+    const bool want = cand || (W > 0.0f && fabsf(D) < mc.trunc);
+    float c[3], p[3];
+    voxel_centre<FMA>(mc, bx, by, bz, lin0 + r, c);
+    xform<FMA>(T_C_L, c, p);
+    const float iz = 1.0f / p[2];
+    const float uu = madd<FMA>(cam.fx, p[0] * iz, cam.cx);
+    const float vv = madd<FMA>(cam.fy, p[1] * iz, cam.cy);
+    const bool proj = !(p[2] <= 1e-6f) && !(uu < 0.0f || vv < 0.0f || uu > (float)cam.W || vv > (float)cam.H);
+    const bool inview = want && proj && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
+    if (cand) {  // uniform over the block
+      const float uc = uu - 0.5f, vc = vv - 0.5f;
+      const float fx0 = floorf(uc), fy0 = floorf(vc);
+      const int ix = (int)fx0, iy = (int)fy0;
+      const bool fp_ok = !(ix < 0 || iy < 0 || ix + 1 > cam.W - 1 || iy + 1 > cam.H - 1);
+      const float wx = uc - fx0, wy = vc - fy0;
+      const int x0c = ix < 0 ? 0 : (ix > cam.W - 2 ? cam.W - 2 : ix), y0c = iy < 0 ? 0 : (iy > cam.H - 2 ? cam.H - 2 : iy);
+      int xn = ifloor(uu), yn = ifloor(vv);
+      xn = xn > cam.W - 1 ? cam.W - 1 : (xn < 0 ? 0 : xn);
+      yn = yn > cam.H - 1 ? cam.H - 1 : (yn < 0 ? 0 : yn);
+      const int sel = ((yn - y0c) << 1) | (xn - x0c);  // which of the four taps is the nearest one (always among them for a projecting voxel)
+      const unsigned i0 = (unsigned)y0c * (unsigned)cam.W + (unsigned)x0c;
+      const float2_u q0 = *reinterpret_cast<const float2_u*>(depth + i0);
+      const float2_u q1 = *reinterpret_cast<const float2_u*>(depth + i0 + cam.W);
+      const float a00 = q0.x, a10 = q0.y, a01 = q1.x, a11 = q1.y;
+      const float dn = (sel & 2) ? ((sel & 1) ? a11 : a01) : ((sel & 1) ? a10 : a00);
+      const bool vn = depth_ok(dn, min_d);
+      bool lin = fp_ok && depth_ok(a00, min_d) && depth_ok(a10, min_d) && depth_ok(a01, min_d) && depth_ok(a11, min_d);
+      if (mc.lin_md > 0.0f)  // uniform
+        lin = lin && !(fabsf(a00 - dn) > mc.lin_md || fabsf(a10 - dn) > mc.lin_md || fabsf(a01 - dn) > mc.lin_md || fabsf(a11 - dn) > mc.lin_md);
+      const float d = lin ? bilin<FMA>(a00, a10, a01, a11, wx, wy) : dn;
+      const float sdf = d - p[2];
+      const float wm = tsdf_measurement_weight(mc, d, sdf);
+      float Dn = madd2<FMA>(sdf, wm, D, W) / (wm + W);
+      Dn = Dn > 0.0f ? fminf(mc.trunc, Dn) : fmaxf(-mc.trunc, Dn);
+      const bool upd = inview && vn && !(sdf < -mc.trunc) && (wm > 0.0f);
+      D = upd ? Dn : D;
+      W = upd ? fminf(W + wm, mc.max_weight) : W;
+      upd_any |= upd;
+    }
+    if (hi) {
+      a.z = D;
+      a.w = W;
+    } else {
+      a.x = D;
+      a.y = W;
+    }
+    const bool near = W > 0.0f && fabsf(D) < mc.trunc;
+    acc.hit |= (near && inview) ? 1 : 0;
+    acc.band |= near ? 1 : 0;
+    acc.freev &= (W > 1e-4f && D == mc.trunc) ? 1 : 0;
+    acc.wmx = fmaxf(acc.wmx, W);
+    acc.wmn = fminf(acc.wmn, W);
+  }
+#ifdef MMF_WG_TRACE
+  if (ph) ph[2] = (long long)wall_clock64();  // the voxel loop is done
+#endif
+  if (may_write && (upd_any || is_new || decayed)) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) vox[q] = av[q];
+  }
+#ifdef MMF_WG_TRACE
+  if (ph) {  // the stores have been acknowledged
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ph[3] = (long long)wall_clock64();
+  }
+#endif
+}
+
 template <bool FMA>
 __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        const float* __restrict__ depth,
@@ -750,7 +863,7 @@ __global__ __launch_bounds__(512 / VPT) MMF_SGPR96 void k_tsdf_pass(LayerDev L, 
   // (uniform constants of the voxel loop in vector registers: mmf_device.h vgpr())
   rigid_to_vgprs(T_C_L);
   cam_to_vgprs(cam);
-  update_consts_to_vgprs(mc);
+  if constexpr (MASKED) update_consts_to_vgprs(mc);  // (the branch-free voxel group keeps them scalar: 68 VGPRs = seven waves per SIMD; 74 with them)
   const int n = LAZY ? *work_n : L.ctr[0];
   const int chunk = (n + 7) >> 3;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
@@ -772,7 +885,10 @@ __global__ __launch_bounds__(512 / VPT) MMF_SGPR96 void k_tsdf_pass(LayerDev L, 
     const float f = LAZY ? L.lag_f : decay_f;
     const bool writes = !LAZY || cand;
     TsdfBlockAcc acc;
-    tsdf_voxel_group<VPT, MASKED, LAZY, FMA>(mc, cam, T_C_L, depth, mask, min_d, f, lag, writes, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
+    if constexpr (!MASKED)
+      tsdf_voxel_group_bf<VPT, LAZY, FMA>(mc, cam, T_C_L, depth, min_d, f, lag, writes, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
+    else
+      tsdf_voxel_group<VPT, MASKED, LAZY, FMA>(mc, cam, T_C_L, depth, mask, min_d, f, lag, writes, bx, by, bz, threadIdx.x * VPT, cand, is_new, vox, acc);
     const int hit = acc.hit, freev = acc.freev;
     float wmx = acc.wmx, wmn = acc.wmn;
     if (writes && (cand || lag > 0)) {  // workgroup-uniform: the block's voxels changed -> its empty-space summary may have
@@ -905,8 +1021,7 @@ __device__ inline void tsdf_frame_block(const LayerDev& L, const TsdfFrameArgs& 
     unpack_key(key, bx, by, bz);
     float4* vox = reinterpret_cast<float4*>(L.pool) + (size_t)slot * (kVPB / 2) + t * 2;
     TsdfBlockAcc acc;
-    tsdf_voxel_group<4, false>(mc, P.cam, P.T_C_L, P.depth, nullptr, 0.0f, P.decay_f, decayed ? 1 : 0, true, bx, by, bz, t * 4, cand, is_new, vox,
-                               acc, ph);
+    tsdf_voxel_group_bf<4, false, false>(mc, P.cam, P.T_C_L, P.depth, 0.0f, P.decay_f, decayed ? 1 : 0, true, bx, by, bz, t * 4, cand, is_new, vox, acc, ph);
     hit = acc.hit;
     freev = acc.freev;
     wmx = acc.wmx;

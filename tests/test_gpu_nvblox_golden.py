@@ -5,6 +5,7 @@ nvblox vectors have been dumped into tests/golden/nvblox_*.npz, the HIP integrat
 block-index sets + 1e-5 abs (north_star), or at least the reference's own regression tolerances
 (mindmap/tests/utils/comparisons.py:95-109).  Skipped until such a file exists: hot-path parity is "unpinned"."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -22,7 +23,9 @@ def test_kit_runs_on_the_drop_in_and_matches_consumer_and_oracle(tmp_path):
     assert meta["backend"].startswith("nvblox_mindmap_amd") and int(gold["n_vertices"]) > 100
     hip = NG.compare(gold, NG.replay_like(gold, NG.mmf_backend(), "cuda"))
     assert NG.passes_north_star(hip, tol=0.0), hip
-    orc = NG.compare(gold, NG.replay_like(gold, NG.oracle_backend(), "cpu"))
+    # (under MMF_FMA_CONTRACTION=1 the drop-in's mappers default to the spec switch: the checker is given the same)
+    fma = {"fma_contraction": 1} if os.environ.get("MMF_FMA_CONTRACTION", "0") == "1" else {}
+    orc = NG.compare(gold, NG.replay_like(gold, NG.oracle_backend(**fma), "cpu"))
     assert NG.passes_north_star(orc), orc
     assert orc["tsdf_max_abs_distance_diff"] == 0.0 and orc["feature_max_abs_diff"] == 0.0, orc
 
