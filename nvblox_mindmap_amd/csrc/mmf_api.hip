@@ -929,7 +929,8 @@ int mmf_add_depth_frame(mmf_handle h, int mapper_id, const float* depth, const u
   ViewGrid vg;
   MMF_TRY(compute_view_grid(*m, cam, T_L_C, vg));
   const int ncells = vg.nx * vg.ny * vg.nz;
-  bool fast = m->allow_merged && m->tsdf.d.dense != nullptr && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap);
+  // (H, W >= 2: the fused launch's branch-free voxel loop clamps a 2 x 2 footprint into the image; one-row / one-column images take the chain below)
+  bool fast = m->allow_merged && m->tsdf.d.dense != nullptr && ncells > 0 && alloc_jobs_fusable(ncells, m->tsdf.d.cap) && H >= 2 && W >= 2;
   MaskJob M;
   if (fast) {
     MMF_TRY(ensure_mask_scratch(*m, H, W));

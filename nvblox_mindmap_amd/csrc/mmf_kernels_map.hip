@@ -1889,7 +1889,9 @@ template <bool FMA>
 static void launch_tsdf_pass_t(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                                const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
   const dim3 grid(grid_for(hinted(L.hint_live, L.cap), 8192));
-  if (mask)
+  // (an image of one row or one column has no 2 x 2 footprint to clamp into: the branch-free voxel loop needs W, H >= 2 -- the branching
+  // form, which accepts a null mask, takes such images)
+  if (mask || cam.W < 2 || cam.H < 2)
     hipLaunchKernelGGL((k_tsdf_pass<4, true, false, FMA>), grid, dim3(128), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f,
                        (const int*)nullptr, (const int*)nullptr);
   else
@@ -1912,7 +1914,14 @@ void launch_tsdf_pass_lazy(const LayerDev& L, const MapConsts& mc, const Cam& ca
   int* cnt = work + (parity & 1);
   int* nxt = work + ((parity & 1) ^ 1);
   hipLaunchKernelGGL(k_tsdf_classify, dim3((unsigned)((live + 1023) / 1024)), dim3(1024), 0, s, L, stamp, flags, cnt, nxt, work + 2);
-  if (mc.spec_flags & kSpecFma)
+  if (cam.W < 2 || cam.H < 2) {  // (degenerate image: the branching form, see launch_tsdf_pass_t)
+    if (mc.spec_flags & kSpecFma)
+      hipLaunchKernelGGL((k_tsdf_pass<4, true, true, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
+                         0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
+    else
+      hipLaunchKernelGGL((k_tsdf_pass<4, true, true, false>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
+                         0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
+  } else if (mc.spec_flags & kSpecFma)
     hipLaunchKernelGGL((k_tsdf_pass<4, false, true, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
                        0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
   else

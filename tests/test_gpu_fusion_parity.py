@@ -576,6 +576,33 @@ def test_degenerate_frames(oracle_mod):
     assert gpu.tsdf_layer_view(0).num_allocated_blocks() > 100
 
 
+@pytest.mark.parametrize("route", ["bounded", "hash"])
+@pytest.mark.parametrize("shape", [(1, 96), (48, 1), (2, 2)])
+def test_one_row_and_one_column_depth_images(oracle_mod, route, shape):
+    """Images without a 2 x 2 footprint (one row, one column) and the smallest one with exactly one: the stand-alone call takes them
+    (the reference's API does not forbid them).  The fused launches' branch-free voxel loop clamps a 2 x 2 footprint into the image and
+    therefore needs two rows and two columns -- thinner images must be routed to the branching form (mmf_api.hip, launch_tsdf_pass_t):
+    HIP == oracle bit for bit, with and without a mask, and nothing is read outside the image (a 1 x W image sits at the very end of
+    its allocation here)."""
+    h, w = shape
+    cfg = small_cfg(4)
+    f = S.frame(cfg, 2, 16)
+    over = {} if route == "bounded" else dict(workspace_bounds_type=0, max_integration_distance_m=2.5)
+    K = f["K"].copy()
+    K[0, 2], K[1, 2] = (w - 1) / 2.0, (h - 1) / 2.0  # the principal point inside the strip
+    r0, c0 = f["depth"].shape[0] // 2, f["depth"].shape[1] // 2
+    depth = np.ascontiguousarray(f["depth"][r0 - h // 2: r0 - h // 2 + h, c0 - w // 2: c0 - w // 2 + w]).astype(np.float32)
+    assert depth.shape == (h, w) and (depth > 0).any()
+    for use_mask in (False, True):
+        gpu, orc = make_mapper(16, **over), make_oracle(oracle_mod, 16, **over)
+        mask = (np.arange(h * w).reshape(h, w) % 5 != 0).astype(np.uint8) if use_mask else None
+        for _ in range(2):
+            orc.add_depth_frame(depth, f["T_W_C"], K, mask)
+            gpu.add_depth_frame(dev(depth), torch.from_numpy(f["T_W_C"]), torch.from_numpy(K), None if mask is None else dev(mask), 0)
+        assert orc.block_indices(0).shape[0] > 0
+        compare_tsdf(orc, gpu)
+
+
 @pytest.mark.parametrize("route", ["fused", "hash", "no_max_distance"])
 def test_non_finite_depth_pixels(oracle_mod, route):
     """What a simulated depth camera delivers for rays that hit nothing: +inf (Isaac Lab's distance_to_image_plane), and NaN /
