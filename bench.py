@@ -192,10 +192,20 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     torch.cuda.set_device(device)
     dist = None
+    forced = world == 1 and os.environ.get("BENCH_FORCE_DIST", "0") == "1"
     if world > 1:
         import torch.distributed as dist  # RCCL via backend "nccl": barrier + max-reduce of the timing, DDP all-reduce
 
         dist.init_process_group(backend=backend, init_method="env://")
+    elif forced:
+        # BENCH_FORCE_DIST=1 on one GPU: a process group of ONE rank over RCCL, and every collective an N-rank run issues is issued
+        # (barriers around the timed regions, the device-tensor max-reduce, the weight broadcast, the flat-gradient all-reduce between
+        # the two HIP graphs, DDP's wrapper) -- the 8-GPU launch must not be the first time backend="nccl" runs in this code base
+        import torch.distributed as dist
+        from nvblox_mindmap_amd.training.distributed import force_collectives, free_port
+
+        dist.init_process_group(backend=backend, init_method=f"tcp://127.0.0.1:{free_port()}", world_size=1, rank=0)
+        force_collectives(True)
 
     if args.file_fed_only:
         out = run_training_file_fed(device, compute_bound_step_per_s=None)

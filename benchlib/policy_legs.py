@@ -129,7 +129,7 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
     from nvblox_mindmap_amd.training import (BackbonePrefetcher, build_model, build_optimizer, synthetic_batch, train_one_step,
                                              wrap_ddp)
-    from nvblox_mindmap_amd.training.distributed import barrier, max_over_ranks
+    from nvblox_mindmap_amd.training.distributed import barrier, collectives_active, max_over_ranks
 
     torch.manual_seed(0)
     cfg = DiffuserActorConfig(backbone_matmul_dtype=backbone_matmul_dtype)
@@ -157,13 +157,14 @@ def run_training(device, world, steps=8, warmup=3, per_gpu_batch=32, backbone_ma
     run(steps, warmup, feats)
     torch.cuda.synchronize(device)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, device if torch.distributed.get_backend() == "nccl" else None) if world > 1 else \
+    dt = max_over_ranks(time.perf_counter() - t0, device if torch.distributed.get_backend() == "nccl" else None) if collectives_active() else \
         time.perf_counter() - t0
     out = {"step_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "samples_per_s": steps * per_gpu_batch * world / dt,
            "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world, "steps": steps, "warmup": warmup,
            "trainable_params": n_train, "frozen_backbone_params": n_frozen, "dtype": "f32", "backbone_prefetch": bool(prefetch_backbone),
            "backbone_matmuls": backbone_matmul_dtype,
            "allreduce_payload_MB": n_train * 4 / 1e6, "parallelism": f"dp{world}" if world > 1 else "single",
+           "ddp_wrapped": ddp is not model,
            "model": "diffuser_actor RGBD_AND_MESH, 1 cam 512x512, 2048 vertices x 768, frozen ViT-B/16-shaped backbone (random init)"}
     del model, ddp, opt, batches
     torch.cuda.empty_cache()
@@ -179,7 +180,7 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
     ones reaches, and every rank's own step time."""
     from nvblox_mindmap_amd.diffuser_actor import DiffuserActorConfig
     from nvblox_mindmap_amd.training import GraphedTrainStep, all_gather_objects, build_model, synthetic_batch
-    from nvblox_mindmap_amd.training.distributed import barrier, max_over_ranks
+    from nvblox_mindmap_amd.training.distributed import barrier, collectives_active, max_over_ranks
 
     torch.manual_seed(0)
     cfg = DiffuserActorConfig(backbone_matmul_dtype=backbone_matmul_dtype)
@@ -207,11 +208,12 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
     mine = time.perf_counter() - t0
     barrier()
     el = time.perf_counter() - t0
-    nccl = world > 1 and torch.distributed.get_backend() == "nccl"
-    dt = max_over_ranks(el, device if nccl else None) if world > 1 else el
+    coll = collectives_active()  # world > 1, or the forced one-rank group (BENCH_FORCE_DIST=1)
+    nccl = coll and torch.distributed.get_backend() == "nccl"
+    dt = max_over_ranks(el, device if nccl else None) if coll else el
     per_rank = [r["ms"] for r in all_gather_objects({"ms": mine / steps * 1e3})]
     allreduce = None
-    if world > 1:  # a second, short region with HIP events around the collective (kept out of the headline region)
+    if g.collective:  # a second, short region with HIP events around the collective (kept out of the headline region)
         g.time_allreduce = True
         run(6, warmup + steps)
         ms = g.collect_allreduce_ms()
@@ -224,7 +226,8 @@ def run_training_graphed(device, world, steps=20, warmup=5, per_gpu_batch=32, ba
            "backbone_matmuls": backbone_matmul_dtype, "backbone_overlap": bool(g.overlap),
            "host_enqueue_ms_per_step": host_s / steps * 1e3, "host_enqueue_frac": host_s / mine,
            "host_cpu_ms_per_step": host_cpu_s / steps * 1e3,
-           "rccl_world_observed": observed, "allreduce": allreduce, "allreduce_payload_MB": g.flat_grad.numel() * 4 / 1e6,
+           "rccl_world_observed": observed, "collective_backend": torch.distributed.get_backend() if coll else None,
+           "collectives_forced_on_one_rank": bool(coll and world == 1), "allreduce": allreduce, "allreduce_payload_MB": g.flat_grad.numel() * 4 / 1e6,
            "per_rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank), "all": per_rank},
            "trainable_params_in_flat_buffer": int(g.n_total), "unused_parameter_tensors": len(g.unused_names),
            "capture_s": capture_s, "tuned_gemms": bool(g.tuned_gemms), "runtime_env": {"ROC_AQL_QUEUE_SIZE": os.environ.get("ROC_AQL_QUEUE_SIZE")}, "parallelism": f"dp{world}" if world > 1 else "single",

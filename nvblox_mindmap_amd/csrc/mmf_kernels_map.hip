@@ -748,13 +748,16 @@ __device__ inline void tsdf_voxel_group_bf(const MapConsts& mc, const Cam& cam, 
     const bool proj = !(p[2] <= 1e-6f) && !(uu < 0.0f || vv < 0.0f || uu > (float)cam.W || vv > (float)cam.H);
     const bool inview = want && proj && !(mc.max_dist > 0.0f && p[2] > mc.max_dist);
     if (cand) {  // uniform over the block
-      const float uc = uu - 0.5f, vc = vv - 0.5f;
+      // This form converts for EVERY voxel of a candidate block, also those that do not project (p[2] ~ 0: uu = inf / NaN / beyond
+      // int's range, whose conversion is undefined): clamp in float first.  A projecting voxel has uu in [0, W], vv in [0, H] -- inside
+      // the clamps, so its values are unchanged; the others get defined indices and are discarded by `inview` as before.
+      const float uc = fminf(fmaxf(uu - 0.5f, -1.0f), (float)cam.W), vc = fminf(fmaxf(vv - 0.5f, -1.0f), (float)cam.H);
       const float fx0 = floorf(uc), fy0 = floorf(vc);
       const int ix = (int)fx0, iy = (int)fy0;
-      const bool fp_ok = !(ix < 0 || iy < 0 || ix + 1 > cam.W - 1 || iy + 1 > cam.H - 1);
+      const bool fp_ok = !(ix < 0 || iy < 0 || ix > cam.W - 2 || iy > cam.H - 2);
       const float wx = uc - fx0, wy = vc - fy0;
       const int x0c = ix < 0 ? 0 : (ix > cam.W - 2 ? cam.W - 2 : ix), y0c = iy < 0 ? 0 : (iy > cam.H - 2 ? cam.H - 2 : iy);
-      int xn = ifloor(uu), yn = ifloor(vv);
+      int xn = ifloor(fminf(fmaxf(uu, 0.0f), (float)cam.W)), yn = ifloor(fminf(fmaxf(vv, 0.0f), (float)cam.H));
       xn = xn > cam.W - 1 ? cam.W - 1 : (xn < 0 ? 0 : xn);
       yn = yn > cam.H - 1 ? cam.H - 1 : (yn < 0 ? 0 : yn);
       const int sel = ((yn - y0c) << 1) | (xn - x0c);  // which of the four taps is the nearest one (always among them for a projecting voxel)

@@ -78,7 +78,7 @@ class MindmapFrameDataset(Dataset):
     def __len__(self) -> int:
         return len(self.samples)
 
-    def _sample_from_raw(self, raw_path: str, geometric, seed, source: str = None):
+    def _sample_from_raw(self, raw_path: str, geometric, seed, source: str = None, generator=None):
         """``sample_to_n_vertices`` on the mapped file: ALL vertices are read (6 B each) and augmented / noised exactly as on
         the decompressed path (same RNG draws), the selection is drawn on the same V, and only the selected FEATURE rows are
         touched.  Returns what the decompressed path returns."""
@@ -90,7 +90,7 @@ class MindmapFrameDataset(Dataset):
         if method == VertexSamplingMethod.NONE or n == want:
             return vertices.to(torch.float32), torch.from_numpy(np.array(f_map)), torch.ones(n, dtype=torch.bool)
         if n > want:
-            sel = select_vertex_indices(n, want, method, "cpu", seed, vertices[:, 2])
+            sel = select_vertex_indices(n, want, method, "cpu", seed, vertices[:, 2], generator)
             rows = sel.numpy()
             order = np.argsort(rows, kind="stable")  # ascending file offsets for the page cache; undone below
             feats = np.empty((want, f_map.shape[1]), dtype=np.float16)
@@ -104,16 +104,24 @@ class MindmapFrameDataset(Dataset):
         return verts.to(torch.float32), feats, valid
 
     def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
+        return self.get(idx)
+
+    def get(self, idx: int, generator: Optional[torch.Generator] = None, pyrandom=None) -> Dict[str, torch.Tensor]:
+        """Sample ``idx``.  Without arguments this is ``__getitem__``: the random draws (vertex selection, pose noise, augmentation)
+        come from the process-wide generators and a seeded dataset calls ``torch.manual_seed(seed + idx)``, exactly like the
+        reference's dataset inside a DataLoader WORKER PROCESS.  A loader THREAD of the training process (data_loading/pinned_loader.py)
+        passes its own ``generator`` (torch, CPU) and ``pyrandom`` (``random.Random``): the same values for the same seed, and the
+        generators the trainer draws its diffusion noise from are neither reseeded nor raced."""
         it = self.samples[idx]
         out = {}
         if self.augmentor is not None:
-            self.augmentor.reset()  # a new transform for this sample, shared by all its geometric items (dataset.py:451-454)
+            self.augmentor.reset(pyrandom)  # a new transform for this sample, shared by all its geometric items (dataset.py:451-454)
 
         def geometric(x, noisy: bool):
             if self.augmentor is not None:
                 x = self.augmentor(x)
             if noisy and self.noiser is not None:
-                x = self.noiser(x)
+                x = self.noiser(x, generator)
             return x
 
         rgb, depth, pose, intr = [], [], [], []
@@ -136,7 +144,7 @@ class MindmapFrameDataset(Dataset):
             sampled = None
             if raw is not None and os.path.exists(raw):
                 try:
-                    sampled = self._sample_from_raw(raw, geometric, seed, it["vertex_features"])
+                    sampled = self._sample_from_raw(raw, geometric, seed, it["vertex_features"], generator)
                 except VC.StaleRawCopy as e:  # a regenerated dataset with old copies lying around: the .zst is the truth
                     D._warn_stale(str(e))
             if sampled is not None:
@@ -147,7 +155,7 @@ class MindmapFrameDataset(Dataset):
                     s["vertices"] = geometric(s["vertices"].to(torch.float32), noisy=True)
                 # sample the stored f16 rows, convert afterwards: the same N rows as sampling the float32 copy (selection / padding
                 # do no arithmetic), without a float32 copy of the whole [V, C] matrix (37 MB at V = 12 k, C = 768) per sample
-                v, f, valid = sample_to_n_vertices(s["vertices"], s["features"], self.num_vertices, self.method, seed)
+                v, f, valid = sample_to_n_vertices(s["vertices"], s["features"], self.num_vertices, self.method, seed, generator)
                 out["vertices"], out["vertex_features"], out["vertices_valid_mask"] = v.to(torch.float32), f.to(torch.float16), valid
         return out
 

@@ -54,7 +54,11 @@ class PinnedBatchLoader:
         self.n_threads, self.n_slots, self.seed, self.rank, self.world = int(threads), int(slots), int(seed), int(rank), int(world_size)
         self.epoch = 0
         pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
-        first = dataset[0]  # shapes and dtypes of a sample (the reference path)
+        # shapes and dtypes of a sample (the reference path), drawn from a generator of our own: building a loader inside the training
+        # process must not reseed / advance the generators the trainer draws from
+        import random as _random
+
+        first = dataset.get(0, generator=torch.Generator().manual_seed(int(seed)), pyrandom=_random.Random(int(seed)))
         self.keys = list(first.keys())
         self.buffers: List[Dict[str, torch.Tensor]] = []
         for _ in range(self.n_slots):
@@ -63,7 +67,7 @@ class PinnedBatchLoader:
         self.pinned = pin
         self._lib = _lib.lib()
         self._meta: Dict[int, object] = {}
-        self._slow_lock = threading.Lock()  # __getitem__ draws from torch's global generator
+        self._slow_lock = threading.Lock()  # the dataset's augmentor keeps the current sample's transform in ITS state: one sample at a time
         self._cv = threading.Condition()
         self._tasks: "queue.SimpleQueue" = queue.SimpleQueue()
         self._done = [0] * self.n_slots          # rows filled per slot
@@ -125,7 +129,8 @@ class PinnedBatchLoader:
             self._meta[idx] = m
         if m is False:
             with self._slow_lock:
-                s = self.ds[idx]
+                # this thread's own generators (never torch.manual_seed / the process-wide ones: the trainer's noise comes from those)
+                s = self.ds.get(idx, generator=tls["gen"], pyrandom=tls["pyrandom"])
             for k in self.keys:
                 self.buffers[slot][k][row].copy_(s[k])
             tls["slow"] += 1
@@ -177,7 +182,9 @@ class PinnedBatchLoader:
         torch.set_num_threads(1)
         gen = torch.Generator()
         gen.manual_seed((self.seed * 1000003 + 7919 * (tid + 1) + 104729 * self.rank) & 0x7FFFFFFF)
-        tls = {"gen": gen, "rows": torch.empty(max(self.ds.num_vertices, 1), dtype=torch.int64),
+        import random as _random
+
+        tls = {"gen": gen, "pyrandom": _random.Random(int(gen.initial_seed())), "rows": torch.empty(max(self.ds.num_vertices, 1), dtype=torch.int64),
                "verts16": np.empty((max(self.ds.num_vertices, 1), 3), dtype=np.float16), "slow": 0}
         while True:
             task = self._tasks.get()
@@ -201,8 +208,15 @@ class PinnedBatchLoader:
                 self._cv.notify_all()
 
     # ---- batches ---------------------------------------------------------------------------------------------------------------
+    def samples_per_rank(self) -> int:
+        """The SAME number on every rank: the index order is padded (wrapping around) to a multiple of the world size before it is
+        strided, as torch's DistributedSampler -- and catalyst's DistributedSamplerWrapper over it, which the reference uses
+        (mindmap/data_loading/dataset.py:566-583) -- does.  Ranks with different batch counts would leave one of them alone in the
+        gradient all-reduce at the end of an epoch."""
+        return -(-len(self.ds) // self.world)
+
     def __len__(self) -> int:
-        n = len(range(self.rank, len(self.ds), self.world))
+        n = self.samples_per_rank()
         return n // self.B if self.drop_last else -(-n // self.B)
 
     def set_epoch(self, epoch: int) -> None:
@@ -216,7 +230,10 @@ class PinnedBatchLoader:
             order = torch.randperm(n, generator=g).tolist()
         else:
             order = list(range(n))
-        return order[self.rank::self.world]  # rank-strided, as the reference's DistributedSamplerWrapper partitions
+        total = self.samples_per_rank() * self.world
+        if total > n:
+            order = order + order[: total - n]  # (pad by wrapping around, like DistributedSampler; n >= 1 here)
+        return order[self.rank:total:self.world]  # rank-strided, as the reference's DistributedSamplerWrapper partitions
 
     def release(self, batch: HostBatch, event=None) -> None:
         """The consumer is done with the batch's host memory -- now, or (``event``: a recorded torch.cuda.Event) once the device

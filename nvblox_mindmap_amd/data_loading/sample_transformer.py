@@ -49,22 +49,25 @@ def _euler_xyz_to_quaternion(angles_rad: torch.Tensor) -> torch.Tensor:
     return torch.where(q[..., :1] < 0, -q, q)
 
 
-def random_transform_uniform(random_translation_range_m, random_rpy_range_deg):
+def random_transform_uniform(random_translation_range_m, random_rpy_range_deg, rng=None):
     """One rigid transform, translation and roll / pitch / yaw uniform in the given (lower, upper) bounds; six draws from
-    Python's ``random``, translation first, like the reference (:188-219).  Returns (translation [3], quaternion [4])."""
-    import random
+    Python's ``random`` (or ``rng``, a ``random.Random`` of the caller's own), translation first, like the reference (:188-219).
+    Returns (translation [3], quaternion [4])."""
+    import random as _random
+
+    random = rng if rng is not None else _random
 
     t = torch.tensor([random.uniform(random_translation_range_m[0][i], random_translation_range_m[1][i]) for i in range(3)])
     rpy = torch.tensor([random.uniform(random_rpy_range_deg[0][i], random_rpy_range_deg[1][i]) for i in range(3)])
     return t, _euler_xyz_to_quaternion(torch.deg2rad(rpy))
 
 
-def random_transform_gaussian(pos_stddev_m: float, rot_stddev_deg: float, num_transforms: int):
+def random_transform_gaussian(pos_stddev_m: float, rot_stddev_deg: float, num_transforms: int, generator=None):
     """``num_transforms`` independent small transforms: zero-mean Gaussian translation and roll / pitch / yaw (two
     ``torch.normal`` draws of shape [N, 3], translation first, :222-245).  Returns ([N, 3], [N, 4])."""
     shape = (num_transforms, 3)
-    t = torch.normal(mean=torch.zeros(shape), std=torch.full(shape, pos_stddev_m))
-    rpy = torch.normal(mean=torch.zeros(shape), std=torch.full(shape, torch.deg2rad(torch.tensor(rot_stddev_deg))))
+    t = torch.normal(mean=torch.zeros(shape), std=torch.full(shape, pos_stddev_m), generator=generator)
+    rpy = torch.normal(mean=torch.zeros(shape), std=torch.full(shape, torch.deg2rad(torch.tensor(rot_stddev_deg))), generator=generator)
     return t, _euler_xyz_to_quaternion(rpy)
 
 
@@ -104,9 +107,9 @@ class GeometryAugmentor(SampleTransformer):
         self._transform = None
         self.reset()
 
-    def reset(self):
+    def reset(self, rng=None):
         if self._t_range is not None and self._rpy_range is not None:
-            self._transform = random_transform_uniform(self._t_range, self._rpy_range)
+            self._transform = random_transform_uniform(self._t_range, self._rpy_range, rng)
 
     def __call__(self, sample):
         return _with_geometry(sample, apply_random_transform_to_sample(_geometry(sample), *self._transform))
@@ -120,9 +123,9 @@ class GeometryNoiser(SampleTransformer):
     def __init__(self, pos_stddev_m: float, rot_stddev_deg: float):
         self._pos, self._rot = pos_stddev_m, rot_stddev_deg
 
-    def __call__(self, sample):
+    def __call__(self, sample, generator=None):
         x = _geometry(sample)
-        t, q = random_transform_gaussian(self._pos, self._rot, x.shape[0])
+        t, q = random_transform_gaussian(self._pos, self._rot, x.shape[0], generator)
         for _ in range(x.dim() - 2):
             t, q = t.unsqueeze(1), q.unsqueeze(1)
         return _with_geometry(sample, apply_random_transform_to_sample(x, t.to(x.device), q.to(x.device)))

@@ -9,17 +9,20 @@ import torch
 from .. import _lib
 
 
-def randperm_prefix(n: int, k: int) -> torch.Tensor:
-    """``torch.randperm(n)[:k]`` (CPU default generator; int64, host) with the same draws and the same generator state
-    afterwards, in O(k) swaps: ``mmf_host_randperm_prefix`` advances torch's own serialised generator state.  A generator
+def randperm_prefix(n: int, k: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """``torch.randperm(n)[:k]`` (CPU default generator, or ``generator``; int64, host) with the same draws and the same generator
+    state afterwards, in O(k) swaps: ``mmf_host_randperm_prefix`` advances torch's own serialised generator state.  A generator
     whose serialised state is not the 5056-byte mt19937 layout is left to ``torch.randperm``."""
-    state = torch.get_rng_state()
+    state = torch.get_rng_state() if generator is None else generator.get_state()
     k = min(int(k), int(n))
     out = torch.empty(k, dtype=torch.int64)
     rc = _lib.lib().mmf_host_randperm_prefix(state.data_ptr(), state.numel(), int(n), k, out.data_ptr())
     if rc != 0:
-        return torch.randperm(n)[:k]
-    torch.set_rng_state(state)
+        return torch.randperm(n, generator=generator)[:k]
+    if generator is None:
+        torch.set_rng_state(state)
+    else:
+        generator.set_state(state)
     return out
 
 
@@ -30,19 +33,28 @@ class VertexSamplingMethod(Enum):
     NONE = "none"
 
 
+def _seed(seed: Optional[int], generator: Optional[torch.Generator]) -> None:
+    if seed is None:
+        return
+    if generator is None:
+        torch.manual_seed(seed)  # the reference's call (vertex_sampling.py:143): every default generator of the process, CUDA's included
+    else:
+        generator.manual_seed(seed)  # a caller-owned stream (a loader thread): the same CPU draws, nobody else's generator touched
+
+
 def select_vertex_indices(n: int, desired_num_vertices: int, method: VertexSamplingMethod, device, seed: Optional[int] = None,
-                          z: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          z: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """Row indices ``sample_to_n_vertices`` keeps when n > desired_num_vertices (same RNG draws / same sort); ``z``: the
-    vertices' z column, needed by LOWEST only."""
+    vertices' z column, needed by LOWEST only.  ``generator``: draw (and seed) THIS CPU generator instead of the process-wide
+    default one -- what a loader thread inside the training process passes, so that it neither reseeds nor races the generators
+    the trainer's diffusion noise comes from (the values drawn for a given seed are the same either way)."""
     if method == VertexSamplingMethod.RANDOM_WITHOUT_REPLACEMENT:
-        if seed is not None:
-            torch.manual_seed(seed)
+        _seed(seed, generator)
         # CPU default generator, exactly like the reference (vertex_sampling.py:143-145)
-        return randperm_prefix(n, desired_num_vertices).to(device)
+        return randperm_prefix(n, desired_num_vertices, generator).to(device)
     if method == VertexSamplingMethod.RANDOM_WITH_REPLACEMENT:
-        if seed is not None:
-            torch.manual_seed(seed)
-        return torch.randint(0, n, (desired_num_vertices,)).to(device)
+        _seed(seed, generator)
+        return torch.randint(0, n, (desired_num_vertices,), generator=generator).to(device)
     if method == VertexSamplingMethod.LOWEST:
         # the reference sorts by -z (np.argsort(-vertices[:, 2]), vertex_sampling.py:122): i.e. it keeps the
         # HIGHEST z despite the name; a stable sort reproduces numpy's tie order
@@ -51,7 +63,7 @@ def select_vertex_indices(n: int, desired_num_vertices: int, method: VertexSampl
 
 
 def sample_to_n_vertices(vertices: torch.Tensor, features: torch.Tensor, desired_num_vertices: int,
-                         method: VertexSamplingMethod, seed: Optional[int] = None
+                         method: VertexSamplingMethod, seed: Optional[int] = None, generator: Optional[torch.Generator] = None
                          ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(V,3), (V,C) -> (N,3), (N,C), (N,) valid mask.  V == N or method NONE: inputs are returned unchanged."""
     assert vertices.dim() == 2 and features.dim() == 2
@@ -62,7 +74,7 @@ def sample_to_n_vertices(vertices: torch.Tensor, features: torch.Tensor, desired
         return vertices, features, torch.ones(n, device=dev, dtype=torch.bool)
     if n > desired_num_vertices:
         valid_mask = torch.ones(desired_num_vertices, device=dev, dtype=torch.bool)
-        sel = select_vertex_indices(n, desired_num_vertices, method, dev, seed, vertices[:, 2])
+        sel = select_vertex_indices(n, desired_num_vertices, method, dev, seed, vertices[:, 2], generator)
         vertices, features = vertices[sel, :], features[sel, :]
     else:
         pad = desired_num_vertices - n

@@ -33,7 +33,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ..diffuser_actor import DiffuserActorConfig
-from .distributed import get_world_size
+from .distributed import collectives_active, get_world_size
 from .trainer import unpack_batch
 
 AQL_QUEUE_PACKETS = 65536
@@ -97,18 +97,29 @@ class GraphedTrainStep:
     ``overlap_backbone``: evaluate the frozen image backbone of ``next_batch`` beside the trainable pass of ``batch`` (graph
     branch / side stream); the caller then hands batch t + 1 to step t, and the SAME dict object to step t + 1.
     ``data_parallel=False``: this rank steps ALONE although a process group exists (a measurement or an evaluation that only one
-    rank runs): no collective is issued -- with the default every rank of the group must call ``step`` the same number of times."""
+    rank runs): no collective is issued -- with the default every rank of the group must call ``step`` the same number of times.
+    ``force_collectives``: issue the collectives (broadcast, gradient scale + all-reduce, ``observed_world``) although the group has ONE
+    rank -- None follows ``training.distributed.force_collectives()`` (MMF_FORCE_COLLECTIVES=1).  The step's results do not change
+    (a sum over one rank, a scale by 1.0); it is how RCCL (``backend="nccl"``) is exercised on a one-GPU box
+    (tests/test_gpu_rccl_single_rank.py)."""
 
     def __init__(self, cfg: DiffuserActorConfig, model: nn.Module, example_batch: Dict[str, torch.Tensor], lr: float = 1e-4,
                  weight_decay: float = 5e-4, use_graphs: Optional[bool] = None, overlap_backbone: bool = True,
-                 unpack: Optional[Callable] = None, process_group=None, tuned_gemms: bool = True, data_parallel: bool = True):
+                 unpack: Optional[Callable] = None, process_group=None, tuned_gemms: bool = True, data_parallel: bool = True,
+                 force_collectives: Optional[bool] = None):
         self.cfg, self.model = cfg, model
         self.unpack = unpack or unpack_batch
         self.group = process_group
         if not data_parallel:
             self.world = 1
+            self.collective = False
         else:
             self.world = get_world_size() if process_group is None else dist.get_world_size(process_group)
+            have_group = dist.is_available() and dist.is_initialized()
+            forced = collectives_active() if force_collectives is None else (bool(force_collectives) and have_group)
+            if force_collectives and not have_group:
+                raise RuntimeError("force_collectives=True needs an initialised process group (training.ProcessGroup(force=True))")
+            self.collective = self.world > 1 or forced  # the exchange steps are issued (always when there is someone to exchange with)
         p0 = next(model.parameters())
         self.device = p0.device
         self.use_graphs = (self.device.type == "cuda") if use_graphs is None else bool(use_graphs)
@@ -130,7 +141,7 @@ class GraphedTrainStep:
         model.train()
         self._find_used_parameters()
         self._flatten(lr, weight_decay)
-        if self.world > 1:
+        if self.collective:
             # what DistributedDataParallel does in its constructor: every replica starts from rank 0's weights (a per-rank seed or a
             # checkpoint loaded on rank 0 only would otherwise diverge silently -- the all-reduced gradients applied to different weights)
             dist.broadcast(self.flat_param, src=0 if process_group is None else dist.get_global_rank(process_group, 0), group=process_group)
@@ -234,7 +245,7 @@ class GraphedTrainStep:
                     v.zero_()  # (a parameter the probe saw a gradient for: not expected)
             for v, (_, p) in zip(self.grad_views, self.used):
                 p.grad = v
-        if self.world > 1:
+        if self.collective:
             self.flat_grad.mul_(1.0 / self.world)  # DDP scales the bucket before its all-reduce (sum)
         with torch.no_grad():
             zero = losses[0].detach().new_zeros(())
@@ -374,7 +385,7 @@ class GraphedTrainStep:
             self.graph_fb.replay()
         else:
             self._forward_backward()
-        if self.world > 1:
+        if self.collective:
             if self.time_allreduce and self.device.type == "cuda":
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -408,7 +419,7 @@ class GraphedTrainStep:
 
     def observed_world(self) -> int:
         """The number of ranks a sum over the process group actually reaches (an all-reduce of ones on this rank's device)."""
-        if self.world == 1:
+        if not self.collective:
             return 1
         one = torch.ones(1, dtype=torch.float32, device=self.device)
         dist.all_reduce(one, group=self.group)

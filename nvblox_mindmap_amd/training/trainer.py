@@ -9,7 +9,7 @@ from ..diffuser_actor import DiffuserActor, DiffuserActorConfig
 from ..image_processing.backprojection import get_camera_pointcloud
 from ..mapping.nvblox_mapper_constants import get_workspace_bounds
 from ..nvblox_torch.timer import Timer
-from .distributed import get_world_size
+from .distributed import collectives_active
 
 
 def build_model(cfg: Optional[DiffuserActorConfig] = None, task: str = "DRILL_IN_BOX", device="cuda") -> DiffuserActor:
@@ -19,8 +19,9 @@ def build_model(cfg: Optional[DiffuserActorConfig] = None, task: str = "DRILL_IN
 
 def wrap_ddp(model: nn.Module, device) -> nn.Module:
     """DDP exactly as the reference wraps it (run_training.py:608-613): find_unused_parameters because the instruction
-    branch is unused when use_instruction = 0, no buffer broadcast.  Single process: the bare model."""
-    if get_world_size() == 1:
+    branch is unused when use_instruction = 0, no buffer broadcast.  Single process: the bare model (unless the forced-collective
+    mode asks for the wrapper over a one-rank group, training/distributed.py: force_collectives)."""
+    if not collectives_active():
         return model
     dev = torch.device(device)
     ids = [dev.index] if dev.type == "cuda" else None

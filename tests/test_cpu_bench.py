@@ -63,7 +63,7 @@ def _stub_full_record(prose=4000, kernels=5):
                          "backprojection": {"batch_32x512x512": {"frames_per_s": 1469382.6145731679, "frac_of_hbm_peak": 0.770379672229337,
                                                                  "cpu_frames_per_s": 328.4920258667571, "cpu_threads": 8}}},
         "train": {"step_per_s": 26.28344812337423, "ms_per_step": 38.04675837454852, "per_gpu_batch": 32, "dtype": "f32", "parallelism": "dp8",
-                  "host_enqueue_frac": 0.013853063540732976, "rccl_world_observed": 8, "allreduce": {"ms": 0.31234567, "payload_MB": 8.57},
+                  "host_enqueue_frac": 0.013853063540732976, "rccl_world_observed": 8, "allreduce": {"mean_ms": 0.31234567, "min_ms": 0.3, "max_ms": 0.33, "payload_MB": 8.57}, "collective_backend": "nccl",
                   "allreduce_payload_MB": 8.573324, "per_rank_ms_per_step": {"min": 38.0, "max": 38.2, "all": [38.0] * 8}, "how": long,
                   "eager_ddp_reference_shaped": {"ms_per_step": 40.3}, "fp16_backbone_matmuls": {"ms_per_step": 25.4},
                   "file_fed": {"steady_state_over_compute_bound": 0.97, "steady_state_step_per_s": 25.5, "samples_timed": 4096,
@@ -91,7 +91,7 @@ def test_compact_line_is_bounded_and_carries_the_contract():
             assert k in rec["cpu_baseline"], k
         assert rec["config"]["workload"] and set(rec["config"]) >= {"workload", "hole_mode", "feature_channels", "voxel_size_m"}
         assert rec["roofline"]["frac"] == 0.17946 and rec["roofline"]["dominant_launch"] == "k_1" and rec["roofline"]["dominant_us"] is not None
-        assert rec["train"]["allreduce_ms"] == 0.31235 and rec["train"]["file_fed_steady_ratio"] == 0.97 and rec["train"]["per_rank_ms_max"] == 38.2
+        assert rec["train"]["allreduce_ms"] == 0.31235 and rec["train"]["collective_backend"] == "nccl" and rec["train"]["file_fed_steady_ratio"] == 0.97 and rec["train"]["per_rank_ms_max"] == 38.2
         assert rec["cpu_baseline"]["backprojection"]["cpu_fps"] == 328.49
 
         def longest(o):

@@ -84,13 +84,33 @@ def test_frames_without_raw_copies_take_the_slow_path(tmp_path):
 
 
 def test_rank_strided_partition(dataset_dir):
+    """Round-5 advisor finding: 11 samples over 2 ranks gave 6 and 5 batches -- the rank with the extra batch waits alone in the
+    gradient all-reduce.  The order is padded (wrapping around) to a multiple of the world size first, like DistributedSampler: every
+    rank gets the same count, the union covers every sample, only the padding repeats."""
     ds = MindmapFrameDataset(dataset_dir, num_vertices=64, seed=1)
-    seen = []
+    assert len(ds) == 11
+    seen, lens = [], []
     for r in range(2):
         ld = PinnedBatchLoader(ds, batch_size=1, shuffle=True, drop_last=False, threads=1, slots=2, seed=9, pin_memory=False, rank=r, world_size=2)
+        lens.append(len(ld))
         seen.append([tuple(b["camera_poses"][0, 0].tolist()) for b in ld])
         ld.close()
-    assert len(seen[0]) == 6 and len(seen[1]) == 5 and not set(seen[0]) & set(seen[1])
+    assert lens == [6, 6] and len(seen[0]) == len(seen[1]) == 6
+    assert len(set(seen[0]) | set(seen[1])) == 11 and len(set(seen[0]) & set(seen[1])) == 1  # one wrapped-around sample
+
+
+@pytest.mark.parametrize("n_world_batch_drop", [(11, 2, 4, True), (11, 2, 4, False), (11, 3, 2, True), (11, 4, 3, False), (11, 8, 1, True)])
+def test_every_rank_has_the_same_number_of_batches(dataset_dir, n_world_batch_drop):
+    n, world, B, drop = n_world_batch_drop
+    ds = MindmapFrameDataset(dataset_dir, num_vertices=64, seed=1)
+    assert len(ds) == n
+    lens, counts = [], []
+    for r in range(world):
+        ld = PinnedBatchLoader(ds, batch_size=B, shuffle=True, drop_last=drop, threads=1, slots=2, seed=2, pin_memory=False, rank=r, world_size=world)
+        lens.append(len(ld))
+        counts.append(sum(1 for _ in ld))
+        ld.close()
+    assert len(set(lens)) == 1 and counts == lens, (lens, counts)
 
 
 def test_copied_dataset_keeps_its_raw_copies(tmp_path):
@@ -162,3 +182,31 @@ def test_host_io_entry_points_fail_loudly(tmp_path):
     assert "out of range" in _lib.last_error()
     assert L.mmf_host_sample_vertex_file(raw.encode(), off_v, off_f, V + 1000, Cc, rows.ctypes.data, 3, v16.ctypes.data, f16.ctypes.data) != 0
     assert "smaller than its header" in _lib.last_error()
+
+
+def test_slow_path_leaves_the_process_generators_alone(dataset_dir):
+    """Round-5 advisor finding: the slow path (taken for every sample when an augmentor / noiser is set) ran ``__getitem__`` in a
+    loader thread of the training process, where a seeded dataset's ``torch.manual_seed(seed + idx)`` reseeded the process-wide
+    generators the trainer's diffusion noise comes from.  Loader threads now draw from generators of their own -- the same values for
+    the same seed -- and neither building the loader nor an epoch through it moves torch's or Python's global streams."""
+    import random
+
+    from nvblox_mindmap_amd.data_loading.sample_transformer import GeometryNoiser
+
+    ds = MindmapFrameDataset(dataset_dir, num_vertices=128, seed=21, geometry_noiser=GeometryNoiser(0.01, 1.0))
+    torch.manual_seed(1234)
+    random.seed(99)
+    t_state, p_state = torch.get_rng_state().clone(), random.getstate()
+    ld = PinnedBatchLoader(ds, batch_size=2, shuffle=False, drop_last=False, threads=2, slots=2, pin_memory=False)
+    batches = [{k: v.clone() for k, v in b.items()} for b in ld]
+    st = ld.stats()
+    ld.close()
+    assert st["slow_path_samples"] == len(ds)  # (a noiser is set: no sample can take the in-place path)
+    assert torch.equal(torch.get_rng_state(), t_state) and random.getstate() == p_state
+    # the selection draw of a seeded dataset is still the dataset's rule: sample idx seeded with seed + idx, the reference's draws
+    ds_plain = MindmapFrameDataset(dataset_dir, num_vertices=128, seed=21)
+    for i in range(len(ds)):
+        want = ds_plain[i]
+        got = {k: v[i % 2] for k, v in batches[i // 2].items()}
+        assert torch.equal(got["vertex_features"], want["vertex_features"]) and torch.equal(got["vertices_valid_mask"], want["vertices_valid_mask"])
+        assert not torch.equal(got["vertices"], want["vertices"]) or not bool(want["vertices_valid_mask"].any())  # (noised)

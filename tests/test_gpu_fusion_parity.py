@@ -576,6 +576,39 @@ def test_degenerate_frames(oracle_mod):
     assert gpu.tsdf_layer_view(0).num_allocated_blocks() > 100
 
 
+@pytest.mark.parametrize("route", ["fused", "hash"])
+def test_voxel_centres_on_the_camera_plane(oracle_mod, route):
+    """Round-5 advisor finding: the branch-free voxel loop projects EVERY voxel of a candidate block, also those on or behind the
+    camera plane (p.z == 0: u = inf / NaN, a float -> int conversion of which is undefined).  A camera INSIDE the workspace, axis
+    aligned, its centre exactly on a voxel centre: a whole plane of voxel centres of the camera's own (candidate) blocks has
+    p.z == +-0 in float32, the planes beside it p.z = +-1 cm.  The indices are clamped in float before the conversion now; the map must
+    equal the oracle's bit for bit and nothing may be read outside the depth image."""
+    cfg = small_cfg(4)
+    pos = np.array([-0.295, 0.005, 0.305])  # a voxel centre ((k + 0.5) cm on every axis), well inside the DRILL_IN_BOX workspace
+    T = np.eye(4)
+    T[:3, 2] = [1.0, 0.0, 0.0]   # optical axis = world +x (towards the sphere)
+    T[:3, 0] = [0.0, -1.0, 0.0]  # image x = world -y
+    T[:3, 1] = [0.0, 0.0, -1.0]  # image y = world -z
+    T[:3, 3] = pos
+    T = T.astype(np.float32)
+
+    def inside():
+        f = dict(S.frame(cfg, 0, 16))
+        f["T_W_C"] = T
+        f["depth"] = S.render_depth(cfg, T)
+        return f
+
+    f = inside()
+    assert (f["depth"] > 0.3).mean() > 0.5
+    # (the oracle's own arithmetic: voxel centres with p.z == 0 exist for this pose)
+    xs = (np.arange(-37, 95, dtype=np.float32) + np.float32(0.5)) * np.float32(0.01)
+    assert np.sum(xs == T[0, 3]) == 1
+    over = {} if route == "fused" else dict(workspace_bounds_type=0, max_integration_distance_m=2.5)
+    gpu, orc = make_mapper(16, **over), make_oracle(oracle_mod, 16, **over)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [inside, 0, inside, 6], 16)
+    assert orc.block_indices(0).shape[0] > 50
+
+
 @pytest.mark.parametrize("route", ["bounded", "hash"])
 @pytest.mark.parametrize("shape", [(1, 96), (48, 1), (2, 2)])
 def test_one_row_and_one_column_depth_images(oracle_mod, route, shape):
