@@ -14,7 +14,7 @@ from .common import *  # noqa: F401,F403
 from .common import ROOT, S, MAPPER_TO_ID, NvbloxMappingCfg, get_nvblox_mapper, integrate_frame  # noqa: F401
 from .fusion_legs import build_facade  # noqa: F401
 
-def run_closed_loop(device, steps=8):
+def run_closed_loop(device, steps=20):
     """BASELINE configs[3]: one control step of the closed loop on one GPU, end to end, through the object the reference's policy
     drives (mapping/isaaclab_nvblox_mapper.py; closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83,206-211):
     mapper.decay() + update_reconstruction_from_sample (input helpers: pose 7-vector -> 4x4, rgb float -> u8, back-projection;
@@ -69,9 +69,21 @@ def run_closed_loop(device, steps=8):
         for i in range(steps):
             control_step(3 + i, True)
         total = (time.perf_counter() - t0) / steps * 1e3
+        # the fusion phase alone, steps back to back (no inference in between), synchronised after each: what the phase costs when
+        # the host's caches are warm and the GPU has not idled -- inside the loop the same code follows 24 ms of inference
+        # (profiles/r06c_facade_closed_loop_between.txt: the first launches after it are slow whatever they are)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fr, smp = frames[i % 4], samples[i % 4]
+            ex.next, ex.low = fr["features"], fr["lowres"]
+            facade.decay()
+            facade.update_reconstruction_from_sample(smp, "pov")
+            torch.cuda.synchronize(device)
+        back_to_back = (time.perf_counter() - t0) / steps * 1e3
     finally:
         DiffuserActor.enable_fused_inference(False)
     out = {"ms_per_control_step": total, "control_steps_per_s": 1e3 / total, "breakdown_ms": {k: v / steps for k, v in parts.items()},
+           "fusion_back_to_back_ms": back_to_back, "steps": steps, "facade_frame_pipelining": bool(facade.frame_pipelining),
            "shape": "512x512 RGB-D, 768 feature channels, 2048 sampled vertices, 100 denoising steps, batch 1",
            "through": "IsaacLabNvbloxMapper.update_reconstruction_from_sample / get_nvblox_model_inputs"}
     del facade, model, frames, samples

@@ -235,6 +235,13 @@ int mmf_backproject_depth(const float* depth_dev, const float* K_dev, const floa
 int mmf_sample_inputs_scratch_floats(void);
 int mmf_sample_frame_inputs(const float* rgb_chw_dev, int H, int W, const float* pose7_dev, const float* K_dev, uint8_t* rgb_hwc_out_dev,
                             float* small_out_dev, float* scratch_dev, void* stream);
+/* The same work with the 20-float record delivered ON THE HOST when the call returns (host_out20: plain host memory): the kernel
+ * stores the record into coherent pinned memory the library owns and the call polls its sequence number -- no copy engine and no
+ * stream synchronisation on the common path (an idle stream: ~10 us; past 300 us of polling it waits on the stream).  Replaces the
+ * reference's three synchronising reads of mapping/helpers/nvblox_input_helpers.py:50-69 (pose .cpu(), rgb.min() / rgb.max()) in the
+ * closed loop's per-step path (mindmap/mapping/isaaclab_nvblox_mapper.py:96-122).  Calls are serialised per process. */
+int mmf_sample_frame_inputs_host(const float* rgb_chw_dev, int H, int W, const float* pose7_dev, const float* K_dev, uint8_t* rgb_hwc_out_dev,
+                                 float* scratch_dev, float* host_out20, void* stream);
 /* erode_mask(mask, kernel_size=3, iterations=k) (image_processing/image_mask_operations.py:16-41):
  * out = NOT dilate_{(2k+1)x(2k+1)}(NOT mask).  mask/out [H,W] u8 (0/1), tmp [H,W] u8 scratch. */
 int mmf_erode_mask(const uint8_t* mask_dev, uint8_t* out_dev, uint8_t* tmp_dev, int H, int W, int iterations, void* stream);

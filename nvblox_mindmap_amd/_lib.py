@@ -155,6 +155,7 @@ SIGNATURES = {
     "mmf_backproject_depth": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "mmf_sample_inputs_scratch_floats": (_I, []),
     "mmf_sample_frame_inputs": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "mmf_sample_frame_inputs_host": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mmf_erode_mask": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmf_feature_mask": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "mmf_depth_mask": (_I, [_VP, _VP, _I, _I, _F, _VP, _VP]),
@@ -285,9 +286,18 @@ def require_gpu() -> None:
 
 
 def stream_ptr(device: Optional[int] = None) -> C.c_void_p:
-    """hipStream_t of torch's current stream on `device`."""
+    """hipStream_t of torch's current stream on `device` (None: the current device; an index; a torch.device)."""
     import torch
 
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:  # the per-frame paths ask several times per call: the raw handle without the Stream object (0.3 us vs 4 us)
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+        return C.c_void_p(raw(idx))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -1,5 +1,8 @@
 // mmf_api_ops.hip -- the stateless entry points of the C ABI (include/mmfusion.h): depth back-projection, mask algebra, feature
 // resize and the policy-side ops (farthest-point sampling, the fused inference kernels).
+#include <chrono>
+#include <mutex>
+
 #include "mmf_api_internal.h"
 
 using namespace mmf;
@@ -21,6 +24,70 @@ int mmf_sample_frame_inputs(const float* rgb_chw, int H, int W, const float* pos
     return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_sample_frame_inputs");
   launch_sample_inputs(rgb_chw, H, W, pose7, K9, rgb_hwc_out, small_out, scratch, (hipStream_t)stream);
   return check_launch();
+}
+
+namespace {
+// The host-visible record of mmf_sample_frame_inputs_host: 20 floats + the sequence number of the call that wrote them, in coherent
+// (fine-grained) pinned host memory the kernel stores to directly; one per device, calls serialised by the mutex.
+struct HostRecord {
+  float v[20];
+  unsigned seq;
+};
+struct HostRecordSlot {
+  HostRecord* host = nullptr;
+  HostRecord* dev = nullptr;
+  unsigned next = 1;
+};
+std::mutex g_rec_mutex;
+HostRecordSlot g_rec[64];
+}  // namespace
+
+int mmf_sample_frame_inputs_host(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_hwc_out, float* scratch,
+                                 float* host_out20, void* stream) {
+  if (!rgb_chw || !pose7 || !K9 || !rgb_hwc_out || !scratch || !host_out20 || H <= 0 || W <= 0)
+    return fail(MMF_ERR_INVALID_ARG, "bad arguments to mmf_sample_frame_inputs_host");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(MMF_ERR_HIP, "mmf_sample_frame_inputs_host: no current device");
+  std::lock_guard<std::mutex> lock(g_rec_mutex);
+  HostRecordSlot& r = g_rec[dev];
+  if (!r.host) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, sizeof(HostRecord), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(MMF_ERR_HIP, "mmf_sample_frame_inputs_host: cannot allocate the host-visible record");
+    }
+    std::memset(h, 0, sizeof(HostRecord));
+    r.host = (HostRecord*)h;
+    r.dev = (HostRecord*)d;
+  }
+  const unsigned seq = r.next++;
+  if (r.next == 0) r.next = 1;
+  launch_sample_inputs(rgb_chw, H, W, pose7, K9, rgb_hwc_out, r.dev->v, scratch, (hipStream_t)stream, &r.dev->seq, seq);
+  const int rc = check_launch();
+  if (rc != MMF_OK) return rc;
+  // Poll the record: the kernels are microseconds of work behind whatever the stream still holds.  A short spin covers the common case
+  // (an idle stream: ~10 us); past it the thread waits on the stream like any synchronising read would.
+  volatile unsigned* flag = &r.host->seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool seen = false;
+  for (long it = 0;; ++it) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+      seen = true;
+      break;
+    }
+    if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+  }
+  if (!seen) {
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(MMF_ERR_HIP, "mmf_sample_frame_inputs_host: stream synchronisation failed");
+    }
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(MMF_ERR_HIP, "mmf_sample_frame_inputs_host: the record was not written");
+  }
+  std::memcpy(host_out20, (const void*)r.host->v, 20 * sizeof(float));
+  return MMF_OK;
 }
 
 int mmf_erode_mask(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int iterations, void* stream) {

@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256) void k_rgb_u8(const float* __restrict__ rgb, s
   }
 }
 
-// one workgroup: small[0..3] = {min, max, saw NaN, 0}, small[4..10] = pose, small[11..19] = K
+// one workgroup: small[0..3] = {min, max, saw NaN, 0}, small[4..10] = pose, small[11..19] = K.
+// HOST: `small` is a record in coherent host memory the caller polls -- every writer fences at system scope, then ONE release store of
+// the call's sequence number into `flag` tells the host the 20 floats are there (no copy engine, no stream synchronisation).
+template <bool HOST>
 __global__ __launch_bounds__(256) void k_sample_small(const float* __restrict__ partial, int n_partial, const float* __restrict__ pose7,
-                                                     const float* __restrict__ K9, float* __restrict__ small) {
+                                                     const float* __restrict__ K9, float* __restrict__ small, unsigned* flag, unsigned seq) {
   __shared__ float s_lo[4], s_hi[4], s_nan[4];
   float lo = INFINITY, hi = -INFINITY, nan = 0.0f;
   for (int i = threadIdx.x; i < n_partial; i += 256) {
@@ -189,12 +192,17 @@ __global__ __launch_bounds__(256) void k_sample_small(const float* __restrict__ 
   }
   if (threadIdx.x < 7) small[4 + threadIdx.x] = pose7[threadIdx.x];
   if (threadIdx.x >= 64 && threadIdx.x < 73) small[11 + threadIdx.x - 64] = K9[threadIdx.x - 64];
+  if (HOST) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 int sample_inputs_scratch_floats() { return 3 * 1024; }
 
 void launch_sample_inputs(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_out, float* small,
-                          float* scratch, hipStream_t s) {
+                          float* scratch, hipStream_t s, unsigned* host_flag, unsigned seq) {
   const size_t HW = (size_t)H * W;
   const bool vec = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(rgb_chw) & 15) == 0 && (reinterpret_cast<uintptr_t>(rgb_out) & 3) == 0;
   const size_t per = vec ? 1024 : 256;
@@ -204,7 +212,10 @@ void launch_sample_inputs(const float* rgb_chw, int H, int W, const float* pose7
     hipLaunchKernelGGL(k_rgb_u8<4>, dim3(g), dim3(256), 0, s, rgb_chw, HW, rgb_out, scratch);
   else
     hipLaunchKernelGGL(k_rgb_u8<1>, dim3(g), dim3(256), 0, s, rgb_chw, HW, rgb_out, scratch);
-  hipLaunchKernelGGL(k_sample_small, dim3(1), dim3(256), 0, s, (const float*)scratch, g, pose7, K9, small);
+  if (host_flag)  // `small` is the host-visible record (mmf_sample_frame_inputs_host)
+    hipLaunchKernelGGL(k_sample_small<true>, dim3(1), dim3(256), 0, s, (const float*)scratch, g, pose7, K9, small, host_flag, seq);
+  else
+    hipLaunchKernelGGL(k_sample_small<false>, dim3(1), dim3(256), 0, s, (const float*)scratch, g, pose7, K9, small, (unsigned*)nullptr, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

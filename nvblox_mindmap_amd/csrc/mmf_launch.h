@@ -332,7 +332,7 @@ void launch_mesh_tri_emit(const LayerDev& tsdf, const LayerDev& color, const Map
 void launch_backproject(const float* depth, const float* K, const float* T, int B, int H, int W, float* out, hipStream_t s);
 int sample_inputs_scratch_floats();
 void launch_sample_inputs(const float* rgb_chw, int H, int W, const float* pose7, const float* K9, uint8_t* rgb_out, float* small,
-                          float* scratch, hipStream_t s);
+                          float* scratch, hipStream_t s, unsigned* host_flag = nullptr, unsigned seq = 0);
 void launch_erode(const uint8_t* mask, uint8_t* out, uint8_t* tmp, int H, int W, int k, hipStream_t s);
 void launch_feature_mask(const uint8_t* input_mask, const float* depth, int H, int W, float min_d, int k_in, int k_depth,
                          int border_percent, int Hf, int Wf, uint8_t* out, uint8_t* tmp, hipStream_t s);

@@ -59,9 +59,13 @@ def _w3(linear):
 
 
 def stale(linear) -> bool:
-    """The layer's weight / bias changed (in place: load_state_dict, copy_) since its split copy was made."""
+    """The layer's weight / bias changed (in place: load_state_dict, copy_) since its split copy was made.  A layer that never HAD a
+    copy (an unsplittable weight: ``_w3`` caches None for it) is never stale -- whoever multiplies by it (a captured graph included)
+    reads the float32 weight itself, which is the changed one."""
     hit = _W3_CACHE.get(id(linear.weight))
-    return hit is not None and hit[0]() is linear.weight and hit[1] != _versions(linear)
+    if hit is None or hit[0]() is not linear.weight or hit[2] is None:
+        return False
+    return hit[1] != _versions(linear)
 
 
 def refresh_in_place(linear) -> bool:

@@ -8,8 +8,10 @@ Same function names, argument meaning, returned tuple and assertions as the refe
     HOST: every consumer of it takes it there (``integrate_frame`` calls ``camera_pose.cpu()``, nvblox_mapping_helpers.py:208),
     so the reference's device round trip (host -> device -> ``.cpu()``) and its synchronisation are saved.
 """
+import ctypes as C
 from typing import Dict, List, Tuple
 
+import numpy as np
 import torch
 
 from ... import _lib
@@ -59,22 +61,25 @@ def get_nvblox_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index:
 
 
 class _SampleScratch:
-    """Per-device buffers of ``frame_inputs_from_sample``: the 20-float record (device + pinned host) and kernel scratch."""
+    """Per-device buffers of ``frame_inputs_from_sample``: kernel scratch on the device, the 20-float record on the host."""
 
     _by_device = {}
 
     def __init__(self, device):
         n = _lib.lib().mmf_sample_inputs_scratch_floats()
-        self.small = torch.empty(20, dtype=torch.float32, device=device)
         self.scratch = torch.empty(n, dtype=torch.float32, device=device)
-        self.host = torch.empty(20, dtype=torch.float32).pin_memory()
+        self.scratch_ptr = _lib.dptr(self.scratch)
+        self.rec = np.zeros(20, dtype=np.float32)
+        self.rec_ptr = self.rec.ctypes.data_as(C.c_void_p)
+        self.call = _lib.lib().mmf_sample_frame_inputs_host
 
     @classmethod
     def of(cls, device):
         key = (device.type, device.index)
-        if key not in cls._by_device:
-            cls._by_device[key] = cls(device)
-        return cls._by_device[key]
+        sc = cls._by_device.get(key)
+        if sc is None:
+            sc = cls._by_device[key] = cls(device)
+        return sc
 
 
 def frame_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index: int):
@@ -108,12 +113,11 @@ def frame_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index: int)
     dev = rgb_chw.device
     sc = _SampleScratch.of(dev)
     rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().mmf_sample_frame_inputs(_lib.dptr(rgb_chw), H, W, _lib.dptr(pose7), _lib.dptr(k_dev), _lib.dptr(rgb),
-                                                  _lib.dptr(sc.small), _lib.dptr(sc.scratch), _lib.stream_ptr(dev.index)),
-               "mmf_sample_frame_inputs")
-    sc.host.copy_(sc.small, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()
-    rec = sc.host.numpy().copy()
+    # the record arrives on the host with the call: the kernel stores it into coherent pinned memory the library polls -- no copy
+    # engine, no stream synchronisation (the step's host path: DESIGN.md section 4.12)
+    _lib.check(sc.call(rgb_chw.data_ptr(), H, W, pose7.data_ptr(), k_dev.data_ptr(), rgb.data_ptr(), sc.scratch_ptr, sc.rec_ptr,
+                       _lib.stream_ptr(dev)), "mmf_sample_frame_inputs_host")
+    rec = sc.rec.copy()
     # the reference's two range assertions (:68); a NaN fails them like it fails `min() >= 0`
     assert rec[2] == 0.0 and rec[0] >= 0 and rec[1] <= 1
     if num_cams > 1:  # the reference checks the range over every camera of the sample
@@ -140,7 +144,13 @@ def get_nvblox_inputs_from_camera_handler(camera_handler, dynamic_class_labels: 
     intrinsics = camera_handler.get_intrinsics().to("cuda")
     assert intrinsics.dtype == torch.float32
     camera_pose = camera_handler.get_pose_as_homo().to(torch.float32).to("cuda")
-    rgb = camera_handler.get_rgb().to(torch.uint8).to("cuda")
+    raw_rgb = camera_handler.get_rgb()
+    rgb = raw_rgb.to(torch.uint8).to("cuda")
+    if rgb is raw_rgb or rgb.data_ptr() == raw_rgb.data_ptr():
+        # a uint8 image already on the GPU comes back as the handler's OWN tensor: the facade pipelines consecutive frames (the
+        # appearance half of this frame reads the image while the next frame is being set up), so the frame gets a copy of its own
+        # -- the reference's handler clones per frame anyway (isaaclab_utils/isaaclab_camera_handler.py:130); 0.8 MB, microseconds
+        rgb = rgb.clone()
     pointcloud = camera_handler.get_pcd()
     assert pointcloud.dtype == torch.float32
     return (depth_frame, intrinsics, camera_pose, rgb, dynamic_mask, pointcloud)

@@ -171,6 +171,14 @@ def _release(feature_extractor) -> None:
         rel()
 
 
+def follow_mapper_arithmetic(feature_extractor, mapper: Mapper) -> None:
+    """An extractor that up-samples with this library's kernel (``fma_contraction`` attribute, e.g. BackboneFeatureExtractor) takes the
+    spec switch from the mapper it feeds: ``compute()`` + add_feature_frame and the fused low-res route then agree bit for bit also
+    when the mapper's parameter was set explicitly and differs from the process default (round-5 advisor finding)."""
+    if hasattr(feature_extractor, "fma_contraction") and feature_extractor.fma_contraction != mapper.fma_contraction:
+        feature_extractor.fma_contraction = mapper.fma_contraction
+
+
 def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, feature_extractor, depth_frame: torch.Tensor,
                      intrinsics: torch.Tensor, camera_pose: torch.Tensor, rgb: torch.Tensor, dynamic_mask: torch.Tensor,
                      include_dynamic: bool) -> Dict[str, Dict[str, torch.Tensor]]:
@@ -178,6 +186,7 @@ def nvblox_integrate(mapper: Mapper, nvblox_mapping_config: NvbloxMappingCfg, fe
     assert dynamic_mask.dtype == torch.bool
     cfg = nvblox_mapping_config
     out = {}
+    follow_mapper_arithmetic(feature_extractor, mapper)
     # static_mask = ~dynamic_mask (:116-117): the native call reads the dynamic mask inverted instead
     use_dyn = bool(cfg.use_dynamic_mask)
 

@@ -46,6 +46,9 @@ class BackboneFeatureExtractor:
         self.pad_to_channels = int(pad_to_channels)
         self.input_size = input_size
         self._channels = None
+        # the spec switch of the mapper this extractor feeds (None: the process default, MMF_FMA_CONTRACTION); set by
+        # follow_mapper_arithmetic() -- the materialised image must blend with the arithmetic the low-res path uses inside the mapper
+        self.fma_contraction = None
 
     def _backbone_output(self, rgb: torch.Tensor, hold: bool = False) -> torch.Tensor:
         assert rgb.ndim == 4 and rgb.shape[0] == 1 and rgb.shape[-1] == 3
@@ -66,7 +69,7 @@ class BackboneFeatureExtractor:
 
     @torch.no_grad()
     def compute(self, rgb: torch.Tensor) -> torch.Tensor:
-        return upsample_features(self._backbone_output(rgb), self.desired_output_size, self.pad_to_channels).unsqueeze(0)
+        return upsample_features(self._backbone_output(rgb), self.desired_output_size, self.pad_to_channels, self.fma_contraction).unsqueeze(0)
 
     @torch.no_grad()
     def compute_lowres(self, rgb: torch.Tensor):
@@ -86,7 +89,7 @@ class IsaacLabNvbloxMapper:
     def __init__(self, mapping_data_type="rgbd_and_mesh", args=None, device: str = "cuda", *, feature_extractor=None,
                  task: Optional[str] = None, include_dynamic: Optional[bool] = None, num_vertices_to_sample: Optional[int] = None,
                  vertex_sampling_method: Optional[VertexSamplingMethod] = None, save_serialized_nvblox_map_to_disk: Optional[bool] = None,
-                 feature_channels: Optional[int] = None) -> None:
+                 feature_channels: Optional[int] = None, frame_pipelining: Optional[bool] = None) -> None:
         def pick(value, name, default):
             return value if value is not None else getattr(args, name, default)
 
@@ -107,6 +110,18 @@ class IsaacLabNvbloxMapper:
         self.feature_extractor = feature_extractor
         # the last nvblox_integration_images per camera (the visualiser reads them)
         self.last_nvblox_integration_images: Dict[str, Dict] = {}
+        # Consecutive frames are software-pipelined BY DEFAULT here (not in the plain Mapper): every tensor the deferred half of a
+        # frame reads is made per frame by this object or its helpers (the uint8 image of frame_inputs_from_sample / the camera
+        # handler's per-frame copy, the extractor's output, the masks the native call writes), and every reader of the map completes
+        # the pending frame first.  The closed loop's step() integrates several cameras / frames between two map reads
+        # (mindmap/closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83,206-211): those overlap.  Results are bit-identical.
+        # ``frame_pipelining=False`` (or MMF_FACADE_PIPELINING=0) gives the frame-at-a-time schedule back.
+        if frame_pipelining is None:
+            import os
+
+            frame_pipelining = os.environ.get("MMF_FACADE_PIPELINING", "1") != "0"
+        self.frame_pipelining = bool(frame_pipelining)
+        self.set_frame_pipelining(self.frame_pipelining)
 
     # -- map update ---------------------------------------------------------------------------------------------------------
     def update_reconstruction_from_camera(self, camera_handler) -> None:
@@ -160,11 +175,14 @@ class IsaacLabNvbloxMapper:
         return samples
 
     def set_frame_pipelining(self, on: bool = True) -> None:
-        """Extension for streams that do not read the map after every frame (dataset generation over a recorded demo, replay):
-        consecutive single-mapper updates are software-pipelined in the native library (``Mapper.set_deferred_feature_rows``, DESIGN.md
-        4.11) -- the appearance half of a frame runs beside the geometry half of the next one.  Results are bit-identical; whatever
-        reads the map (``get_nvblox_model_inputs``, ``save_nvblox_map_to_disk``) completes the last frame first.  Every update makes its
-        own image tensors, which is all the mode asks for (with ``include_dynamic`` both mappers' frames share them)."""
+        """Extension, ON by default (see the constructor): consecutive updates are software-pipelined in the native library
+        (``Mapper.set_deferred_feature_rows``) -- the appearance half of a frame runs beside the geometry half of the
+        next one.  It pays wherever the map is not read after every frame (several cameras or frames per control step, dataset
+        generation over a recorded demo, replay).  Results are bit-identical; whatever reads the map (``get_nvblox_model_inputs``,
+        ``save_nvblox_map_to_disk``, layer views) completes the last frame first.  Every update makes its own image tensors, which is
+        all the mode asks for (with ``include_dynamic`` both mappers' frames share them); a feature extractor that REUSES one output
+        buffer across frames with torch in-place operations is reported by the mapper (RuntimeError), not silently mis-fused."""
+        self.frame_pipelining = bool(on)
         self.mapper.set_deferred_feature_rows(bool(on))
 
     def clear(self):

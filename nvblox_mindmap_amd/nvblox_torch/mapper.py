@@ -276,6 +276,7 @@ class Mapper:
         _lib.check(L.mmf_mapper_create(n, arr, dev_index, C.byref(h)), "mmf_mapper_create")
         self._h = h
         self._n = n
+        self._fma_contraction = bool(arr[0].fma_contraction)
         self._mesh_V = {}
         self._held_rows = {}  # mapper_id -> (tensors of a frame whose appearance tail is deferred, their version counters)
         self._deferred_mode = {}  # mapper_id -> set_deferred_feature_rows state
@@ -288,6 +289,14 @@ class Mapper:
             except Exception:
                 pass
             self._h = None
+
+    @property
+    def fma_contraction(self) -> bool:
+        """The spec switch ``projective_integrator_fma_contraction`` THIS mapper was built with (the switch was read at construction:
+        later edits of the parameter bag do not reach the native mapper).  Ops beside the mapper that must blend with the same
+        arithmetic -- the materialised feature up-sampling, image_processing/feature_resize.py -- take it from here, not from the
+        process environment."""
+        return self._fma_contraction
 
     # -- helpers ------------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:

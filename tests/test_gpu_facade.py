@@ -329,3 +329,109 @@ def test_mirrored_feature_extractor_through_the_facade(monkeypatch):
         assert out["vertex_features"].shape == (1, 2048, 16) and out["vertex_features"].dtype == torch.float32
     finally:
         constants.set_feature_array_num_elements(768)
+
+
+def test_materialised_feature_image_follows_the_mappers_fma_switch(monkeypatch):
+    """Round-5 advisor finding: ``upsample_features`` took its FMA switch from the process environment, the mapper from its own
+    parameter -- with the parameter set explicitly (and differing from the environment's default) the materialised route
+    (compute() + add_feature_frame) and the fused low-res route no longer agreed bit for bit.  The extractor now follows the mapper it
+    feeds (nvblox_mapping_helpers.follow_mapper_arithmetic)."""
+    import fusion_common
+    import nvblox_mindmap_amd.mapping.helpers.nvblox_mapping_helpers as H
+    from fusion_common import make_mapper
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import BackboneFeatureExtractor
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import NvbloxMappingCfg
+
+    C, size = 64, 256
+    flipped = not fusion_common.FMA  # the opposite of what the environment makes the default
+    cfg = S.StreamConfig(width=size, height=size, fx=293.2, fy=293.2, cx=127.5, cy=127.5, hole_mode="patches")
+    mcfg = NvbloxMappingCfg("DRILL_IN_BOX")
+    torch.manual_seed(0)
+    backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 16, stride=16), torch.nn.Tanh()).cuda()
+    maps = {}
+    for lowres in (True, False):
+        m = make_mapper(C, fma_contraction=flipped, tsdf_decay_factor=mcfg.tsdf_decay_factor)
+        assert m.fma_contraction == flipped
+        ex = BackboneFeatureExtractor(backbone, (size, size), C)
+        assert ex.fma_contraction is None
+        monkeypatch.setattr(H, "LOWRES_FEATURES", lowres)
+        for idx in (0, 6, 12):
+            sample, _, _ = make_sample(cfg, idx, "cuda")
+            depth, K, pose, rgb, dyn, _ = __import__("nvblox_mindmap_amd.mapping.helpers.nvblox_input_helpers", fromlist=["x"]).frame_inputs_from_sample(sample, 0)
+            m.decay()
+            H.nvblox_integrate(m, mcfg, ex, depth, K, pose, rgb, dyn, include_dynamic=False)
+        assert ex.fma_contraction == flipped
+        maps[lowres] = m.feature_layer_view(0).get_all_blocks_split()
+    assert maps[True][2].shape[0] > 20 and float(maps[True][0].float().abs().max()) > 0
+    assert all(torch.equal(x, y) for x, y in zip(maps[True], maps[False]))
+
+
+def test_default_facade_pipelines_the_closed_loop_and_equals_the_oracle():
+    """The closed loop's shape (mindmap/closed_loop/policies/nvblox_diffuser_actor_policy.py:77-83,206-211): k step()s -- each
+    ``decay()`` + ``update_reconstruction_from_sample`` -- then ONE map read (``get_nvblox_model_inputs``), repeated.  The facade AS
+    CONSTRUCTED (no mode set by the caller) pipelines the k frames (a frame's appearance half is pending when the next step starts),
+    completes the last one at the read, and map + model inputs equal the oracle's, driven call by call, bit for bit."""
+    from oracle import image_ops as IMG
+    from oracle import oracle as O
+    import fusion_common
+    from nvblox_mindmap_amd import _lib
+    from nvblox_mindmap_amd.mapping.isaaclab_nvblox_mapper import IsaacLabNvbloxMapper
+    from nvblox_mindmap_amd.mapping.nvblox_mapper_constants import MAPPER_TO_ID
+
+    C, size, k = 64, 256, 3
+    cfg = S.StreamConfig(width=size, height=size, fx=293.2, fy=293.2, cx=127.5, cy=127.5, hole_mode="patches")
+    ex = StreamFeatures()
+    facade = IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
+                                  num_vertices_to_sample=512)
+    assert facade.frame_pipelining is True  # the constructor's default
+    mc = facade.mapping_config
+    orc = make_oracle(O, C, tsdf_decay_factor=mc.tsdf_decay_factor)
+    lib, h = _lib.lib(), facade.mapper._h
+    frame = 0
+    for rnd in range(3):
+        for _ in range(k):
+            idx = 5 * frame
+            frame += 1
+            sample, T, depth = make_sample(cfg, idx, "cuda")
+            feat = S.render_features(cfg, idx, C)
+            ex.next = torch.from_numpy(feat).cuda()
+            facade.decay()
+            facade.update_reconstruction_from_sample(sample, "pov")
+            if not fusion_common.FMA:  # (mappers under the FMA switch complete every frame inside the call)
+                assert lib.mmf_deferred_feature_rows_pending(h, 0) == 1
+            rgb_u8 = (sample["rgbs"][0, 0].permute(1, 2, 0) * 255).to(torch.uint8).cpu().numpy()
+            Th = IMG.pose_to_homo(sample["camera_poses"][0, 0].cpu().numpy())[0]
+            dm, fm = IMG.frame_masks(np.ones(depth.shape, bool), depth, mc.min_integration_distance_m, mc.static_mask_erosion_iterations,
+                                     mc.valid_depth_mask_erosion_iterations, mc.feature_mask_border_percent, size, size)
+            orc.decay()
+            orc.add_depth_frame(depth, Th, cfg.intrinsics(), dm.astype(np.uint8))
+            orc.add_color_frame(rgb_u8, Th, cfg.intrinsics(), dm.astype(np.uint8))
+            orc.add_feature_frame(feat, Th, cfg.intrinsics(), fm.astype(np.uint8))
+        torch.manual_seed(10 + rnd)
+        inputs = facade.get_nvblox_model_inputs(MAPPER_TO_ID.STATIC, remove_zero_features=True)
+        assert lib.mmf_deferred_feature_rows_pending(h, 0) == 0  # the read completed the pending frame
+        v, f, valid = inputs["vertices"][0].cpu().numpy(), inputs["vertex_features"][0].cpu().numpy(), inputs["vertices_valid_mask"][0].cpu().numpy()
+        ov, of = orc.feature_mesh()
+        lo, hi = mc.aabb_min_m.numpy(), mc.aabb_max_m.numpy()
+        keep = np.all((ov > lo) & (ov < hi), axis=1) & np.any(of != 0, axis=1)
+        assert keep.sum() > 200 and valid.sum() == min(512, int(keep.sum()))
+        table = {p.tobytes(): i for i, p in enumerate(ov) if keep[i]}
+        for p, row in zip(v[valid], f[valid]):  # every sampled vertex is a kept oracle vertex, bit for bit, carrying that vertex' row
+            assert np.array_equal(row, of[table[p.astype(np.float32).tobytes()]].astype(np.float32))
+        # and the whole map
+        m = facade.mapper
+        blocks, bidx = m.tsdf_layer_view(0).get_all_blocks()
+        assert np.array_equal(bidx.cpu().numpy(), orc.block_indices(0))
+        assert np.array_equal(blocks.cpu().numpy().view(np.uint32), orc.all_tsdf().view(np.uint32))
+        fg, wg, fidx = m.feature_layer_view(0).get_all_blocks_split()
+        fo, wo = orc.all_features()
+        assert np.array_equal(fidx.cpu().numpy(), orc.block_indices(2)) and np.array_equal(wg.cpu().numpy(), wo)
+        assert np.array_equal(fg.cpu().numpy().view(np.uint16), fo.view(np.uint16))
+    # the frame-at-a-time schedule is one keyword away, and gives the same map
+    plain = IsaacLabNvbloxMapper("rgbd_and_mesh", None, "cuda", feature_extractor=ex, task="DRILL_IN_BOX", feature_channels=C,
+                                 frame_pipelining=False)
+    assert plain.frame_pipelining is False
+    sample, _, _ = make_sample(cfg, 0, "cuda")
+    ex.next = torch.from_numpy(S.render_features(cfg, 0, C)).cuda()
+    plain.update_reconstruction_from_sample(sample, "pov")
+    assert lib.mmf_deferred_feature_rows_pending(plain.mapper._h, 0) == 0
