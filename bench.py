@@ -90,6 +90,16 @@ from benchlib.fusion_legs import *  # noqa: E402,F401,F403
 from benchlib.policy_legs import *  # noqa: E402,F401,F403
 
 
+def dist_timeout_s(dist):
+    """The default process group's collective timeout in seconds (what a rank waiting in a barrier for rank 0's solo legs must stay under)."""
+    try:
+        import torch.distributed.distributed_c10d as c10d
+
+        return float(c10d._get_default_timeout(dist.get_backend()).total_seconds())
+    except Exception:
+        return None
+
+
 def emit(full: dict) -> None:
     """full record -> bench_full.json (+ gpurun_out/) and stderr; compact record (<= 4 KB) = the last stdout line."""
     text = json.dumps(full)
@@ -321,9 +331,13 @@ def main():
     stats = mapper.stats(MAPPER_TO_ID.STATIC)
     n_live = int(mapper.tsdf_layer_view(MAPPER_TO_ID.STATIC).num_allocated_blocks())
 
+    # rank 0 runs its single-GPU legs alone while the other ranks sit in the next collective (a barrier): how long they wait there is
+    # reported (`rank0_only_s`), next to the backend's collective timeout that wait must stay under (RCCL's watchdog: 10 min by default)
+    t_solo = time.perf_counter()
     ref_shape = None
     if rank == 0 and not args.no_ref_shape:
         ref_shape = run_reference_shape(device)
+    solo_before_train = time.perf_counter() - t_solo
     train = None
     if not args.no_train:  # every rank takes part (data parallel)
         if dist is not None:
@@ -347,6 +361,7 @@ def main():
                                                   "backbone, fp32 accumulate); everything trainable stays float32"}
         if rank == 0 and not args.no_file_fed:
             train["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=train["step_per_s"])
+    t_solo = time.perf_counter()
     infer = run_policy_inference(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     closed_loop = run_closed_loop(device) if (rank == 0 and not args.no_infer and not args.no_train) else None
     model_inputs = None
@@ -530,6 +545,9 @@ def main():
             "backprojection": backproj,
             "pixel_holes": pixel_holes,
             "train": train,
+            "rank0_only_s": {"before_the_training_barrier": solo_before_train, "before_the_final_barrier": time.perf_counter() - t_solo,
+                             "collective_timeout_s": (dist_timeout_s(dist) if dist is not None else None),
+                             "note": "ranks > 0 wait this long in a barrier while rank 0 runs its single-GPU legs"},
         }
         emit(out)
     if dist is not None:

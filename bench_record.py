@@ -137,6 +137,8 @@ def compact_record(full: dict) -> dict:
                    "feature_channels": cfg.get("feature_channels"), "voxel_size_m": cfg.get("voxel_size_m"),
                    "pipelined": cfg.get("pipelined")},
         "roofline": roofline, "cpu_baseline": cpu, "train": train,
+        "rank0_only_s": ({k: full["rank0_only_s"].get(k) for k in ("before_the_training_barrier", "before_the_final_barrier", "collective_timeout_s")}
+                         if full.get("rank0_only_s") else None),
         "full_record": full.get("full_record"),
     }
     if full.get("dry_run"):

@@ -85,6 +85,9 @@ class MmfParams(C.Structure):
         ("raycast_walk_from_camera", C.c_int32),
         ("appearance_blend_division", C.c_int32),
         ("fma_contraction", C.c_int32),
+        ("block_index_by_division", C.c_int32),
+        ("view_truncation_band_marking", C.c_int32),
+        ("bilinear_four_weight_sum", C.c_int32),
     ]
 
 

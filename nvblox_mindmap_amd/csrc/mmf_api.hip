@@ -80,9 +80,9 @@ void derive_consts(const mmf_params& P, MapConsts& mc) {
   mc.app_wm = P.appearance_measurement_weight;
   mc.app_max_w = P.appearance_max_weight;
   mc.ws_type = P.workspace_bounds_type;
-  for (int a = 0; a < 3; ++a) {
-    mc.ws_lo[a] = ifloor_h(P.ws_min[a] * mc.inv_bs);
-    mc.ws_hi[a] = ifloor_h(P.ws_max[a] * mc.inv_bs);
+  for (int a = 0; a < 3; ++a) {  // (mmf_params.block_index_by_division: the bounds' own blocks by the same rule as any point's)
+    mc.ws_lo[a] = ifloor_h(P.block_index_by_division ? P.ws_min[a] / mc.bs : P.ws_min[a] * mc.inv_bs);
+    mc.ws_hi[a] = ifloor_h(P.block_index_by_division ? P.ws_max[a] / mc.bs : P.ws_max[a] * mc.inv_bs);
   }
   mc.decay_factor = P.tsdf_decay_factor;
   mc.decay_thr = P.decayed_weight_threshold;
@@ -94,7 +94,9 @@ void derive_consts(const mmf_params& P, MapConsts& mc) {
   mc.st_eps = P.st_surface_eps_vox * mc.v;
   mc.C = P.feature_channels;
   mc.reach = P.raycast_to_truncation ? mc.trunc : 0.0f;
-  mc.spec_flags = (P.raycast_walk_from_camera ? 1 : 0) | (P.appearance_blend_division ? 2 : 0) | (P.fma_contraction ? kSpecFma : 0);
+  mc.spec_flags = (P.raycast_walk_from_camera ? 1 : 0) | (P.appearance_blend_division ? 2 : 0) | (P.fma_contraction ? kSpecFma : 0) |
+                  (P.block_index_by_division ? kSpecBlockDiv : 0) | (P.view_truncation_band_marking ? kSpecBandMark : 0) |
+                  (P.bilinear_four_weight_sum ? kSpecBilin4 : 0);
 }
 
 int alloc_layer(Layer& L, int cap, size_t block_bytes, bool has_w) {
@@ -246,8 +248,10 @@ int create_mapper_impl(const mmf_params& P, Mapper* m) {
       const char* e2 = std::getenv("MMF_NO_BIG_MERGE");
       m->allow_big_merge = !(e2 && e2[0] == '1');
     }
-    // (spec switch fma_contraction: the merged launch k_alloc_tsdf is built with the default arithmetic only)
-    m->allow_merged = !(e && e[0] == '1') && !P.fma_contraction;
+    // (spec switches fma_contraction, block_index_by_division, view_truncation_band_marking, bilinear_four_weight_sum: the merged launch
+    // k_alloc_tsdf and the front launch are built with the default forms only -- also for the stand-alone mmf_add_depth_frame)
+    m->allow_merged = !(e && e[0] == '1') && !P.fma_contraction && !P.block_index_by_division && !P.view_truncation_band_marking &&
+                      !P.bilinear_four_weight_sum;
   }
   HIP_TRY(hipMalloc(&m->pub, sizeof(u64) * pub_words(*m)));
   HIP_TRY(hipMemset(m->pub, 0, sizeof(u64) * pub_words(*m)));
@@ -348,7 +352,8 @@ int compute_view_grid(const Mapper& m, const Cam& cam, const Rigid& T_L_C, ViewG
   int lo[3], hi[3];
   if (mc.max_dist > 0.f) {
     const float s = mc.max_dist + mc.trunc;
-    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = ifloor_h(T_L_C.t[a] * mc.inv_bs);
+    const bool bdiv = (mc.spec_flags & kSpecBlockDiv) != 0;
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = ifloor_h(bdiv ? T_L_C.t[a] / mc.bs : T_L_C.t[a] * mc.inv_bs);
     const float us[2] = {0.f, (float)cam.W}, vs[2] = {0.f, (float)cam.H};
     for (int i = 0; i < 2; ++i)
       for (int j = 0; j < 2; ++j) {
@@ -356,7 +361,7 @@ int compute_view_grid(const Mapper& m, const Cam& cam, const Rigid& T_L_C, ViewG
         float pL[3];
         xform_h(T_L_C, pC, pL);
         for (int a = 0; a < 3; ++a) {
-          int b = ifloor_h(pL[a] * mc.inv_bs);
+          int b = ifloor_h(bdiv ? pL[a] / mc.bs : pL[a] * mc.inv_bs);
           if (b < lo[a]) lo[a] = b;
           if (b > hi[a]) hi[a] = b;
         }
@@ -866,6 +871,9 @@ int mmf_default_params(mmf_params* p) {
   p->raycast_walk_from_camera = 0;
   p->appearance_blend_division = 0;
   p->fma_contraction = 0;
+  p->block_index_by_division = 0;
+  p->view_truncation_band_marking = 0;
+  p->bilinear_four_weight_sum = 0;
   return MMF_OK;
 }
 
@@ -1140,7 +1148,8 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   // fused frame with the scalable allocation and list compaction as launches of their own (mmf_alloc_device.h)
   const bool big = packed && ncells > 0 && big_mode(*m, ncells) && alloc_big_supported(m->color.d) && alloc_big_supported(m->feat.d);
   // (spec switch appearance_blend_division: only the stand-alone appearance kernels are built with the per-channel division)
-  const bool fusable = packed && ncells > 0 && (alloc_jobs_fusable(ncells, m->tsdf.d.cap) || big) && !(m->mc.spec_flags & 2);
+  // (and the spec switches of kSpecStandalone: block_index_by_division, view_truncation_band_marking, bilinear_four_weight_sum)
+  const bool fusable = packed && ncells > 0 && (alloc_jobs_fusable(ncells, m->tsdf.d.cap) || big) && !(m->mc.spec_flags & kSpecStandalone);
   if (fusable) M.masked_depth_out = m->masked_depth;  // consumed by the TSDF update (no mask gathers there)
   if (fusable) M.invert = invert_mask ? 1 : 0;
   if (!fusable && invert_mask) {  // stand-alone kernels take the mask as it is: invert it once into scratch
@@ -1476,7 +1485,7 @@ static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGr
   if (ncells <= 0 || !alloc_jobs_fusable(ncells, m.tsdf.d.cap) || ncells > m.sc_cap[0] || m.tsdf.d.cap > m.sc_cap[1] ||
       m.tsdf.d.cap > m.sc_cap[2])
     return false;
-  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & (2 | kSpecFma)) || m.lazy_lag) return false;
+  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & (kSpecStandalone | kSpecFma)) || m.lazy_lag) return false;
   if (m.pending_decay && !m.wmax_valid) return false;  // that decay needs its voxel pass: separate launches
   const int sf = m.mc.st_sf;
   if (in.W / sf <= 0 || in.H / sf <= 0 || (in.W / sf) * (in.H / sf) > m.synth_cap) return false;

@@ -21,7 +21,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));                 // a ch
 // mask).  Same operation order as oracle/mmf_oracle.c:app_gate.
 // ------------------------------------------------------------------------------------------------
 // geometry + occlusion part: everything that does not depend on the integration mask
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ inline bool app_gate_geo(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ synth, int Ws,
                                     int Hs, int bx, int by, int bz, int lin, int& x0, int& y0, float& wx, float& wy) {
   float c[3], p[3], u, v;
@@ -52,7 +52,7 @@ __device__ inline bool app_gate_mask(const uint8_t* __restrict__ mask, int W, in
   return (m0 & 0xffu) && (m0 & 0xff00u) && (m1 & 0xffu) && (m1 & 0xff00u);
 }
 
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const uint8_t* __restrict__ mask,
                                 const float* __restrict__ synth, int Ws, int Hs, int bx, int by, int bz, int lin, int& x0,
                                 int& y0, float& wx, float& wy) {
@@ -90,7 +90,7 @@ __device__ inline bool app_gate(const MapConsts& mc, const Cam& cam, const Rigid
 
 // blend one colour voxel {rgb_, w} with the bilinear sample at footprint (x0,y0,wx,wy)
 // DIV: the spec switch mmf_params.appearance_blend_division (stand-alone kernels only; every fused launch is built with the default)
-template <bool DIV = false, bool FMA = false>
+template <bool DIV = false, int FMA = 0>
 __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, const MapConsts& mc, int x0, int y0, float wx, float wy,
                                     unsigned& ex, unsigned& ey) {
   // the two pixels of a footprint row are 6 consecutive bytes: one 4-byte + one 2-byte load (byte-aligned) instead of six
@@ -117,7 +117,7 @@ __device__ inline void color_update(const uint8_t* __restrict__ rgb, int W, cons
   ey = __float_as_uint(fminf(Wv + wm, mc.app_max_w));
 }
 
-template <bool DIV = false, bool FMA = false>
+template <bool DIV = false, int FMA = 0>
 __device__ inline void color_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs, int bid,
                                   int nb) {
   const LayerDev& L = A.L;
@@ -183,7 +183,7 @@ struct LowAxis {
   int i0, i1;
   float l0, l1;
 };
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ __forceinline__ LowAxis low_axis(float scale, int out_idx, int n_in) {
   float sv = madd<FMA>(scale, (float)out_idx + 0.5f, -0.5f);
   sv = sv < 0.0f ? 0.0f : sv;
@@ -214,7 +214,7 @@ __device__ __forceinline__ float f4_at(const float4& v, int k) { return k == 0 ?
 __device__ __forceinline__ float low_at(const Low8& v, int k) {
   return k == 0 ? v.lo.x : k == 1 ? v.lo.y : k == 2 ? v.lo.z : k == 3 ? v.lo.w : k == 4 ? v.hi.x : k == 5 ? v.hi.y : k == 6 ? v.hi.z : v.hi.w;
 }
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const Low8& a10, const Low8& a11, const LowAxis& X,
                                          const LowAxis& Y) {
   half8 o;
@@ -229,7 +229,7 @@ __device__ __forceinline__ half8 low_tap(const Low8& a00, const Low8& a01, const
 // One tap from its own four texels: the rare case of a footprint that straddles a low-res cell border.  A real call, not
 // inlined: inlined four times it doubles the register count of every kernel that updates rows from a low-res map (and halves
 // the rows in flight per SIMD) for the sake of 1 voxel in ~8.
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ __noinline__ half8 low_tap_at(const float* __restrict__ low, int w, int Cin, int c0, LowAxis X, LowAxis Y) {
   return low_tap<FMA>(low_load8(low, w, Cin, Y.i0, X.i0, c0), low_load8(low, w, Cin, Y.i0, X.i1, c0), low_load8(low, w, Cin, Y.i1, X.i0, c0),
                  low_load8(low, w, Cin, Y.i1, X.i1, c0), X, Y);
@@ -238,18 +238,18 @@ __device__ __noinline__ half8 low_tap_at(const float* __restrict__ low, int w, i
 // One surviving voxel: blend its channel row with the bilinear sample of the feature image (or of the virtual up-sampled
 // low-res map).  `lanes` lanes (gl = 0..lanes-1) share the row in 16-byte pieces.
 // packed forms of madd2 (two channels per instruction: v_pk_fma_f32 / v_pk_mul_f32 + v_pk_add_f32)
-template <bool FMA>
+template <int FMA>
 __device__ __forceinline__ f32x2 pk_madd2(float a, f32x2 x, float b, f32x2 y) {
-  if constexpr (FMA) {
+  if constexpr ((FMA & 1) != 0) {
     const f32x2 av = {a, a};
     return __builtin_elementwise_fma(av, x, b * y);
   } else {
     return a * x + b * y;
   }
 }
-template <bool FMA>
+template <int FMA>
 __device__ __forceinline__ f32x2 pk_madd2(f32x2 a, float x, f32x2 b, float y) {
-  if constexpr (FMA) {
+  if constexpr ((FMA & 1) != 0) {
     const f32x2 xv = {x, x};
     return __builtin_elementwise_fma(a, xv, b * y);
   } else {
@@ -257,7 +257,7 @@ __device__ __forceinline__ f32x2 pk_madd2(f32x2 a, float x, f32x2 b, float y) {
   }
 }
 
-template <bool LOW, bool DIV = false, bool FMA = false>
+template <bool LOW, bool DIV = false, int FMA = 0>
 __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts& mc, __half* __restrict__ A, bool is_new, size_t pix,
                                               float wx, float wy, float Wv, int gl, int lanes) {
   const Cam& cam = Aa.cam;
@@ -282,9 +282,23 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
     for (int k = 0; k < 8; k += 2) {
       const f32x2 v00 = {(float)a00[k], (float)a00[k + 1]}, v10 = {(float)a10[k], (float)a10[k + 1]};
       const f32x2 v01 = {(float)a01[k], (float)a01[k + 1]}, v11 = {(float)a11[k], (float)a11[k + 1]};
-      const f32x2 top = pk_madd2<FMA>(ux, v00, wx, v10);
-      const f32x2 bot = pk_madd2<FMA>(ux, v01, wx, v11);
-      const f32x2 a = pk_madd2<FMA>(uy, top, wy, bot);
+      f32x2 a;
+      if constexpr ((FMA & 2) != 0) {  // mmf_params.bilinear_four_weight_sum: the tree of bilin<FMA> (mmf_device.h), two channels at a time
+        const float w00 = ux * uy, w01 = ux * wy, w10 = wx * uy, w11 = wx * wy;
+        f32x2 t = pk_madd2<FMA>(w00, v00, w01, v01);
+        if constexpr ((FMA & 1) != 0) {
+          const f32x2 w10v = {w10, w10}, w11v = {w11, w11};
+          t = __builtin_elementwise_fma(w10v, v10, t);
+          a = __builtin_elementwise_fma(w11v, v11, t);
+        } else {
+          t = w10 * v10 + t;
+          a = w11 * v11 + t;
+        }
+      } else {
+        const f32x2 top = pk_madd2<FMA>(ux, v00, wx, v10);
+        const f32x2 bot = pk_madd2<FMA>(ux, v01, wx, v11);
+        a = pk_madd2<FMA>(uy, top, wy, bot);
+      }
       const f32x2 old = {(float)av[k], (float)av[k + 1]};
       const f32x2 num = pk_madd2<FMA>(old, Wv, a, wm);
       const f32x2 An = DIV ? num / (Wv + wm) : num * inv;
@@ -364,7 +378,7 @@ __device__ __forceinline__ void feature_voxel(const AppArgs& Aa, const MapConsts
 }
 
 // Phase 2 inside the workgroup that gated the block: 32 groups of 8 lanes walk the survivor list in LDS.
-template <bool LOW, bool DIV = false, bool FMA = false>
+template <bool LOW, bool DIV = false, int FMA = 0>
 __device__ inline void feature_apply(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new) {
   const int C = mc.C;
   const int group = threadIdx.x >> 3, gl = threadIdx.x & 7;
@@ -414,7 +428,7 @@ __device__ inline void feature_zero_fill(const AppArgs& A, const MapConsts& mc, 
 // tail of both gating bodies once the survivor list of the block is complete in LDS (callers synchronised before)
 // PUBLISH_ONLY: the caller guarantees a survivor list (A.flat.rec != nullptr), so the in-workgroup row update is not even
 // compiled in -- it is the register-hungriest code of the gating kernels (LOW: 175 VGPRs = 2 waves per SIMD, against 5).
-template <bool LOW, bool PUBLISH_ONLY = false, bool DIV = false, bool FMA = false>
+template <bool LOW, bool PUBLISH_ONLY = false, bool DIV = false, int FMA = 0>
 __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, FeatLds& S, int slot, bool is_new, int cand) {
   if constexpr (PUBLISH_ONLY) {
     feature_publish(A, S, slot, is_new, cand);
@@ -428,7 +442,7 @@ __device__ inline void feature_finish(const AppArgs& A, const MapConsts& mc, Fea
 }
 
 // Balanced phase 2: the frame's survivor list, `lpv` lanes per voxel row, any grid size (workgroup bid of nb).
-template <bool LOW, bool FMA = false>
+template <bool LOW, int FMA = 0>
 __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, int lpv, int bid, int nb, int* s_prefix) {
   const long long tr0 = wg_trace_begin();
   // prefix sums of the sub-list counters (one wave, shuffles): flat position v lives in sub-list k with prefix[k] <= v < prefix[k+1]
@@ -462,7 +476,7 @@ __device__ inline void feature_flat_role(const AppArgs& A, const MapConsts& mc, 
   wg_trace_end(tr0, kTrFeatureFlat);
 }
 
-template <bool LOW, bool DIV = false, bool FMA = false>
+template <bool LOW, bool DIV = false, int FMA = 0>
 __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const float* __restrict__ synth, int Ws, int Hs,
                                     int bid, int nb, FeatLds& S) {
   const LayerDev& L = A.L;
@@ -528,7 +542,7 @@ __device__ inline void feature_body(const AppArgs& A, const MapConsts& mc, const
 // frame both layers see the same camera and the same candidate list (the allocation jobs read the same flags), so the
 // projection, the two bilinear footprints and the occlusion test against the synthetic depth are evaluated once; only
 // the masks (depth mask for colour, eroded feature mask for features) differ.  Voxel order: thread t owns voxels 2t, 2t+1.
-template <bool LOW, bool PUB = false, bool FMA = false>
+template <bool LOW, bool PUB = false, int FMA = 0>
 __device__ inline void app_frame_body(const AppArgs& Ac, const AppArgs& Af, const MapConsts& mc, const float* __restrict__ synth,
                                       int Ws, int Hs, int bid, int nb, FeatLds& S) {
   const Cam& cam = Ac.cam;

@@ -50,10 +50,19 @@ struct MapConsts {
   float st_max_len, st_eps;
   int C;
   float reach;  // how far past the measured depth the raycast marks blocks: trunc (default) or 0
-  int spec_flags;  // bit 0: raycast walks from the camera; bit 1: appearance blend divides per channel; bit 2: fma_contraction
+  int spec_flags;  // bit 0: raycast walks from the camera; bit 1: appearance blend divides per channel; bit 2: fma_contraction;
+                   // bit 3: block_index_by_division; bit 4: view_truncation_band_marking; bit 5: bilinear_four_weight_sum
                    // (mmf_params spec switches)
 };
 constexpr int kSpecFma = 4;
+constexpr int kSpecBlockDiv = 8;
+constexpr int kSpecBandMark = 16;
+constexpr int kSpecBilin4 = 32;
+// switches only the stand-alone launches implement: frames of a mapper with any of them set are not fused, merged or pipelined
+constexpr int kSpecStandalone = 2 | kSpecBlockDiv | kSpecBandMark | kSpecBilin4;
+// The arithmetic mode the per-voxel device functions are instantiated for (their template parameter `FMA`, an int):
+//   bit 0: fma_contraction, bit 1: bilinear_four_weight_sum.  The fused kernels instantiate 0 (and 1: the un-merged FMA launches).
+__host__ __device__ inline int arith_mode(int spec_flags) { return ((spec_flags & kSpecFma) ? 1 : 0) | ((spec_flags & kSpecBilin4) ? 2 : 0); }
 
 // ---- spec switch mmf_params.fma_contraction (MapConsts::spec_flags & kSpecFma) ---------------------------------------------------
 // The library is built with -ffp-contract=off: `a * b + c` is two rounded operations everywhere.  nvcc contracts by default
@@ -66,9 +75,9 @@ constexpr int kSpecFma = 4;
 // feature taps, the low-res feature map incl. its source-index computation), the TSDF update's numerator and the appearance
 // blend's numerator -- in the oracle (fmaf) and here (v_fma_f32 / v_pk_fma_f32), same tree.  FMA is a template parameter like DIV:
 // the default kernels are not touched by it.
-template <bool FMA>
+template <int FMA>
 __device__ __forceinline__ float madd(float a, float b, float c) {
-  if constexpr (FMA)
+  if constexpr ((FMA & 1) != 0)
     return __builtin_fmaf(a, b, c);
   else
     return a * b + c;
@@ -116,9 +125,9 @@ __device__ __forceinline__ void update_consts_to_vgprs(MapConsts& mc) {
 }
 
 // a*x + b*y
-template <bool FMA>
+template <int FMA>
 __device__ __forceinline__ float madd2(float a, float x, float b, float y) {
-  if constexpr (FMA)
+  if constexpr ((FMA & 1) != 0)
     return __builtin_fmaf(a, x, b * y);
   else
     return a * x + b * y;
@@ -331,7 +340,7 @@ __device__ inline int layer_lookup(const LayerDev& L, u64 key) {
 
 __device__ inline int ifloor(float x) { return (int)floorf(x); }
 
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ inline void xform(const Rigid& T, const float* p, float* q) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) q[i] = madd<FMA>(T.R[i * 3 + 2], p[2], madd2<FMA>(T.R[i * 3 + 0], p[0], T.R[i * 3 + 1], p[1])) + T.t[i];
@@ -341,7 +350,7 @@ __device__ inline void rotate(const Rigid& T, const float* p, float* q) {
   for (int i = 0; i < 3; ++i) q[i] = (T.R[i * 3 + 0] * p[0] + T.R[i * 3 + 1] * p[1]) + T.R[i * 3 + 2] * p[2];
 }
 
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ inline void voxel_centre(const MapConsts& mc, int bx, int by, int bz, int lin, float* c) {
   int vx = lin >> 6, vy = (lin >> 3) & 7, vz = lin & 7;
   c[0] = madd2<FMA>((float)bx, mc.bs, (float)vx + 0.5f, mc.v);
@@ -349,7 +358,7 @@ __device__ inline void voxel_centre(const MapConsts& mc, int bx, int by, int bz,
   c[2] = madd2<FMA>((float)bz, mc.bs, (float)vz + 0.5f, mc.v);
 }
 
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ inline bool project(const Cam& c, const float* p, float& u, float& v) {
   if (p[2] <= 1e-6f) return false;
   float iz = 1.0f / p[2];
@@ -373,8 +382,15 @@ __device__ inline bool bilin_setup(float u, float v, int W, int H, int& x0, int&
   return true;
 }
 
-template <bool FMA = false>
+// (FMA & 2: mmf_params.bilinear_four_weight_sum -- four weighted taps in upstream's order of terms, oracle/mmf_oracle.c bilin_c)
+template <int FMA = 0>
 __device__ inline float bilin(float a00, float a10, float a01, float a11, float wx, float wy) {
+  if constexpr ((FMA & 2) != 0) {
+    const float w00 = (1.0f - wx) * (1.0f - wy), w01 = (1.0f - wx) * wy, w10 = wx * (1.0f - wy), w11 = wx * wy;
+    float t = madd2<FMA>(w00, a00, w01, a01);
+    t = madd<FMA>(w10, a10, t);
+    return madd<FMA>(w11, a11, t);
+  }
   float top = madd2<FMA>(1.0f - wx, a00, wx, a10);
   float bot = madd2<FMA>(1.0f - wx, a01, wx, a11);
   return madd2<FMA>(1.0f - wy, top, wy, bot);
@@ -402,13 +418,16 @@ __device__ inline bool in_workspace(const MapConsts& mc, int x, int y, int z) {
   return true;
 }
 
-// Voxel containing p: block floor(p*inv_bs), voxel clamp(floor((p - b*bs)*inv_v), 0, 7).
+// Voxel containing p: block floor(p*inv_bs), voxel clamp(floor((p - b*bs)*inv_v), 0, 7)  (mmf_params.block_index_by_division: by
+// division instead -- a uniform branch; the callers are the mesh's / the queries' look-ups, not the per-frame kernels).
 __device__ inline u64 voxel_at(const MapConsts& mc, const float* p, int& lin) {
   int b[3], vi[3];
+  const bool bdiv = (mc.spec_flags & kSpecBlockDiv) != 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    b[a] = ifloor(p[a] * mc.inv_bs);
-    int q = ifloor((p[a] - (float)b[a] * mc.bs) * mc.inv_v);
+    b[a] = ifloor(bdiv ? p[a] / mc.bs : p[a] * mc.inv_bs);
+    const float r = p[a] - (float)b[a] * mc.bs;
+    int q = ifloor(bdiv ? r / mc.v : r * mc.inv_v);
     vi[a] = q < 0 ? 0 : (q > 7 ? 7 : q);
   }
   lin = (vi[0] * 8 + vi[1]) * 8 + vi[2];

@@ -17,7 +17,7 @@ namespace mmf {
 // Candidate blocks: live TSDF blocks with a voxel inside the truncation band (W > 0, |D| < trunc)
 // whose centre projects into the appearance image.  One workgroup per live block, 2 voxels/thread.
 // ------------------------------------------------------------------------------------------------
-template <bool FMA>
+template <int FMA>
 __global__ __launch_bounds__(256) void k_app_candidates(LayerDev T, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        uint8_t* __restrict__ flags, u64* __restrict__ cell_key) {
   const int n = T.ctr[0];
@@ -65,7 +65,8 @@ constexpr int kRayLanes = 16;
 // One 4x4 ray patch = 256 threads (4 whole waves; no LDS, no barriers: the body may share a workgroup with other roles).
 // LAZY: the map is lazily decayed (LayerDev::epoch): a sampled voxel's weight may be cur_epoch - epoch[slot] decays behind -- the
 // missing multiplications are applied to the sampled value (block_free is kept current by the decay's compaction).
-template <bool LAZY = false>
+// BDIV: mmf_params.block_index_by_division (the stand-alone launch k_sphere_trace only): the sampled point's block / voxel by division.
+template <bool LAZY = false, bool BDIV = false>
 __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, const Cam& cam, const Rigid& T_L_C,
                                     float* __restrict__ synth, int Ws, int Hs, int patches_x, int patch, int tid,
                                     int* trace_iters = nullptr) {
@@ -152,9 +153,16 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
   };
   auto locate = [&](float tt, int& b0, int& b1, int& b2, int& lin) {  // block / voxel containing the ray point at tt
     const float p0 = o[0] + tt * dL[0], p1 = o[1] + tt * dL[1], p2 = o[2] + tt * dL[2];
-    b0 = ifloor(p0 * c_inv_bs), b1 = ifloor(p1 * c_inv_bs), b2 = ifloor(p2 * c_inv_bs);
-    int q0 = ifloor((p0 - (float)b0 * c_bs) * c_inv_v), q1 = ifloor((p1 - (float)b1 * c_bs) * c_inv_v),
-        q2 = ifloor((p2 - (float)b2 * c_bs) * c_inv_v);
+    int q0, q1, q2;
+    if constexpr (BDIV) {
+      const float c_v = mc.v;
+      b0 = ifloor(p0 / c_bs), b1 = ifloor(p1 / c_bs), b2 = ifloor(p2 / c_bs);
+      q0 = ifloor((p0 - (float)b0 * c_bs) / c_v), q1 = ifloor((p1 - (float)b1 * c_bs) / c_v), q2 = ifloor((p2 - (float)b2 * c_bs) / c_v);
+    } else {
+      b0 = ifloor(p0 * c_inv_bs), b1 = ifloor(p1 * c_inv_bs), b2 = ifloor(p2 * c_inv_bs);
+      q0 = ifloor((p0 - (float)b0 * c_bs) * c_inv_v), q1 = ifloor((p1 - (float)b1 * c_bs) * c_inv_v),
+      q2 = ifloor((p2 - (float)b2 * c_bs) * c_inv_v);
+    }
     q0 = q0 < 0 ? 0 : (q0 > 7 ? 7 : q0);
     q1 = q1 < 0 ? 0 : (q1 > 7 ? 7 : q1);
     q2 = q2 < 0 ? 0 : (q2 > 7 ? 7 : q2);
@@ -294,10 +302,10 @@ __device__ inline void sphere_patch(const LayerDev& T, const MapConsts& mc, cons
 #endif
 }
 
-template <bool LAZY>
+template <bool LAZY, bool BDIV = false>
 __global__ __launch_bounds__(256) void k_sphere_trace(LayerDev T, MapConsts mc, Cam cam, Rigid T_L_C, float* __restrict__ synth,
                                                      int Ws, int Hs, int patches_x) {
-  sphere_patch<LAZY>(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, blockIdx.x, threadIdx.x);
+  sphere_patch<LAZY, BDIV>(T, mc, cam, T_L_C, synth, Ws, Hs, patches_x, blockIdx.x, threadIdx.x);
 }
 
 // Large pools: the scalable colour + feature allocation (alloc_big_body: [job 0 chunks | job 1 chunks], look-back chains) and the
@@ -409,13 +417,13 @@ __global__ __launch_bounds__(256, 8) void k_sphere_alloc_batch(SphereBatch P) {
 }
 
 
-template <bool DIV, bool FMA>
+template <bool DIV, int FMA>
 __global__ __launch_bounds__(256) void k_color_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws, int Hs) {
   color_body<DIV, FMA>(A, mc, synth, Ws, Hs, blockIdx.x, gridDim.x);
 }
 
 
-template <bool LOW, bool FMA = false>
+template <bool LOW, int FMA = 0>
 __global__ __launch_bounds__(256) void k_feature_flat(AppArgs A, MapConsts mc, int lpv) {
   __shared__ int s_prefix[kFlatSubLists + 1];
   feature_flat_role<LOW, FMA>(A, mc, lpv, (int)blockIdx.x, (int)gridDim.x, s_prefix);
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256) void k_feature_flat_batch(FlatBatch P) {
 }
 
 
-template <bool LOW, bool DIV, bool FMA>
+template <bool LOW, bool DIV, int FMA>
 __global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                           int Hs) {
   __shared__ FeatLds S;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(256) void k_feature_integrate(AppArgs A, MapConsts 
 
 // Horizontal fusion: colour and feature update of one frame in ONE launch (different layers, same TSDF / synthetic
 // depth inputs): the first g_col workgroups walk the colour candidates, the rest the feature candidates.
-template <bool LOW, bool FMA>
+template <bool LOW, int FMA>
 __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth,
                                                        int Ws, int Hs, int g_col) {
   __shared__ FeatLds S;
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(256) void k_app_integrate2(AppArgs Acol, AppArgs Af
 
 
 // PUB: the frame has a survivor list (every fused frame): publish-only gating, independent of LOW (launched as <false, true>)
-template <bool LOW, bool PUB, bool FMA = false>
+template <bool LOW, bool PUB, int FMA = 0>
 __global__ __launch_bounds__(256) void k_app_frame(AppArgs Acol, AppArgs Afeat, MapConsts mc, const float* __restrict__ synth, int Ws,
                                                   int Hs) {
   __shared__ FeatLds S;
@@ -576,10 +584,16 @@ void launch_sphere_trace(const LayerDev& tsdf, const MapConsts& mc, const Cam& c
   const int patches_x = (Ws + 3) / 4, patches_y = (Hs + 3) / 4;
   const int n = patches_x * patches_y;
   if (n <= 0) return;
-  if (tsdf.epoch)  // a lazily decayed map: sampled weights are brought up to date on the fly
-    hipLaunchKernelGGL(k_sphere_trace<true>, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+  const bool bdiv = (mc.spec_flags & kSpecBlockDiv) != 0;  // mmf_params.block_index_by_division
+  if (tsdf.epoch) {  // a lazily decayed map: sampled weights are brought up to date on the fly
+    if (bdiv)
+      hipLaunchKernelGGL((k_sphere_trace<true, true>), dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+    else
+      hipLaunchKernelGGL((k_sphere_trace<true, false>), dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+  } else if (bdiv)
+    hipLaunchKernelGGL((k_sphere_trace<false, true>), dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
   else
-    hipLaunchKernelGGL(k_sphere_trace<false>, dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
+    hipLaunchKernelGGL((k_sphere_trace<false, false>), dim3(n), dim3(256), 0, s, tsdf, mc, cam, T_L_C, synth, Ws, Hs, patches_x);
 }
 
 static int flat_lanes_per_voxel(const MapConsts& mc);
@@ -721,16 +735,22 @@ void launch_color_integrate(const LayerDev& L, const MapConsts& mc, const Cam& c
                             const uint8_t* mask, const float* synth, int Ws, int Hs, const Scratch& sc, int max_cand,
                             hipStream_t s) {
   const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
-  const bool div = (mc.spec_flags & 2) != 0, fma = (mc.spec_flags & kSpecFma) != 0;  // mmf_params.appearance_blend_division, .fma_contraction
+  const bool div = (mc.spec_flags & 2) != 0;  // mmf_params.appearance_blend_division
+  const int ar = arith_mode(mc.spec_flags);   // bit 0 .fma_contraction, bit 1 .bilinear_four_weight_sum
   const AppArgs A = make_app_args(L, cam, T_C_L, rgb, mask, sc);
-  if (div && fma)
-    hipLaunchKernelGGL((k_color_integrate<true, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  else if (div)
-    hipLaunchKernelGGL((k_color_integrate<true, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  else if (fma)
-    hipLaunchKernelGGL((k_color_integrate<false, true>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
-  else
-    hipLaunchKernelGGL((k_color_integrate<false, false>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs);
+#define MMF_CI(DIVV, ARV) hipLaunchKernelGGL((k_color_integrate<DIVV, ARV>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs)
+  if (div) {
+    if (ar == 3) MMF_CI(true, 3);
+    else if (ar == 2) MMF_CI(true, 2);
+    else if (ar == 1) MMF_CI(true, 1);
+    else MMF_CI(true, 0);
+  } else {
+    if (ar == 3) MMF_CI(false, 3);
+    else if (ar == 2) MMF_CI(false, 2);
+    else if (ar == 1) MMF_CI(false, 1);
+    else MMF_CI(false, 0);
+  }
+#undef MMF_CI
 }
 
 static AppArgs make_app_args(const LayerDev& L, const Cam& cam, const Rigid& T_C_L, const void* image, const uint8_t* mask,
@@ -757,10 +777,12 @@ AppArgs make_flat_args(const LayerDev& L, const Cam& cam, const __half* feat, co
 
 template <bool LOW>
 static void launch_flat_kernel(dim3 grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const AppArgs& Af, const MapConsts& mc, int lpv) {
-  if (mc.spec_flags & kSpecFma)  // mmf_params.fma_contraction
-    hipExtLaunchKernelGGL((k_feature_flat<LOW, true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
-  else
-    hipExtLaunchKernelGGL((k_feature_flat<LOW, false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv);
+  switch (arith_mode(mc.spec_flags)) {  // bit 0 mmf_params.fma_contraction, bit 1 .bilinear_four_weight_sum
+    case 1: hipExtLaunchKernelGGL((k_feature_flat<LOW, 1>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv); break;
+    case 2: hipExtLaunchKernelGGL((k_feature_flat<LOW, 2>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv); break;
+    case 3: hipExtLaunchKernelGGL((k_feature_flat<LOW, 3>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv); break;
+    default: hipExtLaunchKernelGGL((k_feature_flat<LOW, 0>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Af, mc, lpv); break;
+  }
 }
 
 // the stand-alone row update from a saved argument block (the flush of a deferred one)
@@ -811,19 +833,20 @@ void launch_feature_integrate(const LayerDev& L, const MapConsts& mc, const Cam&
   const dim3 grid(grid8(hinted(sc.hint_cand, max_cand), 8192));
   const bool div = (mc.spec_flags & 2) != 0;  // mmf_params.appearance_blend_division: rows are updated inside the gating workgroup
   const AppArgs A = make_app_args(L, cam, T_C_L, feat, mask, sc, stats, low, div ? nullptr : flat);
-  const bool fma = (mc.spec_flags & kSpecFma) != 0;  // mmf_params.fma_contraction
-#define MMF_FI(LOWV, DIVV, FMAV) hipLaunchKernelGGL((k_feature_integrate<LOWV, DIVV, FMAV>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs)
-  if (fma) {
-    if (low && div) MMF_FI(true, true, true);
-    else if (low) MMF_FI(true, false, true);
-    else if (div) MMF_FI(false, true, true);
-    else MMF_FI(false, false, true);
-  } else {
-    if (low && div) MMF_FI(true, true, false);
-    else if (low) MMF_FI(true, false, false);
-    else if (div) MMF_FI(false, true, false);
-    else MMF_FI(false, false, false);
-  }
+  const int ar = arith_mode(mc.spec_flags);  // bit 0 mmf_params.fma_contraction, bit 1 .bilinear_four_weight_sum
+#define MMF_FI(LOWV, DIVV, ARV) hipLaunchKernelGGL((k_feature_integrate<LOWV, DIVV, ARV>), grid, dim3(256), 0, s, A, mc, synth, Ws, Hs)
+#define MMF_FI4(ARV)                              \
+  do {                                            \
+    if (low && div) MMF_FI(true, true, ARV);      \
+    else if (low) MMF_FI(true, false, ARV);       \
+    else if (div) MMF_FI(false, true, ARV);       \
+    else MMF_FI(false, false, ARV);               \
+  } while (0)
+  if (ar == 3) MMF_FI4(3);
+  else if (ar == 2) MMF_FI4(2);
+  else if (ar == 1) MMF_FI4(1);
+  else MMF_FI4(0);
+#undef MMF_FI4
 #undef MMF_FI
 }
 

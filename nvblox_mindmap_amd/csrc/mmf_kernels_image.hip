@@ -329,7 +329,7 @@ __device__ __forceinline__ Up8 up_load8(const float* __restrict__ low, int w, in
 }
 
 // FMA: the spec switch mmf_params.fma_contraction applied to this op (mmf_upsample_features_spec; see mmf_device.h)
-template <bool VEC, bool FMA>
+template <bool VEC, int FMA>
 __global__ __launch_bounds__(256) void k_upsample_features(const float* __restrict__ low, int h, int w, int Cin,
                                                           __half* __restrict__ out, int Hf, int Wf, int Cpad, float sh,
                                                           float sw) {

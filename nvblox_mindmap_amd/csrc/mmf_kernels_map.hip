@@ -77,7 +77,9 @@ __device__ inline void walk_step(Walk& w) {
 constexpr int kRaycastLdsCells = 32768;
 
 
-template <bool LDSFLAGS>
+// SPEC: the stand-alone launch of a mapper with mmf_params.block_index_by_division / .view_truncation_band_marking set (uniform
+// branches on MapConsts::spec_flags); the fused kernels instantiate SPEC = false and contain neither.
+template <bool LDSFLAGS, bool SPEC = false>
 __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_words) {
   const MapConsts& mc = R.mc;
   const Cam& cam = R.cam;
@@ -120,6 +122,13 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
     xform(T_L_C, pC, pL);
     float s0[3] = {T_L_C.t[0] * mc.inv_bs, T_L_C.t[1] * mc.inv_bs, T_L_C.t[2] * mc.inv_bs};
     float e[3] = {pL[0] * mc.inv_bs, pL[1] * mc.inv_bs, pL[2] * mc.inv_bs};
+    if (SPEC && (mc.spec_flags & kSpecBlockDiv)) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s0[a] = T_L_C.t[a] / mc.bs;
+        e[a] = pL[a] / mc.bs;
+      }
+    }
     // Only blocks inside the workspace bounds can be in view: the walk starts where the ray enters them, two cells early
     // (oracle/mmf_oracle.c clip_walk_start: same operations in the same order), not at the camera -- a quarter of the steps of a
     // camera that orbits the task's box.
@@ -178,6 +187,31 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
       }
       walk_step(w);
     }
+    if (SPEC && (mc.spec_flags & kSpecBandMark)) {
+      // the blocks that intersect the cube [p - trunc, p + trunc]^3 around the pixel's surface point p = T_L_C (d * ray)
+      // (oracle/mmf_oracle.c blocks_in_view, view_truncation_band_marking); the view grid is the workspace intersection, padded by a block
+      const float qC[3] = {d * ray[0], d * ray[1], d * ray[2]};
+      float qL[3];
+      xform(T_L_C, qC, qL);
+      int lo[3], hi[3];
+      const bool bdiv = (mc.spec_flags & kSpecBlockDiv) != 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float l = qL[a] - mc.trunc, h = qL[a] + mc.trunc;
+        lo[a] = ifloor(bdiv ? l / mc.bs : l * mc.inv_bs) - o3[a];
+        hi[a] = ifloor(bdiv ? h / mc.bs : h * mc.inv_bs) - o3[a];
+      }
+      for (int gx = lo[0]; gx <= hi[0]; ++gx)
+        for (int gy = lo[1]; gy <= hi[1]; ++gy)
+          for (int gz = lo[2]; gz <= hi[2]; ++gz)
+            if ((unsigned)gx < (unsigned)vg.nx && (unsigned)gy < (unsigned)vg.ny && (unsigned)gz < (unsigned)vg.nz) {
+              const int cell = (gx * vg.ny + gy) * vg.nz + gz;
+              if (LDSFLAGS)
+                s_flags[cell] = 1;
+              else
+                flags[cell] = (uint8_t)R.flag_value;
+            }
+    }
   }
   if (LDSFLAGS) {
     __syncthreads();
@@ -191,10 +225,10 @@ __device__ inline void raycast_body(const RaycastJob& R, int bid, unsigned* s_wo
   }
 }
 
-template <bool LDSFLAGS>
+template <bool LDSFLAGS, bool SPEC = false>
 __global__ __launch_bounds__(256) void k_raycast_mark(RaycastJob R) {
   extern __shared__ unsigned s_words[];  // LDSFLAGS: ceil(ncells/4) words of 4 byte flags
-  raycast_body<LDSFLAGS>(R, blockIdx.x, s_words);
+  raycast_body<LDSFLAGS, SPEC>(R, blockIdx.x, s_words);
 }
 
 // Horizontal fusion: the raycast tiles and the row pass of the frame's mask job in ONE launch (independent work:
@@ -534,7 +568,7 @@ typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 8-by
 // row-pair loads; the nearest tap (pixel floor(u), floor(v)) is one of the four whenever the footprint is inside
 // the image (u - 0.5 is exact in float32, so floor(u) = x0 + (wx >= 0.5)), which turns 5 scattered depth reads
 // (+5 mask reads) per voxel into 2.
-template <bool FMA = false>
+template <int FMA = 0>
 __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
                                     float min_d, const Cam& cam, float u, float v, float& out) {
   int x0, y0;
@@ -587,7 +621,7 @@ __device__ inline bool sample_depth(const MapConsts& mc, const float* __restrict
 //   in_view <- the voxel centre projects into the image, not beyond the maximum integration distance (evaluated when `want_view`);
 //   if `cand` (the block is integrated this frame) and in view and the depth sample is valid and sdf >= -trunc and w > 0:
 //     D <- clamp((sdf w + D W) / (w + W), +-trunc),  W <- min(W + w, max_weight);  returns true iff D / W changed.
-template <bool MASKED, bool FMA = false>
+template <bool MASKED, int FMA = 0>
 __device__ inline bool tsdf_voxel_update(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
                                          const uint8_t* __restrict__ mask, float min_d, int bx, int by, int bz, int lin, bool cand,
                                          bool want_view, float& D, float& W, bool& in_view) {
@@ -624,7 +658,7 @@ struct TsdfBlockAcc {
 // eager decays would have been (1 for the pending decay of a bounded map, cur_epoch - epoch[slot] in lazy mode, 0: none).
 // `may_write` false: a read-only visit (lazy mode, a block this frame does not integrate: only its appearance flag is wanted).
 // LAGLOOP false: lag is 0 or 1 (the hot bounded kernels: one predicated multiplication, no loop).
-template <int VPT, bool MASKED, bool LAGLOOP = false, bool FMA = false>
+template <int VPT, bool MASKED, bool LAGLOOP = false, int FMA = 0>
 __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth,
                                         const uint8_t* __restrict__ mask, float min_d, float decay_f, int lag, bool may_write, int bx, int by,
                                         int bz, int lin0, bool cand, bool is_new, float4* __restrict__ vox, TsdfBlockAcc& acc,
@@ -702,7 +736,7 @@ __device__ inline void tsdf_voxel_group(const MapConsts& mc, const Cam& cam, con
 // (no trap on this target).  The same float operations on every voxel that is updated: bit-identical to tsdf_voxel_group over the parity,
 // fuzz, soak and hash suites.  Measured (round 5, profiles/r05p_branch_free.txt): k_alloc_tsdf 14.6 -> 14.3 us, the lazy pass of the hash
 // path 116 -> 112 us.  tsdf_voxel_group stays for the masked stand-alone calls (its mask taps are worth skipping).
-template <int VPT, bool LAGLOOP, bool FMA>
+template <int VPT, bool LAGLOOP, int FMA>
 __device__ inline void tsdf_voxel_group_bf(const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* __restrict__ depth, float min_d,
                                            float decay_f, int lag, bool may_write, int bx, int by, int bz, int lin0, bool cand, bool is_new,
                                            float4* __restrict__ vox, TsdfBlockAcc& acc, long long* ph = nullptr) {
@@ -809,7 +843,7 @@ __device__ inline void tsdf_voxel_group_bf(const MapConsts& mc, const Cam& cam, 
 #endif
 }
 
-template <bool FMA>
+template <int FMA>
 __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                        const float* __restrict__ depth,
                                                        const uint8_t* __restrict__ mask, float min_d, Scratch sc) {
@@ -847,7 +881,7 @@ __global__ __launch_bounds__(512) void k_tsdf_integrate(LayerDev L, MapConsts mc
 // the blocks this frame integrates plus the near-surface blocks whose appearance flag needs their voxels -- instead of every live
 // block; a block's missing decays (cur_epoch - epoch[slot]) are applied before it is integrated, a block that is only looked at
 // is not written.  Not LAZY on a layer with lazy summaries (L.epoch != nullptr): the full pass that (re)establishes them.
-template <int VPT, bool MASKED, bool LAZY, bool FMA>
+template <int VPT, bool MASKED, bool LAZY, int FMA>
 __global__ __launch_bounds__(512 / VPT) MMF_SGPR96 void k_tsdf_pass(LayerDev L, MapConsts mc, Cam cam, Rigid T_C_L,
                                                         const float* __restrict__ depth, const uint8_t* __restrict__ mask_arg,
                                                         float min_d, int stamp, uint8_t* __restrict__ flags,
@@ -1560,10 +1594,17 @@ void launch_raycast(const MapConsts& mc, const Cam& cam, const Rigid& T_L_C, con
   RaycastJob R = make_raycast_job(mc, cam, T_L_C, depth, mask, min_d, sub, vg, flags, n_wgs);
   if (n_wgs <= 0) return;
   const int ncells = vg.nx * vg.ny * vg.nz;
-  if (ncells <= kRaycastLdsCells)
-    hipLaunchKernelGGL(k_raycast_mark<true>, dim3(n_wgs), dim3(256), (size_t)((ncells + 3) / 4) * 4, s, R);
+  const bool spec = (mc.spec_flags & (kSpecBlockDiv | kSpecBandMark)) != 0;  // (the stand-alone launch is the only one built with them)
+  const size_t shm = (size_t)((ncells + 3) / 4) * 4;
+  if (ncells <= kRaycastLdsCells) {
+    if (spec)
+      hipLaunchKernelGGL((k_raycast_mark<true, true>), dim3(n_wgs), dim3(256), shm, s, R);
+    else
+      hipLaunchKernelGGL((k_raycast_mark<true, false>), dim3(n_wgs), dim3(256), shm, s, R);
+  } else if (spec)
+    hipLaunchKernelGGL((k_raycast_mark<false, true>), dim3(n_wgs), dim3(256), 0, s, R);
   else
-    hipLaunchKernelGGL(k_raycast_mark<false>, dim3(n_wgs), dim3(256), 0, s, R);
+    hipLaunchKernelGGL((k_raycast_mark<false, false>), dim3(n_wgs), dim3(256), 0, s, R);
 }
 
 // raycast + mask row pass (+ pending decay) of a frame: arguments of its share of the first launch
@@ -1811,12 +1852,13 @@ static inline int grid_for(int upper, int cap) {
 
 void launch_tsdf_integrate(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                            const uint8_t* mask, float min_d, const Scratch& sc, int max_cand, hipStream_t s) {
-  if (mc.spec_flags & kSpecFma)
-    hipLaunchKernelGGL(k_tsdf_integrate<true>, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
-                       mask, min_d, sc);
-  else
-    hipLaunchKernelGGL(k_tsdf_integrate<false>, dim3(grid_for(hinted(sc.hint_cand, max_cand), 8192)), dim3(512), 0, s, L, mc, cam, T_C_L, depth,
-                       mask, min_d, sc);
+  const dim3 grid(grid_for(hinted(sc.hint_cand, max_cand), 8192));
+  switch (arith_mode(mc.spec_flags)) {  // bit 0 fma_contraction, bit 1 bilinear_four_weight_sum
+    case 1: hipLaunchKernelGGL(k_tsdf_integrate<1>, grid, dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, sc); break;
+    case 2: hipLaunchKernelGGL(k_tsdf_integrate<2>, grid, dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, sc); break;
+    case 3: hipLaunchKernelGGL(k_tsdf_integrate<3>, grid, dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, sc); break;
+    default: hipLaunchKernelGGL(k_tsdf_integrate<0>, grid, dim3(512), 0, s, L, mc, cam, T_C_L, depth, mask, min_d, sc); break;
+  }
 }
 
 // ---- import of a saved layer (Mapper.load_from_file): block i of the file takes pool slot i, live position i -----------
@@ -1888,7 +1930,7 @@ void launch_invert_mask(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s
   if (n) hipLaunchKernelGGL(k_invert_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 
-template <bool FMA>
+template <int FMA>
 static void launch_tsdf_pass_t(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                                const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
   const dim3 grid(grid_for(hinted(L.hint_live, L.cap), 8192));

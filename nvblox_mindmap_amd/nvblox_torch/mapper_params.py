@@ -11,6 +11,12 @@ from .. import _lib
 
 # default of the spec switch fma_contraction for every mapper of the process (benchmark legs / whole test suites under the switch)
 FMA_CONTRACTION_DEFAULT = os.environ.get("MMF_FMA_CONTRACTION", "0") == "1"
+# the same for the three spec switches of round 6 (pin tooling: whole parity / fuzz suites under a flip):
+# MMF_SPEC_FLIPS=block_index_by_division,view_truncation_band_marking,bilinear_four_weight_sum (any subset)
+_SPEC_FLIP_NAMES = ("block_index_by_division", "view_truncation_band_marking", "bilinear_four_weight_sum")
+SPEC_FLIP_DEFAULTS = frozenset(x.strip() for x in os.environ.get("MMF_SPEC_FLIPS", "").split(",") if x.strip())
+if SPEC_FLIP_DEFAULTS - set(_SPEC_FLIP_NAMES):
+    raise ValueError(f"MMF_SPEC_FLIPS: unknown spec switch(es) {sorted(SPEC_FLIP_DEFAULTS - set(_SPEC_FLIP_NAMES))}; known: {_SPEC_FLIP_NAMES}")
 
 
 class _Bag:
@@ -51,6 +57,9 @@ class ProjectiveIntegratorParams(_Bag):
         # the two blends' numerators, as nvcc's default -fmad=true would (include/mmfusion.h: mmf_params.fma_contraction)
         # (MMF_FMA_CONTRACTION=1 in the environment makes it the default of every mapper of the process: benchmarks / whole test suites)
         "projective_integrator_fma_contraction": FMA_CONTRACTION_DEFAULT,
+        # spec switch (not an upstream field): bilinear samples (depth, synthetic depth, colour / feature taps) as four weighted taps in
+        # upstream's order of terms instead of nested lerps (include/mmfusion.h: mmf_params.bilinear_four_weight_sum)
+        "projective_integrator_bilinear_four_weight_sum": "bilinear_four_weight_sum" in SPEC_FLIP_DEFAULTS,
     }
 
 
@@ -78,6 +87,10 @@ class ViewCalculatorParams(_Bag):
         "raycast_to_truncation_distance": True,
         # spec switch (not an upstream field): a ray's block walk starts at the camera (True) or where it enters the workspace bounds
         "raycast_walk_from_camera": False,
+        # spec switch (not an upstream field): the block (and voxel) of a point by floor(p / size) (True) or floor(p * (1 / size))
+        "block_index_by_division": "block_index_by_division" in SPEC_FLIP_DEFAULTS,
+        # spec switch (not an upstream field): a pixel also marks the blocks within `truncation` of its surface point
+        "view_truncation_band_marking": "view_truncation_band_marking" in SPEC_FLIP_DEFAULTS,
     }
 
 
@@ -200,4 +213,7 @@ class MapperParams:
         p.raycast_walk_from_camera = 1 if vc.raycast_walk_from_camera else 0
         p.appearance_blend_division = 1 if pi.projective_appearance_integrator_blend_division else 0
         p.fma_contraction = 1 if pi.projective_integrator_fma_contraction else 0
+        p.bilinear_four_weight_sum = 1 if pi.projective_integrator_bilinear_four_weight_sum else 0
+        p.block_index_by_division = 1 if vc.block_index_by_division else 0
+        p.view_truncation_band_marking = 1 if vc.view_truncation_band_marking else 0
         return p

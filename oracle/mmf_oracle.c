@@ -101,6 +101,24 @@ typedef struct {
    * appearance gate, colour / feature taps), the TSDF update's numerator and the appearance blend's numerator -- MADD / MADD2
    * below.  The raycast walk, the sphere tracer and the mesh stay as they are (they decide block sets and gates, not values). */
   int fma_contraction;
+  /* Three more places where this restatement may have mis-recollected upstream; each switchable in the oracle
+   * and in the HIP library alike (frames of a mapper with any of them set take the stand-alone launches), so that a pin that
+   * differs only there is attributable:
+   * block_index_by_division      0: block of p = floor(p * (1 / block_size)), voxel = floor((p - b * block_size) * (1 / voxel_size));
+   *                              1: floor(p / block_size), floor((p - b * block_size) / voxel_size) -- differs exactly for points within
+   *                                 an ulp of a block / voxel face (the block SET can differ: workspace bounds, ray end points, walk
+   *                                 coordinates, the sphere tracer's and the mesh's voxel look-ups all use it).
+   * view_truncation_band_marking 0: a pixel's ray marks the blocks it traverses (camera -> depth + truncation);
+   *                              1: additionally every block that intersects the axis-aligned cube of half-width `truncation` around
+   *                                 the SURFACE point of the pixel (depth, clamped like the ray's) -- SURVEY.md App. A.2's "second kernel".
+   * bilinear_four_weight_sum     0: nested lerps  (1-wy)((1-wx) a00 + wx a10) + wy((1-wx) a01 + wx a11);
+   *                              1: four weighted taps, in upstream's order of terms
+   *                                 (((1-wx)(1-wy)) a00 + ((1-wx) wy) a01) + (wx (1-wy)) a10 + (wx wy) a11   (left to right),
+   *                                 contracted under fma_contraction as fma(w11, a11, fma(w10, a10, fma(w00, a00, w01 a01))).
+   *                                 Applies to every bilinear sample of the integrator (depth, synthetic depth, colour, feature taps). */
+  int block_index_by_division;
+  int view_truncation_band_marking;
+  int bilinear_four_weight_sum;
 } orc_params;
 
 void orc_default_params(orc_params* p) {
@@ -124,6 +142,9 @@ void orc_default_params(orc_params* p) {
   p->raycast_walk_from_camera = 0;
   p->appearance_blend_division = 0;
   p->fma_contraction = 0;
+  p->block_index_by_division = 0;
+  p->view_truncation_band_marking = 0;
+  p->bilinear_four_weight_sum = 0;
   p->st_subsampling = 4;
   p->st_max_steps = 100;
   p->st_max_ray_length_m = 15.0f;
@@ -132,6 +153,7 @@ void orc_default_params(orc_params* p) {
 }
 
 int orc_params_size(void) { return (int)sizeof(orc_params); }
+static inline int bilin_mode(const orc_params* P) { return (P->fma_contraction ? 1 : 0) | (P->bilinear_four_weight_sum ? 2 : 0); }
 
 /* ------------------------------------------------------------------------------- */
 /* half <-> float (round-to-nearest-even, denormals kept)                          */
@@ -287,7 +309,15 @@ static inline int bilin_setup(float u, float v, int W, int H, int* x0, int* y0, 
   return 1;
 }
 
-static inline float bilin_c(float a00, float a10, float a01, float a11, float wx, float wy, int fma) {
+/* fma: bit 0 = orc_params.fma_contraction, bit 1 = orc_params.bilinear_four_weight_sum (bilin_mode() below packs them) */
+static inline float bilin_c(float a00, float a10, float a01, float a11, float wx, float wy, int mode) {
+  const int fma = mode & 1;
+  if (mode & 2) {
+    float w00 = (1.0f - wx) * (1.0f - wy), w01 = (1.0f - wx) * wy, w10 = wx * (1.0f - wy), w11 = wx * wy;
+    float t = MADD2(fma, w00, a00, w01, a01);
+    t = MADD(fma, w10, a10, t);
+    return MADD(fma, w11, a11, t);
+  }
   float top = MADD2(fma, 1.0f - wx, a00, wx, a10);
   float bot = MADD2(fma, 1.0f - wx, a01, wx, a11);
   return MADD2(fma, 1.0f - wy, top, wy, bot);
@@ -482,14 +512,18 @@ static inline int project_voxel(const orc_mapper* m, const cam_t* cam, const rig
   return project_c(cam, p, u, v, fma);
 }
 
+/* position -> block units / voxel units under orc_params.block_index_by_division */
+static inline float to_blocks(const orc_mapper* m, float x) { return m->P.block_index_by_division ? x / m->bs : x * m->inv_bs; }
+static inline float to_voxels(const orc_mapper* m, float x) { return m->P.block_index_by_division ? x / m->v : x * m->inv_v; }
+
 /* workspace test on a block index (inclusive index range of the bounds' own blocks) */
 static inline int in_workspace(const orc_mapper* m, int x, int y, int z) {
   const orc_params* P = &m->P;
   if (P->workspace_bounds_type == 0) return 1;
-  if (z < ifloor(P->ws_min[2] * m->inv_bs) || z > ifloor(P->ws_max[2] * m->inv_bs)) return 0;
+  if (z < ifloor(to_blocks(m, P->ws_min[2])) || z > ifloor(to_blocks(m, P->ws_max[2]))) return 0;
   if (P->workspace_bounds_type == 1) return 1;
-  if (x < ifloor(P->ws_min[0] * m->inv_bs) || x > ifloor(P->ws_max[0] * m->inv_bs)) return 0;
-  if (y < ifloor(P->ws_min[1] * m->inv_bs) || y > ifloor(P->ws_max[1] * m->inv_bs)) return 0;
+  if (x < ifloor(to_blocks(m, P->ws_min[0])) || x > ifloor(to_blocks(m, P->ws_max[0]))) return 0;
+  if (y < ifloor(to_blocks(m, P->ws_min[1])) || y > ifloor(to_blocks(m, P->ws_max[1]))) return 0;
   return 1;
 }
 
@@ -616,7 +650,7 @@ static void clip_walk_start(const orc_mapper* m, const float* s0, const float* e
     float ar = fabsf(r[a]);
     if (ar > big) big = ar;
     if (type == 1 && a < 2) continue;
-    float lo = (float)ifloor(m->P.ws_min[a] * m->inv_bs), hi = (float)(ifloor(m->P.ws_max[a] * m->inv_bs) + 1), ta = 0.0f;
+    float lo = (float)ifloor(to_blocks(m, m->P.ws_min[a])), hi = (float)(ifloor(to_blocks(m, m->P.ws_max[a])) + 1), ta = 0.0f;
     if (r[a] > 0.0f) ta = (lo - s0[a]) / r[a];
     else if (r[a] < 0.0f) ta = (hi - s0[a]) / r[a];
     if (ta > t0) t0 = ta;
@@ -643,7 +677,7 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
   set3_init(&S, 4096);
   int sub = P->raycast_subsampling < 1 ? 1 : P->raycast_subsampling;
   float s0[3];
-  for (int a = 0; a < 3; ++a) s0[a] = T_L_C->t[a] * m->inv_bs;
+  for (int a = 0; a < 3; ++a) s0[a] = to_blocks(m, T_L_C->t[a]);
   /* rows are independent: every thread collects into its own set, the sets are merged afterwards (the result is a
    * sorted set, so neither the thread count nor the merge order can change it) */
 #pragma omp parallel
@@ -664,7 +698,7 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
         float pC[3] = {s * ray[0], s * ray[1], s * ray[2]};
         float pL[3];
         xform(T_L_C, pC, pL);
-        float e[3] = {pL[0] * m->inv_bs, pL[1] * m->inv_bs, pL[2] * m->inv_bs};
+        float e[3] = {to_blocks(m, pL[0]), to_blocks(m, pL[1]), to_blocks(m, pL[2])};
         float sc[3];
         clip_walk_start(m, s0, e, sc);
         walk_t w;
@@ -672,6 +706,20 @@ static void blocks_in_view(orc_mapper* m, const float* depth, const uint8_t* mas
         for (int i = 0; i <= w.n; ++i) {
           if (in_workspace(m, w.c[0], w.c[1], w.c[2])) set3_insert(&Sl, w.c[0], w.c[1], w.c[2]);
           walk_step(&w);
+        }
+        if (P->view_truncation_band_marking) {
+          /* the blocks that intersect the cube [p - trunc, p + trunc]^3 around the pixel's surface point p = T_L_C (d * ray) */
+          float qC[3] = {d * ray[0], d * ray[1], d * ray[2]}, qL[3];
+          int lo[3], hi[3];
+          xform(T_L_C, qC, qL);
+          for (int a = 0; a < 3; ++a) {
+            lo[a] = ifloor(to_blocks(m, qL[a] - m->trunc));
+            hi[a] = ifloor(to_blocks(m, qL[a] + m->trunc));
+          }
+          for (int x = lo[0]; x <= hi[0]; ++x)
+            for (int y = lo[1]; y <= hi[1]; ++y)
+              for (int z = lo[2]; z <= hi[2]; ++z)
+                if (in_workspace(m, x, y, z)) set3_insert(&Sl, x, y, z);
         }
       }
     }
@@ -737,7 +785,7 @@ static inline int sample_depth(const orc_mapper* m, const float* depth, const ui
         if (fabsf(a00 - dn) > md || fabsf(a10 - dn) > md || fabsf(a01 - dn) > md || fabsf(a11 - dn) > md) ok = 0;
       }
       if (ok) {
-        *out = bilin_c(a00, a10, a01, a11, wx, wy, m->P.fma_contraction);
+        *out = bilin_c(a00, a10, a01, a11, wx, wy, bilin_mode(&m->P));
         return 1;
       }
     }
@@ -831,8 +879,8 @@ int orc_add_depth_frame(orc_mapper* m, const float* depth, const uint8_t* mask, 
 static inline int voxel_at(const orc_mapper* m, const layer_t* L, const float* p, int* lin) {
   int b[3], vi[3];
   for (int a = 0; a < 3; ++a) {
-    b[a] = ifloor(p[a] * m->inv_bs);
-    int q = ifloor((p[a] - (float)b[a] * m->bs) * m->inv_v);
+    b[a] = ifloor(to_blocks(m, p[a]));
+    int q = ifloor(to_voxels(m, p[a] - (float)b[a] * m->bs));
     vi[a] = q < 0 ? 0 : (q > 7 ? 7 : q);
   }
   int pos = layer_find(L, b[0], b[1], b[2]);
@@ -969,7 +1017,7 @@ static inline int app_gate(const orc_mapper* m, const cam_t* cam, const rigid_t*
   float s00 = S[(size_t)sy * m->synth_W + sx], s10 = S[(size_t)sy * m->synth_W + sx + 1];
   float s01 = S[(size_t)(sy + 1) * m->synth_W + sx], s11 = S[(size_t)(sy + 1) * m->synth_W + sx + 1];
   if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) return 0;
-  float s = bilin_c(s00, s10, s01, s11, swx, swy, P->fma_contraction);
+  float s = bilin_c(s00, s10, s01, s11, swx, swy, bilin_mode(P));
   if (fabsf(s - p[2]) > m->trunc) return 0;
   if (!bilin_setup(u, v, cam->W, cam->H, x0, y0, wx, wy)) return 0;
   if (mask) {
@@ -1018,7 +1066,7 @@ int orc_add_feature_frame(orc_mapper* m, const uint16_t* feat, const uint8_t* ma
       float inv = 1.0f / (Wv + wm);
       uint16_t* Av = A + (size_t)lin * C;
       for (int k = 0; k < C; ++k) {
-        float a = bilin_c(h2f(t00[k]), h2f(t10[k]), h2f(t01[k]), h2f(t11[k]), wx, wy, m->P.fma_contraction);
+        float a = bilin_c(h2f(t00[k]), h2f(t10[k]), h2f(t01[k]), h2f(t11[k]), wx, wy, bilin_mode(&m->P));
         float num = MADD2(m->P.fma_contraction, h2f(Av[k]), Wv, a, wm);
         float An = m->P.appearance_blend_division ? num / (Wv + wm) : num * inv;
         Av[k] = f2h(An);
@@ -1060,7 +1108,7 @@ int orc_add_color_frame(orc_mapper* m, const uint8_t* rgb, const uint8_t* mask, 
       float Wv = cb->w[lin];
       float inv = 1.0f / (Wv + wm);
       for (int k = 0; k < 3; ++k) {
-        float a = bilin_c((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy, m->P.fma_contraction);
+        float a = bilin_c((float)t00[k], (float)t10[k], (float)t01[k], (float)t11[k], wx, wy, bilin_mode(&m->P));
         float num = MADD2(m->P.fma_contraction, (float)cb->rgb[lin * 3 + k], Wv, a, wm);
         float An = m->P.appearance_blend_division ? num / (Wv + wm) : num * inv;
         cb->rgb[lin * 3 + k] = (uint8_t)floorf(An + 0.5f);

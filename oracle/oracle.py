@@ -44,6 +44,9 @@ class OrcParams(C.Structure):
         ("raycast_walk_from_camera", C.c_int),
         ("appearance_blend_division", C.c_int),
         ("fma_contraction", C.c_int),
+        ("block_index_by_division", C.c_int),
+        ("view_truncation_band_marking", C.c_int),
+        ("bilinear_four_weight_sum", C.c_int),
     ]
 
 

@@ -9,6 +9,12 @@ from nvblox_mindmap_amd import synthetic as S
 # MMF_FMA_CONTRACTION=1: every mapper of the process (nvblox_torch/mapper_params.py) and every oracle built here carry the spec
 # switch fma_contraction (mmf_params / orc_params) -- the parity, fuzz and soak suites then check the contracted arithmetic
 FMA = os.environ.get("MMF_FMA_CONTRACTION", "0") == "1"
+# MMF_SPEC_FLIPS=name[,name...]: the same for the spec switches block_index_by_division / view_truncation_band_marking /
+# bilinear_four_weight_sum (mapper_params.SPEC_FLIP_DEFAULTS): every mapper of the process and every oracle built here carry them
+SPEC_FLIPS = tuple(x.strip() for x in os.environ.get("MMF_SPEC_FLIPS", "").split(",") if x.strip())
+# frames of such mappers take the un-merged / stand-alone launches and are not pipelined: tests that assert the default ROUTE skip
+NOT_DEFAULT_ROUTE = FMA or bool(SPEC_FLIPS)
+ROUTE_SKIP_REASON = "asserts a route (merged launch / deferred rows) that mappers under MMF_FMA_CONTRACTION / MMF_SPEC_FLIPS do not take"
 
 REF_PARAMS = dict(  # what get_nvblox_mapper sets for DRILL_IN_BOX (nvblox_mapping_helpers.py:40-70)
     voxel_size=0.01,
@@ -20,6 +26,7 @@ REF_PARAMS = dict(  # what get_nvblox_mapper sets for DRILL_IN_BOX (nvblox_mappi
     tsdf_decay_factor=0.98,
     appearance_measurement_weight=1.0,
     **({"fma_contraction": 1} if FMA else {}),
+    **{name: 1 for name in SPEC_FLIPS},
 )
 
 
@@ -63,6 +70,9 @@ def make_mapper(channels, **over):
         "raycast_walk_from_camera": (vc, "raycast_walk_from_camera", bool),
         "appearance_blend_division": (pi, "projective_appearance_integrator_blend_division", bool),
         "fma_contraction": (pi, "projective_integrator_fma_contraction", bool),
+        "bilinear_four_weight_sum": (pi, "projective_integrator_bilinear_four_weight_sum", bool),
+        "block_index_by_division": (vc, "block_index_by_division", bool),
+        "view_truncation_band_marking": (vc, "view_truncation_band_marking", bool),
         "mesh_min_weight": (me, "mesh_integrator_min_weight", float),
         "num_preallocated_blocks": (pool, "num_preallocated_blocks", int),
     }

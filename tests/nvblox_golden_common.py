@@ -133,12 +133,15 @@ def oracle_backend(**overrides):
 
 
 def replay_like(gold, backend, device):
-    """Re-run exactly what the golden file's meta describes on `backend`."""
+    """Re-run exactly what the golden file's meta describes on `backend` (same block / channel / vertex sampling)."""
     kit = load_kit()
     meta = json.loads(str(gold["meta"]))
+    # vertex_stride 1 = the file holds every vertex: ours then too (a flipped item changes the vertex count, and two strided samples
+    # of different lists are different vertices -- their distance would measure the sampling, not the flip)
+    every_vertex = int(meta.get("vertex_stride", 0)) == 1
     return kit.replay(backend, meta["config"], meta["hole_mode"], meta["frames"], meta["decay"], meta["masks"],
                       n_block_samples=len(gold["tsdf_sample_idx"]) or 6, n_channel_samples=len(meta["feature_channel_sample"]),
-                      device=device, frame_indices=meta["frame_indices"])
+                      device=device, frame_indices=meta["frame_indices"], **({"n_vertex_samples": 1 << 40} if every_vertex else {}))
 
 
 # ---- comparison ----------------------------------------------------------------------------------------------------------

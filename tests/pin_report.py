@@ -25,12 +25,27 @@ COLUMNS = ["tsdf_blocks_missing", "tsdf_blocks_extra", "feature_blocks_missing",
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("golden")
+    ap.add_argument("golden", nargs="?", help="a file dumped by tools/dump_nvblox_golden.py (omit with --self)")
     ap.add_argument("--backend", choices=["oracle", "mmf"], default="oracle")
+    ap.add_argument("--self", dest="self_dump", action="store_true",
+                    help="SENSITIVITY table: no upstream dump -- the stream is dumped from this repository's own integrator AS SPECIFIED "
+                         "(the --backend), then replayed once per flipped item: how far each recollection risk moves the outputs, and "
+                         "whether the north star / the reference's own e2e tolerances (mindmap/tests/utils/comparisons.py:95-109) would "
+                         "still hold if upstream had the other variant")
+    ap.add_argument("--config", default="bl")
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--hole-mode", default="patches")
     args = ap.parse_args(argv)
-    gold = np.load(args.golden, allow_pickle=False)
-    meta = json.loads(str(gold["meta"]))
     make, device = (NG.oracle_backend, "cpu") if args.backend == "oracle" else (NG.mmf_backend, "cuda")
+    if args.self_dump:
+        kit = NG.load_kit()
+        # every vertex (stride 1) and 24 sampled blocks per layer: the reference's tolerances are statements about all vertices
+        gold = kit.replay(make(), args.config, args.hole_mode, args.frames, True, True, device=device, n_block_samples=24,
+                          n_vertex_samples=1 << 40)
+        args.golden = f"(self-dump of the {args.backend} as specified)"
+    else:
+        gold = np.load(args.golden, allow_pickle=False)
+    meta = json.loads(str(gold["meta"]))
     rows = [("as specified", {})]
     by_hand = []
     for it in meta["spec_items"]:

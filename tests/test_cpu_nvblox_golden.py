@@ -62,7 +62,7 @@ def test_kit_round_trip_on_the_cpu_oracle(tmp_path):
 
 
 def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
-    """tests/pin_report.py on a file dumped from the oracle itself: "as specified" reproduces it, at least seventeen spec items are
+    """tests/pin_report.py on a file dumped from the oracle itself: "as specified" reproduces it, at least twenty spec items are
     parameters (flipped with zero code edits), and the flips are not no-ops -- all but a few change the replay."""
     import pin_report
 
@@ -72,9 +72,10 @@ def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
     np.savez_compressed(path, **out)
     meta = json.loads(str(np.load(path, allow_pickle=False)["meta"]))
     items = [it for it in meta["spec_items"] if it.get("param") is not None]
-    assert len(items) >= 17, [it["item"] for it in items]
+    assert len(items) >= 20, [it["item"] for it in items]
     assert {"weighting_mode", "raycast_to_truncation", "decay_appearance_layers", "raycast_walk_from_camera",
-            "appearance_blend_division", "fma_contraction"} <= {it["param"] for it in items}
+            "appearance_blend_division", "fma_contraction", "block_index_by_division", "view_truncation_band_marking",
+            "bilinear_four_weight_sum"} <= {it["param"] for it in items}
     wm = next(it for it in items if it["param"] == "weighting_mode")
     assert sorted(wm["flips"] + [wm["ours"]]) == [0, 1, 2, 3, 4, 5], "upstream's six weighting functions"
     results = pin_report.main([str(path)])
@@ -100,6 +101,14 @@ def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
     assert fma["tsdf_blocks_missing"] == fma["tsdf_blocks_extra"] == fma["feature_blocks_missing"] == fma["feature_blocks_extra"] == 0, fma
     assert 0.0 < fma["tsdf_max_abs_distance_diff"] <= 1e-5 and 0.0 < fma["feature_max_abs_diff"] <= 2e-3, fma
     assert NG.passes_reference_tolerances(fma), fma
+    # round 6: three more recollection risks are flips -- the four-tap bilinear sum moves values at the last bits (same blocks), the
+    # second marking pass only ever ADDS blocks, the division rule keeps this stream's maps (its differences live on block faces)
+    w4, band, bdiv = by_name["bilinear_four_weight_sum=1"], by_name["view_truncation_band_marking=1"], by_name["block_index_by_division=1"]
+    assert w4["tsdf_blocks_missing"] == w4["tsdf_blocks_extra"] == 0 and 0.0 < w4["tsdf_max_abs_distance_diff"] <= 1e-5, w4
+    assert NG.passes_reference_tolerances(w4), w4
+    assert band["tsdf_blocks_missing"] == 0 and band["tsdf_blocks_extra"] > 0 and band["tsdf_max_abs_distance_diff"] == 0.0, band
+    assert NG.passes_reference_tolerances(band), band
+    assert bdiv["tsdf_blocks_missing"] == bdiv["tsdf_blocks_extra"] == 0, bdiv
 
 
 @pytest.mark.parametrize("path", NG.golden_files() or [None])

@@ -7,6 +7,7 @@ import os
 import pytest
 import torch
 
+import fusion_common
 from fusion_common import make_mapper, make_oracle, small_cfg
 from nvblox_mindmap_amd import _lib
 from nvblox_mindmap_amd import synthetic as S
@@ -15,8 +16,7 @@ from test_gpu_frame_batch import frame_args, same_maps, single
 from test_gpu_fusion_parity import compare_features, compare_tsdf
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1",
-                                 reason="asserts the deferred-row schedule, which mappers with fma_contraction do not take")]
+              pytest.mark.skipif(fusion_common.NOT_DEFAULT_ROUTE, reason=fusion_common.ROUTE_SKIP_REASON)]
 
 
 def pending(m, mapper_id=0):

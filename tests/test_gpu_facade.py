@@ -6,6 +6,7 @@ import os
 import pytest
 import torch
 
+import fusion_common
 from fusion_common import make_oracle
 from nvblox_mindmap_amd import synthetic as S
 
@@ -221,7 +222,7 @@ def test_facade_hands_the_backbone_output_to_the_native_call(include_dynamic, mo
         assert all(torch.equal(x, y) for x, y in zip(ca, cb))
 
 
-@pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1", reason="asserts a route (merged launch / deferred rows) that mappers with fma_contraction do not take")
+@pytest.mark.skipif(fusion_common.NOT_DEFAULT_ROUTE, reason=fusion_common.ROUTE_SKIP_REASON)
 @pytest.mark.parametrize("include_dynamic", [False, True])
 def test_facade_frame_pipelining_changes_nothing_but_the_schedule(include_dynamic):
     """``set_frame_pipelining``: the facade's default path (backbone output handed to the native call) with consecutive frames
@@ -397,7 +398,7 @@ def test_default_facade_pipelines_the_closed_loop_and_equals_the_oracle():
             ex.next = torch.from_numpy(feat).cuda()
             facade.decay()
             facade.update_reconstruction_from_sample(sample, "pov")
-            if not fusion_common.FMA:  # (mappers under the FMA switch complete every frame inside the call)
+            if not fusion_common.NOT_DEFAULT_ROUTE:  # (mappers under a spec switch complete every frame inside the call)
                 assert lib.mmf_deferred_feature_rows_pending(h, 0) == 1
             rgb_u8 = (sample["rgbs"][0, 0].permute(1, 2, 0) * 255).to(torch.uint8).cpu().numpy()
             Th = IMG.pose_to_homo(sample["camera_poses"][0, 0].cpu().numpy())[0]

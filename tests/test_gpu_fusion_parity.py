@@ -12,6 +12,7 @@ import torch
 
 from nvblox_mindmap_amd import synthetic as S
 
+import fusion_common
 from fusion_common import REF_PARAMS, frame_masks, make_mapper, make_oracle, small_cfg, sort_rows
 
 pytestmark = pytest.mark.gpu
@@ -545,6 +546,82 @@ def test_switchable_spec_arrangements_match_the_oracle(oracle_mod, flip):
         assert np.array_equal(ref.block_indices(0), orc.block_indices(0)) and np.array_equal(ref.all_tsdf().view(np.uint32), orc.all_tsdf().view(np.uint32))
 
 
+ROUND6_FLIPS = ["block_index_by_division", "view_truncation_band_marking", "bilinear_four_weight_sum"]
+
+
+@pytest.mark.parametrize("route", ["bounded", "hash"])
+@pytest.mark.parametrize("flips", [(f,) for f in ROUND6_FLIPS] + [tuple(ROUND6_FLIPS), ("bilinear_four_weight_sum", "fma_contraction"),
+                                   tuple(ROUND6_FLIPS) + ("fma_contraction", "appearance_blend_division")])
+def test_round6_spec_switches_match_the_oracle(oracle_mod, flips, route):
+    """Three more recollection risks made switchable in both implementations (oracle/mmf_oracle.c orc_params):
+    the block of a point by division, the second marking pass of the view calculator, bilinear samples as four weighted taps.  With
+    any of them set -- alone, together, with the FMA and the blend-division switches on top -- HIP (stand-alone launches) and oracle
+    agree bit for bit: block sets in allocation order, TSDF, colours, feature halves; through the fused entry point and, for a
+    stream of stand-alone calls, in a bounded workspace and on the hash path."""
+    cfg = small_cfg(4)
+    over = {f: True for f in flips}
+    if route == "hash":
+        over.update(workspace_bounds_type=0, max_integration_distance_m=2.5)
+    gpu, orc = make_mapper(16, **over), make_oracle(oracle_mod, 16, **over)
+    _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 6, 40, 46, 90], 16)
+    orc2, gpu2 = run_both(oracle_mod, cfg, 16, [3, 9, 50], **over)
+    compare_tsdf(orc2, gpu2)
+    compare_features(orc2, gpu2)
+    # mesh + vertex features (voxel look-ups under block_index_by_division)
+    gpu.update_feature_mesh(0)
+    mesh = gpu.get_feature_mesh(0)
+    ov, of = orc.feature_mesh()
+    assert np.array_equal(mesh.vertices().cpu().numpy(), ov) and np.array_equal(mesh.vertex_features().cpu().numpy().view(np.uint16), of.view(np.uint16))
+
+
+def test_round6_flips_are_not_no_ops(oracle_mod):
+    """Each flip changes what it says it changes (and only that) on the oracle: the band marking adds blocks to the view, the four-tap
+    sum moves values by rounding, the division keeps this stream's block sets (its differences live on block faces: the constructed
+    case below)."""
+    cfg = small_cfg(4)
+    frames = [0, 6, 40, 46, 90]
+
+    def run(**over):
+        orc = make_oracle(oracle_mod, 16, **over)
+        for i in frames:
+            f = S.frame(cfg, i, 16)
+            orc.decay()
+            orc.add_depth_frame(f["depth"], f["T_W_C"], f["K"], None)
+            orc.add_feature_frame(f["features"], f["T_W_C"], f["K"], None)
+        return orc
+
+    base = run()
+    band = run(view_truncation_band_marking=1)
+    b0, b1 = {tuple(r) for r in base.block_indices(0).tolist()}, {tuple(r) for r in band.block_indices(0).tolist()}
+    assert b0 < b1  # a strict superset
+    w4 = run(bilinear_four_weight_sum=1)
+    assert np.array_equal(w4.block_indices(0), base.block_indices(0))
+    d = np.abs(w4.all_tsdf() - base.all_tsdf())
+    assert 0.0 < float(d.max()) < 1e-5
+    # division: a workspace bound whose reciprocal product lands on the other side of a block face.  floor(x * (1 / bs)) and
+    # floor(x / bs) differ for SOME float32 x next to a multiple of bs = 0.08f: search one, then the two rules give other block sets.
+    bs, inv = np.float32(0.08), np.float32(1.0) / np.float32(0.08)
+    ks = np.arange(1, 4000, dtype=np.float32)
+    for eps in (0, 1, -1):
+        x = np.nextafter(ks * bs, np.float32(np.inf) if eps > 0 else np.float32(-np.inf)).astype(np.float32) if eps else (ks * bs).astype(np.float32)
+        diff = np.floor(x * inv) != np.floor(x / bs)
+        if diff.any():
+            break
+    assert diff.any(), "no float32 near a block face where the two rules differ (unexpected)"
+    xf = float(x[np.argmax(diff)])
+    lo = np.array([-0.37, -0.75, -0.13], dtype=np.float32)
+    hi = np.array([xf, 0.75, 0.65], dtype=np.float32)
+    a = make_oracle(oracle_mod, 16, ws_min=lo, ws_max=hi)
+    b = make_oracle(oracle_mod, 16, ws_min=lo, ws_max=hi, block_index_by_division=1)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 2], T[:3, 0], T[:3, 1] = [1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]
+    T[:3, 3] = [xf - 1.0, 0.005, 0.305]
+    depth = np.full((cfg.height, cfg.width), 1.0 + 0.01, dtype=np.float32)  # a wall just beyond the bound: rays end in its last blocks
+    for o in (a, b):
+        o.add_depth_frame(depth, T, cfg.intrinsics(), None)
+    assert a.block_indices(0).shape != b.block_indices(0).shape or not np.array_equal(a.block_indices(0), b.block_indices(0))
+
+
 def test_fused_call_on_images_too_narrow_for_the_bit_packed_masks(oracle_mod):
     """W < 16: the bit-packed mask job does not fit its scratch, the byte kernels run instead."""
     cfg = S.StreamConfig(width=12, height=40, fx=10.0, fy=10.0, cx=5.5, cy=19.5)
@@ -774,7 +851,7 @@ def test_merged_launch_with_churn_matches_oracle(oracle_mod):
     _fused_vs_oracle(oracle_mod, gpu, orc, cfg, [0, 90, 10, 200, 100, 20, 300, 110, 30], 8)
 
 
-@pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1", reason="asserts a route (merged launch / deferred rows) that mappers with fma_contraction do not take")
+@pytest.mark.skipif(fusion_common.NOT_DEFAULT_ROUTE, reason=fusion_common.ROUTE_SKIP_REASON)
 def test_hand_over_recovery_yields_the_oracle_map(oracle_mod, monkeypatch):
     """MMF_DEBUG_FORCE_ALLOC_TIMEOUT=1: every second waiter workgroup of k_alloc_tsdf "times out" at once and abandons its rounds;
     the workgroup that terminates last sweeps them.  Same churn sequence as above (hundreds of new blocks per frame): block
@@ -799,7 +876,7 @@ def test_hand_over_recovery_yields_the_oracle_map(oracle_mod, monkeypatch):
     assert normal.debug_alloc_recoveries(0) == 0  # ordinary operation never needs the sweeper
 
 
-@pytest.mark.skipif(os.environ.get("MMF_FMA_CONTRACTION", "0") == "1", reason="asserts a route (merged launch / deferred rows) that mappers with fma_contraction do not take")
+@pytest.mark.skipif(fusion_common.NOT_DEFAULT_ROUTE, reason=fusion_common.ROUTE_SKIP_REASON)
 def test_hand_over_failure_is_reported_once_and_cleared(monkeypatch):
     """MMF_DEBUG_FORCE_ALLOC_TIMEOUT=2: the sweeper gives up as well -> the map is incomplete.  The next call on the mapper
     fails with MMF_ERR_BAD_STATE (no integration on top of a broken map), the error is then cleared, clear() gives a usable

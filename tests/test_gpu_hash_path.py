@@ -153,7 +153,7 @@ def test_large_map_launch_arrangements_give_the_same_map(oracle_mod, monkeypatch
                               torch.from_numpy(f["K"]), 0.3, 17, 20, 5, 0)
         pend = _lib.lib().mmf_deferred_feature_rows_pending(piped._h, 0)
         # (without the merged launches -- or with fma_contraction -- a large map's frame is complete when the call returns)
-        assert pend == (1 if (merged and not fusion_common.FMA) else 0)
+        assert pend == (1 if (merged and not fusion_common.NOT_DEFAULT_ROUTE) else 0)
     for m in (gpu, piped):
         _, exact = compare_tsdf(orc, m)
         assert exact

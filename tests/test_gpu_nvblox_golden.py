@@ -25,6 +25,7 @@ def test_kit_runs_on_the_drop_in_and_matches_consumer_and_oracle(tmp_path):
     assert NG.passes_north_star(hip, tol=0.0), hip
     # (under MMF_FMA_CONTRACTION=1 the drop-in's mappers default to the spec switch: the checker is given the same)
     fma = {"fma_contraction": 1} if os.environ.get("MMF_FMA_CONTRACTION", "0") == "1" else {}
+    fma.update({name.strip(): 1 for name in os.environ.get("MMF_SPEC_FLIPS", "").split(",") if name.strip()})
     orc = NG.compare(gold, NG.replay_like(gold, NG.oracle_backend(**fma), "cpu"))
     assert NG.passes_north_star(orc), orc
     assert orc["tsdf_max_abs_distance_diff"] == 0.0 and orc["feature_max_abs_diff"] == 0.0, orc

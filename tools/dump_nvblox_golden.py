@@ -140,6 +140,13 @@ SPEC_ITEMS = [
     dict(item="multiply-adds contracted into FMAs (projection, bilinear samples, TSDF / appearance blend numerators)", param="fma_contraction",
          ours=0, flips=[1], note="a contraction-only difference shows up in (nearly) every voxel at the last bits: if flipping this one item "
                                  "removes it, upstream's build contracts where this restatement assumes it does"),
+    # three more recollection risks (round 6): each switchable in the oracle and in the HIP library alike
+    dict(item="block (and voxel) of a point by floor(p * (1 / size)) (1: floor(p / size))", param="block_index_by_division", ours=0, flips=[1],
+         note="differs exactly for points within an ulp of a block / voxel face: workspace bounds, ray end points, the tracer's and the mesh's voxel look-ups"),
+    dict(item="blocks in view: the traversed blocks of each pixel's ray (1: plus every block within the truncation distance of its surface point)",
+         param="view_truncation_band_marking", ours=0, flips=[1], note="SURVEY.md App. A.2's second marking kernel: adds blocks, never removes one"),
+    dict(item="bilinear samples as nested lerps (1: four weighted taps in upstream's order of terms)", param="bilinear_four_weight_sum", ours=0,
+         flips=[1], note="depth, synthetic depth, colour and feature taps; a rounding-level difference in (nearly) every observed voxel"),
     dict(item="feature storage rounding (RNE)", param=None, flips=None, note="code: __float2half_rn"),
     dict(item="feature-mesh vertex takes the feature of the voxel containing it", param=None, flips=None, note="code: k_mesh_emit"),
 ]
