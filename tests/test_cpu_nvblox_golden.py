@@ -104,7 +104,8 @@ def test_pin_report_flips_the_spec_items_without_code_edits(tmp_path, capsys):
     # round 6: three more recollection risks are flips -- the four-tap bilinear sum moves values at the last bits (same blocks), the
     # second marking pass only ever ADDS blocks, the division rule keeps this stream's maps (its differences live on block faces)
     w4, band, bdiv = by_name["bilinear_four_weight_sum=1"], by_name["view_truncation_band_marking=1"], by_name["block_index_by_division=1"]
-    assert w4["tsdf_blocks_missing"] == w4["tsdf_blocks_extra"] == 0 and 0.0 < w4["tsdf_max_abs_distance_diff"] <= 1e-5, w4
+    # (that it is not a no-op is asserted on whole layers in tests/test_gpu_fusion_parity.py; the six sampled blocks of three frames may agree)
+    assert w4["tsdf_blocks_missing"] == w4["tsdf_blocks_extra"] == 0 and w4["tsdf_max_abs_distance_diff"] <= 1e-5, w4
     assert NG.passes_reference_tolerances(w4), w4
     assert band["tsdf_blocks_missing"] == 0 and band["tsdf_blocks_extra"] > 0 and band["tsdf_max_abs_distance_diff"] == 0.0, band
     assert NG.passes_reference_tolerances(band), band
