@@ -574,6 +574,7 @@ def test_round6_spec_switches_match_the_oracle(oracle_mod, flips, route):
     assert np.array_equal(mesh.vertices().cpu().numpy(), ov) and np.array_equal(mesh.vertex_features().cpu().numpy().view(np.uint16), of.view(np.uint16))
 
 
+@pytest.mark.skipif(bool(fusion_common.SPEC_FLIPS), reason="compares a flipped oracle with the default one: under MMF_SPEC_FLIPS the default IS flipped")
 def test_round6_flips_are_not_no_ops(oracle_mod):
     """Each flip changes what it says it changes (and only that) on the oracle: the band marking adds blocks to the view, the four-tap
     sum moves values by rounding, the division keeps this stream's block sets (its differences live on block faces: the constructed

@@ -116,7 +116,8 @@ def test_lazy_decay_of_a_large_map_matches_the_eager_oracle(oracle_mod):
             ov, _ = orc.feature_mesh()
             assert np.array_equal(gpu.get_feature_mesh(0).vertices().cpu().numpy(), ov)
     st = gpu.hash_state(0)
-    assert st["lazy_decays"] >= 10 and st["live_blocks"] == orc.num_blocks(0), st
+    # (mappers under MMF_SPEC_FLIPS take the stand-alone launches: eager decay -- the map must still be the oracle's)
+    assert (st["lazy_decays"] >= 10 or bool(fusion_common.SPEC_FLIPS)) and st["live_blocks"] == orc.num_blocks(0), st
     assert gpu.stats(0)["tsdf_blocks_allocated"] > st["live_blocks"] + 500, "blocks must have died along the way"
     mx, exact = compare_tsdf(orc, gpu)
     assert exact
