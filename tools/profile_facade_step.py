@@ -55,7 +55,7 @@ def closed_loop(args):
     probe = torch.zeros(64, device=dev)
 
     def control_step(i, between="policy"):
-        with_policy = between in ("policy", "policy_poll", "policy_probe") or between.startswith("policy_spin")
+        with_policy = between in ("policy", "policy_poll", "policy_probe", "policy_nograph") or between.startswith("policy_spin")
         if between.startswith("policy_spin"):  # a busy host for N us after the inference, outside the fusion timers: is the cost transient?
             t_end = time.perf_counter() + float(between[len("policy_spin"):]) * 1e-6
             while time.perf_counter() < t_end:
@@ -103,7 +103,11 @@ def closed_loop(args):
             torch.cuda.synchronize(dev)
 
     lines = []
+    def graph_mode(on):
+        model.enable_graph_sampling(on)
+
     for label, with_policy in (("closed loop (policy inference between fusion steps; torch.cuda.synchronize)", "policy"),
+                               ("closed loop, the inference WITHOUT the captured HIP graph (same kernels launched one by one)", "policy_nograph"),
                                ("closed loop, the inference awaited by polling an event", "policy_poll"),
                                ("closed loop, one trivial launch + wait before each fusion step", "policy_probe"),
                                ("closed loop, 200 us of busy host between the inference and the fusion step", "policy_spin200"),
@@ -111,7 +115,9 @@ def closed_loop(args):
                                ("closed loop, 5 ms of busy host between the inference and the fusion step", "policy_spin5000"),
                                ("24 ms time.sleep between fusion steps (no GPU work)", "sleep"),
                                ("24 ms busy host loop between fusion steps (no GPU work)", "spin"),
-                               ("fusion steps back to back", "none")):
+                               ("fusion steps back to back", "none"),
+                               ("closed loop again (the first mode, after everything else has run: is the first figure a warm-up effect?)", "policy")):
+        graph_mode(with_policy != "policy_nograph")
         for i in range(3):
             control_step(i, with_policy)
         import gc
