@@ -90,6 +90,37 @@ from benchlib.fusion_legs import *  # noqa: E402,F401,F403
 from benchlib.policy_legs import *  # noqa: E402,F401,F403
 
 
+def _flush_c_stdio() -> None:
+    """Flush the C library's stdio buffers: native libraries of this process print through them -- RCCL its five-line version banner
+    at communicator creation -- and a pipe makes them fully buffered, i.e. written at process EXIT, behind everything Python printed."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def silence_stdout() -> None:
+    """File descriptor 1 of THIS process -> /dev/null, for good (Python's sys.stdout and every native library's printf alike)."""
+    sys.stdout.flush()
+    _flush_c_stdio()
+    fd = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(fd, 1)
+    os.close(fd)
+
+
+def print_last_line(text: str) -> None:
+    """The driver parses the LAST line of the job's stdout, which every rank shares.  Round 6 found RCCL's banner (buffered C stdio,
+    flushed at exit) landing BEHIND rank 0's record once `backend="nccl"` really ran -- on an 8-GPU launch eight times.  So: ranks > 0
+    never own stdout (`silence_stdout` at start-up), rank 0 flushes whatever native code has buffered, prints the record, and closes its
+    stdout behind it: nothing can follow the record."""
+    sys.stdout.flush()
+    _flush_c_stdio()
+    print(text, flush=True)
+    silence_stdout()
+
+
 def dist_timeout_s(dist):
     """The default process group's collective timeout in seconds (what a rank waiting in a barrier for rank 0's solo legs must stay under)."""
     try:
@@ -114,7 +145,7 @@ def emit(full: dict) -> None:
                 pass
     full["full_record"] = written
     print(text, file=sys.stderr, flush=True)
-    print(bench_record.compact_line(full), flush=True)
+    print_last_line(bench_record.compact_line(full))
 
 
 def dry_run(args, world: int, rank: int) -> None:
@@ -143,7 +174,7 @@ def dry_run(args, world: int, rank: int) -> None:
     elapsed = statistics.median(regions)
     if rank == 0:
         # the same shape as a real run's last line (bench_record.compact_line), from a record with the legs absent
-        print(bench_record.compact_line({
+        print_last_line(bench_record.compact_line({
             "metric": "RGB-D+feature frames/s fused @1 cm voxels", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
@@ -151,7 +182,7 @@ def dry_run(args, world: int, rank: int) -> None:
             "roofline": {"bound": "hbm", "kernel": "none (dry run)", "achieved": None, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                          "frac": None, "traffic": None},
             "cpu_baseline": {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "none (dry run)"},
-            "train": {"parallelism": f"dp{world}" if world > 1 else "single"}}), flush=True)
+            "train": {"parallelism": f"dp{world}" if world > 1 else "single"}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -192,6 +223,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and "WORLD_SIZE" in os.environ:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if rank != 0:
+        silence_stdout()  # the job's stdout carries ONE record, rank 0's, as its last line (print_last_line)
     if args.dry_run:
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
@@ -220,7 +253,7 @@ def main():
     if args.file_fed_only:
         out = run_training_file_fed(device, compute_bound_step_per_s=None)
         if rank == 0:
-            print(json.dumps({"file_fed": out}), flush=True)
+            print_last_line(json.dumps({"file_fed": out}))
         return
     if args.train_only:
         out = run_training_graphed(device, world, steps=args.train_steps,
@@ -234,7 +267,7 @@ def main():
             if rank == 0:
                 out["file_fed"] = run_training_file_fed(device, compute_bound_step_per_s=out["step_per_s"], steps=max(args.train_steps // 2, 2), reference_loader=False)
         if rank == 0:
-            print(json.dumps({"train": out, "n_gpus": world}), flush=True)
+            print_last_line(json.dumps({"train": out, "n_gpus": world}))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -242,7 +275,7 @@ def main():
     if args.ref_shape_only:
         out = run_reference_shape(device)
         if rank == 0:
-            print(json.dumps({"reference_shape": out}), flush=True)
+            print_last_line(json.dumps({"reference_shape": out}))
         return
 
     cfg = S.StreamConfig(hole_mode="patches")
@@ -252,12 +285,12 @@ def main():
     if args.in_flight_only:
         out = run_frames_in_flight(device, frames, args.channels)
         if rank == 0:
-            print(json.dumps({"frames_in_flight": out}), flush=True)
+            print_last_line(json.dumps({"frames_in_flight": out}))
         return
     if args.unbounded_only:
         out = run_unbounded(device, frames, args.channels, steps=args.steps, warmup=args.warmup)
         if rank == 0:
-            print(json.dumps({"unbounded_workspace": out}), flush=True)
+            print_last_line(json.dumps({"unbounded_workspace": out}))
         return
     mapper = get_nvblox_mapper(mcfg, feature_channels=args.channels)
     # consecutive frames software-pipelined (mmf_set_deferred_feature_rows): a frame's last launch rides in the next frame's

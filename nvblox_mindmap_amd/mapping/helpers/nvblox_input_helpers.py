@@ -8,7 +8,6 @@ Same function names, argument meaning, returned tuple and assertions as the refe
     HOST: every consumer of it takes it there (``integrate_frame`` calls ``camera_pose.cpu()``, nvblox_mapping_helpers.py:208),
     so the reference's device round trip (host -> device -> ``.cpu()``) and its synchronisation are saved.
 """
-import ctypes as C
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -61,7 +60,7 @@ def get_nvblox_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index:
 
 
 class _SampleScratch:
-    """Per-device buffers of ``frame_inputs_from_sample``: kernel scratch on the device, the 20-float record on the host."""
+    """Per-device kernel scratch of ``frame_inputs_from_sample`` (calls are serialised inside the library)."""
 
     _by_device = {}
 
@@ -69,8 +68,6 @@ class _SampleScratch:
         n = _lib.lib().mmf_sample_inputs_scratch_floats()
         self.scratch = torch.empty(n, dtype=torch.float32, device=device)
         self.scratch_ptr = _lib.dptr(self.scratch)
-        self.rec = np.zeros(20, dtype=np.float32)
-        self.rec_ptr = self.rec.ctypes.data_as(C.c_void_p)
         self.call = _lib.lib().mmf_sample_frame_inputs_host
 
     @classmethod
@@ -115,9 +112,11 @@ def frame_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index: int)
     rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     # the record arrives on the host with the call: the kernel stores it into coherent pinned memory the library polls -- no copy
     # engine, no stream synchronisation (the step's host path: DESIGN.md section 4.12)
-    _lib.check(sc.call(rgb_chw.data_ptr(), H, W, pose7.data_ptr(), k_dev.data_ptr(), rgb.data_ptr(), sc.scratch_ptr, sc.rec_ptr,
+    # (the record is this call's own array: the native call serialises concurrent callers -- and with them the shared device scratch --
+    # but hands each its result in the buffer it passed)
+    rec = np.empty(20, dtype=np.float32)
+    _lib.check(sc.call(rgb_chw.data_ptr(), H, W, pose7.data_ptr(), k_dev.data_ptr(), rgb.data_ptr(), sc.scratch_ptr, rec.ctypes.data,
                        _lib.stream_ptr(dev)), "mmf_sample_frame_inputs_host")
-    rec = sc.rec.copy()
     # the reference's two range assertions (:68); a NaN fails them like it fails `min() >= 0`
     assert rec[2] == 0.0 and rec[0] >= 0 and rec[1] <= 1
     if num_cams > 1:  # the reference checks the range over every camera of the sample

@@ -112,3 +112,20 @@ def test_dry_run_prints_the_compact_shape():
     for k in bench_record.CONTRACT_KEYS:
         assert k in out, k
     assert set(out["roofline"]) >= set(bench_record.ROOFLINE_KEYS) and set(out["cpu_baseline"]) >= set(bench_record.CPU_BASELINE_KEYS)
+
+
+def test_the_record_is_the_last_stdout_line_whatever_native_code_prints():
+    """Round 6, found by running RCCL for the first time: its version banner goes through C stdio, which a pipe makes fully buffered --
+    it was written at process exit, BEHIND rank 0's record (and the driver parses the last stdout line).  `bench.print_last_line`
+    flushes what native code has buffered, prints the record and closes the process's stdout behind it."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; sys.argv = ['bench.py']; import bench; libc = ctypes.CDLL(None); "
+            "libc.printf(b'native banner (buffered)\\n'); bench.print_last_line('{\"record\": 1}'); "
+            "libc.printf(b'late native line\\n'); print('late python line')")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert lines[-1] == '{"record": 1}' and "native banner (buffered)" in lines[:-1], lines
+    assert not any("late" in ln for ln in lines)

@@ -436,3 +436,37 @@ def test_default_facade_pipelines_the_closed_loop_and_equals_the_oracle():
     ex.next = torch.from_numpy(S.render_features(cfg, 0, C)).cuda()
     plain.update_reconstruction_from_sample(sample, "pov")
     assert lib.mmf_deferred_feature_rows_pending(plain.mapper._h, 0) == 0
+
+
+def test_frame_inputs_from_sample_from_two_threads():
+    """``mmf_sample_frame_inputs_host`` keeps ONE host-visible record per device and serialises its callers: two threads converting
+    different samples at once each get their own pose / intrinsics / image back (the record a call returns is the buffer it passed)."""
+    import threading
+
+    from nvblox_mindmap_amd.mapping.helpers.nvblox_input_helpers import frame_inputs_from_sample, get_nvblox_inputs_from_sample
+
+    cfg = S.StreamConfig(width=160, height=120, fx=131.25, fy=131.25, cx=79.5, cy=59.5)
+    samples = [make_sample(cfg, idx, "cuda")[0] for idx in (0, 50, 100, 150)]
+    want = [get_nvblox_inputs_from_sample(s, 0) for s in samples]
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for rep in range(200):
+                    i = (k + 2 * rep) % 4 if k < 2 else (k + rep) % 4
+                    d, K, T, rgb, dyn, _ = frame_inputs_from_sample(samples[i], 0)
+                    assert torch.equal(T, want[i][2]) and torch.equal(K, want[i][1].cpu()), (k, rep, i)
+                    if rep % 50 == 0:
+                        stream.synchronize()
+                        assert torch.equal(rgb, want[i][3])
+        except BaseException as e:  # noqa: BLE001 -- surfaced by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]

@@ -49,6 +49,8 @@ def test_bench_train_leg_under_forced_rccl():
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    # the record is the LAST stdout line: RCCL's version banner (buffered C stdio, flushed at exit) used to land behind it
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()][-1] == lines[0], p.stdout[-1500:]
     t = json.loads(lines[0])["train"]
     assert t["collective_backend"] == "nccl" and t["collectives_forced_on_one_rank"] is True and t["rccl_world_observed"] == 1
     assert t["allreduce"]["payload_MB"] > 1.0 and t["allreduce"]["mean_ms"] > 0.0 and t["parallelism"] == "single"
