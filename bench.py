@@ -411,7 +411,9 @@ def main():
     in_flight = run_frames_in_flight(device, leg_frames, args.channels) if (rank == 0 and not args.no_ref_shape) else None
     del leg_frames
     pixel_holes = run_pixel_holes(device, args.channels) if (rank == 0 and not args.no_ref_shape) else None
-    backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj) else None  # has CPU legs: after every GPU measurement
+    # (has CPU legs -- the reference's torch-CPU back-projection on every host thread: after every GPU measurement, and like the CPU
+    # baseline a figure of the N = 1 run)
+    backproj = run_backprojection(device) if (rank == 0 and not args.no_backproj and world == 1) else None
 
     if rank == 0:
         C = args.channels
@@ -523,8 +525,12 @@ def main():
             legs["closed_loop_ms"] = closed_loop.get("ms_per_control_step") if isinstance(closed_loop, dict) else None
         roofline["legs"] = legs
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:
             cpu = cpu_baseline(cfg, mcfg, frames, C, min(args.cpu_sample, n_frames))
+        elif world > 1:
+            # the CPU baseline is a figure of the N = 1 run (rank 0, one GPU, the host to itself): with N ranks alive the other ranks'
+            # host threads sit in a barrier on the same cores
+            cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "not measured at n_gpus > 1: the CPU baseline is taken by the N = 1 run"}
         if cpu is not None and backproj:
             cpu["backprojection"] = backproj  # the reference's CPU back-projection path beside the HIP kernel
         out = {
