@@ -111,7 +111,7 @@ def frame_inputs_from_sample(sample: Dict[str, torch.Tensor], camera_index: int)
     sc = _SampleScratch.of(dev)
     rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     # the record arrives on the host with the call: the kernel stores it into coherent pinned memory the library polls -- no copy
-    # engine, no stream synchronisation (the step's host path: DESIGN.md section 4.12)
+    # engine, no stream synchronisation (the step's host path: DESIGN.md sections 4.5 and 8)
     # (the record is this call's own array: the native call serialises concurrent callers -- and with them the shared device scratch --
     # but hands each its result in the buffer it passed)
     rec = np.empty(20, dtype=np.float32)

@@ -176,7 +176,7 @@ class IsaacLabNvbloxMapper:
 
     def set_frame_pipelining(self, on: bool = True) -> None:
         """Extension, ON by default (see the constructor): consecutive updates are software-pipelined in the native library
-        (``Mapper.set_deferred_feature_rows``, DESIGN.md 4.11) -- the appearance half of a frame runs beside the geometry half of the
+        (``Mapper.set_deferred_feature_rows``, DESIGN.md 4.5) -- the appearance half of a frame runs beside the geometry half of the
         next one.  It pays wherever the map is not read after every frame (several cameras or frames per control step, dataset
         generation over a recorded demo, replay).  Results are bit-identical; whatever reads the map (``get_nvblox_model_inputs``,
         ``save_nvblox_map_to_disk``, layer views) completes the last frame first.  Every update makes its own image tensors, which is
