@@ -77,6 +77,9 @@ def compact_record(full: dict) -> dict:
         "undeferred_fps": und.get("frames_per_s"), "undeferred_frac": und.get("frac"), "undeferred_launches": und.get("launches_per_frame"),
         "pixel_holes_fps": holes.get("frames_per_s"), "pixel_holes_frac": holes.get("frac_of_hbm_peak"),
         "closed_loop_ms": legs_in.get("closed_loop_ms"),
+        # the fusion phase of a control step through the facade: inside the loop (behind the 23 ms inference) and steps back to back
+        "closed_loop_fusion_ms": _get(full, "closed_loop", "breakdown_ms", "fusion"),
+        "closed_loop_fusion_back_to_back_ms": _get(full, "closed_loop", "fusion_back_to_back_ms"),
         "in_flight_1_fps": _get(full, "frames_in_flight", "1", "aggregate_frames_per_s"),
         "in_flight_4_fps": _get(full, "frames_in_flight", "4", "aggregate_frames_per_s"),
     }
