@@ -100,8 +100,9 @@ typedef struct {
    * oracle (fmaf).  Frames then take the un-merged launches (allocation | TSDF pass | sphere trace | gating | rows), not pipelined. */
   int32_t fma_contraction;
   /* Three more switchable recollection risks (oracle/mmf_oracle.c orc_params documents the exact arithmetic; defaults 0).  Frames
-   * of a mapper with any of them set take the stand-alone launches (raycast | allocation | TSDF | sphere trace | colour | gating | rows),
-   * not merged, not pipelined: the fused kernels implement the default forms only. */
+   * of a mapper with one of the first two set take the stand-alone launches (raycast | allocation | TSDF | sphere trace | colour | gating |
+   * rows), not merged, not pipelined: the fused kernels implement the default forms only.  bilinear_four_weight_sum is an ARITHMETIC mode
+   * like fma_contraction: its frames take the un-merged fused launches (allocation | TSDF pass | sphere trace | gating | rows), not pipelined. */
   int32_t block_index_by_division;      /* 1: block / voxel of a point by floor(p / size) instead of floor(p * (1 / size)) */
   int32_t view_truncation_band_marking; /* 1: a pixel additionally marks every block intersecting the cube of half-width `truncation`
                                            around its surface point (SURVEY.md App. A.2's second kernel) */

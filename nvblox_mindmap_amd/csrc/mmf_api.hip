@@ -1165,7 +1165,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   }
   const bool can_host = fusable && (!big || m->allow_big_merge);  // (large maps: the merged launches of round 5 host a pending tail too)
   if (!can_host) MMF_TRY(flush_rows(h, *m));  // no launch of this frame can host it
-  if (m->defer_rows && can_host && !(m->mc.spec_flags & kSpecFma)) MMF_TRY(ensure_flat_other(*m));
+  if (m->defer_rows && can_host && !(m->mc.spec_flags & kSpecArith)) MMF_TRY(ensure_flat_other(*m));
   if (!fusable) {
     // odd shapes / very large grids: the plain sequence of stand-alone launches
     flush_decay(h, *m, s);
@@ -1221,7 +1221,7 @@ static int integrate_frame_impl(mmf_handle h, int mapper_id, const float* depth,
   // k_front ends, so the TSDF pass of the existing blocks runs beside the allocation workgroup instead of after it.
   // (spec switch fma_contraction: built into the un-merged launches only -- allocation, then k_tsdf_pass; the gating launch and the
   // row update of this frame, not deferred)
-  const bool fma = (m->mc.spec_flags & kSpecFma) != 0;
+  const bool fma = (m->mc.spec_flags & kSpecArith) != 0;  // (fma_contraction and / or bilinear_four_weight_sum: a non-default arithmetic mode)
   const bool merged = !big && !fma && m->allow_merged && m->tsdf.d.dense != nullptr && (!do_decay || light_decay);
   // the light decay's deallocations for a large pool: the scalable compaction (decided from wmax, no voxel touched; k_front's single
   // decay workgroup would need dozens of serial passes over 10^5 list entries) -- as roles of this frame's FIRST launch, beside the
@@ -1485,7 +1485,7 @@ static bool pair_eligible(const Mapper& m, const FrameIn& in, MaskJob& M, ViewGr
   if (ncells <= 0 || !alloc_jobs_fusable(ncells, m.tsdf.d.cap) || ncells > m.sc_cap[0] || m.tsdf.d.cap > m.sc_cap[1] ||
       m.tsdf.d.cap > m.sc_cap[2])
     return false;
-  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & (kSpecStandalone | kSpecFma)) || m.lazy_lag) return false;
+  if (!m.allow_merged || !m.tsdf.d.dense || (m.mc.spec_flags & (kSpecStandalone | kSpecArith)) || m.lazy_lag) return false;
   if (m.pending_decay && !m.wmax_valid) return false;  // that decay needs its voxel pass: separate launches
   const int sf = m.mc.st_sf;
   if (in.W / sf <= 0 || in.H / sf <= 0 || (in.W / sf) * (in.H / sf) > m.synth_cap) return false;

@@ -59,7 +59,9 @@ constexpr int kSpecBlockDiv = 8;
 constexpr int kSpecBandMark = 16;
 constexpr int kSpecBilin4 = 32;
 // switches only the stand-alone launches implement: frames of a mapper with any of them set are not fused, merged or pipelined
-constexpr int kSpecStandalone = 2 | kSpecBlockDiv | kSpecBandMark | kSpecBilin4;
+// (bilinear_four_weight_sum is NOT among them: like fma_contraction it is an arithmetic mode the un-merged fused launches are built for)
+constexpr int kSpecStandalone = 2 | kSpecBlockDiv | kSpecBandMark;
+constexpr int kSpecArith = kSpecFma | kSpecBilin4;  // non-default arithmetic: un-merged launches, not pipelined
 // The arithmetic mode the per-voxel device functions are instantiated for (their template parameter `FMA`, an int):
 //   bit 0: fma_contraction, bit 1: bilinear_four_weight_sum.  The fused kernels instantiate 0 (and 1: the un-merged FMA launches).
 __host__ __device__ inline int arith_mode(int spec_flags) { return ((spec_flags & kSpecFma) ? 1 : 0) | ((spec_flags & kSpecBilin4) ? 2 : 0); }

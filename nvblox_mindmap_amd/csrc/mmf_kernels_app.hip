@@ -891,12 +891,14 @@ AppTail app_tail_of(const AppFrameArgs& F, int max_cand) {
 int app_tail_grid(const AppTail& T) { return grid8(hinted(T.Ac.sc.hint_cand, T.max_cand), 8192); }
 
 void launch_app_tail(const AppTail& T, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  if (T.mc.spec_flags & kSpecFma)
-    hipExtLaunchKernelGGL((k_app_frame<false, true, true>), dim3(app_tail_grid(T)), dim3(256), 0, s, ev_start, ev_stop, 0, T.Ac, T.Af, T.mc,
-                          T.synth, T.Ws, T.Hs);
-  else
-    hipExtLaunchKernelGGL((k_app_frame<false, true>), dim3(app_tail_grid(T)), dim3(256), 0, s, ev_start, ev_stop, 0, T.Ac, T.Af, T.mc, T.synth,
-                          T.Ws, T.Hs);
+#define MMF_AT(ARV) hipExtLaunchKernelGGL((k_app_frame<false, true, ARV>), dim3(app_tail_grid(T)), dim3(256), 0, s, ev_start, ev_stop, 0, T.Ac, T.Af, T.mc, T.synth, T.Ws, T.Hs)
+  switch (arith_mode(T.mc.spec_flags)) {  // bit 0 mmf_params.fma_contraction, bit 1 .bilinear_four_weight_sum
+    case 1: MMF_AT(1); break;
+    case 2: MMF_AT(2); break;
+    case 3: MMF_AT(3); break;
+    default: MMF_AT(0); break;
+  }
+#undef MMF_AT
 }
 
 // colour + feature update of one frame (gating launch, then the balanced feature pass when a survivor list is given)
@@ -910,30 +912,35 @@ void launch_app_integrate2(const LayerDev& Lc, const Cam& ccam, const uint8_t* r
   // same_candidates: both allocation jobs compacted the same flag array, so candidate i is the same block in both lists
   const bool same_cam = same_candidates && ccam.W == fcam.W && ccam.H == fcam.H && ccam.fx == fcam.fx && ccam.fy == fcam.fy &&
                         ccam.cx == fcam.cx && ccam.cy == fcam.cy;
-  const bool fma = (mc.spec_flags & kSpecFma) != 0;
+  const int ar = arith_mode(mc.spec_flags);  // bit 0 mmf_params.fma_contraction, bit 1 .bilinear_four_weight_sum
   if (same_cam) {  // one candidate list, one geometric gate per voxel
     const dim3 grid(grid8(hinted(csc.hint_cand, max_cand), 8192));
-#define MMF_AF(LOWV, PUBV, FMAV) hipExtLaunchKernelGGL((k_app_frame<LOWV, PUBV, FMAV>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs)
-    if (fma) {  // mmf_params.fma_contraction
-      if (flat && flat->rec) MMF_AF(false, true, true);
-      else if (low) MMF_AF(true, false, true);
-      else MMF_AF(false, false, true);
-    } else {
-      if (flat && flat->rec) MMF_AF(false, true, false);
-      else if (low) MMF_AF(true, false, false);
-      else MMF_AF(false, false, false);
-    }
+#define MMF_AF(LOWV, PUBV, ARV) hipExtLaunchKernelGGL((k_app_frame<LOWV, PUBV, ARV>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs)
+#define MMF_AF3(ARV)                                      \
+  do {                                                    \
+    if (flat && flat->rec) MMF_AF(false, true, ARV);      \
+    else if (low) MMF_AF(true, false, ARV);               \
+    else MMF_AF(false, false, ARV);                       \
+  } while (0)
+    if (ar == 3) MMF_AF3(3);
+    else if (ar == 2) MMF_AF3(2);
+    else if (ar == 1) MMF_AF3(1);
+    else MMF_AF3(0);
+#undef MMF_AF3
 #undef MMF_AF
   } else {
     const int gc = grid8(hinted(csc.hint_cand, max_cand), 4096), gf = grid8(hinted(fsc.hint_cand, max_cand), 4096);
-#define MMF_AI(LOWV, FMAV) hipExtLaunchKernelGGL((k_app_integrate2<LOWV, FMAV>), dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc)
-    if (fma) {
-      if (low) MMF_AI(true, true);
-      else MMF_AI(false, true);
-    } else {
-      if (low) MMF_AI(true, false);
-      else MMF_AI(false, false);
-    }
+#define MMF_AI(LOWV, ARV) hipExtLaunchKernelGGL((k_app_integrate2<LOWV, ARV>), dim3(gc + gf), dim3(256), 0, s, ev_start, ev_stop, 0, Ac, Af, mc, synth, Ws, Hs, gc)
+#define MMF_AI2(ARV)               \
+  do {                             \
+    if (low) MMF_AI(true, ARV);    \
+    else MMF_AI(false, ARV);       \
+  } while (0)
+    if (ar == 3) MMF_AI2(3);
+    else if (ar == 2) MMF_AI2(2);
+    else if (ar == 1) MMF_AI2(1);
+    else MMF_AI2(0);
+#undef MMF_AI2
 #undef MMF_AI
   }
 }

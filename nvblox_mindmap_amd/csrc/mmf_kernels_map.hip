@@ -1945,10 +1945,23 @@ static void launch_tsdf_pass_t(const LayerDev& L, const MapConsts& mc, const Cam
 }
 void launch_tsdf_pass(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth,
                       const uint8_t* mask, float min_d, int stamp, uint8_t* flags, u64* cell_key, float decay_f, hipStream_t s) {
-  if (mc.spec_flags & kSpecFma)
-    launch_tsdf_pass_t<true>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s);
+  switch (arith_mode(mc.spec_flags)) {  // bit 0 mmf_params.fma_contraction, bit 1 .bilinear_four_weight_sum
+    case 1: launch_tsdf_pass_t<1>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s); break;
+    case 2: launch_tsdf_pass_t<2>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s); break;
+    case 3: launch_tsdf_pass_t<3>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s); break;
+    default: launch_tsdf_pass_t<0>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s); break;
+  }
+}
+
+template <int AR>
+static void launch_tsdf_pass_lazy_t(const LayerDev& L, const MapConsts& mc, const Cam& cam, const Rigid& T_C_L, const float* depth, int stamp,
+                                    uint8_t* flags, u64* cell_key, const int* cnt, const int* list, int live, hipStream_t s) {
+  if (cam.W < 2 || cam.H < 2)  // (degenerate image: the branching form, see launch_tsdf_pass_t)
+    hipLaunchKernelGGL((k_tsdf_pass<4, true, true, AR>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
+                       0.0f, stamp, flags, cell_key, 0.0f, cnt, list);
   else
-    launch_tsdf_pass_t<false>(L, mc, cam, T_C_L, depth, mask, min_d, stamp, flags, cell_key, decay_f, s);
+    hipLaunchKernelGGL((k_tsdf_pass<4, false, true, AR>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
+                       0.0f, stamp, flags, cell_key, 0.0f, cnt, list);
 }
 
 // the lazy form (L.epoch / L.cur_epoch / L.lag_f set): classify the live list, then pass over the work list only
@@ -1959,19 +1972,12 @@ void launch_tsdf_pass_lazy(const LayerDev& L, const MapConsts& mc, const Cam& ca
   int* cnt = work + (parity & 1);
   int* nxt = work + ((parity & 1) ^ 1);
   hipLaunchKernelGGL(k_tsdf_classify, dim3((unsigned)((live + 1023) / 1024)), dim3(1024), 0, s, L, stamp, flags, cnt, nxt, work + 2);
-  if (cam.W < 2 || cam.H < 2) {  // (degenerate image: the branching form, see launch_tsdf_pass_t)
-    if (mc.spec_flags & kSpecFma)
-      hipLaunchKernelGGL((k_tsdf_pass<4, true, true, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
-                         0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
-    else
-      hipLaunchKernelGGL((k_tsdf_pass<4, true, true, false>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
-                         0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
-  } else if (mc.spec_flags & kSpecFma)
-    hipLaunchKernelGGL((k_tsdf_pass<4, false, true, true>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
-                       0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
-  else
-    hipLaunchKernelGGL((k_tsdf_pass<4, false, true, false>), dim3(grid_for(live, 8192)), dim3(128), 0, s, L, mc, cam, T_C_L, depth, (const uint8_t*)nullptr,
-                       0.0f, stamp, flags, cell_key, 0.0f, (const int*)cnt, (const int*)(work + 2));
+  switch (arith_mode(mc.spec_flags)) {
+    case 1: launch_tsdf_pass_lazy_t<1>(L, mc, cam, T_C_L, depth, stamp, flags, cell_key, cnt, work + 2, live, s); break;
+    case 2: launch_tsdf_pass_lazy_t<2>(L, mc, cam, T_C_L, depth, stamp, flags, cell_key, cnt, work + 2, live, s); break;
+    case 3: launch_tsdf_pass_lazy_t<3>(L, mc, cam, T_C_L, depth, stamp, flags, cell_key, cnt, work + 2, live, s); break;
+    default: launch_tsdf_pass_lazy_t<0>(L, mc, cam, T_C_L, depth, stamp, flags, cell_key, cnt, work + 2, live, s); break;
+  }
 }
 
 void launch_lazy_catchup(const LayerDev& L, hipStream_t s) {
